@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Extract the known-answer vectors of the reference's legacy I/O fixture.
+
+Source (read-only, reference-authored DATA, not code):
+  /root/reference/tests/test_resources/iotest_asciiLE.txt
+It is the only value-level DoubleCRT fixture in the HElib 2.2.0 tree
+(SURVEY.md section 0 fact 9): context m=12, p=7, five primes; a public
+encryption key (b, a) on primes 0-2 and the secret key on primes 0-4.
+
+Run once in the build container (the GPU box has no /root/reference):
+    python tests/golden/make_golden.py
+writes tests/golden/iotest_m12.json, which is committed.
+"""
+import json
+import os
+import re
+import sys
+
+SRC = "/root/reference/tests/test_resources/iotest_asciiLE.txt"
+DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "iotest_m12.json")
+
+
+def rows_after(lines, start):
+    """Parse '[[idx...]\n [row]\n [row] ... ]' starting at line `start` (0-based)."""
+    idx = [int(t) for t in re.findall(r"-?\d+", lines[start])]
+    rows = []
+    i = start + 1
+    while lines[i].strip().startswith("[") and not lines[i].strip().startswith("[["):
+        rows.append([int(t) for t in re.findall(r"\d+", lines[i])])
+        i += 1
+    return idx, rows
+
+
+def main():
+    if not os.path.exists(SRC):
+        sys.exit("reference fixture not present (expected in the build container only)")
+    lines = open(SRC).read().split("\n")
+    hdr = [int(t) for t in re.findall(r"\d+", lines[0])]
+    m, p, r = hdr[0], hdr[1], hdr[2]
+    primes = [int(t) for t in lines[4].split()]
+    # public encryption key: part b (handle one) at line 12, part a (handle s) at line 18
+    idx_b, rows_b = rows_after(lines, 11)
+    idx_a, rows_a = rows_after(lines, 17)
+    # secret key DoubleCRT at line 181 (1-based)
+    idx_s, rows_s = rows_after(lines, 180)
+    # four key-switching matrices (fromKey handle, two b columns each) -- kept for
+    # layout tests only: the matching a-columns come from NTL's PRG and are not
+    # reproducible without NTL.
+    ksw = []
+    for ln in (27, 43, 59, 75):
+        handle = [int(t) for t in re.findall(r"-?\d+", lines[ln - 1])]
+        i0, b0 = rows_after(lines, ln)
+        i1, b1 = rows_after(lines, ln + 7)
+        ksw.append({"header": handle, "b0_idx": i0, "b0": b0, "b1_idx": i1, "b1": b1})
+    out = {
+        "source": "HElib 2.2.0 tests/test_resources/iotest_asciiLE.txt",
+        "m": m, "p": p, "r": r, "primes": primes,
+        "pubkey_b": {"idx": idx_b, "rows": rows_b},
+        "pubkey_a": {"idx": idx_a, "rows": rows_a},
+        "seckey": {"idx": idx_s, "rows": rows_s},
+        "ksw": ksw,
+        # facts verified when the fixture was analysed:
+        "expect_s_coeffs": [1, -1, 1, 1],
+        "expect_e_coeffs": [-2, -4, 0, 1],
+    }
+    with open(DST, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", DST)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,185 @@
+"""Pin the CPU oracle against the only value-level vectors the reference ships
+(tests/test_resources/iotest_asciiLE.txt, extracted by tests/golden/make_golden.py)
+and against the mathematical definition of Cmodulus::FFT."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "iotest_m12.json")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(GOLD) as f:
+        return json.load(f)
+
+
+def centered(v, q):
+    return [int(x) - q if int(x) > q // 2 else int(x) for x in v]
+
+
+def test_fixture_secret_key_is_small_poly(gold):
+    # secret key rows inverse-transform to s = 1 - X + X^2 + X^3 under every prime
+    for q, row in zip(gold["primes"], gold["seckey"]["rows"]):
+        cm = O.Cmod(gold["m"], q)
+        s = cm.ifft(np.array(row, dtype=np.uint64))
+        assert centered(s, q) == gold["expect_s_coeffs"]
+        # and forward transform reproduces the fixture row bit-for-bit
+        assert cm.fft(s).tolist() == row
+
+
+def test_fixture_public_key_relation(gold):
+    # b + a*s = p*e with e = -2 - 4X + X^3 (Hadamard mul + add in the eval domain)
+    p = gold["p"]
+    for i in range(3):
+        q = gold["primes"][i]
+        cm = O.Cmod(gold["m"], q)
+        b = np.array(gold["pubkey_b"]["rows"][i], dtype=np.uint64)
+        a = np.array(gold["pubkey_a"]["rows"][i], dtype=np.uint64)
+        s = np.array(gold["seckey"]["rows"][i], dtype=np.uint64)
+        t = O.row_op("add", b, O.row_op("mul", a, s, q), q)
+        pe = centered(cm.ifft(t), q)
+        assert pe == [p * c for c in gold["expect_e_coeffs"]]
+
+
+def test_fixture_root_is_findprimroot(gold):
+    # root convention: e = 2m for even m (src/CModulus.cpp:148-164)
+    for q in gold["primes"]:
+        r = O.lib().ho_find_prim_root(q, 2 * gold["m"])
+        assert pow(r, 2 * gold["m"], q) == 1 and pow(r, gold["m"], q) != 1
+        assert O.Cmod(gold["m"], q).root == r
+
+
+def py_find_prim_root(q, e):
+    """independent python restatement of FindPrimRootT (src/NumbTh.cpp:436-493)"""
+    import sympy
+    root = 1
+    for p in sorted(sympy.factorint(e)):
+        pp = p ** sympy.factorint(e)[p]
+        s = 1
+        while True:
+            s = sympy.nextprime(s)
+            if pow(s, (q - 1) // p, q) != 1:
+                break
+        root = root * pow(s, (q - 1) // pp, q) % q
+    return root
+
+
+@pytest.mark.parametrize("m", [12, 15, 16, 21, 64, 105, 257])
+def test_find_prim_root_matches_python(m):
+    g = O.PrimeGen(40, m)
+    for _ in range(3):
+        q = g.next()
+        e = 2 * m if m % 2 == 0 else m
+        assert O.lib().ho_find_prim_root(q, e) == py_find_prim_root(q, e)
+
+
+@pytest.mark.parametrize("length,m", [(49, 16384), (60, 32768), (60, 21845), (56, 32768), (30, 12)])
+def test_prime_generator_contract(length, m):
+    import sympy
+    g = O.PrimeGen(length, m)
+    seen = set()
+    for _ in range(6):
+        q = g.next()
+        assert sympy.isprime(q)
+        assert (1 << length) - (1 << (length - 3)) <= q < (1 << length)
+        assert q % m == 1
+        assert q not in seen
+        seen.add(q)
+
+
+def test_prime_generator_first_values_m32768():
+    # deterministic sequence (frozen so every other test is reproducible)
+    g = O.PrimeGen(60, 32768)
+    qs = [g.next() for _ in range(3)]
+    for q in qs:
+        # q = 2^k t m + 1 with 2^k m > 2^57 => 2^58 | q-1 or close: at least 2m | q-1
+        assert (q - 1) % (2 * 32768) == 0
+    assert qs == sorted(set(qs), key=qs.index)
+
+
+@pytest.mark.parametrize("m", [8, 16, 32, 12, 20, 18, 15, 21, 35, 45])
+def test_fft_equals_definition(m):
+    g = O.PrimeGen(50, m)
+    q = g.next()
+    cm = O.Cmod(m, q)
+    x = O.fill_uniform(cm.phim, q, seed=m)
+    y = cm.fft(x)
+    assert y.tolist() == cm.eval_naive(x).tolist()
+    assert cm.ifft(y).tolist() == x.tolist()
+
+
+@pytest.mark.parametrize("phim_m", [(8, 16), (64, 128), (256, 512)])
+def test_roundtrip_like_TestHEXL_CModulusFFT(phim_m):
+    # tests/TestHEXL.cpp:189-218 : FFT then iFFT of 5X round-trips
+    phim, m = phim_m
+    q = O.PrimeGen(60, m).next()
+    cm = O.Cmod(m, q)
+    assert cm.phim == phim
+    x = np.zeros(phim, dtype=np.uint64)
+    x[1] = 5
+    assert cm.ifft(cm.fft(x)).tolist() == x.tolist()
+
+
+def polymul_mod_phi(a, b, m, q):
+    phi = [int(c) for c in O.phimx(m)]
+    n = len(phi) - 1
+    prod = [0] * (2 * n - 1)
+    for i, ai in enumerate(a):
+        for j, bj in enumerate(b):
+            prod[i + j] = (prod[i + j] + int(ai) * int(bj)) % q
+    for i in range(len(prod) - 1, n - 1, -1):
+        c = prod[i]
+        if c:
+            for j in range(n + 1):
+                prod[i - n + j] = (prod[i - n + j] - c * phi[j]) % q
+    return prod[:n]
+
+
+@pytest.mark.parametrize("m", [16, 12, 15, 21])
+def test_convolution_property(m):
+    q = O.PrimeGen(45, m).next()
+    cm = O.Cmod(m, q)
+    a = O.fill_uniform(cm.phim, q, 1)
+    b = O.fill_uniform(cm.phim, q, 2)
+    lhs = O.row_op("mul", cm.fft(a), cm.fft(b), q)
+    rhs = cm.fft(np.array(polymul_mod_phi(a, b, m, q), dtype=np.uint64))
+    assert lhs.tolist() == rhs.tolist()
+
+
+def test_phimx_known():
+    assert O.phimx(12).tolist() == [1, 0, -1, 0, 1]
+    assert O.phimx(16).tolist() == [1, 0, 0, 0, 0, 0, 0, 0, 1]
+    assert O.phimx(15).tolist() == [1, -1, 0, 1, -1, 1, 0, -1, 1]
+    c105 = O.phimx(105)
+    assert c105[7] == -2 and c105[41] == -2  # the famous first non-{0,+-1} coefficients
+
+
+def test_automorph_matches_polynomial_substitution():
+    m = 20
+    q = O.PrimeGen(40, m).next()
+    cm = O.Cmod(m, q)
+    zms = O.zmstar(m)
+    x = O.fill_uniform(cm.phim, q, 7)
+    k = 3
+    # X -> X^k on coefficients, reduced mod Phi_m
+    sub = [0] * (m)
+    for i, c in enumerate(x):
+        sub[(i * k) % m] = (sub[(i * k) % m] + int(c)) % q
+    # reduce degree < m polynomial modulo Phi_m (X^m = 1 already used)
+    phi = [int(c) for c in O.phimx(m)]
+    n = cm.phim
+    for i in range(m - 1, n - 1, -1):
+        c = sub[i]
+        if c:
+            for j in range(n + 1):
+                sub[i - n + j] = (sub[i - n + j] - c * phi[j]) % q
+    want = cm.fft(np.array(sub[:n], dtype=np.uint64))
+    got = O.automorph(cm.fft(x), m, zms, k)
+    assert got.tolist() == want.tolist()
+    with pytest.raises(RuntimeError):
+        O.automorph(cm.fft(x), m, zms, 4)
