@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X.
+
+metric   : ciphertext x ciphertext multiplications per second, including relinearisation
+           (Ctxt::multiplyBy data path: tensorProduct + reLinearize, benchmarks/bgv_basic.cpp:144-165)
+workload : BGV m=32768 (N=16384), L=16 x 60-bit ctxt primes, K=6 x 56-bit special primes,
+           D=3 digits (6/5/5) -- SURVEY.md Appendix B "bits=950" shape (BASELINE configs[2]).
+step     : one hx_mul_relin over a batch of independent ciphertext pairs resident in HBM.
+scaling  : weak -- every rank multiplies its own batch; no data-path collective
+           (independent ciphertexts shard across GPUs).
+
+Adds "roofline" for the dominant kernel (the forward NTT over the D*(L+K) digit rows, timed
+with HIP events on the launch stream) and "cpu_baseline" (the CPU oracle = a port of the
+reference algorithm, single thread, bounded sample).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M = 32768
+L, K = 16, 6
+DIGITS = [list(range(0, 6)), list(range(6, 11)), list(range(11, 16))]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def gen_primes():
+    """PrimeGenerator(60, m) x L then PrimeGenerator(56, m) x K, roots by FindPrimRootT.
+    Product-side code (helib_amd) supplies its own number theory; the oracle is only
+    loaded for the cpu_baseline leg."""
+    from helib_amd import hostnt
+    g = hostnt.PrimeGen(60, M)
+    primes = [g.next() for _ in range(L)]
+    g2 = hostnt.PrimeGen(56, M)
+    primes += [g2.next() for _ in range(K)]
+    return primes
+
+
+def uniform_rows(rng, primes, idx, batch, n):
+    out = np.empty((len(idx), batch, n), dtype=np.uint64)
+    for r, i in enumerate(idx):
+        out[r] = rng.integers(0, primes[i], size=(batch, n), dtype=np.uint64)
+    return out
+
+
+def algorithmic_bytes_per_mult(n, l, k, d):
+    """compulsory traffic of one multiply at a fixed level, as built
+    (all D*(L+K) digit rows go through the forward NTT in this round)."""
+    tensor = l * 56 * n                       # 4 parts in, 3 out (scaling fused)
+    ntt = (l + d * (l + k)) * 16 * n          # L inverse + D(L+K) forward
+    ext = (l + d * (l + k)) * 8 * n           # read L rows, write D(L+K) rows
+    ks = (l + k) * (3 * d + 4) * 8 * n
+    return tensor + ntt + ext + ks
+
+
+def cpu_baseline(primes, sample_mults):
+    """Oracle (port of the reference algorithm, -O3, 1 thread) on `sample_mults` multiplies."""
+    from oracle import oracle as O
+    so_dir = os.path.join(ROOT, "oracle")
+    # a native-tuned build of the same C file, made on the machine that runs it
+    native = os.path.join(so_dir, "liboracle_native.so")
+    try:
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-shared", "-o",
+                               native, os.path.join(so_dir, "hx_oracle.c"), "-lm"],
+                              stderr=subprocess.DEVNULL)
+        os.environ["HX_ORACLE_SO"] = native
+        O._LIB = None
+    except Exception:
+        pass
+    octx = O.Ctx(M)
+    for q in primes:
+        octx.add_prime(q)
+    own, sp = list(range(L)), list(range(L, L + K))
+    allp = own + sp
+    rng = np.random.default_rng(99)
+    n = octx.N
+    kb = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in DIGITS])
+    ka = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in DIGITS])
+    ops = [uniform_rows(rng, primes, own, 1, n)[:, 0] for _ in range(4)]
+    octx.mul_relin(own, sp, DIGITS, *ops, kb, ka)  # warm
+    t0 = time.perf_counter()
+    for _ in range(sample_mults):
+        octx.mul_relin(own, sp, DIGITS, *ops, kb, ka)
+    dt = time.perf_counter() - t0
+    return {"value": sample_mults / dt, "unit": "mult/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_mults} multiplies (tensor+relinearise) at m={M}, L={L}, K={K}, D=3; "
+                      "CPU restatement of HElib 2.2.0 algorithms (not NTL), gcc -O3 -march=native, "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="independent ciphertext pairs per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="multiplies timed on the CPU (0 = skip)")
+    ap.add_argument("--ntt-iters", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from helib_amd import capi as hx
+
+    primes = gen_primes()
+    ctx = hx.Context(M, local_rank)
+    for q in primes:
+        ctx.add_prime(q)  # root = FindPrimRootT(q, m): the host-supplied root convention
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.set_stream(stream)
+    n = ctx.phim
+    own, sp = list(range(L)), list(range(L, L + K))
+    allp = own + sp
+    B = args.batch
+    rng = np.random.default_rng(1234 + rank)
+    kb = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in DIGITS])
+    ka = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in DIGITS])
+    W = hx.KeySwitch(ctx, allp, kb, ka)
+    polys = [hx.DoubleCRT(ctx, own, B, uniform_rows(rng, primes, own, B, n)) for _ in range(4)]
+    out0 = hx.DoubleCRT(ctx, allp, B)
+    out1 = hx.DoubleCRT(ctx, allp, B)
+
+    def step():
+        hx.multiplyBy(*polys, W, DIGITS, out0, out1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    mults = world * B * args.steps
+    value = mults / dt
+
+    # ---- roofline of the dominant kernel: forward NTT over the digit rows ----
+    roof = None
+    cpu = None
+    if rank == 0:
+        nrows = len(DIGITS) * (L + K)
+        digp = hx.DoubleCRT(ctx, own, B, uniform_rows(rng, primes, own, B, n))
+        dg = digp.breakIntoDigits(DIGITS, sp)          # D*(L+K) rows x B, evaluation domain
+        hx.time_ntt(dg, True, 2)                        # warm both directions
+        hx.time_ntt(dg, False, 2)
+        ms_inv = hx.time_ntt(dg, True, args.ntt_iters)
+        ms_fwd = hx.time_ntt(dg, False, args.ntt_iters)
+        bytes_launch = 16.0 * n * nrows * B             # 16*N bytes per row transform
+        ach = bytes_launch / (ms_fwd * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "ntt_row_kernel<14,fwd>", "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "rows_per_launch": nrows * B,
+                "avg_launch_ms": round(ms_fwd, 4), "inverse_avg_launch_ms": round(ms_inv, 4),
+                "bytes_per_launch": bytes_launch}
+        if args.cpu_sample > 0 and world == 1:
+            cpu = cpu_baseline(primes, args.cpu_sample)
+
+    if rank == 0:
+        per_mult = algorithmic_bytes_per_mult(n, L, K, len(DIGITS))
+        line = {
+            "metric": "ctxt_x_ctxt_mults_per_sec_incl_relinearize", "value": round(value, 1),
+            "unit": "mult/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BGV m=32768 N=16384 L=16x60b K=6x56b D=3 (6/5/5) "
+                                   "tensorProduct+reLinearize at fixed level",
+                       "batch_per_gpu": B, "parallelism": f"replica x{world}, batch-sharded",
+                       "algorithmic_MB_per_mult": round(per_mult / 1e6, 2),
+                       "hbm_roofline_mult_per_s_per_gpu": round(HBM_PEAK_GBS * 1e9 / per_mult, 0)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

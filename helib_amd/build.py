@@ -1,0 +1,63 @@
+"""Build the HIP extension in-tree: helib_amd/lib/libhelib_amd.so (gfx950 only).
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the
+gpurun snapshot, so the GPU box loads exactly what was built here.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+SO = os.path.join(LIBDIR, "libhelib_amd.so")
+SOURCES = ["ntt_kernels.hip", "engine.hip"]
+HEADERS = ["ntt_core.h", "dev_common.h", "rns_kernels.h", "hostmath.h",
+           os.path.join("..", "..", "include", "helib_amd.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+         "-Wno-pass-failed"]
+
+
+def hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X engine cannot be built")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, extra_flags=(), verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    cc = hipcc()
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, deps + [src]):
+            jobs.append([cc, *FLAGS, *extra_flags, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(SO, objs):
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs])
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

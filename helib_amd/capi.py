@@ -1,0 +1,361 @@
+"""ctypes binding of the C ABI (include/helib_amd.h) + a thin host-side mirror of
+the reference's DoubleCRT interface for this path.
+
+The HIP extension is the only compute path: importing works without a GPU (so
+that the symbol table can be checked), but every compute call needs a gfx950
+device and raises otherwise.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+# HX_LIB selects an alternative build of the same extension (kernel A/B experiments)
+_SO = os.environ.get("HX_LIB") or os.path.join(_HERE, "lib", "libhelib_amd.so")
+_lib = None
+
+HX_OK = 0
+HX_ERR_INVALID, HX_ERR_DEVICE, HX_ERR_PRIMESET = -1, -2, -3
+HX_ERR_NOT_IN_ZMSTAR, HX_ERR_UNSUPPORTED, HX_ERR_NOMEM = -4, -5, -6
+
+
+class HxError(RuntimeError):
+    """helib::RuntimeError / LogicError analogue (include/helib/exceptions.h)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+class InvalidArgument(HxError):
+    pass
+
+
+# every symbol include/helib_amd.h declares (checked by tests without a GPU)
+SYMBOLS = [
+    "hx_last_error", "hx_version", "hx_device_count",
+    "hx_ctx_create", "hx_ctx_destroy", "hx_ctx_phim", "hx_ctx_set_stream", "hx_ctx_sync",
+    "hx_ctx_add_prime", "hx_ctx_num_primes", "hx_ctx_prime",
+    "hx_poly_create", "hx_poly_wrap", "hx_poly_destroy", "hx_poly_shape", "hx_poly_primes",
+    "hx_poly_device_ptr", "hx_poly_upload", "hx_poly_download", "hx_poly_copy",
+    "hx_poly_set_zero", "hx_poly_remove_primes",
+    "hx_ntt_forward", "hx_ntt_inverse",
+    "hx_add", "hx_sub", "hx_mul", "hx_negate", "hx_add_scalar", "hx_sub_scalar", "hx_mul_scalar",
+    "hx_automorph", "hx_complex_conj",
+    "hx_add_primes_and_scale", "hx_add_primes", "hx_scale_down", "hx_break_into_digits",
+    "hx_ksk_create", "hx_ksk_destroy", "hx_tensor", "hx_key_switch_digits", "hx_mul_relin",
+    "hx_intel_FFTFwd", "hx_intel_FFTRev1", "hx_intel_EltwiseAddMod", "hx_intel_EltwiseAddModScalar",
+    "hx_intel_EltwiseSubMod", "hx_intel_EltwiseSubModScalar", "hx_intel_EltwiseMultMod",
+    "hx_intel_EltwiseMultModScalar",
+    "hx_time_ntt",
+]
+
+
+def lib():
+    """Load the HIP extension; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ImportError(
+                f"{_SO} is missing: build it with `python -m helib_amd.build` "
+                "(there is no CPU fallback)")
+        L = C.CDLL(_SO)
+        L.hx_last_error.restype = C.c_char_p
+        L.hx_version.restype = C.c_char_p
+        L.hx_poly_device_ptr.restype = C.c_void_p
+        L.hx_poly_device_ptr.argtypes = [C.c_void_p]
+        vp, ip, u64 = C.c_void_p, C.c_int, C.c_uint64
+        sig = {
+            "hx_device_count": [vp],
+            "hx_ctx_create": [vp, ip, u64], "hx_ctx_destroy": [vp], "hx_ctx_phim": [vp, vp],
+            "hx_ctx_set_stream": [vp, vp], "hx_ctx_sync": [vp],
+            "hx_ctx_add_prime": [vp, u64, u64, vp], "hx_ctx_num_primes": [vp, vp],
+            "hx_ctx_prime": [vp, ip, vp, vp],
+            "hx_poly_create": [vp, ip, vp, ip, vp], "hx_poly_wrap": [vp, ip, vp, ip, vp, vp],
+            "hx_poly_destroy": [vp], "hx_poly_shape": [vp, vp, vp, vp], "hx_poly_primes": [vp, vp],
+            "hx_poly_upload": [vp, vp], "hx_poly_download": [vp, vp], "hx_poly_copy": [vp, vp],
+            "hx_poly_set_zero": [vp], "hx_poly_remove_primes": [vp, vp, ip],
+            "hx_ntt_forward": [vp], "hx_ntt_inverse": [vp],
+            "hx_add": [vp, vp], "hx_sub": [vp, vp], "hx_mul": [vp, vp], "hx_negate": [vp],
+            "hx_add_scalar": [vp, vp], "hx_sub_scalar": [vp, vp], "hx_mul_scalar": [vp, vp],
+            "hx_automorph": [vp, u64], "hx_complex_conj": [vp],
+            "hx_add_primes_and_scale": [vp, vp, ip], "hx_add_primes": [vp, vp, ip],
+            "hx_scale_down": [vp, vp, ip, u64],
+            "hx_break_into_digits": [vp, vp, vp, ip, vp, ip, vp],
+            "hx_ksk_create": [vp, ip, vp, ip, vp, vp, vp], "hx_ksk_destroy": [vp],
+            "hx_tensor": [vp] * 7, "hx_key_switch_digits": [vp] * 4,
+            "hx_mul_relin": [vp, vp, vp, vp, vp, vp, vp, ip, vp, vp],
+            "hx_intel_FFTFwd": [vp, vp, C.c_long, C.c_long],
+            "hx_intel_FFTRev1": [vp, vp, C.c_long, C.c_long],
+            "hx_intel_EltwiseAddMod": [vp, vp, vp, C.c_long, C.c_long],
+            "hx_intel_EltwiseSubMod": [vp, vp, vp, C.c_long, C.c_long],
+            "hx_intel_EltwiseMultMod": [vp, vp, vp, C.c_long, C.c_long],
+            "hx_intel_EltwiseAddModScalar": [vp, vp, C.c_long, C.c_long, C.c_long],
+            "hx_intel_EltwiseSubModScalar": [vp, vp, C.c_long, C.c_long, C.c_long],
+            "hx_intel_EltwiseMultModScalar": [vp, vp, C.c_long, C.c_long, C.c_long],
+            "hx_time_ntt": [vp, ip, ip, vp],
+        }
+        for name, args in sig.items():
+            f = getattr(L, name)
+            f.argtypes = args
+            f.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != HX_OK:
+        msg = lib().hx_last_error().decode()
+        raise (InvalidArgument if rc == HX_ERR_INVALID else HxError)(rc, msg)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().hx_device_count(C.byref(n))
+    return n.value if rc == HX_OK else 0
+
+
+class Context:
+    """Context::moduli + PAlgebra tables resident on one GPU."""
+
+    def __init__(self, m, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().hx_ctx_create(C.byref(self.h), device, m))
+        self.m = m
+        n = C.c_uint64()
+        _chk(lib().hx_ctx_phim(self.h, C.byref(n)))
+        self.phim = int(n.value)
+        self.primes, self.roots = [], []
+
+    def close(self):
+        if self.h:
+            lib().hx_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_prime(self, q, root=0):
+        """Cmodulus(zms, q, root) -- returns the index in Context::moduli."""
+        idx = C.c_int()
+        _chk(lib().hx_ctx_add_prime(self.h, q, root, C.byref(idx)))
+        qq, rr = C.c_uint64(), C.c_uint64()
+        _chk(lib().hx_ctx_prime(self.h, idx.value, C.byref(qq), C.byref(rr)))
+        self.primes.append(int(qq.value))
+        self.roots.append(int(rr.value))
+        return idx.value
+
+    def ithPrime(self, i):
+        return self.primes[i]
+
+    def set_stream(self, stream_ptr):
+        _chk(lib().hx_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def sync(self):
+        _chk(lib().hx_ctx_sync(self.h))
+
+
+class DoubleCRT:
+    """Batched DoubleCRT (include/helib/DoubleCRT.h:212-385 for the ops of this path).
+
+    rows are numpy uint64 arrays of shape [nrows, batch, phim] on the host side."""
+
+    def __init__(self, context, index_set, batch=1, data=None):
+        self.context = context
+        idx = _i32(list(index_set))
+        self.h = C.c_void_p()
+        _chk(lib().hx_poly_create(context.h, batch, _p(idx), len(idx), C.byref(self.h)))
+        self.batch = batch
+        if data is not None:
+            self.upload(data)
+
+    def close(self):
+        if self.h:
+            lib().hx_poly_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- storage ---
+    def getIndexSet(self):
+        n = C.c_int()
+        _chk(lib().hx_poly_shape(self.h, None, C.byref(n), None))
+        out = np.zeros(max(n.value, 1), dtype=np.int32)
+        _chk(lib().hx_poly_primes(self.h, _p(out)))
+        return [int(x) for x in out[:n.value]]
+
+    def upload(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        nrows = len(self.getIndexSet())
+        assert rows.size == nrows * self.batch * self.context.phim, rows.shape
+        _chk(lib().hx_poly_upload(self.h, _p(rows)))
+        return self
+
+    def download(self):
+        nrows = len(self.getIndexSet())
+        out = np.zeros((nrows, self.batch, self.context.phim), dtype=np.uint64)
+        _chk(lib().hx_poly_download(self.h, _p(out)))
+        return out
+
+    def copy(self):
+        o = DoubleCRT(self.context, self.getIndexSet(), self.batch)
+        _chk(lib().hx_poly_copy(o.h, self.h))
+        return o
+
+    def device_ptr(self):
+        return lib().hx_poly_device_ptr(self.h)
+
+    # --- transforms (Cmodulus::FFT / iFFT over all rows) ---
+    def FFT(self):
+        _chk(lib().hx_ntt_forward(self.h))
+        return self
+
+    def iFFT(self):
+        _chk(lib().hx_ntt_inverse(self.h))
+        return self
+
+    # --- ring ops ---
+    def __iadd__(self, o):
+        _chk(lib().hx_add(self.h, o.h))
+        return self
+
+    def __isub__(self, o):
+        _chk(lib().hx_sub(self.h, o.h))
+        return self
+
+    def __imul__(self, o):
+        _chk(lib().hx_mul(self.h, o.h))
+        return self
+
+    def Negate(self):
+        _chk(lib().hx_negate(self.h))
+        return self
+
+    def _scalars(self, num):
+        idx = self.getIndexSet()
+        if np.isscalar(num) or isinstance(num, int):
+            vals = [int(num) % self.context.primes[i] for i in idx]
+        else:
+            vals = [int(v) for v in num]
+        return np.array(vals, dtype=np.uint64)
+
+    def addConstant(self, num):
+        s = self._scalars(num)
+        _chk(lib().hx_add_scalar(self.h, _p(s)))
+        return self
+
+    def subConstant(self, num):
+        s = self._scalars(num)
+        _chk(lib().hx_sub_scalar(self.h, _p(s)))
+        return self
+
+    def mulConstant(self, num):
+        s = self._scalars(num)
+        _chk(lib().hx_mul_scalar(self.h, _p(s)))
+        return self
+
+    def automorph(self, k):
+        _chk(lib().hx_automorph(self.h, k))
+        return self
+
+    def complexConj(self):
+        _chk(lib().hx_complex_conj(self.h))
+        return self
+
+    # --- prime-set operations ---
+    def removePrimes(self, s):
+        s = _i32(list(s))
+        _chk(lib().hx_poly_remove_primes(self.h, _p(s), len(s)))
+        return self
+
+    def addPrimesAndScale(self, s):
+        s = _i32(list(s))
+        _chk(lib().hx_add_primes_and_scale(self.h, _p(s), len(s)))
+        return self
+
+    def addPrimes(self, s):
+        s = _i32(list(s))
+        _chk(lib().hx_add_primes(self.h, _p(s), len(s)))
+        return self
+
+    def scaleDownToSet(self, keep_set, ptxtSpace):
+        drop = _i32([i for i in self.getIndexSet() if i not in set(keep_set)])
+        _chk(lib().hx_scale_down(self.h, _p(drop), len(drop), ptxtSpace))
+        return self
+
+    def breakIntoDigits(self, digits, special):
+        dig_idx = _i32([p for d in digits for p in d])
+        dig_off = _i32(np.concatenate([[0], np.cumsum([len(d) for d in digits])]))
+        sp = _i32(list(special))
+        out = DoubleCRT(self.context, self.getIndexSet(), self.batch)
+        _chk(lib().hx_break_into_digits(self.h, _p(dig_idx), _p(dig_off), len(digits), _p(sp),
+                                        len(sp), out.h))
+        return out
+
+
+class KeySwitch:
+    """KeySwitch matrix W (include/helib/keySwitching.h:86-101) with explicit (b, a)."""
+
+    def __init__(self, context, row_idx, b, a):
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        idx = _i32(list(row_idx))
+        self.ndig = b.shape[0]
+        self.h = C.c_void_p()
+        self.context = context
+        _chk(lib().hx_ksk_create(context.h, self.ndig, _p(idx), len(idx), _p(b), _p(a),
+                                 C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().hx_ksk_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def tensorProduct(c0, c1, d0, d1):
+    ctx = c0.context
+    outs = [DoubleCRT(ctx, c0.getIndexSet(), c0.batch) for _ in range(3)]
+    _chk(lib().hx_tensor(c0.h, c1.h, d0.h, d1.h, outs[0].h, outs[1].h, outs[2].h))
+    return outs
+
+
+def keySwitchDigits(digits, W, out0, out1):
+    _chk(lib().hx_key_switch_digits(digits.h, W.h, out0.h, out1.h))
+
+
+def multiplyBy(c0, c1, d0, d1, W, digits, out0=None, out1=None):
+    """Ctxt::multiplyBy data path at a fixed level (tensorProduct + reLinearize)."""
+    ctx = c0.context
+    dig_idx = _i32([p for d in digits for p in d])
+    dig_off = _i32(np.concatenate([[0], np.cumsum([len(d) for d in digits])]))
+    if out0 is None:
+        out0 = DoubleCRT(ctx, c0.getIndexSet(), c0.batch)
+        out1 = DoubleCRT(ctx, c0.getIndexSet(), c0.batch)
+    _chk(lib().hx_mul_relin(c0.h, c1.h, d0.h, d1.h, W.h, _p(dig_idx), _p(dig_off), len(digits),
+                            out0.h, out1.h))
+    return out0, out1
+
+
+def time_ntt(poly, inverse, iters):
+    ms = C.c_float()
+    _chk(lib().hx_time_ntt(poly.h, 1 if inverse else 0, iters, C.byref(ms)))
+    return ms.value

@@ -1,0 +1,81 @@
+// dev_common.h -- device-visible constants and 64-bit modular arithmetic for
+// gfx950.  All values are canonical residues of word-sized primes q < 2^62
+// (HElib: q < 2^60, src/macro.h:21); arithmetic is exact integer (no MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ntt_core.h"
+
+namespace hx {
+
+constexpr int MAX_ROWS = 160;  // rows addressable by one launch descriptor
+
+// Per-prime constants, one entry per Context::moduli index, resident in HBM.
+struct PrimeDev {
+  uint64_t q;
+  uint64_t q2;     // 2q
+  uint64_t mu;     // floor(2^(2k) / q), k = bitlen(q)   (Barrett, 128-bit products)
+  uint64_t mu64;   // floor(2^64 / q)                     (Barrett, 64-bit values)
+  uint32_t k;      // bitlen(q)
+  uint32_t pad;
+  const TW* tw_fwd;  // power-of-two NTT tables (ntt_core.h layout), or null
+  const TW* tw_inv;
+};
+
+// launch descriptor passed BY VALUE (kernel-arg segment): row r of the
+// operand uses prime p[r % period]; b_row[r] = matching row of the second
+// operand (element-wise binary ops).
+struct RowMap {
+  uint16_t p[MAX_ROWS];
+};
+struct RowMap2 {
+  uint16_t p[MAX_ROWS];
+  uint16_t brow[MAX_ROWS];
+};
+struct RowScalars {
+  uint64_t c[MAX_ROWS];   // scalar in [0,q)
+  uint64_t cp[MAX_ROWS];  // Shoup precon floor(c*2^64/q)
+};
+
+typedef unsigned __int128 u128;
+
+__device__ __forceinline__ uint64_t add_mod(uint64_t a, uint64_t b, uint64_t q)
+{
+  uint64_t s = a + b;
+  return s >= q ? s - q : s;
+}
+__device__ __forceinline__ uint64_t sub_mod(uint64_t a, uint64_t b, uint64_t q)
+{
+  return a >= b ? a - b : a + q - b;
+}
+__device__ __forceinline__ uint64_t neg_mod(uint64_t a, uint64_t q) { return a ? q - a : 0; }
+
+// a*b mod q for a,b in [0,q): NTL::MulMod(a,b,q,qinv) (src/DoubleCRT.cpp:331).
+// Classical Barrett on the 128-bit product; exact canonical result.
+__device__ __forceinline__ uint64_t mul_mod(uint64_t a, uint64_t b, uint64_t q, uint64_t mu,
+                                            uint32_t k)
+{
+  u128 x = (u128)a * b;
+  uint64_t xs = (uint64_t)(x >> (k - 1));            // < 2^(k+1)
+  uint64_t qh = (uint64_t)(((u128)xs * mu) >> (k + 1));
+  uint64_t r = (uint64_t)x - qh * q;                  // < 3q
+  r = r >= q ? r - q : r;
+  return r >= q ? r - q : r;
+}
+// x mod q for any 64-bit x.
+__device__ __forceinline__ uint64_t red64(uint64_t x, uint64_t q, uint64_t mu64)
+{
+  uint64_t qh = __umul64hi(x, mu64);
+  uint64_t r = x - qh * q;  // < 2q
+  return r >= q ? r - q : r;
+}
+// x*c mod q with precomputed cp = floor(c*2^64/q): NTL::MulModPrecon.
+__device__ __forceinline__ uint64_t mul_shoup(uint64_t x, uint64_t c, uint64_t cp, uint64_t q)
+{
+  uint64_t h = __umul64hi(x, cp);
+  uint64_t r = x * c - h * q;  // [0,2q)
+  return r >= q ? r - q : r;
+}
+
+}  // namespace hx

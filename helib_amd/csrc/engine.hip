@@ -1,0 +1,1370 @@
+// engine.hip -- host runtime + C ABI (include/helib_amd.h) of the MI355X-native
+// DoubleCRT engine.  Device memory, tables and launches only: there is no CPU
+// compute path -- if no gfx950 device is usable every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/helib_amd.h"
+#include "dev_common.h"
+#include "hostmath.h"
+#include "rns_kernels.h"
+
+namespace hx {
+hipError_t launch_ntt_pow2(int logn, bool inverse, uint64_t* data, const RowMap& map, int period,
+                           int row0, int nrows, int batch, const PrimeDev* primes, hipStream_t st);
+}
+
+using hx::ExtArgs;
+using hx::ExtPlanDev;
+using hx::MAX_ROWS;
+using hx::PrimeDev;
+using hx::RowMap;
+using hx::RowMap2;
+using hx::RowScalars;
+using hx::TW;
+
+// ------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess)                                                                \
+      return fail(HX_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
+                  __FILE__, __LINE__);                                                   \
+  } while (0)
+#define CHK(expr)          \
+  do {                     \
+    int _rc = (expr);      \
+    if (_rc != HX_OK)      \
+      return _rc;          \
+  } while (0)
+
+extern "C" const char* hx_last_error(void) { return g_err.c_str(); }
+extern "C" const char* hx_version(void) { return "helib_amd 0.1 (gfx950)"; }
+extern "C" int hx_device_count(int* count)
+{
+  if (!count)
+    return fail(HX_ERR_INVALID, "null argument");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(HX_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------
+// objects
+// ------------------------------------------------------------------
+struct PrimeHost {
+  uint64_t q, root, rinv;
+  TW* d_tw_fwd = nullptr;
+  TW* d_tw_inv = nullptr;
+};
+
+struct ExtPlan {
+  ExtPlanDev dev;
+  void* blob = nullptr;
+};
+
+struct hx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint64_t m = 0;
+  uint32_t phim = 0;
+  int logn = 0;  // log2(phim) when m is a power of two, else 0
+  bool pow2 = false;
+  std::vector<uint32_t> zms;
+  uint32_t* d_zms = nullptr;
+  int32_t* d_zms_index = nullptr;
+  uint32_t* d_perm = nullptr;
+  std::vector<PrimeHost> primes;
+  PrimeDev* d_primes = nullptr;
+  int primes_cap = 0;
+  uint64_t* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_words[4] = {0, 0, 0, 0};
+  std::map<std::vector<uint64_t>, ExtPlan*> plans;
+};
+
+struct hx_poly {
+  hx_ctx* ctx;
+  int batch;
+  int cap_rows;
+  std::vector<int> prime_idx;  // one per row
+  uint64_t* d;
+  bool owns;
+  size_t row_words() const { return (size_t)batch * ctx->phim; }
+  int nrows() const { return (int)prime_idx.size(); }
+};
+
+struct hx_ksk {
+  hx_ctx* ctx;
+  int ndig;
+  std::vector<int> row_idx;
+  uint64_t* d_b;
+  uint64_t* d_a;
+};
+
+static int use(hx_ctx* c)
+{
+  HIPCHK(hipSetDevice(c->device));
+  return HX_OK;
+}
+
+static int ensure_scratch(hx_ctx* c, int slot, size_t words)
+{
+  if (c->scratch_words[slot] >= words)
+    return HX_OK;
+  if (c->scratch[slot]) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(c->scratch[slot]));
+    c->scratch[slot] = nullptr;
+    c->scratch_words[slot] = 0;
+  }
+  HIPCHK(hipMalloc((void**)&c->scratch[slot], words * 8));
+  c->scratch_words[slot] = words;
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------
+extern "C" int hx_ctx_create(hx_ctx** out, int device, uint64_t m)
+{
+  if (!out || m < 2 || m > (1ull << 24))
+    return fail(HX_ERR_INVALID, "Bad Z_m^* modulus m (must be in [2, 2^24])");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(HX_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev)
+    return fail(HX_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  hx_ctx* c = new hx_ctx();
+  c->device = device;
+  c->m = m;
+  std::vector<int32_t> zidx((size_t)m, -1);
+  for (uint64_t i = 1; i < m; i++)
+    if (hxh::gcd(i, m) == 1) {
+      zidx[i] = (int32_t)c->zms.size();
+      c->zms.push_back((uint32_t)i);
+    }
+  c->phim = (uint32_t)c->zms.size();
+  c->pow2 = (m & (m - 1)) == 0;
+  if (c->pow2) {
+    int l = 0;
+    while ((1u << l) < c->phim)
+      l++;
+    c->logn = l;
+  }
+  HIPCHK(hipMalloc((void**)&c->d_zms, (size_t)c->phim * 4));
+  HIPCHK(hipMalloc((void**)&c->d_zms_index, (size_t)m * 4));
+  HIPCHK(hipMalloc((void**)&c->d_perm, (size_t)c->phim * 4));
+  HIPCHK(hipMemcpy(c->d_zms, c->zms.data(), (size_t)c->phim * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_zms_index, zidx.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+  c->primes_cap = 1024;
+  HIPCHK(hipMalloc((void**)&c->d_primes, sizeof(PrimeDev) * c->primes_cap));
+  *out = c;
+  return HX_OK;
+}
+
+extern "C" int hx_ctx_destroy(hx_ctx* c)
+{
+  if (!c)
+    return HX_OK;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (auto& p : c->primes) {
+    if (p.d_tw_fwd)
+      hipFree(p.d_tw_fwd);
+    if (p.d_tw_inv)
+      hipFree(p.d_tw_inv);
+  }
+  for (auto& kv : c->plans) {
+    hipFree(kv.second->blob);
+    delete kv.second;
+  }
+  for (int i = 0; i < 4; i++)
+    if (c->scratch[i])
+      hipFree(c->scratch[i]);
+  hipFree(c->d_zms);
+  hipFree(c->d_zms_index);
+  hipFree(c->d_perm);
+  hipFree(c->d_primes);
+  delete c;
+  return HX_OK;
+}
+
+extern "C" int hx_ctx_phim(const hx_ctx* c, uint64_t* phim)
+{
+  if (!c || !phim)
+    return fail(HX_ERR_INVALID, "null argument");
+  *phim = c->phim;
+  return HX_OK;
+}
+extern "C" int hx_ctx_set_stream(hx_ctx* c, void* s)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null context");
+  c->stream = (hipStream_t)s;
+  return HX_OK;
+}
+extern "C" int hx_ctx_sync(hx_ctx* c)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null context");
+  CHK(use(c));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HX_OK;
+}
+extern "C" int hx_ctx_num_primes(const hx_ctx* c, int* n)
+{
+  if (!c || !n)
+    return fail(HX_ERR_INVALID, "null argument");
+  *n = (int)c->primes.size();
+  return HX_OK;
+}
+extern "C" int hx_ctx_prime(const hx_ctx* c, int idx, uint64_t* q, uint64_t* root)
+{
+  if (!c || idx < 0 || idx >= (int)c->primes.size())
+    return fail(HX_ERR_INVALID, "prime index out of range");
+  if (q)
+    *q = c->primes[idx].q;
+  if (root)
+    *root = c->primes[idx].root;
+  return HX_OK;
+}
+
+template <int LOGN>
+static int upload_tw(hx_ctx* c, PrimeHost& ph)
+{
+  using G = hx::Geo<LOGN>;
+  std::vector<TW> f(G::TW_TOTAL), i(G::TW_TOTAL);
+  uint64_t ninv = hxh::invmod((uint64_t)G::N % ph.q, ph.q);
+  hx::build_tw_tables<LOGN>(ph.q, ph.root, ph.rinv, ninv, hxh::mulmod, f.data(), i.data());
+  HIPCHK(hipMalloc((void**)&ph.d_tw_fwd, sizeof(TW) * G::TW_TOTAL));
+  HIPCHK(hipMalloc((void**)&ph.d_tw_inv, sizeof(TW) * G::TW_TOTAL));
+  HIPCHK(hipMemcpy(ph.d_tw_fwd, f.data(), sizeof(TW) * G::TW_TOTAL, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ph.d_tw_inv, i.data(), sizeof(TW) * G::TW_TOTAL, hipMemcpyHostToDevice));
+  return HX_OK;
+}
+
+extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_out)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null context");
+  CHK(use(c));
+  if (q < 3 || q >= (1ull << 62) || !hxh::is_prime(q))
+    return fail(HX_ERR_INVALID, "q=%llu is not a prime below 2^62", (unsigned long long)q);
+  if ((int)c->primes.size() >= c->primes_cap)
+    return fail(HX_ERR_UNSUPPORTED, "too many primes");
+  uint64_t e = c->pow2 ? c->m : ((c->m % 2 == 0) ? 2 * c->m : c->m);
+  if ((q - 1) % e != 0)
+    return fail(HX_ERR_INVALID, "e=%llu does not divide q-1 (no primitive root)",
+                (unsigned long long)e);
+  if (root == 0)
+    root = hxh::find_prim_root(q, e);
+  // verify the order (reference: FindPrimRootT's independent check)
+  if (hxh::powmod(root, e, q) != 1 || hxh::powmod(root, e / 2, q) == 1)
+    return fail(HX_ERR_INVALID, "root is not a primitive %llu-th root of unity mod q",
+                (unsigned long long)e);
+  PrimeHost ph;
+  ph.q = q;
+  ph.root = root;
+  ph.rinv = hxh::invmod(root, q);
+  if (c->pow2) {
+    switch (c->logn) {
+      case 13: CHK(upload_tw<13>(c, ph)); break;
+      case 14: CHK(upload_tw<14>(c, ph)); break;
+      case 15: CHK(upload_tw<15>(c, ph)); break;
+      default: break;  // element-wise / RNS ops still work; NTT reports UNSUPPORTED
+    }
+  }
+  PrimeDev pd;
+  memset(&pd, 0, sizeof pd);
+  pd.q = q;
+  pd.q2 = 2 * q;
+  pd.k = (uint32_t)hxh::bitlen(q);
+  pd.mu = (uint64_t)((((hxh::u128)1) << (2 * pd.k)) / q);
+  pd.mu64 = (uint64_t)((((hxh::u128)1) << 64) / q);
+  pd.tw_fwd = ph.d_tw_fwd;
+  pd.tw_inv = ph.d_tw_inv;
+  int idx = (int)c->primes.size();
+  HIPCHK(hipMemcpy(c->d_primes + idx, &pd, sizeof pd, hipMemcpyHostToDevice));
+  c->primes.push_back(ph);
+  if (idx_out)
+    *idx_out = idx;
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------
+// polys
+// ------------------------------------------------------------------
+static int check_rows(hx_ctx* c, const int* idx, int n, bool allow_dup = false)
+{
+  if (n < 0 || (n > 0 && !idx))
+    return fail(HX_ERR_INVALID, "bad prime index list");
+  for (int i = 0; i < n; i++) {
+    if (idx[i] < 0 || idx[i] >= (int)c->primes.size())
+      return fail(HX_ERR_INVALID, "prime index %d not in the context", idx[i]);
+    if (!allow_dup)
+      for (int j = 0; j < i; j++)
+        if (idx[j] == idx[i])
+          return fail(HX_ERR_INVALID, "duplicate prime index %d", idx[i]);
+  }
+  return HX_OK;
+}
+
+static int poly_new(hx_ctx* c, int batch, const int* idx, int nrows, int cap, void* wrap,
+                    bool allow_dup, hx_poly** out)
+{
+  if (!c || !out || batch < 1)
+    return fail(HX_ERR_INVALID, "bad argument");
+  CHK(check_rows(c, idx, nrows, allow_dup));
+  CHK(use(c));
+  if (cap < nrows)
+    cap = nrows;
+  if (cap < 1)
+    cap = 1;
+  hx_poly* p = new hx_poly();
+  p->ctx = c;
+  p->batch = batch;
+  p->cap_rows = cap;
+  p->prime_idx.assign(idx, idx + nrows);
+  p->owns = wrap == nullptr;
+  if (wrap) {
+    p->d = (uint64_t*)wrap;
+  } else {
+    size_t bytes = (size_t)cap * batch * c->phim * 8;
+    hipError_t e = hipMalloc((void**)&p->d, bytes);
+    if (e != hipSuccess) {
+      delete p;
+      return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    e = hipMemsetAsync(p->d, 0, bytes, c->stream);
+    if (e != hipSuccess) {
+      hipFree(p->d);
+      delete p;
+      return fail(HX_ERR_DEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
+  }
+  *out = p;
+  return HX_OK;
+}
+
+extern "C" int hx_poly_create(hx_ctx* c, int batch, const int* idx, int nrows, hx_poly** out)
+{
+  return poly_new(c, batch, idx, nrows, nrows, nullptr, false, out);
+}
+extern "C" int hx_poly_wrap(hx_ctx* c, int batch, const int* idx, int nrows, void* dptr,
+                            hx_poly** out)
+{
+  if (!dptr)
+    return fail(HX_ERR_INVALID, "null device pointer");
+  return poly_new(c, batch, idx, nrows, nrows, dptr, false, out);
+}
+extern "C" int hx_poly_destroy(hx_poly* p)
+{
+  if (!p)
+    return HX_OK;
+  hipSetDevice(p->ctx->device);
+  if (p->owns && p->d) {
+    hipStreamSynchronize(p->ctx->stream);
+    hipFree(p->d);
+  }
+  delete p;
+  return HX_OK;
+}
+extern "C" int hx_poly_shape(const hx_poly* p, int* batch, int* nrows, uint64_t* phim)
+{
+  if (!p)
+    return fail(HX_ERR_INVALID, "null poly");
+  if (batch)
+    *batch = p->batch;
+  if (nrows)
+    *nrows = p->nrows();
+  if (phim)
+    *phim = p->ctx->phim;
+  return HX_OK;
+}
+extern "C" int hx_poly_primes(const hx_poly* p, int* out)
+{
+  if (!p || !out)
+    return fail(HX_ERR_INVALID, "null argument");
+  for (int i = 0; i < p->nrows(); i++)
+    out[i] = p->prime_idx[i];
+  return HX_OK;
+}
+extern "C" void* hx_poly_device_ptr(hx_poly* p) { return p ? p->d : nullptr; }
+
+extern "C" int hx_poly_upload(hx_poly* p, const uint64_t* host)
+{
+  if (!p || !host)
+    return fail(HX_ERR_INVALID, "null argument");
+  CHK(use(p->ctx));
+  size_t bytes = (size_t)p->nrows() * p->row_words() * 8;
+  HIPCHK(hipMemcpyAsync(p->d, host, bytes, hipMemcpyHostToDevice, p->ctx->stream));
+  HIPCHK(hipStreamSynchronize(p->ctx->stream));
+  return HX_OK;
+}
+extern "C" int hx_poly_download(const hx_poly* p, uint64_t* host)
+{
+  if (!p || !host)
+    return fail(HX_ERR_INVALID, "null argument");
+  CHK(use(p->ctx));
+  size_t bytes = (size_t)p->nrows() * p->row_words() * 8;
+  HIPCHK(hipMemcpyAsync(host, p->d, bytes, hipMemcpyDeviceToHost, p->ctx->stream));
+  HIPCHK(hipStreamSynchronize(p->ctx->stream));
+  return HX_OK;
+}
+
+static int poly_reserve(hx_poly* p, int cap)
+{
+  if (cap <= p->cap_rows)
+    return HX_OK;
+  if (!p->owns)
+    return fail(HX_ERR_NOMEM, "wrapped poly has no room for %d rows", cap);
+  hx_ctx* c = p->ctx;
+  uint64_t* nd = nullptr;
+  size_t bytes = (size_t)cap * p->row_words() * 8;
+  hipError_t e = hipMalloc((void**)&nd, bytes);
+  if (e != hipSuccess)
+    return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  HIPCHK(hipMemcpyAsync(nd, p->d, (size_t)p->nrows() * p->row_words() * 8,
+                        hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(p->d));
+  p->d = nd;
+  p->cap_rows = cap;
+  return HX_OK;
+}
+
+extern "C" int hx_poly_copy(hx_poly* dst, const hx_poly* src)
+{
+  if (!dst || !src || dst->ctx != src->ctx || dst->batch != src->batch)
+    return fail(HX_ERR_INVALID, "Context mismatch");
+  CHK(use(dst->ctx));
+  CHK(poly_reserve(dst, src->nrows()));
+  dst->prime_idx = src->prime_idx;
+  HIPCHK(hipMemcpyAsync(dst->d, src->d, (size_t)src->nrows() * src->row_words() * 8,
+                        hipMemcpyDeviceToDevice, dst->ctx->stream));
+  return HX_OK;
+}
+extern "C" int hx_poly_set_zero(hx_poly* p)
+{
+  if (!p)
+    return fail(HX_ERR_INVALID, "null poly");
+  CHK(use(p->ctx));
+  HIPCHK(hipMemsetAsync(p->d, 0, (size_t)p->nrows() * p->row_words() * 8, p->ctx->stream));
+  return HX_OK;
+}
+
+static int find_row(const std::vector<int>& v, int prime)
+{
+  for (size_t i = 0; i < v.size(); i++)
+    if (v[i] == prime)
+      return (int)i;
+  return -1;
+}
+
+extern "C" int hx_poly_remove_primes(hx_poly* p, const int* idx, int n)
+{
+  if (!p || (n > 0 && !idx))
+    return fail(HX_ERR_INVALID, "null argument");
+  CHK(use(p->ctx));
+  std::vector<int> keep;
+  size_t rw = p->row_words();
+  int w = 0;
+  for (int r = 0; r < p->nrows(); r++) {
+    bool drop = false;
+    for (int i = 0; i < n; i++)
+      if (idx[i] == p->prime_idx[r])
+        drop = true;
+    if (drop)
+      continue;
+    if (w != r)
+      HIPCHK(hipMemcpyAsync(p->d + (size_t)w * rw, p->d + (size_t)r * rw, rw * 8,
+                            hipMemcpyDeviceToDevice, p->ctx->stream));
+    keep.push_back(p->prime_idx[r]);
+    w++;
+  }
+  p->prime_idx = keep;
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------
+// NTT
+// ------------------------------------------------------------------
+static int make_map(const std::vector<int>& primes, int first, int count, RowMap& map)
+{
+  if (count > MAX_ROWS)
+    return fail(HX_ERR_UNSUPPORTED, "more than %d rows per launch descriptor", MAX_ROWS);
+  for (int r = 0; r < count; r++)
+    map.p[r] = (uint16_t)primes[first + r];
+  return HX_OK;
+}
+
+// transform rows [row0,row0+nrows) of a [rows][batch][N] buffer; row r uses
+// prime plist[(r - row0_of_list) % period]
+static int ntt_rows(hx_ctx* c, uint64_t* data, const std::vector<int>& plist, int period,
+                    int row0, int nrows, int batch, bool inverse)
+{
+  if (nrows == 0)
+    return HX_OK;
+  if (!c->pow2)
+    return fail(HX_ERR_UNSUPPORTED, "NTT for non-power-of-two m (Bluestein) is not built yet");
+  if (c->logn < 13 || c->logn > 15)
+    return fail(HX_ERR_UNSUPPORTED, "power-of-two NTT supports phi(m) in {8192,16384,32768}");
+  RowMap map;
+  CHK(make_map(plist, 0, period, map));
+  hipError_t e = hx::launch_ntt_pow2(c->logn, inverse, data, map, period, row0, nrows, batch,
+                                     c->d_primes, c->stream);
+  if (e != hipSuccess)
+    return fail(HX_ERR_DEVICE, "NTT launch failed: %s", hipGetErrorString(e));
+  return HX_OK;
+}
+
+extern "C" int hx_ntt_forward(hx_poly* p)
+{
+  if (!p)
+    return fail(HX_ERR_INVALID, "null poly");
+  CHK(use(p->ctx));
+  if (p->nrows() > MAX_ROWS)
+    return fail(HX_ERR_UNSUPPORTED, "too many rows");
+  return ntt_rows(p->ctx, p->d, p->prime_idx, p->nrows(), 0, p->nrows(), p->batch, false);
+}
+extern "C" int hx_ntt_inverse(hx_poly* p)
+{
+  if (!p)
+    return fail(HX_ERR_INVALID, "null poly");
+  CHK(use(p->ctx));
+  if (p->nrows() > MAX_ROWS)
+    return fail(HX_ERR_UNSUPPORTED, "too many rows");
+  return ntt_rows(p->ctx, p->d, p->prime_idx, p->nrows(), 0, p->nrows(), p->batch, true);
+}
+
+extern "C" int hx_time_ntt(hx_poly* p, int dir, int iters, float* avg_ms)
+{
+  if (!p || !avg_ms || iters < 1)
+    return fail(HX_ERR_INVALID, "bad argument");
+  hx_ctx* c = p->ctx;
+  CHK(use(c));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < iters; i++) {
+    int rc = ntt_rows(c, p->d, p->prime_idx, p->nrows(), 0, p->nrows(), p->batch, dir != 0);
+    if (rc != HX_OK)
+      return rc;
+  }
+  HIPCHK(hipEventRecord(e1, c->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *avg_ms = ms / iters;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------
+// element-wise
+// ------------------------------------------------------------------
+static dim3 ew_grid(size_t row_words, int rows)
+{
+  size_t nvec = row_words / 2;
+  size_t blocks = (nvec + 255) / 256;
+  size_t cap = 8192 / (size_t)(rows > 0 ? rows : 1) + 1;  // ~ 32 blocks per CU overall
+  if (blocks > cap)
+    blocks = cap;
+  if (blocks < 1)
+    blocks = 1;
+  return dim3((unsigned)blocks, (unsigned)rows);
+}
+
+template <int OP>
+static int ew_binary(hx_poly* a, const hx_poly* b)
+{
+  if (!a || !b)
+    return fail(HX_ERR_INVALID, "null poly");
+  if (a->ctx != b->ctx)
+    return fail(HX_ERR_INVALID, "DoubleCRT::Op: incompatible objects");
+  if (b->batch != a->batch && b->batch != 1)
+    return fail(HX_ERR_INVALID, "batch mismatch");
+  CHK(use(a->ctx));
+  int rows = a->nrows();
+  if (rows == 0)
+    return HX_OK;
+  if (rows > MAX_ROWS)
+    return fail(HX_ERR_UNSUPPORTED, "too many rows");
+  RowMap2 map;
+  for (int r = 0; r < rows; r++) {
+    int br = find_row(b->prime_idx, a->prime_idx[r]);
+    if (br < 0)
+      return fail(HX_ERR_PRIMESET, "DoubleCRT::Op: incompatible index sets (prime %d)",
+                  a->prime_idx[r]);
+    map.p[r] = (uint16_t)a->prime_idx[r];
+    map.brow[r] = (uint16_t)br;
+  }
+  size_t rw = a->row_words();
+  hipLaunchKernelGGL((hx::ew_binary_kernel<OP>), ew_grid(rw, rows), dim3(256), 0, a->ctx->stream,
+                     a->d, b->d, map, rw, b->row_words(), (int)(b->batch != a->batch),
+                     (size_t)a->ctx->phim, a->ctx->d_primes);
+  HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+extern "C" int hx_add(hx_poly* a, const hx_poly* b) { return ew_binary<hx::EW_ADD>(a, b); }
+extern "C" int hx_sub(hx_poly* a, const hx_poly* b) { return ew_binary<hx::EW_SUB>(a, b); }
+extern "C" int hx_mul(hx_poly* a, const hx_poly* b) { return ew_binary<hx::EW_MUL>(a, b); }
+
+template <int OP>
+static int ew_scalar_rows(hx_poly* a, const uint64_t* c_per_row)
+{
+  if (!a)
+    return fail(HX_ERR_INVALID, "null poly");
+  CHK(use(a->ctx));
+  int rows = a->nrows();
+  if (rows == 0)
+    return HX_OK;
+  if (rows > MAX_ROWS)
+    return fail(HX_ERR_UNSUPPORTED, "too many rows");
+  RowMap map;
+  RowScalars sc;
+  for (int r = 0; r < rows; r++) {
+    uint64_t q = a->ctx->primes[a->prime_idx[r]].q;
+    map.p[r] = (uint16_t)a->prime_idx[r];
+    uint64_t cv = c_per_row ? c_per_row[r] % q : 0;
+    sc.c[r] = cv;
+    sc.cp[r] = hxh::shoup(cv, q);
+  }
+  size_t rw = a->row_words();
+  hipLaunchKernelGGL((hx::ew_scalar_kernel<OP>), ew_grid(rw, rows), dim3(256), 0, a->ctx->stream,
+                     a->d, map, sc, rw, a->ctx->d_primes);
+  HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+extern "C" int hx_add_scalar(hx_poly* a, const uint64_t* c)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null scalars");
+  return ew_scalar_rows<hx::EWS_ADD>(a, c);
+}
+extern "C" int hx_sub_scalar(hx_poly* a, const uint64_t* c)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null scalars");
+  return ew_scalar_rows<hx::EWS_SUB>(a, c);
+}
+extern "C" int hx_mul_scalar(hx_poly* a, const uint64_t* c)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null scalars");
+  return ew_scalar_rows<hx::EWS_MUL>(a, c);
+}
+extern "C" int hx_negate(hx_poly* a) { return ew_scalar_rows<hx::EWS_NEG>(a, nullptr); }
+
+extern "C" int hx_automorph(hx_poly* a, uint64_t k)
+{
+  if (!a)
+    return fail(HX_ERR_INVALID, "null poly");
+  hx_ctx* c = a->ctx;
+  CHK(use(c));
+  k %= c->m;
+  if (hxh::gcd(k, c->m) != 1)
+    return fail(HX_ERR_NOT_IN_ZMSTAR, "DoubleCRT::automorph: k not in Zm*");
+  int rows = a->nrows();
+  if (rows == 0)
+    return HX_OK;
+  size_t words = (size_t)rows * a->row_words();
+  CHK(ensure_scratch(c, 3, words));
+  if (!c->pow2) {
+    hipLaunchKernelGGL(hx::perm_build_kernel, dim3((c->phim + 255) / 256), dim3(256), 0, c->stream,
+                       c->d_perm, c->d_zms, c->d_zms_index, c->phim, c->m, k);
+    HIPCHK(hipGetLastError());
+  }
+  size_t nseg = (size_t)rows * a->batch;
+  unsigned bx = (c->phim + 255) / 256;
+  if (bx > 64)
+    bx = 64;
+  hipLaunchKernelGGL(hx::gather_kernel, dim3(bx, (unsigned)nseg), dim3(256), 0, c->stream,
+                     c->scratch[3], a->d, c->d_perm, c->phim, nseg, (int)c->pow2, c->m, k);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(a->d, c->scratch[3], words * 8, hipMemcpyDeviceToDevice, c->stream));
+  return HX_OK;
+}
+extern "C" int hx_complex_conj(hx_poly* a)
+{
+  if (!a)
+    return fail(HX_ERR_INVALID, "null poly");
+  return hx_automorph(a, a->ctx->m - 1);  // src/DoubleCRT.cpp:1239
+}
+
+// ------------------------------------------------------------------
+// exact RNS plans
+// ------------------------------------------------------------------
+static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<int>& tgt,
+                    uint64_t ptxt, ExtPlan** out)
+{
+  int n = (int)src.size(), nt = (int)tgt.size();
+  if (n < 1 || n > 64)
+    return fail(HX_ERR_UNSUPPORTED, "basis extension supports 1..64 source primes (got %d)", n);
+  if (nt > MAX_ROWS)
+    return fail(HX_ERR_UNSUPPORTED, "too many target primes");
+  std::vector<uint64_t> key;
+  key.push_back((uint64_t)n);
+  for (int s : src)
+    key.push_back((uint64_t)s);
+  for (int t : tgt)
+    key.push_back((uint64_t)t);
+  key.push_back(ptxt);
+  auto it = c->plans.find(key);
+  if (it != c->plans.end()) {
+    *out = it->second;
+    return HX_OK;
+  }
+  std::vector<uint64_t> p(n);
+  for (int k = 0; k < n; k++)
+    p[k] = c->primes[src[k]].q;
+  // blob layout in 64-bit words
+  size_t off = 0;
+  auto take = [&](size_t words) {
+    size_t o = off;
+    off += (words + 1) & ~(size_t)1;  // keep 16-byte alignment
+    return o;
+  };
+  size_t o_srcq = take(n), o_srcmu = take(n), o_ginv = take((size_t)2 * n * n), o_half = take(n);
+  size_t o_tq = take(nt), o_tmu64 = take(nt), o_tmu = take(nt), o_tk = take((nt + 1) / 2);
+  size_t o_pmod = take(nt), o_W = take((size_t)2 * nt * n), o_upd = take((size_t)2 * nt);
+  size_t o_Wp = take((size_t)2 * n);
+  std::vector<uint64_t> h(off, 0);
+  hxh::BigU P(1);
+  for (int k = 0; k < n; k++) {
+    h[o_srcq + k] = p[k];
+    h[o_srcmu + k] = (uint64_t)((((hxh::u128)1) << 64) / p[k]);
+    for (int l = 0; l < k; l++) {
+      uint64_t inv = hxh::invmod(p[l] % p[k], p[k]);
+      if (inv == 0)
+        return fail(HX_ERR_INVALID, "source primes are not pairwise coprime");
+      h[o_ginv + 2 * ((size_t)k * n + l)] = inv;
+      h[o_ginv + 2 * ((size_t)k * n + l) + 1] = hxh::shoup(inv, p[k]);
+    }
+    P.mul_word(p[k]);
+  }
+  {
+    hxh::BigU H = P;  // (P-1)/2 ; P is odd
+    H.sub_word(1);
+    H.shr1();
+    for (int k = 0; k < n; k++)
+      h[o_half + k] = H.divmod_word(p[k]);
+  }
+  uint32_t* tk = reinterpret_cast<uint32_t*>(&h[o_tk]);
+  for (int t = 0; t < nt; t++) {
+    uint64_t q = c->primes[tgt[t]].q;
+    h[o_tq + t] = q;
+    h[o_tmu64 + t] = (uint64_t)((((hxh::u128)1) << 64) / q);
+    int kb = hxh::bitlen(q);
+    tk[t] = (uint32_t)kb;
+    h[o_tmu + t] = (uint64_t)((((hxh::u128)1) << (2 * kb)) / q);
+    uint64_t run = 1 % q;
+    for (int k = 0; k < n; k++) {
+      h[o_W + 2 * ((size_t)t * n + k)] = run;
+      h[o_W + 2 * ((size_t)t * n + k) + 1] = hxh::shoup(run, q);
+      run = hxh::mulmod(run, p[k] % q, q);
+    }
+    h[o_pmod + t] = run;  // P mod q
+    uint64_t pinv = hxh::invmod(run, q);
+    h[o_upd + 2 * (size_t)t] = pinv;
+    h[o_upd + 2 * (size_t)t + 1] = hxh::shoup(pinv, q);
+  }
+  ExtPlan* pl = new ExtPlan();
+  memset(&pl->dev, 0, sizeof pl->dev);
+  if (ptxt > 1) {
+    uint64_t run = 1 % ptxt;
+    for (int k = 0; k < n; k++) {
+      h[o_Wp + 2 * (size_t)k] = run;
+      h[o_Wp + 2 * (size_t)k + 1] = hxh::shoup(run, ptxt);
+      run = hxh::mulmod(run, p[k] % ptxt, ptxt);
+    }
+    uint64_t pinv = hxh::invmod(run, ptxt);
+    if (pinv == 0) {
+      delete pl;
+      return fail(HX_ERR_INVALID, "dropped primes are not invertible modulo ptxtSpace");
+    }
+    pl->dev.ptxt = ptxt;
+    pl->dev.ptxt_mu64 = (uint64_t)((((hxh::u128)1) << 64) / ptxt);
+    int kb = hxh::bitlen(ptxt);
+    pl->dev.ptxt_k = (uint32_t)kb;
+    pl->dev.ptxt_mu = (uint64_t)((((hxh::u128)1) << (2 * kb)) / ptxt);
+    pl->dev.pinv_ptxt = pinv;
+    pl->dev.pmod_ptxt = run;
+  }
+  uint64_t* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, off * 8));
+  HIPCHK(hipMemcpy(d, h.data(), off * 8, hipMemcpyHostToDevice));
+  pl->blob = d;
+  pl->dev.n = n;
+  pl->dev.nt = nt;
+  pl->dev.src_q = d + o_srcq;
+  pl->dev.src_mu64 = d + o_srcmu;
+  pl->dev.ginv = reinterpret_cast<const TW*>(d + o_ginv);
+  pl->dev.half = d + o_half;
+  pl->dev.tgt_q = d + o_tq;
+  pl->dev.tgt_mu64 = d + o_tmu64;
+  pl->dev.tgt_mu = d + o_tmu;
+  pl->dev.tgt_k = reinterpret_cast<const uint32_t*>(d + o_tk);
+  pl->dev.pmod = d + o_pmod;
+  pl->dev.W = reinterpret_cast<const TW*>(d + o_W);
+  pl->dev.upd = reinterpret_cast<const TW*>(d + o_upd);
+  pl->dev.Wp = reinterpret_cast<const TW*>(d + o_Wp);
+  c->plans[key] = pl;
+  *out = pl;
+  return HX_OK;
+}
+
+static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args, size_t row_words)
+{
+  dim3 grid((unsigned)((row_words + 255) / 256)), block(256);
+  int n = pl->dev.n;
+  if (n <= 8)
+    hipLaunchKernelGGL((hx::rns_extend_kernel<8>), grid, block, 0, c->stream, pl->dev, args,
+                       row_words);
+  else if (n <= 16)
+    hipLaunchKernelGGL((hx::rns_extend_kernel<16>), grid, block, 0, c->stream, pl->dev, args,
+                       row_words);
+  else if (n <= 40)
+    hipLaunchKernelGGL((hx::rns_extend_kernel<40>), grid, block, 0, c->stream, pl->dev, args,
+                       row_words);
+  else
+    hipLaunchKernelGGL((hx::rns_extend_kernel<64>), grid, block, 0, c->stream, pl->dev, args,
+                       row_words);
+  HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+
+static void clear_args(ExtArgs& a)
+{
+  memset(&a, 0xff, sizeof a);
+  a.src = nullptr;
+  a.dst = nullptr;
+  a.upd = nullptr;
+}
+
+// ------------------------------------------------------------------
+// addPrimesAndScale / addPrimes / scaleDownToSet
+// ------------------------------------------------------------------
+static int scale_rows_by_primes(hx_poly* a, const int* add_idx, int nadd)
+{
+  hx_ctx* c = a->ctx;
+  std::vector<uint64_t> f(a->nrows());
+  for (int r = 0; r < a->nrows(); r++) {
+    uint64_t q = c->primes[a->prime_idx[r]].q, v = 1;
+    for (int i = 0; i < nadd; i++)
+      v = hxh::mulmod(v, c->primes[add_idx[i]].q % q, q);
+    f[r] = v;
+  }
+  return ew_scalar_rows<hx::EWS_MUL>(a, f.data());
+}
+
+extern "C" int hx_add_primes_and_scale(hx_poly* a, const int* add_idx, int nadd)
+{
+  if (!a)
+    return fail(HX_ERR_INVALID, "null poly");
+  if (nadd == 0)
+    return HX_OK;
+  hx_ctx* c = a->ctx;
+  CHK(use(c));
+  CHK(check_rows(c, add_idx, nadd));
+  for (int i = 0; i < nadd; i++)
+    if (find_row(a->prime_idx, add_idx[i]) >= 0)
+      return fail(HX_ERR_PRIMESET, "addPrimes can only be called on a disjoint set");
+  int old = a->nrows();
+  if (old > 0)
+    CHK(scale_rows_by_primes(a, add_idx, nadd));
+  CHK(poly_reserve(a, old + nadd));
+  HIPCHK(hipMemsetAsync(a->d + (size_t)old * a->row_words(), 0,
+                        (size_t)nadd * a->row_words() * 8, c->stream));
+  for (int i = 0; i < nadd; i++)
+    a->prime_idx.push_back(add_idx[i]);
+  return HX_OK;
+}
+
+extern "C" int hx_add_primes(hx_poly* a, const int* add_idx, int nadd)
+{
+  if (!a)
+    return fail(HX_ERR_INVALID, "null poly");
+  if (nadd == 0)
+    return HX_OK;
+  hx_ctx* c = a->ctx;
+  CHK(use(c));
+  CHK(check_rows(c, add_idx, nadd));
+  for (int i = 0; i < nadd; i++)
+    if (find_row(a->prime_idx, add_idx[i]) >= 0)
+      return fail(HX_ERR_PRIMESET, "addPrimes can only be called on a disjoint set");
+  int old = a->nrows();
+  CHK(poly_reserve(a, old + nadd));
+  size_t rw = a->row_words();
+  if (old == 0) {  // special case for empty DCRT (src/DoubleCRT.cpp:579-585)
+    HIPCHK(hipMemsetAsync(a->d, 0, (size_t)nadd * rw * 8, c->stream));
+    a->prime_idx.assign(add_idx, add_idx + nadd);
+    return HX_OK;
+  }
+  if (old > 64)
+    return fail(HX_ERR_UNSUPPORTED, "addPrimes from more than 64 primes");
+  // toPoly: inverse transform of a copy
+  CHK(ensure_scratch(c, 0, (size_t)old * rw));
+  HIPCHK(hipMemcpyAsync(c->scratch[0], a->d, (size_t)old * rw * 8, hipMemcpyDeviceToDevice,
+                        c->stream));
+  CHK(ntt_rows(c, c->scratch[0], a->prime_idx, old, 0, old, a->batch, true));
+  std::vector<int> tgt(add_idx, add_idx + nadd);
+  ExtPlan* pl;
+  CHK(get_plan(c, a->prime_idx, tgt, 0, &pl));
+  ExtArgs args;
+  clear_args(args);
+  args.src = c->scratch[0];
+  args.dst = a->d;
+  for (int k = 0; k < old; k++)
+    args.src_row[k] = (uint16_t)k;
+  for (int t = 0; t < nadd; t++)
+    args.dst_row[t] = (uint16_t)(old + t);
+  CHK(launch_extend(c, pl, args, rw));
+  std::vector<int> all = a->prime_idx;
+  for (int i = 0; i < nadd; i++)
+    all.push_back(add_idx[i]);
+  // FFT(poly, s1) on the new rows only
+  if (old + nadd > MAX_ROWS)
+    return fail(HX_ERR_UNSUPPORTED, "too many rows");
+  CHK(ntt_rows(c, a->d, all, old + nadd, old, nadd, a->batch, false));
+  a->prime_idx = all;
+  return HX_OK;
+}
+
+extern "C" int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_t ptxt)
+{
+  if (!a)
+    return fail(HX_ERR_INVALID, "null poly");
+  hx_ctx* c = a->ctx;
+  CHK(use(c));
+  if (ptxt < 1)
+    return fail(HX_ERR_INVALID, "ptxtSpace must be at least 1");
+  // diff = getIndexSet() / s : only primes actually present are dropped
+  std::vector<int> drop, keep;
+  for (int r = 0; r < a->nrows(); r++) {
+    bool d = false;
+    for (int i = 0; i < ndrop; i++)
+      if (drop_idx[i] == a->prime_idx[r])
+        d = true;
+    (d ? drop : keep).push_back(a->prime_idx[r]);
+  }
+  if (drop.empty())
+    return HX_OK;  // nothing to do
+  if (keep.empty())
+    return fail(HX_ERR_PRIMESET, "s and the index set must have some intersection");
+  if ((int)drop.size() > 64)
+    return fail(HX_ERR_UNSUPPORTED, "scaleDownToSet dropping more than 64 primes");
+  size_t rw = a->row_words();
+  int nd = (int)drop.size(), nk = (int)keep.size();
+  // toPoly(delta, diff): inverse transform of the dropped rows
+  CHK(ensure_scratch(c, 0, (size_t)nd * rw));
+  CHK(ensure_scratch(c, 1, (size_t)nk * rw));
+  for (int k = 0; k < nd; k++) {
+    int r = find_row(a->prime_idx, drop[k]);
+    HIPCHK(hipMemcpyAsync(c->scratch[0] + (size_t)k * rw, a->d + (size_t)r * rw, rw * 8,
+                          hipMemcpyDeviceToDevice, c->stream));
+  }
+  CHK(ntt_rows(c, c->scratch[0], drop, nd, 0, nd, a->batch, true));
+  ExtPlan* pl;
+  CHK(get_plan(c, drop, keep, ptxt > 1 ? ptxt : 0, &pl));
+  ExtArgs args;
+  clear_args(args);
+  args.src = c->scratch[0];
+  args.dst = c->scratch[1];
+  for (int k = 0; k < nd; k++)
+    args.src_row[k] = (uint16_t)k;
+  for (int t = 0; t < nk; t++)
+    args.dst_row[t] = (uint16_t)t;
+  CHK(launch_extend(c, pl, args, rw));
+  CHK(ntt_rows(c, c->scratch[1], keep, nk, 0, nk, a->batch, false));
+  // removePrimes(diff); *this -= delta; *this /= diffProd
+  CHK(hx_poly_remove_primes(a, drop.data(), nd));
+  RowMap2 map;
+  RowScalars sc;
+  for (int r = 0; r < nk; r++) {
+    uint64_t q = c->primes[keep[r]].q, v = 1;
+    for (int k = 0; k < nd; k++)
+      v = hxh::mulmod(v, c->primes[drop[k]].q % q, q);
+    uint64_t inv = hxh::invmod(v, q);
+    map.p[r] = (uint16_t)keep[r];
+    map.brow[r] = (uint16_t)r;
+    sc.c[r] = inv;
+    sc.cp[r] = hxh::shoup(inv, q);
+  }
+  hipLaunchKernelGGL(hx::sub_scale_kernel, ew_grid(rw, nk), dim3(256), 0, c->stream, a->d,
+                     c->scratch[1], map, sc, rw, c->d_primes);
+  HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------
+// breakIntoDigits
+// ------------------------------------------------------------------
+// coef: inverse-transformed copy of the ctxt rows (modified in place),
+// dig : [ndig][nall][batch][N] output in the coefficient domain.
+static int break_digits_coef(hx_ctx* c, uint64_t* coef, const std::vector<int>& own,
+                             const int* dig_idx, const int* dig_off, int ndig,
+                             const std::vector<int>& all, uint64_t* dig, size_t rw)
+{
+  int nall = (int)all.size();
+  // which digit owns each ctxt prime
+  std::vector<int> owner(all.size(), -1);
+  for (int d = 0; d < ndig; d++)
+    for (int p = dig_off[d]; p < dig_off[d + 1]; p++) {
+      int pos = find_row(all, dig_idx[p]);
+      if (pos < 0 || find_row(own, dig_idx[p]) < 0)
+        return fail(HX_ERR_PRIMESET, "digit prime %d is not a row of the operand", dig_idx[p]);
+      if (owner[pos] >= 0)
+        return fail(HX_ERR_INVALID, "digit sets overlap");
+      owner[pos] = d;
+    }
+  for (size_t r = 0; r < own.size(); r++)
+    if (owner[find_row(all, own[r])] < 0)
+      return fail(HX_ERR_PRIMESET, "prime %d of the operand is in no digit", own[r]);
+  for (int d = 0; d < ndig; d++) {
+    std::vector<int> src(dig_idx + dig_off[d], dig_idx + dig_off[d + 1]);
+    if (src.empty())
+      return fail(HX_ERR_INVALID, "empty digit");
+    std::vector<int> tgt;
+    for (int r = 0; r < nall; r++)
+      if (owner[r] != d)
+        tgt.push_back(all[r]);
+    ExtPlan* pl;
+    CHK(get_plan(c, src, tgt, 0, &pl));
+    ExtArgs args;
+    clear_args(args);
+    args.src = coef;
+    args.dst = dig;
+    args.upd = coef;
+    for (size_t k = 0; k < src.size(); k++) {
+      args.src_row[k] = (uint16_t)find_row(own, src[k]);
+      args.own_dst_row[k] = (uint16_t)(d * nall + find_row(all, src[k]));
+    }
+    for (size_t t = 0; t < tgt.size(); t++) {
+      int pos = find_row(all, tgt[t]);
+      args.dst_row[t] = (uint16_t)(d * nall + pos);
+      if (owner[pos] > d)
+        args.upd_row[t] = (uint16_t)find_row(own, tgt[t]);
+    }
+    CHK(launch_extend(c, pl, args, rw));
+  }
+  return HX_OK;
+}
+
+static int build_all(const hx_poly* a, const int* sp_idx, int nsp, std::vector<int>& all)
+{
+  all = a->prime_idx;
+  for (int i = 0; i < nsp; i++) {
+    if (find_row(all, sp_idx[i]) >= 0)
+      return fail(HX_ERR_PRIMESET,
+                  "Special primes and CtxtPart's index set have non-empty intersection");
+    all.push_back(sp_idx[i]);
+  }
+  return HX_OK;
+}
+
+extern "C" int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const int* dig_off,
+                                    int ndig, const int* sp_idx, int nsp, hx_poly* out)
+{
+  if (!a || !out || !dig_idx || !dig_off || ndig < 1)
+    return fail(HX_ERR_INVALID, "bad argument");
+  hx_ctx* c = a->ctx;
+  if (out->ctx != c || out->batch != a->batch)
+    return fail(HX_ERR_INVALID, "Context mismatch");
+  CHK(use(c));
+  CHK(check_rows(c, sp_idx, nsp));
+  std::vector<int> all;
+  CHK(build_all(a, sp_idx, nsp, all));
+  int nall = (int)all.size(), L = a->nrows();
+  if (nall > MAX_ROWS)
+    return fail(HX_ERR_UNSUPPORTED, "too many rows");
+  size_t rw = a->row_words();
+  CHK(poly_reserve(out, ndig * nall));
+  out->prime_idx.clear();
+  for (int d = 0; d < ndig; d++)
+    out->prime_idx.insert(out->prime_idx.end(), all.begin(), all.end());
+  CHK(ensure_scratch(c, 0, (size_t)L * rw));
+  HIPCHK(hipMemcpyAsync(c->scratch[0], a->d, (size_t)L * rw * 8, hipMemcpyDeviceToDevice,
+                        c->stream));
+  CHK(ntt_rows(c, c->scratch[0], a->prime_idx, L, 0, L, a->batch, true));
+  CHK(break_digits_coef(c, c->scratch[0], a->prime_idx, dig_idx, dig_off, ndig, all, out->d, rw));
+  CHK(ntt_rows(c, out->d, all, nall, 0, ndig * nall, a->batch, false));
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------
+// key-switch matrices, tensor, key switch, multiply
+// ------------------------------------------------------------------
+extern "C" int hx_ksk_create(hx_ctx* c, int ndig, const int* row_idx, int nrows, const uint64_t* b,
+                             const uint64_t* a, hx_ksk** out)
+{
+  if (!c || !out || !b || !a || ndig < 1)
+    return fail(HX_ERR_INVALID, "bad argument");
+  CHK(use(c));
+  CHK(check_rows(c, row_idx, nrows));
+  hx_ksk* k = new hx_ksk();
+  k->ctx = c;
+  k->ndig = ndig;
+  k->row_idx.assign(row_idx, row_idx + nrows);
+  size_t bytes = (size_t)ndig * nrows * c->phim * 8;
+  HIPCHK(hipMalloc((void**)&k->d_b, bytes));
+  HIPCHK(hipMalloc((void**)&k->d_a, bytes));
+  HIPCHK(hipMemcpy(k->d_b, b, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(k->d_a, a, bytes, hipMemcpyHostToDevice));
+  *out = k;
+  return HX_OK;
+}
+extern "C" int hx_ksk_destroy(hx_ksk* k)
+{
+  if (!k)
+    return HX_OK;
+  hipSetDevice(k->ctx->device);
+  hipStreamSynchronize(k->ctx->stream);
+  hipFree(k->d_b);
+  hipFree(k->d_a);
+  delete k;
+  return HX_OK;
+}
+
+static int tensor_launch(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0,
+                         const hx_poly* d1, uint64_t* o0, uint64_t* o1, uint64_t* o2,
+                         const uint64_t* scale_per_row)
+{
+  hx_ctx* c = c0->ctx;
+  int rows = c0->nrows();
+  if (rows > MAX_ROWS)
+    return fail(HX_ERR_UNSUPPORTED, "too many rows");
+  const hx_poly* ps[3] = {c1, d0, d1};
+  for (auto* p : ps)
+    if (p->ctx != c || p->batch != c0->batch || p->prime_idx != c0->prime_idx)
+      return fail(HX_ERR_PRIMESET,
+                  "tensorProduct: parts must be defined relative to the same set of primes");
+  RowMap map;
+  RowScalars sc;
+  memset(&sc, 0, sizeof sc);
+  for (int r = 0; r < rows; r++) {
+    map.p[r] = (uint16_t)c0->prime_idx[r];
+    if (scale_per_row) {
+      uint64_t q = c->primes[c0->prime_idx[r]].q;
+      sc.c[r] = scale_per_row[r] % q;
+      sc.cp[r] = hxh::shoup(sc.c[r], q);
+    }
+  }
+  size_t rw = c0->row_words();
+  hipLaunchKernelGGL(hx::tensor_kernel, ew_grid(rw, rows), dim3(256), 0, c->stream, c0->d, c1->d,
+                     d0->d, d1->d, o0, o1, o2, map, sc, scale_per_row ? 1 : 0, rw, c->d_primes);
+  HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+
+extern "C" int hx_tensor(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0,
+                         const hx_poly* d1, hx_poly* o0, hx_poly* o1, hx_poly* o2)
+{
+  if (!c0 || !c1 || !d0 || !d1 || !o0 || !o1 || !o2)
+    return fail(HX_ERR_INVALID, "null poly");
+  CHK(use(c0->ctx));
+  hx_poly* os[3] = {o0, o1, o2};
+  for (auto* o : os) {
+    if (o->ctx != c0->ctx || o->batch != c0->batch)
+      return fail(HX_ERR_INVALID, "Context mismatch");
+    CHK(poly_reserve(o, c0->nrows()));
+    o->prime_idx = c0->prime_idx;
+  }
+  return tensor_launch(c0, c1, d0, d1, o0->d, o1->d, o2->d, nullptr);
+}
+
+static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
+                            const std::vector<int>& all, int batch, uint64_t* out0, uint64_t* out1,
+                            int accumulate_rows)
+{
+  int nall = (int)all.size();
+  if (W->row_idx != all)
+    return fail(HX_ERR_PRIMESET, "key-switching matrix is not defined on the operand's primes");
+  RowMap map;
+  CHK(make_map(all, 0, nall, map));
+  size_t rw = (size_t)batch * c->phim;
+  hipLaunchKernelGGL(hx::keyswitch_kernel, ew_grid(rw, nall), dim3(256), 0, c->stream, dig, W->d_b,
+                     W->d_a, out0, out1, map, W->ndig, nall, batch, c->phim, accumulate_rows,
+                     c->d_primes);
+  HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+
+extern "C" int hx_key_switch_digits(const hx_poly* digits, const hx_ksk* W, hx_poly* out0,
+                                    hx_poly* out1)
+{
+  if (!digits || !W || !out0 || !out1)
+    return fail(HX_ERR_INVALID, "null argument");
+  hx_ctx* c = digits->ctx;
+  CHK(use(c));
+  int nall = (int)W->row_idx.size();
+  if (digits->nrows() != W->ndig * nall)
+    return fail(HX_ERR_INVALID, "W must have as many columns as there are digits");
+  if (out0->prime_idx != W->row_idx || out1->prime_idx != W->row_idx ||
+      out0->batch != digits->batch || out1->batch != digits->batch)
+    return fail(HX_ERR_PRIMESET, "Ctxt::addPart: ctxt has primes not in part");
+  return keyswitch_launch(c, digits->d, W, W->row_idx, digits->batch, out0->d, out1->d, nall);
+}
+
+extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0,
+                            const hx_poly* d1, const hx_ksk* W, const int* dig_idx,
+                            const int* dig_off, int ndig, hx_poly* out0, hx_poly* out1)
+{
+  if (!c0 || !c1 || !d0 || !d1 || !W || !out0 || !out1 || !dig_idx || !dig_off)
+    return fail(HX_ERR_INVALID, "null argument");
+  hx_ctx* c = c0->ctx;
+  CHK(use(c));
+  if (ndig != W->ndig)
+    return fail(HX_ERR_INVALID, "W must have as many columns as there are digits");
+  int L = c0->nrows(), nall = (int)W->row_idx.size(), K = nall - L;
+  if (K < 0)
+    return fail(HX_ERR_PRIMESET, "key-switching matrix has fewer primes than the ciphertext");
+  for (int r = 0; r < L; r++)
+    if (W->row_idx[r] != c0->prime_idx[r])
+      return fail(HX_ERR_PRIMESET, "key-switching matrix rows must start with the ctxt primes");
+  if (out0->batch != c0->batch || out1->batch != c0->batch || out0->ctx != c || out1->ctx != c)
+    return fail(HX_ERR_INVALID, "Context mismatch");
+  size_t rw = c0->row_words();
+  CHK(poly_reserve(out0, nall));
+  CHK(poly_reserve(out1, nall));
+  out0->prime_idx = W->row_idx;
+  out1->prime_idx = W->row_idx;
+  // scratch: [0] = s^2 part (L rows), [1] = digits (ndig*nall rows)
+  CHK(ensure_scratch(c, 0, (size_t)L * rw));
+  CHK(ensure_scratch(c, 1, (size_t)ndig * nall * rw));
+  // tensorProduct + (parts 1,s) addPrimesAndScale(special)
+  std::vector<uint64_t> f(L);
+  for (int r = 0; r < L; r++) {
+    uint64_t q = c->primes[c0->prime_idx[r]].q, v = 1;
+    for (int s = L; s < nall; s++)
+      v = hxh::mulmod(v, c->primes[W->row_idx[s]].q % q, q);
+    f[r] = v;
+  }
+  CHK(tensor_launch(c0, c1, d0, d1, out0->d, out1->d, c->scratch[0], f.data()));
+  // keySwitchPart on the s^2 part
+  CHK(ntt_rows(c, c->scratch[0], c0->prime_idx, L, 0, L, c0->batch, true));
+  CHK(break_digits_coef(c, c->scratch[0], c0->prime_idx, dig_idx, dig_off, ndig, W->row_idx,
+                        c->scratch[1], rw));
+  CHK(ntt_rows(c, c->scratch[1], W->row_idx, nall, 0, ndig * nall, c0->batch, false));
+  CHK(keyswitch_launch(c, c->scratch[1], W, W->row_idx, c0->batch, out0->d, out1->d, L));
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------
+// HEXL-shim compatibility layer (src/intelExt.h:20-59): host pointers,
+// synchronous, one context per (n, q) cached under a mutex like the HEXL NTT
+// cache (src/intelExt.cpp:46-73).
+// ------------------------------------------------------------------
+namespace {
+struct ShimEntry {
+  hx_ctx* ctx;
+  hx_poly* a;
+  hx_poly* b;
+};
+std::mutex g_shim_mu;
+std::map<std::pair<long, long>, ShimEntry> g_shim;
+
+int shim_get(long n, long q, ShimEntry** out)
+{
+  auto key = std::make_pair(n, q);
+  auto it = g_shim.find(key);
+  if (it == g_shim.end()) {
+    if (n < 2 || (n & (n - 1)))
+      return fail(HX_ERR_INVALID, "intel:: shim needs a power-of-two n");
+    ShimEntry e;
+    CHK(hx_ctx_create(&e.ctx, 0, (uint64_t)(2 * n)));
+    int idx;
+    CHK(hx_ctx_add_prime(e.ctx, (uint64_t)q, 0, &idx));
+    CHK(hx_poly_create(e.ctx, 1, &idx, 1, &e.a));
+    CHK(hx_poly_create(e.ctx, 1, &idx, 1, &e.b));
+    it = g_shim.emplace(key, e).first;
+  }
+  *out = &it->second;
+  return HX_OK;
+}
+template <class F>
+int shim_unary(long* out, const long* in, long n, long q, F op)
+{
+  std::lock_guard<std::mutex> lk(g_shim_mu);
+  ShimEntry* e;
+  CHK(shim_get(n, q, &e));
+  CHK(hx_poly_upload(e->a, (const uint64_t*)in));
+  CHK(op(e));
+  return hx_poly_download(e->a, (uint64_t*)out);
+}
+template <class F>
+int shim_binary(long* r, const long* a, const long* b, long n, long q, F op)
+{
+  std::lock_guard<std::mutex> lk(g_shim_mu);
+  ShimEntry* e;
+  CHK(shim_get(n, q, &e));
+  CHK(hx_poly_upload(e->a, (const uint64_t*)a));
+  CHK(hx_poly_upload(e->b, (const uint64_t*)b));
+  CHK(op(e));
+  return hx_poly_download(e->a, (uint64_t*)r);
+}
+}  // namespace
+
+extern "C" int hx_intel_FFTFwd(long* out, const long* in, long n, long q)
+{
+  return shim_unary(out, in, n, q, [](ShimEntry* e) { return hx_ntt_forward(e->a); });
+}
+extern "C" int hx_intel_FFTRev1(long* out, const long* in, long n, long q)
+{
+  return shim_unary(out, in, n, q, [](ShimEntry* e) { return hx_ntt_inverse(e->a); });
+}
+extern "C" int hx_intel_EltwiseAddMod(long* r, const long* a, const long* b, long n, long q)
+{
+  return shim_binary(r, a, b, n, q, [](ShimEntry* e) { return hx_add(e->a, e->b); });
+}
+extern "C" int hx_intel_EltwiseSubMod(long* r, const long* a, const long* b, long n, long q)
+{
+  return shim_binary(r, a, b, n, q, [](ShimEntry* e) { return hx_sub(e->a, e->b); });
+}
+extern "C" int hx_intel_EltwiseMultMod(long* r, const long* a, const long* b, long n, long q)
+{
+  return shim_binary(r, a, b, n, q, [](ShimEntry* e) { return hx_mul(e->a, e->b); });
+}
+extern "C" int hx_intel_EltwiseAddModScalar(long* r, const long* a, long s, long n, long q)
+{
+  uint64_t sv = (uint64_t)s;
+  return shim_unary(r, a, n, q, [sv](ShimEntry* e) { return hx_add_scalar(e->a, &sv); });
+}
+extern "C" int hx_intel_EltwiseSubModScalar(long* r, const long* a, long s, long n, long q)
+{
+  uint64_t sv = (uint64_t)s;
+  return shim_unary(r, a, n, q, [sv](ShimEntry* e) { return hx_sub_scalar(e->a, &sv); });
+}
+extern "C" int hx_intel_EltwiseMultModScalar(long* r, const long* a, long s, long n, long q)
+{
+  uint64_t sv = (uint64_t)s;
+  return shim_unary(r, a, n, q, [sv](ShimEntry* e) { return hx_mul_scalar(e->a, &sv); });
+}

@@ -1,0 +1,458 @@
+// ntt_core.h -- negacyclic NTT of one DoubleCRT row (m = 2^k, N = m/2), written
+// for gfx950: one workgroup owns one row, 32 coefficients per thread live in
+// VGPRs, three register passes (radix-32, radix-32, radix-2^LC) with two LDS
+// transposes between them.  Replaces Cmodulus::FFT_aux / iFFT power-of-two
+// branches (HElib src/CModulus.cpp:362-429, :493-553) including NTL's
+// FFTFwd/FFTRev1, the powers[] pre-twist and the BitReverseCopy passes.
+//
+// The phase functions are HOST+DEVICE so that tests/ can replay the exact
+// index arithmetic of the kernel thread-by-thread on the CPU (no GPU in the
+// build container).  The product path only ever runs them inside the HIP
+// kernels of ntt_kernels.hip.
+//
+// Math: y[j] = sum_i x_i * psi^(i*(2j+1)), psi = w0 a
+// primitive 2N-th root of unity, j natural order.  Forward = Cooley-Tukey
+// butterflies with psi powers merged into the twiddles (bit-reversed table),
+// natural in -> bit-reversed positions, un-reversed for free by the store
+// addressing of the last pass.  Inverse = the mirrored Gentleman-Sande network
+// with N^-1 folded into the last stage.  Harvey lazy butterflies keep values in
+// [0,4q) (forward) / [0,2q) (inverse); q < 2^62 is required (HElib: q < 2^60).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define HXD __host__ __device__ __forceinline__
+#else
+#define HXD inline
+#endif
+
+namespace hx {
+
+struct TW {
+  uint64_t w;   // twiddle in [0,q)
+  uint64_t wp;  // floor(w * 2^64 / q)   (NTL::PrepMulModPrecon analogue)
+};
+
+HXD uint64_t mulhi64(uint64_t a, uint64_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// x * w mod q, result in [0, 2q) for ANY 64-bit x (Shoup / Harvey).
+HXD uint64_t shoup_lazy(uint64_t x, TW t, uint64_t q)
+{
+  uint64_t h = mulhi64(x, t.wp);
+  return x * t.w - h * q;
+}
+
+HXD constexpr unsigned brev_bits(unsigned x, int bits)
+{
+  unsigned r = 0;
+  for (int i = 0; i < bits; i++)
+    r |= ((x >> i) & 1u) << (bits - 1 - i);
+  return r;
+}
+HXD unsigned brev5(unsigned x)
+{
+  return ((x & 1u) << 4) | ((x & 2u) << 2) | (x & 4u) | ((x & 8u) >> 2) | ((x & 16u) >> 4);
+}
+HXD unsigned brev10(unsigned x) { return (brev5(x & 31u) << 5) | brev5(x >> 5); }
+
+// Geometry for N = 2^LOGN, LOGN in {13,14,15}.
+template <int LOGN>
+struct Geo {
+  static constexpr int LC = LOGN - 10;       // stages in the last pass
+  static constexpr int N = 1 << LOGN;
+  static constexpr int T = 1 << (LOGN - 5);  // threads per workgroup
+  static constexpr int E = 32;               // coefficients per thread
+  static constexpr int GC = 1 << LC;         // points per pass-C group
+  static constexpr int NGC = 32 >> LC;       // pass-C groups per thread
+  static constexpr int LDS_WORDS = 33 * T;   // 32-bit words (AB layout is padded 33/32)
+  // twiddle table layout (forward and inverse tables have the same shape):
+  //   [0,31)                       pass A : index 2^s-1+k               (uniform)
+  //   [TWB, TWB+31*32)             pass B : (2^s'-1+k)*32 + hi'
+  //   [TWC, TWC+(GC-1)*1024)       pass C : (2^s'-1+k)*1024 + u
+  static constexpr int TWB = 32;
+  static constexpr int TWC = TWB + 31 * 32;
+  static constexpr int TW_TOTAL = TWC + (GC - 1) * 1024;
+};
+
+// ---- original (bit-reversed psi table) twiddle index for each slot ----
+// psi_rev[idx] = psi^{brev_LOGN(idx)}, 1 <= idx < N.  Stage s (m = 2^s groups)
+// butterfly on position p uses idx = 2^s + (p >> (LOGN - s)).
+template <int LOGN>
+HXD unsigned twA_src(int s, int k) { return (1u << s) + (unsigned)k; }
+template <int LOGN>
+HXD unsigned twB_src(int sp, int k, unsigned hip)
+{
+  return (1u << (5 + sp)) + (brev5(hip) << sp) + (unsigned)k;
+}
+template <int LOGN>
+HXD unsigned twC_src(int sp, int k, unsigned u)
+{
+  return (1u << (10 + sp)) + (brev10(u) << sp) + (unsigned)k;
+}
+
+// ---------------------------------------------------------------------
+// butterflies
+// ---------------------------------------------------------------------
+HXD void ct_bfly(uint64_t& X, uint64_t& Y, TW t, uint64_t q, uint64_t q2)
+{
+  uint64_t x = X;
+  x = (x >= q2) ? x - q2 : x;           // [0,2q)
+  uint64_t v = shoup_lazy(Y, t, q);     // [0,2q)
+  X = x + v;                            // [0,4q)
+  Y = x - v + q2;                       // (0,4q)
+}
+HXD void gs_bfly(uint64_t& X, uint64_t& Y, TW t, uint64_t q, uint64_t q2)
+{
+  uint64_t x = X, y = Y;                // [0,2q)
+  uint64_t s = x + y;
+  s = (s >= q2) ? s - q2 : s;           // [0,2q)
+  X = s;
+  Y = shoup_lazy(x - y + q2, t, q);     // [0,2q)
+}
+// last inverse stage with N^-1 folded in: X = (x+y)*Ninv, Y = (x-y)*S0*Ninv
+HXD void gs_bfly_last(uint64_t& X, uint64_t& Y, TW tNinv, TW tS0Ninv, uint64_t q, uint64_t q2)
+{
+  uint64_t x = X, y = Y;                // [0,2q)
+  X = shoup_lazy(x + y, tNinv, q);      // [0,2q)
+  Y = shoup_lazy(x - y + q2, tS0Ninv, q);
+}
+
+// ---------------------------------------------------------------------
+// register passes.  v[32] is the thread's coefficient file.
+// ---------------------------------------------------------------------
+// forward pass over 5 in-thread bits: element index e (5 bits), stage sp pairs
+// e and e + (16 >> sp); group k = e >> (5 - sp).
+template <class TWF>
+HXD void fwd_pass5(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
+{
+#pragma unroll
+  for (int sp = 0; sp < 5; sp++) {
+    const int half = 16 >> sp;
+#pragma unroll
+    for (int k = 0; k < (1 << sp); k++) {
+      TW t = tw(sp, k);
+#pragma unroll
+      for (int j = 0; j < half; j++) {
+        int a = k * 2 * half + j;
+        ct_bfly(v[a], v[a + half], t, q, q2);
+      }
+    }
+  }
+}
+// LAST: this is the final pass of the inverse transform (pass A); its stage 0
+// uses slot (0,0) = S0*Ninv and the extra slot tw(-1,0) = Ninv.
+template <bool LAST, class TWF>
+HXD void inv_pass5(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
+{
+#pragma unroll
+  for (int sp = 4; sp >= (LAST ? 1 : 0); sp--) {
+    const int half = 16 >> sp;
+#pragma unroll
+    for (int k = 0; k < (1 << sp); k++) {
+      TW t = tw(sp, k);
+#pragma unroll
+      for (int j = 0; j < half; j++) {
+        int a = k * 2 * half + j;
+        gs_bfly(v[a], v[a + half], t, q, q2);
+      }
+    }
+  }
+  if (LAST) {
+    TW tS = tw(0, 0), tN = tw(-1, 0);
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      gs_bfly_last(v[j], v[j + 16], tN, tS, q, q2);
+  }
+}
+// last pass: NGC independent groups of GC = 2^LC points, group gi occupies
+// v[gi*GC .. gi*GC+GC).
+template <int LC, class TWF>
+HXD void fwd_passC(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
+{
+  constexpr int GC = 1 << LC, NGC = 32 >> LC;
+#pragma unroll
+  for (int gi = 0; gi < NGC; gi++) {
+#pragma unroll
+    for (int sp = 0; sp < LC; sp++) {
+      const int half = (GC / 2) >> sp;
+#pragma unroll
+      for (int k = 0; k < (1 << sp); k++) {
+        TW t = tw(gi, sp, k);
+#pragma unroll
+        for (int j = 0; j < half; j++) {
+          int a = gi * GC + k * 2 * half + j;
+          ct_bfly(v[a], v[a + half], t, q, q2);
+        }
+      }
+    }
+  }
+}
+template <int LC, class TWF>
+HXD void inv_passC(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
+{
+  constexpr int GC = 1 << LC, NGC = 32 >> LC;
+#pragma unroll
+  for (int gi = 0; gi < NGC; gi++) {
+#pragma unroll
+    for (int sp = LC - 1; sp >= 0; sp--) {
+      const int half = (GC / 2) >> sp;
+#pragma unroll
+      for (int k = 0; k < (1 << sp); k++) {
+        TW t = tw(gi, sp, k);
+#pragma unroll
+        for (int j = 0; j < half; j++) {
+          int a = gi * GC + k * 2 * half + j;
+          gs_bfly(v[a], v[a + half], t, q, q2);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------
+// LDS transposes, one 32-bit half at a time (half = 0: low words, 1: high).
+// Position p of the row (LOGN bits):
+//   pass A thread: tid = p & (T-1),          e  = p >> (LOGN-5)
+//   pass B thread: tid = lo*32 + brev5(hi),  eB = (p >> LC) & 31,
+//                  hi = p >> (LOGN-5), lo = p & (GC-1)
+//   pass C thread: u = brev10(p >> LC) = tid + T*gi, e' = p & (GC-1)
+// AB layout: word = brev5(hi) + 33*(p & (T-1))    (33: conflict-free both ways)
+// BC layout: word = u + 1024*e'
+// ---------------------------------------------------------------------
+template <int LOGN>
+HXD unsigned ab_addr_A(unsigned tid, int e) { return brev5((unsigned)e) + 33u * tid; }
+template <int LOGN>
+HXD unsigned ab_addr_B(unsigned tid, int eB)
+{
+  constexpr int LC = Geo<LOGN>::LC;
+  return (tid & 31u) + 33u * (((unsigned)eB << LC) + (tid >> 5));
+}
+template <int LOGN>
+HXD unsigned bc_addr_B(unsigned tid, int eB)
+{
+  return (tid & 31u) + 32u * brev5((unsigned)eB) + 1024u * (tid >> 5);
+}
+template <int LOGN>
+HXD unsigned bc_addr_C(unsigned tid, int i)  // i = gi*GC + e'
+{
+  constexpr int LC = Geo<LOGN>::LC;
+  constexpr int T = Geo<LOGN>::T;
+  unsigned gi = (unsigned)i >> LC, ep = (unsigned)i & ((1u << LC) - 1u);
+  return (tid + (unsigned)T * gi) + 1024u * ep;
+}
+
+HXD uint32_t half_of(uint64_t x, int half) { return half ? (uint32_t)(x >> 32) : (uint32_t)x; }
+HXD void set_half(uint64_t& x, int half, uint32_t w)
+{
+  x = half ? ((x & 0xffffffffull) | ((uint64_t)w << 32)) : ((x & 0xffffffff00000000ull) | w);
+}
+
+// global <-> register index maps
+// natural coefficient index held in v[e] of pass-A thread tid
+template <int LOGN>
+HXD unsigned coef_index(unsigned tid, int e) { return ((unsigned)e << (LOGN - 5)) + tid; }
+// natural evaluation index j (= 2j+1-th power) held in v[i] of pass-C thread tid
+template <int LOGN>
+HXD unsigned eval_index(unsigned tid, int i)
+{
+  constexpr int LC = Geo<LOGN>::LC;
+  constexpr int T = Geo<LOGN>::T;
+  unsigned gi = (unsigned)i >> LC, ep = (unsigned)i & ((1u << LC) - 1u);
+  return brev_bits(ep, LC) * 1024u + tid + (unsigned)T * gi;
+}
+
+HXD uint64_t norm4(uint64_t x, uint64_t q, uint64_t q2)  // [0,4q) -> [0,q)
+{
+  x = (x >= q2) ? x - q2 : x;
+  return (x >= q) ? x - q : x;
+}
+HXD uint64_t norm2(uint64_t x, uint64_t q)  // [0,2q) -> [0,q)
+{
+  return (x >= q) ? x - q : x;
+}
+
+// ---------------------------------------------------------------------
+// The transform as barrier-separated phases.  The HIP kernel runs
+//   phase<0>; barrier; phase<1>; barrier; ... phase<7>
+// for its own tid; the CPU replay in tests/ runs every tid through phase k
+// before moving to phase k+1.  v = 32 coefficients, nl = 32 staged low words.
+// ---------------------------------------------------------------------
+template <int LOGN>
+struct RowNTT {
+  using G = Geo<LOGN>;
+  static constexpr int NPHASE = 8;
+
+  // -------- forward: coefficients (natural) -> evaluations (natural) -----
+  template <int PH>
+  static HXD void fwd(unsigned tid, uint64_t (&v)[32], uint32_t (&nl)[32], uint32_t* lds,
+                      const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                      const TW* __restrict__ tw, uint64_t q)
+  {
+    const uint64_t q2 = q + q;
+    if constexpr (PH == 0) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        v[e] = in[coef_index<LOGN>(tid, e)];
+      fwd_pass5(v, q, q2, [&](int sp, int k) { return tw[(1 << sp) - 1 + k]; });
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        lds[ab_addr_A<LOGN>(tid, e)] = half_of(v[e], 0);
+    } else if constexpr (PH == 1) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        nl[e] = lds[ab_addr_B<LOGN>(tid, e)];
+    } else if constexpr (PH == 2) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        lds[ab_addr_A<LOGN>(tid, e)] = half_of(v[e], 1);
+    } else if constexpr (PH == 3) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        v[e] = ((uint64_t)lds[ab_addr_B<LOGN>(tid, e)] << 32) | nl[e];
+      const TW* twb = tw + G::TWB + (tid & 31u);
+      fwd_pass5(v, q, q2, [&](int sp, int k) { return twb[((1 << sp) - 1 + k) * 32]; });
+    } else if constexpr (PH == 4) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        lds[bc_addr_B<LOGN>(tid, e)] = half_of(v[e], 0);
+    } else if constexpr (PH == 5) {
+#pragma unroll
+      for (int i = 0; i < 32; i++)
+        nl[i] = lds[bc_addr_C<LOGN>(tid, i)];
+    } else if constexpr (PH == 6) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        lds[bc_addr_B<LOGN>(tid, e)] = half_of(v[e], 1);
+    } else if constexpr (PH == 7) {
+#pragma unroll
+      for (int i = 0; i < 32; i++)
+        v[i] = ((uint64_t)lds[bc_addr_C<LOGN>(tid, i)] << 32) | nl[i];
+      const TW* twc = tw + G::TWC + tid;
+      fwd_passC<G::LC>(v, q, q2, [&](int gi, int sp, int k) {
+        return twc[((1 << sp) - 1 + k) * 1024 + G::T * gi];
+      });
+#pragma unroll
+      for (int i = 0; i < 32; i++)
+        out[eval_index<LOGN>(tid, i)] = norm4(v[i], q, q2);
+    }
+  }
+
+  // -------- inverse: evaluations (natural) -> coefficients (natural) -----
+  template <int PH>
+  static HXD void inv(unsigned tid, uint64_t (&v)[32], uint32_t (&nl)[32], uint32_t* lds,
+                      const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                      const TW* __restrict__ tw, uint64_t q)
+  {
+    const uint64_t q2 = q + q;
+    if constexpr (PH == 0) {
+#pragma unroll
+      for (int i = 0; i < 32; i++)
+        v[i] = in[eval_index<LOGN>(tid, i)];
+      const TW* twc = tw + G::TWC + tid;
+      inv_passC<G::LC>(v, q, q2, [&](int gi, int sp, int k) {
+        return twc[((1 << sp) - 1 + k) * 1024 + G::T * gi];
+      });
+#pragma unroll
+      for (int i = 0; i < 32; i++)
+        lds[bc_addr_C<LOGN>(tid, i)] = half_of(v[i], 0);
+    } else if constexpr (PH == 1) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        nl[e] = lds[bc_addr_B<LOGN>(tid, e)];
+    } else if constexpr (PH == 2) {
+#pragma unroll
+      for (int i = 0; i < 32; i++)
+        lds[bc_addr_C<LOGN>(tid, i)] = half_of(v[i], 1);
+    } else if constexpr (PH == 3) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        v[e] = ((uint64_t)lds[bc_addr_B<LOGN>(tid, e)] << 32) | nl[e];
+      const TW* twb = tw + G::TWB + (tid & 31u);
+      inv_pass5<false>(v, q, q2, [&](int sp, int k) { return twb[((1 << sp) - 1 + k) * 32]; });
+    } else if constexpr (PH == 4) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        lds[ab_addr_B<LOGN>(tid, e)] = half_of(v[e], 0);
+    } else if constexpr (PH == 5) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        nl[e] = lds[ab_addr_A<LOGN>(tid, e)];
+    } else if constexpr (PH == 6) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        lds[ab_addr_B<LOGN>(tid, e)] = half_of(v[e], 1);
+    } else if constexpr (PH == 7) {
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        v[e] = ((uint64_t)lds[ab_addr_A<LOGN>(tid, e)] << 32) | nl[e];
+      inv_pass5<true>(v, q, q2, [&](int sp, int k) { return sp < 0 ? tw[31] : tw[(1 << sp) - 1 + k]; });
+#pragma unroll
+      for (int e = 0; e < 32; e++)
+        out[coef_index<LOGN>(tid, e)] = norm2(v[e], q);
+    }
+  }
+};
+
+// Host-side table builder (used by the library when a prime is registered and
+// by the CPU replay test).  psi = primitive 2N-th root of unity (w0).
+// mulmod/powmod/invmod are supplied by the caller (exact 128-bit arithmetic).
+template <int LOGN, class MulMod>
+inline void build_tw_tables(uint64_t q, uint64_t psi, uint64_t psi_inv, uint64_t n_inv,
+                            MulMod mulmod, TW* fwd, TW* inv)
+{
+  using G = Geo<LOGN>;
+  const int N = G::N;
+  // pw[i] = psi^i, ipw[i] = psi^-i
+  uint64_t* pw = new uint64_t[N];
+  uint64_t* ipw = new uint64_t[N];
+  pw[0] = ipw[0] = 1;
+  for (int i = 1; i < N; i++) {
+    pw[i] = mulmod(pw[i - 1], psi, q);
+    ipw[i] = mulmod(ipw[i - 1], psi_inv, q);
+  }
+  auto mk = [&](uint64_t w) {
+    TW t;
+    t.w = w;
+    t.wp = (uint64_t)((((unsigned __int128)w) << 64) / q);
+    return t;
+  };
+  auto src = [&](unsigned idx) { return brev_bits(idx, LOGN); };
+  for (int i = 0; i < G::TW_TOTAL; i++) {
+    fwd[i] = mk(0);
+    inv[i] = mk(0);
+  }
+  for (int s = 0; s < 5; s++)
+    for (int k = 0; k < (1 << s); k++) {
+      unsigned e = src(twA_src<LOGN>(s, k));
+      fwd[(1 << s) - 1 + k] = mk(pw[e]);
+      inv[(1 << s) - 1 + k] = mk(ipw[e]);
+    }
+  // inverse: slot 0 = S0 * N^-1, slot 31 = N^-1
+  inv[0] = mk(mulmod(ipw[src(1)], n_inv, q));
+  inv[31] = mk(n_inv);
+  for (int sp = 0; sp < 5; sp++)
+    for (int k = 0; k < (1 << sp); k++)
+      for (unsigned hip = 0; hip < 32; hip++) {
+        unsigned e = src(twB_src<LOGN>(sp, k, hip));
+        fwd[G::TWB + ((1 << sp) - 1 + k) * 32 + hip] = mk(pw[e]);
+        inv[G::TWB + ((1 << sp) - 1 + k) * 32 + hip] = mk(ipw[e]);
+      }
+  for (int sp = 0; sp < G::LC; sp++)
+    for (int k = 0; k < (1 << sp); k++)
+      for (unsigned u = 0; u < 1024; u++) {
+        unsigned e = src(twC_src<LOGN>(sp, k, u));
+        fwd[G::TWC + ((1 << sp) - 1 + k) * 1024 + u] = mk(pw[e]);
+        inv[G::TWC + ((1 << sp) - 1 + k) * 1024 + u] = mk(ipw[e]);
+      }
+  delete[] pw;
+  delete[] ipw;
+}
+
+}  // namespace hx

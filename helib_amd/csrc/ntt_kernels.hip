@@ -1,0 +1,109 @@
+// ntt_kernels.hip -- power-of-two negacyclic NTT kernels for gfx950.
+//
+// One workgroup transforms one DoubleCRT row (one prime, one batch element)
+// held entirely on-chip: 32 coefficients per thread in VGPRs, two LDS
+// transposes (32-bit halves, 33/32-padded so both sides are bank-conflict
+// free), twiddles streamed from L2-resident per-prime tables laid out so that
+// every wave-load is contiguous.  HBM traffic = the algorithmic 16*N bytes.
+// See ntt_core.h for the math and the phase functions.
+#include "dev_common.h"
+
+// Minimum waves per SIMD requested from the register allocator.  T = N/32
+// threads: N=2^13 -> 4 waves/WG, 2^14 -> 8, 2^15 -> 16 (=4 per SIMD already).
+// Default 2 => up to 256 VGPRs (no spills) for N <= 2^14.
+#ifndef HX_NTT_MINWAVES
+#define HX_NTT_MINWAVES(LOGN) ((LOGN) == 15 ? 4 : 2)
+#endif
+
+namespace hx {
+
+template <int LOGN, bool INV>
+__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
+ntt_row_kernel(uint64_t* __restrict__ data, RowMap map, int period, int row0, int batch,
+               const PrimeDev* __restrict__ primes)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  using R = RowNTT<LOGN>;
+  const unsigned tid = threadIdx.x;
+  const int row = row0 + (int)(blockIdx.x / (unsigned)batch);
+  const int b = (int)(blockIdx.x % (unsigned)batch);
+  const PrimeDev pd = primes[map.p[row % period]];
+  uint64_t* ptr = data + ((size_t)row * batch + b) * (size_t)Geo<LOGN>::N;
+  const TW* tw = INV ? pd.tw_inv : pd.tw_fwd;
+  const uint64_t q = pd.q;
+
+  uint64_t v[32];
+  uint32_t nl[32];
+  if constexpr (!INV) {
+    R::template fwd<0>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template fwd<1>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template fwd<2>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template fwd<3>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template fwd<4>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template fwd<5>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template fwd<6>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template fwd<7>(tid, v, nl, lds, ptr, ptr, tw, q);
+  } else {
+    R::template inv<0>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template inv<1>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template inv<2>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template inv<3>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template inv<4>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template inv<5>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template inv<6>(tid, v, nl, lds, ptr, ptr, tw, q);
+    __syncthreads();
+    R::template inv<7>(tid, v, nl, lds, ptr, ptr, tw, q);
+  }
+}
+
+template <int LOGN, bool INV>
+static hipError_t launch_one(uint64_t* data, const RowMap& map, int period, int row0, int nrows,
+                             int batch, const PrimeDev* primes, hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)ntt_row_kernel<LOGN, INV>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess)
+      return e;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)nrows * (unsigned)batch), block(Geo<LOGN>::T);
+  hipLaunchKernelGGL((ntt_row_kernel<LOGN, INV>), grid, block, lds_bytes, st, data, map, period,
+                     row0, batch, primes);
+  return hipGetLastError();
+}
+
+// entry point used by engine.hip
+hipError_t launch_ntt_pow2(int logn, bool inverse, uint64_t* data, const RowMap& map, int period,
+                           int row0, int nrows, int batch, const PrimeDev* primes, hipStream_t st)
+{
+  switch (logn) {
+    case 13:
+      return inverse ? launch_one<13, true>(data, map, period, row0, nrows, batch, primes, st)
+                     : launch_one<13, false>(data, map, period, row0, nrows, batch, primes, st);
+    case 14:
+      return inverse ? launch_one<14, true>(data, map, period, row0, nrows, batch, primes, st)
+                     : launch_one<14, false>(data, map, period, row0, nrows, batch, primes, st);
+    case 15:
+      return inverse ? launch_one<15, true>(data, map, period, row0, nrows, batch, primes, st)
+                     : launch_one<15, false>(data, map, period, row0, nrows, batch, primes, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace hx

@@ -1,0 +1,363 @@
+// rns_kernels.h -- element-wise DoubleCRT kernels and the exact RNS
+// basis-extension kernel (device side of addPrimes / breakIntoDigits /
+// scaleDownToSet).  Included by engine.hip only.
+#pragma once
+#include "dev_common.h"
+
+namespace hx {
+
+// =====================================================================
+// element-wise kernels: layout [row][batch][N]; grid = (chunks, rows)
+// Each thread handles 2 consecutive words (16-byte accesses) per step.
+// HBM-bound: 24 B/element (binary), 16 B/element (unary/scalar).
+// =====================================================================
+enum EwOp { EW_ADD = 0, EW_SUB = 1, EW_MUL = 2 };
+
+template <int OP>
+__global__ void __launch_bounds__(256)
+ew_binary_kernel(uint64_t* __restrict__ a, const uint64_t* __restrict__ b, RowMap2 map,
+                 size_t row_words /* batch*N */, size_t b_row_words, int b_broadcast, size_t n,
+                 const PrimeDev* __restrict__ primes)
+{
+  const int row = blockIdx.y;
+  const PrimeDev pd = primes[map.p[row]];
+  const uint64_t q = pd.q;
+  ulonglong2* pa = reinterpret_cast<ulonglong2*>(a + (size_t)row * row_words);
+  const uint64_t* pb_base = b + (size_t)map.brow[row] * b_row_words;
+  const size_t nvec = row_words / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (size_t)gridDim.x * blockDim.x) {
+    size_t bi = b_broadcast ? ((2 * i) % n) : (2 * i);
+    ulonglong2 x = pa[i];
+    ulonglong2 y = *reinterpret_cast<const ulonglong2*>(pb_base + bi);
+    if (OP == EW_ADD) {
+      x.x = add_mod(x.x, y.x, q);
+      x.y = add_mod(x.y, y.y, q);
+    } else if (OP == EW_SUB) {
+      x.x = sub_mod(x.x, y.x, q);
+      x.y = sub_mod(x.y, y.y, q);
+    } else {
+      x.x = mul_mod(x.x, y.x, q, pd.mu, pd.k);
+      x.y = mul_mod(x.y, y.y, q, pd.mu, pd.k);
+    }
+    pa[i] = x;
+  }
+}
+
+enum EwSOp { EWS_ADD = 0, EWS_SUB = 1, EWS_MUL = 2, EWS_NEG = 3 };
+
+template <int OP>
+__global__ void __launch_bounds__(256)
+ew_scalar_kernel(uint64_t* __restrict__ a, RowMap map, RowScalars sc, size_t row_words,
+                 const PrimeDev* __restrict__ primes)
+{
+  const int row = blockIdx.y;
+  const uint64_t q = primes[map.p[row]].q;
+  const uint64_t c = sc.c[row], cp = sc.cp[row];
+  ulonglong2* pa = reinterpret_cast<ulonglong2*>(a + (size_t)row * row_words);
+  const size_t nvec = row_words / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (size_t)gridDim.x * blockDim.x) {
+    ulonglong2 x = pa[i];
+    if (OP == EWS_ADD) {
+      x.x = add_mod(x.x, c, q);
+      x.y = add_mod(x.y, c, q);
+    } else if (OP == EWS_SUB) {
+      x.x = sub_mod(x.x, c, q);
+      x.y = sub_mod(x.y, c, q);
+    } else if (OP == EWS_MUL) {
+      x.x = mul_shoup(x.x, c, cp, q);
+      x.y = mul_shoup(x.y, c, cp, q);
+    } else {
+      x.x = neg_mod(x.x, q);
+      x.y = neg_mod(x.y, q);
+    }
+    pa[i] = x;
+  }
+}
+
+// automorph: out[row][b][j] = in[row][b][perm(j)], perm shared by all rows.
+// pow2 m: perm(j) = (((2j+1)*k mod m) - 1)/2 computed in registers;
+// general m: perm table built once per call by perm_kernel.
+__global__ void __launch_bounds__(256)
+perm_build_kernel(uint32_t* __restrict__ perm, const uint32_t* __restrict__ zms,
+                  const int32_t* __restrict__ zms_index, uint32_t phim, uint64_t m, uint64_t k)
+{
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < phim) {
+    uint64_t t = ((uint64_t)zms[j] * k) % m;
+    perm[j] = (uint32_t)zms_index[t];
+  }
+}
+__global__ void __launch_bounds__(256)
+gather_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ in,
+              const uint32_t* __restrict__ perm, uint32_t n, size_t nseg /* rows*batch */,
+              int pow2, uint64_t m, uint64_t k)
+{
+  const size_t seg = blockIdx.y;
+  const uint64_t* src = in + seg * n;
+  uint64_t* dst = out + seg * n;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    uint32_t s;
+    if (pow2)
+      s = (uint32_t)(((((uint64_t)(2 * j + 1)) * k) & (m - 1)) >> 1);
+    else
+      s = perm[j];
+    dst[j] = src[s];
+  }
+}
+
+// =====================================================================
+// Ctxt::tensorProduct for 2x2 parts, fused (src/Ctxt.cpp:1576-1597), with the
+// optional scalar of addPrimesAndScale (src/DoubleCRT.cpp:617-636) applied to
+// the parts that point at 1 and s (reLinearize, src/Ctxt.cpp:764-767).
+// 56 B/element instead of the reference's 5 separate passes (120 B/element).
+// =====================================================================
+__global__ void __launch_bounds__(256)
+tensor_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
+              const uint64_t* __restrict__ d0, const uint64_t* __restrict__ d1,
+              uint64_t* __restrict__ o0, uint64_t* __restrict__ o1, uint64_t* __restrict__ o2,
+              RowMap map, RowScalars sc, int scale, size_t row_words,
+              const PrimeDev* __restrict__ primes)
+{
+  const int row = blockIdx.y;
+  const PrimeDev pd = primes[map.p[row]];
+  const uint64_t q = pd.q, mu = pd.mu;
+  const uint32_t k = pd.k;
+  const uint64_t c = sc.c[row], cp = sc.cp[row];
+  const size_t off = (size_t)row * row_words;
+  const size_t nvec = row_words / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = off + 2 * i;
+    ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(c0 + e);
+    ulonglong2 a1 = *reinterpret_cast<const ulonglong2*>(c1 + e);
+    ulonglong2 b0 = *reinterpret_cast<const ulonglong2*>(d0 + e);
+    ulonglong2 b1 = *reinterpret_cast<const ulonglong2*>(d1 + e);
+    ulonglong2 r0, r1, r2;
+    r0.x = mul_mod(a0.x, b0.x, q, mu, k);
+    r0.y = mul_mod(a0.y, b0.y, q, mu, k);
+    r1.x = add_mod(mul_mod(a0.x, b1.x, q, mu, k), mul_mod(a1.x, b0.x, q, mu, k), q);
+    r1.y = add_mod(mul_mod(a0.y, b1.y, q, mu, k), mul_mod(a1.y, b0.y, q, mu, k), q);
+    r2.x = mul_mod(a1.x, b1.x, q, mu, k);
+    r2.y = mul_mod(a1.y, b1.y, q, mu, k);
+    if (scale) {
+      r0.x = mul_shoup(r0.x, c, cp, q);
+      r0.y = mul_shoup(r0.y, c, cp, q);
+      r1.x = mul_shoup(r1.x, c, cp, q);
+      r1.y = mul_shoup(r1.y, c, cp, q);
+    }
+    *reinterpret_cast<ulonglong2*>(o0 + e) = r0;
+    *reinterpret_cast<ulonglong2*>(o1 + e) = r1;
+    *reinterpret_cast<ulonglong2*>(o2 + e) = r2;
+  }
+}
+
+// =====================================================================
+// Ctxt::keySwitchDigits, fused over digits (src/Ctxt.cpp:204-229):
+//   out0[r] += sum_d dig[d][r] * kb[d][r] ; out1[r] += sum_d dig[d][r] * ka[d][r]
+// dig: [ndig][nall][batch][N]; kb/ka: [ndig][nall][N] (shared by the batch).
+// =====================================================================
+__global__ void __launch_bounds__(256)
+keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ kb,
+                 const uint64_t* __restrict__ ka, uint64_t* __restrict__ out0,
+                 uint64_t* __restrict__ out1, RowMap map, int ndig, int nall, int batch,
+                 uint32_t n, int accumulate_rows /* rows < this accumulate, others overwrite */,
+                 const PrimeDev* __restrict__ primes)
+{
+  const int row = blockIdx.y;
+  const PrimeDev pd = primes[map.p[row]];
+  const uint64_t q = pd.q, mu = pd.mu;
+  const uint32_t k = pd.k;
+  const size_t row_words = (size_t)batch * n;
+  const size_t nvec = row_words / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = 2 * i;            // within the row: b*n + j
+    const size_t j = e % n;            // coefficient index (pairs never straddle: n even)
+    ulonglong2 acc0, acc1;
+    if (row < accumulate_rows) {
+      acc0 = *reinterpret_cast<const ulonglong2*>(out0 + (size_t)row * row_words + e);
+      acc1 = *reinterpret_cast<const ulonglong2*>(out1 + (size_t)row * row_words + e);
+    } else {
+      acc0 = make_ulonglong2(0, 0);
+      acc1 = make_ulonglong2(0, 0);
+    }
+    for (int d = 0; d < ndig; d++) {
+      const size_t dr = (size_t)d * nall + row;
+      ulonglong2 x = *reinterpret_cast<const ulonglong2*>(dig + dr * row_words + e);
+      ulonglong2 b = *reinterpret_cast<const ulonglong2*>(kb + dr * n + j);
+      ulonglong2 a = *reinterpret_cast<const ulonglong2*>(ka + dr * n + j);
+      acc0.x = add_mod(acc0.x, mul_mod(x.x, b.x, q, mu, k), q);
+      acc0.y = add_mod(acc0.y, mul_mod(x.y, b.y, q, mu, k), q);
+      acc1.x = add_mod(acc1.x, mul_mod(x.x, a.x, q, mu, k), q);
+      acc1.y = add_mod(acc1.y, mul_mod(x.y, a.y, q, mu, k), q);
+    }
+    *reinterpret_cast<ulonglong2*>(out0 + (size_t)row * row_words + e) = acc0;
+    *reinterpret_cast<ulonglong2*>(out1 + (size_t)row * row_words + e) = acc1;
+  }
+}
+
+// =====================================================================
+// Exact RNS basis extension (device side of DoubleCRT::addPrimes,
+// breakIntoDigits and scaleDownToSet).  Per coefficient:
+//   1. Garner mixed-radix digits a_k of v = CRT(x_0..x_{n-1}) in [0,P)
+//   2. centred: neg = (v > (P-1)/2)  <=>  toPoly's "tmp >= prod_half"
+//      (src/DoubleCRT.cpp:1056-1059,1098-1099), compared digit-wise
+//   3. for every target prime t: (sum_k a_k*W[t][k] - neg*P) mod t
+// Integer-only and exact -- no floating-point quotient estimate (the
+// reference's double estimate at :1085-1096 is corrected to the same value).
+// Plan tables (uniform -> scalar loads), all uint64:
+// =====================================================================
+struct ExtPlanDev {
+  int n;                   // source primes
+  int nt;                  // target primes
+  const uint64_t* src_q;   // [n]
+  const uint64_t* src_mu64;  // [n]
+  const TW* ginv;          // [n*n]  ginv[k*n+l] = p_l^-1 mod p_k   (l<k)
+  const uint64_t* half;    // [n] mixed-radix digits of (P-1)/2
+  const uint64_t* tgt_q;   // [nt]
+  const uint64_t* tgt_mu64;  // [nt]
+  const uint64_t* tgt_mu;  // [nt]  Barrett mu (128-bit products)
+  const uint32_t* tgt_k;   // [nt]
+  const uint64_t* pmod;    // [nt]  P mod t
+  const TW* W;             // [nt*n] W[t*n+k] = (p_0..p_{k-1}) mod t
+  const TW* upd;           // [nt]  P^-1 mod t (Shoup) for the breakIntoDigits update
+  // BGV mod-switch correction (scaleDownToSet): ptxt = 0 disables
+  uint64_t ptxt, ptxt_mu64, pinv_ptxt /* P^-1 mod ptxt */, pmod_ptxt /* P mod ptxt */;
+  uint64_t ptxt_mu;  uint32_t ptxt_k;
+  const TW* Wp;            // [n] (p_0..p_{k-1}) mod ptxt
+};
+
+struct ExtArgs {
+  const uint64_t* src;       // coefficient rows, [row][batch][N]
+  uint64_t* dst;             // output rows,      [row][batch][N]
+  uint64_t* upd;             // rows updated in place (breakIntoDigits), may alias src
+  uint16_t src_row[64];      // row of source prime k inside src      (n <= 64)
+  uint16_t own_dst_row[64];  // where to copy the source residue in dst (0xffff: no copy)
+  uint16_t dst_row[MAX_ROWS];  // output row of target t inside dst
+  uint16_t upd_row[MAX_ROWS];  // row inside upd to update (0xffff: none)
+};
+
+template <int NMAX>
+__global__ void __launch_bounds__(256)
+rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= row_words)
+    return;
+  const int n = P.n;
+  uint64_t a[NMAX];
+  // ---- load + Garner ----
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) {
+    if (k < n) {
+      uint64_t x = A.src[(size_t)A.src_row[k] * row_words + i];
+      if (A.own_dst_row[k] != 0xffff)
+        A.dst[(size_t)A.own_dst_row[k] * row_words + i] = x;
+      const uint64_t pk = P.src_q[k], mk = P.src_mu64[k];
+#pragma unroll
+      for (int l = 0; l < NMAX; l++) {
+        if (l < k) {
+          uint64_t al = red64(a[l], pk, mk);
+          uint64_t d = sub_mod(x, al, pk);
+          TW g = P.ginv[k * n + l];
+          x = mul_shoup(d, g.w, g.wp, pk);
+        }
+      }
+      a[k] = x;
+    }
+  }
+  // ---- centring: v > (P-1)/2 by mixed-radix comparison, top digit first ----
+  int cmp = 0;  // sign of (v - half)
+#pragma unroll
+  for (int k = NMAX - 1; k >= 0; k--) {
+    if (k < n && cmp == 0) {
+      uint64_t h = P.half[k];
+      cmp = a[k] > h ? 1 : (a[k] < h ? -1 : 0);
+    }
+  }
+  const bool neg = cmp > 0;
+
+  // ---- BGV: make delta divisible by ptxtSpace (src/DoubleCRT.cpp:1485-1508) ----
+  bool dm_nonzero = false, dm_negative = false;
+  uint64_t dm_abs = 0;
+  if (P.ptxt > 1) {
+    const uint64_t p = P.ptxt;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NMAX; k++) {
+      if (k < n) {
+        TW w = P.Wp[k];
+        acc += shoup_lazy(a[k], w, p);  // each < 2p
+        if ((k & 3) == 3)
+          acc = red64(acc, p, P.ptxt_mu64);
+      }
+    }
+    uint64_t r = red64(acc, p, P.ptxt_mu64);
+    if (neg)
+      r = sub_mod(r, P.pmod_ptxt, p);  // delta mod p, non-negative (NTL rem)
+    if (r != 0) {
+      uint64_t dm = mul_mod(r, P.pinv_ptxt, p, P.ptxt_mu, P.ptxt_k);
+      const uint64_t p_over_2 = p >> 1;
+      bool sub_p = dm > p_over_2 || (((p & 1) == 0) && dm == p_over_2 && neg);
+      dm_nonzero = true;
+      dm_negative = sub_p;
+      dm_abs = sub_p ? p - dm : dm;  // |delta_i_modP| after balancing
+    }
+  }
+
+  // ---- residues modulo every target prime ----
+  for (int t = 0; t < P.nt; t++) {
+    const uint64_t q = P.tgt_q[t], mu64 = P.tgt_mu64[t];
+    const TW* Wt = P.W + (size_t)t * n;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NMAX; k++) {
+      if (k < n) {
+        acc += shoup_lazy(a[k], Wt[k], q);  // each < 2q < 2^61 (q < 2^60)
+        if ((k & 3) == 3)
+          acc = red64(acc, q, mu64);
+      }
+    }
+    uint64_t r = red64(acc, q, mu64);
+    if (neg)
+      r = sub_mod(r, P.pmod[t], q);
+    if (dm_nonzero) {
+      // delta -= diffProd * delta_i_modP
+      uint64_t d = red64(dm_abs, q, mu64);
+      uint64_t corr = mul_mod(P.pmod[t], d, q, P.tgt_mu[t], P.tgt_k[t]);
+      r = dm_negative ? add_mod(r, corr, q) : sub_mod(r, corr, q);
+    }
+    if (A.dst_row[t] != 0xffff)
+      A.dst[(size_t)A.dst_row[t] * row_words + i] = r;
+    if (A.upd_row[t] != 0xffff) {
+      // digits[j] -= digits[i]; digits[j] /= pi   (src/DoubleCRT.cpp:552-556)
+      uint64_t* u = A.upd + (size_t)A.upd_row[t] * row_words + i;
+      TW pinv = P.upd[t];
+      *u = mul_shoup(sub_mod(*u, r, q), pinv.w, pinv.wp, q);
+    }
+  }
+}
+
+// (x - y) * c per row: the tail of scaleDownToSet (*this -= delta; *this /= diffProd)
+__global__ void __launch_bounds__(256)
+sub_scale_kernel(uint64_t* __restrict__ a, const uint64_t* __restrict__ b, RowMap2 map,
+                 RowScalars sc, size_t row_words, const PrimeDev* __restrict__ primes)
+{
+  const int row = blockIdx.y;
+  const uint64_t q = primes[map.p[row]].q;
+  const uint64_t c = sc.c[row], cp = sc.cp[row];
+  ulonglong2* pa = reinterpret_cast<ulonglong2*>(a + (size_t)row * row_words);
+  const ulonglong2* pb = reinterpret_cast<const ulonglong2*>(b + (size_t)map.brow[row] * row_words);
+  const size_t nvec = row_words / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (size_t)gridDim.x * blockDim.x) {
+    ulonglong2 x = pa[i], y = pb[i];
+    x.x = mul_shoup(sub_mod(x.x, y.x, q), c, cp, q);
+    x.y = mul_shoup(sub_mod(x.y, y.y, q), c, cp, q);
+    pa[i] = x;
+  }
+}
+
+}  // namespace hx

@@ -1,0 +1,198 @@
+/*
+ * helib_amd.h -- C ABI of the MI355X-native DoubleCRT engine.
+ *
+ * This is the drop-in boundary for HElib 2.2.0's polynomial-arithmetic hot
+ * path.  It replaces, one level above HElib's own accelerator seam (the
+ * `intel::` HEXL shim, src/intelExt.h:20-59), the following reference
+ * interfaces; each entry point below names the one it stands in for:
+ *
+ *   Cmodulus  ctor / FFT / iFFT        include/helib/CModulus.h:112-145
+ *   DoubleCRT storage + ring ops       include/helib/DoubleCRT.h:212-385
+ *   DoubleCRT::breakIntoDigits         src/DoubleCRT.cpp:479-561
+ *   DoubleCRT::addPrimes / AndScale    src/DoubleCRT.cpp:565-647
+ *   DoubleCRT::scaleDownToSet          src/DoubleCRT.cpp:1464-1516
+ *   Ctxt::tensorProduct inner loop     src/Ctxt.cpp:1576-1597
+ *   Ctxt::keySwitchDigits              src/Ctxt.cpp:191-230
+ *   intel::FFTFwd/FFTRev1/Eltwise*     src/intelExt.h:20-59 (compat layer)
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw pointers, sizes.  No exceptions cross the
+ *     ABI: every call returns HX_OK (0) or a negative hx_status; the message
+ *     of the last failure on the calling thread is hx_last_error().
+ *   - a `hx_poly` is a BATCH of `batch` independent DoubleCRT objects that
+ *     share one prime set: device layout [row][batch][phi(m)] of uint64
+ *     residues in [0, q_row), row r holding prime `prime_idx[r]`
+ *     (HElib: IndexMap<vec_long>, one heap vector per prime,
+ *     include/helib/DoubleCRT.h:87-95).  batch = 1 is a single DoubleCRT.
+ *   - host buffers passed to upload/download use the same [row][batch][N]
+ *     order and are owned by the caller; device memory is owned by the
+ *     library unless the poly was created with hx_poly_wrap.
+ *   - all work of a context is enqueued on one HIP stream (settable); calls
+ *     are asynchronous with respect to the host except upload/download/sync.
+ *   - calls on distinct contexts are thread-safe; a context is not.
+ *   - results are bit-identical to reference HElib's DoubleCRT rows for the
+ *     same (q, root) -- values are canonical residues, there is no rounding.
+ *   - the library never falls back to the CPU: without a usable gfx950 device
+ *     every compute entry point fails with HX_ERR_DEVICE.
+ */
+#ifndef HELIB_AMD_H
+#define HELIB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hx_ctx hx_ctx;   /* Context (prime chain) + PAlgebra bits used by the path */
+typedef struct hx_poly hx_poly; /* batched DoubleCRT                                         */
+typedef struct hx_ksk hx_ksk;   /* one KeySwitch matrix resident on the device               */
+
+typedef enum {
+  HX_OK = 0,
+  HX_ERR_INVALID = -1,     /* bad argument (helib::InvalidArgument)                       */
+  HX_ERR_DEVICE = -2,      /* HIP error / no gfx950 device                                  */
+  HX_ERR_PRIMESET = -3,    /* index-set mismatch (helib::RuntimeError, DoubleCRT.cpp:243-253)*/
+  HX_ERR_NOT_IN_ZMSTAR = -4, /* automorph: k not in Zm* (DoubleCRT.cpp:1166-1167)          */
+  HX_ERR_UNSUPPORTED = -5, /* shape not supported by this build                             */
+  HX_ERR_NOMEM = -6
+} hx_status;
+
+const char* hx_last_error(void);
+const char* hx_version(void);
+int hx_device_count(int* count);
+
+/* ---------------- context: Context::moduli + zMStar ---------------- */
+/* m > 1.  Builds the Z_m^* tables (PAlgebra, src/PAlgebra.cpp:532-538). */
+int hx_ctx_create(hx_ctx** out, int device, uint64_t m);
+int hx_ctx_destroy(hx_ctx* ctx);
+int hx_ctx_phim(const hx_ctx* ctx, uint64_t* phim);
+/* stream: a hipStream_t (void*); NULL = the device's default stream. */
+int hx_ctx_set_stream(hx_ctx* ctx, void* hip_stream);
+int hx_ctx_sync(hx_ctx* ctx);
+/* Cmodulus::Cmodulus(zms, q, rt) (src/CModulus.cpp:64-181).
+ * root: m = 2^k  -> w0 = NTL RootTable[0][k], a primitive m-th root of unity
+ *                   mod q; it is an INPUT because it only exists inside NTL's
+ *                   seeded PRG (src/CModulus.cpp:93-119).  root = 0 selects
+ *                   FindPrimRootT(q, m) (src/NumbTh.cpp:436-493).
+ *       general m -> the FindPrimitiveRoot output of order 2m (m even) / m
+ *                   (m odd); 0 = compute it exactly as the reference does.
+ * idx_out: position in Context::moduli order (0,1,2,...).                 */
+int hx_ctx_add_prime(hx_ctx* ctx, uint64_t q, uint64_t root, int* idx_out);
+int hx_ctx_num_primes(const hx_ctx* ctx, int* n);
+int hx_ctx_prime(const hx_ctx* ctx, int idx, uint64_t* q, uint64_t* root);
+
+/* ---------------- DoubleCRT storage ---------------- */
+/* DoubleCRT(context, indexSet): zero-initialised rows for primes prime_idx[]. */
+int hx_poly_create(hx_ctx* ctx, int batch, const int* prime_idx, int nrows, hx_poly** out);
+/* Same, on caller-owned device memory (e.g. a torch tensor's data_ptr) of
+ * nrows*batch*phim uint64; not zeroed, never freed by the library. */
+int hx_poly_wrap(hx_ctx* ctx, int batch, const int* prime_idx, int nrows, void* device_ptr,
+                 hx_poly** out);
+int hx_poly_destroy(hx_poly* p);
+int hx_poly_shape(const hx_poly* p, int* batch, int* nrows, uint64_t* phim);
+int hx_poly_primes(const hx_poly* p, int* prime_idx_out /* nrows */);
+void* hx_poly_device_ptr(hx_poly* p);
+int hx_poly_upload(hx_poly* p, const uint64_t* host);         /* synchronous */
+int hx_poly_download(const hx_poly* p, uint64_t* host);       /* synchronous */
+/* DoubleCRT::operator= (src/DoubleCRT.cpp:815-837): dst takes src's prime set
+ * (dst capacity must be >= src rows). */
+int hx_poly_copy(hx_poly* dst, const hx_poly* src);
+int hx_poly_set_zero(hx_poly* p);
+/* DoubleCRT::removePrimes: metadata only (rows are compacted on the device). */
+int hx_poly_remove_primes(hx_poly* p, const int* prime_idx, int n);
+
+/* ---------------- Cmodulus::FFT / iFFT over all rows ---------------- */
+/* In place: coefficient rows (deg < phim, reduced mod q) <-> evaluation rows
+ * at the primitive m-th roots, natural (Z_m^*) order.
+ * src/CModulus.cpp:358-444 / :486-578 ; DoubleCRT::FFT src/DoubleCRT.cpp:68-105 */
+int hx_ntt_forward(hx_poly* p);
+int hx_ntt_inverse(hx_poly* p);
+
+/* ---------------- DoubleCRT element-wise ring ops ---------------- */
+/* a op= b on the rows of a; requires primes(a) subset of primes(b), otherwise
+ * HX_ERR_PRIMESET (DoubleCRT::Op, src/DoubleCRT.cpp:216-273, do_mul :278-337).
+ * batch(b) must equal batch(a) or be 1 (broadcast). */
+int hx_add(hx_poly* a, const hx_poly* b);
+int hx_sub(hx_poly* a, const hx_poly* b);
+int hx_mul(hx_poly* a, const hx_poly* b);
+int hx_negate(hx_poly* a); /* DoubleCRT::Negate src/DoubleCRT.cpp:363-384 */
+/* a op= scalar, scalar given per row already reduced mod that row's prime
+ * (DoubleCRT::Op(ZZ) src/DoubleCRT.cpp:339-361). */
+int hx_add_scalar(hx_poly* a, const uint64_t* c_per_row);
+int hx_sub_scalar(hx_poly* a, const uint64_t* c_per_row);
+int hx_mul_scalar(hx_poly* a, const uint64_t* c_per_row);
+/* DoubleCRT::automorph(k) (src/DoubleCRT.cpp:1160-1202); in place. */
+int hx_automorph(hx_poly* a, uint64_t k);
+/* DoubleCRT::complexConj (src/DoubleCRT.cpp:1240-1255) */
+int hx_complex_conj(hx_poly* a);
+
+/* ---------------- exact RNS basis operations ---------------- */
+/* DoubleCRT::addPrimesAndScale (src/DoubleCRT.cpp:603-647): multiply rows by
+ * prod(add_idx) and append zero rows for add_idx (capacity permitting). */
+int hx_add_primes_and_scale(hx_poly* a, const int* add_idx, int nadd);
+/* DoubleCRT::addPrimes (src/DoubleCRT.cpp:565-599): exact centred extension of
+ * the RNS basis by add_idx (toPoly + FFT on the new primes), in place. */
+int hx_add_primes(hx_poly* a, const int* add_idx, int nadd);
+/* DoubleCRT::scaleDownToSet (src/DoubleCRT.cpp:1464-1516): drop drop_idx with
+ * exact rounding, delta forced to 0 mod ptxt_space.  In place. */
+int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_t ptxt_space);
+/* DoubleCRT::breakIntoDigits (src/DoubleCRT.cpp:479-561).  a has ctxt primes
+ * only; digit d = dig_idx[dig_off[d]..dig_off[d+1]); special primes sp_idx.
+ * digits_out: poly with ndig*(nrows(a)+nsp) rows, block d holding digit d on
+ * primes(a) followed by sp_idx. */
+int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const int* dig_off, int ndig,
+                         const int* sp_idx, int nsp, hx_poly* digits_out);
+
+/* ---------------- ciphertext-level fused loops ---------------- */
+/* KeySwitch matrix W (include/helib/keySwitching.h:86-101) with the a-column
+ * expanded once by the host (HElib regenerates it from W.prgSeed on every key
+ * switch, src/Ctxt.cpp:196-206).  b, a: host arrays [ndig][nrows][phim] on
+ * primes row_idx[nrows] (ctxt primes followed by special primes). */
+int hx_ksk_create(hx_ctx* ctx, int ndig, const int* row_idx, int nrows, const uint64_t* b,
+                  const uint64_t* a, hx_ksk** out);
+int hx_ksk_destroy(hx_ksk* k);
+
+/* Ctxt::tensorProduct for two 2-part ciphertexts (src/Ctxt.cpp:1576-1597):
+ * o0 = c0*d0, o1 = c0*d1 + c1*d0, o2 = c1*d1. */
+int hx_tensor(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1,
+              hx_poly* o0, hx_poly* o1, hx_poly* o2);
+/* Ctxt::keySwitchDigits (src/Ctxt.cpp:191-230):
+ * out0 += sum_d digit_d*b_d ; out1 += sum_d digit_d*a_d */
+int hx_key_switch_digits(const hx_poly* digits, const hx_ksk* W, hx_poly* out0, hx_poly* out1);
+
+/* Ctxt::multiplyBy data path at a fixed level: tensorProduct + reLinearize
+ * (src/Ctxt.cpp:1563-1608, :720-842).  Inputs: 2-part ciphertexts (c0,c1),
+ * (d0,d1) on the same ctxt primes; outputs (out0,out1) on ctxt ∪ special
+ * primes (W's row set), exactly what reLinearize leaves in the Ctxt.
+ * Digits as in hx_break_into_digits. */
+int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1,
+                 const hx_ksk* W, const int* dig_idx, const int* dig_off, int ndig,
+                 hx_poly* out0, hx_poly* out1);
+
+/* ---------------- HEXL-shim compatibility layer ---------------- */
+/* Same signatures and semantics as namespace intel (src/intelExt.h:20-59):
+ * host pointers, synchronous, in-place allowed, negacyclic NTT whose root is
+ * the shim's own choice (as with HEXL): here
+ * FindPrimRootT(q, 2n).  One PCIe round trip per call -- provided for link
+ * compatibility of a USE_INTEL_HEXL-style build, not for speed. */
+int hx_intel_FFTFwd(long* out, const long* in, long n, long q);
+int hx_intel_FFTRev1(long* out, const long* in, long n, long q);
+int hx_intel_EltwiseAddMod(long* r, const long* a, const long* b, long n, long q);
+int hx_intel_EltwiseAddModScalar(long* r, const long* a, long scalar, long n, long q);
+int hx_intel_EltwiseSubMod(long* r, const long* a, const long* b, long n, long q);
+int hx_intel_EltwiseSubModScalar(long* r, const long* a, long scalar, long n, long q);
+int hx_intel_EltwiseMultMod(long* r, const long* a, const long* b, long n, long q);
+int hx_intel_EltwiseMultModScalar(long* r, const long* a, long scalar, long n, long q);
+
+/* ---------------- measurement helpers ---------------- */
+/* Runs `iters` back-to-back launches of the forward (dir=0) or inverse (dir=1)
+ * NTT kernel on p between two HIP events recorded on the context's stream and
+ * returns the average kernel time in milliseconds (bench.py roofline leg). */
+int hx_time_ntt(hx_poly* p, int dir, int iters, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELIB_AMD_H */

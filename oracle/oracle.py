@@ -29,7 +29,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        so = os.environ.get("HX_ORACLE_SO") or os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             so = build()
         L = C.CDLL(so)

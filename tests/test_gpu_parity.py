@@ -1,0 +1,343 @@
+"""GPU parity tests: the HIP path (through the C ABI, include/helib_amd.h) against the
+CPU oracle on the same seeded inputs.  Bit-exact: every word is compared.
+Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hx():
+    from helib_amd import capi
+    assert capi.device_count() > 0, "no HIP device: the GPU tests must run on an MI355X"
+    return capi
+
+
+class Pair:
+    """A device context and an oracle context with the same primes/roots."""
+
+    def __init__(self, hx, m, primes):
+        self.hx = hx
+        self.g = hx.Context(m)
+        self.o = O.Ctx(m)
+        for q in primes:
+            i = self.o.add_prime(q)
+            j = self.g.add_prime(q, self.o.roots[i])   # host supplies the root (fact 4)
+            assert i == j
+        self.N = self.o.N
+        self.primes = list(primes)
+
+    def rand(self, idx, seed, batch=1):
+        """[nrows, batch, N] uniform residues"""
+        out = np.zeros((len(idx), batch, self.N), dtype=np.uint64)
+        for r, i in enumerate(idx):
+            for b in range(batch):
+                out[r, b] = O.fill_uniform(self.N, self.primes[i], seed * 100003 + i * 131 + b)
+        return out
+
+
+def primes_for(m, n, bits=60):
+    g = O.PrimeGen(bits, m)
+    return [g.next() for _ in range(n)]
+
+
+# ---------------------------------------------------------------- config 1: fft_bench
+@pytest.mark.parametrize("m", [16384, 32768, 65536])
+def test_ntt_single_prime_like_fft_bench(hx, m):
+    # benchmarks/fft_bench.cpp:24-73: one 49-bit prime, forward on random / monomial,
+    # inverse on y[i] = i
+    q = O.PrimeGen(49, m).next()
+    P = Pair(hx, m, [q])
+    N = P.N
+    x = P.rand([0], 1)
+    d = hx.DoubleCRT(P.g, [0], 1, x)
+    got = d.FFT().download()
+    assert np.array_equal(got[0, 0], P.o.fft([0], x[:, 0])[0])
+    assert np.array_equal(d.iFFT().download(), x)
+    mono = np.zeros((1, 1, N), dtype=np.uint64)
+    mono[0, 0, N - 1] = 1
+    d.upload(mono)
+    assert np.array_equal(d.FFT().download()[0, 0], P.o.fft([0], mono[:, 0])[0])
+    y = (np.arange(N, dtype=np.uint64) % np.uint64(q)).reshape(1, 1, N)
+    d.upload(y)
+    assert np.array_equal(d.iFFT().download()[0, 0], P.o.ifft([0], y[:, 0])[0])
+
+
+@pytest.mark.parametrize("m,L,batch", [(32768, 16, 3), (16384, 5, 2), (65536, 4, 2)])
+def test_ntt_doublecrt_batched(hx, m, L, batch):
+    P = Pair(hx, m, primes_for(m, L))
+    idx = list(range(L))
+    x = P.rand(idx, 7, batch)
+    d = hx.DoubleCRT(P.g, idx, batch, x)
+    got = d.FFT().download()
+    for b in range(batch):
+        assert np.array_equal(got[:, b], P.o.fft(idx, x[:, b]))
+    back = d.iFFT().download()
+    assert np.array_equal(back, x)
+
+
+def test_ntt_edge_values(hx):
+    m = 32768
+    P = Pair(hx, m, primes_for(m, 2))
+    q0, q1 = P.primes
+    x = np.zeros((2, 1, P.N), dtype=np.uint64)
+    x[0, 0, :] = q0 - 1          # maximal residues
+    x[1, 0, ::2] = q1 - 1
+    d = hx.DoubleCRT(P.g, [0, 1], 1, x)
+    assert np.array_equal(d.FFT().download()[:, 0], P.o.fft([0, 1], x[:, 0]))
+    z = np.zeros_like(x)
+    d.upload(z)
+    assert not d.FFT().download().any()
+
+
+# ---------------------------------------------------------------- config 2: add / mul
+def test_doublecrt_add_mul_m32768_L16(hx):
+    m, L = 32768, 16
+    P = Pair(hx, m, primes_for(m, L))
+    idx = list(range(L))
+    a, b = P.rand(idx, 1), P.rand(idx, 2)
+    da, db = hx.DoubleCRT(P.g, idx, 1, a), hx.DoubleCRT(P.g, idx, 1, b)
+    da += db
+    want = np.stack([O.row_op("add", a[r, 0], b[r, 0], P.primes[r]) for r in idx])
+    assert np.array_equal(da.download()[:, 0], want)
+    da *= db
+    want = np.stack([O.row_op("mul", want[r], b[r, 0], P.primes[r]) for r in idx])
+    assert np.array_equal(da.download()[:, 0], want)
+    da -= db
+    want = np.stack([O.row_op("sub", want[r], b[r, 0], P.primes[r]) for r in idx])
+    assert np.array_equal(da.download()[:, 0], want)
+    da.Negate()
+    want = np.stack([O.row_op("neg", want[r], None, P.primes[r]) for r in idx])
+    assert np.array_equal(da.download()[:, 0], want)
+
+
+def test_elementwise_subset_broadcast_and_scalars(hx):
+    m = 16384
+    P = Pair(hx, m, primes_for(m, 5))
+    a = P.rand([1, 3], 4, batch=3)
+    b = P.rand([0, 1, 2, 3], 5, batch=1)          # superset, broadcast over the batch
+    da = hx.DoubleCRT(P.g, [1, 3], 3, a)
+    db = hx.DoubleCRT(P.g, [0, 1, 2, 3], 1, b)
+    da *= db
+    for r, (pi, br) in enumerate([(1, 1), (3, 3)]):
+        for bb in range(3):
+            assert np.array_equal(da.download()[r, bb],
+                                  O.row_op("mul", a[r, bb], b[br, 0], P.primes[pi]))
+    cur = da.download()
+    big = (1 << 200) + 12345
+    da.mulConstant(big)
+    da.addConstant(7)
+    da.subConstant(big)
+    got = da.download()
+    for r, pi in enumerate([1, 3]):
+        q = P.primes[pi]
+        for bb in range(3):
+            w = O.row_op("mul_scalar", cur[r, bb], big % q, q)
+            w = O.row_op("add_scalar", w, 7, q)
+            w = O.row_op("sub_scalar", w, big % q, q)
+            assert np.array_equal(got[r, bb], w)
+    # DoubleCRT::Op throws when this.set is not a subset of other.set
+    dc = hx.DoubleCRT(P.g, [1, 4], 3)
+    with pytest.raises(hx.HxError) as ei:
+        dc += db
+    assert ei.value.code == hx.HX_ERR_PRIMESET
+
+
+@pytest.mark.parametrize("m,k", [(32768, 3), (32768, 32767), (16384, 5 * 5 * 5)])
+def test_automorph_pow2(hx, m, k):
+    P = Pair(hx, m, primes_for(m, 3))
+    idx = [0, 1, 2]
+    a = P.rand(idx, 9, batch=2)
+    d = hx.DoubleCRT(P.g, idx, 2, a)
+    got = d.automorph(k).download()
+    zms = O.zmstar(m)
+    for r in idx:
+        for b in range(2):
+            assert np.array_equal(got[r, b], O.automorph(a[r, b], m, zms, k))
+    with pytest.raises(hx.HxError) as ei:
+        d.automorph(4)
+    assert ei.value.code == hx.HX_ERR_NOT_IN_ZMSTAR
+    # complexConj == row reversal (src/DoubleCRT.cpp:1240-1255)
+    d.upload(a)
+    assert np.array_equal(d.complexConj().download(), a[:, :, ::-1])
+
+
+# ---------------------------------------------------------------- exact RNS pieces
+def setup_rns(hx, m=16384, L=5, K=2, bits=60):
+    P = Pair(hx, m, primes_for(m, L + K, bits))
+    own, sp = list(range(L)), list(range(L, L + K))
+    return P, own, sp
+
+
+def test_add_primes_and_scale_and_add_primes(hx):
+    P, own, sp = setup_rns(hx)
+    a = P.rand(own, 3, batch=2)
+    d = hx.DoubleCRT(P.g, own, 2, a)
+    d.addPrimesAndScale(sp)
+    got = d.download()
+    assert d.getIndexSet() == own + sp
+    for b in range(2):
+        assert np.array_equal(got[:len(own), b], P.o.scale_by_primes(own, a[:, b], sp))
+    assert not got[len(own):].any()
+    d2 = hx.DoubleCRT(P.g, own[:3], 2, a[:3])
+    d2.addPrimes([3, 5])
+    got = d2.download()
+    assert d2.getIndexSet() == [0, 1, 2, 3, 5]
+    for b in range(2):
+        assert np.array_equal(got[:3, b], a[:3, b])
+        assert np.array_equal(got[3:, b], P.o.add_primes(own[:3], a[:3, b], [3, 5]))
+    with pytest.raises(hx.HxError):
+        d2.addPrimes([1])
+
+
+@pytest.mark.parametrize("ptxt", [65537, 2, 1, 4])
+def test_scale_down_to_set(hx, ptxt):
+    P, own, sp = setup_rns(hx, L=5, K=2)
+    allp = own + sp
+    a = P.rand(allp, 5, batch=2)
+    d = hx.DoubleCRT(P.g, allp, 2, a)
+    d.scaleDownToSet(own, ptxt)             # drop the special primes
+    got = d.download()
+    assert d.getIndexSet() == own
+    for b in range(2):
+        assert np.array_equal(got[:, b], P.o.scale_down(allp, a[:, b], sp, ptxt))
+    # dropping ctxt primes from the middle
+    d = hx.DoubleCRT(P.g, own, 1, a[:5, :1])
+    d.scaleDownToSet([0, 2, 4], ptxt)
+    assert np.array_equal(d.download()[:, 0], P.o.scale_down(own, a[:5, 0], [1, 3], ptxt))
+
+
+@pytest.mark.parametrize("digits", [[[0, 1], [2, 3], [4]], [[0, 1, 2, 3, 4]], [[0], [1], [2], [3], [4]]])
+def test_break_into_digits(hx, digits):
+    P, own, sp = setup_rns(hx)
+    a = P.rand(own, 6, batch=2)
+    d = hx.DoubleCRT(P.g, own, 2, a)
+    dg = d.breakIntoDigits(digits, sp)
+    got = dg.download()                      # [ndig*nall, batch, N]
+    nall = len(own) + len(sp)
+    for b in range(2):
+        want = P.o.break_into_digits(own, a[:, b], digits, own + sp)
+        assert np.array_equal(got[:, b].reshape(len(digits), nall, P.N), want)
+
+
+def test_tensor_and_keyswitch(hx):
+    P, own, sp = setup_rns(hx)
+    allp = own + sp
+    c0, c1, d0, d1 = (P.rand(own, s, batch=2) for s in (1, 2, 3, 4))
+    G = [hx.DoubleCRT(P.g, own, 2, x) for x in (c0, c1, d0, d1)]
+    t = hx.tensorProduct(*G)
+    for b in range(2):
+        w = P.o.tensor(own, c0[:, b], c1[:, b], d0[:, b], d1[:, b])
+        for i in range(3):
+            assert np.array_equal(t[i].download()[:, b], w[i])
+    digits = [[0, 1], [2, 3], [4]]
+    kb = np.stack([P.rand(allp, 20 + i)[:, 0] for i in range(3)])
+    ka = np.stack([P.rand(allp, 30 + i)[:, 0] for i in range(3)])
+    W = hx.KeySwitch(P.g, allp, kb, ka)
+    dg = t[2].breakIntoDigits(digits, sp)
+    o0 = hx.DoubleCRT(P.g, allp, 2, P.rand(allp, 40, 2))
+    o1 = hx.DoubleCRT(P.g, allp, 2, P.rand(allp, 41, 2))
+    i0, i1 = o0.download(), o1.download()
+    hx.keySwitchDigits(dg, W, o0, o1)
+    g0, g1 = o0.download(), o1.download()
+    dgh = dg.download()
+    for b in range(2):
+        w0, w1 = P.o.key_switch_digits(allp, dgh[:, b].reshape(3, len(allp), P.N), kb, ka,
+                                       i0[:, b], i1[:, b])
+        assert np.array_equal(g0[:, b], w0) and np.array_equal(g1[:, b], w1)
+
+
+@pytest.mark.parametrize("m,L,K,digits,batch", [
+    (16384, 5, 2, [[0, 1], [2, 3], [4]], 2),
+    # BASELINE config 3 shape: m=32768, L=16 x 60-bit, K=6 x 56-bit, D=3 (6/5/5)
+    (32768, 16, 6, [list(range(0, 6)), list(range(6, 11)), list(range(11, 16))], 1),
+])
+def test_multiply_relin_matches_oracle(hx, m, L, K, digits, batch):
+    g = O.PrimeGen(60, m)
+    primes = [g.next() for _ in range(L)]
+    g2 = O.PrimeGen(56, m)
+    primes += [g2.next() for _ in range(K)]
+    P = Pair(hx, m, primes)
+    own, sp = list(range(L)), list(range(L, L + K))
+    allp = own + sp
+    c0, c1, d0, d1 = (P.rand(own, s, batch) for s in (1, 2, 3, 4))
+    D = len(digits)
+    kb = np.stack([P.rand(allp, 20 + i)[:, 0] for i in range(D)])
+    ka = np.stack([P.rand(allp, 30 + i)[:, 0] for i in range(D)])
+    W = hx.KeySwitch(P.g, allp, kb, ka)
+    G = [hx.DoubleCRT(P.g, own, batch, x) for x in (c0, c1, d0, d1)]
+    o0, o1 = hx.multiplyBy(*G, W, digits)
+    g0, g1 = o0.download(), o1.download()
+    assert o0.getIndexSet() == allp
+    for b in range(batch):
+        w0, w1 = P.o.mul_relin(own, sp, digits, c0[:, b], c1[:, b], d0[:, b], d1[:, b], kb, ka)
+        assert np.array_equal(g0[:, b], w0)
+        assert np.array_equal(g1[:, b], w1)
+
+
+def test_bgv_multiply_decrypts_on_gpu(hx):
+    """decrypt(multiplyBy(enc a, enc b)) == a*b, with the multiply + mod-down on the GPU
+    (tests/TestHEXL.cpp:158-187 style)."""
+    from tests import bgv_ref as B
+    m, p = 16384, 65537
+    L, K = 5, 2
+    digits = [[0, 1], [2, 3], [4]]
+    P = Pair(hx, m, primes_for(m, L + K, 60))
+    bp = B.Params(m, p, L, K, digits, ctx=P.o)
+    s = B.keygen(bp)
+    rng = np.random.default_rng(3)
+    ma, mb = rng.integers(0, p, size=P.N), rng.integers(0, p, size=P.N)
+    c0, c1 = B.encrypt(bp, s, ma, 1)
+    d0, d1 = B.encrypt(bp, s, mb, 2)
+    kb, ka = B.gen_ksk(bp, s)
+    W = hx.KeySwitch(P.g, bp.all, kb, ka)
+    G = [hx.DoubleCRT(P.g, bp.own, 1, x[:, None, :]) for x in (c0, c1, d0, d1)]
+    o0, o1 = hx.multiplyBy(*G, W, digits)
+    o0.scaleDownToSet(bp.own, p)
+    o1.scaleDownToSet(bp.own, p)
+    got, _ = B.decrypt(bp, s, o0.download()[:, 0], o1.download()[:, 0], bp.own)
+    # negacyclic product of the plaintexts mod p
+    want = np.zeros(P.N, dtype=object)
+    fa = np.array([int(v) for v in ma], dtype=object)
+    # use the oracle transform mod a big prime to multiply exactly, then reduce mod p
+    q = P.primes[0]
+    ea = P.o.fft([0], np.array([ma % q], dtype=np.uint64))
+    eb = P.o.fft([0], np.array([mb % q], dtype=np.uint64))
+    prod = P.o.ifft([0], np.array([O.row_op("mul", ea[0], eb[0], q)]))[0]
+    want = [int(v) - q if int(v) > q // 2 else int(v) for v in prod]
+    assert got == [w % p for w in want]
+
+
+# ---------------------------------------------------------------- full-size properties
+def test_full_size_properties_m32768(hx):
+    """size-independent properties at BASELINE size with a batch: round trip, linearity,
+    convolution theorem."""
+    m, L, batch = 32768, 16, 8
+    P = Pair(hx, m, primes_for(m, L))
+    idx = list(range(L))
+    a, b = P.rand(idx, 1, batch), P.rand(idx, 2, batch)
+    da, db = hx.DoubleCRT(P.g, idx, batch, a), hx.DoubleCRT(P.g, idx, batch, b)
+    s = da.copy()
+    s += db
+    s.FFT()
+    da.FFT()
+    db.FFT()
+    t = da.copy()
+    t += db
+    assert np.array_equal(s.download(), t.download())          # NTT(a+b) = NTT(a)+NTT(b)
+    assert np.array_equal(da.copy().iFFT().download(), a)       # round trip
+    # X * a(X): multiply by the monomial in the eval domain == negacyclic shift
+    mono = np.zeros((L, 1, P.N), dtype=np.uint64)
+    mono[:, 0, 1] = 1
+    dm = hx.DoubleCRT(P.g, idx, 1, mono).FFT()
+    da *= dm
+    sh = da.iFFT().download()
+    want = np.roll(a, 1, axis=2)
+    for r in idx:
+        q = np.uint64(P.primes[r])
+        w0 = want[r, :, 0]
+        want[r, :, 0] = np.where(w0 == 0, np.uint64(0), q - w0)
+    assert np.array_equal(sh, want)
