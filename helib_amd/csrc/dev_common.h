@@ -19,8 +19,12 @@ struct PrimeDev {
   uint64_t mu64;   // floor(2^64 / q)                     (Barrett, 64-bit values)
   uint32_t k;      // bitlen(q)
   uint32_t pad;
-  const TW* tw_fwd;  // power-of-two NTT tables (ntt_core.h layout), or null
-  const TW* tw_inv;
+  // power-of-two NTT tables (ntt_core.h layout) as offsets, in TW units, into the
+  // context's single twiddle arena: the arena base is a kernel ARGUMENT so the
+  // compiler addresses it as global memory (scalar loads for uniform entries)
+  // instead of through a flat pointer fetched from memory.
+  uint64_t tw_fwd_off;
+  uint64_t tw_inv_off;
 };
 
 // launch descriptor passed BY VALUE (kernel-arg segment): row r of the

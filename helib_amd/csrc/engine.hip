@@ -18,7 +18,8 @@
 
 namespace hx {
 hipError_t launch_ntt_pow2(int logn, bool inverse, uint64_t* data, const RowMap& map, int period,
-                           int row0, int nrows, int batch, const PrimeDev* primes, hipStream_t st);
+                           int row0, int nrows, int batch, const PrimeDev* primes,
+                           const TW* tw_arena, hipStream_t st);
 }
 
 using hx::ExtArgs;
@@ -79,8 +80,7 @@ extern "C" int hx_device_count(int* count)
 // ------------------------------------------------------------------
 struct PrimeHost {
   uint64_t q, root, rinv;
-  TW* d_tw_fwd = nullptr;
-  TW* d_tw_inv = nullptr;
+  uint64_t tw_fwd_off = 0, tw_inv_off = 0;  // into hx_ctx::d_tw (TW units)
 };
 
 struct ExtPlan {
@@ -102,9 +102,15 @@ struct hx_ctx {
   std::vector<PrimeHost> primes;
   PrimeDev* d_primes = nullptr;
   int primes_cap = 0;
+  TW* d_tw = nullptr;  // twiddle arena shared by all primes
+  size_t tw_cap = 0, tw_used = 0;
   uint64_t* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t scratch_words[4] = {0, 0, 0, 0};
   std::map<std::vector<uint64_t>, ExtPlan*> plans;
+  // lifetime: polys and key-switch matrices keep their context alive, so the
+  // handles may be destroyed in any order (hx_ctx_destroy only drops the
+  // caller's reference).
+  int refs = 1;
 };
 
 struct hx_poly {
@@ -188,18 +194,25 @@ extern "C" int hx_ctx_create(hx_ctx** out, int device, uint64_t m)
   return HX_OK;
 }
 
+static void ctx_free(hx_ctx* c);
+static void ctx_release(hx_ctx* c)
+{
+  if (--c->refs == 0)
+    ctx_free(c);
+}
 extern "C" int hx_ctx_destroy(hx_ctx* c)
 {
   if (!c)
     return HX_OK;
+  ctx_release(c);
+  return HX_OK;
+}
+static void ctx_free(hx_ctx* c)
+{
   hipSetDevice(c->device);
   hipDeviceSynchronize();
-  for (auto& p : c->primes) {
-    if (p.d_tw_fwd)
-      hipFree(p.d_tw_fwd);
-    if (p.d_tw_inv)
-      hipFree(p.d_tw_inv);
-  }
+  if (c->d_tw)
+    hipFree(c->d_tw);
   for (auto& kv : c->plans) {
     hipFree(kv.second->blob);
     delete kv.second;
@@ -212,7 +225,6 @@ extern "C" int hx_ctx_destroy(hx_ctx* c)
   hipFree(c->d_perm);
   hipFree(c->d_primes);
   delete c;
-  return HX_OK;
 }
 
 extern "C" int hx_ctx_phim(const hx_ctx* c, uint64_t* phim)
@@ -255,6 +267,25 @@ extern "C" int hx_ctx_prime(const hx_ctx* c, int idx, uint64_t* q, uint64_t* roo
   return HX_OK;
 }
 
+static int tw_reserve(hx_ctx* c, size_t extra)
+{
+  if (c->tw_used + extra <= c->tw_cap)
+    return HX_OK;
+  size_t ncap = c->tw_cap ? c->tw_cap * 2 : extra * 32;
+  while (ncap < c->tw_used + extra)
+    ncap *= 2;
+  TW* nd = nullptr;
+  HIPCHK(hipMalloc((void**)&nd, ncap * sizeof(TW)));
+  if (c->d_tw) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(nd, c->d_tw, c->tw_used * sizeof(TW), hipMemcpyDeviceToDevice));
+    HIPCHK(hipFree(c->d_tw));
+  }
+  c->d_tw = nd;
+  c->tw_cap = ncap;
+  return HX_OK;
+}
+
 template <int LOGN>
 static int upload_tw(hx_ctx* c, PrimeHost& ph)
 {
@@ -262,10 +293,14 @@ static int upload_tw(hx_ctx* c, PrimeHost& ph)
   std::vector<TW> f(G::TW_TOTAL), i(G::TW_TOTAL);
   uint64_t ninv = hxh::invmod((uint64_t)G::N % ph.q, ph.q);
   hx::build_tw_tables<LOGN>(ph.q, ph.root, ph.rinv, ninv, hxh::mulmod, f.data(), i.data());
-  HIPCHK(hipMalloc((void**)&ph.d_tw_fwd, sizeof(TW) * G::TW_TOTAL));
-  HIPCHK(hipMalloc((void**)&ph.d_tw_inv, sizeof(TW) * G::TW_TOTAL));
-  HIPCHK(hipMemcpy(ph.d_tw_fwd, f.data(), sizeof(TW) * G::TW_TOTAL, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ph.d_tw_inv, i.data(), sizeof(TW) * G::TW_TOTAL, hipMemcpyHostToDevice));
+  CHK(tw_reserve(c, 2 * (size_t)G::TW_TOTAL));
+  ph.tw_fwd_off = c->tw_used;
+  ph.tw_inv_off = c->tw_used + G::TW_TOTAL;
+  HIPCHK(hipMemcpy(c->d_tw + ph.tw_fwd_off, f.data(), sizeof(TW) * G::TW_TOTAL,
+                   hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_tw + ph.tw_inv_off, i.data(), sizeof(TW) * G::TW_TOTAL,
+                   hipMemcpyHostToDevice));
+  c->tw_used += 2 * (size_t)G::TW_TOTAL;
   return HX_OK;
 }
 
@@ -307,8 +342,8 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
   pd.k = (uint32_t)hxh::bitlen(q);
   pd.mu = (uint64_t)((((hxh::u128)1) << (2 * pd.k)) / q);
   pd.mu64 = (uint64_t)((((hxh::u128)1) << 64) / q);
-  pd.tw_fwd = ph.d_tw_fwd;
-  pd.tw_inv = ph.d_tw_inv;
+  pd.tw_fwd_off = ph.tw_fwd_off;
+  pd.tw_inv_off = ph.tw_inv_off;
   int idx = (int)c->primes.size();
   HIPCHK(hipMemcpy(c->d_primes + idx, &pd, sizeof pd, hipMemcpyHostToDevice));
   c->primes.push_back(ph);
@@ -368,6 +403,7 @@ static int poly_new(hx_ctx* c, int batch, const int* idx, int nrows, int cap, vo
       return fail(HX_ERR_DEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
     }
   }
+  c->refs++;
   *out = p;
   return HX_OK;
 }
@@ -392,6 +428,7 @@ extern "C" int hx_poly_destroy(hx_poly* p)
     hipStreamSynchronize(p->ctx->stream);
     hipFree(p->d);
   }
+  ctx_release(p->ctx);
   delete p;
   return HX_OK;
 }
@@ -538,7 +575,7 @@ static int ntt_rows(hx_ctx* c, uint64_t* data, const std::vector<int>& plist, in
   RowMap map;
   CHK(make_map(plist, 0, period, map));
   hipError_t e = hx::launch_ntt_pow2(c->logn, inverse, data, map, period, row0, nrows, batch,
-                                     c->d_primes, c->stream);
+                                     c->d_primes, c->d_tw, c->stream);
   if (e != hipSuccess)
     return fail(HX_ERR_DEVICE, "NTT launch failed: %s", hipGetErrorString(e));
   return HX_OK;
@@ -1139,6 +1176,7 @@ extern "C" int hx_ksk_create(hx_ctx* c, int ndig, const int* row_idx, int nrows,
   HIPCHK(hipMalloc((void**)&k->d_a, bytes));
   HIPCHK(hipMemcpy(k->d_b, b, bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(k->d_a, a, bytes, hipMemcpyHostToDevice));
+  c->refs++;
   *out = k;
   return HX_OK;
 }
@@ -1150,6 +1188,7 @@ extern "C" int hx_ksk_destroy(hx_ksk* k)
   hipStreamSynchronize(k->ctx->stream);
   hipFree(k->d_b);
   hipFree(k->d_a);
+  ctx_release(k->ctx);
   delete k;
   return HX_OK;
 }

@@ -26,6 +26,14 @@
 #define HXD inline
 #endif
 
+// Compiler-only fence: stops hipcc from hoisting every twiddle load of a pass to
+// its top (31 twiddles x 4 VGPRs), which costs a wave of occupancy per SIMD.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_NO_TW_FENCE)
+#define HX_TW_FENCE() asm volatile("" ::: "memory")
+#else
+#define HX_TW_FENCE() ((void)0)
+#endif
+
 namespace hx {
 
 struct TW {
@@ -137,6 +145,8 @@ HXD void fwd_pass5(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
     const int half = 16 >> sp;
 #pragma unroll
     for (int k = 0; k < (1 << sp); k++) {
+      if ((k & 3) == 0)
+        HX_TW_FENCE();
       TW t = tw(sp, k);
 #pragma unroll
       for (int j = 0; j < half; j++) {
@@ -156,6 +166,8 @@ HXD void inv_pass5(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
     const int half = 16 >> sp;
 #pragma unroll
     for (int k = 0; k < (1 << sp); k++) {
+      if ((k & 3) == 0)
+        HX_TW_FENCE();
       TW t = tw(sp, k);
 #pragma unroll
       for (int j = 0; j < half; j++) {
@@ -184,6 +196,8 @@ HXD void fwd_passC(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
       const int half = (GC / 2) >> sp;
 #pragma unroll
       for (int k = 0; k < (1 << sp); k++) {
+        if ((k & 3) == 0)
+          HX_TW_FENCE();
         TW t = tw(gi, sp, k);
 #pragma unroll
         for (int j = 0; j < half; j++) {
@@ -205,6 +219,8 @@ HXD void inv_passC(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
       const int half = (GC / 2) >> sp;
 #pragma unroll
       for (int k = 0; k < (1 << sp); k++) {
+        if ((k & 3) == 0)
+          HX_TW_FENCE();
         TW t = tw(gi, sp, k);
 #pragma unroll
         for (int j = 0; j < half; j++) {

@@ -20,17 +20,17 @@ namespace hx {
 template <int LOGN, bool INV>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
 ntt_row_kernel(uint64_t* __restrict__ data, RowMap map, int period, int row0, int batch,
-               const PrimeDev* __restrict__ primes)
+               const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   using R = RowNTT<LOGN>;
   const unsigned tid = threadIdx.x;
   const int row = row0 + (int)(blockIdx.x / (unsigned)batch);
   const int b = (int)(blockIdx.x % (unsigned)batch);
-  const PrimeDev pd = primes[map.p[row % period]];
+  const PrimeDev* pd = primes + map.p[row % period];
   uint64_t* ptr = data + ((size_t)row * batch + b) * (size_t)Geo<LOGN>::N;
-  const TW* tw = INV ? pd.tw_inv : pd.tw_fwd;
-  const uint64_t q = pd.q;
+  const TW* tw = tw_arena + (INV ? pd->tw_inv_off : pd->tw_fwd_off);
+  const uint64_t q = pd->q;
 
   uint64_t v[32];
   uint32_t nl[32];
@@ -71,7 +71,8 @@ ntt_row_kernel(uint64_t* __restrict__ data, RowMap map, int period, int row0, in
 
 template <int LOGN, bool INV>
 static hipError_t launch_one(uint64_t* data, const RowMap& map, int period, int row0, int nrows,
-                             int batch, const PrimeDev* primes, hipStream_t st)
+                             int batch, const PrimeDev* primes, const TW* tw_arena,
+                             hipStream_t st)
 {
   constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
   static bool attr_set = false;
@@ -84,24 +85,25 @@ static hipError_t launch_one(uint64_t* data, const RowMap& map, int period, int 
   }
   dim3 grid((unsigned)nrows * (unsigned)batch), block(Geo<LOGN>::T);
   hipLaunchKernelGGL((ntt_row_kernel<LOGN, INV>), grid, block, lds_bytes, st, data, map, period,
-                     row0, batch, primes);
+                     row0, batch, primes, tw_arena);
   return hipGetLastError();
 }
 
 // entry point used by engine.hip
 hipError_t launch_ntt_pow2(int logn, bool inverse, uint64_t* data, const RowMap& map, int period,
-                           int row0, int nrows, int batch, const PrimeDev* primes, hipStream_t st)
+                           int row0, int nrows, int batch, const PrimeDev* primes,
+                           const TW* tw_arena, hipStream_t st)
 {
   switch (logn) {
     case 13:
-      return inverse ? launch_one<13, true>(data, map, period, row0, nrows, batch, primes, st)
-                     : launch_one<13, false>(data, map, period, row0, nrows, batch, primes, st);
+      return inverse ? launch_one<13, true>(data, map, period, row0, nrows, batch, primes, tw_arena, st)
+                     : launch_one<13, false>(data, map, period, row0, nrows, batch, primes, tw_arena, st);
     case 14:
-      return inverse ? launch_one<14, true>(data, map, period, row0, nrows, batch, primes, st)
-                     : launch_one<14, false>(data, map, period, row0, nrows, batch, primes, st);
+      return inverse ? launch_one<14, true>(data, map, period, row0, nrows, batch, primes, tw_arena, st)
+                     : launch_one<14, false>(data, map, period, row0, nrows, batch, primes, tw_arena, st);
     case 15:
-      return inverse ? launch_one<15, true>(data, map, period, row0, nrows, batch, primes, st)
-                     : launch_one<15, false>(data, map, period, row0, nrows, batch, primes, st);
+      return inverse ? launch_one<15, true>(data, map, period, row0, nrows, batch, primes, tw_arena, st)
+                     : launch_one<15, false>(data, map, period, row0, nrows, batch, primes, tw_arena, st);
   }
   return hipErrorInvalidValue;
 }
