@@ -29,9 +29,19 @@
 // Compiler-only fence: stops hipcc from hoisting every twiddle load of a pass to
 // its top (31 twiddles x 4 VGPRs), which costs a wave of occupancy per SIMD.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_NO_TW_FENCE)
+#ifndef HX_TW_FENCE_KIND
+#define HX_TW_FENCE_KIND 0
+#endif
+#if HX_TW_FENCE_KIND == 0
 #define HX_TW_FENCE() asm volatile("" ::: "memory")
 #else
+#define HX_TW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#else
 #define HX_TW_FENCE() ((void)0)
+#endif
+#ifndef HX_TW_FENCE_MASK
+#define HX_TW_FENCE_MASK 3
 #endif
 
 namespace hx {
@@ -134,102 +144,93 @@ HXD void gs_bfly_last(uint64_t& X, uint64_t& Y, TW tNinv, TW tS0Ninv, uint64_t q
 
 // ---------------------------------------------------------------------
 // register passes.  v[32] is the thread's coefficient file.
+//
+// A pass is REP independent radix-2^S sub-transforms on v[rep*2^S ..]; stage sp
+// pairs element e with e + (2^(S-1) >> sp) and all butterflies of "group"
+// (sp, k = e >> (S - sp)) share one twiddle.  Groups are visited in a fixed flat
+// order (forward: sp ascending, inverse: sp descending) and their twiddles are
+// fetched through a PF-deep software queue: the load for group i+PF is issued
+// right after group i has been computed and is made data-dependent on one of its
+// results (HX_LAUNDER), so hipcc can neither hoist all 31 loads of a pass to its
+// top (124 VGPRs, costs a wave of occupancy) nor sink them to the point of use.
 // ---------------------------------------------------------------------
-// forward pass over 5 in-thread bits: element index e (5 bits), stage sp pairs
-// e and e + (16 >> sp); group k = e >> (5 - sp).
-template <class TWF>
-HXD void fwd_pass5(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_NO_LAUNDER)
+#define HX_LAUNDER(ptr, dep) asm volatile("" : "+v"(ptr) : "v"(dep))
+#else
+#define HX_LAUNDER(ptr, dep) ((void)(dep))
+#endif
+#ifndef HX_TW_PF
+#define HX_TW_PF 4
+#endif
+
+template <int S, bool INV>
+HXD constexpr int grp_sp(int i)
 {
-#pragma unroll
-  for (int sp = 0; sp < 5; sp++) {
-    const int half = 16 >> sp;
-#pragma unroll
-    for (int k = 0; k < (1 << sp); k++) {
-      if ((k & 3) == 0)
-        HX_TW_FENCE();
-      TW t = tw(sp, k);
-#pragma unroll
-      for (int j = 0; j < half; j++) {
-        int a = k * 2 * half + j;
-        ct_bfly(v[a], v[a + half], t, q, q2);
-      }
-    }
+  int sp = INV ? S - 1 : 0;
+  while (i >= (1 << sp)) {
+    i -= (1 << sp);
+    sp += INV ? -1 : 1;
+  }
+  return sp;
+}
+template <int S, bool INV>
+HXD constexpr int grp_k(int i)
+{
+  int sp = INV ? S - 1 : 0;
+  while (i >= (1 << sp)) {
+    i -= (1 << sp);
+    sp += INV ? -1 : 1;
+  }
+  return i;
+}
+
+// compile-time loop: f(integral_constant<int, I>) for I in [0, N)
+template <int I>
+struct IC {
+  static constexpr int value = I;
+};
+template <int I, int N, class F>
+HXD void static_for(F&& f)
+{
+  if constexpr (I < N) {
+    f(IC<I>{});
+    static_for<I + 1, N>(f);
   }
 }
-// LAST: this is the final pass of the inverse transform (pass A); its stage 0
-// uses slot (0,0) = S0*Ninv and the extra slot tw(-1,0) = Ninv.
-template <bool LAST, class TWF>
-HXD void inv_pass5(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
+
+// NGRUN: number of leading groups (flat order) to run per repetition; the inverse
+// pass A runs 2^S-2 groups here and finishes stage 0 with gs_bfly_last.
+template <int S, bool INV, int REP, int NGRUN, class Fetch>
+HXD void run_pass(uint64_t (&v)[32], uint64_t q, uint64_t q2, Fetch fetch)
 {
-#pragma unroll
-  for (int sp = 4; sp >= (LAST ? 1 : 0); sp--) {
-    const int half = 16 >> sp;
-#pragma unroll
-    for (int k = 0; k < (1 << sp); k++) {
-      if ((k & 3) == 0)
-        HX_TW_FENCE();
-      TW t = tw(sp, k);
-#pragma unroll
-      for (int j = 0; j < half; j++) {
-        int a = k * 2 * half + j;
-        gs_bfly(v[a], v[a + half], t, q, q2);
-      }
+  constexpr int PF = HX_TW_PF;
+  constexpr int TOT = REP * NGRUN;
+  TW tq[PF];
+  static_for<0, (PF < TOT ? PF : TOT)>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int rep = i / NGRUN, sp = grp_sp<S, INV>(i % NGRUN), k = grp_k<S, INV>(i % NGRUN);
+    tq[i] = fetch(rep, sp, k, (uint32_t)v[0]);
+  });
+  static_for<0, TOT>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int rep = i / NGRUN, ii = i % NGRUN;
+    constexpr int sp = grp_sp<S, INV>(ii), k = grp_k<S, INV>(ii);
+    constexpr int half = (1 << (S - 1)) >> sp;
+    constexpr int base = rep * (1 << S) + k * 2 * half;
+    const TW t = tq[i % PF];
+    static_for<0, half>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (INV)
+        gs_bfly(v[base + j], v[base + j + half], t, q, q2);
+      else
+        ct_bfly(v[base + j], v[base + j + half], t, q, q2);
+    });
+    if constexpr (i + PF < TOT) {
+      constexpr int n = i + PF;
+      constexpr int nrep = n / NGRUN, nsp = grp_sp<S, INV>(n % NGRUN), nk = grp_k<S, INV>(n % NGRUN);
+      tq[i % PF] = fetch(nrep, nsp, nk, (uint32_t)v[base]);
     }
-  }
-  if (LAST) {
-    TW tS = tw(0, 0), tN = tw(-1, 0);
-#pragma unroll
-    for (int j = 0; j < 16; j++)
-      gs_bfly_last(v[j], v[j + 16], tN, tS, q, q2);
-  }
-}
-// last pass: NGC independent groups of GC = 2^LC points, group gi occupies
-// v[gi*GC .. gi*GC+GC).
-template <int LC, class TWF>
-HXD void fwd_passC(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
-{
-  constexpr int GC = 1 << LC, NGC = 32 >> LC;
-#pragma unroll
-  for (int gi = 0; gi < NGC; gi++) {
-#pragma unroll
-    for (int sp = 0; sp < LC; sp++) {
-      const int half = (GC / 2) >> sp;
-#pragma unroll
-      for (int k = 0; k < (1 << sp); k++) {
-        if ((k & 3) == 0)
-          HX_TW_FENCE();
-        TW t = tw(gi, sp, k);
-#pragma unroll
-        for (int j = 0; j < half; j++) {
-          int a = gi * GC + k * 2 * half + j;
-          ct_bfly(v[a], v[a + half], t, q, q2);
-        }
-      }
-    }
-  }
-}
-template <int LC, class TWF>
-HXD void inv_passC(uint64_t (&v)[32], uint64_t q, uint64_t q2, TWF tw)
-{
-  constexpr int GC = 1 << LC, NGC = 32 >> LC;
-#pragma unroll
-  for (int gi = 0; gi < NGC; gi++) {
-#pragma unroll
-    for (int sp = LC - 1; sp >= 0; sp--) {
-      const int half = (GC / 2) >> sp;
-#pragma unroll
-      for (int k = 0; k < (1 << sp); k++) {
-        if ((k & 3) == 0)
-          HX_TW_FENCE();
-        TW t = tw(gi, sp, k);
-#pragma unroll
-        for (int j = 0; j < half; j++) {
-          int a = gi * GC + k * 2 * half + j;
-          gs_bfly(v[a], v[a + half], t, q, q2);
-        }
-      }
-    }
-  }
+  });
 }
 
 // ---------------------------------------------------------------------
@@ -284,6 +285,26 @@ HXD unsigned eval_index(unsigned tid, int i)
   return brev_bits(ep, LC) * 1024u + tid + (unsigned)T * gi;
 }
 
+// constant (thread-independent) part of the two index maps: index = tid + const
+template <int LOGN>
+HXD unsigned coef_const(int e) { return (unsigned)e << (LOGN - 5); }
+template <int LOGN>
+HXD unsigned eval_const(int i)
+{
+  constexpr int LC = Geo<LOGN>::LC;
+  constexpr int T = Geo<LOGN>::T;
+  unsigned gi = (unsigned)i >> LC, ep = (unsigned)i & ((1u << LC) - 1u);
+  return brev_bits(ep, LC) * 1024u + (unsigned)T * gi;
+}
+
+// Plain-pointer row accessor (CPU replay; also valid on the device).
+struct PtrIO {
+  const uint64_t* in;
+  uint64_t* out;
+  HXD uint64_t load(unsigned tid, unsigned c) const { return in[tid + c]; }
+  HXD void store(unsigned tid, unsigned c, uint64_t v) const { out[tid + c] = v; }
+};
+
 HXD uint64_t norm4(uint64_t x, uint64_t q, uint64_t q2)  // [0,4q) -> [0,q)
 {
   x = (x >= q2) ? x - q2 : x;
@@ -306,17 +327,18 @@ struct RowNTT {
   static constexpr int NPHASE = 8;
 
   // -------- forward: coefficients (natural) -> evaluations (natural) -----
-  template <int PH>
+  template <int PH, class IO>
   static HXD void fwd(unsigned tid, uint64_t (&v)[32], uint32_t (&nl)[32], uint32_t* lds,
-                      const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
-                      const TW* __restrict__ tw, uint64_t q)
+                      const IO& io, const TW* __restrict__ tw, uint64_t q)
   {
     const uint64_t q2 = q + q;
     if constexpr (PH == 0) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
-        v[e] = in[coef_index<LOGN>(tid, e)];
-      fwd_pass5(v, q, q2, [&](int sp, int k) { return tw[(1 << sp) - 1 + k]; });
+        v[e] = io.load(tid, coef_const<LOGN>(e));
+      run_pass<5, false, 1, 31>(v, q, q2, [&](int, int sp, int k, uint32_t) {
+        return tw[(1 << sp) - 1 + k];  // uniform: scalar loads
+      });
 #pragma unroll
       for (int e = 0; e < 32; e++)
         lds[ab_addr_A<LOGN>(tid, e)] = half_of(v[e], 0);
@@ -333,7 +355,11 @@ struct RowNTT {
       for (int e = 0; e < 32; e++)
         v[e] = ((uint64_t)lds[ab_addr_B<LOGN>(tid, e)] << 32) | nl[e];
       const TW* twb = tw + G::TWB + (tid & 31u);
-      fwd_pass5(v, q, q2, [&](int sp, int k) { return twb[((1 << sp) - 1 + k) * 32]; });
+      run_pass<5, false, 1, 31>(v, q, q2, [&](int, int sp, int k, uint32_t dep) {
+        unsigned off = ((1u << sp) - 1u + (unsigned)k) * 32u;
+        HX_LAUNDER(off, dep);
+        return twb[off];
+      });
     } else if constexpr (PH == 4) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
@@ -351,29 +377,32 @@ struct RowNTT {
       for (int i = 0; i < 32; i++)
         v[i] = ((uint64_t)lds[bc_addr_C<LOGN>(tid, i)] << 32) | nl[i];
       const TW* twc = tw + G::TWC + tid;
-      fwd_passC<G::LC>(v, q, q2, [&](int gi, int sp, int k) {
-        return twc[((1 << sp) - 1 + k) * 1024 + G::T * gi];
+      run_pass<G::LC, false, G::NGC, G::GC - 1>(v, q, q2, [&](int gi, int sp, int k, uint32_t dep) {
+        unsigned off = ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi);
+        HX_LAUNDER(off, dep);
+        return twc[off];
       });
 #pragma unroll
       for (int i = 0; i < 32; i++)
-        out[eval_index<LOGN>(tid, i)] = norm4(v[i], q, q2);
+        io.store(tid, eval_const<LOGN>(i), norm4(v[i], q, q2));
     }
   }
 
   // -------- inverse: evaluations (natural) -> coefficients (natural) -----
-  template <int PH>
+  template <int PH, class IO>
   static HXD void inv(unsigned tid, uint64_t (&v)[32], uint32_t (&nl)[32], uint32_t* lds,
-                      const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
-                      const TW* __restrict__ tw, uint64_t q)
+                      const IO& io, const TW* __restrict__ tw, uint64_t q)
   {
     const uint64_t q2 = q + q;
     if constexpr (PH == 0) {
 #pragma unroll
       for (int i = 0; i < 32; i++)
-        v[i] = in[eval_index<LOGN>(tid, i)];
+        v[i] = io.load(tid, eval_const<LOGN>(i));
       const TW* twc = tw + G::TWC + tid;
-      inv_passC<G::LC>(v, q, q2, [&](int gi, int sp, int k) {
-        return twc[((1 << sp) - 1 + k) * 1024 + G::T * gi];
+      run_pass<G::LC, true, G::NGC, G::GC - 1>(v, q, q2, [&](int gi, int sp, int k, uint32_t dep) {
+        unsigned off = ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi);
+        HX_LAUNDER(off, dep);
+        return twc[off];
       });
 #pragma unroll
       for (int i = 0; i < 32; i++)
@@ -391,7 +420,11 @@ struct RowNTT {
       for (int e = 0; e < 32; e++)
         v[e] = ((uint64_t)lds[bc_addr_B<LOGN>(tid, e)] << 32) | nl[e];
       const TW* twb = tw + G::TWB + (tid & 31u);
-      inv_pass5<false>(v, q, q2, [&](int sp, int k) { return twb[((1 << sp) - 1 + k) * 32]; });
+      run_pass<5, true, 1, 31>(v, q, q2, [&](int, int sp, int k, uint32_t dep) {
+        unsigned off = ((1u << sp) - 1u + (unsigned)k) * 32u;
+        HX_LAUNDER(off, dep);
+        return twb[off];
+      });
     } else if constexpr (PH == 4) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
@@ -408,10 +441,20 @@ struct RowNTT {
 #pragma unroll
       for (int e = 0; e < 32; e++)
         v[e] = ((uint64_t)lds[ab_addr_A<LOGN>(tid, e)] << 32) | nl[e];
-      inv_pass5<true>(v, q, q2, [&](int sp, int k) { return sp < 0 ? tw[31] : tw[(1 << sp) - 1 + k]; });
+      // stages 4..1 (30 groups), then stage 0 with N^-1 folded in:
+      // slot 0 = S0*N^-1, slot 31 = N^-1
+      run_pass<5, true, 1, 30>(v, q, q2, [&](int, int sp, int k, uint32_t) {
+        return tw[(1 << sp) - 1 + k];
+      });
+      {
+        const TW tS = tw[0], tN = tw[31];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+          gs_bfly_last(v[j], v[j + 16], tN, tS, q, q2);
+      }
 #pragma unroll
       for (int e = 0; e < 32; e++)
-        out[coef_index<LOGN>(tid, e)] = norm2(v[e], q);
+        io.store(tid, coef_const<LOGN>(e), norm2(v[e], q));
     }
   }
 };

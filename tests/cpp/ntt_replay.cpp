@@ -32,10 +32,11 @@ static void run_phase(bool inverse, std::vector<uint64_t>& V, std::vector<uint32
   for (unsigned tid = 0; tid < (unsigned)T; tid++) {
     uint64_t(&v)[32] = *reinterpret_cast<uint64_t(*)[32]>(&V[tid * 32]);
     uint32_t(&nl)[32] = *reinterpret_cast<uint32_t(*)[32]>(&NL[tid * 32]);
+    hx::PtrIO io{in, out};
     if (inverse)
-      R::template inv<PH>(tid, v, nl, lds.data(), in, out, tw, q);
+      R::template inv<PH>(tid, v, nl, lds.data(), io, tw, q);
     else
-      R::template fwd<PH>(tid, v, nl, lds.data(), in, out, tw, q);
+      R::template fwd<PH>(tid, v, nl, lds.data(), io, tw, q);
   }
 }
 

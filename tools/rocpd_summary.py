@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (ROCm 7.x, sqlite `*_results.db`) kernel trace the way
+`--stats` CSV used to: per-kernel calls / total / avg / min / max durations and share.
+usage: python tools/rocpd_summary.py gpurun_out/prof1 > profiles/<name>.txt"""
+import glob
+import os
+import sqlite3
+import sys
+
+
+def main():
+    path = sys.argv[1]
+    dbs = [path] if path.endswith(".db") else sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True))
+    for db in dbs:
+        c = sqlite3.connect(db)
+        cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+        name_col = "name" if "name" in cols else [x for x in cols if "name" in x][0]
+        rows = c.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                         "from kernels group by 1 order by 3 desc").fetchall()
+        tot = sum(r[2] for r in rows) or 1
+        print(f"# {os.path.basename(db)}  (durations in microseconds)")
+        print(f"{'kernel':70s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+        for n, k, s, a, mn, mx in rows:
+            short = n if len(n) <= 70 else n[:67] + "..."
+            print(f"{short:70s} {k:6d} {s/1e3:12.1f} {a/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f} {100*s/tot:6.2f}")
+        try:
+            pm = c.execute("select * from pmc_events limit 1").fetchall()
+            if pm:
+                pc = [r[1] for r in c.execute("pragma table_info(pmc_events)")]
+                print("# pmc_events columns:", pc)
+        except Exception:
+            pass
+
+
+if __name__ == "__main__":
+    main()
