@@ -106,18 +106,13 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
+    from helib_amd import dist as hdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local_rank = hdist.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+    group = hdist.Group(backend="nccl", device=torch.device("cuda", local_rank))
 
     from helib_amd import capi as hx
 
@@ -142,9 +137,7 @@ def main():
     def step():
         hx.multiplyBy(*polys, W, DIGITS, out0, out1)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = group.barrier
 
     for _ in range(args.warmup):
         step()
@@ -157,10 +150,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = group.max_over_ranks(dt)
     mults = world * B * args.steps
     value = mults / dt
 
@@ -200,8 +190,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,67 @@
+"""world_size-2 gloo test of the N>1 harness (batch sharding, barrier, max-over-ranks timing)
+that bench.py uses on the GPUs with RCCL.  Runs on CPU."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_partitions_exactly():
+    from helib_amd.dist import shard
+    for total in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            parts = [shard(total, world, r) for r in range(world)]
+            assert sum(c for _, c in parts) == total
+            pos = 0
+            for s, c in parts:
+                assert s == pos
+                pos += c
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_two_rank_gloo_timing_and_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, time, json
+        sys.path.insert(0, {ROOT!r})
+        from helib_amd.dist import Group, shard
+        g = Group(backend="gloo")
+        start, count = shard(513, g.world, g.rank)
+        g.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.05 * (g.rank + 1))          # rank 1 is the slow one
+        g.barrier()
+        dt = g.max_over_ranks(time.perf_counter() - t0)
+        total = g.sum_over_ranks(count)
+        print(json.dumps({{"rank": g.rank, "start": start, "count": count, "dt": dt, "total": total}}))
+        g.close()
+    """))
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0, e
+        import json
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    assert outs[0]["count"] + outs[1]["count"] == 513 and outs[1]["start"] == outs[0]["count"]
+    assert outs[0]["total"] == 513 and outs[1]["total"] == 513
+    # both ranks report the slow rank's time
+    assert abs(outs[0]["dt"] - outs[1]["dt"]) < 1e-9 and outs[0]["dt"] >= 0.09
