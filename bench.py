@@ -51,12 +51,11 @@ def uniform_rows(rng, primes, idx, batch, n):
 
 
 def algorithmic_bytes_per_mult(n, l, k, d):
-    """compulsory traffic of one multiply at a fixed level, as built
-    (all D*(L+K) digit rows go through the forward NTT in this round)."""
+    """compulsory traffic of one multiply at a fixed level."""
     tensor = l * 56 * n                       # 4 parts in, 3 out (scaling fused)
-    ntt = (l + d * (l + k)) * 16 * n          # L inverse + D(L+K) forward
-    ext = (l + d * (l + k)) * 8 * n           # read L rows, write D(L+K) rows
-    ks = (l + k) * (3 * d + 4) * 8 * n
+    ntt = d * (l + k) * 16 * n                # L inverse + D(L+K)-L forward row transforms
+    ext = d * (l + k) * 8 * n                 # read each digit's own rows once, write the extension rows
+    ks = (l + k) * (3 * d + 4) * 8 * n        # fused inner product incl. own-row rebuild
     return tensor + ntt + ext + ks
 
 
@@ -158,13 +157,14 @@ def main():
     roof = None
     cpu = None
     if rank == 0:
-        nrows = len(DIGITS) * (L + K)
+        # the forward launch inside one multiply covers the D*(L+K)-L extension rows x B
+        nrows = len(DIGITS) * (L + K) - L
         digp = hx.DoubleCRT(ctx, own, B, uniform_rows(rng, primes, own, B, n))
         dg = digp.breakIntoDigits(DIGITS, sp)          # D*(L+K) rows x B, evaluation domain
-        hx.time_ntt(dg, True, 2)                        # warm both directions
-        hx.time_ntt(dg, False, 2)
-        ms_inv = hx.time_ntt(dg, True, args.ntt_iters)
-        ms_fwd = hx.time_ntt(dg, False, args.ntt_iters)
+        hx.time_ntt(dg, True, 2, nrows)                 # warm both directions
+        hx.time_ntt(dg, False, 2, nrows)
+        ms_inv = hx.time_ntt(dg, True, args.ntt_iters, nrows)
+        ms_fwd = hx.time_ntt(dg, False, args.ntt_iters, nrows)
         bytes_launch = 16.0 * n * nrows * B             # 16*N bytes per row transform
         ach = bytes_launch / (ms_fwd * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "ntt_row_kernel<14,fwd>", "achieved": round(ach, 1),

@@ -94,7 +94,7 @@ def lib():
             "hx_intel_EltwiseAddModScalar": [vp, vp, C.c_long, C.c_long, C.c_long],
             "hx_intel_EltwiseSubModScalar": [vp, vp, C.c_long, C.c_long, C.c_long],
             "hx_intel_EltwiseMultModScalar": [vp, vp, C.c_long, C.c_long, C.c_long],
-            "hx_time_ntt": [vp, ip, ip, vp],
+            "hx_time_ntt": [vp, ip, ip, ip, vp],
         }
         for name, args in sig.items():
             f = getattr(L, name)
@@ -355,7 +355,7 @@ def multiplyBy(c0, c1, d0, d1, W, digits, out0=None, out1=None):
     return out0, out1
 
 
-def time_ntt(poly, inverse, iters):
+def time_ntt(poly, inverse, iters, max_rows=0):
     ms = C.c_float()
-    _chk(lib().hx_time_ntt(poly.h, 1 if inverse else 0, iters, C.byref(ms)))
+    _chk(lib().hx_time_ntt(poly.h, 1 if inverse else 0, iters, max_rows, C.byref(ms)))
     return ms.value

@@ -33,6 +33,11 @@ struct PrimeDev {
 struct RowMap {
   uint16_t p[MAX_ROWS];
 };
+// NTT launch descriptor: the i-th transformed row is buffer row `row[i]`, prime `prime[i]`.
+struct NttRows {
+  uint16_t row[MAX_ROWS];
+  uint16_t prime[MAX_ROWS];
+};
 struct RowMap2 {
   uint16_t p[MAX_ROWS];
   uint16_t brow[MAX_ROWS];

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -17,14 +18,15 @@
 #include "rns_kernels.h"
 
 namespace hx {
-hipError_t launch_ntt_pow2(int logn, bool inverse, uint64_t* data, const RowMap& map, int period,
-                           int row0, int nrows, int batch, const PrimeDev* primes,
+hipError_t launch_ntt_pow2(int logn, bool inverse, const uint64_t* in, uint64_t* out,
+                           const NttRows& rows, int nrows, int batch, const PrimeDev* primes,
                            const TW* tw_arena, hipStream_t st);
 }
 
 using hx::ExtArgs;
 using hx::ExtPlanDev;
 using hx::MAX_ROWS;
+using hx::NttRows;
 using hx::PrimeDev;
 using hx::RowMap;
 using hx::RowMap2;
@@ -561,24 +563,40 @@ static int make_map(const std::vector<int>& primes, int first, int count, RowMap
   return HX_OK;
 }
 
-// transform rows [row0,row0+nrows) of a [rows][batch][N] buffer; row r uses
-// prime plist[(r - row0_of_list) % period]
-static int ntt_rows(hx_ctx* c, uint64_t* data, const std::vector<int>& plist, int period,
-                    int row0, int nrows, int batch, bool inverse)
+// transform the listed (row, prime) pairs of a [rows][batch][N] buffer, in -> out
+static int ntt_list(hx_ctx* c, const uint64_t* in, uint64_t* out,
+                    const std::vector<std::pair<int, int>>& rows, int batch, bool inverse)
 {
-  if (nrows == 0)
+  if (rows.empty())
     return HX_OK;
   if (!c->pow2)
     return fail(HX_ERR_UNSUPPORTED, "NTT for non-power-of-two m (Bluestein) is not built yet");
   if (c->logn < 13 || c->logn > 15)
     return fail(HX_ERR_UNSUPPORTED, "power-of-two NTT supports phi(m) in {8192,16384,32768}");
-  RowMap map;
-  CHK(make_map(plist, 0, period, map));
-  hipError_t e = hx::launch_ntt_pow2(c->logn, inverse, data, map, period, row0, nrows, batch,
-                                     c->d_primes, c->d_tw, c->stream);
-  if (e != hipSuccess)
-    return fail(HX_ERR_DEVICE, "NTT launch failed: %s", hipGetErrorString(e));
+  for (size_t first = 0; first < rows.size(); first += MAX_ROWS) {
+    int n = (int)std::min<size_t>(MAX_ROWS, rows.size() - first);
+    NttRows d;
+    for (int i = 0; i < n; i++) {
+      d.row[i] = (uint16_t)rows[first + i].first;
+      d.prime[i] = (uint16_t)rows[first + i].second;
+    }
+    hipError_t e = hx::launch_ntt_pow2(c->logn, inverse, in, out, d, n, batch, c->d_primes, c->d_tw,
+                                       c->stream);
+    if (e != hipSuccess)
+      return fail(HX_ERR_DEVICE, "NTT launch failed: %s", hipGetErrorString(e));
+  }
   return HX_OK;
+}
+
+// in place: rows [row0,row0+nrows); row r uses prime plist[r % period]
+static int ntt_rows(hx_ctx* c, uint64_t* data, const std::vector<int>& plist, int period,
+                    int row0, int nrows, int batch, bool inverse)
+{
+  std::vector<std::pair<int, int>> rows;
+  rows.reserve(nrows);
+  for (int r = row0; r < row0 + nrows; r++)
+    rows.emplace_back(r, plist[r % period]);
+  return ntt_list(c, data, data, rows, batch, inverse);
 }
 
 extern "C" int hx_ntt_forward(hx_poly* p)
@@ -586,8 +604,6 @@ extern "C" int hx_ntt_forward(hx_poly* p)
   if (!p)
     return fail(HX_ERR_INVALID, "null poly");
   CHK(use(p->ctx));
-  if (p->nrows() > MAX_ROWS)
-    return fail(HX_ERR_UNSUPPORTED, "too many rows");
   return ntt_rows(p->ctx, p->d, p->prime_idx, p->nrows(), 0, p->nrows(), p->batch, false);
 }
 extern "C" int hx_ntt_inverse(hx_poly* p)
@@ -595,12 +611,10 @@ extern "C" int hx_ntt_inverse(hx_poly* p)
   if (!p)
     return fail(HX_ERR_INVALID, "null poly");
   CHK(use(p->ctx));
-  if (p->nrows() > MAX_ROWS)
-    return fail(HX_ERR_UNSUPPORTED, "too many rows");
   return ntt_rows(p->ctx, p->d, p->prime_idx, p->nrows(), 0, p->nrows(), p->batch, true);
 }
 
-extern "C" int hx_time_ntt(hx_poly* p, int dir, int iters, float* avg_ms)
+extern "C" int hx_time_ntt(hx_poly* p, int dir, int iters, int max_rows, float* avg_ms)
 {
   if (!p || !avg_ms || iters < 1)
     return fail(HX_ERR_INVALID, "bad argument");
@@ -611,7 +625,8 @@ extern "C" int hx_time_ntt(hx_poly* p, int dir, int iters, float* avg_ms)
   HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, c->stream));
   for (int i = 0; i < iters; i++) {
-    int rc = ntt_rows(c, p->d, p->prime_idx, p->nrows(), 0, p->nrows(), p->batch, dir != 0);
+    int nr = (max_rows > 0 && max_rows < p->nrows()) ? max_rows : p->nrows();
+    int rc = ntt_rows(c, p->d, p->prime_idx, p->nrows(), 0, nr, p->batch, dir != 0);
     if (rc != HX_OK)
       return rc;
   }
@@ -1069,7 +1084,8 @@ extern "C" int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_
 // dig : [ndig][nall][batch][N] output in the coefficient domain.
 static int break_digits_coef(hx_ctx* c, uint64_t* coef, const std::vector<int>& own,
                              const int* dig_idx, const int* dig_off, int ndig,
-                             const std::vector<int>& all, uint64_t* dig, size_t rw)
+                             const std::vector<int>& all, uint64_t* dig, size_t rw,
+                             bool copy_own = true, std::vector<int>* owner_out = nullptr)
 {
   int nall = (int)all.size();
   // which digit owns each ctxt prime
@@ -1103,7 +1119,8 @@ static int break_digits_coef(hx_ctx* c, uint64_t* coef, const std::vector<int>& 
     args.upd = coef;
     for (size_t k = 0; k < src.size(); k++) {
       args.src_row[k] = (uint16_t)find_row(own, src[k]);
-      args.own_dst_row[k] = (uint16_t)(d * nall + find_row(all, src[k]));
+      if (copy_own)
+        args.own_dst_row[k] = (uint16_t)(d * nall + find_row(all, src[k]));
     }
     for (size_t t = 0; t < tgt.size(); t++) {
       int pos = find_row(all, tgt[t]);
@@ -1113,6 +1130,8 @@ static int break_digits_coef(hx_ctx* c, uint64_t* coef, const std::vector<int>& 
     }
     CHK(launch_extend(c, pl, args, rw));
   }
+  if (owner_out)
+    *owner_out = owner;
   return HX_OK;
 }
 
@@ -1240,9 +1259,14 @@ extern "C" int hx_tensor(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0
   return tensor_launch(c0, c1, d0, d1, o0->d, o1->d, o2->d, nullptr);
 }
 
+// own_src/owner: when given, digit `owner[r]` of row r is not read from `dig` but rebuilt in the
+// evaluation domain from the s^2 part and the earlier digits (src/DoubleCRT.cpp:552-556 applied
+// row-wise): own = (...((c - d_0)/P_0 - d_1)/P_1 ...).
 static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
                             const std::vector<int>& all, int batch, uint64_t* out0, uint64_t* out1,
-                            int accumulate_rows)
+                            int accumulate_rows, const uint64_t* own_src = nullptr,
+                            const std::vector<int>* owner = nullptr,
+                            const std::vector<std::vector<int>>* digit_primes = nullptr)
 {
   int nall = (int)all.size();
   if (W->row_idx != all)
@@ -1250,9 +1274,47 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
   RowMap map;
   CHK(make_map(all, 0, nall, map));
   size_t rw = (size_t)batch * c->phim;
+  const hx::KsFix* d_fix = nullptr;
+  if (own_src) {
+    // cached table: owner digit of every row and P_e^-1 mod q_row for the earlier digits
+    std::vector<uint64_t> key;
+    key.push_back(0xF1F1F1F1ull);
+    for (int r : all)
+      key.push_back((uint64_t)r);
+    for (auto& dp : *digit_primes) {
+      key.push_back(0xFFFFull);
+      for (int p : dp)
+        key.push_back((uint64_t)p);
+    }
+    auto it = c->plans.find(key);
+    if (it == c->plans.end()) {
+      if ((int)digit_primes->size() > hx::KS_MAXD)
+        return fail(HX_ERR_UNSUPPORTED, "more than %d digits", hx::KS_MAXD);
+      std::vector<hx::KsFix> h(nall);
+      for (int r = 0; r < nall; r++) {
+        memset(&h[r], 0, sizeof(hx::KsFix));
+        h[r].owner = (*owner)[r];
+        uint64_t q = c->primes[all[r]].q;
+        for (int e = 0; e < (int)digit_primes->size(); e++) {
+          uint64_t pe = 1;
+          for (int p : (*digit_primes)[e])
+            pe = hxh::mulmod(pe, c->primes[p].q % q, q);
+          uint64_t inv = (h[r].owner >= 0 && e < h[r].owner) ? hxh::invmod(pe, q) : 0;
+          h[r].pinv[e].w = inv;
+          h[r].pinv[e].wp = hxh::shoup(inv, q);
+        }
+      }
+      ExtPlan* pl = new ExtPlan();
+      memset(&pl->dev, 0, sizeof pl->dev);
+      HIPCHK(hipMalloc(&pl->blob, sizeof(hx::KsFix) * nall));
+      HIPCHK(hipMemcpy(pl->blob, h.data(), sizeof(hx::KsFix) * nall, hipMemcpyHostToDevice));
+      it = c->plans.emplace(key, pl).first;
+    }
+    d_fix = reinterpret_cast<const hx::KsFix*>(it->second->blob);
+  }
   hipLaunchKernelGGL(hx::keyswitch_kernel, ew_grid(rw, nall), dim3(256), 0, c->stream, dig, W->d_b,
                      W->d_a, out0, out1, map, W->ndig, nall, batch, c->phim, accumulate_rows,
-                     c->d_primes);
+                     c->d_primes, own_src, d_fix);
   HIPCHK(hipGetLastError());
   return HX_OK;
 }
@@ -1296,8 +1358,10 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
   CHK(poly_reserve(out1, nall));
   out0->prime_idx = W->row_idx;
   out1->prime_idx = W->row_idx;
-  // scratch: [0] = s^2 part (L rows), [1] = digits (ndig*nall rows)
+  // scratch: [0] = s^2 part, evaluation domain (L rows); [2] = the same in the coefficient
+  // domain; [1] = digits (ndig*nall rows; a digit's own rows are never materialised)
   CHK(ensure_scratch(c, 0, (size_t)L * rw));
+  CHK(ensure_scratch(c, 2, (size_t)L * rw));
   CHK(ensure_scratch(c, 1, (size_t)ndig * nall * rw));
   // tensorProduct + (parts 1,s) addPrimesAndScale(special)
   std::vector<uint64_t> f(L);
@@ -1308,12 +1372,30 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
     f[r] = v;
   }
   CHK(tensor_launch(c0, c1, d0, d1, out0->d, out1->d, c->scratch[0], f.data()));
-  // keySwitchPart on the s^2 part
-  CHK(ntt_rows(c, c->scratch[0], c0->prime_idx, L, 0, L, c0->batch, true));
-  CHK(break_digits_coef(c, c->scratch[0], c0->prime_idx, dig_idx, dig_off, ndig, W->row_idx,
-                        c->scratch[1], rw));
-  CHK(ntt_rows(c, c->scratch[1], W->row_idx, nall, 0, ndig * nall, c0->batch, false));
-  CHK(keyswitch_launch(c, c->scratch[1], W, W->row_idx, c0->batch, out0->d, out1->d, L));
+  // keySwitchPart on the s^2 part: toPoly side (inverse NTT, out of place)
+  {
+    std::vector<std::pair<int, int>> rows;
+    for (int r = 0; r < L; r++)
+      rows.emplace_back(r, c0->prime_idx[r]);
+    CHK(ntt_list(c, c->scratch[0], c->scratch[2], rows, c0->batch, true));
+  }
+  std::vector<int> owner;
+  CHK(break_digits_coef(c, c->scratch[2], c0->prime_idx, dig_idx, dig_off, ndig, W->row_idx,
+                        c->scratch[1], rw, /*copy_own=*/false, &owner));
+  // forward NTT of the extension rows only: D*(L+K) - L transforms, as in the reference
+  {
+    std::vector<std::pair<int, int>> rows;
+    for (int d = 0; d < ndig; d++)
+      for (int r = 0; r < nall; r++)
+        if (owner[r] != d)
+          rows.emplace_back(d * nall + r, W->row_idx[r]);
+    CHK(ntt_list(c, c->scratch[1], c->scratch[1], rows, c0->batch, false));
+  }
+  std::vector<std::vector<int>> dprimes(ndig);
+  for (int d = 0; d < ndig; d++)
+    dprimes[d].assign(dig_idx + dig_off[d], dig_idx + dig_off[d + 1]);
+  CHK(keyswitch_launch(c, c->scratch[1], W, W->row_idx, c0->batch, out0->d, out1->d, L,
+                       c->scratch[0], &owner, &dprimes));
   return HX_OK;
 }
 

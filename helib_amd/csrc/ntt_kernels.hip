@@ -30,19 +30,25 @@ __device__ v2i32 hx_buffer_load_v2(v4i32 rsrc, int voffset, int soffset,
 __device__ void hx_buffer_store_v2(v2i32 data, v4i32 rsrc, int voffset, int soffset,
                                    int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
 
+__device__ __forceinline__ v4i32 make_rsrc(const uint64_t* row, unsigned bytes)
+{
+  uint64_t a = (uint64_t)row;
+  v4i32 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  r.z = (int)bytes;
+  r.w = 0x00020000;  // gfx9 family: raw buffer, dword elements
+  return r;
+}
 struct BufIO {
-  v4i32 rsrc;
-  __device__ BufIO(const uint64_t* row, unsigned bytes)
+  v4i32 rin, rout;
+  __device__ BufIO(const uint64_t* in_row, uint64_t* out_row, unsigned bytes)
+      : rin(make_rsrc(in_row, bytes)), rout(make_rsrc(out_row, bytes))
   {
-    uint64_t a = (uint64_t)row;
-    rsrc.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-    rsrc.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
-    rsrc.z = (int)bytes;
-    rsrc.w = 0x00020000;  // gfx9 family: raw buffer, dword elements
   }
   __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
   {
-    v2i32 r = hx_buffer_load_v2(rsrc, (int)(tid * 8u), (int)(c * 8u), 0);
+    v2i32 r = hx_buffer_load_v2(rin, (int)(tid * 8u), (int)(c * 8u), 0);
     return ((uint64_t)(uint32_t)r.y << 32) | (uint32_t)r.x;
   }
   __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t v) const
@@ -50,29 +56,30 @@ struct BufIO {
     v2i32 d;
     d.x = (int)(uint32_t)v;
     d.y = (int)(uint32_t)(v >> 32);
-    hx_buffer_store_v2(d, rsrc, (int)(tid * 8u), (int)(c * 8u), 0);
+    hx_buffer_store_v2(d, rout, (int)(tid * 8u), (int)(c * 8u), 0);
   }
 };
 
 template <int LOGN, bool INV>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
-ntt_row_kernel(uint64_t* __restrict__ data, RowMap map, int period, int row0, int batch,
+ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
                const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   using R = RowNTT<LOGN>;
   const unsigned tid = threadIdx.x;
-  const int row = row0 + (int)(blockIdx.x / (unsigned)batch);
+  const unsigned ri = blockIdx.x / (unsigned)batch;
   const int b = (int)(blockIdx.x % (unsigned)batch);
-  const PrimeDev* pd = primes + map.p[row % period];
-  uint64_t* ptr = data + ((size_t)row * batch + b) * (size_t)Geo<LOGN>::N;
+  const int row = rows.row[ri];
+  const PrimeDev* pd = primes + rows.prime[ri];
+  const size_t roff = ((size_t)row * batch + b) * (size_t)Geo<LOGN>::N;
   const TW* tw = tw_arena + (INV ? pd->tw_inv_off : pd->tw_fwd_off);
   const uint64_t q = pd->q;
 
 #ifdef HX_NTT_PTRIO
-  const PtrIO io{ptr, ptr};
+  const PtrIO io{in + roff, out + roff};
 #else
-  const BufIO io(ptr, (unsigned)Geo<LOGN>::N * 8u);
+  const BufIO io(in + roff, out + roff, (unsigned)Geo<LOGN>::N * 8u);
 #endif
   uint64_t v[32];
   uint32_t nl[32];
@@ -112,9 +119,8 @@ ntt_row_kernel(uint64_t* __restrict__ data, RowMap map, int period, int row0, in
 }
 
 template <int LOGN, bool INV>
-static hipError_t launch_one(uint64_t* data, const RowMap& map, int period, int row0, int nrows,
-                             int batch, const PrimeDev* primes, const TW* tw_arena,
-                             hipStream_t st)
+static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows,
+                             int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
 {
   constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
   static bool attr_set = false;
@@ -126,26 +132,27 @@ static hipError_t launch_one(uint64_t* data, const RowMap& map, int period, int 
     attr_set = true;
   }
   dim3 grid((unsigned)nrows * (unsigned)batch), block(Geo<LOGN>::T);
-  hipLaunchKernelGGL((ntt_row_kernel<LOGN, INV>), grid, block, lds_bytes, st, data, map, period,
-                     row0, batch, primes, tw_arena);
+  hipLaunchKernelGGL((ntt_row_kernel<LOGN, INV>), grid, block, lds_bytes, st, in, out, rows, batch,
+                     primes, tw_arena);
   return hipGetLastError();
 }
 
-// entry point used by engine.hip
-hipError_t launch_ntt_pow2(int logn, bool inverse, uint64_t* data, const RowMap& map, int period,
-                           int row0, int nrows, int batch, const PrimeDev* primes,
+// entry point used by engine.hip: transform `nrows` (<= MAX_ROWS) listed rows, in -> out
+// (in == out allowed: a workgroup reads its whole row before it writes it).
+hipError_t launch_ntt_pow2(int logn, bool inverse, const uint64_t* in, uint64_t* out,
+                           const NttRows& rows, int nrows, int batch, const PrimeDev* primes,
                            const TW* tw_arena, hipStream_t st)
 {
   switch (logn) {
     case 13:
-      return inverse ? launch_one<13, true>(data, map, period, row0, nrows, batch, primes, tw_arena, st)
-                     : launch_one<13, false>(data, map, period, row0, nrows, batch, primes, tw_arena, st);
+      return inverse ? launch_one<13, true>(in, out, rows, nrows, batch, primes, tw_arena, st)
+                     : launch_one<13, false>(in, out, rows, nrows, batch, primes, tw_arena, st);
     case 14:
-      return inverse ? launch_one<14, true>(data, map, period, row0, nrows, batch, primes, tw_arena, st)
-                     : launch_one<14, false>(data, map, period, row0, nrows, batch, primes, tw_arena, st);
+      return inverse ? launch_one<14, true>(in, out, rows, nrows, batch, primes, tw_arena, st)
+                     : launch_one<14, false>(in, out, rows, nrows, batch, primes, tw_arena, st);
     case 15:
-      return inverse ? launch_one<15, true>(data, map, period, row0, nrows, batch, primes, tw_arena, st)
-                     : launch_one<15, false>(data, map, period, row0, nrows, batch, primes, tw_arena, st);
+      return inverse ? launch_one<15, true>(in, out, rows, nrows, batch, primes, tw_arena, st)
+                     : launch_one<15, false>(in, out, rows, nrows, batch, primes, tw_arena, st);
   }
   return hipErrorInvalidValue;
 }

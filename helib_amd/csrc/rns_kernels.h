@@ -158,12 +158,24 @@ tensor_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
 //   out0[r] += sum_d dig[d][r] * kb[d][r] ; out1[r] += sum_d dig[d][r] * ka[d][r]
 // dig: [ndig][nall][batch][N]; kb/ka: [ndig][nall][N] (shared by the batch).
 // =====================================================================
+// Optional own-row reconstruction: digit `owner` of a ctxt row is not stored in `dig`; it is
+//   own = (...((c - d_0) * P_0^-1 - d_1) * P_1^-1 ...)          (src/DoubleCRT.cpp:552-556)
+// in the evaluation domain, c = the s^2 part (own_src), d_e = the earlier digits' extension
+// rows that the accumulation reads anyway -- so those 16 rows are neither written, transformed
+// nor re-read.
+constexpr int KS_MAXD = 8;
+struct KsFix {
+  int64_t owner;        // digit owning this row, -1 for special primes
+  TW pinv[KS_MAXD];     // P_e^-1 mod q_row for e < owner
+};
+
 __global__ void __launch_bounds__(256)
 keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ kb,
                  const uint64_t* __restrict__ ka, uint64_t* __restrict__ out0,
                  uint64_t* __restrict__ out1, RowMap map, int ndig, int nall, int batch,
                  uint32_t n, int accumulate_rows /* rows < this accumulate, others overwrite */,
-                 const PrimeDev* __restrict__ primes)
+                 const PrimeDev* __restrict__ primes, const uint64_t* __restrict__ own_src,
+                 const KsFix* __restrict__ fix)
 {
   const int row = blockIdx.y;
   const PrimeDev pd = primes[map.p[row]];
@@ -183,9 +195,23 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
       acc0 = make_ulonglong2(0, 0);
       acc1 = make_ulonglong2(0, 0);
     }
+    const int owner = fix ? (int)fix[row].owner : -1;
+    ulonglong2 own = make_ulonglong2(0, 0);
+    if (owner >= 0)
+      own = *reinterpret_cast<const ulonglong2*>(own_src + (size_t)row * row_words + e);
     for (int d = 0; d < ndig; d++) {
       const size_t dr = (size_t)d * nall + row;
-      ulonglong2 x = *reinterpret_cast<const ulonglong2*>(dig + dr * row_words + e);
+      ulonglong2 x;
+      if (d == owner) {
+        x = own;
+      } else {
+        x = *reinterpret_cast<const ulonglong2*>(dig + dr * row_words + e);
+        if (d < owner) {
+          const TW pi = fix[row].pinv[d];
+          own.x = mul_shoup(sub_mod(own.x, x.x, q), pi.w, pi.wp, q);
+          own.y = mul_shoup(sub_mod(own.y, x.y, q), pi.w, pi.wp, q);
+        }
+      }
       ulonglong2 b = *reinterpret_cast<const ulonglong2*>(kb + dr * n + j);
       ulonglong2 a = *reinterpret_cast<const ulonglong2*>(ka + dr * n + j);
       acc0.x = add_mod(acc0.x, mul_mod(x.x, b.x, q, mu, k), q);

@@ -188,9 +188,10 @@ int hx_intel_EltwiseMultModScalar(long* r, const long* a, long scalar, long n, l
 
 /* ---------------- measurement helpers ---------------- */
 /* Runs `iters` back-to-back launches of the forward (dir=0) or inverse (dir=1)
- * NTT kernel on p between two HIP events recorded on the context's stream and
- * returns the average kernel time in milliseconds (bench.py roofline leg). */
-int hx_time_ntt(hx_poly* p, int dir, int iters, float* avg_ms);
+ * NTT kernel on the first max_rows rows of p (0 = all rows) between two HIP
+ * events recorded on the context's stream and returns the average kernel time
+ * in milliseconds (bench.py roofline leg). */
+int hx_time_ntt(hx_poly* p, int dir, int iters, int max_rows, float* avg_ms);
 
 #ifdef __cplusplus
 }
