@@ -25,10 +25,28 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# default workload = BASELINE configs[2] (the configuration the metric is quoted on)
 M = 32768
 L, K = 16, 6
+CT_BITS, SP_BITS = 60, 56
 DIGITS = [list(range(0, 6)), list(range(6, 11)), list(range(11, 16))]
+WORKLOAD = ("BGV m=32768 N=16384 L=16x60b K=6x56b D=3 (6/5/5) "
+            "tensorProduct+reLinearize at fixed level")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def select_workload(name):
+    """bgv32768 (default, BASELINE configs[2]) or ckks65536 (configs[3]: m=65536, L=24, K=8,
+    D=3 x 8, SURVEY.md Appendix B `bits=1400`; the tensor+relinearise data path is identical,
+    CKKS only changes host-side bookkeeping)."""
+    global M, L, K, CT_BITS, SP_BITS, DIGITS, WORKLOAD
+    if name == "ckks65536":
+        M, L, K, CT_BITS, SP_BITS = 65536, 24, 8, 59, 59
+        DIGITS = [list(range(0, 8)), list(range(8, 16)), list(range(16, 24))]
+        WORKLOAD = ("CKKS m=65536 N=32768 L=24x59b K=8x59b D=3 (8/8/8) "
+                    "tensorProduct+reLinearize at fixed level")
+    elif name != "bgv32768":
+        raise SystemExit(f"unknown workload {name}")
 
 
 def gen_primes():
@@ -36,10 +54,13 @@ def gen_primes():
     Product-side code (helib_amd) supplies its own number theory; the oracle is only
     loaded for the cpu_baseline leg."""
     from helib_amd import hostnt
-    g = hostnt.PrimeGen(60, M)
+    g = hostnt.PrimeGen(CT_BITS, M)
     primes = [g.next() for _ in range(L)]
-    g2 = hostnt.PrimeGen(56, M)
-    primes += [g2.next() for _ in range(K)]
+    if SP_BITS == CT_BITS:
+        primes += [g.next() for _ in range(K)]
+    else:
+        g2 = hostnt.PrimeGen(SP_BITS, M)
+        primes += [g2.next() for _ in range(K)]
     return primes
 
 
@@ -89,7 +110,8 @@ def cpu_baseline(primes, sample_mults):
         octx.mul_relin(own, sp, DIGITS, *ops, kb, ka)
     dt = time.perf_counter() - t0
     return {"value": sample_mults / dt, "unit": "mult/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_mults} multiplies (tensor+relinearise) at m={M}, L={L}, K={K}, D=3; "
+            "sample": f"{sample_mults} multiplies (tensor+relinearise) at m={M}, L={L}, K={K}, "
+                      f"D={len(DIGITS)}; "
                       "CPU restatement of HElib 2.2.0 algorithms (not NTL), gcc -O3 -march=native, "
                       f"{dt:.1f} s"}
 
@@ -102,7 +124,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="independent ciphertext pairs per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=8, help="multiplies timed on the CPU (0 = skip)")
     ap.add_argument("--ntt-iters", type=int, default=20)
+    ap.add_argument("--workload", default="bgv32768", choices=["bgv32768", "ckks65536"])
     args = ap.parse_args()
+    select_workload(args.workload)
 
     import torch
     from helib_amd import dist as hdist
@@ -167,7 +191,7 @@ def main():
         ms_fwd = hx.time_ntt(dg, False, args.ntt_iters, nrows)
         bytes_launch = 16.0 * n * nrows * B             # 16*N bytes per row transform
         ach = bytes_launch / (ms_fwd * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "ntt_row_kernel<14,fwd>", "achieved": round(ach, 1),
+        roof = {"bound": "hbm", "kernel": f"ntt_row_kernel<{n.bit_length() - 1},fwd>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": None, "rows_per_launch": nrows * B,
                 "avg_launch_ms": round(ms_fwd, 4), "inverse_avg_launch_ms": round(ms_inv, 4),
@@ -182,8 +206,7 @@ def main():
             "unit": "mult/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BGV m=32768 N=16384 L=16x60b K=6x56b D=3 (6/5/5) "
-                                   "tensorProduct+reLinearize at fixed level",
+            "config": {"workload": WORKLOAD,
                        "batch_per_gpu": B, "parallelism": f"replica x{world}, batch-sharded",
                        "algorithmic_MB_per_mult": round(per_mult / 1e6, 2),
                        "hbm_roofline_mult_per_s_per_gpu": round(HBM_PEAK_GBS * 1e9 / per_mult, 0)},

@@ -72,6 +72,20 @@ __device__ __forceinline__ uint64_t mul_mod(uint64_t a, uint64_t b, uint64_t q, 
   r = r >= q ? r - q : r;
   return r >= q ? r - q : r;
 }
+// x mod q for a 128-bit x < 8*q^2 (sum of up to 8 products of residues), q < 2^60:
+// Barrett with the same mu; the quotient estimate is at most 10 short, fixed by
+// conditional subtractions.  Used to reduce once per accumulated inner product.
+__device__ __forceinline__ uint64_t red128_wide(u128 x, uint64_t q, uint64_t mu, uint32_t k)
+{
+  uint64_t xs = (uint64_t)(x >> (k - 1));            // < 2^(k+4) <= 2^64
+  uint64_t qh = (uint64_t)(((u128)xs * mu) >> (k + 1));
+  uint64_t r = (uint64_t)x - qh * q;                  // < 11q < 2^64
+  uint64_t q8 = q << 3, q4 = q << 2, q2 = q << 1;
+  r = r >= q8 ? r - q8 : r;
+  r = r >= q4 ? r - q4 : r;
+  r = r >= q2 ? r - q2 : r;
+  return r >= q ? r - q : r;
+}
 // x mod q for any 64-bit x.
 __device__ __forceinline__ uint64_t red64(uint64_t x, uint64_t q, uint64_t mu64)
 {

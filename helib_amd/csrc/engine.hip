@@ -306,6 +306,21 @@ static int upload_tw(hx_ctx* c, PrimeHost& ph)
   return HX_OK;
 }
 
+static int upload_tw_small(hx_ctx* c, PrimeHost& ph)
+{
+  const size_t N = (size_t)1 << c->logn;
+  std::vector<TW> f(N), i(N);
+  uint64_t ninv = hxh::invmod((uint64_t)N % ph.q, ph.q);
+  hx::build_tw_small(c->logn, ph.q, ph.root, ph.rinv, ninv, hxh::mulmod, f.data(), i.data());
+  CHK(tw_reserve(c, 2 * N));
+  ph.tw_fwd_off = c->tw_used;
+  ph.tw_inv_off = c->tw_used + N;
+  HIPCHK(hipMemcpy(c->d_tw + ph.tw_fwd_off, f.data(), sizeof(TW) * N, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_tw + ph.tw_inv_off, i.data(), sizeof(TW) * N, hipMemcpyHostToDevice));
+  c->tw_used += 2 * N;
+  return HX_OK;
+}
+
 extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_out)
 {
   if (!c)
@@ -334,7 +349,10 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
       case 13: CHK(upload_tw<13>(c, ph)); break;
       case 14: CHK(upload_tw<14>(c, ph)); break;
       case 15: CHK(upload_tw<15>(c, ph)); break;
-      default: break;  // element-wise / RNS ops still work; NTT reports UNSUPPORTED
+      default:
+        if (c->logn >= 1 && c->logn <= 12)
+          CHK(upload_tw_small(c, ph));
+        break;  // larger rings: element-wise / RNS ops still work; NTT reports UNSUPPORTED
     }
   }
   PrimeDev pd;
@@ -571,8 +589,8 @@ static int ntt_list(hx_ctx* c, const uint64_t* in, uint64_t* out,
     return HX_OK;
   if (!c->pow2)
     return fail(HX_ERR_UNSUPPORTED, "NTT for non-power-of-two m (Bluestein) is not built yet");
-  if (c->logn < 13 || c->logn > 15)
-    return fail(HX_ERR_UNSUPPORTED, "power-of-two NTT supports phi(m) in {8192,16384,32768}");
+  if (c->logn < 1 || c->logn > 15)
+    return fail(HX_ERR_UNSUPPORTED, "power-of-two NTT supports 2 <= phi(m) <= 32768");
   for (size_t first = 0; first < rows.size(); first += MAX_ROWS) {
     int n = (int)std::min<size_t>(MAX_ROWS, rows.size() - first);
     NttRows d;
@@ -920,6 +938,7 @@ static void clear_args(ExtArgs& a)
   a.src = nullptr;
   a.dst = nullptr;
   a.upd = nullptr;
+  a.nu = 0;
 }
 
 // ------------------------------------------------------------------
@@ -1106,9 +1125,15 @@ static int break_digits_coef(hx_ctx* c, uint64_t* coef, const std::vector<int>& 
     std::vector<int> src(dig_idx + dig_off[d], dig_idx + dig_off[d + 1]);
     if (src.empty())
       return fail(HX_ERR_INVALID, "empty digit");
+    // targets: first the rows owned by later digits (they are also updated in place), then
+    // the rest (earlier digits' rows and the special primes)
     std::vector<int> tgt;
     for (int r = 0; r < nall; r++)
-      if (owner[r] != d)
+      if (owner[r] > d)
+        tgt.push_back(all[r]);
+    int nu = (int)tgt.size();
+    for (int r = 0; r < nall; r++)
+      if (owner[r] < d)
         tgt.push_back(all[r]);
     ExtPlan* pl;
     CHK(get_plan(c, src, tgt, 0, &pl));
@@ -1128,8 +1153,75 @@ static int break_digits_coef(hx_ctx* c, uint64_t* coef, const std::vector<int>& 
       if (owner[pos] > d)
         args.upd_row[t] = (uint16_t)find_row(own, tgt[t]);
     }
+    args.nu = nu;
     CHK(launch_extend(c, pl, args, rw));
   }
+  if (owner_out)
+    *owner_out = owner;
+  return HX_OK;
+}
+
+// Fused variant for hx_mul_relin: digits are contiguous row runs of `own` (checked), own rows
+// are not materialised.  Returns HX_ERR_UNSUPPORTED when the shape does not fit (caller falls
+// back to break_digits_coef).
+static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector<int>& own,
+                              const int* dig_idx, const int* dig_off, int ndig,
+                              const std::vector<int>& all, uint64_t* dig, size_t rw,
+                              std::vector<int>* owner_out)
+{
+  const int L = (int)own.size(), nall = (int)all.size();
+  if (ndig > hx::KS_MAXD || L > 64 || dig_off[ndig] != L)
+    return HX_ERR_UNSUPPORTED;
+  for (int r = 0; r < L; r++)
+    if (all[r] != own[r] || dig_idx[r] != own[r])
+      return HX_ERR_UNSUPPORTED;  // digits must tile the operand's rows in order
+  int nmax = 0;
+  hx::BreakArgs A;
+  memset(&A, 0, sizeof A);
+  A.src = coef;
+  A.dst = dig;
+  A.L = L;
+  A.nall = nall;
+  A.ndig = ndig;
+  std::vector<int> owner(nall, -1);
+  for (int d = 0; d < ndig; d++) {
+    A.off[d] = dig_off[d];
+    int n = dig_off[d + 1] - dig_off[d];
+    if (n < 1 || n > 16)
+      return HX_ERR_UNSUPPORTED;
+    nmax = std::max(nmax, n);
+    std::vector<int> src(dig_idx + dig_off[d], dig_idx + dig_off[d + 1]), tgt;
+    for (int r = 0; r < nall; r++) {
+      if (r >= dig_off[d] && r < dig_off[d + 1])
+        owner[r] = d;
+      else
+        tgt.push_back(all[r]);
+    }
+    ExtPlan* pl;
+    CHK(get_plan(c, src, tgt, 0, &pl));
+    A.plan[d] = pl->dev;
+  }
+  A.off[ndig] = dig_off[ndig];
+  dim3 grid((unsigned)((rw + hx::BRK_THREADS - 1) / hx::BRK_THREADS)), block(hx::BRK_THREADS);
+  size_t lds = (size_t)L * hx::BRK_THREADS * 8;
+  if (nmax <= 8) {
+    static bool attr8 = false;
+    if (!attr8) {
+      HIPCHK(hipFuncSetAttribute((const void*)hx::break_digits_kernel<8>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
+      attr8 = true;
+    }
+    hipLaunchKernelGGL((hx::break_digits_kernel<8>), grid, block, lds, c->stream, A, rw);
+  } else {
+    static bool attr16 = false;
+    if (!attr16) {
+      HIPCHK(hipFuncSetAttribute((const void*)hx::break_digits_kernel<16>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
+      attr16 = true;
+    }
+    hipLaunchKernelGGL((hx::break_digits_kernel<16>), grid, block, lds, c->stream, A, rw);
+  }
+  HIPCHK(hipGetLastError());
   if (owner_out)
     *owner_out = owner;
   return HX_OK;
@@ -1274,6 +1366,10 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
   RowMap map;
   CHK(make_map(all, 0, nall, map));
   size_t rw = (size_t)batch * c->phim;
+  int lazy = W->ndig <= 8 ? 1 : 0;
+  for (int r : all)
+    if (hxh::bitlen(c->primes[r].q) > 60)
+      lazy = 0;
   const hx::KsFix* d_fix = nullptr;
   if (own_src) {
     // cached table: owner digit of every row and P_e^-1 mod q_row for the earlier digits
@@ -1314,7 +1410,7 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
   }
   hipLaunchKernelGGL(hx::keyswitch_kernel, ew_grid(rw, nall), dim3(256), 0, c->stream, dig, W->d_b,
                      W->d_a, out0, out1, map, W->ndig, nall, batch, c->phim, accumulate_rows,
-                     c->d_primes, own_src, d_fix);
+                     c->d_primes, own_src, d_fix, lazy);
   HIPCHK(hipGetLastError());
   return HX_OK;
 }
@@ -1380,8 +1476,15 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
     CHK(ntt_list(c, c->scratch[0], c->scratch[2], rows, c0->batch, true));
   }
   std::vector<int> owner;
-  CHK(break_digits_coef(c, c->scratch[2], c0->prime_idx, dig_idx, dig_off, ndig, W->row_idx,
-                        c->scratch[1], rw, /*copy_own=*/false, &owner));
+  {
+    int rc = break_digits_fused(c, c->scratch[2], c0->prime_idx, dig_idx, dig_off, ndig,
+                                W->row_idx, c->scratch[1], rw, &owner);
+    if (rc == HX_ERR_UNSUPPORTED)
+      rc = break_digits_coef(c, c->scratch[2], c0->prime_idx, dig_idx, dig_off, ndig, W->row_idx,
+                             c->scratch[1], rw, /*copy_own=*/false, &owner);
+    if (rc != HX_OK)
+      return rc;
+  }
   // forward NTT of the extension rows only: D*(L+K) - L transforms, as in the reference
   {
     std::vector<std::pair<int, int>> rows;

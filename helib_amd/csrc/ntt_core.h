@@ -514,4 +514,38 @@ inline void build_tw_tables(uint64_t q, uint64_t psi, uint64_t psi_inv, uint64_t
   delete[] ipw;
 }
 
+// ---------------------------------------------------------------------
+// Small transforms (N = 2^logn <= 4096): plain bit-reversed psi tables,
+//   fwd[idx] = psi^{brev_logn(idx)}, inv[idx] = psi^{-brev_logn(idx)}, 1 <= idx < N,
+//   inv[0] = N^-1.  Used by ntt_small_kernel (one workgroup, row resident in LDS).
+// ---------------------------------------------------------------------
+template <class MulMod>
+inline void build_tw_small(int logn, uint64_t q, uint64_t psi, uint64_t psi_inv, uint64_t n_inv,
+                           MulMod mulmod, TW* fwd, TW* inv)
+{
+  const int N = 1 << logn;
+  uint64_t* pw = new uint64_t[N];
+  uint64_t* ipw = new uint64_t[N];
+  pw[0] = ipw[0] = 1;
+  for (int i = 1; i < N; i++) {
+    pw[i] = mulmod(pw[i - 1], psi, q);
+    ipw[i] = mulmod(ipw[i - 1], psi_inv, q);
+  }
+  auto mk = [&](uint64_t w) {
+    TW t;
+    t.w = w;
+    t.wp = (uint64_t)((((unsigned __int128)w) << 64) / q);
+    return t;
+  };
+  fwd[0] = mk(0);
+  inv[0] = mk(n_inv);
+  for (int idx = 1; idx < N; idx++) {
+    unsigned e = brev_bits((unsigned)idx, logn);
+    fwd[idx] = mk(pw[e]);
+    inv[idx] = mk(ipw[e]);
+  }
+  delete[] pw;
+  delete[] ipw;
+}
+
 }  // namespace hx

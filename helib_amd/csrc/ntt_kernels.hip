@@ -137,12 +137,80 @@ static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& r
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------
+// Small rings (N = 2^logn <= 4096; the reference's own unit tests use phi(m) in
+// {8, 64, 256}, tests/TestHEXL.cpp:139-231): one workgroup per row, the row lives
+// in LDS as 64-bit words, one __syncthreads per stage.  Not a throughput kernel.
+// ---------------------------------------------------------------------
+template <bool INV>
+__global__ void __launch_bounds__(256)
+ntt_small_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch, int logn,
+                 const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
+{
+  extern __shared__ __attribute__((aligned(16))) uint64_t sm[];
+  const unsigned N = 1u << logn, tid = threadIdx.x, nth = blockDim.x;
+  const unsigned ri = blockIdx.x / (unsigned)batch;
+  const int b = (int)(blockIdx.x % (unsigned)batch);
+  const PrimeDev* pd = primes + rows.prime[ri];
+  const size_t roff = ((size_t)rows.row[ri] * batch + b) * (size_t)N;
+  const TW* tw = tw_arena + (INV ? pd->tw_inv_off : pd->tw_fwd_off);
+  const uint64_t q = pd->q, q2 = q + q;
+  const uint64_t* src = in + roff;
+  uint64_t* dst = out + roff;
+  for (unsigned i = tid; i < N; i += nth)
+    sm[INV ? (__brev(i) >> (32 - logn)) : i] = src[i];
+  __syncthreads();
+  if (!INV) {
+    for (int s = 0; s < logn; s++) {
+      const unsigned t = N >> (s + 1);
+      for (unsigned bf = tid; bf < N / 2; bf += nth) {
+        const unsigned g = bf >> (logn - 1 - s), j = bf & (t - 1), p = 2 * g * t + j;
+        ct_bfly(sm[p], sm[p + t], tw[(1u << s) + g], q, q2);
+      }
+      __syncthreads();
+    }
+    for (unsigned p = tid; p < N; p += nth)
+      dst[__brev(p) >> (32 - logn)] = norm4(sm[p], q, q2);
+  } else {
+    for (int s = logn - 1; s >= 0; s--) {
+      const unsigned t = N >> (s + 1);
+      for (unsigned bf = tid; bf < N / 2; bf += nth) {
+        const unsigned g = bf >> (logn - 1 - s), j = bf & (t - 1), p = 2 * g * t + j;
+        gs_bfly(sm[p], sm[p + t], tw[(1u << s) + g], q, q2);
+      }
+      __syncthreads();
+    }
+    const TW ninv = tw[0];
+    for (unsigned i = tid; i < N; i += nth)
+      dst[i] = norm2(shoup_lazy(sm[i], ninv, q), q);
+  }
+}
+
+static hipError_t launch_small(bool inverse, const uint64_t* in, uint64_t* out, const NttRows& rows,
+                               int nrows, int batch, int logn, const PrimeDev* primes,
+                               const TW* tw_arena, hipStream_t st)
+{
+  unsigned N = 1u << logn;
+  unsigned threads = N / 2 < 64 ? 64 : (N / 2 > 256 ? 256 : N / 2);
+  dim3 grid((unsigned)nrows * (unsigned)batch), block(threads);
+  size_t lds = (size_t)N * 8;
+  if (inverse)
+    hipLaunchKernelGGL(ntt_small_kernel<true>, grid, block, lds, st, in, out, rows, batch, logn,
+                       primes, tw_arena);
+  else
+    hipLaunchKernelGGL(ntt_small_kernel<false>, grid, block, lds, st, in, out, rows, batch, logn,
+                       primes, tw_arena);
+  return hipGetLastError();
+}
+
 // entry point used by engine.hip: transform `nrows` (<= MAX_ROWS) listed rows, in -> out
 // (in == out allowed: a workgroup reads its whole row before it writes it).
 hipError_t launch_ntt_pow2(int logn, bool inverse, const uint64_t* in, uint64_t* out,
                            const NttRows& rows, int nrows, int batch, const PrimeDev* primes,
                            const TW* tw_arena, hipStream_t st)
 {
+  if (logn >= 1 && logn <= 12)
+    return launch_small(inverse, in, out, rows, nrows, batch, logn, primes, tw_arena, st);
   switch (logn) {
     case 13:
       return inverse ? launch_one<13, true>(in, out, rows, nrows, batch, primes, tw_arena, st)

@@ -175,7 +175,7 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
                  uint64_t* __restrict__ out1, RowMap map, int ndig, int nall, int batch,
                  uint32_t n, int accumulate_rows /* rows < this accumulate, others overwrite */,
                  const PrimeDev* __restrict__ primes, const uint64_t* __restrict__ own_src,
-                 const KsFix* __restrict__ fix)
+                 const KsFix* __restrict__ fix, int lazy)
 {
   const int row = blockIdx.y;
   const PrimeDev pd = primes[map.p[row]];
@@ -199,6 +199,9 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
     ulonglong2 own = make_ulonglong2(0, 0);
     if (owner >= 0)
       own = *reinterpret_cast<const ulonglong2*>(own_src + (size_t)row * row_words + e);
+    // lazy inner product: 128-bit sums of the D products, ONE Barrett reduction per output word
+    // (q < 2^60 and D <= 8 => the sums stay below 2^123)
+    u128 s0x = 0, s0y = 0, s1x = 0, s1y = 0;
     for (int d = 0; d < ndig; d++) {
       const size_t dr = (size_t)d * nall + row;
       ulonglong2 x;
@@ -214,10 +217,23 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
       }
       ulonglong2 b = *reinterpret_cast<const ulonglong2*>(kb + dr * n + j);
       ulonglong2 a = *reinterpret_cast<const ulonglong2*>(ka + dr * n + j);
-      acc0.x = add_mod(acc0.x, mul_mod(x.x, b.x, q, mu, k), q);
-      acc0.y = add_mod(acc0.y, mul_mod(x.y, b.y, q, mu, k), q);
-      acc1.x = add_mod(acc1.x, mul_mod(x.x, a.x, q, mu, k), q);
-      acc1.y = add_mod(acc1.y, mul_mod(x.y, a.y, q, mu, k), q);
+      if (lazy) {
+        s0x += (u128)x.x * b.x;
+        s0y += (u128)x.y * b.y;
+        s1x += (u128)x.x * a.x;
+        s1y += (u128)x.y * a.y;
+      } else {
+        acc0.x = add_mod(acc0.x, mul_mod(x.x, b.x, q, mu, k), q);
+        acc0.y = add_mod(acc0.y, mul_mod(x.y, b.y, q, mu, k), q);
+        acc1.x = add_mod(acc1.x, mul_mod(x.x, a.x, q, mu, k), q);
+        acc1.y = add_mod(acc1.y, mul_mod(x.y, a.y, q, mu, k), q);
+      }
+    }
+    if (lazy) {
+      acc0.x = add_mod(acc0.x, red128_wide(s0x, q, mu, k), q);
+      acc0.y = add_mod(acc0.y, red128_wide(s0y, q, mu, k), q);
+      acc1.x = add_mod(acc1.x, red128_wide(s1x, q, mu, k), q);
+      acc1.y = add_mod(acc1.y, red128_wide(s1y, q, mu, k), q);
     }
     *reinterpret_cast<ulonglong2*>(out0 + (size_t)row * row_words + e) = acc0;
     *reinterpret_cast<ulonglong2*>(out1 + (size_t)row * row_words + e) = acc1;
@@ -263,6 +279,7 @@ struct ExtArgs {
   uint16_t own_dst_row[64];  // where to copy the source residue in dst (0xffff: no copy)
   uint16_t dst_row[MAX_ROWS];  // output row of target t inside dst
   uint16_t upd_row[MAX_ROWS];  // row inside upd to update (0xffff: none)
+  int nu;                    // targets [0,nu) are the ones with an upd_row (host orders them first)
 };
 
 template <int NMAX>
@@ -334,7 +351,7 @@ rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
   }
 
   // ---- residues modulo every target prime ----
-  for (int t = 0; t < P.nt; t++) {
+  auto residue = [&](int t) -> uint64_t {
     const uint64_t q = P.tgt_q[t], mu64 = P.tgt_mu64[t];
     const TW* Wt = P.W + (size_t)t * n;
     uint64_t acc = 0;
@@ -355,13 +372,104 @@ rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
       uint64_t corr = mul_mod(P.pmod[t], d, q, P.tgt_mu[t], P.tgt_k[t]);
       r = dm_negative ? add_mod(r, corr, q) : sub_mod(r, corr, q);
     }
+    return r;
+  };
+  // (preloading the read-modify-write rows up front measured slower than this simple loop)
+  for (int t = 0; t < P.nt; t++) {
+    const uint64_t q = P.tgt_q[t];
+    const uint64_t r = residue(t);
     if (A.dst_row[t] != 0xffff)
       A.dst[(size_t)A.dst_row[t] * row_words + i] = r;
     if (A.upd_row[t] != 0xffff) {
-      // digits[j] -= digits[i]; digits[j] /= pi   (src/DoubleCRT.cpp:552-556)
       uint64_t* u = A.upd + (size_t)A.upd_row[t] * row_words + i;
-      TW pinv = P.upd[t];
+      const TW pinv = P.upd[t];
       *u = mul_shoup(sub_mod(*u, r, q), pinv.w, pinv.wp, q);
+    }
+  }
+}
+
+// =====================================================================
+// breakIntoDigits, all digits in ONE pass over the coefficients
+// (src/DoubleCRT.cpp:479-561).  Each thread owns one coefficient of one batch
+// element: it reads the L residues of the s^2 part once into a private LDS
+// column, then for digit d = 0,1,..: Garner on the digit's own residues, centred
+// lift, residues modulo every other prime written straight to the digit block,
+// and the later digits' residues updated in LDS ("digits[j] -= digits[i];
+// digits[j] /= pi").  Algorithmic traffic: 8*N*(L + D*(L+K) - L) bytes.
+// Digits must be contiguous runs of the operand's rows (HElib's digits are).
+// =====================================================================
+constexpr int BRK_THREADS = 128;
+struct BreakArgs {
+  const uint64_t* src;   // coefficient rows of the operand, [L][batch][N]
+  uint64_t* dst;         // digit blocks, [ndig][nall][batch][N] (own rows are not written)
+  int L, nall, ndig;
+  int off[KS_MAXD + 1];  // digit d = rows [off[d], off[d+1])
+  ExtPlanDev plan[KS_MAXD];  // plan d: sources = digit d's primes, targets = all other rows, ascending
+};
+
+template <int NMAX>
+__global__ void __launch_bounds__(BRK_THREADS)
+break_digits_kernel(BreakArgs A, size_t row_words)
+{
+  extern __shared__ __attribute__((aligned(16))) uint64_t xs[];  // [L][BRK_THREADS]
+  const unsigned tid = threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * BRK_THREADS + tid;
+  if (i >= row_words)
+    return;
+  for (int r = 0; r < A.L; r++)
+    xs[r * BRK_THREADS + tid] = A.src[(size_t)r * row_words + i];
+  for (int d = 0; d < A.ndig; d++) {
+    const ExtPlanDev& P = A.plan[d];
+    const int n = P.n, off = A.off[d];
+    uint64_t a[NMAX];
+#pragma unroll
+    for (int k = 0; k < NMAX; k++) {
+      if (k < n) {
+        uint64_t x = xs[(off + k) * BRK_THREADS + tid];
+        const uint64_t pk = P.src_q[k], mk = P.src_mu64[k];
+#pragma unroll
+        for (int l = 0; l < NMAX; l++) {
+          if (l < k) {
+            uint64_t al = red64(a[l], pk, mk);
+            TW g = P.ginv[k * n + l];
+            x = mul_shoup(sub_mod(x, al, pk), g.w, g.wp, pk);
+          }
+        }
+        a[k] = x;
+      }
+    }
+    int cmp = 0;
+#pragma unroll
+    for (int k = NMAX - 1; k >= 0; k--) {
+      if (k < n && cmp == 0) {
+        uint64_t h = P.half[k];
+        cmp = a[k] > h ? 1 : (a[k] < h ? -1 : 0);
+      }
+    }
+    const bool neg = cmp > 0;
+    uint64_t* dd = A.dst + (size_t)d * A.nall * row_words + i;
+    for (int t = 0; t < P.nt; t++) {
+      const int r = t < off ? t : t + n;  // row of target t in the all-rows order
+      const uint64_t q = P.tgt_q[t], mu64 = P.tgt_mu64[t];
+      const TW* Wt = P.W + (size_t)t * n;
+      uint64_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < NMAX; k++) {
+        if (k < n) {
+          acc += shoup_lazy(a[k], Wt[k], q);
+          if ((k & 3) == 3)
+            acc = red64(acc, q, mu64);
+        }
+      }
+      uint64_t v = red64(acc, q, mu64);
+      if (neg)
+        v = sub_mod(v, P.pmod[t], q);
+      dd[(size_t)r * row_words] = v;
+      if (r >= off + n && r < A.L) {
+        const TW pinv = P.upd[t];
+        uint64_t* u = &xs[r * BRK_THREADS + tid];
+        *u = mul_shoup(sub_mod(*u, v, q), pinv.w, pinv.wp, q);
+      }
     }
   }
 }

@@ -341,3 +341,63 @@ def test_full_size_properties_m32768(hx):
         w0 = want[r, :, 0]
         want[r, :, 0] = np.where(w0 == 0, np.uint64(0), q - w0)
     assert np.array_equal(sh, want)
+
+
+# ---------------------------------------------------------------- small rings / HEXL shim
+@pytest.mark.parametrize("logn", list(range(1, 13)))
+def test_ntt_small_rings_match_oracle(hx, logn):
+    N = 1 << logn
+    m = 2 * N
+    primes = primes_for(m, 2, 50)
+    P = Pair(hx, m, primes)
+    x = P.rand([0, 1], 3, batch=3)
+    d = hx.DoubleCRT(P.g, [0, 1], 3, x)
+    got = d.FFT().download()
+    for b in range(3):
+        assert np.array_equal(got[:, b], P.o.fft([0, 1], x[:, b]))
+    assert np.array_equal(d.iFFT().download(), x)
+
+
+@pytest.mark.parametrize("phim,m", [(8, 16), (64, 128), (256, 512)])
+def test_CModulusFFT_like_TestHEXL(hx, phim, m):
+    # tests/TestHEXL.cpp:189-218: q = PrimeGenerator(HELIB_SP_NBITS, m).next(); FFT then iFFT of 5X
+    q = O.PrimeGen(60, m).next()
+    P = Pair(hx, m, [q])
+    assert P.N == phim
+    x = np.zeros((1, 1, phim), dtype=np.uint64)
+    x[0, 0, 1] = 5
+    d = hx.DoubleCRT(P.g, [0], 1, x)
+    y = d.FFT().download()
+    assert np.array_equal(y[0, 0], P.o.fft([0], x[:, 0])[0])
+    assert np.array_equal(d.iFFT().download(), x)
+
+
+def test_intel_shim_like_TestHEXL_hexlInUse(hx):
+    # tests/TestHEXL.cpp:139-156: intel::FFTFwd then FFTRev1 on N=64, q=769 is the identity
+    import ctypes as C
+    L = hx.lib()
+    N, q = 64, 769
+    a = (np.arange(N, dtype=np.int64) * 7 + 1) % q
+    out = np.zeros(N, dtype=np.int64)
+    assert L.hx_intel_FFTFwd(out.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), N, q) == 0
+    assert not np.array_equal(out, a)
+    cm = O.Cmod(2 * N, q)                       # same root rule: FindPrimRootT(q, 2n)
+    assert np.array_equal(out.astype(np.uint64), cm.fft(a.astype(np.uint64)))
+    back = np.zeros(N, dtype=np.int64)
+    assert L.hx_intel_FFTRev1(back.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), N, q) == 0
+    assert np.array_equal(back, a)
+    b = (np.arange(N, dtype=np.int64) * 13 + 5) % q
+    r = np.zeros(N, dtype=np.int64)
+    p = lambda v: v.ctypes.data_as(C.c_void_p)
+    assert L.hx_intel_EltwiseAddMod(p(r), p(a), p(b), N, q) == 0
+    assert np.array_equal(r, (a + b) % q)
+    assert L.hx_intel_EltwiseSubMod(p(r), p(a), p(b), N, q) == 0
+    assert np.array_equal(r, (a - b) % q)
+    assert L.hx_intel_EltwiseMultMod(p(r), p(a), p(b), N, q) == 0
+    assert np.array_equal(r, (a * b) % q)
+    assert L.hx_intel_EltwiseMultModScalar(p(r), p(a), 5, N, q) == 0
+    assert np.array_equal(r, (a * 5) % q)
+    assert L.hx_intel_EltwiseAddModScalar(p(r), p(a), 768, N, q) == 0
+    assert np.array_equal(r, (a + 768) % q)
+    assert L.hx_intel_EltwiseSubModScalar(p(r), p(a), 768, N, q) == 0
+    assert np.array_equal(r, (a - 768) % q)
