@@ -1,0 +1,174 @@
+// bluestein.h -- device side of Cmodulus::FFT / iFFT for general (non power-of-two) m:
+// HElib src/CModulus.cpp:431-443, :555-577 and src/bluestein.cpp:76-201.
+//
+//   forward : x_i *= powers[i]  ->  linear convolution with the chirp b  ->  window / fold
+//             -> *= powers[k]   ->  keep k in Z_m^* (increasing)
+//   inverse : scatter y onto Z_m^*  ->  the same with rInv  ->  rem Phi_m  ->  * m^-1
+//
+// The convolution (NTL fftRep in the reference) is a negacyclic NTT product of size
+// 2^bk >= 2m-1 on the row kernels (conv_core.h); "rem Phi_m" (reference: zz_pXModulus1,
+// src/NumbTh.cpp:1741-1804, two FFT multiplications with a precomputed inverse) uses
+// Phi_m * Psi = X^m - 1 with Phi_m palindromic, so rev(Phi_m)^-1 = -Psi mod X^m: the quotient
+// is rev(top(x) * (-Psi)) and the remainder x - Q*Phi_m, two more exact convolutions.
+// Included by engine.hip only.
+#pragma once
+#include "conv_core.h"
+#include "dev_common.h"
+
+namespace hx {
+
+// per (prime, conv size) constants
+struct ConvPrimeDev {
+  uint64_t q, mu, mu64;
+  uint32_t k, logn;
+  SplitTW S;           // only for split sizes
+};
+// per prime constants of the Bluestein transform
+struct BluePrimeDev {
+  uint64_t q;
+  const TW* powers;    // [m] root^(i^2)      (src/bluestein.cpp:94-98)
+  const TW* ipowers;   // [m] rInv^(i^2)
+  TW minv;             // m^-1 mod q          (src/CModulus.cpp:574-577)
+};
+struct PtrList {
+  const void* p[MAX_ROWS];
+};
+
+// cbuf[(ri*batch+b)][Nc] <- x_i * powers[i] (i < phim), 0 elsewhere.  in: poly rows [row][b][phim]
+__global__ void __launch_bounds__(256)
+blue_pre_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ cbuf, NttRows rows, PtrList bp,
+                int batch, uint32_t phim, uint32_t nc, int inverse_tables)
+{
+  const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
+  const BluePrimeDev* P = (const BluePrimeDev*)bp.p[ri];
+  const uint64_t q = P->q;
+  const TW* pw = inverse_tables ? P->ipowers : P->powers;
+  const uint64_t* src = in + ((size_t)rows.row[ri] * batch + b) * phim;
+  uint64_t* dst = cbuf + ((size_t)ri * batch + b) * nc;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += gridDim.x * blockDim.x)
+    dst[i] = i < phim ? shoup_full(src[i], pw[i], q) : 0;
+}
+
+// inverse direction: place y_j at index t_j of a length-m vector (src/CModulus.cpp:559-563)
+__global__ void __launch_bounds__(256)
+blue_scatter_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ cbuf, NttRows rows,
+                    PtrList bp, int batch, uint32_t phim, uint32_t m, uint32_t nc,
+                    const int32_t* __restrict__ zidx)
+{
+  const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
+  const BluePrimeDev* P = (const BluePrimeDev*)bp.p[ri];
+  const uint64_t q = P->q;
+  const uint64_t* src = in + ((size_t)rows.row[ri] * batch + b) * phim;
+  uint64_t* dst = cbuf + ((size_t)ri * batch + b) * nc;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += gridDim.x * blockDim.x) {
+    uint64_t v = 0;
+    if (i < m) {
+      int32_t j = zidx[i];
+      if (j >= 0)
+        v = shoup_full(src[j], P->ipowers[i], q);
+    }
+    dst[i] = v;
+  }
+}
+
+// window / fold + second twist.  gather != 0: forward transform, out = poly rows [row][b][phim]
+// holding X_k for k = zms[j]; gather == 0: inverse, out = xfull[(ri*batch+b)][mpad], all k < m.
+__global__ void __launch_bounds__(256)
+blue_post_kernel(const uint64_t* __restrict__ cbuf, uint64_t* __restrict__ out, NttRows rows, PtrList bp,
+                 int batch, uint32_t phim, uint32_t m, uint32_t nc, uint32_t mpad,
+                 const uint32_t* __restrict__ zms, int gather)
+{
+  const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
+  const BluePrimeDev* P = (const BluePrimeDev*)bp.p[ri];
+  const uint64_t q = P->q;
+  const TW* pw = gather ? P->powers : P->ipowers;
+  const uint64_t* h = cbuf + ((size_t)ri * batch + b) * nc;
+  uint64_t* dst = gather ? out + ((size_t)rows.row[ri] * batch + b) * phim
+                         : out + ((size_t)ri * batch + b) * mpad;
+  const uint32_t n = gather ? phim : m;
+  const bool odd = (m & 1u) != 0;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const uint32_t i = gather ? zms[j] : j;
+    // odd m : coefficients 0..2(m-1), folded mod x^m - 1  (src/bluestein.cpp:166-187)
+    // even m: coefficients m-1 .. 2(m-1)                   (src/bluestein.cpp:189-199)
+    uint64_t v = odd ? addm(h[i], h[i + m], q) : h[m - 1 + i];
+    dst[j] = shoup_full(v, pw[i], q);
+  }
+}
+
+// data[(u*batch+b)][n] *= hat_u[n]   (u = conv unit: a row, or a (row, quarter) pair)
+__global__ void __launch_bounds__(256)
+conv_pointwise_kernel(uint64_t* __restrict__ data, PtrList hats, PtrList cps, int units_per_row,
+                      int batch, uint32_t n)
+{
+  const unsigned u = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
+  const ConvPrimeDev* C = (const ConvPrimeDev*)cps.p[u / units_per_row];
+  const uint64_t q = C->q, mu = C->mu;
+  const uint32_t k = C->k;
+  const uint64_t* hat = (const uint64_t*)hats.p[u / units_per_row] + (size_t)(u % units_per_row) * n;
+  uint64_t* d = data + ((size_t)u * batch + b) * n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    d[i] = mul_mod(d[i], hat[i], q, mu, k);
+}
+
+// radix-4 split (conv_core.h): cbuf[(ri*batch+b)][4Q]  <->  qbuf[((ri*4+g)*batch+b)][Q]
+__global__ void __launch_bounds__(256)
+conv_split_kernel(uint64_t* __restrict__ cbuf, uint64_t* __restrict__ qbuf, PtrList cps, int batch,
+                  uint32_t Q, int inverse)
+{
+  const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
+  const ConvPrimeDev* C = (const ConvPrimeDev*)cps.p[ri];
+  const uint64_t q = C->q;
+  const SplitTW S = C->S;
+  uint64_t* c = cbuf + ((size_t)ri * batch + b) * 4 * Q;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < Q; p += gridDim.x * blockDim.x) {
+    uint64_t o[4];
+    if (!inverse) {
+      split_fwd4(c[p], c[p + Q], c[p + 2 * Q], c[p + 3 * Q], S, q, o);
+      for (int g = 0; g < 4; g++)
+        qbuf[(((size_t)ri * 4 + g) * batch + b) * Q + p] = o[g];
+    } else {
+      uint64_t in4[4];
+      for (int g = 0; g < 4; g++)
+        in4[g] = qbuf[(((size_t)ri * 4 + g) * batch + b) * Q + p];
+      split_inv4(in4, S, q, o);
+      c[p] = o[0];
+      c[p + Q] = o[1];
+      c[p + 2 * Q] = o[2];
+      c[p + 3 * Q] = o[3];
+    }
+  }
+}
+
+// dst[(ri*batch+b)][nd] <- k <= d ? src[(ri*batch+b)][base -/+ k] : 0   (reversal + zero padding)
+//   mode 0: top of x reversed : dst[k] = x[m-1-k]        (src stride mpad, base = m-1)
+//   mode 1: Q from rev_d(Q)   : dst[k] = s[d-k]          (src stride ns,   base = d)
+__global__ void __launch_bounds__(256)
+blue_rev_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int batch, uint32_t sstride,
+                uint32_t base, uint32_t d, uint32_t nd)
+{
+  const size_t seg = blockIdx.y;
+  const uint64_t* s = src + seg * sstride;
+  uint64_t* o = dst + seg * nd;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += gridDim.x * blockDim.x)
+    o[k] = k <= d ? s[base - k] : 0;
+}
+
+// out[row][b][i] = (xfull[i] - (Q*Phi)[i]) * m^-1,  i < phim     (rem Phi_m, then x *= mm_inv)
+__global__ void __launch_bounds__(256)
+blue_final_kernel(const uint64_t* __restrict__ xfull, const uint64_t* __restrict__ qphi,
+                  uint64_t* __restrict__ out, NttRows rows, PtrList bp, int batch, uint32_t phim,
+                  uint32_t mpad, uint32_t n2)
+{
+  const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
+  const BluePrimeDev* P = (const BluePrimeDev*)bp.p[ri];
+  const uint64_t q = P->q;
+  const TW minv = P->minv;
+  const uint64_t* x = xfull + ((size_t)ri * batch + b) * mpad;
+  const uint64_t* z = qphi + ((size_t)ri * batch + b) * n2;
+  uint64_t* dst = out + ((size_t)rows.row[ri] * batch + b) * phim;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < phim; i += gridDim.x * blockDim.x)
+    dst[i] = shoup_full(subm(x[i], z[i], q), minv, q);
+}
+
+}  // namespace hx

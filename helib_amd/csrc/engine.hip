@@ -15,6 +15,7 @@
 #include "../../include/helib_amd.h"
 #include "dev_common.h"
 #include "hostmath.h"
+#include "bluestein.h"
 #include "rns_kernels.h"
 
 namespace hx {
@@ -90,6 +91,20 @@ struct ExtPlan {
   void* blob = nullptr;
 };
 
+struct ConvPlan {  // negacyclic NTT of size 2^logn for one prime
+  int logn = 0;
+  bool split = false;
+  int pd[4] = {0, 0, 0, 0};  // indices into hx_ctx::d_cprimes
+  hx::ConvPrimeDev* dev = nullptr;
+};
+struct BluePrime {
+  hx::BluePrimeDev* dev = nullptr;
+  TW* d_powers = nullptr;
+  TW* d_ipowers = nullptr;
+  uint64_t* d_hat[4] = {nullptr, nullptr, nullptr, nullptr};  // Rb, iRb, NTT(-Psi), NTT(Phi)
+  ConvPlan conv[3];                                           // sizes bk, n1, n2
+};
+
 struct hx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -106,8 +121,16 @@ struct hx_ctx {
   int primes_cap = 0;
   TW* d_tw = nullptr;  // twiddle arena shared by all primes
   size_t tw_cap = 0, tw_used = 0;
-  uint64_t* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_words[4] = {0, 0, 0, 0};
+  uint64_t* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // general m (Bluestein): conv sizes 2^bk (chirp), 2^n1 / 2^n2 (rem Phi_m), pseudo "primes"
+  // (twiddle tables of the conv sizes) and per-prime tables
+  int bk = 0, n1 = 0, n2 = 0;
+  uint32_t dq = 0, mpad = 0;  // dq = m-1-phi(m) = deg of the quotient by Phi_m
+  PrimeDev* d_cprimes = nullptr;
+  int ncprimes = 0, cprimes_cap = 0;
+  std::vector<struct BluePrime*> blue;
+  std::vector<int64_t> psi_low, phi_coef;  // -Psi mod X^(dq+1) and Phi_m, small integers
   std::map<std::vector<uint64_t>, ExtPlan*> plans;
   // lifetime: polys and key-switch matrices keep their context alive, so the
   // handles may be destroyed in any order (hx_ctx_destroy only drops the
@@ -219,9 +242,23 @@ static void ctx_free(hx_ctx* c)
     hipFree(kv.second->blob);
     delete kv.second;
   }
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < 8; i++)
     if (c->scratch[i])
       hipFree(c->scratch[i]);
+  for (BluePrime* b : c->blue) {
+    if (!b)
+      continue;
+    hipFree(b->dev);
+    hipFree(b->d_powers);
+    hipFree(b->d_ipowers);
+    for (int i = 0; i < 4; i++)
+      hipFree(b->d_hat[i]);
+    for (int i = 0; i < 3; i++)
+      hipFree(b->conv[i].dev);
+    delete b;
+  }
+  if (c->d_cprimes)
+    hipFree(c->d_cprimes);
   hipFree(c->d_zms);
   hipFree(c->d_zms_index);
   hipFree(c->d_perm);
@@ -321,6 +358,428 @@ static int upload_tw_small(hx_ctx* c, PrimeHost& ph)
   return HX_OK;
 }
 
+// ------------------------------------------------------------------
+// general m: Bluestein tables and convolution plans
+// ------------------------------------------------------------------
+static int ntt_launch(hx_ctx* c, int logn, const PrimeDev* table, const uint64_t* in, uint64_t* out,
+                      const std::vector<std::pair<int, int>>& rows, int batch, bool inverse);
+static int ensure_scratch(hx_ctx* c, int slot, size_t words);
+
+static int next_pow2_exp(uint64_t n)  // NTL::NextPowerOfTwo: least k with 2^k >= n
+{
+  int k = 0;
+  while (((uint64_t)1 << k) < n)
+    k++;
+  return k;
+}
+
+// Phi_m(X) and Psi(X) = (X^m - 1)/Phi_m(X) over Z (small coefficients), by exact power-series
+// arithmetic on the products of (X^d - 1)^(mu(m/d)).
+static int mobius(uint64_t n)
+{
+  int mu = 1;
+  for (uint64_t p = 2; p * p <= n; p++)
+    if (n % p == 0) {
+      n /= p;
+      if (n % p == 0)
+        return 0;
+      mu = -mu;
+    }
+  return n > 1 ? -mu : mu;
+}
+static std::vector<int64_t> cyclo_product(uint64_t m, size_t len, bool want_phi)
+{
+  // want_phi: prod_{d|m} (X^d-1)^{mu(m/d)} ; else Psi = prod_{d|m, d<m} Phi_d = (X^m-1)/Phi_m
+  // computed as (X^m - 1) * prod (X^d-1)^{-mu(m/d)}; both truncated to `len` coefficients.
+  std::vector<int64_t> a(len, 0);
+  a[0] = 1;
+  auto mul = [&](uint64_t d) {  // *= (X^d - 1)
+    for (size_t i = len; i-- > 0;) {
+      int64_t v = -a[i];
+      if (i >= d)
+        v += a[i - d];
+      a[i] = v;
+    }
+  };
+  auto div = [&](uint64_t d) {  // /= (X^d - 1)
+    for (size_t i = 0; i < len; i++) {
+      int64_t v = -a[i];
+      if (i >= d)
+        v += a[i - d];
+      a[i] = v;
+    }
+  };
+  for (uint64_t d = 1; d <= m; d++) {
+    if (m % d)
+      continue;
+    int mu = mobius(m / d);
+    if (!want_phi)
+      mu = -mu;
+    if (mu == 1)
+      mul(d);
+  }
+  if (!want_phi)
+    mul(m);
+  for (uint64_t d = 1; d <= m; d++) {
+    if (m % d)
+      continue;
+    int mu = mobius(m / d);
+    if (!want_phi)
+      mu = -mu;
+    if (mu == -1)
+      div(d);
+  }
+  return a;
+}
+
+static int cprime_add(hx_ctx* c, uint64_t q, uint64_t fwd_off, uint64_t inv_off, int* idx)
+{
+  if (c->ncprimes == c->cprimes_cap) {
+    int ncap = c->cprimes_cap ? c->cprimes_cap * 2 : 256;
+    PrimeDev* nd = nullptr;
+    HIPCHK(hipMalloc((void**)&nd, sizeof(PrimeDev) * ncap));
+    if (c->d_cprimes) {
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipMemcpy(nd, c->d_cprimes, sizeof(PrimeDev) * c->ncprimes, hipMemcpyDeviceToDevice));
+      HIPCHK(hipFree(c->d_cprimes));
+    }
+    c->d_cprimes = nd;
+    c->cprimes_cap = ncap;
+  }
+  PrimeDev pd;
+  memset(&pd, 0, sizeof pd);
+  pd.q = q;
+  pd.q2 = 2 * q;
+  pd.k = (uint32_t)hxh::bitlen(q);
+  pd.mu = (uint64_t)((((hxh::u128)1) << (2 * pd.k)) / q);
+  pd.mu64 = (uint64_t)((((hxh::u128)1) << 64) / q);
+  pd.tw_fwd_off = fwd_off;
+  pd.tw_inv_off = inv_off;
+  HIPCHK(hipMemcpy(c->d_cprimes + c->ncprimes, &pd, sizeof pd, hipMemcpyHostToDevice));
+  *idx = c->ncprimes++;
+  return HX_OK;
+}
+
+static int tw_upload(hx_ctx* c, const std::vector<TW>& f, const std::vector<TW>& i, uint64_t* fo,
+                     uint64_t* io)
+{
+  CHK(tw_reserve(c, f.size() + i.size()));
+  *fo = c->tw_used;
+  *io = c->tw_used + f.size();
+  HIPCHK(hipMemcpy(c->d_tw + *fo, f.data(), sizeof(TW) * f.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_tw + *io, i.data(), sizeof(TW) * i.size(), hipMemcpyHostToDevice));
+  c->tw_used += f.size() + i.size();
+  return HX_OK;
+}
+
+template <int LOGQ>
+static int conv_tables_sub(hx_ctx* c, uint64_t q, uint64_t psi, int OUT, unsigned g, int* pd_idx)
+{
+  using G = hx::Geo<LOGQ>;
+  std::vector<TW> f(G::TW_TOTAL), i(G::TW_TOTAL);
+  uint64_t ninv = hxh::invmod((uint64_t)G::N % q, q);
+  hx::build_tw_tables_sub<LOGQ>(q, psi, hxh::invmod(psi, q), ninv, hxh::mulmod, OUT, g, f.data(),
+                                i.data());
+  uint64_t fo, io;
+  CHK(tw_upload(c, f, i, &fo, &io));
+  return cprime_add(c, q, fo, io, pd_idx);
+}
+
+// psi: primitive 2^(logn+1)-th root of unity mod q
+static int conv_plan_create(hx_ctx* c, uint64_t q, int logn, uint64_t psi, ConvPlan* pl)
+{
+  pl->logn = logn;
+  pl->split = logn > 15;
+  if (logn < 1 || logn > 17)
+    return fail(HX_ERR_UNSUPPORTED, "convolution size 2^%d not supported (m too large)", logn);
+  hx::ConvPrimeDev h;
+  memset(&h, 0, sizeof h);
+  h.q = q;
+  h.k = (uint32_t)hxh::bitlen(q);
+  h.mu = (uint64_t)((((hxh::u128)1) << (2 * h.k)) / q);
+  h.mu64 = (uint64_t)((((hxh::u128)1) << 64) / q);
+  h.logn = (uint32_t)logn;
+  if (logn <= 12) {
+    size_t N = (size_t)1 << logn;
+    std::vector<TW> f(N), i(N);
+    hx::build_tw_small(logn, q, psi, hxh::invmod(psi, q), hxh::invmod((uint64_t)N % q, q),
+                       hxh::mulmod, f.data(), i.data());
+    uint64_t fo, io;
+    CHK(tw_upload(c, f, i, &fo, &io));
+    CHK(cprime_add(c, q, fo, io, &pl->pd[0]));
+  } else if (!pl->split) {
+    switch (logn) {
+      case 13: CHK(conv_tables_sub<13>(c, q, psi, 0, 0, &pl->pd[0])); break;
+      case 14: CHK(conv_tables_sub<14>(c, q, psi, 0, 0, &pl->pd[0])); break;
+      case 15: CHK(conv_tables_sub<15>(c, q, psi, 0, 0, &pl->pd[0])); break;
+    }
+  } else {
+    for (unsigned g = 0; g < 4; g++) {
+      if (logn == 16)
+        CHK(conv_tables_sub<14>(c, q, psi, 2, g, &pl->pd[g]));
+      else
+        CHK(conv_tables_sub<15>(c, q, psi, 2, g, &pl->pd[g]));
+    }
+    auto mk = [&](uint64_t w) {
+      TW t;
+      t.w = w;
+      t.wp = hxh::shoup(w, q);
+      return t;
+    };
+    auto prev = [&](unsigned idx) { return hxh::powmod(psi, hx::brev_bits(idx, logn), q); };
+    uint64_t T1 = prev(1), T2 = prev(2), T3 = prev(3), quarter = hxh::invmod(4 % q, q);
+    h.S.T1 = mk(T1);
+    h.S.T2 = mk(T2);
+    h.S.T3 = mk(T3);
+    h.S.iT2 = mk(hxh::invmod(T2, q));
+    h.S.iT3 = mk(hxh::invmod(T3, q));
+    h.S.iT1q = mk(hxh::mulmod(hxh::invmod(T1, q), quarter, q));
+    h.S.quarter = mk(quarter);
+  }
+  HIPCHK(hipMalloc((void**)&pl->dev, sizeof h));
+  HIPCHK(hipMemcpy(pl->dev, &h, sizeof h, hipMemcpyHostToDevice));
+  return HX_OK;
+}
+
+static dim3 grid2(uint32_t n, size_t segs)
+{
+  unsigned bx = (n + 255) / 256;
+  if (bx > 64)
+    bx = 64;
+  if (bx < 1)
+    bx = 1;
+  return dim3(bx, (unsigned)segs);
+}
+
+// In-place convolution with a precomputed transform: buf[(ri*batch+b)][2^logn] (time domain)
+// <- buf * hat_ri.  hat_sel < 0: forward transform only (result left in transform order in buf,
+// or in qbuf for split sizes).  prime_of_row[ri] = context prime index; which = 0/1/2 (bk/n1/n2).
+static int conv_apply(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vector<int>& prime_of_row,
+                      int batch, int which, int hat_sel)
+{
+  const int R = (int)prime_of_row.size();
+  if (R == 0)
+    return HX_OK;
+  if (R > MAX_ROWS / 4)
+    return fail(HX_ERR_INVALID, "internal: conv chunk too large");
+  const ConvPlan& p0 = c->blue[prime_of_row[0]]->conv[which];
+  const int logn = p0.logn;
+  const bool split = p0.split;
+  const uint32_t N = 1u << logn;
+  hx::PtrList cps, hats;
+  for (int r = 0; r < R; r++) {
+    const BluePrime* bp = c->blue[prime_of_row[r]];
+    cps.p[r] = bp->conv[which].dev;
+    hats.p[r] = hat_sel >= 0 ? bp->d_hat[hat_sel] : nullptr;
+  }
+  std::vector<std::pair<int, int>> rows;
+  if (!split) {
+    for (int r = 0; r < R; r++)
+      rows.emplace_back(r, c->blue[prime_of_row[r]]->conv[which].pd[0]);
+    CHK(ntt_launch(c, logn, c->d_cprimes, buf, buf, rows, batch, false));
+    if (hat_sel < 0)
+      return HX_OK;
+    hipLaunchKernelGGL(hx::conv_pointwise_kernel, grid2(N, (size_t)R * batch), dim3(256), 0, c->stream,
+                       buf, hats, cps, 1, batch, N);
+    HIPCHK(hipGetLastError());
+    return ntt_launch(c, logn, c->d_cprimes, buf, buf, rows, batch, true);
+  }
+  const uint32_t Q = N / 4;
+  for (int r = 0; r < R; r++)
+    for (int g = 0; g < 4; g++)
+      rows.emplace_back(r * 4 + g, c->blue[prime_of_row[r]]->conv[which].pd[g]);
+  hipLaunchKernelGGL(hx::conv_split_kernel, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf,
+                     qbuf, cps, batch, Q, 0);
+  HIPCHK(hipGetLastError());
+  CHK(ntt_launch(c, logn - 2, c->d_cprimes, qbuf, qbuf, rows, batch, false));
+  if (hat_sel < 0)
+    return HX_OK;
+  hipLaunchKernelGGL(hx::conv_pointwise_kernel, grid2(Q, (size_t)R * 4 * batch), dim3(256), 0, c->stream,
+                     qbuf, hats, cps, 4, batch, Q);
+  HIPCHK(hipGetLastError());
+  CHK(ntt_launch(c, logn - 2, c->d_cprimes, qbuf, qbuf, rows, batch, true));
+  hipLaunchKernelGGL(hx::conv_split_kernel, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf,
+                     qbuf, cps, batch, Q, 1);
+  HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+
+// upload a time-domain polynomial (host, length <= 2^logn), transform it on the device with the
+// prime's own plan and keep the result as hat table `slot`
+static int make_hat(hx_ctx* c, int prime, int which, int slot, const std::vector<uint64_t>& poly)
+{
+  BluePrime* bp = c->blue[prime];
+  const int logn = bp->conv[which].logn;
+  const size_t N = (size_t)1 << logn;
+  CHK(ensure_scratch(c, 4, N));
+  CHK(ensure_scratch(c, 5, N));
+  std::vector<uint64_t> h(N, 0);
+  std::copy(poly.begin(), poly.end(), h.begin());
+  HIPCHK(hipMemcpyAsync(c->scratch[4], h.data(), N * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<int> pr(1, prime);
+  CHK(conv_apply(c, c->scratch[4], c->scratch[5], pr, 1, which, -1));
+  HIPCHK(hipMalloc((void**)&bp->d_hat[slot], N * 8));
+  HIPCHK(hipMemcpyAsync(bp->d_hat[slot], bp->conv[which].split ? c->scratch[5] : c->scratch[4], N * 8,
+                        hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return HX_OK;
+}
+
+// Cmodulus constructor, general-m branch (src/CModulus.cpp:140-181) + BluesteinInit x2
+static int blue_prime_create(hx_ctx* c, int idx)
+{
+  const PrimeHost& ph = c->primes[idx];
+  const uint64_t q = ph.q, m = c->m;
+  if (c->bk == 0) {
+    c->bk = next_pow2_exp(2 * m - 1);
+    c->dq = (uint32_t)(m - 1 - c->phim);
+    c->n1 = std::max(1, next_pow2_exp(2 * (uint64_t)c->dq + 1));
+    c->n2 = std::max(1, next_pow2_exp(m));
+    c->mpad = (uint32_t)((m + 1) & ~(uint64_t)1);
+    c->phi_coef = cyclo_product(m, c->phim + 1, true);
+    std::vector<int64_t> psi = cyclo_product(m, c->dq + 2, false);
+    c->psi_low.assign(psi.begin(), psi.begin() + c->dq + 1);
+  }
+  int maxk = std::max(c->bk, std::max(c->n1, c->n2));
+  if (maxk > 17)
+    return fail(HX_ERR_UNSUPPORTED, "m too large for the Bluestein path (conv size 2^%d)", maxk);
+  if ((q - 1) % ((uint64_t)1 << (maxk + 1)) != 0)
+    return fail(HX_ERR_UNSUPPORTED,
+                "Bluestein path needs 2^%d | q-1 (true for PrimeGenerator primes); q=%llu", maxk + 1,
+                (unsigned long long)q);
+  if ((int)c->blue.size() <= idx)
+    c->blue.resize(idx + 1, nullptr);
+  BluePrime* bp = new BluePrime();
+  c->blue[idx] = bp;
+  const uint64_t gen = hxh::find_prim_root(q, (uint64_t)1 << (maxk + 1));
+  const int sizes[3] = {c->bk, c->n1, c->n2};
+  for (int w = 0; w < 3; w++) {
+    uint64_t psi = hxh::powmod(gen, (uint64_t)1 << (maxk - sizes[w]), q);
+    CHK(conv_plan_create(c, q, sizes[w], psi, &bp->conv[w]));
+  }
+  // powers[i] = root^(i^2 mod e), chirp b (src/bluestein.cpp:76-132)
+  const uint64_t e = (m % 2 == 0) ? 2 * m : m;
+  std::vector<TW> pw(m), ipw(m);
+  const size_t NB = (size_t)1 << c->bk;
+  std::vector<uint64_t> b(NB, 0), ib(NB, 0);
+  for (uint64_t i = 0; i < m; i++) {
+    uint64_t isq = hxh::mulmod(i, i, e);
+    uint64_t v = hxh::powmod(ph.root, isq, q), iv = hxh::powmod(ph.rinv, isq, q);
+    pw[i].w = v;
+    pw[i].wp = hxh::shoup(v, q);
+    ipw[i].w = iv;
+    ipw[i].wp = hxh::shoup(iv, q);
+    // forward chirp uses rInv^(i^2) = iv, the inverse-direction chirp uses root^(i^2) = v
+    if (m == e) {
+      b[i] = iv;
+      ib[i] = v;
+    } else {
+      b[m - 1 + i] = iv;
+      b[m - 1 - i] = iv;
+      ib[m - 1 + i] = v;
+      ib[m - 1 - i] = v;
+    }
+  }
+  HIPCHK(hipMalloc((void**)&bp->d_powers, sizeof(TW) * m));
+  HIPCHK(hipMalloc((void**)&bp->d_ipowers, sizeof(TW) * m));
+  HIPCHK(hipMemcpy(bp->d_powers, pw.data(), sizeof(TW) * m, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(bp->d_ipowers, ipw.data(), sizeof(TW) * m, hipMemcpyHostToDevice));
+  hx::BluePrimeDev hd;
+  hd.q = q;
+  hd.powers = bp->d_powers;
+  hd.ipowers = bp->d_ipowers;
+  uint64_t minv = hxh::invmod(m % q, q);
+  hd.minv.w = minv;
+  hd.minv.wp = hxh::shoup(minv, q);
+  HIPCHK(hipMalloc((void**)&bp->dev, sizeof hd));
+  HIPCHK(hipMemcpy(bp->dev, &hd, sizeof hd, hipMemcpyHostToDevice));
+  CHK(make_hat(c, idx, 0, 0, b));
+  CHK(make_hat(c, idx, 0, 1, ib));
+  // rem Phi_m helpers: -Psi mod X^(dq+1) and Phi_m, reduced mod q
+  std::vector<uint64_t> npsi(c->dq + 1), phi(c->phim + 1);
+  for (size_t i = 0; i < npsi.size(); i++) {
+    int64_t v = -c->psi_low[i];
+    npsi[i] = v >= 0 ? (uint64_t)v % q : q - ((uint64_t)(-v) % q);
+    if (npsi[i] == q)
+      npsi[i] = 0;
+  }
+  for (size_t i = 0; i < phi.size(); i++) {
+    int64_t v = c->phi_coef[i];
+    phi[i] = v >= 0 ? (uint64_t)v % q : q - ((uint64_t)(-v) % q);
+    if (phi[i] == q)
+      phi[i] = 0;
+  }
+  CHK(make_hat(c, idx, 1, 2, npsi));
+  CHK(make_hat(c, idx, 2, 3, phi));
+  return HX_OK;
+}
+
+// Cmodulus::FFT_aux / iFFT, general-m branch, for the listed rows of a [rows][batch][phi] buffer
+static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
+                          const std::vector<std::pair<int, int>>& rows, int batch, bool inverse)
+{
+  const uint32_t phim = c->phim, m = (uint32_t)c->m;
+  const uint32_t NB = 1u << c->bk, N1 = 1u << c->n1, N2 = 1u << c->n2;
+  // chunk so that the convolution buffers stay below ~1 GiB each
+  size_t per_row = (size_t)batch * NB * 8;
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>(MAX_ROWS / 4, ((size_t)1 << 30) / per_row));
+  for (size_t first = 0; first < rows.size(); first += chunk) {
+    const int R = (int)std::min<size_t>(chunk, rows.size() - first);
+    NttRows nr;
+    hx::PtrList bp;
+    std::vector<int> pr(R);
+    for (int r = 0; r < R; r++) {
+      nr.row[r] = (uint16_t)rows[first + r].first;
+      nr.prime[r] = (uint16_t)rows[first + r].second;
+      pr[r] = rows[first + r].second;
+      if (pr[r] >= (int)c->blue.size() || !c->blue[pr[r]])
+        return fail(HX_ERR_INVALID, "prime %d has no Bluestein tables", pr[r]);
+      bp.p[r] = c->blue[pr[r]]->dev;
+    }
+    const size_t segs = (size_t)R * batch;
+    CHK(ensure_scratch(c, 4, segs * NB));
+    CHK(ensure_scratch(c, 5, segs * NB));
+    uint64_t* cbuf = c->scratch[4];
+    uint64_t* qbuf = c->scratch[5];
+    if (!inverse) {
+      hipLaunchKernelGGL(hx::blue_pre_kernel, grid2(NB, segs), dim3(256), 0, c->stream, in, cbuf, nr, bp,
+                         batch, phim, NB, 0);
+      HIPCHK(hipGetLastError());
+      CHK(conv_apply(c, cbuf, qbuf, pr, batch, 0, 0));
+      hipLaunchKernelGGL(hx::blue_post_kernel, grid2(phim, segs), dim3(256), 0, c->stream, cbuf, out, nr,
+                         bp, batch, phim, m, NB, c->mpad, c->d_zms, 1);
+      HIPCHK(hipGetLastError());
+      continue;
+    }
+    CHK(ensure_scratch(c, 6, segs * c->mpad));
+    CHK(ensure_scratch(c, 7, segs * std::max(N1, N2)));
+    uint64_t* xfull = c->scratch[6];
+    uint64_t* wbuf = c->scratch[7];
+    hipLaunchKernelGGL(hx::blue_scatter_kernel, grid2(NB, segs), dim3(256), 0, c->stream, in, cbuf, nr, bp,
+                       batch, phim, m, NB, c->d_zms_index);
+    HIPCHK(hipGetLastError());
+    CHK(conv_apply(c, cbuf, qbuf, pr, batch, 0, 1));
+    hipLaunchKernelGGL(hx::blue_post_kernel, grid2(m, segs), dim3(256), 0, c->stream, cbuf, xfull, nr, bp,
+                       batch, phim, m, NB, c->mpad, c->d_zms, 0);
+    HIPCHK(hipGetLastError());
+    // rem Phi_m: Q = rev_d( top(x) * (-Psi) mod X^(d+1) ), r = x - Q*Phi_m
+    hipLaunchKernelGGL(hx::blue_rev_kernel, grid2(N1, segs), dim3(256), 0, c->stream, xfull, wbuf, batch,
+                       c->mpad, m - 1, c->dq, N1);
+    HIPCHK(hipGetLastError());
+    CHK(conv_apply(c, wbuf, qbuf, pr, batch, 1, 2));
+    // Q (zero padded to N2) goes to cbuf, which is free again
+    hipLaunchKernelGGL(hx::blue_rev_kernel, grid2(N2, segs), dim3(256), 0, c->stream, wbuf, cbuf, batch, N1,
+                       c->dq, c->dq, N2);
+    HIPCHK(hipGetLastError());
+    CHK(conv_apply(c, cbuf, qbuf, pr, batch, 2, 3));
+    hipLaunchKernelGGL(hx::blue_final_kernel, grid2(phim, segs), dim3(256), 0, c->stream, xfull, cbuf, out,
+                       nr, bp, batch, phim, c->mpad, N2);
+    HIPCHK(hipGetLastError());
+  }
+  return HX_OK;
+}
+
 extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_out)
 {
   if (!c)
@@ -367,6 +826,13 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
   int idx = (int)c->primes.size();
   HIPCHK(hipMemcpy(c->d_primes + idx, &pd, sizeof pd, hipMemcpyHostToDevice));
   c->primes.push_back(ph);
+  if (!c->pow2) {
+    int rc = blue_prime_create(c, idx);
+    if (rc != HX_OK) {
+      c->primes.pop_back();
+      return rc;
+    }
+  }
   if (idx_out)
     *idx_out = idx;
   return HX_OK;
@@ -581,29 +1047,44 @@ static int make_map(const std::vector<int>& primes, int first, int count, RowMap
   return HX_OK;
 }
 
-// transform the listed (row, prime) pairs of a [rows][batch][N] buffer, in -> out
+// raw launch: listed (row, table-entry) pairs of a [rows][batch][2^logn] buffer, in -> out
+static int ntt_launch(hx_ctx* c, int logn, const PrimeDev* table, const uint64_t* in, uint64_t* out,
+                      const std::vector<std::pair<int, int>>& rows, int batch, bool inverse)
+{
+  if (rows.empty())
+    return HX_OK;
+  if (logn < 1 || logn > 15)
+    return fail(HX_ERR_UNSUPPORTED, "negacyclic NTT kernels support sizes 2..32768");
+  for (size_t first = 0; first < rows.size(); first += MAX_ROWS) {
+    int n = (int)std::min<size_t>(MAX_ROWS, rows.size() - first);
+    NttRows d;
+    for (int i = 0; i < n; i++) {
+      if (rows[first + i].first > 0xffff || rows[first + i].second > 0xffff)
+        return fail(HX_ERR_UNSUPPORTED, "row index too large for one launch descriptor");
+      d.row[i] = (uint16_t)rows[first + i].first;
+      d.prime[i] = (uint16_t)rows[first + i].second;
+    }
+    hipError_t e = hx::launch_ntt_pow2(logn, inverse, in, out, d, n, batch, table, c->d_tw, c->stream);
+    if (e != hipSuccess)
+      return fail(HX_ERR_DEVICE, "NTT launch failed: %s", hipGetErrorString(e));
+  }
+  return HX_OK;
+}
+
+static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
+                          const std::vector<std::pair<int, int>>& rows, int batch, bool inverse);
+
+// Cmodulus::FFT / iFFT on the listed (row, prime) pairs of a [rows][batch][phi(m)] buffer
 static int ntt_list(hx_ctx* c, const uint64_t* in, uint64_t* out,
                     const std::vector<std::pair<int, int>>& rows, int batch, bool inverse)
 {
   if (rows.empty())
     return HX_OK;
   if (!c->pow2)
-    return fail(HX_ERR_UNSUPPORTED, "NTT for non-power-of-two m (Bluestein) is not built yet");
+    return bluestein_rows(c, in, out, rows, batch, inverse);
   if (c->logn < 1 || c->logn > 15)
     return fail(HX_ERR_UNSUPPORTED, "power-of-two NTT supports 2 <= phi(m) <= 32768");
-  for (size_t first = 0; first < rows.size(); first += MAX_ROWS) {
-    int n = (int)std::min<size_t>(MAX_ROWS, rows.size() - first);
-    NttRows d;
-    for (int i = 0; i < n; i++) {
-      d.row[i] = (uint16_t)rows[first + i].first;
-      d.prime[i] = (uint16_t)rows[first + i].second;
-    }
-    hipError_t e = hx::launch_ntt_pow2(c->logn, inverse, in, out, d, n, batch, c->d_primes, c->d_tw,
-                                       c->stream);
-    if (e != hipSuccess)
-      return fail(HX_ERR_DEVICE, "NTT launch failed: %s", hipGetErrorString(e));
-  }
-  return HX_OK;
+  return ntt_launch(c, c->logn, c->d_primes, in, out, rows, batch, inverse);
 }
 
 // in place: rows [row0,row0+nrows); row r uses prime plist[r % period]

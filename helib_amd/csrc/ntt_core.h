@@ -462,17 +462,22 @@ struct RowNTT {
 // Host-side table builder (used by the library when a prime is registered and
 // by the CPU replay test).  psi = primitive 2N-th root of unity (w0).
 // mulmod/powmod/invmod are supplied by the caller (exact 128-bit arithmetic).
+// Generalised form: the tables of sub-transform `g` of a 2^(LOGN+OUT)-point transform whose
+// first OUT stages were done elsewhere (OUT = 0, g = 0: the plain transform).  After OUT
+// Cooley-Tukey stages the block with top bits g continues with the same network, its stage-s'
+// group-j butterflies using psi_rev_full[((2^OUT + g) << s') + j].
 template <int LOGN, class MulMod>
-inline void build_tw_tables(uint64_t q, uint64_t psi, uint64_t psi_inv, uint64_t n_inv,
-                            MulMod mulmod, TW* fwd, TW* inv)
+inline void build_tw_tables_sub(uint64_t q, uint64_t psi, uint64_t psi_inv, uint64_t n_inv,
+                                MulMod mulmod, int OUT, unsigned g, TW* fwd, TW* inv)
 {
   using G = Geo<LOGN>;
-  const int N = G::N;
+  const int FULL = LOGN + OUT;
+  const int NF = 1 << FULL;
   // pw[i] = psi^i, ipw[i] = psi^-i
-  uint64_t* pw = new uint64_t[N];
-  uint64_t* ipw = new uint64_t[N];
+  uint64_t* pw = new uint64_t[NF];
+  uint64_t* ipw = new uint64_t[NF];
   pw[0] = ipw[0] = 1;
-  for (int i = 1; i < N; i++) {
+  for (int i = 1; i < NF; i++) {
     pw[i] = mulmod(pw[i - 1], psi, q);
     ipw[i] = mulmod(ipw[i - 1], psi_inv, q);
   }
@@ -482,7 +487,13 @@ inline void build_tw_tables(uint64_t q, uint64_t psi, uint64_t psi_inv, uint64_t
     t.wp = (uint64_t)((((unsigned __int128)w) << 64) / q);
     return t;
   };
-  auto src = [&](unsigned idx) { return brev_bits(idx, LOGN); };
+  // local index (2^s' + j) -> exponent of psi
+  auto src = [&](unsigned idx) {
+    int sp = 31 - __builtin_clz(idx);
+    unsigned j = idx - (1u << sp);
+    unsigned full = (((1u << OUT) + g) << sp) + j;
+    return brev_bits(full, FULL);
+  };
   for (int i = 0; i < G::TW_TOTAL; i++) {
     fwd[i] = mk(0);
     inv[i] = mk(0);
@@ -512,6 +523,13 @@ inline void build_tw_tables(uint64_t q, uint64_t psi, uint64_t psi_inv, uint64_t
       }
   delete[] pw;
   delete[] ipw;
+}
+
+template <int LOGN, class MulMod>
+inline void build_tw_tables(uint64_t q, uint64_t psi, uint64_t psi_inv, uint64_t n_inv,
+                            MulMod mulmod, TW* fwd, TW* inv)
+{
+  build_tw_tables_sub<LOGN>(q, psi, psi_inv, n_inv, mulmod, 0, 0u, fwd, inv);
 }
 
 // ---------------------------------------------------------------------

@@ -74,3 +74,79 @@ extern "C" int ntt_replay(int logn, int inverse, uint64_t q, uint64_t psi, const
   }
   return -1;
 }
+
+// ---------------------------------------------------------------------------------------
+// CPU replay of the radix-4 split convolution (conv_core.h): c = a * b mod (X^(4Q) + 1) through
+// split_fwd4 + four Q-point sub-transforms (replayed kernel phases with build_tw_tables_sub
+// tables) + pointwise + inverse.  Checks the split math and the sub-transform twiddle tables.
+// ---------------------------------------------------------------------------------------
+#include "../../helib_amd/csrc/conv_core.h"
+
+template <int LOGQ>
+static void sub_transform(bool inverse, const hx::TW* tw, uint64_t q, const uint64_t* in, uint64_t* out)
+{
+  using G = hx::Geo<LOGQ>;
+  std::vector<uint64_t> V((size_t)G::T * 32);
+  std::vector<uint32_t> NL((size_t)G::T * 32);
+  std::vector<uint32_t> lds(G::LDS_WORDS, 0);
+  std::vector<uint64_t> inc(in, in + G::N);
+  run_phase<LOGQ, 0>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 1>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 2>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 3>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 4>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 5>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 6>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 7>(inverse, V, NL, lds, inc.data(), out, tw, q);
+}
+
+template <int LOGQ>
+static int split_conv(uint64_t q, uint64_t psi /* primitive 2^(LOGQ+3)-th root */, const uint64_t* a,
+                      const uint64_t* b, uint64_t* c)
+{
+  using G = hx::Geo<LOGQ>;
+  const int Q = G::N, FULL = LOGQ + 2;
+  uint64_t psi_inv = pw(psi, q - 2, q);
+  uint64_t qinv = pw((uint64_t)Q % q, q - 2, q);
+  std::vector<std::vector<hx::TW>> F(4, std::vector<hx::TW>(G::TW_TOTAL)), I(4, std::vector<hx::TW>(G::TW_TOTAL));
+  for (unsigned g = 0; g < 4; g++)
+    hx::build_tw_tables_sub<LOGQ>(q, psi, psi_inv, qinv, mm, 2, g, F[g].data(), I[g].data());
+  auto mk = [&](uint64_t w) { hx::TW t; t.w = w; t.wp = (uint64_t)((((u128)w) << 64) / q); return t; };
+  auto prev = [&](unsigned idx) { return pw(psi, hx::brev_bits(idx, FULL), q); };
+  hx::SplitTW S;
+  uint64_t T1 = prev(1), T2 = prev(2), T3 = prev(3), quarter = pw(4, q - 2, q);
+  S.T1 = mk(T1); S.T2 = mk(T2); S.T3 = mk(T3);
+  S.iT2 = mk(pw(T2, q - 2, q)); S.iT3 = mk(pw(T3, q - 2, q));
+  S.iT1q = mk(mm(pw(T1, q - 2, q), quarter, q)); S.quarter = mk(quarter);
+  std::vector<uint64_t> qa(4 * Q), qb(4 * Q), fa(4 * Q), fb(4 * Q);
+  for (int p = 0; p < Q; p++) {
+    uint64_t o[4];
+    hx::split_fwd4(a[p], a[p + Q], a[p + 2 * Q], a[p + 3 * Q], S, q, o);
+    for (int g = 0; g < 4; g++) qa[g * Q + p] = o[g];
+    hx::split_fwd4(b[p], b[p + Q], b[p + 2 * Q], b[p + 3 * Q], S, q, o);
+    for (int g = 0; g < 4; g++) qb[g * Q + p] = o[g];
+  }
+  for (int g = 0; g < 4; g++) {
+    sub_transform<LOGQ>(false, F[g].data(), q, qa.data() + g * Q, fa.data() + g * Q);
+    sub_transform<LOGQ>(false, F[g].data(), q, qb.data() + g * Q, fb.data() + g * Q);
+    for (int j = 0; j < Q; j++) fa[g * Q + j] = mm(fa[g * Q + j], fb[g * Q + j], q);
+    sub_transform<LOGQ>(true, I[g].data(), q, fa.data() + g * Q, qa.data() + g * Q);
+  }
+  for (int p = 0; p < Q; p++) {
+    uint64_t in4[4] = {qa[p], qa[Q + p], qa[2 * Q + p], qa[3 * Q + p]}, o[4];
+    hx::split_inv4(in4, S, q, o);
+    for (int g = 0; g < 4; g++) c[g * Q + p] = o[g];
+  }
+  return 0;
+}
+
+extern "C" int split_conv_replay(int logq, uint64_t q, uint64_t psi, const uint64_t* a, const uint64_t* b,
+                                 uint64_t* c)
+{
+  switch (logq) {
+    case 13: return split_conv<13>(q, psi, a, b, c);
+    case 14: return split_conv<14>(q, psi, a, b, c);
+    case 15: return split_conv<15>(q, psi, a, b, c);
+  }
+  return -1;
+}

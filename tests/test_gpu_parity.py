@@ -401,3 +401,77 @@ def test_intel_shim_like_TestHEXL_hexlInUse(hx):
     assert np.array_equal(r, (a + 768) % q)
     assert L.hx_intel_EltwiseSubModScalar(p(r), p(a), 768, N, q) == 0
     assert np.array_equal(r, (a - 768) % q)
+
+
+# ---------------------------------------------------------------- general m (Bluestein)
+@pytest.mark.parametrize("m", [105, 1705, 4369, 12, 20, 1000, 28])
+def test_bluestein_small_m_matches_oracle(hx, m):
+    primes = primes_for(m, 3, 60)
+    P = Pair(hx, m, primes)
+    idx = [0, 1, 2]
+    x = P.rand(idx, 5, batch=2)
+    d = hx.DoubleCRT(P.g, idx, 2, x)
+    got = d.FFT().download()
+    for b in range(2):
+        assert np.array_equal(got[:, b], P.o.fft(idx, x[:, b]))
+    y = P.rand(idx, 6, batch=2)
+    d.upload(y)
+    back = d.iFFT().download()
+    for b in range(2):
+        assert np.array_equal(back[:, b], P.o.ifft(idx, y[:, b]))
+    assert np.array_equal(d.FFT().download(), y)
+
+
+def test_bluestein_m21845_config5(hx):
+    """BASELINE configs[4]: bootstrapping-style m = 21845 = 5*17*257, phi = 16384, conv 2^16
+    (tests/GTestBootstrapping.cpp:113 parameters); forward + inverse DoubleCRT NTT bit-exact vs
+    the restatement of src/bluestein.cpp."""
+    m = 21845
+    primes = primes_for(m, 4, 60)
+    P = Pair(hx, m, primes)
+    assert P.N == 16384
+    idx = [0, 1, 2, 3]
+    x = P.rand(idx, 9, batch=2)
+    d = hx.DoubleCRT(P.g, idx, 2, x)
+    got = d.FFT().download()
+    for b in range(2):
+        assert np.array_equal(got[:, b], P.o.fft(idx, x[:, b]))
+    assert np.array_equal(d.iFFT().download(), x)          # round trip
+    y = P.rand(idx, 10, batch=1)
+    d1 = hx.DoubleCRT(P.g, idx, 1, y)
+    assert np.array_equal(d1.iFFT().download()[:, 0], P.o.ifft(idx, y[:, 0]))
+    # ring identity at full size: FFT(a)*FFT(b) = FFT(a*b mod Phi_m): X * a(X) with deg a < phi-1
+    a = x.copy()
+    a[:, :, -1] = 0
+    da = hx.DoubleCRT(P.g, idx, 2, a).FFT()
+    mono = np.zeros((4, 1, P.N), dtype=np.uint64)
+    mono[:, 0, 1] = 1
+    da *= hx.DoubleCRT(P.g, idx, 1, mono).FFT()
+    assert np.array_equal(da.iFFT().download(), np.roll(a, 1, axis=2))
+
+
+def test_general_m_multiply_relin_and_automorph(hx):
+    m = 1705                                    # 5*11*31, phi = 1200
+    L, K = 4, 2
+    digits = [[0, 1], [2, 3]]
+    P = Pair(hx, m, primes_for(m, L + K, 60))
+    own, sp = list(range(L)), list(range(L, L + K))
+    allp = own + sp
+    c0, c1, d0, d1 = (P.rand(own, s, 2) for s in (1, 2, 3, 4))
+    kb = np.stack([P.rand(allp, 20 + i)[:, 0] for i in range(2)])
+    ka = np.stack([P.rand(allp, 30 + i)[:, 0] for i in range(2)])
+    W = hx.KeySwitch(P.g, allp, kb, ka)
+    G = [hx.DoubleCRT(P.g, own, 2, x) for x in (c0, c1, d0, d1)]
+    o0, o1 = hx.multiplyBy(*G, W, digits)
+    for b in range(2):
+        w0, w1 = P.o.mul_relin(own, sp, digits, c0[:, b], c1[:, b], d0[:, b], d1[:, b], kb, ka)
+        assert np.array_equal(o0.download()[:, b], w0) and np.array_equal(o1.download()[:, b], w1)
+    o0.scaleDownToSet(own, 7)
+    assert np.array_equal(o0.download()[:, 0],
+                          P.o.scale_down(allp, P.o.mul_relin(own, sp, digits, c0[:, 0], c1[:, 0], d0[:, 0],
+                                                             d1[:, 0], kb, ka)[0], sp, 7))
+    zms = O.zmstar(m)
+    a = P.rand(own, 8, 1)
+    got = hx.DoubleCRT(P.g, own, 1, a).automorph(3).download()
+    for r in own:
+        assert np.array_equal(got[r, 0], O.automorph(a[r, 0], m, zms, 3))
