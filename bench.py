@@ -2,16 +2,25 @@
 """bench.py -- BASELINE.json metric on MI355X.
 
 metric   : ciphertext x ciphertext multiplications per second, including relinearisation
-           (Ctxt::multiplyBy data path: tensorProduct + reLinearize, benchmarks/bgv_basic.cpp:144-165)
-workload : BGV m=32768 (N=16384), L=16 x 60-bit ctxt primes, K=6 x 56-bit special primes,
-           D=3 digits (6/5/5) -- SURVEY.md Appendix B "bits=950" shape (BASELINE configs[2]).
-step     : one hx_mul_relin over a batch of independent ciphertext pairs resident in HBM.
+           (Ctxt::multiplyBy; timed region of benchmarks/bgv_basic.cpp:144-165)
+workload : (default `bgv32768`) BGV m=32768, p=65537, bits=950 -> L=16 x 60-bit ctxt primes,
+           K=6 x 56-bit special primes, 6 small primes, D=3 digits (6/5/5) -- SURVEY.md Appendix B
+           shape of BASELINE configs[2].  FRESH ciphertexts, the reference's own sequence:
+             multLowLvl  = bringToSet x2 (mod-up by a small prime, mod-down by a ctxt prime,
+                           4 parts) + tensorProduct
+             reLinearize = dropSmallAndSpecialPrimes (3 parts) + addPrimesAndScale + key switch
+           with the operand copy outside the timed region (state.PauseTiming() in the reference).
+           Host control flow = helib_amd.ctxt (restating src/Ctxt.cpp); polynomial work on the GPU.
+           `config.fixed_level_mult_per_s` additionally reports tensorProduct+reLinearize alone
+           (hx_mul_relin, no prime-set changes), the kernel-level pipeline DESIGN.md analyses.
+step     : one multiplyBy over a batch of independent ciphertext pairs resident in HBM.
 scaling  : weak -- every rank multiplies its own batch; no data-path collective
            (independent ciphertexts shard across GPUs).
+other    : --workload bgv32768_fixed (fixed-level only), ckks65536 (configs[3] shape, fixed level).
 
-Adds "roofline" for the dominant kernel (the forward NTT over the D*(L+K) digit rows, timed
-with HIP events on the launch stream) and "cpu_baseline" (the CPU oracle = a port of the
-reference algorithm, single thread, bounded sample).
+Adds "roofline" for the dominant kernel (forward NTT at the launch shape of the key switch,
+timed with HIP events on the launch stream) and "cpu_baseline" (the CPU oracle = a port of the
+reference algorithm driven through the same sequence, single thread, bounded sample).
 """
 import argparse
 import json
@@ -25,42 +34,33 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# default workload = BASELINE configs[2] (the configuration the metric is quoted on)
-M = 32768
-L, K = 16, 6
-CT_BITS, SP_BITS = 60, 56
-DIGITS = [list(range(0, 6)), list(range(6, 11)), list(range(11, 16))]
-WORKLOAD = ("BGV m=32768 N=16384 L=16x60b K=6x56b D=3 (6/5/5) "
-            "tensorProduct+reLinearize at fixed level")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
+# fixed-level shapes (prime indices 0..L-1 ctxt, L..L+K-1 special)
+SHAPES = {
+    "bgv32768_fixed": dict(M=32768, L=16, K=6, ct_bits=60, sp_bits=56,
+                           digits=[list(range(0, 6)), list(range(6, 11)), list(range(11, 16))],
+                           name="BGV m=32768 N=16384 L=16x60b K=6x56b D=3 (6/5/5) "
+                                "tensorProduct+reLinearize at fixed level"),
+    "ckks65536": dict(M=65536, L=24, K=8, ct_bits=59, sp_bits=59,
+                      digits=[list(range(0, 8)), list(range(8, 16)), list(range(16, 24))],
+                      name="CKKS m=65536 N=32768 L=24x59b K=8x59b D=3 (8/8/8) "
+                           "tensorProduct+reLinearize at fixed level"),
+}
+# module-level view of the default fixed shape (used by tools/prof_ntt.py)
+M, L, K = 32768, 16, 6
+DIGITS = SHAPES["bgv32768_fixed"]["digits"]
 
-def select_workload(name):
-    """bgv32768 (default, BASELINE configs[2]) or ckks65536 (configs[3]: m=65536, L=24, K=8,
-    D=3 x 8, SURVEY.md Appendix B `bits=1400`; the tensor+relinearise data path is identical,
-    CKKS only changes host-side bookkeeping)."""
-    global M, L, K, CT_BITS, SP_BITS, DIGITS, WORKLOAD
-    if name == "ckks65536":
-        M, L, K, CT_BITS, SP_BITS = 65536, 24, 8, 59, 59
-        DIGITS = [list(range(0, 8)), list(range(8, 16)), list(range(16, 24))]
-        WORKLOAD = ("CKKS m=65536 N=32768 L=24x59b K=8x59b D=3 (8/8/8) "
-                    "tensorProduct+reLinearize at fixed level")
-    elif name != "bgv32768":
-        raise SystemExit(f"unknown workload {name}")
 
-
-def gen_primes():
-    """PrimeGenerator(60, m) x L then PrimeGenerator(56, m) x K, roots by FindPrimRootT.
-    Product-side code (helib_amd) supplies its own number theory; the oracle is only
-    loaded for the cpu_baseline leg."""
+def gen_primes(shape=None):
+    """PrimeGenerator(ct_bits, m) x L then PrimeGenerator(sp_bits, m) x K (product-side helpers;
+    the oracle is only loaded for the cpu_baseline leg)."""
     from helib_amd import hostnt
-    g = hostnt.PrimeGen(CT_BITS, M)
-    primes = [g.next() for _ in range(L)]
-    if SP_BITS == CT_BITS:
-        primes += [g.next() for _ in range(K)]
-    else:
-        g2 = hostnt.PrimeGen(SP_BITS, M)
-        primes += [g2.next() for _ in range(K)]
+    sh = shape or SHAPES["bgv32768_fixed"]
+    g = hostnt.PrimeGen(sh["ct_bits"], sh["M"])
+    primes = [g.next() for _ in range(sh["L"])]
+    g2 = g if sh["sp_bits"] == sh["ct_bits"] else hostnt.PrimeGen(sh["sp_bits"], sh["M"])
+    primes += [g2.next() for _ in range(sh["K"])]
     return primes
 
 
@@ -71,8 +71,8 @@ def uniform_rows(rng, primes, idx, batch, n):
     return out
 
 
-def algorithmic_bytes_per_mult(n, l, k, d):
-    """compulsory traffic of one multiply at a fixed level."""
+def algorithmic_bytes_fixed(n, l, k, d):
+    """compulsory traffic of tensorProduct+reLinearize at a fixed level."""
     tensor = l * 56 * n                       # 4 parts in, 3 out (scaling fused)
     ntt = d * (l + k) * 16 * n                # L inverse + D(L+K)-L forward row transforms
     ext = d * (l + k) * 8 * n                 # read each digit's own rows once, write the extension rows
@@ -80,13 +80,23 @@ def algorithmic_bytes_per_mult(n, l, k, d):
     return tensor + ntt + ext + ks
 
 
-def cpu_baseline(primes, sample_mults):
-    """Oracle (port of the reference algorithm, -O3, 1 thread) on `sample_mults` multiplies."""
+def algorithmic_bytes_fresh(n, l, k, d):
+    """The reference sequence for fresh operands: + 4 parts x [mod-up scale 16n per row + mod-down
+    (drop 1 of l+1 rows): 1 inverse + l forward transforms, delta rows 8n, (c-delta)/D 24n per
+    kept row] + 3 parts x the same mod-down for dropping the small prime after the tensor product."""
+    def moddown(rows_before, dropped):
+        kept = rows_before - dropped
+        return (dropped + kept) * 16 * n + (dropped + kept) * 8 * n + kept * 24 * n
+    pre = 4 * (l * 16 * n + moddown(l + 1, 1))
+    mid = 3 * moddown(l, 1)
+    return pre + algorithmic_bytes_fixed(n, l, k, d) + mid
+
+
+def build_native_oracle():
     from oracle import oracle as O
     so_dir = os.path.join(ROOT, "oracle")
-    # a native-tuned build of the same C file, made on the machine that runs it
     native = os.path.join(so_dir, "liboracle_native.so")
-    try:
+    try:  # a native-tuned build of the same C file, made on the machine that runs it
         subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-shared", "-o",
                                native, os.path.join(so_dir, "hx_oracle.c"), "-lm"],
                               stderr=subprocess.DEVNULL)
@@ -94,26 +104,144 @@ def cpu_baseline(primes, sample_mults):
         O._LIB = None
     except Exception:
         pass
-    octx = O.Ctx(M)
+    return O
+
+
+def cpu_baseline_fixed(shape, primes, sample_mults):
+    O = build_native_oracle()
+    octx = O.Ctx(shape["M"])
     for q in primes:
         octx.add_prime(q)
-    own, sp = list(range(L)), list(range(L, L + K))
+    l, k = shape["L"], shape["K"]
+    own, sp = list(range(l)), list(range(l, l + k))
     allp = own + sp
     rng = np.random.default_rng(99)
     n = octx.N
-    kb = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in DIGITS])
-    ka = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in DIGITS])
+    kb = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in shape["digits"]])
+    ka = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in shape["digits"]])
     ops = [uniform_rows(rng, primes, own, 1, n)[:, 0] for _ in range(4)]
-    octx.mul_relin(own, sp, DIGITS, *ops, kb, ka)  # warm
+    octx.mul_relin(own, sp, shape["digits"], *ops, kb, ka)  # warm
     t0 = time.perf_counter()
     for _ in range(sample_mults):
-        octx.mul_relin(own, sp, DIGITS, *ops, kb, ka)
+        octx.mul_relin(own, sp, shape["digits"], *ops, kb, ka)
     dt = time.perf_counter() - t0
     return {"value": sample_mults / dt, "unit": "mult/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_mults} multiplies (tensor+relinearise) at m={M}, L={L}, K={K}, "
-                      f"D={len(DIGITS)}; "
-                      "CPU restatement of HElib 2.2.0 algorithms (not NTL), gcc -O3 -march=native, "
-                      f"{dt:.1f} s"}
+            "sample": f"{sample_mults} multiplies (tensorProduct+reLinearize, fixed level) at "
+                      f"m={shape['M']}, L={l}, K={k}, D={len(shape['digits'])}; CPU restatement of HElib "
+                      f"2.2.0 algorithms (not NTL), gcc -O3 -march=native, {dt:.1f} s"}
+
+
+def cpu_baseline_fresh(cc, sample_mults):
+    """The same multLowLvl+reLinearize sequence, host logic over the oracle backend."""
+    O = build_native_oracle()
+    from helib_amd import ctxt as hc
+    from oracle.backend import OKeySwitch, OPoly, OracleOps
+    octx = O.Ctx(cc.m)
+    for q in cc.primes:
+        octx.add_prime(q)
+    n = octx.N
+    rng = np.random.default_rng(98)
+    allp = cc.ctxtPrimes + cc.specialPrimes
+    D = len(cc.digits)
+    kb = np.stack([uniform_rows(rng, cc.primes, allp, 1, n)[:, 0] for _ in range(D)])
+    ka = np.stack([uniform_rows(rng, cc.primes, allp, 1, n)[:, 0] for _ in range(D)])
+    W = OKeySwitch(allp, kb, ka)
+    ops = OracleOps(octx)
+    base = [OPoly(octx, cc.ctxtPrimes, uniform_rows(rng, cc.primes, cc.ctxtPrimes, 1, n)[:, 0])
+            for _ in range(4)]
+    fa = hc.Ctxt.fresh(cc, ops, base[0], base[1], ksw=W)
+    fb = hc.Ctxt.fresh(cc, ops, base[2], base[3], ksw=W)
+
+    def one():
+        a, b = fa.clone(), fb.clone()
+        t0 = time.perf_counter()
+        a.multLowLvl(b, destructive=True)
+        a.reLinearize()
+        return time.perf_counter() - t0
+
+    one()
+    dt = sum(one() for _ in range(sample_mults))
+    return {"value": sample_mults / dt, "unit": "mult/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_mults} fresh-ciphertext multiplyBy (bringToSet x2, tensorProduct, "
+                      f"dropSmallAndSpecialPrimes, reLinearize) at m={cc.m}, bits=950; CPU restatement of "
+                      f"HElib 2.2.0 algorithms (not NTL), gcc -O3 -march=native, {dt:.1f} s"}
+
+
+def run_fixed(hx, ctx, primes, shape, B, steps, warmup, rng, sync, barrier):
+    l, k = shape["L"], shape["K"]
+    n = ctx.phim
+    own, sp = list(range(l)), list(range(l, l + k))
+    allp = own + sp
+    kb = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in shape["digits"]])
+    ka = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in shape["digits"]])
+    W = hx.KeySwitch(ctx, allp, kb, ka)
+    polys = [hx.DoubleCRT(ctx, own, B, uniform_rows(rng, primes, own, B, n)) for _ in range(4)]
+    out0, out1 = hx.DoubleCRT(ctx, allp, B), hx.DoubleCRT(ctx, allp, B)
+
+    def step():
+        hx.multiplyBy(*polys, W, shape["digits"], out0, out1)
+
+    for _ in range(warmup):
+        step()
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def run_fresh(hx, hc, cc, ctx, B, steps, warmup, rng, sync, barrier):
+    n = ctx.phim
+    allp = cc.ctxtPrimes + cc.specialPrimes
+    D = len(cc.digits)
+    kb = np.stack([uniform_rows(rng, cc.primes, allp, 1, n)[:, 0] for _ in range(D)])
+    ka = np.stack([uniform_rows(rng, cc.primes, allp, 1, n)[:, 0] for _ in range(D)])
+    W = hx.KeySwitch(ctx, allp, kb, ka)
+    base = [hx.DoubleCRT(ctx, cc.ctxtPrimes, B, uniform_rows(rng, cc.primes, cc.ctxtPrimes, B, n))
+            for _ in range(4)]
+    fa = hc.Ctxt.fresh(cc, hx, base[0], base[1], ksw=W)
+    fb = hc.Ctxt.fresh(cc, hx, base[2], base[3], ksw=W)
+    res = [None]
+
+    def one():
+        a, b = fa.clone(), fb.clone()   # untimed copies (state.PauseTiming() in the reference)
+        sync()
+        t0 = time.perf_counter()
+        a.multLowLvl(b, destructive=True)
+        a.reLinearize()
+        sync()
+        res[0] = a
+        return time.perf_counter() - t0
+
+    for _ in range(warmup):
+        one()
+    barrier()
+    dt = sum(one() for _ in range(steps))
+    barrier()
+    return dt, sorted(res[0].primeSet)
+
+
+def ntt_roofline(hx, ctx, primes_list, own, sp, digits, B, rng, iters):
+    """Forward NTT at the launch shape it has inside the key switch: D*(L+K)-L rows x B."""
+    n = ctx.phim
+    nrows = len(digits) * (len(own) + len(sp)) - len(own)
+    digp = hx.DoubleCRT(ctx, own, B, uniform_rows(rng, primes_list, own, B, n))
+    dg = digp.breakIntoDigits(digits, sp)          # D*(L+K) rows x B, evaluation domain
+    hx.time_ntt(dg, True, 2, nrows)                 # warm both directions
+    hx.time_ntt(dg, False, 2, nrows)
+    ms_inv = hx.time_ntt(dg, True, iters, nrows)
+    ms_fwd = hx.time_ntt(dg, False, iters, nrows)
+    bytes_launch = 16.0 * n * nrows * B             # SURVEY 8(d): 16*N bytes per row transform
+    ach = bytes_launch / (ms_fwd * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": f"ntt_row_kernel<{n.bit_length() - 1},fwd>",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "rows_per_launch": nrows * B,
+            "avg_launch_ms": round(ms_fwd, 4), "inverse_avg_launch_ms": round(ms_inv, 4),
+            "bytes_per_launch": bytes_launch}
 
 
 def main():
@@ -122,11 +250,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="independent ciphertext pairs per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="multiplies timed on the CPU (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=6, help="multiplies timed on the CPU (0 = skip)")
     ap.add_argument("--ntt-iters", type=int, default=20)
-    ap.add_argument("--workload", default="bgv32768", choices=["bgv32768", "ckks65536"])
+    ap.add_argument("--workload", default="bgv32768", choices=["bgv32768", "bgv32768_fixed", "ckks65536"])
     args = ap.parse_args()
-    select_workload(args.workload)
 
     import torch
     from helib_amd import dist as hdist
@@ -136,82 +263,77 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     torch.cuda.set_device(local_rank)
     group = hdist.Group(backend="nccl", device=torch.device("cuda", local_rank))
+    from helib_amd import capi as hx, ctxt as hc
 
-    from helib_amd import capi as hx
-
-    primes = gen_primes()
-    ctx = hx.Context(M, local_rank)
-    for q in primes:
-        ctx.add_prime(q)  # root = FindPrimRootT(q, m): the host-supplied root convention
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx.set_stream(stream)
-    n = ctx.phim
-    own, sp = list(range(L)), list(range(L, L + K))
-    allp = own + sp
     B = args.batch
     rng = np.random.default_rng(1234 + rank)
-    kb = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in DIGITS])
-    ka = np.stack([uniform_rows(rng, primes, allp, 1, n)[:, 0] for _ in DIGITS])
-    W = hx.KeySwitch(ctx, allp, kb, ka)
-    polys = [hx.DoubleCRT(ctx, own, B, uniform_rows(rng, primes, own, B, n)) for _ in range(4)]
-    out0 = hx.DoubleCRT(ctx, allp, B)
-    out1 = hx.DoubleCRT(ctx, allp, B)
+    sync = torch.cuda.synchronize
+    stream = torch.cuda.current_stream().cuda_stream
+    extra, roof, cpu = {}, None, None
 
-    def step():
-        hx.multiplyBy(*polys, W, DIGITS, out0, out1)
+    if args.workload == "bgv32768":
+        cc = hc.ChainContext(32768, 65537, 1, bits=950, c=3)
+        ctx = hx.Context(cc.m, local_rank)
+        for q in cc.primes:
+            ctx.add_prime(q)  # root = FindPrimRootT(q, m): the host-supplied root convention
+        ctx.set_stream(stream)
+        n = ctx.phim
+        l, k, d = len(cc.ctxtPrimes), len(cc.specialPrimes), len(cc.digits)
+        dt, res_primes = run_fresh(hx, hc, cc, ctx, B, args.steps, args.warmup, rng, sync, group.barrier)
+        dt = group.max_over_ranks(dt)
+        # the kernel-level pipeline alone (ctxt primes as rows 0.., specials after)
+        shape = dict(M=cc.m, L=l, K=k, digits=[[i - cc.ctxtPrimes[0] for i in dg] for dg in cc.digits])
+        sub = hx.Context(cc.m, local_rank)
+        fixed_primes = [cc.primes[i] for i in cc.ctxtPrimes + cc.specialPrimes]
+        for q in fixed_primes:
+            sub.add_prime(q)
+        sub.set_stream(stream)
+        dtf = run_fixed(hx, sub, fixed_primes, shape, B, args.steps, args.warmup, rng, sync, group.barrier)
+        dtf = group.max_over_ranks(dtf)
+        workload = ("BGV m=32768 p=65537 bits=950 (L=16x60b, K=6x56b, 6 small primes, D=3 6/5/5): "
+                    "Ctxt::multiplyBy on FRESH ciphertexts = multLowLvl (bringToSet x2 + tensorProduct) + "
+                    "reLinearize (dropSmallAndSpecialPrimes + key switch); operand copies untimed")
+        per_mult = algorithmic_bytes_fresh(n, l, k, d)
+        extra = {"fixed_level_mult_per_s": round(world * B * args.steps / dtf, 1),
+                 "fixed_level_ms_per_step": round(dtf / args.steps * 1e3, 4),
+                 "fixed_level_algorithmic_MB_per_mult": round(algorithmic_bytes_fixed(n, l, k, d) / 1e6, 2),
+                 "result_primes": res_primes}
+        if rank == 0:
+            roof = ntt_roofline(hx, sub, fixed_primes, list(range(l)), list(range(l, l + k)),
+                                shape["digits"], B, rng, args.ntt_iters)
+            if args.cpu_sample > 0 and world == 1:
+                cpu = cpu_baseline_fresh(cc, max(1, args.cpu_sample // 2))
+                cpu["fixed_level_value"] = cpu_baseline_fixed(
+                    dict(M=cc.m, L=l, K=k, digits=shape["digits"]), fixed_primes, args.cpu_sample)["value"]
+    else:
+        shape = SHAPES[args.workload]
+        primes = gen_primes(shape)
+        ctx = hx.Context(shape["M"], local_rank)
+        for q in primes:
+            ctx.add_prime(q)
+        ctx.set_stream(stream)
+        n = ctx.phim
+        l, k, d = shape["L"], shape["K"], len(shape["digits"])
+        dt = run_fixed(hx, ctx, primes, shape, B, args.steps, args.warmup, rng, sync, group.barrier)
+        dt = group.max_over_ranks(dt)
+        workload = shape["name"]
+        per_mult = algorithmic_bytes_fixed(n, l, k, d)
+        if rank == 0:
+            roof = ntt_roofline(hx, ctx, primes, list(range(l)), list(range(l, l + k)), shape["digits"], B,
+                                rng, args.ntt_iters)
+            if args.cpu_sample > 0 and world == 1:
+                cpu = cpu_baseline_fixed(shape, primes, args.cpu_sample)
 
-    barrier = group.barrier
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    dt = group.max_over_ranks(dt)
-    mults = world * B * args.steps
-    value = mults / dt
-
-    # ---- roofline of the dominant kernel: forward NTT over the digit rows ----
-    roof = None
-    cpu = None
     if rank == 0:
-        # the forward launch inside one multiply covers the D*(L+K)-L extension rows x B
-        nrows = len(DIGITS) * (L + K) - L
-        digp = hx.DoubleCRT(ctx, own, B, uniform_rows(rng, primes, own, B, n))
-        dg = digp.breakIntoDigits(DIGITS, sp)          # D*(L+K) rows x B, evaluation domain
-        hx.time_ntt(dg, True, 2, nrows)                 # warm both directions
-        hx.time_ntt(dg, False, 2, nrows)
-        ms_inv = hx.time_ntt(dg, True, args.ntt_iters, nrows)
-        ms_fwd = hx.time_ntt(dg, False, args.ntt_iters, nrows)
-        bytes_launch = 16.0 * n * nrows * B             # 16*N bytes per row transform
-        ach = bytes_launch / (ms_fwd * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": f"ntt_row_kernel<{n.bit_length() - 1},fwd>", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "rows_per_launch": nrows * B,
-                "avg_launch_ms": round(ms_fwd, 4), "inverse_avg_launch_ms": round(ms_inv, 4),
-                "bytes_per_launch": bytes_launch}
-        if args.cpu_sample > 0 and world == 1:
-            cpu = cpu_baseline(primes, args.cpu_sample)
-
-    if rank == 0:
-        per_mult = algorithmic_bytes_per_mult(n, L, K, len(DIGITS))
-        line = {
-            "metric": "ctxt_x_ctxt_mults_per_sec_incl_relinearize", "value": round(value, 1),
-            "unit": "mult/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": WORKLOAD,
-                       "batch_per_gpu": B, "parallelism": f"replica x{world}, batch-sharded",
-                       "algorithmic_MB_per_mult": round(per_mult / 1e6, 2),
-                       "hbm_roofline_mult_per_s_per_gpu": round(HBM_PEAK_GBS * 1e9 / per_mult, 0)},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
+        cfg = {"workload": workload, "batch_per_gpu": B, "parallelism": f"replica x{world}, batch-sharded",
+               "algorithmic_MB_per_mult": round(per_mult / 1e6, 2),
+               "hbm_roofline_mult_per_s_per_gpu": round(HBM_PEAK_GBS * 1e9 / per_mult, 0)}
+        cfg.update(extra)
+        line = {"metric": "ctxt_x_ctxt_mults_per_sec_incl_relinearize",
+                "value": round(world * B * args.steps / dt, 1), "unit": "mult/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+                "data": "synthetic", "config": cfg, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line))
     group.close()
 

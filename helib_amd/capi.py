@@ -45,6 +45,7 @@ SYMBOLS = [
     "hx_automorph", "hx_complex_conj",
     "hx_add_primes_and_scale", "hx_add_primes", "hx_scale_down", "hx_break_into_digits",
     "hx_ksk_create", "hx_ksk_destroy", "hx_tensor", "hx_key_switch_digits", "hx_mul_relin",
+    "hx_relinearize",
     "hx_intel_FFTFwd", "hx_intel_FFTRev1", "hx_intel_EltwiseAddMod", "hx_intel_EltwiseAddModScalar",
     "hx_intel_EltwiseSubMod", "hx_intel_EltwiseSubModScalar", "hx_intel_EltwiseMultMod",
     "hx_intel_EltwiseMultModScalar",
@@ -86,6 +87,7 @@ def lib():
             "hx_ksk_create": [vp, ip, vp, ip, vp, vp, vp], "hx_ksk_destroy": [vp],
             "hx_tensor": [vp] * 7, "hx_key_switch_digits": [vp] * 4,
             "hx_mul_relin": [vp, vp, vp, vp, vp, vp, vp, ip, vp, vp],
+            "hx_relinearize": [vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, vp],
             "hx_intel_FFTFwd": [vp, vp, C.c_long, C.c_long],
             "hx_intel_FFTRev1": [vp, vp, C.c_long, C.c_long],
             "hx_intel_EltwiseAddMod": [vp, vp, vp, C.c_long, C.c_long],
@@ -352,6 +354,20 @@ def multiplyBy(c0, c1, d0, d1, W, digits, out0=None, out1=None):
         out1 = DoubleCRT(ctx, c0.getIndexSet(), c0.batch)
     _chk(lib().hx_mul_relin(c0.h, c1.h, d0.h, d1.h, W.h, _p(dig_idx), _p(dig_off), len(digits),
                             out0.h, out1.h))
+    return out0, out1
+
+
+def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None):
+    """Ctxt::reLinearize data path for a 3-part ciphertext (1, s, s^2)."""
+    ctx = t0.context
+    dig_idx = _i32([p for d in digits for p in d])
+    dig_off = _i32(np.concatenate([[0], np.cumsum([len(d) for d in digits])]))
+    sp = _i32(list(special))
+    if out0 is None:
+        out0 = DoubleCRT(ctx, t0.getIndexSet(), t0.batch)
+        out1 = DoubleCRT(ctx, t0.getIndexSet(), t0.batch)
+    _chk(lib().hx_relinearize(t0.h, t1.h, t2.h, W.h, _p(dig_idx), _p(dig_off), len(digits), _p(sp),
+                              len(sp), out0.h, out1.h))
     return out0, out1
 
 

@@ -132,6 +132,11 @@ struct hx_ctx {
   std::vector<struct BluePrime*> blue;
   std::vector<int64_t> psi_low, phi_coef;  // -Psi mod X^(dq+1) and Phi_m, small integers
   std::map<std::vector<uint64_t>, ExtPlan*> plans;
+  // stream-ordered device-memory pool for poly slabs: every slab is used on the context's one
+  // stream only, so a freed slab can be handed out again without synchronising (hipMalloc /
+  // hipFree would serialise the device on every DoubleCRT temporary).
+  std::multimap<size_t, void*> pool;
+  size_t pool_bytes = 0;
   // lifetime: polys and key-switch matrices keep their context alive, so the
   // handles may be destroyed in any order (hx_ctx_destroy only drops the
   // caller's reference).
@@ -161,6 +166,42 @@ static int use(hx_ctx* c)
 {
   HIPCHK(hipSetDevice(c->device));
   return HX_OK;
+}
+
+static constexpr size_t POOL_GRAIN = (size_t)2 << 20;        // slabs are multiples of 2 MiB
+static constexpr size_t POOL_LIMIT = (size_t)64 << 30;        // keep at most 64 GiB cached
+static size_t pool_round(size_t bytes) { return (bytes + POOL_GRAIN - 1) / POOL_GRAIN * POOL_GRAIN; }
+static hipError_t pool_alloc(hx_ctx* c, size_t bytes, void** out)
+{
+  size_t sz = pool_round(bytes);
+  auto it = c->pool.find(sz);
+  if (it != c->pool.end()) {
+    *out = it->second;
+    c->pool.erase(it);
+    c->pool_bytes -= sz;
+    return hipSuccess;
+  }
+  hipError_t e = hipMalloc(out, sz);
+  if (e != hipSuccess && !c->pool.empty()) {  // release the cache and retry once
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pool)
+      hipFree(kv.second);
+    c->pool.clear();
+    c->pool_bytes = 0;
+    e = hipMalloc(out, sz);
+  }
+  return e;
+}
+static void pool_free(hx_ctx* c, void* p, size_t bytes)
+{
+  size_t sz = pool_round(bytes);
+  if (c->pool_bytes + sz > POOL_LIMIT) {
+    hipStreamSynchronize(c->stream);
+    hipFree(p);
+    return;
+  }
+  c->pool.emplace(sz, p);
+  c->pool_bytes += sz;
 }
 
 static int ensure_scratch(hx_ctx* c, int slot, size_t words)
@@ -245,6 +286,8 @@ static void ctx_free(hx_ctx* c)
   for (int i = 0; i < 8; i++)
     if (c->scratch[i])
       hipFree(c->scratch[i]);
+  for (auto& kv : c->pool)
+    hipFree(kv.second);
   for (BluePrime* b : c->blue) {
     if (!b)
       continue;
@@ -277,6 +320,11 @@ extern "C" int hx_ctx_set_stream(hx_ctx* c, void* s)
 {
   if (!c)
     return fail(HX_ERR_INVALID, "null context");
+  if (c->stream != (hipStream_t)s) {
+    // pooled slabs are recycled in stream order: drain the old stream before switching
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+  }
   c->stream = (hipStream_t)s;
   return HX_OK;
 }
@@ -867,6 +915,8 @@ static int poly_new(hx_ctx* c, int batch, const int* idx, int nrows, int cap, vo
     cap = nrows;
   if (cap < 1)
     cap = 1;
+  if (!wrap)
+    cap += 2;  // room for a mod-up by a couple of primes without reallocating
   hx_poly* p = new hx_poly();
   p->ctx = c;
   p->batch = batch;
@@ -877,14 +927,15 @@ static int poly_new(hx_ctx* c, int batch, const int* idx, int nrows, int cap, vo
     p->d = (uint64_t*)wrap;
   } else {
     size_t bytes = (size_t)cap * batch * c->phim * 8;
-    hipError_t e = hipMalloc((void**)&p->d, bytes);
+    hipError_t e = pool_alloc(c, bytes, (void**)&p->d);
     if (e != hipSuccess) {
       delete p;
       return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
-    e = hipMemsetAsync(p->d, 0, bytes, c->stream);
+    // DoubleCRT(context, set) is zero-initialised: only the live rows need it
+    e = hipMemsetAsync(p->d, 0, (size_t)nrows * batch * c->phim * 8, c->stream);
     if (e != hipSuccess) {
-      hipFree(p->d);
+      pool_free(c, p->d, bytes);
       delete p;
       return fail(HX_ERR_DEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
     }
@@ -910,10 +961,8 @@ extern "C" int hx_poly_destroy(hx_poly* p)
   if (!p)
     return HX_OK;
   hipSetDevice(p->ctx->device);
-  if (p->owns && p->d) {
-    hipStreamSynchronize(p->ctx->stream);
-    hipFree(p->d);
-  }
+  if (p->owns && p->d)
+    pool_free(p->ctx, p->d, (size_t)p->cap_rows * p->row_words() * 8);
   ctx_release(p->ctx);
   delete p;
   return HX_OK;
@@ -969,14 +1018,14 @@ static int poly_reserve(hx_poly* p, int cap)
     return fail(HX_ERR_NOMEM, "wrapped poly has no room for %d rows", cap);
   hx_ctx* c = p->ctx;
   uint64_t* nd = nullptr;
+  cap += 2;
   size_t bytes = (size_t)cap * p->row_words() * 8;
-  hipError_t e = hipMalloc((void**)&nd, bytes);
+  hipError_t e = pool_alloc(c, bytes, (void**)&nd);
   if (e != hipSuccess)
     return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
   HIPCHK(hipMemcpyAsync(nd, p->d, (size_t)p->nrows() * p->row_words() * 8,
                         hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipFree(p->d));
+  pool_free(c, p->d, (size_t)p->cap_rows * p->row_words() * 8);  // stream-ordered reuse
   p->d = nd;
   p->cap_rows = cap;
   return HX_OK;
@@ -1839,13 +1888,22 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
                             const std::vector<int>& all, int batch, uint64_t* out0, uint64_t* out1,
                             int accumulate_rows, const uint64_t* own_src = nullptr,
                             const std::vector<int>* owner = nullptr,
-                            const std::vector<std::vector<int>>* digit_primes = nullptr)
+                            const std::vector<std::vector<int>>* digit_primes = nullptr,
+                            int ndig = -1)
 {
   int nall = (int)all.size();
-  if (W->row_idx != all)
-    return fail(HX_ERR_PRIMESET, "key-switching matrix is not defined on the operand's primes");
-  RowMap map;
-  CHK(make_map(all, 0, nall, map));
+  if (ndig < 0)
+    ndig = W->ndig;
+  if (nall > MAX_ROWS)
+    return fail(HX_ERR_UNSUPPORTED, "too many rows");
+  RowMap2 map;  // p = prime of the row, brow = its row inside W (W may cover more primes)
+  for (int r = 0; r < nall; r++) {
+    int wr = find_row(W->row_idx, all[r]);
+    if (wr < 0)
+      return fail(HX_ERR_PRIMESET, "key-switching matrix is not defined on the operand's primes");
+    map.p[r] = (uint16_t)all[r];
+    map.brow[r] = (uint16_t)wr;
+  }
   size_t rw = (size_t)batch * c->phim;
   int lazy = W->ndig <= 8 ? 1 : 0;
   for (int r : all)
@@ -1890,8 +1948,8 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
     d_fix = reinterpret_cast<const hx::KsFix*>(it->second->blob);
   }
   hipLaunchKernelGGL(hx::keyswitch_kernel, ew_grid(rw, nall), dim3(256), 0, c->stream, dig, W->d_b,
-                     W->d_a, out0, out1, map, W->ndig, nall, batch, c->phim, accumulate_rows,
-                     c->d_primes, own_src, d_fix, lazy);
+                     W->d_a, out0, out1, map, ndig, nall, (int)W->row_idx.size(), batch, c->phim,
+                     accumulate_rows, c->d_primes, own_src, d_fix, lazy);
   HIPCHK(hipGetLastError());
   return HX_OK;
 }
@@ -1912,6 +1970,63 @@ extern "C" int hx_key_switch_digits(const hx_poly* digits, const hx_ksk* W, hx_p
   return keyswitch_launch(c, digits->d, W, W->row_idx, digits->batch, out0->d, out1->d, nall);
 }
 
+// Ctxt::keySwitchPart on the s^2 part (src/Ctxt.cpp:805-842): t2e = its evaluation rows on `own`
+// (left untouched), all = own followed by the special primes; accumulates into out0/out1 whose
+// first L rows already hold the scaled parts (1), (s).
+static int relin_core(hx_ctx* c, const uint64_t* t2e, const std::vector<int>& own,
+                      const std::vector<int>& all, const hx_ksk* W, const int* dig_idx,
+                      const int* dig_off, int ndig, int batch, uint64_t* out0, uint64_t* out1)
+{
+  const int L = (int)own.size(), nall = (int)all.size();
+  const size_t rw = (size_t)batch * c->phim;
+  // scratch: [2] = s^2 part in the coefficient domain; [1] = digits (ndig*nall rows; a digit's
+  // own rows are never materialised)
+  CHK(ensure_scratch(c, 2, (size_t)L * rw));
+  CHK(ensure_scratch(c, 1, (size_t)ndig * nall * rw));
+  {
+    std::vector<std::pair<int, int>> rows;
+    for (int r = 0; r < L; r++)
+      rows.emplace_back(r, own[r]);
+    CHK(ntt_list(c, t2e, c->scratch[2], rows, batch, true));  // toPoly side, out of place
+  }
+  std::vector<int> owner;
+  {
+    int rc = break_digits_fused(c, c->scratch[2], own, dig_idx, dig_off, ndig, all, c->scratch[1],
+                                rw, &owner);
+    if (rc == HX_ERR_UNSUPPORTED)
+      rc = break_digits_coef(c, c->scratch[2], own, dig_idx, dig_off, ndig, all, c->scratch[1], rw,
+                             /*copy_own=*/false, &owner);
+    if (rc != HX_OK)
+      return rc;
+  }
+  // forward NTT of the extension rows only: D*(L+K) - L transforms, as in the reference
+  {
+    std::vector<std::pair<int, int>> rows;
+    for (int d = 0; d < ndig; d++)
+      for (int r = 0; r < nall; r++)
+        if (owner[r] != d)
+          rows.emplace_back(d * nall + r, all[r]);
+    CHK(ntt_list(c, c->scratch[1], c->scratch[1], rows, batch, false));
+  }
+  std::vector<std::vector<int>> dprimes(ndig);
+  for (int d = 0; d < ndig; d++)
+    dprimes[d].assign(dig_idx + dig_off[d], dig_idx + dig_off[d + 1]);
+  return keyswitch_launch(c, c->scratch[1], W, all, batch, out0, out1, L, t2e, &owner, &dprimes, ndig);
+}
+
+static std::vector<uint64_t> special_factor(hx_ctx* c, const std::vector<int>& own, const int* sp,
+                                            int nsp)
+{
+  std::vector<uint64_t> f(own.size());
+  for (size_t r = 0; r < own.size(); r++) {
+    uint64_t q = c->primes[own[r]].q, v = 1;
+    for (int s = 0; s < nsp; s++)
+      v = hxh::mulmod(v, c->primes[sp[s]].q % q, q);
+    f[r] = v;
+  }
+  return f;
+}
+
 extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0,
                             const hx_poly* d1, const hx_ksk* W, const int* dig_idx,
                             const int* dig_off, int ndig, hx_poly* out0, hx_poly* out1)
@@ -1920,7 +2035,7 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
     return fail(HX_ERR_INVALID, "null argument");
   hx_ctx* c = c0->ctx;
   CHK(use(c));
-  if (ndig != W->ndig)
+  if (ndig > W->ndig || ndig < 1)
     return fail(HX_ERR_INVALID, "W must have as many columns as there are digits");
   int L = c0->nrows(), nall = (int)W->row_idx.size(), K = nall - L;
   if (K < 0)
@@ -1935,52 +2050,54 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
   CHK(poly_reserve(out1, nall));
   out0->prime_idx = W->row_idx;
   out1->prime_idx = W->row_idx;
-  // scratch: [0] = s^2 part, evaluation domain (L rows); [2] = the same in the coefficient
-  // domain; [1] = digits (ndig*nall rows; a digit's own rows are never materialised)
-  CHK(ensure_scratch(c, 0, (size_t)L * rw));
-  CHK(ensure_scratch(c, 2, (size_t)L * rw));
-  CHK(ensure_scratch(c, 1, (size_t)ndig * nall * rw));
+  CHK(ensure_scratch(c, 0, (size_t)L * rw));  // s^2 part, evaluation domain
   // tensorProduct + (parts 1,s) addPrimesAndScale(special)
-  std::vector<uint64_t> f(L);
-  for (int r = 0; r < L; r++) {
-    uint64_t q = c->primes[c0->prime_idx[r]].q, v = 1;
-    for (int s = L; s < nall; s++)
-      v = hxh::mulmod(v, c->primes[W->row_idx[s]].q % q, q);
-    f[r] = v;
-  }
+  std::vector<uint64_t> f = special_factor(c, c0->prime_idx, W->row_idx.data() + L, K);
   CHK(tensor_launch(c0, c1, d0, d1, out0->d, out1->d, c->scratch[0], f.data()));
-  // keySwitchPart on the s^2 part: toPoly side (inverse NTT, out of place)
-  {
-    std::vector<std::pair<int, int>> rows;
-    for (int r = 0; r < L; r++)
-      rows.emplace_back(r, c0->prime_idx[r]);
-    CHK(ntt_list(c, c->scratch[0], c->scratch[2], rows, c0->batch, true));
-  }
-  std::vector<int> owner;
-  {
-    int rc = break_digits_fused(c, c->scratch[2], c0->prime_idx, dig_idx, dig_off, ndig,
-                                W->row_idx, c->scratch[1], rw, &owner);
-    if (rc == HX_ERR_UNSUPPORTED)
-      rc = break_digits_coef(c, c->scratch[2], c0->prime_idx, dig_idx, dig_off, ndig, W->row_idx,
-                             c->scratch[1], rw, /*copy_own=*/false, &owner);
-    if (rc != HX_OK)
-      return rc;
-  }
-  // forward NTT of the extension rows only: D*(L+K) - L transforms, as in the reference
-  {
-    std::vector<std::pair<int, int>> rows;
-    for (int d = 0; d < ndig; d++)
-      for (int r = 0; r < nall; r++)
-        if (owner[r] != d)
-          rows.emplace_back(d * nall + r, W->row_idx[r]);
-    CHK(ntt_list(c, c->scratch[1], c->scratch[1], rows, c0->batch, false));
-  }
-  std::vector<std::vector<int>> dprimes(ndig);
-  for (int d = 0; d < ndig; d++)
-    dprimes[d].assign(dig_idx + dig_off[d], dig_idx + dig_off[d + 1]);
-  CHK(keyswitch_launch(c, c->scratch[1], W, W->row_idx, c0->batch, out0->d, out1->d, L,
-                       c->scratch[0], &owner, &dprimes));
-  return HX_OK;
+  return relin_core(c, c->scratch[0], c0->prime_idx, W->row_idx, W, dig_idx, dig_off, ndig,
+                    c0->batch, out0->d, out1->d);
+}
+
+// Ctxt::reLinearize for a 3-part ciphertext (1, s, s^2) (src/Ctxt.cpp:720-786): parts 1 and s get
+// addPrimesAndScale(special), part s^2 goes through keySwitchPart.  W may cover more ctxt primes
+// than the ciphertext currently has (lower level); digits are the context digits restricted to
+// the ciphertext's primes.  out0/out1 end up on primes(t*) followed by sp_idx.
+extern "C" int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_poly* t2,
+                              const hx_ksk* W, const int* dig_idx, const int* dig_off, int ndig,
+                              const int* sp_idx, int nsp, hx_poly* out0, hx_poly* out1)
+{
+  if (!t0 || !t1 || !t2 || !W || !out0 || !out1 || !dig_idx || !dig_off || (nsp > 0 && !sp_idx))
+    return fail(HX_ERR_INVALID, "null argument");
+  hx_ctx* c = t0->ctx;
+  CHK(use(c));
+  if (ndig > W->ndig || ndig < 1)
+    return fail(HX_ERR_INVALID, "W must have as many columns as there are digits");
+  if (t1->prime_idx != t0->prime_idx || t2->prime_idx != t0->prime_idx || t1->batch != t0->batch ||
+      t2->batch != t0->batch || out0->batch != t0->batch || out1->batch != t0->batch)
+    return fail(HX_ERR_PRIMESET, "reLinearize: parts must share one prime set and batch");
+  CHK(check_rows(c, sp_idx, nsp));
+  std::vector<int> all;
+  CHK(build_all(t0, sp_idx, nsp, all));
+  const int L = t0->nrows(), nall = (int)all.size();
+  if (nall > MAX_ROWS)
+    return fail(HX_ERR_UNSUPPORTED, "too many rows");
+  for (int r : all)
+    if (find_row(W->row_idx, r) < 0)
+      return fail(HX_ERR_PRIMESET, "No key-switching matrix row for prime %d", r);
+  size_t rw = t0->row_words();
+  CHK(poly_reserve(out0, nall));
+  CHK(poly_reserve(out1, nall));
+  HIPCHK(hipMemcpyAsync(out0->d, t0->d, (size_t)L * rw * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(out1->d, t1->d, (size_t)L * rw * 8, hipMemcpyDeviceToDevice, c->stream));
+  out0->prime_idx = t0->prime_idx;
+  out1->prime_idx = t0->prime_idx;
+  std::vector<uint64_t> f = special_factor(c, t0->prime_idx, sp_idx, nsp);
+  CHK(ew_scalar_rows<hx::EWS_MUL>(out0, f.data()));
+  CHK(ew_scalar_rows<hx::EWS_MUL>(out1, f.data()));
+  out0->prime_idx = all;
+  out1->prime_idx = all;
+  return relin_core(c, t2->d, t0->prime_idx, all, W, dig_idx, dig_off, ndig, t0->batch, out0->d,
+                    out1->d);
 }
 
 // ------------------------------------------------------------------

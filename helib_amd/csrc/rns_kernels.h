@@ -172,7 +172,7 @@ struct KsFix {
 __global__ void __launch_bounds__(256)
 keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ kb,
                  const uint64_t* __restrict__ ka, uint64_t* __restrict__ out0,
-                 uint64_t* __restrict__ out1, RowMap map, int ndig, int nall, int batch,
+                 uint64_t* __restrict__ out1, RowMap2 map, int ndig, int nall, int wrows, int batch,
                  uint32_t n, int accumulate_rows /* rows < this accumulate, others overwrite */,
                  const PrimeDev* __restrict__ primes, const uint64_t* __restrict__ own_src,
                  const KsFix* __restrict__ fix, int lazy)
@@ -215,8 +215,9 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
           own.y = mul_shoup(sub_mod(own.y, x.y, q), pi.w, pi.wp, q);
         }
       }
-      ulonglong2 b = *reinterpret_cast<const ulonglong2*>(kb + dr * n + j);
-      ulonglong2 a = *reinterpret_cast<const ulonglong2*>(ka + dr * n + j);
+      const size_t kr = (size_t)d * wrows + map.brow[row];  // row of W (may cover more primes)
+      ulonglong2 b = *reinterpret_cast<const ulonglong2*>(kb + kr * n + j);
+      ulonglong2 a = *reinterpret_cast<const ulonglong2*>(ka + kr * n + j);
       if (lazy) {
         s0x += (u128)x.x * b.x;
         s0y += (u128)x.y * b.y;

@@ -1,0 +1,431 @@
+"""Host-side mirror of the reference's ciphertext bookkeeping for this path (BGV):
+
+  ChainContext  -- Context::buildModChain (src/Context.cpp:728-1073): small / ctxt / special
+                   primes, digits, and ModuliSizes (src/primeChain.cpp:68-335)
+  Ctxt          -- the orchestration rows of SURVEY.md 8(a): modUpToSet / modDownToSet /
+                   bringToSet (src/Ctxt.cpp:346-562), dropSmallAndSpecialPrimes (:589-662),
+                   tensorProduct bookkeeping (:1563-1608), computeIntervalForMul (:1610-1656),
+                   multLowLvl / multiplyBy (:1681-1774), reLinearize / keySwitchPart (:720-842),
+                   addCtxt for equal prime sets (:1540-1553)
+
+The polynomial work is delegated to a backend (`ops`): on the GPU that is helib_amd.capi
+(DoubleCRT parts resident in HBM, possibly a batch of independent ciphertexts sharing this
+bookkeeping).  The class itself is pure control flow + floating-point noise estimates, exactly the
+part SURVEY.md keeps on the host (risk R3).  Two documented deviations from the reference, both the
+reference's own alternative branches: mod-switch added noise uses modSwitchAddedNoiseBound()
+(src/Ctxt.cpp:546-559 `#else`) and the key-switch added noise uses noiseBoundForUniform per digit
+(src/DoubleCRT.cpp:520-529 `#if 0`) instead of PGFFT-measured norms.  Noise bounds are kept as
+natural logarithms (NTL::xdouble in the reference) -- only their logs are ever compared.
+"""
+import math
+from functools import reduce
+
+from . import hostnt
+
+HELIB_SP_NBITS = 60
+LN2 = math.log(2.0)
+
+
+def phi(m):
+    r, x, p = m, m, 2
+    while p * p <= x:
+        if x % p == 0:
+            while x % p == 0:
+                x //= p
+            r -= r // p
+        p += 1
+    if x > 1:
+        r -= r // x
+    return r
+
+
+def _divc(a, b):
+    return -(-a // b)
+
+
+def logaddexp(a, b):
+    if a == -math.inf:
+        return b
+    if b == -math.inf:
+        return a
+    hi, lo = (a, b) if a >= b else (b, a)
+    return hi + math.log1p(math.exp(lo - hi))
+
+
+class ModuliSizes:
+    """src/primeChain.cpp:68-335"""
+
+    def __init__(self, context):
+        self.iFFT_cost = 0 if context.pow2 else 20
+        sizes = [(0.0, frozenset())]
+        for i in context.smallPrimes:
+            sq = math.log(context.primes[i])
+            sizes += [(s + sq, st | {i}) for s, st in sizes]
+        base = list(sizes)
+        interval, isz = set(), 0.0
+        for i in context.ctxtPrimes:
+            interval.add(i)
+            isz += math.log(context.primes[i])
+            fs = frozenset(interval)
+            sizes += [(s + isz, st | fs) for s, st in base]
+        sizes.sort(key=lambda e: (e[0], sorted(e[1])))
+        self.sizes = sizes
+
+    def _cost(self, frm, to):
+        if self.iFFT_cost == 0:
+            return 100 * len(to - frm)
+        return 100 * len(to - frm) + self.iFFT_cost * len(frm - to)
+
+    def getSet4Size(self, low, high, from1, from2=None, reverse=False):
+        import bisect
+        from1 = frozenset(from1)
+        from2 = frozenset(from2) if from2 is not None else None
+        cost = (lambda s: self._cost(from1, s)) if from2 is None else \
+               (lambda s: self._cost(from1, s) + self._cost(from2, s))
+        keys = [s for s, _ in self.sizes]
+        idx = bisect.bisect_left(keys, low)
+        best, best_cost = -1, None
+        ii = idx
+        n = len(self.sizes)
+        while ii < n and self.sizes[ii][0] <= high:
+            c = cost(self.sizes[ii][1])
+            if best_cost is None or c <= best_cost:
+                best, best_cost = ii, c
+            ii += 1
+        if best == -1:
+            if reverse:
+                if ii < n:
+                    ub = self.sizes[ii][0] + LN2
+                    i = ii
+                    while i < n and self.sizes[i][0] <= ub:
+                        c = cost(self.sizes[i][1])
+                        if best_cost is None or c < best_cost:
+                            best, best_cost = i, c
+                        i += 1
+            elif idx > 0:
+                lb = self.sizes[idx - 1][0] - LN2
+                i = idx - 1
+                while i >= 0 and self.sizes[i][0] >= lb:
+                    c = cost(self.sizes[i][1])
+                    if best_cost is None or c < best_cost:
+                        best, best_cost = i, c
+                    i -= 1
+        if best == -1:
+            return frozenset()
+        return self.sizes[best][1]
+
+
+class ChainContext:
+    """ContextBuilder<BGV>().m(m).p(p).r(r).bits(bits).c(c) -> buildModChain."""
+
+    def __init__(self, m, p, r=1, bits=300, c=3, stdev=3.2, scale=10.0, skHwt=0, resolution=3,
+                 bitsInSpecialPrimes=0):
+        self.m, self.p, self.r = m, p, r
+        self.ptxtSpace = p ** r
+        self.phim = phi(m)
+        self.pow2 = (m & (m - 1)) == 0
+        self.stdev, self.scale, self.hwt = stdev, scale, skHwt
+        self.primes = []
+        self.smallPrimes, self.ctxtPrimes, self.specialPrimes = [], [], []
+        pSize = self._ctxtPrimeSize(bits)
+        self._addSmallPrimes(resolution, pSize)
+        self._addCtxtPrimes(bits, pSize)
+        self._addSpecialPrimes(c, bitsInSpecialPrimes)
+        self.modSizes = ModuliSizes(self)
+
+    # ---- chain construction (src/Context.cpp:728-1035) ----
+    @staticmethod
+    def _bit_loss():
+        return -math.log1p(-1.0 / (1 << hostnt.PrimeGen.B)) / LN2
+
+    def _ctxtPrimeSize(self, nBits):
+        bit_loss = self._bit_loss()
+        nPrimes = int(math.ceil(nBits / (HELIB_SP_NBITS - bit_loss)))
+        t = HELIB_SP_NBITS
+        while 10 * (t - 1) >= 9 * HELIB_SP_NBITS and (t - 1) >= 30 and \
+                ((t - 1) - bit_loss) * nPrimes >= nBits:
+            t -= 1
+        return t
+
+    def _add(self, q, where):
+        assert q not in self.primes, "Prime q is already in the prime chain"
+        self.primes.append(q)
+        where.append(len(self.primes) - 1)
+
+    def _addSmallPrimes(self, resolution, cpSize):
+        if resolution < 1 or resolution > 10:
+            resolution = 3
+        sizes = []
+        if cpSize >= 54:
+            smallest = _divc(2 * cpSize, 3)
+        elif cpSize >= 45:
+            smallest = _divc(7 * cpSize, 10)
+        else:
+            smallest = _divc(11 * cpSize, 15)
+            sizes.append(smallest)
+        sizes += [smallest, smallest]
+        delta = resolution
+        while cpSize - delta > smallest:
+            sizes.append(cpSize - delta)
+            delta *= 2
+        if cpSize - 3 * resolution > smallest:
+            sizes.append(cpSize - 3 * resolution)
+        if resolution == 1 and cpSize - 11 > smallest:
+            sizes.append(cpSize - 11)
+        sizes.sort()
+        last, gen = 0, None
+        for sz in sizes:
+            if sz != last:
+                gen = hostnt.PrimeGen(sz, self.m)
+            self._add(gen.next(), self.smallPrimes)
+            last = sz
+
+    def _addCtxtPrimes(self, nBits, targetSize):
+        gen = hostnt.PrimeGen(targetSize, self.m)
+        bitlen = 0.0
+        while bitlen < nBits - 0.5:
+            q = gen.next()
+            self._add(q, self.ctxtPrimes)
+            bitlen += math.log2(q)
+
+    def _addSpecialPrimes(self, nDgts, bitsInSpecialPrimes):
+        n = len(self.ctxtPrimes)
+        nDgts = max(1, min(nDgts, n))
+        digits = []
+        if nDgts > 1:
+            remaining = list(self.ctxtPrimes)
+            for dgt in range(nDgts - 1):
+                card = _divc(len(remaining), nDgts - dgt)
+                digits.append(remaining[:card])
+                remaining = remaining[card:]
+            if remaining:
+                digits.append(remaining)
+        else:
+            digits = [list(self.ctxtPrimes)]
+        self.digits = digits
+        maxDigitLog = max(self.logOfProduct(d) for d in digits)
+        nDgts = len(digits)
+        if bitsInSpecialPrimes:
+            nBits = bitsInSpecialPrimes
+        else:
+            h = self.phim / 2.0 if self.hwt == 0 else self.hwt
+            log_phim = max(math.log(self.phim), 1.0)
+            p2e = self.ptxtSpace
+            if self.pow2:
+                nBits = (maxDigitLog + math.log(p2e) + math.log(self.stdev) + 0.5 * math.log(12.0) +
+                         math.log(nDgts) - 0.5 * math.log(log_phim) - 2 * math.log(self.p) -
+                         math.log(h)) / LN2
+            else:
+                nBits = (maxDigitLog + math.log(self.m) + math.log(p2e) + math.log(self.stdev) +
+                         0.5 * math.log(12.0) + math.log(nDgts) - 0.5 * log_phim -
+                         0.5 * math.log(log_phim) - 2 * math.log(self.p) - math.log(h)) / LN2
+        nBits = max(nBits, 1.0)
+        bit_loss = self._bit_loss()
+        nPrimes = int(math.ceil(nBits / (HELIB_SP_NBITS - bit_loss)))
+        t = HELIB_SP_NBITS
+        while (t - 1) >= 0.55 * HELIB_SP_NBITS and (t - 1) >= 30 and \
+                ((t - 1) - bit_loss) * nPrimes >= nBits:
+            t -= 1
+        gen = hostnt.PrimeGen(t, self.m)
+        while nPrimes > 0:
+            q = gen.next()
+            if q in self.primes:
+                continue
+            self._add(q, self.specialPrimes)
+            nPrimes -= 1
+
+    # ---- helpers ----
+    def logOfPrime(self, i):
+        return math.log(self.primes[i])
+
+    def logOfProduct(self, s):
+        return sum(math.log(self.primes[i]) for i in s)
+
+    def productOfPrimes(self, s):
+        return reduce(lambda a, b: a * b, (self.primes[i] for i in s), 1)
+
+    def noiseBoundForUniform(self, magBound, degBound):
+        return self.scale * math.sqrt(degBound / 3.0) * magBound
+
+    def noiseBoundForMod(self, modulus, degBound):
+        var = modulus * modulus / 12.0 + (1.0 / 6.0 if modulus % 2 == 0 else 0.0)
+        return self.scale * math.sqrt(degBound * var)
+
+    # sample*Bounded return values (src/sample.cpp:260-267, 342-396, 445-463)
+    def skBound(self):
+        if self.hwt > 0:
+            return math.sqrt(self.hwt * math.log(self.phim))
+        return math.sqrt(self.phim * math.log(self.phim) / 2.0)
+
+    def gaussBound(self):
+        eff = math.sqrt(self.phim * math.log(self.phim)) if self.pow2 else \
+            math.sqrt(self.m * math.log(self.phim))
+        st = self.stdev if self.pow2 else self.stdev * math.sqrt(self.m)
+        return st * eff
+
+    def freshNoiseBound(self):
+        """noiseBound of PubKey::Encrypt output (src/keys.cpp:395-475)."""
+        p = self.ptxtSpace
+        e = self.gaussBound() * p
+        pk_noise = e                                   # RLWE1: bound *= p
+        r_bound = math.sqrt(self.phim * math.log(self.phim) / 2.0)
+        return r_bound * pk_noise + e + e * self.skBound() + self.noiseBoundForMod(p, self.phim)
+
+
+class Ctxt:
+    """BGV ciphertext: parts keyed by secret-key handle ("1", "s", "s2")."""
+    safety = LN2  # src/Ctxt.cpp:39
+
+    def __init__(self, context, ops, ksw=None, ksw_ptxtSpace=None, ksw_noise=None):
+        self.context, self.ops = context, ops
+        self.parts = {}
+        self.primeSet = frozenset()
+        self.ptxtSpace = context.ptxtSpace
+        self.lnNoise = -math.inf
+        self.intFactor = 1
+        self.ksw, self.ksw_ptxtSpace = ksw, ksw_ptxtSpace or context.ptxtSpace
+        self.ksw_lnNoise = ksw_noise if ksw_noise is not None else \
+            math.log(context.gaussBound() * context.ptxtSpace)
+
+    @classmethod
+    def fresh(cls, context, ops, c0, c1, ksw=None, **kw):
+        c = cls(context, ops, ksw, **kw)
+        c.parts = {"1": c0, "s": c1}
+        c.primeSet = frozenset(context.ctxtPrimes)
+        c.lnNoise = math.log(context.freshNoiseBound())
+        return c
+
+    def clone(self):
+        c = Ctxt(self.context, self.ops, self.ksw, self.ksw_ptxtSpace, self.ksw_lnNoise)
+        c.parts = {h: p.copy() for h, p in self.parts.items()}
+        c.primeSet, c.ptxtSpace = self.primeSet, self.ptxtSpace
+        c.lnNoise, c.intFactor = self.lnNoise, self.intFactor
+        return c
+
+    # ---- bookkeeping ----
+    def logOfPrimeSet(self):
+        return self.context.logOfProduct(self.primeSet)
+
+    def modSwitchAddedNoiseBound(self):
+        h = self.context.skBound()
+        power = {"1": 0, "s": 1, "s2": 2}
+        added = sum(1.0 if k == "1" else h ** power[k] for k in self.parts)
+        return added * self.context.noiseBoundForUniform(self.ptxtSpace / 2.0, self.context.phim)
+
+    # ---- prime-set maintenance ----
+    def modUpToSet(self, s):
+        diff = sorted(frozenset(s) - self.primeSet)
+        if not diff:
+            return
+        for p in self.parts.values():
+            p.addPrimesAndScale(diff)
+        self.lnNoise += self.context.logOfProduct(diff)
+        self.primeSet = self.primeSet | frozenset(diff)
+
+    def modDownToSet(self, s):
+        inter = self.primeSet & frozenset(s)
+        if not inter:
+            raise RuntimeError(f"modDownToSet called from {sorted(self.primeSet)} to {sorted(s)}")
+        diff = self.primeSet - inter
+        if not diff:
+            return
+        added = self.modSwitchAddedNoiseBound()
+        for p in self.parts.values():
+            p.scaleDownToSet(sorted(inter), self.ptxtSpace)
+        self.lnNoise = logaddexp(self.lnNoise - self.context.logOfProduct(diff), math.log(added))
+        self.primeSet = inter
+
+    def bringToSet(self, s):
+        s = frozenset(s) if s else frozenset([self.context.ctxtPrimes[0]])
+        self.modUpToSet(s)
+        self.modDownToSet(s)
+
+    def dropSmallAndSpecialPrimes(self):
+        ctx = self.context
+        small, ctp = frozenset(ctx.smallPrimes), frozenset(ctx.ctxtPrimes)
+        if not (self.primeSet & small):
+            self.modDownToSet(ctp)
+            return
+        target = set(self.primeSet & ctp)
+        dropping = self.primeSet - target
+        log_dropping = ctx.logOfProduct(dropping)
+        log_msn = math.log(self.modSwitchAddedNoiseBound()) + 3 * LN2
+        comp = 0.0
+        if self.lnNoise - log_dropping + comp < log_msn:
+            for i in sorted(ctp - target):
+                target.add(i)
+                comp += ctx.logOfPrime(i)
+                if self.lnNoise - log_dropping + comp >= log_msn:
+                    break
+        self.bringToSet(target)
+
+    # ---- arithmetic ----
+    def addCtxt(self, other):
+        if self.primeSet != other.primeSet or self.intFactor != other.intFactor or \
+                self.ptxtSpace != other.ptxtSpace:
+            raise NotImplementedError("addCtxt: operands must share prime set / intFactor here")
+        for h, p in other.parts.items():
+            if h in self.parts:
+                self.parts[h] += p
+            else:
+                self.parts[h] = p.copy()
+        self.lnNoise = logaddexp(self.lnNoise, other.lnNoise)
+
+    @staticmethod
+    def computeIntervalForMul(c1, c2):
+        cap1 = c1.logOfPrimeSet() - max(c1.lnNoise, 0.0)
+        cap2 = c2.logOfPrimeSet() - max(c2.lnNoise, 0.0)
+        adn1 = math.log(c1.modSwitchAddedNoiseBound())
+        adn2 = math.log(c2.modSwitchAddedNoiseBound())
+        hi = min(cap1 + adn1, cap2 + adn2) - Ctxt.safety
+        return hi - 4 * LN2, hi
+
+    def multLowLvl(self, other, destructive=False):
+        o = other if destructive else other.clone()
+        g = math.gcd(self.ptxtSpace, o.ptxtSpace)
+        assert g > 1, "Plaintext spaces are co-prime"
+        self.ptxtSpace = o.ptxtSpace = g
+        self.intFactor %= g
+        o.intFactor %= g
+        lo, hi = Ctxt.computeIntervalForMul(self, o)
+        common = self.context.modSizes.getSet4Size(lo, hi, self.primeSet, o.primeSet, False)
+        self.bringToSet(common)
+        o.bringToSet(common)
+        self._tensorProduct(o)
+
+    def _tensorProduct(self, o):
+        assert set(self.parts) == {"1", "s"} and set(o.parts) == {"1", "s"}
+        if self.ptxtSpace > 2:
+            q = self.context.productOfPrimes(self.primeSet) % self.ptxtSpace
+            self.intFactor = self.intFactor * o.intFactor % self.ptxtSpace * q % self.ptxtSpace
+        t0, t1, t2 = self.ops.tensorProduct(self.parts["1"], self.parts["s"], o.parts["1"], o.parts["s"])
+        self.parts = {"1": t0, "s": t1, "s2": t2}
+        self.lnNoise = self.lnNoise + o.lnNoise
+
+    def reLinearize(self):
+        if "s2" not in self.parts:
+            return
+        ctx = self.context
+        self.dropSmallAndSpecialPrimes()
+        sp = list(ctx.specialPrimes)
+        logProd = ctx.logOfProduct(sp)
+        # digits of the context restricted to the current prime set (src/DoubleCRT.cpp:485-493)
+        digits = [[i for i in d if i in self.primeSet] for d in ctx.digits]
+        digits = [d for d in digits if d]
+        self.ptxtSpace = math.gcd(self.ptxtSpace, self.ksw_ptxtSpace)
+        self.intFactor %= self.ptxtSpace
+        o0, o1 = self.ops.reLinearize(self.parts["1"], self.parts["s"], self.parts["s2"], self.ksw,
+                                      digits, sp)
+        # noise: scaled parts + key-switch added noise (src/Ctxt.cpp:746, 827-841)
+        added = -math.inf
+        for d in digits:
+            nb = math.log(ctx.noiseBoundForUniform(0.5, ctx.phim)) + ctx.logOfProduct(d)
+            added = logaddexp(added, nb + self.ksw_lnNoise)
+        self.lnNoise = logaddexp(self.lnNoise + logProd, added)
+        self.parts = {"1": o0, "s": o1}
+        self.primeSet = self.primeSet | frozenset(sp)
+
+    def multiplyBy(self, other):
+        self.multLowLvl(other)
+        self.reLinearize()
+        return self

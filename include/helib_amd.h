@@ -171,6 +171,15 @@ int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const 
                  const hx_ksk* W, const int* dig_idx, const int* dig_off, int ndig,
                  hx_poly* out0, hx_poly* out1);
 
+/* Ctxt::reLinearize of a 3-part ciphertext (1, s, s^2) (src/Ctxt.cpp:720-786, keySwitchPart
+ * :805-842): parts (1),(s) get addPrimesAndScale(special), part s^2 is broken into digits and
+ * multiplied by W.  W may cover more ctxt primes than the parts currently have (lower level);
+ * digits = the context's digits restricted to the parts' primes (leading digits of W).
+ * out0/out1: primes(t0) followed by sp_idx. */
+int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_poly* t2, const hx_ksk* W,
+                   const int* dig_idx, const int* dig_off, int ndig, const int* sp_idx, int nsp,
+                   hx_poly* out0, hx_poly* out1);
+
 /* ---------------- HEXL-shim compatibility layer ---------------- */
 /* Same signatures and semantics as namespace intel (src/intelExt.h:20-59):
  * host pointers, synchronous, in-place allowed, negacyclic NTT whose root is

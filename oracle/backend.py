@@ -1,0 +1,72 @@
+"""Oracle-backed stand-in for helib_amd.capi so that helib_amd.ctxt.Ctxt (the host control flow)
+can be driven on the CPU in tests: same method names as capi.DoubleCRT / capi module functions.
+TEST INFRASTRUCTURE: lives under oracle/ so that only tests/, smoke() and the cpu_baseline leg of
+bench.py can reach it."""
+import numpy as np
+
+from oracle import oracle as O
+
+
+class OPoly:
+    def __init__(self, octx, idx, rows):
+        self.o, self.idx = octx, list(idx)
+        self.rows = np.ascontiguousarray(rows, dtype=np.uint64)   # [nrows, N]
+
+    def getIndexSet(self):
+        return list(self.idx)
+
+    def copy(self):
+        return OPoly(self.o, self.idx, self.rows.copy())
+
+    def download(self):
+        return self.rows[:, None, :]
+
+    def __iadd__(self, other):
+        for r, i in enumerate(self.idx):
+            self.rows[r] = O.row_op("add", self.rows[r], other.rows[other.idx.index(i)], self.o.primes[i])
+        return self
+
+    def addPrimesAndScale(self, s):
+        s = list(s)
+        self.rows = np.vstack([self.o.scale_by_primes(self.idx, self.rows, s),
+                               np.zeros((len(s), self.o.N), dtype=np.uint64)])
+        self.idx += s
+        return self
+
+    def scaleDownToSet(self, keep, ptxt):
+        keep = set(keep)
+        drop = [i for i in self.idx if i not in keep]
+        if not drop:
+            return self
+        self.rows = self.o.scale_down(self.idx, self.rows, drop, ptxt)
+        self.idx = [i for i in self.idx if i in keep]
+        return self
+
+
+class OKeySwitch:
+    def __init__(self, row_idx, b, a):
+        self.row_idx, self.b, self.a = list(row_idx), b, a
+
+
+class OracleOps:
+    def __init__(self, octx):
+        self.o = octx
+
+    def tensorProduct(self, c0, c1, d0, d1):
+        assert c0.idx == c1.idx == d0.idx == d1.idx
+        t = self.o.tensor(c0.idx, c0.rows, c1.rows, d0.rows, d1.rows)
+        return [OPoly(self.o, c0.idx, x) for x in t]
+
+    def reLinearize(self, t0, t1, t2, W, digits, special):
+        own, sp = t0.idx, list(special)
+        allp = own + sp
+        sel = [W.row_idx.index(i) for i in allp]
+        D = len(digits)
+        kb, ka = W.b[:D][:, sel], W.a[:D][:, sel]
+        s0 = self.o.scale_by_primes(own, t0.rows, sp)
+        s1 = self.o.scale_by_primes(own, t1.rows, sp)
+        z = np.zeros((len(sp), self.o.N), dtype=np.uint64)
+        dg = self.o.break_into_digits(own, t2.rows, digits, allp)
+        o0, o1 = self.o.key_switch_digits(allp, dg, np.ascontiguousarray(kb), np.ascontiguousarray(ka),
+                                          np.vstack([s0, z]), np.vstack([s1, z]))
+        return OPoly(self.o, allp, o0), OPoly(self.o, allp, o1)

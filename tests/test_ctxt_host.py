@@ -1,0 +1,135 @@
+"""Host control flow of helib_amd.ctxt (Context chain, prime-set decisions, multiplyBy
+orchestration) on the CPU with the oracle as the polynomial backend: chain shapes of SURVEY.md
+Appendix B, and decrypt(multiplyBy(enc a, enc b)) == a*b through the full reference sequence
+bringToSet -> tensorProduct -> dropSmallAndSpecialPrimes -> reLinearize."""
+import math
+
+import numpy as np
+import pytest
+
+from helib_amd import ctxt as hc
+from oracle import oracle as O
+from tests import bgv_ref as B
+from oracle.backend import OKeySwitch, OPoly, OracleOps
+
+
+def test_chain_shapes_match_survey_appendix_B():
+    c = hc.ChainContext(32768, 65537, 1, bits=950, c=3)
+    assert len(c.ctxtPrimes) == 16 and all(q.bit_length() == 60 for q in (c.primes[i] for i in c.ctxtPrimes))
+    assert [len(d) for d in c.digits] == [6, 5, 5]
+    assert len(c.specialPrimes) == 6 and all(c.primes[i].bit_length() == 56 for i in c.specialPrimes)
+    assert sorted(c.primes[i].bit_length() for i in c.smallPrimes) == [40, 40, 48, 51, 54, 57]
+    # moduli order: small, ctxt, special
+    assert c.smallPrimes == list(range(6)) and c.ctxtPrimes == list(range(6, 22))
+    assert len(c.modSizes.sizes) == (1 << 6) * 17
+
+
+def test_fresh_multiply_prime_set_decision_m32768():
+    """fresh ciphertexts at m=32768 bits=950: the reference drops to a set that trades one 60-bit
+    ctxt prime for a small prime (cost 100 = one added prime)."""
+    c = hc.ChainContext(32768, 65537, 1, bits=950, c=3)
+    a = hc.Ctxt(c, None)
+    a.parts = {"1": None, "s": None}
+    a.primeSet = frozenset(c.ctxtPrimes)
+    a.lnNoise = math.log(c.freshNoiseBound())
+    lo, hi = hc.Ctxt.computeIntervalForMul(a, a)
+    s = c.modSizes.getSet4Size(lo, hi, a.primeSet, a.primeSet, False)
+    assert lo <= c.logOfProduct(s) <= hi
+    added, removed = s - a.primeSet, a.primeSet - s
+    assert len(added) == 1 and added <= set(c.smallPrimes)
+    assert removed == {c.ctxtPrimes[-1]}
+
+
+def make_keys(ctx, octx, seed=3):
+    rng = np.random.default_rng(seed)
+    N = octx.N
+    s = rng.integers(-1, 2, size=N)
+    allp = ctx.ctxtPrimes + ctx.specialPrimes
+
+    def rows(coeffs, idx):
+        coef = np.array([[int(v) % ctx.primes[i] for v in coeffs] for i in idx], dtype=np.uint64)
+        return octx.fft(idx, coef)
+
+    def mul(a, b, idx):
+        return np.stack([O.row_op("mul", a[r], b[r], ctx.primes[i]) for r, i in enumerate(idx)])
+
+    def sub(a, b, idx):
+        return np.stack([O.row_op("sub", a[r], b[r], ctx.primes[i]) for r, i in enumerate(idx)])
+
+    def add(a, b, idx):
+        return np.stack([O.row_op("add", a[r], b[r], ctx.primes[i]) for r, i in enumerate(idx)])
+
+    s_all = rows(s, allp)
+    s2 = mul(s_all, s_all, allp)
+    P = ctx.productOfPrimes(ctx.specialPrimes)
+    p = ctx.ptxtSpace
+    kb, ka, Bj = [], [], 1
+    for j, d in enumerate(ctx.digits):
+        a = np.stack([O.fill_uniform(N, ctx.primes[i], 900 + j * 100 + i) for i in allp])
+        e = np.rint(rng.normal(0, 3.2, size=N)).astype(np.int64)
+        pe = rows([p * int(x) for x in e], allp)
+        fac = P * Bj
+        t = np.stack([O.row_op("mul_scalar", s2[r], fac % ctx.primes[i], ctx.primes[i])
+                      for r, i in enumerate(allp)])
+        kb.append(sub(add(t, pe, allp), mul(s_all, a, allp), allp))
+        ka.append(a)
+        Bj *= ctx.productOfPrimes(d)
+    return s, allp, np.stack(kb), np.stack(ka), rows
+
+
+def encrypt(ctx, octx, s, msg, seed, rows):
+    """c0 + c1*s = p*e + (Q mod p)*msg on the ctxt primes (src/keys.cpp:454-458)."""
+    idx = ctx.ctxtPrimes
+    rng = np.random.default_rng(100 + seed)
+    N, p = octx.N, ctx.ptxtSpace
+    QmodP = ctx.productOfPrimes(idx) % p
+    c1 = np.stack([O.fill_uniform(N, ctx.primes[i], 77 * seed + i) for i in idx])
+    e = np.rint(rng.normal(0, 3.2, size=N)).astype(np.int64)
+    rhs = rows([p * int(x) + QmodP * int(mm) for x, mm in zip(e, msg)], idx)
+    s_rows = rows(s, idx)
+    c0 = np.stack([O.row_op("sub", rhs[r], O.row_op("mul", c1[r], s_rows[r], ctx.primes[i]), ctx.primes[i])
+                   for r, i in enumerate(idx)])
+    return c0, c1
+
+
+def decrypt(ctx, octx, s, ct, rows):
+    """SecKey::Decrypt core (src/keys.cpp:1327-1420) for a 2-part ciphertext."""
+    idx = sorted(ct.primeSet)
+    p0, p1 = ct.parts["1"], ct.parts["s"]
+    order = p0.getIndexSet()
+    d0, d1 = p0.download()[:, 0], p1.download()[:, 0]
+    s_rows = rows(s, order)
+    t = np.stack([O.row_op("add", d0[r], O.row_op("mul", d1[r], s_rows[r], ctx.primes[i]), ctx.primes[i])
+                  for r, i in enumerate(order)])
+    poly = octx.to_poly(order, t)
+    p = ct.ptxtSpace
+    factor = ctx.productOfPrimes(idx) % p * ct.intFactor % p
+    finv = pow(factor, -1, p)
+    Q = ctx.productOfPrimes(idx)
+    assert max(abs(v) for v in poly) < Q // 4, "noise too large"
+    return [(v % p) * finv % p for v in poly]
+
+
+@pytest.mark.parametrize("m,p,bits", [(128, 257, 150), (64, 65537, 250)])
+def test_multiplyBy_full_sequence_decrypts(m, p, bits):
+    ctx = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    octx = O.Ctx(m)
+    for q in ctx.primes:
+        octx.add_prime(q)
+    s, allp, kb, ka, rows = make_keys(ctx, octx)
+    ops = OracleOps(octx)
+    W = OKeySwitch(allp, kb, ka)
+    rng = np.random.default_rng(9)
+    ma, mb = rng.integers(0, p, size=octx.N), rng.integers(0, p, size=octx.N)
+    ca = hc.Ctxt.fresh(ctx, ops, *(OPoly(octx, ctx.ctxtPrimes, x) for x in encrypt(ctx, octx, s, ma, 1, rows)), ksw=W)
+    cb = hc.Ctxt.fresh(ctx, ops, *(OPoly(octx, ctx.ctxtPrimes, x) for x in encrypt(ctx, octx, s, mb, 2, rows)), ksw=W)
+    assert decrypt(ctx, octx, s, ca, rows) == [int(v) for v in ma]
+    ca.multiplyBy(cb)
+    assert set(ca.parts) == {"1", "s"}
+    assert ca.primeSet >= frozenset(ctx.specialPrimes)
+    want = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
+    assert decrypt(ctx, octx, s, ca, rows) == want
+    # the next operation's bringToSet drops the special primes again
+    ca.dropSmallAndSpecialPrimes()
+    assert not (ca.primeSet & frozenset(ctx.specialPrimes))
+    assert decrypt(ctx, octx, s, ca, rows) == want

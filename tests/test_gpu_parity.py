@@ -475,3 +475,47 @@ def test_general_m_multiply_relin_and_automorph(hx):
     got = hx.DoubleCRT(P.g, own, 1, a).automorph(3).download()
     for r in own:
         assert np.array_equal(got[r, 0], O.automorph(a[r, 0], m, zms, 3))
+
+
+# ---------------------------------------------------------------- full Ctxt::multiplyBy sequence
+@pytest.mark.parametrize("m,p,bits", [(16384, 65537, 250), (1705, 7, 200)])
+def test_ctxt_multiplyBy_full_sequence_gpu_vs_oracle(hx, m, p, bits):
+    """The reference's own order of operations for fresh ciphertexts (src/Ctxt.cpp:1681-1774):
+    bringToSet (mod-up by a small prime, mod-down by a ctxt prime) -> tensorProduct ->
+    dropSmallAndSpecialPrimes -> reLinearize, driven by the same host logic (helib_amd.ctxt) once
+    over the GPU and once over the oracle; every part must agree bit-for-bit and decrypt to a*b."""
+    from helib_amd import ctxt as hc
+    from tests import test_ctxt_host as T
+    from oracle.backend import OKeySwitch, OPoly, OracleOps
+    ctx = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    P = Pair(hx, m, ctx.primes)
+    s, allp, kb, ka, rows = T.make_keys(ctx, P.o)
+    rng = np.random.default_rng(4)
+    ma, mb = rng.integers(0, p, size=P.N), rng.integers(0, p, size=P.N)
+    ea, eb = T.encrypt(ctx, P.o, s, ma, 1, rows), T.encrypt(ctx, P.o, s, mb, 2, rows)
+    # oracle-driven
+    oops = OracleOps(P.o)
+    oW = OKeySwitch(allp, kb, ka)
+    oa = hc.Ctxt.fresh(ctx, oops, *(OPoly(P.o, ctx.ctxtPrimes, x) for x in ea), ksw=oW)
+    ob = hc.Ctxt.fresh(ctx, oops, *(OPoly(P.o, ctx.ctxtPrimes, x) for x in eb), ksw=oW)
+    oa.multiplyBy(ob)
+    # GPU-driven
+    gW = hx.KeySwitch(P.g, allp, kb, ka)
+    ga = hc.Ctxt.fresh(ctx, hx, *(hx.DoubleCRT(P.g, ctx.ctxtPrimes, 1, x[:, None, :]) for x in ea), ksw=gW)
+    gb = hc.Ctxt.fresh(ctx, hx, *(hx.DoubleCRT(P.g, ctx.ctxtPrimes, 1, x[:, None, :]) for x in eb), ksw=gW)
+    ga.multiplyBy(gb)
+    assert ga.primeSet == oa.primeSet and ga.intFactor == oa.intFactor
+    assert abs(ga.lnNoise - oa.lnNoise) < 1e-9
+    for h in ("1", "s"):
+        gi, oi = ga.parts[h].getIndexSet(), oa.parts[h].getIndexSet()
+        assert sorted(gi) == sorted(oi)
+        gd, od = ga.parts[h].download()[:, 0], oa.parts[h].download()[:, 0]
+        for r, i in enumerate(gi):
+            assert np.array_equal(gd[r], od[oi.index(i)]), (h, i)
+    from tests import bgv_ref as B
+    want = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)] if m < 4096 else None
+    got = T.decrypt(ctx, P.o, s, ga, rows)
+    if want is not None:
+        assert got == want
+    else:
+        assert got == T.decrypt(ctx, P.o, s, oa, rows)
