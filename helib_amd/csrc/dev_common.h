@@ -38,6 +38,31 @@ struct NttRows {
   uint16_t row[MAX_ROWS];
   uint16_t prime[MAX_ROWS];
 };
+
+// Fused DoubleCRT::scaleDownToSet for ONE dropped prime qd (src/DoubleCRT.cpp:1464-1516):
+//   prep  (IO of the inverse transform of the dropped row): per coefficient x in [0,qd) ->
+//         delta = x - qd*S,  S = [x > (qd-1)/2] + balanced((delta0 mod p) * qd^-1 mod p)
+//         (centring :1098-1099, ptxtSpace correction :1485-1508); stores x and S.
+//   apply (IO of the forward transform of every kept row r): loads delta mod q_r =
+//         x - (qd mod q_r)*S, and its store is  c_r <- (c_r - NTT(delta)) * qd^-1 mod q_r.
+struct ModDownPrep {
+  uint64_t* xs;        // [batch][N]
+  int64_t* S;          // [batch][N]
+  uint64_t half;       // (qd-1)/2
+  uint64_t ptxt;       // 0/1: no correction
+  uint64_t ptxt_mu64, ptxt_mu, qd_mod_p, qdinv_mod_p;
+  uint32_t ptxt_k, pad;
+};
+struct ModDownRow {
+  TW qdm;              // qd mod q_r
+  TW inv;              // qd^-1 mod q_r
+  uint32_t out_row, pad;
+};
+struct ModDownApply {
+  const uint64_t* xs;
+  const int64_t* S;
+  const ModDownRow* rows;  // [launch rows]
+};
 struct RowMap2 {
   uint16_t p[MAX_ROWS];
   uint16_t brow[MAX_ROWS];

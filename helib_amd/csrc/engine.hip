@@ -22,11 +22,17 @@ namespace hx {
 hipError_t launch_ntt_pow2(int logn, bool inverse, const uint64_t* in, uint64_t* out,
                            const NttRows& rows, int nrows, int batch, const PrimeDev* primes,
                            const TW* tw_arena, hipStream_t st);
+hipError_t launch_moddown_pow2(int logn, uint64_t* data, int drop_row, int drop_prime,
+                               const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
+                               const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena,
+                               hipStream_t st);
 }
 
 using hx::ExtArgs;
 using hx::ExtPlanDev;
 using hx::MAX_ROWS;
+using hx::ModDownApply;
+using hx::ModDownPrep;
 using hx::NttRows;
 using hx::PrimeDev;
 using hx::RowMap;
@@ -1585,6 +1591,75 @@ extern "C" int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_
     return fail(HX_ERR_UNSUPPORTED, "scaleDownToSet dropping more than 64 primes");
   size_t rw = a->row_words();
   int nd = (int)drop.size(), nk = (int)keep.size();
+  if (nd == 1 && c->pow2 && c->logn >= 13 && c->logn <= 15 && nk <= MAX_ROWS && ptxt < ((uint64_t)1 << 62)) {
+    // fused path: [inverse NTT of the dropped row + delta preparation] then [forward NTT of
+    // delta on every kept row, with  c <- (c - delta) / qd  in its store].  The last row takes
+    // the dropped row's slot, so no compaction copy is needed.
+    const int dprime = drop[0], drow = find_row(a->prime_idx, dprime), last = a->nrows() - 1;
+    const uint64_t qd = c->primes[dprime].q;
+    CHK(ensure_scratch(c, 0, rw));
+    CHK(ensure_scratch(c, 1, rw));
+    hx::ModDownPrep P;
+    memset(&P, 0, sizeof P);
+    P.xs = c->scratch[0];
+    P.S = reinterpret_cast<int64_t*>(c->scratch[1]);
+    P.half = (qd - 1) / 2;
+    if (ptxt > 1) {
+      P.ptxt = ptxt;
+      P.ptxt_mu64 = (uint64_t)((((hxh::u128)1) << 64) / ptxt);
+      int kb = hxh::bitlen(ptxt);
+      P.ptxt_k = (uint32_t)kb;
+      P.ptxt_mu = (uint64_t)((((hxh::u128)1) << (2 * kb)) / ptxt);
+      P.qd_mod_p = qd % ptxt;
+      P.qdinv_mod_p = hxh::invmod(qd % ptxt, ptxt);
+      if (P.qdinv_mod_p == 0)
+        return fail(HX_ERR_INVALID, "dropped primes are not invertible modulo ptxtSpace");
+    }
+    // per-row constants (cached per (dropped prime, kept rows and their output slots))
+    std::vector<uint64_t> key;
+    key.push_back(0xD0D0D0D0ull);
+    key.push_back((uint64_t)dprime);
+    NttRows kr;
+    std::vector<hx::ModDownRow> hr(nk);
+    int i = 0;
+    for (int r = 0; r <= last; r++) {
+      if (r == drow)
+        continue;
+      const int pr = a->prime_idx[r];
+      const uint64_t q = c->primes[pr].q;
+      kr.row[i] = (uint16_t)r;
+      kr.prime[i] = (uint16_t)pr;
+      uint64_t qdm = qd % q, inv = hxh::invmod(qdm, q);
+      hr[i].qdm.w = qdm;
+      hr[i].qdm.wp = hxh::shoup(qdm, q);
+      hr[i].inv.w = inv;
+      hr[i].inv.wp = hxh::shoup(inv, q);
+      hr[i].out_row = (uint32_t)((r == last && drow != last) ? drow : r);
+      hr[i].pad = 0;
+      key.push_back(((uint64_t)pr << 16) | hr[i].out_row);
+      i++;
+    }
+    auto it = c->plans.find(key);
+    if (it == c->plans.end()) {
+      ExtPlan* pl = new ExtPlan();
+      memset(&pl->dev, 0, sizeof pl->dev);
+      HIPCHK(hipMalloc(&pl->blob, sizeof(hx::ModDownRow) * nk));
+      HIPCHK(hipMemcpy(pl->blob, hr.data(), sizeof(hx::ModDownRow) * nk, hipMemcpyHostToDevice));
+      it = c->plans.emplace(key, pl).first;
+    }
+    hx::ModDownApply A;
+    A.xs = c->scratch[0];
+    A.S = reinterpret_cast<const int64_t*>(c->scratch[1]);
+    A.rows = reinterpret_cast<const hx::ModDownRow*>(it->second->blob);
+    hipError_t e = hx::launch_moddown_pow2(c->logn, a->d, drow, dprime, kr, nk, a->batch, P, A,
+                                           c->d_primes, c->d_tw, c->stream);
+    if (e != hipSuccess)
+      return fail(HX_ERR_DEVICE, "mod-down launch failed: %s", hipGetErrorString(e));
+    if (drow != last)
+      a->prime_idx[drow] = a->prime_idx[last];
+    a->prime_idx.pop_back();
+    return HX_OK;
+  }
   // toPoly(delta, diff): inverse transform of the dropped rows
   CHK(ensure_scratch(c, 0, (size_t)nd * rw));
   CHK(ensure_scratch(c, 1, (size_t)nk * rw));

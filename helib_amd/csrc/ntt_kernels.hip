@@ -60,27 +60,88 @@ struct BufIO {
   }
 };
 
-template <int LOGN, bool INV>
-__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
-ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
-               const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
-{
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  using R = RowNTT<LOGN>;
-  const unsigned tid = threadIdx.x;
-  const unsigned ri = blockIdx.x / (unsigned)batch;
-  const int b = (int)(blockIdx.x % (unsigned)batch);
-  const int row = rows.row[ri];
-  const PrimeDev* pd = primes + rows.prime[ri];
-  const size_t roff = ((size_t)row * batch + b) * (size_t)Geo<LOGN>::N;
-  const TW* tw = tw_arena + (INV ? pd->tw_inv_off : pd->tw_fwd_off);
-  const uint64_t q = pd->q;
+// inverse transform of the dropped row + delta preparation (see ModDownPrep)
+struct InvPrepIO {
+  v4i32 rin, rx, rS;
+  ModDownPrep P;
+  __device__ InvPrepIO(const uint64_t* in_row, const ModDownPrep& p, size_t boff, unsigned bytes)
+      : rin(make_rsrc(in_row, bytes)), rx(make_rsrc(p.xs + boff, bytes)),
+        rS(make_rsrc((const uint64_t*)(p.S + boff), bytes)), P(p)
+  {
+  }
+  __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
+  {
+    v2i32 r = hx_buffer_load_v2(rin, (int)(tid * 8u), (int)(c * 8u), 0);
+    return ((uint64_t)(uint32_t)r.y << 32) | (uint32_t)r.x;
+  }
+  __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t x) const
+  {
+    const bool neg = x > P.half;
+    int64_t S = neg ? 1 : 0;
+    if (P.ptxt > 1) {
+      const uint64_t p = P.ptxt;
+      uint64_t r = red64(x, p, P.ptxt_mu64);
+      if (neg)
+        r = sub_mod(r, P.qd_mod_p, p);  // delta mod p, non-negative
+      if (r != 0) {
+        uint64_t dm = mul_mod(r, P.qdinv_mod_p, p, P.ptxt_mu, P.ptxt_k);
+        const uint64_t p2 = p >> 1;
+        const bool sub_p = dm > p2 || (((p & 1) == 0) && dm == p2 && neg);
+        S += sub_p ? (int64_t)dm - (int64_t)p : (int64_t)dm;
+      }
+    }
+    v2i32 d;
+    d.x = (int)(uint32_t)x;
+    d.y = (int)(uint32_t)(x >> 32);
+    hx_buffer_store_v2(d, rx, (int)(tid * 8u), (int)(c * 8u), 0);
+    d.x = (int)(uint32_t)(uint64_t)S;
+    d.y = (int)(uint32_t)((uint64_t)S >> 32);
+    hx_buffer_store_v2(d, rS, (int)(tid * 8u), (int)(c * 8u), 0);
+  }
+};
+// forward transform of a kept row: load = delta mod q_r, store = (c_r - v) * qd^-1
+struct ModDownIO {
+  v4i32 rx, rS, rc, ro;
+  TW qdm, inv;
+  uint64_t q, mu64;
+  __device__ ModDownIO(const ModDownApply& A, const ModDownRow& R, size_t boff, const uint64_t* c_row,
+                       uint64_t* o_row, unsigned bytes, uint64_t q_, uint64_t mu64_)
+      : rx(make_rsrc(A.xs + boff, bytes)), rS(make_rsrc((const uint64_t*)(A.S + boff), bytes)),
+        rc(make_rsrc(c_row, bytes)), ro(make_rsrc(o_row, bytes)), qdm(R.qdm), inv(R.inv), q(q_),
+        mu64(mu64_)
+  {
+  }
+  __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
+  {
+    v2i32 a = hx_buffer_load_v2(rx, (int)(tid * 8u), (int)(c * 8u), 0);
+    v2i32 b = hx_buffer_load_v2(rS, (int)(tid * 8u), (int)(c * 8u), 0);
+    const uint64_t x = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
+    const int64_t S = (int64_t)(((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x);
+    uint64_t r = red64(x, q, mu64);
+    if (S != 0) {
+      const uint64_t mag = red64((uint64_t)(S < 0 ? -S : S), q, mu64);
+      const uint64_t t = mul_shoup(mag, qdm.w, qdm.wp, q);
+      r = S > 0 ? sub_mod(r, t, q) : add_mod(r, t, q);
+    }
+    return r;
+  }
+  __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t v) const
+  {
+    v2i32 a = hx_buffer_load_v2(rc, (int)(tid * 8u), (int)(c * 8u), 0);
+    const uint64_t cc = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
+    const uint64_t o = mul_shoup(sub_mod(cc, v, q), inv.w, inv.wp, q);
+    v2i32 d;
+    d.x = (int)(uint32_t)o;
+    d.y = (int)(uint32_t)(o >> 32);
+    hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), 0);
+  }
+};
 
-#ifdef HX_NTT_PTRIO
-  const PtrIO io{in + roff, out + roff};
-#else
-  const BufIO io(in + roff, out + roff, (unsigned)Geo<LOGN>::N * 8u);
-#endif
+template <int LOGN, bool INV, class IO>
+__device__ __forceinline__ void ntt_body(unsigned tid, uint32_t* lds, const IO& io, const TW* tw,
+                                         uint64_t q)
+{
+  using R = RowNTT<LOGN>;
   uint64_t v[32];
   uint32_t nl[32];
   if constexpr (!INV) {
@@ -118,6 +179,59 @@ ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
   }
 }
 
+// scaleDownToSet, one dropped prime: inverse transform of its row with the delta preparation
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
+ntt_moddown_prep_kernel(const uint64_t* in, int row, int prime, int batch, ModDownPrep P,
+                        const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int b = (int)blockIdx.x;
+  const PrimeDev* pd = primes + prime;
+  const size_t N = Geo<LOGN>::N;
+  const InvPrepIO io(in + ((size_t)row * batch + b) * N, P, (size_t)b * N, (unsigned)N * 8u);
+  ntt_body<LOGN, true>(threadIdx.x, lds, io, tw_arena + pd->tw_inv_off, pd->q);
+}
+// ... forward transform of delta on every kept row, subtract + divide in the store
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
+ntt_moddown_apply_kernel(uint64_t* data, NttRows rows, int batch, ModDownApply A,
+                         const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const unsigned ri = blockIdx.x / (unsigned)batch;
+  const int b = (int)(blockIdx.x % (unsigned)batch);
+  const PrimeDev* pd = primes + rows.prime[ri];
+  const size_t N = Geo<LOGN>::N;
+  const ModDownRow R = A.rows[ri];
+  const ModDownIO io(A, R, (size_t)b * N, data + ((size_t)rows.row[ri] * batch + b) * N,
+                     data + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd->q, pd->mu64);
+  ntt_body<LOGN, false>(threadIdx.x, lds, io, tw_arena + pd->tw_fwd_off, pd->q);
+}
+
+template <int LOGN, bool INV>
+__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
+ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
+               const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const unsigned tid = threadIdx.x;
+  const unsigned ri = blockIdx.x / (unsigned)batch;
+  const int b = (int)(blockIdx.x % (unsigned)batch);
+  const int row = rows.row[ri];
+  const PrimeDev* pd = primes + rows.prime[ri];
+  const size_t roff = ((size_t)row * batch + b) * (size_t)Geo<LOGN>::N;
+  const TW* tw = tw_arena + (INV ? pd->tw_inv_off : pd->tw_fwd_off);
+  const uint64_t q = pd->q;
+
+#ifdef HX_NTT_PTRIO
+  const PtrIO io{in + roff, out + roff};
+#else
+  const BufIO io(in + roff, out + roff, (unsigned)Geo<LOGN>::N * 8u);
+#endif
+  ntt_body<LOGN, INV>(tid, lds, io, tw, q);
+}
+
 template <int LOGN, bool INV>
 static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows,
                              int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
@@ -135,6 +249,43 @@ static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& r
   hipLaunchKernelGGL((ntt_row_kernel<LOGN, INV>), grid, block, lds_bytes, st, in, out, rows, batch,
                      primes, tw_arena);
   return hipGetLastError();
+}
+
+template <int LOGN>
+static hipError_t launch_moddown(uint64_t* data, int drop_row, int drop_prime, const NttRows& keep,
+                                 int nkeep, int batch, const ModDownPrep& P, const ModDownApply& A,
+                                 const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)ntt_moddown_prep_kernel<LOGN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_kernel<LOGN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess)
+      return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((ntt_moddown_prep_kernel<LOGN>), dim3((unsigned)batch), dim3(Geo<LOGN>::T), lds_bytes,
+                     st, (const uint64_t*)data, drop_row, drop_prime, batch, P, primes, tw_arena);
+  hipLaunchKernelGGL((ntt_moddown_apply_kernel<LOGN>), dim3((unsigned)nkeep * (unsigned)batch),
+                     dim3(Geo<LOGN>::T), lds_bytes, st, data, keep, batch, A, primes, tw_arena);
+  return hipGetLastError();
+}
+
+hipError_t launch_moddown_pow2(int logn, uint64_t* data, int drop_row, int drop_prime,
+                               const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
+                               const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena,
+                               hipStream_t st)
+{
+  switch (logn) {
+    case 13: return launch_moddown<13>(data, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+    case 14: return launch_moddown<14>(data, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+    case 15: return launch_moddown<15>(data, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+  }
+  return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------

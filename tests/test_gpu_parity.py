@@ -519,3 +519,25 @@ def test_ctxt_multiplyBy_full_sequence_gpu_vs_oracle(hx, m, p, bits):
         assert got == want
     else:
         assert got == T.decrypt(ctx, P.o, s, oa, rows)
+
+
+@pytest.mark.parametrize("ptxt", [65537, 2, 1, 4])
+@pytest.mark.parametrize("m", [16384, 32768])
+def test_scale_down_single_prime_fused_path(hx, m, ptxt):
+    """One dropped prime takes the fused path (delta prepared inside the inverse transform of
+    the dropped row, subtract/divide inside the forward transform's store); the surviving rows
+    may be re-ordered (last row moves into the freed slot), so rows are matched by prime."""
+    P, own, sp = setup_rns(hx, m=m, L=5, K=2)
+    allp = own + sp
+    a = P.rand(allp, 12, batch=2)
+    for drop in (allp[-1], allp[2], allp[0]):
+        d = hx.DoubleCRT(P.g, allp, 2, a)
+        keep = [i for i in allp if i != drop]
+        d.scaleDownToSet(keep, ptxt)
+        got_idx = d.getIndexSet()
+        assert sorted(got_idx) == sorted(keep)
+        got = d.download()
+        for b in range(2):
+            want = P.o.scale_down(allp, a[:, b], [drop], ptxt)
+            for r, i in enumerate(got_idx):
+                assert np.array_equal(got[r, b], want[keep.index(i)]), (drop, i)
