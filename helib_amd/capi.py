@@ -43,7 +43,8 @@ SYMBOLS = [
     "hx_ntt_forward", "hx_ntt_inverse",
     "hx_add", "hx_sub", "hx_mul", "hx_negate", "hx_add_scalar", "hx_sub_scalar", "hx_mul_scalar",
     "hx_automorph", "hx_complex_conj",
-    "hx_add_primes_and_scale", "hx_add_primes", "hx_scale_down", "hx_break_into_digits",
+    "hx_add_primes_and_scale", "hx_add_primes", "hx_scale_down", "hx_scale_down_multi",
+    "hx_break_into_digits",
     "hx_ksk_create", "hx_ksk_destroy", "hx_tensor", "hx_key_switch_digits", "hx_mul_relin",
     "hx_relinearize",
     "hx_intel_FFTFwd", "hx_intel_FFTRev1", "hx_intel_EltwiseAddMod", "hx_intel_EltwiseAddModScalar",
@@ -83,6 +84,7 @@ def lib():
             "hx_automorph": [vp, u64], "hx_complex_conj": [vp],
             "hx_add_primes_and_scale": [vp, vp, ip], "hx_add_primes": [vp, vp, ip],
             "hx_scale_down": [vp, vp, ip, u64],
+            "hx_scale_down_multi": [vp, ip, vp, ip, u64],
             "hx_break_into_digits": [vp, vp, vp, ip, vp, ip, vp],
             "hx_ksk_create": [vp, ip, vp, ip, vp, vp, vp], "hx_ksk_destroy": [vp],
             "hx_tensor": [vp] * 7, "hx_key_switch_digits": [vp] * 4,
@@ -355,6 +357,16 @@ def multiplyBy(c0, c1, d0, d1, W, digits, out0=None, out1=None):
     _chk(lib().hx_mul_relin(c0.h, c1.h, d0.h, d1.h, W.h, _p(dig_idx), _p(dig_off), len(digits),
                             out0.h, out1.h))
     return out0, out1
+
+
+def scaleDownToSetMulti(polys, keep_set, ptxtSpace):
+    """DoubleCRT::scaleDownToSet on several parts that share one prime set, batched into one
+    pair of launches where possible."""
+    polys = list(polys)
+    keep = set(keep_set)
+    drop = _i32([i for i in polys[0].getIndexSet() if i not in keep])
+    arr = (C.c_void_p * len(polys))(*[p.h for p in polys])
+    _chk(lib().hx_scale_down_multi(arr, len(polys), _p(drop), len(drop), ptxtSpace))
 
 
 def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None):

@@ -63,6 +63,13 @@ struct ModDownApply {
   const int64_t* S;
   const ModDownRow* rows;  // [launch rows]
 };
+// several DoubleCRT objects with the same prime set (the parts of one or two ciphertexts) are
+// mod-switched by one pair of launches: xs/S hold [poly][batch][N]
+constexpr int MD_MAXPOLY = 8;
+struct PolyBases {
+  uint64_t* d[MD_MAXPOLY];
+  int n;
+};
 struct RowMap2 {
   uint16_t p[MAX_ROWS];
   uint16_t brow[MAX_ROWS];

@@ -22,7 +22,7 @@ namespace hx {
 hipError_t launch_ntt_pow2(int logn, bool inverse, const uint64_t* in, uint64_t* out,
                            const NttRows& rows, int nrows, int batch, const PrimeDev* primes,
                            const TW* tw_arena, hipStream_t st);
-hipError_t launch_moddown_pow2(int logn, uint64_t* data, int drop_row, int drop_prime,
+hipError_t launch_moddown_pow2(int logn, const PolyBases& data, int drop_row, int drop_prime,
                                const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
                                const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena,
                                hipStream_t st);
@@ -34,6 +34,7 @@ using hx::MAX_ROWS;
 using hx::ModDownApply;
 using hx::ModDownPrep;
 using hx::NttRows;
+using hx::PolyBases;
 using hx::PrimeDev;
 using hx::RowMap;
 using hx::RowMap2;
@@ -1566,8 +1567,13 @@ extern "C" int hx_add_primes(hx_poly* a, const int* add_idx, int nadd)
   return HX_OK;
 }
 
-extern "C" int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_t ptxt)
+// others[0..nother): further polys with exactly a's prime rows and batch, mod-switched by the
+// same launches when the fused single-prime path applies (returns HX_ERR_UNSUPPORTED otherwise
+// when nother > 0, so that the caller can fall back to one call per poly).
+static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* drop_idx, int ndrop,
+                           uint64_t ptxt)
 {
+
   if (!a)
     return fail(HX_ERR_INVALID, "null poly");
   hx_ctx* c = a->ctx;
@@ -1597,8 +1603,14 @@ extern "C" int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_
     // the dropped row's slot, so no compaction copy is needed.
     const int dprime = drop[0], drow = find_row(a->prime_idx, dprime), last = a->nrows() - 1;
     const uint64_t qd = c->primes[dprime].q;
-    CHK(ensure_scratch(c, 0, rw));
-    CHK(ensure_scratch(c, 1, rw));
+    PolyBases pb;
+    memset(&pb, 0, sizeof pb);
+    pb.n = 1 + nother;
+    pb.d[0] = a->d;
+    for (int i = 0; i < nother; i++)
+      pb.d[1 + i] = others[i]->d;
+    CHK(ensure_scratch(c, 0, rw * pb.n));
+    CHK(ensure_scratch(c, 1, rw * pb.n));
     hx::ModDownPrep P;
     memset(&P, 0, sizeof P);
     P.xs = c->scratch[0];
@@ -1651,15 +1663,19 @@ extern "C" int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_
     A.xs = c->scratch[0];
     A.S = reinterpret_cast<const int64_t*>(c->scratch[1]);
     A.rows = reinterpret_cast<const hx::ModDownRow*>(it->second->blob);
-    hipError_t e = hx::launch_moddown_pow2(c->logn, a->d, drow, dprime, kr, nk, a->batch, P, A,
+    hipError_t e = hx::launch_moddown_pow2(c->logn, pb, drow, dprime, kr, nk, a->batch, P, A,
                                            c->d_primes, c->d_tw, c->stream);
     if (e != hipSuccess)
       return fail(HX_ERR_DEVICE, "mod-down launch failed: %s", hipGetErrorString(e));
     if (drow != last)
       a->prime_idx[drow] = a->prime_idx[last];
     a->prime_idx.pop_back();
+    for (int i = 0; i < nother; i++)
+      others[i]->prime_idx = a->prime_idx;
     return HX_OK;
   }
+  if (nother > 0)
+    return HX_ERR_UNSUPPORTED;
   // toPoly(delta, diff): inverse transform of the dropped rows
   CHK(ensure_scratch(c, 0, (size_t)nd * rw));
   CHK(ensure_scratch(c, 1, (size_t)nk * rw));
@@ -1698,6 +1714,40 @@ extern "C" int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_
   hipLaunchKernelGGL(hx::sub_scale_kernel, ew_grid(rw, nk), dim3(256), 0, c->stream, a->d,
                      c->scratch[1], map, sc, rw, c->d_primes);
   HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+
+extern "C" int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_t ptxt)
+{
+  return scale_down_impl(a, nullptr, 0, drop_idx, ndrop, ptxt);
+}
+
+// The same mod-switch applied to several DoubleCRT objects that share one prime set and batch
+// (the parts of the ciphertexts being brought to a common level, src/Ctxt.cpp:462-465): one pair
+// of launches covers all of them when a single prime is dropped.
+extern "C" int hx_scale_down_multi(hx_poly** polys, int npoly, const int* drop_idx, int ndrop,
+                                   uint64_t ptxt)
+{
+  if (!polys || npoly < 1)
+    return fail(HX_ERR_INVALID, "bad argument");
+  bool same = npoly <= hx::MD_MAXPOLY;
+  for (int i = 0; i < npoly; i++) {
+    if (!polys[i])
+      return fail(HX_ERR_INVALID, "null poly");
+    if (polys[i]->ctx != polys[0]->ctx || polys[i]->batch != polys[0]->batch ||
+        polys[i]->prime_idx != polys[0]->prime_idx)
+      same = false;
+    for (int j = 0; j < i; j++)
+      if (polys[j] == polys[i])
+        return fail(HX_ERR_INVALID, "the same poly listed twice");
+  }
+  if (same && npoly > 1) {
+    int rc = scale_down_impl(polys[0], polys + 1, npoly - 1, drop_idx, ndrop, ptxt);
+    if (rc != HX_ERR_UNSUPPORTED)
+      return rc;
+  }
+  for (int i = 0; i < npoly; i++)
+    CHK(scale_down_impl(polys[i], nullptr, 0, drop_idx, ndrop, ptxt));
   return HX_OK;
 }
 

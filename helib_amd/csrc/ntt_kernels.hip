@@ -182,29 +182,33 @@ __device__ __forceinline__ void ntt_body(unsigned tid, uint32_t* lds, const IO& 
 // scaleDownToSet, one dropped prime: inverse transform of its row with the delta preparation
 template <int LOGN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
-ntt_moddown_prep_kernel(const uint64_t* in, int row, int prime, int batch, ModDownPrep P,
+ntt_moddown_prep_kernel(PolyBases polys, int row, int prime, int batch, ModDownPrep P,
                         const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const int b = (int)blockIdx.x;
+  const int b = (int)(blockIdx.x % (unsigned)batch), pi = (int)(blockIdx.x / (unsigned)batch);
   const PrimeDev* pd = primes + prime;
   const size_t N = Geo<LOGN>::N;
-  const InvPrepIO io(in + ((size_t)row * batch + b) * N, P, (size_t)b * N, (unsigned)N * 8u);
+  const uint64_t* in = polys.d[pi];
+  const InvPrepIO io(in + ((size_t)row * batch + b) * N, P, ((size_t)pi * batch + b) * N,
+                     (unsigned)N * 8u);
   ntt_body<LOGN, true>(threadIdx.x, lds, io, tw_arena + pd->tw_inv_off, pd->q);
 }
 // ... forward transform of delta on every kept row, subtract + divide in the store
 template <int LOGN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
-ntt_moddown_apply_kernel(uint64_t* data, NttRows rows, int batch, ModDownApply A,
+ntt_moddown_apply_kernel(PolyBases polys, NttRows rows, int nkeep, int batch, ModDownApply A,
                          const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const unsigned ri = blockIdx.x / (unsigned)batch;
   const int b = (int)(blockIdx.x % (unsigned)batch);
+  const unsigned rp = blockIdx.x / (unsigned)batch;
+  const unsigned ri = rp % (unsigned)nkeep, pi = rp / (unsigned)nkeep;
   const PrimeDev* pd = primes + rows.prime[ri];
   const size_t N = Geo<LOGN>::N;
   const ModDownRow R = A.rows[ri];
-  const ModDownIO io(A, R, (size_t)b * N, data + ((size_t)rows.row[ri] * batch + b) * N,
+  uint64_t* data = polys.d[pi];
+  const ModDownIO io(A, R, ((size_t)pi * batch + b) * N, data + ((size_t)rows.row[ri] * batch + b) * N,
                      data + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd->q, pd->mu64);
   ntt_body<LOGN, false>(threadIdx.x, lds, io, tw_arena + pd->tw_fwd_off, pd->q);
 }
@@ -252,9 +256,10 @@ static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& r
 }
 
 template <int LOGN>
-static hipError_t launch_moddown(uint64_t* data, int drop_row, int drop_prime, const NttRows& keep,
-                                 int nkeep, int batch, const ModDownPrep& P, const ModDownApply& A,
-                                 const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+static hipError_t launch_moddown(const PolyBases& polys, int drop_row, int drop_prime,
+                                 const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
+                                 const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena,
+                                 hipStream_t st)
 {
   constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
   static bool attr_set = false;
@@ -268,14 +273,16 @@ static hipError_t launch_moddown(uint64_t* data, int drop_row, int drop_prime, c
       return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((ntt_moddown_prep_kernel<LOGN>), dim3((unsigned)batch), dim3(Geo<LOGN>::T), lds_bytes,
-                     st, (const uint64_t*)data, drop_row, drop_prime, batch, P, primes, tw_arena);
-  hipLaunchKernelGGL((ntt_moddown_apply_kernel<LOGN>), dim3((unsigned)nkeep * (unsigned)batch),
-                     dim3(Geo<LOGN>::T), lds_bytes, st, data, keep, batch, A, primes, tw_arena);
+  hipLaunchKernelGGL((ntt_moddown_prep_kernel<LOGN>), dim3((unsigned)polys.n * (unsigned)batch),
+                     dim3(Geo<LOGN>::T), lds_bytes, st, polys, drop_row, drop_prime, batch, P, primes,
+                     tw_arena);
+  hipLaunchKernelGGL((ntt_moddown_apply_kernel<LOGN>),
+                     dim3((unsigned)polys.n * (unsigned)nkeep * (unsigned)batch), dim3(Geo<LOGN>::T),
+                     lds_bytes, st, polys, keep, nkeep, batch, A, primes, tw_arena);
   return hipGetLastError();
 }
 
-hipError_t launch_moddown_pow2(int logn, uint64_t* data, int drop_row, int drop_prime,
+hipError_t launch_moddown_pow2(int logn, const PolyBases& data, int drop_row, int drop_prime,
                                const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
                                const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena,
                                hipStream_t st)

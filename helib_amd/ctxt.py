@@ -330,8 +330,11 @@ class Ctxt:
         if not diff:
             return
         added = self.modSwitchAddedNoiseBound()
-        for p in self.parts.values():
-            p.scaleDownToSet(sorted(inter), self.ptxtSpace)
+        if hasattr(self.ops, "scaleDownToSetMulti"):
+            self.ops.scaleDownToSetMulti(list(self.parts.values()), sorted(inter), self.ptxtSpace)
+        else:
+            for p in self.parts.values():
+                p.scaleDownToSet(sorted(inter), self.ptxtSpace)
         self.lnNoise = logaddexp(self.lnNoise - self.context.logOfProduct(diff), math.log(added))
         self.primeSet = inter
 
@@ -339,6 +342,26 @@ class Ctxt:
         s = frozenset(s) if s else frozenset([self.context.ctxtPrimes[0]])
         self.modUpToSet(s)
         self.modDownToSet(s)
+
+    @staticmethod
+    def _bringBothToSet(a, b, s):
+        """bringToSet(s) on two ciphertexts that sit on the same prime set: identical arithmetic
+        and bookkeeping to calling it on each, with one batched mod-switch for all parts."""
+        s = frozenset(s) if s else frozenset([a.context.ctxtPrimes[0]])
+        a.modUpToSet(s)
+        b.modUpToSet(s)
+        inter = a.primeSet & s
+        if not inter:
+            raise RuntimeError(f"modDownToSet called from {sorted(a.primeSet)} to {sorted(s)}")
+        diff = a.primeSet - inter
+        if not diff:
+            return
+        a.ops.scaleDownToSetMulti(list(a.parts.values()) + list(b.parts.values()), sorted(inter),
+                                  a.ptxtSpace)
+        for c in (a, b):
+            added = c.modSwitchAddedNoiseBound()
+            c.lnNoise = logaddexp(c.lnNoise - c.context.logOfProduct(diff), math.log(added))
+            c.primeSet = inter
 
     def dropSmallAndSpecialPrimes(self):
         ctx = self.context
@@ -389,8 +412,11 @@ class Ctxt:
         o.intFactor %= g
         lo, hi = Ctxt.computeIntervalForMul(self, o)
         common = self.context.modSizes.getSet4Size(lo, hi, self.primeSet, o.primeSet, False)
-        self.bringToSet(common)
-        o.bringToSet(common)
+        if self.primeSet == o.primeSet and hasattr(self.ops, "scaleDownToSetMulti"):
+            Ctxt._bringBothToSet(self, o, common)   # same result, the 4 parts share the launches
+        else:
+            self.bringToSet(common)
+            o.bringToSet(common)
         self._tensorProduct(o)
 
     def _tensorProduct(self, o):

@@ -138,6 +138,10 @@ int hx_add_primes(hx_poly* a, const int* add_idx, int nadd);
 /* DoubleCRT::scaleDownToSet (src/DoubleCRT.cpp:1464-1516): drop drop_idx with
  * exact rounding, delta forced to 0 mod ptxt_space.  In place. */
 int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_t ptxt_space);
+/* The same for several DoubleCRT objects sharing one prime set and batch (all parts of the
+ * ciphertexts of one Ctxt::modDownToSet, src/Ctxt.cpp:462-465) in one pair of launches. */
+int hx_scale_down_multi(hx_poly** polys, int npoly, const int* drop_idx, int ndrop,
+                        uint64_t ptxt_space);
 /* DoubleCRT::breakIntoDigits (src/DoubleCRT.cpp:479-561).  a has ctxt primes
  * only; digit d = dig_idx[dig_off[d]..dig_off[d+1]); special primes sp_idx.
  * digits_out: poly with ndig*(nrows(a)+nsp) rows, block d holding digit d on
