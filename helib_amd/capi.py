@@ -37,7 +37,7 @@ SYMBOLS = [
     "hx_last_error", "hx_version", "hx_device_count",
     "hx_ctx_create", "hx_ctx_destroy", "hx_ctx_phim", "hx_ctx_set_stream", "hx_ctx_sync",
     "hx_ctx_add_prime", "hx_ctx_num_primes", "hx_ctx_prime",
-    "hx_poly_create", "hx_poly_wrap", "hx_poly_destroy", "hx_poly_shape", "hx_poly_primes",
+    "hx_poly_create", "hx_poly_create_uninit", "hx_poly_wrap", "hx_poly_destroy", "hx_poly_shape", "hx_poly_primes",
     "hx_poly_device_ptr", "hx_poly_upload", "hx_poly_download", "hx_poly_copy",
     "hx_poly_set_zero", "hx_poly_remove_primes",
     "hx_ntt_forward", "hx_ntt_inverse",
@@ -74,7 +74,8 @@ def lib():
             "hx_ctx_set_stream": [vp, vp], "hx_ctx_sync": [vp],
             "hx_ctx_add_prime": [vp, u64, u64, vp], "hx_ctx_num_primes": [vp, vp],
             "hx_ctx_prime": [vp, ip, vp, vp],
-            "hx_poly_create": [vp, ip, vp, ip, vp], "hx_poly_wrap": [vp, ip, vp, ip, vp, vp],
+            "hx_poly_create": [vp, ip, vp, ip, vp], "hx_poly_create_uninit": [vp, ip, vp, ip, vp],
+            "hx_poly_wrap": [vp, ip, vp, ip, vp, vp],
             "hx_poly_destroy": [vp], "hx_poly_shape": [vp, vp, vp, vp], "hx_poly_primes": [vp, vp],
             "hx_poly_upload": [vp, vp], "hx_poly_download": [vp, vp], "hx_poly_copy": [vp, vp],
             "hx_poly_set_zero": [vp], "hx_poly_remove_primes": [vp, vp, ip],
@@ -176,11 +177,12 @@ class DoubleCRT:
 
     rows are numpy uint64 arrays of shape [nrows, batch, phim] on the host side."""
 
-    def __init__(self, context, index_set, batch=1, data=None):
+    def __init__(self, context, index_set, batch=1, data=None, zero=True):
         self.context = context
         idx = _i32(list(index_set))
         self.h = C.c_void_p()
-        _chk(lib().hx_poly_create(context.h, batch, _p(idx), len(idx), C.byref(self.h)))
+        create = lib().hx_poly_create if (zero and data is None) else lib().hx_poly_create_uninit
+        _chk(create(context.h, batch, _p(idx), len(idx), C.byref(self.h)))
         self.batch = batch
         if data is not None:
             self.upload(data)
@@ -218,7 +220,7 @@ class DoubleCRT:
         return out
 
     def copy(self):
-        o = DoubleCRT(self.context, self.getIndexSet(), self.batch)
+        o = DoubleCRT(self.context, self.getIndexSet(), self.batch, zero=False)
         _chk(lib().hx_poly_copy(o.h, self.h))
         return o
 
@@ -307,7 +309,7 @@ class DoubleCRT:
         dig_idx = _i32([p for d in digits for p in d])
         dig_off = _i32(np.concatenate([[0], np.cumsum([len(d) for d in digits])]))
         sp = _i32(list(special))
-        out = DoubleCRT(self.context, self.getIndexSet(), self.batch)
+        out = DoubleCRT(self.context, self.getIndexSet(), self.batch, zero=False)
         _chk(lib().hx_break_into_digits(self.h, _p(dig_idx), _p(dig_off), len(digits), _p(sp),
                                         len(sp), out.h))
         return out
@@ -337,7 +339,7 @@ class KeySwitch:
 
 def tensorProduct(c0, c1, d0, d1):
     ctx = c0.context
-    outs = [DoubleCRT(ctx, c0.getIndexSet(), c0.batch) for _ in range(3)]
+    outs = [DoubleCRT(ctx, c0.getIndexSet(), c0.batch, zero=False) for _ in range(3)]
     _chk(lib().hx_tensor(c0.h, c1.h, d0.h, d1.h, outs[0].h, outs[1].h, outs[2].h))
     return outs
 
@@ -352,8 +354,8 @@ def multiplyBy(c0, c1, d0, d1, W, digits, out0=None, out1=None):
     dig_idx = _i32([p for d in digits for p in d])
     dig_off = _i32(np.concatenate([[0], np.cumsum([len(d) for d in digits])]))
     if out0 is None:
-        out0 = DoubleCRT(ctx, c0.getIndexSet(), c0.batch)
-        out1 = DoubleCRT(ctx, c0.getIndexSet(), c0.batch)
+        out0 = DoubleCRT(ctx, c0.getIndexSet(), c0.batch, zero=False)
+        out1 = DoubleCRT(ctx, c0.getIndexSet(), c0.batch, zero=False)
     _chk(lib().hx_mul_relin(c0.h, c1.h, d0.h, d1.h, W.h, _p(dig_idx), _p(dig_off), len(digits),
                             out0.h, out1.h))
     return out0, out1
@@ -376,8 +378,8 @@ def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None):
     dig_off = _i32(np.concatenate([[0], np.cumsum([len(d) for d in digits])]))
     sp = _i32(list(special))
     if out0 is None:
-        out0 = DoubleCRT(ctx, t0.getIndexSet(), t0.batch)
-        out1 = DoubleCRT(ctx, t0.getIndexSet(), t0.batch)
+        out0 = DoubleCRT(ctx, t0.getIndexSet(), t0.batch, zero=False)
+        out1 = DoubleCRT(ctx, t0.getIndexSet(), t0.batch, zero=False)
     _chk(lib().hx_relinearize(t0.h, t1.h, t2.h, W.h, _p(dig_idx), _p(dig_off), len(digits), _p(sp),
                               len(sp), out0.h, out1.h))
     return out0, out1

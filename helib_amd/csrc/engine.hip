@@ -912,7 +912,7 @@ static int check_rows(hx_ctx* c, const int* idx, int n, bool allow_dup = false)
 }
 
 static int poly_new(hx_ctx* c, int batch, const int* idx, int nrows, int cap, void* wrap,
-                    bool allow_dup, hx_poly** out)
+                    bool allow_dup, hx_poly** out, bool zero = true)
 {
   if (!c || !out || batch < 1)
     return fail(HX_ERR_INVALID, "bad argument");
@@ -940,7 +940,7 @@ static int poly_new(hx_ctx* c, int batch, const int* idx, int nrows, int cap, vo
       return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
     // DoubleCRT(context, set) is zero-initialised: only the live rows need it
-    e = hipMemsetAsync(p->d, 0, (size_t)nrows * batch * c->phim * 8, c->stream);
+    e = zero ? hipMemsetAsync(p->d, 0, (size_t)nrows * batch * c->phim * 8, c->stream) : hipSuccess;
     if (e != hipSuccess) {
       pool_free(c, p->d, bytes);
       delete p;
@@ -955,6 +955,10 @@ static int poly_new(hx_ctx* c, int batch, const int* idx, int nrows, int cap, vo
 extern "C" int hx_poly_create(hx_ctx* c, int batch, const int* idx, int nrows, hx_poly** out)
 {
   return poly_new(c, batch, idx, nrows, nrows, nullptr, false, out);
+}
+extern "C" int hx_poly_create_uninit(hx_ctx* c, int batch, const int* idx, int nrows, hx_poly** out)
+{
+  return poly_new(c, batch, idx, nrows, nrows, nullptr, false, out, false);
 }
 extern "C" int hx_poly_wrap(hx_ctx* c, int batch, const int* idx, int nrows, void* dptr,
                             hx_poly** out)
@@ -2212,13 +2216,21 @@ extern "C" int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_pol
   size_t rw = t0->row_words();
   CHK(poly_reserve(out0, nall));
   CHK(poly_reserve(out1, nall));
-  HIPCHK(hipMemcpyAsync(out0->d, t0->d, (size_t)L * rw * 8, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(out1->d, t1->d, (size_t)L * rw * 8, hipMemcpyDeviceToDevice, c->stream));
-  out0->prime_idx = t0->prime_idx;
-  out1->prime_idx = t0->prime_idx;
+  // parts (1),(s): addPrimesAndScale(special) written straight into the outputs
   std::vector<uint64_t> f = special_factor(c, t0->prime_idx, sp_idx, nsp);
-  CHK(ew_scalar_rows<hx::EWS_MUL>(out0, f.data()));
-  CHK(ew_scalar_rows<hx::EWS_MUL>(out1, f.data()));
+  {
+    RowMap map;
+    RowScalars sc;
+    for (int r = 0; r < L; r++) {
+      uint64_t q = c->primes[t0->prime_idx[r]].q;
+      map.p[r] = (uint16_t)t0->prime_idx[r];
+      sc.c[r] = f[r] % q;
+      sc.cp[r] = hxh::shoup(sc.c[r], q);
+    }
+    hipLaunchKernelGGL(hx::scale2_kernel, ew_grid(rw, L), dim3(256), 0, c->stream, t0->d, t1->d, out0->d,
+                       out1->d, map, sc, rw, c->d_primes);
+    HIPCHK(hipGetLastError());
+  }
   out0->prime_idx = all;
   out1->prime_idx = all;
   return relin_core(c, t2->d, t0->prime_idx, all, W, dig_idx, dig_off, ndig, t0->batch, out0->d,

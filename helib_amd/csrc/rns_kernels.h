@@ -76,6 +76,31 @@ ew_scalar_kernel(uint64_t* __restrict__ a, RowMap map, RowScalars sc, size_t row
   }
 }
 
+// (o0, o1) = (a0, a1) * c per row, out of place: parts (1) and (s) of reLinearize
+__global__ void __launch_bounds__(256)
+scale2_kernel(const uint64_t* __restrict__ a0, const uint64_t* __restrict__ a1,
+              uint64_t* __restrict__ o0, uint64_t* __restrict__ o1, RowMap map, RowScalars sc,
+              size_t row_words, const PrimeDev* __restrict__ primes)
+{
+  const int row = blockIdx.y;
+  const uint64_t q = primes[map.p[row]].q;
+  const uint64_t c = sc.c[row], cp = sc.cp[row];
+  const size_t off = (size_t)row * row_words;
+  const size_t nvec = row_words / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = off + 2 * i;
+    ulonglong2 x = *reinterpret_cast<const ulonglong2*>(a0 + e);
+    ulonglong2 y = *reinterpret_cast<const ulonglong2*>(a1 + e);
+    x.x = mul_shoup(x.x, c, cp, q);
+    x.y = mul_shoup(x.y, c, cp, q);
+    y.x = mul_shoup(y.x, c, cp, q);
+    y.y = mul_shoup(y.y, c, cp, q);
+    *reinterpret_cast<ulonglong2*>(o0 + e) = x;
+    *reinterpret_cast<ulonglong2*>(o1 + e) = y;
+  }
+}
+
 // automorph: out[row][b][j] = in[row][b][perm(j)], perm shared by all rows.
 // pow2 m: perm(j) = (((2j+1)*k mod m) - 1)/2 computed in registers;
 // general m: perm table built once per call by perm_kernel.

@@ -86,6 +86,8 @@ int hx_ctx_prime(const hx_ctx* ctx, int idx, uint64_t* q, uint64_t* root);
 /* ---------------- DoubleCRT storage ---------------- */
 /* DoubleCRT(context, indexSet): zero-initialised rows for primes prime_idx[]. */
 int hx_poly_create(hx_ctx* ctx, int batch, const int* prime_idx, int nrows, hx_poly** out);
+/* Same without the zero fill, for objects that are about to be overwritten (outputs). */
+int hx_poly_create_uninit(hx_ctx* ctx, int batch, const int* prime_idx, int nrows, hx_poly** out);
 /* Same, on caller-owned device memory (e.g. a torch tensor's data_ptr) of
  * nrows*batch*phim uint64; not zeroed, never freed by the library. */
 int hx_poly_wrap(hx_ctx* ctx, int batch, const int* prime_idx, int nrows, void* device_ptr,
