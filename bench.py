@@ -206,6 +206,7 @@ def run_fresh(hx, hc, cc, ctx, B, steps, warmup, rng, sync, barrier):
     fa = hc.Ctxt.fresh(cc, hx, base[0], base[1], ksw=W)
     fb = hc.Ctxt.fresh(cc, hx, base[2], base[3], ksw=W)
     res = [None]
+    host = [0.0]
 
     def one():
         a, b = fa.clone(), fb.clone()   # untimed copies (state.PauseTiming() in the reference)
@@ -213,16 +214,19 @@ def run_fresh(hx, hc, cc, ctx, B, steps, warmup, rng, sync, barrier):
         t0 = time.perf_counter()
         a.multLowLvl(b, destructive=True)
         a.reLinearize()
+        t1 = time.perf_counter()        # everything enqueued; the GPU may still be running
         sync()
         res[0] = a
+        host[0] += t1 - t0
         return time.perf_counter() - t0
 
     for _ in range(warmup):
         one()
     barrier()
+    host[0] = 0.0
     dt = sum(one() for _ in range(steps))
     barrier()
-    return dt, sorted(res[0].primeSet)
+    return dt, sorted(res[0].primeSet), host[0]
 
 
 def ntt_roofline(hx, ctx, primes_list, own, sp, digits, B, rng, iters):
@@ -279,7 +283,8 @@ def main():
         ctx.set_stream(stream)
         n = ctx.phim
         l, k, d = len(cc.ctxtPrimes), len(cc.specialPrimes), len(cc.digits)
-        dt, res_primes = run_fresh(hx, hc, cc, ctx, B, args.steps, args.warmup, rng, sync, group.barrier)
+        dt, res_primes, host_s = run_fresh(hx, hc, cc, ctx, B, args.steps, args.warmup, rng, sync,
+                                           group.barrier)
         dt = group.max_over_ranks(dt)
         # the kernel-level pipeline alone (ctxt primes as rows 0.., specials after)
         shape = dict(M=cc.m, L=l, K=k, digits=[[i - cc.ctxtPrimes[0] for i in dg] for dg in cc.digits])
@@ -297,6 +302,7 @@ def main():
         extra = {"fixed_level_mult_per_s": round(world * B * args.steps / dtf, 1),
                  "fixed_level_ms_per_step": round(dtf / args.steps * 1e3, 4),
                  "fixed_level_algorithmic_MB_per_mult": round(algorithmic_bytes_fixed(n, l, k, d) / 1e6, 2),
+                 "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 4),
                  "result_primes": res_primes}
         if rank == 0:
             roof = ntt_roofline(hx, sub, fixed_primes, list(range(l)), list(range(l, l + k)),

@@ -137,6 +137,20 @@ struct ModDownIO {
   }
 };
 
+// XCD-aware work mapping: hardware places workgroup id on XCD (id % 8) (observed, used for speed
+// only).  Remap so that each XCD works on a contiguous chunk of the (row, batch) space, i.e. on a
+// few primes only: their twiddle tables (2*N*16 B each) then stay resident in that XCD's 4 MiB
+// L2 instead of all primes' tables cycling through every L2.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned nwg)
+{
+#ifdef HX_NO_XCD_REMAP
+  return id;
+#else
+  const unsigned xcd = id & 7u, slot = id >> 3, qd = nwg >> 3, r = nwg & 7u;
+  return (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + slot;
+#endif
+}
+
 template <int LOGN, bool INV, class IO>
 __device__ __forceinline__ void ntt_body(unsigned tid, uint32_t* lds, const IO& io, const TW* tw,
                                          uint64_t q)
@@ -201,9 +215,11 @@ ntt_moddown_apply_kernel(PolyBases polys, NttRows rows, int nkeep, int batch, Mo
                          const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const int b = (int)(blockIdx.x % (unsigned)batch);
-  const unsigned rp = blockIdx.x / (unsigned)batch;
-  const unsigned ri = rp % (unsigned)nkeep, pi = rp / (unsigned)nkeep;
+  // (row, poly, batch) order so that a chunk of consecutive work items shares one prime
+  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = (int)(wid % (unsigned)batch);
+  const unsigned rp = wid / (unsigned)batch;
+  const unsigned pi = rp % (unsigned)polys.n, ri = rp / (unsigned)polys.n;
   const PrimeDev* pd = primes + rows.prime[ri];
   const size_t N = Geo<LOGN>::N;
   const ModDownRow R = A.rows[ri];
@@ -220,8 +236,9 @@ ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const unsigned tid = threadIdx.x;
-  const unsigned ri = blockIdx.x / (unsigned)batch;
-  const int b = (int)(blockIdx.x % (unsigned)batch);
+  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned ri = wid / (unsigned)batch;
+  const int b = (int)(wid % (unsigned)batch);
   const int row = rows.row[ri];
   const PrimeDev* pd = primes + rows.prime[ri];
   const size_t roff = ((size_t)row * batch + b) * (size_t)Geo<LOGN>::N;

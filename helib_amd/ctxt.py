@@ -70,6 +70,7 @@ class ModuliSizes:
             sizes += [(s + isz, st | fs) for s, st in base]
         sizes.sort(key=lambda e: (e[0], sorted(e[1])))
         self.sizes = sizes
+        self._keys = [s for s, _ in sizes]
 
     def _cost(self, frm, to):
         if self.iFFT_cost == 0:
@@ -82,8 +83,7 @@ class ModuliSizes:
         from2 = frozenset(from2) if from2 is not None else None
         cost = (lambda s: self._cost(from1, s)) if from2 is None else \
                (lambda s: self._cost(from1, s) + self._cost(from2, s))
-        keys = [s for s, _ in self.sizes]
-        idx = bisect.bisect_left(keys, low)
+        idx = bisect.bisect_left(self._keys, low)
         best, best_cost = -1, None
         ii = idx
         n = len(self.sizes)
