@@ -44,7 +44,7 @@ SYMBOLS = [
     "hx_add", "hx_sub", "hx_mul", "hx_negate", "hx_add_scalar", "hx_sub_scalar", "hx_mul_scalar",
     "hx_automorph", "hx_complex_conj",
     "hx_add_primes_and_scale", "hx_add_primes", "hx_scale_down", "hx_scale_down_multi",
-    "hx_break_into_digits",
+    "hx_bring_to_set_multi", "hx_break_into_digits",
     "hx_ksk_create", "hx_ksk_destroy", "hx_tensor", "hx_key_switch_digits", "hx_mul_relin",
     "hx_relinearize",
     "hx_intel_FFTFwd", "hx_intel_FFTRev1", "hx_intel_EltwiseAddMod", "hx_intel_EltwiseAddModScalar",
@@ -86,6 +86,7 @@ def lib():
             "hx_add_primes_and_scale": [vp, vp, ip], "hx_add_primes": [vp, vp, ip],
             "hx_scale_down": [vp, vp, ip, u64],
             "hx_scale_down_multi": [vp, ip, vp, ip, u64],
+            "hx_bring_to_set_multi": [vp, ip, vp, ip, vp, ip, u64],
             "hx_break_into_digits": [vp, vp, vp, ip, vp, ip, vp],
             "hx_ksk_create": [vp, ip, vp, ip, vp, vp, vp], "hx_ksk_destroy": [vp],
             "hx_tensor": [vp] * 7, "hx_key_switch_digits": [vp] * 4,
@@ -369,6 +370,18 @@ def scaleDownToSetMulti(polys, keep_set, ptxtSpace):
     drop = _i32([i for i in polys[0].getIndexSet() if i not in keep])
     arr = (C.c_void_p * len(polys))(*[p.h for p in polys])
     _chk(lib().hx_scale_down_multi(arr, len(polys), _p(drop), len(drop), ptxtSpace))
+
+
+def bringToSetMulti(polys, add_set, keep_set, ptxtSpace):
+    """Ctxt::bringToSet on several parts sharing one prime set: mod-up by add_set, then mod-down
+    to keep_set (fused into one pair of launches when a single prime is dropped)."""
+    polys = list(polys)
+    add = _i32(list(add_set))
+    keep = set(keep_set)
+    cur = polys[0].getIndexSet() + [int(i) for i in add]
+    drop = _i32([i for i in cur if i not in keep])
+    arr = (C.c_void_p * len(polys))(*[p.h for p in polys])
+    _chk(lib().hx_bring_to_set_multi(arr, len(polys), _p(add), len(add), _p(drop), len(drop), ptxtSpace))
 
 
 def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None):

@@ -51,12 +51,16 @@ struct ModDownPrep {
   uint64_t half;       // (qd-1)/2
   uint64_t ptxt;       // 0/1: no correction
   uint64_t ptxt_mu64, ptxt_mu, qd_mod_p, qdinv_mod_p;
-  uint32_t ptxt_k, pad;
+  uint32_t ptxt_k, has_up;
+  TW up;               // fused mod-up: the dropped row is first multiplied by F = prod(added primes)
+  uint64_t qd;
 };
 struct ModDownRow {
   TW qdm;              // qd mod q_r
   TW inv;              // qd^-1 mod q_r
-  uint32_t out_row, pad;
+  TW cf;               // fused mod-up: F * qd^-1 mod q_r (multiplies c_r instead of inv)
+  uint32_t out_row;
+  uint32_t mode;       // 0: c_r <- (c_r - v)*inv ; 1: c_r <- c_r*cf - v*inv ; 2: new row, c_r = 0
 };
 struct ModDownApply {
   const uint64_t* xs;

@@ -1575,8 +1575,11 @@ extern "C" int hx_add_primes(hx_poly* a, const int* add_idx, int nadd)
 // same launches when the fused single-prime path applies (returns HX_ERR_UNSUPPORTED otherwise
 // when nother > 0, so that the caller can fall back to one call per poly).
 static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* drop_idx, int ndrop,
-                           uint64_t ptxt)
+                           uint64_t ptxt, const int* add_idx = nullptr, int nadd = 0)
 {
+  // add_idx (fused bringToSet): the polys are first mod-switched UP by these primes
+  // (addPrimesAndScale); only the fused single-prime path folds that in, otherwise the caller
+  // gets HX_ERR_UNSUPPORTED and does the two steps separately.
 
   if (!a)
     return fail(HX_ERR_INVALID, "null poly");
@@ -1584,6 +1587,22 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
   CHK(use(c));
   if (ptxt < 1)
     return fail(HX_ERR_INVALID, "ptxtSpace must be at least 1");
+  if (nadd > 0) {
+    bool ok = ndrop == 1 && c->pow2 && c->logn >= 13 && c->logn <= 15 && find_row(a->prime_idx, drop_idx[0]) >= 0 &&
+              a->nrows() + nadd - 1 <= MAX_ROWS && ptxt < ((uint64_t)1 << 62);
+    for (int i = 0; i < nadd && ok; i++)
+      if (find_row(a->prime_idx, add_idx[i]) >= 0 || add_idx[i] == drop_idx[0])
+        ok = false;
+    if (!ok)
+      return HX_ERR_UNSUPPORTED;
+    // make room and append the new (all-zero, never read) rows
+    CHK(poly_reserve(a, a->nrows() + nadd));
+    for (int i = 0; i < nother; i++)
+      CHK(poly_reserve(others[i], a->nrows() + nadd));
+    for (int i = 0; i < nadd; i++)
+      a->prime_idx.push_back(add_idx[i]);
+  }
+  const int nrows_old = a->nrows() - nadd;
   // diff = getIndexSet() / s : only primes actually present are dropped
   std::vector<int> drop, keep;
   for (int r = 0; r < a->nrows(); r++) {
@@ -1631,10 +1650,21 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
       if (P.qdinv_mod_p == 0)
         return fail(HX_ERR_INVALID, "dropped primes are not invertible modulo ptxtSpace");
     }
+    P.qd = qd;
+    if (nadd > 0) {
+      uint64_t F = 1;
+      for (int i = 0; i < nadd; i++)
+        F = hxh::mulmod(F, c->primes[add_idx[i]].q % qd, qd);
+      P.has_up = 1;
+      P.up.w = F;
+      P.up.wp = hxh::shoup(F, qd);
+    }
     // per-row constants (cached per (dropped prime, kept rows and their output slots))
     std::vector<uint64_t> key;
     key.push_back(0xD0D0D0D0ull);
     key.push_back((uint64_t)dprime);
+    for (int j = 0; j < nadd; j++)
+      key.push_back(0xA000000ull | (uint64_t)add_idx[j]);
     NttRows kr;
     std::vector<hx::ModDownRow> hr(nk);
     int i = 0;
@@ -1651,8 +1681,22 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
       hr[i].inv.w = inv;
       hr[i].inv.wp = hxh::shoup(inv, q);
       hr[i].out_row = (uint32_t)((r == last && drow != last) ? drow : r);
-      hr[i].pad = 0;
-      key.push_back(((uint64_t)pr << 16) | hr[i].out_row);
+      hr[i].mode = 0;
+      hr[i].cf = hr[i].inv;
+      if (nadd > 0) {
+        if (r >= nrows_old) {
+          hr[i].mode = 2;
+        } else {
+          uint64_t F = 1;
+          for (int j = 0; j < nadd; j++)
+            F = hxh::mulmod(F, c->primes[add_idx[j]].q % q, q);
+          uint64_t cf = hxh::mulmod(F, inv, q);
+          hr[i].mode = 1;
+          hr[i].cf.w = cf;
+          hr[i].cf.wp = hxh::shoup(cf, q);
+        }
+      }
+      key.push_back(((uint64_t)pr << 20) | ((uint64_t)hr[i].out_row << 4) | hr[i].mode);
       i++;
     }
     auto it = c->plans.find(key);
@@ -1753,6 +1797,39 @@ extern "C" int hx_scale_down_multi(hx_poly** polys, int npoly, const int* drop_i
   for (int i = 0; i < npoly; i++)
     CHK(scale_down_impl(polys[i], nullptr, 0, drop_idx, ndrop, ptxt));
   return HX_OK;
+}
+
+// Ctxt::bringToSet on several parts (src/Ctxt.cpp:373-389): modUpToSet by add_idx
+// (addPrimesAndScale) immediately followed by modDownToSet dropping drop_idx.  When exactly one
+// prime is dropped the up-scaling is folded into the fused mod-down kernels (the scaled rows
+// and the zero rows are never materialised); otherwise the two steps run one after the other.
+extern "C" int hx_bring_to_set_multi(hx_poly** polys, int npoly, const int* add_idx, int nadd,
+                                     const int* drop_idx, int ndrop, uint64_t ptxt)
+{
+  if (!polys || npoly < 1 || (nadd > 0 && !add_idx) || (ndrop > 0 && !drop_idx))
+    return fail(HX_ERR_INVALID, "bad argument");
+  bool same = npoly <= hx::MD_MAXPOLY;
+  for (int i = 0; i < npoly; i++) {
+    if (!polys[i])
+      return fail(HX_ERR_INVALID, "null poly");
+    if (polys[i]->ctx != polys[0]->ctx || polys[i]->batch != polys[0]->batch ||
+        polys[i]->prime_idx != polys[0]->prime_idx)
+      same = false;
+    for (int j = 0; j < i; j++)
+      if (polys[j] == polys[i])
+        return fail(HX_ERR_INVALID, "the same poly listed twice");
+  }
+  CHK(check_rows(polys[0]->ctx, add_idx, nadd));
+  if (same && nadd > 0 && ndrop == 1) {
+    int rc = scale_down_impl(polys[0], polys + 1, npoly - 1, drop_idx, ndrop, ptxt, add_idx, nadd);
+    if (rc != HX_ERR_UNSUPPORTED)
+      return rc;
+  }
+  for (int i = 0; i < npoly && nadd > 0; i++)
+    CHK(hx_add_primes_and_scale(polys[i], add_idx, nadd));
+  if (ndrop == 0)
+    return HX_OK;
+  return hx_scale_down_multi(polys, npoly, drop_idx, ndrop, ptxt);
 }
 
 // ------------------------------------------------------------------

@@ -76,6 +76,8 @@ struct InvPrepIO {
   }
   __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t x) const
   {
+    if (P.has_up)
+      x = mul_shoup(x, P.up.w, P.up.wp, P.qd);  // iNTT(F*c) = F*iNTT(c)
     const bool neg = x > P.half;
     int64_t S = neg ? 1 : 0;
     if (P.ptxt > 1) {
@@ -102,13 +104,14 @@ struct InvPrepIO {
 // forward transform of a kept row: load = delta mod q_r, store = (c_r - v) * qd^-1
 struct ModDownIO {
   v4i32 rx, rS, rc, ro;
-  TW qdm, inv;
+  TW qdm, inv, cf;
+  uint32_t mode;
   uint64_t q, mu64;
   __device__ ModDownIO(const ModDownApply& A, const ModDownRow& R, size_t boff, const uint64_t* c_row,
                        uint64_t* o_row, unsigned bytes, uint64_t q_, uint64_t mu64_)
       : rx(make_rsrc(A.xs + boff, bytes)), rS(make_rsrc((const uint64_t*)(A.S + boff), bytes)),
-        rc(make_rsrc(c_row, bytes)), ro(make_rsrc(o_row, bytes)), qdm(R.qdm), inv(R.inv), q(q_),
-        mu64(mu64_)
+        rc(make_rsrc(c_row, bytes)), ro(make_rsrc(o_row, bytes)), qdm(R.qdm), inv(R.inv), cf(R.cf),
+        mode(R.mode), q(q_), mu64(mu64_)
   {
   }
   __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
@@ -127,9 +130,17 @@ struct ModDownIO {
   }
   __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t v) const
   {
-    v2i32 a = hx_buffer_load_v2(rc, (int)(tid * 8u), (int)(c * 8u), 0);
-    const uint64_t cc = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
-    const uint64_t o = mul_shoup(sub_mod(cc, v, q), inv.w, inv.wp, q);
+    uint64_t o;
+    if (mode == 2) {  // row added by the fused mod-up: c_r = 0
+      o = mul_shoup(neg_mod(v, q), inv.w, inv.wp, q);
+    } else {
+      v2i32 a = hx_buffer_load_v2(rc, (int)(tid * 8u), (int)(c * 8u), 0);
+      const uint64_t cc = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
+      if (mode == 0)
+        o = mul_shoup(sub_mod(cc, v, q), inv.w, inv.wp, q);
+      else  // (F*c_r - v)/qd with the mod-up scaling folded in
+        o = sub_mod(mul_shoup(cc, cf.w, cf.wp, q), mul_shoup(v, inv.w, inv.wp, q), q);
+    }
     v2i32 d;
     d.x = (int)(uint32_t)o;
     d.y = (int)(uint32_t)(o >> 32);

@@ -340,8 +340,33 @@ class Ctxt:
 
     def bringToSet(self, s):
         s = frozenset(s) if s else frozenset([self.context.ctxtPrimes[0]])
+        if hasattr(self.ops, "bringToSetMulti"):
+            Ctxt._bringManyToSet([self], s)
+            return
         self.modUpToSet(s)
         self.modDownToSet(s)
+
+    @staticmethod
+    def _bringManyToSet(cts, s):
+        """bringToSet(s) = modUpToSet(s); modDownToSet(s) for ciphertexts that sit on one prime
+        set, with the polynomial work of all their parts in one backend call (the mod-up scaling
+        is folded into the mod-down kernels on the GPU).  Bookkeeping as in src/Ctxt.cpp:346-562."""
+        a = cts[0]
+        add = sorted(s - a.primeSet)
+        up = a.primeSet | frozenset(add)
+        inter = up & s
+        if not inter:
+            raise RuntimeError(f"modDownToSet called from {sorted(up)} to {sorted(s)}")
+        diff = up - inter
+        parts = [p for c in cts for p in c.parts.values()]
+        a.ops.bringToSetMulti(parts, add, sorted(inter), a.ptxtSpace)
+        for c in cts:
+            c.lnNoise += c.context.logOfProduct(add)
+            c.primeSet = up
+            if diff:
+                added = c.modSwitchAddedNoiseBound()
+                c.lnNoise = logaddexp(c.lnNoise - c.context.logOfProduct(diff), math.log(added))
+                c.primeSet = inter
 
     @staticmethod
     def _bringBothToSet(a, b, s):
@@ -412,7 +437,10 @@ class Ctxt:
         o.intFactor %= g
         lo, hi = Ctxt.computeIntervalForMul(self, o)
         common = self.context.modSizes.getSet4Size(lo, hi, self.primeSet, o.primeSet, False)
-        if self.primeSet == o.primeSet and hasattr(self.ops, "scaleDownToSetMulti"):
+        if self.primeSet == o.primeSet and hasattr(self.ops, "bringToSetMulti"):
+            Ctxt._bringManyToSet([self, o], frozenset(common) if common else
+                                 frozenset([self.context.ctxtPrimes[0]]))
+        elif self.primeSet == o.primeSet and hasattr(self.ops, "scaleDownToSetMulti"):
             Ctxt._bringBothToSet(self, o, common)   # same result, the 4 parts share the launches
         else:
             self.bringToSet(common)

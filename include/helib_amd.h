@@ -144,6 +144,11 @@ int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_t ptxt_spac
  * ciphertexts of one Ctxt::modDownToSet, src/Ctxt.cpp:462-465) in one pair of launches. */
 int hx_scale_down_multi(hx_poly** polys, int npoly, const int* drop_idx, int ndrop,
                         uint64_t ptxt_space);
+/* Ctxt::bringToSet (src/Ctxt.cpp:373-389) on several parts: modUpToSet by add_idx
+ * (addPrimesAndScale) followed by modDownToSet dropping drop_idx; one fused pair of launches
+ * when a single prime is dropped. */
+int hx_bring_to_set_multi(hx_poly** polys, int npoly, const int* add_idx, int nadd,
+                          const int* drop_idx, int ndrop, uint64_t ptxt_space);
 /* DoubleCRT::breakIntoDigits (src/DoubleCRT.cpp:479-561).  a has ctxt primes
  * only; digit d = dig_idx[dig_off[d]..dig_off[d+1]); special primes sp_idx.
  * digits_out: poly with ndig*(nrows(a)+nsp) rows, block d holding digit d on

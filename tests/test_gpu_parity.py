@@ -541,3 +541,25 @@ def test_scale_down_single_prime_fused_path(hx, m, ptxt):
             want = P.o.scale_down(allp, a[:, b], [drop], ptxt)
             for r, i in enumerate(got_idx):
                 assert np.array_equal(got[r, b], want[keep.index(i)]), (drop, i)
+
+
+@pytest.mark.parametrize("ndrop", [1, 2])
+def test_bring_to_set_multi_matches_separate_steps(hx, ndrop):
+    """hx_bring_to_set_multi == addPrimesAndScale then scaleDownToSet (oracle), for the fused
+    single-drop path and for the generic fallback, on several parts at once."""
+    P, own, sp = setup_rns(hx, m=16384, L=5, K=2)
+    add = [sp[0]]
+    drop = own[-ndrop:]
+    parts = [P.rand(own, 50 + i, batch=2) for i in range(3)]
+    polys = [hx.DoubleCRT(P.g, own, 2, x) for x in parts]
+    keep = [i for i in own + add if i not in drop]
+    hx.bringToSetMulti(polys, add, keep, 65537)
+    for x, d in zip(parts, polys):
+        idx = d.getIndexSet()
+        assert sorted(idx) == sorted(keep)
+        got = d.download()
+        for b in range(2):
+            up = np.vstack([P.o.scale_by_primes(own, x[:, b], add), np.zeros((1, P.N), dtype=np.uint64)])
+            want = P.o.scale_down(own + add, up, drop, 65537)
+            for r, i in enumerate(idx):
+                assert np.array_equal(got[r, b], want[keep.index(i)])
