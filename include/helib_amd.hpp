@@ -1,0 +1,279 @@
+// helib_amd.hpp -- C++17 host facade over the C ABI (helib_amd.h) with the reference's names,
+// argument meaning and error behaviour for this path, so that code written against
+// include/helib/DoubleCRT.h / CModulus.h / keySwitching.h reads the same:
+//
+//   helib_amd::Context      Context::moduli + zMStar      (include/helib/Context.h:117, 339-366)
+//   helib_amd::DoubleCRT    DoubleCRT                     (include/helib/DoubleCRT.h:212-385)
+//   helib_amd::KeySwitch    KeySwitch (b columns + expanded a columns, keySwitching.h:86-101)
+//   tensorProduct / keySwitchDigits / multiplyBy / reLinearize   (src/Ctxt.cpp:191-230, 720-842, 1563-1774)
+//
+// Exceptions mirror include/helib/exceptions.h: InvalidArgument for bad arguments, RuntimeError
+// for index-set mismatches / k not in Zm*, LogicError otherwise; messages come from the library
+// (hx_last_error) and are the reference's own where one exists.
+// Header-only; link with -lhelib_amd.  No NTL: coefficients cross the boundary as uint64 rows.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "helib_amd.h"
+
+namespace helib_amd {
+
+struct RuntimeError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct LogicError : std::logic_error {
+  using std::logic_error::logic_error;
+};
+struct InvalidArgument : std::invalid_argument {
+  using std::invalid_argument::invalid_argument;
+};
+
+inline void check(int rc)
+{
+  if (rc == HX_OK)
+    return;
+  std::string msg = hx_last_error();
+  switch (rc) {
+    case HX_ERR_INVALID: throw InvalidArgument(msg);
+    case HX_ERR_PRIMESET:
+    case HX_ERR_NOT_IN_ZMSTAR:
+    case HX_ERR_DEVICE:
+    case HX_ERR_NOMEM: throw RuntimeError(msg);
+    default: throw LogicError(msg);
+  }
+}
+
+using IndexSet = std::vector<int>;  // prime indices, Context::moduli order
+
+class Context {
+public:
+  explicit Context(uint64_t m, int device = 0) : m_(m)
+  {
+    hx_ctx* c = nullptr;
+    check(hx_ctx_create(&c, device, m));
+    h_.reset(c, [](hx_ctx* p) { hx_ctx_destroy(p); });
+    uint64_t n = 0;
+    check(hx_ctx_phim(c, &n));
+    phim_ = (long)n;
+  }
+  // Cmodulus(zms, q, root): root = NTL's RootTable[0][k] for m = 2^k, FindPrimitiveRoot output
+  // otherwise; 0 = FindPrimRootT.  Returns the index in Context::moduli.
+  long addPrime(uint64_t q, uint64_t root = 0)
+  {
+    int idx = -1;
+    check(hx_ctx_add_prime(h_.get(), q, root, &idx));
+    uint64_t qq, rr;
+    check(hx_ctx_prime(h_.get(), idx, &qq, &rr));
+    primes_.push_back(qq);
+    roots_.push_back(rr);
+    return idx;
+  }
+  long getM() const { return (long)m_; }
+  long getPhiM() const { return phim_; }
+  long ithPrime(long i) const { return (long)primes_.at((size_t)i); }
+  uint64_t ithRoot(long i) const { return roots_.at((size_t)i); }
+  long numPrimes() const { return (long)primes_.size(); }
+  void sync() const { check(hx_ctx_sync(h_.get())); }
+  hx_ctx* handle() const { return h_.get(); }
+
+private:
+  uint64_t m_;
+  long phim_ = 0;
+  std::shared_ptr<hx_ctx> h_;
+  std::vector<uint64_t> primes_, roots_;
+};
+
+class DoubleCRT {
+public:
+  // DoubleCRT(context, indexSet): all-zero rows; `batch` independent objects share the prime set
+  DoubleCRT(const Context& context, const IndexSet& s, int batch = 1) : context_(&context), batch_(batch)
+  {
+    hx_poly* p = nullptr;
+    check(hx_poly_create(context.handle(), batch, s.data(), (int)s.size(), &p));
+    h_.reset(p);
+  }
+  DoubleCRT(const DoubleCRT& other) : context_(other.context_), batch_(other.batch_)
+  {
+    IndexSet s = other.getIndexSet();
+    hx_poly* p = nullptr;
+    check(hx_poly_create_uninit(context_->handle(), batch_, s.data(), (int)s.size(), &p));
+    h_.reset(p);
+    check(hx_poly_copy(h_.get(), other.h_.get()));
+  }
+  DoubleCRT(DoubleCRT&&) = default;
+  DoubleCRT& operator=(DoubleCRT&&) = default;
+  DoubleCRT& operator=(const DoubleCRT& other)
+  {
+    if (this != &other) {
+      if (context_ != other.context_)
+        throw LogicError("DoubleCRT::operator=: incompatible objects");
+      check(hx_poly_copy(h_.get(), other.h_.get()));
+    }
+    return *this;
+  }
+
+  const Context& getContext() const { return *context_; }
+  IndexSet getIndexSet() const
+  {
+    int n = 0;
+    check(hx_poly_shape(h_.get(), nullptr, &n, nullptr));
+    IndexSet s((size_t)n);
+    if (n)
+      check(hx_poly_primes(h_.get(), s.data()));
+    return s;
+  }
+  int batch() const { return batch_; }
+
+  // rows in [row][batch][phi(m)] order
+  void setRows(const std::vector<uint64_t>& rows) { check(hx_poly_upload(h_.get(), rows.data())); }
+  std::vector<uint64_t> getRows() const
+  {
+    std::vector<uint64_t> out(getIndexSet().size() * (size_t)batch_ * (size_t)context_->getPhiM());
+    check(hx_poly_download(h_.get(), out.data()));
+    return out;
+  }
+
+  // Cmodulus::FFT / iFFT on every row (coefficients <-> evaluations)
+  DoubleCRT& FFT() { return chk(hx_ntt_forward(h_.get())); }
+  DoubleCRT& iFFT() { return chk(hx_ntt_inverse(h_.get())); }
+
+  // ring operations: require getIndexSet() <= other.getIndexSet(), else RuntimeError
+  DoubleCRT& operator+=(const DoubleCRT& o) { return chk(hx_add(h_.get(), o.h_.get())); }
+  DoubleCRT& operator-=(const DoubleCRT& o) { return chk(hx_sub(h_.get(), o.h_.get())); }
+  DoubleCRT& operator*=(const DoubleCRT& o) { return chk(hx_mul(h_.get(), o.h_.get())); }
+  DoubleCRT& Negate() { return chk(hx_negate(h_.get())); }
+  // scalar given as its residues per row (the host reduces the ZZ modulo each prime)
+  DoubleCRT& addConstant(const std::vector<uint64_t>& c) { return chk(hx_add_scalar(h_.get(), c.data())); }
+  DoubleCRT& subConstant(const std::vector<uint64_t>& c) { return chk(hx_sub_scalar(h_.get(), c.data())); }
+  DoubleCRT& mulConstant(const std::vector<uint64_t>& c) { return chk(hx_mul_scalar(h_.get(), c.data())); }
+  DoubleCRT& operator*=(long num)
+  {
+    IndexSet s = getIndexSet();
+    std::vector<uint64_t> c(s.size());
+    for (size_t i = 0; i < s.size(); i++) {
+      long q = context_->ithPrime(s[i]);
+      long r = num % q;
+      c[i] = (uint64_t)(r < 0 ? r + q : r);
+    }
+    return mulConstant(c);
+  }
+  DoubleCRT& automorph(long k) { return chk(hx_automorph(h_.get(), (uint64_t)k)); }
+  DoubleCRT& complexConj() { return chk(hx_complex_conj(h_.get())); }
+
+  // prime-set operations
+  DoubleCRT& removePrimes(const IndexSet& s) { return chk(hx_poly_remove_primes(h_.get(), s.data(), (int)s.size())); }
+  DoubleCRT& addPrimes(const IndexSet& s) { return chk(hx_add_primes(h_.get(), s.data(), (int)s.size())); }
+  DoubleCRT& addPrimesAndScale(const IndexSet& s)
+  {
+    return chk(hx_add_primes_and_scale(h_.get(), s.data(), (int)s.size()));
+  }
+  // scaleDownToSet(s, ptxtSpace): keep only the primes in s
+  DoubleCRT& scaleDownToSet(const IndexSet& s, long ptxtSpace)
+  {
+    IndexSet drop;
+    for (int i : getIndexSet()) {
+      bool keep = false;
+      for (int j : s)
+        keep |= (i == j);
+      if (!keep)
+        drop.push_back(i);
+    }
+    return chk(hx_scale_down(h_.get(), drop.data(), (int)drop.size(), (uint64_t)ptxtSpace));
+  }
+  // breakIntoDigits: digit d = digits[d] (prime indices), special primes appended to every digit;
+  // result: one object with digits.size()*(rows+|special|) rows, block d = digit d
+  DoubleCRT breakIntoDigits(const std::vector<IndexSet>& digits, const IndexSet& special) const
+  {
+    std::vector<int> idx, off(1, 0);
+    for (auto& d : digits) {
+      idx.insert(idx.end(), d.begin(), d.end());
+      off.push_back((int)idx.size());
+    }
+    DoubleCRT out(*context_, getIndexSet(), batch_);
+    check(hx_break_into_digits(h_.get(), idx.data(), off.data(), (int)digits.size(), special.data(),
+                               (int)special.size(), out.h_.get()));
+    return out;
+  }
+
+  hx_poly* handle() const { return h_.get(); }
+
+private:
+  struct Del {
+    void operator()(hx_poly* p) const { hx_poly_destroy(p); }
+  };
+  DoubleCRT& chk(int rc)
+  {
+    check(rc);
+    return *this;
+  }
+  const Context* context_;
+  int batch_;
+  std::unique_ptr<hx_poly, Del> h_;
+};
+
+class KeySwitch {
+public:
+  // b, a: [ndig][rows][phi(m)] on primes `rows` (ctxt primes followed by special primes)
+  KeySwitch(const Context& c, int ndig, const IndexSet& rows, const std::vector<uint64_t>& b,
+            const std::vector<uint64_t>& a)
+  {
+    hx_ksk* k = nullptr;
+    check(hx_ksk_create(c.handle(), ndig, rows.data(), (int)rows.size(), b.data(), a.data(), &k));
+    h_.reset(k);
+  }
+  hx_ksk* handle() const { return h_.get(); }
+
+private:
+  struct Del {
+    void operator()(hx_ksk* p) const { hx_ksk_destroy(p); }
+  };
+  std::unique_ptr<hx_ksk, Del> h_;
+};
+
+inline void flatten(const std::vector<IndexSet>& digits, std::vector<int>& idx, std::vector<int>& off)
+{
+  idx.clear();
+  off.assign(1, 0);
+  for (auto& d : digits) {
+    idx.insert(idx.end(), d.begin(), d.end());
+    off.push_back((int)idx.size());
+  }
+}
+
+// Ctxt::tensorProduct for two 2-part ciphertexts
+inline void tensorProduct(const DoubleCRT& c0, const DoubleCRT& c1, const DoubleCRT& d0, const DoubleCRT& d1,
+                          DoubleCRT& o0, DoubleCRT& o1, DoubleCRT& o2)
+{
+  check(hx_tensor(c0.handle(), c1.handle(), d0.handle(), d1.handle(), o0.handle(), o1.handle(), o2.handle()));
+}
+// Ctxt::keySwitchDigits
+inline void keySwitchDigits(const KeySwitch& W, const DoubleCRT& digits, DoubleCRT& partOne, DoubleCRT& partS)
+{
+  check(hx_key_switch_digits(digits.handle(), W.handle(), partOne.handle(), partS.handle()));
+}
+// Ctxt::multiplyBy data path at a fixed level (tensorProduct + reLinearize)
+inline void multiplyBy(const DoubleCRT& c0, const DoubleCRT& c1, const DoubleCRT& d0, const DoubleCRT& d1,
+                       const KeySwitch& W, const std::vector<IndexSet>& digits, DoubleCRT& out0, DoubleCRT& out1)
+{
+  std::vector<int> idx, off;
+  flatten(digits, idx, off);
+  check(hx_mul_relin(c0.handle(), c1.handle(), d0.handle(), d1.handle(), W.handle(), idx.data(), off.data(),
+                     (int)digits.size(), out0.handle(), out1.handle()));
+}
+// Ctxt::reLinearize for parts (1, s, s^2)
+inline void reLinearize(const DoubleCRT& t0, const DoubleCRT& t1, const DoubleCRT& t2, const KeySwitch& W,
+                        const std::vector<IndexSet>& digits, const IndexSet& special, DoubleCRT& out0,
+                        DoubleCRT& out1)
+{
+  std::vector<int> idx, off;
+  flatten(digits, idx, off);
+  check(hx_relinearize(t0.handle(), t1.handle(), t2.handle(), W.handle(), idx.data(), off.data(),
+                       (int)digits.size(), special.data(), (int)special.size(), out0.handle(), out1.handle()));
+}
+
+}  // namespace helib_amd

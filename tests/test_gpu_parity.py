@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI, include/helib_amd.h) against the
 CPU oracle on the same seeded inputs.  Bit-exact: every word is compared.
 Run with `pytest -m gpu` on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -563,3 +565,25 @@ def test_bring_to_set_multi_matches_separate_steps(hx, ndrop):
             want = P.o.scale_down(own + add, up, drop, 65537)
             for r, i in enumerate(idx):
                 assert np.array_equal(got[r, b], want[keep.index(i)])
+
+
+# ---------------------------------------------------------------- C++ host facade
+def test_cpp_facade_matches_oracle(hx, tmp_path):
+    """include/helib_amd.hpp (the reference-named C++ classes over the C ABI) driven by a C++
+    program and compared with the C oracle: FFT/iFFT, ring ops, automorph + its RuntimeError,
+    IndexSet mismatch, addPrimes, scaleDownToSet, breakIntoDigits, multiplyBy; m = 4096 and the
+    Bluestein case m = 1705."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle")])
+    exe = str(tmp_path / "facade_test")
+    libdir = os.path.join(root, "helib_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"),
+                           "-I" + os.path.join(root, "oracle"),
+                           os.path.join(root, "tests", "cpp", "facade_test.cpp"),
+                           "-L" + libdir, "-lhelib_amd", os.path.join(root, "oracle", "liboracle.so"),
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.join(root, "oracle"),
+                           "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout + r.stderr
+    assert "FAIL" not in r.stdout

@@ -83,3 +83,17 @@ def test_hostnt_matches_oracle():
         assert [a.next() for _ in range(6)] == [b.next() for _ in range(6)]
     q = O.PrimeGen(60, 21845).next()
     assert hostnt.find_primitive_root(q, 21845) == O.lib().ho_find_prim_root(q, 21845)
+
+
+def test_cpp_facade_header_compiles_and_links():
+    """include/helib_amd.hpp + tests/cpp/facade_test.cpp build against the C ABI and the oracle
+    (no GPU needed to compile/link; the program itself runs in the -m gpu suite)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    out = os.path.join(ROOT, "tests", "cpp", "facade_test.bin")
+    libdir = os.path.join(ROOT, "helib_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "oracle"),
+                           os.path.join(ROOT, "tests", "cpp", "facade_test.cpp"),
+                           "-L" + libdir, "-lhelib_amd", os.path.join(ROOT, "oracle", "liboracle.so"),
+                           "-Wl,-rpath," + libdir, "-o", out])
+    os.remove(out)
