@@ -47,6 +47,8 @@ SYMBOLS = [
     "hx_bring_to_set_multi", "hx_break_into_digits",
     "hx_ksk_create", "hx_ksk_destroy", "hx_tensor", "hx_key_switch_digits", "hx_mul_relin",
     "hx_relinearize",
+    "hx_embedding_norm", "hx_scale_down_multi_norms", "hx_bring_to_set_multi_norms",
+    "hx_break_into_digits_norms", "hx_relinearize_norms",
     "hx_intel_FFTFwd", "hx_intel_FFTRev1", "hx_intel_EltwiseAddMod", "hx_intel_EltwiseAddModScalar",
     "hx_intel_EltwiseSubMod", "hx_intel_EltwiseSubModScalar", "hx_intel_EltwiseMultMod",
     "hx_intel_EltwiseMultModScalar",
@@ -92,6 +94,11 @@ def lib():
             "hx_tensor": [vp] * 7, "hx_key_switch_digits": [vp] * 4,
             "hx_mul_relin": [vp, vp, vp, vp, vp, vp, vp, ip, vp, vp],
             "hx_relinearize": [vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, vp],
+            "hx_embedding_norm": [vp, vp, ip, vp],
+            "hx_scale_down_multi_norms": [vp, ip, vp, ip, u64, vp, vp],
+            "hx_bring_to_set_multi_norms": [vp, ip, vp, ip, vp, ip, u64, vp],
+            "hx_break_into_digits_norms": [vp, vp, vp, ip, vp, ip, vp, vp],
+            "hx_relinearize_norms": [vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, vp, vp],
             "hx_intel_FFTFwd": [vp, vp, C.c_long, C.c_long],
             "hx_intel_FFTRev1": [vp, vp, C.c_long, C.c_long],
             "hx_intel_EltwiseAddMod": [vp, vp, vp, C.c_long, C.c_long],
@@ -301,19 +308,28 @@ class DoubleCRT:
         _chk(lib().hx_add_primes(self.h, _p(s), len(s)))
         return self
 
-    def scaleDownToSet(self, keep_set, ptxtSpace):
+    def scaleDownToSet(self, keep_set, ptxtSpace, norms=False):
+        """norms=True: returns embeddingLargestCoeff(delta/diffProd) per batch element instead of
+        self (see scaleDownToSetMulti)."""
+        if norms:
+            return scaleDownToSetMulti([self], keep_set, ptxtSpace, norms=True)[0]
         drop = _i32([i for i in self.getIndexSet() if i not in set(keep_set)])
         _chk(lib().hx_scale_down(self.h, _p(drop), len(drop), ptxtSpace))
         return self
 
-    def breakIntoDigits(self, digits, special):
+    def breakIntoDigits(self, digits, special, norms=False):
         dig_idx = _i32([p for d in digits for p in d])
         dig_off = _i32(np.concatenate([[0], np.cumsum([len(d) for d in digits])]))
         sp = _i32(list(special))
         out = DoubleCRT(self.context, self.getIndexSet(), self.batch, zero=False)
-        _chk(lib().hx_break_into_digits(self.h, _p(dig_idx), _p(dig_off), len(digits), _p(sp),
-                                        len(sp), out.h))
-        return out
+        if not norms:
+            _chk(lib().hx_break_into_digits(self.h, _p(dig_idx), _p(dig_off), len(digits), _p(sp),
+                                            len(sp), out.h))
+            return out
+        nrm = np.zeros((len(digits), self.batch), dtype=np.float64)
+        _chk(lib().hx_break_into_digits_norms(self.h, _p(dig_idx), _p(dig_off), len(digits), _p(sp),
+                                              len(sp), out.h, _p(nrm)))
+        return out, nrm
 
 
 class KeySwitch:
@@ -362,30 +378,63 @@ def multiplyBy(c0, c1, d0, d1, W, digits, out0=None, out1=None):
     return out0, out1
 
 
-def scaleDownToSetMulti(polys, keep_set, ptxtSpace):
+def scaleDownToSetMulti(polys, keep_set, ptxtSpace, norms=False, fdelta=False):
     """DoubleCRT::scaleDownToSet on several parts that share one prime set, batched into one
-    pair of launches where possible."""
+    pair of launches where possible.  norms=True additionally returns
+    embeddingLargestCoeff(delta/diffProd) per (part, batch element) -- the measured mod-switch
+    noise of Ctxt::modDownToSet (src/Ctxt.cpp:466-507) -- as an [nparts, batch] array
+    (and the fdelta coefficients [nparts, batch, phi(m)] when fdelta=True)."""
     polys = list(polys)
     keep = set(keep_set)
     drop = _i32([i for i in polys[0].getIndexSet() if i not in keep])
     arr = (C.c_void_p * len(polys))(*[p.h for p in polys])
-    _chk(lib().hx_scale_down_multi(arr, len(polys), _p(drop), len(drop), ptxtSpace))
+    if not norms:
+        _chk(lib().hx_scale_down_multi(arr, len(polys), _p(drop), len(drop), ptxtSpace))
+        return None
+    out = np.zeros((len(polys), polys[0].batch), dtype=np.float64)
+    fd = np.zeros((len(polys), polys[0].batch, polys[0].context.phim), dtype=np.float64) if fdelta else None
+    _chk(lib().hx_scale_down_multi_norms(arr, len(polys), _p(drop), len(drop), ptxtSpace, _p(out),
+                                         _p(fd) if fdelta else None))
+    return (out, fd) if fdelta else out
 
 
-def bringToSetMulti(polys, add_set, keep_set, ptxtSpace):
+def bringToSetMulti(polys, add_set, keep_set, ptxtSpace, norms=False):
     """Ctxt::bringToSet on several parts sharing one prime set: mod-up by add_set, then mod-down
-    to keep_set (fused into one pair of launches when a single prime is dropped)."""
+    to keep_set (fused into one pair of launches when a single prime is dropped).
+    norms=True: also the measured mod-down noise, as in scaleDownToSetMulti."""
     polys = list(polys)
     add = _i32(list(add_set))
     keep = set(keep_set)
     cur = polys[0].getIndexSet() + [int(i) for i in add]
     drop = _i32([i for i in cur if i not in keep])
     arr = (C.c_void_p * len(polys))(*[p.h for p in polys])
-    _chk(lib().hx_bring_to_set_multi(arr, len(polys), _p(add), len(add), _p(drop), len(drop), ptxtSpace))
+    if not norms:
+        _chk(lib().hx_bring_to_set_multi(arr, len(polys), _p(add), len(add), _p(drop), len(drop), ptxtSpace))
+        return None
+    out = np.zeros((len(polys), polys[0].batch), dtype=np.float64)
+    _chk(lib().hx_bring_to_set_multi_norms(arr, len(polys), _p(add), len(add), _p(drop), len(drop),
+                                           ptxtSpace, _p(out)))
+    return out
 
 
-def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None):
-    """Ctxt::reLinearize data path for a 3-part ciphertext (1, s, s^2)."""
+def supportsNorms(m):
+    """Measured (PGFFT-style) noise norms run on the device for power-of-two m."""
+    return m >= 2 and (m & (m - 1)) == 0
+
+
+def embeddingLargestCoeff(context, f):
+    """embeddingLargestCoeff (src/norms.cpp:480-493) of real polynomials f[rows, phi(m)] on the
+    device (m a power of two)."""
+    f = np.ascontiguousarray(f, dtype=np.float64).reshape(-1, context.phim)
+    out = np.zeros(f.shape[0], dtype=np.float64)
+    _chk(lib().hx_embedding_norm(context.h, _p(f), f.shape[0], _p(out)))
+    return out
+
+
+def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None, norms=False):
+    """Ctxt::reLinearize data path for a 3-part ciphertext (1, s, s^2).  norms=True also returns
+    the [ndigits, batch] array embeddingLargestCoeff(digit)/P_digit (the pieces of
+    breakIntoDigits' return value, src/DoubleCRT.cpp:538-545)."""
     ctx = t0.context
     dig_idx = _i32([p for d in digits for p in d])
     dig_off = _i32(np.concatenate([[0], np.cumsum([len(d) for d in digits])]))
@@ -393,9 +442,14 @@ def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None):
     if out0 is None:
         out0 = DoubleCRT(ctx, t0.getIndexSet(), t0.batch, zero=False)
         out1 = DoubleCRT(ctx, t0.getIndexSet(), t0.batch, zero=False)
-    _chk(lib().hx_relinearize(t0.h, t1.h, t2.h, W.h, _p(dig_idx), _p(dig_off), len(digits), _p(sp),
-                              len(sp), out0.h, out1.h))
-    return out0, out1
+    if not norms:
+        _chk(lib().hx_relinearize(t0.h, t1.h, t2.h, W.h, _p(dig_idx), _p(dig_off), len(digits), _p(sp),
+                                  len(sp), out0.h, out1.h))
+        return out0, out1
+    nrm = np.zeros((len(digits), t0.batch), dtype=np.float64)
+    _chk(lib().hx_relinearize_norms(t0.h, t1.h, t2.h, W.h, _p(dig_idx), _p(dig_off), len(digits),
+                                    _p(sp), len(sp), out0.h, out1.h, _p(nrm)))
+    return out0, out1, nrm
 
 
 def time_ntt(poly, inverse, iters, max_rows=0):

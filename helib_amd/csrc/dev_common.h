@@ -43,8 +43,8 @@ struct NttRows {
 //   prep  (IO of the inverse transform of the dropped row): per coefficient x in [0,qd) ->
 //         delta = x - qd*S,  S = [x > (qd-1)/2] + balanced((delta0 mod p) * qd^-1 mod p)
 //         (centring :1098-1099, ptxtSpace correction :1485-1508); stores x and S.
-//   apply (IO of the forward transform of every kept row r): loads delta mod q_r =
-//         x - (qd mod q_r)*S, and its store is  c_r <- (c_r - NTT(delta)) * qd^-1 mod q_r.
+//   apply (IO of the forward transform of every kept row r): loads delta * qd^-1 mod q_r =
+//         x*inv_r - S  (qd*inv_r = 1), and its store is  c_r <- c_r*inv_r - NTT(.)  mod q_r.
 struct ModDownPrep {
   uint64_t* xs;        // [batch][N]
   int64_t* S;          // [batch][N]
@@ -60,7 +60,8 @@ struct ModDownRow {
   TW inv;              // qd^-1 mod q_r
   TW cf;               // fused mod-up: F * qd^-1 mod q_r (multiplies c_r instead of inv)
   uint32_t out_row;
-  uint32_t mode;       // 0: c_r <- (c_r - v)*inv ; 1: c_r <- c_r*cf - v*inv ; 2: new row, c_r = 0
+  uint32_t mode;       // low 4 bits: 0/1: c_r <- c_r*cf - v (cf = inv or F*inv) ; 2: new row, c_r = 0
+                       // bit 4: |S| may reach q_r (huge ptxtSpace) and is reduced first
 };
 struct ModDownApply {
   const uint64_t* xs;

@@ -17,6 +17,7 @@
 #include "hostmath.h"
 #include "bluestein.h"
 #include "rns_kernels.h"
+#include "norm_kernels.h"
 
 namespace hx {
 hipError_t launch_ntt_pow2(int logn, bool inverse, const uint64_t* in, uint64_t* out,
@@ -148,6 +149,14 @@ struct hx_ctx {
   // handles may be destroyed in any order (hx_ctx_destroy only drops the
   // caller's reference).
   int refs = 1;
+  // canonical-embedding norms (N1): when frac is non-null the exact-RNS kernels also emit
+  // value/P as doubles there (one [batch][N] block per poly / digit, starting at frac_pos)
+  double* d_frac = nullptr;
+  size_t frac_cap = 0, frac_pos = 0;
+  bool want_frac = false;
+  double2* d_wtab = nullptr;           // W^k, k < N, W = exp(2 pi i / m)  (m a power of two)
+  unsigned long long* d_norm2 = nullptr;
+  size_t norm_cap = 0;
 };
 
 struct hx_poly {
@@ -295,6 +304,9 @@ static void ctx_free(hx_ctx* c)
       hipFree(c->scratch[i]);
   for (auto& kv : c->pool)
     hipFree(kv.second);
+  hipFree(c->d_frac);
+  hipFree(c->d_wtab);
+  hipFree(c->d_norm2);
   for (BluePrime* b : c->blue) {
     if (!b)
       continue;
@@ -1480,6 +1492,107 @@ static void clear_args(ExtArgs& a)
   a.dst = nullptr;
   a.upd = nullptr;
   a.nu = 0;
+  a.frac = nullptr;
+}
+
+// ------------------------------------------------------------------
+// canonical-embedding norms on the device (src/norms.cpp:129-262)
+// ------------------------------------------------------------------
+// Arms the "fraction" side output of the exact-RNS kernels: `doubles` values of room.
+static int frac_begin(hx_ctx* c, size_t doubles)
+{
+  if (!c->pow2)
+    return fail(HX_ERR_UNSUPPORTED,
+                "device embedding norms need m a power of two (for general m the host keeps "
+                "the reference's noiseBoundForUniform bound)");
+  if (c->frac_cap < doubles) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_frac)
+      HIPCHK(hipFree(c->d_frac));
+    c->d_frac = nullptr;
+    c->frac_cap = 0;
+    HIPCHK(hipMalloc((void**)&c->d_frac, doubles * sizeof(double)));
+    c->frac_cap = doubles;
+  }
+  HIPCHK(hipMemsetAsync(c->d_frac, 0, doubles * sizeof(double), c->stream));
+  c->frac_pos = 0;
+  c->want_frac = true;
+  return HX_OK;
+}
+static double* frac_take(hx_ctx* c, size_t doubles)
+{
+  if (!c->want_frac || c->frac_pos + doubles > c->frac_cap)
+    return nullptr;
+  double* p = c->d_frac + c->frac_pos;
+  c->frac_pos += doubles;
+  return p;
+}
+
+// out_host[r] = max_j |f_r(W^(2j+1))| for `rows` real polynomials of N coefficients at d_f.
+// Synchronises the stream (the caller needs the numbers on the host).
+static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
+{
+  if (!c->pow2)
+    return fail(HX_ERR_UNSUPPORTED, "device embedding norms need m a power of two");
+  const uint32_t N = c->phim;
+  const int logn = c->logn;
+  if (!c->d_wtab) {
+    std::vector<double> h(2 * (size_t)N);
+    const long double two_pi = 6.283185307179586476925286766559005768394L;
+    for (uint32_t k = 0; k < N; k++) {
+      long double ang = two_pi * (long double)k / (long double)c->m;
+      h[2 * (size_t)k] = (double)cosl(ang);
+      h[2 * (size_t)k + 1] = (double)sinl(ang);
+    }
+    HIPCHK(hipMalloc((void**)&c->d_wtab, sizeof(double) * 2 * (size_t)N));
+    HIPCHK(hipMemcpy(c->d_wtab, h.data(), sizeof(double) * 2 * (size_t)N, hipMemcpyHostToDevice));
+  }
+  if (c->norm_cap < (size_t)rows) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_norm2)
+      HIPCHK(hipFree(c->d_norm2));
+    c->d_norm2 = nullptr;
+    c->norm_cap = 0;
+    HIPCHK(hipMalloc((void**)&c->d_norm2, sizeof(unsigned long long) * (size_t)rows));
+    c->norm_cap = (size_t)rows;
+  }
+  HIPCHK(hipMemsetAsync(c->d_norm2, 0, sizeof(unsigned long long) * (size_t)rows, c->stream));
+  const int logh = std::min(logn, hx::NORM_MAX_LOGH);
+  const unsigned H = 1u << logh, S = N >> logh;
+  const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, H / 2));
+  const size_t lds = std::max<size_t>(16 * (size_t)H, 256);
+  static bool attr = false;
+  if (!attr) {
+    HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               16 << hx::NORM_MAX_LOGH));
+    attr = true;
+  }
+  hipLaunchKernelGGL(hx::embed_norm_kernel, dim3((unsigned)rows * S), dim3(threads), lds, c->stream, d_f,
+                     c->d_wtab, logn, logh, c->d_norm2);
+  HIPCHK(hipGetLastError());
+  std::vector<unsigned long long> h((size_t)rows);
+  HIPCHK(hipMemcpyAsync(h.data(), c->d_norm2, sizeof(unsigned long long) * (size_t)rows,
+                        hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int r = 0; r < rows; r++) {
+    double v;
+    memcpy(&v, &h[(size_t)r], 8);
+    out_host[r] = sqrt(v);
+  }
+  return HX_OK;
+}
+
+extern "C" int hx_embedding_norm(hx_ctx* c, const double* f_host, int rows, double* norms_out)
+{
+  if (!c || !f_host || !norms_out || rows < 1)
+    return fail(HX_ERR_INVALID, "bad argument");
+  CHK(use(c));
+  const size_t n = (size_t)rows * c->phim;
+  CHK(frac_begin(c, n));
+  c->want_frac = false;
+  HIPCHK(hipMemcpyAsync(c->d_frac, f_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return embed_norms(c, c->d_frac, rows, norms_out);
 }
 
 // ------------------------------------------------------------------
@@ -1696,7 +1809,9 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
           hr[i].cf.wp = hxh::shoup(cf, q);
         }
       }
-      key.push_back(((uint64_t)pr << 20) | ((uint64_t)hr[i].out_row << 4) | hr[i].mode);
+      // bit 4: |S| <= ptxtSpace/2 + 1 may reach q and needs reducing
+      hr[i].mode |= (ptxt / 2 + 2 >= q) ? 16u : 0u;
+      key.push_back(((uint64_t)pr << 28) | ((uint64_t)hr[i].out_row << 12) | hr[i].mode);
       i++;
     }
     auto it = c->plans.find(key);
@@ -1715,6 +1830,16 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
                                            c->d_primes, c->d_tw, c->stream);
     if (e != hipSuccess)
       return fail(HX_ERR_DEVICE, "mod-down launch failed: %s", hipGetErrorString(e));
+    if (c->want_frac) {
+      const size_t n = rw * (size_t)pb.n;
+      double* fr = frac_take(c, n);
+      if (!fr)
+        return fail(HX_ERR_INVALID, "internal: fraction buffer too small");
+      hipLaunchKernelGGL(hx::frac_from_xs_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)),
+                         dim3(256), 0, c->stream, c->scratch[0],
+                         reinterpret_cast<const int64_t*>(c->scratch[1]), 1.0 / (double)qd, fr, n);
+      HIPCHK(hipGetLastError());
+    }
     if (drow != last)
       a->prime_idx[drow] = a->prime_idx[last];
     a->prime_idx.pop_back();
@@ -1743,6 +1868,11 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     args.src_row[k] = (uint16_t)k;
   for (int t = 0; t < nk; t++)
     args.dst_row[t] = (uint16_t)t;
+  if (c->want_frac) {
+    args.frac = frac_take(c, rw);
+    if (!args.frac)
+      return fail(HX_ERR_INVALID, "internal: fraction buffer too small");
+  }
   CHK(launch_extend(c, pl, args, rw));
   CHK(ntt_rows(c, c->scratch[1], keep, nk, 0, nk, a->batch, false));
   // removePrimes(diff); *this -= delta; *this /= diffProd
@@ -1832,6 +1962,49 @@ extern "C" int hx_bring_to_set_multi(hx_poly** polys, int npoly, const int* add_
   return hx_scale_down_multi(polys, npoly, drop_idx, ndrop, ptxt);
 }
 
+// ---- measured mod-switch noise (src/Ctxt.cpp:466-530): the same operations, additionally
+// returning embeddingLargestCoeff(fdelta) per (poly, batch element), fdelta = delta / diffProd.
+static int finish_norms(hx_ctx* c, int rc, size_t doubles, int rows, double* norms, double* frac_host)
+{
+  c->want_frac = false;
+  if (rc != HX_OK)
+    return rc;
+  // blocks no kernel wrote (nothing to drop) stay zero from frac_begin
+  if (frac_host)
+    HIPCHK(hipMemcpyAsync(frac_host, c->d_frac, doubles * sizeof(double), hipMemcpyDeviceToHost,
+                          c->stream));
+  return embed_norms(c, c->d_frac, rows, norms);
+}
+
+extern "C" int hx_scale_down_multi_norms(hx_poly** polys, int npoly, const int* drop_idx, int ndrop,
+                                         uint64_t ptxt, double* norms, double* fdelta)
+{
+  if (!polys || npoly < 1 || !polys[0] || !norms)
+    return fail(HX_ERR_INVALID, "bad argument");
+  hx_ctx* c = polys[0]->ctx;
+  CHK(use(c));
+  const size_t rw = polys[0]->row_words();
+  const int batch = polys[0]->batch;
+  CHK(frac_begin(c, (size_t)npoly * rw));
+  int rc = hx_scale_down_multi(polys, npoly, drop_idx, ndrop, ptxt);
+  return finish_norms(c, rc, (size_t)npoly * rw, npoly * batch, norms, fdelta);
+}
+
+extern "C" int hx_bring_to_set_multi_norms(hx_poly** polys, int npoly, const int* add_idx, int nadd,
+                                           const int* drop_idx, int ndrop, uint64_t ptxt,
+                                           double* norms)
+{
+  if (!polys || npoly < 1 || !polys[0] || !norms)
+    return fail(HX_ERR_INVALID, "bad argument");
+  hx_ctx* c = polys[0]->ctx;
+  CHK(use(c));
+  const size_t rw = polys[0]->row_words();
+  const int batch = polys[0]->batch;
+  CHK(frac_begin(c, (size_t)npoly * rw));
+  int rc = hx_bring_to_set_multi(polys, npoly, add_idx, nadd, drop_idx, ndrop, ptxt);
+  return finish_norms(c, rc, (size_t)npoly * rw, npoly * batch, norms, nullptr);
+}
+
 // ------------------------------------------------------------------
 // breakIntoDigits
 // ------------------------------------------------------------------
@@ -1890,6 +2063,11 @@ static int break_digits_coef(hx_ctx* c, uint64_t* coef, const std::vector<int>& 
         args.upd_row[t] = (uint16_t)find_row(own, tgt[t]);
     }
     args.nu = nu;
+    if (c->want_frac) {
+      args.frac = frac_take(c, rw);
+      if (!args.frac)
+        return fail(HX_ERR_INVALID, "internal: fraction buffer too small");
+    }
     CHK(launch_extend(c, pl, args, rw));
   }
   if (owner_out)
@@ -1938,6 +2116,11 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
     A.plan[d] = pl->dev;
   }
   A.off[ndig] = dig_off[ndig];
+  if (c->want_frac) {
+    A.frac = frac_take(c, (size_t)ndig * rw);
+    if (!A.frac)
+      return fail(HX_ERR_INVALID, "internal: fraction buffer too small");
+  }
   dim3 grid((unsigned)((rw + hx::BRK_THREADS - 1) / hx::BRK_THREADS)), block(hx::BRK_THREADS);
   size_t lds = (size_t)L * hx::BRK_THREADS * 8;
   if (nmax <= 8) {
@@ -2002,6 +2185,23 @@ extern "C" int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const 
   CHK(break_digits_coef(c, c->scratch[0], a->prime_idx, dig_idx, dig_off, ndig, all, out->d, rw));
   CHK(ntt_rows(c, out->d, all, nall, 0, ndig * nall, a->batch, false));
   return HX_OK;
+}
+
+// DoubleCRT::breakIntoDigits with its return value (src/DoubleCRT.cpp:538-545): norms[d*batch+b] =
+// embeddingLargestCoeff(digit_d of element b) / P_d  (P_d = product of the digit's primes; the
+// host multiplies it back in extended range, digits reach 2^2000).
+extern "C" int hx_break_into_digits_norms(const hx_poly* a, const int* dig_idx, const int* dig_off,
+                                          int ndig, const int* sp_idx, int nsp, hx_poly* out,
+                                          double* norms)
+{
+  if (!a || !norms || ndig < 1)
+    return fail(HX_ERR_INVALID, "bad argument");
+  hx_ctx* c = a->ctx;
+  CHK(use(c));
+  const size_t rw = a->row_words();
+  CHK(frac_begin(c, (size_t)ndig * rw));
+  int rc = hx_break_into_digits(a, dig_idx, dig_off, ndig, sp_idx, nsp, out);
+  return finish_norms(c, rc, (size_t)ndig * rw, ndig * a->batch, norms, nullptr);
 }
 
 // ------------------------------------------------------------------
@@ -2312,6 +2512,23 @@ extern "C" int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_pol
   out1->prime_idx = all;
   return relin_core(c, t2->d, t0->prime_idx, all, W, dig_idx, dig_off, ndig, t0->batch, out0->d,
                     out1->d);
+}
+
+// Ctxt::reLinearize with the digit norms keySwitchPart feeds into the noise estimate
+// (src/Ctxt.cpp:828-829): norms as in hx_break_into_digits_norms.
+extern "C" int hx_relinearize_norms(const hx_poly* t0, const hx_poly* t1, const hx_poly* t2,
+                                    const hx_ksk* W, const int* dig_idx, const int* dig_off, int ndig,
+                                    const int* sp_idx, int nsp, hx_poly* out0, hx_poly* out1,
+                                    double* norms)
+{
+  if (!t0 || !norms || ndig < 1)
+    return fail(HX_ERR_INVALID, "bad argument");
+  hx_ctx* c = t0->ctx;
+  CHK(use(c));
+  const size_t rw = t0->row_words();
+  CHK(frac_begin(c, (size_t)ndig * rw));
+  int rc = hx_relinearize(t0, t1, t2, W, dig_idx, dig_off, ndig, sp_idx, nsp, out0, out1);
+  return finish_norms(c, rc, (size_t)ndig * rw, ndig * t0->batch, norms, nullptr);
 }
 
 // ------------------------------------------------------------------

@@ -101,17 +101,20 @@ struct InvPrepIO {
     hx_buffer_store_v2(d, rS, (int)(tid * 8u), (int)(c * 8u), 0);
   }
 };
-// forward transform of a kept row: load = delta mod q_r, store = (c_r - v) * qd^-1
+// forward transform of a kept row.  With inv = qd^-1 mod q_r and delta = x - qd*S:
+//   load  = delta * inv = x*inv - S  (mod q_r)      (qd*inv = 1: S needs no multiplication,
+//                                                    and x < 2^64 needs no reduction before Shoup)
+//   store = c_r*cf - NTT(load)   with cf = inv (plain scale-down) or F*inv (mod-up folded in)
 struct ModDownIO {
   v4i32 rx, rS, rc, ro;
-  TW qdm, inv, cf;
-  uint32_t mode;
+  TW inv, cf;
+  uint32_t mode, sred;
   uint64_t q, mu64;
   __device__ ModDownIO(const ModDownApply& A, const ModDownRow& R, size_t boff, const uint64_t* c_row,
                        uint64_t* o_row, unsigned bytes, uint64_t q_, uint64_t mu64_)
       : rx(make_rsrc(A.xs + boff, bytes)), rS(make_rsrc((const uint64_t*)(A.S + boff), bytes)),
-        rc(make_rsrc(c_row, bytes)), ro(make_rsrc(o_row, bytes)), qdm(R.qdm), inv(R.inv), cf(R.cf),
-        mode(R.mode), q(q_), mu64(mu64_)
+        rc(make_rsrc(c_row, bytes)), ro(make_rsrc(o_row, bytes)), inv(R.inv), cf(R.cf),
+        mode(R.mode & 15u), sred(R.mode >> 4), q(q_), mu64(mu64_)
   {
   }
   __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
@@ -120,11 +123,12 @@ struct ModDownIO {
     v2i32 b = hx_buffer_load_v2(rS, (int)(tid * 8u), (int)(c * 8u), 0);
     const uint64_t x = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
     const int64_t S = (int64_t)(((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x);
-    uint64_t r = red64(x, q, mu64);
+    uint64_t r = mul_shoup(x, inv.w, inv.wp, q);
     if (S != 0) {
-      const uint64_t mag = red64((uint64_t)(S < 0 ? -S : S), q, mu64);
-      const uint64_t t = mul_shoup(mag, qdm.w, qdm.wp, q);
-      r = S > 0 ? sub_mod(r, t, q) : add_mod(r, t, q);
+      uint64_t mag = (uint64_t)(S < 0 ? -S : S);  // <= ptxtSpace/2 + 1
+      if (sred)
+        mag = red64(mag, q, mu64);
+      r = S > 0 ? sub_mod(r, mag, q) : add_mod(r, mag, q);
     }
     return r;
   }
@@ -132,14 +136,11 @@ struct ModDownIO {
   {
     uint64_t o;
     if (mode == 2) {  // row added by the fused mod-up: c_r = 0
-      o = mul_shoup(neg_mod(v, q), inv.w, inv.wp, q);
+      o = neg_mod(v, q);
     } else {
       v2i32 a = hx_buffer_load_v2(rc, (int)(tid * 8u), (int)(c * 8u), 0);
       const uint64_t cc = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
-      if (mode == 0)
-        o = mul_shoup(sub_mod(cc, v, q), inv.w, inv.wp, q);
-      else  // (F*c_r - v)/qd with the mod-up scaling folded in
-        o = sub_mod(mul_shoup(cc, cf.w, cf.wp, q), mul_shoup(v, inv.w, inv.wp, q), q);
+      o = sub_mod(mul_shoup(cc, cf.w, cf.wp, q), v, q);
     }
     v2i32 d;
     d.x = (int)(uint32_t)o;
@@ -147,6 +148,24 @@ struct ModDownIO {
     hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), 0);
   }
 };
+
+// Tile shape of the mod-down apply kernel (see there): g row groups of rg rows, 8/g XCDs per group
+// each taking `chunk` (poly, batch) elements; per_xcd = workgroups launched per XCD.
+struct MdTile {
+  unsigned g, rg, chunk, per_xcd;
+};
+__host__ __device__ inline MdTile md_tile(unsigned nkeep, unsigned npb)
+{
+  MdTile t;
+  t.g = 1;
+  while (t.g < 8 && (nkeep + t.g - 1) / t.g > 8)
+    t.g *= 2;
+  t.rg = (nkeep + t.g - 1) / t.g;
+  const unsigned xpg = 8 / t.g;
+  t.chunk = (npb + xpg - 1) / xpg;
+  t.per_xcd = t.rg * t.chunk;
+  return t;
+}
 
 // XCD-aware work mapping: hardware places workgroup id on XCD (id % 8) (observed, used for speed
 // only).  Remap so that each XCD works on a contiguous chunk of the (row, batch) space, i.e. on a
@@ -226,11 +245,32 @@ ntt_moddown_apply_kernel(PolyBases polys, NttRows rows, int nkeep, int batch, Mo
                          const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+#ifdef HX_MD_OLDMAP
   // (row, poly, batch) order so that a chunk of consecutive work items shares one prime
   const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
   const int b = (int)(wid % (unsigned)batch);
   const unsigned rp = wid / (unsigned)batch;
   const unsigned pi = rp % (unsigned)polys.n, ri = rp / (unsigned)polys.n;
+#else
+  // 2-D XCD-aware tiling.  Every kept row of one (poly, batch) element re-reads the same
+  // x and S streams, and every element of one row re-reads the same twiddle table.  XCD k (the
+  // hardware places workgroup id on XCD id % 8) owns a tile of `rg` rows x a chunk of the
+  // elements: its twiddle footprint is rg tables (<= 8 x 16N bytes, L2 resident), and the rg
+  // workgroups that share x/S are consecutive in its dispatch order, so they load them while
+  // the lines are still in that XCD's L2 -- x/S cross the fabric nkeep/rg times instead of nkeep.
+  const MdTile T = md_tile((unsigned)nkeep, (unsigned)polys.n * (unsigned)batch);
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const unsigned grp = xcd % T.g, part = xcd / T.g;
+  const unsigned r0 = grp * T.rg, pb0 = part * T.chunk;
+  const unsigned nr = r0 < (unsigned)nkeep ? min(T.rg, (unsigned)nkeep - r0) : 0u;
+  const unsigned npb = (unsigned)polys.n * (unsigned)batch;
+  const unsigned nloc = pb0 < npb ? min(T.chunk, npb - pb0) : 0u;
+  if (slot >= nr * nloc)
+    return;  // padding workgroup of an uneven tile (whole workgroup, before any barrier)
+  const unsigned ri = r0 + slot % nr, pb = pb0 + slot / nr;
+  const int b = (int)(pb % (unsigned)batch);
+  const unsigned pi = pb / (unsigned)batch;
+#endif
   const PrimeDev* pd = primes + rows.prime[ri];
   const size_t N = Geo<LOGN>::N;
   const ModDownRow R = A.rows[ri];
@@ -304,8 +344,12 @@ static hipError_t launch_moddown(const PolyBases& polys, int drop_row, int drop_
   hipLaunchKernelGGL((ntt_moddown_prep_kernel<LOGN>), dim3((unsigned)polys.n * (unsigned)batch),
                      dim3(Geo<LOGN>::T), lds_bytes, st, polys, drop_row, drop_prime, batch, P, primes,
                      tw_arena);
-  hipLaunchKernelGGL((ntt_moddown_apply_kernel<LOGN>),
-                     dim3((unsigned)polys.n * (unsigned)nkeep * (unsigned)batch), dim3(Geo<LOGN>::T),
+#ifdef HX_MD_OLDMAP
+  const unsigned apply_grid = (unsigned)polys.n * (unsigned)nkeep * (unsigned)batch;
+#else
+  const unsigned apply_grid = 8u * md_tile((unsigned)nkeep, (unsigned)polys.n * (unsigned)batch).per_xcd;
+#endif
+  hipLaunchKernelGGL((ntt_moddown_apply_kernel<LOGN>), dim3(apply_grid), dim3(Geo<LOGN>::T),
                      lds_bytes, st, polys, keep, nkeep, batch, A, primes, tw_arena);
   return hipGetLastError();
 }

@@ -306,7 +306,22 @@ struct ExtArgs {
   uint16_t dst_row[MAX_ROWS];  // output row of target t inside dst
   uint16_t upd_row[MAX_ROWS];  // row inside upd to update (0xffff: none)
   int nu;                    // targets [0,nu) are the ones with an upd_row (host orders them first)
+  double* frac;              // optional [batch][N]: (centred, corrected) value / P as a double
+                             // (the fdelta of src/Ctxt.cpp:466-478 for scaleDownToSet)
 };
+
+// value / P in [0,1) from the mixed-radix digits (value = a_0 + a_1 q_0 + a_2 q_0 q_1 + ...):
+// (((a_0/q_0 + a_1)/q_1 + a_2)/q_2 ...)/q_(n-1), the most significant digit entering last
+template <int NMAX>
+__device__ __forceinline__ double mixed_radix_fraction(const uint64_t (&a)[NMAX], const uint64_t* q, int n)
+{
+  double acc = 0;
+#pragma unroll
+  for (int k = 0; k < NMAX; k++)
+    if (k < n)
+      acc = ((double)a[k] + acc) / (double)q[k];
+  return acc;
+}
 
 template <int NMAX>
 __global__ void __launch_bounds__(256)
@@ -376,6 +391,13 @@ rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
     }
   }
 
+  if (A.frac) {
+    double fr = mixed_radix_fraction<NMAX>(a, P.src_q, n) - (neg ? 1.0 : 0.0);
+    if (dm_nonzero)
+      fr += dm_negative ? (double)dm_abs : -(double)dm_abs;
+    A.frac[i] = fr;
+  }
+
   // ---- residues modulo every target prime ----
   auto residue = [&](int t) -> uint64_t {
     const uint64_t q = P.tgt_q[t], mu64 = P.tgt_mu64[t];
@@ -431,6 +453,8 @@ struct BreakArgs {
   int L, nall, ndig;
   int off[KS_MAXD + 1];  // digit d = rows [off[d], off[d+1])
   ExtPlanDev plan[KS_MAXD];  // plan d: sources = digit d's primes, targets = all other rows, ascending
+  double* frac;          // optional [ndig][batch][N]: centred digit / P_d (for its canonical norm,
+                         // src/DoubleCRT.cpp:538-545)
 };
 
 template <int NMAX>
@@ -473,6 +497,8 @@ break_digits_kernel(BreakArgs A, size_t row_words)
       }
     }
     const bool neg = cmp > 0;
+    if (A.frac)
+      A.frac[(size_t)d * row_words + i] = mixed_radix_fraction<NMAX>(a, P.src_q, n) - (neg ? 1.0 : 0.0);
     uint64_t* dd = A.dst + (size_t)d * A.nall * row_words + i;
     for (int t = 0; t < P.nt; t++) {
       const int r = t < off ? t : t + n;  // row of target t in the all-rows order

@@ -11,11 +11,16 @@
 The polynomial work is delegated to a backend (`ops`): on the GPU that is helib_amd.capi
 (DoubleCRT parts resident in HBM, possibly a batch of independent ciphertexts sharing this
 bookkeeping).  The class itself is pure control flow + floating-point noise estimates, exactly the
-part SURVEY.md keeps on the host (risk R3).  Two documented deviations from the reference, both the
-reference's own alternative branches: mod-switch added noise uses modSwitchAddedNoiseBound()
-(src/Ctxt.cpp:546-559 `#else`) and the key-switch added noise uses noiseBoundForUniform per digit
-(src/DoubleCRT.cpp:520-529 `#if 0`) instead of PGFFT-measured norms.  Noise bounds are kept as
-natural logarithms (NTL::xdouble in the reference) -- only their logs are ever compared.
+part SURVEY.md keeps on the host (risk R3).  Added noise follows the reference's default
+branches when the backend can measure it (Ctxt.measure, power-of-two m on the GPU): the mod-switch
+noise is sum_parts embeddingLargestCoeff(delta/diffProd) * skBound^power (src/Ctxt.cpp:466-530)
+and the key-switch noise is W.noiseBound * sum_digits embeddingLargestCoeff(digit)
+(src/DoubleCRT.cpp:530-545, src/Ctxt.cpp:828-841), both norms evaluated on the device (SURVEY
+row N1).  A batch of ciphertexts behind one Ctxt shares one bound: the maximum over the batch.
+Otherwise (general m, or Ctxt.measure = False) the reference's own alternative branches are used:
+modSwitchAddedNoiseBound() (src/Ctxt.cpp:546-559 `#else`) and noiseBoundForUniform per digit
+(src/DoubleCRT.cpp:520-529 `#if 0`).  Noise bounds are kept as natural logarithms (NTL::xdouble
+in the reference) -- only their logs are ever compared.
 """
 import math
 from functools import reduce
@@ -41,6 +46,10 @@ def phi(m):
 
 def _divc(a, b):
     return -(-a // b)
+
+
+def _ln(x):
+    return math.log(x) if x > 0 else -math.inf
 
 
 def logaddexp(a, b):
@@ -275,9 +284,11 @@ class ChainContext:
 class Ctxt:
     """BGV ciphertext: parts keyed by secret-key handle ("1", "s", "s2")."""
     safety = LN2  # src/Ctxt.cpp:39
+    measure = True  # measured added noise (the reference's default) when the backend supports it
 
     def __init__(self, context, ops, ksw=None, ksw_ptxtSpace=None, ksw_noise=None):
         self.context, self.ops = context, ops
+        self._meas = bool(Ctxt.measure and hasattr(ops, "supportsNorms") and ops.supportsNorms(context.m))
         self.parts = {}
         self.primeSet = frozenset()
         self.ptxtSpace = context.ptxtSpace
@@ -329,14 +340,37 @@ class Ctxt:
         diff = self.primeSet - inter
         if not diff:
             return
-        added = self.modSwitchAddedNoiseBound()
-        if hasattr(self.ops, "scaleDownToSetMulti"):
-            self.ops.scaleDownToSetMulti(list(self.parts.values()), sorted(inter), self.ptxtSpace)
-        else:
-            for p in self.parts.values():
-                p.scaleDownToSet(sorted(inter), self.ptxtSpace)
-        self.lnNoise = logaddexp(self.lnNoise - self.context.logOfProduct(diff), math.log(added))
+        added = Ctxt._modDownParts([self], sorted(inter))[0]
+        self.lnNoise = logaddexp(self.lnNoise - self.context.logOfProduct(diff), _ln(added))
         self.primeSet = inter
+
+    @staticmethod
+    def _modDownParts(cts, keep, add=()):
+        """The polynomial work of modDownToSet (after a mod-up by `add`, if given) on all parts of
+        ciphertexts that share one prime set, in one backend call where the backend has one.
+        Returns each ciphertext's added noise: measured, sum over parts of
+        embeddingLargestCoeff(fdelta) * h^power (src/Ctxt.cpp:495-527), else the bound."""
+        a = cts[0]
+        ops, meas, ptxt = a.ops, a._meas, a.ptxtSpace
+        parts = [p for c in cts for p in c.parts.values()]
+        if add:
+            norms = ops.bringToSetMulti(parts, add, keep, ptxt, norms=meas)
+        elif hasattr(ops, "scaleDownToSetMulti"):
+            norms = ops.scaleDownToSetMulti(parts, keep, ptxt, norms=meas)
+        else:
+            norms = [p.scaleDownToSet(keep, ptxt, norms=meas) for p in parts]
+        if not meas:
+            return [c.modSwitchAddedNoiseBound() for c in cts]
+        h = a.context.skBound()
+        power = {"1": 0, "s": 1, "s2": 2}
+        out, k = [], 0
+        for c in cts:
+            added = 0.0
+            for key in c.parts:
+                added += float(max(norms[k])) * h ** power[key]
+                k += 1
+            out.append(added)
+        return out
 
     def bringToSet(self, s):
         s = frozenset(s) if s else frozenset([self.context.ctxtPrimes[0]])
@@ -358,14 +392,14 @@ class Ctxt:
         if not inter:
             raise RuntimeError(f"modDownToSet called from {sorted(up)} to {sorted(s)}")
         diff = up - inter
-        parts = [p for c in cts for p in c.parts.values()]
-        a.ops.bringToSetMulti(parts, add, sorted(inter), a.ptxtSpace)
-        for c in cts:
+        added = Ctxt._modDownParts(cts, sorted(inter), add=add or ())
+        if not add and not diff:
+            return
+        for c, ad in zip(cts, added):
             c.lnNoise += c.context.logOfProduct(add)
             c.primeSet = up
             if diff:
-                added = c.modSwitchAddedNoiseBound()
-                c.lnNoise = logaddexp(c.lnNoise - c.context.logOfProduct(diff), math.log(added))
+                c.lnNoise = logaddexp(c.lnNoise - c.context.logOfProduct(diff), _ln(ad))
                 c.primeSet = inter
 
     @staticmethod
@@ -381,11 +415,9 @@ class Ctxt:
         diff = a.primeSet - inter
         if not diff:
             return
-        a.ops.scaleDownToSetMulti(list(a.parts.values()) + list(b.parts.values()), sorted(inter),
-                                  a.ptxtSpace)
-        for c in (a, b):
-            added = c.modSwitchAddedNoiseBound()
-            c.lnNoise = logaddexp(c.lnNoise - c.context.logOfProduct(diff), math.log(added))
+        added = Ctxt._modDownParts([a, b], sorted(inter))
+        for c, ad in zip((a, b), added):
+            c.lnNoise = logaddexp(c.lnNoise - c.context.logOfProduct(diff), _ln(ad))
             c.primeSet = inter
 
     def dropSmallAndSpecialPrimes(self):
@@ -468,12 +500,16 @@ class Ctxt:
         digits = [d for d in digits if d]
         self.ptxtSpace = math.gcd(self.ptxtSpace, self.ksw_ptxtSpace)
         self.intFactor %= self.ptxtSpace
-        o0, o1 = self.ops.reLinearize(self.parts["1"], self.parts["s"], self.parts["s2"], self.ksw,
-                                      digits, sp)
+        res = self.ops.reLinearize(self.parts["1"], self.parts["s"], self.parts["s2"], self.ksw,
+                                   digits, sp, **({"norms": True} if self._meas else {}))
+        o0, o1 = res[0], res[1]
         # noise: scaled parts + key-switch added noise (src/Ctxt.cpp:746, 827-841)
         added = -math.inf
-        for d in digits:
-            nb = math.log(ctx.noiseBoundForUniform(0.5, ctx.phim)) + ctx.logOfProduct(d)
+        for k, d in enumerate(digits):
+            if self._meas:   # norm_val = embeddingLargestCoeff(digit) (src/DoubleCRT.cpp:538-545)
+                nb = _ln(float(max(res[2][k]))) + ctx.logOfProduct(d)
+            else:            # high-probability bound (src/DoubleCRT.cpp:520-529)
+                nb = math.log(ctx.noiseBoundForUniform(0.5, ctx.phim)) + ctx.logOfProduct(d)
             added = logaddexp(added, nb + self.ksw_lnNoise)
         self.lnNoise = logaddexp(self.lnNoise + logProd, added)
         self.parts = {"1": o0, "s": o1}

@@ -191,6 +191,34 @@ int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_poly* t2, cons
                    const int* dig_idx, const int* dig_off, int ndig, const int* sp_idx, int nsp,
                    hx_poly* out0, hx_poly* out1);
 
+/* ---------------- measured noise: canonical-embedding norms ----------------
+ * embeddingLargestCoeff (src/norms.cpp:129-262,480-493): max over j in Z_m^* of |f(W^j)|,
+ * W = exp(2 pi i/m), evaluated on the device in double precision (the reference uses PGFFT,
+ * src/PGFFT.cpp); parity is to a relative tolerance of 1e-9.  m must be a power of two
+ * (otherwise HX_ERR_UNSUPPORTED: the host keeps the reference's high-probability bound,
+ * src/DoubleCRT.cpp:520-529).  These calls synchronise the stream: the numbers land in host
+ * memory.  The arithmetic results are exactly those of the plain calls. */
+/* rows real polynomials of phi(m) coefficients each (host) -> norms_out[rows] (host) */
+int hx_embedding_norm(hx_ctx* ctx, const double* f_host, int rows, double* norms_out);
+/* hx_scale_down_multi + norms[npoly*batch] = embeddingLargestCoeff(fdelta) with
+ * fdelta = delta/diffProd (src/Ctxt.cpp:466-507); fdelta (optional, host,
+ * [npoly][batch][phim]) receives the coefficients themselves. */
+int hx_scale_down_multi_norms(hx_poly** polys, int npoly, const int* drop_idx, int ndrop,
+                              uint64_t ptxt_space, double* norms, double* fdelta);
+int hx_bring_to_set_multi_norms(hx_poly** polys, int npoly, const int* add_idx, int nadd,
+                                const int* drop_idx, int ndrop, uint64_t ptxt_space,
+                                double* norms);
+/* hx_break_into_digits + its return value (src/DoubleCRT.cpp:538-545) in pieces:
+ * norms[d*batch+b] = embeddingLargestCoeff(digit d of element b) / P_d, P_d = product of the
+ * digit's primes (multiplied back by the host in extended range). */
+int hx_break_into_digits_norms(const hx_poly* a, const int* dig_idx, const int* dig_off, int ndig,
+                               const int* sp_idx, int nsp, hx_poly* digits_out, double* norms);
+/* hx_relinearize + the digit norms Ctxt::keySwitchPart multiplies by W.noiseBound
+ * (src/Ctxt.cpp:828-829); layout as above. */
+int hx_relinearize_norms(const hx_poly* t0, const hx_poly* t1, const hx_poly* t2, const hx_ksk* W,
+                         const int* dig_idx, const int* dig_off, int ndig, const int* sp_idx,
+                         int nsp, hx_poly* out0, hx_poly* out1, double* norms);
+
 /* ---------------- HEXL-shim compatibility layer ---------------- */
 /* Same signatures and semantics as namespace intel (src/intelExt.h:20-59):
  * host pointers, synchronous, in-place allowed, negacyclic NTT whose root is

@@ -33,14 +33,18 @@ class OPoly:
         self.idx += s
         return self
 
-    def scaleDownToSet(self, keep, ptxt):
+    def scaleDownToSet(self, keep, ptxt, norms=False):
+        """norms=True: returns [embeddingLargestCoeff(delta/diffProd)] (src/Ctxt.cpp:466-507)."""
         keep = set(keep)
         drop = [i for i in self.idx if i not in keep]
         if not drop:
-            return self
-        self.rows = self.o.scale_down(self.idx, self.rows, drop, ptxt)
+            return np.zeros(1) if norms else self
+        if norms:
+            self.rows, fd = self.o.scale_down(self.idx, self.rows, drop, ptxt, want_fdelta=True)
+        else:
+            self.rows = self.o.scale_down(self.idx, self.rows, drop, ptxt)
         self.idx = [i for i in self.idx if i in keep]
-        return self
+        return np.array([O.embedding_largest_coeff(self.o.m, fd)]) if norms else self
 
 
 class OKeySwitch:
@@ -57,7 +61,11 @@ class OracleOps:
         t = self.o.tensor(c0.idx, c0.rows, c1.rows, d0.rows, d1.rows)
         return [OPoly(self.o, c0.idx, x) for x in t]
 
-    def reLinearize(self, t0, t1, t2, W, digits, special):
+    @staticmethod
+    def supportsNorms(m):
+        return True
+
+    def reLinearize(self, t0, t1, t2, W, digits, special, norms=False):
         own, sp = t0.idx, list(special)
         allp = own + sp
         sel = [W.row_idx.index(i) for i in allp]
@@ -66,7 +74,12 @@ class OracleOps:
         s0 = self.o.scale_by_primes(own, t0.rows, sp)
         s1 = self.o.scale_by_primes(own, t1.rows, sp)
         z = np.zeros((len(sp), self.o.N), dtype=np.uint64)
-        dg = self.o.break_into_digits(own, t2.rows, digits, allp)
+        if norms:
+            dg, nrm = self.o.break_into_digits(own, t2.rows, digits, allp, want_norms=True)
+        else:
+            dg = self.o.break_into_digits(own, t2.rows, digits, allp)
         o0, o1 = self.o.key_switch_digits(allp, dg, np.ascontiguousarray(kb), np.ascontiguousarray(ka),
                                           np.vstack([s0, z]), np.vstack([s1, z]))
+        if norms:
+            return OPoly(self.o, allp, o0), OPoly(self.o, allp, o1), nrm.reshape(-1, 1)
         return OPoly(self.o, allp, o0), OPoly(self.o, allp, o1)

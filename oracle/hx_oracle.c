@@ -793,6 +793,20 @@ static uint64_t bn_smod_word(const uint64_t* a, int nl, uint64_t q, uint64_t* tm
   uint64_t r = bn_mod_word(tmp, nl, q);
   return r ? q - r : 0;
 }
+static long double bn_to_ldouble_signed(const uint64_t* a, int nl, uint64_t* tmp)
+{
+  int neg = bn_is_neg(a, nl);
+  const uint64_t* mag = a;
+  if (neg) {
+    bn_copy(tmp, a, nl);
+    bn_negate(tmp, nl);
+    mag = tmp;
+  }
+  long double v = 0;
+  for (int i = nl - 1; i >= 0; i--)
+    v = v * 18446744073709551616.0L + (long double)mag[i];
+  return neg ? -v : v;
+}
 static double bn_to_double_signed(const uint64_t* a, int nl, uint64_t* tmp)
 {
   int neg = bn_is_neg(a, nl);
@@ -993,11 +1007,24 @@ int ho_dcrt_to_poly_limbs(const ho_ctx* c, const int* idx, int nrows,
 /* ------------------------------------------------------------------ */
 /* addPrimes  (src/DoubleCRT.cpp:565-599)                               */
 /* ------------------------------------------------------------------ */
+static void add_primes_impl(const ho_ctx* c, const int* from_idx, int nfrom,
+                            const uint64_t* from_rows, const int* to_idx, int nto,
+                            uint64_t* to_rows, double* poly_f, double* poly_frac);
 void ho_dcrt_add_primes(const ho_ctx* c, const int* from_idx, int nfrom,
                         const uint64_t* from_rows, const int* to_idx, int nto,
                         uint64_t* to_rows, double* poly_f)
 {
+  add_primes_impl(c, from_idx, nfrom, from_rows, to_idx, nto, to_rows, poly_f, NULL);
+}
+/* poly_frac (optional): the centred coefficients divided by the product of the from-primes */
+static void add_primes_impl(const ho_ctx* c, const int* from_idx, int nfrom,
+                            const uint64_t* from_rows, const int* to_idx, int nto,
+                            uint64_t* to_rows, double* poly_f, double* poly_frac)
+{
   long N = c->phim;
+  long double prod_ld = 1.0L;
+  for (int i = 0; i < nfrom; i++)
+    prod_ld *= (long double)c->mod[from_idx[i]]->q;
   int nl = limbs_for(c, from_idx, nfrom, 8);
   crt_tab t;
   crt_tab_init(&t, c, from_idx, nfrom, nl);
@@ -1009,6 +1036,8 @@ void ho_dcrt_add_primes(const ho_ctx* c, const int* from_idx, int nfrom,
     crt_one(&t, remtab + (size_t)h * nfrom, 0, v);
     if (poly_f)
       poly_f[h] = bn_to_double_signed(v, nl, tmp);
+    if (poly_frac)
+      poly_frac[h] = (double)(bn_to_ldouble_signed(v, nl, tmp) / prod_ld);
     /* FFT(poly, s1): "convert(tmp, x)" reduces each bignum mod q
      * (src/CModulus.cpp:446-460) */
     for (int r = 0; r < nto; r++)
@@ -1055,7 +1084,17 @@ void ho_dcrt_break_into_digits(const ho_ctx* c, const int* own_idx, int nown,
                                const int* dig_off, int ndig,
                                const int* all_idx, int nall, uint64_t* digits)
 {
+  ho_dcrt_break_into_digits_norms(c, own_idx, nown, rows, dig_idx, dig_off, ndig,
+                                  all_idx, nall, digits, NULL);
+}
+void ho_dcrt_break_into_digits_norms(const ho_ctx* c, const int* own_idx, int nown,
+                                     const uint64_t* rows, const int* dig_idx,
+                                     const int* dig_off, int ndig,
+                                     const int* all_idx, int nall,
+                                     uint64_t* digits, double* frac_norms)
+{
   long N = c->phim;
+  double* frac = frac_norms ? (double*)malloc((size_t)N * sizeof(double)) : NULL;
   size_t dstride = (size_t)nall * N;
   /* :509-513  digits[i] = *this restricted to the digit's primes.  We keep
    * each digit's own rows in place inside its [nall][N] output block. */
@@ -1083,7 +1122,9 @@ void ho_dcrt_break_into_digits(const ho_ctx* c, const int* own_idx, int nown,
       if (find_idx(didx, nd, all_idx[r]) < 0)
         to[nto++] = all_idx[r];
     uint64_t* ext = (uint64_t*)malloc((size_t)nto * N * 8);
-    ho_dcrt_add_primes(c, didx, nd, own, to, nto, ext, NULL); /* :535 */
+    add_primes_impl(c, didx, nd, own, to, nto, ext, NULL, frac); /* :535 */
+    if (frac_norms) /* :541 norm_val = embeddingLargestCoeff(poly) */
+      frac_norms[d] = ho_embedding_largest_coeff(c->m, frac, N);
     for (int r = 0; r < nto; r++) {
       int pos = find_idx(all_idx, nall, to[r]);
       memcpy(digits + d * dstride + (size_t)pos * N, ext + (size_t)r * N,
@@ -1109,6 +1150,7 @@ void ho_dcrt_break_into_digits(const ho_ctx* c, const int* own_idx, int nown,
     free(to);
     free(own);
   }
+  free(frac);
 }
 
 /* ------------------------------------------------------------------ */
@@ -1297,4 +1339,77 @@ void ho_fill_uniform(uint64_t* out, long n, uint64_t q, uint64_t seed)
     } while (v >= q);
     out[i] = v;
   }
+}
+
+/* ------------------------------------------------------------------ */
+/* embeddingLargestCoeff  (src/norms.cpp:129-262, 480-493)              */
+/* ------------------------------------------------------------------ */
+double ho_embedding_largest_coeff(uint64_t m, const double* f, long n)
+{
+  const long double two_pi = 6.283185307179586476925286766559005768394L;
+  long double best = 0;
+  if (m >= 2 && (m & (m - 1)) == 0) {
+    /* "odd-power trick" (src/norms.cpp:159-198): g_i = f_i W^i, then an (m/2)-point DFT with
+     * root W^2 gives f(W^(2j+1)) for every j; all odd powers are in Z_m^*. */
+    long N = (long)(m / 2);
+    if (N < 1)
+      N = 1;
+    long double* re = (long double*)calloc((size_t)N, sizeof(long double));
+    long double* im = (long double*)calloc((size_t)N, sizeof(long double));
+    for (long i = 0; i < n && i < N; i++) {
+      long double ang = two_pi * (long double)i / (long double)m;
+      re[i] = (long double)f[i] * cosl(ang);
+      im[i] = (long double)f[i] * sinl(ang);
+    }
+    /* in-place decimation-in-frequency, output order irrelevant for a maximum */
+    for (long len = N / 2; len >= 1; len /= 2) {
+      for (long blk = 0; blk < N; blk += 2 * len) {
+        for (long j = 0; j < len; j++) {
+          long double ang = two_pi * (long double)j / (long double)(2 * len);
+          long double wr = cosl(ang), wi = sinl(ang);
+          long a = blk + j, b = a + len;
+          long double dr = re[a] - re[b], di = im[a] - im[b];
+          re[a] += re[b];
+          im[a] += im[b];
+          re[b] = dr * wr - di * wi;
+          im[b] = dr * wi + di * wr;
+        }
+      }
+    }
+    for (long i = 0; i < N; i++) {
+      long double v = re[i] * re[i] + im[i] * im[i];
+      if (v > best)
+        best = v;
+    }
+    free(re);
+    free(im);
+    return (double)sqrtl(best);
+  }
+  /* general m: the definition (src/norms.cpp:129-157), j in Z_m^*, j <= m/2 */
+  long double* cw = (long double*)malloc((size_t)m * sizeof(long double));
+  long double* sw = (long double*)malloc((size_t)m * sizeof(long double));
+  for (uint64_t k = 0; k < m; k++) {
+    long double ang = two_pi * (long double)k / (long double)m;
+    cw[k] = cosl(ang);
+    sw[k] = sinl(ang);
+  }
+  for (uint64_t j = 1; j <= m / 2 || j == 1; j++) {
+    if (gcd_u64(j, m) != 1)
+      continue;
+    long double ar = 0, ai = 0;
+    uint64_t e = 0;
+    for (long i = 0; i < n; i++) {
+      ar += (long double)f[i] * cw[e];
+      ai += (long double)f[i] * sw[e];
+      e += j;
+      if (e >= m)
+        e -= m;
+    }
+    long double v = ar * ar + ai * ai;
+    if (v > best)
+      best = v;
+  }
+  free(cw);
+  free(sw);
+  return (double)sqrtl(best);
 }

@@ -174,6 +174,22 @@ int ho_dcrt_to_poly_limbs(const ho_ctx* c, const int* idx, int nrows,
                           const uint64_t* eval_rows, int positive,
                           uint64_t* mag, int nlimbs, int8_t* sign);
 
+/* ---- canonical-embedding norm ----
+ * embeddingLargestCoeff (src/norms.cpp:480-493 -> basic_/half_/quarter_ variants :129-262):
+ * max over j in Z_m^*, 1 <= j <= m/2, of |sum_i f_i W^(ij)|, W = exp(2 pi i/m).  The reference
+ * evaluates it with PGFFT (a complex-double DFT); here it is the definition, in long double
+ * (an FFT for m a power of two, the direct sum otherwise).  Floating point: compare to 1e-9. */
+double ho_embedding_largest_coeff(uint64_t m, const double* f, long n);
+
+/* DoubleCRT::breakIntoDigits with the pieces of its return value (src/DoubleCRT.cpp:538-545):
+ * frac_norms[d] = embeddingLargestCoeff(digit_d) / P_d, P_d = product of digit d's primes
+ * (scaled so that it fits a double whatever the digit size).  frac_norms may be NULL. */
+void ho_dcrt_break_into_digits_norms(const ho_ctx* c, const int* own_idx, int nown,
+                                     const uint64_t* rows, const int* dig_idx,
+                                     const int* dig_off, int ndig,
+                                     const int* all_idx, int nall,
+                                     uint64_t* digits, double* frac_norms);
+
 /* deterministic test data: splitmix64 stream, rejection-sampled into [0,q) */
 void ho_fill_uniform(uint64_t* out, long n, uint64_t q, uint64_t seed);
 

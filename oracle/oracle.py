@@ -88,6 +88,11 @@ def lib():
         L.ho_dcrt_break_into_digits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_int,
                                                 C.c_void_p, C.c_int, C.c_void_p]
+        L.ho_dcrt_break_into_digits_norms.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                      C.c_int, C.c_void_p, C.c_void_p]
+        L.ho_embedding_largest_coeff.restype = C.c_double
+        L.ho_embedding_largest_coeff.argtypes = [C.c_uint64, C.c_void_p, C.c_long]
         L.ho_dcrt_scale_down.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
         L.ho_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
@@ -140,6 +145,12 @@ def phimx(m):
     out = np.zeros(n + 1, dtype=np.int64)
     lib().ho_phimx(m, _p(out))
     return out
+
+
+def embedding_largest_coeff(m, f):
+    """embeddingLargestCoeff (src/norms.cpp:480-493) of the real polynomial f."""
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    return float(lib().ho_embedding_largest_coeff(m, _p(f), len(f)))
 
 
 def fill_uniform(n, q, seed):
@@ -234,15 +245,19 @@ class Ctx:
                                       _p(add_idx), len(add_idx))
         return rows
 
-    def break_into_digits(self, own_idx, rows, digits, all_idx):
+    def break_into_digits(self, own_idx, rows, digits, all_idx, want_norms=False):
+        """want_norms: also embeddingLargestCoeff(digit_d)/P_d per digit (the pieces of the
+        reference's return value, src/DoubleCRT.cpp:538-545)."""
         own_idx, all_idx, rows = _i32(own_idx), _i32(all_idx), _u64(rows)
         dig_idx = _i32([p for d in digits for p in d])
         dig_off = _i32(np.concatenate([[0], np.cumsum([len(d) for d in digits])]))
         out = np.zeros((len(digits), len(all_idx), self.N), dtype=np.uint64)
-        lib().ho_dcrt_break_into_digits(self.h, _p(own_idx), len(own_idx), _p(rows),
-                                        _p(dig_idx), _p(dig_off), len(digits),
-                                        _p(all_idx), len(all_idx), _p(out))
-        return out
+        nrm = np.zeros(len(digits), dtype=np.float64) if want_norms else None
+        lib().ho_dcrt_break_into_digits_norms(self.h, _p(own_idx), len(own_idx), _p(rows),
+                                              _p(dig_idx), _p(dig_off), len(digits),
+                                              _p(all_idx), len(all_idx), _p(out),
+                                              _p(nrm) if want_norms else None)
+        return (out, nrm) if want_norms else out
 
     def scale_down(self, own_idx, rows, drop_idx, ptxt_space, want_fdelta=False):
         own_idx, drop_idx, rows = _i32(own_idx), _i32(drop_idx), _u64(rows)
