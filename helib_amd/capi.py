@@ -47,6 +47,7 @@ SYMBOLS = [
     "hx_bring_to_set_multi", "hx_break_into_digits",
     "hx_ksk_create", "hx_ksk_destroy", "hx_tensor", "hx_key_switch_digits", "hx_mul_relin",
     "hx_relinearize",
+    "hx_ctx_defer_norms", "hx_norms_flush",
     "hx_embedding_norm", "hx_scale_down_multi_norms", "hx_bring_to_set_multi_norms",
     "hx_break_into_digits_norms", "hx_relinearize_norms",
     "hx_intel_FFTFwd", "hx_intel_FFTRev1", "hx_intel_EltwiseAddMod", "hx_intel_EltwiseAddModScalar",
@@ -94,6 +95,7 @@ def lib():
             "hx_tensor": [vp] * 7, "hx_key_switch_digits": [vp] * 4,
             "hx_mul_relin": [vp, vp, vp, vp, vp, vp, vp, ip, vp, vp],
             "hx_relinearize": [vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, vp],
+            "hx_ctx_defer_norms": [vp, ip], "hx_norms_flush": [vp],
             "hx_embedding_norm": [vp, vp, ip, vp],
             "hx_scale_down_multi_norms": [vp, ip, vp, ip, u64, vp, vp],
             "hx_bring_to_set_multi_norms": [vp, ip, vp, ip, vp, ip, u64, vp],
@@ -175,6 +177,15 @@ class Context:
 
     def set_stream(self, stream_ptr):
         _chk(lib().hx_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def deferNorms(self, on):
+        """Deferred read-back of the measured-noise norms (hx_ctx_defer_norms)."""
+        if bool(on) != getattr(self, "_defer", False):
+            _chk(lib().hx_ctx_defer_norms(self.h, 1 if on else 0))
+            self._defer = bool(on)
+
+    def flushNorms(self):
+        _chk(lib().hx_norms_flush(self.h))
 
     def sync(self):
         _chk(lib().hx_ctx_sync(self.h))
@@ -327,6 +338,7 @@ class DoubleCRT:
                                             len(sp), out.h))
             return out
         nrm = np.zeros((len(digits), self.batch), dtype=np.float64)
+        self.context.deferNorms(False)
         _chk(lib().hx_break_into_digits_norms(self.h, _p(dig_idx), _p(dig_off), len(digits), _p(sp),
                                               len(sp), out.h, _p(nrm)))
         return out, nrm
@@ -378,7 +390,7 @@ def multiplyBy(c0, c1, d0, d1, W, digits, out0=None, out1=None):
     return out0, out1
 
 
-def scaleDownToSetMulti(polys, keep_set, ptxtSpace, norms=False, fdelta=False):
+def scaleDownToSetMulti(polys, keep_set, ptxtSpace, norms=False, fdelta=False, defer=False):
     """DoubleCRT::scaleDownToSet on several parts that share one prime set, batched into one
     pair of launches where possible.  norms=True additionally returns
     embeddingLargestCoeff(delta/diffProd) per (part, batch element) -- the measured mod-switch
@@ -393,12 +405,13 @@ def scaleDownToSetMulti(polys, keep_set, ptxtSpace, norms=False, fdelta=False):
         return None
     out = np.zeros((len(polys), polys[0].batch), dtype=np.float64)
     fd = np.zeros((len(polys), polys[0].batch, polys[0].context.phim), dtype=np.float64) if fdelta else None
+    polys[0].context.deferNorms(defer)   # defer=True: `out` is filled by normsFlush()
     _chk(lib().hx_scale_down_multi_norms(arr, len(polys), _p(drop), len(drop), ptxtSpace, _p(out),
                                          _p(fd) if fdelta else None))
     return (out, fd) if fdelta else out
 
 
-def bringToSetMulti(polys, add_set, keep_set, ptxtSpace, norms=False):
+def bringToSetMulti(polys, add_set, keep_set, ptxtSpace, norms=False, defer=False):
     """Ctxt::bringToSet on several parts sharing one prime set: mod-up by add_set, then mod-down
     to keep_set (fused into one pair of launches when a single prime is dropped).
     norms=True: also the measured mod-down noise, as in scaleDownToSetMulti."""
@@ -412,9 +425,16 @@ def bringToSetMulti(polys, add_set, keep_set, ptxtSpace, norms=False):
         _chk(lib().hx_bring_to_set_multi(arr, len(polys), _p(add), len(add), _p(drop), len(drop), ptxtSpace))
         return None
     out = np.zeros((len(polys), polys[0].batch), dtype=np.float64)
+    polys[0].context.deferNorms(defer)
     _chk(lib().hx_bring_to_set_multi_norms(arr, len(polys), _p(add), len(add), _p(drop), len(drop),
                                            ptxtSpace, _p(out)))
     return out
+
+
+def normsFlush(poly):
+    """Complete every deferred norms read-back of poly's context (waits for the norm kernels
+    only)."""
+    poly.context.flushNorms()
 
 
 def supportsNorms(m):
@@ -431,7 +451,7 @@ def embeddingLargestCoeff(context, f):
     return out
 
 
-def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None, norms=False):
+def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None, norms=False, defer=False):
     """Ctxt::reLinearize data path for a 3-part ciphertext (1, s, s^2).  norms=True also returns
     the [ndigits, batch] array embeddingLargestCoeff(digit)/P_digit (the pieces of
     breakIntoDigits' return value, src/DoubleCRT.cpp:538-545)."""
@@ -447,6 +467,7 @@ def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None, norms=Fals
                                   len(sp), out0.h, out1.h))
         return out0, out1
     nrm = np.zeros((len(digits), t0.batch), dtype=np.float64)
+    ctx.deferNorms(defer)
     _chk(lib().hx_relinearize_norms(t0.h, t1.h, t2.h, W.h, _p(dig_idx), _p(dig_off), len(digits),
                                     _p(sp), len(sp), out0.h, out1.h, _p(nrm)))
     return out0, out1, nrm

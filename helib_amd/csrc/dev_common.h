@@ -52,7 +52,8 @@ struct ModDownPrep {
   uint64_t ptxt;       // 0/1: no correction
   uint64_t ptxt_mu64, ptxt_mu, qd_mod_p, qdinv_mod_p;
   uint32_t ptxt_k, has_up;
-  TW up;               // fused mod-up: the dropped row is first multiplied by F = prod(added primes)
+  TW upS, upN;         // fused mod-up (the dropped row times F = prod(added primes)): the last
+                       // inverse stage's twiddles with F folded in, F*S0*N^-1 and F*N^-1
   uint64_t qd;
 };
 struct ModDownRow {
@@ -75,6 +76,20 @@ struct PolyBases {
   uint64_t* d[MD_MAXPOLY];
   int n;
 };
+// d[i] for a wave-uniform i without indexing the by-value kernel argument dynamically (that makes
+// the compiler copy the struct to scratch memory): a chain of scalar selects.
+__host__ __device__ inline uint64_t* poly_base(const PolyBases& p, unsigned i)
+{
+  uint64_t* r = p.d[0];
+  r = i == 1 ? p.d[1] : r;
+  r = i == 2 ? p.d[2] : r;
+  r = i == 3 ? p.d[3] : r;
+  r = i == 4 ? p.d[4] : r;
+  r = i == 5 ? p.d[5] : r;
+  r = i == 6 ? p.d[6] : r;
+  r = i == 7 ? p.d[7] : r;
+  return r;
+}
 struct RowMap2 {
   uint16_t p[MAX_ROWS];
   uint16_t brow[MAX_ROWS];

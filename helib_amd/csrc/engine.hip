@@ -91,6 +91,7 @@ extern "C" int hx_device_count(int* count)
 // ------------------------------------------------------------------
 struct PrimeHost {
   uint64_t q, root, rinv;
+  uint64_t last_s = 0, last_n = 0;  // inverse table slots 0 / 31: S0*N^-1 and N^-1
   uint64_t tw_fwd_off = 0, tw_inv_off = 0;  // into hx_ctx::d_tw (TW units)
 };
 
@@ -157,6 +158,17 @@ struct hx_ctx {
   double2* d_wtab = nullptr;           // W^k, k < N, W = exp(2 pi i / m)  (m a power of two)
   unsigned long long* d_norm2 = nullptr;
   size_t norm_cap = 0;
+  // deferred read-back of norms (hx_ctx_defer_norms): squared norms land in pinned host slots,
+  // an event marks each; hx_norms_flush converts them into the callers' arrays
+  struct NormPending {
+    hipEvent_t ev;
+    unsigned long long* pinned;
+    size_t cap;
+    int rows;
+    double* out;
+  };
+  bool defer_norms = false;
+  std::vector<NormPending> norm_pending, norm_free;
 };
 
 struct hx_poly {
@@ -307,6 +319,11 @@ static void ctx_free(hx_ctx* c)
   hipFree(c->d_frac);
   hipFree(c->d_wtab);
   hipFree(c->d_norm2);
+  for (auto* v : {&c->norm_pending, &c->norm_free})
+    for (auto& np : *v) {
+      hipEventDestroy(np.ev);
+      hipHostFree(np.pinned);
+    }
   for (BluePrime* b : c->blue) {
     if (!b)
       continue;
@@ -407,6 +424,8 @@ static int upload_tw(hx_ctx* c, PrimeHost& ph)
   HIPCHK(hipMemcpy(c->d_tw + ph.tw_inv_off, i.data(), sizeof(TW) * G::TW_TOTAL,
                    hipMemcpyHostToDevice));
   c->tw_used += 2 * (size_t)G::TW_TOTAL;
+  ph.last_s = i[0].w;
+  ph.last_n = i[31].w;
   return HX_OK;
 }
 
@@ -1557,29 +1576,83 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     c->norm_cap = (size_t)rows;
   }
   HIPCHK(hipMemsetAsync(c->d_norm2, 0, sizeof(unsigned long long) * (size_t)rows, c->stream));
-  const int logh = std::min(logn, hx::NORM_MAX_LOGH);
-  const unsigned H = 1u << logh, S = N >> logh;
-  const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, H / 2));
-  const size_t lds = std::max<size_t>(16 * (size_t)H, 256);
   static bool attr = false;
   if (!attr) {
     HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_kernel,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                16 << hx::NORM_MAX_LOGH));
+    HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               16 << hx::NORM_MAX_LOGH));
     attr = true;
   }
-  hipLaunchKernelGGL(hx::embed_norm_kernel, dim3((unsigned)rows * S), dim3(threads), lds, c->stream, d_f,
-                     c->d_wtab, logn, logh, c->d_norm2);
-  HIPCHK(hipGetLastError());
-  std::vector<unsigned long long> h((size_t)rows);
-  HIPCHK(hipMemcpyAsync(h.data(), c->d_norm2, sizeof(unsigned long long) * (size_t)rows,
-                        hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  for (int r = 0; r < rows; r++) {
-    double v;
-    memcpy(&v, &h[(size_t)r], 8);
-    out_host[r] = sqrt(v);
+  if (logn >= 2 && logn - 1 <= hx::NORM_MAX_LOGH) {
+    // real-input form: one N/2-point transform per polynomial, one workgroup each
+    const unsigned M = N >> 1;
+    const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, M / 4));
+    const size_t lds = std::max<size_t>(16 * (size_t)M, 256);
+    hipLaunchKernelGGL(hx::embed_norm_quarter_kernel, dim3((unsigned)rows), dim3(threads), lds, c->stream,
+                       d_f, c->d_wtab, logn, c->d_norm2);
+  } else {
+    const int logh = std::min(logn, hx::NORM_MAX_LOGH);
+    const unsigned H = 1u << logh, S = N >> logh;
+    const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, H / 4));
+    const size_t lds = std::max<size_t>(16 * (size_t)H, 256);
+    hipLaunchKernelGGL(hx::embed_norm_kernel, dim3((unsigned)rows * S), dim3(threads), lds, c->stream, d_f,
+                       c->d_wtab, logn, logh, c->d_norm2);
   }
+  HIPCHK(hipGetLastError());
+  // read-back through a pinned slot and an event
+  hx_ctx::NormPending np;
+  bool have = false;
+  for (size_t i = 0; i < c->norm_free.size(); i++)
+    if (c->norm_free[i].cap >= (size_t)rows) {
+      np = c->norm_free[i];
+      c->norm_free.erase(c->norm_free.begin() + (long)i);
+      have = true;
+      break;
+    }
+  if (!have) {
+    np.cap = std::max<size_t>((size_t)rows, 1024);
+    HIPCHK(hipHostMalloc((void**)&np.pinned, np.cap * sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&np.ev, hipEventDisableTiming));
+  }
+  np.rows = rows;
+  np.out = out_host;
+  HIPCHK(hipMemcpyAsync(np.pinned, c->d_norm2, sizeof(unsigned long long) * (size_t)rows,
+                        hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipEventRecord(np.ev, c->stream));
+  c->norm_pending.push_back(np);
+  if (c->defer_norms)
+    return HX_OK;
+  return hx_norms_flush(c);
+}
+
+extern "C" int hx_norms_flush(hx_ctx* c)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null context");
+  CHK(use(c));
+  for (auto& np : c->norm_pending) {
+    HIPCHK(hipEventSynchronize(np.ev));
+    for (int r = 0; r < np.rows; r++) {
+      double v;
+      memcpy(&v, &np.pinned[r], 8);
+      np.out[r] = sqrt(v);
+    }
+    c->norm_free.push_back(np);
+  }
+  c->norm_pending.clear();
+  return HX_OK;
+}
+
+extern "C" int hx_ctx_defer_norms(hx_ctx* c, int on)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null context");
+  c->defer_norms = on != 0;
+  if (!on)
+    return hx_norms_flush(c);
   return HX_OK;
 }
 
@@ -1592,7 +1665,8 @@ extern "C" int hx_embedding_norm(hx_ctx* c, const double* f_host, int rows, doub
   CHK(frac_begin(c, n));
   c->want_frac = false;
   HIPCHK(hipMemcpyAsync(c->d_frac, f_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  return embed_norms(c, c->d_frac, rows, norms_out);
+  CHK(embed_norms(c, c->d_frac, rows, norms_out));
+  return hx_norms_flush(c);  // host in, host out: always complete on return
 }
 
 // ------------------------------------------------------------------
@@ -1769,8 +1843,10 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
       for (int i = 0; i < nadd; i++)
         F = hxh::mulmod(F, c->primes[add_idx[i]].q % qd, qd);
       P.has_up = 1;
-      P.up.w = F;
-      P.up.wp = hxh::shoup(F, qd);
+      P.upS.w = hxh::mulmod(F, c->primes[dprime].last_s, qd);
+      P.upS.wp = hxh::shoup(P.upS.w, qd);
+      P.upN.w = hxh::mulmod(F, c->primes[dprime].last_n, qd);
+      P.upN.wp = hxh::shoup(P.upN.w, qd);
     }
     // per-row constants (cached per (dropped prime, kept rows and their output slots))
     std::vector<uint64_t> key;

@@ -8,10 +8,11 @@
 //
 // m = 2N a power of two ("odd-power trick", src/norms.cpp:159-198): with g_i = f_i W^i,
 // f(W^(2j+1)) = sum_i g_i V^(ij), V = W^2 -- one N-point complex DFT.  Only the maximum modulus is
-// wanted, so the output order is irrelevant: decimation-in-frequency radix-2, in place, no
-// bit-reversal.  An N-point transform is split by log2(S) DIF levels applied while loading into S
+// wanted, so the output order is irrelevant: decimation-in-frequency, in place, no bit-reversal,
+// two stages per LDS pass.  N <= 2^14 uses the real-input "quarter" form (one N/2-point transform
+// in one workgroup); larger N is split by log2(S) DIF levels applied while loading into S
 // independent H-point transforms (H = N/S <= 8192 complex doubles = 128 KiB of LDS), one workgroup
-// each; every workgroup folds its own maximum into out2[row] with an atomic max on the bit pattern
+// each.  Every workgroup folds its maximum into out2[row] with an atomic max on the bit pattern
 // (non-negative doubles order like unsigned integers).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -22,7 +23,82 @@ namespace hx {
 constexpr int NORM_MAX_LOGH = 13;  // 2^13 complex doubles = 128 KiB LDS
 constexpr int NORM_THREADS = 1024;
 
+struct cplx {
+  double x, y;
+};
+__device__ __forceinline__ cplx cmul(cplx a, double2 w) { return {a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cplx cmul_i(cplx a) { return {-a.y, a.x}; }
+
+// In-place decimation-in-frequency DFT of the H = 2^logh points in (re, im).  Both callers use a
+// root for which the stage of half-length len multiplies position j by W^(j*N/len) = wtab[j*N/len]
+// (N = table size): the H-point root is W^(2N/H).
+// Two stages are fused into one radix-4 pass (one barrier, one LDS round trip per two stages):
+//   stage len  : x0=a0+a2, x2=(a0-a2)T, x1=a1+a3, x3=(a1-a3)T*i      (T = T_len(j), T_len(j+len/2) = i T)
+//   stage len/2: y0=x0+x1, y1=(x0-x1)T2, y2=x2+x3, y3=(x2-x3)T2     (T2 = T_(len/2)(j))
+// Output order is bit-reversed; callers only take maxima (or pair positions p and H-1-p).
+__device__ __forceinline__ void dif_fft_lds(double* re, double* im, int logh, unsigned tw_half,
+                                            const double2* __restrict__ wtab, unsigned tid, unsigned nth)
+{
+  // tw_half: the table size N
+  const unsigned H = 1u << logh;
+  int stages = logh;
+  unsigned len = H >> 1;
+  while (stages >= 2) {
+    const unsigned hl = len >> 1;        // j < len/2
+    const unsigned s1 = tw_half / len;   // T_len(j)      = wtab[j * s1]
+    const unsigned s2 = s1 * 2;          // T_(len/2)(j)  = wtab[j * s2]
+    for (unsigned q = tid; q < (H >> 2); q += nth) {
+      const unsigned j = q & (hl - 1), blk = q / hl, k = blk * 2 * len + j;
+      const cplx a0{re[k], im[k]}, a1{re[k + hl], im[k + hl]}, a2{re[k + len], im[k + len]},
+          a3{re[k + len + hl], im[k + len + hl]};
+      const double2 T = wtab[j * s1], T2 = wtab[j * s2];
+      const cplx x0 = cadd(a0, a2), x2 = cmul(csub(a0, a2), T);
+      const cplx x1 = cadd(a1, a3), x3 = cmul_i(cmul(csub(a1, a3), T));
+      const cplx y0 = cadd(x0, x1), y1 = cmul(csub(x0, x1), T2);
+      const cplx y2 = cadd(x2, x3), y3 = cmul(csub(x2, x3), T2);
+      re[k] = y0.x, im[k] = y0.y;
+      re[k + hl] = y1.x, im[k + hl] = y1.y;
+      re[k + len] = y2.x, im[k + len] = y2.y;
+      re[k + len + hl] = y3.x, im[k + len + hl] = y3.y;
+    }
+    __syncthreads();
+    len >>= 2;
+    stages -= 2;
+  }
+  if (stages == 1) {  // len == 1: twiddle 1
+    for (unsigned k2 = tid; k2 < (H >> 1); k2 += nth) {
+      const unsigned k = 2 * k2;
+      const double ar = re[k], ai = im[k], br = re[k + 1], bi = im[k + 1];
+      re[k] = ar + br, im[k] = ai + bi;
+      re[k + 1] = ar - br, im[k + 1] = ai - bi;
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void block_max_to(double mx, double* sm, unsigned tid, unsigned nth,
+                                             unsigned long long* dst)
+{
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(mx, off, 64);
+    mx = o > mx ? o : mx;
+  }
+  __syncthreads();
+  if ((tid & 63u) == 0)
+    sm[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned nw = (nth + 63) >> 6;
+    for (unsigned w = 1; w < nw; w++)
+      mx = sm[w] > mx ? sm[w] : mx;
+    atomicMax(dst, (unsigned long long)__double_as_longlong(mx));
+  }
+}
+
 // f: rows x N doubles; wtab[k] = W^k for k < N (W^(k+N) = -W^k); out2[row] must be zeroed.
+// General form: the N-point DFT of g_i = f_i W^i, S = N/H sub-transforms per row.
 __global__ void __launch_bounds__(NORM_THREADS)
 embed_norm_kernel(const double* __restrict__ f, const double2* __restrict__ wtab, int logn, int logh,
                   unsigned long long* __restrict__ out2)
@@ -50,42 +126,59 @@ embed_norm_kernel(const double* __restrict__ f, const double2* __restrict__ wtab
     im[i] = ai;
   }
   __syncthreads();
-  // H-point DIF with root U = W^(2S): stage of half-length len uses U^(j*H/(2 len)) = W^(j*N/len)
-  for (unsigned len = H >> 1, sh = logh - 1; len >= 1; len >>= 1, sh--) {
-    const unsigned tstride = N >> sh;  // N/len
-    for (unsigned bf = tid; bf < (H >> 1); bf += nth) {
-      const unsigned j = bf & (len - 1), k = ((bf >> sh) << (sh + 1)) + j;
-      const double ar = re[k], ai = im[k], br = re[k + len], bi = im[k + len];
-      const double2 w = wtab[j * tstride];
-      const double dr = ar - br, di = ai - bi;
-      re[k] = ar + br;
-      im[k] = ai + bi;
-      re[k + len] = dr * w.x - di * w.y;
-      im[k + len] = dr * w.y + di * w.x;
-    }
-    __syncthreads();
-    if (len == 1)
-      break;
-  }
+  // root U = W^(2S) (primitive H-th root): T_len(j) = U^(j H/(2 len)) = W^(j N/len)
+  dif_fft_lds(re, im, logh, N, wtab, tid, nth);
   double mx = 0;
   for (unsigned i = tid; i < H; i += nth) {
     const double n2 = re[i] * re[i] + im[i] * im[i];
     mx = n2 > mx ? n2 : mx;
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_down(mx, off, 64);
-    mx = o > mx ? o : mx;
+  block_max_to(mx, sm, tid, nth, out2 + row);
+}
+
+// "Quarter" form for N <= 2^14 (src/norms.cpp:200-262 has the reference's version of the trick):
+// with e_i = f_2i, o_i = f_(2i+1), M = N/2 and V = W^2,
+//   f(W^(2j+1)) = E_j + W^(2j+1) O_j,  f(W^(2(j+M)+1)) = E_j - W^(2j+1) O_j,
+//   E_j = sum_i e_i V^(i(2j+1)),  conj(E_j) = E_(M-1-j)  (real e), likewise O,
+// so ONE M-point complex DFT of z_i = (e_i + i o_i) V^i gives Z_j = E_j + i O_j and
+//   E_j = (Z_j + conj Z_(M-1-j))/2,  O_j = (Z_j - conj Z_(M-1-j))/(2i).
+// In the bit-reversed output order Z_j sits at p = brev(j) and Z_(M-1-j) at M-1-p.
+__global__ void __launch_bounds__(NORM_THREADS)
+embed_norm_quarter_kernel(const double* __restrict__ f, const double2* __restrict__ wtab, int logn,
+                          unsigned long long* __restrict__ out2)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const unsigned N = 1u << logn, M = N >> 1;
+  const int logm = logn - 1;
+  double* re = sm;
+  double* im = sm + M;
+  const unsigned row = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+  const double2* fr = reinterpret_cast<const double2*>(f + (size_t)row * N);
+  for (unsigned i = tid; i < M; i += nth) {
+    const double2 v = fr[i];          // (f_2i, f_(2i+1))
+    const double2 w = wtab[2 * i];    // V^i = W^(2i)
+    re[i] = v.x * w.x - v.y * w.y;
+    im[i] = v.x * w.y + v.y * w.x;
   }
   __syncthreads();
-  if ((tid & 63u) == 0)
-    sm[tid >> 6] = mx;
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned nw = (nth + 63) >> 6;
-    for (unsigned w = 1; w < nw; w++)
-      mx = sm[w] > mx ? sm[w] : mx;
-    atomicMax(out2 + row, (unsigned long long)__double_as_longlong(mx));
+  // root V^2 = W^4 (primitive M-th root): T_len(j) = W^(4 j M/(2 len)) = W^(j N/len)
+  dif_fft_lds(re, im, logm, N, wtab, tid, nth);
+  double mx = 0;
+  for (unsigned p = tid; p < M; p += nth) {
+    const unsigned j = __brev(p) >> (32 - logm);
+    const double zr = re[p], zi = im[p], cr = re[M - 1 - p], ci = -im[M - 1 - p];
+    const double er = 0.5 * (zr + cr), ei = 0.5 * (zi + ci);
+    // O = (Z - C)/(2i) = (-i/2)(Z - C)
+    const double dr = zr - cr, di = zi - ci;
+    const double orr = 0.5 * di, oi = -0.5 * dr;
+    const double2 w = wtab[2 * j + 1];
+    const double tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
+    const double a = (er + tr) * (er + tr) + (ei + ti) * (ei + ti);
+    const double b = (er - tr) * (er - tr) + (ei - ti) * (ei - ti);
+    const double n2 = a > b ? a : b;
+    mx = n2 > mx ? n2 : mx;
   }
+  block_max_to(mx, sm, tid, nth, out2 + row);
 }
 
 // fdelta of the fused single-prime scale-down: delta = x - qd*S  =>  delta/qd = x/qd - S

@@ -159,9 +159,38 @@ HXD void gs_bfly_last(uint64_t& X, uint64_t& Y, TW tNinv, TW tS0Ninv, uint64_t q
 #else
 #define HX_LAUNDER(ptr, dep) ((void)(dep))
 #endif
+// Depth 2 (with the per-phase work-item id and the IO fences below) is what keeps the N = 2^14
+// kernels at or near zero scratch inside the 128-VGPR budget of two workgroups per CU; depth 4
+// measured the same speed where scratch is fast and up to 1.8x slower where it is not.
 #ifndef HX_TW_PF
-#define HX_TW_PF 4
+#define HX_TW_PF 2
 #endif
+#ifndef HX_IO_GROUP
+#define HX_IO_GROUP 4
+#endif
+// The fused IO functors (mod-down prep/apply) do tens of instructions per element; without a
+// fence the scheduler interleaves many elements' temporaries while all 32 coefficients are still
+// live.  HX_IO_FENCE(i) stops code motion across every HX_IO_GROUP-th element.
+#if defined(__HIP_DEVICE_COMPILE__) && HX_IO_GROUP > 0
+#define HX_IO_FENCE(i)                          \
+  do {                                          \
+    if (((i) % HX_IO_GROUP) == HX_IO_GROUP - 1) \
+      __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+#else
+#define HX_IO_FENCE(i) ((void)0)
+#endif
+
+// Twiddle-table access, overloaded on the table handle: a plain pointer here (CPU replay, and
+// valid on the device), a buffer resource in ntt_kernels.hip (one address VGPR per load instead
+// of a 64-bit pointer).  tw_uni: wave-uniform entry; tw_vec: entry base + lane + off, whose
+// issue is tied to `dep` (see HX_LAUNDER above run_pass).
+HXD TW tw_uni(const TW* tw, unsigned i) { return tw[i]; }
+HXD TW tw_vec(const TW* tw, unsigned base, unsigned lane, unsigned off, uint32_t dep)
+{
+  HX_LAUNDER(off, dep);
+  return tw[base + lane + off];
+}
 
 template <int S, bool INV>
 HXD constexpr int grp_sp(int i)
@@ -303,6 +332,7 @@ struct PtrIO {
   uint64_t* out;
   HXD uint64_t load(unsigned tid, unsigned c) const { return in[tid + c]; }
   HXD void store(unsigned tid, unsigned c, uint64_t v) const { out[tid + c] = v; }
+  HXD TW last_tw(TW def, int) const { return def; }
 };
 
 HXD uint64_t norm4(uint64_t x, uint64_t q, uint64_t q2)  // [0,4q) -> [0,q)
@@ -327,17 +357,19 @@ struct RowNTT {
   static constexpr int NPHASE = 8;
 
   // -------- forward: coefficients (natural) -> evaluations (natural) -----
-  template <int PH, class IO>
+  template <int PH, class IO, class TWS>
   static HXD void fwd(unsigned tid, uint64_t (&v)[32], uint32_t (&nl)[32], uint32_t* lds,
-                      const IO& io, const TW* __restrict__ tw, uint64_t q)
+                      const IO& io, const TWS& tw, uint64_t q)
   {
     const uint64_t q2 = q + q;
     if constexpr (PH == 0) {
 #pragma unroll
-      for (int e = 0; e < 32; e++)
+      for (int e = 0; e < 32; e++) {
         v[e] = io.load(tid, coef_const<LOGN>(e));
+        HX_IO_FENCE(e);
+      }
       run_pass<5, false, 1, 31>(v, q, q2, [&](int, int sp, int k, uint32_t) {
-        return tw[(1 << sp) - 1 + k];  // uniform: scalar loads
+        return tw_uni(tw, (unsigned)((1 << sp) - 1 + k));  // uniform: scalar loads
       });
 #pragma unroll
       for (int e = 0; e < 32; e++)
@@ -354,11 +386,8 @@ struct RowNTT {
 #pragma unroll
       for (int e = 0; e < 32; e++)
         v[e] = ((uint64_t)lds[ab_addr_B<LOGN>(tid, e)] << 32) | nl[e];
-      const TW* twb = tw + G::TWB + (tid & 31u);
       run_pass<5, false, 1, 31>(v, q, q2, [&](int, int sp, int k, uint32_t dep) {
-        unsigned off = ((1u << sp) - 1u + (unsigned)k) * 32u;
-        HX_LAUNDER(off, dep);
-        return twb[off];
+        return tw_vec(tw, G::TWB, tid & 31u, ((1u << sp) - 1u + (unsigned)k) * 32u, dep);
       });
     } else if constexpr (PH == 4) {
 #pragma unroll
@@ -376,33 +405,29 @@ struct RowNTT {
 #pragma unroll
       for (int i = 0; i < 32; i++)
         v[i] = ((uint64_t)lds[bc_addr_C<LOGN>(tid, i)] << 32) | nl[i];
-      const TW* twc = tw + G::TWC + tid;
       run_pass<G::LC, false, G::NGC, G::GC - 1>(v, q, q2, [&](int gi, int sp, int k, uint32_t dep) {
-        unsigned off = ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi);
-        HX_LAUNDER(off, dep);
-        return twc[off];
+        return tw_vec(tw, G::TWC, tid, ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi), dep);
       });
 #pragma unroll
-      for (int i = 0; i < 32; i++)
+      for (int i = 0; i < 32; i++) {
         io.store(tid, eval_const<LOGN>(i), norm4(v[i], q, q2));
+        HX_IO_FENCE(i);
+      }
     }
   }
 
   // -------- inverse: evaluations (natural) -> coefficients (natural) -----
-  template <int PH, class IO>
+  template <int PH, class IO, class TWS>
   static HXD void inv(unsigned tid, uint64_t (&v)[32], uint32_t (&nl)[32], uint32_t* lds,
-                      const IO& io, const TW* __restrict__ tw, uint64_t q)
+                      const IO& io, const TWS& tw, uint64_t q)
   {
     const uint64_t q2 = q + q;
     if constexpr (PH == 0) {
 #pragma unroll
       for (int i = 0; i < 32; i++)
         v[i] = io.load(tid, eval_const<LOGN>(i));
-      const TW* twc = tw + G::TWC + tid;
       run_pass<G::LC, true, G::NGC, G::GC - 1>(v, q, q2, [&](int gi, int sp, int k, uint32_t dep) {
-        unsigned off = ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi);
-        HX_LAUNDER(off, dep);
-        return twc[off];
+        return tw_vec(tw, G::TWC, tid, ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi), dep);
       });
 #pragma unroll
       for (int i = 0; i < 32; i++)
@@ -419,11 +444,8 @@ struct RowNTT {
 #pragma unroll
       for (int e = 0; e < 32; e++)
         v[e] = ((uint64_t)lds[bc_addr_B<LOGN>(tid, e)] << 32) | nl[e];
-      const TW* twb = tw + G::TWB + (tid & 31u);
       run_pass<5, true, 1, 31>(v, q, q2, [&](int, int sp, int k, uint32_t dep) {
-        unsigned off = ((1u << sp) - 1u + (unsigned)k) * 32u;
-        HX_LAUNDER(off, dep);
-        return twb[off];
+        return tw_vec(tw, G::TWB, tid & 31u, ((1u << sp) - 1u + (unsigned)k) * 32u, dep);
       });
     } else if constexpr (PH == 4) {
 #pragma unroll
@@ -444,17 +466,20 @@ struct RowNTT {
       // stages 4..1 (30 groups), then stage 0 with N^-1 folded in:
       // slot 0 = S0*N^-1, slot 31 = N^-1
       run_pass<5, true, 1, 30>(v, q, q2, [&](int, int sp, int k, uint32_t) {
-        return tw[(1 << sp) - 1 + k];
+        return tw_uni(tw, (unsigned)((1 << sp) - 1 + k));
       });
       {
-        const TW tS = tw[0], tN = tw[31];
+        // (the IO functor may substitute its own pair: a constant factor folded into N^-1)
+        const TW tS = io.last_tw(tw_uni(tw, 0), 0), tN = io.last_tw(tw_uni(tw, 31), 1);
 #pragma unroll
         for (int j = 0; j < 16; j++)
           gs_bfly_last(v[j], v[j + 16], tN, tS, q, q2);
       }
 #pragma unroll
-      for (int e = 0; e < 32; e++)
+      for (int e = 0; e < 32; e++) {
         io.store(tid, coef_const<LOGN>(e), norm2(v[e], q));
+        HX_IO_FENCE(e);
+      }
     }
   }
 };

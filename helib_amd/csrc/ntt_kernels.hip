@@ -30,6 +30,9 @@ __device__ v2i32 hx_buffer_load_v2(v4i32 rsrc, int voffset, int soffset,
 __device__ void hx_buffer_store_v2(v2i32 data, v4i32 rsrc, int voffset, int soffset,
                                    int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
 
+__device__ v4i32 hx_buffer_load_v4(v4i32 rsrc, int voffset, int soffset,
+                                   int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
+
 __device__ __forceinline__ v4i32 make_rsrc(const uint64_t* row, unsigned bytes)
 {
   uint64_t a = (uint64_t)row;
@@ -40,6 +43,27 @@ __device__ __forceinline__ v4i32 make_rsrc(const uint64_t* row, unsigned bytes)
   r.w = 0x00020000;  // gfx9 family: raw buffer, dword elements
   return r;
 }
+// Twiddle table of one prime behind a buffer resource (see tw_uni / tw_vec in ntt_core.h):
+// the per-lane part of the address is one 32-bit VGPR (lane*16), the table position of the
+// (stage, group) goes into the scalar offset, so a fetch costs one v_mov (the launder copy) and
+// no 64-bit address arithmetic.
+struct BufTw {
+  v4i32 r;
+  const TW* p;
+  __device__ explicit BufTw(const TW* tw) : r(make_rsrc(reinterpret_cast<const uint64_t*>(tw), 0xfffffff0u)), p(tw) {}
+};
+__device__ __forceinline__ TW tw_uni(const BufTw& t, unsigned i) { return t.p[i]; }
+__device__ __forceinline__ TW tw_vec(const BufTw& t, unsigned base, unsigned lane, unsigned off, uint32_t dep)
+{
+  int vo = (int)(lane * 16u);
+  asm volatile("" : "+v"(vo) : "v"(dep));
+  const v4i32 x = hx_buffer_load_v4(t.r, vo, (int)((base + off) * 16u), 0);
+  TW w;
+  w.w = ((uint64_t)(uint32_t)x.y << 32) | (uint32_t)x.x;
+  w.wp = ((uint64_t)(uint32_t)x.w << 32) | (uint32_t)x.z;
+  return w;
+}
+
 struct BufIO {
   v4i32 rin, rout;
   __device__ BufIO(const uint64_t* in_row, uint64_t* out_row, unsigned bytes)
@@ -58,15 +82,20 @@ struct BufIO {
     d.y = (int)(uint32_t)(v >> 32);
     hx_buffer_store_v2(d, rout, (int)(tid * 8u), (int)(c * 8u), 0);
   }
+  __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
 };
 
-// inverse transform of the dropped row + delta preparation (see ModDownPrep)
+// inverse transform of the dropped row: stores x = F * iNTT(row) in [0,qd)  (F = 1 without the
+// fused mod-up; otherwise F rides on the last stage's N^-1 twiddles, no extra multiplication).
+// The delta preparation S(x) is a separate element-wise kernel (below): inside this store its
+// ~250 instructions per element and dozen uniform 64-bit constants pushed the kernel into scratch.
 struct InvPrepIO {
-  v4i32 rin, rx, rS;
-  ModDownPrep P;
+  v4i32 rin, rx;
+  TW upS, upN;
+  uint32_t has_up;
   __device__ InvPrepIO(const uint64_t* in_row, const ModDownPrep& p, size_t boff, unsigned bytes)
-      : rin(make_rsrc(in_row, bytes)), rx(make_rsrc(p.xs + boff, bytes)),
-        rS(make_rsrc((const uint64_t*)(p.S + boff), bytes)), P(p)
+      : rin(make_rsrc(in_row, bytes)), rx(make_rsrc(p.xs + boff, bytes)), upS(p.upS), upN(p.upN),
+        has_up(p.has_up)
   {
   }
   __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
@@ -76,8 +105,24 @@ struct InvPrepIO {
   }
   __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t x) const
   {
-    if (P.has_up)
-      x = mul_shoup(x, P.up.w, P.up.wp, P.qd);  // iNTT(F*c) = F*iNTT(c)
+    v2i32 d;
+    d.x = (int)(uint32_t)x;
+    d.y = (int)(uint32_t)(x >> 32);
+    hx_buffer_store_v2(d, rx, (int)(tid * 8u), (int)(c * 8u), 0);
+  }
+  __device__ __forceinline__ TW last_tw(TW def, int which) const
+  {
+    return has_up ? (which ? upN : upS) : def;
+  }
+};
+
+// delta = x - qd*S:  S = [x > (qd-1)/2]  (centring, src/DoubleCRT.cpp:1098-1099)
+//                      + balanced((delta0 mod p) * qd^-1 mod p)  (ptxtSpace correction, :1485-1508)
+__global__ void __launch_bounds__(256)
+moddown_S_kernel(ModDownPrep P, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t x = P.xs[i];
     const bool neg = x > P.half;
     int64_t S = neg ? 1 : 0;
     if (P.ptxt > 1) {
@@ -92,15 +137,10 @@ struct InvPrepIO {
         S += sub_p ? (int64_t)dm - (int64_t)p : (int64_t)dm;
       }
     }
-    v2i32 d;
-    d.x = (int)(uint32_t)x;
-    d.y = (int)(uint32_t)(x >> 32);
-    hx_buffer_store_v2(d, rx, (int)(tid * 8u), (int)(c * 8u), 0);
-    d.x = (int)(uint32_t)(uint64_t)S;
-    d.y = (int)(uint32_t)((uint64_t)S >> 32);
-    hx_buffer_store_v2(d, rS, (int)(tid * 8u), (int)(c * 8u), 0);
+    P.S[i] = S;
   }
-};
+}
+
 // forward transform of a kept row.  With inv = qd^-1 mod q_r and delta = x - qd*S:
 //   load  = delta * inv = x*inv - S  (mod q_r)      (qd*inv = 1: S needs no multiplication,
 //                                                    and x < 2^64 needs no reduction before Shoup)
@@ -138,7 +178,11 @@ struct ModDownIO {
     if (mode == 2) {  // row added by the fused mod-up: c_r = 0
       o = neg_mod(v, q);
     } else {
-      v2i32 a = hx_buffer_load_v2(rc, (int)(tid * 8u), (int)(c * 8u), 0);
+      // the address is made to depend on v: otherwise all 32 loads of c_r are hoisted above
+      // the last register pass (64 more live VGPRs -> scratch spills)
+      int voff = (int)(tid * 8u);
+      asm volatile("" : "+v"(voff) : "v"((uint32_t)v));
+      v2i32 a = hx_buffer_load_v2(rc, voff, (int)(c * 8u), 0);
       const uint64_t cc = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
       o = sub_mod(mul_shoup(cc, cf.w, cf.wp, q), v, q);
     }
@@ -147,6 +191,7 @@ struct ModDownIO {
     d.y = (int)(uint32_t)(o >> 32);
     hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), 0);
   }
+  __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
 };
 
 // Tile shape of the mod-down apply kernel (see there): g row groups of rg rows, 8/g XCDs per group
@@ -181,45 +226,76 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned nwg)
 #endif
 }
 
+// The work-item id, recomputed from the lane counter and the (scalar) wave index each time it is
+// asked for.  Every phase gets its own copy: the address arithmetic derived from it then lives
+// only inside that phase instead of being kept (and spilled to scratch) across the whole kernel.
+// Scratch is what must not happen here: on part of the MI355X pool private-memory accesses are
+// slow enough that a dozen spill/reload pairs per thread cost 1.5-3x on these kernels.
+__device__ __forceinline__ unsigned fresh_tid(unsigned wave)
+{
+#ifdef HX_NO_FRESH_TID
+  (void)wave;
+  return threadIdx.x;
+#else
+  unsigned lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  return (wave << 6) | lane;
+#endif
+}
+__device__ __forceinline__ unsigned wave_index()
+{
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+// uniform 16-bit table entry as a scalar
+__device__ __forceinline__ unsigned uniform_u16(const uint16_t* tab, unsigned i)
+{
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)tab[i]);
+}
+
 template <int LOGN, bool INV, class IO>
-__device__ __forceinline__ void ntt_body(unsigned tid, uint32_t* lds, const IO& io, const TW* tw,
-                                         uint64_t q)
+__device__ __forceinline__ void ntt_body(uint32_t* lds, const IO& io, const TW* tw_ptr, uint64_t q)
 {
   using R = RowNTT<LOGN>;
+#ifdef HX_TW_BUF  // experiment: measured register allocation gets worse with it (scratch 3-5x)
+  const BufTw tw(tw_ptr);
+#else
+  const TW* tw = tw_ptr;
+#endif
   uint64_t v[32];
   uint32_t nl[32];
+  const unsigned w = wave_index();
   if constexpr (!INV) {
-    R::template fwd<0>(tid, v, nl, lds, io, tw, q);
+    R::template fwd<0>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template fwd<1>(tid, v, nl, lds, io, tw, q);
+    R::template fwd<1>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template fwd<2>(tid, v, nl, lds, io, tw, q);
+    R::template fwd<2>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template fwd<3>(tid, v, nl, lds, io, tw, q);
+    R::template fwd<3>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template fwd<4>(tid, v, nl, lds, io, tw, q);
+    R::template fwd<4>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template fwd<5>(tid, v, nl, lds, io, tw, q);
+    R::template fwd<5>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template fwd<6>(tid, v, nl, lds, io, tw, q);
+    R::template fwd<6>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template fwd<7>(tid, v, nl, lds, io, tw, q);
+    R::template fwd<7>(fresh_tid(w), v, nl, lds, io, tw, q);
   } else {
-    R::template inv<0>(tid, v, nl, lds, io, tw, q);
+    R::template inv<0>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template inv<1>(tid, v, nl, lds, io, tw, q);
+    R::template inv<1>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template inv<2>(tid, v, nl, lds, io, tw, q);
+    R::template inv<2>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template inv<3>(tid, v, nl, lds, io, tw, q);
+    R::template inv<3>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template inv<4>(tid, v, nl, lds, io, tw, q);
+    R::template inv<4>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template inv<5>(tid, v, nl, lds, io, tw, q);
+    R::template inv<5>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template inv<6>(tid, v, nl, lds, io, tw, q);
+    R::template inv<6>(fresh_tid(w), v, nl, lds, io, tw, q);
     __syncthreads();
-    R::template inv<7>(tid, v, nl, lds, io, tw, q);
+    R::template inv<7>(fresh_tid(w), v, nl, lds, io, tw, q);
   }
 }
 
@@ -233,10 +309,10 @@ ntt_moddown_prep_kernel(PolyBases polys, int row, int prime, int batch, ModDownP
   const int b = (int)(blockIdx.x % (unsigned)batch), pi = (int)(blockIdx.x / (unsigned)batch);
   const PrimeDev* pd = primes + prime;
   const size_t N = Geo<LOGN>::N;
-  const uint64_t* in = polys.d[pi];
+  const uint64_t* in = poly_base(polys, (unsigned)pi);
   const InvPrepIO io(in + ((size_t)row * batch + b) * N, P, ((size_t)pi * batch + b) * N,
                      (unsigned)N * 8u);
-  ntt_body<LOGN, true>(threadIdx.x, lds, io, tw_arena + pd->tw_inv_off, pd->q);
+  ntt_body<LOGN, true>(lds, io, tw_arena + pd->tw_inv_off, pd->q);
 }
 // ... forward transform of delta on every kept row, subtract + divide in the store
 template <int LOGN>
@@ -271,13 +347,14 @@ ntt_moddown_apply_kernel(PolyBases polys, NttRows rows, int nkeep, int batch, Mo
   const int b = (int)(pb % (unsigned)batch);
   const unsigned pi = pb / (unsigned)batch;
 #endif
-  const PrimeDev* pd = primes + rows.prime[ri];
+  const PrimeDev* pd = primes + uniform_u16(rows.prime, ri);
   const size_t N = Geo<LOGN>::N;
   const ModDownRow R = A.rows[ri];
-  uint64_t* data = polys.d[pi];
-  const ModDownIO io(A, R, ((size_t)pi * batch + b) * N, data + ((size_t)rows.row[ri] * batch + b) * N,
+  uint64_t* data = poly_base(polys, pi);
+  const ModDownIO io(A, R, ((size_t)pi * batch + b) * N,
+                     data + ((size_t)uniform_u16(rows.row, ri) * batch + b) * N,
                      data + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd->q, pd->mu64);
-  ntt_body<LOGN, false>(threadIdx.x, lds, io, tw_arena + pd->tw_fwd_off, pd->q);
+  ntt_body<LOGN, false>(lds, io, tw_arena + pd->tw_fwd_off, pd->q);
 }
 
 template <int LOGN, bool INV>
@@ -286,12 +363,11 @@ ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
                const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const unsigned tid = threadIdx.x;
   const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned ri = wid / (unsigned)batch;
   const int b = (int)(wid % (unsigned)batch);
-  const int row = rows.row[ri];
-  const PrimeDev* pd = primes + rows.prime[ri];
+  const int row = (int)uniform_u16(rows.row, ri);
+  const PrimeDev* pd = primes + uniform_u16(rows.prime, ri);
   const size_t roff = ((size_t)row * batch + b) * (size_t)Geo<LOGN>::N;
   const TW* tw = tw_arena + (INV ? pd->tw_inv_off : pd->tw_fwd_off);
   const uint64_t q = pd->q;
@@ -301,7 +377,7 @@ ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
 #else
   const BufIO io(in + roff, out + roff, (unsigned)Geo<LOGN>::N * 8u);
 #endif
-  ntt_body<LOGN, INV>(tid, lds, io, tw, q);
+  ntt_body<LOGN, INV>(lds, io, tw, q);
 }
 
 template <int LOGN, bool INV>
@@ -344,6 +420,11 @@ static hipError_t launch_moddown(const PolyBases& polys, int drop_row, int drop_
   hipLaunchKernelGGL((ntt_moddown_prep_kernel<LOGN>), dim3((unsigned)polys.n * (unsigned)batch),
                      dim3(Geo<LOGN>::T), lds_bytes, st, polys, drop_row, drop_prime, batch, P, primes,
                      tw_arena);
+  {
+    const size_t n = (size_t)polys.n * (size_t)batch * Geo<LOGN>::N;
+    hipLaunchKernelGGL(moddown_S_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)),
+                       dim3(256), 0, st, P, n);
+  }
 #ifdef HX_MD_OLDMAP
   const unsigned apply_grid = (unsigned)polys.n * (unsigned)nkeep * (unsigned)batch;
 #else

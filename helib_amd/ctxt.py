@@ -289,10 +289,11 @@ class Ctxt:
     def __init__(self, context, ops, ksw=None, ksw_ptxtSpace=None, ksw_noise=None):
         self.context, self.ops = context, ops
         self._meas = bool(Ctxt.measure and hasattr(ops, "supportsNorms") and ops.supportsNorms(context.m))
+        self._ln = -math.inf
+        self._pending = []     # deferred noise updates waiting for norms still on the device
         self.parts = {}
         self.primeSet = frozenset()
         self.ptxtSpace = context.ptxtSpace
-        self.lnNoise = -math.inf
         self.intFactor = 1
         self.ksw, self.ksw_ptxtSpace = ksw, ksw_ptxtSpace or context.ptxtSpace
         self.ksw_lnNoise = ksw_noise if ksw_noise is not None else \
@@ -312,6 +313,33 @@ class Ctxt:
         c.primeSet, c.ptxtSpace = self.primeSet, self.ptxtSpace
         c.lnNoise, c.intFactor = self.lnNoise, self.intFactor
         return c
+
+    # ---- noise estimate: ln(noiseBound) ----
+    # Measured norms are read back lazily: an operation enqueues its kernels, registers how the
+    # norms will enter the estimate, and returns; the estimate is completed (waiting only for the
+    # norm kernels, hx_norms_flush) when somebody reads it -- normally the next prime-set
+    # decision, by which time more work is already queued behind on the GPU.
+    @property
+    def lnNoise(self):
+        if self._pending:
+            if hasattr(self.ops, "normsFlush") and self.parts:
+                self.ops.normsFlush(next(iter(self.parts.values())))
+            todo, self._pending = self._pending, []
+            for fn in todo:
+                fn()
+        return self._ln
+
+    @lnNoise.setter
+    def lnNoise(self, v):
+        if self._pending:
+            self.lnNoise  # noqa: B018 -- complete earlier updates first, in order
+        self._ln = v
+
+    def _defer(self, fn):
+        if self._meas:
+            self._pending.append(fn)
+        else:
+            fn()
 
     # ---- bookkeeping ----
     def logOfPrimeSet(self):
@@ -341,35 +369,37 @@ class Ctxt:
         if not diff:
             return
         added = Ctxt._modDownParts([self], sorted(inter))[0]
-        self.lnNoise = logaddexp(self.lnNoise - self.context.logOfProduct(diff), _ln(added))
+        logdiff = self.context.logOfProduct(diff)
+        self._defer(lambda: setattr(self, "_ln", logaddexp(self._ln - logdiff, _ln(added()))))
         self.primeSet = inter
 
     @staticmethod
     def _modDownParts(cts, keep, add=()):
         """The polynomial work of modDownToSet (after a mod-up by `add`, if given) on all parts of
         ciphertexts that share one prime set, in one backend call where the backend has one.
-        Returns each ciphertext's added noise: measured, sum over parts of
-        embeddingLargestCoeff(fdelta) * h^power (src/Ctxt.cpp:495-527), else the bound."""
+        Returns, per ciphertext, a function giving its added noise: measured, sum over parts of
+        embeddingLargestCoeff(fdelta) * h^power (src/Ctxt.cpp:495-527) -- to be called once the
+        norms have been read back (Ctxt.lnNoise does) -- else the bound."""
         a = cts[0]
         ops, meas, ptxt = a.ops, a._meas, a.ptxtSpace
         parts = [p for c in cts for p in c.parts.values()]
+        kw = {"norms": True, "defer": True} if meas else {}
         if add:
-            norms = ops.bringToSetMulti(parts, add, keep, ptxt, norms=meas)
+            norms = ops.bringToSetMulti(parts, add, keep, ptxt, **kw)
         elif hasattr(ops, "scaleDownToSetMulti"):
-            norms = ops.scaleDownToSetMulti(parts, keep, ptxt, norms=meas)
+            norms = ops.scaleDownToSetMulti(parts, keep, ptxt, **kw)
         else:
-            norms = [p.scaleDownToSet(keep, ptxt, norms=meas) for p in parts]
+            norms = [p.scaleDownToSet(keep, ptxt, **({"norms": True} if meas else {})) for p in parts]
         if not meas:
-            return [c.modSwitchAddedNoiseBound() for c in cts]
+            return [c.modSwitchAddedNoiseBound for c in cts]
         h = a.context.skBound()
         power = {"1": 0, "s": 1, "s2": 2}
         out, k = [], 0
         for c in cts:
-            added = 0.0
-            for key in c.parts:
-                added += float(max(norms[k])) * h ** power[key]
-                k += 1
-            out.append(added)
+            keys = list(c.parts)
+            out.append(lambda k0=k, keys=keys: sum(float(max(norms[k0 + i])) * h ** power[key]
+                                                   for i, key in enumerate(keys)))
+            k += len(keys)
         return out
 
     def bringToSet(self, s):
@@ -399,7 +429,9 @@ class Ctxt:
             c.lnNoise += c.context.logOfProduct(add)
             c.primeSet = up
             if diff:
-                c.lnNoise = logaddexp(c.lnNoise - c.context.logOfProduct(diff), _ln(ad))
+                logdiff = c.context.logOfProduct(diff)
+                c._defer(lambda c=c, ad=ad, logdiff=logdiff:
+                         setattr(c, "_ln", logaddexp(c._ln - logdiff, _ln(ad()))))
                 c.primeSet = inter
 
     @staticmethod
@@ -416,8 +448,9 @@ class Ctxt:
         if not diff:
             return
         added = Ctxt._modDownParts([a, b], sorted(inter))
+        logdiff = a.context.logOfProduct(diff)
         for c, ad in zip((a, b), added):
-            c.lnNoise = logaddexp(c.lnNoise - c.context.logOfProduct(diff), _ln(ad))
+            c._defer(lambda c=c, ad=ad: setattr(c, "_ln", logaddexp(c._ln - logdiff, _ln(ad()))))
             c.primeSet = inter
 
     def dropSmallAndSpecialPrimes(self):
@@ -501,19 +534,23 @@ class Ctxt:
         self.ptxtSpace = math.gcd(self.ptxtSpace, self.ksw_ptxtSpace)
         self.intFactor %= self.ptxtSpace
         res = self.ops.reLinearize(self.parts["1"], self.parts["s"], self.parts["s2"], self.ksw,
-                                   digits, sp, **({"norms": True} if self._meas else {}))
+                                   digits, sp, **({"norms": True, "defer": True} if self._meas else {}))
         o0, o1 = res[0], res[1]
+
         # noise: scaled parts + key-switch added noise (src/Ctxt.cpp:746, 827-841)
-        added = -math.inf
-        for k, d in enumerate(digits):
-            if self._meas:   # norm_val = embeddingLargestCoeff(digit) (src/DoubleCRT.cpp:538-545)
-                nb = _ln(float(max(res[2][k]))) + ctx.logOfProduct(d)
-            else:            # high-probability bound (src/DoubleCRT.cpp:520-529)
-                nb = math.log(ctx.noiseBoundForUniform(0.5, ctx.phim)) + ctx.logOfProduct(d)
-            added = logaddexp(added, nb + self.ksw_lnNoise)
-        self.lnNoise = logaddexp(self.lnNoise + logProd, added)
+        def update():
+            added = -math.inf
+            for k, d in enumerate(digits):
+                if self._meas:   # norm_val = embeddingLargestCoeff(digit) (src/DoubleCRT.cpp:538-545)
+                    nb = _ln(float(max(res[2][k]))) + ctx.logOfProduct(d)
+                else:            # high-probability bound (src/DoubleCRT.cpp:520-529)
+                    nb = math.log(ctx.noiseBoundForUniform(0.5, ctx.phim)) + ctx.logOfProduct(d)
+                added = logaddexp(added, nb + self.ksw_lnNoise)
+            self._ln = logaddexp(self._ln + logProd, added)
+
         self.parts = {"1": o0, "s": o1}
         self.primeSet = self.primeSet | frozenset(sp)
+        self._defer(update)
 
     def multiplyBy(self, other):
         self.multLowLvl(other)

@@ -198,6 +198,13 @@ int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_poly* t2, cons
  * (otherwise HX_ERR_UNSUPPORTED: the host keeps the reference's high-probability bound,
  * src/DoubleCRT.cpp:520-529).  These calls synchronise the stream: the numbers land in host
  * memory.  The arithmetic results are exactly those of the plain calls. */
+/* Deferred read-back: after hx_ctx_defer_norms(ctx, 1) the *_norms calls do not synchronise;
+ * their `norms` arrays (which must stay valid) are filled by hx_norms_flush(ctx), which waits only
+ * for the norm kernels already enqueued, not for work enqueued after them -- the host can keep
+ * the GPU fed while it waits for the numbers its next prime-set decision needs.
+ * hx_ctx_defer_norms(ctx, 0) flushes and returns to synchronous behaviour. */
+int hx_ctx_defer_norms(hx_ctx* ctx, int on);
+int hx_norms_flush(hx_ctx* ctx);
 /* rows real polynomials of phi(m) coefficients each (host) -> norms_out[rows] (host) */
 int hx_embedding_norm(hx_ctx* ctx, const double* f_host, int rows, double* norms_out);
 /* hx_scale_down_multi + norms[npoly*batch] = embeddingLargestCoeff(fdelta) with

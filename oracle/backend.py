@@ -65,7 +65,7 @@ class OracleOps:
     def supportsNorms(m):
         return True
 
-    def reLinearize(self, t0, t1, t2, W, digits, special, norms=False):
+    def reLinearize(self, t0, t1, t2, W, digits, special, norms=False, defer=False):
         own, sp = t0.idx, list(special)
         allp = own + sp
         sel = [W.row_idx.index(i) for i in allp]
