@@ -252,9 +252,22 @@ def ntt_roofline(hx, ctx, primes_list, own, sp, digits, B, rng, iters):
     ms_fwd = hx.time_ntt(dg, False, iters, nrows)
     bytes_launch = 16.0 * n * nrows * B             # 16*N bytes per row transform
     ach = bytes_launch / (ms_fwd * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": f"ntt_row_kernel<{n.bit_length() - 1},fwd>",
+    kernel = f"ntt_row_kernel<{n.bit_length() - 1},fwd>"
+    # HBM bytes per launch from the PMC counters cannot be collected inside this process: they come
+    # from the committed rocprofv3 --pmc passes over the same kernel and launch shape (two passes,
+    # FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, calibrated on kernels of known
+    # traffic in the same passes) -- null when no recorded pass matches this launch.
+    traffic, src = None, None
+    rec = os.path.join(ROOT, "profiles", "r01_pmc_ntt_fwd_traffic.json")
+    if os.path.exists(rec):
+        with open(rec) as f:
+            r = json.load(f)
+        if r.get("kernel") == kernel and r.get("rows_per_launch") == nrows * B and r.get("N") == n:
+            traffic, src = r["traffic_bytes_per_launch"], "profiles/r01_pmc_ntt_fwd_traffic.json"
+    return {"bound": "hbm", "kernel": kernel,
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "rows_per_launch": nrows * B,
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+            "rows_per_launch": nrows * B,
             "avg_launch_ms": round(ms_fwd, 4), "inverse_avg_launch_ms": round(ms_inv, 4),
             "bytes_per_launch": bytes_launch}
 
