@@ -1052,7 +1052,8 @@ extern "C" int hx_poly_download(const hx_poly* p, uint64_t* host)
   return HX_OK;
 }
 
-static int poly_reserve(hx_poly* p, int cap)
+// keep = false: the caller overwrites every row (pure output), so the old contents are not copied
+static int poly_reserve(hx_poly* p, int cap, bool keep = true)
 {
   if (cap <= p->cap_rows)
     return HX_OK;
@@ -1065,8 +1066,9 @@ static int poly_reserve(hx_poly* p, int cap)
   hipError_t e = pool_alloc(c, bytes, (void**)&nd);
   if (e != hipSuccess)
     return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-  HIPCHK(hipMemcpyAsync(nd, p->d, (size_t)p->nrows() * p->row_words() * 8,
-                        hipMemcpyDeviceToDevice, c->stream));
+  if (keep && p->nrows() > 0)
+    HIPCHK(hipMemcpyAsync(nd, p->d, (size_t)p->nrows() * p->row_words() * 8,
+                          hipMemcpyDeviceToDevice, c->stream));
   pool_free(c, p->d, (size_t)p->cap_rows * p->row_words() * 8);  // stream-ordered reuse
   p->d = nd;
   p->cap_rows = cap;
@@ -1078,7 +1080,7 @@ extern "C" int hx_poly_copy(hx_poly* dst, const hx_poly* src)
   if (!dst || !src || dst->ctx != src->ctx || dst->batch != src->batch)
     return fail(HX_ERR_INVALID, "Context mismatch");
   CHK(use(dst->ctx));
-  CHK(poly_reserve(dst, src->nrows()));
+  CHK(poly_reserve(dst, src->nrows(), /*keep=*/false));
   dst->prime_idx = src->prime_idx;
   HIPCHK(hipMemcpyAsync(dst->d, src->d, (size_t)src->nrows() * src->row_words() * 8,
                         hipMemcpyDeviceToDevice, dst->ctx->stream));
@@ -2250,7 +2252,7 @@ extern "C" int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const 
   if (nall > MAX_ROWS)
     return fail(HX_ERR_UNSUPPORTED, "too many rows");
   size_t rw = a->row_words();
-  CHK(poly_reserve(out, ndig * nall));
+  CHK(poly_reserve(out, ndig * nall, /*keep=*/out == a));
   out->prime_idx.clear();
   for (int d = 0; d < ndig; d++)
     out->prime_idx.insert(out->prime_idx.end(), all.begin(), all.end());
@@ -2357,7 +2359,7 @@ extern "C" int hx_tensor(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0
   for (auto* o : os) {
     if (o->ctx != c0->ctx || o->batch != c0->batch)
       return fail(HX_ERR_INVALID, "Context mismatch");
-    CHK(poly_reserve(o, c0->nrows()));
+    CHK(poly_reserve(o, c0->nrows(), /*keep=*/false));
     o->prime_idx = c0->prime_idx;
   }
   return tensor_launch(c0, c1, d0, d1, o0->d, o1->d, o2->d, nullptr);
@@ -2371,7 +2373,7 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
                             int accumulate_rows, const uint64_t* own_src = nullptr,
                             const std::vector<int>* owner = nullptr,
                             const std::vector<std::vector<int>>* digit_primes = nullptr,
-                            int ndig = -1)
+                            int ndig = -1, const uint64_t* t0s = nullptr, const uint64_t* t1s = nullptr)
 {
   int nall = (int)all.size();
   if (ndig < 0)
@@ -2420,6 +2422,12 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
           h[r].pinv[e].w = inv;
           h[r].pinv[e].wp = hxh::shoup(inv, q);
         }
+        uint64_t ps = 1;
+        for (int t = 0; t < nall; t++)
+          if ((*owner)[t] < 0)
+            ps = hxh::mulmod(ps, c->primes[all[t]].q % q, q);
+        h[r].pscale.w = ps;
+        h[r].pscale.wp = hxh::shoup(ps, q);
       }
       ExtPlan* pl = new ExtPlan();
       memset(&pl->dev, 0, sizeof pl->dev);
@@ -2431,7 +2439,8 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
   }
   hipLaunchKernelGGL(hx::keyswitch_kernel, ew_grid(rw, nall), dim3(256), 0, c->stream, dig, W->d_b,
                      W->d_a, out0, out1, map, ndig, nall, (int)W->row_idx.size(), batch, c->phim,
-                     accumulate_rows, c->d_primes, own_src, d_fix, lazy);
+                     accumulate_rows, c->d_primes, own_src, d_fix, lazy, d_fix ? t0s : nullptr,
+                     d_fix ? t1s : nullptr);
   HIPCHK(hipGetLastError());
   return HX_OK;
 }
@@ -2455,9 +2464,12 @@ extern "C" int hx_key_switch_digits(const hx_poly* digits, const hx_ksk* W, hx_p
 // Ctxt::keySwitchPart on the s^2 part (src/Ctxt.cpp:805-842): t2e = its evaluation rows on `own`
 // (left untouched), all = own followed by the special primes; accumulates into out0/out1 whose
 // first L rows already hold the scaled parts (1), (s).
+// t0s/t1s (optional): the unscaled parts (1),(s); the key-switch kernel then multiplies them by
+// the special primes itself and out0/out1 need not be initialised.
 static int relin_core(hx_ctx* c, const uint64_t* t2e, const std::vector<int>& own,
                       const std::vector<int>& all, const hx_ksk* W, const int* dig_idx,
-                      const int* dig_off, int ndig, int batch, uint64_t* out0, uint64_t* out1)
+                      const int* dig_off, int ndig, int batch, uint64_t* out0, uint64_t* out1,
+                      const uint64_t* t0s = nullptr, const uint64_t* t1s = nullptr)
 {
   const int L = (int)own.size(), nall = (int)all.size();
   const size_t rw = (size_t)batch * c->phim;
@@ -2493,7 +2505,8 @@ static int relin_core(hx_ctx* c, const uint64_t* t2e, const std::vector<int>& ow
   std::vector<std::vector<int>> dprimes(ndig);
   for (int d = 0; d < ndig; d++)
     dprimes[d].assign(dig_idx + dig_off[d], dig_idx + dig_off[d + 1]);
-  return keyswitch_launch(c, c->scratch[1], W, all, batch, out0, out1, L, t2e, &owner, &dprimes, ndig);
+  return keyswitch_launch(c, c->scratch[1], W, all, batch, out0, out1, L, t2e, &owner, &dprimes, ndig,
+                          t0s, t1s);
 }
 
 static std::vector<uint64_t> special_factor(hx_ctx* c, const std::vector<int>& own, const int* sp,
@@ -2528,8 +2541,9 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
   if (out0->batch != c0->batch || out1->batch != c0->batch || out0->ctx != c || out1->ctx != c)
     return fail(HX_ERR_INVALID, "Context mismatch");
   size_t rw = c0->row_words();
-  CHK(poly_reserve(out0, nall));
-  CHK(poly_reserve(out1, nall));
+  // (an output that aliases an input keeps its rows when it has to grow)
+  CHK(poly_reserve(out0, nall, out0 == c0 || out0 == c1 || out0 == d0 || out0 == d1));
+  CHK(poly_reserve(out1, nall, out1 == c0 || out1 == c1 || out1 == d0 || out1 == d1));
   out0->prime_idx = W->row_idx;
   out1->prime_idx = W->row_idx;
   CHK(ensure_scratch(c, 0, (size_t)L * rw));  // s^2 part, evaluation domain
@@ -2567,27 +2581,16 @@ extern "C" int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_pol
     if (find_row(W->row_idx, r) < 0)
       return fail(HX_ERR_PRIMESET, "No key-switching matrix row for prime %d", r);
   size_t rw = t0->row_words();
-  CHK(poly_reserve(out0, nall));
-  CHK(poly_reserve(out1, nall));
-  // parts (1),(s): addPrimesAndScale(special) written straight into the outputs
-  std::vector<uint64_t> f = special_factor(c, t0->prime_idx, sp_idx, nsp);
-  {
-    RowMap map;
-    RowScalars sc;
-    for (int r = 0; r < L; r++) {
-      uint64_t q = c->primes[t0->prime_idx[r]].q;
-      map.p[r] = (uint16_t)t0->prime_idx[r];
-      sc.c[r] = f[r] % q;
-      sc.cp[r] = hxh::shoup(sc.c[r], q);
-    }
-    hipLaunchKernelGGL(hx::scale2_kernel, ew_grid(rw, L), dim3(256), 0, c->stream, t0->d, t1->d, out0->d,
-                       out1->d, map, sc, rw, c->d_primes);
-    HIPCHK(hipGetLastError());
-  }
+  // (an output that aliases an input keeps its rows when it has to grow)
+  CHK(poly_reserve(out0, nall, out0 == t0 || out0 == t1 || out0 == t2));
+  CHK(poly_reserve(out1, nall, out1 == t0 || out1 == t1 || out1 == t2));
+  // parts (1),(s): addPrimesAndScale(special) happens inside the key-switch kernel, which reads
+  // them unscaled (no separate pass over 2L rows)
+  const std::vector<int> own = t0->prime_idx;  // (out0 may be t0 itself)
   out0->prime_idx = all;
   out1->prime_idx = all;
-  return relin_core(c, t2->d, t0->prime_idx, all, W, dig_idx, dig_off, ndig, t0->batch, out0->d,
-                    out1->d);
+  return relin_core(c, t2->d, own, all, W, dig_idx, dig_off, ndig, t0->batch, out0->d, out1->d, t0->d,
+                    t1->d);
 }
 
 // Ctxt::reLinearize with the digit norms keySwitchPart feeds into the noise estimate

@@ -192,6 +192,7 @@ constexpr int KS_MAXD = 8;
 struct KsFix {
   int64_t owner;        // digit owning this row, -1 for special primes
   TW pinv[KS_MAXD];     // P_e^-1 mod q_row for e < owner
+  TW pscale;            // product of the special primes mod q_row (addPrimesAndScale factor)
 };
 
 __global__ void __launch_bounds__(256)
@@ -200,7 +201,8 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
                  uint64_t* __restrict__ out1, RowMap2 map, int ndig, int nall, int wrows, int batch,
                  uint32_t n, int accumulate_rows /* rows < this accumulate, others overwrite */,
                  const PrimeDev* __restrict__ primes, const uint64_t* __restrict__ own_src,
-                 const KsFix* __restrict__ fix, int lazy)
+                 const KsFix* __restrict__ fix, int lazy, const uint64_t* __restrict__ t0s,
+                 const uint64_t* __restrict__ t1s)
 {
   const int row = blockIdx.y;
   const PrimeDev pd = primes[map.p[row]];
@@ -213,7 +215,17 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
     const size_t e = 2 * i;            // within the row: b*n + j
     const size_t j = e % n;            // coefficient index (pairs never straddle: n even)
     ulonglong2 acc0, acc1;
-    if (row < accumulate_rows) {
+    if (row < accumulate_rows && t0s) {
+      // parts (1),(s) enter scaled by the special primes (Ctxt::keySwitchPart's
+      // addPrimesAndScale, src/Ctxt.cpp:816-820), read straight from the unscaled parts
+      const TW ps = fix[row].pscale;
+      acc0 = *reinterpret_cast<const ulonglong2*>(t0s + (size_t)row * row_words + e);
+      acc1 = *reinterpret_cast<const ulonglong2*>(t1s + (size_t)row * row_words + e);
+      acc0.x = mul_shoup(acc0.x, ps.w, ps.wp, q);
+      acc0.y = mul_shoup(acc0.y, ps.w, ps.wp, q);
+      acc1.x = mul_shoup(acc1.x, ps.w, ps.wp, q);
+      acc1.y = mul_shoup(acc1.y, ps.w, ps.wp, q);
+    } else if (row < accumulate_rows) {
       acc0 = *reinterpret_cast<const ulonglong2*>(out0 + (size_t)row * row_words + e);
       acc1 = *reinterpret_cast<const ulonglong2*>(out1 + (size_t)row * row_words + e);
     } else {
