@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <map>
@@ -1401,6 +1402,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   size_t o_tq = take(nt), o_tmu64 = take(nt), o_tmu = take(nt), o_tk = take((nt + 1) / 2);
   size_t o_pmod = take(nt), o_W = take((size_t)2 * nt * n), o_upd = take((size_t)2 * nt);
   size_t o_Wp = take((size_t)2 * n);
+  size_t o_tlazy = take((nt + 1) / 2);
   std::vector<uint64_t> h(off, 0);
   hxh::BigU P(1);
   for (int k = 0; k < n; k++) {
@@ -1423,8 +1425,19 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
       h[o_half + k] = H.divmod_word(p[k]);
   }
   uint32_t* tk = reinterpret_cast<uint32_t*>(&h[o_tk]);
+  uint32_t* tlazy = reinterpret_cast<uint32_t*>(&h[o_tlazy]);
+  hxh::u128 sum_src = 0;
+  uint64_t max_src = 0, min_src = ~0ull;
+  for (int k = 0; k < n; k++) {
+    sum_src += p[k];
+    max_src = std::max(max_src, p[k]);
+    min_src = std::min(min_src, p[k]);
+  }
   for (int t = 0; t < nt; t++) {
     uint64_t q = c->primes[tgt[t]].q;
+    // lazy 128-bit accumulation is exact when sum_k a_k*W_k < (sum_k q_k)*q_t <= 8*q_t^2
+    // (red128_wide's domain; q_t <= 60 bits)
+    tlazy[t] = (hxh::bitlen(q) <= 60 && sum_src <= (hxh::u128)8 * q && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;
     h[o_tq + t] = q;
     h[o_tmu64 + t] = (uint64_t)((((hxh::u128)1) << 64) / q);
     int kb = hxh::bitlen(q);
@@ -1481,6 +1494,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   pl->dev.W = reinterpret_cast<const TW*>(d + o_W);
   pl->dev.upd = reinterpret_cast<const TW*>(d + o_upd);
   pl->dev.Wp = reinterpret_cast<const TW*>(d + o_Wp);
+  pl->dev.tgt_lazy = reinterpret_cast<const uint32_t*>(d + o_tlazy);
+  pl->dev.garner_cs = (max_src / 2 < min_src && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;  // a_l < q_l <= max < 2*min <= 2*p_k
   c->plans[key] = pl;
   *out = pl;
   return HX_OK;

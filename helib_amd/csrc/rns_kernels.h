@@ -307,7 +307,25 @@ struct ExtPlanDev {
   uint64_t ptxt, ptxt_mu64, pinv_ptxt /* P^-1 mod ptxt */, pmod_ptxt /* P mod ptxt */;
   uint64_t ptxt_mu;  uint32_t ptxt_k;
   const TW* Wp;            // [n] (p_0..p_{k-1}) mod ptxt
+  // strength reductions decided by the host from the actual primes:
+  uint32_t garner_cs;        // every source residue is < 2*p_k for every later source prime p_k:
+                             // "a_l mod p_k" is one conditional subtraction
+  const uint32_t* tgt_lazy;  // [nt] 1: sum_k q_k <= 8*q_t, so the target residue can be taken from
+                             // the 128-bit sum of the n products with ONE Barrett reduction
 };
+
+// sum_k a_k * W[k]  mod q for a target whose plan says the lazy 128-bit form is exact
+template <int NMAX>
+__device__ __forceinline__ uint64_t mixed_radix_residue_lazy(const uint64_t (&a)[NMAX], const TW* Wt, int n,
+                                                             uint64_t q, uint64_t mu, uint32_t k)
+{
+  u128 acc = 0;
+#pragma unroll
+  for (int i = 0; i < NMAX; i++)
+    if (i < n)
+      acc += (u128)a[i] * Wt[i].w;
+  return red128_wide(acc, q, mu, k);
+}
 
 struct ExtArgs {
   const uint64_t* src;       // coefficient rows, [row][batch][N]
@@ -355,7 +373,7 @@ rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
 #pragma unroll
       for (int l = 0; l < NMAX; l++) {
         if (l < k) {
-          uint64_t al = red64(a[l], pk, mk);
+          uint64_t al = P.garner_cs ? (a[l] >= pk ? a[l] - pk : a[l]) : red64(a[l], pk, mk);
           uint64_t d = sub_mod(x, al, pk);
           TW g = P.ginv[k * n + l];
           x = mul_shoup(d, g.w, g.wp, pk);
@@ -414,16 +432,21 @@ rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
   auto residue = [&](int t) -> uint64_t {
     const uint64_t q = P.tgt_q[t], mu64 = P.tgt_mu64[t];
     const TW* Wt = P.W + (size_t)t * n;
-    uint64_t acc = 0;
+    uint64_t r;
+    if (P.tgt_lazy[t]) {
+      r = mixed_radix_residue_lazy<NMAX>(a, Wt, n, q, P.tgt_mu[t], P.tgt_k[t]);
+    } else {
+      uint64_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < NMAX; k++) {
-      if (k < n) {
-        acc += shoup_lazy(a[k], Wt[k], q);  // each < 2q < 2^61 (q < 2^60)
-        if ((k & 3) == 3)
-          acc = red64(acc, q, mu64);
+      for (int k = 0; k < NMAX; k++) {
+        if (k < n) {
+          acc += shoup_lazy(a[k], Wt[k], q);  // each < 2q < 2^61 (q < 2^60)
+          if ((k & 3) == 3)
+            acc = red64(acc, q, mu64);
+        }
       }
+      r = red64(acc, q, mu64);
     }
-    uint64_t r = red64(acc, q, mu64);
     if (neg)
       r = sub_mod(r, P.pmod[t], q);
     if (dm_nonzero) {
@@ -492,7 +515,7 @@ break_digits_kernel(BreakArgs A, size_t row_words)
 #pragma unroll
         for (int l = 0; l < NMAX; l++) {
           if (l < k) {
-            uint64_t al = red64(a[l], pk, mk);
+            uint64_t al = P.garner_cs ? (a[l] >= pk ? a[l] - pk : a[l]) : red64(a[l], pk, mk);
             TW g = P.ginv[k * n + l];
             x = mul_shoup(sub_mod(x, al, pk), g.w, g.wp, pk);
           }
@@ -516,16 +539,21 @@ break_digits_kernel(BreakArgs A, size_t row_words)
       const int r = t < off ? t : t + n;  // row of target t in the all-rows order
       const uint64_t q = P.tgt_q[t], mu64 = P.tgt_mu64[t];
       const TW* Wt = P.W + (size_t)t * n;
-      uint64_t acc = 0;
+      uint64_t v;
+      if (P.tgt_lazy[t]) {
+        v = mixed_radix_residue_lazy<NMAX>(a, Wt, n, q, P.tgt_mu[t], P.tgt_k[t]);
+      } else {
+        uint64_t acc = 0;
 #pragma unroll
-      for (int k = 0; k < NMAX; k++) {
-        if (k < n) {
-          acc += shoup_lazy(a[k], Wt[k], q);
-          if ((k & 3) == 3)
-            acc = red64(acc, q, mu64);
+        for (int k = 0; k < NMAX; k++) {
+          if (k < n) {
+            acc += shoup_lazy(a[k], Wt[k], q);
+            if ((k & 3) == 3)
+              acc = red64(acc, q, mu64);
+          }
         }
+        v = red64(acc, q, mu64);
       }
-      uint64_t v = red64(acc, q, mu64);
       if (neg)
         v = sub_mod(v, P.pmod[t], q);
       dd[(size_t)r * row_words] = v;
