@@ -452,7 +452,8 @@ def embeddingLargestCoeff(context, f):
 
 
 def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None, norms=False, defer=False):
-    """Ctxt::reLinearize data path for a 3-part ciphertext (1, s, s^2).  norms=True also returns
+    """Ctxt::reLinearize data path for a 3-part ciphertext (1, s, s^2), or with t1 = None for the
+    (1, s(X^k)) ciphertext of Ctxt::smartAutomorph (t2 = the s(X^k) part).  norms=True also returns
     the [ndigits, batch] array embeddingLargestCoeff(digit)/P_digit (the pieces of
     breakIntoDigits' return value, src/DoubleCRT.cpp:538-545)."""
     ctx = t0.context
@@ -463,13 +464,13 @@ def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None, norms=Fals
         out0 = DoubleCRT(ctx, t0.getIndexSet(), t0.batch, zero=False)
         out1 = DoubleCRT(ctx, t0.getIndexSet(), t0.batch, zero=False)
     if not norms:
-        _chk(lib().hx_relinearize(t0.h, t1.h, t2.h, W.h, _p(dig_idx), _p(dig_off), len(digits), _p(sp),
-                                  len(sp), out0.h, out1.h))
+        _chk(lib().hx_relinearize(t0.h, t1.h if t1 is not None else None, t2.h, W.h, _p(dig_idx),
+                                  _p(dig_off), len(digits), _p(sp), len(sp), out0.h, out1.h))
         return out0, out1
     nrm = np.zeros((len(digits), t0.batch), dtype=np.float64)
     ctx.deferNorms(defer)
-    _chk(lib().hx_relinearize_norms(t0.h, t1.h, t2.h, W.h, _p(dig_idx), _p(dig_off), len(digits),
-                                    _p(sp), len(sp), out0.h, out1.h, _p(nrm)))
+    _chk(lib().hx_relinearize_norms(t0.h, t1.h if t1 is not None else None, t2.h, W.h, _p(dig_idx),
+                                    _p(dig_off), len(digits), _p(sp), len(sp), out0.h, out1.h, _p(nrm)))
     return out0, out1, nrm
 
 

@@ -2577,14 +2577,17 @@ extern "C" int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_pol
                               const hx_ksk* W, const int* dig_idx, const int* dig_off, int ndig,
                               const int* sp_idx, int nsp, hx_poly* out0, hx_poly* out1)
 {
-  if (!t0 || !t1 || !t2 || !W || !out0 || !out1 || !dig_idx || !dig_off || (nsp > 0 && !sp_idx))
+  // t1 == NULL: no part pointing at s -- the (1, s(X^k)) ciphertext Ctxt::smartAutomorph
+  // relinearises after Ctxt::automorph (src/Ctxt.cpp:2437-2515); t2 is then the s(X^k) part
+  if (!t0 || !t2 || !W || !out0 || !out1 || !dig_idx || !dig_off || (nsp > 0 && !sp_idx))
     return fail(HX_ERR_INVALID, "null argument");
   hx_ctx* c = t0->ctx;
   CHK(use(c));
   if (ndig > W->ndig || ndig < 1)
     return fail(HX_ERR_INVALID, "W must have as many columns as there are digits");
-  if (t1->prime_idx != t0->prime_idx || t2->prime_idx != t0->prime_idx || t1->batch != t0->batch ||
-      t2->batch != t0->batch || out0->batch != t0->batch || out1->batch != t0->batch)
+  if ((t1 && (t1->prime_idx != t0->prime_idx || t1->batch != t0->batch)) ||
+      t2->prime_idx != t0->prime_idx || t2->batch != t0->batch || out0->batch != t0->batch ||
+      out1->batch != t0->batch)
     return fail(HX_ERR_PRIMESET, "reLinearize: parts must share one prime set and batch");
   CHK(check_rows(c, sp_idx, nsp));
   std::vector<int> all;
@@ -2605,7 +2608,7 @@ extern "C" int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_pol
   out0->prime_idx = all;
   out1->prime_idx = all;
   return relin_core(c, t2->d, own, all, W, dig_idx, dig_off, ndig, t0->batch, out0->d, out1->d, t0->d,
-                    t1->d);
+                    t1 ? t1->d : nullptr);
 }
 
 // Ctxt::reLinearize with the digit norms keySwitchPart feeds into the noise estimate

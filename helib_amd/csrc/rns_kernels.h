@@ -220,11 +220,15 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
       // addPrimesAndScale, src/Ctxt.cpp:816-820), read straight from the unscaled parts
       const TW ps = fix[row].pscale;
       acc0 = *reinterpret_cast<const ulonglong2*>(t0s + (size_t)row * row_words + e);
-      acc1 = *reinterpret_cast<const ulonglong2*>(t1s + (size_t)row * row_words + e);
       acc0.x = mul_shoup(acc0.x, ps.w, ps.wp, q);
       acc0.y = mul_shoup(acc0.y, ps.w, ps.wp, q);
-      acc1.x = mul_shoup(acc1.x, ps.w, ps.wp, q);
-      acc1.y = mul_shoup(acc1.y, ps.w, ps.wp, q);
+      if (t1s) {  // no part pointing at s (a 2-part ciphertext after an automorphism): zero
+        acc1 = *reinterpret_cast<const ulonglong2*>(t1s + (size_t)row * row_words + e);
+        acc1.x = mul_shoup(acc1.x, ps.w, ps.wp, q);
+        acc1.y = mul_shoup(acc1.y, ps.w, ps.wp, q);
+      } else {
+        acc1 = make_ulonglong2(0, 0);
+      }
     } else if (row < accumulate_rows) {
       acc0 = *reinterpret_cast<const ulonglong2*>(out0 + (size_t)row * row_words + e);
       acc1 = *reinterpret_cast<const ulonglong2*>(out1 + (size_t)row * row_words + e);

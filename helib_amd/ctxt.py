@@ -48,6 +48,11 @@ def _divc(a, b):
     return -(-a // b)
 
 
+def _powerOfS(handle):
+    """SKHandle::getPowerOfS for the part keys used here: "1", "s", "s2", ("s", k) = s(X^k)."""
+    return {"1": 0, "s": 1, "s2": 2}.get(handle, 1)
+
+
 def _ln(x):
     return math.log(x) if x > 0 else -math.inf
 
@@ -291,6 +296,7 @@ class Ctxt:
         self._meas = bool(Ctxt.measure and hasattr(ops, "supportsNorms") and ops.supportsNorms(context.m))
         self._ln = -math.inf
         self._pending = []     # deferred noise updates waiting for norms still on the device
+        self.ksw_auto = {}     # k -> key-switching matrix from s(X^k) to s (PubKey::getKeySWmatrix)
         self.parts = {}
         self.primeSet = frozenset()
         self.ptxtSpace = context.ptxtSpace
@@ -312,6 +318,7 @@ class Ctxt:
         c.parts = {h: p.copy() for h, p in self.parts.items()}
         c.primeSet, c.ptxtSpace = self.primeSet, self.ptxtSpace
         c.lnNoise, c.intFactor = self.lnNoise, self.intFactor
+        c.ksw_auto = self.ksw_auto
         return c
 
     # ---- noise estimate: ln(noiseBound) ----
@@ -347,8 +354,7 @@ class Ctxt:
 
     def modSwitchAddedNoiseBound(self):
         h = self.context.skBound()
-        power = {"1": 0, "s": 1, "s2": 2}
-        added = sum(1.0 if k == "1" else h ** power[k] for k in self.parts)
+        added = sum(h ** _powerOfS(k) for k in self.parts)
         return added * self.context.noiseBoundForUniform(self.ptxtSpace / 2.0, self.context.phim)
 
     # ---- prime-set maintenance ----
@@ -393,11 +399,10 @@ class Ctxt:
         if not meas:
             return [c.modSwitchAddedNoiseBound for c in cts]
         h = a.context.skBound()
-        power = {"1": 0, "s": 1, "s2": 2}
         out, k = [], 0
         for c in cts:
             keys = list(c.parts)
-            out.append(lambda k0=k, keys=keys: sum(float(max(norms[k0 + i])) * h ** power[key]
+            out.append(lambda k0=k, keys=keys: sum(float(max(norms[k0 + i])) * h ** _powerOfS(key)
                                                    for i, key in enumerate(keys)))
             k += len(keys)
         return out
@@ -522,8 +527,19 @@ class Ctxt:
         self.lnNoise = self.lnNoise + o.lnNoise
 
     def reLinearize(self):
-        if "s2" not in self.parts:
+        """Ctxt::reLinearize (src/Ctxt.cpp:720-786) for the shapes of this path: (1, s, s^2) after a
+        multiplication, or (1, [s,] s(X^k)) after an automorphism."""
+        other = [h for h in self.parts if h not in ("1", "s")]
+        if not other:
             return
+        assert len(other) == 1, "one non-canonical part at a time"
+        hnd = other[0]
+        if hnd == "s2":
+            W = self.ksw
+        else:
+            W = self.ksw_auto.get(hnd[1])
+            if W is None:
+                raise LookupError(f"no key-switching matrices for k={hnd[1]}")   # LogicError in the reference
         ctx = self.context
         self.dropSmallAndSpecialPrimes()
         sp = list(ctx.specialPrimes)
@@ -533,7 +549,7 @@ class Ctxt:
         digits = [d for d in digits if d]
         self.ptxtSpace = math.gcd(self.ptxtSpace, self.ksw_ptxtSpace)
         self.intFactor %= self.ptxtSpace
-        res = self.ops.reLinearize(self.parts["1"], self.parts["s"], self.parts["s2"], self.ksw,
+        res = self.ops.reLinearize(self.parts["1"], self.parts.get("s"), self.parts[hnd], W,
                                    digits, sp, **({"norms": True, "defer": True} if self._meas else {}))
         o0, o1 = res[0], res[1]
 
@@ -551,6 +567,42 @@ class Ctxt:
         self.parts = {"1": o0, "s": o1}
         self.primeSet = self.primeSet | frozenset(sp)
         self._defer(update)
+
+    # ---- rotations ----
+    def automorph(self, k):
+        """Ctxt::automorph (src/Ctxt.cpp:2437-2457): F(X) -> F(X^k) on every part; the part that
+        pointed at s now points at s(X^k).  No change in the noise bound."""
+        m = self.context.m
+        k %= m
+        if math.gcd(k, m) != 1:
+            raise ValueError("k must be in Zm*")
+        if k == 1:
+            return self
+        assert "s2" not in self.parts, "relinearise before an automorphism"
+        new = {}
+        for h, p in self.parts.items():
+            p.automorph(k)
+            if h == "1":
+                new[h] = p
+            else:
+                j = (1 if h == "s" else h[1]) * k % m
+                new["s" if j == 1 else ("s", j)] = p
+        self.parts = new
+        return self
+
+    def smartAutomorph(self, k):
+        """Ctxt::smartAutomorph (src/Ctxt.cpp:2462-2515) when a matrix for k itself is available
+        (the reference walks a tree of generators' matrices, PubKey::getNextKSWmatrix; that walk is
+        key management and stays with the caller: apply the steps one by one)."""
+        k %= self.context.m
+        if k == 1 or not self.parts:
+            return self
+        if k not in self.ksw_auto:
+            raise LookupError(f"no key-switching matrices for k={k}")
+        self.reLinearize()          # canonical form first
+        self.automorph(k)
+        self.reLinearize()
+        return self
 
     def multiplyBy(self, other):
         self.multLowLvl(other)

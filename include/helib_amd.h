@@ -186,7 +186,10 @@ int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const 
  * :805-842): parts (1),(s) get addPrimesAndScale(special), part s^2 is broken into digits and
  * multiplied by W.  W may cover more ctxt primes than the parts currently have (lower level);
  * digits = the context's digits restricted to the parts' primes (leading digits of W).
- * out0/out1: primes(t0) followed by sp_idx. */
+ * out0/out1: primes(t0) followed by sp_idx.
+ * t1 may be NULL: no part points at s -- the (1, s(X^k)) ciphertext that Ctxt::smartAutomorph
+ * relinearises after Ctxt::automorph (src/Ctxt.cpp:2437-2515), t2 then being the s(X^k) part and
+ * W the matrix for that automorphism. */
 int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_poly* t2, const hx_ksk* W,
                    const int* dig_idx, const int* dig_off, int ndig, const int* sp_idx, int nsp,
                    hx_poly* out0, hx_poly* out1);

@@ -26,6 +26,11 @@ class OPoly:
             self.rows[r] = O.row_op("add", self.rows[r], other.rows[other.idx.index(i)], self.o.primes[i])
         return self
 
+    def automorph(self, k):
+        zms = O.zmstar(self.o.m)
+        self.rows = np.stack([O.automorph(r, self.o.m, zms, k) for r in self.rows])
+        return self
+
     def addPrimesAndScale(self, s):
         s = list(s)
         self.rows = np.vstack([self.o.scale_by_primes(self.idx, self.rows, s),
@@ -72,7 +77,7 @@ class OracleOps:
         D = len(digits)
         kb, ka = W.b[:D][:, sel], W.a[:D][:, sel]
         s0 = self.o.scale_by_primes(own, t0.rows, sp)
-        s1 = self.o.scale_by_primes(own, t1.rows, sp)
+        s1 = self.o.scale_by_primes(own, t1.rows, sp) if t1 is not None else np.zeros_like(s0)
         z = np.zeros((len(sp), self.o.N), dtype=np.uint64)
         if norms:
             dg, nrm = self.o.break_into_digits(own, t2.rows, digits, allp, want_norms=True)

@@ -123,3 +123,18 @@ def polymul_mod_phi(a, b, m, q):
             for j in range(n + 1):
                 out[i - n + j] = (out[i - n + j] - c * phi[j]) % q
     return out[:n]
+
+
+def automorph_mod_phi(a, m, k, q):
+    """F(X) -> F(X^k) mod (Phi_m(X), q) on the coefficient vector a (len phi(m))."""
+    phi = [int(c) for c in O.phimx(m)]
+    n = len(phi) - 1
+    full = [0] * m                       # first modulo X^m - 1
+    for i, ai in enumerate(a):
+        full[(i * k) % m] = (full[(i * k) % m] + int(ai)) % q
+    for i in range(m - 1, n - 1, -1):    # then modulo Phi_m (monic)
+        c = full[i]
+        if c:
+            for j in range(n + 1):
+                full[i - n + j] = (full[i - n + j] - c * phi[j]) % q
+    return full[:n]

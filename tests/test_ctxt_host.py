@@ -40,7 +40,9 @@ def test_fresh_multiply_prime_set_decision_m32768():
     assert removed == {c.ctxtPrimes[-1]}
 
 
-def make_keys(ctx, octx, seed=3):
+def make_keys(ctx, octx, seed=3, auto_k=None):
+    """Secret key s and a key-switching matrix W (src/keys.cpp:1159-1255) from s^2 to s, or --
+    auto_k given -- from s(X^k) to s:  b_j = P*B_j*s' + p*e_j - s*a_j."""
     rng = np.random.default_rng(seed)
     N = octx.N
     s = rng.integers(-1, 2, size=N)
@@ -60,12 +62,18 @@ def make_keys(ctx, octx, seed=3):
         return np.stack([O.row_op("add", a[r], b[r], ctx.primes[i]) for r, i in enumerate(idx)])
 
     s_all = rows(s, allp)
-    s2 = mul(s_all, s_all, allp)
+    if auto_k is None:
+        s2 = mul(s_all, s_all, allp)
+    else:   # s(X^k): the automorphism permutes evaluation rows
+        zms = O.zmstar(octx.m)
+        s2 = np.stack([O.automorph(r, octx.m, zms, auto_k) for r in s_all])
+        rng = np.random.default_rng(seed + 1000 + auto_k)   # fresh errors, same secret key
+        rng.integers(-1, 2, size=N)
     P = ctx.productOfPrimes(ctx.specialPrimes)
     p = ctx.ptxtSpace
     kb, ka, Bj = [], [], 1
     for j, d in enumerate(ctx.digits):
-        a = np.stack([O.fill_uniform(N, ctx.primes[i], 900 + j * 100 + i) for i in allp])
+        a = np.stack([O.fill_uniform(N, ctx.primes[i], 900 + j * 100 + i + 7919 * (auto_k or 0)) for i in allp])
         e = np.rint(rng.normal(0, 3.2, size=N)).astype(np.int64)
         pe = rows([p * int(x) for x in e], allp)
         fac = P * Bj
@@ -133,3 +141,39 @@ def test_multiplyBy_full_sequence_decrypts(m, p, bits):
     ca.dropSmallAndSpecialPrimes()
     assert not (ca.primeSet & frozenset(ctx.specialPrimes))
     assert decrypt(ctx, octx, s, ca, rows) == want
+
+
+def plain_automorph(msg, m, k, p):
+    """F(X) -> F(X^k) mod (Phi_m, p) on coefficient vectors, through the evaluation rows of a
+    prime the oracle knows (any prime works: the map is the same permutation of evaluations)."""
+    from tests import bgv_ref as B
+    return B.automorph_mod_phi(msg, m, k, p)
+
+
+@pytest.mark.parametrize("m,p,bits,k", [(128, 257, 150, 3), (128, 257, 150, 127), (64, 65537, 250, 5)])
+def test_smartAutomorph_decrypts_to_the_rotated_plaintext(m, p, bits, k):
+    """Ctxt::smartAutomorph = automorph + reLinearize with the matrix for s(X^k)
+    (src/Ctxt.cpp:2437-2515), host logic over the oracle backend; then a multiplication on the
+    rotated ciphertext to check the bookkeeping carries on."""
+    ctx = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    octx = O.Ctx(m)
+    for q in ctx.primes:
+        octx.add_prime(q)
+    s, allp, kb, ka, rows = make_keys(ctx, octx)
+    _, _, kbk, kak, _ = make_keys(ctx, octx, auto_k=k)
+    ops = OracleOps(octx)
+    W, Wk = OKeySwitch(allp, kb, ka), OKeySwitch(allp, kbk, kak)
+    rng = np.random.default_rng(21)
+    ma, mb = rng.integers(0, p, size=octx.N), rng.integers(0, p, size=octx.N)
+    ca = hc.Ctxt.fresh(ctx, ops, *(OPoly(octx, ctx.ctxtPrimes, x) for x in encrypt(ctx, octx, s, ma, 1, rows)), ksw=W)
+    cb = hc.Ctxt.fresh(ctx, ops, *(OPoly(octx, ctx.ctxtPrimes, x) for x in encrypt(ctx, octx, s, mb, 2, rows)), ksw=W)
+    ca.ksw_auto = {k: Wk}
+    with pytest.raises(LookupError):
+        ca.clone().smartAutomorph(9 if k != 9 else 11)      # no matrix for that one
+    ca.smartAutomorph(k)
+    assert set(ca.parts) == {"1", "s"} and ca.primeSet == frozenset(allp)
+    rot = plain_automorph(ma, m, k, p)
+    assert decrypt(ctx, octx, s, ca, rows) == rot
+    ca.multiplyBy(cb)
+    from tests import bgv_ref as B
+    assert decrypt(ctx, octx, s, ca, rows) == [int(v) for v in B.polymul_mod_phi(rot, mb, m, p)]

@@ -682,3 +682,42 @@ def test_break_into_digits_and_relinearize_norms(hx, digits):
     p0, p1 = hx.reLinearize(t0, t1, d, W, digits, sp)
     assert np.array_equal(o0.download(), p0.download()) and np.array_equal(o1.download(), p1.download())
     assert np.allclose(nrm2, nrm, rtol=1e-12, atol=0)
+
+
+# ---------------------------------------------------------------- N4: rotation path
+@pytest.mark.parametrize("m,p,bits,k", [(16384, 65537, 250, 3), (16384, 65537, 250, 16383), (1705, 7, 200, 2)])
+def test_smartAutomorph_gpu_vs_oracle(hx, m, p, bits, k, monkeypatch):
+    """Ctxt::smartAutomorph (automorph + reLinearize with the s(X^k) -> s matrix,
+    src/Ctxt.cpp:2437-2515): hx_automorph on both parts, hx_relinearize with no s part, driven by
+    the same host logic on the GPU and on the oracle; parts bit-identical, decrypts to m(X^k)."""
+    from helib_amd import ctxt as hc
+    from tests import test_ctxt_host as T
+    from oracle.backend import OKeySwitch, OPoly, OracleOps
+    monkeypatch.setattr(hc.Ctxt, "measure", hx.supportsNorms(m))
+    ctx = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    P = Pair(hx, m, ctx.primes)
+    s, allp, kb, ka, rows = T.make_keys(ctx, P.o)
+    _, _, kbk, kak, _ = T.make_keys(ctx, P.o, auto_k=k)
+    rng = np.random.default_rng(5)
+    ma = rng.integers(0, p, size=P.N)
+    ea = T.encrypt(ctx, P.o, s, ma, 1, rows)
+    oa = hc.Ctxt.fresh(ctx, OracleOps(P.o), *(OPoly(P.o, ctx.ctxtPrimes, x) for x in ea), ksw=OKeySwitch(allp, kb, ka))
+    oa.ksw_auto = {k: OKeySwitch(allp, kbk, kak)}
+    oa.smartAutomorph(k)
+    ga = hc.Ctxt.fresh(ctx, hx, *(hx.DoubleCRT(P.g, ctx.ctxtPrimes, 1, x[:, None, :]) for x in ea),
+                       ksw=hx.KeySwitch(P.g, allp, kb, ka))
+    ga.ksw_auto = {k: hx.KeySwitch(P.g, allp, kbk, kak)}
+    ga.smartAutomorph(k)
+    assert ga.primeSet == oa.primeSet and abs(ga.lnNoise - oa.lnNoise) < 1e-8
+    for h in ("1", "s"):
+        gi, oi = ga.parts[h].getIndexSet(), oa.parts[h].getIndexSet()
+        assert sorted(gi) == sorted(oi)
+        gd, od = ga.parts[h].download()[:, 0], oa.parts[h].download()[:, 0]
+        for r, i in enumerate(gi):
+            assert np.array_equal(gd[r], od[oi.index(i)]), (h, i)
+    got = T.decrypt(ctx, P.o, s, ga, rows)
+    if m < 4096:
+        from tests import bgv_ref as B
+        assert got == B.automorph_mod_phi(ma, m, k, p)
+    else:
+        assert got == T.decrypt(ctx, P.o, s, oa, rows)
