@@ -66,6 +66,37 @@ def main():
     with open(DST, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", DST)
+    bin_blocks()
+
+
+def bin_blocks():
+    """The same fixture in HElib's binary format (iotest_binLE.bin): every DoubleCRT block
+    (DoubleCRT::writeTo: IndexSet then one vec_long per prime) cut out byte-for-byte, for the
+    wire-format tests of helib_amd/wire.py."""
+    import struct
+    src = os.path.join(os.path.dirname(SRC), "iotest_binLE.bin")
+    b = open(src, "rb").read()
+    blocks = []
+    for card in (3, 5):
+        pat = struct.pack(f"<{card + 1}q", card, *range(card))
+        i = b.find(pat)
+        while i >= 0:
+            end = i + 8 * (card + 1)
+            ok = True
+            for _ in range(card):
+                n, sz = struct.unpack_from("<ii", b, end)
+                if n != 4 or sz != 8:
+                    ok = False
+                    break
+                end += 8 + n * sz
+            if ok:
+                blocks.append({"offset": i, "hex": b[i:end].hex()})
+            i = b.find(pat, i + 1)
+    blocks.sort(key=lambda x: x["offset"])
+    dst = os.path.join(os.path.dirname(DST), "iotest_m12_bin_blocks.json")
+    with open(dst, "w") as f:
+        json.dump({"source": "HElib 2.2.0 tests/test_resources/iotest_binLE.bin", "blocks": blocks}, f, indent=1)
+    print("wrote", dst, len(blocks), "blocks")
 
 
 if __name__ == "__main__":

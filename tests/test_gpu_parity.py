@@ -721,3 +721,25 @@ def test_smartAutomorph_gpu_vs_oracle(hx, m, p, bits, k, monkeypatch):
         assert got == B.automorph_mod_phi(ma, m, k, p)
     else:
         assert got == T.decrypt(ctx, P.o, s, oa, rows)
+
+
+# ---------------------------------------------------------------- N3: wire format
+def test_wire_format_round_trip_through_device(hx):
+    """DoubleCRT::writeTo -> read (helib_amd/wire.py) through device-resident objects."""
+    from helib_amd import wire
+    P = Pair(hx, 4096, primes_for(4096, 4))
+    idx = [2, 0, 3]                                    # device row order need not be ascending
+    x = P.rand(idx, 3, batch=2)
+    d = hx.DoubleCRT(P.g, idx, 2, x)
+    for b in range(2):
+        raw = wire.writeTo(d, b)
+        i2, rows, off = wire.read_rows(raw)
+        assert off == len(raw) and i2 == [0, 2, 3]
+        assert np.array_equal(rows, x[[1, 0, 2], b])
+    e, off = wire.readFrom(hx, P.g, wire.writeTo(d, 1), batch=3)
+    assert e.getIndexSet() == [0, 2, 3] and e.batch == 3
+    got = e.download()
+    for b in range(3):
+        assert np.array_equal(got[:, b], x[[1, 0, 2], 1])
+    e.FFT()                                            # a loaded object is a normal DoubleCRT
+    assert np.array_equal(e.download()[:, 0], P.o.fft([0, 2, 3], x[[1, 0, 2], 1]))
