@@ -42,6 +42,7 @@ SYMBOLS = [
     "hx_poly_set_zero", "hx_poly_remove_primes",
     "hx_ntt_forward", "hx_ntt_inverse",
     "hx_add", "hx_sub", "hx_mul", "hx_negate", "hx_add_scalar", "hx_sub_scalar", "hx_mul_scalar",
+    "hx_set_scalar", "hx_exp",
     "hx_automorph", "hx_complex_conj",
     "hx_add_primes_and_scale", "hx_add_primes", "hx_scale_down", "hx_scale_down_multi",
     "hx_bring_to_set_multi", "hx_break_into_digits",
@@ -85,6 +86,7 @@ def lib():
             "hx_ntt_forward": [vp], "hx_ntt_inverse": [vp],
             "hx_add": [vp, vp], "hx_sub": [vp, vp], "hx_mul": [vp, vp], "hx_negate": [vp],
             "hx_add_scalar": [vp, vp], "hx_sub_scalar": [vp, vp], "hx_mul_scalar": [vp, vp],
+            "hx_set_scalar": [vp, vp], "hx_exp": [vp, u64],
             "hx_automorph": [vp, u64], "hx_complex_conj": [vp],
             "hx_add_primes_and_scale": [vp, vp, ip], "hx_add_primes": [vp, vp, ip],
             "hx_scale_down": [vp, vp, ip, u64],
@@ -293,6 +295,19 @@ class DoubleCRT:
     def mulConstant(self, num):
         s = self._scalars(num)
         _chk(lib().hx_mul_scalar(self.h, _p(s)))
+        return self
+
+    def setConstant(self, num):
+        """DoubleCRT::operator=(ZZ): every entry becomes num mod q_i."""
+        s = self._scalars(num)
+        _chk(lib().hx_set_scalar(self.h, _p(s)))
+        return self
+
+    def Exp(self, e):
+        """DoubleCRT::Exp: entry-wise PowerMod(x, e, q_i) for e >= 0."""
+        if e < 0:
+            raise ValueError("negative exponent")
+        _chk(lib().hx_exp(self.h, int(e)))
         return self
 
     def automorph(self, k):

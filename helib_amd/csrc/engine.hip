@@ -1284,7 +1284,7 @@ extern "C" int hx_sub(hx_poly* a, const hx_poly* b) { return ew_binary<hx::EW_SU
 extern "C" int hx_mul(hx_poly* a, const hx_poly* b) { return ew_binary<hx::EW_MUL>(a, b); }
 
 template <int OP>
-static int ew_scalar_rows(hx_poly* a, const uint64_t* c_per_row)
+static int ew_scalar_rows(hx_poly* a, const uint64_t* c_per_row, uint64_t exponent = 0)
 {
   if (!a)
     return fail(HX_ERR_INVALID, "null poly");
@@ -1301,7 +1301,7 @@ static int ew_scalar_rows(hx_poly* a, const uint64_t* c_per_row)
     map.p[r] = (uint16_t)a->prime_idx[r];
     uint64_t cv = c_per_row ? c_per_row[r] % q : 0;
     sc.c[r] = cv;
-    sc.cp[r] = hxh::shoup(cv, q);
+    sc.cp[r] = OP == hx::EWS_EXP ? exponent : hxh::shoup(cv, q);
   }
   size_t rw = a->row_words();
   hipLaunchKernelGGL((hx::ew_scalar_kernel<OP>), ew_grid(rw, rows), dim3(256), 0, a->ctx->stream,
@@ -1328,6 +1328,19 @@ extern "C" int hx_mul_scalar(hx_poly* a, const uint64_t* c)
   return ew_scalar_rows<hx::EWS_MUL>(a, c);
 }
 extern "C" int hx_negate(hx_poly* a) { return ew_scalar_rows<hx::EWS_NEG>(a, nullptr); }
+extern "C" int hx_set_scalar(hx_poly* a, const uint64_t* c)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null scalars");
+  return ew_scalar_rows<hx::EWS_SET>(a, c);
+}
+extern "C" int hx_exp(hx_poly* a, uint64_t e)
+{
+  if (!a)
+    return fail(HX_ERR_INVALID, "null poly");
+  std::vector<uint64_t> zero((size_t)std::max(1, a->nrows()), 0);
+  return ew_scalar_rows<hx::EWS_EXP>(a, zero.data(), e);
+}
 
 extern "C" int hx_automorph(hx_poly* a, uint64_t k)
 {

@@ -44,7 +44,7 @@ ew_binary_kernel(uint64_t* __restrict__ a, const uint64_t* __restrict__ b, RowMa
   }
 }
 
-enum EwSOp { EWS_ADD = 0, EWS_SUB = 1, EWS_MUL = 2, EWS_NEG = 3 };
+enum EwSOp { EWS_ADD = 0, EWS_SUB = 1, EWS_MUL = 2, EWS_NEG = 3, EWS_SET = 4, EWS_EXP = 5 };
 
 template <int OP>
 __global__ void __launch_bounds__(256)
@@ -52,13 +52,31 @@ ew_scalar_kernel(uint64_t* __restrict__ a, RowMap map, RowScalars sc, size_t row
                  const PrimeDev* __restrict__ primes)
 {
   const int row = blockIdx.y;
-  const uint64_t q = primes[map.p[row]].q;
+  const PrimeDev pd = primes[map.p[row]];
+  const uint64_t q = pd.q;
   const uint64_t c = sc.c[row], cp = sc.cp[row];
   ulonglong2* pa = reinterpret_cast<ulonglong2*>(a + (size_t)row * row_words);
   const size_t nvec = row_words / 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
        i += (size_t)gridDim.x * blockDim.x) {
+    if (OP == EWS_SET) {  // DoubleCRT::operator=(ZZ): every entry = num mod q
+      pa[i] = make_ulonglong2(c, c);
+      continue;
+    }
     ulonglong2 x = pa[i];
+    if (OP == EWS_EXP) {  // DoubleCRT::Exp: PowerMod(x, e, q), e = cp (the same for every row)
+      uint64_t rx = 1 % q, ry = 1 % q, bx = x.x, by = x.y;
+      for (uint64_t e = cp; e; e >>= 1) {
+        if (e & 1) {
+          rx = mul_mod(rx, bx, q, pd.mu, pd.k);
+          ry = mul_mod(ry, by, q, pd.mu, pd.k);
+        }
+        bx = mul_mod(bx, bx, q, pd.mu, pd.k);
+        by = mul_mod(by, by, q, pd.mu, pd.k);
+      }
+      pa[i] = make_ulonglong2(rx, ry);
+      continue;
+    }
     if (OP == EWS_ADD) {
       x.x = add_mod(x.x, c, q);
       x.y = add_mod(x.y, c, q);

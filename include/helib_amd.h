@@ -125,6 +125,10 @@ int hx_negate(hx_poly* a); /* DoubleCRT::Negate src/DoubleCRT.cpp:363-384 */
 int hx_add_scalar(hx_poly* a, const uint64_t* c_per_row);
 int hx_sub_scalar(hx_poly* a, const uint64_t* c_per_row);
 int hx_mul_scalar(hx_poly* a, const uint64_t* c_per_row);
+/* DoubleCRT::operator=(ZZ) (src/DoubleCRT.cpp:866-884): every entry of row r = c_per_row[r] mod q_r */
+int hx_set_scalar(hx_poly* a, const uint64_t* c_per_row);
+/* DoubleCRT::Exp (src/DoubleCRT.cpp:1142-1156): entry-wise PowerMod(x, e, q_r), e >= 0 */
+int hx_exp(hx_poly* a, uint64_t e);
 /* DoubleCRT::automorph(k) (src/DoubleCRT.cpp:1160-1202); in place. */
 int hx_automorph(hx_poly* a, uint64_t k);
 /* DoubleCRT::complexConj (src/DoubleCRT.cpp:1240-1255) */

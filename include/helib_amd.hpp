@@ -162,6 +162,14 @@ public:
     }
     return mulConstant(c);
   }
+  // operator=(ZZ) with the per-row residues; Exp(e): entry-wise PowerMod
+  DoubleCRT& setConstant(const std::vector<uint64_t>& c) { return chk(hx_set_scalar(h_.get(), c.data())); }
+  DoubleCRT& Exp(long e)
+  {
+    if (e < 0)
+      throw InvalidArgument("DoubleCRT::Exp: negative exponent");
+    return chk(hx_exp(h_.get(), (uint64_t)e));
+  }
   DoubleCRT& automorph(long k) { return chk(hx_automorph(h_.get(), (uint64_t)k)); }
   DoubleCRT& complexConj() { return chk(hx_complex_conj(h_.get())); }
 

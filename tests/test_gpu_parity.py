@@ -743,3 +743,27 @@ def test_wire_format_round_trip_through_device(hx):
         assert np.array_equal(got[:, b], x[[1, 0, 2], 1])
     e.FFT()                                            # a loaded object is a normal DoubleCRT
     assert np.array_equal(e.download()[:, 0], P.o.fft([0, 2, 3], x[[1, 0, 2], 1]))
+
+
+def test_set_constant_and_exp(hx):
+    """DoubleCRT::operator=(ZZ) (src/DoubleCRT.cpp:866-884) and DoubleCRT::Exp (:1142-1156)."""
+    P = Pair(hx, 8192, primes_for(8192, 3))
+    idx = [0, 1, 2]
+    x = P.rand(idx, 11, batch=2)
+    d = hx.DoubleCRT(P.g, idx, 2, x)
+    for e in (0, 1, 2, 5, 65537):
+        d.upload(x)
+        got = d.Exp(e).download()
+        for r, i in enumerate(idx):
+            q = P.primes[i]
+            want = np.array([pow(int(v), e, q) for v in x[r, 0, :64]], dtype=np.uint64)
+            assert np.array_equal(got[r, 0, :64], want)
+            assert got[r, 1, 100] == pow(int(x[r, 1, 100]), e, q)
+    big = (1 << 190) + 77
+    got = d.setConstant(big).download()
+    for r, i in enumerate(idx):
+        assert (got[r] == big % P.primes[i]).all()
+    # a constant polynomial evaluates to the constant everywhere: iFFT gives (c, 0, 0, ...)
+    back = d.iFFT().download()
+    for r, i in enumerate(idx):
+        assert back[r, 0, 0] == big % P.primes[i] and not back[r, 0, 1:].any()
