@@ -156,6 +156,11 @@ struct hx_ctx {
   double* d_frac = nullptr;
   size_t frac_cap = 0, frac_pos = 0;
   bool want_frac = false;
+  // the fused single-prime mod-down leaves (x, S) in scratch[0]/[1]: the norm kernel reads them
+  // directly (rows [xs_first, xs_first + xs_rows) of the norm batch, delta/qd = x/qd - S)
+  int xs_first = 0, xs_rows = 0;
+  double xs_inv_qd = 0;
+  bool want_fdelta = false;  // the caller also wants the fdelta coefficients on the host
   double2* d_wtab = nullptr;           // W^k, k < N, W = exp(2 pi i / m)  (m a power of two)
   unsigned long long* d_norm2 = nullptr;
   size_t norm_cap = 0;
@@ -1563,9 +1568,9 @@ static int frac_begin(hx_ctx* c, size_t doubles)
     HIPCHK(hipMalloc((void**)&c->d_frac, doubles * sizeof(double)));
     c->frac_cap = doubles;
   }
-  HIPCHK(hipMemsetAsync(c->d_frac, 0, doubles * sizeof(double), c->stream));
   c->frac_pos = 0;
   c->want_frac = true;
+  c->xs_rows = 0;
   return HX_OK;
 }
 static double* frac_take(hx_ctx* c, size_t doubles)
@@ -1575,6 +1580,22 @@ static double* frac_take(hx_ctx* c, size_t doubles)
   double* p = c->d_frac + c->frac_pos;
   c->frac_pos += doubles;
   return p;
+}
+
+// A fused mod-down block whose (x, S) the norm kernel was going to read in place: write its
+// fdelta out now (something else is about to reuse the scratch slots, or the batch is mixed).
+static int flush_xs(hx_ctx* c)
+{
+  if (c->xs_rows <= 0)
+    return HX_OK;
+  const size_t n = (size_t)c->xs_rows * c->phim;
+  hipLaunchKernelGGL(hx::frac_from_xs_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)),
+                     dim3(256), 0, c->stream, c->scratch[0],
+                     reinterpret_cast<const int64_t*>(c->scratch[1]), c->xs_inv_qd,
+                     c->d_frac + (size_t)c->xs_first * c->phim, n);
+  HIPCHK(hipGetLastError());
+  c->xs_rows = 0;
+  return HX_OK;
 }
 
 // out_host[r] = max_j |f_r(W^(2j+1))| for `rows` real polynomials of N coefficients at d_f.
@@ -1611,7 +1632,10 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_kernel,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                16 << hx::NORM_MAX_LOGH));
-    HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_kernel,
+    HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_kernel<hx::NormSrcF64>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               16 << hx::NORM_MAX_LOGH));
+    HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_kernel<hx::NormSrcXS>,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                16 << hx::NORM_MAX_LOGH));
     attr = true;
@@ -1621,9 +1645,19 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     const unsigned M = N >> 1;
     const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, M / 4));
     const size_t lds = std::max<size_t>(16 * (size_t)M, 256);
-    hipLaunchKernelGGL(hx::embed_norm_quarter_kernel, dim3((unsigned)rows), dim3(threads), lds, c->stream,
-                       d_f, c->d_wtab, logn, c->d_norm2);
+    if (c->xs_rows == rows && d_f == c->d_frac) {
+      hx::NormSrcXS src{c->scratch[0], reinterpret_cast<const int64_t*>(c->scratch[1]), c->xs_inv_qd};
+      hipLaunchKernelGGL(hx::embed_norm_quarter_kernel<hx::NormSrcXS>, dim3((unsigned)rows), dim3(threads),
+                         lds, c->stream, src, c->d_wtab, logn, c->d_norm2);
+    } else {
+      CHK(flush_xs(c));
+      hx::NormSrcF64 src{d_f};
+      hipLaunchKernelGGL(hx::embed_norm_quarter_kernel<hx::NormSrcF64>, dim3((unsigned)rows), dim3(threads),
+                         lds, c->stream, src, c->d_wtab, logn, c->d_norm2);
+    }
+    c->xs_rows = 0;
   } else {
+    CHK(flush_xs(c));
     const int logh = std::min(logn, hx::NORM_MAX_LOGH);
     const unsigned H = 1u << logh, S = N >> logh;
     const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, H / 4));
@@ -1802,6 +1836,8 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     return fail(HX_ERR_INVALID, "null poly");
   hx_ctx* c = a->ctx;
   CHK(use(c));
+  if (c->want_frac)
+    CHK(flush_xs(c));  // the scratch slots of an earlier fused block are about to be reused
   if (ptxt < 1)
     return fail(HX_ERR_INVALID, "ptxtSpace must be at least 1");
   if (nadd > 0) {
@@ -1829,8 +1865,14 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
         d = true;
     (d ? drop : keep).push_back(a->prime_idx[r]);
   }
-  if (drop.empty())
-    return HX_OK;  // nothing to do
+  if (drop.empty()) {  // nothing to do; a requested norm is that of delta = 0
+    if (c->want_frac) {
+      double* fr = frac_take(c, a->row_words() * (size_t)(1 + nother));
+      if (fr)
+        HIPCHK(hipMemsetAsync(fr, 0, a->row_words() * (size_t)(1 + nother) * sizeof(double), c->stream));
+    }
+    return HX_OK;
+  }
   if (keep.empty())
     return fail(HX_ERR_PRIMESET, "s and the index set must have some intersection");
   if ((int)drop.size() > 64)
@@ -1941,10 +1983,17 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
       double* fr = frac_take(c, n);
       if (!fr)
         return fail(HX_ERR_INVALID, "internal: fraction buffer too small");
-      hipLaunchKernelGGL(hx::frac_from_xs_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)),
-                         dim3(256), 0, c->stream, c->scratch[0],
-                         reinterpret_cast<const int64_t*>(c->scratch[1]), 1.0 / (double)qd, fr, n);
-      HIPCHK(hipGetLastError());
+      if (c->xs_rows == 0 && c->frac_pos == n && !c->want_fdelta) {
+        // the whole norm batch comes from this call: the norm kernel reads (x, S) itself
+        c->xs_first = 0;
+        c->xs_rows = pb.n * a->batch;
+        c->xs_inv_qd = 1.0 / (double)qd;
+      } else {
+        hipLaunchKernelGGL(hx::frac_from_xs_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)),
+                           dim3(256), 0, c->stream, c->scratch[0],
+                           reinterpret_cast<const int64_t*>(c->scratch[1]), 1.0 / (double)qd, fr, n);
+        HIPCHK(hipGetLastError());
+      }
     }
     if (drow != last)
       a->prime_idx[drow] = a->prime_idx[last];
@@ -2092,7 +2141,9 @@ extern "C" int hx_scale_down_multi_norms(hx_poly** polys, int npoly, const int* 
   const size_t rw = polys[0]->row_words();
   const int batch = polys[0]->batch;
   CHK(frac_begin(c, (size_t)npoly * rw));
+  c->want_fdelta = fdelta != nullptr;
   int rc = hx_scale_down_multi(polys, npoly, drop_idx, ndrop, ptxt);
+  c->want_fdelta = false;
   return finish_norms(c, rc, (size_t)npoly * rw, npoly * batch, norms, fdelta);
 }
 

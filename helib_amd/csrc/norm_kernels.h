@@ -143,8 +143,30 @@ embed_norm_kernel(const double* __restrict__ f, const double2* __restrict__ wtab
 // so ONE M-point complex DFT of z_i = (e_i + i o_i) V^i gives Z_j = E_j + i O_j and
 //   E_j = (Z_j + conj Z_(M-1-j))/2,  O_j = (Z_j - conj Z_(M-1-j))/(2i).
 // In the bit-reversed output order Z_j sits at p = brev(j) and Z_(M-1-j) at M-1-p.
+// Coefficient sources: doubles in memory, or the (x, S) pair of the fused single-prime mod-down
+// (delta/qd = x/qd - S) read directly -- no fdelta array is materialised for the norm.
+struct NormSrcF64 {
+  const double* f;
+  __device__ __forceinline__ double2 pair(unsigned row, unsigned N, unsigned i) const
+  {
+    return reinterpret_cast<const double2*>(f + (size_t)row * N)[i];
+  }
+};
+struct NormSrcXS {
+  const uint64_t* xs;
+  const int64_t* S;
+  double inv_qd;
+  __device__ __forceinline__ double2 pair(unsigned row, unsigned N, unsigned i) const
+  {
+    const ulonglong2 x = reinterpret_cast<const ulonglong2*>(xs + (size_t)row * N)[i];
+    const longlong2 s = reinterpret_cast<const longlong2*>(S + (size_t)row * N)[i];
+    return make_double2((double)x.x * inv_qd - (double)s.x, (double)x.y * inv_qd - (double)s.y);
+  }
+};
+
+template <class SRC>
 __global__ void __launch_bounds__(NORM_THREADS)
-embed_norm_quarter_kernel(const double* __restrict__ f, const double2* __restrict__ wtab, int logn,
+embed_norm_quarter_kernel(SRC src, const double2* __restrict__ wtab, int logn,
                           unsigned long long* __restrict__ out2)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -153,9 +175,8 @@ embed_norm_quarter_kernel(const double* __restrict__ f, const double2* __restric
   double* re = sm;
   double* im = sm + M;
   const unsigned row = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
-  const double2* fr = reinterpret_cast<const double2*>(f + (size_t)row * N);
   for (unsigned i = tid; i < M; i += nth) {
-    const double2 v = fr[i];          // (f_2i, f_(2i+1))
+    const double2 v = src.pair(row, N, i);   // (f_2i, f_(2i+1))
     const double2 w = wtab[2 * i];    // V^i = W^(2i)
     re[i] = v.x * w.x - v.y * w.y;
     im[i] = v.x * w.y + v.y * w.x;

@@ -767,3 +767,25 @@ def test_set_constant_and_exp(hx):
     back = d.iFFT().download()
     for r, i in enumerate(idx):
         assert back[r, 0, 0] == big % P.primes[i] and not back[r, 0, 1:].any()
+
+
+def test_scale_down_norms_when_parts_are_switched_one_by_one(hx):
+    """Parts whose rows sit in different orders cannot share the fused launches: every part then
+    runs the single-prime path on its own and reuses the same (x, S) scratch -- the norms must
+    still be those of each part's own delta."""
+    P, own, sp = setup_rns(hx, m=16384, L=4, K=1)
+    allp = own + sp
+    orders = [allp, [allp[1], allp[0]] + allp[2:], allp[::-1][1:] + [allp[-1]]]
+    parts = [P.rand(o, 90 + i, batch=2) for i, o in enumerate(orders)]
+    polys = [hx.DoubleCRT(P.g, o, 2, x) for o, x in zip(orders, parts)]
+    keep = own
+    norms = hx.scaleDownToSetMulti(polys, keep, 65537, norms=True)
+    for k, (o, x, d) in enumerate(zip(orders, parts, polys)):
+        idx = d.getIndexSet()
+        got = d.download()
+        for b in range(2):
+            want, wfd = P.o.scale_down(o, x[:, b], sp, 65537, want_fdelta=True)
+            kept = [i for i in o if i in keep]
+            for r, i in enumerate(idx):
+                assert np.array_equal(got[r, b], want[kept.index(i)])
+            assert norms[k, b] == pytest.approx(O.embedding_largest_coeff(P.o.m, wfd), rel=NORM_RTOL)
