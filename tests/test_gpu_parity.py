@@ -789,3 +789,58 @@ def test_scale_down_norms_when_parts_are_switched_one_by_one(hx):
             for r, i in enumerate(idx):
                 assert np.array_equal(got[r, b], want[kept.index(i)])
             assert norms[k, b] == pytest.approx(O.embedding_largest_coeff(P.o.m, wfd), rel=NORM_RTOL)
+
+
+# ---------------------------------------------------------------- edge cases and maximum sizes
+def test_empty_index_set_and_single_element_batch(hx):
+    """A DoubleCRT on the empty prime set (the reference constructs these, e.g.
+    src/DoubleCRT.cpp:506) and the degenerate calls on it."""
+    P = Pair(hx, 4096, primes_for(4096, 3))
+    e = hx.DoubleCRT(P.g, [], 1)
+    assert e.getIndexSet() == [] and e.download().shape[0] == 0
+    e.FFT().iFFT().Negate()
+    e += e
+    e *= e
+    e.automorph(3)
+    full = hx.DoubleCRT(P.g, [0, 1, 2], 1, P.rand([0, 1, 2], 1))
+    before = full.download()
+    e += full                              # empty set is a subset of every set
+    with pytest.raises(hx.HxError) as ei:
+        full += e                          # ... but not the other way round
+    assert ei.value.code == hx.HX_ERR_PRIMESET
+    assert np.array_equal(full.download(), before)
+    # nothing to drop / nothing to add
+    full.scaleDownToSet([0, 1, 2], 65537)
+    full.addPrimes([])
+    full.addPrimesAndScale([])
+    assert np.array_equal(full.download(), before) and full.getIndexSet() == [0, 1, 2]
+    with pytest.raises(hx.HxError):
+        full.scaleDownToSet([], 65537)     # "s and the index set must have some intersection"
+    with pytest.raises(hx.HxError):
+        hx.DoubleCRT(P.g, [0, 0], 1)       # repeated prime
+    with pytest.raises(hx.HxError):
+        hx.DoubleCRT(P.g, [7], 1)          # prime index out of range
+
+
+def test_multiply_relin_at_the_reference_benchmark_chain_size(hx):
+    """The reference's own bgv_basic parameter (bits=6400 at m=32768, benchmarks/bgv_basic.cpp:247):
+    L=107 ctxt primes, K=36 special primes, D=3 digits of 36/36/35 -- 143 rows, digits wider than
+    the 16-prime fast path (rns_extend_kernel<40>), batch 1.  Against the oracle, bit-exact."""
+    m, L, K = 32768, 107, 36
+    digits = [list(range(0, 36)), list(range(36, 72)), list(range(72, 107))]
+    P = Pair(hx, m, primes_for(m, L + K, 60))
+    own, sp = list(range(L)), list(range(L, L + K))
+    allp = own + sp
+    c0, c1, d0, d1 = (P.rand(own, s, 1) for s in (1, 2, 3, 4))
+    kb = np.stack([P.rand(allp, 20 + i)[:, 0] for i in range(3)])
+    ka = np.stack([P.rand(allp, 30 + i)[:, 0] for i in range(3)])
+    W = hx.KeySwitch(P.g, allp, kb, ka)
+    G = [hx.DoubleCRT(P.g, own, 1, x) for x in (c0, c1, d0, d1)]
+    o0, o1 = hx.multiplyBy(*G, W, digits)
+    w0, w1 = P.o.mul_relin(own, sp, digits, c0[:, 0], c1[:, 0], d0[:, 0], d1[:, 0], kb, ka)
+    assert o0.getIndexSet() == allp
+    assert np.array_equal(o0.download()[:, 0], w0)
+    assert np.array_equal(o1.download()[:, 0], w1)
+    # and the mod-down of the result by all 36 special primes at once (generic path, 36 sources)
+    o0.scaleDownToSet(own, 65537)
+    assert np.array_equal(o0.download()[:, 0], P.o.scale_down(allp, w0, sp, 65537))
