@@ -61,8 +61,8 @@ struct ModDownRow {
   TW inv;              // qd^-1 mod q_r
   TW cf;               // fused mod-up: F * qd^-1 mod q_r (multiplies c_r instead of inv)
   uint32_t out_row;
-  uint32_t mode;       // low 4 bits: 0/1: c_r <- c_r*cf - v (cf = inv or F*inv) ; 2: new row, c_r = 0
-                       // bit 4: |S| may reach q_r (huge ptxtSpace) and is reduced first
+  uint32_t mode;       // 0/1: c_r <- c_r*cf - v (cf = inv or F*inv) ; 2: new row, c_r = 0
+                       // (|S| < q_r is checked by the host before it takes the fused path)
 };
 struct ModDownApply {
   const uint64_t* xs;

@@ -877,8 +877,10 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
   if (!c)
     return fail(HX_ERR_INVALID, "null context");
   CHK(use(c));
-  if (q < 3 || q >= (1ull << 62) || !hxh::is_prime(q))
-    return fail(HX_ERR_INVALID, "q=%llu is not a prime below 2^62", (unsigned long long)q);
+  // 16q <= 2^64 is what the lazy butterflies of the row kernels need (ntt_core.h); the reference
+  // cannot make larger primes either (HELIB_SP_NBITS <= 60, src/PrimeGenerator.h:54-59)
+  if (q < 3 || q >= (1ull << 60) || !hxh::is_prime(q))
+    return fail(HX_ERR_INVALID, "q=%llu is not a prime below 2^60", (unsigned long long)q);
   if ((int)c->primes.size() >= c->primes_cap)
     return fail(HX_ERR_UNSUPPORTED, "too many primes");
   uint64_t e = c->pow2 ? c->m : ((c->m % 2 == 0) ? 2 * c->m : c->m);
@@ -1846,6 +1848,11 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     for (int i = 0; i < nadd && ok; i++)
       if (find_row(a->prime_idx, add_idx[i]) >= 0 || add_idx[i] == drop_idx[0])
         ok = false;
+    // the fused kernels take |S| <= ptxtSpace/2 + 1 as already reduced modulo every kept prime
+    for (int i = 0; i < nadd && ok; i++)
+      ok = ptxt / 2 + 2 < c->primes[add_idx[i]].q;
+    for (int r = 0; r < a->nrows() && ok; r++)
+      ok = a->prime_idx[r] == drop_idx[0] || ptxt / 2 + 2 < c->primes[a->prime_idx[r]].q;
     if (!ok)
       return HX_ERR_UNSUPPORTED;
     // make room and append the new (all-zero, never read) rows
@@ -1879,7 +1886,10 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     return fail(HX_ERR_UNSUPPORTED, "scaleDownToSet dropping more than 64 primes");
   size_t rw = a->row_words();
   int nd = (int)drop.size(), nk = (int)keep.size();
-  if (nd == 1 && c->pow2 && c->logn >= 13 && c->logn <= 15 && nk <= MAX_ROWS && ptxt < ((uint64_t)1 << 62)) {
+  bool small_S = true;  // |S| <= ptxtSpace/2 + 1 is a reduced residue of every kept prime
+  for (int pr : keep)
+    small_S = small_S && ptxt / 2 + 2 < c->primes[pr].q;
+  if (nd == 1 && c->pow2 && c->logn >= 13 && c->logn <= 15 && nk <= MAX_ROWS && ptxt < ((uint64_t)1 << 62) && small_S) {
     // fused path: [inverse NTT of the dropped row + delta preparation] then [forward NTT of
     // delta on every kept row, with  c <- (c - delta) / qd  in its store].  The last row takes
     // the dropped row's slot, so no compaction copy is needed.
@@ -1957,8 +1967,6 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
           hr[i].cf.wp = hxh::shoup(cf, q);
         }
       }
-      // bit 4: |S| <= ptxtSpace/2 + 1 may reach q and needs reducing
-      hr[i].mode |= (ptxt / 2 + 2 >= q) ? 16u : 0u;
       key.push_back(((uint64_t)pr << 28) | ((uint64_t)hr[i].out_row << 12) | hr[i].mode);
       i++;
     }

@@ -15,10 +15,21 @@
 // butterflies with psi powers merged into the twiddles (bit-reversed table),
 // natural in -> bit-reversed positions, un-reversed for free by the store
 // addressing of the last pass.  Inverse = the mirrored Gentleman-Sande network
-// with N^-1 folded into the last stage.  Harvey lazy butterflies keep values in
-// [0,4q) (forward) / [0,2q) (inverse); q < 2^62 is required (HElib: q < 2^60).
+// with N^-1 folded into the last stage.
+//
+// Lazy arithmetic of the row kernels (q < 2^60, i.e. 16q <= 2^64, is REQUIRED; HElib never
+// makes larger primes, src/macro.h:21): the twiddle product is Shoup's with an APPROXIMATE
+// high product (shoup4: the quotient estimate may be up to 2 short, result in [0,4q) for any
+// 64-bit input; 3 instead of 4 partial products and no carry chain), and the conditional
+// subtraction of the untouched butterfly arm is done only where a compile-time bound
+// (in units of q, tracked per stage / per element below) would pass 16q.  The small-ring
+// kernel keeps the classical Harvey butterflies ([0,4q) forward / [0,2q) inverse).
 #pragma once
 #include <stdint.h>
+#if defined(HX_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 #if defined(__HIPCC__)
 #define HXD __host__ __device__ __forceinline__
@@ -65,6 +76,101 @@ HXD uint64_t shoup_lazy(uint64_t x, TW t, uint64_t q)
 {
   uint64_t h = mulhi64(x, t.wp);
   return x * t.w - h * q;
+}
+
+HXD uint32_t mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(a, b);
+#else
+  return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+// Optional run-time check of the compile-time bounds (CPU replay only).
+#if defined(HX_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+#define HX_BOUND(x, B, q)                                                              \
+  do {                                                                                 \
+    if ((unsigned __int128)(x) >= (unsigned __int128)(B) * (q)) {                      \
+      std::fprintf(stderr, "bound violated at %s:%d (B=%d)\n", __FILE__, __LINE__, (int)(B)); \
+      std::abort();                                                                    \
+    }                                                                                  \
+  } while (0)
+#else
+#define HX_BOUND(x, B, q) ((void)0)
+#endif
+
+// per-row constants of the lazy scheme
+struct QC {
+  uint64_t q;
+  uint64_t nq;  // 2^64 - q
+  uint64_t q4, q8;
+  uint32_t mu32;  // floor(2^64 / q) when that fits 32 bits (q > 2^32), else 0
+};
+// mu64 = floor(2^64 / q) (PrimeDev::mu64 on the device)
+HXD QC make_qc(uint64_t q, uint64_t mu64)
+{
+  QC c;
+  c.q = q;
+  c.nq = 0 - q;
+  c.q4 = q << 2;
+  c.q8 = q << 3;
+  c.mu32 = (mu64 >> 32) ? 0u : (uint32_t)mu64;
+  return c;
+}
+// floor(2^64/q) = floor((2^64-1)/q) for odd q > 1
+HXD QC make_qc(uint64_t q) { return make_qc(q, ~(uint64_t)0 / q); }
+
+// y * w mod q as a value in [0, 4q), for ANY 64-bit y.  With wp = floor(w 2^64 / q) and
+// h = floor(y wp / 2^64), Shoup's r = y w - h q lies in [0, 2q).  Here h is replaced by
+//   h' = yh*ph + hi32(yh*pl) + hi32(yl*ph)      (the yl*pl term and the carries of the two
+// middle products' low halves are dropped), h - 2 <= h' <= h, so r' = r + (h-h') q < 4q; all of
+// it modulo 2^64, which is exact because r' < 2^62.  -h' q is accumulated as + h' * (2^64 - q)
+// so that the low 64 bits form one multiply-add chain.
+HXD uint64_t shoup4(uint64_t y, TW t, uint64_t nq)
+{
+  const uint32_t yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
+  const uint32_t pl = (uint32_t)t.wp, ph = (uint32_t)(t.wp >> 32);
+  const uint32_t wl = (uint32_t)t.w, wh = (uint32_t)(t.w >> 32);
+  const uint32_t nl = (uint32_t)nq, nh = (uint32_t)(nq >> 32);
+  const uint32_t a1 = mulhi32(yh, pl), b1 = mulhi32(yl, ph);
+  const uint64_t h = (uint64_t)yh * ph + a1 + b1;
+  const uint32_t hl = (uint32_t)h, hh = (uint32_t)(h >> 32);
+  const uint32_t t0 = yl * wh + yh * wl + hl * nh + hh * nl;
+  uint64_t acc = (uint64_t)yl * wl;
+  acc += (uint64_t)hl * nl;
+  const uint32_t al = (uint32_t)acc, ah = (uint32_t)(acc >> 32);
+  uint32_t rh;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // kept opaque: otherwise the high-word sum is re-associated into a 64-bit shift+add pair
+  asm("v_add_u32 %0, %1, %2" : "=v"(rh) : "v"(ah), "v"(t0));
+#else
+  rh = ah + t0;
+#endif
+  return ((uint64_t)rh << 32) | al;
+}
+// x in [0, 2m) -> [0, m)
+HXD uint64_t csub(uint64_t x, uint64_t m)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_CSUB_PLAIN)
+  // subtract, then select on the borrow: 4 instructions (the compiler's own form compares first: 5).
+  // gfx950 needs two wait states between a VALU write of VCC and a VALU read of it as carry-in or
+  // select mask; the compiler's hazard recogniser does not look inside inline asm, hence the s_nops.
+  const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32), ml = (uint32_t)m, mh = (uint32_t)(m >> 32);
+  uint32_t dl, dh;
+  asm("v_sub_co_u32 %0, vcc, %2, %4\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %1, vcc, %3, %5, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32 %0, %0, %2, vcc\n\t"
+      "v_cndmask_b32 %1, %1, %3, vcc"
+      : "=&v"(dl), "=&v"(dh)
+      : "v"(xl), "v"(xh), "v"(ml), "v"(mh)
+      : "vcc");
+  return ((uint64_t)dh << 32) | dl;
+#else
+  return x >= m ? x - m : x;
+#endif
 }
 
 HXD constexpr unsigned brev_bits(unsigned x, int bits)
@@ -142,6 +248,71 @@ HXD void gs_bfly_last(uint64_t& X, uint64_t& Y, TW tNinv, TW tS0Ninv, uint64_t q
   Y = shoup_lazy(x - y + q2, tS0Ninv, q);
 }
 
+// ---- bound-tracked butterflies of the row kernels (bounds in units of q) ----
+// forward (Cooley-Tukey):  X' = x + T, Y' = x + 4q - T with T = shoup4(Y) in [0,4q), so every
+// value grows by 4q per stage; x is brought from [0,16q) to [0,8q) first (CORR) exactly in the
+// stages where the bound would otherwise pass 16q.
+template <bool CORR>
+HXD void ct_bfly4(uint64_t& X, uint64_t& Y, TW t, const QC& c)
+{
+  uint64_t x = X;
+  if constexpr (CORR)
+    x = csub(x, c.q8);
+  const uint64_t v = shoup4(Y, t, c.nq);
+  X = x + v;
+  Y = x + c.q4 - v;
+}
+constexpr int fwd_bound_in(int bin, int sp)  // bound of the values entering stage sp of a pass
+{
+  int b = bin;
+  for (int s = 0; s < sp; s++) {
+    if (b + 4 > 16)
+      b = 8;
+    b += 4;
+  }
+  return b;
+}
+constexpr bool fwd_corr(int bin, int sp) { return fwd_bound_in(bin, sp) + 4 > 16; }
+
+// inverse (Gentleman-Sande):  X' = x + y, Y' = shoup4(x - y + B q) in [0,4q).  The bound of an
+// element after the ex-th executed stage of a pass (pair distance 2^ex) depends only on its
+// local index e: 4 if it left that stage on the multiplied arm (bit ex of e set), else twice
+// its previous bound, brought back to 8 by one conditional subtraction when that passes 8.
+// Both members of a pair have the same previous bound (they differ in bit ex only).
+constexpr int inv_bound_after(int bin, int ex, int e)
+{
+  if (ex < 0)
+    return bin;
+  if ((e >> ex) & 1)
+    return 4;
+  const int b = 2 * inv_bound_after(bin, ex - 1, e);
+  return b > 8 ? 8 : b;
+}
+template <int BPREV>  // common bound of x and y
+HXD void gs_bfly4(uint64_t& X, uint64_t& Y, TW t, const QC& c)
+{
+  static_assert(BPREV >= 1 && BPREV <= 8, "bound");
+  const uint64_t x = X, y = Y;
+  HX_BOUND(x, BPREV, c.q);
+  HX_BOUND(y, BPREV, c.q);
+  uint64_t s = x + y;
+  if constexpr (2 * BPREV > 8)
+    s = csub(s, c.q8);
+  X = s;
+  Y = shoup4(x + c.q8 - y, t, c.nq);  // one offset constant (8q >= any bound here) keeps q4 dead
+}
+// last inverse stage with N^-1 folded in: X = (x+y)*Ninv, Y = (x-y)*S0*Ninv, both in [0,4q)
+template <int BPREV>
+HXD void gs_bfly4_last(uint64_t& X, uint64_t& Y, TW tNinv, TW tS0Ninv, const QC& c)
+{
+  static_assert(BPREV >= 1 && BPREV <= 8, "bound");
+  const uint64_t x = X, y = Y;
+  HX_BOUND(x, BPREV, c.q);
+  HX_BOUND(y, BPREV, c.q);
+  X = shoup4(x + y, tNinv, c.nq);
+  Y = shoup4(x + c.q8 - y, tS0Ninv, c.nq);
+}
+
 // ---------------------------------------------------------------------
 // register passes.  v[32] is the thread's coefficient file.
 //
@@ -167,6 +338,14 @@ HXD void gs_bfly_last(uint64_t& X, uint64_t& Y, TW tNinv, TW tS0Ninv, uint64_t q
 #endif
 #ifndef HX_IO_GROUP
 #define HX_IO_GROUP 4
+#endif
+#ifndef HX_BF_FENCE
+#define HX_BF_FENCE 4
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define HX_SCHED_FENCE() ((void)0)
 #endif
 // The fused IO functors (mod-down prep/apply) do tens of instructions per element; without a
 // fence the scheduler interleaves many elements' temporaries while all 32 coefficients are still
@@ -228,9 +407,32 @@ HXD void static_for(F&& f)
 }
 
 // NGRUN: number of leading groups (flat order) to run per repetition; the inverse
-// pass A runs 2^S-2 groups here and finishes stage 0 with gs_bfly_last.
-template <int S, bool INV, int REP, int NGRUN, class Fetch>
-HXD void run_pass(uint64_t (&v)[32], uint64_t q, uint64_t q2, Fetch fetch)
+// pass A runs 2^S-2 groups here and finishes stage 0 with gs_bfly4_last.
+// BIN: bound (units of q) of every value entering the pass; pass_bound_out gives the bound
+// of every value leaving it (forward: exact schedule above; inverse: 8, or less for short runs).
+template <int S, bool INV, int NGRUN, int BIN>
+constexpr int pass_bound_out()
+{
+  if constexpr (!INV) {
+    static_assert(NGRUN == (1 << S) - 1, "forward passes run all stages");
+    return fwd_bound_in(BIN, S);
+  } else {
+    // executed stages: ex = 0 .. nst-1 (whole stages only)
+    int nst = 0, g = NGRUN;
+    for (int sp = S - 1; sp >= 0 && g >= (1 << sp); sp--) {
+      g -= (1 << sp);
+      nst++;
+    }
+    int b = 0;
+    for (int e = 0; e < (1 << S); e++) {
+      const int be = inv_bound_after(BIN, nst - 1, e);
+      b = be > b ? be : b;
+    }
+    return b;
+  }
+}
+template <int S, bool INV, int REP, int NGRUN, int BIN, class Fetch>
+HXD void run_pass(uint64_t (&v)[32], const QC& c, Fetch fetch)
 {
   constexpr int PF = HX_TW_PF;
   constexpr int TOT = REP * NGRUN;
@@ -249,15 +451,28 @@ HXD void run_pass(uint64_t (&v)[32], uint64_t q, uint64_t q2, Fetch fetch)
     const TW t = tq[i % PF];
     static_for<0, half>([&](auto J) {
       constexpr int j = decltype(J)::value;
-      if constexpr (INV)
-        gs_bfly(v[base + j], v[base + j + half], t, q, q2);
-      else
-        ct_bfly(v[base + j], v[base + j + half], t, q, q2);
+      if constexpr (INV) {
+        constexpr int ex = S - 1 - sp;  // executed-stage index, pair distance 2^ex
+        constexpr int bprev = inv_bound_after(BIN, ex - 1, k * 2 * half + j);
+        gs_bfly4<bprev>(v[base + j], v[base + j + half], t, c);
+      } else {
+        HX_BOUND(v[base + j], fwd_bound_in(BIN, sp), c.q);
+        ct_bfly4<fwd_corr(BIN, sp)>(v[base + j], v[base + j + half], t, c);
+      }
     });
     if constexpr (i + PF < TOT) {
       constexpr int n = i + PF;
       constexpr int nrep = n / NGRUN, nsp = grp_sp<S, INV>(n % NGRUN), nk = grp_k<S, INV>(n % NGRUN);
       tq[i % PF] = fetch(nrep, nsp, nk, (uint32_t)v[base]);
+    }
+    // keep the instruction scheduler from interleaving more than HX_BF_FENCE butterflies'
+    // worth of independent groups (the single-butterfly groups of the fine stages otherwise
+    // pile up a dozen twiddle loads and partial products, and the register file spills)
+    if constexpr (HX_BF_FENCE > 0) {
+      if constexpr (half >= HX_BF_FENCE)
+        HX_SCHED_FENCE();
+      else if constexpr ((k + 1) % (HX_BF_FENCE / half) == 0)
+        HX_SCHED_FENCE();
     }
   });
 }
@@ -294,6 +509,15 @@ HXD unsigned bc_addr_C(unsigned tid, int i)  // i = gi*GC + e'
   return (tid + (unsigned)T * gi) + 1024u * ep;
 }
 
+// LDS read that the compiler may not fuse with a neighbour into a ds_read2: the two results of
+// a fused read land in one register pair although they are halves of two DIFFERENT 64-bit
+// coefficients, and un-pairing them costs a v_mov per word plus the registers to hold both
+// copies (the inverse kernels spilled on exactly that).
+#ifndef HX_LDS_RD_PLAIN
+HXD uint32_t lds_rd(const uint32_t* lds, unsigned a) { return *(const volatile uint32_t*)(lds + a); }
+#else
+HXD uint32_t lds_rd(const uint32_t* lds, unsigned a) { return lds[a]; }
+#endif
 HXD uint32_t half_of(uint64_t x, int half) { return half ? (uint32_t)(x >> 32) : (uint32_t)x; }
 HXD void set_half(uint64_t& x, int half, uint32_t w)
 {
@@ -328,6 +552,8 @@ HXD unsigned eval_const(int i)
 
 // Plain-pointer row accessor (CPU replay; also valid on the device).
 struct PtrIO {
+  static constexpr int LOAD_BOUND = 1;
+  static constexpr bool LAZY_STORE = false;
   const uint64_t* in;
   uint64_t* out;
   HXD uint64_t load(unsigned tid, unsigned c) const { return in[tid + c]; }
@@ -344,6 +570,38 @@ HXD uint64_t norm2(uint64_t x, uint64_t q)  // [0,2q) -> [0,q)
 {
   return (x >= q) ? x - q : x;
 }
+// [0, B q) -> [0, q) for a compile-time B <= 16.
+// EST (requires c.mu32 != 0, i.e. q > 2^32): quotient estimate from the 32-bit reciprocal,
+// e = floor(x mu32 / 2^64) is floor(x/q) or one less (x mu32 < 2^96 is formed exactly below;
+// 0 <= x/q - x mu32/2^64 < x/2^64 <= 1), so x - e q is in [0, 2q): two multiplications and ONE
+// conditional subtraction instead of four.  Callers branch on c.mu32 once per phase, outside
+// their element loops (a branch per element fragments the schedule and spills).
+template <int B, bool EST = false>
+HXD uint64_t norm_from(uint64_t x, const QC& c)
+{
+  static_assert(B >= 1 && B <= 16, "bound");
+  HX_BOUND(x, B, c.q);
+  if constexpr (EST && B > 4) {
+    const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    const uint64_t t = (uint64_t)xh * c.mu32 + mulhi32(xl, c.mu32);
+    const uint32_t e = (uint32_t)(t >> 32);
+    const uint32_t nl = (uint32_t)c.nq, nh = (uint32_t)(c.nq >> 32);
+    uint64_t r = (uint64_t)e * nl + x;  // x + e (2^64 - q) mod 2^64
+    r += (uint64_t)(e * nh) << 32;
+    HX_BOUND(r, 2, c.q);
+    return csub(r, c.q);
+  } else {
+    if constexpr (B > 8)
+      x = csub(x, c.q8);
+    if constexpr (B > 4)
+      x = csub(x, c.q4);
+    if constexpr (B > 2)
+      x = csub(x, c.q + c.q);
+    if constexpr (B > 1)
+      x = csub(x, c.q);
+    return x;
+  }
+}
 
 // ---------------------------------------------------------------------
 // The transform as barrier-separated phases.  The HIP kernel runs
@@ -356,19 +614,29 @@ struct RowNTT {
   using G = Geo<LOGN>;
   static constexpr int NPHASE = 8;
 
+  // bounds (units of q) of the register file between the inverse passes (inputs canonical)
+  static constexpr int IC_ = pass_bound_out<G::LC, true, G::GC - 1, 1>();  // after inverse pass C
+  static constexpr int IB = pass_bound_out<5, true, 31, IC_>();
+  static_assert(IC_ <= 8 && IB <= 8, "lazy bounds");
+
   // -------- forward: coefficients (natural) -> evaluations (natural) -----
   template <int PH, class IO, class TWS>
   static HXD void fwd(unsigned tid, uint64_t (&v)[32], uint32_t (&nl)[32], uint32_t* lds,
-                      const IO& io, const TWS& tw, uint64_t q)
+                      const IO& io, const TWS& tw, const QC& c)
   {
-    const uint64_t q2 = q + q;
+    // bounds between the forward passes; the IO functor states the bound of what it loads
+    // (IO::LOAD_BOUND, 1 = canonical) and whether its store takes the lazy value (IO::LAZY_STORE)
+    constexpr int FA = pass_bound_out<5, false, 31, IO::LOAD_BOUND>();
+    constexpr int FB = pass_bound_out<5, false, 31, FA>();
+    constexpr int FC = pass_bound_out<G::LC, false, G::GC - 1, FB>();
+    static_assert(IO::LOAD_BOUND <= 12 && FA <= 16 && FB <= 16 && FC <= 16, "lazy bounds");
     if constexpr (PH == 0) {
 #pragma unroll
       for (int e = 0; e < 32; e++) {
         v[e] = io.load(tid, coef_const<LOGN>(e));
         HX_IO_FENCE(e);
       }
-      run_pass<5, false, 1, 31>(v, q, q2, [&](int, int sp, int k, uint32_t) {
+      run_pass<5, false, 1, 31, IO::LOAD_BOUND>(v, c, [&](int, int sp, int k, uint32_t) {
         return tw_uni(tw, (unsigned)((1 << sp) - 1 + k));  // uniform: scalar loads
       });
 #pragma unroll
@@ -377,7 +645,7 @@ struct RowNTT {
     } else if constexpr (PH == 1) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
-        nl[e] = lds[ab_addr_B<LOGN>(tid, e)];
+        nl[e] = lds_rd(lds, ab_addr_B<LOGN>(tid, e));
     } else if constexpr (PH == 2) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
@@ -385,8 +653,8 @@ struct RowNTT {
     } else if constexpr (PH == 3) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
-        v[e] = ((uint64_t)lds[ab_addr_B<LOGN>(tid, e)] << 32) | nl[e];
-      run_pass<5, false, 1, 31>(v, q, q2, [&](int, int sp, int k, uint32_t dep) {
+        v[e] = ((uint64_t)lds_rd(lds, ab_addr_B<LOGN>(tid, e)) << 32) | nl[e];
+      run_pass<5, false, 1, 31, FA>(v, c, [&](int, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWB, tid & 31u, ((1u << sp) - 1u + (unsigned)k) * 32u, dep);
       });
     } else if constexpr (PH == 4) {
@@ -396,7 +664,7 @@ struct RowNTT {
     } else if constexpr (PH == 5) {
 #pragma unroll
       for (int i = 0; i < 32; i++)
-        nl[i] = lds[bc_addr_C<LOGN>(tid, i)];
+        nl[i] = lds_rd(lds, bc_addr_C<LOGN>(tid, i));
     } else if constexpr (PH == 6) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
@@ -404,14 +672,29 @@ struct RowNTT {
     } else if constexpr (PH == 7) {
 #pragma unroll
       for (int i = 0; i < 32; i++)
-        v[i] = ((uint64_t)lds[bc_addr_C<LOGN>(tid, i)] << 32) | nl[i];
-      run_pass<G::LC, false, G::NGC, G::GC - 1>(v, q, q2, [&](int gi, int sp, int k, uint32_t dep) {
+        v[i] = ((uint64_t)lds_rd(lds, bc_addr_C<LOGN>(tid, i)) << 32) | nl[i];
+      run_pass<G::LC, false, G::NGC, G::GC - 1, FB>(v, c, [&](int gi, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWC, tid, ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi), dep);
       });
+      // (uniform branches are taken once here / inside store_all, never per element: a branch
+      // per element fragments the schedule into 32 blocks and the register file spills)
+      if constexpr (IO::LAZY_STORE) {
+        if (c.mu32)
+          io.template store_all<LOGN, FC, true>(tid, v, c);
+        else
+          io.template store_all<LOGN, FC, false>(tid, v, c);
+      } else if (c.mu32) {
 #pragma unroll
-      for (int i = 0; i < 32; i++) {
-        io.store(tid, eval_const<LOGN>(i), norm4(v[i], q, q2));
-        HX_IO_FENCE(i);
+        for (int i = 0; i < 32; i++) {
+          io.store(tid, eval_const<LOGN>(i), norm_from<FC, true>(v[i], c));
+          HX_IO_FENCE(i);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+          io.store(tid, eval_const<LOGN>(i), norm_from<FC, false>(v[i], c));
+          HX_IO_FENCE(i);
+        }
       }
     }
   }
@@ -419,14 +702,13 @@ struct RowNTT {
   // -------- inverse: evaluations (natural) -> coefficients (natural) -----
   template <int PH, class IO, class TWS>
   static HXD void inv(unsigned tid, uint64_t (&v)[32], uint32_t (&nl)[32], uint32_t* lds,
-                      const IO& io, const TWS& tw, uint64_t q)
+                      const IO& io, const TWS& tw, const QC& c)
   {
-    const uint64_t q2 = q + q;
     if constexpr (PH == 0) {
 #pragma unroll
       for (int i = 0; i < 32; i++)
         v[i] = io.load(tid, eval_const<LOGN>(i));
-      run_pass<G::LC, true, G::NGC, G::GC - 1>(v, q, q2, [&](int gi, int sp, int k, uint32_t dep) {
+      run_pass<G::LC, true, G::NGC, G::GC - 1, 1>(v, c, [&](int gi, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWC, tid, ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi), dep);
       });
 #pragma unroll
@@ -435,7 +717,7 @@ struct RowNTT {
     } else if constexpr (PH == 1) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
-        nl[e] = lds[bc_addr_B<LOGN>(tid, e)];
+        nl[e] = lds_rd(lds, bc_addr_B<LOGN>(tid, e));
     } else if constexpr (PH == 2) {
 #pragma unroll
       for (int i = 0; i < 32; i++)
@@ -443,8 +725,8 @@ struct RowNTT {
     } else if constexpr (PH == 3) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
-        v[e] = ((uint64_t)lds[bc_addr_B<LOGN>(tid, e)] << 32) | nl[e];
-      run_pass<5, true, 1, 31>(v, q, q2, [&](int, int sp, int k, uint32_t dep) {
+        v[e] = ((uint64_t)lds_rd(lds, bc_addr_B<LOGN>(tid, e)) << 32) | nl[e];
+      run_pass<5, true, 1, 31, IC_>(v, c, [&](int, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWB, tid & 31u, ((1u << sp) - 1u + (unsigned)k) * 32u, dep);
       });
     } else if constexpr (PH == 4) {
@@ -454,7 +736,7 @@ struct RowNTT {
     } else if constexpr (PH == 5) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
-        nl[e] = lds[ab_addr_A<LOGN>(tid, e)];
+        nl[e] = lds_rd(lds, ab_addr_A<LOGN>(tid, e));
     } else if constexpr (PH == 6) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
@@ -462,22 +744,25 @@ struct RowNTT {
     } else if constexpr (PH == 7) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
-        v[e] = ((uint64_t)lds[ab_addr_A<LOGN>(tid, e)] << 32) | nl[e];
+        v[e] = ((uint64_t)lds_rd(lds, ab_addr_A<LOGN>(tid, e)) << 32) | nl[e];
       // stages 4..1 (30 groups), then stage 0 with N^-1 folded in:
       // slot 0 = S0*N^-1, slot 31 = N^-1
-      run_pass<5, true, 1, 30>(v, q, q2, [&](int, int sp, int k, uint32_t) {
+      run_pass<5, true, 1, 30, IB>(v, c, [&](int, int sp, int k, uint32_t) {
         return tw_uni(tw, (unsigned)((1 << sp) - 1 + k));
       });
       {
         // (the IO functor may substitute its own pair: a constant factor folded into N^-1)
         const TW tS = io.last_tw(tw_uni(tw, 0), 0), tN = io.last_tw(tw_uni(tw, 31), 1);
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-          gs_bfly_last(v[j], v[j + 16], tN, tS, q, q2);
+        static_for<0, 16>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          gs_bfly4_last<inv_bound_after(IB, 3, j)>(v[j], v[j + 16], tN, tS, c);
+          if constexpr (HX_BF_FENCE > 0 && j % 2 == 1)
+            HX_SCHED_FENCE();
+        });
       }
 #pragma unroll
       for (int e = 0; e < 32; e++) {
-        io.store(tid, coef_const<LOGN>(e), norm2(v[e], q));
+        io.store(tid, coef_const<LOGN>(e), norm_from<4>(v[e], c));
         HX_IO_FENCE(e);
       }
     }

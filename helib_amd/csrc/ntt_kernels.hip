@@ -65,6 +65,8 @@ __device__ __forceinline__ TW tw_vec(const BufTw& t, unsigned base, unsigned lan
 }
 
 struct BufIO {
+  static constexpr int LOAD_BOUND = 1;
+  static constexpr bool LAZY_STORE = false;
   v4i32 rin, rout;
   __device__ BufIO(const uint64_t* in_row, uint64_t* out_row, unsigned bytes)
       : rin(make_rsrc(in_row, bytes)), rout(make_rsrc(out_row, bytes))
@@ -90,6 +92,8 @@ struct BufIO {
 // The delta preparation S(x) is a separate element-wise kernel (below): inside this store its
 // ~250 instructions per element and dozen uniform 64-bit constants pushed the kernel into scratch.
 struct InvPrepIO {
+  static constexpr int LOAD_BOUND = 1;
+  static constexpr bool LAZY_STORE = false;
   v4i32 rin, rx;
   TW upS, upN;
   uint32_t has_up;
@@ -146,15 +150,19 @@ moddown_S_kernel(ModDownPrep P, size_t n)
 //                                                    and x < 2^64 needs no reduction before Shoup)
 //   store = c_r*cf - NTT(load)   with cf = inv (plain scale-down) or F*inv (mod-up folded in)
 struct ModDownIO {
+  // the load is x*inv (shoup4: [0,4q)) plus a residue of -S in [0,q]; the store takes the lazy
+  // transform output and normalises once, after the subtraction
+  static constexpr int LOAD_BOUND = 5;
+  static constexpr bool LAZY_STORE = true;
   v4i32 rx, rS, rc, ro;
   TW inv, cf;
-  uint32_t mode, sred;
-  uint64_t q, mu64;
+  uint32_t mode;
+  uint64_t q;
   __device__ ModDownIO(const ModDownApply& A, const ModDownRow& R, size_t boff, const uint64_t* c_row,
-                       uint64_t* o_row, unsigned bytes, uint64_t q_, uint64_t mu64_)
+                       uint64_t* o_row, unsigned bytes, uint64_t q_)
       : rx(make_rsrc(A.xs + boff, bytes)), rS(make_rsrc((const uint64_t*)(A.S + boff), bytes)),
         rc(make_rsrc(c_row, bytes)), ro(make_rsrc(o_row, bytes)), inv(R.inv), cf(R.cf),
-        mode(R.mode & 15u), sred(R.mode >> 4), q(q_), mu64(mu64_)
+        mode(R.mode), q(q_)
   {
   }
   __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
@@ -163,29 +171,40 @@ struct ModDownIO {
     v2i32 b = hx_buffer_load_v2(rS, (int)(tid * 8u), (int)(c * 8u), 0);
     const uint64_t x = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
     const int64_t S = (int64_t)(((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x);
-    uint64_t r = mul_shoup(x, inv.w, inv.wp, q);
-    if (S != 0) {
-      uint64_t mag = (uint64_t)(S < 0 ? -S : S);  // <= ptxtSpace/2 + 1
-      if (sred)
-        mag = red64(mag, q, mu64);
-      r = S > 0 ? sub_mod(r, mag, q) : add_mod(r, mag, q);
-    }
-    return r;
+    const uint64_t r = shoup4(x, inv, 0 - q);            // [0,4q)
+    const uint64_t mag = (uint64_t)(S < 0 ? -S : S);     // <= ptxtSpace/2 + 1 < q (host-checked)
+    return r + (S > 0 ? q - mag : mag);                  // -S mod q as a value in [0,q]
   }
-  __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t v) const
+  // the whole store loop of the forward transform (v[i] in [0, B q), evaluation order)
+  template <int LOGN, int B, bool EST>
+  __device__ __forceinline__ void store_all(unsigned tid, uint64_t (&v)[32], const QC& qc) const
   {
-    uint64_t o;
-    if (mode == 2) {  // row added by the fused mod-up: c_r = 0
-      o = neg_mod(v, q);
+    if (mode == 2) {  // rows added by the fused mod-up: c_r = 0, output -NTT(.)
+#pragma unroll
+      for (int i = 0; i < 32; i++) {
+        put(tid, eval_const<LOGN>(i), neg_mod(norm_from<B, EST>(v[i], qc), q));
+        HX_IO_FENCE(i);
+      }
     } else {
-      // the address is made to depend on v: otherwise all 32 loads of c_r are hoisted above
-      // the last register pass (64 more live VGPRs -> scratch spills)
-      int voff = (int)(tid * 8u);
-      asm volatile("" : "+v"(voff) : "v"((uint32_t)v));
-      v2i32 a = hx_buffer_load_v2(rc, voff, (int)(c * 8u), 0);
-      const uint64_t cc = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
-      o = sub_mod(mul_shoup(cc, cf.w, cf.wp, q), v, q);
+#pragma unroll
+      for (int i = 0; i < 32; i++) {
+        // the address is made to depend on v: otherwise all 32 loads of c_r are hoisted above
+        // the last register pass (64 more live VGPRs -> scratch spills)
+        int voff = (int)(tid * 8u);
+        asm volatile("" : "+v"(voff) : "v"((uint32_t)v[i]));
+        v2i32 a = hx_buffer_load_v2(rc, voff, (int)(eval_const<LOGN>(i) * 8u), 0);
+        const uint64_t cc = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
+        uint64_t x = v[i];
+        if constexpr (B > 8)
+          x = csub(x, qc.q8);                            // [0,8q)
+        // c_r*cf - x as a value in (0,12q), normalised once
+        put(tid, eval_const<LOGN>(i), norm_from<12, EST>(shoup4(cc, cf, qc.nq) + qc.q8 - x, qc));
+        HX_IO_FENCE(i);
+      }
     }
+  }
+  __device__ __forceinline__ void put(unsigned tid, unsigned c, uint64_t o) const
+  {
     v2i32 d;
     d.x = (int)(uint32_t)o;
     d.y = (int)(uint32_t)(o >> 32);
@@ -253,8 +272,9 @@ __device__ __forceinline__ unsigned uniform_u16(const uint16_t* tab, unsigned i)
 }
 
 template <int LOGN, bool INV, class IO>
-__device__ __forceinline__ void ntt_body(uint32_t* lds, const IO& io, const TW* tw_ptr, uint64_t q)
+__device__ __forceinline__ void ntt_body(uint32_t* lds, const IO& io, const TW* tw_ptr, const PrimeDev* pd)
 {
+  const QC q = make_qc(pd->q, pd->mu64);  // (the phase functions' last argument)
   using R = RowNTT<LOGN>;
 #ifdef HX_TW_BUF  // experiment: measured register allocation gets worse with it (scratch 3-5x)
   const BufTw tw(tw_ptr);
@@ -312,7 +332,7 @@ ntt_moddown_prep_kernel(PolyBases polys, int row, int prime, int batch, ModDownP
   const uint64_t* in = poly_base(polys, (unsigned)pi);
   const InvPrepIO io(in + ((size_t)row * batch + b) * N, P, ((size_t)pi * batch + b) * N,
                      (unsigned)N * 8u);
-  ntt_body<LOGN, true>(lds, io, tw_arena + pd->tw_inv_off, pd->q);
+  ntt_body<LOGN, true>(lds, io, tw_arena + pd->tw_inv_off, pd);
 }
 // ... forward transform of delta on every kept row, subtract + divide in the store
 template <int LOGN>
@@ -353,8 +373,8 @@ ntt_moddown_apply_kernel(PolyBases polys, NttRows rows, int nkeep, int batch, Mo
   uint64_t* data = poly_base(polys, pi);
   const ModDownIO io(A, R, ((size_t)pi * batch + b) * N,
                      data + ((size_t)uniform_u16(rows.row, ri) * batch + b) * N,
-                     data + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd->q, pd->mu64);
-  ntt_body<LOGN, false>(lds, io, tw_arena + pd->tw_fwd_off, pd->q);
+                     data + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd->q);
+  ntt_body<LOGN, false>(lds, io, tw_arena + pd->tw_fwd_off, pd);
 }
 
 template <int LOGN, bool INV>
@@ -370,14 +390,13 @@ ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
   const PrimeDev* pd = primes + uniform_u16(rows.prime, ri);
   const size_t roff = ((size_t)row * batch + b) * (size_t)Geo<LOGN>::N;
   const TW* tw = tw_arena + (INV ? pd->tw_inv_off : pd->tw_fwd_off);
-  const uint64_t q = pd->q;
 
 #ifdef HX_NTT_PTRIO
   const PtrIO io{in + roff, out + roff};
 #else
   const BufIO io(in + roff, out + roff, (unsigned)Geo<LOGN>::N * 8u);
 #endif
-  ntt_body<LOGN, INV>(lds, io, tw, q);
+  ntt_body<LOGN, INV>(lds, io, tw, pd);
 }
 
 template <int LOGN, bool INV>

@@ -34,9 +34,9 @@ static void run_phase(bool inverse, std::vector<uint64_t>& V, std::vector<uint32
     uint32_t(&nl)[32] = *reinterpret_cast<uint32_t(*)[32]>(&NL[tid * 32]);
     hx::PtrIO io{in, out};
     if (inverse)
-      R::template inv<PH>(tid, v, nl, lds.data(), io, tw, q);
+      R::template inv<PH>(tid, v, nl, lds.data(), io, tw, hx::make_qc(q));
     else
-      R::template fwd<PH>(tid, v, nl, lds.data(), io, tw, q);
+      R::template fwd<PH>(tid, v, nl, lds.data(), io, tw, hx::make_qc(q));
   }
 }
 

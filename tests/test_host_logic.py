@@ -22,20 +22,25 @@ def replay():
     so = os.path.join(ROOT, "tests", "cpp", "libntt_replay.so")
     hdr = os.path.join(ROOT, "helib_amd", "csrc", "ntt_core.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+        # HX_CHECK_BOUNDS: every compile-time lazy bound of the kernel (values < B*q before each
+        # butterfly / normalisation) is also asserted at run time in the replay
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-DHX_CHECK_BOUNDS", "-shared", "-fPIC", "-o", so, src])
     L = C.CDLL(so)
     L.ntt_replay.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     return L
 
 
 @pytest.mark.parametrize("logn", [13, 14, 15])
-@pytest.mark.parametrize("bits", [60, 49])
+@pytest.mark.parametrize("bits", [60, 49, 36, 31])
 def test_ntt_kernel_phases_replayed_on_cpu(replay, logn, bits):
+    # 60: the largest primes the lazy scheme admits (16q <= 2^64); 31: q < 2^32, the normaliser's
+    # conditional-subtraction chain instead of the reciprocal estimate
     N = 1 << logn
     m = 2 * N
     q = O.PrimeGen(bits, m).next()
     cm = O.Cmod(m, q)
-    for seed, x in ((1, O.fill_uniform(N, q, 5)), (2, np.full(N, q - 1, dtype=np.uint64))):
+    for seed, x in ((1, O.fill_uniform(N, q, 5)), (2, np.full(N, q - 1, dtype=np.uint64)),
+                    (3, np.zeros(N, dtype=np.uint64))):
         y = cm.fft(x)
         out = np.zeros(N, dtype=np.uint64)
         assert replay.ntt_replay(logn, 0, q, cm.root, x.ctypes.data, out.ctypes.data) == 0
