@@ -294,7 +294,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="independent ciphertext pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=128, help="independent ciphertext pairs per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=6, help="multiplies timed on the CPU (0 = skip)")
     ap.add_argument("--ntt-iters", type=int, default=20)
     ap.add_argument("--workload", default="bgv32768", choices=["bgv32768", "bgv32768_fixed", "ckks65536"])

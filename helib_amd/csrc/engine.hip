@@ -1423,11 +1423,16 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   size_t o_pmod = take(nt), o_W = take((size_t)2 * nt * n), o_upd = take((size_t)2 * nt);
   size_t o_Wp = take((size_t)2 * n);
   size_t o_tlazy = take((nt + 1) / 2);
+  size_t o_srcrq = take(n), o_tmu63 = take(nt);
   std::vector<uint64_t> h(off, 0);
   hxh::BigU P(1);
   for (int k = 0; k < n; k++) {
     h[o_srcq + k] = p[k];
     h[o_srcmu + k] = (uint64_t)((((hxh::u128)1) << 64) / p[k]);
+    {
+      const double rq = 1.0 / (double)p[k];
+      memcpy(&h[o_srcrq + k], &rq, 8);
+    }
     for (int l = 0; l < k; l++) {
       uint64_t inv = hxh::invmod(p[l] % p[k], p[k]);
       if (inv == 0)
@@ -1463,6 +1468,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     int kb = hxh::bitlen(q);
     tk[t] = (uint32_t)kb;
     h[o_tmu + t] = (uint64_t)((((hxh::u128)1) << (2 * kb)) / q);
+    h[o_tmu63 + t] = (uint64_t)((((hxh::u128)1) << (63 + kb)) / q);  // < 2^64: q > 2^(kb-1)
     uint64_t run = 1 % q;
     for (int k = 0; k < n; k++) {
       h[o_W + 2 * ((size_t)t * n + k)] = run;
@@ -1516,6 +1522,14 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   pl->dev.Wp = reinterpret_cast<const TW*>(d + o_Wp);
   pl->dev.tgt_lazy = reinterpret_cast<const uint32_t*>(d + o_tlazy);
   pl->dev.garner_cs = (max_src / 2 < min_src && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;  // a_l < q_l <= max < 2*min <= 2*p_k
+  pl->dev.src_rq = reinterpret_cast<const double*>(d + o_srcrq);
+  pl->dev.tgt_mu63 = d + o_tmu63;
+  {
+    bool ok = pl->dev.garner_cs && n <= 8 && (min_src >> 32) != 0 && !getenv("HX_NO_FAST_BREAK");
+    for (int t = 0; t < nt && ok; t++)
+      ok = (c->primes[tgt[t]].q >> 32) != 0;
+    pl->dev.fast_ok = ok ? 1u : 0u;
+  }
   c->plans[key] = pl;
   *out = pl;
   return HX_OK;
@@ -2288,7 +2302,18 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
   }
   dim3 grid((unsigned)((rw + hx::BRK_THREADS - 1) / hx::BRK_THREADS)), block(hx::BRK_THREADS);
   size_t lds = (size_t)L * hx::BRK_THREADS * 8;
-  if (nmax <= 8) {
+  bool fast = true;
+  for (int d = 0; d < ndig; d++)
+    fast = fast && A.plan[d].fast_ok;
+  if (fast) {
+    static bool attrf = false;
+    if (!attrf) {
+      HIPCHK(hipFuncSetAttribute((const void*)hx::break_digits_fast_kernel,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
+      attrf = true;
+    }
+    hipLaunchKernelGGL(hx::break_digits_fast_kernel, grid, block, lds, c->stream, A, rw);
+  } else if (nmax <= 8) {
     static bool attr8 = false;
     if (!attr8) {
       HIPCHK(hipFuncSetAttribute((const void*)hx::break_digits_kernel<8>,

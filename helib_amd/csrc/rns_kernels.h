@@ -334,6 +334,10 @@ struct ExtPlanDev {
                              // "a_l mod p_k" is one conditional subtraction
   const uint32_t* tgt_lazy;  // [nt] 1: sum_k q_k <= 8*q_t, so the target residue can be taken from
                              // the 128-bit sum of the n products with ONE Barrett reduction
+  const double* src_rq;      // [n] 1.0 / q_k (host-rounded), for the value/P fraction
+  const uint64_t* tgt_mu63;  // [nt] floor(2^(63+k) / q_t), k = bitlen(q_t)  (red128_q8)
+  uint32_t fast_ok;          // break_digits_fast_kernel's preconditions hold for this plan:
+                             // garner_cs, every prime > 2^32 (32-bit reciprocals), n <= 8
 };
 
 // sum_k a_k * W[k]  mod q for a target whose plan says the lazy 128-bit form is exact
@@ -584,6 +588,160 @@ break_digits_kernel(BreakArgs A, size_t row_words)
         uint64_t* u = &xs[r * BRK_THREADS + tid];
         *u = mul_shoup(sub_mod(*u, v, q), pinv.w, pinv.wp, q);
       }
+    }
+  }
+}
+
+// =====================================================================
+// breakIntoDigits, fast form (same contract as break_digits_kernel; chosen by the host when every
+// plan has fast_ok).  Differences, all exact:
+//   * the digit size n is a compile-time constant per digit (switch on n), so the Garner chain
+//     and the inner products are straight-line code without per-element branches;
+//   * Garner steps and the later-digit updates use shoup4 (approximate high product, [0,4q)) on
+//     lazy values; each mixed-radix digit is normalised once;
+//   * a target whose plan allows the wide sum (tgt_lazy) accumulates sum_k a_k W_k in three
+//     64-bit accumulators over 30-bit limbs -- a = a1 2^30 + a0, W = w1 2^30 + w0 (both < 2^60):
+//     acc00 += a0 w0, acc01 += a0 w1 + a1 w0, acc11 += a1 w1, i.e. four v_mad_u64_u32 per term
+//     and no carry handling (16 products of < 2^60 fit 64 bits; the W limbs are split on the
+//     scalar unit) -- followed by ONE Barrett reduction of acc00 + 2^30 acc01 + 2^60 acc11;
+//     other targets sum shoup4 products and normalise once with the 32-bit reciprocal;
+//   * the centring correction "- P mod t" enters the sum as + (t - P mod t) before the reduction.
+// =====================================================================
+// S mod q for S < 8 q^2 (q < 2^60, k = bitlen(q)), mu63 = floor(2^(63+k)/q) < 2^64.
+// xt = floor(S / 2^(k-1)) < 2^(k+4) fits 64 bits and xt mu63 / 2^64 > S/q - 2 (S/2^(k+63) < 1 and
+// 2^(k-1)/q < 1); the approximate high product loses at most 2 more and the floor 1, so the
+// quotient estimate is at most 5 short: r = S - qh q (mod 2^64) lies in [0, 6q) and three
+// conditional subtractions finish.  7 word multiplications instead of the 11 of the classical form.
+__device__ __forceinline__ uint64_t red128_q8(u128 S, uint64_t q, uint64_t mu63, uint32_t k)
+{
+  const uint64_t xt = (uint64_t)(S >> (k - 1));
+  const uint32_t xl = (uint32_t)xt, xh = (uint32_t)(xt >> 32);
+  const uint32_t ml = (uint32_t)mu63, mh = (uint32_t)(mu63 >> 32);
+  const uint64_t qh = (uint64_t)xh * mh + __umulhi(xh, ml) + __umulhi(xl, mh);
+  uint64_t r = (uint64_t)S - qh * q;
+  r = csub(r, q << 2);
+  r = csub(r, q << 1);
+  return csub(r, q);
+}
+
+__device__ __forceinline__ uint64_t norm_any(uint64_t x, uint64_t q, uint32_t mu32)
+{
+  // any 64-bit x -> [0,q), q > 2^32: e = floor(x mu32 / 2^64) is floor(x/q) or one less
+  const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+  const uint64_t t = (uint64_t)xh * mu32 + __umulhi(xl, mu32);
+  const uint32_t e = (uint32_t)(t >> 32);
+  const uint64_t nq = 0 - q;
+  uint64_t r = (uint64_t)e * (uint32_t)nq + x;
+  r += (uint64_t)(e * (uint32_t)(nq >> 32)) << 32;
+  return csub(r, q);
+}
+
+template <int N>
+__device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* xs, unsigned tid, int off, int L,
+                                                 uint64_t* dd, size_t row_words, double* frac_out)
+{
+  uint64_t a[N];
+  // ---- Garner mixed-radix digits (src/DoubleCRT.cpp:1031-1100 computes the same value by CRT) ----
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    uint64_t x = xs[(off + k) * BRK_THREADS + tid];  // [0,4 p_k): later digits' rows are updated lazily
+    const uint64_t pk = P.src_q[k], npk = 0 - pk, pk2 = pk + pk;
+#pragma unroll
+    for (int l = 0; l < k; l++)
+      x = shoup4(x + pk2 - a[l], P.ginv[k * N + l], npk);  // a_l < p_l < 2 p_k (garner_cs)
+    x = csub(x, pk2);
+    a[k] = csub(x, pk);
+  }
+  // ---- centring: v > (P-1)/2, top digit first ----
+  int cmp = 0;
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) {
+    const uint64_t h = P.half[k];
+    cmp = cmp != 0 ? cmp : (a[k] > h ? 1 : (a[k] < h ? -1 : 0));
+  }
+  const bool neg = cmp > 0;
+  if (frac_out) {
+    double f = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      f = ((double)a[k] + f) * P.src_rq[k];
+    *frac_out = f - (neg ? 1.0 : 0.0);
+  }
+  uint32_t a0[N], a1[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    a0[k] = (uint32_t)a[k] & 0x3fffffffu;
+    a1[k] = (uint32_t)(a[k] >> 30);
+  }
+  // ---- residues modulo every other prime ----
+  for (int t = 0; t < P.nt; t++) {
+    const int r = t < off ? t : t + N;  // row of target t in the all-rows order
+    const uint64_t q = P.tgt_q[t];
+    const TW* Wt = P.W + (size_t)t * N;
+    const uint64_t negfix = neg ? q - P.pmod[t] : 0;
+    uint64_t v;
+    if (P.tgt_lazy[t]) {
+      uint64_t c00 = negfix, c01 = 0, c11 = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        const uint64_t w = Wt[k].w;
+        const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
+        c00 += (uint64_t)a0[k] * w0;
+        c01 += (uint64_t)a0[k] * w1;
+        c01 += (uint64_t)a1[k] * w0;
+        c11 += (uint64_t)a1[k] * w1;
+      }
+      const u128 S = (u128)c00 + ((u128)c01 << 30) + ((u128)c11 << 60);
+#ifdef HX_RED128_WIDE
+      v = red128_wide(S, q, P.tgt_mu[t], P.tgt_k[t]);
+#else
+      v = red128_q8(S, q, P.tgt_mu63[t], P.tgt_k[t]);
+#endif
+    } else {
+      const uint64_t nq = 0 - q, q8 = q << 3;
+      const bool wide = P.tgt_k[t] >= 58;  // 8 terms of < 4q could pass 2^64: fold every second term
+      uint64_t acc = negfix;
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        acc += shoup4(a[k], Wt[k], nq);
+        if ((k & 1) && wide)
+          acc = csub(acc, q8);
+      }
+      v = norm_any(acc, q, (uint32_t)P.tgt_mu64[t]);
+    }
+    dd[(size_t)r * row_words] = v;
+    if (r >= off + N && r < L) {
+      // digits[j] -= digits[i]; digits[j] /= P_i on a later digit's own row (kept lazy, < 4q)
+      uint64_t* u = &xs[r * BRK_THREADS + tid];
+      *u = shoup4(*u + q - v, P.upd[t], 0 - q);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(BRK_THREADS)
+break_digits_fast_kernel(BreakArgs A, size_t row_words)
+{
+  extern __shared__ __attribute__((aligned(16))) uint64_t xs[];  // [L][BRK_THREADS]
+  const unsigned tid = threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * BRK_THREADS + tid;
+  if (i >= row_words)
+    return;
+  for (int r = 0; r < A.L; r++)
+    xs[r * BRK_THREADS + tid] = A.src[(size_t)r * row_words + i];
+  for (int d = 0; d < A.ndig; d++) {
+    const ExtPlanDev& P = A.plan[d];
+    const int off = A.off[d];
+    uint64_t* dd = A.dst + (size_t)d * A.nall * row_words + i;
+    double* fo = A.frac ? A.frac + (size_t)d * row_words + i : nullptr;
+    switch (P.n) {
+      case 1: break_digit_pass<1>(P, xs, tid, off, A.L, dd, row_words, fo); break;
+      case 2: break_digit_pass<2>(P, xs, tid, off, A.L, dd, row_words, fo); break;
+      case 3: break_digit_pass<3>(P, xs, tid, off, A.L, dd, row_words, fo); break;
+      case 4: break_digit_pass<4>(P, xs, tid, off, A.L, dd, row_words, fo); break;
+      case 5: break_digit_pass<5>(P, xs, tid, off, A.L, dd, row_words, fo); break;
+      case 6: break_digit_pass<6>(P, xs, tid, off, A.L, dd, row_words, fo); break;
+      case 7: break_digit_pass<7>(P, xs, tid, off, A.L, dd, row_words, fo); break;
+      default: break_digit_pass<8>(P, xs, tid, off, A.L, dd, row_words, fo); break;
     }
   }
 }
