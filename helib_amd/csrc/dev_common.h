@@ -1,5 +1,5 @@
 // dev_common.h -- device-visible constants and 64-bit modular arithmetic for
-// gfx950.  All values are canonical residues of word-sized primes q < 2^62
+// gfx950.  All values are canonical residues of word-sized primes q < 2^60
 // (HElib: q < 2^60, src/macro.h:21); arithmetic is exact integer (no MFMA).
 #pragma once
 #include <hip/hip_runtime.h>
