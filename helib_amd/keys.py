@@ -1,0 +1,363 @@
+"""Host-side mirror of the reference's key material and encryption for the BGV path (SURVEY.md
+row N2): every polynomial operation is a DoubleCRT operation of the engine (rows resident on the
+GPU through helib_amd.capi); the samplers and the control flow stay on the host, as in the
+reference.
+
+  Sampler                 -- src/sample.cpp: sampleSmall :67-112, sampleHWt :29-65, sampleGaussian
+                             :114-199 and their *Bounded forms (:269-304, :342-396, :459-509:
+                             redraw until embeddingLargestCoeff <= the high-probability bound)
+  RLWE1 / RLWE            -- src/keys.cpp:39-85     c0 = p*e - c1*s
+  SecKey.GenSecKey        -- src/keys.cpp:1139-1157 (ImportSecKey :1099-1137: public encryption
+                             key = one RLWE instance over the ctxt primes, s^e -> s matrices)
+  SecKey.GenKeySWmatrix   -- src/keys.cpp:1161-1255 b_i = p*e_i - a_i*s' + P*B_i*s^r(X^t),
+                             P = prod(special primes), B_i = prod(digits before i)
+  PubKey.Encrypt          -- src/keys.cpp:358-488   r*pk + p*(e0,e1) + (ptxt*Q mod p balanced, 0)
+  SecKey.skEncrypt        -- src/keys.cpp:1425-1520 (BGV branch)
+  SecKey.Decrypt          -- src/keys.cpp:1327-1420 sum_parts part*s^r(X^t), toPoly (centred CRT,
+                             src/DoubleCRT.cpp:925-1113), PolyRed mod ptxtSpace, times
+                             (intFactor*Q)^-1 mod p
+
+The random streams are numpy's, not NTL's (the distributions are what matters; NTL's
+PRG is not available to pin a stream against).  The backend object supplies the polynomial side:
+
+  be.fromCoeffs(idx, coeffs)     DoubleCRT = zzX / ZZX  (reduce mod each prime, forward transform)
+  be.randomize(idx, rng)         DoubleCRT::randomize   (uniform rows)
+  be.toPoly(poly)                DoubleCRT::toPoly      (centred big integers)
+  be.embeddingLargestCoeff(f)    norms.cpp              (canonical-embedding l-infinity norm)
+  be.keySwitch(row_idx, b, a)    KeySwitch storage for Ctxt.reLinearize / smartAutomorph
+  be.ops                         the tensorProduct / reLinearize entry points (helib_amd.capi)
+
+`HxBackend` below is the GPU one.  tests/ drive the same classes over the CPU oracle's backend and
+compare bit for bit.
+"""
+import math
+
+import numpy as np
+
+from . import ctxt as hc
+
+
+# ---------------------------------------------------------------------------------------------
+# samplers (host, as in the reference)
+# ---------------------------------------------------------------------------------------------
+class Sampler:
+    def __init__(self, context, backend, seed=0):
+        self.cc, self.be = context, backend
+        self.rng = np.random.default_rng(seed)
+
+    # -- unbounded draws over phi(m) coefficients (power-of-two m: src/sample.cpp:252-256,
+    #    :337-341, :436-440 take n = phi(m) directly; general m samples m coefficients and reduces
+    #    modulo Phi_m, which this mirror does not provide) --
+    def _n(self):
+        if not self.cc.pow2:
+            raise NotImplementedError("samplers for general m (reduceModPhimX) are not built")
+        return self.cc.phim
+
+    def sampleSmall(self, prob=0.5):
+        """each coefficient 0 with probability 1-prob, +-1 with probability prob/2 each"""
+        n = self._n()
+        nz = self.rng.random(n) < prob
+        sign = self.rng.integers(0, 2, size=n) * 2 - 1
+        return (nz * sign).astype(np.int64)
+
+    def sampleHWt(self, hwt):
+        n = self._n()
+        hwt = min(hwt, n)
+        out = np.zeros(n, dtype=np.int64)
+        pos = self.rng.choice(n, size=hwt, replace=False)
+        out[pos] = self.rng.integers(0, 2, size=hwt) * 2 - 1
+        return out
+
+    def sampleGaussian(self, stdev):
+        return np.rint(self.rng.normal(0.0, stdev, size=self._n())).astype(np.int64)
+
+    def _bounded(self, draw, bound, what):
+        for _ in range(1000):           # "while (++count < 1000 && val > bound)"
+            f = draw()
+            if self.be.embeddingLargestCoeff(f) <= bound:
+                return f, bound
+        raise RuntimeError(f"Error: {what}, after 1000 trials, still val > bound={bound}")
+
+    def sampleSmallBounded(self):
+        n = self.cc.phim
+        return self._bounded(self.sampleSmall, math.sqrt(n * math.log(n) / 2.0), "sampleSmallBounded")
+
+    def sampleHWtBounded(self, hwt):
+        bound = math.sqrt(hwt * math.log(self.cc.phim))
+        return self._bounded(lambda: self.sampleHWt(hwt), bound, "sampleHWtBounded")
+
+    def sampleGaussianBounded(self, stdev=0.0):
+        stdev = stdev or self.cc.stdev
+        eff = math.sqrt(self.cc.phim * math.log(self.cc.phim)) if self.cc.pow2 else \
+            math.sqrt(self.cc.m * math.log(self.cc.phim))
+        return self._bounded(lambda: self.sampleGaussian(stdev), stdev * eff, "sampleGaussianBounded")
+
+
+def RLWE1(be, sampler, idx, c1, s_coeffs, p):
+    """c0 = p*e - c1*s over the primes idx (those of c1); returns (c0, bound)."""
+    cc = sampler.cc
+    stdev = cc.stdev if cc.pow2 else cc.stdev * math.sqrt(cc.m)
+    e, bound = sampler.sampleGaussianBounded(stdev)
+    c0 = be.fromCoeffs(idx, e)
+    if p > 1:
+        c0.mulConstant(p)
+        bound *= p
+    tmp = c1.copy()
+    tmp *= be.fromCoeffs(idx, s_coeffs)   # Mul(s, matchIndexSets=false): s restricted to c1's primes
+    c0 -= tmp
+    return c0, bound
+
+
+# ---------------------------------------------------------------------------------------------
+# keys
+# ---------------------------------------------------------------------------------------------
+class KeySwitchInfo:
+    """include/helib/keySwitching.h:86-101 bookkeeping around the backend's storage."""
+
+    def __init__(self, fromSPower, fromXPower, W, ptxtSpace, noiseBound, b=None, a=None):
+        self.fromSPower, self.fromXPower = fromSPower, fromXPower
+        self.W, self.ptxtSpace, self.noiseBound = W, ptxtSpace, noiseBound
+        self.b, self.a = b, a             # host copies of the rows [D][rows][N] (wire format, tests)
+
+
+class PubKey:
+    def __init__(self, context, backend, seed=0):
+        self.cc, self.be = context, backend
+        self.sampler = Sampler(context, backend, seed)
+        self.pubEncrKey = None            # (part "1", part "s") over the ctxt primes
+        self.pubEncrKeyNoise = 0.0
+        self.ptxtSpace = context.ptxtSpace
+        self.skBounds = []
+        self.keySwitching = {}            # (fromSPower, fromXPower) -> KeySwitchInfo
+
+    # -- PubKey::getKeySWmatrix --
+    def haveKeySWmatrix(self, fromSPower, fromXPower):
+        return (fromSPower, fromXPower) in self.keySwitching
+
+    def getKeySWmatrix(self, fromSPower, fromXPower):
+        return self.keySwitching[(fromSPower, fromXPower)]
+
+    def getSKeyBound(self):
+        return self.skBounds[0]
+
+    def _newCtxt(self, c0, c1, noiseBound, ptxtSpace):
+        relin = self.keySwitching.get((2, 1))
+        ct = hc.Ctxt(self.cc, self.be.ops, relin.W if relin else None,
+                     relin.ptxtSpace if relin else None,
+                     math.log(relin.noiseBound) if relin else None)
+        ct.parts = {"1": c0, "s": c1}
+        ct.primeSet = frozenset(self.cc.ctxtPrimes)
+        ct.ptxtSpace, ct.intFactor = ptxtSpace, 1
+        ct.lnNoise = math.log(noiseBound)
+        for (sp, xp), ks in self.keySwitching.items():
+            if sp == 1 and xp > 1:
+                ct.ksw_auto[xp] = ks.W
+        return ct
+
+    def _ptxt_fixed(self, ptxt, primeSet, ptxtSpace):
+        """balanced_MulMod(ptxt, Q mod p, p) (src/NumbTh.cpp:876-891; the coin for c == p/2 at even
+        p is the sampler's)."""
+        QmodP = self.cc.productOfPrimes(primeSet) % ptxtSpace
+        out = np.zeros(self.cc.phim, dtype=np.int64)
+        for i, v in enumerate(ptxt):
+            c = (int(v) % ptxtSpace) * QmodP % ptxtSpace
+            if c > ptxtSpace // 2 or (ptxtSpace % 2 == 0 and c == ptxtSpace // 2
+                                      and self.sampler.rng.integers(0, 2)):
+                c -= ptxtSpace
+            out[i] = c
+        return out
+
+    def Encrypt(self, ptxt, ptxtSpace=0):
+        """PubKey::Encrypt (BGV): returns a helib_amd.ctxt.Ctxt over the ctxt primes."""
+        cc, be = self.cc, self.be
+        if self.pubEncrKey is None:
+            raise RuntimeError("no public encryption key")
+        ptxtSpace = ptxtSpace or self.ptxtSpace
+        if ptxtSpace != self.ptxtSpace:
+            ptxtSpace = math.gcd(ptxtSpace, self.ptxtSpace)
+            if ptxtSpace <= 1:
+                raise RuntimeError("Plaintext-space mismatch on encryption")
+        idx = list(cc.ctxtPrimes)
+        parts = [self.pubEncrKey[0].copy(), self.pubEncrKey[1].copy()]
+        r, r_bound = self.sampler.sampleSmallBounded()
+        rr = be.fromCoeffs(idx, r)
+        noise = r_bound * self.pubEncrKeyNoise
+        stdev = cc.stdev if cc.pow2 else cc.stdev * math.sqrt(cc.m)
+        for i in range(2):
+            parts[i] *= rr
+            e, e_bound = self.sampler.sampleGaussianBounded(stdev)
+            ee = be.fromCoeffs(idx, e)
+            ee.mulConstant(ptxtSpace)
+            e_bound *= ptxtSpace
+            if i == 1:
+                e_bound *= self.getSKeyBound()
+            parts[i] += ee
+            noise += e_bound
+        parts[0] += be.fromCoeffs(idx, self._ptxt_fixed(ptxt, idx, ptxtSpace))
+        noise += cc.noiseBoundForMod(ptxtSpace, cc.phim)
+        return self._newCtxt(parts[0], parts[1], noise, ptxtSpace)
+
+
+class SecKey(PubKey):
+    def __init__(self, context, backend, seed=0):
+        super().__init__(context, backend, seed)
+        self.sKeys = []                   # secret keys as small coefficient vectors (the DoubleCRT
+                                          # over any prime set is be.fromCoeffs(set, coeffs))
+
+    def GenSecKey(self, ptxtSpace=0, maxDegKswitch=3):
+        if self.cc.hwt > 0:
+            s, bound = self.sampler.sampleHWtBounded(self.cc.hwt)
+        else:
+            s, bound = self.sampler.sampleSmallBounded()
+        return self.ImportSecKey(s, bound, ptxtSpace, maxDegKswitch)
+
+    def ImportSecKey(self, s_coeffs, bound, ptxtSpace=0, maxDegKswitch=3):
+        cc, be = self.cc, self.be
+        s_coeffs = np.asarray(s_coeffs, dtype=np.int64)
+        if not self.sKeys:
+            if ptxtSpace < 2:
+                ptxtSpace = cc.ptxtSpace
+            idx = list(cc.ctxtPrimes)
+            c1 = be.randomize(idx, self.sampler.rng)
+            c0, nb = RLWE1(be, self.sampler, idx, c1, s_coeffs, ptxtSpace)
+            self.pubEncrKey, self.pubEncrKeyNoise, self.ptxtSpace = (c0, c1), nb, ptxtSpace
+        self.skBounds.append(bound)
+        self.sKeys.append(s_coeffs)
+        keyID = len(self.sKeys) - 1
+        for e in range(2, maxDegKswitch + 1):
+            self.GenKeySWmatrix(e, 1, keyID, keyID)
+        return keyID
+
+    def _keyRows(self, idx, sPower=1, xPower=1, keyID=0):
+        key = self.be.fromCoeffs(idx, self.sKeys[keyID])
+        if xPower > 1:
+            key.automorph(xPower)         # s(X^t)
+        if sPower > 1:
+            key.Exp(sPower)               # s^r(X^t), computed modulo every prime (:1189-1192)
+        return key
+
+    def GenKeySWmatrix(self, fromSPower, fromXPower, fromIdx=0, toIdx=0, p=0):
+        cc, be = self.cc, self.be
+        if fromSPower <= 0 or fromXPower <= 0:
+            return None
+        if fromSPower == 1 and fromXPower == 1 and fromIdx == toIdx:
+            return None
+        if self.haveKeySWmatrix(fromSPower, fromXPower):
+            return self.keySwitching[(fromSPower, fromXPower)]
+        idx = list(cc.ctxtPrimes) + list(cc.specialPrimes)
+        fromKey = self._keyRows(idx, fromSPower, fromXPower, fromIdx)
+        n = len(cc.digits)
+        a = [be.randomize(idx, self.sampler.rng) for _ in range(n)]
+        if p < 2:
+            p = self.ptxtSpace
+        b, noise = [], 0.0
+        for i in range(n):
+            bi, noise = RLWE1(be, self.sampler, idx, a[i], self.sKeys[toIdx], p)
+            b.append(bi)
+        fromKey.mulConstant(cc.productOfPrimes(cc.specialPrimes))
+        for i in range(n):
+            b[i] += fromKey
+            fromKey.mulConstant(cc.productOfPrimes(cc.digits[i]))
+        hb = np.stack([x.download()[:, 0] for x in b])
+        ha = np.stack([x.download()[:, 0] for x in a])
+        ks = KeySwitchInfo(fromSPower, fromXPower, be.keySwitch(idx, hb, ha), p, noise, hb, ha)
+        self.keySwitching[(fromSPower, fromXPower)] = ks
+        return ks
+
+    def skEncrypt(self, ptxt, ptxtSpace=0, skIdx=0):
+        cc, be = self.cc, self.be
+        if ptxtSpace < 2:
+            ptxtSpace = self.ptxtSpace
+        idx = list(cc.ctxtPrimes)
+        c1 = be.randomize(idx, self.sampler.rng)
+        c0, noise = RLWE1(be, self.sampler, idx, c1, self.sKeys[skIdx], ptxtSpace)
+        c0 += be.fromCoeffs(idx, self._ptxt_fixed(ptxt, idx, ptxtSpace))
+        noise += cc.noiseBoundForMod(ptxtSpace, cc.phim)
+        return self._newCtxt(c0, c1, noise, ptxtSpace)
+
+    def Decrypt(self, ct, raw=False):
+        """SecKey::Decrypt: plaintext coefficients in [0, ptxtSpace) (raw=True: the centred
+        integers f before the modular reduction)."""
+        cc, be = self.cc, self.be
+        idx = sorted(ct.primeSet)
+        acc = None
+        for handle, part in ct.parts.items():
+            if handle == "1":
+                term = part.copy()
+            else:
+                sPower = {"s": 1, "s2": 2}.get(handle, 1)
+                xPower = handle[1] if isinstance(handle, tuple) else 1
+                term = self._keyRows(part.getIndexSet(), sPower, xPower)
+                term *= part
+            if acc is None:
+                acc = term
+            else:
+                acc += term
+        f = be.toPoly(acc)
+        if raw:
+            return f
+        p = ct.ptxtSpace
+        out = [int(v) % p for v in f]
+        if p > 2:
+            factor = cc.productOfPrimes(idx) % p * ct.intFactor % p
+            if factor != 1:
+                inv = pow(factor, -1, p)
+                out = [v * inv % p for v in out]
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU backend
+# ---------------------------------------------------------------------------------------------
+def crt_centred(primes, rows):
+    """DoubleCRT::toPoly's CRT (src/DoubleCRT.cpp:992-1112): rows[i][j] = value_j mod primes[i]
+    -> centred integers in (-Q/2, Q/2]."""
+    Q = 1
+    for q in primes:
+        Q *= q
+    acc = np.zeros(rows.shape[1], dtype=object)
+    for q, row in zip(primes, rows):
+        Qi = Q // q
+        c = Qi * pow(Qi % q, -1, q)
+        acc = (acc + row.astype(object) * c) % Q
+    half = Q // 2
+    return [int(v) - Q if int(v) > half else int(v) for v in acc]
+
+
+class HxBackend:
+    def __init__(self, hxctx, context):
+        from . import capi
+        self.ops, self.hx, self.gctx, self.cc = capi, capi, hxctx, context
+
+    def _rows(self, idx, coeffs):
+        primes = self.cc.primes
+        c = np.asarray(coeffs)
+        if c.dtype == object:
+            return np.array([[int(v) % primes[i] for v in c] for i in idx], dtype=np.uint64)
+        c = c.astype(np.int64)
+        out = np.empty((len(idx), len(c)), dtype=np.uint64)
+        for r, i in enumerate(idx):
+            out[r] = np.mod(c, np.int64(primes[i])).astype(np.uint64)   # q < 2^60 fits int64
+        return out
+
+    def fromCoeffs(self, idx, coeffs):
+        idx = list(idx)
+        rows = self._rows(idx, coeffs)
+        return self.hx.DoubleCRT(self.gctx, idx, 1, rows[:, None, :]).FFT()
+
+    def randomize(self, idx, rng):
+        idx = list(idx)
+        n = self.cc.phim
+        rows = np.stack([rng.integers(0, self.cc.primes[i], size=n, dtype=np.uint64) for i in idx])
+        return self.hx.DoubleCRT(self.gctx, idx, 1, rows[:, None, :])
+
+    def toPoly(self, poly):
+        idx = poly.getIndexSet()
+        rows = poly.copy().iFFT().download()[:, 0]
+        return crt_centred([self.cc.primes[i] for i in idx], rows)
+
+    def embeddingLargestCoeff(self, f):
+        return float(self.hx.embeddingLargestCoeff(self.gctx, np.asarray(f, dtype=np.float64)))
+
+    def keySwitch(self, row_idx, b, a):
+        return self.hx.KeySwitch(self.gctx, list(row_idx), b, a)

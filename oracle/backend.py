@@ -26,6 +26,39 @@ class OPoly:
             self.rows[r] = O.row_op("add", self.rows[r], other.rows[other.idx.index(i)], self.o.primes[i])
         return self
 
+    def _binary(self, name, other):
+        for r, i in enumerate(self.idx):
+            self.rows[r] = O.row_op(name, self.rows[r], other.rows[other.idx.index(i)], self.o.primes[i])
+        return self
+
+    def __isub__(self, other):
+        return self._binary("sub", other)
+
+    def __imul__(self, other):
+        return self._binary("mul", other)
+
+    def mulConstant(self, num):
+        for r, i in enumerate(self.idx):
+            q = self.o.primes[i]
+            self.rows[r] = O.row_op("mul_scalar", self.rows[r], int(num) % q, q)
+        return self
+
+    def Exp(self, e):
+        """DoubleCRT::Exp (src/DoubleCRT.cpp:1142-1156): entry-wise PowerMod by square and multiply"""
+        base, acc = self.copy(), None
+        while e:
+            if e & 1:
+                acc = base.copy() if acc is None else acc._binary("mul", base)
+            e >>= 1
+            if e:
+                base._binary("mul", base.copy())
+        if acc is None:
+            for r, i in enumerate(self.idx):
+                self.rows[r] = 1 % self.o.primes[i]
+        else:
+            self.rows = acc.rows
+        return self
+
     def automorph(self, k):
         zms = O.zmstar(self.o.m)
         self.rows = np.stack([O.automorph(r, self.o.m, zms, k) for r in self.rows])
@@ -88,3 +121,31 @@ class OracleOps:
         if norms:
             return OPoly(self.o, allp, o0), OPoly(self.o, allp, o1), nrm.reshape(-1, 1)
         return OPoly(self.o, allp, o0), OPoly(self.o, allp, o1)
+
+
+class OracleBackend:
+    """The polynomial side of helib_amd.keys over the CPU oracle (same interface as
+    helib_amd.keys.HxBackend)."""
+
+    def __init__(self, octx, context):
+        self.o, self.cc = octx, context
+        self.ops = OracleOps(octx)
+
+    def fromCoeffs(self, idx, coeffs):
+        idx = list(idx)
+        coef = np.array([[int(c) % self.o.primes[i] for c in coeffs] for i in idx], dtype=np.uint64)
+        return OPoly(self.o, idx, self.o.fft(idx, coef))
+
+    def randomize(self, idx, rng):
+        idx = list(idx)
+        rows = np.stack([rng.integers(0, self.o.primes[i], size=self.o.N, dtype=np.uint64) for i in idx])
+        return OPoly(self.o, idx, rows)
+
+    def toPoly(self, poly):
+        return self.o.to_poly(poly.idx, poly.rows)
+
+    def embeddingLargestCoeff(self, f):
+        return O.embedding_largest_coeff(self.o.m, np.asarray(f, dtype=np.float64))
+
+    def keySwitch(self, row_idx, b, a):
+        return OKeySwitch(row_idx, b, a)

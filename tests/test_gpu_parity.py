@@ -844,3 +844,59 @@ def test_multiply_relin_at_the_reference_benchmark_chain_size(hx):
     # and the mod-down of the result by all 36 special primes at once (generic path, 36 sources)
     o0.scaleDownToSet(own, 65537)
     assert np.array_equal(o0.download()[:, 0], P.o.scale_down(allp, w0, sp, 65537))
+
+
+# ---------------------------------------------------------------- keys, encrypt, decrypt
+@pytest.mark.parametrize("m,p,bits", [(16384, 65537, 250), (128, 257, 150)])
+def test_keys_encrypt_decrypt_gpu_vs_oracle(hx, m, p, bits, monkeypatch):
+    """helib_amd.keys (GenSecKey, GenKeySWmatrix, PubKey::Encrypt, multiplyBy, smartAutomorph,
+    SecKey::Decrypt; src/keys.cpp:39-85, 358-488, 1099-1255, 1327-1420) run twice from the same
+    seed -- DoubleCRT operations on the GPU vs the oracle backend: every key row, ciphertext
+    part and decrypted coefficient must be identical."""
+    from helib_amd import ctxt as hc, keys as hk
+    from oracle.backend import OracleBackend
+    monkeypatch.setattr(hc.Ctxt, "measure", hx.supportsNorms(m))
+    cc = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    P = Pair(hx, m, cc.primes)
+    gsk = hk.SecKey(cc, hk.HxBackend(P.g, cc), seed=11)
+    osk = hk.SecKey(cc, OracleBackend(P.o, cc), seed=11)
+    for sk in (gsk, osk):
+        sk.GenSecKey(maxDegKswitch=2)
+        sk.GenKeySWmatrix(1, 3)
+    assert np.array_equal(gsk.sKeys[0], osk.sKeys[0])
+
+    def same(gp, op):
+        gi, oi = gp.getIndexSet(), op.getIndexSet()
+        assert sorted(gi) == sorted(oi)
+        gd, od = gp.download()[:, 0], op.download()[:, 0]
+        for r, i in enumerate(gi):
+            assert np.array_equal(gd[r], od[oi.index(i)]), i
+
+    for k in range(2):
+        same(gsk.pubEncrKey[k], osk.pubEncrKey[k])
+    for key in ((2, 1), (1, 3)):
+        g, o = gsk.getKeySWmatrix(*key), osk.getKeySWmatrix(*key)
+        assert np.array_equal(g.b, o.b) and np.array_equal(g.a, o.a) and g.noiseBound == o.noiseBound
+    rng = np.random.default_rng(8)
+    ma, mb = rng.integers(0, p, size=cc.phim), rng.integers(0, p, size=cc.phim)
+    ga, gb, oa, ob = gsk.Encrypt(ma), gsk.Encrypt(mb), osk.Encrypt(ma), osk.Encrypt(mb)
+    for h in ("1", "s"):
+        same(ga.parts[h], oa.parts[h])
+    assert gsk.Decrypt(ga) == [int(v) for v in ma] == osk.Decrypt(oa)
+    ga.multiplyBy(gb)
+    oa.multiplyBy(ob)
+    assert ga.primeSet == oa.primeSet and ga.intFactor == oa.intFactor
+    for h in ("1", "s"):
+        same(ga.parts[h], oa.parts[h])
+    prod = gsk.Decrypt(ga)
+    assert prod == osk.Decrypt(oa)
+    ga.smartAutomorph(3)
+    oa.smartAutomorph(3)
+    for h in ("1", "s"):
+        same(ga.parts[h], oa.parts[h])
+    rot = gsk.Decrypt(ga)
+    assert rot == osk.Decrypt(oa)
+    if m < 4096:
+        from tests import bgv_ref as B
+        want = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
+        assert prod == want and rot == [int(v) for v in B.automorph_mod_phi(want, m, 3, p)]

@@ -1,0 +1,110 @@
+"""helib_amd.keys (key generation, encryption, decryption as compositions of
+DoubleCRT operations) driven on the CPU over the oracle backend: the reference's own end-to-end
+properties (tests/GTestGeneral.cpp:220-457 style) -- decrypt(encrypt(m)) == m for public- and
+secret-key encryption, decrypt(a*b) and decrypt(rotate(a)) against plain polynomial arithmetic
+modulo (Phi_m, p) -- and the defining relation of every key-switching matrix."""
+import math
+
+import numpy as np
+import pytest
+
+from helib_amd import ctxt as hc, keys as hk
+from oracle import oracle as O
+from oracle.backend import OracleBackend
+from tests import bgv_ref as B
+
+
+def setup(m, p, bits, seed=5, hwt=0):
+    cc = hc.ChainContext(m, p, 1, bits=bits, c=3, skHwt=hwt)
+    octx = O.Ctx(m)
+    for q in cc.primes:
+        octx.add_prime(q)
+    be = OracleBackend(octx, cc)
+    sk = hk.SecKey(cc, be, seed)
+    sk.GenSecKey()
+    return cc, octx, be, sk
+
+
+@pytest.mark.parametrize("m,p,bits,hwt", [(128, 257, 150, 0), (64, 65537, 250, 0), (256, 17, 150, 24)])
+def test_encrypt_decrypt_round_trips(m, p, bits, hwt):
+    cc, octx, be, sk = setup(m, p, bits, hwt=hwt)
+    s = sk.sKeys[0]
+    assert set(np.unique(s)) <= {-1, 0, 1}
+    if hwt:
+        assert np.count_nonzero(s) == hwt
+    # the *Bounded samplers hold their bound (src/sample.cpp:342-396, 269-304)
+    assert be.embeddingLargestCoeff(s) <= sk.skBounds[0]
+    rng = np.random.default_rng(1)
+    msg = rng.integers(0, p, size=cc.phim)
+    ct = sk.Encrypt(msg)                       # PubKey::Encrypt
+    assert set(ct.parts) == {"1", "s"} and ct.primeSet == frozenset(cc.ctxtPrimes)
+    assert sk.Decrypt(ct) == [int(v) for v in msg]
+    # the measured noise is below the bookkeeping bound (what isCorrect() relies on)
+    raw = sk.Decrypt(ct, raw=True)
+    assert math.log(be.embeddingLargestCoeff(np.array(raw, dtype=np.float64))) <= ct.lnNoise
+    ct2 = sk.skEncrypt(msg)                    # SecKey::skEncrypt
+    assert sk.Decrypt(ct2) == [int(v) for v in msg]
+    # a mismatching plaintext space falls back to the gcd or throws (src/keys.cpp:374-379)
+    with pytest.raises(RuntimeError):
+        sk.Encrypt(msg, ptxtSpace=p + 1 if math.gcd(p, p + 1) == 1 else 3)
+
+
+@pytest.mark.parametrize("m,p,bits", [(128, 257, 150), (64, 65537, 250)])
+def test_keygen_multiply_decrypt(m, p, bits):
+    cc, octx, be, sk = setup(m, p, bits)
+    assert sk.haveKeySWmatrix(2, 1) and sk.haveKeySWmatrix(3, 1)    # maxDegKswitch = 3
+    rng = np.random.default_rng(2)
+    ma, mb = rng.integers(0, p, size=cc.phim), rng.integers(0, p, size=cc.phim)
+    ca, cb = sk.Encrypt(ma), sk.Encrypt(mb)
+    ca.multiplyBy(cb)
+    want = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
+    assert sk.Decrypt(ca) == want
+    # before relinearisation the s^2 part decrypts with s^2 (Decrypt's sPower branch, :1379-1381)
+    cc_, cd = sk.Encrypt(ma), sk.Encrypt(mb)
+    cc_.multLowLvl(cd)
+    assert set(cc_.parts) == {"1", "s", "s2"}
+    assert sk.Decrypt(cc_) == want
+
+
+@pytest.mark.parametrize("m,p,bits,k", [(128, 257, 150, 3), (64, 65537, 250, 63)])
+def test_rotation_keys_and_smartAutomorph(m, p, bits, k):
+    cc, octx, be, sk = setup(m, p, bits)
+    sk.GenKeySWmatrix(1, k)                    # s(X^k) -> s
+    rng = np.random.default_rng(3)
+    ma = rng.integers(0, p, size=cc.phim)
+    ca = sk.Encrypt(ma)
+    assert k in ca.ksw_auto
+    cr = ca.clone()
+    cr.automorph(k)                            # decrypts under s(X^k) before the key switch
+    rot = [int(v) for v in B.automorph_mod_phi(ma, m, k, p)]
+    assert sk.Decrypt(cr) == rot
+    ca.smartAutomorph(k)
+    assert set(ca.parts) == {"1", "s"}
+    assert sk.Decrypt(ca) == rot
+
+
+@pytest.mark.parametrize("spow,xpow", [(2, 1), (3, 1), (1, 5)])
+def test_key_switching_matrix_relation(spow, xpow):
+    """b_i + a_i*s = p*e_i + P*B_i*s^r(X^t) with a short e_i (src/keys.cpp:1228-1236,
+    include/helib/keySwitching.h:30-90)."""
+    m, p = 128, 257
+    cc, octx, be, sk = setup(m, p, 150)
+    ks = sk.GenKeySWmatrix(spow, xpow)
+    assert ks is sk.getKeySWmatrix(spow, xpow) and ks.ptxtSpace == p
+    idx = list(cc.ctxtPrimes) + list(cc.specialPrimes)
+    Q = cc.productOfPrimes(idx)
+    s_rows = be.fromCoeffs(idx, sk.sKeys[0])
+    from_key = be.toPoly(sk._keyRows(idx, spow, xpow))          # s^r(X^t) mod Q, centred
+    fac = cc.productOfPrimes(cc.specialPrimes)
+    from oracle.backend import OPoly
+    for i, d in enumerate(cc.digits):
+        t = OPoly(octx, idx, ks.a[i].copy())
+        t *= s_rows
+        t += OPoly(octx, idx, ks.b[i])
+        lhs = be.toPoly(t)
+        for j in range(cc.phim):
+            e = (lhs[j] - fac * from_key[j]) % Q
+            e = e - Q if e > Q // 2 else e
+            assert e % p == 0 and abs(e) <= p * 8 * cc.stdev, (i, j, e)
+        fac *= cc.productOfPrimes(d)
+    assert sk.GenKeySWmatrix(1, 1) is None and sk.GenKeySWmatrix(0, 3) is None
