@@ -44,7 +44,7 @@ SYMBOLS = [
     "hx_add", "hx_sub", "hx_mul", "hx_negate", "hx_add_scalar", "hx_sub_scalar", "hx_mul_scalar",
     "hx_set_scalar", "hx_exp",
     "hx_automorph", "hx_complex_conj",
-    "hx_add_primes_and_scale", "hx_add_primes", "hx_scale_down", "hx_scale_down_multi",
+    "hx_add_primes_and_scale", "hx_add_primes", "hx_poly_rem", "hx_scale_down", "hx_scale_down_multi",
     "hx_bring_to_set_multi", "hx_break_into_digits",
     "hx_ksk_create", "hx_ksk_destroy", "hx_tensor", "hx_key_switch_digits", "hx_mul_relin",
     "hx_relinearize",
@@ -89,6 +89,7 @@ def lib():
             "hx_set_scalar": [vp, vp], "hx_exp": [vp, u64],
             "hx_automorph": [vp, u64], "hx_complex_conj": [vp],
             "hx_add_primes_and_scale": [vp, vp, ip], "hx_add_primes": [vp, vp, ip],
+            "hx_poly_rem": [vp, C.c_uint64, vp],
             "hx_scale_down": [vp, vp, ip, u64],
             "hx_scale_down_multi": [vp, ip, vp, ip, u64],
             "hx_bring_to_set_multi": [vp, ip, vp, ip, vp, ip, u64],
@@ -333,6 +334,13 @@ class DoubleCRT:
         s = _i32(list(s))
         _chk(lib().hx_add_primes(self.h, _p(s), len(s)))
         return self
+
+    def toPolyMod(self, t):
+        """toPoly + PolyRed(t, abs=true) on the device: [batch, phim] residues in [0,t) of the
+        centred coefficients (the tail of SecKey::Decrypt)."""
+        out = np.zeros((self.batch, self.context.phim), dtype=np.uint64)
+        _chk(lib().hx_poly_rem(self.h, int(t), _p(out)))
+        return out
 
     def scaleDownToSet(self, keep_set, ptxtSpace, norms=False):
         """norms=True: returns embeddingLargestCoeff(delta/diffProd) per batch element instead of

@@ -1388,8 +1388,10 @@ extern "C" int hx_complex_conj(hx_poly* a)
 // ------------------------------------------------------------------
 // exact RNS plans
 // ------------------------------------------------------------------
+// tgt_moduli (optional): explicit target moduli instead of context primes (tgt then only sizes the
+// plan): any t in [2, 2^60) -- a target needs no transform tables (hx_poly_rem).
 static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<int>& tgt,
-                    uint64_t ptxt, ExtPlan** out)
+                    uint64_t ptxt, ExtPlan** out, const std::vector<uint64_t>* tgt_moduli = nullptr)
 {
   int n = (int)src.size(), nt = (int)tgt.size();
   if (n < 1 || n > 64)
@@ -1403,6 +1405,12 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   for (int t : tgt)
     key.push_back((uint64_t)t);
   key.push_back(ptxt);
+  if (tgt_moduli) {
+    key.push_back(0x7e57ull << 48);
+    for (uint64_t t : *tgt_moduli)
+      key.push_back(t);
+  }
+  auto tq = [&](int t) { return tgt_moduli ? (*tgt_moduli)[t] : c->primes[tgt[t]].q; };
   auto it = c->plans.find(key);
   if (it != c->plans.end()) {
     *out = it->second;
@@ -1459,7 +1467,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     min_src = std::min(min_src, p[k]);
   }
   for (int t = 0; t < nt; t++) {
-    uint64_t q = c->primes[tgt[t]].q;
+    uint64_t q = tq(t);
     // lazy 128-bit accumulation is exact when sum_k a_k*W_k < (sum_k q_k)*q_t <= 8*q_t^2
     // (red128_wide's domain; q_t <= 60 bits)
     tlazy[t] = (hxh::bitlen(q) <= 60 && sum_src <= (hxh::u128)8 * q && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;
@@ -1527,7 +1535,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   {
     bool ok = pl->dev.garner_cs && n <= 8 && (min_src >> 32) != 0 && !getenv("HX_NO_FAST_BREAK");
     for (int t = 0; t < nt && ok; t++)
-      ok = (c->primes[tgt[t]].q >> 32) != 0;
+      ok = (tq(t) >> 32) != 0;
     pl->dev.fast_ok = ok ? 1u : 0u;
   }
   c->plans[key] = pl;
@@ -1835,6 +1843,46 @@ extern "C" int hx_add_primes(hx_poly* a, const int* add_idx, int nadd)
     return fail(HX_ERR_UNSUPPORTED, "too many rows");
   CHK(ntt_rows(c, a->d, all, old + nadd, old, nadd, a->batch, false));
   a->prime_idx = all;
+  return HX_OK;
+}
+
+// DoubleCRT::toPoly followed by PolyRed(.., t, abs = true) (src/DoubleCRT.cpp:925-1113,
+// src/NumbTh.cpp:775-803): out[b][j] = (coefficient j of the centred polynomial) mod t in [0,t).
+// This is the tail of SecKey::Decrypt (src/keys.cpp:1383-1405) without big integers: inverse
+// transform of a copy, Garner mixed-radix digits, centring, residue modulo t -- exact.
+extern "C" int hx_poly_rem(const hx_poly* a, uint64_t t, uint64_t* out_host)
+{
+  if (!a || !out_host)
+    return fail(HX_ERR_INVALID, "null argument");
+  if (t < 2 || t >= (1ull << 60))
+    return fail(HX_ERR_INVALID, "modulus must be in [2, 2^60)");
+  hx_ctx* c = a->ctx;
+  CHK(use(c));
+  const int n = a->nrows();
+  const size_t rw = a->row_words();
+  if (n == 0) {  // the zero polynomial
+    memset(out_host, 0, rw * 8);
+    return HX_OK;
+  }
+  if (n > 64)
+    return fail(HX_ERR_UNSUPPORTED, "toPoly from more than 64 primes on the device");
+  CHK(ensure_scratch(c, 0, (size_t)(n + 1) * rw));
+  HIPCHK(hipMemcpyAsync(c->scratch[0], a->d, (size_t)n * rw * 8, hipMemcpyDeviceToDevice, c->stream));
+  CHK(ntt_rows(c, c->scratch[0], a->prime_idx, n, 0, n, a->batch, true));
+  std::vector<int> tgt(1, 0);
+  std::vector<uint64_t> mod(1, t);
+  ExtPlan* pl;
+  CHK(get_plan(c, a->prime_idx, tgt, 0, &pl, &mod));
+  ExtArgs args;
+  clear_args(args);
+  args.src = c->scratch[0];
+  args.dst = c->scratch[0];
+  for (int k = 0; k < n; k++)
+    args.src_row[k] = (uint16_t)k;
+  args.dst_row[0] = (uint16_t)n;
+  CHK(launch_extend(c, pl, args, rw));
+  HIPCHK(hipMemcpyAsync(out_host, c->scratch[0] + (size_t)n * rw, rw * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return HX_OK;
 }
 

@@ -23,6 +23,7 @@ PRG is not available to pin a stream against).  The backend object supplies the 
   be.fromCoeffs(idx, coeffs)     DoubleCRT = zzX / ZZX  (reduce mod each prime, forward transform)
   be.randomize(idx, rng)         DoubleCRT::randomize   (uniform rows)
   be.toPoly(poly)                DoubleCRT::toPoly      (centred big integers)
+  be.toPolyMod(poly, t)          toPoly + PolyRed(t)    (hx_poly_rem: exact, no big integers)
   be.embeddingLargestCoeff(f)    norms.cpp              (canonical-embedding l-infinity norm)
   be.keySwitch(row_idx, b, a)    KeySwitch storage for Ctxt.reLinearize / smartAutomorph
   be.ops                         the tensorProduct / reLinearize entry points (helib_amd.capi)
@@ -293,11 +294,10 @@ class SecKey(PubKey):
                 acc = term
             else:
                 acc += term
-        f = be.toPoly(acc)
         if raw:
-            return f
+            return be.toPoly(acc)
         p = ct.ptxtSpace
-        out = [int(v) % p for v in f]
+        out = be.toPolyMod(acc, p)        # toPoly + PolyRed(p, abs=true), on the device
         if p > 2:
             factor = cc.productOfPrimes(idx) % p * ct.intFactor % p
             if factor != 1:
@@ -356,8 +356,11 @@ class HxBackend:
         rows = poly.copy().iFFT().download()[:, 0]
         return crt_centred([self.cc.primes[i] for i in idx], rows)
 
+    def toPolyMod(self, poly, t):
+        return [int(v) for v in poly.toPolyMod(t)[0]]
+
     def embeddingLargestCoeff(self, f):
-        return float(self.hx.embeddingLargestCoeff(self.gctx, np.asarray(f, dtype=np.float64)))
+        return float(self.hx.embeddingLargestCoeff(self.gctx, np.asarray(f, dtype=np.float64))[0])
 
     def keySwitch(self, row_idx, b, a):
         return self.hx.KeySwitch(self.gctx, list(row_idx), b, a)

@@ -141,6 +141,12 @@ int hx_add_primes_and_scale(hx_poly* a, const int* add_idx, int nadd);
 /* DoubleCRT::addPrimes (src/DoubleCRT.cpp:565-599): exact centred extension of
  * the RNS basis by add_idx (toPoly + FFT on the new primes), in place. */
 int hx_add_primes(hx_poly* a, const int* add_idx, int nadd);
+/* DoubleCRT::toPoly (src/DoubleCRT.cpp:925-1113: iFFT of every row, CRT, centring) followed by
+ * PolyRed(poly, t, abs=true) (src/NumbTh.cpp:775-803), the tail of SecKey::Decrypt
+ * (src/keys.cpp:1383-1405): out_host[b*phi(m) + j] = centred coefficient j of batch element b,
+ * reduced into [0,t).  Exact (mixed-radix digits on the device, no big integers); `a` is unchanged.
+ * t in [2, 2^60); at most 64 rows.  Synchronous (the result is on the host when it returns). */
+int hx_poly_rem(const hx_poly* a, uint64_t t, uint64_t* out_host);
 /* DoubleCRT::scaleDownToSet (src/DoubleCRT.cpp:1464-1516): drop drop_idx with
  * exact rounding, delta forced to 0 mod ptxt_space.  In place. */
 int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_t ptxt_space);

@@ -144,6 +144,9 @@ class OracleBackend:
     def toPoly(self, poly):
         return self.o.to_poly(poly.idx, poly.rows)
 
+    def toPolyMod(self, poly, t):
+        return [int(v) % t for v in self.toPoly(poly)]
+
     def embeddingLargestCoeff(self, f):
         return O.embedding_largest_coeff(self.o.m, np.asarray(f, dtype=np.float64))
 

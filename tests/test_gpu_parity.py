@@ -900,3 +900,26 @@ def test_keys_encrypt_decrypt_gpu_vs_oracle(hx, m, p, bits, monkeypatch):
         from tests import bgv_ref as B
         want = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
         assert prod == want and rot == [int(v) for v in B.automorph_mod_phi(want, m, 3, p)]
+
+
+@pytest.mark.parametrize("m,L,t", [(16384, 5, 65537), (16384, 3, 2), (128, 4, (1 << 59) + 1), (1705, 3, 49)])
+def test_poly_rem_is_toPoly_then_PolyRed(hx, m, L, t):
+    """hx_poly_rem = DoubleCRT::toPoly (centred CRT) + PolyRed(t, abs=true), the tail of
+    SecKey::Decrypt (src/keys.cpp:1383-1405), against the oracle's big-integer toPoly."""
+    P = Pair(hx, m, primes_for(m, L))
+    idx = list(range(L))
+    x = P.rand(idx, 31, batch=2)
+    d = hx.DoubleCRT(P.g, idx, 2, x)
+    got = d.toPolyMod(t)
+    assert np.array_equal(d.download(), x)                       # operand unchanged
+    for b in range(2):
+        want = [int(v) % t for v in P.o.to_poly(idx, x[:, b])]
+        assert [int(v) for v in got[b]] == want
+    # small centred values survive exactly: a polynomial with coefficients in (-t/2, t/2)
+    rng = np.random.default_rng(5)
+    small = rng.integers(-min(t // 2, 1000), min(t // 2, 1000) + 1, size=P.N)
+    rows = np.array([[int(c) % P.primes[i] for c in small] for i in idx], dtype=np.uint64)
+    e = hx.DoubleCRT(P.g, idx, 1, P.o.fft(idx, rows)[:, None, :])
+    assert [int(v) for v in e.toPolyMod(t)[0]] == [int(c) % t for c in small]
+    with pytest.raises(hx.HxError):
+        d.toPolyMod(1)
