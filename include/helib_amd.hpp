@@ -176,6 +176,11 @@ public:
   // prime-set operations
   DoubleCRT& removePrimes(const IndexSet& s) { return chk(hx_poly_remove_primes(h_.get(), s.data(), (int)s.size())); }
   DoubleCRT& addPrimes(const IndexSet& s) { return chk(hx_add_primes(h_.get(), s.data(), (int)s.size())); }
+  // toPoly + PolyRed(t, abs=true) (the tail of SecKey::Decrypt): batch*phi(m) residues in [0,t)
+  void toPolyMod(unsigned long t, unsigned long* out) const
+  {
+    check(hx_poly_rem(h_.get(), (uint64_t)t, reinterpret_cast<uint64_t*>(out)));
+  }
   DoubleCRT& addPrimesAndScale(const IndexSet& s)
   {
     return chk(hx_add_primes_and_scale(h_.get(), s.data(), (int)s.size()));
