@@ -67,6 +67,33 @@ def main():
         json.dump(out, f, indent=1)
     print("wrote", DST)
     bin_blocks()
+    bin_objects()
+
+
+def bin_objects():
+    """Whole serialised objects of the binary fixture, cut between their eye catchers: the four
+    key-switching matrices ("|KM[" .. "]KM|") and the ciphertext-typed members ("|CX[" .. "]CX|":
+    pubEncrKey and the empty recryptEkey of the public and of the secret key).  The file was
+    written by an older HElib: same field encodings as 2.2.0 (SKHandle, IndexSet, vec_long rows,
+    ZZ, xdouble), without the 2.2.0 additions (SerializeHeader, intFactor/ptxtMag/ratFactor,
+    KeySwitch::noiseBound) -- helib_amd/wire.py reads it with legacy=True."""
+    src = os.path.join(os.path.dirname(SRC), "iotest_binLE.bin")
+    b = open(src, "rb").read()
+    objs = []
+    for tag in (b"KM", b"CX"):
+        beg, end = b"|" + tag + b"[", b"]" + tag + b"|"
+        pos = 0
+        while True:
+            i = b.find(beg, pos)
+            if i < 0:
+                break
+            j = b.index(end, i) + 4
+            objs.append({"kind": tag.decode(), "offset": i, "hex": b[i:j].hex()})
+            pos = j
+    dst = os.path.join(os.path.dirname(DST), "iotest_m12_bin_objects.json")
+    with open(dst, "w") as f:
+        json.dump({"source": "HElib 2.2.0 tests/test_resources/iotest_binLE.bin", "objects": objs}, f, indent=1)
+    print("wrote", dst, len(objs), "objects")
 
 
 def bin_blocks():
