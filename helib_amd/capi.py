@@ -184,11 +184,26 @@ class Context:
     def deferNorms(self, on):
         """Deferred read-back of the measured-noise norms (hx_ctx_defer_norms)."""
         if bool(on) != getattr(self, "_defer", False):
-            _chk(lib().hx_ctx_defer_norms(self.h, 1 if on else 0))
+            _chk(lib().hx_ctx_defer_norms(self.h, 1 if on else 0))   # switching off flushes
             self._defer = bool(on)
+            if not on:
+                self._deferred = []
+
+    def keepUntilFlush(self, out):
+        """The library writes a deferred norm into the caller's array when the context is next
+        flushed: the array must outlive that, whatever becomes of the ciphertext that asked for it
+        (a result dropped without reading its noise estimate used to leave a dangling pointer)."""
+        if getattr(self, "_defer", False):
+            if not hasattr(self, "_deferred"):
+                self._deferred = []
+            self._deferred.append(out)
+            if len(self._deferred) > 256:     # nobody is reading: complete them, keep the list short
+                self.flushNorms()
+        return out
 
     def flushNorms(self):
         _chk(lib().hx_norms_flush(self.h))
+        self._deferred = []
 
     def sync(self):
         _chk(lib().hx_ctx_sync(self.h))
@@ -242,7 +257,9 @@ class DoubleCRT:
         return out
 
     def copy(self):
-        o = DoubleCRT(self.context, self.getIndexSet(), self.batch, zero=False)
+        # (a digit block lists its primes once per digit: hx_poly_copy resizes the destination and
+        # takes over the source's row list, the destination only has to exist)
+        o = DoubleCRT(self.context, list(dict.fromkeys(self.getIndexSet())), self.batch, zero=False)
         _chk(lib().hx_poly_copy(o.h, self.h))
         return o
 
@@ -397,7 +414,19 @@ def tensorProduct(c0, c1, d0, d1):
 
 
 def keySwitchDigits(digits, W, out0, out1):
+    """Ctxt::keySwitchDigits: out0 += sum_d digit_d*b_d, out1 += sum_d digit_d*a_d (out0/out1 on the
+    ciphertext's primes followed by the special primes; digits as breakIntoDigits returns them)."""
     _chk(lib().hx_key_switch_digits(digits.h, W.h, out0.h, out1.h))
+
+
+def breakIntoDigits(part, digits, special, norms=False):
+    """DoubleCRT::breakIntoDigits as a backend entry point of helib_amd.ctxt (hoisting): the digit
+    block (and, norms=True, embeddingLargestCoeff(digit)/P_d per digit and batch element)."""
+    return part.breakIntoDigits(digits, special, norms)
+
+
+def zerosLike(poly):
+    return DoubleCRT(poly.context, poly.getIndexSet(), poly.batch)
 
 
 def multiplyBy(c0, c1, d0, d1, W, digits, out0=None, out1=None):
@@ -429,6 +458,7 @@ def scaleDownToSetMulti(polys, keep_set, ptxtSpace, norms=False, fdelta=False, d
     out = np.zeros((len(polys), polys[0].batch), dtype=np.float64)
     fd = np.zeros((len(polys), polys[0].batch, polys[0].context.phim), dtype=np.float64) if fdelta else None
     polys[0].context.deferNorms(defer)   # defer=True: `out` is filled by normsFlush()
+    polys[0].context.keepUntilFlush(out)
     _chk(lib().hx_scale_down_multi_norms(arr, len(polys), _p(drop), len(drop), ptxtSpace, _p(out),
                                          _p(fd) if fdelta else None))
     return (out, fd) if fdelta else out
@@ -449,6 +479,7 @@ def bringToSetMulti(polys, add_set, keep_set, ptxtSpace, norms=False, defer=Fals
         return None
     out = np.zeros((len(polys), polys[0].batch), dtype=np.float64)
     polys[0].context.deferNorms(defer)
+    polys[0].context.keepUntilFlush(out)
     _chk(lib().hx_bring_to_set_multi_norms(arr, len(polys), _p(add), len(add), _p(drop), len(drop),
                                            ptxtSpace, _p(out)))
     return out
@@ -492,6 +523,7 @@ def reLinearize(t0, t1, t2, W, digits, special, out0=None, out1=None, norms=Fals
         return out0, out1
     nrm = np.zeros((len(digits), t0.batch), dtype=np.float64)
     ctx.deferNorms(defer)
+    ctx.keepUntilFlush(nrm)
     _chk(lib().hx_relinearize_norms(t0.h, t1.h if t1 is not None else None, t2.h, W.h, _p(dig_idx),
                                     _p(dig_off), len(digits), _p(sp), len(sp), out0.h, out1.h, _p(nrm)))
     return out0, out1, nrm

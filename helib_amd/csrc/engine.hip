@@ -2612,13 +2612,22 @@ extern "C" int hx_key_switch_digits(const hx_poly* digits, const hx_ksk* W, hx_p
     return fail(HX_ERR_INVALID, "null argument");
   hx_ctx* c = digits->ctx;
   CHK(use(c));
-  int nall = (int)W->row_idx.size();
-  if (digits->nrows() != W->ndig * nall)
-    return fail(HX_ERR_INVALID, "W must have as many columns as there are digits");
-  if (out0->prime_idx != W->row_idx || out1->prime_idx != W->row_idx ||
-      out0->batch != digits->batch || out1->batch != digits->batch)
+  // out0/out1 live on ctxt primes (possibly a lower level than W was made for) followed by the
+  // special primes; the operand then has the first ndig <= W->ndig digits (src/DoubleCRT.cpp:485-493
+  // keeps the digits that still intersect the prime set, which are the leading ones)
+  const int nall = out0->nrows();
+  if (nall == 0 || out1->prime_idx != out0->prime_idx || out0->batch != digits->batch ||
+      out1->batch != digits->batch)
     return fail(HX_ERR_PRIMESET, "Ctxt::addPart: ctxt has primes not in part");
-  return keyswitch_launch(c, digits->d, W, W->row_idx, digits->batch, out0->d, out1->d, nall);
+  if (digits->nrows() % nall != 0 || digits->nrows() / nall > W->ndig || digits->nrows() == 0)
+    return fail(HX_ERR_INVALID, "W must have as many columns as there are digits");
+  const int ndig = digits->nrows() / nall;
+  for (int d = 0; d < ndig; d++)
+    for (int r = 0; r < nall; r++)
+      if (digits->prime_idx[(size_t)d * nall + r] != out0->prime_idx[r])
+        return fail(HX_ERR_PRIMESET, "digit rows do not match the ciphertext's primes");
+  return keyswitch_launch(c, digits->d, W, out0->prime_idx, digits->batch, out0->d, out1->d, nall,
+                          nullptr, nullptr, nullptr, ndig);
 }
 
 // Ctxt::keySwitchPart on the s^2 part (src/Ctxt.cpp:805-842): t2e = its evaluation rows on `own`

@@ -608,3 +608,76 @@ class Ctxt:
         self.multLowLvl(other)
         self.reLinearize()
         return self
+
+    def cleanUp(self):
+        """Ctxt::cleanUp (src/Ctxt.cpp:788-797)"""
+        self.reLinearize()
+        ctx = self.context
+        if self.primeSet & (frozenset(ctx.specialPrimes) | frozenset(ctx.smallPrimes)):
+            self.dropSmallAndSpecialPrimes()
+        return self
+
+
+class BasicAutomorphPrecon:
+    """Hoisting (src/matmul.cpp:48-184): break the `s` part of a ciphertext into digits ONCE, then
+    every automorphism rotates the digits (a permutation of evaluation rows, hx_automorph on the
+    whole digit block) and key-switches them with the matrix of that automorphism -- no inverse
+    transform, no basis extension and no forward transforms per rotation.  As in the reference the
+    matrix for k itself must be available (the generator-tree walk of PubKey::getNextKSWmatrix is
+    key management and stays with the caller)."""
+
+    def __init__(self, ct):
+        self.ctxt = ct.clone()
+        self.polyDigits, self.lnNoise = None, 0.0
+        c = self.ctxt
+        if len(c.parts) <= 1:
+            return
+        c.cleanUp()
+        assert set(c.parts) == {"1", "s"}, "Ciphertext is not in canonical form"
+        ctx = c.context
+        sp = list(ctx.specialPrimes)
+        digits = [[i for i in d if i in c.primeSet] for d in ctx.digits]
+        self.digits = [d for d in digits if d]
+        if c._meas:
+            self.polyDigits, nrm = c.ops.breakIntoDigits(c.parts["s"], self.digits, sp, norms=True)
+        else:
+            self.polyDigits, nrm = c.ops.breakIntoDigits(c.parts["s"], self.digits, sp), None
+        # addedNoise = breakIntoDigits' return value * max over the matrices' noise bounds
+        # (src/matmul.cpp:91-97); noise = ctxt.noise * P + addedNoise (:99-112)
+        added = -math.inf
+        for k, d in enumerate(self.digits):
+            nb = _ln(float(max(nrm[k]))) if nrm is not None else math.log(ctx.noiseBoundForUniform(0.5, ctx.phim))
+            added = logaddexp(added, nb + ctx.logOfProduct(d))
+        added += c.ksw_lnNoise
+        self.lnNoise = logaddexp(c.lnNoise + ctx.logOfProduct(sp), added)
+
+    def automorph(self, k):
+        c = self.ctxt
+        ctx = c.context
+        k %= ctx.m
+        if k == 1 or not c.parts:
+            return c.clone()
+        if math.gcd(k, ctx.m) != 1:
+            raise ValueError("k must be in Zm*")
+        sp = list(ctx.specialPrimes)
+        res = Ctxt(ctx, c.ops, c.ksw, c.ksw_ptxtSpace, c.ksw_lnNoise)
+        res.ksw_auto = c.ksw_auto
+        res.ptxtSpace, res.intFactor = c.ptxtSpace, c.intFactor
+        res.primeSet = c.primeSet | frozenset(sp)
+        part0 = c.parts["1"].copy()
+        part0.automorph(k)
+        part0.addPrimesAndScale(sp)
+        if len(c.parts) == 1:        # only the constant part: nothing to key-switch (:145-151)
+            res.parts = {"1": part0}
+            res.lnNoise = c.lnNoise + ctx.logOfProduct(sp)
+            return res
+        W = c.ksw_auto.get(k)
+        if W is None:
+            raise LookupError(f"no key-switching matrices for k={k}")
+        dg = self.polyDigits.copy()
+        dg.automorph(k)
+        part1 = c.ops.zerosLike(part0)
+        c.ops.keySwitchDigits(dg, W, part0, part1)
+        res.parts = {"1": part0, "s": part1}
+        res.lnNoise = self.lnNoise
+        return res

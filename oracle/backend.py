@@ -103,6 +103,27 @@ class OracleOps:
     def supportsNorms(m):
         return True
 
+    def breakIntoDigits(self, part, digits, special, norms=False):
+        allp = part.idx + list(special)
+        if norms:
+            dg, nrm = self.o.break_into_digits(part.idx, part.rows, digits, allp, want_norms=True)
+        else:
+            dg, nrm = self.o.break_into_digits(part.idx, part.rows, digits, allp), None
+        blk = OPoly(self.o, allp * len(digits), dg.reshape(-1, self.o.N))
+        return (blk, nrm.reshape(-1, 1)) if norms else blk
+
+    def keySwitchDigits(self, dg, W, out0, out1):
+        allp = out0.idx
+        D = dg.rows.shape[0] // len(allp)
+        sel = [W.row_idx.index(i) for i in allp]
+        kb, ka = np.ascontiguousarray(W.b[:D][:, sel]), np.ascontiguousarray(W.a[:D][:, sel])
+        out0.rows, out1.rows = self.o.key_switch_digits(allp, dg.rows.reshape(D, len(allp), -1), kb, ka,
+                                                        out0.rows, out1.rows)
+
+    @staticmethod
+    def zerosLike(poly):
+        return OPoly(poly.o, poly.idx, np.zeros_like(poly.rows))
+
     def reLinearize(self, t0, t1, t2, W, digits, special, norms=False, defer=False):
         own, sp = t0.idx, list(special)
         allp = own + sp

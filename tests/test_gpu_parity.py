@@ -923,3 +923,79 @@ def test_poly_rem_is_toPoly_then_PolyRed(hx, m, L, t):
     assert [int(v) for v in e.toPolyMod(t)[0]] == [int(c) % t for c in small]
     with pytest.raises(hx.HxError):
         d.toPolyMod(1)
+
+
+@pytest.mark.parametrize("m,p,bits", [(16384, 65537, 250), (128, 257, 150)])
+def test_hoisted_automorphisms_gpu_vs_oracle(hx, m, p, bits, monkeypatch):
+    """BasicAutomorphPrecon (src/matmul.cpp:48-184): digits broken once on the device,
+    each rotation = hx_automorph on the digit block + hx_key_switch_digits; GPU vs the oracle
+    backend from the same seed, at full level and after a multiplication (fewer primes, leading
+    digits only); power-of-two m: equal to smartAutomorph bit for bit."""
+    from helib_amd import ctxt as hc, keys as hk
+    from oracle.backend import OracleBackend
+    monkeypatch.setattr(hc.Ctxt, "measure", hx.supportsNorms(m))
+    cc = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    P = Pair(hx, m, cc.primes)
+    gsk = hk.SecKey(cc, hk.HxBackend(P.g, cc), seed=21)
+    osk = hk.SecKey(cc, OracleBackend(P.o, cc), seed=21)
+    ks = [3, m - 1]
+    for sk in (gsk, osk):
+        sk.GenSecKey(maxDegKswitch=2)
+        for k in ks:
+            sk.GenKeySWmatrix(1, k)
+    rng = np.random.default_rng(3)
+    ma, mb = rng.integers(0, p, size=cc.phim), rng.integers(0, p, size=cc.phim)
+
+    def same(g, o):
+        assert g.primeSet == o.primeSet and abs(g.lnNoise - o.lnNoise) < 1e-8
+        for h in ("1", "s"):
+            gi, oi = g.parts[h].getIndexSet(), o.parts[h].getIndexSet()
+            gd, od = g.parts[h].download()[:, 0], o.parts[h].download()[:, 0]
+            for r, i in enumerate(gi):
+                assert np.array_equal(gd[r], od[oi.index(i)]), (h, i)
+
+    ga, oa = gsk.Encrypt(ma), osk.Encrypt(ma)
+    gpre, opre = hc.BasicAutomorphPrecon(ga), hc.BasicAutomorphPrecon(oa)
+    for k in ks:
+        gr, orr = gpre.automorph(k), opre.automorph(k)
+        same(gr, orr)
+        assert gsk.Decrypt(gr) == osk.Decrypt(orr)
+        ref = ga.clone()
+        ref.smartAutomorph(k)
+        for h in ("1", "s"):
+            assert np.array_equal(gr.parts[h].download(), ref.parts[h].download())
+    ga.multiplyBy(gsk.Encrypt(mb))
+    oa.multiplyBy(osk.Encrypt(mb))
+    gpre, opre = hc.BasicAutomorphPrecon(ga), hc.BasicAutomorphPrecon(oa)
+    assert gpre.ctxt.primeSet == opre.ctxt.primeSet <= frozenset(cc.ctxtPrimes)
+    gr, orr = gpre.automorph(3), opre.automorph(3)
+    same(gr, orr)
+    assert gsk.Decrypt(gr) == osk.Decrypt(orr)
+
+
+def test_dropped_results_do_not_leave_dangling_norm_buffers(hx):
+    """Deferred norms are written into host arrays at the next flush; a ciphertext dropped without
+    reading its noise estimate must not take its array with it (regression: heap corruption at
+    interpreter exit after tools/bench_keys.py dropped 40 rotated ciphertexts)."""
+    import gc
+    from helib_amd import ctxt as hc, keys as hk
+    m, p = 16384, 65537
+    cc = hc.ChainContext(m, p, 1, bits=250, c=3)
+    P = Pair(hx, m, cc.primes)
+    sk = hk.SecKey(cc, hk.HxBackend(P.g, cc), seed=2)
+    sk.GenSecKey(maxDegKswitch=2)
+    sk.GenKeySWmatrix(1, 3)
+    rng = np.random.default_rng(0)
+    ma = rng.integers(0, p, size=cc.phim)
+    ca = sk.Encrypt(ma)
+    want = sk.Decrypt(ca.clone().smartAutomorph(3))
+    for _ in range(30):
+        c = ca.clone()
+        c.smartAutomorph(3)          # leaves deferred norms behind
+        del c
+    gc.collect()
+    junk = [np.ones(64) for _ in range(2000)]      # reuse the freed heap blocks
+    assert len(getattr(P.g, "_deferred", [])) > 0
+    P.g.flushNorms()
+    assert P.g._deferred == [] and all(float(j.sum()) == 64.0 for j in junk)
+    assert sk.Decrypt(ca.clone().smartAutomorph(3)) == want

@@ -108,3 +108,39 @@ def test_key_switching_matrix_relation(spow, xpow):
             assert e % p == 0 and abs(e) <= p * 8 * cc.stdev, (i, j, e)
         fac *= cc.productOfPrimes(d)
     assert sk.GenKeySWmatrix(1, 1) is None and sk.GenKeySWmatrix(0, 3) is None
+
+
+@pytest.mark.parametrize("m,p,bits", [(128, 257, 150), (64, 65537, 250)])
+def test_hoisted_automorphisms(m, p, bits):
+    """BasicAutomorphPrecon (src/matmul.cpp:48-184): digits broken once, each rotation = rotate the
+    digits + key switch.  Every rotation decrypts to the rotated plaintext; for power-of-two m the
+    digits of a rotated part ARE the rotated digits (a signed permutation of coefficients commutes
+    with the centred lift), so the hoisted result equals smartAutomorph's bit for bit."""
+    cc, octx, be, sk = setup(m, p, bits)
+    ks = [3, 5, m - 1]
+    for k in ks:
+        sk.GenKeySWmatrix(1, k)
+    rng = np.random.default_rng(12)
+    ma, mb = rng.integers(0, p, size=cc.phim), rng.integers(0, p, size=cc.phim)
+    ca = sk.Encrypt(ma)
+    pre = hc.BasicAutomorphPrecon(ca)
+    for k in ks:
+        r = pre.automorph(k)
+        assert set(r.parts) == {"1", "s"} and r.primeSet == frozenset(cc.ctxtPrimes) | frozenset(cc.specialPrimes)
+        assert sk.Decrypt(r) == [int(v) for v in B.automorph_mod_phi(ma, m, k, p)]
+        ref = ca.clone()
+        ref.smartAutomorph(k)
+        for h in ("1", "s"):
+            assert np.array_equal(r.parts[h].download(), ref.parts[h].download()), (k, h)
+        assert abs(r.lnNoise - ref.lnNoise) < 1.0          # same estimate up to the max-over-matrices
+    assert sk.Decrypt(pre.automorph(1)) == [int(v) for v in ma]
+    with pytest.raises(LookupError):
+        pre.automorph(7)
+    # at a lower level (after a multiplication): fewer primes, the leading digits only
+    cm = sk.Encrypt(ma)
+    cm.multiplyBy(sk.Encrypt(mb))
+    prod = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
+    pre2 = hc.BasicAutomorphPrecon(cm)
+    assert pre2.ctxt.primeSet <= frozenset(cc.ctxtPrimes)
+    for k in ks[:2]:
+        assert sk.Decrypt(pre2.automorph(k)) == [int(v) for v in B.automorph_mod_phi(prod, m, k, p)]

@@ -58,7 +58,27 @@ def main():
         a, b = sk.Encrypt(msg), sk.Encrypt(msg)
         a.multiplyBy(b)
         t_dec2, _ = timed(lambda: sk.Decrypt(a), reps)
-        for op, t in (("GenSecKey+pubEncrKey+relin matrix", t_keygen), ("PubKey::Encrypt", t_enc),
+        rot = [3, 5, 7, 9, 11, 13, 15, 17]
+        for k in rot:
+            sk.GenKeySWmatrix(1, k)
+        cr = sk.Encrypt(msg)
+
+        def plain_rotations():
+            outs = []
+            for k in rot:
+                c = cr.clone()
+                c.smartAutomorph(k)
+                outs.append(c)
+            return outs
+
+        def hoisted_rotations():
+            pre = hc.BasicAutomorphPrecon(cr)
+            return [pre.automorph(k) for k in rot]
+        t_rot, _ = timed(plain_rotations, reps)
+        t_hoist, _ = timed(hoisted_rotations, reps)
+        for op, t in (("8 rotations, smartAutomorph each (benchmarks/bgv_basic.cpp rotate)", t_rot),
+                      ("8 rotations, hoisted (BasicAutomorphPrecon: digits broken once)", t_hoist),
+                      ("GenSecKey+pubEncrKey+relin matrix", t_keygen), ("PubKey::Encrypt", t_enc),
                       ("SecKey::Decrypt (fresh, 16 primes)", t_dec),
                       ("SecKey::Decrypt (after multiplyBy, 22 primes)", t_dec2)):
             print(json.dumps({"backend": name, "op": op, "ms": round(t * 1e3, 2),
