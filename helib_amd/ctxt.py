@@ -609,6 +609,43 @@ class Ctxt:
         self.reLinearize()
         return self
 
+    # ---- plaintext constants ----
+    def multByConstant(self, dcrt, size=-1.0):
+        """Ctxt::multByConstant(const DoubleCRT&, double size) (src/Ctxt.cpp:1832-1856), BGV: every
+        part times the constant (Mul with matchIndexSets=false: dcrt may live on more primes);
+        size < 0: the bound for coefficients uniform in [-ptxtSpace/2, ptxtSpace/2]."""
+        if not self.parts:
+            return self
+        if size < 0.0:
+            size = self.context.noiseBoundForMod(self.ptxtSpace, self.context.phim)
+        for p in self.parts.values():
+            p *= dcrt
+        self.lnNoise = self.lnNoise + _ln(size)
+        return self
+
+    def addConstant(self, dcrt, size=-1.0):
+        """Ctxt::addConstant(const DoubleCRT&, double size) (src/Ctxt.cpp:896-935), BGV: the
+        constant is scaled by f = balRem(intFactor * Q mod ptxtSpace) and added to the part of 1."""
+        ctx = self.context
+        if size < 0.0:
+            size = ctx.noiseBoundForMod(self.ptxtSpace, ctx.phim)
+        f = 1
+        if self.ptxtSpace > 2:
+            p = self.ptxtSpace
+            f = ctx.productOfPrimes(self.primeSet) % p * self.intFactor % p
+            if f > p // 2:                      # balRem: into (-p/2, p/2]
+                f -= p
+        self.lnNoise = logaddexp(self.lnNoise, _ln(size * abs(f)))
+        if "1" not in self.parts:
+            raise RuntimeError("Ctxt::addPart: no part pointing at 1")   # (an empty ctxt in the reference)
+        if f == 1:
+            self.parts["1"] += dcrt
+        else:
+            tmp = dcrt.copy()
+            tmp.mulConstant(f)
+            self.parts["1"] += tmp
+        return self
+
     def cleanUp(self):
         """Ctxt::cleanUp (src/Ctxt.cpp:788-797)"""
         self.reLinearize()

@@ -896,10 +896,22 @@ def test_keys_encrypt_decrypt_gpu_vs_oracle(hx, m, p, bits, monkeypatch):
         same(ga.parts[h], oa.parts[h])
     rot = gsk.Decrypt(ga)
     assert rot == osk.Decrypt(oa)
+    # plaintext constants (Ctxt::multByConstant / addConstant, src/Ctxt.cpp:896-935, 1832-1856)
+    allp = list(cc.ctxtPrimes) + list(cc.specialPrimes)
+    bal = np.array([int(x) - p if int(x) > p // 2 else int(x) for x in mb], dtype=np.int64)
+    for sk, ct in ((gsk, ga), (osk, oa)):
+        ct.multByConstant(sk.be.fromCoeffs(allp, bal))
+        ct.addConstant(sk.be.fromCoeffs(allp, bal))
+    for h in ("1", "s"):
+        same(ga.parts[h], oa.parts[h])
+    assert abs(ga.lnNoise - oa.lnNoise) < 1e-8
+    withc = gsk.Decrypt(ga)
+    assert withc == osk.Decrypt(oa)
     if m < 4096:
         from tests import bgv_ref as B
         want = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
         assert prod == want and rot == [int(v) for v in B.automorph_mod_phi(want, m, 3, p)]
+        assert withc == [(int(x) + int(y)) % p for x, y in zip(B.polymul_mod_phi(rot, mb, m, p), mb)]
 
 
 @pytest.mark.parametrize("m,L,t", [(16384, 5, 65537), (16384, 3, 2), (128, 4, (1 << 59) + 1), (1705, 3, 49)])

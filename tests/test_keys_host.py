@@ -144,3 +144,34 @@ def test_hoisted_automorphisms(m, p, bits):
     assert pre2.ctxt.primeSet <= frozenset(cc.ctxtPrimes)
     for k in ks[:2]:
         assert sk.Decrypt(pre2.automorph(k)) == [int(v) for v in B.automorph_mod_phi(prod, m, k, p)]
+
+
+@pytest.mark.parametrize("m,p,bits", [(128, 257, 150), (64, 65537, 250), (128, 2, 150)])
+def test_constants_multByConstant_addConstant(m, p, bits):
+    """Ctxt::multByConstant / addConstant with a DoubleCRT constant (src/Ctxt.cpp:896-935,
+    1832-1856), on fresh ciphertexts and after a multiplication (intFactor != 1, more primes)."""
+    cc, octx, be, sk = setup(m, p, bits)
+    rng = np.random.default_rng(17)
+    ma, mb, mc = (rng.integers(0, p, size=cc.phim) for _ in range(3))
+    allp = list(cc.ctxtPrimes) + list(cc.specialPrimes)
+
+    def const(v):        # balanced representative, as an encoded plaintext would be
+        bal = [int(x) - p if int(x) > p // 2 else int(x) for x in v]
+        return be.fromCoeffs(allp, np.array(bal, dtype=np.int64))
+    ca = sk.Encrypt(ma)
+    n0 = ca.lnNoise
+    ca.multByConstant(const(mb))
+    assert ca.lnNoise > n0
+    ab = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
+    assert sk.Decrypt(ca) == ab
+    ca.addConstant(const(mc))
+    abc = [(x + int(y)) % p for x, y in zip(ab, mc)]
+    assert sk.Decrypt(ca) == abc
+    cd = sk.Encrypt(ma)
+    cd.multiplyBy(sk.Encrypt(mb))                    # intFactor = Q mod p now (p > 2)
+    cd.addConstant(const(mc))
+    assert sk.Decrypt(cd) == abc
+    cd.multByConstant(const(mc))
+    assert sk.Decrypt(cd) == [int(v) for v in B.polymul_mod_phi(abc, mc, m, p)]
+    raw = sk.Decrypt(cd, raw=True)
+    assert math.log(be.embeddingLargestCoeff(np.array(raw, dtype=np.float64))) <= cd.lnNoise
