@@ -1011,3 +1011,77 @@ def test_dropped_results_do_not_leave_dangling_norm_buffers(hx):
     P.g.flushNorms()
     assert P.g._deferred == [] and all(float(j.sum()) == 64.0 for j in junk)
     assert sk.Decrypt(ca.clone().smartAutomorph(3)) == want
+
+
+@pytest.mark.parametrize("m,p,bits,k,measure", [(16384, 65537, 250, 3, 0), (16384, 65537, 250, 5, 1), (128, 257, 150, 3, 0)])
+def test_cpp_host_ctxt_matches_python_mirror(hx, m, p, bits, k, measure, tmp_path, monkeypatch):
+    """include/helib_amd_ctxt.hpp -- the C++ host side (ChainContext, ModuliSizes, Ctxt::multiplyBy /
+    addCtxt / smartAutomorph with the reference's bookkeeping) over the C ABI -- against the python
+    mirror on the same keys and ciphertexts: prime sets, intFactor, noise estimate and every word
+    of every part, for the product, product + product and the rotated product; and decrypt."""
+    import struct
+    import subprocess
+    from helib_amd import ctxt as hc
+    from tests import test_ctxt_host as T
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ctxt_test")
+    libdir = os.path.join(root, "helib_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "ctxt_test.cpp"), "-L" + libdir, "-lhelib_amd",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    monkeypatch.setattr(hc.Ctxt, "measure", bool(measure))
+    cc = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    P = Pair(hx, m, cc.primes)
+    s, allp, kb, ka, rows = T.make_keys(cc, P.o)
+    _, _, kbk, kak, _ = T.make_keys(cc, P.o, auto_k=k)
+    rng = np.random.default_rng(4)
+    ma, mb = rng.integers(0, p, size=P.N), rng.integers(0, p, size=P.N)
+    ea, eb = T.encrypt(cc, P.o, s, ma, 1, rows), T.encrypt(cc, P.o, s, mb, 2, rows)
+    L, D, N = len(cc.ctxtPrimes), len(cc.digits), P.N
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<10q", m, p, bits, k, measure, len(cc.primes), D, len(allp), L, N))
+        f.write(np.array(P.o.roots, dtype="<u8").tobytes())
+        for arr in (kb, ka, kbk, kak, ea[0], ea[1], eb[0], eb[1]):
+            f.write(np.ascontiguousarray(arr, dtype="<u8").tobytes())
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # the python mirror over the same device backend
+    gW, gWk = hx.KeySwitch(P.g, allp, kb, ka), hx.KeySwitch(P.g, allp, kbk, kak)
+    mk = lambda e: hc.Ctxt.fresh(cc, hx, *(hx.DoubleCRT(P.g, cc.ctxtPrimes, 1, x[:, None, :]) for x in e), ksw=gW)  # noqa: E731
+    ga, gb = mk(ea), mk(eb)
+    ga.ksw_auto = {k: gWk}
+    ga.multiplyBy(gb)
+    prod = ga.clone()
+    gsum = ga.clone()
+    gsum.addCtxt(ga)
+    ga.smartAutomorph(k)
+    buf = open(fout, "rb").read()
+    off = 0
+    hname = {(0, 1): "1", (1, 1): "s"}
+    for want in (prod, gsum, ga):
+        nset, intFactor, nparts = struct.unpack_from("<3q", buf, off)
+        (ln,) = struct.unpack_from("<d", buf, off + 24)
+        off += 32
+        pset = list(struct.unpack_from(f"<{nset}q", buf, off))
+        off += 8 * nset
+        assert pset == sorted(want.primeSet) and intFactor == want.intFactor and nparts == len(want.parts)
+        assert abs(ln - want.lnNoise) < 1e-8, (ln, want.lnNoise)
+        for _ in range(nparts):
+            sp, xp, nr = struct.unpack_from("<3q", buf, off)
+            idx = list(struct.unpack_from(f"<{nr}q", buf, off + 24))
+            off += 24 + 8 * nr
+            got = np.frombuffer(buf, dtype="<u8", count=nr * N, offset=off).reshape(nr, N)
+            off += 8 * nr * N
+            part = want.parts[hname[(sp, xp)]]
+            wi, wd = part.getIndexSet(), part.download()[:, 0]
+            assert sorted(idx) == sorted(wi)
+            for rr, i in enumerate(idx):
+                assert np.array_equal(got[rr], wd[wi.index(i)]), (sp, xp, i)
+    (errs,) = struct.unpack_from("<q", buf, off)
+    assert errs == 3 and off + 8 == len(buf)          # LogicError and InvalidArgument both raised
+    if m < 4096:
+        from tests import bgv_ref as B
+        ab = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
+        assert T.decrypt(cc, P.o, s, prod, rows) == ab
+        assert T.decrypt(cc, P.o, s, ga, rows) == [int(v) for v in B.automorph_mod_phi(ab, m, k, p)]

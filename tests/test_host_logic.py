@@ -102,3 +102,37 @@ def test_cpp_facade_header_compiles_and_links():
                            "-L" + libdir, "-lhelib_amd", os.path.join(ROOT, "oracle", "liboracle.so"),
                            "-Wl,-rpath," + libdir, "-o", out])
     os.remove(out)
+    out2 = os.path.join(ROOT, "tests", "cpp", "ctxt_test.bin")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "ctxt_test.cpp"), "-L" + libdir, "-lhelib_amd",
+                           "-Wl,-rpath," + libdir, "-o", out2])
+    os.remove(out2)
+
+
+@pytest.mark.parametrize("m,p,bits", [(32768, 65537, 950), (16384, 65537, 250), (128, 257, 150), (1705, 7, 200),
+                                      (32768, 2, 300)])
+def test_cpp_host_chain_and_prime_set_decision_match_the_python_mirror(m, p, bits, tmp_path):
+    """include/helib_amd_ctxt.hpp (C++ host side: PrimeGenerator, buildModChain, ModuliSizes,
+    computeIntervalForMul) against helib_amd/ctxt.py: same primes, digits, table size and the same
+    prime set chosen for the product of two fresh ciphertexts."""
+    import json
+    import math
+    from helib_amd import ctxt as hc
+    exe = str(tmp_path / "chain_test")
+    libdir = os.path.join(ROOT, "helib_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "chain_test.cpp"), "-L" + libdir, "-lhelib_amd",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    got = json.loads(subprocess.check_output([exe, str(m), str(p), str(bits)]))
+    c = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    assert got["primes"] == c.primes
+    assert got["small"] == c.smallPrimes and got["ctxt"] == c.ctxtPrimes and got["special"] == c.specialPrimes
+    assert got["digits"] == c.digits and got["nsizes"] == len(c.modSizes.sizes)
+    assert abs(got["fresh_ln"] - math.log(c.freshNoiseBound())) < 1e-12
+    a = hc.Ctxt(c, None)
+    a.parts = {"1": None, "s": None}
+    a.primeSet = frozenset(c.ctxtPrimes)
+    a.lnNoise = math.log(c.freshNoiseBound())
+    lo, hi = hc.Ctxt.computeIntervalForMul(a, a)
+    assert abs(got["lo"] - lo) < 1e-9 and abs(got["hi"] - hi) < 1e-9
+    assert got["common"] == sorted(c.modSizes.getSet4Size(lo, hi, a.primeSet, a.primeSet, False))
