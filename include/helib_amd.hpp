@@ -97,6 +97,14 @@ public:
     check(hx_poly_create(context.handle(), batch, s.data(), (int)s.size(), &p));
     h_.reset(p);
   }
+  // storage only, contents unspecified (an output about to be overwritten by the engine)
+  struct Uninitialized {};
+  DoubleCRT(const Context& context, const IndexSet& s, int batch, Uninitialized) : context_(&context), batch_(batch)
+  {
+    hx_poly* p = nullptr;
+    check(hx_poly_create_uninit(context.handle(), batch, s.data(), (int)s.size(), &p));
+    h_.reset(p);
+  }
   DoubleCRT(const DoubleCRT& other) : context_(other.context_), batch_(other.batch_)
   {
     IndexSet s = other.getIndexSet();

@@ -614,7 +614,12 @@ public:
   }
   void multiplyBy(const Ctxt& other)
   {
-    multLowLvl(other);
+    multLowLvl(other);  // works on a copy of `other`, as the reference does (src/Ctxt.cpp:1716-1745)
+    reLinearize();
+  }
+  void multiplyBy(Ctxt&& other)  // the operand may be consumed: no copy
+  {
+    multLowLvl(std::move(other));
     reLinearize();
   }
   void reLinearize()
@@ -657,7 +662,7 @@ public:
     auto its = parts.find(SKHandle{1, 1});
     DoubleCRT& t2 = parts.at(hnd);
     IndexSet own = t0.getIndexSet();
-    DoubleCRT o0(*dev, own, t0.batch()), o1(*dev, own, t0.batch());
+    DoubleCRT o0(*dev, own, t0.batch(), DoubleCRT::Uninitialized{}), o1(*dev, own, t0.batch(), DoubleCRT::Uninitialized{});
     std::vector<int> idx, off;
     flatten(digits, idx, off);
     std::vector<double> nrm((size_t)digits.size() * (size_t)t0.batch(), 0.0);
@@ -742,7 +747,8 @@ private:
     const DoubleCRT &c0 = parts.at(SKHandle{0, 1}), &c1 = parts.at(SKHandle{1, 1});
     const DoubleCRT &d0 = o.parts.at(SKHandle{0, 1}), &d1 = o.parts.at(SKHandle{1, 1});
     IndexSet idx = c0.getIndexSet();
-    DoubleCRT t0(*dev, idx, c0.batch()), t1(*dev, idx, c0.batch()), t2(*dev, idx, c0.batch());
+    DoubleCRT::Uninitialized u;
+    DoubleCRT t0(*dev, idx, c0.batch(), u), t1(*dev, idx, c0.batch(), u), t2(*dev, idx, c0.batch(), u);
     helib_amd::tensorProduct(c0, c1, d0, d1, t0, t1, t2);
     parts.clear();
     parts.emplace(SKHandle{0, 1}, std::move(t0));
