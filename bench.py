@@ -295,7 +295,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="independent ciphertext pairs per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=6, help="multiplies timed on the CPU (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=60, help="multiplies timed on the CPU (0 = skip); 60 = about 15 s of one core")
     ap.add_argument("--ntt-iters", type=int, default=20)
     ap.add_argument("--workload", default="bgv32768", choices=["bgv32768", "bgv32768_fixed", "ckks65536"])
     ap.add_argument("--bits", type=int, default=950,
