@@ -151,6 +151,7 @@ struct hx_ctx {
   // handles may be destroyed in any order (hx_ctx_destroy only drops the
   // caller's reference).
   int refs = 1;
+  std::recursive_mutex mu;   // see CTX_ENTER
   // canonical-embedding norms (N1): when frac is non-null the exact-RNS kernels also emit
   // value/P as doubles there (one [batch][N] block per poly / digit, starting at frac_pos)
   double* d_frac = nullptr;
@@ -201,6 +202,14 @@ static int use(hx_ctx* c)
   HIPCHK(hipSetDevice(c->device));
   return HX_OK;
 }
+// Every entry point holds its context's (recursive) mutex while it touches host-side state -- the
+// plan cache, the slab pool, scratch slots, prime tables -- and enqueues its kernels; the device work
+// itself is ordered by the context's single stream.  This makes calls on distinct polys of ONE
+// context safe from several threads, which is how HElib's NTL thread pool uses DoubleCRT objects
+// (re-entrant on distinct objects, src/CModulus.cpp:580-610).
+#define CTX_ENTER(ctx)                                             \
+  std::lock_guard<std::recursive_mutex> _ctx_lock((ctx)->mu);      \
+  CHK(use(ctx))
 
 static constexpr size_t POOL_GRAIN = (size_t)2 << 20;        // slabs are multiples of 2 MiB
 static constexpr size_t POOL_LIMIT = (size_t)64 << 30;        // keep at most 64 GiB cached
@@ -297,7 +306,12 @@ extern "C" int hx_ctx_create(hx_ctx** out, int device, uint64_t m)
 static void ctx_free(hx_ctx* c);
 static void ctx_release(hx_ctx* c)
 {
-  if (--c->refs == 0)
+  bool last;
+  {
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    last = --c->refs == 0;
+  }
+  if (last)  // nobody else can hold a handle into this context any more
     ctx_free(c);
 }
 extern "C" int hx_ctx_destroy(hx_ctx* c)
@@ -362,6 +376,7 @@ extern "C" int hx_ctx_set_stream(hx_ctx* c, void* s)
 {
   if (!c)
     return fail(HX_ERR_INVALID, "null context");
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
   if (c->stream != (hipStream_t)s) {
     // pooled slabs are recycled in stream order: drain the old stream before switching
     hipSetDevice(c->device);
@@ -374,7 +389,7 @@ extern "C" int hx_ctx_sync(hx_ctx* c)
 {
   if (!c)
     return fail(HX_ERR_INVALID, "null context");
-  CHK(use(c));
+  CTX_ENTER(c);
   HIPCHK(hipStreamSynchronize(c->stream));
   return HX_OK;
 }
@@ -387,7 +402,10 @@ extern "C" int hx_ctx_num_primes(const hx_ctx* c, int* n)
 }
 extern "C" int hx_ctx_prime(const hx_ctx* c, int idx, uint64_t* q, uint64_t* root)
 {
-  if (!c || idx < 0 || idx >= (int)c->primes.size())
+  if (!c)
+    return fail(HX_ERR_INVALID, "prime index out of range");
+  std::lock_guard<std::recursive_mutex> lk(const_cast<hx_ctx*>(c)->mu);
+  if (idx < 0 || idx >= (int)c->primes.size())
     return fail(HX_ERR_INVALID, "prime index out of range");
   if (q)
     *q = c->primes[idx].q;
@@ -876,7 +894,7 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
 {
   if (!c)
     return fail(HX_ERR_INVALID, "null context");
-  CHK(use(c));
+  CTX_ENTER(c);
   // 16q <= 2^64 is what the lazy butterflies of the row kernels need (ntt_core.h); the reference
   // cannot make larger primes either (HELIB_SP_NBITS <= 60, src/PrimeGenerator.h:54-59)
   if (q < 3 || q >= (1ull << 60) || !hxh::is_prime(q))
@@ -956,7 +974,7 @@ static int poly_new(hx_ctx* c, int batch, const int* idx, int nrows, int cap, vo
   if (!c || !out || batch < 1)
     return fail(HX_ERR_INVALID, "bad argument");
   CHK(check_rows(c, idx, nrows, allow_dup));
-  CHK(use(c));
+  CTX_ENTER(c);
   if (cap < nrows)
     cap = nrows;
   if (cap < 1)
@@ -1010,9 +1028,12 @@ extern "C" int hx_poly_destroy(hx_poly* p)
 {
   if (!p)
     return HX_OK;
-  hipSetDevice(p->ctx->device);
-  if (p->owns && p->d)
-    pool_free(p->ctx, p->d, (size_t)p->cap_rows * p->row_words() * 8);
+  {
+    std::lock_guard<std::recursive_mutex> lk(p->ctx->mu);
+    hipSetDevice(p->ctx->device);
+    if (p->owns && p->d)
+      pool_free(p->ctx, p->d, (size_t)p->cap_rows * p->row_words() * 8);
+  }
   ctx_release(p->ctx);
   delete p;
   return HX_OK;
@@ -1043,7 +1064,7 @@ extern "C" int hx_poly_upload(hx_poly* p, const uint64_t* host)
 {
   if (!p || !host)
     return fail(HX_ERR_INVALID, "null argument");
-  CHK(use(p->ctx));
+  CTX_ENTER(p->ctx);
   size_t bytes = (size_t)p->nrows() * p->row_words() * 8;
   HIPCHK(hipMemcpyAsync(p->d, host, bytes, hipMemcpyHostToDevice, p->ctx->stream));
   HIPCHK(hipStreamSynchronize(p->ctx->stream));
@@ -1053,7 +1074,7 @@ extern "C" int hx_poly_download(const hx_poly* p, uint64_t* host)
 {
   if (!p || !host)
     return fail(HX_ERR_INVALID, "null argument");
-  CHK(use(p->ctx));
+  CTX_ENTER(p->ctx);
   size_t bytes = (size_t)p->nrows() * p->row_words() * 8;
   HIPCHK(hipMemcpyAsync(host, p->d, bytes, hipMemcpyDeviceToHost, p->ctx->stream));
   HIPCHK(hipStreamSynchronize(p->ctx->stream));
@@ -1087,7 +1108,7 @@ extern "C" int hx_poly_copy(hx_poly* dst, const hx_poly* src)
 {
   if (!dst || !src || dst->ctx != src->ctx || dst->batch != src->batch)
     return fail(HX_ERR_INVALID, "Context mismatch");
-  CHK(use(dst->ctx));
+  CTX_ENTER(dst->ctx);
   CHK(poly_reserve(dst, src->nrows(), /*keep=*/false));
   dst->prime_idx = src->prime_idx;
   HIPCHK(hipMemcpyAsync(dst->d, src->d, (size_t)src->nrows() * src->row_words() * 8,
@@ -1098,7 +1119,7 @@ extern "C" int hx_poly_set_zero(hx_poly* p)
 {
   if (!p)
     return fail(HX_ERR_INVALID, "null poly");
-  CHK(use(p->ctx));
+  CTX_ENTER(p->ctx);
   HIPCHK(hipMemsetAsync(p->d, 0, (size_t)p->nrows() * p->row_words() * 8, p->ctx->stream));
   return HX_OK;
 }
@@ -1115,7 +1136,7 @@ extern "C" int hx_poly_remove_primes(hx_poly* p, const int* idx, int n)
 {
   if (!p || (n > 0 && !idx))
     return fail(HX_ERR_INVALID, "null argument");
-  CHK(use(p->ctx));
+  CTX_ENTER(p->ctx);
   std::vector<int> keep;
   size_t rw = p->row_words();
   int w = 0;
@@ -1203,14 +1224,14 @@ extern "C" int hx_ntt_forward(hx_poly* p)
 {
   if (!p)
     return fail(HX_ERR_INVALID, "null poly");
-  CHK(use(p->ctx));
+  CTX_ENTER(p->ctx);
   return ntt_rows(p->ctx, p->d, p->prime_idx, p->nrows(), 0, p->nrows(), p->batch, false);
 }
 extern "C" int hx_ntt_inverse(hx_poly* p)
 {
   if (!p)
     return fail(HX_ERR_INVALID, "null poly");
-  CHK(use(p->ctx));
+  CTX_ENTER(p->ctx);
   return ntt_rows(p->ctx, p->d, p->prime_idx, p->nrows(), 0, p->nrows(), p->batch, true);
 }
 
@@ -1219,7 +1240,7 @@ extern "C" int hx_time_ntt(hx_poly* p, int dir, int iters, int max_rows, float* 
   if (!p || !avg_ms || iters < 1)
     return fail(HX_ERR_INVALID, "bad argument");
   hx_ctx* c = p->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
@@ -1264,7 +1285,7 @@ static int ew_binary(hx_poly* a, const hx_poly* b)
     return fail(HX_ERR_INVALID, "DoubleCRT::Op: incompatible objects");
   if (b->batch != a->batch && b->batch != 1)
     return fail(HX_ERR_INVALID, "batch mismatch");
-  CHK(use(a->ctx));
+  CTX_ENTER(a->ctx);
   int rows = a->nrows();
   if (rows == 0)
     return HX_OK;
@@ -1295,7 +1316,7 @@ static int ew_scalar_rows(hx_poly* a, const uint64_t* c_per_row, uint64_t expone
 {
   if (!a)
     return fail(HX_ERR_INVALID, "null poly");
-  CHK(use(a->ctx));
+  CTX_ENTER(a->ctx);
   int rows = a->nrows();
   if (rows == 0)
     return HX_OK;
@@ -1354,7 +1375,7 @@ extern "C" int hx_automorph(hx_poly* a, uint64_t k)
   if (!a)
     return fail(HX_ERR_INVALID, "null poly");
   hx_ctx* c = a->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   k %= c->m;
   if (hxh::gcd(k, c->m) != 1)
     return fail(HX_ERR_NOT_IN_ZMSTAR, "DoubleCRT::automorph: k not in Zm*");
@@ -1720,7 +1741,7 @@ extern "C" int hx_norms_flush(hx_ctx* c)
 {
   if (!c)
     return fail(HX_ERR_INVALID, "null context");
-  CHK(use(c));
+  CTX_ENTER(c);
   for (auto& np : c->norm_pending) {
     HIPCHK(hipEventSynchronize(np.ev));
     for (int r = 0; r < np.rows; r++) {
@@ -1748,7 +1769,7 @@ extern "C" int hx_embedding_norm(hx_ctx* c, const double* f_host, int rows, doub
 {
   if (!c || !f_host || !norms_out || rows < 1)
     return fail(HX_ERR_INVALID, "bad argument");
-  CHK(use(c));
+  CTX_ENTER(c);
   const size_t n = (size_t)rows * c->phim;
   CHK(frac_begin(c, n));
   c->want_frac = false;
@@ -1780,7 +1801,7 @@ extern "C" int hx_add_primes_and_scale(hx_poly* a, const int* add_idx, int nadd)
   if (nadd == 0)
     return HX_OK;
   hx_ctx* c = a->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   CHK(check_rows(c, add_idx, nadd));
   for (int i = 0; i < nadd; i++)
     if (find_row(a->prime_idx, add_idx[i]) >= 0)
@@ -1803,7 +1824,7 @@ extern "C" int hx_add_primes(hx_poly* a, const int* add_idx, int nadd)
   if (nadd == 0)
     return HX_OK;
   hx_ctx* c = a->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   CHK(check_rows(c, add_idx, nadd));
   for (int i = 0; i < nadd; i++)
     if (find_row(a->prime_idx, add_idx[i]) >= 0)
@@ -1857,7 +1878,7 @@ extern "C" int hx_poly_rem(const hx_poly* a, uint64_t t, uint64_t* out_host)
   if (t < 2 || t >= (1ull << 60))
     return fail(HX_ERR_INVALID, "modulus must be in [2, 2^60)");
   hx_ctx* c = a->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   const int n = a->nrows();
   const size_t rw = a->row_words();
   if (n == 0) {  // the zero polynomial
@@ -1899,7 +1920,7 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
   if (!a)
     return fail(HX_ERR_INVALID, "null poly");
   hx_ctx* c = a->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   if (c->want_frac)
     CHK(flush_xs(c));  // the scratch slots of an earlier fused block are about to be reused
   if (ptxt < 1)
@@ -2207,7 +2228,7 @@ extern "C" int hx_scale_down_multi_norms(hx_poly** polys, int npoly, const int* 
   if (!polys || npoly < 1 || !polys[0] || !norms)
     return fail(HX_ERR_INVALID, "bad argument");
   hx_ctx* c = polys[0]->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   const size_t rw = polys[0]->row_words();
   const int batch = polys[0]->batch;
   CHK(frac_begin(c, (size_t)npoly * rw));
@@ -2224,7 +2245,7 @@ extern "C" int hx_bring_to_set_multi_norms(hx_poly** polys, int npoly, const int
   if (!polys || npoly < 1 || !polys[0] || !norms)
     return fail(HX_ERR_INVALID, "bad argument");
   hx_ctx* c = polys[0]->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   const size_t rw = polys[0]->row_words();
   const int batch = polys[0]->batch;
   CHK(frac_begin(c, (size_t)npoly * rw));
@@ -2404,7 +2425,7 @@ extern "C" int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const 
   hx_ctx* c = a->ctx;
   if (out->ctx != c || out->batch != a->batch)
     return fail(HX_ERR_INVALID, "Context mismatch");
-  CHK(use(c));
+  CTX_ENTER(c);
   CHK(check_rows(c, sp_idx, nsp));
   std::vector<int> all;
   CHK(build_all(a, sp_idx, nsp, all));
@@ -2435,7 +2456,7 @@ extern "C" int hx_break_into_digits_norms(const hx_poly* a, const int* dig_idx, 
   if (!a || !norms || ndig < 1)
     return fail(HX_ERR_INVALID, "bad argument");
   hx_ctx* c = a->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   const size_t rw = a->row_words();
   CHK(frac_begin(c, (size_t)ndig * rw));
   int rc = hx_break_into_digits(a, dig_idx, dig_off, ndig, sp_idx, nsp, out);
@@ -2450,7 +2471,7 @@ extern "C" int hx_ksk_create(hx_ctx* c, int ndig, const int* row_idx, int nrows,
 {
   if (!c || !out || !b || !a || ndig < 1)
     return fail(HX_ERR_INVALID, "bad argument");
-  CHK(use(c));
+  CTX_ENTER(c);
   CHK(check_rows(c, row_idx, nrows));
   hx_ksk* k = new hx_ksk();
   k->ctx = c;
@@ -2514,7 +2535,7 @@ extern "C" int hx_tensor(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0
 {
   if (!c0 || !c1 || !d0 || !d1 || !o0 || !o1 || !o2)
     return fail(HX_ERR_INVALID, "null poly");
-  CHK(use(c0->ctx));
+  CTX_ENTER(c0->ctx);
   hx_poly* os[3] = {o0, o1, o2};
   for (auto* o : os) {
     if (o->ctx != c0->ctx || o->batch != c0->batch)
@@ -2611,7 +2632,7 @@ extern "C" int hx_key_switch_digits(const hx_poly* digits, const hx_ksk* W, hx_p
   if (!digits || !W || !out0 || !out1)
     return fail(HX_ERR_INVALID, "null argument");
   hx_ctx* c = digits->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   // out0/out1 live on ctxt primes (possibly a lower level than W was made for) followed by the
   // special primes; the operand then has the first ndig <= W->ndig digits (src/DoubleCRT.cpp:485-493
   // keeps the digits that still intersect the prime set, which are the leading ones)
@@ -2698,7 +2719,7 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
   if (!c0 || !c1 || !d0 || !d1 || !W || !out0 || !out1 || !dig_idx || !dig_off)
     return fail(HX_ERR_INVALID, "null argument");
   hx_ctx* c = c0->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   if (ndig > W->ndig || ndig < 1)
     return fail(HX_ERR_INVALID, "W must have as many columns as there are digits");
   int L = c0->nrows(), nall = (int)W->row_idx.size(), K = nall - L;
@@ -2736,7 +2757,7 @@ extern "C" int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_pol
   if (!t0 || !t2 || !W || !out0 || !out1 || !dig_idx || !dig_off || (nsp > 0 && !sp_idx))
     return fail(HX_ERR_INVALID, "null argument");
   hx_ctx* c = t0->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   if (ndig > W->ndig || ndig < 1)
     return fail(HX_ERR_INVALID, "W must have as many columns as there are digits");
   if ((t1 && (t1->prime_idx != t0->prime_idx || t1->batch != t0->batch)) ||
@@ -2775,7 +2796,7 @@ extern "C" int hx_relinearize_norms(const hx_poly* t0, const hx_poly* t1, const 
   if (!t0 || !norms || ndig < 1)
     return fail(HX_ERR_INVALID, "bad argument");
   hx_ctx* c = t0->ctx;
-  CHK(use(c));
+  CTX_ENTER(c);
   const size_t rw = t0->row_words();
   CHK(frac_begin(c, (size_t)ndig * rw));
   int rc = hx_relinearize(t0, t1, t2, W, dig_idx, dig_off, ndig, sp_idx, nsp, out0, out1);

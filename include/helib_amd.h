@@ -29,7 +29,10 @@
  *     library unless the poly was created with hx_poly_wrap.
  *   - all work of a context is enqueued on one HIP stream (settable); calls
  *     are asynchronous with respect to the host except upload/download/sync.
- *   - calls on distinct contexts are thread-safe; a context is not.
+ *   - thread-safe: every call takes its context's lock while it updates host-side state and
+ *     enqueues its kernels (device work is ordered by the context's stream), so several threads
+ *     may operate on DISTINCT polys of one context concurrently -- the re-entrancy HElib's NTL
+ *     thread pool relies on (src/CModulus.cpp:580-610).  Two threads must not use the SAME poly.
  *   - results are bit-identical to reference HElib's DoubleCRT rows for the
  *     same (q, root) -- values are canonical residues, there is no rounding.
  *   - the library never falls back to the CPU: without a usable gfx950 device

@@ -1085,3 +1085,45 @@ def test_cpp_host_ctxt_matches_python_mirror(hx, m, p, bits, k, measure, tmp_pat
         ab = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
         assert T.decrypt(cc, P.o, s, prod, rows) == ab
         assert T.decrypt(cc, P.o, s, ga, rows) == [int(v) for v in B.automorph_mod_phi(ab, m, k, p)]
+
+
+def test_threads_on_distinct_polys_of_one_context(hx):
+    """HElib's NTL thread pool calls DoubleCRT operations concurrently on distinct objects of one
+    Context (re-entrancy, src/CModulus.cpp:580-610).  Eight threads drive their own polys through
+    transforms, ring operations and the exact-RNS operations (shared plan cache, scratch slots and
+    slab pool inside the context); every result must equal the single-threaded oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    m, L = 16384, 5
+    P = Pair(hx, m, primes_for(m, L + 2))
+    own, extra = list(range(L)), [L, L + 1]
+
+    def work(t):
+        x, y = P.rand(own, 100 + t), P.rand(own, 200 + t)
+        a, b = hx.DoubleCRT(P.g, own, 1, x), hx.DoubleCRT(P.g, own, 1, y)
+        out = {}
+        for _ in range(3):                                  # repeat: more interleavings
+            a2 = a.copy()
+            a2 *= b
+            a2.automorph(3 + 2 * t)
+            out["mul"] = a2.download()[:, 0]
+            c = a.copy()
+            c.addPrimes(extra)
+            out["addPrimes"] = c.download()[:, 0]
+            d = a.copy()
+            d.scaleDownToSet(own[:-2], 65537)                # two dropped primes: the generic path
+            out["scaleDown"] = d.download()[:, 0]
+            e = a.copy()
+            e.scaleDownToSet(own[:-1], 65537)                # one dropped prime: the fused path
+            out["scaleDown1"] = e.download()[:, 0]
+        return t, x[:, 0], y[:, 0], out
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        results = list(ex.map(work, range(8)))
+    zms = O.zmstar(m)
+    for t, x, y, out in results:
+        prod = np.stack([O.row_op("mul", x[r], y[r], P.primes[i]) for r, i in enumerate(own)])
+        want = np.stack([O.automorph(r, m, zms, 3 + 2 * t) for r in prod])
+        assert np.array_equal(out["mul"], want), t
+        assert np.array_equal(out["addPrimes"], np.vstack([x, P.o.add_primes(own, x, extra)])), t
+        assert np.array_equal(out["scaleDown"], P.o.scale_down(own, x, own[-2:], 65537)), t
+        assert np.array_equal(out["scaleDown1"], P.o.scale_down(own, x, own[-1:], 65537)), t
