@@ -140,6 +140,49 @@ conv_split_kernel(uint64_t* __restrict__ cbuf, uint64_t* __restrict__ qbuf, PtrL
   }
 }
 
+// ---- convolution modulo a prime WITHOUT the 2-power roots (q-1 not divisible by 2^(bk+1)):
+// the exact integer convolution is taken modulo three auxiliary NTT primes A0, A1, A2 (each
+// 2^20 | A-1, A > 2^59) and recombined -- what NTL does for a zz_p modulus that is not an FFT prime.
+// Inputs are < q, at most 2^17 terms: every coefficient is < 2^17 q^2 < 2^137 < A0 A1 A2.
+struct Crt3Dev {
+  uint64_t A[3], muA[3];   // aux primes, floor(2^(2k)/A) (k = 60)
+  uint64_t inv01;          // A0^-1 mod A1
+  uint64_t a0m2, inv012;   // A0 mod A2, (A0 A1)^-1 mod A2
+  uint64_t q, mu, mu64;    // the real modulus
+  uint32_t k;
+  uint64_t a0q, a01q;      // A0 mod q, A0 A1 mod q
+};
+// dst[i] = src[i] mod A (src < 2^60 < 2A)
+__global__ void __launch_bounds__(256) aux_load_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
+                                                       size_t n, uint64_t A)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint64_t x = src[i];
+    dst[i] = x >= A ? x - A : x;
+  }
+}
+// out[i] = CRT(t0[i] mod A0, t1[i] mod A1, t2[i] mod A2) mod q  (Garner mixed radix, exact)
+__global__ void __launch_bounds__(256) crt3_kernel(const uint64_t* __restrict__ t0, const uint64_t* __restrict__ t1,
+                                                   const uint64_t* __restrict__ t2, uint64_t* __restrict__ out,
+                                                   size_t n, Crt3Dev C)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t d0 = t0[i];
+    const uint64_t A1 = C.A[1], A2 = C.A[2];
+    const uint64_t d0m1 = d0 >= A1 ? d0 - A1 : d0;       // aux primes are within 2x of each other
+    const uint64_t d1 = mul_mod(sub_mod(t1[i], d0m1, A1), C.inv01, A1, C.muA[1], 60);
+    const uint64_t d0m2 = d0 >= A2 ? d0 - A2 : d0, d1m2 = d1 >= A2 ? d1 - A2 : d1;
+    uint64_t v = sub_mod(t2[i], d0m2, A2);
+    v = sub_mod(v, mul_mod(C.a0m2, d1m2, A2, C.muA[2], 60), A2);
+    const uint64_t d2 = mul_mod(v, C.inv012, A2, C.muA[2], 60);
+    // value = d0 + A0 d1 + A0 A1 d2, reduced modulo q
+    uint64_t r = red64(d0, C.q, C.mu64);
+    r = add_mod(r, mul_mod(C.a0q, red64(d1, C.q, C.mu64), C.q, C.mu, C.k), C.q);
+    r = add_mod(r, mul_mod(C.a01q, red64(d2, C.q, C.mu64), C.q, C.mu, C.k), C.q);
+    out[i] = r;
+  }
+}
+
 // dst[(ri*batch+b)][nd] <- k <= d ? src[(ri*batch+b)][base -/+ k] : 0   (reversal + zero padding)
 //   mode 0: top of x reversed : dst[k] = x[m-1-k]        (src stride mpad, base = m-1)
 //   mode 1: Q from rev_d(Q)   : dst[k] = s[d-k]          (src stride ns,   base = d)

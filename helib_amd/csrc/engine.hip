@@ -108,6 +108,13 @@ struct ConvPlan {  // negacyclic NTT of size 2^logn for one prime
   hx::ConvPrimeDev* dev = nullptr;
 };
 struct BluePrime {
+  // aux: q-1 lacks the 2-power roots the chirp convolutions need; they run modulo three auxiliary
+  // NTT primes and are recombined exactly (bluestein.h, crt3_kernel)
+  bool aux = false;
+  ConvPlan aconv[3][3];                                       // [aux prime][size]
+  uint64_t* d_ahat[3][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr},
+                            {nullptr, nullptr, nullptr, nullptr}};
+  hx::Crt3Dev crt;
   hx::BluePrimeDev* dev = nullptr;
   TW* d_powers = nullptr;
   TW* d_ipowers = nullptr;
@@ -131,8 +138,9 @@ struct hx_ctx {
   int primes_cap = 0;
   TW* d_tw = nullptr;  // twiddle arena shared by all primes
   size_t tw_cap = 0, tw_used = 0;
-  uint64_t* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t* scratch[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_words[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t aux_q[3] = {0, 0, 0};  // auxiliary NTT primes of the aux Bluestein path (lazily chosen)
   // general m (Bluestein): conv sizes 2^bk (chirp), 2^n1 / 2^n2 (rem Phi_m), pseudo "primes"
   // (twiddle tables of the conv sizes) and per-prime tables
   int bk = 0, n1 = 0, n2 = 0;
@@ -331,7 +339,7 @@ static void ctx_free(hx_ctx* c)
     hipFree(kv.second->blob);
     delete kv.second;
   }
-  for (int i = 0; i < 8; i++)
+  for (int i = 0; i < 10; i++)
     if (c->scratch[i])
       hipFree(c->scratch[i]);
   for (auto& kv : c->pool)
@@ -354,6 +362,12 @@ static void ctx_free(hx_ctx* c)
       hipFree(b->d_hat[i]);
     for (int i = 0; i < 3; i++)
       hipFree(b->conv[i].dev);
+    for (int j = 0; j < 3; j++) {
+      for (int i = 0; i < 4; i++)
+        hipFree(b->d_ahat[j][i]);
+      for (int i = 0; i < 3; i++)
+        hipFree(b->aconv[j][i].dev);
+    }
     delete b;
   }
   if (c->d_cprimes)
@@ -662,32 +676,32 @@ static dim3 grid2(uint32_t n, size_t segs)
 }
 
 // In-place convolution with a precomputed transform: buf[(ri*batch+b)][2^logn] (time domain)
-// <- buf * hat_ri.  hat_sel < 0: forward transform only (result left in transform order in buf,
-// or in qbuf for split sizes).  prime_of_row[ri] = context prime index; which = 0/1/2 (bk/n1/n2).
-static int conv_apply(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vector<int>& prime_of_row,
-                      int batch, int which, int hat_sel)
+// <- buf * hat_ri.  hats[ri] == nullptr for all rows: forward transform only (result left in
+// transform order in buf, or in qbuf for split sizes).  plans[ri]: the row's transform plan.
+static int conv_core(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vector<const ConvPlan*>& plans,
+                     const std::vector<const uint64_t*>& hatv, int batch)
 {
-  const int R = (int)prime_of_row.size();
+  const int R = (int)plans.size();
   if (R == 0)
     return HX_OK;
   if (R > MAX_ROWS / 4)
     return fail(HX_ERR_INVALID, "internal: conv chunk too large");
-  const ConvPlan& p0 = c->blue[prime_of_row[0]]->conv[which];
+  const ConvPlan& p0 = *plans[0];
   const int logn = p0.logn;
   const bool split = p0.split;
   const uint32_t N = 1u << logn;
+  const bool fwd_only = hatv[0] == nullptr;
   hx::PtrList cps, hats;
   for (int r = 0; r < R; r++) {
-    const BluePrime* bp = c->blue[prime_of_row[r]];
-    cps.p[r] = bp->conv[which].dev;
-    hats.p[r] = hat_sel >= 0 ? bp->d_hat[hat_sel] : nullptr;
+    cps.p[r] = plans[r]->dev;
+    hats.p[r] = hatv[r];
   }
   std::vector<std::pair<int, int>> rows;
   if (!split) {
     for (int r = 0; r < R; r++)
-      rows.emplace_back(r, c->blue[prime_of_row[r]]->conv[which].pd[0]);
+      rows.emplace_back(r, plans[r]->pd[0]);
     CHK(ntt_launch(c, logn, c->d_cprimes, buf, buf, rows, batch, false));
-    if (hat_sel < 0)
+    if (fwd_only)
       return HX_OK;
     hipLaunchKernelGGL(hx::conv_pointwise_kernel, grid2(N, (size_t)R * batch), dim3(256), 0, c->stream,
                        buf, hats, cps, 1, batch, N);
@@ -697,12 +711,12 @@ static int conv_apply(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vecto
   const uint32_t Q = N / 4;
   for (int r = 0; r < R; r++)
     for (int g = 0; g < 4; g++)
-      rows.emplace_back(r * 4 + g, c->blue[prime_of_row[r]]->conv[which].pd[g]);
+      rows.emplace_back(r * 4 + g, plans[r]->pd[g]);
   hipLaunchKernelGGL(hx::conv_split_kernel, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf,
                      qbuf, cps, batch, Q, 0);
   HIPCHK(hipGetLastError());
   CHK(ntt_launch(c, logn - 2, c->d_cprimes, qbuf, qbuf, rows, batch, false));
-  if (hat_sel < 0)
+  if (fwd_only)
     return HX_OK;
   hipLaunchKernelGGL(hx::conv_pointwise_kernel, grid2(Q, (size_t)R * 4 * batch), dim3(256), 0, c->stream,
                      qbuf, hats, cps, 4, batch, Q);
@@ -714,11 +728,88 @@ static int conv_apply(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vecto
   return HX_OK;
 }
 
+// one row (batch blocks of N words at `sub`) of an aux-mode prime: three convolutions modulo the
+// auxiliary primes, then the exact recombination modulo q
+static int aux_conv_row(hx_ctx* c, uint64_t* sub, const BluePrime* bp, int batch, int which, int hat_sel)
+{
+  const int logn = bp->aconv[0][which].logn;
+  const size_t n = (size_t)batch << logn;
+  CHK(ensure_scratch(c, 8, 3 * n));
+  CHK(ensure_scratch(c, 9, n));
+  const unsigned blocks = (unsigned)std::min<size_t>(4096, (n + 255) / 256);
+  for (int j = 0; j < 3; j++) {
+    uint64_t* t = c->scratch[8] + (size_t)j * n;
+    hipLaunchKernelGGL(hx::aux_load_kernel, dim3(blocks), dim3(256), 0, c->stream, sub, t, n, bp->crt.A[j]);
+    HIPCHK(hipGetLastError());
+    std::vector<const ConvPlan*> pl(1, &bp->aconv[j][which]);
+    std::vector<const uint64_t*> hv(1, bp->d_ahat[j][hat_sel]);
+    CHK(conv_core(c, t, c->scratch[9], pl, hv, batch));
+  }
+  hipLaunchKernelGGL(hx::crt3_kernel, dim3(blocks), dim3(256), 0, c->stream, c->scratch[8], c->scratch[8] + n,
+                     c->scratch[8] + 2 * n, sub, n, bp->crt);
+  HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+
+// prime_of_row[ri] = context prime index; which = 0/1/2 (bk/n1/n2); hat_sel: the hat table
+static int conv_apply(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vector<int>& prime_of_row,
+                      int batch, int which, int hat_sel)
+{
+  const int R = (int)prime_of_row.size();
+  bool any_aux = false;
+  for (int r = 0; r < R; r++)
+    any_aux = any_aux || c->blue[prime_of_row[r]]->aux;
+  if (!any_aux) {
+    std::vector<const ConvPlan*> pl(R);
+    std::vector<const uint64_t*> hv(R);
+    for (int r = 0; r < R; r++) {
+      pl[r] = &c->blue[prime_of_row[r]]->conv[which];
+      hv[r] = hat_sel >= 0 ? c->blue[prime_of_row[r]]->d_hat[hat_sel] : nullptr;
+    }
+    return conv_core(c, buf, qbuf, pl, hv, batch);
+  }
+  // a chunk with aux-mode primes (exotic: e.g. the reference's legacy fixture): row by row
+  for (int r = 0; r < R; r++) {
+    const BluePrime* bp = c->blue[prime_of_row[r]];
+    const int logn = bp->aux ? bp->aconv[0][which].logn : bp->conv[which].logn;
+    uint64_t* sub = buf + ((size_t)r * batch << logn);
+    if (bp->aux) {
+      CHK(aux_conv_row(c, sub, bp, batch, which, hat_sel));
+    } else {
+      std::vector<const ConvPlan*> pl(1, &bp->conv[which]);
+      std::vector<const uint64_t*> hv(1, bp->d_hat[hat_sel]);
+      CHK(conv_core(c, sub, qbuf, pl, hv, batch));
+    }
+  }
+  return HX_OK;
+}
+
 // upload a time-domain polynomial (host, length <= 2^logn), transform it on the device with the
 // prime's own plan and keep the result as hat table `slot`
 static int make_hat(hx_ctx* c, int prime, int which, int slot, const std::vector<uint64_t>& poly)
 {
   BluePrime* bp = c->blue[prime];
+  if (bp->aux) {  // the same polynomial reduced and transformed modulo each auxiliary prime
+    const int logn = bp->aconv[0][which].logn;
+    const size_t N = (size_t)1 << logn;
+    CHK(ensure_scratch(c, 4, N));
+    CHK(ensure_scratch(c, 5, N));
+    for (int j = 0; j < 3; j++) {
+      std::vector<uint64_t> h(N, 0);
+      for (size_t i = 0; i < poly.size(); i++)
+        h[i] = poly[i] % bp->crt.A[j];
+      HIPCHK(hipMemcpyAsync(c->scratch[4], h.data(), N * 8, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      std::vector<const ConvPlan*> pl(1, &bp->aconv[j][which]);
+      std::vector<const uint64_t*> hv(1, nullptr);
+      CHK(conv_core(c, c->scratch[4], c->scratch[5], pl, hv, 1));
+      HIPCHK(hipMalloc((void**)&bp->d_ahat[j][slot], N * 8));
+      HIPCHK(hipMemcpyAsync(bp->d_ahat[j][slot], bp->aconv[j][which].split ? c->scratch[5] : c->scratch[4], N * 8,
+                            hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return HX_OK;
+  }
   const int logn = bp->conv[which].logn;
   const size_t N = (size_t)1 << logn;
   CHK(ensure_scratch(c, 4, N));
@@ -754,19 +845,52 @@ static int blue_prime_create(hx_ctx* c, int idx)
   int maxk = std::max(c->bk, std::max(c->n1, c->n2));
   if (maxk > 17)
     return fail(HX_ERR_UNSUPPORTED, "m too large for the Bluestein path (conv size 2^%d)", maxk);
-  if ((q - 1) % ((uint64_t)1 << (maxk + 1)) != 0)
-    return fail(HX_ERR_UNSUPPORTED,
-                "Bluestein path needs 2^%d | q-1 (true for PrimeGenerator primes); q=%llu", maxk + 1,
-                (unsigned long long)q);
   if ((int)c->blue.size() <= idx)
     c->blue.resize(idx + 1, nullptr);
   BluePrime* bp = new BluePrime();
   c->blue[idx] = bp;
-  const uint64_t gen = hxh::find_prim_root(q, (uint64_t)1 << (maxk + 1));
   const int sizes[3] = {c->bk, c->n1, c->n2};
-  for (int w = 0; w < 3; w++) {
-    uint64_t psi = hxh::powmod(gen, (uint64_t)1 << (maxk - sizes[w]), q);
-    CHK(conv_plan_create(c, q, sizes[w], psi, &bp->conv[w]));
+  if ((q - 1) % ((uint64_t)1 << (maxk + 1)) == 0) {
+    // PrimeGenerator primes: q = 2^k t m + 1 with a large k -- the convolutions run modulo q itself
+    const uint64_t gen = hxh::find_prim_root(q, (uint64_t)1 << (maxk + 1));
+    for (int w = 0; w < 3; w++) {
+      uint64_t psi = hxh::powmod(gen, (uint64_t)1 << (maxk - sizes[w]), q);
+      CHK(conv_plan_create(c, q, sizes[w], psi, &bp->conv[w]));
+    }
+  } else {
+    // no 2^(maxk+1)-th root of unity modulo q (e.g. the primes of the reference's legacy fixture):
+    // exact convolutions through three auxiliary NTT primes
+    bp->aux = true;
+    if (c->aux_q[0] == 0) {
+      int found = 0;
+      for (uint64_t a = ((uint64_t)1 << 60) - ((uint64_t)1 << 20) + 1; found < 3 && a > ((uint64_t)1 << 59);
+           a -= (uint64_t)1 << 20)
+        if (hxh::is_prime(a))
+          c->aux_q[found++] = a;
+      if (found < 3)
+        return fail(HX_ERR_UNSUPPORTED, "internal: no auxiliary NTT primes");
+    }
+    hx::Crt3Dev& C = bp->crt;
+    memset(&C, 0, sizeof C);
+    for (int j = 0; j < 3; j++) {
+      const uint64_t A = c->aux_q[j];
+      C.A[j] = A;
+      C.muA[j] = (uint64_t)((((hxh::u128)1) << 120) / A);
+      const uint64_t gen = hxh::find_prim_root(A, (uint64_t)1 << (maxk + 1));
+      for (int w = 0; w < 3; w++) {
+        uint64_t psi = hxh::powmod(gen, (uint64_t)1 << (maxk - sizes[w]), A);
+        CHK(conv_plan_create(c, A, sizes[w], psi, &bp->aconv[j][w]));
+      }
+    }
+    C.inv01 = hxh::invmod(C.A[0] % C.A[1], C.A[1]);
+    C.a0m2 = C.A[0] % C.A[2];
+    C.inv012 = hxh::invmod(hxh::mulmod(C.A[0] % C.A[2], C.A[1] % C.A[2], C.A[2]), C.A[2]);
+    C.q = q;
+    C.k = (uint32_t)hxh::bitlen(q);
+    C.mu = (uint64_t)((((hxh::u128)1) << (2 * C.k)) / q);
+    C.mu64 = (uint64_t)((((hxh::u128)1) << 64) / q);
+    C.a0q = C.A[0] % q;
+    C.a01q = hxh::mulmod(C.A[0] % q, C.A[1] % q, q);
   }
   // powers[i] = root^(i^2 mod e), chirp b (src/bluestein.cpp:76-132)
   const uint64_t e = (m % 2 == 0) ? 2 * m : m;

@@ -1127,3 +1127,71 @@ def test_threads_on_distinct_polys_of_one_context(hx):
         assert np.array_equal(out["addPrimes"], np.vstack([x, P.o.add_primes(own, x, extra)])), t
         assert np.array_equal(out["scaleDown"], P.o.scale_down(own, x, own[-2:], 65537)), t
         assert np.array_equal(out["scaleDown1"], P.o.scale_down(own, x, own[-1:], 65537)), t
+
+
+# ---------------------------------------------------------------- the reference's own fixture, on the device
+def test_reference_fixture_on_the_device(hx):
+    """The only value-level vectors the reference ships (tests/test_resources/iotest_asciiLE.txt, m = 12,
+    five primes written by an older HElib; tests/golden/iotest_m12.json) through the HIP path itself:
+    the secret-key rows inverse-transform to s = 1 - X + X^2 + X^3 under every prime and transform
+    back to the fixture rows bit for bit; the public key satisfies b + a*s = 7*e with the short e of
+    the fixture; and hx_poly_rem recovers e's sign pattern.  These primes have only 2^3..2^15 | q-1,
+    so the Bluestein convolutions run through the auxiliary-prime path (crt3_kernel)."""
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "iotest_m12.json")))
+    m, p, primes = gold["m"], gold["p"], gold["primes"]
+    g = hx.Context(m)
+    for q in primes:
+        g.add_prime(q)                                    # FindPrimRootT(q, 2m), the fixture's convention
+    idx5, idx3 = list(range(5)), list(range(3))
+    srows = np.array(gold["seckey"]["rows"], dtype=np.uint64)
+    s = hx.DoubleCRT(g, idx5, 1, srows[:, None, :])
+    coef = s.copy().iFFT().download()[:, 0]
+    for q, row in zip(primes, coef):
+        assert [int(x) - q if int(x) > q // 2 else int(x) for x in row] == gold["expect_s_coeffs"]
+    assert np.array_equal(s.copy().iFFT().FFT().download()[:, 0], srows)
+    b = hx.DoubleCRT(g, idx3, 1, np.array(gold["pubkey_b"]["rows"], dtype=np.uint64)[:, None, :])
+    a = hx.DoubleCRT(g, idx3, 1, np.array(gold["pubkey_a"]["rows"], dtype=np.uint64)[:, None, :])
+    a *= s                                                # s lives on more primes: Mul(matchIndexSets=false)
+    b += a
+    pe = b.copy().iFFT().download()[:, 0]
+    for q, row in zip(primes, pe):
+        assert [int(x) - q if int(x) > q // 2 else int(x) for x in row] == [p * c for c in gold["expect_e_coeffs"]]
+    # the decryption tail on the device: (b + a s) centred mod Q, reduced mod p = 7 -> 0; mod 1000003 -> 7 e
+    assert [int(v) for v in b.toPolyMod(p)[0]] == [0, 0, 0, 0]
+    t = 1000003
+    assert [int(v) for v in b.toPolyMod(t)[0]] == [(p * c) % t for c in gold["expect_e_coeffs"]]
+    # the oracle agrees row for row on a random polynomial under these primes (forward and inverse)
+    o = O.Ctx(m)
+    for q in primes:
+        o.add_prime(q)
+    x = np.stack([O.fill_uniform(4, q, 3 + i) for i, q in enumerate(primes)])
+    d = hx.DoubleCRT(g, idx5, 1, x[:, None, :])
+    assert np.array_equal(d.FFT().download()[:, 0], o.fft(idx5, x))
+    assert np.array_equal(d.iFFT().download()[:, 0], x)
+
+
+@pytest.mark.parametrize("m", [105, 1705, 12])
+def test_bluestein_auxiliary_prime_path_matches_oracle(hx, m):
+    """General m with primes that lack the 2-power roots (q = 2 k e + 1 with k odd-ish): the chirp and
+    rem-Phi_m convolutions go through three auxiliary NTT primes; mixed with a PrimeGenerator prime
+    in the same DoubleCRT."""
+    e = 2 * m if m % 2 == 0 else m
+    primes, k = [], (1 << 40) // e
+    while len(primes) < 2:
+        k += 1
+        q = k * e + 1
+        v2 = (q - 1) & -(q - 1)
+        if v2 <= 8 and all(q % s for s in (3, 5, 7, 11, 13)) and pow(2, q - 1, q) == 1 and pow(3, q - 1, q) == 1:
+            from helib_amd import hostnt
+            if hostnt.is_prime(q):
+                primes.append(q)
+    primes.append(O.PrimeGen(50, m).next())               # a normal one beside them
+    P = Pair(hx, m, primes)
+    idx = [0, 1, 2]
+    x = P.rand(idx, 5, batch=2)
+    d = hx.DoubleCRT(P.g, idx, 2, x)
+    y = d.FFT().download()
+    for b in range(2):
+        assert np.array_equal(y[:, b], P.o.fft(idx, x[:, b]))
+    assert np.array_equal(d.iFFT().download(), x)
