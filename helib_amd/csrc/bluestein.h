@@ -21,7 +21,8 @@ namespace hx {
 struct ConvPrimeDev {
   uint64_t q, mu, mu64;
   uint32_t k, logn;
-  SplitTW S;           // only for split sizes
+  SplitTW S;           // only for split sizes (radix 4: 2^16, 2^17)
+  SplitTW8 S8;         // radix 8: 2^18
 };
 // per prime constants of the Bluestein transform
 struct BluePrimeDev {
@@ -136,6 +137,37 @@ conv_split_kernel(uint64_t* __restrict__ cbuf, uint64_t* __restrict__ qbuf, PtrL
       c[p + Q] = o[1];
       c[p + 2 * Q] = o[2];
       c[p + 3 * Q] = o[3];
+    }
+  }
+}
+
+// radix-8 split: cbuf[(ri*batch+b)][8Q]  <->  qbuf[((ri*8+g)*batch+b)][Q]
+__global__ void __launch_bounds__(256)
+conv_split8_kernel(uint64_t* __restrict__ cbuf, uint64_t* __restrict__ qbuf, PtrList cps, int batch,
+                   uint32_t Q, int inverse)
+{
+  const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
+  const ConvPrimeDev* C = (const ConvPrimeDev*)cps.p[ri];
+  const uint64_t q = C->q;
+  uint64_t* c = cbuf + ((size_t)ri * batch + b) * 8 * Q;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < Q; p += gridDim.x * blockDim.x) {
+    uint64_t e[8];
+    if (!inverse) {
+#pragma unroll
+      for (int g = 0; g < 8; g++)
+        e[g] = c[p + (size_t)g * Q];
+      split_fwd8(e, C->S8, q);
+#pragma unroll
+      for (int g = 0; g < 8; g++)
+        qbuf[(((size_t)ri * 8 + g) * batch + b) * Q + p] = e[g];
+    } else {
+#pragma unroll
+      for (int g = 0; g < 8; g++)
+        e[g] = qbuf[(((size_t)ri * 8 + g) * batch + b) * Q + p];
+      split_inv8(e, C->S8, q);
+#pragma unroll
+      for (int g = 0; g < 8; g++)
+        c[p + (size_t)g * Q] = e[g];
     }
   }
 }

@@ -52,4 +52,45 @@ HXD void split_inv4(const uint64_t (&c)[4], const SplitTW& S, uint64_t q, uint64
   a[3] = shoup_full(subm(e1, e3, q), S.iT1q, q);
 }
 
+// ---- radix-8 split (convolution size 2^18 = 8 x 2^15): the first THREE Cooley-Tukey stages on
+// eight elements Q = 2^(k-3) apart, generic form of the above.  T[idx] = psi_rev_full[idx] for
+// idx = 1..7 (stage s uses idx = 2^s + group), iT[idx] their inverses; the inverse folds 1/8 into
+// its last stage (iT1e = T[1]^-1 / 8, eighth = 1/8).
+struct SplitTW8 {
+  TW T[8], iT[8];
+  TW iT1e, eighth;
+};
+HXD void split_fwd8(uint64_t (&e)[8], const SplitTW8& S, uint64_t q)
+{
+  for (int s = 0; s < 3; s++) {
+    const int m = 1 << s, half = 4 >> s;
+    for (int g = 0; g < m; g++)
+      for (int j = 0; j < half; j++) {
+        const int a = g * 2 * half + j, b = a + half;
+        const uint64_t t = shoup_full(e[b], S.T[m + g], q);
+        const uint64_t x = e[a];
+        e[a] = addm(x, t, q);
+        e[b] = subm(x, t, q);
+      }
+  }
+}
+HXD void split_inv8(uint64_t (&e)[8], const SplitTW8& S, uint64_t q)
+{
+  for (int s = 2; s >= 1; s--) {
+    const int m = 1 << s, half = 4 >> s;
+    for (int g = 0; g < m; g++)
+      for (int j = 0; j < half; j++) {
+        const int a = g * 2 * half + j, b = a + half;
+        const uint64_t x = e[a], y = e[b];
+        e[a] = addm(x, y, q);
+        e[b] = shoup_full(subm(x, y, q), S.iT[m + g], q);
+      }
+  }
+  for (int j = 0; j < 4; j++) {
+    const uint64_t x = e[j], y = e[j + 4];
+    e[j] = shoup_full(addm(x, y, q), S.eighth, q);
+    e[j + 4] = shoup_full(subm(x, y, q), S.iT1e, q);
+  }
+}
+
 }  // namespace hx

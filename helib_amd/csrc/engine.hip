@@ -103,8 +103,8 @@ struct ExtPlan {
 
 struct ConvPlan {  // negacyclic NTT of size 2^logn for one prime
   int logn = 0;
-  bool split = false;
-  int pd[4] = {0, 0, 0, 0};  // indices into hx_ctx::d_cprimes
+  int split = 0;             // 0: one row transform; 4 / 8: radix-4 / radix-8 split into sub-transforms
+  int pd[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // indices into hx_ctx::d_cprimes
   hx::ConvPrimeDev* dev = nullptr;
 };
 struct BluePrime {
@@ -613,8 +613,8 @@ static int conv_tables_sub(hx_ctx* c, uint64_t q, uint64_t psi, int OUT, unsigne
 static int conv_plan_create(hx_ctx* c, uint64_t q, int logn, uint64_t psi, ConvPlan* pl)
 {
   pl->logn = logn;
-  pl->split = logn > 15;
-  if (logn < 1 || logn > 17)
+  pl->split = logn > 17 ? 8 : (logn > 15 ? 4 : 0);
+  if (logn < 1 || logn > 18)
     return fail(HX_ERR_UNSUPPORTED, "convolution size 2^%d not supported (m too large)", logn);
   hx::ConvPrimeDev h;
   memset(&h, 0, sizeof h);
@@ -637,6 +637,24 @@ static int conv_plan_create(hx_ctx* c, uint64_t q, int logn, uint64_t psi, ConvP
       case 14: CHK(conv_tables_sub<14>(c, q, psi, 0, 0, &pl->pd[0])); break;
       case 15: CHK(conv_tables_sub<15>(c, q, psi, 0, 0, &pl->pd[0])); break;
     }
+  } else if (pl->split == 8) {
+    for (unsigned g = 0; g < 8; g++)
+      CHK(conv_tables_sub<15>(c, q, psi, 3, g, &pl->pd[g]));
+    auto mk = [&](uint64_t w) {
+      TW t;
+      t.w = w;
+      t.wp = hxh::shoup(w, q);
+      return t;
+    };
+    const uint64_t eighth = hxh::invmod(8 % q, q);
+    for (unsigned idx = 1; idx < 8; idx++) {
+      const uint64_t T = hxh::powmod(psi, hx::brev_bits(idx, logn), q);
+      h.S8.T[idx] = mk(T);
+      h.S8.iT[idx] = mk(hxh::invmod(T, q));
+    }
+    h.S8.T[0] = h.S8.iT[0] = mk(0);
+    h.S8.eighth = mk(eighth);
+    h.S8.iT1e = mk(hxh::mulmod(h.S8.iT[1].w, eighth, q));
   } else {
     for (unsigned g = 0; g < 4; g++) {
       if (logn == 16)
@@ -688,7 +706,9 @@ static int conv_core(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vector
     return fail(HX_ERR_INVALID, "internal: conv chunk too large");
   const ConvPlan& p0 = *plans[0];
   const int logn = p0.logn;
-  const bool split = p0.split;
+  const int split = p0.split;
+  if (split && R > MAX_ROWS / split)
+    return fail(HX_ERR_INVALID, "internal: conv chunk too large");
   const uint32_t N = 1u << logn;
   const bool fwd_only = hatv[0] == nullptr;
   hx::PtrList cps, hats;
@@ -708,23 +728,29 @@ static int conv_core(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vector
     HIPCHK(hipGetLastError());
     return ntt_launch(c, logn, c->d_cprimes, buf, buf, rows, batch, true);
   }
-  const uint32_t Q = N / 4;
+  const uint32_t Q = N / (uint32_t)split;
+  const int lsub = logn - (split == 8 ? 3 : 2);
   for (int r = 0; r < R; r++)
-    for (int g = 0; g < 4; g++)
-      rows.emplace_back(r * 4 + g, plans[r]->pd[g]);
-  hipLaunchKernelGGL(hx::conv_split_kernel, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf,
-                     qbuf, cps, batch, Q, 0);
-  HIPCHK(hipGetLastError());
-  CHK(ntt_launch(c, logn - 2, c->d_cprimes, qbuf, qbuf, rows, batch, false));
+    for (int g = 0; g < split; g++)
+      rows.emplace_back(r * split + g, plans[r]->pd[g]);
+  auto split_launch = [&](int inverse) {
+    if (split == 8)
+      hipLaunchKernelGGL(hx::conv_split8_kernel, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
+                         cps, batch, Q, inverse);
+    else
+      hipLaunchKernelGGL(hx::conv_split_kernel, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
+                         cps, batch, Q, inverse);
+    return hipGetLastError();
+  };
+  HIPCHK(split_launch(0));
+  CHK(ntt_launch(c, lsub, c->d_cprimes, qbuf, qbuf, rows, batch, false));
   if (fwd_only)
     return HX_OK;
-  hipLaunchKernelGGL(hx::conv_pointwise_kernel, grid2(Q, (size_t)R * 4 * batch), dim3(256), 0, c->stream,
-                     qbuf, hats, cps, 4, batch, Q);
+  hipLaunchKernelGGL(hx::conv_pointwise_kernel, grid2(Q, (size_t)R * split * batch), dim3(256), 0, c->stream,
+                     qbuf, hats, cps, split, batch, Q);
   HIPCHK(hipGetLastError());
-  CHK(ntt_launch(c, logn - 2, c->d_cprimes, qbuf, qbuf, rows, batch, true));
-  hipLaunchKernelGGL(hx::conv_split_kernel, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf,
-                     qbuf, cps, batch, Q, 1);
-  HIPCHK(hipGetLastError());
+  CHK(ntt_launch(c, lsub, c->d_cprimes, qbuf, qbuf, rows, batch, true));
+  HIPCHK(split_launch(1));
   return HX_OK;
 }
 
@@ -843,7 +869,7 @@ static int blue_prime_create(hx_ctx* c, int idx)
     c->psi_low.assign(psi.begin(), psi.begin() + c->dq + 1);
   }
   int maxk = std::max(c->bk, std::max(c->n1, c->n2));
-  if (maxk > 17)
+  if (maxk > 18)
     return fail(HX_ERR_UNSUPPORTED, "m too large for the Bluestein path (conv size 2^%d)", maxk);
   if ((int)c->blue.size() <= idx)
     c->blue.resize(idx + 1, nullptr);
@@ -957,7 +983,7 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
   const uint32_t NB = 1u << c->bk, N1 = 1u << c->n1, N2 = 1u << c->n2;
   // chunk so that the convolution buffers stay below ~1 GiB each
   size_t per_row = (size_t)batch * NB * 8;
-  int chunk = (int)std::max<size_t>(1, std::min<size_t>(MAX_ROWS / 4, ((size_t)1 << 30) / per_row));
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>(MAX_ROWS / (c->bk > 17 ? 8 : 4), ((size_t)1 << 30) / per_row));
   for (size_t first = 0; first < rows.size(); first += chunk) {
     const int R = (int)std::min<size_t>(chunk, rows.size() - first);
     NttRows nr;

@@ -150,3 +150,63 @@ extern "C" int split_conv_replay(int logq, uint64_t q, uint64_t psi, const uint6
   }
   return -1;
 }
+
+
+// The same for the radix-8 split (conv size 8 * 2^LOGQ): split_fwd8 + eight sub-transforms with
+// build_tw_tables_sub(OUT = 3) tables + pointwise + inverse.
+template <int LOGQ>
+static int split_conv8(uint64_t q, uint64_t psi /* primitive 2^(LOGQ+4)-th root */, const uint64_t* a,
+                       const uint64_t* b, uint64_t* c)
+{
+  using G = hx::Geo<LOGQ>;
+  const int Q = G::N, FULL = LOGQ + 3;
+  uint64_t psi_inv = pw(psi, q - 2, q);
+  uint64_t qinv = pw((uint64_t)Q % q, q - 2, q);
+  std::vector<std::vector<hx::TW>> F(8, std::vector<hx::TW>(G::TW_TOTAL)), I(8, std::vector<hx::TW>(G::TW_TOTAL));
+  for (unsigned g = 0; g < 8; g++)
+    hx::build_tw_tables_sub<LOGQ>(q, psi, psi_inv, qinv, mm, 3, g, F[g].data(), I[g].data());
+  auto mk = [&](uint64_t w) { hx::TW t; t.w = w; t.wp = (uint64_t)((((u128)w) << 64) / q); return t; };
+  hx::SplitTW8 S;
+  uint64_t eighth = pw(8, q - 2, q);
+  S.T[0] = S.iT[0] = mk(0);
+  for (unsigned idx = 1; idx < 8; idx++) {
+    uint64_t T = pw(psi, hx::brev_bits(idx, FULL), q);
+    S.T[idx] = mk(T);
+    S.iT[idx] = mk(pw(T, q - 2, q));
+  }
+  S.eighth = mk(eighth);
+  S.iT1e = mk(mm(S.iT[1].w, eighth, q));
+  std::vector<uint64_t> qa(8 * Q), qb(8 * Q), fa(8 * Q), fb(8 * Q);
+  for (int p = 0; p < Q; p++) {
+    uint64_t e[8];
+    for (int g = 0; g < 8; g++) e[g] = a[p + g * Q];
+    hx::split_fwd8(e, S, q);
+    for (int g = 0; g < 8; g++) qa[g * Q + p] = e[g];
+    for (int g = 0; g < 8; g++) e[g] = b[p + g * Q];
+    hx::split_fwd8(e, S, q);
+    for (int g = 0; g < 8; g++) qb[g * Q + p] = e[g];
+  }
+  for (int g = 0; g < 8; g++) {
+    sub_transform<LOGQ>(false, F[g].data(), q, qa.data() + g * Q, fa.data() + g * Q);
+    sub_transform<LOGQ>(false, F[g].data(), q, qb.data() + g * Q, fb.data() + g * Q);
+    for (int j = 0; j < Q; j++) fa[g * Q + j] = mm(fa[g * Q + j], fb[g * Q + j], q);
+    sub_transform<LOGQ>(true, I[g].data(), q, fa.data() + g * Q, qa.data() + g * Q);
+  }
+  for (int p = 0; p < Q; p++) {
+    uint64_t e[8];
+    for (int g = 0; g < 8; g++) e[g] = qa[g * Q + p];
+    hx::split_inv8(e, S, q);
+    for (int g = 0; g < 8; g++) c[g * Q + p] = e[g];
+  }
+  return 0;
+}
+
+extern "C" int split_conv8_replay(int logq, uint64_t q, uint64_t psi, const uint64_t* a, const uint64_t* b,
+                                  uint64_t* c)
+{
+  switch (logq) {
+    case 13: return split_conv8<13>(q, psi, a, b, c);
+    case 15: return split_conv8<15>(q, psi, a, b, c);
+  }
+  return -1;
+}

@@ -1195,3 +1195,21 @@ def test_bluestein_auxiliary_prime_path_matches_oracle(hx, m):
     for b in range(2):
         assert np.array_equal(y[:, b], P.o.fft(idx, x[:, b]))
     assert np.array_equal(d.iFFT().download(), x)
+
+
+@pytest.mark.parametrize("m", [65539, 131071])
+def test_bluestein_conv_2_18_radix8_split(hx, m):
+    """General m with 2m-1 > 2^17: the chirp convolution has 2^18 points = eight 2^15-point
+    sub-transforms behind a radix-8 split (conv_core.h split_fwd8/inv8); m = 131071 is the largest
+    prime m with 2m-1 <= 2^18.  Forward and inverse vs the oracle, batch 2."""
+    g = O.PrimeGen(56, m)
+    P = Pair(hx, m, [g.next(), g.next()])
+    idx = [0, 1]
+    x = P.rand(idx, 9, batch=2)
+    d = hx.DoubleCRT(P.g, idx, 2, x)
+    y = d.FFT().download()
+    for b in range(2):
+        assert np.array_equal(y[:, b], P.o.fft(idx, x[:, b]))
+    assert np.array_equal(d.iFFT().download(), x)
+    with pytest.raises(hx.HxError):                      # one step further: conv size 2^19
+        hx.Context(131073).add_prime(O.PrimeGen(56, 131073).next())

@@ -136,3 +136,32 @@ def test_cpp_host_chain_and_prime_set_decision_match_the_python_mirror(m, p, bit
     lo, hi = hc.Ctxt.computeIntervalForMul(a, a)
     assert abs(got["lo"] - lo) < 1e-9 and abs(got["hi"] - hi) < 1e-9
     assert got["common"] == sorted(c.modSizes.getSet4Size(lo, hi, a.primeSet, a.primeSet, False))
+
+
+@pytest.mark.parametrize("radix,logq", [(4, 13), (8, 13)])
+def test_split_convolution_replayed_on_cpu(replay, radix, logq):
+    """The long convolutions of the Bluestein path (conv_core.h): radix-4 split (2^16 / 2^17) and
+    radix-8 split (2^18) = first stages on elements Q apart, then independent Q-point sub-transforms
+    with their own twiddle tables.  Replayed on the CPU with the kernel's phase functions and
+    compared with a direct negacyclic product of two sparse polynomials."""
+    Q = 1 << logq
+    n = radix * Q
+    q = O.PrimeGen(50, 4 * n).next()                     # 2n | q-1 with room
+    psi = O.lib().ho_find_prim_root(q, 2 * n)
+    rng = np.random.default_rng(radix)
+    a, b = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    ia, ib = rng.choice(n, 6, replace=False), rng.choice(n, 5, replace=False)
+    a[ia] = rng.integers(1, q, 6, dtype=np.uint64)
+    b[ib] = rng.integers(1, q, 5, dtype=np.uint64)
+    want = [0] * n
+    for i in ia:
+        for j in ib:
+            k, v = int(i + j), int(a[i]) * int(b[j]) % q
+            if k >= n:                                    # X^n = -1
+                k, v = k - n, (q - v) % q
+            want[k] = (want[k] + v) % q
+    c = np.zeros(n, dtype=np.uint64)
+    fn = replay.split_conv_replay if radix == 4 else replay.split_conv8_replay
+    fn.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert fn(logq, q, psi, a.ctypes.data, b.ctypes.data, c.ctypes.data) == 0
+    assert [int(v) for v in c] == want
