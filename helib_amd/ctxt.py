@@ -297,6 +297,7 @@ class Ctxt:
         self._ln = -math.inf
         self._pending = []     # deferred noise updates waiting for norms still on the device
         self.ksw_auto = {}     # k -> key-switching matrix from s(X^k) to s (PubKey::getKeySWmatrix)
+        self.ksw_map = None    # PubKey::keySwitchMap: k -> first step n on the way to X -> X^k (0: none)
         self.parts = {}
         self.primeSet = frozenset()
         self.ptxtSpace = context.ptxtSpace
@@ -319,6 +320,7 @@ class Ctxt:
         c.primeSet, c.ptxtSpace = self.primeSet, self.ptxtSpace
         c.lnNoise, c.intFactor = self.lnNoise, self.intFactor
         c.ksw_auto = self.ksw_auto
+        c.ksw_map = self.ksw_map
         return c
 
     # ---- noise estimate: ln(noiseBound) ----
@@ -590,18 +592,34 @@ class Ctxt:
         self.parts = new
         return self
 
-    def smartAutomorph(self, k):
-        """Ctxt::smartAutomorph (src/Ctxt.cpp:2462-2515) when a matrix for k itself is available
-        (the reference walks a tree of generators' matrices, PubKey::getNextKSWmatrix; that walk is
-        key management and stays with the caller: apply the steps one by one)."""
-        k %= self.context.m
-        if k == 1 or not self.parts:
-            return self
+    def _firstStep(self, k):
+        """PubKey::getNextKSWmatrix(k).fromKey.getPowerOfX(): k itself when there is a matrix for it
+        and no map was set, otherwise the first edge of the BFS path (PubKey::setKeySwitchMap)."""
+        if self.ksw_map is not None:
+            amt = self.ksw_map[k]
+            if amt == 0 or amt not in self.ksw_auto:
+                raise LookupError(f"no key-switching matrices for k={k}")   # LogicError in the reference
+            return amt
         if k not in self.ksw_auto:
             raise LookupError(f"no key-switching matrices for k={k}")
+        return k
+
+    def smartAutomorph(self, k):
+        """Ctxt::smartAutomorph (src/Ctxt.cpp:2462-2515): re-linearise, then walk the path of
+        available matrices -- automorph(amt), reLinearize, k <- k * amt^-1 -- until k = 1."""
+        m = self.context.m
+        k %= m
+        if k == 1 or not self.parts:
+            return self
+        if math.gcd(k, m) != 1:
+            raise ValueError("k must be in Zm*")
+        self._firstStep(k)          # isReachable, before anything is touched
         self.reLinearize()          # canonical form first
-        self.automorph(k)
-        self.reLinearize()
+        while k != 1:
+            amt = self._firstStep(k)
+            self.automorph(amt)
+            self.reLinearize()
+            k = k * pow(amt, -1, m) % m
         return self
 
     def multiplyBy(self, other):
@@ -704,17 +722,24 @@ class BasicAutomorphPrecon:
         part0 = c.parts["1"].copy()
         part0.automorph(k)
         part0.addPrimesAndScale(sp)
+        res.ksw_map = c.ksw_map
         if len(c.parts) == 1:        # only the constant part: nothing to key-switch (:145-151)
             res.parts = {"1": part0}
             res.lnNoise = c.lnNoise + ctx.logOfProduct(sp)
             return res
-        W = c.ksw_auto.get(k)
-        if W is None:
-            raise LookupError(f"no key-switching matrices for k={k}")
+        amt = c._firstStep(k)          # first key-switching matrix on the way to k (:153-162)
+        W = c.ksw_auto[amt]
+        if amt != k:                   # the constant part was rotated by k above: redo it by amt
+            part0 = c.parts["1"].copy()
+            part0.automorph(amt)
+            part0.addPrimesAndScale(sp)
         dg = self.polyDigits.copy()
-        dg.automorph(k)
+        dg.automorph(amt)
         part1 = c.ops.zerosLike(part0)
         c.ops.keySwitchDigits(dg, W, part0, part1)
         res.parts = {"1": part0, "s": part1}
         res.lnNoise = self.lnNoise
+        res.ksw_map = c.ksw_map
+        if amt != k:                   # more automorphisms to do: the usual smartAutomorph (:177-181)
+            res.smartAutomorph(k * pow(amt, -1, ctx.m) % ctx.m)
         return res

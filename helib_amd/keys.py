@@ -141,6 +141,33 @@ class PubKey:
     def getSKeyBound(self):
         return self.skBounds[0]
 
+    # -- PubKey::setKeySwitchMap / isReachable / getNextKSWmatrix (src/keys.cpp:122-172, 226-250) --
+    def setKeySwitchMap(self):
+        """BFS over Zm* from 1 along the available matrices W[s(X^n) -> s]: keySwitchMap[k] = the n
+        of the matrix to use as the FIRST step of the automorphism X -> X^k (0: unreachable)."""
+        m = self.cc.m
+        edges = [xp for (sp, xp) in self.keySwitching if sp == 1 and xp > 1]   # insertion order, as the reference's list
+        kmap = [0] * m
+        queue, head = [1], 0
+        while head < len(queue):
+            cur = queue[head]
+            head += 1
+            for n in edges:
+                nxt = cur * n % m
+                if kmap[nxt] == 0 and nxt != 1:
+                    kmap[nxt] = n
+                    queue.append(nxt)
+        self.keySwitchMap = kmap
+        return kmap
+
+    def isReachable(self, k):
+        km = getattr(self, "keySwitchMap", None)
+        k %= self.cc.m
+        return k == 1 or (km is not None and km[k] != 0)
+
+    def getNextKSWmatrix(self, k):
+        return self.keySwitching[(1, self.keySwitchMap[k % self.cc.m])]
+
     def _newCtxt(self, c0, c1, noiseBound, ptxtSpace):
         relin = self.keySwitching.get((2, 1))
         ct = hc.Ctxt(self.cc, self.be.ops, relin.W if relin else None,
@@ -153,6 +180,7 @@ class PubKey:
         for (sp, xp), ks in self.keySwitching.items():
             if sp == 1 and xp > 1:
                 ct.ksw_auto[xp] = ks.W
+        ct.ksw_map = getattr(self, "keySwitchMap", None)
         return ct
 
     def _ptxt_fixed(self, ptxt, primeSet, ptxtSpace):

@@ -480,6 +480,32 @@ struct KeySet {
   std::map<long, const KeySwitch*> automorph;   // k -> s(X^k) -> s
   long ptxtSpace = 0;                           // KeySwitch::ptxtSpace
   double lnNoise = 0;                           // ln KeySwitch::noiseBound
+  std::vector<long> keySwitchMap;               // k -> first step on the way to X -> X^k (0: none)
+
+  // PubKey::setKeySwitchMap (src/keys.cpp:122-172): BFS over Zm* from 1 along the available matrices
+  void setKeySwitchMap(long m)
+  {
+    keySwitchMap.assign((size_t)m, 0);
+    std::vector<long> queue{1};
+    for (size_t head = 0; head < queue.size(); head++) {
+      long cur = queue[head];
+      for (auto& kv : automorph) {
+        long nxt = (long)((unsigned __int128)cur * (unsigned long)kv.first % (unsigned long)m);
+        if (nxt != 1 && keySwitchMap[(size_t)nxt] == 0) {
+          keySwitchMap[(size_t)nxt] = kv.first;
+          queue.push_back(nxt);
+        }
+      }
+    }
+  }
+  bool isReachable(long k) const { return k == 1 || firstStep(k) != 0; }
+  // PubKey::getNextKSWmatrix(k).fromKey.getPowerOfX()
+  long firstStep(long k) const
+  {
+    if (!keySwitchMap.empty())
+      return keySwitchMap[(size_t)k];
+    return automorph.count(k) ? k : 0;
+  }
 };
 
 class Ctxt {
@@ -714,18 +740,34 @@ public:
     }
     parts = std::move(np);
   }
-  // Ctxt::smartAutomorph when a matrix for k itself is available
+  // Ctxt::smartAutomorph (src/Ctxt.cpp:2462-2515): walk the path of available matrices
   void smartAutomorph(long k)
   {
     long m = context->m;
     k = ((k % m) + m) % m;
     if (k == 1 || parts.empty())
       return;
-    if (!keys->automorph.count(k))
+    if (std::gcd(k, m) != 1)
+      throw InvalidArgument("k must be in Zm*");
+    if (!keys->isReachable(k))
       throw LogicError("no key-switching matrices for k=" + std::to_string(k));
     reLinearize();
-    automorph(k);
-    reLinearize();
+    while (k != 1) {
+      long amt = keys->firstStep(k);
+      if (amt == 0)
+        throw LogicError("no key-switching matrices for k=" + std::to_string(k));
+      automorph(amt);
+      reLinearize();
+      // k *= amt^-1 mod m
+      long inv = 1, a = amt % m, e = ChainContext::eulerPhi(m) - 1;
+      while (e) {
+        if (e & 1)
+          inv = (long)((unsigned __int128)inv * (unsigned long)a % (unsigned long)m);
+        a = (long)((unsigned __int128)a * (unsigned long)a % (unsigned long)m);
+        e >>= 1;
+      }
+      k = (long)((unsigned __int128)k * (unsigned long)inv % (unsigned long)m);
+    }
   }
   void cleanUp()
   {

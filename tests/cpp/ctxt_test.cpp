@@ -7,7 +7,7 @@
 // in : int64 m, p, bits, k, measure, nprimes, D, nall, L, N ; uint64 roots[nprimes] ;
 //      uint64 kb[D][nall][N], ka[D][nall][N], kbk[..], kak[..] (matrix for s(X^k)) ;
 //      uint64 a0[L][N], a1[L][N], b0[L][N], b1[L][N]
-// out: per result (product, product+product, rotated product):
+// out: per result (product, product+product, rotated product, rotated twice more through the map):
 //      int64 nprimes_in_set, intFactor, nparts ; double lnNoise ; int64 primeSet[] ;
 //      per part: int64 powerOfS, powerOfX, nrows, idx[nrows] ; uint64 rows[nrows][N]
 #include <cstdio>
@@ -97,11 +97,14 @@ int main(int argc, char** argv)
     dump(o, sum);
     ca.smartAutomorph(k);
     dump(o, ca);
+    keys.setKeySwitchMap(m);  // BFS over Zm*: k*k is reachable in two steps
+    ca.smartAutomorph((long)((unsigned __int128)k * (unsigned long)k % (unsigned long)m));
+    dump(o, ca);
     // error behaviour: no matrix for this rotation -> LogicError, k outside Zm* -> InvalidArgument
     int errs = 0;
     try {
       Ctxt t = ca;
-      t.smartAutomorph(k == 5 ? 7 : 5);
+      t.smartAutomorph(m - 1);   // -1 is not a power of k
     } catch (const LogicError&) {
       errs |= 1;
     }

@@ -976,6 +976,13 @@ def test_hoisted_automorphisms_gpu_vs_oracle(hx, m, p, bits, monkeypatch):
         ref.smartAutomorph(k)
         for h in ("1", "s"):
             assert np.array_equal(gr.parts[h].download(), ref.parts[h].download())
+    # a rotation that needs two steps of the key-switch map (3 then 3): first step hoisted, rest plain
+    for sk in (gsk, osk):
+        sk.setKeySwitchMap()
+    g2, o2 = gsk.Encrypt(ma), osk.Encrypt(ma)
+    gr, orr = hc.BasicAutomorphPrecon(g2).automorph(9), hc.BasicAutomorphPrecon(o2).automorph(9)
+    same(gr, orr)
+    assert gsk.Decrypt(gr) == osk.Decrypt(orr)
     ga.multiplyBy(gsk.Encrypt(mb))
     oa.multiplyBy(osk.Encrypt(mb))
     gpre, opre = hc.BasicAutomorphPrecon(ga), hc.BasicAutomorphPrecon(oa)
@@ -1056,10 +1063,18 @@ def test_cpp_host_ctxt_matches_python_mirror(hx, m, p, bits, k, measure, tmp_pat
     gsum = ga.clone()
     gsum.addCtxt(ga)
     ga.smartAutomorph(k)
+    rot1 = ga.clone()
+    kmap = [0] * m                   # PubKey::setKeySwitchMap with the single edge k
+    cur = k
+    while cur != 1 and kmap[cur] == 0:
+        kmap[cur] = k
+        cur = cur * k % m
+    ga.ksw_map = kmap
+    ga.smartAutomorph(k * k % m)
     buf = open(fout, "rb").read()
     off = 0
     hname = {(0, 1): "1", (1, 1): "s"}
-    for want in (prod, gsum, ga):
+    for want in (prod, gsum, rot1, ga):
         nset, intFactor, nparts = struct.unpack_from("<3q", buf, off)
         (ln,) = struct.unpack_from("<d", buf, off + 24)
         off += 32
@@ -1084,7 +1099,8 @@ def test_cpp_host_ctxt_matches_python_mirror(hx, m, p, bits, k, measure, tmp_pat
         from tests import bgv_ref as B
         ab = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
         assert T.decrypt(cc, P.o, s, prod, rows) == ab
-        assert T.decrypt(cc, P.o, s, ga, rows) == [int(v) for v in B.automorph_mod_phi(ab, m, k, p)]
+        assert T.decrypt(cc, P.o, s, rot1, rows) == [int(v) for v in B.automorph_mod_phi(ab, m, k, p)]
+        assert T.decrypt(cc, P.o, s, ga, rows) == [int(v) for v in B.automorph_mod_phi(ab, m, pow(k, 3, m), p)]
 
 
 def test_threads_on_distinct_polys_of_one_context(hx):

@@ -175,3 +175,41 @@ def test_constants_multByConstant_addConstant(m, p, bits):
     assert sk.Decrypt(cd) == [int(v) for v in B.polymul_mod_phi(abc, mc, m, p)]
     raw = sk.Decrypt(cd, raw=True)
     assert math.log(be.embeddingLargestCoeff(np.array(raw, dtype=np.float64))) <= cd.lnNoise
+
+
+def test_keySwitchMap_bfs_and_multi_step_rotations():
+    """PubKey::setKeySwitchMap (src/keys.cpp:122-172): BFS over Zm* along the available matrices;
+    Ctxt::smartAutomorph then walks the path (src/Ctxt.cpp:2497-2511), and BasicAutomorphPrecon takes
+    the first step with the hoisted digits and the rest the usual way (src/matmul.cpp:160-181)."""
+    m, p = 128, 257
+    cc, octx, be, sk = setup(m, p, 150)
+    for k in (3, 9):
+        sk.GenKeySWmatrix(1, k)
+    kmap = sk.setKeySwitchMap()
+    assert kmap[3] == 3 and kmap[9] in (3, 9) and kmap[27] in (3, 9) and kmap[81] in (3, 9)
+    assert sk.isReachable(27) and sk.isReachable(1) and not sk.isReachable(5) and not sk.isReachable(127)
+    # every reachable node's first step leads to a node that is closer (or 1)
+    for k in range(m):
+        if kmap[k]:
+            rest = k * pow(kmap[k], -1, m) % m
+            assert rest == 1 or kmap[rest]
+    assert sk.getNextKSWmatrix(27).fromXPower == kmap[27]
+    rng = np.random.default_rng(33)
+    ma = rng.integers(0, p, size=cc.phim)
+    for k in (27, 81, 3 ** 7 % m):
+        ca = sk.Encrypt(ma)
+        assert ca.ksw_map is kmap
+        want = [int(v) for v in B.automorph_mod_phi(ma, m, k, p)]
+        c1 = ca.clone()
+        c1.smartAutomorph(k)
+        assert sk.Decrypt(c1) == want
+        c2 = hc.BasicAutomorphPrecon(ca).automorph(k)
+        assert sk.Decrypt(c2) == want
+        for h in ("1", "s"):        # power-of-two m: identical to the plain walk
+            assert np.array_equal(c1.parts[h].download(), c2.parts[h].download())
+    with pytest.raises(LookupError):
+        sk.Encrypt(ma).smartAutomorph(5)
+    with pytest.raises(LookupError):
+        hc.BasicAutomorphPrecon(sk.Encrypt(ma)).automorph(127)
+    with pytest.raises(ValueError):
+        sk.Encrypt(ma).smartAutomorph(6)
