@@ -10,6 +10,9 @@ workload : (default `bgv32768`) BGV m=32768, p=65537, bits=950 -> L=16 x 60-bit 
                            4 parts) + tensorProduct
              reLinearize = dropSmallAndSpecialPrimes (3 parts) + addPrimesAndScale + key switch
            with the operand copy outside the timed region (state.PauseTiming() in the reference).
+           Inputs as the reference benchmark prepares them (benchmarks/bgv_basic.cpp:144-157): a key
+           pair + relinearisation matrix and public-key encryptions of random plaintexts
+           (helib_amd.keys); the last product is decrypted and checked (config.verified).
            Host control flow = helib_amd.ctxt (restating src/Ctxt.cpp); polynomial work on the GPU.
            Added noise is MEASURED as in the reference's default build (embeddingLargestCoeff of
            the mod-switch deltas and of the key-switch digits, src/Ctxt.cpp:466-530,
@@ -201,21 +204,69 @@ def run_fixed(hx, ctx, primes, shape, B, steps, warmup, rng, sync, barrier):
     return time.perf_counter() - t0
 
 
-def run_fresh(hx, hc, cc, ctx, B, steps, warmup, rng, sync, barrier, measure=True):
+def real_inputs(hx, hc, cc, ctx, B, seed):
+    """What benchmarks/bgv_basic.cpp:144-157 prepares: a key pair with its relinearisation matrix and
+    two fresh public-key encryptions of random plaintexts -- B independent pairs, generated with
+    helib_amd.keys on the device and packed along the batch axis.  Returns the two batched
+    ciphertexts and a checker for element b of a product."""
+    from helib_amd import keys as hk
+    sk = hk.SecKey(cc, hk.HxBackend(ctx, cc), seed)
+    sk.GenSecKey(maxDegKswitch=2)
+    rng = np.random.default_rng(seed + 1)
+    p, n, L = cc.ptxtSpace, cc.phim, len(cc.ctxtPrimes)
+    msgs = rng.integers(0, p, size=(2, B, n))
+    rows = np.empty((2, 2, L, B, n), dtype=np.uint64)
+    first = None
+    for j in range(2):
+        for b in range(B):
+            ct = sk.Encrypt(msgs[j, b])
+            first = first or ct
+            assert ct.parts["1"].getIndexSet() == list(cc.ctxtPrimes)
+            rows[j, 0, :, b] = ct.parts["1"].download()[:, 0]
+            rows[j, 1, :, b] = ct.parts["s"].download()[:, 0]
+    out = []
+    for j in range(2):
+        c = first.clone()
+        c.parts = {"1": hx.DoubleCRT(ctx, cc.ctxtPrimes, B, rows[j, 0]),
+                   "s": hx.DoubleCRT(ctx, cc.ctxtPrimes, B, rows[j, 1])}
+        out.append(c)
+
+    def check(result, b=0):
+        """decrypt(result[b]) == m_a[b] * m_b[b] mod (Phi_m, p)  (m a power of two: X^n + 1)"""
+        one = result.clone()
+        one.parts = {h: hx.DoubleCRT(ctx, q.getIndexSet(), 1, q.download()[:, b:b + 1])
+                     for h, q in result.parts.items()}
+        got = sk.Decrypt(one)
+        full = np.convolve(msgs[0, b].astype(np.int64), msgs[1, b].astype(np.int64))
+        want = (full[:n] - np.append(full[n:], 0)) % p
+        if got != [int(v) for v in want]:
+            raise SystemExit("bench: decrypt(multiplyBy(a, b)) != a*b -- results are wrong")
+        return True
+    return out[0], out[1], check
+
+
+def run_fresh(hx, hc, cc, ctx, B, steps, warmup, rng, sync, barrier, measure=True, inputs="real", seed=7,
+              prepared=None):
     """measure=True: added noise measured as in the reference's default build (canonical-embedding
     norms of the mod-switch deltas and of the key-switch digits, evaluated on the device);
-    False: the reference's alternative high-probability bounds, no norms."""
+    False: the reference's alternative high-probability bounds, no norms.
+    inputs="real": keys and ciphertexts from helib_amd.keys, the last product is decrypted and
+    checked against the plaintext product; "uniform": uniform rows (no keys)."""
     hc.Ctxt.measure = measure
     n = ctx.phim
     allp = cc.ctxtPrimes + cc.specialPrimes
     D = len(cc.digits)
-    kb = np.stack([uniform_rows(rng, cc.primes, allp, 1, n)[:, 0] for _ in range(D)])
-    ka = np.stack([uniform_rows(rng, cc.primes, allp, 1, n)[:, 0] for _ in range(D)])
-    W = hx.KeySwitch(ctx, allp, kb, ka)
-    base = [hx.DoubleCRT(ctx, cc.ctxtPrimes, B, uniform_rows(rng, cc.primes, cc.ctxtPrimes, B, n))
-            for _ in range(4)]
-    fa = hc.Ctxt.fresh(cc, hx, base[0], base[1], ksw=W)
-    fb = hc.Ctxt.fresh(cc, hx, base[2], base[3], ksw=W)
+    check = None
+    if inputs == "real":
+        fa, fb, check = prepared or real_inputs(hx, hc, cc, ctx, B, seed)
+    else:
+        kb = np.stack([uniform_rows(rng, cc.primes, allp, 1, n)[:, 0] for _ in range(D)])
+        ka = np.stack([uniform_rows(rng, cc.primes, allp, 1, n)[:, 0] for _ in range(D)])
+        W = hx.KeySwitch(ctx, allp, kb, ka)
+        base = [hx.DoubleCRT(ctx, cc.ctxtPrimes, B, uniform_rows(rng, cc.primes, cc.ctxtPrimes, B, n))
+                for _ in range(4)]
+        fa = hc.Ctxt.fresh(cc, hx, base[0], base[1], ksw=W)
+        fb = hc.Ctxt.fresh(cc, hx, base[2], base[3], ksw=W)
 
     def clones(k):   # operand copies are made OUTSIDE the timed region (state.PauseTiming() in
         return [(fa.clone(), fb.clone()) for _ in range(k)]   # benchmarks/bgv_basic.cpp:158-164)
@@ -254,7 +305,8 @@ def run_fresh(hx, hc, cc, ctx, B, steps, warmup, rng, sync, barrier, measure=Tru
         host += t1 - t0
         done += k
         del pairs
-    return total, sorted(last.primeSet), host
+    verified = bool(check(last, 0) and check(last, B - 1)) if check else False
+    return total, sorted(last.primeSet), host, verified
 
 
 def ntt_roofline(hx, ctx, primes_list, own, sp, digits, B, rng, iters):
@@ -298,6 +350,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=60, help="multiplies timed on the CPU (0 = skip); 60 = about 15 s of one core")
     ap.add_argument("--ntt-iters", type=int, default=20)
     ap.add_argument("--workload", default="bgv32768", choices=["bgv32768", "bgv32768_fixed", "ckks65536"])
+    ap.add_argument("--inputs", default="real", choices=["real", "uniform"],
+                    help="bgv32768: real keys + encryptions (the product is decrypted and checked) or uniform rows")
     ap.add_argument("--bits", type=int, default=950,
                     help="bgv32768 only: ContextBuilder::bits; 950 = the L~16 shape the metric is quoted on, "
                          "6400 = the reference's own benchmarks/bgv_basic.cpp:247 parameter (L=107, K=36)")
@@ -327,11 +381,14 @@ def main():
         ctx.set_stream(stream)
         n = ctx.phim
         l, k, d = len(cc.ctxtPrimes), len(cc.specialPrimes), len(cc.digits)
-        dtb, _, _ = run_fresh(hx, hc, cc, ctx, B, args.steps, args.warmup, rng, sync, group.barrier,
-                              measure=False)
+        hc.Ctxt.measure = True
+        prepared = real_inputs(hx, hc, cc, ctx, B, 7 + rank) if args.inputs == "real" else None
+        dtb, _, _, _ = run_fresh(hx, hc, cc, ctx, B, args.steps, args.warmup, rng, sync, group.barrier,
+                                 measure=False, inputs=args.inputs, prepared=prepared)
         dtb = group.max_over_ranks(dtb)
-        dt, res_primes, host_s = run_fresh(hx, hc, cc, ctx, B, args.steps, args.warmup, rng, sync,
-                                           group.barrier, measure=True)
+        dt, res_primes, host_s, verified = run_fresh(hx, hc, cc, ctx, B, args.steps, args.warmup, rng, sync,
+                                                     group.barrier, measure=True, inputs=args.inputs,
+                                                     prepared=prepared)
         dt = group.max_over_ranks(dt)
         # the kernel-level pipeline alone (ctxt primes as rows 0.., specials after)
         shape = dict(M=cc.m, L=l, K=k, digits=[[i - cc.ctxtPrimes[0] for i in dg] for dg in cc.digits])
@@ -348,7 +405,7 @@ def main():
                     "Ctxt::multiplyBy on FRESH ciphertexts = multLowLvl (bringToSet x2 + tensorProduct) + "
                     "reLinearize (dropSmallAndSpecialPrimes + key switch), added noise MEASURED as in the "
                     "reference (device canonical-embedding norms, read back lazily); operand "
-                    "copies untimed")
+                    "copies untimed; synthetic random plaintexts")
         per_mult = algorithmic_bytes_fresh(n, l, k, d)
         extra = {"bound_noise_mult_per_s": round(world * B * args.steps / dtb, 1),
                  "bound_noise_ms_per_step": round(dtb / args.steps * 1e3, 4),
@@ -356,7 +413,12 @@ def main():
                  "fixed_level_ms_per_step": round(dtf / args.steps * 1e3, 4),
                  "fixed_level_algorithmic_MB_per_mult": round(algorithmic_bytes_fixed(n, l, k, d) / 1e6, 2),
                  "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 4),
-                 "result_primes": res_primes}
+                 "result_primes": res_primes,
+                 "inputs": ("key pair, relinearisation matrix and public-key encryptions of random plaintexts "
+                            "from helib_amd.keys (as benchmarks/bgv_basic.cpp:144-157)" if args.inputs == "real"
+                            else "uniform rows, no keys"),
+                 "verified": ("decrypt(last product, batch elements 0 and B-1) == m_a*m_b mod (X^N+1, p)"
+                              if verified else None)}
         if rank == 0:
             roof = ntt_roofline(hx, sub, fixed_primes, list(range(l)), list(range(l, l + k)),
                                 shape["digits"], B, rng, args.ntt_iters)

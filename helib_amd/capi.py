@@ -58,6 +58,24 @@ SYMBOLS = [
 ]
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so.7 and dlopens it by
+    path; if this library (linked against /opt/rocm's copy of the same SONAME) was loaded first, the
+    process ends up with two runtimes and the first one loses its devices (hipGetDeviceCount = 0).
+    Loading torch's copy first -- without importing torch -- makes both resolve to one runtime
+    whatever the import order.  No torch installed: nothing to do."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load the HIP extension; fails loudly when it has not been built."""
     global _lib
@@ -66,6 +84,7 @@ def lib():
             raise ImportError(
                 f"{_SO} is missing: build it with `python -m helib_amd.build` "
                 "(there is no CPU fallback)")
+        _preload_hip_runtime()
         L = C.CDLL(_SO)
         L.hx_last_error.restype = C.c_char_p
         L.hx_version.restype = C.c_char_p

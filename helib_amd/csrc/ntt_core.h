@@ -37,24 +37,6 @@
 #define HXD inline
 #endif
 
-// Compiler-only fence: stops hipcc from hoisting every twiddle load of a pass to
-// its top (31 twiddles x 4 VGPRs), which costs a wave of occupancy per SIMD.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_NO_TW_FENCE)
-#ifndef HX_TW_FENCE_KIND
-#define HX_TW_FENCE_KIND 0
-#endif
-#if HX_TW_FENCE_KIND == 0
-#define HX_TW_FENCE() asm volatile("" ::: "memory")
-#else
-#define HX_TW_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-#else
-#define HX_TW_FENCE() ((void)0)
-#endif
-#ifndef HX_TW_FENCE_MASK
-#define HX_TW_FENCE_MASK 3
-#endif
-
 namespace hx {
 
 struct TW {
