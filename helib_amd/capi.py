@@ -511,8 +511,9 @@ def normsFlush(poly):
 
 
 def supportsNorms(m):
-    """Measured (PGFFT-style) noise norms run on the device for power-of-two m."""
-    return m >= 2 and (m & (m - 1)) == 0
+    """Measured (PGFFT-style) noise norms run on the device: power-of-two m (one N/2-point complex
+    transform) and general m up to 131072 (complex-double Bluestein)."""
+    return m >= 2 and ((m & (m - 1)) == 0 or m <= 131072)
 
 
 def embeddingLargestCoeff(context, f):

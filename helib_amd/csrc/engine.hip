@@ -171,6 +171,10 @@ struct hx_ctx {
   double xs_inv_qd = 0;
   bool want_fdelta = false;  // the caller also wants the fdelta coefficients on the host
   double2* d_wtab = nullptr;           // W^k, k < N, W = exp(2 pi i / m)  (m a power of two)
+  // general m (complex-double Bluestein, norm_kernels.h): v_k, exp(2 pi i k/P) (k < P/2), transform
+  // of the chirp, and the transform-domain work buffer
+  double2 *d_bn_v = nullptr, *d_bn_w = nullptr, *d_bn_chat = nullptr, *d_bn_Z = nullptr;
+  size_t bn_rows_cap = 0;
   unsigned long long* d_norm2 = nullptr;
   size_t norm_cap = 0;
   // deferred read-back of norms (hx_ctx_defer_norms): squared norms land in pinned host slots,
@@ -346,6 +350,10 @@ static void ctx_free(hx_ctx* c)
     hipFree(kv.second);
   hipFree(c->d_frac);
   hipFree(c->d_wtab);
+  hipFree(c->d_bn_v);
+  hipFree(c->d_bn_w);
+  hipFree(c->d_bn_chat);
+  hipFree(c->d_bn_Z);
   hipFree(c->d_norm2);
   for (auto* v : {&c->norm_pending, &c->norm_free})
     for (auto& np : *v) {
@@ -1748,11 +1756,14 @@ static void clear_args(ExtArgs& a)
 // canonical-embedding norms on the device (src/norms.cpp:129-262)
 // ------------------------------------------------------------------
 // Arms the "fraction" side output of the exact-RNS kernels: `doubles` values of room.
+// size of the complex Bluestein transform of the general-m norms: the integer transform's 2^bk
+static int bn_logp(const hx_ctx* c) { return next_pow2_exp(2 * c->m - 1); }
+
 static int frac_begin(hx_ctx* c, size_t doubles)
 {
-  if (!c->pow2)
+  if (!c->pow2 && bn_logp(c) > 18)
     return fail(HX_ERR_UNSUPPORTED,
-                "device embedding norms need m a power of two (for general m the host keeps "
+                "device embedding norms need m a power of two or m <= 131072 (otherwise the host keeps "
                 "the reference's noiseBoundForUniform bound)");
   if (c->frac_cap < doubles) {
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1795,13 +1806,103 @@ static int flush_xs(hx_ctx* c)
 
 // out_host[r] = max_j |f_r(W^(2j+1))| for `rows` real polynomials of N coefficients at d_f.
 // Synchronises the stream (the caller needs the numbers on the host).
+// general m: tables of the complex-double Bluestein transform (norm_kernels.h), made on first use
+static int bnorm_setup(hx_ctx* c)
+{
+  if (c->d_bn_chat)
+    return HX_OK;
+  const int bk = bn_logp(c);
+  if (bk > 18)
+    return fail(HX_ERR_UNSUPPORTED, "device embedding norms: m too large (2m-1 > 2^18)");
+  const uint64_t m = c->m;
+  const size_t P = (size_t)1 << bk;
+  const long double pi = 3.141592653589793238462643383279502884L;
+  std::vector<double> v(2 * m), cv(2 * P, 0.0), w(P);
+  for (uint64_t k = 0; k < m; k++) {
+    const uint64_t k2 = (uint64_t)(((hxh::u128)k * k) % (2 * m));  // exact angle reduction
+    const long double ang = pi * (long double)k2 / (long double)m;
+    const double cr = (double)cosl(ang), si = (double)sinl(ang);
+    v[2 * k] = cr;
+    v[2 * k + 1] = si;
+    cv[2 * k] = cr;  // c_k = conj(v_k), at k and at P-k
+    cv[2 * k + 1] = -si;
+    if (k) {
+      cv[2 * (P - k)] = cr;
+      cv[2 * (P - k) + 1] = -si;
+    }
+  }
+  for (size_t k = 0; k < P / 2; k++) {
+    const long double ang = 2 * pi * (long double)k / (long double)P;
+    w[2 * k] = (double)cosl(ang);
+    w[2 * k + 1] = (double)sinl(ang);
+  }
+  double2* d_cv = nullptr;
+  HIPCHK(hipMalloc((void**)&c->d_bn_v, sizeof(double) * 2 * m));
+  HIPCHK(hipMalloc((void**)&c->d_bn_w, sizeof(double) * P));
+  HIPCHK(hipMalloc((void**)&c->d_bn_chat, sizeof(double) * 2 * P));
+  HIPCHK(hipMalloc((void**)&d_cv, sizeof(double) * 2 * P));
+  HIPCHK(hipMemcpy(c->d_bn_v, v.data(), sizeof(double) * 2 * m, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_bn_w, w.data(), sizeof(double) * P, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_cv, cv.data(), sizeof(double) * 2 * P, hipMemcpyHostToDevice));
+  static bool attr = false;
+  if (!attr) {
+    HIPCHK(hipFuncSetAttribute((const void*)hx::bnorm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               16 << hx::NORM_MAX_LOGH));
+    HIPCHK(hipFuncSetAttribute((const void*)hx::bnorm_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               16 << hx::NORM_MAX_LOGH));
+    attr = true;
+  }
+  const int logp = bk, logh = std::min(logp, hx::NORM_MAX_LOGH);
+  const unsigned H = 1u << logh, S = (unsigned)(P >> logh);
+  const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, H / 4));
+  hipLaunchKernelGGL(hx::bnorm_fwd_kernel, dim3(S), dim3(threads), std::max<size_t>(16 * (size_t)H, 256), c->stream,
+                     (const double*)nullptr, (const double2*)nullptr, (const double2*)d_cv, c->d_bn_w,
+                     (const double2*)nullptr, c->d_bn_chat, logp, logh, c->phim, 1);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(d_cv));
+  return HX_OK;
+}
+
+// squared norms of `rows` polynomials into c->d_norm2 (general m)
+static int embed_norms_general(hx_ctx* c, const double* d_f, int rows)
+{
+  CHK(bnorm_setup(c));
+  const int logp = bn_logp(c), logh = std::min(logp, hx::NORM_MAX_LOGH);
+  const size_t P = (size_t)1 << logp;
+  const unsigned H = 1u << logh, S = (unsigned)(P >> logh);
+  const size_t cap = std::max<size_t>(1, ((size_t)1 << 28) / (16 * P));  // <= 256 MiB of work buffer
+  if (c->bn_rows_cap < std::min<size_t>(cap, (size_t)rows)) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(c->d_bn_Z);
+    c->d_bn_Z = nullptr;
+    c->bn_rows_cap = std::min<size_t>(cap, (size_t)rows);
+    HIPCHK(hipMalloc((void**)&c->d_bn_Z, c->bn_rows_cap * P * 16));
+  }
+  const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, H / 4));
+  const size_t lds = std::max<size_t>(16 * (size_t)H, 256);
+  for (size_t r0 = 0; r0 < (size_t)rows; r0 += c->bn_rows_cap) {
+    const unsigned nr = (unsigned)std::min<size_t>(c->bn_rows_cap, (size_t)rows - r0);
+    hipLaunchKernelGGL(hx::bnorm_fwd_kernel, dim3(nr * S), dim3(threads), lds, c->stream,
+                       d_f + r0 * c->phim, (const double2*)c->d_bn_v, (const double2*)nullptr, c->d_bn_w,
+                       (const double2*)c->d_bn_chat, c->d_bn_Z, logp, logh, c->phim, 0);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(hx::bnorm_inv_kernel, dim3(nr * S), dim3(threads), lds, c->stream, c->d_bn_Z, c->d_bn_w,
+                       logp, logh);
+    HIPCHK(hipGetLastError());
+    const unsigned gx = std::min<unsigned>(64u, (c->phim + 255u) / 256u);
+    hipLaunchKernelGGL(hx::bnorm_max_kernel, dim3(gx, nr), dim3(256), 0, c->stream, (const double2*)c->d_bn_Z,
+                       c->d_bn_w, c->d_zms, c->phim, logp, logh, c->d_norm2 + r0);
+    HIPCHK(hipGetLastError());
+  }
+  return HX_OK;
+}
+
 static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
 {
-  if (!c->pow2)
-    return fail(HX_ERR_UNSUPPORTED, "device embedding norms need m a power of two");
   const uint32_t N = c->phim;
   const int logn = c->logn;
-  if (!c->d_wtab) {
+  if (c->pow2 && !c->d_wtab) {
     std::vector<double> h(2 * (size_t)N);
     const long double two_pi = 6.283185307179586476925286766559005768394L;
     for (uint32_t k = 0; k < N; k++) {
@@ -1823,7 +1924,10 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   }
   HIPCHK(hipMemsetAsync(c->d_norm2, 0, sizeof(unsigned long long) * (size_t)rows, c->stream));
   static bool attr = false;
-  if (!attr) {
+  if (!c->pow2) {
+    CHK(flush_xs(c));
+    CHK(embed_norms_general(c, d_f, rows));
+  } else if (!attr) {
     HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_kernel,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                16 << hx::NORM_MAX_LOGH));
@@ -1835,7 +1939,9 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
                                16 << hx::NORM_MAX_LOGH));
     attr = true;
   }
-  if (logn >= 2 && logn - 1 <= hx::NORM_MAX_LOGH) {
+  if (!c->pow2) {
+    // (done above)
+  } else if (logn >= 2 && logn - 1 <= hx::NORM_MAX_LOGH) {
     // real-input form: one N/2-point transform per polynomial, one workgroup each
     const unsigned M = N >> 1;
     const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, M / 4));

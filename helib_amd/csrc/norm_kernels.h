@@ -202,6 +202,148 @@ embed_norm_quarter_kernel(SRC src, const double2* __restrict__ wtab, int logn,
   block_max_to(mx, sm, tid, nth, out2 + row);
 }
 
+// =====================================================================
+// General m: Bluestein in complex double (the reference's PGFFT does the same for a non-power-of-two
+// size, src/PGFFT.cpp).  With omega = exp(2 pi i/m) and v_k = exp(pi i k^2/m),
+//     f(omega^j) = v_j * sum_i (f_i v_i) conj(v_(j-i)),
+// so |f(omega^j)| = |conv_j| for the cyclic convolution of a_i = f_i v_i with c_k = conj(v_|k|) over
+// P = 2^bk >= 2m-1 points (the same size as the integer Bluestein transform).  P-point transforms are
+// S = P/H sub-transforms of H <= 8192 points held in LDS (one workgroup each), the first log2(S)
+// decimation-in-frequency levels folded into the load and, for the inverse, into the final
+// gather over the units of Z_m^*:
+//   forward   X[s + S k'] = sum_{i<H} ( sum_{t<S} x[i+tH] W^((i+tH)s) ) W_H^(i k'),  W = exp(2 pi i/P)
+//   inverse   x[i + tH]   = (1/P) sum_{s<S} W^(-(i+tH)s) y_s[i],   y_s[i] = sum_k' X[s+S k'] W_H^(-i k')
+// Transform-domain data is kept as [row][s][p] with p the bit-reversed k' (dif_fft_lds order).
+// =====================================================================
+// inverse of dif_fft_lds without the 1/H: bit-reversed input, natural output, conjugate twiddles
+__device__ __forceinline__ void dit_ifft_lds(double* re, double* im, int logh, unsigned tw_half,
+                                             const double2* __restrict__ wtab, unsigned tid, unsigned nth)
+{
+  const unsigned H = 1u << logh;
+  for (unsigned len = 1; len < H; len <<= 1) {
+    const unsigned s1 = tw_half / len;
+    for (unsigned q = tid; q < (H >> 1); q += nth) {
+      const unsigned j = q & (len - 1), k = ((q / len) * 2 * len) + j;
+      const double2 T = wtab[j * s1];
+      const double br = re[k + len] * T.x + im[k + len] * T.y;   // B * conj(T)
+      const double bi = im[k + len] * T.x - re[k + len] * T.y;
+      const double ar = re[k], ai = im[k];
+      re[k] = ar + br, im[k] = ai + bi;
+      re[k + len] = ar - br, im[k + len] = ai - bi;
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ double2 wpow(const double2* __restrict__ wtab, unsigned e, unsigned P)
+{
+  e &= P - 1;
+  const unsigned half = P >> 1;
+  double2 w = wtab[e & (half - 1)];
+  if (e >= half) {
+    w.x = -w.x;
+    w.y = -w.y;
+  }
+  return w;
+}
+// forward transform of one (row, s) block.  mode 0: x[n] = f[row][n] * v[n] (n < phim), Z multiplied by
+// chat; mode 1 (set-up): x = the complex vector cin (P entries), Z stored as is.
+__global__ void __launch_bounds__(NORM_THREADS)
+bnorm_fwd_kernel(const double* __restrict__ f, const double2* __restrict__ v, const double2* __restrict__ cin,
+                 const double2* __restrict__ wtab, const double2* __restrict__ chat,
+                 double2* __restrict__ Z, int logp, int logh, unsigned phim, int mode)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const unsigned P = 1u << logp, H = 1u << logh, S = P >> logh;
+  double* re = sm;
+  double* im = sm + H;
+  const unsigned row = blockIdx.x / S, s = blockIdx.x % S;
+  const unsigned tid = threadIdx.x, nth = blockDim.x;
+  for (unsigned i = tid; i < H; i += nth) {
+    double ar = 0, ai = 0;
+    for (unsigned t = 0; t < S; t++) {
+      const unsigned n = i + t * H;
+      double xr, xi;
+      if (mode == 0) {
+        if (n >= phim)
+          break;
+        const double fv = f[(size_t)row * phim + n];
+        const double2 vv = v[n];
+        xr = fv * vv.x;
+        xi = fv * vv.y;
+      } else {
+        const double2 cv = cin[n];
+        xr = cv.x;
+        xi = cv.y;
+      }
+      const double2 w = wpow(wtab, n * s, P);
+      ar += xr * w.x - xi * w.y;
+      ai += xr * w.y + xi * w.x;
+    }
+    re[i] = ar;
+    im[i] = ai;
+  }
+  __syncthreads();
+  dif_fft_lds(re, im, logh, P >> 1, wtab, tid, nth);
+  double2* out = Z + ((size_t)row * S + s) * H;
+  for (unsigned p = tid; p < H; p += nth) {
+    double zr = re[p], zi = im[p];
+    if (chat) {
+      const double2 c = chat[(size_t)s * H + p];
+      const double t = zr * c.x - zi * c.y;
+      zi = zr * c.y + zi * c.x;
+      zr = t;
+    }
+    out[p] = make_double2(zr, zi);
+  }
+}
+// y_s = H-point inverse sub-transform of block (row, s), in place
+__global__ void __launch_bounds__(NORM_THREADS)
+bnorm_inv_kernel(double2* __restrict__ Z, const double2* __restrict__ wtab, int logp, int logh)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const unsigned P = 1u << logp, H = 1u << logh;
+  double* re = sm;
+  double* im = sm + H;
+  const unsigned tid = threadIdx.x, nth = blockDim.x;
+  double2* blk = Z + (size_t)blockIdx.x * H;
+  for (unsigned p = tid; p < H; p += nth) {
+    const double2 z = blk[p];
+    re[p] = z.x;
+    im[p] = z.y;
+  }
+  __syncthreads();
+  dit_ifft_lds(re, im, logh, P >> 1, wtab, tid, nth);
+  for (unsigned i = tid; i < H; i += nth)
+    blk[i] = make_double2(re[i], im[i]);
+}
+// out2[row] = max over the units n of Z_m^* of |conv_n|^2 / P^2,  conv_n = sum_s W^(-n s) y_s[n mod H]
+__global__ void __launch_bounds__(256)
+bnorm_max_kernel(const double2* __restrict__ Y, const double2* __restrict__ wtab, const uint32_t* __restrict__ zms,
+                 unsigned phim, int logp, int logh, unsigned long long* __restrict__ out2)
+{
+  __shared__ double smax[8];
+  const unsigned P = 1u << logp, H = 1u << logh, S = P >> logh;
+  const unsigned row = blockIdx.y, tid = threadIdx.x;
+  const double2* y = Y + (size_t)row * P;
+  const double inv = 1.0 / (double)P;
+  double mx = 0;
+  for (unsigned idx = blockIdx.x * blockDim.x + tid; idx < phim; idx += gridDim.x * blockDim.x) {
+    const unsigned n = zms[idx], i = n & (H - 1);
+    double cr = 0, ci = 0;
+    for (unsigned s = 0; s < S; s++) {
+      const double2 w = wpow(wtab, n * s, P);          // conj(w) = W^(-n s)
+      const double2 yv = y[(size_t)s * H + i];
+      cr += yv.x * w.x + yv.y * w.y;
+      ci += yv.y * w.x - yv.x * w.y;
+    }
+    cr *= inv;
+    ci *= inv;
+    const double n2 = cr * cr + ci * ci;
+    mx = n2 > mx ? n2 : mx;
+  }
+  block_max_to(mx, smax, tid, blockDim.x, out2 + row);
+}
+
 // fdelta of the fused single-prime scale-down: delta = x - qd*S  =>  delta/qd = x/qd - S
 __global__ void __launch_bounds__(256)
 frac_from_xs_kernel(const uint64_t* __restrict__ xs, const int64_t* __restrict__ S, double inv_qd,

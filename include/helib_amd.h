@@ -210,9 +210,9 @@ int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_poly* t2, cons
 /* ---------------- measured noise: canonical-embedding norms ----------------
  * embeddingLargestCoeff (src/norms.cpp:129-262,480-493): max over j in Z_m^* of |f(W^j)|,
  * W = exp(2 pi i/m), evaluated on the device in double precision (the reference uses PGFFT,
- * src/PGFFT.cpp); parity is to a relative tolerance of 1e-9.  m must be a power of two
- * (otherwise HX_ERR_UNSUPPORTED: the host keeps the reference's high-probability bound,
- * src/DoubleCRT.cpp:520-529).  These calls synchronise the stream: the numbers land in host
+ * src/PGFFT.cpp); parity is to a relative tolerance of 1e-9.  m a power of two, or any
+ * m <= 131072 (complex-double Bluestein); beyond that HX_ERR_UNSUPPORTED: the host keeps the
+ * reference's high-probability bound, src/DoubleCRT.cpp:520-529.  These calls synchronise the stream: the numbers land in host
  * memory.  The arithmetic results are exactly those of the plain calls. */
 /* Deferred read-back: after hx_ctx_defer_norms(ctx, 1) the *_norms calls do not synchronise;
  * their `norms` arrays (which must stay valid) are filled by hx_norms_flush(ctx), which waits only

@@ -613,8 +613,27 @@ def test_embedding_norm_device_matches_oracle(hx, m):
         assert got[r] == pytest.approx(want, rel=NORM_RTOL, abs=1e-300), (m, r)
 
 
-def test_embedding_norm_unsupported_for_general_m(hx):
-    g = hx.Context(105)
+@pytest.mark.parametrize("m", [12, 105, 1705, 21845, 65539])
+def test_embedding_norm_general_m_matches_oracle(hx, m):
+    """General m: complex-double Bluestein on the device (norm_kernels.h bnorm_*; 2^bk-point
+    transforms in sub-transforms of <= 8192 points) against the oracle's long-double evaluation of
+    max_j |f(omega^j)|, j in Z_m^* (src/norms.cpp:480-493 via PGFFT in the reference)."""
+    g = hx.Context(m)
+    rng = np.random.default_rng(m)
+    n = g.phim
+    rows = 3 if m > 20000 else 6
+    f = rng.normal(0, 1000.0, size=(rows, n))
+    f[0] = np.rint(rng.normal(0, 3.2, size=n))                 # an error polynomial
+    f[1] = 0.0
+    f[1, n // 3] = 1.0                                         # a monomial: every |f(omega^j)| = 1
+    got = hx.embeddingLargestCoeff(g, f)
+    want = np.array([O.embedding_largest_coeff(m, r) for r in f])
+    assert abs(got[1] - 1.0) < 1e-12
+    assert np.allclose(got, want, rtol=NORM_RTOL, atol=0), (got, want)
+
+
+def test_embedding_norm_unsupported_beyond_2_18(hx):
+    g = hx.Context(131073)
     with pytest.raises(hx.HxError) as ei:
         hx.embeddingLargestCoeff(g, np.ones(g.phim))
     assert ei.value.code == hx.HX_ERR_UNSUPPORTED
