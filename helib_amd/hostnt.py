@@ -92,3 +92,29 @@ def find_primitive_root(q, e):
                 break
         root = root * pow(s, (q - 1) // pp, q) % q
     return root
+
+
+def phimx(m):
+    """Coefficients (lowest first) of the m-th cyclotomic polynomial Phi_m(X), by exact division of
+    X^m - 1 by the Phi_d of the proper divisors d of m (PAlgebra's PhimX, src/PAlgebra.cpp)."""
+    cache = {}
+
+    def phi(n):
+        if n in cache:
+            return cache[n]
+        num = [-1] + [0] * (n - 1) + [1]                     # X^n - 1
+        for d in range(1, n):
+            if n % d == 0:
+                den = phi(d)
+                # exact long division of num by the monic den
+                q = [0] * (len(num) - len(den) + 1)
+                num = num[:]
+                for i in range(len(q) - 1, -1, -1):
+                    q[i] = num[i + len(den) - 1]
+                    if q[i]:
+                        for j, c in enumerate(den):
+                            num[i + j] -= q[i] * c
+                num = q
+        cache[n] = num
+        return num
+    return phi(m)

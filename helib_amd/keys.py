@@ -46,20 +46,35 @@ class Sampler:
         self.cc, self.be = context, backend
         self.rng = np.random.default_rng(seed)
 
-    # -- unbounded draws over phi(m) coefficients (power-of-two m: src/sample.cpp:252-256,
-    #    :337-341, :436-440 take n = phi(m) directly; general m samples m coefficients and reduces
-    #    modulo Phi_m, which this mirror does not provide) --
+    # -- unbounded draws: power-of-two m takes n = phi(m) coefficients directly; general m samples m
+    #    coefficients and reduces modulo Phi_m (src/sample.cpp:240-256, 321-341, 420-440) --
     def _n(self):
-        if not self.cc.pow2:
-            raise NotImplementedError("samplers for general m (reduceModPhimX) are not built")
-        return self.cc.phim
+        return self.cc.phim if self.cc.pow2 else self.cc.m
 
-    def sampleSmall(self, prob=0.5):
-        """each coefficient 0 with probability 1-prob, +-1 with probability prob/2 each"""
+    def _reduce(self, poly):
+        """reduceModPhimX (src/sample.cpp:216-226): remainder modulo the monic Phi_m(X)"""
+        if self.cc.pow2:
+            return poly
+        if not hasattr(self, "_phimx"):
+            from . import hostnt
+            self._phimx = np.array(hostnt.phimx(self.cc.m), dtype=np.int64)
+        phi, n = self._phimx, self.cc.phim
+        a = poly.astype(np.int64).copy()
+        for i in range(len(a) - 1, n - 1, -1):
+            c = a[i]
+            if c:
+                a[i - n:i + 1] -= c * phi
+        return a[:n]
+
+    def sampleSmall(self, prob=None):
+        """each coefficient 0 with probability 1-prob, +-1 with probability prob/2 each (prob = 1/2 for
+        power-of-two m, phi(m)/(2m) otherwise: src/sample.cpp:327-339)"""
+        if prob is None:
+            prob = 0.5 if self.cc.pow2 else self.cc.phim / (2.0 * self.cc.m)
         n = self._n()
         nz = self.rng.random(n) < prob
         sign = self.rng.integers(0, 2, size=n) * 2 - 1
-        return (nz * sign).astype(np.int64)
+        return self._reduce((nz * sign).astype(np.int64))
 
     def sampleHWt(self, hwt):
         n = self._n()
@@ -67,10 +82,10 @@ class Sampler:
         out = np.zeros(n, dtype=np.int64)
         pos = self.rng.choice(n, size=hwt, replace=False)
         out[pos] = self.rng.integers(0, 2, size=hwt) * 2 - 1
-        return out
+        return self._reduce(out)
 
     def sampleGaussian(self, stdev):
-        return np.rint(self.rng.normal(0.0, stdev, size=self._n())).astype(np.int64)
+        return self._reduce(np.rint(self.rng.normal(0.0, stdev, size=self._n())).astype(np.int64))
 
     def _bounded(self, draw, bound, what):
         for _ in range(1000):           # "while (++count < 1000 && val > bound)"
@@ -84,7 +99,7 @@ class Sampler:
         return self._bounded(self.sampleSmall, math.sqrt(n * math.log(n) / 2.0), "sampleSmallBounded")
 
     def sampleHWtBounded(self, hwt):
-        bound = math.sqrt(hwt * math.log(self.cc.phim))
+        bound = math.sqrt(hwt * math.log(self.cc.phim))   # sampleHWtBoundedEffectiveBound
         return self._bounded(lambda: self.sampleHWt(hwt), bound, "sampleHWtBounded")
 
     def sampleGaussianBounded(self, stdev=0.0):

@@ -866,7 +866,7 @@ def test_multiply_relin_at_the_reference_benchmark_chain_size(hx):
 
 
 # ---------------------------------------------------------------- keys, encrypt, decrypt
-@pytest.mark.parametrize("m,p,bits", [(16384, 65537, 250), (128, 257, 150)])
+@pytest.mark.parametrize("m,p,bits", [(16384, 65537, 250), (128, 257, 150), (1705, 7, 200)])
 def test_keys_encrypt_decrypt_gpu_vs_oracle(hx, m, p, bits, monkeypatch):
     """helib_amd.keys (GenSecKey, GenKeySWmatrix, PubKey::Encrypt, multiplyBy, smartAutomorph,
     SecKey::Decrypt; src/keys.cpp:39-85, 358-488, 1099-1255, 1327-1420) run twice from the same

@@ -25,13 +25,16 @@ def setup(m, p, bits, seed=5, hwt=0):
     return cc, octx, be, sk
 
 
-@pytest.mark.parametrize("m,p,bits,hwt", [(128, 257, 150, 0), (64, 65537, 250, 0), (256, 17, 150, 24)])
+@pytest.mark.parametrize("m,p,bits,hwt", [(128, 257, 150, 0), (64, 65537, 250, 0), (256, 17, 150, 24),
+                                          (105, 2, 150, 0), (45, 7, 200, 8)])
 def test_encrypt_decrypt_round_trips(m, p, bits, hwt):
     cc, octx, be, sk = setup(m, p, bits, hwt=hwt)
     s = sk.sKeys[0]
-    assert set(np.unique(s)) <= {-1, 0, 1}
-    if hwt:
-        assert np.count_nonzero(s) == hwt
+    if cc.pow2:                      # general m: m coefficients reduced modulo Phi_m are no longer ternary
+        assert set(np.unique(s)) <= {-1, 0, 1}
+        if hwt:
+            assert np.count_nonzero(s) == hwt
+    assert len(s) == cc.phim
     # the *Bounded samplers hold their bound (src/sample.cpp:342-396, 269-304)
     assert be.embeddingLargestCoeff(s) <= sk.skBounds[0]
     rng = np.random.default_rng(1)
@@ -49,7 +52,7 @@ def test_encrypt_decrypt_round_trips(m, p, bits, hwt):
         sk.Encrypt(msg, ptxtSpace=p + 1 if math.gcd(p, p + 1) == 1 else 3)
 
 
-@pytest.mark.parametrize("m,p,bits", [(128, 257, 150), (64, 65537, 250)])
+@pytest.mark.parametrize("m,p,bits", [(128, 257, 150), (64, 65537, 250), (105, 2, 200)])
 def test_keygen_multiply_decrypt(m, p, bits):
     cc, octx, be, sk = setup(m, p, bits)
     assert sk.haveKeySWmatrix(2, 1) and sk.haveKeySWmatrix(3, 1)    # maxDegKswitch = 3
