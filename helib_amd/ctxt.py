@@ -130,12 +130,17 @@ class ModuliSizes:
 
 
 class ChainContext:
-    """ContextBuilder<BGV>().m(m).p(p).r(r).bits(bits).c(c) -> buildModChain."""
+    """ContextBuilder<BGV>().m(m).p(p).r(r).bits(bits).c(c) -> buildModChain; with ckks=True
+    ContextBuilder<CKKS>().m(m).precision(r).bits(bits).c(c): p = -1, plaintext space 1, r = the
+    precision in bits (include/helib/Context.h:1040-1130)."""
 
     def __init__(self, m, p, r=1, bits=300, c=3, stdev=3.2, scale=10.0, skHwt=0, resolution=3,
-                 bitsInSpecialPrimes=0):
+                 bitsInSpecialPrimes=0, ckks=False):
+        self.ckks = bool(ckks)
+        if self.ckks:
+            p = -1
         self.m, self.p, self.r = m, p, r
-        self.ptxtSpace = p ** r
+        self.ptxtSpace = 1 if self.ckks else p ** r
         self.phim = phi(m)
         self.pow2 = (m & (m - 1)) == 0
         self.stdev, self.scale, self.hwt = stdev, scale, skHwt
@@ -225,7 +230,9 @@ class ChainContext:
             h = self.phim / 2.0 if self.hwt == 0 else self.hwt
             log_phim = max(math.log(self.phim), 1.0)
             p2e = self.ptxtSpace
-            if self.pow2:
+            if self.ckks:   # a smaller noise estimate, to protect precision (src/Context.cpp:957-965)
+                nBits = (maxDigitLog + math.log(self.stdev) + math.log(nDgts) - 0.5 * math.log(h)) / LN2
+            elif self.pow2:
                 nBits = (maxDigitLog + math.log(p2e) + math.log(self.stdev) + 0.5 * math.log(12.0) +
                          math.log(nDgts) - 0.5 * math.log(log_phim) - 2 * math.log(self.p) -
                          math.log(h)) / LN2
@@ -302,6 +309,8 @@ class Ctxt:
         self.primeSet = frozenset()
         self.ptxtSpace = context.ptxtSpace
         self.intFactor = 1
+        # CKKS (src/Ctxt.h: ptxtMag, ratFactor): |plaintext| bound and ln of the scaling factor
+        self.ptxtMag, self.lnRatFactor = 1.0, 0.0
         self.ksw, self.ksw_ptxtSpace = ksw, ksw_ptxtSpace or context.ptxtSpace
         self.ksw_lnNoise = ksw_noise if ksw_noise is not None else \
             math.log(context.gaussBound() * context.ptxtSpace)
@@ -319,6 +328,7 @@ class Ctxt:
         c.parts = {h: p.copy() for h, p in self.parts.items()}
         c.primeSet, c.ptxtSpace = self.primeSet, self.ptxtSpace
         c.lnNoise, c.intFactor = self.lnNoise, self.intFactor
+        c.ptxtMag, c.lnRatFactor = self.ptxtMag, self.lnRatFactor
         c.ksw_auto = self.ksw_auto
         c.ksw_map = self.ksw_map
         return c
@@ -367,6 +377,7 @@ class Ctxt:
         for p in self.parts.values():
             p.addPrimesAndScale(diff)
         self.lnNoise += self.context.logOfProduct(diff)
+        self.lnRatFactor += self.context.logOfProduct(diff)   # "If CKKS, the rational factor grows" (:366)
         self.primeSet = self.primeSet | frozenset(diff)
 
     def modDownToSet(self, s):
@@ -378,6 +389,7 @@ class Ctxt:
             return
         added = Ctxt._modDownParts([self], sorted(inter))[0]
         logdiff = self.context.logOfProduct(diff)
+        self.lnRatFactor -= logdiff                              # ratFactor /= f (:533, :553)
         self._defer(lambda: setattr(self, "_ln", logaddexp(self._ln - logdiff, _ln(added()))))
         self.primeSet = inter
 
@@ -434,6 +446,7 @@ class Ctxt:
             return
         for c, ad in zip(cts, added):
             c.lnNoise += c.context.logOfProduct(add)
+            c.lnRatFactor += c.context.logOfProduct(add) - c.context.logOfProduct(diff)
             c.primeSet = up
             if diff:
                 logdiff = c.context.logOfProduct(diff)
@@ -457,6 +470,7 @@ class Ctxt:
         added = Ctxt._modDownParts([a, b], sorted(inter))
         logdiff = a.context.logOfProduct(diff)
         for c, ad in zip((a, b), added):
+            c.lnRatFactor -= logdiff
             c._defer(lambda c=c, ad=ad: setattr(c, "_ln", logaddexp(c._ln - logdiff, _ln(ad()))))
             c.primeSet = inter
 
@@ -497,18 +511,25 @@ class Ctxt:
         cap2 = c2.logOfPrimeSet() - max(c2.lnNoise, 0.0)
         adn1 = math.log(c1.modSwitchAddedNoiseBound())
         adn2 = math.log(c2.modSwitchAddedNoiseBound())
+        if c1.context.ckks:     # the opposite end: keep n*q'/q above the added noise (:1637-1651)
+            lo = max(cap1 + adn1, cap2 + adn2) + Ctxt.safety
+            return lo, lo + 4 * LN2
         hi = min(cap1 + adn1, cap2 + adn2) - Ctxt.safety
         return hi - 4 * LN2, hi
 
     def multLowLvl(self, other, destructive=False):
         o = other if destructive else other.clone()
-        g = math.gcd(self.ptxtSpace, o.ptxtSpace)
-        assert g > 1, "Plaintext spaces are co-prime"
-        self.ptxtSpace = o.ptxtSpace = g
-        self.intFactor %= g
-        o.intFactor %= g
+        ckks = self.context.ckks
+        if ckks:
+            assert self.ptxtSpace == 1 and o.ptxtSpace == 1, "Plaintext spaces incompatible"
+        else:
+            g = math.gcd(self.ptxtSpace, o.ptxtSpace)
+            assert g > 1, "Plaintext spaces are co-prime"
+            self.ptxtSpace = o.ptxtSpace = g
+            self.intFactor %= g
+            o.intFactor %= g
         lo, hi = Ctxt.computeIntervalForMul(self, o)
-        common = self.context.modSizes.getSet4Size(lo, hi, self.primeSet, o.primeSet, False)
+        common = self.context.modSizes.getSet4Size(lo, hi, self.primeSet, o.primeSet, ckks)
         if self.primeSet == o.primeSet and hasattr(self.ops, "bringToSetMulti"):
             Ctxt._bringManyToSet([self, o], frozenset(common) if common else
                                  frozenset([self.context.ctxtPrimes[0]]))
@@ -526,7 +547,14 @@ class Ctxt:
             self.intFactor = self.intFactor * o.intFactor % self.ptxtSpace * q % self.ptxtSpace
         t0, t1, t2 = self.ops.tensorProduct(self.parts["1"], self.parts["s"], o.parts["1"], o.parts["s"])
         self.parts = {"1": t0, "s": t1, "s2": t2}
-        self.lnNoise = self.lnNoise + o.lnNoise
+        if self.context.ckks:   # totalNoiseBound = factor*ptxt + noiseBound on both sides (:1600-1606)
+            n1, n2 = self.lnNoise, o.lnNoise
+            self.lnNoise = logaddexp(logaddexp(n1 + _ln(o.ptxtMag) + o.lnRatFactor,
+                                               n2 + _ln(self.ptxtMag) + self.lnRatFactor), n1 + n2)
+            self.lnRatFactor += o.lnRatFactor
+            self.ptxtMag *= o.ptxtMag
+        else:
+            self.lnNoise = self.lnNoise + o.lnNoise
 
     def reLinearize(self):
         """Ctxt::reLinearize (src/Ctxt.cpp:720-786) for the shapes of this path: (1, s, s^2) after a
@@ -544,13 +572,16 @@ class Ctxt:
                 raise LookupError(f"no key-switching matrices for k={hnd[1]}")   # LogicError in the reference
         ctx = self.context
         self.dropSmallAndSpecialPrimes()
+        self._relin_CKKS_adjust()
         sp = list(ctx.specialPrimes)
         logProd = ctx.logOfProduct(sp)
+        self.lnRatFactor += logProd                              # CKKS factor after mod-up (:757)
         # digits of the context restricted to the current prime set (src/DoubleCRT.cpp:485-493)
         digits = [[i for i in d if i in self.primeSet] for d in ctx.digits]
         digits = [d for d in digits if d]
-        self.ptxtSpace = math.gcd(self.ptxtSpace, self.ksw_ptxtSpace)
-        self.intFactor %= self.ptxtSpace
+        if self.ptxtSpace > 1:   # g == 1 for CKKS
+            self.ptxtSpace = math.gcd(self.ptxtSpace, self.ksw_ptxtSpace)
+            self.intFactor %= self.ptxtSpace
         res = self.ops.reLinearize(self.parts["1"], self.parts.get("s"), self.parts[hnd], W,
                                    digits, sp, **({"norms": True, "defer": True} if self._meas else {}))
         o0, o1 = res[0], res[1]
@@ -569,6 +600,22 @@ class Ctxt:
         self.parts = {"1": o0, "s": o1}
         self.primeSet = self.primeSet | frozenset(sp)
         self._defer(update)
+
+    def _relin_CKKS_adjust(self):
+        """Ctxt::relin_CKKS_adjust (src/Ctxt.cpp:664-717): if the noise is below what the special
+        primes were sized for, scale the ciphertext (and its factor) up by an integer."""
+        ctx = self.context
+        if not ctx.ckks:
+            return
+        h = ctx.phim / 2.0 if ctx.hwt == 0 else float(ctx.hwt)
+        log_phim = max(math.log(ctx.phim), 1.0)
+        gamma = 8.0 * int(ctx.scale) * math.sqrt(ctx.phim * log_phim * h / 12.0)
+        if math.log(gamma) > self.lnNoise:
+            xf = int(math.ceil(math.exp(math.log(gamma) - self.lnNoise)))
+            for p in self.parts.values():
+                p.mulConstant(xf)
+            self.lnNoise = self.lnNoise + math.log(xf)
+            self.lnRatFactor += math.log(xf)
 
     # ---- rotations (SURVEY row N4) ----
     def automorph(self, k):

@@ -198,6 +198,45 @@ class PubKey:
         ct.ksw_map = getattr(self, "keySwitchMap", None)
         return ct
 
+    def CKKSencrypt(self, ptxt, ptxtSize=1.0, scaling=0.0):
+        """PubKey::CKKSencrypt (src/keys.cpp:501-581): ptxt is an integer polynomial already scaled
+        by `scaling`; ctxt = r*pk + (e0, e1) + (ef*ptxt, 0) with ef = ceil(error_bound*prec /
+        (scaling*ptxtSize)), prec = 2^precision.  Decrypts to ptxt*ef + noise; ratFactor =
+        scaling*ef."""
+        cc, be = self.cc, self.be
+        if not cc.ckks:
+            raise RuntimeError("CKKSencrypt on a BGV context")
+        if ptxtSize <= 0:
+            ptxtSize = 1.0
+        prec = 1 << cc.r
+        if scaling <= 0:
+            scaling = float(prec) / ptxtSize
+        idx = list(cc.ctxtPrimes)
+        parts = [self.pubEncrKey[0].copy(), self.pubEncrKey[1].copy()]
+        r, r_bound = self.sampler.sampleSmallBounded()
+        rr = be.fromCoeffs(idx, r)
+        error_bound = r_bound * self.pubEncrKeyNoise
+        stdev = cc.stdev if cc.pow2 else cc.stdev * math.sqrt(cc.m)
+        for i in range(2):
+            parts[i] *= rr
+            e, e_bound = self.sampler.sampleGaussianBounded(stdev)
+            parts[i] += be.fromCoeffs(idx, e)
+            if i == 1:
+                e_bound *= self.getSKeyBound()
+            error_bound += e_bound
+        ef = int(math.ceil(error_bound * prec / (scaling * ptxtSize)))
+        coeffs = np.zeros(cc.phim, dtype=object)
+        for i, v in enumerate(ptxt):
+            coeffs[i] = int(v) * ef if ef > 1 else int(v)
+        if ef > 1:
+            scaling *= ef
+        parts[0] += be.fromCoeffs(idx, coeffs)
+        ct = self._newCtxt(parts[0], parts[1], error_bound, 1)
+        # EncryptedArrayCx::roundedSize: the next power of two, so as not to leak the size
+        ct.ptxtMag = 1.0 if ptxtSize <= 1 else float(1 << (int(math.ceil(ptxtSize)) - 1).bit_length())
+        ct.lnRatFactor = math.log(scaling)
+        return ct
+
     def _ptxt_fixed(self, ptxt, primeSet, ptxtSpace):
         """balanced_MulMod(ptxt, Q mod p, p) (src/NumbTh.cpp:876-891; the coin for c == p/2 at even
         p is the sampler's)."""
@@ -337,7 +376,7 @@ class SecKey(PubKey):
                 acc = term
             else:
                 acc += term
-        if raw:
+        if raw or cc.ckks:                # "if (isCKKS()) return;" -- the caller divides by ratFactor
             return be.toPoly(acc)
         p = ct.ptxtSpace
         out = be.toPolyMod(acc, p)        # toPoly + PolyRed(p, abs=true), on the device

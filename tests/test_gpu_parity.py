@@ -3,6 +3,7 @@ CPU oracle on the same seeded inputs.  Bit-exact: every word is compared.
 Run with `pytest -m gpu` on an MI355X."""
 import os
 
+import math
 import numpy as np
 import pytest
 
@@ -931,6 +932,54 @@ def test_keys_encrypt_decrypt_gpu_vs_oracle(hx, m, p, bits, monkeypatch):
         want = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
         assert prod == want and rot == [int(v) for v in B.automorph_mod_phi(want, m, 3, p)]
         assert withc == [(int(x) + int(y)) % p for x, y in zip(B.polymul_mod_phi(rot, mb, m, p), mb)]
+
+
+@pytest.mark.parametrize("m,precision,bits", [(16384, 20, 300), (128, 20, 200)])
+def test_ckks_encrypt_multiply_decrypt_gpu_vs_oracle(hx, m, precision, bits, monkeypatch):
+    """The CKKS chain of the same path (BASELINE configs[3]; PubKey::CKKSencrypt src/keys.cpp:501-581,
+    the CKKS branches of computeIntervalForMul / tensorProduct / relin_CKKS_adjust in src/Ctxt.cpp):
+    device vs oracle backend from one seed -- identical parts, prime sets and raw decryptions, and
+    the decoded product is the real product to the promised precision."""
+    from helib_amd import ctxt as hc, keys as hk
+    from oracle.backend import OracleBackend
+    monkeypatch.setattr(hc.Ctxt, "measure", True)
+    cc = hc.ChainContext(m, -1, precision, bits=bits, c=2, ckks=True)
+    P = Pair(hx, m, cc.primes)
+    gsk = hk.SecKey(cc, hk.HxBackend(P.g, cc), seed=13)
+    osk = hk.SecKey(cc, OracleBackend(P.o, cc), seed=13)
+    for sk in (gsk, osk):
+        sk.GenSecKey(maxDegKswitch=2)
+    n = cc.phim
+    rng = np.random.default_rng(4)
+    a, b = rng.uniform(-1, 1, n) / n, rng.uniform(-1, 1, n) / n
+    f = float(1 << precision)
+    pa, pb = np.rint(a * f).astype(np.int64), np.rint(b * f).astype(np.int64)
+    ga, gb = gsk.CKKSencrypt(pa, 1.0, f), gsk.CKKSencrypt(pb, 1.0, f)
+    oa, ob = osk.CKKSencrypt(pa, 1.0, f), osk.CKKSencrypt(pb, 1.0, f)
+
+    def same(gc, oc):
+        assert gc.primeSet == oc.primeSet and set(gc.parts) == set(oc.parts)
+        assert abs(gc.lnRatFactor - oc.lnRatFactor) < 1e-9 and abs(gc.lnNoise - oc.lnNoise) < 1e-7
+        for h in gc.parts:
+            gi, oi = gc.parts[h].getIndexSet(), oc.parts[h].getIndexSet()
+            gd, od = gc.parts[h].download()[:, 0], oc.parts[h].download()[:, 0]
+            for r, i in enumerate(gi):
+                assert np.array_equal(gd[r], od[oi.index(i)]), (h, i)
+
+    same(ga, oa)
+    for g, o in ((ga, gb), (oa, ob)):
+        g.multiplyBy(o)
+        g.multiplyBy(g.clone())           # (a*b)^2: the second product is mod-switched first
+    same(ga, oa)
+    raw = gsk.Decrypt(ga)
+    assert raw == osk.Decrypt(oa)
+    if m <= 1024:
+        got = np.array([float(v) for v in raw]) / math.exp(ga.lnRatFactor)
+        ab = np.convolve(a, b)
+        ab = ab[:n] - np.append(ab[n:], 0.0)
+        w = np.convolve(ab, ab)
+        want = w[:n] - np.append(w[n:], 0.0)
+        assert np.max(np.abs(got - want)) < 2.0 ** (-precision + 6) / n
 
 
 @pytest.mark.parametrize("m,L,t", [(16384, 5, 65537), (16384, 3, 2), (128, 4, (1 << 59) + 1), (1705, 3, 49)])

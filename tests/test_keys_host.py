@@ -216,3 +216,75 @@ def test_keySwitchMap_bfs_and_multi_step_rotations():
         hc.BasicAutomorphPrecon(sk.Encrypt(ma)).automorph(127)
     with pytest.raises(ValueError):
         sk.Encrypt(ma).smartAutomorph(6)
+
+
+# ---------------------------------------------------------------------------------------------
+# CKKS bookkeeping (BASELINE configs[3]: the CKKS chain of the same DoubleCRT path)
+# ---------------------------------------------------------------------------------------------
+def setup_ckks(m, precision, bits, seed=7):
+    cc = hc.ChainContext(m, -1, precision, bits=bits, c=2, ckks=True)
+    octx = O.Ctx(m)
+    for q in cc.primes:
+        octx.add_prime(q)
+    be = OracleBackend(octx, cc)
+    sk = hk.SecKey(cc, be, seed)
+    sk.GenSecKey()
+    return cc, octx, be, sk
+
+
+def negacyclic(a, b):
+    n = len(a)
+    full = np.convolve(a, b)
+    out = full[:n].copy()
+    out[: n - 1] -= full[n:]
+    return out
+
+
+@pytest.mark.parametrize("m,precision,bits", [(128, 20, 200), (256, 16, 300)])
+def test_ckks_encrypt_multiply_decrypt(m, precision, bits):
+    cc, octx, be, sk = setup_ckks(m, precision, bits)
+    assert cc.ptxtSpace == 1 and sk.ptxtSpace == 1
+    rng = np.random.default_rng(3)
+    n = cc.phim
+    a, b = rng.uniform(-1, 1, n) / n, rng.uniform(-1, 1, n) / n   # |embedding| <= 1
+    f = float(1 << precision)
+    ca = sk.CKKSencrypt(np.rint(a * f).astype(np.int64), 1.0, f)
+    cb = sk.CKKSencrypt(np.rint(b * f).astype(np.int64), 1.0, f)
+    assert ca.ptxtSpace == 1 and ca.ptxtMag == 1.0
+    # ef*f >= error_bound*prec: the noise sits `precision` bits below the scaled plaintext
+    assert ca.lnRatFactor >= ca.lnNoise + precision * math.log(2) - 1e-9
+
+    def dec(ct):
+        raw = np.array(sk.Decrypt(ct), dtype=object)
+        return np.array([float(v) for v in raw]) / math.exp(ct.lnRatFactor)
+
+    assert np.max(np.abs(dec(ca) - a)) < 2.0 ** (-precision + 1)
+    ca.multiplyBy(cb)
+    assert set(ca.parts) == {"1", "s"} and ca.ptxtSpace == 1
+    got, want = dec(ca), negacyclic(a, b)
+    # the reported bound holds for the real error, and the error is small next to the product
+    err = be.embeddingLargestCoeff((got - want) * math.exp(ca.lnRatFactor))
+    assert math.log(err) <= ca.lnNoise
+    assert np.max(np.abs(got - want)) < 2.0 ** (-precision + 4) / n
+    # one more level: (a*b)^2.  A fresh CKKS ciphertext has (almost) no noise to scale down, so
+    # the first product keeps every prime; squaring the product is mod-switched first
+    # (computeIntervalForMul's CKKS end, :1637-1651)
+    ca.multiplyBy(ca.clone())
+    if m == 128:
+        assert len(ca.primeSet & frozenset(cc.ctxtPrimes)) < len(cc.ctxtPrimes)
+    got, want = dec(ca), negacyclic(want, want)
+    err = be.embeddingLargestCoeff((got - want) * math.exp(ca.lnRatFactor))
+    assert math.log(err) <= ca.lnNoise
+    assert np.max(np.abs(got - want)) < 2.0 ** (-precision + 6) / n
+
+
+def test_ckks_chain_matches_reference_formulas():
+    # BASELINE configs[3]: m=65536, bits=1400 -> the special primes follow the CKKS sizing rule
+    # nBits = (maxDigitLog + ln(stdev) + ln(nDgts) - ln(h)/2)/ln2 (src/Context.cpp:957-965)
+    ck = hc.ChainContext(65536, -1, 20, bits=1400, c=3, ckks=True)
+    assert ck.ptxtSpace == 1 and len(ck.digits) == 3
+    maxDigit = max(ck.logOfProduct(d) for d in ck.digits)
+    nBits = (maxDigit + math.log(3.2) + math.log(3) - 0.5 * math.log(ck.phim / 2.0)) / math.log(2)
+    got = ck.logOfProduct(ck.specialPrimes) / math.log(2)
+    assert nBits <= got < nBits + 60
+    assert abs(ck.logOfProduct(ck.ctxtPrimes) / math.log(2) - 1400) < 60
