@@ -221,7 +221,7 @@ def write_ctxt(c, legacy=False):
         out = [b"|CX[", struct.pack("<q", int(c["ptxtSpace"])), _xd(c["noiseBound"])]
     else:
         out = [header("Ctxt"), b"|CX[", struct.pack("<qq", int(c["ptxtSpace"]), int(c["intFactor"])),
-               _xd(c.get("ptxtMag", 0.0)), _xd(c.get("ratFactor", 1.0)), _xd(c["noiseBound"])]
+               _xd(c.get("ptxtMag", 1.0)), _xd(c.get("ratFactor", 1.0)), _xd(c["noiseBound"])]
     ps = sorted(int(i) for i in c["primeSet"])
     out.append(struct.pack(f"<q{len(ps)}q", len(ps), *ps))
     out.append(struct.pack("<q", len(c["parts"])))
@@ -251,7 +251,7 @@ def read_ctxt(buf, off=0, legacy=False):
         xs.append(xdouble_value(m, e))
         off += 16
     if legacy:
-        xs = [0.0, 1.0, xs[0]]
+        xs = [1.0, 1.0, xs[0]]
     (card,) = struct.unpack_from("<q", buf, off)
     ps = list(struct.unpack_from(f"<{card}q", buf, off + 8))
     off += 8 + 8 * card
@@ -299,7 +299,7 @@ def ctxt_to_json(c):
     return _typed("Ctxt", {
         "ptxtSpace": int(c["ptxtSpace"]), "noiseBound": _xdj(c["noiseBound"]),
         "primeSet": sorted(int(i) for i in c["primeSet"]), "intFactor": int(c["intFactor"]),
-        "ptxtMag": _xdj(c.get("ptxtMag", 0.0)), "ratFactor": _xdj(c.get("ratFactor", 1.0)),
+        "ptxtMag": _xdj(c.get("ptxtMag", 1.0)), "ratFactor": _xdj(c.get("ratFactor", 1.0)),
         "parts": [{"DoubleCRT": to_json(idx, rows), "skHandle": _skh_json(h)} for idx, rows, h in c["parts"]]})
 
 
@@ -386,7 +386,10 @@ def from_ctxt(ct, b=0):
     import math
     order = sorted(ct.parts, key=lambda h: _handle_of(h)[:2])
     parts = [(ct.parts[h].getIndexSet(), ct.parts[h].download()[:, b], _handle_of(h)) for h in order]
-    return {"ptxtSpace": ct.ptxtSpace, "intFactor": ct.intFactor, "ptxtMag": 0.0, "ratFactor": 1.0,
+    ckks = getattr(ct.context, "ckks", False)
+    return {"ptxtSpace": ct.ptxtSpace, "intFactor": ct.intFactor,
+            "ptxtMag": float(ct.ptxtMag) if ckks else 1.0,
+            "ratFactor": _xd_from_ln(ct.lnRatFactor) if ckks else 1.0,
             "noiseBound": _xd_from_ln(ct.lnNoise),
             "primeSet": sorted(ct.primeSet), "parts": parts}
 
@@ -402,4 +405,367 @@ def to_ctxt(desc, ctxt_cls, context, ops, make_poly, **kw):
     nb = desc["noiseBound"]
     ct.lnNoise = (math.log(nb[0]) + 114 * math.log(2.0) * nb[1]) if isinstance(nb, tuple) else \
         (math.log(nb) if nb > 0 else -math.inf)
+    ct.ptxtMag = desc.get("ptxtMag", 1.0) if not isinstance(desc.get("ptxtMag", 1.0), tuple) else \
+        xdouble_value(*desc["ptxtMag"])
+    rf = desc.get("ratFactor", 1.0)
+    ct.lnRatFactor = (math.log(rf[0]) + 114 * math.log(2.0) * rf[1]) if isinstance(rf, tuple) else \
+        (math.log(rf) if rf > 0 else 0.0)
     return ct
+
+
+# ---- containers: Context, PubKey, SecKey ---------------------------------------------------------
+def _vec_long(v, int_size=BIT64):
+    """write_ntl_vec_long (src/binio.cpp:103-125)"""
+    fmt = "<u8" if int_size == BIT64 else "<u4"
+    return struct.pack("<ii", len(v), int_size) + np.asarray(v, dtype=np.int64).astype(fmt).tobytes()
+
+
+def _read_vec_long(buf, off):
+    n, int_size = struct.unpack_from("<ii", buf, off)
+    if int_size not in (BIT32, BIT64) or n < 0:
+        raise ValueError("intSize must be 32 or 64 bit for binary IO")
+    dt = "<i8" if int_size == BIT64 else "<i4"
+    v = [int(x) for x in np.frombuffer(buf, dtype=dt, count=n, offset=off + 8)]
+    return v, off + 8 + n * int_size
+
+
+def _longs(v):
+    return struct.pack(f"<q{len(v)}q", len(v), *[int(x) for x in v])     # write_raw_vector<long>
+
+
+def _read_longs(buf, off):
+    (n,) = struct.unpack_from("<q", buf, off)
+    if n < 0 or n > (len(buf) - off) // 8:
+        raise ValueError("implausible vector length")
+    return list(struct.unpack_from(f"<{n}q", buf, off + 8)), off + 8 + 8 * n
+
+
+def _eye(buf, off, tag, what):
+    if buf[off:off + 4] != tag:
+        raise ValueError(f"Could not find {what} eye catcher")
+    return off + 4
+
+
+def _base(c):
+    return [struct.pack("<qqq", int(c["p"]), int(c["r"]), int(c["m"])), _longs(c["gens"]), _longs(c["ords"])]
+
+
+def write_context_base(c):
+    return b"".join([b"|BS["] + _base(c) + [b"]BS|"])
+
+
+def write_context(c, legacy=False):
+    """Context::writeTo (src/Context.cpp:324-387).  c = {p, r, m, gens, ords (negated = bad
+    dimension), stdev, scale, smallPrimes, specialPrimes, qs, digits, hwt_param, e_param,
+    ePrime_param, mvec, build_cache, alsoThick}.  gens/ords describe Zm*/<p> (PAlgebra), which
+    this engine never computes: they are carried through as data.
+    legacy=True: the two blocks of the reference's fixture (context base |BS[..]BS| = p r m gens
+    ords, then |CN[..]CN| = stdev as a double, the index sets, primes, digits, mvec and two flags)."""
+    base = _base(c)
+    sets = [_longs(sorted(c["smallPrimes"])), _longs(sorted(c["specialPrimes"])), _longs(c["qs"]),
+            struct.pack("<q", len(c["digits"]))] + [_longs(sorted(d)) for d in c["digits"]]
+    tail = [_vec_long(c.get("mvec", [])), struct.pack("<qq", int(c.get("build_cache", 0)), int(c.get("alsoThick", 0)))]
+    if legacy:
+        return b"".join([b"|BS["] + base + [b"]BS|", b"|CN[", struct.pack("<d", float(c["stdev"]))] + sets
+                        + tail + [b"]CN|"])
+    return b"".join([header("Context"), b"|CN["] + base + [_xd(c["stdev"]), struct.pack("<d", float(c["scale"]))]
+                    + sets + [struct.pack("<qqq", int(c.get("hwt_param", 0)), int(c.get("e_param", 0)),
+                                          int(c.get("ePrime_param", 0)))] + tail + [b"]CN|"])
+
+
+def _read_base(buf, off):
+    p, r, m = struct.unpack_from("<qqq", buf, off)
+    gens, off = _read_longs(buf, off + 24)
+    ords, off = _read_longs(buf, off)
+    return {"p": p, "r": r, "m": m, "gens": gens, "ords": ords}, off
+
+
+def read_context_base(buf, off=0):
+    """the legacy |BS[ p r m gens ords ]BS| block"""
+    off = _eye(buf, off, b"|BS[", "pre-context-base")
+    c, off = _read_base(buf, off)
+    return c, _eye(buf, off, b"]BS|", "post-context-base")
+
+
+def read_context(buf, off=0, legacy=False):
+    """Context::readParamsFrom (src/Context.cpp:389-442) -> (dict, offset)"""
+    if legacy:
+        c, off = read_context_base(buf, off)
+        off = _eye(buf, off, b"|CN[", "pre-context")
+        (c["stdev"],) = struct.unpack_from("<d", buf, off)
+        off += 8
+        c["scale"] = 10.0
+    else:
+        off = _read_header(buf, off, "Context")
+        off = _eye(buf, off, b"|CN[", "pre-context")
+        c, off = _read_base(buf, off)
+        mnt, e, c["scale"] = struct.unpack_from("<dqd", buf, off)
+        c["stdev"] = xdouble_value(mnt, e)
+        off += 24
+    c["smallPrimes"], off = _read_longs(buf, off)
+    c["specialPrimes"], off = _read_longs(buf, off)
+    c["qs"], off = _read_longs(buf, off)
+    (nd,) = struct.unpack_from("<q", buf, off)
+    off += 8
+    c["digits"] = []
+    for _ in range(nd):
+        d, off = _read_longs(buf, off)
+        c["digits"].append(d)
+    if not legacy:
+        c["hwt_param"], c["e_param"], c["ePrime_param"] = struct.unpack_from("<qqq", buf, off)
+        off += 24
+    c["mvec"], off = _read_vec_long(buf, off)
+    c["build_cache"], c["alsoThick"] = struct.unpack_from("<qq", buf, off)
+    return c, _eye(buf, off + 16, b"]CN|", "post-context")
+
+
+def context_to_json(c):
+    idx = lambda s: sorted(int(i) for i in s)   # IndexSet::writeToJSON: a plain array (src/IndexSet.cpp:319-330)  # noqa: E731
+    return _typed("Context", {
+        "m": int(c["m"]), "p": int(c["p"]), "r": int(c["r"]), "gens": list(c["gens"]), "ords": list(c["ords"]),
+        "stdev": _xdj(c["stdev"]), "scale": float(c["scale"]),
+        "smallPrimes": idx(c["smallPrimes"]), "specialPrimes": idx(c["specialPrimes"]),
+        "qs": [int(q) for q in c["qs"]], "digits": [idx(d) for d in c["digits"]],
+        "hwt_param": int(c.get("hwt_param", 0)), "e_param": int(c.get("e_param", 0)),
+        "ePrime_param": int(c.get("ePrime_param", 0)), "mvec": list(c.get("mvec", [])),
+        "build_cache": bool(c.get("build_cache", 0)), "alsoThick": bool(c.get("alsoThick", 0))})
+
+
+def context_from_json(j):
+    c = dict(_untyped(j, "Context"))
+    for k in ("smallPrimes", "specialPrimes"):
+        c[k] = sorted(c[k])
+    c["digits"] = [sorted(d) for d in c["digits"]]
+    c["stdev"] = xdouble_value(c["stdev"]["mantissa"], c["stdev"]["exponent"])
+    c["build_cache"], c["alsoThick"] = int(c["build_cache"]), int(c["alsoThick"])
+    return c
+
+
+def context_of(cc, gens=(), ords=()):
+    """helib_amd.ctxt.ChainContext -> the Context description"""
+    return {"p": cc.p, "r": cc.r, "m": cc.m, "gens": list(gens), "ords": list(ords), "stdev": cc.stdev,
+            "scale": float(cc.scale), "smallPrimes": list(cc.smallPrimes), "specialPrimes": list(cc.specialPrimes),
+            "qs": [int(q) for q in cc.primes], "digits": [list(d) for d in cc.digits], "hwt_param": int(cc.hwt),
+            "e_param": 0, "ePrime_param": 0, "mvec": [], "build_cache": 0, "alsoThick": 0}
+
+
+def write_pubkey(k, legacy=False):
+    """PubKey::writeTo (src/keys.cpp:888-921).  k = {context, pubEncrKey (ctxt description),
+    skBounds [double], keySwitching [key-switch descriptions], keySwitchMap [[long]], KS_strategy
+    [long], recryptKeyID, recryptEkey (ctxt description)}.
+    legacy=True (the fixture): context base only, skBounds still the integer Hamming weights."""
+    out = [b"|PK["] if legacy else [header("PubKey"), b"|PK["]
+    if legacy:
+        out.append(write_context_base(k["context"]))
+    else:
+        out.append(write_context(k["context"]))
+    out.append(write_ctxt(k["pubEncrKey"], legacy))
+    if legacy:
+        out.append(_longs(k["skBounds"]))
+    else:
+        out.append(struct.pack(f"<q{len(k['skBounds'])}d", len(k["skBounds"]), *[float(x) for x in k["skBounds"]]))
+    out.append(struct.pack("<q", len(k["keySwitching"])))
+    out += [write_keyswitch(w, legacy) for w in k["keySwitching"]]
+    out.append(struct.pack("<q", len(k["keySwitchMap"])))
+    out += [_longs(v) for v in k["keySwitchMap"]]
+    out += [_vec_long(k["KS_strategy"]), struct.pack("<q", int(k["recryptKeyID"])),
+            write_ctxt(k["recryptEkey"], legacy), b"]PK|"]
+    return b"".join(out)
+
+
+def read_pubkey(buf, off=0, legacy=False, context=None):
+    """PubKey::readFrom (src/keys.cpp:923-974); with `context` (a description) the reference's
+    "Context mismatch" check is applied."""
+    if not legacy:
+        off = _read_header(buf, off, "PubKey")
+    off = _eye(buf, off, b"|PK[", "pre-public key")
+    k = {}
+    if legacy:
+        k["context"], off = read_context_base(buf, off)
+    else:
+        k["context"], off = read_context(buf, off)
+    if context is not None:
+        for f in k["context"]:
+            if f in context and k["context"][f] != context[f]:
+                raise ValueError("Context mismatch")
+    k["pubEncrKey"], off = read_ctxt(buf, off, legacy)
+    if legacy:
+        k["skBounds"], off = _read_longs(buf, off)
+    else:
+        (n,) = struct.unpack_from("<q", buf, off)
+        k["skBounds"] = list(struct.unpack_from(f"<{n}d", buf, off + 8))
+        off += 8 + 8 * n
+    (n,) = struct.unpack_from("<q", buf, off)
+    off += 8
+    k["keySwitching"] = []
+    for _ in range(n):
+        w, off = read_keyswitch(buf, off, legacy)
+        k["keySwitching"].append(w)
+    (n,) = struct.unpack_from("<q", buf, off)
+    off += 8
+    k["keySwitchMap"] = []
+    for _ in range(n):
+        v, off = _read_longs(buf, off)
+        k["keySwitchMap"].append(v)
+    k["KS_strategy"], off = _read_vec_long(buf, off)
+    (k["recryptKeyID"],) = struct.unpack_from("<q", buf, off)
+    k["recryptEkey"], off = read_ctxt(buf, off + 8, legacy)
+    return k, _eye(buf, off, b"]PK|", "post-public key")
+
+
+def write_seckey(k, legacy=False, sk_only=False):
+    """SecKey::writeTo (src/keys.cpp:1736-1753): the public key (or, sk_only, just the context),
+    then vector<DoubleCRT> sKeys.  k = the PubKey description + {"sKeys": [(idx, rows)]}."""
+    out = [b"|SK["] if legacy else [header("SecKey"), b"|SK["]
+    out.append(write_context(k["context"], legacy) if sk_only else write_pubkey(k, legacy))
+    out.append(struct.pack("<q", len(k["sKeys"])))
+    out += [write_rows(idx, rows) for idx, rows in k["sKeys"]]
+    out.append(b"]SK|")
+    return b"".join(out)
+
+
+def read_seckey(buf, off=0, legacy=False, sk_only=False, context=None):
+    if not legacy:
+        off = _read_header(buf, off, "SecKey")
+    off = _eye(buf, off, b"|SK[", "pre-secret key")
+    if sk_only:
+        c, off = read_context(buf, off, legacy)
+        if context is not None and any(c[f] != context[f] for f in c if f in context):
+            raise ValueError("Context mismatch")
+        k = {"context": c}
+    else:
+        k, off = read_pubkey(buf, off, legacy, context)
+    (n,) = struct.unpack_from("<q", buf, off)
+    off += 8
+    k["sKeys"] = []
+    for _ in range(n):
+        idx, rows, off = read_rows(buf, off)
+        k["sKeys"].append((idx, rows))
+    return k, _eye(buf, off, b"]SK|", "post-secret key")
+
+
+def pubkey_to_json(k):
+    return _typed("PubKey", {
+        "context": context_to_json(k["context"]), "pubEncrKey": ctxt_to_json(k["pubEncrKey"]),
+        "skBounds": [float(x) for x in k["skBounds"]],
+        "keySwitching": [keyswitch_to_json(w) for w in k["keySwitching"]],
+        "keySwitchMap": [list(v) for v in k["keySwitchMap"]], "KS_strategy": list(k["KS_strategy"]),
+        "recryptKeyID": int(k["recryptKeyID"]),
+        "recryptEkey": ctxt_to_json(k["recryptEkey"]) if k["recryptKeyID"] >= 0 else "nullptr"})
+
+
+def pubkey_from_json(j, primes=None, phim=None):
+    c = _untyped(j, "PubKey")
+    k = {"context": context_from_json(c["context"]), "pubEncrKey": ctxt_from_json(c["pubEncrKey"], primes, phim),
+         "skBounds": list(c["skBounds"]),
+         "keySwitching": [keyswitch_from_json(w, primes, phim) for w in c["keySwitching"]],
+         "keySwitchMap": [list(v) for v in c["keySwitchMap"]], "KS_strategy": list(c["KS_strategy"]),
+         "recryptKeyID": c["recryptKeyID"]}
+    if c["recryptKeyID"] >= 0:
+        k["recryptEkey"] = ctxt_from_json(c["recryptEkey"], primes, phim)
+    else:   # left as constructed by Ctxt(pubKey): empty, over the ctxt primes
+        k["recryptEkey"] = {"ptxtSpace": k["pubEncrKey"]["ptxtSpace"], "intFactor": 1, "ptxtMag": 1.0,
+                            "ratFactor": 1.0, "noiseBound": 0.0, "primeSet": list(k["pubEncrKey"]["primeSet"]),
+                            "parts": []}
+    return k
+
+
+def seckey_to_json(k, sk_only=False):
+    body = {"context": context_to_json(k["context"])} if sk_only else {"PubKey": pubkey_to_json(k)}
+    body["sKeys"] = [to_json(idx, rows) for idx, rows in k["sKeys"]]
+    return _typed("SecKey", body)
+
+
+def seckey_from_json(j, sk_only=False, primes=None, phim=None):
+    c = _untyped(j, "SecKey")
+    k = {"context": context_from_json(c["context"])} if sk_only else pubkey_from_json(c["PubKey"], primes, phim)
+    k["sKeys"] = [from_json(x, primes, phim) for x in c["sKeys"]]
+    return k
+
+
+def key_switch_map(m, keySwitching, keyId=0):
+    """PubKey::setKeySwitchMap in the stored form (src/keys.cpp:122-172): entry k = the INDEX in
+    keySwitching of the matrix for the first step of X -> X^k, -1 if unreachable."""
+    edges = [(w["fromKey"][1], i) for i, w in enumerate(keySwitching)
+             if w["toKeyID"] == keyId and w["fromKey"][0] == 1 and w["fromKey"][2] == keyId]
+    kmap = [-1] * m
+    queue, head = [1], 0
+    while head < len(queue):
+        cur = queue[head]
+        head += 1
+        for n, idx in edges:
+            nxt = cur * n % m
+            if kmap[nxt] == -1:
+                kmap[nxt] = idx
+                queue.append(nxt)
+    return kmap
+
+
+# ---- helib_amd.keys objects ----------------------------------------------------------------------
+def from_pubkey(pk, gens=(), ords=()):
+    """helib_amd.keys.PubKey/SecKey -> the PubKey description.  The a-columns of a key-switching
+    matrix are regenerated by the reference from prgSeed with NTL's PRG; this engine keeps them
+    explicitly (helib_amd.keys.KeySwitchInfo.a), so matrices written here carry prgSeed = 1 and are
+    only loadable by this engine (to_pubkey(..., a_columns=...)), as DESIGN.md section 7.2 says."""
+    import math
+    cc = pk.cc
+    enc = {"ptxtSpace": pk.ptxtSpace, "intFactor": 1, "ptxtMag": 1.0, "ratFactor": 1.0,
+           "noiseBound": float(pk.pubEncrKeyNoise), "primeSet": sorted(cc.ctxtPrimes),
+           "parts": [(pk.pubEncrKey[0].getIndexSet(), pk.pubEncrKey[0].download()[:, 0], (0, 1, 0)),
+                     (pk.pubEncrKey[1].getIndexSet(), pk.pubEncrKey[1].download()[:, 0], (1, 1, 0))]}
+    allp = list(cc.ctxtPrimes) + list(cc.specialPrimes)
+    ksw = [{"fromKey": (sp, xp, 0), "toKeyID": 0, "ptxtSpace": w.ptxtSpace,
+            "b": [(allp, np.asarray(w.b[i])) for i in range(len(w.b))], "prgSeed": 1,
+            "noiseBound": float(w.noiseBound)} for (sp, xp), w in pk.keySwitching.items()]
+    kmap = [key_switch_map(cc.m, ksw)] if getattr(pk, "keySwitchMap", None) else []
+    empty = {"ptxtSpace": pk.ptxtSpace, "intFactor": 1, "ptxtMag": 1.0, "ratFactor": 1.0, "noiseBound": 0.0,
+             "primeSet": sorted(cc.ctxtPrimes), "parts": []}
+    return {"context": context_of(cc, gens, ords), "pubEncrKey": enc, "skBounds": [float(b) for b in pk.skBounds],
+            "keySwitching": ksw, "keySwitchMap": kmap, "KS_strategy": [], "recryptKeyID": -1, "recryptEkey": empty}
+
+
+def from_seckey(sk, gens=(), ords=()):
+    k = from_pubkey(sk, gens, ords)
+    allp = list(sk.cc.ctxtPrimes) + list(sk.cc.specialPrimes)
+    k["sKeys"] = []
+    for s in sk.sKeys:
+        d = sk.be.fromCoeffs(allp, s)
+        k["sKeys"].append((d.getIndexSet(), d.download()[:, 0]))
+    return k
+
+
+def to_seckey(desc, key_cls, cc, be, make_poly, ksw_a=None, seed=0):
+    """the SecKey (or PubKey) description -> key_cls (helib_amd.keys.SecKey / PubKey) over backend
+    `be`; make_poly(idx, rows) builds a backend DoubleCRT.  Key-switching matrices are installed
+    only when their a-columns are supplied (ksw_a[(powerOfS, powerOfX)] = [D][rows][N]) -- see
+    from_pubkey."""
+    from . import keys as hk
+    ctx = desc["context"]
+    if (ctx["m"], ctx["p"], ctx["r"]) != (cc.m, cc.p, cc.r) or \
+            ("qs" in ctx and [int(q) for q in ctx["qs"]] != [int(q) for q in cc.primes]):
+        raise ValueError("Context mismatch")
+    key = key_cls(cc, be, seed)
+    enc = desc["pubEncrKey"]
+    byh = {h[:2]: make_poly(idx, rows) for idx, rows, h in enc["parts"]}
+    key.pubEncrKey = (byh[(0, 1)], byh[(1, 1)])
+    nb = enc["noiseBound"]
+    key.pubEncrKeyNoise = xdouble_value(*nb) if isinstance(nb, tuple) else float(nb)
+    key.ptxtSpace = enc["ptxtSpace"]
+    key.skBounds = [float(b) for b in desc["skBounds"]]
+    for w in desc["keySwitching"]:
+        k2 = tuple(w["fromKey"][:2])
+        if ksw_a is not None and k2 in ksw_a:
+            hb = np.stack([rows for _, rows in w["b"]])
+            ha = np.asarray(ksw_a[k2])
+            idx = w["b"][0][0]
+            nbw = w["noiseBound"]
+            key.keySwitching[k2] = hk.KeySwitchInfo(k2[0], k2[1], be.keySwitch(idx, hb, ha), w["ptxtSpace"],
+                                                    xdouble_value(*nbw) if isinstance(nbw, tuple) else float(nbw),
+                                                    hb, ha)
+    if desc.get("keySwitchMap") and any(k[0] == 1 and k[1] > 1 for k in key.keySwitching):
+        key.setKeySwitchMap()
+    if "sKeys" in desc and hasattr(key, "sKeys"):
+        for idx, rows in desc["sKeys"]:
+            poly = be.toPoly(make_poly(idx, rows))
+            key.sKeys.append(np.array([int(v) for v in poly], dtype=np.int64))
+    return key

@@ -68,6 +68,19 @@ def main():
     print("wrote", DST)
     bin_blocks()
     bin_objects()
+    bin_whole()
+
+
+def bin_whole():
+    """The whole binary fixture (6704 bytes: context base + context + public key + secret key in
+    the older layout), for the container readers/writers of helib_amd/wire.py."""
+    src = os.path.join(os.path.dirname(SRC), "iotest_binLE.bin")
+    b = open(src, "rb").read()
+    dst = os.path.join(os.path.dirname(DST), "iotest_m12_bin_whole.json")
+    with open(dst, "w") as f:
+        json.dump({"source": "HElib 2.2.0 tests/test_resources/iotest_binLE.bin", "bytes": len(b),
+                   "hex": b.hex()}, f)
+    print("wrote", dst, len(b), "bytes")
 
 
 def bin_objects():

@@ -194,3 +194,138 @@ def test_ctxt_objects_through_the_wire_still_decrypt():
     cm = through(cm)
     from tests import bgv_ref as B
     assert sk.Decrypt(cm) == [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
+
+
+# ---------------------------------------------------------------------------------------------
+# containers: Context, PubKey, SecKey
+# ---------------------------------------------------------------------------------------------
+WHOLE = bytes.fromhex(json.load(open(os.path.join(HERE, "golden", "iotest_m12_bin_whole.json")))["hex"])
+
+
+def test_whole_fixture_parses_and_round_trips_bytewise():
+    """The reference's binary fixture end to end: context base + context, the public key, the
+    secret key (which embeds the same public key) -- every byte consumed, every byte re-emitted."""
+    c, off = wire.read_context(WHOLE, 0, legacy=True)
+    assert (c["m"], c["p"], c["r"], c["gens"], c["ords"]) == (12, 7, 1, [5], [2])
+    assert c["qs"] == ASCII["primes"] and c["specialPrimes"] == [3, 4] and c["digits"] == [[0, 1], [2]]
+    assert c["stdev"] == 3.2
+    pk, off2 = wire.read_pubkey(WHOLE, off, legacy=True)
+    sk, off3 = wire.read_seckey(WHOLE, off2, legacy=True)
+    assert off3 == len(WHOLE) == 6704
+    assert wire.write_context(c, legacy=True) == WHOLE[:off]
+    assert wire.write_pubkey(pk, legacy=True) == WHOLE[off:off2]
+    assert wire.write_seckey(sk, legacy=True) == WHOLE[off2:]
+    # the secret key file embeds the public key byte for byte
+    assert WHOLE[off:off2] == WHOLE[off2 + 4:off2 + 4 + (off2 - off)]
+    # PubKey::setKeySwitchMap's BFS reproduces the stored map from the stored matrices
+    assert [w["fromKey"] for w in pk["keySwitching"]] == [(2, 1, 0), (3, 1, 0), (1, 5, 0), (1, 7, 0)]
+    assert pk["keySwitchMap"] == [wire.key_switch_map(12, pk["keySwitching"])]
+    assert pk["recryptKeyID"] == -1 and pk["recryptEkey"]["parts"] == []
+    # the secret key rows are the ASCII fixture's
+    (idx, rows), = sk["sKeys"]
+    assert idx == ASCII["seckey"]["idx"] and rows.tolist() == ASCII["seckey"]["rows"]
+    # and the public encryption key is an RLWE sample under it: b + a*s = small (p*e) modulo every prime
+    from oracle import oracle as O
+    octx = O.Ctx(12)
+    for q in c["qs"]:
+        octx.add_prime(q)
+    (bi, b, _), (ai, a, _) = pk["pubEncrKey"]["parts"]
+    acc = np.array([[(int(x) + int(y) * int(s)) % c["qs"][i] for x, y, s in zip(b[r], a[r], rows[idx.index(i)])]
+                    for r, i in enumerate(bi)], dtype=np.uint64)
+    e = octx.to_poly(bi, acc)
+    assert all(int(v) % 7 == 0 for v in e) and [int(v) // 7 for v in e] == ASCII["expect_e_coeffs"]
+
+
+def _keys(m=128, p=257, bits=150):
+    from helib_amd import ctxt as hc, keys as hk
+    from oracle import oracle as O
+    from oracle.backend import OracleBackend
+    cc = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    octx = O.Ctx(m)
+    for q in cc.primes:
+        octx.add_prime(q)
+    be = OracleBackend(octx, cc)
+    sk = hk.SecKey(cc, be, 9)
+    sk.GenSecKey()
+    sk.GenKeySWmatrix(1, 3)
+    sk.GenKeySWmatrix(1, 5)
+    sk.setKeySwitchMap()
+    return cc, octx, be, sk
+
+
+def test_context_pubkey_seckey_2_2_0_layout_round_trip():
+    cc, octx, be, sk = _keys()
+    d = wire.from_seckey(sk, gens=[3, 127], ords=[32, -2])
+    # Context
+    raw = wire.write_context(d["context"])
+    assert raw[:4] == b"|HE[" and raw[12] == 5 and raw[24:28] == b"|CN[" and raw[-4:] == b"]CN|"
+    c2, off = wire.read_context(raw)
+    assert off == len(raw) and wire.write_context(c2) == raw
+    assert c2["qs"] == [int(q) for q in cc.primes] and c2["ords"] == [32, -2] and c2["scale"] == 10.0
+    assert wire.context_from_json(json.dumps(wire.context_to_json(d["context"]))) == c2
+    # PubKey / SecKey, binary
+    for writer, reader, sid in ((wire.write_pubkey, wire.read_pubkey, 10), (wire.write_seckey, wire.read_seckey, 15)):
+        raw = writer(d)
+        assert raw[12] == sid
+        k2, off = reader(raw, context=d["context"])
+        assert off == len(raw) and writer(k2) == raw
+        assert k2["skBounds"] == [float(b) for b in sk.skBounds]
+        assert [w["fromKey"] for w in k2["keySwitching"]] == [(2, 1, 0), (3, 1, 0), (1, 3, 0), (1, 5, 0)]
+        assert k2["keySwitchMap"] == [wire.key_switch_map(cc.m, k2["keySwitching"])]
+        # the stored map (matrix indices) and helib_amd.keys' map (powers of X) say the same thing
+        for k in range(2, cc.m):
+            i = k2["keySwitchMap"][0][k]
+            assert (k2["keySwitching"][i]["fromKey"][1] if i >= 0 else 0) == sk.keySwitchMap[k]
+        with pytest.raises(ValueError, match="Context mismatch"):
+            reader(raw, context=dict(d["context"], m=64))
+        with pytest.raises(ValueError, match="header"):
+            reader(b"|XX[" + raw[4:])
+        with pytest.raises(ValueError, match="structId"):
+            reader(raw[:12] + bytes([20]) + raw[13:])
+        bad = raw[:-4] + b"]XX|"
+        with pytest.raises(ValueError, match="eye catcher"):
+            reader(bad)
+    # sk_only: context + secret rows only (src/keys.cpp:1741-1750)
+    raw = wire.write_seckey(d, sk_only=True)
+    k3, off = wire.read_seckey(raw, sk_only=True, context=d["context"])
+    assert off == len(raw) and set(k3) == {"context", "sKeys"} and len(raw) < 40000
+    assert np.array_equal(k3["sKeys"][0][1], d["sKeys"][0][1])
+    # JSON
+    j = json.dumps(wire.seckey_to_json(d))
+    k4 = wire.seckey_from_json(j, primes={i: q for i, q in enumerate(cc.primes)}, phim=cc.phim)
+    assert wire.write_seckey(k4) == wire.write_seckey(d)
+    jj = json.loads(j)
+    assert jj["type"] == "SecKey" and jj["content"]["PubKey"]["type"] == "PubKey"
+    assert jj["content"]["PubKey"]["content"]["recryptEkey"] == "nullptr"
+
+
+def test_keys_through_the_wire_still_work():
+    """SecKey -> bytes -> SecKey: the reloaded key decrypts what the original encrypted, the
+    original decrypts what the reloaded public key encrypts, and the reloaded relinearisation /
+    rotation matrices give the right products and rotations."""
+    from helib_amd import keys as hk
+    from oracle.backend import OPoly
+    from tests import bgv_ref as B
+    cc, octx, be, sk = _keys()
+    p, m = cc.p, cc.m
+    raw = wire.write_seckey(wire.from_seckey(sk))
+    desc, _ = wire.read_seckey(raw)
+    a_cols = {k: w.a for k, w in sk.keySwitching.items()}
+    sk2 = wire.to_seckey(desc, hk.SecKey, cc, be, lambda idx, rows: OPoly(octx, idx, rows), ksw_a=a_cols, seed=77)
+    assert np.array_equal(sk2.sKeys[0], sk.sKeys[0]) and sk2.skBounds == sk.skBounds
+    assert sk2.keySwitchMap == sk.keySwitchMap
+    rng = np.random.default_rng(12)
+    ma, mb = rng.integers(0, p, size=cc.phim), rng.integers(0, p, size=cc.phim)
+    assert sk2.Decrypt(sk.Encrypt(ma)) == [int(v) for v in ma]
+    ca, cb = sk2.Encrypt(ma), sk2.Encrypt(mb)
+    assert sk.Decrypt(ca) == [int(v) for v in ma]
+    ca.multiplyBy(cb)
+    want = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
+    assert sk.Decrypt(ca) == want
+    ca.smartAutomorph(15)       # 3 * 5: two steps along the reloaded map
+    assert sk.Decrypt(ca) == [int(v) for v in B.automorph_mod_phi(want, m, 15, p)]
+    # without the a-columns the matrices are not installed (they are not derivable here: NTL's PRG)
+    sk3 = wire.to_seckey(desc, hk.SecKey, cc, be, lambda idx, rows: OPoly(octx, idx, rows))
+    assert sk3.keySwitching == {} and sk3.Decrypt(sk.Encrypt(mb)) == [int(v) for v in mb]
+    with pytest.raises(ValueError, match="Context mismatch"):
+        wire.to_seckey(dict(desc, context=dict(desc["context"], m=64)), hk.SecKey, cc, be, None)
