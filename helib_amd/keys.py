@@ -36,6 +36,7 @@ import math
 import numpy as np
 
 from . import ctxt as hc
+from . import hostnt
 
 
 # ---------------------------------------------------------------------------------------------
@@ -386,6 +387,138 @@ class SecKey(PubKey):
                 inv = pow(factor, -1, p)
                 out = [v * inv % p for v in out]
         return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Families of key-switching matrices (src/keySwitching.cpp:297-700)
+# ---------------------------------------------------------------------------------------------
+HELIB_KSS_UNKNOWN, HELIB_KSS_FULL, HELIB_KSS_BSGS, HELIB_KSS_MIN = 0, 1, 2, 3
+HELIB_KEYSWITCH_THRESH, HELIB_KEYSWITCH_MIN_THRESH = 50, 8
+LONG_MAX = (1 << 63) - 1
+
+
+def KSGiantStepSize(D):
+    if D <= 0:
+        raise ValueError("Step size must be positive")
+    g = math.isqrt(D)
+    return g + 1 if g * g < D else g
+
+
+def _zmstar(sk):
+    z = getattr(sk, "zMStar", None)
+    if z is None:
+        z = sk.zMStar = hostnt.ZmStar(sk.cc.m, sk.cc.p)     # CKKS: p = -1, the quotient by <-1>
+    return z
+
+
+def _setKSStrategy(sk, dim, val):
+    ks = sk.__dict__.setdefault("KS_strategy", [])
+    while len(ks) <= dim + 1:
+        ks.append(HELIB_KSS_UNKNOWN)
+    ks[dim + 1] = val
+
+
+def getKSStrategy(sk, dim):
+    ks = getattr(sk, "KS_strategy", [])
+    return ks[dim + 1] if 0 <= dim + 1 < len(ks) else HELIB_KSS_UNKNOWN
+
+
+def _dim(z, i):
+    return (z.ordP, True) if i == -1 else (z.OrderOf(i), z.SameOrd(i))
+
+
+def _add1Dmats4dim(sk, i, keyID):
+    z = _zmstar(sk)
+    ord_, native = _dim(z, i)
+    for j in range(1, ord_):
+        sk.GenKeySWmatrix(1, z.genToPow(i, j), keyID, keyID)
+    if not native:
+        sk.GenKeySWmatrix(1, z.genToPow(i, -ord_), keyID, keyID)
+    _setKSStrategy(sk, i, HELIB_KSS_FULL)
+
+
+def _addSome1Dmats4dim(sk, i, keyID):
+    z = _zmstar(sk)
+    ord_, native = _dim(z, i)
+    g = KSGiantStepSize(ord_)
+    for j in range(1, g):                     # baby steps
+        sk.GenKeySWmatrix(1, z.genToPow(i, j), keyID, keyID)
+    for j in range(g, ord_, g):               # giant steps
+        sk.GenKeySWmatrix(1, z.genToPow(i, j), keyID, keyID)
+    if not native:
+        sk.GenKeySWmatrix(1, z.genToPow(i, -ord_), keyID, keyID)
+    _setKSStrategy(sk, i, HELIB_KSS_BSGS)
+
+
+def _addMinimal1Dmats4dim(sk, i, keyID):
+    z = _zmstar(sk)
+    ord_, native = _dim(z, i)
+    sk.GenKeySWmatrix(1, z.genToPow(i, 1), keyID, keyID)
+    if not native:
+        sk.GenKeySWmatrix(1, z.genToPow(i, -ord_), keyID, keyID)
+    if ord_ > HELIB_KEYSWITCH_MIN_THRESH:
+        sk.GenKeySWmatrix(1, z.genToPow(i, KSGiantStepSize(ord_)), keyID, keyID)
+    _setKSStrategy(sk, i, HELIB_KSS_MIN)
+
+
+def addSome1DMatrices(sk, bound=HELIB_KEYSWITCH_THRESH, keyID=0):
+    """all powers for generators of order <= bound, baby/giant steps for the others"""
+    z = _zmstar(sk)
+    for i in range(z.numOfGens()):
+        if bound >= z.OrderOf(i):
+            _add1Dmats4dim(sk, i, keyID)
+        else:
+            _addSome1Dmats4dim(sk, i, keyID)
+    sk.setKeySwitchMap()
+
+
+def add1DMatrices(sk, keyID=0):
+    addSome1DMatrices(sk, LONG_MAX, keyID)
+
+
+def addBSGS1DMatrices(sk, keyID=0):
+    addSome1DMatrices(sk, 0, keyID)
+
+
+def addSomeFrbMatrices(sk, bound=HELIB_KEYSWITCH_THRESH, keyID=0):
+    if bound >= _zmstar(sk).ordP:
+        _add1Dmats4dim(sk, -1, keyID)
+    else:
+        _addSome1Dmats4dim(sk, -1, keyID)
+    sk.setKeySwitchMap()
+
+
+def addFrbMatrices(sk, keyID=0):
+    addSomeFrbMatrices(sk, LONG_MAX, keyID)
+
+
+def addBSGSFrbMatrices(sk, keyID=0):
+    addSomeFrbMatrices(sk, 0, keyID)
+
+
+def addMinimal1DMatrices(sk, keyID=0):
+    for i in range(_zmstar(sk).numOfGens()):
+        _addMinimal1Dmats4dim(sk, i, keyID)
+    sk.setKeySwitchMap()
+
+
+def addMinimalFrbMatrices(sk, keyID=0):
+    _addMinimal1Dmats4dim(sk, -1, keyID)
+    sk.setKeySwitchMap()
+
+
+def addAllMatrices(sk, keyID=0):
+    m = sk.cc.m
+    for i in range(m):
+        if math.gcd(i, m) == 1:
+            sk.GenKeySWmatrix(1, i, keyID, keyID)
+    sk.setKeySwitchMap()
+
+
+def addTheseMatrices(sk, automVals, keyID=0):
+    for k in sorted(set(automVals)):
+        sk.GenKeySWmatrix(1, k, keyID, keyID)
+    sk.setKeySwitchMap()
 
 
 # ---------------------------------------------------------------------------------------------

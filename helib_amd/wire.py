@@ -720,8 +720,12 @@ def from_pubkey(pk, gens=(), ords=()):
     kmap = [key_switch_map(cc.m, ksw)] if getattr(pk, "keySwitchMap", None) else []
     empty = {"ptxtSpace": pk.ptxtSpace, "intFactor": 1, "ptxtMag": 1.0, "ratFactor": 1.0, "noiseBound": 0.0,
              "primeSet": sorted(cc.ctxtPrimes), "parts": []}
+    z = getattr(pk, "zMStar", None)
+    if z is not None and not gens:
+        gens, ords = z.gens, z.signedOrds()
     return {"context": context_of(cc, gens, ords), "pubEncrKey": enc, "skBounds": [float(b) for b in pk.skBounds],
-            "keySwitching": ksw, "keySwitchMap": kmap, "KS_strategy": [], "recryptKeyID": -1, "recryptEkey": empty}
+            "keySwitching": ksw, "keySwitchMap": kmap, "KS_strategy": list(getattr(pk, "KS_strategy", [])),
+            "recryptKeyID": -1, "recryptEkey": empty}
 
 
 def from_seckey(sk, gens=(), ords=()):
