@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""BASELINE configs[3] through the reference's own sequence: ContextBuilder<CKKS>().m(65536)
+.precision(20).bits(1400).c(3) (benchmarks/ckks_common.h:45-50 shape), a key pair with its
+relinearisation matrix, B independent pairs of PubKey::CKKSencrypt ciphertexts packed along the
+batch axis, then Ctxt::multiplyBy (src/Ctxt.cpp:1681-1774 with the CKKS branches, mirrored in
+helib_amd/ctxt.py) timed on the device:
+
+  level 1   fresh x fresh: no mod-switch (a fresh CKKS ciphertext has no noise to scale down),
+            tensorProduct + relin_CKKS_adjust + key switch at the full level;
+  level 2   product x product: both operands are mod-switched first (bringToSet), then the same.
+
+The last product of each level is decrypted and decoded (raw / ratFactor) and compared with the real
+negacyclic product of the plaintexts.  One JSON line on stdout.
+
+  python tools/bench_ckks.py                      # MI355X, m=65536 bits=1400 batch 64
+  python tools/bench_ckks.py --backend oracle --m 128 --bits 200 --batch 2 --steps 1   # CPU logic check
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def negacyclic(a, b):
+    n = len(a)
+    full = np.convolve(a, b)
+    return full[:n] - np.append(full[n:], 0.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--m", type=int, default=65536)
+    ap.add_argument("--bits", type=int, default=1400)
+    ap.add_argument("--precision", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--backend", default="hx", choices=["hx", "oracle"])
+    ap.add_argument("--bounds", action="store_true", help="noise bounds instead of measured noise")
+    args = ap.parse_args()
+
+    from helib_amd import ctxt as hc, keys as hk
+    cc = hc.ChainContext(args.m, -1, args.precision, bits=args.bits, c=3, ckks=True)
+    n, B = cc.phim, args.batch
+    if args.backend == "hx":
+        import torch
+        from helib_amd import capi as hx
+        if not torch.cuda.is_available():
+            raise SystemExit("bench_ckks.py --backend hx needs an MI355X (no CPU path)")
+        ctx = hx.Context(cc.m, 0)
+        for q in cc.primes:
+            ctx.add_prime(q)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        be, sync = hk.HxBackend(ctx, cc), torch.cuda.synchronize
+        make = lambda idx, rows: hx.DoubleCRT(ctx, idx, rows.shape[1], rows)              # noqa: E731
+    else:
+        from oracle import oracle as O
+        from oracle.backend import OPoly, OracleBackend
+        octx = O.Ctx(cc.m)
+        for q in cc.primes:
+            octx.add_prime(q)
+        be, sync = OracleBackend(octx, cc), (lambda: None)
+        if B != 1:
+            raise SystemExit("--backend oracle is unbatched: use --batch 1")
+        make = lambda idx, rows: OPoly(octx, idx, rows[:, 0])                             # noqa: E731
+    hc.Ctxt.measure = not args.bounds
+    sk = hk.SecKey(cc, be, 3)
+    t0 = time.perf_counter()
+    sk.GenSecKey(maxDegKswitch=2)
+    sync()
+    t_keygen = time.perf_counter() - t0
+
+    rng = np.random.default_rng(11)
+    f = float(1 << args.precision)
+    vals = rng.uniform(-1, 1, size=(2, B, n)) / n                 # |canonical embedding| <= 1
+    L = len(cc.ctxtPrimes)
+    rows = np.empty((2, 2, L, B, n), dtype=np.uint64)
+    first, t_enc = None, 0.0
+    for j in range(2):
+        for b in range(B):
+            t0 = time.perf_counter()
+            ct = sk.CKKSencrypt(np.rint(vals[j, b] * f).astype(np.int64), 1.0, f)
+            sync()
+            t_enc += time.perf_counter() - t0
+            if first is None:
+                first = ct
+            assert abs(ct.lnRatFactor - first.lnRatFactor) < 1e-12 and ct.lnNoise == first.lnNoise
+            rows[j, 0, :, b] = np.asarray(ct.parts["1"].download()).reshape(L, -1, n)[:, 0]
+            rows[j, 1, :, b] = np.asarray(ct.parts["s"].download()).reshape(L, -1, n)[:, 0]
+    ops = []
+    for j in range(2):
+        c = first.clone()
+        c.parts = {"1": make(list(cc.ctxtPrimes), rows[j, 0]), "s": make(list(cc.ctxtPrimes), rows[j, 1])}
+        ops.append(c)
+    fa, fb = ops
+
+    def decode(ct, b):
+        one = ct.clone()
+        one.parts = {}
+        for h, q in ct.parts.items():
+            d = np.asarray(q.download())
+            d = d.reshape(len(q.getIndexSet()), -1, n)[:, b:b + 1]
+            one.parts[h] = make(q.getIndexSet(), d)
+        raw = sk.Decrypt(one)
+        return np.array([float(v) for v in raw]) / math.exp(ct.lnRatFactor)
+
+    def timed(pairs_of, steps):
+        pairs = pairs_of(max(1, args.warmup))
+        for a, b in pairs:
+            a.multiplyBy(b)
+            _ = a.lnNoise
+        pairs = pairs_of(steps)
+        sync()
+        t0 = time.perf_counter()
+        prev = None
+        for a, b in pairs:
+            a.multLowLvl(b, destructive=True)
+            a.reLinearize()
+            if prev is not None:
+                _ = prev.lnNoise
+            prev = a
+        _ = prev.lnNoise
+        sync()
+        return time.perf_counter() - t0, prev
+
+    dt1, p1 = timed(lambda k: [(fa.clone(), fb.clone()) for _ in range(k)], args.steps)
+    want1 = [negacyclic(vals[0, b], vals[1, b]) for b in (0, B - 1)]
+    err1 = max(float(np.max(np.abs(decode(p1, b) - w))) for b, w in zip((0, B - 1), want1))
+    dt2, p2 = timed(lambda k: [(p1.clone(), p1.clone()) for _ in range(k)], args.steps)
+    want2 = [negacyclic(w, w) for w in want1]
+    err2 = max(float(np.max(np.abs(decode(p2, b) - w))) for b, w in zip((0, B - 1), want2))
+    tol = 2.0 ** (6 - args.precision) / n
+    ok = err1 < tol and err2 < tol
+    line = {
+        "tool": "bench_ckks", "backend": args.backend,
+        "workload": f"CKKS m={cc.m} precision={args.precision} bits={args.bits}: L={L} ctxt primes, "
+                    f"K={len(cc.specialPrimes)} special, D={len(cc.digits)}; Ctxt::multiplyBy on CKKSencrypt "
+                    f"ciphertexts, batch {B}, noise {'bounds' if args.bounds else 'measured'}",
+        "level1_fresh_mult_per_s": round(B * args.steps / dt1, 1), "level1_ms_per_step": round(dt1 / args.steps * 1e3, 3),
+        "level1_primes": len(p1.primeSet),
+        "level2_mult_per_s": round(B * args.steps / dt2, 1), "level2_ms_per_step": round(dt2 / args.steps * 1e3, 3),
+        "level2_operand_primes_after_bringToSet": len(p2.primeSet) - len(cc.specialPrimes),
+        "decode_max_abs_err": [err1, err2], "decode_tolerance": tol, "verified": bool(ok),
+        "log2_ratFactor": [round(p1.lnRatFactor / math.log(2), 2), round(p2.lnRatFactor / math.log(2), 2)],
+        "log2_noise": [round(p1.lnNoise / math.log(2), 2), round(p2.lnNoise / math.log(2), 2)],
+        "keygen_ms": round(t_keygen * 1e3, 2), "encrypt_ms": round(t_enc / (2 * B) * 1e3, 3),
+    }
+    print(json.dumps(line))
+    if not ok:
+        raise SystemExit("bench_ckks: decoded product is off -- results are wrong")
+
+
+if __name__ == "__main__":
+    main()
