@@ -243,6 +243,18 @@ class DoubleCRT:
         if data is not None:
             self.upload(data)
 
+    @classmethod
+    def wrap(cls, context, index_set, batch, device_ptr):
+        """hx_poly_wrap: a DoubleCRT over caller-owned device memory ([nrows][batch][phim] u64 at
+        device_ptr, e.g. a torch tensor's data_ptr()); the rows never move out of that buffer and
+        the caller keeps it alive.  Operations that need more rows than it holds fail."""
+        self = cls.__new__(cls)
+        self.context, self.batch = context, batch
+        idx = _i32(list(index_set))
+        self.h = C.c_void_p()
+        _chk(lib().hx_poly_wrap(context.h, batch, _p(idx), len(idx), C.c_void_p(int(device_ptr)), C.byref(self.h)))
+        return self
+
     def close(self):
         if self.h:
             lib().hx_poly_destroy(self.h)

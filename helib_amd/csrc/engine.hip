@@ -274,6 +274,22 @@ static int ensure_scratch(hx_ctx* c, int slot, size_t words)
   return HX_OK;
 }
 
+// stream-ordered device-to-device copy of `words` 64-bit words by a kernel (see copy_words_kernel)
+static int dcopy(hx_ctx* c, uint64_t* dst, const uint64_t* src, size_t words)
+{
+  if (words == 0 || dst == src)
+    return HX_OK;
+  if (((uintptr_t)dst | (uintptr_t)src) & 15) {  // never the case for pool slabs and whole rows
+    HIPCHK(hipMemcpyAsync(dst, src, words * 8, hipMemcpyDeviceToDevice, c->stream));
+    return HX_OK;
+  }
+  const size_t blocks = std::min<size_t>((words / 2 + 255) / 256, (size_t)256 * 16);
+  hipLaunchKernelGGL(hx::copy_words_kernel, dim3((unsigned)std::max<size_t>(blocks, 1)), dim3(256), 0, c->stream,
+                     dst, src, words);
+  HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+
 // ------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------
@@ -1254,8 +1270,7 @@ static int poly_reserve(hx_poly* p, int cap, bool keep = true)
   if (e != hipSuccess)
     return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
   if (keep && p->nrows() > 0)
-    HIPCHK(hipMemcpyAsync(nd, p->d, (size_t)p->nrows() * p->row_words() * 8,
-                          hipMemcpyDeviceToDevice, c->stream));
+    CHK(dcopy(c, nd, p->d, (size_t)p->nrows() * p->row_words()));
   pool_free(c, p->d, (size_t)p->cap_rows * p->row_words() * 8);  // stream-ordered reuse
   p->d = nd;
   p->cap_rows = cap;
@@ -1269,8 +1284,7 @@ extern "C" int hx_poly_copy(hx_poly* dst, const hx_poly* src)
   CTX_ENTER(dst->ctx);
   CHK(poly_reserve(dst, src->nrows(), /*keep=*/false));
   dst->prime_idx = src->prime_idx;
-  HIPCHK(hipMemcpyAsync(dst->d, src->d, (size_t)src->nrows() * src->row_words() * 8,
-                        hipMemcpyDeviceToDevice, dst->ctx->stream));
+  CHK(dcopy(dst->ctx, dst->d, src->d, (size_t)src->nrows() * src->row_words()));
   return HX_OK;
 }
 extern "C" int hx_poly_set_zero(hx_poly* p)
@@ -1306,8 +1320,7 @@ extern "C" int hx_poly_remove_primes(hx_poly* p, const int* idx, int n)
     if (drop)
       continue;
     if (w != r)
-      HIPCHK(hipMemcpyAsync(p->d + (size_t)w * rw, p->d + (size_t)r * rw, rw * 8,
-                            hipMemcpyDeviceToDevice, p->ctx->stream));
+      CHK(dcopy(p->ctx, p->d + (size_t)w * rw, p->d + (size_t)r * rw, rw));
     keep.push_back(p->prime_idx[r]);
     w++;
   }
@@ -1554,7 +1567,7 @@ extern "C" int hx_automorph(hx_poly* a, uint64_t k)
   hipLaunchKernelGGL(hx::gather_kernel, dim3(bx, (unsigned)nseg), dim3(256), 0, c->stream,
                      c->scratch[3], a->d, c->d_perm, c->phim, nseg, (int)c->pow2, c->m, k);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(a->d, c->scratch[3], words * 8, hipMemcpyDeviceToDevice, c->stream));
+  CHK(dcopy(c, a->d, c->scratch[3], words));
   return HX_OK;
 }
 extern "C" int hx_complex_conj(hx_poly* a)
@@ -2097,8 +2110,7 @@ extern "C" int hx_add_primes(hx_poly* a, const int* add_idx, int nadd)
     return fail(HX_ERR_UNSUPPORTED, "addPrimes from more than 64 primes");
   // toPoly: inverse transform of a copy
   CHK(ensure_scratch(c, 0, (size_t)old * rw));
-  HIPCHK(hipMemcpyAsync(c->scratch[0], a->d, (size_t)old * rw * 8, hipMemcpyDeviceToDevice,
-                        c->stream));
+  CHK(dcopy(c, c->scratch[0], a->d, (size_t)old * rw));
   CHK(ntt_rows(c, c->scratch[0], a->prime_idx, old, 0, old, a->batch, true));
   std::vector<int> tgt(add_idx, add_idx + nadd);
   ExtPlan* pl;
@@ -2144,7 +2156,7 @@ extern "C" int hx_poly_rem(const hx_poly* a, uint64_t t, uint64_t* out_host)
   if (n > 64)
     return fail(HX_ERR_UNSUPPORTED, "toPoly from more than 64 primes on the device");
   CHK(ensure_scratch(c, 0, (size_t)(n + 1) * rw));
-  HIPCHK(hipMemcpyAsync(c->scratch[0], a->d, (size_t)n * rw * 8, hipMemcpyDeviceToDevice, c->stream));
+  CHK(dcopy(c, c->scratch[0], a->d, (size_t)n * rw));
   CHK(ntt_rows(c, c->scratch[0], a->prime_idx, n, 0, n, a->batch, true));
   std::vector<int> tgt(1, 0);
   std::vector<uint64_t> mod(1, t);
@@ -2351,34 +2363,47 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
   }
   if (nother > 0)
     return HX_ERR_UNSUPPORTED;
-  // toPoly(delta, diff): inverse transform of the dropped rows
-  CHK(ensure_scratch(c, 0, (size_t)nd * rw));
-  CHK(ensure_scratch(c, 1, (size_t)nk * rw));
-  for (int k = 0; k < nd; k++) {
-    int r = find_row(a->prime_idx, drop[k]);
-    HIPCHK(hipMemcpyAsync(c->scratch[0] + (size_t)k * rw, a->d + (size_t)r * rw, rw * 8,
-                          hipMemcpyDeviceToDevice, c->stream));
-  }
-  CHK(ntt_rows(c, c->scratch[0], drop, nd, 0, nd, a->batch, true));
+  // toPoly(delta, diff): inverse transform of the dropped rows, out of place into scratch rows
+  // of the same index (no row copies)
+  CHK(ensure_scratch(c, 0, (size_t)a->nrows() * rw));
+  std::vector<std::pair<int, int>> drows;
+  for (int k = 0; k < nd; k++)
+    drows.emplace_back(find_row(a->prime_idx, drop[k]), drop[k]);
+  CHK(ntt_list(c, a->d, c->scratch[0], drows, a->batch, true));
   ExtPlan* pl;
   CHK(get_plan(c, drop, keep, ptxt > 1 ? ptxt : 0, &pl));
+  // delta on the kept primes goes into a fresh slab that then becomes the polynomial's storage:
+  // new[w] = (old[row of keep[w]] - delta[w]) / diffProd, so neither removePrimes' compaction nor
+  // a second buffer is needed
+  uint64_t* nd_buf = nullptr;
+  const int ncap = nk + 2;
+  const size_t nbytes = (size_t)ncap * rw * 8;
+  hipError_t pe = pool_alloc(c, nbytes, (void**)&nd_buf);
+  if (pe != hipSuccess)
+    return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(pe));
   ExtArgs args;
   clear_args(args);
   args.src = c->scratch[0];
-  args.dst = c->scratch[1];
+  args.dst = nd_buf;
   for (int k = 0; k < nd; k++)
-    args.src_row[k] = (uint16_t)k;
+    args.src_row[k] = (uint16_t)drows[k].first;
   for (int t = 0; t < nk; t++)
     args.dst_row[t] = (uint16_t)t;
+  int rc = HX_OK;
   if (c->want_frac) {
     args.frac = frac_take(c, rw);
     if (!args.frac)
-      return fail(HX_ERR_INVALID, "internal: fraction buffer too small");
+      rc = fail(HX_ERR_INVALID, "internal: fraction buffer too small");
   }
-  CHK(launch_extend(c, pl, args, rw));
-  CHK(ntt_rows(c, c->scratch[1], keep, nk, 0, nk, a->batch, false));
-  // removePrimes(diff); *this -= delta; *this /= diffProd
-  CHK(hx_poly_remove_primes(a, drop.data(), nd));
+  if (rc == HX_OK)
+    rc = launch_extend(c, pl, args, rw);
+  if (rc == HX_OK)
+    rc = ntt_rows(c, nd_buf, keep, nk, 0, nk, a->batch, false);
+  if (rc != HX_OK) {
+    pool_free(c, nd_buf, nbytes);
+    return rc;
+  }
+  // *this -= delta; *this /= diffProd, reading the kept rows where they are
   RowMap2 map;
   RowScalars sc;
   for (int r = 0; r < nk; r++) {
@@ -2387,13 +2412,22 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
       v = hxh::mulmod(v, c->primes[drop[k]].q % q, q);
     uint64_t inv = hxh::invmod(v, q);
     map.p[r] = (uint16_t)keep[r];
-    map.brow[r] = (uint16_t)r;
+    map.brow[r] = (uint16_t)find_row(a->prime_idx, keep[r]);
     sc.c[r] = inv;
     sc.cp[r] = hxh::shoup(inv, q);
   }
-  hipLaunchKernelGGL(hx::sub_scale_kernel, ew_grid(rw, nk), dim3(256), 0, c->stream, a->d,
-                     c->scratch[1], map, sc, rw, c->d_primes);
+  hipLaunchKernelGGL(hx::sub_scale_from_kernel, ew_grid(rw, nk), dim3(256), 0, c->stream, nd_buf,
+                     a->d, map, sc, rw, c->d_primes);
   HIPCHK(hipGetLastError());
+  if (a->owns) {
+    pool_free(c, a->d, (size_t)a->cap_rows * rw * 8);  // stream-ordered reuse
+    a->d = nd_buf;
+    a->cap_rows = ncap;
+  } else {  // caller-owned storage: the compact result goes back into it
+    CHK(dcopy(c, a->d, nd_buf, (size_t)nk * rw));
+    pool_free(c, nd_buf, nbytes);
+  }
+  a->prime_idx = keep;
   return HX_OK;
 }
 
@@ -2694,8 +2728,7 @@ extern "C" int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const 
   for (int d = 0; d < ndig; d++)
     out->prime_idx.insert(out->prime_idx.end(), all.begin(), all.end());
   CHK(ensure_scratch(c, 0, (size_t)L * rw));
-  HIPCHK(hipMemcpyAsync(c->scratch[0], a->d, (size_t)L * rw * 8, hipMemcpyDeviceToDevice,
-                        c->stream));
+  CHK(dcopy(c, c->scratch[0], a->d, (size_t)L * rw));
   CHK(ntt_rows(c, c->scratch[0], a->prime_idx, L, 0, L, a->batch, true));
   CHK(break_digits_coef(c, c->scratch[0], a->prime_idx, dig_idx, dig_off, ndig, all, out->d, rw));
   CHK(ntt_rows(c, out->d, all, nall, 0, ndig * nall, a->batch, false));

@@ -13,6 +13,23 @@ namespace hx {
 // =====================================================================
 enum EwOp { EW_ADD = 0, EW_SUB = 1, EW_MUL = 2 };
 
+// Device-to-device copies of the engine's own buffers go through this kernel instead of
+// hipMemcpyAsync: one route (a shader at HBM speed, visible in a kernel trace) whatever copy
+// engine the runtime would have picked.  n words, 16 B per lane and step; dst/src 16-byte aligned
+// (rows of the slab pool are).
+__global__ void __launch_bounds__(256)
+copy_words_kernel(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, size_t n)
+{
+  const size_t nvec = n / 2;
+  ulonglong2* d = reinterpret_cast<ulonglong2*>(dst);
+  const ulonglong2* s = reinterpret_cast<const ulonglong2*>(src);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (size_t)gridDim.x * blockDim.x)
+    d[i] = s[i];
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+    dst[n - 1] = src[n - 1];
+}
+
 template <int OP>
 __global__ void __launch_bounds__(256)
 ew_binary_kernel(uint64_t* __restrict__ a, const uint64_t* __restrict__ b, RowMap2 map,
@@ -763,6 +780,28 @@ sub_scale_kernel(uint64_t* __restrict__ a, const uint64_t* __restrict__ b, RowMa
     x.x = mul_shoup(sub_mod(x.x, y.x, q), c, cp, q);
     x.y = mul_shoup(sub_mod(x.y, y.y, q), c, cp, q);
     pa[i] = x;
+  }
+}
+
+// the same with the minuend elsewhere: d[row] = (x[map.brow[row]] - d[row]) * c, where d holds
+// delta on entry -- the kept rows are read from the old slab where they lie and the result becomes
+// the polynomial's new, compact storage
+__global__ void __launch_bounds__(256)
+sub_scale_from_kernel(uint64_t* __restrict__ d, const uint64_t* __restrict__ x, RowMap2 map,
+                      RowScalars sc, size_t row_words, const PrimeDev* __restrict__ primes)
+{
+  const int row = blockIdx.y;
+  const uint64_t q = primes[map.p[row]].q;
+  const uint64_t c = sc.c[row], cp = sc.cp[row];
+  ulonglong2* pd = reinterpret_cast<ulonglong2*>(d + (size_t)row * row_words);
+  const ulonglong2* px = reinterpret_cast<const ulonglong2*>(x + (size_t)map.brow[row] * row_words);
+  const size_t nvec = row_words / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (size_t)gridDim.x * blockDim.x) {
+    ulonglong2 y = pd[i], v = px[i];
+    v.x = mul_shoup(sub_mod(v.x, y.x, q), c, cp, q);
+    v.y = mul_shoup(sub_mod(v.y, y.y, q), c, cp, q);
+    pd[i] = v;
   }
 }
 

@@ -1297,3 +1297,31 @@ def test_bluestein_conv_2_18_radix8_split(hx, m):
     assert np.array_equal(d.iFFT().download(), x)
     with pytest.raises(hx.HxError):                      # one step further: conv size 2^19
         hx.Context(131073).add_prime(O.PrimeGen(56, 131073).next())
+
+
+def test_wrapped_poly_multi_prime_scale_down_stays_in_caller_memory(hx):
+    """hx_poly_wrap + the generic (several dropped primes) scaleDownToSet: a library-owned poly
+    swaps to a fresh compact slab, a wrapped one must get the same rows written back into the
+    caller's buffer."""
+    import torch
+    m = 16384
+    primes = primes_for(m, 7)
+    P = Pair(hx, m, primes)
+    idx = list(range(7))
+    x = P.rand(idx, 71, batch=3)
+    own = hx.DoubleCRT(P.g, idx, 3, x)
+    buf = torch.from_numpy(x.view(np.int64).copy()).to("cuda:0")
+    w = hx.DoubleCRT.wrap(P.g, idx, 3, buf.data_ptr())
+    assert np.array_equal(w.download(), x)
+    keep = [0, 2, 3, 6]                                    # drops 1, 4, 5: compaction would move rows 2, 3, 6
+    own.scaleDownToSet(keep, 65537)
+    w.scaleDownToSet(keep, 65537)
+    assert w.getIndexSet() == own.getIndexSet() == keep
+    want = own.download()
+    for b in range(3):
+        assert np.array_equal(want[:, b], P.o.scale_down(idx, x[:, b], [1, 4, 5], 65537))
+    assert np.array_equal(w.download(), want)
+    torch.cuda.synchronize()
+    back = buf.cpu().numpy().view(np.uint64).reshape(7, 3, P.N)
+    assert np.array_equal(back[:4], want)                 # the result lives in the caller's tensor
+    w.close()

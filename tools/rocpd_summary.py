@@ -9,7 +9,7 @@ import sys
 
 
 def main():
-    path = sys.argv[1]
+    path = [a for a in sys.argv[1:] if not a.startswith("--")][0]
     dbs = [path] if path.endswith(".db") else sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True))
     for db in dbs:
         c = sqlite3.connect(db)
@@ -23,6 +23,19 @@ def main():
         for n, k, s, a, mn, mx in rows:
             short = n if len(n) <= 70 else n[:67] + "..."
             print(f"{short:70s} {k:6d} {s/1e3:12.1f} {a/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f} {100*s/tot:6.2f}")
+        if "--gaps" in sys.argv:
+            # where the device sat idle: the largest gaps between the end of one kernel and the
+            # start of the next (host-bound stretches, synchronous API calls, copy engines)
+            seq = c.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
+            gaps = []
+            for (n0, s0, e0), (n1, s1, e1) in zip(seq, seq[1:]):
+                if s1 - e0 > 100000:
+                    gaps.append((s1 - e0, n0, n1, e0 - seq[0][1]))
+            print(f"# idle gaps > 100 us: {len(gaps)}, total {sum(g[0] for g in gaps)/1e6:.1f} ms; "
+                  f"trace span {(seq[-1][2]-seq[0][1])/1e6:.1f} ms, busy {tot/1e6:.1f} ms")
+            last = [g for g in gaps if g[3] > 0.5 * (seq[-1][2] - seq[0][1])]   # second half: the timed loops
+            for g, n0, n1, at in sorted(last, reverse=True)[:25]:
+                print(f"  {g/1e3:10.1f} us at +{at/1e6:9.1f} ms  after {n0[:48]:48s} before {n1[:48]}")
         try:
             pm = c.execute("select * from pmc_events limit 1").fetchall()
             if pm:
