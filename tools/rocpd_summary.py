@@ -23,6 +23,16 @@ def main():
         for n, k, s, a, mn, mx in rows:
             short = n if len(n) <= 70 else n[:67] + "..."
             print(f"{short:70s} {k:6d} {s/1e3:12.1f} {a/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f} {100*s/tot:6.2f}")
+        if "--by-grid" in sys.argv and "grid_x" in cols:
+            # the same kernel is launched at very different sizes (batch-1 key generation and
+            # encryption next to the batch-128 timed loop): one line per (kernel, grid)
+            print("# by launch size (kernels with >= 2 sizes; workgroups = grid_x / workgroup_x)")
+            for n, gx, wx, k, a, mn, mx in c.execute(
+                    f"select {name_col}, grid_x, workgroup_x, count(*), avg(end-start), min(end-start), max(end-start) "
+                    "from kernels group by 1, 2 having count(*) >= 4 order by 1, 2 desc").fetchall():
+                if "ntt_" in n or "break_digits" in n or "keyswitch" in n or "tensor" in n:
+                    short = n if len(n) <= 60 else n[:57] + "..."
+                    print(f"  {short:60s} wgs {gx // max(wx, 1):7d} calls {k:5d} avg {a/1e3:9.2f} us  min {mn/1e3:9.2f}  max {mx/1e3:9.2f}")
         if "--gaps" in sys.argv:
             # where the device sat idle: the largest gaps between the end of one kernel and the
             # start of the next (host-bound stretches, synchronous API calls, copy engines)
