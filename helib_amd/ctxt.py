@@ -494,16 +494,145 @@ class Ctxt:
         self.bringToSet(target)
 
     # ---- arithmetic ----
-    def addCtxt(self, other):
-        if self.primeSet != other.primeSet or self.intFactor != other.intFactor or \
-                self.ptxtSpace != other.ptxtSpace:
-            raise NotImplementedError("addCtxt: operands must share prime set / intFactor here")
-        for h, p in other.parts.items():
+    def mulIntFactor(self, e):
+        """Ctxt::mulIntFactor (src/Ctxt.cpp:331-340)"""
+        if e == 1:
+            return
+        self.intFactor = self.intFactor * e % self.ptxtSpace
+        bal = e - self.ptxtSpace if e > self.ptxtSpace // 2 else e
+        for p in self.parts.values():
+            p.mulConstant(bal)
+        self.lnNoise = self.lnNoise + math.log(abs(bal))
+
+    def negate(self):
+        for p in self.parts.values():
+            p.Negate()
+
+    @staticmethod
+    def equalizeRationalFactors(c1, c2):
+        """Ctxt::equalizeRationalFactors (src/Ctxt.cpp:1212-1356): scale both CKKS ciphertexts by
+        small integers (continued-fraction convergents of the ratio of their factors) until they
+        share one factor, stopping as soon as the discretisation error is within sqrt(2) of the
+        error the sum has anyway.  Computed relative to the smaller factor, so plain doubles do
+        (the reference's xdouble carries the same 53 bits)."""
+        big, small = (c1, c2) if c1.lnRatFactor > c2.lnRatFactor else (c2, c1)
+        base = small.lnRatFactor
+        x = math.exp(big.lnRatFactor - base)
+        r = c1.context.r
+        denomBound = 1 << (r + 1)
+        epsilon = 0.125 / denomBound
+        a = int(math.floor(x + epsilon))
+        xi = x - a
+        prevDenom, denom = 0, 1
+        numer = int(math.floor(denom * x + 0.5))
+        m1, of1, oe1 = big.ptxtMag, x, math.exp(big.lnNoise - base)
+        m2, of2, oe2 = small.ptxtMag, 1.0, math.exp(small.lnNoise - base)
+        target = oe1 / of1 + oe2 / of2
+
+        def calc_err(f, f1, e1, f2, e2):
+            return m1 * abs(f1 / f - 1.0) + m2 * abs(f2 / f - 1.0) + (e1 + e2) / f
+        while True:
+            f1, e1 = of1 * denom, oe1 * denom
+            f2, e2 = of2 * numer, oe2 * numer
+            err1, err2 = calc_err(f1, f1, e1, f2, e2), calc_err(f2, f1, e1, f2, e2)
+            if err1 < err2:
+                f, fe1, fe2, err = f1, e1, e2 + m2 * abs(f2 - f1), err1
+            else:
+                f, fe1, fe2, err = f2, e1 + m1 * abs(f2 - f1), e2, err2
+            if err < math.sqrt(2.0) * target or xi <= 0:
+                break
+            xi = 1.0 / xi
+            ai = int(math.floor(xi + epsilon))
+            xi -= ai
+            tmpDenom = denom * ai + prevDenom
+            if tmpDenom > denomBound:
+                break
+            prevDenom, denom = denom, tmpDenom
+            numer = int(math.floor(denom * x + 0.5))
+        if denom != 1:
+            for p in big.parts.values():
+                p.mulConstant(denom)
+        if numer != 1:
+            for p in small.parts.values():
+                p.mulConstant(numer)
+        big.lnRatFactor = small.lnRatFactor = math.log(f) + base
+        big.lnNoise, small.lnNoise = _ln(fe1) + base, _ln(fe2) + base
+
+    def addCtxt(self, other, negative=False):
+        """Ctxt::addCtxt (src/Ctxt.cpp:1405-1556): plaintext spaces reduced to their gcd (BGV),
+        both operands mod-switched UP to the union of their prime sets, CKKS factors equalised,
+        BGV intFactors harmonised by the (e1, e2) of least noise along the extended Euclidean
+        sequence, then the parts added handle by handle."""
+        ctx = self.context
+        if not other.parts:
+            return
+        if not self.parts:
+            c = other.clone()
+            self.__dict__.update(c.__dict__)
+            if negative:
+                self.negate()
+            return
+        o = other
+        owned = False
+
+        def own():
+            nonlocal o, owned
+            if not owned:
+                o, owned = other.clone(), True
+            return o
+        if ctx.ckks:
+            if self.ptxtSpace != 1 or other.ptxtSpace != 1:
+                raise ValueError("Plaintext spaces incompatible")
+        else:
+            g = math.gcd(self.ptxtSpace, other.ptxtSpace)
+            if g <= 1:
+                raise ValueError("New and old plaintext spaces are coprime")
+            self.ptxtSpace = g
+            self.intFactor %= g
+            if other.ptxtSpace != g:
+                own().ptxtSpace = g
+                o.intFactor %= g
+        if o.primeSet - self.primeSet:
+            self.modUpToSet(self.primeSet | o.primeSet)
+        if self.primeSet - o.primeSet:
+            own().modUpToSet(self.primeSet)
+        if ctx.ckks:
+            Ctxt.equalizeRationalFactors(self, own())
+        e1 = e2 = 1
+        if not ctx.ckks and self.intFactor != o.intFactor:
+            P = self.ptxtSpace
+            ratio = o.intFactor * pow(self.intFactor, -1, P) % P
+            bal = lambda e: abs(e - P if e > P // 2 else e)                 # noqa: E731
+            norm = lambda a, b: logaddexp(self.lnNoise + _ln(bal(a)), o.lnNoise + _ln(bal(b)))  # noqa: E731
+            r0, t0, r1, t1 = P, 0, ratio, 1
+            e1, e2 = r1, t1
+            best = norm(e1, e2)
+            while r1 != 0:
+                q = r0 // r1
+                r0, r1, t0, t1 = r1, r0 % r1, t1, t0 - t1 * q
+                a, b = r1 % P, t1 % P
+                if a % ctx.p != 0:
+                    cand = norm(a, b)
+                    if cand < best:
+                        e1, e2, best = a, b, cand
+            assert e1 * self.intFactor % P == e2 * o.intFactor % P
+            assert math.gcd(e1, P) == 1 and math.gcd(e2, P) == 1
+        if e2 != 1:
+            own().mulIntFactor(e2)
+        if e1 != 1:
+            self.mulIntFactor(e1)
+        for h, p in o.parts.items():
             if h in self.parts:
-                self.parts[h] += p
+                if negative:
+                    self.parts[h] -= p
+                else:
+                    self.parts[h] += p
             else:
                 self.parts[h] = p.copy()
-        self.lnNoise = logaddexp(self.lnNoise, other.lnNoise)
+                if negative:
+                    self.parts[h].Negate()
+        self.ptxtMag += o.ptxtMag
+        self.lnNoise = logaddexp(self.lnNoise, o.lnNoise)
 
     @staticmethod
     def computeIntervalForMul(c1, c2):

@@ -388,7 +388,7 @@ def from_ctxt(ct, b=0):
     parts = [(ct.parts[h].getIndexSet(), ct.parts[h].download()[:, b], _handle_of(h)) for h in order]
     ckks = getattr(ct.context, "ckks", False)
     return {"ptxtSpace": ct.ptxtSpace, "intFactor": ct.intFactor,
-            "ptxtMag": float(ct.ptxtMag) if ckks else 1.0,
+            "ptxtMag": float(ct.ptxtMag),
             "ratFactor": _xd_from_ln(ct.lnRatFactor) if ckks else 1.0,
             "noiseBound": _xd_from_ln(ct.lnNoise),
             "primeSet": sorted(ct.primeSet), "parts": parts}

@@ -43,6 +43,9 @@ class OPoly:
             self.rows[r] = O.row_op("mul_scalar", self.rows[r], int(num) % q, q)
         return self
 
+    def Negate(self):
+        return self.mulConstant(-1)
+
     def Exp(self, e):
         """DoubleCRT::Exp (src/DoubleCRT.cpp:1142-1156): entry-wise PowerMod by square and multiply"""
         base, acc = self.copy(), None

