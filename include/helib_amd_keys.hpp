@@ -1,0 +1,378 @@
+// helib_amd_keys.hpp -- header-only C++17 host side of SURVEY row N2: keys, encryption and
+// decryption as compositions of the engine's DoubleCRT operations, in the reference's names.
+//
+//   Sampler   src/sample.cpp: sampleSmall :321-341, sampleHWt :257-304, sampleGaussian :398-440 and the
+//             *Bounded redraw loops :269-304, 342-396, 443-486 (the test is the device's
+//             embeddingLargestCoeff, hx_embedding_norm)
+//   RLWE1     src/keys.cpp:39-72            c0 = p*e - c1*s
+//   SecKey    src/keys.cpp: GenSecKey/ImportSecKey :1099-1157, GenKeySWmatrix :1161-1255,
+//             PubKey::Encrypt :358-488 (BGV), SecKey::Decrypt :1327-1420, setKeySwitchMap :122-172
+//
+// Randomness is std::mt19937_64 (the reference's is NTL's PRG; distributions, not streams, are what
+// the algorithms fix -- SURVEY section 8c).  Power-of-two m only on this host side (the general-m
+// samplers, which reduce modulo Phi_m, are in helib_amd/keys.py).  One secret key per object.
+// No CPU fallback: every polynomial operation is a call into libhelib_amd.so.
+#pragma once
+#include <cmath>
+#include <memory>
+#include <random>
+
+#include "helib_amd_ctxt.hpp"
+
+namespace helib_amd {
+
+class Sampler {
+public:
+  Sampler(const ChainContext& c, const Context& d, uint64_t seed) : cc_(&c), dev_(&d), rng_(seed)
+  {
+    if (!c.pow2)
+      throw LogicError("helib_amd_keys.hpp samples for power-of-two m only");
+  }
+  std::mt19937_64& rng() { return rng_; }
+
+  // each coefficient 0 with probability 1/2, +-1 with probability 1/4 each
+  std::vector<long> sampleSmall()
+  {
+    std::vector<long> v((size_t)cc_->phim);
+    for (auto& x : v) {
+      uint64_t r = rng_();
+      x = (r & 1) ? ((r & 2) ? 1 : -1) : 0;
+    }
+    return v;
+  }
+  std::vector<long> sampleHWt(long hwt)
+  {
+    long n = cc_->phim;
+    hwt = std::min(hwt, n);
+    std::vector<long> v((size_t)n, 0);
+    long placed = 0;
+    while (placed < hwt) {
+      size_t pos = (size_t)(rng_() % (uint64_t)n);
+      if (v[pos] == 0) {
+        v[pos] = (rng_() & 1) ? 1 : -1;
+        placed++;
+      }
+    }
+    return v;
+  }
+  std::vector<long> sampleGaussian(double stdev)
+  {
+    std::normal_distribution<double> g(0.0, stdev);
+    std::vector<long> v((size_t)cc_->phim);
+    for (auto& x : v)
+      x = std::lround(g(rng_));
+    return v;
+  }
+  double embeddingLargestCoeff(const std::vector<long>& f) const
+  {
+    std::vector<double> d(f.begin(), f.end());
+    double out = 0;
+    check(hx_embedding_norm(dev_->handle(), d.data(), 1, &out));
+    return out;
+  }
+  // "while (++count < 1000 && val > bound)" redraw loops; return the bound that holds
+  template <class Draw>
+  std::vector<long> bounded(Draw draw, double bound, const char* what)
+  {
+    for (int i = 0; i < 1000; i++) {
+      std::vector<long> f = draw();
+      if (embeddingLargestCoeff(f) <= bound)
+        return f;
+    }
+    throw RuntimeError(std::string("Error: ") + what + ", after 1000 trials, still val > bound");
+  }
+  std::vector<long> sampleSmallBounded(double& bound)
+  {
+    double n = (double)cc_->phim;
+    bound = std::sqrt(n * std::log(n) / 2.0);
+    return bounded([&] { return sampleSmall(); }, bound, "sampleSmallBounded");
+  }
+  std::vector<long> sampleHWtBounded(long hwt, double& bound)
+  {
+    bound = std::sqrt((double)hwt * std::log((double)cc_->phim));
+    return bounded([&] { return sampleHWt(hwt); }, bound, "sampleHWtBounded");
+  }
+  std::vector<long> sampleGaussianBounded(double stdev, double& bound)
+  {
+    double n = (double)cc_->phim;
+    bound = stdev * std::sqrt(n * std::log(n));
+    return bounded([&] { return sampleGaussian(stdev); }, bound, "sampleGaussianBounded");
+  }
+
+private:
+  const ChainContext* cc_;
+  const Context* dev_;
+  std::mt19937_64 rng_;
+};
+
+// one key-switching matrix W[s^r(X^t) -> s] with its bookkeeping (include/helib/keySwitching.h:86-101)
+struct KeySwitchMatrix {
+  long fromSPower = 0, fromXPower = 1;
+  std::unique_ptr<KeySwitch> W;
+  long ptxtSpace = 0;
+  double noiseBound = 0;
+};
+
+class SecKey {
+public:
+  SecKey(const ChainContext& c, const Context& d, uint64_t seed = 0) : cc(&c), dev(&d), sampler(c, d, seed) {}
+
+  const ChainContext* cc;
+  const Context* dev;
+  Sampler sampler;
+  std::vector<long> sKey;        // the secret polynomial (small coefficients)
+  double skBound = 0;
+  std::unique_ptr<DoubleCRT> pubEncrKey0, pubEncrKey1;
+  double pubEncrKeyNoise = 0;
+  long ptxtSpace = 0;
+  std::vector<KeySwitchMatrix> keySwitching;   // in generation order, as the reference's vector
+  KeySet keys;                                  // what a Ctxt consults
+
+  // ---- DoubleCRT helpers ----
+  static uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)((unsigned __int128)a * b % q); }
+  DoubleCRT fromCoeffs(const IndexSet& idx, const std::vector<long>& coeffs) const
+  {
+    size_t n = (size_t)cc->phim;
+    std::vector<uint64_t> rows(idx.size() * n);
+    for (size_t r = 0; r < idx.size(); r++) {
+      long q = cc->primes[(size_t)idx[r]];
+      for (size_t j = 0; j < n; j++) {
+        long v = j < coeffs.size() ? coeffs[j] % q : 0;
+        rows[r * n + j] = (uint64_t)(v < 0 ? v + q : v);
+      }
+    }
+    DoubleCRT d(*dev, idx, 1, DoubleCRT::Uninitialized{});
+    d.setRows(rows);
+    d.FFT();
+    return d;
+  }
+  // DoubleCRT::randomize: uniform residues (the evaluation rows of a uniform polynomial are uniform)
+  DoubleCRT randomize(const IndexSet& idx, std::vector<uint64_t>* host = nullptr)
+  {
+    size_t n = (size_t)cc->phim;
+    std::vector<uint64_t> rows(idx.size() * n);
+    for (size_t r = 0; r < idx.size(); r++) {
+      std::uniform_int_distribution<uint64_t> u(0, (uint64_t)cc->primes[(size_t)idx[r]] - 1);
+      for (size_t j = 0; j < n; j++)
+        rows[r * n + j] = u(sampler.rng());
+    }
+    DoubleCRT d(*dev, idx, 1, DoubleCRT::Uninitialized{});
+    d.setRows(rows);
+    if (host)
+      *host = std::move(rows);
+    return d;
+  }
+  // per-row residues of prod_{i in s} q_i (a ZZ in the reference)
+  std::vector<uint64_t> productMod(const IndexSet& rows, const IndexSet& s) const
+  {
+    std::vector<uint64_t> out(rows.size(), 1);
+    for (size_t r = 0; r < rows.size(); r++) {
+      uint64_t q = (uint64_t)cc->primes[(size_t)rows[r]];
+      for (int i : s)
+        out[r] = mulmod(out[r], (uint64_t)cc->primes[(size_t)i] % q, q);
+    }
+    return out;
+  }
+  static std::vector<uint64_t> scalarRows(const IndexSet& rows, const ChainContext& c, long v)
+  {
+    std::vector<uint64_t> out(rows.size());
+    for (size_t r = 0; r < rows.size(); r++) {
+      long q = c.primes[(size_t)rows[r]];
+      long t = v % q;
+      out[r] = (uint64_t)(t < 0 ? t + q : t);
+    }
+    return out;
+  }
+
+  // RLWE1 (src/keys.cpp:39-72): c0 = p*e - c1*s on the primes of c1; returns the noise bound
+  double RLWE1(DoubleCRT& c0, const DoubleCRT& c1, const IndexSet& idx, long p)
+  {
+    double bound = 0;
+    std::vector<long> e = sampler.sampleGaussianBounded(cc->stdev, bound);
+    c0 = fromCoeffs(idx, e);
+    if (p > 1) {
+      c0.mulConstant(scalarRows(idx, *cc, p));
+      bound *= (double)p;
+    }
+    DoubleCRT tmp = c1;
+    tmp *= fromCoeffs(idx, sKey);
+    c0 -= tmp;
+    return bound;
+  }
+
+  // SecKey::GenSecKey + ImportSecKey (src/keys.cpp:1099-1157)
+  void GenSecKey(long maxDegKswitch = 3)
+  {
+    if (!sKey.empty())
+      throw LogicError("this host side holds one secret key per SecKey object");
+    sKey = cc->hwt > 0 ? sampler.sampleHWtBounded(cc->hwt, skBound) : sampler.sampleSmallBounded(skBound);
+    ptxtSpace = cc->ptxtSpace;
+    const IndexSet& idx = cc->ctxtPrimes;
+    pubEncrKey1 = std::make_unique<DoubleCRT>(randomize(idx));
+    pubEncrKey0 = std::make_unique<DoubleCRT>(*dev, idx, 1, DoubleCRT::Uninitialized{});
+    pubEncrKeyNoise = RLWE1(*pubEncrKey0, *pubEncrKey1, idx, ptxtSpace);
+    keys.ptxtSpace = ptxtSpace;
+    for (long e = 2; e <= maxDegKswitch; e++)
+      GenKeySWmatrix(e, 1);
+  }
+
+  bool haveKeySWmatrix(long sPow, long xPow) const
+  {
+    for (auto& k : keySwitching)
+      if (k.fromSPower == sPow && k.fromXPower == xPow)
+        return true;
+    return false;
+  }
+
+  // SecKey::GenKeySWmatrix (src/keys.cpp:1161-1255): b_i = p*e_i - a_i*s + P*B_i*s^r(X^t),
+  // B_i = product of the digits before i
+  void GenKeySWmatrix(long fromSPower, long fromXPower)
+  {
+    if (fromSPower <= 0 || fromXPower <= 0 || (fromSPower == 1 && fromXPower == 1) ||
+        haveKeySWmatrix(fromSPower, fromXPower))
+      return;
+    IndexSet idx = cc->ctxtPrimes;
+    idx.insert(idx.end(), cc->specialPrimes.begin(), cc->specialPrimes.end());
+    DoubleCRT fromKey = fromCoeffs(idx, sKey);
+    if (fromXPower > 1)
+      fromKey.automorph(fromXPower);
+    if (fromSPower > 1)
+      fromKey.Exp(fromSPower);
+    const size_t D = cc->digits.size(), n = (size_t)cc->phim, nr = idx.size();
+    std::vector<uint64_t> hb(D * nr * n), ha(D * nr * n);
+    double noise = 0;
+    fromKey.mulConstant(productMod(idx, cc->specialPrimes));
+    for (size_t i = 0; i < D; i++) {
+      std::vector<uint64_t> arow;
+      DoubleCRT a = randomize(idx, &arow);
+      DoubleCRT b(*dev, idx, 1, DoubleCRT::Uninitialized{});
+      noise = RLWE1(b, a, idx, ptxtSpace);
+      b += fromKey;
+      fromKey.mulConstant(productMod(idx, cc->digits[i]));
+      std::vector<uint64_t> brow = b.getRows();
+      std::copy(brow.begin(), brow.end(), hb.begin() + i * nr * n);
+      std::copy(arow.begin(), arow.end(), ha.begin() + i * nr * n);
+    }
+    KeySwitchMatrix ks;
+    ks.fromSPower = fromSPower;
+    ks.fromXPower = fromXPower;
+    ks.W = std::make_unique<KeySwitch>(*dev, (int)D, idx, hb, ha);
+    ks.ptxtSpace = ptxtSpace;
+    ks.noiseBound = noise;
+    keySwitching.push_back(std::move(ks));
+    const KeySwitchMatrix& k = keySwitching.back();
+    if (fromSPower == 2 && fromXPower == 1) {
+      keys.relin = k.W.get();
+      keys.lnNoise = std::log(k.noiseBound);
+    } else if (fromSPower == 1) {
+      keys.automorph[fromXPower] = k.W.get();
+      if (!keys.relin)
+        keys.lnNoise = std::log(k.noiseBound);
+    }
+  }
+  void setKeySwitchMap() { keys.setKeySwitchMap(cc->m); }
+
+  // balanced_MulMod(ptxt, Q mod p, p) (src/NumbTh.cpp:876-891)
+  std::vector<long> ptxtFixed(const std::vector<long>& ptxt, const IndexSet& primeSet, long p)
+  {
+    uint64_t QmodP = 1;
+    for (int i : primeSet)
+      QmodP = mulmod(QmodP, (uint64_t)cc->primes[(size_t)i] % (uint64_t)p, (uint64_t)p);
+    std::vector<long> out((size_t)cc->phim, 0);
+    for (size_t i = 0; i < ptxt.size() && i < out.size(); i++) {
+      long v = ptxt[i] % p;
+      if (v < 0)
+        v += p;
+      long c = (long)mulmod((uint64_t)v, QmodP, (uint64_t)p);
+      if (c > p / 2 || (p % 2 == 0 && c == p / 2 && (sampler.rng()() & 1)))
+        c -= p;
+      out[i] = c;
+    }
+    return out;
+  }
+
+  // PubKey::Encrypt, BGV (src/keys.cpp:358-488): r*pk + p*(e0, e1) + balanced(ptxt * Q mod p)
+  Ctxt Encrypt(const std::vector<long>& ptxt)
+  {
+    if (!pubEncrKey0)
+      throw LogicError("no public encryption key");
+    const long p = ptxtSpace;
+    const IndexSet& idx = cc->ctxtPrimes;
+    DoubleCRT parts[2] = {*pubEncrKey0, *pubEncrKey1};
+    double r_bound = 0;
+    DoubleCRT rr = fromCoeffs(idx, sampler.sampleSmallBounded(r_bound));
+    double noise = r_bound * pubEncrKeyNoise;
+    for (int i = 0; i < 2; i++) {
+      parts[i] *= rr;
+      double e_bound = 0;
+      DoubleCRT ee = fromCoeffs(idx, sampler.sampleGaussianBounded(cc->stdev, e_bound));
+      ee.mulConstant(scalarRows(idx, *cc, p));
+      e_bound *= (double)p;
+      if (i == 1)
+        e_bound *= skBound;
+      parts[i] += ee;
+      noise += e_bound;
+    }
+    parts[0] += fromCoeffs(idx, ptxtFixed(ptxt, idx, p));
+    noise += cc->noiseBoundForMod(p, cc->phim);
+    Ctxt ct = Ctxt::fresh(*cc, *dev, keys, std::move(parts[0]), std::move(parts[1]));
+    ct.ptxtSpace = p;
+    ct.lnNoise = std::log(noise);
+    return ct;
+  }
+
+  // SecKey::Decrypt (src/keys.cpp:1327-1420): sum_parts part * s^r(X^t), toPoly, PolyRed(p), then the
+  // (intFactor * Q)^-1 factor for p > 2
+  std::vector<long> Decrypt(const Ctxt& ct) const
+  {
+    std::unique_ptr<DoubleCRT> acc;
+    for (auto& kv : ct.parts) {
+      const SKHandle& h = kv.first;
+      IndexSet idx = kv.second.getIndexSet();
+      std::unique_ptr<DoubleCRT> term;
+      if (h.isOne()) {
+        term = std::make_unique<DoubleCRT>(kv.second);
+      } else {
+        term = std::make_unique<DoubleCRT>(fromCoeffs(idx, sKey));
+        if (h.powerOfX > 1)
+          term->automorph(h.powerOfX);
+        if (h.powerOfS > 1)
+          term->Exp(h.powerOfS);
+        *term *= kv.second;
+      }
+      if (!acc)
+        acc = std::move(term);
+      else
+        *acc += *term;
+    }
+    const long p = ct.ptxtSpace;
+    std::vector<unsigned long> raw((size_t)cc->phim);
+    acc->toPolyMod((unsigned long)p, raw.data());
+    std::vector<long> out(raw.begin(), raw.end());
+    if (p > 2) {
+      uint64_t factor = (uint64_t)(ct.intFactor % p);
+      for (int i : ct.primeSet)
+        factor = mulmod(factor, (uint64_t)cc->primes[(size_t)i] % (uint64_t)p, (uint64_t)p);
+      if (factor != 1) {
+        // inverse modulo p by the extended Euclidean algorithm
+        long a = (long)factor, b = p, x0 = 1, x1 = 0;
+        while (b) {
+          long q = a / b, t = a % b;
+          a = b;
+          b = t;
+          t = x0 - q * x1;
+          x0 = x1;
+          x1 = t;
+        }
+        if (a != 1)
+          throw LogicError("intFactor * Q is not invertible modulo the plaintext space");
+        uint64_t inv = (uint64_t)((x0 % p + p) % p);
+        for (auto& v : out)
+          v = (long)mulmod((uint64_t)v, inv, (uint64_t)p);
+      }
+    }
+    return out;
+  }
+};
+
+}  // namespace helib_amd

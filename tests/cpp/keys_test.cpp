@@ -1,0 +1,117 @@
+// GPU check of include/helib_amd_keys.hpp: key generation, PubKey::Encrypt, Ctxt::multiplyBy,
+// smartAutomorph (one step and two steps along the key-switch map) and SecKey::Decrypt, all
+// driven from C++ over the C ABI, against plain polynomial arithmetic modulo (X^N + 1, p).
+//   keys_test <m> <p> <bits> <measure>
+#include <cstdio>
+#include <cstdlib>
+
+#include "helib_amd_keys.hpp"
+
+using namespace helib_amd;
+
+static std::vector<long> negacyclic(const std::vector<long>& a, const std::vector<long>& b, long p)
+{
+  size_t n = a.size();
+  std::vector<long> out(n, 0);
+  for (size_t i = 0; i < n; i++) {
+    if (a[i] == 0)
+      continue;
+    for (size_t j = 0; j < n; j++) {
+      long t = (long)((unsigned __int128)a[i] * (unsigned long)b[j] % (unsigned long)p);
+      size_t k = i + j;
+      if (k < n)
+        out[k] = (out[k] + t) % p;
+      else
+        out[k - n] = (out[k - n] + p - t) % p;
+    }
+  }
+  return out;
+}
+// f(X) -> f(X^k) modulo X^N + 1
+static std::vector<long> automorph(const std::vector<long>& a, long k, long p)
+{
+  size_t n = a.size();
+  std::vector<long> out(n, 0);
+  for (size_t i = 0; i < n; i++) {
+    size_t e = (size_t)((unsigned __int128)i * (unsigned long)k % (2 * n));
+    if (e < n)
+      out[e] = (out[e] + a[i]) % p;
+    else
+      out[e - n] = (out[e - n] + p - a[i]) % p;
+  }
+  return out;
+}
+#define REQUIRE(c)                                             \
+  do {                                                         \
+    if (!(c)) {                                                \
+      fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); \
+      return 1;                                                \
+    }                                                          \
+  } while (0)
+
+int main(int argc, char** argv)
+{
+  if (argc < 5)
+    return 2;
+  long m = atol(argv[1]), p = atol(argv[2]), bits = atol(argv[3]);
+  bool measure = atol(argv[4]) != 0;
+  try {
+    ChainContext cc(m, p, 1, bits, 3);
+    auto dev = cc.makeDeviceContext(0);
+    SecKey sk(cc, *dev, 12345);
+    sk.GenSecKey(2);
+    sk.GenKeySWmatrix(1, 3);
+    sk.setKeySwitchMap();
+    REQUIRE(sk.keySwitching.size() == 2 && sk.keys.relin && sk.keys.automorph.count(3));
+    REQUIRE(sk.keys.isReachable(9) && sk.keys.firstStep(9) == 3 && !sk.keys.isReachable(m - 1));
+    long nz = 0;
+    for (long v : sk.sKey) {
+      REQUIRE(v >= -1 && v <= 1);
+      nz += v != 0;
+    }
+    REQUIRE(nz > cc.phim / 4 && nz < 3 * cc.phim / 4);
+    REQUIRE(sk.sampler.embeddingLargestCoeff(sk.sKey) <= sk.skBound);
+
+    std::mt19937_64 rng(7);
+    std::vector<long> ma((size_t)cc.phim), mb((size_t)cc.phim);
+    for (auto& v : ma)
+      v = (long)(rng() % (uint64_t)p);
+    for (auto& v : mb)
+      v = (long)(rng() % (uint64_t)p);
+    Ctxt ca = sk.Encrypt(ma), cb = sk.Encrypt(mb);
+    ca.measure = cb.measure = measure;
+    REQUIRE(sk.Decrypt(ca) == ma && sk.Decrypt(cb) == mb);
+    REQUIRE(ca.parts.size() == 2 && ca.primeSet.size() == cc.ctxtPrimes.size());
+
+    ca.multiplyBy(cb);
+    std::vector<long> prod = negacyclic(ma, mb, p);
+    REQUIRE(ca.parts.size() == 2);
+    REQUIRE(sk.Decrypt(ca) == prod);
+    {  // before relinearisation the s^2 part decrypts with s^2
+      Ctxt c1 = sk.Encrypt(ma), c2 = sk.Encrypt(mb);
+      c1.measure = c2.measure = measure;
+      c1.multLowLvl(c2);
+      REQUIRE(c1.parts.size() == 3);
+      REQUIRE(sk.Decrypt(c1) == prod);
+    }
+    Ctxt sum = ca;
+    sum.addCtxt(ca);
+    std::vector<long> twice(prod);
+    for (auto& v : twice)
+      v = 2 * v % p;
+    REQUIRE(sk.Decrypt(sum) == twice);
+
+    ca.smartAutomorph(3);
+    std::vector<long> rot = automorph(prod, 3, p);
+    REQUIRE(sk.Decrypt(ca) == rot);
+    ca.smartAutomorph(9);   // two steps of 3 along the map
+    REQUIRE(sk.Decrypt(ca) == automorph(rot, 9, p));
+    REQUIRE(std::isfinite(ca.lnNoise) && ca.lnNoise > 0);
+    dev->sync();
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "exception: %s\n", ex.what());
+    return 1;
+  }
+  printf("keys_test OK\n");
+  return 0;
+}

@@ -1325,3 +1325,21 @@ def test_wrapped_poly_multi_prime_scale_down_stays_in_caller_memory(hx):
     back = buf.cpu().numpy().view(np.uint64).reshape(7, 3, P.N)
     assert np.array_equal(back[:4], want)                 # the result lives in the caller's tensor
     w.close()
+
+
+@pytest.mark.parametrize("m,p,bits,measure", [(128, 257, 150, 0), (16384, 65537, 250, 1), (16384, 2, 250, 0)])
+def test_cpp_host_keys_encrypt_multiply_rotate_decrypt(hx, m, p, bits, measure, tmp_path):
+    """include/helib_amd_keys.hpp -- SecKey::GenSecKey / GenKeySWmatrix / PubKey::Encrypt /
+    SecKey::Decrypt in C++ over the C ABI (src/keys.cpp:39-85, 358-488, 1099-1255, 1327-1420) --
+    with the C++ Ctxt: decrypt(encrypt(m)) = m, decrypt(a*b) = a*b mod (X^N+1, p) also before
+    relinearisation, a*b + a*b, and rotations in one and two key-switch-map steps
+    (tests/cpp/keys_test.cpp checks against schoolbook arithmetic)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "keys_test")
+    libdir = os.path.join(root, "helib_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "keys_test.cpp"), "-L" + libdir, "-lhelib_amd",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    r = subprocess.run([exe, str(m), str(p), str(bits), str(measure)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "keys_test OK" in r.stdout, r.stdout + r.stderr

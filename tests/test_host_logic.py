@@ -107,6 +107,16 @@ def test_cpp_facade_header_compiles_and_links():
                            os.path.join(ROOT, "tests", "cpp", "ctxt_test.cpp"), "-L" + libdir, "-lhelib_amd",
                            "-Wl,-rpath," + libdir, "-o", out2])
     os.remove(out2)
+    out3 = os.path.join(ROOT, "tests", "cpp", "keys_test.bin")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "keys_test.cpp"), "-L" + libdir, "-lhelib_amd",
+                           "-Wl,-rpath," + libdir, "-o", out3])
+    # the product path fails loudly without a device: no CPU fallback behind the C++ keys either
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([out3, "128", "257", "150", "0"], capture_output=True, text=True)
+        assert r.returncode != 0 and "no HIP device" in r.stderr
+    os.remove(out3)
 
 
 @pytest.mark.parametrize("m,p,bits", [(32768, 65537, 950), (16384, 65537, 250), (128, 257, 150), (1705, 7, 200),
