@@ -226,7 +226,7 @@ private:
 class ChainContext {
 public:
   long m, p, r, ptxtSpace, phim, hwt;
-  bool pow2;
+  bool pow2, ckks;   // ckks: ContextBuilder<CKKS> -- p = -1, plaintext space 1, r = precision in bits
   double stdev, scale;
   std::vector<uint64_t> primes;  // Context::moduli order: small, ctxt, special
   IndexSet smallPrimes, ctxtPrimes, specialPrimes;
@@ -234,11 +234,12 @@ public:
   ModuliSizes modSizes;
 
   ChainContext(long m_, long p_, long r_ = 1, long bits = 300, long c = 3, double stdev_ = 3.2,
-               double scale_ = 10.0, long skHwt = 0, long resolution = 3, long bitsInSpecialPrimes = 0)
-      : m(m_), p(p_), r(r_), hwt(skHwt), stdev(stdev_), scale(scale_)
+               double scale_ = 10.0, long skHwt = 0, long resolution = 3, long bitsInSpecialPrimes = 0,
+               bool ckks_ = false)
+      : m(m_), p(ckks_ ? -1 : p_), r(r_), hwt(skHwt), ckks(ckks_), stdev(stdev_), scale(scale_)
   {
     ptxtSpace = 1;
-    for (long i = 0; i < r; i++)
+    for (long i = 0; i < r && !ckks; i++)
       ptxtSpace *= p;
     phim = eulerPhi(m);
     pow2 = (m & (m - 1)) == 0;
@@ -403,7 +404,9 @@ private:
       double h = hwt == 0 ? phim / 2.0 : (double)hwt;
       double log_phim = std::max(std::log((double)phim), 1.0);
       double p2e = (double)ptxtSpace;
-      if (pow2)
+      if (ckks)  // a smaller noise estimate, to protect precision (src/Context.cpp:957-965)
+        nBits = (maxDigitLog + std::log(stdev) + std::log((double)nDgts) - 0.5 * std::log(h)) / LN2;
+      else if (pow2)
         nBits = (maxDigitLog + std::log(p2e) + std::log(stdev) + 0.5 * std::log(12.0) + std::log((double)nDgts) -
                  0.5 * std::log(log_phim) - 2 * std::log((double)p) - std::log(h)) / LN2;
       else
@@ -520,6 +523,7 @@ public:
   PrimeSet primeSet;
   long ptxtSpace, intFactor = 1;
   double lnNoise = -INFINITY;
+  double ptxtMag = 1.0, lnRatFactor = 0.0;  // CKKS: |plaintext| bound, ln of the scaling factor
 
   Ctxt(const ChainContext& c, const Context& d, const KeySet& k) : context(&c), dev(&d), keys(&k), ptxtSpace(c.ptxtSpace) {}
   // a fresh 2-part ciphertext over the ctxt primes (noise bound of PubKey::Encrypt)
@@ -552,6 +556,7 @@ public:
     for (auto& kv : parts)
       kv.second.addPrimesAndScale(d);
     lnNoise += context->logOfProduct(diff);
+    lnRatFactor += context->logOfProduct(diff);  // "If CKKS, the rational factor grows" (:366)
     primeSet = primeSet | diff;
   }
   void modDownToSet(const PrimeSet& s)
@@ -565,6 +570,7 @@ public:
     std::vector<Ctxt*> one{this};
     std::vector<double> added = modDownParts(one, inter, PrimeSet());
     lnNoise = detail::logaddexp(lnNoise - context->logOfProduct(diff), detail::ln(added[0]));
+    lnRatFactor -= context->logOfProduct(diff);  // ratFactor /= f (:533, :553)
     primeSet = inter;
   }
   void bringToSet(const PrimeSet& s0)
@@ -597,20 +603,178 @@ public:
   }
 
   // ---- arithmetic ----
-  // Ctxt::addCtxt for operands on equal prime sets and factors (the general case first calls
-  // equalizeRationalFactors / bringToSet, src/Ctxt.cpp:1406-1538)
-  void addCtxt(const Ctxt& other)
+  // Ctxt::relin_CKKS_adjust (src/Ctxt.cpp:664-717): if the noise is below what the special primes
+  // were sized for, scale the ciphertext (and its factor) up by an integer
+  void relin_CKKS_adjust()
   {
-    if (primeSet != other.primeSet || intFactor != other.intFactor || ptxtSpace != other.ptxtSpace)
-      throw LogicError("addCtxt: operands must share prime set, intFactor and ptxtSpace here");
-    for (auto& kv : other.parts) {
-      auto it = parts.find(kv.first);
-      if (it == parts.end())
-        parts.emplace(kv.first, kv.second);
-      else
-        it->second += kv.second;
+    if (!context->ckks)
+      return;
+    double h = context->hwt == 0 ? context->phim / 2.0 : (double)context->hwt;
+    double log_phim = std::max(std::log((double)context->phim), 1.0);
+    double lnGamma = std::log(8.0 * (double)(long)context->scale * std::sqrt(context->phim * log_phim * h / 12.0));
+    if (lnGamma > lnNoise) {
+      long xf = (long)std::ceil(std::exp(lnGamma - lnNoise));
+      for (auto& kv : parts)
+        kv.second *= xf;
+      lnNoise += std::log((double)xf);
+      lnRatFactor += std::log((double)xf);
     }
-    lnNoise = detail::logaddexp(lnNoise, other.lnNoise);
+  }
+  // Ctxt::mulIntFactor (src/Ctxt.cpp:331-340)
+  void mulIntFactor(long e)
+  {
+    if (e == 1)
+      return;
+    intFactor = (long)detail::mulmod((uint64_t)intFactor, (uint64_t)e, (uint64_t)ptxtSpace);
+    long bal = e > ptxtSpace / 2 ? e - ptxtSpace : e;
+    for (auto& kv : parts)
+      kv.second *= bal;
+    lnNoise += std::log((double)std::labs(bal));
+  }
+  void negate()
+  {
+    for (auto& kv : parts)
+      kv.second.Negate();
+  }
+  // Ctxt::equalizeRationalFactors (src/Ctxt.cpp:1212-1356): bring two CKKS ciphertexts to one factor
+  // by small integer multipliers (continued-fraction convergents of the ratio), stopping once the
+  // discretisation error is within sqrt(2) of the error the sum has anyway.  Relative to the smaller
+  // factor, so doubles do (the reference's xdouble carries the same 53 bits).
+  static void equalizeRationalFactors(Ctxt& c1, Ctxt& c2)
+  {
+    Ctxt& big = c1.lnRatFactor > c2.lnRatFactor ? c1 : c2;
+    Ctxt& small = c1.lnRatFactor > c2.lnRatFactor ? c2 : c1;
+    const double base = small.lnRatFactor, x = std::exp(big.lnRatFactor - base);
+    const double denomBound = std::ldexp(1.0, (int)c1.context->r + 1), epsilon = 0.125 / denomBound;
+    double a = std::floor(x + epsilon), xi = x - a;
+    double prevDenom = 0, denom = 1, numer = std::floor(denom * x + 0.5);
+    const double m1 = big.ptxtMag, of1 = x, oe1 = std::exp(big.lnNoise - base);
+    const double m2 = small.ptxtMag, of2 = 1.0, oe2 = std::exp(small.lnNoise - base);
+    const double target = oe1 / of1 + oe2 / of2;
+    double f, fe1, fe2;
+    for (;;) {
+      double f1 = of1 * denom, e1 = oe1 * denom, f2 = of2 * numer, e2 = oe2 * numer;
+      auto calc = [&](double ff) { return m1 * std::fabs(f1 / ff - 1.0) + m2 * std::fabs(f2 / ff - 1.0) + (e1 + e2) / ff; };
+      double err1 = calc(f1), err2 = calc(f2), err;
+      if (err1 < err2) {
+        f = f1, fe1 = e1, fe2 = e2 + m2 * std::fabs(f2 - f1), err = err1;
+      } else {
+        f = f2, fe1 = e1 + m1 * std::fabs(f2 - f1), fe2 = e2, err = err2;
+      }
+      if (err < std::sqrt(2.0) * target || xi <= 0)
+        break;
+      xi = 1.0 / xi;
+      double ai = std::floor(xi + epsilon);
+      xi -= ai;
+      double tmpDenom = denom * ai + prevDenom;
+      if (tmpDenom > denomBound)
+        break;
+      prevDenom = denom;
+      denom = tmpDenom;
+      numer = std::floor(denom * x + 0.5);
+    }
+    if (denom != 1)
+      for (auto& kv : big.parts)
+        kv.second *= (long)denom;
+    if (numer != 1)
+      for (auto& kv : small.parts)
+        kv.second *= (long)numer;
+    big.lnRatFactor = small.lnRatFactor = std::log(f) + base;
+    big.lnNoise = detail::ln(fe1) + base;
+    small.lnNoise = detail::ln(fe2) + base;
+  }
+  // Ctxt::addCtxt (src/Ctxt.cpp:1405-1556): plaintext spaces reduced to their gcd (BGV), both
+  // operands mod-switched UP to the union of their prime sets, CKKS factors equalised, BGV
+  // intFactors harmonised by the (e1, e2) of least noise along the extended Euclidean sequence,
+  // then the parts added handle by handle.
+  void addCtxt(const Ctxt& other, bool negative = false)
+  {
+    if (other.parts.empty())
+      return;
+    if (parts.empty()) {
+      *this = other;
+      if (negative)
+        negate();
+      return;
+    }
+    const Ctxt* o = &other;
+    std::unique_ptr<Ctxt> tmp;
+    auto own = [&]() -> Ctxt& {
+      if (!tmp) {
+        tmp = std::make_unique<Ctxt>(other);
+        o = tmp.get();
+      }
+      return *tmp;
+    };
+    if (context->ckks) {
+      if (ptxtSpace != 1 || other.ptxtSpace != 1)
+        throw RuntimeError("Plaintext spaces incompatible");
+    } else {
+      long g = std::gcd(ptxtSpace, other.ptxtSpace);
+      if (g <= 1)
+        throw RuntimeError("New and old plaintext spaces are coprime");
+      ptxtSpace = g;
+      intFactor %= g;
+      if (other.ptxtSpace != g) {
+        own().ptxtSpace = g;
+        tmp->intFactor %= g;
+      }
+    }
+    if (!(o->primeSet - primeSet).empty())
+      modUpToSet(primeSet | o->primeSet);
+    if (!(primeSet - o->primeSet).empty())
+      own().modUpToSet(primeSet);
+    if (context->ckks)
+      equalizeRationalFactors(*this, own());
+    long e1 = 1, e2 = 1;
+    if (!context->ckks && intFactor != o->intFactor) {
+      const long P = ptxtSpace;
+      auto inv = [&](long v) {  // v^-1 mod P
+        long aa = v, bb = P, x0 = 1, x1 = 0;
+        while (bb) {
+          long q = aa / bb, t = aa % bb;
+          aa = bb, bb = t;
+          t = x0 - q * x1, x0 = x1, x1 = t;
+        }
+        return ((x0 % P) + P) % P;
+      };
+      long ratio = (long)detail::mulmod((uint64_t)o->intFactor, (uint64_t)inv(intFactor), (uint64_t)P);
+      auto bal = [&](long e) { return (double)std::labs(e > P / 2 ? e - P : e); };
+      auto norm = [&](long ea, long eb) {
+        return detail::logaddexp(lnNoise + detail::ln(bal(ea)), o->lnNoise + detail::ln(bal(eb)));
+      };
+      long r0 = P, t0 = 0, r1 = ratio, t1 = 1;
+      e1 = r1, e2 = t1;
+      double best = norm(e1, e2);
+      while (r1 != 0) {
+        long q = r0 / r1, r2 = r0 % r1, t2 = t0 - t1 * q;
+        r0 = r1, r1 = r2, t0 = t1, t1 = t2;
+        long ea = ((r1 % P) + P) % P, eb = ((t1 % P) + P) % P;
+        if (ea % context->p != 0) {
+          double cand = norm(ea, eb);
+          if (cand < best)
+            e1 = ea, e2 = eb, best = cand;
+        }
+      }
+    }
+    if (e2 != 1)
+      own().mulIntFactor(e2);
+    if (e1 != 1)
+      mulIntFactor(e1);
+    for (auto& kv : o->parts) {
+      auto it = parts.find(kv.first);
+      if (it == parts.end()) {
+        auto ins = parts.emplace(kv.first, kv.second).first;
+        if (negative)
+          ins->second.Negate();
+      } else if (negative) {
+        it->second -= kv.second;
+      } else {
+        it->second += kv.second;
+      }
+    }
+    ptxtMag += o->ptxtMag;
+    lnNoise = detail::logaddexp(lnNoise, o->lnNoise);
   }
   // Ctxt::computeIntervalForMul (src/Ctxt.cpp:1610-1656): [lo, hi] = ln of the target modulus size
   static std::pair<double, double> computeIntervalForMul(const Ctxt& c1, const Ctxt& c2);
@@ -621,14 +785,19 @@ public:
       parts.clear();
       return;
     }
-    long g = std::gcd(ptxtSpace, other.ptxtSpace);
-    if (g <= 1)
-      throw RuntimeError("Plaintext spaces are co-prime");
-    ptxtSpace = other.ptxtSpace = g;
-    intFactor %= g;
-    other.intFactor %= g;
+    if (context->ckks) {
+      if (ptxtSpace != 1 || other.ptxtSpace != 1)
+        throw RuntimeError("Plaintext spaces incompatible");
+    } else {
+      long g = std::gcd(ptxtSpace, other.ptxtSpace);
+      if (g <= 1)
+        throw RuntimeError("Plaintext spaces are co-prime");
+      ptxtSpace = other.ptxtSpace = g;
+      intFactor %= g;
+      other.intFactor %= g;
+    }
     auto iv = computeIntervalForMul(*this, other);
-    PrimeSet s = context->modSizes.getSet4Size(iv.first, iv.second, primeSet, &other.primeSet, false);
+    PrimeSet s = context->modSizes.getSet4Size(iv.first, iv.second, primeSet, &other.primeSet, context->ckks);
     if (primeSet == other.primeSet) {
       std::vector<Ctxt*> both{this, &other};
       bringManyToSet(both, s.empty() ? PrimeSet{context->ctxtPrimes[0]} : s);
@@ -671,8 +840,10 @@ public:
     if (!W)
       throw LogicError("no key-switching matrices for this part");
     dropSmallAndSpecialPrimes();
+    relin_CKKS_adjust();
     const IndexSet& sp = context->specialPrimes;
     double logProd = context->logOfProduct(sp);
+    lnRatFactor += logProd;  // the CKKS factor after the mod-up by the special primes (:757)
     std::vector<IndexSet> digits;
     for (auto& d : context->digits) {
       IndexSet r;
@@ -682,8 +853,10 @@ public:
       if (!r.empty())
         digits.push_back(r);
     }
-    ptxtSpace = std::gcd(ptxtSpace, keys->ptxtSpace ? keys->ptxtSpace : context->ptxtSpace);
-    intFactor %= ptxtSpace;
+    if (ptxtSpace > 1) {  // g == 1 for CKKS
+      ptxtSpace = std::gcd(ptxtSpace, keys->ptxtSpace ? keys->ptxtSpace : context->ptxtSpace);
+      intFactor %= ptxtSpace;
+    }
     DoubleCRT& t0 = parts.at(SKHandle{0, 1});
     auto its = parts.find(SKHandle{1, 1});
     DoubleCRT& t2 = parts.at(hnd);
@@ -796,7 +969,15 @@ private:
     parts.emplace(SKHandle{0, 1}, std::move(t0));
     parts.emplace(SKHandle{1, 1}, std::move(t1));
     parts.emplace(SKHandle{2, 1}, std::move(t2));
-    lnNoise += o.lnNoise;
+    if (context->ckks) {  // totalNoiseBound = factor*ptxt + noiseBound on both sides (:1600-1606)
+      double n1 = lnNoise, n2 = o.lnNoise;
+      lnNoise = detail::logaddexp(detail::logaddexp(n1 + detail::ln(o.ptxtMag) + o.lnRatFactor,
+                                                    n2 + detail::ln(ptxtMag) + lnRatFactor), n1 + n2);
+      lnRatFactor += o.lnRatFactor;
+      ptxtMag *= o.ptxtMag;
+    } else {
+      lnNoise += o.lnNoise;
+    }
   }
   // polynomial work of modDownToSet (after a mod-up by `add`) on all parts of ciphertexts that share
   // one prime set: one fused call; returns the added noise per ciphertext
@@ -867,6 +1048,7 @@ private:
     for (size_t i = 0; i < cts.size(); i++) {
       Ctxt* c = cts[i];
       c->lnNoise += c->context->logOfProduct(add);
+      c->lnRatFactor += c->context->logOfProduct(add) - c->context->logOfProduct(diff);
       c->primeSet = up;
       if (!diff.empty()) {
         c->lnNoise = detail::logaddexp(c->lnNoise - c->context->logOfProduct(diff), detail::ln(added[i]));
@@ -882,6 +1064,10 @@ inline std::pair<double, double> Ctxt::computeIntervalForMul(const Ctxt& c1, con
   double cap1 = c1.logOfPrimeSet() - std::max(c1.lnNoise, 0.0);
   double cap2 = c2.logOfPrimeSet() - std::max(c2.lnNoise, 0.0);
   double adn1 = std::log(c1.modSwitchAddedNoiseBound()), adn2 = std::log(c2.modSwitchAddedNoiseBound());
+  if (c1.context->ckks) {  // the opposite end: keep n*q'/q above the added noise (:1637-1651)
+    double lo = std::max(cap1 + adn1, cap2 + adn2) + safety;
+    return {lo, lo + 4 * LN2};
+  }
   double hi = std::min(cap1 + adn1, cap2 + adn2) - safety;
   return {hi - 4 * LN2, hi};
 }

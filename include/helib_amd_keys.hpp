@@ -321,9 +321,58 @@ public:
     return ct;
   }
 
-  // SecKey::Decrypt (src/keys.cpp:1327-1420): sum_parts part * s^r(X^t), toPoly, PolyRed(p), then the
-  // (intFactor * Q)^-1 factor for p > 2
-  std::vector<long> Decrypt(const Ctxt& ct) const
+  // PubKey::CKKSencrypt (src/keys.cpp:501-581): ptxt is an integer polynomial already scaled by
+  // `scaling`; ctxt = r*pk + (e0, e1) + (ef*ptxt, 0) with ef = ceil(error_bound * 2^precision /
+  // (scaling * ptxtSize)); ratFactor = scaling * ef, ptxtMag = ptxtSize rounded up to a power of two
+  Ctxt CKKSencrypt(const std::vector<long>& ptxt, double ptxtSize = 1.0, double scaling = 0.0)
+  {
+    if (!cc->ckks)
+      throw LogicError("CKKSencrypt on a BGV context");
+    if (!pubEncrKey0)
+      throw LogicError("no public encryption key");
+    if (ptxtSize <= 0)
+      ptxtSize = 1.0;
+    const double prec = std::ldexp(1.0, (int)cc->r);
+    if (scaling <= 0)
+      scaling = prec / ptxtSize;
+    const IndexSet& idx = cc->ctxtPrimes;
+    DoubleCRT parts[2] = {*pubEncrKey0, *pubEncrKey1};
+    double r_bound = 0;
+    DoubleCRT rr = fromCoeffs(idx, sampler.sampleSmallBounded(r_bound));
+    double error_bound = r_bound * pubEncrKeyNoise;
+    for (int i = 0; i < 2; i++) {
+      parts[i] *= rr;
+      double e_bound = 0;
+      parts[i] += fromCoeffs(idx, sampler.sampleGaussianBounded(cc->stdev, e_bound));
+      if (i == 1)
+        e_bound *= skBound;
+      error_bound += e_bound;
+    }
+    long ef = (long)std::ceil(error_bound * prec / (scaling * ptxtSize));
+    DoubleCRT pt = fromCoeffs(idx, ptxt);
+    if (ef > 1) {
+      pt *= ef;
+      scaling *= (double)ef;
+    }
+    parts[0] += pt;
+    Ctxt ct = Ctxt::fresh(*cc, *dev, keys, std::move(parts[0]), std::move(parts[1]));
+    ct.ptxtSpace = 1;
+    ct.lnNoise = std::log(error_bound);
+    ct.lnRatFactor = std::log(scaling);
+    ct.ptxtMag = 1.0;
+    if (ptxtSize > 1) {  // EncryptedArrayCx::roundedSize
+      long v = (long)std::ceil(ptxtSize) - 1, bits = 0;
+      while (v) {
+        bits++;
+        v >>= 1;
+      }
+      ct.ptxtMag = std::ldexp(1.0, (int)bits);
+    }
+    return ct;
+  }
+
+  // sum_parts part * s^r(X^t): what both decryptions start from (src/keys.cpp:1360-1381)
+  std::unique_ptr<DoubleCRT> innerProduct(const Ctxt& ct) const
   {
     std::unique_ptr<DoubleCRT> acc;
     for (auto& kv : ct.parts) {
@@ -345,6 +394,66 @@ public:
       else
         *acc += *term;
     }
+    return acc;
+  }
+
+  // CKKS: SecKey::Decrypt stops at the centred integer polynomial ("if (isCKKS()) return;",
+  // src/keys.cpp:1383-1386) and the caller divides by ratFactor.  Both are hundreds of bits wide, so
+  // this host side returns the quotient: every coefficient's centred CRT value / ratFactor, from the
+  // mixed-radix (Garner) digits of the rows -- no big integers; double precision relative to the value.
+  std::vector<double> DecryptCKKS(const Ctxt& ct) const
+  {
+    std::unique_ptr<DoubleCRT> acc = innerProduct(ct);
+    acc->iFFT();
+    IndexSet idx = acc->getIndexSet();
+    std::vector<uint64_t> rows = acc->getRows();
+    const size_t L = idx.size(), n = (size_t)cc->phim;
+    std::vector<uint64_t> q(L);
+    std::vector<long double> lnP(L);   // ln prod_{j<k} q_j - ln ratFactor
+    long double run = -(long double)ct.lnRatFactor;
+    for (size_t k = 0; k < L; k++) {
+      q[k] = (uint64_t)cc->primes[(size_t)idx[k]];
+      lnP[k] = run;
+      run += std::log((long double)q[k]);
+    }
+    // Garner constants: inv[k][l] = q_l^-1 mod q_k for l < k
+    std::vector<uint64_t> inv(L * L, 0);
+    for (size_t k = 0; k < L; k++)
+      for (size_t l = 0; l < k; l++)
+        inv[k * L + l] = detail::powmod(q[l] % q[k], q[k] - 2, q[k]);
+    std::vector<double> out(n);
+    std::vector<uint64_t> a(L);
+    for (size_t j = 0; j < n; j++) {
+      for (size_t k = 0; k < L; k++) {
+        uint64_t x = rows[k * n + j];
+        for (size_t l = 0; l < k; l++) {
+          uint64_t al = a[l] % q[k];
+          x = mulmod(x >= al ? x - al : x + q[k] - al, inv[k * L + l], q[k]);
+        }
+        a[k] = x;
+      }
+      long double frac = 0;   // value / Q
+      for (size_t k = 0; k < L; k++)
+        frac = (frac + (long double)a[k]) / (long double)q[k];
+      const bool neg = frac > 0.5L;
+      long double v = neg ? std::exp(lnP[0]) : 0.0L;   // Q - value = (Q - 1 - value) + 1
+      for (size_t k = 0; k < L; k++) {
+        uint64_t d = neg ? q[k] - 1 - a[k] : a[k];
+        if (d)
+          v += (long double)d * std::exp(lnP[k]);
+      }
+      out[j] = (double)(neg ? -v : v);
+    }
+    return out;
+  }
+
+  // SecKey::Decrypt (src/keys.cpp:1327-1420): sum_parts part * s^r(X^t), toPoly, PolyRed(p), then the
+  // (intFactor * Q)^-1 factor for p > 2
+  std::vector<long> Decrypt(const Ctxt& ct) const
+  {
+    if (cc->ckks)
+      throw LogicError("CKKS ciphertexts decrypt with DecryptCKKS");
+    std::unique_ptr<DoubleCRT> acc = innerProduct(ct);
     const long p = ct.ptxtSpace;
     std::vector<unsigned long> raw((size_t)cc->phim);
     acc->toPolyMod((unsigned long)p, raw.data());

@@ -22,7 +22,8 @@ int main(int argc, char** argv)
   if (argc < 4)
     return 2;
   long m = atol(argv[1]), p = atol(argv[2]), bits = atol(argv[3]);
-  ChainContext c(m, p, 1, bits, 3);
+  const bool ckks = p == -1;   // ContextBuilder<CKKS>().precision(20)
+  ChainContext c(m, p, ckks ? 20 : 1, bits, 3, 3.2, 10.0, 0, 3, 0, ckks);
   printf("{\"primes\": [");
   for (size_t i = 0; i < c.primes.size(); i++)
     printf("%s%llu", i ? ", " : "", (unsigned long long)c.primes[i]);
@@ -44,7 +45,11 @@ int main(int argc, char** argv)
   double msn = (1.0 + c.skBound()) * c.noiseBoundForUniform(c.ptxtSpace / 2.0, c.phim);
   double hi = c.logOfProduct(fresh) - std::max(lnNoise, 0.0) + std::log(msn) - Ctxt::safety;
   std::pair<double, double> iv{hi - 4 * std::log(2.0), hi};
-  PrimeSet s = c.modSizes.getSet4Size(iv.first, iv.second, fresh, &fresh, false);
+  if (ckks) {   // the opposite end of the window (src/Ctxt.cpp:1637-1651)
+    double lo = c.logOfProduct(fresh) - std::max(lnNoise, 0.0) + std::log(msn) + Ctxt::safety;
+    iv = {lo, lo + 4 * std::log(2.0)};
+  }
+  PrimeSet s = c.modSizes.getSet4Size(iv.first, iv.second, fresh, &fresh, ckks);
   printf("\"lo\": %.17g, \"hi\": %.17g, ", iv.first, iv.second);
   list("common", toVec(s), true);
   printf("}\n");

@@ -41,6 +41,28 @@ static std::vector<long> automorph(const std::vector<long>& a, long k, long p)
   }
   return out;
 }
+static std::vector<double> negacyclic_d(const std::vector<double>& a, const std::vector<double>& b)
+{
+  size_t n = a.size();
+  std::vector<double> out(n, 0.0);
+  for (size_t i = 0; i < n; i++)
+    for (size_t j = 0; j < n; j++) {
+      size_t k = i + j;
+      if (k < n)
+        out[k] += a[i] * b[j];
+      else
+        out[k - n] -= a[i] * b[j];
+    }
+  return out;
+}
+static double maxdiff(const std::vector<double>& a, const std::vector<double>& b)
+{
+  double d = 0;
+  for (size_t i = 0; i < a.size(); i++)
+    d = std::max(d, std::fabs(a[i] - b[i]));
+  return d;
+}
+static int ckks_main(long m, long bits, bool measure);
 #define REQUIRE(c)                                             \
   do {                                                         \
     if (!(c)) {                                                \
@@ -55,6 +77,8 @@ int main(int argc, char** argv)
     return 2;
   long m = atol(argv[1]), p = atol(argv[2]), bits = atol(argv[3]);
   bool measure = atol(argv[4]) != 0;
+  if (p == -1)
+    return ckks_main(m, bits, measure);
   try {
     ChainContext cc(m, p, 1, bits, 3);
     auto dev = cc.makeDeviceContext(0);
@@ -107,6 +131,77 @@ int main(int argc, char** argv)
     ca.smartAutomorph(9);   // two steps of 3 along the map
     REQUIRE(sk.Decrypt(ca) == automorph(rot, 9, p));
     REQUIRE(std::isfinite(ca.lnNoise) && ca.lnNoise > 0);
+    dev->sync();
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "exception: %s\n", ex.what());
+    return 1;
+  }
+  printf("keys_test OK\n");
+  return 0;
+}
+
+// CKKS: ContextBuilder<CKKS>().m(m).precision(20).bits(bits).c(3); CKKSencrypt of scaled real
+// polynomials, products over two levels, a sum across different scaling factors and a difference,
+// decoded by DecryptCKKS and compared with double arithmetic on the encoded values; every error
+// must also stay below the bound the ciphertext reports (noiseBound / ratFactor).
+static int ckks_main(long m, long bits, bool measure)
+{
+  try {
+    const long precision = 20;
+    ChainContext cc(m, -1, precision, bits, 3, 3.2, 10.0, 0, 3, 0, true);
+    REQUIRE(cc.ckks && cc.ptxtSpace == 1 && cc.p == -1);
+    auto dev = cc.makeDeviceContext(0);
+    SecKey sk(cc, *dev, 777);
+    sk.GenSecKey(2);
+    const size_t n = (size_t)cc.phim;
+    const double f = std::ldexp(1.0, (int)precision);
+    std::mt19937_64 rng(3);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    auto draw = [&](std::vector<long>& scaled, std::vector<double>& enc) {
+      scaled.resize(n);
+      enc.resize(n);
+      for (size_t i = 0; i < n; i++) {
+        scaled[i] = std::lround(U(rng) / (double)n * f);
+        enc[i] = (double)scaled[i] / f;        // the value actually encrypted
+      }
+    };
+    std::vector<long> pa, pb, pc;
+    std::vector<double> a, b, c;
+    draw(pa, a), draw(pb, b), draw(pc, c);
+    Ctxt ca = sk.CKKSencrypt(pa, 1.0, f), cb = sk.CKKSencrypt(pb, 1.0, f), c3 = sk.CKKSencrypt(pc, 1.0, f);
+    ca.measure = cb.measure = c3.measure = measure;
+    REQUIRE(ca.ptxtSpace == 1 && ca.ptxtMag == 1.0);
+    REQUIRE(ca.lnRatFactor >= ca.lnNoise + precision * std::log(2.0) - 1e-9);
+    auto within = [&](const Ctxt& ct, const std::vector<double>& want) {
+      double err = maxdiff(sk.DecryptCKKS(ct), want), bound = std::exp(ct.lnNoise - ct.lnRatFactor);
+      if (!(err <= bound))
+        fprintf(stderr, "error %g above the reported bound %g\n", err, bound);
+      return err <= bound;
+    };
+    REQUIRE(within(ca, a));
+    REQUIRE(maxdiff(sk.DecryptCKKS(ca), a) < std::ldexp(1.0, -(int)precision));
+
+    ca.multiplyBy(cb);                              // level 1: no mod-switch for fresh operands
+    std::vector<double> ab = negacyclic_d(a, b);
+    REQUIRE(ca.parts.size() == 2 && within(ca, ab));
+    Ctxt sum = ca, diff = ca;
+    sum.addCtxt(c3);                                // factors f^2-ish and f: equalizeRationalFactors
+    REQUIRE(std::fabs(sum.lnRatFactor - ca.lnRatFactor) < 40.0 && sum.ptxtMag == 2.0);
+    std::vector<double> want(n);
+    for (size_t i = 0; i < n; i++)
+      want[i] = ab[i] + c[i];
+    REQUIRE(within(sum, want));
+    diff.addCtxt(c3, true);
+    for (size_t i = 0; i < n; i++)
+      want[i] = ab[i] - c[i];
+    REQUIRE(within(diff, want));
+    Ctxt sq = ca;
+    sq.multiplyBy(ca);                              // level 2: both operands mod-switched first
+    REQUIRE(within(sq, negacyclic_d(ab, ab)));
+    size_t kept = 0;
+    for (int i : sq.primeSet)
+      kept += std::find(cc.ctxtPrimes.begin(), cc.ctxtPrimes.end(), i) != cc.ctxtPrimes.end();
+    REQUIRE(kept <= cc.ctxtPrimes.size());
     dev->sync();
   } catch (const std::exception& ex) {
     fprintf(stderr, "exception: %s\n", ex.what());

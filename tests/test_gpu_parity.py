@@ -1327,13 +1327,16 @@ def test_wrapped_poly_multi_prime_scale_down_stays_in_caller_memory(hx):
     w.close()
 
 
-@pytest.mark.parametrize("m,p,bits,measure", [(128, 257, 150, 0), (16384, 65537, 250, 1), (16384, 2, 250, 0)])
+@pytest.mark.parametrize("m,p,bits,measure", [(128, 257, 150, 0), (16384, 65537, 250, 1), (16384, 2, 250, 0),
+                                              (128, -1, 250, 0), (8192, -1, 300, 1)])
 def test_cpp_host_keys_encrypt_multiply_rotate_decrypt(hx, m, p, bits, measure, tmp_path):
     """include/helib_amd_keys.hpp -- SecKey::GenSecKey / GenKeySWmatrix / PubKey::Encrypt /
     SecKey::Decrypt in C++ over the C ABI (src/keys.cpp:39-85, 358-488, 1099-1255, 1327-1420) --
     with the C++ Ctxt: decrypt(encrypt(m)) = m, decrypt(a*b) = a*b mod (X^N+1, p) also before
     relinearisation, a*b + a*b, and rotations in one and two key-switch-map steps
-    (tests/cpp/keys_test.cpp checks against schoolbook arithmetic)."""
+    (tests/cpp/keys_test.cpp checks against schoolbook arithmetic).  p = -1: the CKKS chain --
+    CKKSencrypt, products over two levels, sums/differences across scaling factors
+    (equalizeRationalFactors), DecryptCKKS; every decoded error below the ciphertext's own bound."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "keys_test")

@@ -120,7 +120,7 @@ def test_cpp_facade_header_compiles_and_links():
 
 
 @pytest.mark.parametrize("m,p,bits", [(32768, 65537, 950), (16384, 65537, 250), (128, 257, 150), (1705, 7, 200),
-                                      (32768, 2, 300)])
+                                      (32768, 2, 300), (65536, -1, 1400), (128, -1, 250)])
 def test_cpp_host_chain_and_prime_set_decision_match_the_python_mirror(m, p, bits, tmp_path):
     """include/helib_amd_ctxt.hpp (C++ host side: PrimeGenerator, buildModChain, ModuliSizes,
     computeIntervalForMul) against helib_amd/ctxt.py: same primes, digits, table size and the same
@@ -134,7 +134,8 @@ def test_cpp_host_chain_and_prime_set_decision_match_the_python_mirror(m, p, bit
                            os.path.join(ROOT, "tests", "cpp", "chain_test.cpp"), "-L" + libdir, "-lhelib_amd",
                            "-Wl,-rpath," + libdir, "-o", exe])
     got = json.loads(subprocess.check_output([exe, str(m), str(p), str(bits)]))
-    c = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    ckks = p == -1                  # the CKKS chain (precision 20): other special-prime sizing, other window end
+    c = hc.ChainContext(m, p, 20 if ckks else 1, bits=bits, c=3, ckks=ckks)
     assert got["primes"] == c.primes
     assert got["small"] == c.smallPrimes and got["ctxt"] == c.ctxtPrimes and got["special"] == c.specialPrimes
     assert got["digits"] == c.digits and got["nsizes"] == len(c.modSizes.sizes)
@@ -145,7 +146,7 @@ def test_cpp_host_chain_and_prime_set_decision_match_the_python_mirror(m, p, bit
     a.lnNoise = math.log(c.freshNoiseBound())
     lo, hi = hc.Ctxt.computeIntervalForMul(a, a)
     assert abs(got["lo"] - lo) < 1e-9 and abs(got["hi"] - hi) < 1e-9
-    assert got["common"] == sorted(c.modSizes.getSet4Size(lo, hi, a.primeSet, a.primeSet, False))
+    assert got["common"] == sorted(c.modSizes.getSet4Size(lo, hi, a.primeSet, a.primeSet, ckks))
 
 
 @pytest.mark.parametrize("radix,logq", [(4, 13), (8, 13)])
