@@ -275,12 +275,15 @@ def run_fresh(hx, hc, cc, ctx, B, steps, warmup, rng, sync, barrier, measure=Tru
         """K multiplies back to back.  Each result's (lazily read) noise estimate is completed one
         multiply later, so that the host has the next multiply queued while it waits."""
         prev = None
-        for a, b in pairs:
-            a.multLowLvl(b, destructive=True)
-            a.reLinearize()
+        pairs.reverse()
+        while pairs:
+            a, b = pairs.pop()        # a result is dropped once the next one is complete, as the
+            a.multLowLvl(b, destructive=True)   # reference's loop overwrites its ciphertext: the slab
+            a.reLinearize()           # pool recycles result storage instead of growing by K results
             if prev is not None:
                 _ = prev.lnNoise
             prev = a
+            del a, b
         _ = prev.lnNoise
         return prev
 

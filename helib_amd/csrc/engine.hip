@@ -1624,6 +1624,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   size_t o_Wp = take((size_t)2 * n);
   size_t o_tlazy = take((nt + 1) / 2);
   size_t o_srcrq = take(n), o_tmu63 = take(nt);
+  size_t o_tchunk = take((nt + 1) / 2);
   std::vector<uint64_t> h(off, 0);
   hxh::BigU P(1);
   for (int k = 0; k < n; k++) {
@@ -1651,6 +1652,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   }
   uint32_t* tk = reinterpret_cast<uint32_t*>(&h[o_tk]);
   uint32_t* tlazy = reinterpret_cast<uint32_t*>(&h[o_tlazy]);
+  uint32_t* tchunk = reinterpret_cast<uint32_t*>(&h[o_tchunk]);
   hxh::u128 sum_src = 0;
   uint64_t max_src = 0, min_src = ~0ull;
   for (int k = 0; k < n; k++) {
@@ -1663,6 +1665,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     // lazy 128-bit accumulation is exact when sum_k a_k*W_k < (sum_k q_k)*q_t <= 8*q_t^2
     // (red128_wide's domain; q_t <= 60 bits)
     tlazy[t] = (hxh::bitlen(q) <= 60 && sum_src <= (hxh::u128)8 * q && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;
+    // seven terms + the carried remainder: r + 7 max_src q < 8 q^2 needs max_src <= q
+    tchunk[t] = (hxh::bitlen(q) <= 60 && max_src <= q && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;
     h[o_tq + t] = q;
     h[o_tmu64 + t] = (uint64_t)((((hxh::u128)1) << 64) / q);
     int kb = hxh::bitlen(q);
@@ -1729,7 +1733,12 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     for (int t = 0; t < nt && ok; t++)
       ok = (tq(t) >> 32) != 0;
     pl->dev.fast_ok = ok ? 1u : 0u;
+    bool ok16 = pl->dev.garner_cs && n <= 16 && (min_src >> 32) != 0 && !getenv("HX_NO_FAST_EXTEND");
+    for (int t = 0; t < nt && ok16; t++)
+      ok16 = (tq(t) >> 32) != 0;
+    pl->dev.fast16_ok = ok16 ? 1u : 0u;
   }
+  pl->dev.tgt_chunk7 = reinterpret_cast<const uint32_t*>(d + o_tchunk);
   c->plans[key] = pl;
   *out = pl;
   return HX_OK;
@@ -1739,6 +1748,20 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args, size
 {
   dim3 grid((unsigned)((row_words + 255) / 256)), block(256);
   int n = pl->dev.n;
+  if (pl->dev.fast16_ok) {
+#define HX_EXT_FAST(NN)                                                                                 \
+  case NN:                                                                                              \
+    hipLaunchKernelGGL((hx::rns_extend_fast_kernel<NN>), grid, block, 0, c->stream, pl->dev, args, row_words); \
+    break;
+    switch (n) {
+      HX_EXT_FAST(1) HX_EXT_FAST(2) HX_EXT_FAST(3) HX_EXT_FAST(4) HX_EXT_FAST(5) HX_EXT_FAST(6) HX_EXT_FAST(7) HX_EXT_FAST(8)
+      HX_EXT_FAST(9) HX_EXT_FAST(10) HX_EXT_FAST(11) HX_EXT_FAST(12) HX_EXT_FAST(13) HX_EXT_FAST(14) HX_EXT_FAST(15)
+      HX_EXT_FAST(16)
+    }
+#undef HX_EXT_FAST
+    HIPCHK(hipGetLastError());
+    return HX_OK;
+  }
   if (n <= 8)
     hipLaunchKernelGGL((hx::rns_extend_kernel<8>), grid, block, 0, c->stream, pl->dev, args,
                        row_words);

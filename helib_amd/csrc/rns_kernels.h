@@ -355,6 +355,9 @@ struct ExtPlanDev {
   const uint64_t* tgt_mu63;  // [nt] floor(2^(63+k) / q_t), k = bitlen(q_t)  (red128_q8)
   uint32_t fast_ok;          // break_digits_fast_kernel's preconditions hold for this plan:
                              // garner_cs, every prime > 2^32 (32-bit reciprocals), n <= 8
+  uint32_t fast16_ok;        // the same with n <= 16: rns_extend_fast_kernel
+  const uint32_t* tgt_chunk7;  // [nt] 1: every source prime <= q_t, so the limb sum may be taken 7
+                               // terms at a time with the previous remainder carried (r + 7 p q < 8 q^2)
 };
 
 // sum_k a_k * W[k]  mod q for a target whose plan says the lazy 128-bit form is exact
@@ -731,6 +734,143 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
       // digits[j] -= digits[i]; digits[j] /= P_i on a later digit's own row (kept lazy, < 4q)
       uint64_t* u = &xs[r * BRK_THREADS + tid];
       *u = shoup4(*u + q - v, P.upd[t], 0 - q);
+    }
+  }
+}
+
+// =====================================================================
+// rns_extend_kernel in the fast form (same contract, chosen by the host when the plan has
+// fast16_ok): N compile-time, Garner with shoup4 on lazy values, residues by 30-bit-limb
+// accumulation -- the whole sum at once (tgt_lazy), or seven terms at a time with the previous
+// remainder carried (tgt_chunk7) when sum_k p_k is just above 8 q_t, as when as many same-size
+// primes are dropped as a 60-bit accumulator scheme was sized for plus one -- otherwise shoup4
+// products normalised once.  The plaintext-space correction, the fraction and the stores are the
+// generic kernel's, so every output word and every fraction is the same.
+// =====================================================================
+template <int N>
+__global__ void __launch_bounds__(256)
+rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= row_words)
+    return;
+  uint64_t a[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    uint64_t x = A.src[(size_t)A.src_row[k] * row_words + i];
+    if (A.own_dst_row[k] != 0xffff)
+      A.dst[(size_t)A.own_dst_row[k] * row_words + i] = x;
+    const uint64_t pk = P.src_q[k], npk = 0 - pk, pk2 = pk + pk;
+#pragma unroll
+    for (int l = 0; l < k; l++)
+      x = shoup4(x + pk2 - a[l], P.ginv[k * N + l], npk);  // a_l < p_l < 2 p_k (garner_cs)
+    x = csub(x, pk2);
+    a[k] = csub(x, pk);
+  }
+  int cmp = 0;
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) {
+    const uint64_t h = P.half[k];
+    cmp = cmp != 0 ? cmp : (a[k] > h ? 1 : (a[k] < h ? -1 : 0));
+  }
+  const bool neg = cmp > 0;
+
+  // ---- BGV: make delta divisible by ptxtSpace (src/DoubleCRT.cpp:1485-1508) ----
+  bool dm_nonzero = false, dm_negative = false;
+  uint64_t dm_abs = 0;
+  if (P.ptxt > 1) {
+    const uint64_t p = P.ptxt;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      acc += shoup_lazy(a[k], P.Wp[k], p);  // each < 2p
+      if ((k & 3) == 3)
+        acc = red64(acc, p, P.ptxt_mu64);
+    }
+    uint64_t r = red64(acc, p, P.ptxt_mu64);
+    if (neg)
+      r = sub_mod(r, P.pmod_ptxt, p);
+    if (r != 0) {
+      uint64_t dm = mul_mod(r, P.pinv_ptxt, p, P.ptxt_mu, P.ptxt_k);
+      const uint64_t p_over_2 = p >> 1;
+      bool sub_p = dm > p_over_2 || (((p & 1) == 0) && dm == p_over_2 && neg);
+      dm_nonzero = true;
+      dm_negative = sub_p;
+      dm_abs = sub_p ? p - dm : dm;
+    }
+  }
+  if (A.frac) {
+    double fr = mixed_radix_fraction<N>(a, P.src_q, N) - (neg ? 1.0 : 0.0);
+    if (dm_nonzero)
+      fr += dm_negative ? (double)dm_abs : -(double)dm_abs;
+    A.frac[i] = fr;
+  }
+  uint32_t a0[N], a1[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    a0[k] = (uint32_t)a[k] & 0x3fffffffu;
+    a1[k] = (uint32_t)(a[k] >> 30);
+  }
+  for (int t = 0; t < P.nt; t++) {
+    const uint64_t q = P.tgt_q[t];
+    const TW* Wt = P.W + (size_t)t * N;
+    const uint64_t negfix = neg ? q - P.pmod[t] : 0;
+    uint64_t r;
+    if (P.tgt_lazy[t]) {
+      // N <= 16 products of < 2^60 per accumulator
+      uint64_t c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        const uint64_t w = Wt[k].w;
+        const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
+        c00 += (uint64_t)a0[k] * w0;
+        c01 += (uint64_t)a0[k] * w1;
+        c10 += (uint64_t)a1[k] * w0;
+        c11 += (uint64_t)a1[k] * w1;
+      }
+      const u128 S = (u128)negfix + c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
+      r = red128_q8(S, q, P.tgt_mu63[t], P.tgt_k[t]);
+    } else if (P.tgt_chunk7[t]) {
+      r = negfix;
+#pragma unroll
+      for (int k0 = 0; k0 < N; k0 += 7) {
+        uint64_t c00 = 0, c01 = 0, c11 = 0;
+#pragma unroll
+        for (int k = k0; k < (k0 + 7 < N ? k0 + 7 : N); k++) {
+          const uint64_t w = Wt[k].w;
+          const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
+          c00 += (uint64_t)a0[k] * w0;
+          c01 += (uint64_t)a0[k] * w1;
+          c01 += (uint64_t)a1[k] * w0;
+          c11 += (uint64_t)a1[k] * w1;
+        }
+        const u128 S = (u128)r + c00 + ((u128)c01 << 30) + ((u128)c11 << 60);
+        r = red128_q8(S, q, P.tgt_mu63[t], P.tgt_k[t]);
+      }
+    } else {
+      const uint64_t nq = 0 - q, q8 = q << 3;
+      const bool wide = P.tgt_k[t] >= 58;  // terms of < 4q could pass 2^64: fold every second term
+      uint64_t acc = negfix;
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        acc += shoup4(a[k], Wt[k], nq);
+        if ((k & 1) && wide)
+          acc = csub(acc, q8);
+      }
+      r = norm_any(acc, q, (uint32_t)P.tgt_mu64[t]);
+    }
+    if (dm_nonzero) {
+      // delta -= diffProd * delta_i_modP
+      uint64_t d = red64(dm_abs, q, P.tgt_mu64[t]);
+      uint64_t corr = mul_mod(P.pmod[t], d, q, P.tgt_mu[t], P.tgt_k[t]);
+      r = dm_negative ? add_mod(r, corr, q) : sub_mod(r, corr, q);
+    }
+    if (A.dst_row[t] != 0xffff)
+      A.dst[(size_t)A.dst_row[t] * row_words + i] = r;
+    if (A.upd_row[t] != 0xffff) {
+      uint64_t* u = A.upd + (size_t)A.upd_row[t] * row_words + i;
+      const TW pinv = P.upd[t];
+      *u = mul_shoup(sub_mod(*u, r, q), pinv.w, pinv.wp, q);
     }
   }
 }

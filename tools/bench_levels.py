@@ -157,12 +157,15 @@ def main():
         sync()
         t0 = time.perf_counter()
         prev = None
-        for a, b in pairs:
+        pairs.reverse()
+        while pairs:                  # results are dropped as the loop goes (the reference's loop
+            a, b = pairs.pop()        # overwrites one ciphertext), so their storage is recycled
             a.multLowLvl(b, destructive=True)
             a.reLinearize()
             if prev is not None:
                 _ = prev.lnNoise
             prev = a
+            del a, b
         _ = prev.lnNoise
         sync()
         return time.perf_counter() - t0, prev

@@ -26,13 +26,17 @@ def main():
         if "--by-grid" in sys.argv and "grid_x" in cols:
             # the same kernel is launched at very different sizes (batch-1 key generation and
             # encryption next to the batch-128 timed loop): one line per (kernel, grid)
-            print("# by launch size (kernels with >= 2 sizes; workgroups = grid_x / workgroup_x)")
+            print("# by launch size (workgroups = grid_x / workgroup_x); last20 = average of the last 20 launches of that")
+            print("# size -- for ntt_row_kernel<14,fwd> at 6400 workgroups that is bench.py's roofline loop, which runs last")
             for n, gx, wx, k, a, mn, mx in c.execute(
                     f"select {name_col}, grid_x, workgroup_x, count(*), avg(end-start), min(end-start), max(end-start) "
                     "from kernels group by 1, 2 having count(*) >= 4 order by 1, 2 desc").fetchall():
-                if "ntt_" in n or "break_digits" in n or "keyswitch" in n or "tensor" in n:
+                if "ntt_" in n or "break_digits" in n or "keyswitch" in n or "tensor" in n or "rns_extend" in n:
                     short = n if len(n) <= 60 else n[:57] + "..."
-                    print(f"  {short:60s} wgs {gx // max(wx, 1):7d} calls {k:5d} avg {a/1e3:9.2f} us  min {mn/1e3:9.2f}  max {mx/1e3:9.2f}")
+                    tail = c.execute(f"select avg(d) from (select end-start as d from kernels where {name_col} = ? and "
+                                     "grid_x = ? order by start desc limit 20)", (n, gx)).fetchone()[0]
+                    print(f"  {short:60s} wgs {gx // max(wx, 1):7d} calls {k:5d} avg {a/1e3:9.2f} us  min {mn/1e3:9.2f}  "
+                          f"max {mx/1e3:9.2f}  last20 {tail/1e3:9.2f}")
         if "--gaps" in sys.argv:
             # where the device sat idle: the largest gaps between the end of one kernel and the
             # start of the next (host-bound stretches, synchronous API calls, copy engines)
