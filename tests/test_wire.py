@@ -329,3 +329,86 @@ def test_keys_through_the_wire_still_work():
     assert sk3.keySwitching == {} and sk3.Decrypt(sk.Encrypt(mb)) == [int(v) for v in mb]
     with pytest.raises(ValueError, match="Context mismatch"):
         wire.to_seckey(dict(desc, context=dict(desc["context"], m=64)), hk.SecKey, cc, be, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# the same formats from C++ (include/helib_amd_wire.hpp), no device involved
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def wire_exe(tmp_path_factory):
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path_factory.mktemp("wire") / "wire_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "wire_test.cpp"), "-o", exe])
+
+    def run(mode, blob, tmp=exe + ".bin"):
+        with open(tmp, "wb") as f:
+            f.write(blob)
+        r = subprocess.run([exe, mode, tmp], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return json.loads(r.stdout)
+    return run
+
+
+def test_cpp_wire_header_on_the_reference_fixture(wire_exe):
+    """helib_amd_wire.hpp reads the reference's whole binary fixture to the last byte, writes the
+    same 6704 bytes back, and sees what helib_amd/wire.py sees."""
+    got = wire_exe("legacy", WHOLE)
+    assert got["consumed"] and got["same_bytes"] and got["embedded_pk_equal"]
+    c, off = wire.read_context(WHOLE, 0, legacy=True)
+    pk, off2 = wire.read_pubkey(WHOLE, off, legacy=True)
+    assert got["offsets"] == [off, off2, len(WHOLE)]
+    assert (got["context"]["m"], got["context"]["p"], got["context"]["gens"], got["context"]["ords"]) == \
+        (12, 7, [5], [2])
+    assert [tuple(h) for h in got["handles"]] == [w["fromKey"] for w in pk["keySwitching"]]
+    assert got["keySwitchMap"] == pk["keySwitchMap"][0] == got["keySwitchMap_bfs"]
+    assert got["KS_strategy"] == pk["KS_strategy"] and got["skBounds"] == [64.0] and got["recryptKeyID"] == -1
+    assert got["pubEncrKey_primeSet"] == pk["pubEncrKey"]["primeSet"] and got["pubEncrKey_parts"] == 2
+    assert got["pubEncrKey_noise"] == [pk["pubEncrKey"]["noiseBound"], 0]
+    assert got["sk_idx"] == ASCII["seckey"]["idx"] and got["sk_row0"] == ASCII["seckey"]["rows"][0]
+
+
+def test_cpp_wire_header_2_2_0_layout_against_the_python_writer(wire_exe):
+    """Blobs written by helib_amd/wire.py in the 2.2.0 layout (Context, PubKey, SecKey, sk_only,
+    Ctxt incl. a CKKS one with a non-trivial ratFactor) are consumed and reproduced byte for byte
+    by the C++ reader/writer; header / eye-catcher / truncation / context errors are raised."""
+    cc, octx, be, sk = _keys()
+    d = wire.from_seckey(sk)
+    for mode, blob in (("context", wire.write_context(d["context"])), ("pubkey", wire.write_pubkey(d)),
+                       ("seckey", wire.write_seckey(d)), ("skonly", wire.write_seckey(d, sk_only=True))):
+        got = wire_exe(mode, blob)
+        assert got["consumed"] and got["same_bytes"], mode
+        assert got["context"]["qs"] == [int(q) for q in cc.primes] and got["context"]["gens"] == d["context"]["gens"]
+        assert got["context"]["specialPrimes"] == list(cc.specialPrimes) and got["context"]["ndigits"] == len(cc.digits)
+        if mode in ("pubkey", "seckey"):
+            assert [tuple(h) for h in got["handles"]] == [w["fromKey"] for w in d["keySwitching"]]
+            assert got["keySwitchMap"] == d["keySwitchMap"][0] == got["keySwitchMap_bfs"]
+            assert got["skBounds"] == d["skBounds"]
+        if mode in ("seckey", "skonly"):
+            assert got["nsk"] == 1
+    rng = np.random.default_rng(1)
+    ca, cb = sk.Encrypt(rng.integers(0, 257, size=cc.phim)), sk.Encrypt(rng.integers(0, 257, size=cc.phim))
+    ca.multiplyBy(cb)
+    got = wire_exe("ctxt", wire.write_ctxt(wire.from_ctxt(ca)))
+    assert got["consumed"] and got["same_bytes"] and got["poly_round_trip"]
+    assert got["primeSet"] == sorted(ca.primeSet) and got["intFactor"] == ca.intFactor and got["parts"] == 2
+    # a CKKS ciphertext: ratFactor far outside a double's range travels as (mantissa, exponent)
+    from helib_amd import ctxt as hc, keys as hk
+    from oracle import oracle as O
+    from oracle.backend import OracleBackend
+    ck = hc.ChainContext(128, -1, 20, bits=250, c=2, ckks=True)
+    oc = O.Ctx(128)
+    for q in ck.primes:
+        oc.add_prime(q)
+    sk2 = hk.SecKey(ck, OracleBackend(oc, ck), 3)
+    sk2.GenSecKey()
+    f = float(1 << 20)
+    pt = np.rint(rng.uniform(-1, 1, ck.phim) / ck.phim * f).astype(np.int64)
+    c1, c2 = sk2.CKKSencrypt(pt, 1.0, f), sk2.CKKSencrypt(pt, 1.0, f)
+    c1.multiplyBy(c2)
+    desc = wire.from_ctxt(c1)
+    got = wire_exe("ctxt", wire.write_ctxt(desc))
+    assert got["consumed"] and got["same_bytes"] and got["ptxtSpace"] == 1
+    assert got["ratFactor"] == [desc["ratFactor"][0], desc["ratFactor"][1]] and got["ratFactor"][1] >= 1
+    assert all(wire_exe("errors", wire.write_seckey(d))["errors"])
