@@ -13,13 +13,231 @@
 // samplers, which reduce modulo Phi_m, are in helib_amd/keys.py).  One secret key per object.
 // No CPU fallback: every polynomial operation is a call into libhelib_amd.so.
 #pragma once
+#include <climits>
 #include <cmath>
 #include <memory>
+#include <numeric>
 #include <random>
 
 #include "helib_amd_ctxt.hpp"
 
 namespace helib_amd {
+
+// Z_m^* / <p>: the generators HElib rotates along.  findGenerators (src/NumbTh.cpp:276-430): classes of
+// Z_m^* merged by p, then by each chosen generator; the next generator is an element of largest order
+// in the running quotient, preferring one whose order there equals its order in Z_m^* ("quality 2"),
+// then one whose power lands in <p>; `candidates` are tried first.  ZmStar is the slice of PAlgebra
+// the matrix families use (src/PAlgebra.cpp:470-507, 619-637).
+class ZmStar {
+public:
+  long m, p, ordP = 0;
+  std::vector<long> gens, ords;   // |order| of each generator in the quotient
+  std::vector<bool> native;       // SameOrd: the generator has that order in Z_m^* too
+
+  ZmStar(long m_, long p_, std::vector<long> candidates = {}, std::vector<long> given_ords = {}) : m(m_), p(p_)
+  {
+    if (!candidates.empty() && candidates.size() == given_ords.size()) {  // supplied as is
+      gens = candidates;
+      for (long o : given_ords)
+        ords.push_back(o < 0 ? -o : o);   // a user-supplied sign is ignored (:497-501)
+      long x = mod(p);
+      ordP = 1;
+      while (x != 1) {
+        x = mul(x, mod(p));
+        ordP++;
+      }
+    } else {
+      findGenerators(candidates);
+    }
+    for (size_t i = 0; i < gens.size(); i++)
+      native.push_back(power(gens[i], ords[i]) == 1);
+  }
+  long numOfGens() const { return (long)gens.size(); }
+  long OrderOf(long i) const { return ords[(size_t)i]; }
+  bool SameOrd(long i) const { return native[(size_t)i]; }
+  std::vector<long> signedOrds() const  // Context::writeTo's form: bad dimensions negated
+  {
+    std::vector<long> o;
+    for (size_t i = 0; i < ords.size(); i++)
+      o.push_back(native[i] ? ords[i] : -ords[i]);
+    return o;
+  }
+  long getNSlots() const
+  {
+    long n = 1;
+    for (long o : ords)
+      n *= o;
+    return n;
+  }
+  // g_i^j mod m; i == -1: the Frobenius p^j; negative j through the inverse
+  long genToPow(long i, long j) const
+  {
+    if (i == (long)gens.size()) {
+      if (j != 0)
+        throw InvalidArgument("PAlgebra::genToPow: i == sz but j != 0");
+      return 1;
+    }
+    if (i < -1 || i >= (long)gens.size())
+      throw InvalidArgument("PAlgebra::genToPow: bad dim");
+    long base = i == -1 ? mod(p) : gens[(size_t)i];
+    if (j < 0) {
+      base = inverse(base);
+      j = -j;
+    }
+    return power(base, j);
+  }
+
+private:
+  long mod(long a) const { return ((a % m) + m) % m; }
+  long mul(long a, long b) const { return (long)((unsigned __int128)a * (unsigned long)b % (unsigned long)m); }
+  long power(long b, long e) const
+  {
+    long r = 1 % m;
+    b = mod(b);
+    while (e) {
+      if (e & 1)
+        r = mul(r, b);
+      b = mul(b, b);
+      e >>= 1;
+    }
+    return r;
+  }
+  long inverse(long a) const
+  {
+    long x0 = 1, x1 = 0, aa = mod(a), bb = m;
+    while (bb) {
+      long q = aa / bb, t = aa % bb;
+      aa = bb, bb = t;
+      t = x0 - q * x1, x0 = x1, x1 = t;
+    }
+    if (aa != 1)
+      throw InvalidArgument("not a unit modulo m");
+    return mod(x0);
+  }
+  static void conjClasses(std::vector<long>& classes, long g, long m)
+  {
+    for (long i = 0; i < m; i++) {
+      if (classes[(size_t)i] == 0)
+        continue;
+      if (classes[(size_t)i] < i) {
+        classes[(size_t)i] = classes[(size_t)classes[(size_t)i]];
+        continue;
+      }
+      long j = (long)((unsigned __int128)i * (unsigned long)g % (unsigned long)m);
+      while (classes[(size_t)j] != i) {
+        classes[(size_t)classes[(size_t)j]] = i;
+        j = (long)((unsigned __int128)j * (unsigned long)g % (unsigned long)m);
+      }
+    }
+  }
+  static std::vector<long> compOrder(const std::vector<long>& classes, long m)
+  {
+    std::vector<long> orders((size_t)m, 0);
+    if (m > 1)
+      orders[1] = 1;
+    for (long i = 2; i < m; i++) {
+      if (classes[(size_t)i] <= 1) {
+        orders[(size_t)i] = classes[(size_t)i] == 1 ? 1 : 0;
+        continue;
+      }
+      if (classes[(size_t)i] < i) {
+        orders[(size_t)i] = orders[(size_t)classes[(size_t)i]];
+        continue;
+      }
+      long j = (long)((unsigned __int128)i * (unsigned long)i % (unsigned long)m), o = 2;
+      while (classes[(size_t)j] != 1) {
+        j = (long)((unsigned __int128)j * (unsigned long)i % (unsigned long)m);
+        o++;
+      }
+      orders[(size_t)i] = o;
+    }
+    return orders;
+  }
+  void findGenerators(const std::vector<long>& candidates)
+  {
+    std::vector<long> classes((size_t)m);
+    for (long i = 0; i < m; i++)
+      classes[(size_t)i] = std::gcd(i, m) == 1 ? i : 0;
+    conjClasses(classes, mod(p), m);
+    std::vector<char> p_subgp((size_t)m, 0);
+    for (long i = 0; i < m; i++)
+      if (classes[(size_t)i] == 1) {
+        p_subgp[(size_t)i] = 1;
+        ordP++;
+      }
+    size_t cand = 0;
+    for (;;) {
+      std::vector<long> orders = compOrder(classes, m);
+      long idx = 0;
+      if (cand < candidates.size()) {
+        idx = candidates[cand++];
+        if (orders[(size_t)idx] <= 1)
+          idx = 0;
+      }
+      if (idx == 0) {
+        long largest = 1;
+        for (long o : orders)
+          largest = std::max(largest, o);
+        if (largest > 1) {
+          int best_q = 0;
+          long best = -1;
+          for (long i = 0; i < m && best_q < 2; i++)
+            if (orders[(size_t)i] == largest) {
+              long j = power(i, largest);
+              if (j == 1)
+                best = i, best_q = 2;
+              else if (best_q < 1 && p_subgp[(size_t)j])
+                best = i, best_q = 1;
+            }
+          idx = best > 0 ? best : 0;
+        }
+      }
+      if (!idx)
+        break;
+      gens.push_back(idx);
+      ords.push_back(orders[(size_t)idx]);
+      conjClasses(classes, idx, m);
+    }
+  }
+};
+
+// which automorphisms a family of key-switching matrices covers for dimension i (-1: Frobenius)
+// (src/keySwitching.cpp:297-304, 381-401, 528-562, 620-646)
+enum KSStrategy { HELIB_KSS_UNKNOWN = 0, HELIB_KSS_FULL = 1, HELIB_KSS_BSGS = 2, HELIB_KSS_MIN = 3 };
+inline long KSGiantStepSize(long D)
+{
+  if (D <= 0)
+    throw InvalidArgument("Step size must be positive");
+  long g = (long)std::sqrt((double)D);
+  while (g * g > D)
+    g--;
+  while ((g + 1) * (g + 1) <= D)
+    g++;
+  return g * g < D ? g + 1 : g;
+}
+inline std::vector<long> family1D(const ZmStar& z, long i, KSStrategy kind)
+{
+  const long ord = i == -1 ? z.ordP : z.OrderOf(i);
+  const bool native = i == -1 ? true : z.SameOrd(i);
+  std::vector<long> ks;
+  if (kind == HELIB_KSS_FULL) {
+    for (long j = 1; j < ord; j++)
+      ks.push_back(z.genToPow(i, j));
+  } else if (kind == HELIB_KSS_BSGS) {
+    long g = KSGiantStepSize(ord);
+    for (long j = 1; j < g; j++)
+      ks.push_back(z.genToPow(i, j));
+    for (long j = g; j < ord; j += g)
+      ks.push_back(z.genToPow(i, j));
+  } else {
+    ks.push_back(z.genToPow(i, 1));
+  }
+  if (!native)
+    ks.push_back(z.genToPow(i, -ord));
+  if (kind == HELIB_KSS_MIN && ord > 8)   // HELIB_KEYSWITCH_MIN_THRESH
+    ks.push_back(z.genToPow(i, KSGiantStepSize(ord)));
+  return ks;
+}
 
 class Sampler {
 public:
@@ -483,5 +701,42 @@ public:
     return out;
   }
 };
+
+// add1DMatrices / addSome1DMatrices / addBSGS1DMatrices / addMinimal1DMatrices and the Frobenius
+// variants (src/keySwitching.cpp:573-664): GenKeySWmatrix(1, k) for every k of the family, the
+// strategy recorded per dimension (index dim + 1, as PubKey::KS_strategy), then setKeySwitchMap
+inline void addFamily(SecKey& sk, const ZmStar& z, long i, KSStrategy kind, std::vector<long>& KS_strategy)
+{
+  for (long k : family1D(z, i, kind))
+    sk.GenKeySWmatrix(1, k);
+  if ((long)KS_strategy.size() <= i + 1)
+    KS_strategy.resize((size_t)i + 2, HELIB_KSS_UNKNOWN);
+  KS_strategy[(size_t)(i + 1)] = kind;
+}
+inline void addSome1DMatrices(SecKey& sk, const ZmStar& z, std::vector<long>& KS_strategy, long bound = 50)
+{
+  for (long i = 0; i < z.numOfGens(); i++)
+    addFamily(sk, z, i, bound >= z.OrderOf(i) ? HELIB_KSS_FULL : HELIB_KSS_BSGS, KS_strategy);
+  sk.setKeySwitchMap();
+}
+inline void add1DMatrices(SecKey& sk, const ZmStar& z, std::vector<long>& ks) { addSome1DMatrices(sk, z, ks, LONG_MAX); }
+inline void addBSGS1DMatrices(SecKey& sk, const ZmStar& z, std::vector<long>& ks) { addSome1DMatrices(sk, z, ks, 0); }
+inline void addMinimal1DMatrices(SecKey& sk, const ZmStar& z, std::vector<long>& ks)
+{
+  for (long i = 0; i < z.numOfGens(); i++)
+    addFamily(sk, z, i, HELIB_KSS_MIN, ks);
+  sk.setKeySwitchMap();
+}
+inline void addSomeFrbMatrices(SecKey& sk, const ZmStar& z, std::vector<long>& ks, long bound = 50)
+{
+  addFamily(sk, z, -1, bound >= z.ordP ? HELIB_KSS_FULL : HELIB_KSS_BSGS, ks);
+  sk.setKeySwitchMap();
+}
+inline void addFrbMatrices(SecKey& sk, const ZmStar& z, std::vector<long>& ks) { addSomeFrbMatrices(sk, z, ks, LONG_MAX); }
+inline void addMinimalFrbMatrices(SecKey& sk, const ZmStar& z, std::vector<long>& ks)
+{
+  addFamily(sk, z, -1, HELIB_KSS_MIN, ks);
+  sk.setKeySwitchMap();
+}
 
 }  // namespace helib_amd

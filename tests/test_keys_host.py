@@ -488,3 +488,47 @@ def test_ckks_add_at_different_scales(m, precision, bits):
     assert abs(c1.lnRatFactor - r) < 1e-12
     got = np.array([float(v) for v in sk.Decrypt(c1)]) / math.exp(c1.lnRatFactor)
     assert np.max(np.abs(got - (a - b))) < 2.0 ** (-precision + 2)
+
+
+def test_cpp_zmstar_and_matrix_families_match_the_python_side(tmp_path):
+    """include/helib_amd_keys.hpp: ZmStar (findGenerators, candidates, SameOrd, genToPow) and
+    family1D (the automorphisms add1DMatrices / addBSGS... / addMinimal... / addFrbMatrices ask
+    GenKeySWmatrix for) against helib_amd.hostnt / helib_amd.keys on the reference's table rows."""
+    import json
+    import os
+    import subprocess
+    from helib_amd import hostnt as H
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "zmstar_test")
+    libdir = os.path.join(root, "helib_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "zmstar_test.cpp"), "-L" + libdir, "-lhelib_amd",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+
+    def families(z, kind):
+        out = []
+        for i in range(z.numOfGens()):
+            o, g = z.OrderOf(i), hk.KSGiantStepSize(z.OrderOf(i))
+            if kind == "full":
+                f = [z.genToPow(i, j) for j in range(1, o)]
+            elif kind == "bsgs":
+                f = [z.genToPow(i, j) for j in range(1, g)] + [z.genToPow(i, j) for j in range(g, o, g)]
+            else:
+                f = [z.genToPow(i, 1)]
+            if not z.SameOrd(i):
+                f.append(z.genToPow(i, -o))
+            if kind == "min" and o > 8:
+                f.append(z.genToPow(i, g))
+            out.append(f)
+        return out
+
+    cases = [(12, 7, []), (128, 257, []), (32768, 65537, []), (105, 2, [])] + \
+            [(m, p, gens) for p, _, m, _, gens, _ in ZM_TABLE[:6]] + [(m, p, []) for p, _, m, _, _, _ in ZM_TABLE[:6]]
+    for m, p, cand in cases:
+        got = json.loads(subprocess.check_output([exe, str(m), str(p)] + [str(c) for c in cand]))
+        z = H.ZmStar(m, p, cand)
+        assert got["gens"] == z.gens and got["ords"] == z.signedOrds() and got["ordP"] == z.ordP, (m, p)
+        assert got["nslots"] == z.getNSlots()
+        for kind in ("full", "bsgs", "min"):
+            assert got[kind] == families(z, kind), (m, p, kind)
+        assert got["frob"] == [pow(p, j, m) for j in range(1, z.ordP)]
