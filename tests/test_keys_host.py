@@ -532,3 +532,29 @@ def test_cpp_zmstar_and_matrix_families_match_the_python_side(tmp_path):
         for kind in ("full", "bsgs", "min"):
             assert got[kind] == families(z, kind), (m, p, kind)
         assert got["frob"] == [pow(p, j, m) for j in range(1, z.ordP)]
+
+
+@pytest.mark.parametrize("scheme", ["ckks", "bgv"])
+def test_bench_levels_control_flow_over_the_oracle_backend(scheme):
+    """tools/bench_levels.py is a device-only tool; its run() -- keys, batched operands, the two
+    levels, decrypt/decode checks -- is driven here with the test oracle's backend at a small ring."""
+    import argparse
+    import importlib.util
+    import os
+    from oracle.backend import OPoly
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_levels", os.path.join(root, "tools", "bench_levels.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    args = argparse.Namespace(m=128, bits=200, precision=20, batch=1, steps=1, warmup=1, bounds=False,
+                              scheme=scheme, p=257, l1_steps=0, phases=False)
+    if scheme == "ckks":
+        cc, octx, be, _ = setup_ckks(128, 20, 200)
+    else:
+        cc, octx, be, _ = setup(128, 257, 200)
+    measure = hc.Ctxt.measure
+    try:
+        line = mod.run(cc, be, lambda: None, lambda idx, rows: OPoly(octx, idx, rows[:, 0]), args, "oracle")
+    finally:
+        hc.Ctxt.measure = measure
+    assert line["verified"] and line["level1_fresh_mult_per_s"] > 0 and line["level2_mult_per_s"] > 0

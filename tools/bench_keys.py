@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Timings for SURVEY row N2 at the BASELINE shape (BGV m=32768, p=65537, bits=950): key
 generation, PubKey::Encrypt and SecKey::Decrypt (benchmarks/bgv_basic.cpp:186-211 time the same
-calls) with the DoubleCRT work on the GPU, next to the CPU oracle backend driven by the same host
-code.  One JSON line per operation.  usage: python tools/bench_keys.py [--cpu] [--reps R]"""
+calls) with the DoubleCRT work on the GPU.  One JSON line per operation.
+usage: python tools/bench_keys.py [--reps R]   (device only; the CPU figures quoted in DESIGN.md
+section 7.1 came from the same host code over the test oracle's backend)"""
 import argparse
 import json
 import os
@@ -17,7 +18,6 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cpu", action="store_true", help="also time the oracle backend (test infrastructure)")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--bits", type=int, default=950)
     args = ap.parse_args()
@@ -28,13 +28,6 @@ def main():
     for q in cc.primes:
         gctx.add_prime(q)
     backends = [("gpu", hk.HxBackend(gctx, cc), gctx.sync)]
-    if args.cpu:
-        from oracle import oracle as O
-        from oracle.backend import OracleBackend
-        octx = O.Ctx(cc.m)
-        for q in cc.primes:
-            octx.add_prime(q)
-        backends.append(("cpu_oracle", OracleBackend(octx, cc), lambda: None))
     rng = np.random.default_rng(3)
     msg = rng.integers(0, cc.ptxtSpace, size=cc.phim)
     for name, be, sync in backends:

@@ -13,7 +13,8 @@ The last product of each level is decrypted and decoded (raw / ratFactor) and co
 negacyclic product of the plaintexts.  One JSON line on stdout.
 
   python tools/bench_levels.py                      # MI355X, m=65536 bits=1400 batch 64
-  python tools/bench_levels.py --backend oracle --m 128 --bits 200 --batch 2 --steps 1   # CPU logic check
+(the control flow of run() is exercised on the CPU by tests/test_keys_host.py, which hands it the
+test oracle's backend; this tool itself only knows the device)
 """
 import argparse
 import json
@@ -41,7 +42,6 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--backend", default="hx", choices=["hx", "oracle"])
     ap.add_argument("--bounds", action="store_true", help="noise bounds instead of measured noise")
     ap.add_argument("--scheme", default="ckks", choices=["ckks", "bgv"],
                     help="bgv: the same two levels for ContextBuilder<BGV>().m(m).p(p).bits(bits) -- level 2 is the "
@@ -59,31 +59,30 @@ def main():
         cc = hc.ChainContext(args.m, -1, args.precision, bits=args.bits, c=3, ckks=True)
     else:
         cc = hc.ChainContext(args.m, args.p, 1, bits=args.bits, c=3)
+    import torch
+    from helib_amd import capi as hx
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_levels.py needs an MI355X (no CPU path)")
+    ctx = hx.Context(cc.m, 0)
+    for q in cc.primes:
+        ctx.add_prime(q)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    line = run(cc, hk.HxBackend(ctx, cc), torch.cuda.synchronize,
+               lambda idx, rows: hx.DoubleCRT(ctx, idx, rows.shape[1], rows), args, "hx")
+    print(json.dumps(line))
+    if not line["verified"]:
+        raise SystemExit("bench_levels: the decrypted / decoded product is off -- results are wrong")
+
+
+def run(cc, be, sync, make, args, backend):
+    """The two levels over backend `be` (make(idx, rows[nrows, batch, phim]) builds its DoubleCRT);
+    returns the result line."""
+    from helib_amd import ctxt as hc, keys as hk
+    ckks = args.scheme == "ckks"
     n, B = cc.phim, args.batch
-    if args.backend == "hx":
-        import torch
-        from helib_amd import capi as hx
-        if not torch.cuda.is_available():
-            raise SystemExit("bench_levels.py --backend hx needs an MI355X (no CPU path)")
-        ctx = hx.Context(cc.m, 0)
-        for q in cc.primes:
-            ctx.add_prime(q)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        be, sync = hk.HxBackend(ctx, cc), torch.cuda.synchronize
-        make = lambda idx, rows: hx.DoubleCRT(ctx, idx, rows.shape[1], rows)              # noqa: E731
-    else:
-        from oracle import oracle as O
-        from oracle.backend import OPoly, OracleBackend
-        octx = O.Ctx(cc.m)
-        for q in cc.primes:
-            octx.add_prime(q)
-        be, sync = OracleBackend(octx, cc), (lambda: None)
-        if B != 1:
-            raise SystemExit("--backend oracle is unbatched: use --batch 1")
-        make = lambda idx, rows: OPoly(octx, idx, rows[:, 0])                             # noqa: E731
     hc.Ctxt.measure = not args.bounds
     phase_ms = {}
-    if args.phases:
+    if args.phases:   # (class-level wrappers: meant for the one-shot tool process)
         def wrap(owner, name, static=False):
             fn = getattr(owner, name)
 
@@ -182,7 +181,7 @@ def main():
         ok1 = all(np.array_equal(decode(p1, b).astype(object), w) for b, w in zip((0, B - 1), want1))
         dt2, p2 = timed(lambda k: [(p1.clone(), p1.clone()) for _ in range(k)], args.steps)
         ok2 = all(np.array_equal(decode(p2, b).astype(object), modmul(w, w)) for b, w in zip((0, B - 1), want1))
-        line = {"tool": "bench_levels", "backend": args.backend, "scheme": "bgv",
+        line = {"tool": "bench_levels", "backend": backend, "scheme": "bgv",
                 "workload": f"BGV m={cc.m} p={args.p} bits={args.bits}: L={L}, K={len(cc.specialPrimes)}, "
                             f"D={len(cc.digits)}, batch {B}, noise {'bounds' if args.bounds else 'measured'}",
                 "level1_fresh_mult_per_s": round(B * s1 / dt1, 1), "level1_ms_per_step": round(dt1 / s1 * 1e3, 3),
@@ -193,10 +192,7 @@ def main():
         if args.phases:
             line["phases_level1"] = phases1
             line["phases_level2"] = {k: [v[0], round(v[1], 2), round(v[2], 2)] for k, v in phase_ms.items()}
-        print(json.dumps(line))
-        if not (ok1 and ok2):
-            raise SystemExit("bench_levels --scheme bgv: decrypted product is wrong")
-        return
+        return line
     # the encoded plaintexts are rint(v*f)/f: compare with THEIR product, so that what is left is
     # the scheme's error, which must stay below the bound the ciphertext itself reports
     # (noiseBound / ratFactor; a coefficient is at most the canonical-embedding norm for m = 2^k)
@@ -210,7 +206,7 @@ def main():
     mag = [float(np.max(np.abs(want1[0]))), float(np.max(np.abs(want2[0])))]
     ok = err1 <= tol[0] and err2 <= tol[1] and err1 < 1e-3 * mag[0] and err2 < 1e-3 * mag[1]
     line = {
-        "tool": "bench_levels", "backend": args.backend,
+        "tool": "bench_levels", "backend": backend,
         "workload": f"CKKS m={cc.m} precision={args.precision} bits={args.bits}: L={L} ctxt primes, "
                     f"K={len(cc.specialPrimes)} special, D={len(cc.digits)}; Ctxt::multiplyBy on CKKSencrypt "
                     f"ciphertexts, batch {B}, noise {'bounds' if args.bounds else 'measured'}",
@@ -227,9 +223,7 @@ def main():
     if args.phases:   # [calls, host ms, host+device ms] summed over warm-up and timed multiplies
         line["phases_level1"] = phases1
         line["phases_level2"] = {k: [v[0], round(v[1], 2), round(v[2], 2)] for k, v in phase_ms.items()}
-    print(json.dumps(line))
-    if not ok:
-        raise SystemExit("bench_levels: decoded product is off -- results are wrong")
+    return line
 
 
 if __name__ == "__main__":
