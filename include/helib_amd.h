@@ -151,7 +151,9 @@ int hx_add_primes(hx_poly* a, const int* add_idx, int nadd);
  * t in [2, 2^60); at most 64 rows.  Synchronous (the result is on the host when it returns). */
 int hx_poly_rem(const hx_poly* a, uint64_t t, uint64_t* out_host);
 /* DoubleCRT::scaleDownToSet (src/DoubleCRT.cpp:1464-1516): drop drop_idx with
- * exact rounding, delta forced to 0 mod ptxt_space.  In place. */
+ * exact rounding, delta forced to 0 mod ptxt_space.  In place as far as the caller can tell: the
+ * kept rows keep their order; a library-owned poly may move to another slab (hx_poly_device_ptr
+ * changes), a poly made with hx_poly_wrap always has its result in the caller's buffer. */
 int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_t ptxt_space);
 /* The same for several DoubleCRT objects sharing one prime set and batch (all parts of the
  * ciphertexts of one Ctxt::modDownToSet, src/Ctxt.cpp:462-465) in one pair of launches. */
