@@ -412,3 +412,27 @@ def test_cpp_wire_header_2_2_0_layout_against_the_python_writer(wire_exe):
     assert got["consumed"] and got["same_bytes"] and got["ptxtSpace"] == 1
     assert got["ratFactor"] == [desc["ratFactor"][0], desc["ratFactor"][1]] and got["ratFactor"][1] >= 1
     assert all(wire_exe("errors", wire.write_seckey(d))["errors"])
+
+
+def test_cpp_and_python_wire_agree_on_random_objects(wire_exe):
+    """Random ciphertext descriptions (ragged prime sets, 1-3 parts, xdouble fields across many
+    exponents, negative handles excluded as in the reference) -> python writer -> C++ reader/writer:
+    the same bytes come back, for 2.2.0 Ctxt objects embedded in nothing and inside a SecKey."""
+    rng = np.random.default_rng(2024)
+    for trial in range(12):
+        n = int(rng.choice([1, 4, 16]))
+        nprimes = int(rng.integers(1, 7))
+        idx = sorted(rng.choice(40, size=nprimes, replace=False).tolist())
+        parts = []
+        for h in [(0, 1, 0), (1, 1, 0), (int(rng.integers(1, 4)), int(rng.integers(2, 50)), 0)][:int(rng.integers(1, 4))]:
+            rows = rng.integers(0, 1 << 60, size=(nprimes, n), dtype=np.uint64)
+            parts.append((idx, rows, h))
+        xd = lambda: (float(rng.uniform(1.0, 2.0 ** 56)), int(rng.integers(-3, 9)))   # noqa: E731
+        desc = {"ptxtSpace": int(rng.choice([1, 2, 257, 65537])), "intFactor": int(rng.integers(1, 200)),
+                "ptxtMag": xd(), "ratFactor": xd(), "noiseBound": xd(), "primeSet": idx, "parts": parts}
+        blob = wire.write_ctxt(desc)
+        got = wire_exe("ctxt", blob)
+        assert got["consumed"] and got["same_bytes"] and got["primeSet"] == idx and got["parts"] == len(parts)
+        assert got["ratFactor"] == list(desc["ratFactor"]) and got["poly_round_trip"]
+        back, off = wire.read_ctxt(blob)
+        assert off == len(blob) and wire.write_ctxt(back) == blob
