@@ -21,14 +21,19 @@ workload : (default `bgv32768`) BGV m=32768, p=65537, bits=950 -> L=16 x 60-bit 
            reference's alternative noise bounds (no norms).
            `config.fixed_level_mult_per_s` additionally reports tensorProduct+reLinearize alone
            (hx_mul_relin, no prime-set changes), the kernel-level pipeline DESIGN.md analyses.
-step     : one multiplyBy over a batch of independent ciphertext pairs resident in HBM.
+step     : one multiplyBy over a batch of independent ciphertext pairs resident in HBM.  A result is
+           dropped once the next one is complete (the reference's loop overwrites its ciphertext),
+           so result storage is recycled by the engine's slab pool.
 scaling  : weak -- every rank multiplies its own batch; no data-path collective
            (independent ciphertexts shard across GPUs).
 other    : --workload bgv32768_fixed (fixed-level only), ckks65536 (configs[3] shape, fixed level).
 
 Adds "roofline" for the dominant kernel (forward NTT at the launch shape of the key switch,
 timed with HIP events on the launch stream) and "cpu_baseline" (the CPU oracle = a port of the
-reference algorithm driven through the same sequence, single thread, bounded sample).
+reference algorithm driven through the same sequence: `value` on one core, as the reference
+benchmarks run, `all_cores` with one process per host core, both on a bounded sample).
+other workloads: tools/bench_levels.py times the multiply one level further down (operands that
+carry special primes) for BGV and for the CKKS chain of configs[3], with decoded results checked.
 """
 import argparse
 import json
