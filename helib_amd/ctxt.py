@@ -48,9 +48,43 @@ def _divc(a, b):
     return -(-a // b)
 
 
+def handle_powers(handle):
+    """(powerOfS, powerOfX) of a part key: "1", "s", "s2", ("s", k) = s(X^k), ("s^", r) = s^r,
+    ("s^", r, k) = s^r(X^k)  (SKHandle, include/helib/Ctxt.h:74-170)."""
+    if handle == "1":
+        return 0, 1
+    if handle == "s":
+        return 1, 1
+    if handle == "s2":
+        return 2, 1
+    if handle[0] == "s":
+        return 1, int(handle[1])
+    return int(handle[1]), (int(handle[2]) if len(handle) > 2 else 1)
+
+
+def handle_of(powerOfS, powerOfX=1):
+    if powerOfS == 0:
+        return "1"
+    if powerOfX == 1:
+        return {1: "s", 2: "s2"}.get(powerOfS, ("s^", powerOfS))
+    return ("s", powerOfX) if powerOfS == 1 else ("s^", powerOfS, powerOfX)
+
+
+def handle_mul(h1, h2):
+    """SKHandle::mul (include/helib/Ctxt.h:140-165): powers of s add; the automorphism amounts must
+    agree unless one side is the constant handle."""
+    (s1, x1), (s2, x2) = handle_powers(h1), handle_powers(h2)
+    if s1 == 0:
+        return h2
+    if s2 == 0:
+        return h1
+    if x1 != x2:
+        raise ValueError("cannot multiply parts under different automorphisms")
+    return handle_of(s1 + s2, x1)
+
+
 def _powerOfS(handle):
-    """SKHandle::getPowerOfS for the part keys used here: "1", "s", "s2", ("s", k) = s(X^k)."""
-    return {"1": 0, "s": 1, "s2": 2}.get(handle, 1)
+    return handle_powers(handle)[0]
 
 
 def _ln(x):
@@ -304,6 +338,7 @@ class Ctxt:
         self._ln = -math.inf
         self._pending = []     # deferred noise updates waiting for norms still on the device
         self.ksw_auto = {}     # k -> key-switching matrix from s(X^k) to s (PubKey::getKeySWmatrix)
+        self.ksw_pow = {}      # r -> key-switching matrix from s^r to s, r >= 3 (r = 2 is self.ksw)
         self.ksw_map = None    # PubKey::keySwitchMap: k -> first step n on the way to X -> X^k (0: none)
         self.parts = {}
         self.primeSet = frozenset()
@@ -330,6 +365,7 @@ class Ctxt:
         c.lnNoise, c.intFactor = self.lnNoise, self.intFactor
         c.ptxtMag, c.lnRatFactor = self.ptxtMag, self.lnRatFactor
         c.ksw_auto = self.ksw_auto
+        c.ksw_pow = self.ksw_pow
         c.ksw_map = self.ksw_map
         return c
 
@@ -670,12 +706,24 @@ class Ctxt:
         self._tensorProduct(o)
 
     def _tensorProduct(self, o):
-        assert set(self.parts) == {"1", "s"} and set(o.parts) == {"1", "s"}
         if self.ptxtSpace > 2:
             q = self.context.productOfPrimes(self.primeSet) % self.ptxtSpace
             self.intFactor = self.intFactor * o.intFactor % self.ptxtSpace * q % self.ptxtSpace
-        t0, t1, t2 = self.ops.tensorProduct(self.parts["1"], self.parts["s"], o.parts["1"], o.parts["s"])
-        self.parts = {"1": t0, "s": t1, "s2": t2}
+        if set(self.parts) == {"1", "s"} and set(o.parts) == {"1", "s"}:
+            t0, t1, t2 = self.ops.tensorProduct(self.parts["1"], self.parts["s"], o.parts["1"], o.parts["s"])
+            self.parts = {"1": t0, "s": t1, "s2": t2}
+        else:   # any parts (src/Ctxt.cpp:1576-1597): all pairwise products, accumulated by handle
+            new = {}
+            for h1, p1 in self.parts.items():
+                for h2, p2 in o.parts.items():
+                    h = handle_mul(h1, h2)
+                    t = p1.copy()
+                    t *= p2
+                    if h in new:
+                        new[h] += t
+                    else:
+                        new[h] = t
+            self.parts = new
         if self.context.ckks:   # totalNoiseBound = factor*ptxt + noiseBound on both sides (:1600-1606)
             n1, n2 = self.lnNoise, o.lnNoise
             self.lnNoise = logaddexp(logaddexp(n1 + _ln(o.ptxtMag) + o.lnRatFactor,
@@ -691,14 +739,10 @@ class Ctxt:
         other = [h for h in self.parts if h not in ("1", "s")]
         if not other:
             return
-        assert len(other) == 1, "one non-canonical part at a time"
+        if len(other) > 1:
+            return self._reLinearizeMany(other)
         hnd = other[0]
-        if hnd == "s2":
-            W = self.ksw
-        else:
-            W = self.ksw_auto.get(hnd[1])
-            if W is None:
-                raise LookupError(f"no key-switching matrices for k={hnd[1]}")   # LogicError in the reference
+        W = self._matrixFor(hnd)
         ctx = self.context
         self.dropSmallAndSpecialPrimes()
         self._relin_CKKS_adjust()
@@ -729,6 +773,92 @@ class Ctxt:
         self.parts = {"1": o0, "s": o1}
         self.primeSet = self.primeSet | frozenset(sp)
         self._defer(update)
+
+    def _matrixFor(self, hnd):
+        """PubKey::getKeySWmatrix for the part's handle; LogicError in the reference when absent"""
+        sp_, xp_ = handle_powers(hnd)
+        if (sp_, xp_) == (2, 1):
+            W = self.ksw
+        elif sp_ == 1:
+            W = self.ksw_auto.get(xp_)
+        elif xp_ == 1:
+            W = self.ksw_pow.get(sp_)
+        else:
+            W = None
+        if W is None:
+            raise LookupError(f"no key-switching matrices for s^{sp_}(X^{xp_})")
+        return W
+
+    def _reLinearizeMany(self, other):
+        """Ctxt::reLinearize with several non-canonical parts (after multiplyBy2: s^2 and s^3):
+        parts 1 and s are scaled by P, every other part goes through keySwitchPart -- break into
+        digits, key-switch with its own matrix, accumulate (src/Ctxt.cpp:720-842)."""
+        ctx = self.context
+        mats = {h: self._matrixFor(h) for h in other}
+        self.dropSmallAndSpecialPrimes()
+        self._relin_CKKS_adjust()
+        sp = list(ctx.specialPrimes)
+        logProd = ctx.logOfProduct(sp)
+        self.lnRatFactor += logProd
+        digits = [[i for i in d if i in self.primeSet] for d in ctx.digits]
+        digits = [d for d in digits if d]
+        if self.ptxtSpace > 1:
+            self.ptxtSpace = math.gcd(self.ptxtSpace, self.ksw_ptxtSpace)
+            self.intFactor %= self.ptxtSpace
+        part0 = self.parts["1"]
+        part0.addPrimesAndScale(sp)
+        if "s" in self.parts:
+            part1 = self.parts["s"]
+            part1.addPrimesAndScale(sp)
+        else:
+            part1 = self.ops.zerosLike(part0)
+        added = -math.inf
+        for h in other:
+            if self._meas:
+                dg, nrm = self.ops.breakIntoDigits(self.parts[h], digits, sp, norms=True)
+            else:
+                dg, nrm = self.ops.breakIntoDigits(self.parts[h], digits, sp), None
+            self.ops.keySwitchDigits(dg, mats[h], part0, part1)
+            for k, d in enumerate(digits):
+                nb = _ln(float(max(nrm[k]))) if nrm is not None else \
+                    math.log(ctx.noiseBoundForUniform(0.5, ctx.phim))
+                added = logaddexp(added, nb + ctx.logOfProduct(d) + self.ksw_lnNoise)
+        self.lnNoise = logaddexp(self.lnNoise + logProd, added)
+        self.parts = {"1": part0, "s": part1}
+        self.primeSet = self.primeSet | frozenset(sp)
+
+    def multiplyBy2(self, other1, other2):
+        """Ctxt::multiplyBy2 (src/Ctxt.cpp:1776-1828): the product of three ciphertexts with ONE
+        relinearisation at the end (parts up to s^3), multiplying in the order of their capacities."""
+        if not self.parts:
+            return
+        for o in (other1, other2):
+            if not o.parts:
+                c = o.clone()
+                self.__dict__.update(c.__dict__)
+                return
+        cap = self.logOfPrimeSet() - max(self.lnNoise, 0.0)
+        cap1 = other1.logOfPrimeSet() - max(other1.lnNoise, 0.0)
+        cap2 = other2.logOfPrimeSet() - max(other2.lnNoise, 0.0)
+        if cap < cap1 and cap < cap2:
+            tmp = other1.clone()
+            tmp.multLowLvl(other2)
+            self.multLowLvl(tmp, destructive=True)
+            self.reLinearize()
+            return
+        first, second = (other2, other1) if (cap < cap2 or cap1 < cap2) else (other1, other2)
+        second = second.clone() if second is self else second
+        self.multLowLvl(first if first is not self else first.clone())
+        self.multLowLvl(second)
+        self.reLinearize()
+
+    def square(self):
+        """Ctxt::square: multiplyBy(*this)"""
+        self.multiplyBy(self.clone())
+
+    def cube(self):
+        """Ctxt::cube: multiplyBy2(*this, *this)"""
+        self.multiplyBy2(self.clone(), self.clone())
 
     def _relin_CKKS_adjust(self):
         """Ctxt::relin_CKKS_adjust (src/Ctxt.cpp:664-717): if the noise is below what the special

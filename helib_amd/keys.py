@@ -196,6 +196,8 @@ class PubKey:
         for (sp, xp), ks in self.keySwitching.items():
             if sp == 1 and xp > 1:
                 ct.ksw_auto[xp] = ks.W
+            elif sp > 2 and xp == 1:
+                ct.ksw_pow[sp] = ks.W
         ct.ksw_map = getattr(self, "keySwitchMap", None)
         return ct
 
@@ -369,8 +371,7 @@ class SecKey(PubKey):
             if handle == "1":
                 term = part.copy()
             else:
-                sPower = {"s": 1, "s2": 2}.get(handle, 1)
-                xPower = handle[1] if isinstance(handle, tuple) else 1
+                sPower, xPower = hc.handle_powers(handle)
                 term = self._keyRows(part.getIndexSet(), sPower, xPower)
                 term *= part
             if acc is None:

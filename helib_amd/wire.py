@@ -197,13 +197,9 @@ def _xd(v):
 
 
 def _handle_of(h):
-    if h == "1":
-        return (0, 1, 0)
-    if h == "s":
-        return (1, 1, 0)
-    if h == "s2":
-        return (2, 1, 0)
-    return (1, int(h[1]), 0)
+    from .ctxt import handle_powers
+    sp, xp = handle_powers(h)
+    return (sp, xp, 0)
 
 
 def _handle_name(sp, xp):

@@ -558,3 +558,49 @@ def test_bench_levels_control_flow_over_the_oracle_backend(scheme):
     finally:
         hc.Ctxt.measure = measure
     assert line["verified"] and line["level1_fresh_mult_per_s"] > 0 and line["level2_mult_per_s"] > 0
+
+
+@pytest.mark.parametrize("m,p,bits", [(128, 257, 300), (64, 65537, 400), (105, 2, 300)])
+def test_multiplyBy2_square_cube(m, p, bits):
+    """Ctxt::multiplyBy2 (src/Ctxt.cpp:1776-1828): three ciphertexts, one relinearisation -- the
+    tensor of a 3-part by a 2-part ciphertext (parts up to s^3) and keySwitchPart for s^2 and s^3 with
+    their own matrices; square = multiplyBy(*this), cube = multiplyBy2(*this, *this)."""
+    cc, octx, be, sk = setup(m, p, bits)
+    assert sk.haveKeySWmatrix(3, 1)
+    rng = np.random.default_rng(31)
+    ma, mb, mc = (rng.integers(0, p, size=cc.phim) for _ in range(3))
+    mul = lambda x, y: [int(v) for v in B.polymul_mod_phi(x, y, m, p)]   # noqa: E731
+    ca, cb, c3 = sk.Encrypt(ma), sk.Encrypt(mb), sk.Encrypt(mc)
+    # the unrelinearised triple product decrypts with s, s^2 and s^3
+    t = sk.Encrypt(ma)
+    t.multLowLvl(cb)
+    t.multLowLvl(c3)
+    assert set(t.parts) == {"1", "s", "s2", ("s^", 3)}
+    abc = mul(mul(ma, mb), mc)
+    assert sk.Decrypt(t) == abc
+    ca.multiplyBy2(cb, c3)
+    assert set(ca.parts) == {"1", "s"} and sk.Decrypt(ca) == abc
+    raw = sk.Decrypt(ca, raw=True)
+    assert math.log(be.embeddingLargestCoeff(np.array(raw, dtype=np.float64))) <= ca.lnNoise
+    # operands at different levels: (a*b) with fresh c and fresh a -- the order follows the capacities
+    low = sk.Encrypt(ma)
+    low.multiplyBy(cb)
+    low.multiplyBy2(sk.Encrypt(mc), sk.Encrypt(ma))
+    assert sk.Decrypt(low) == mul(abc, ma)
+    sq, cu = sk.Encrypt(mb), sk.Encrypt(mb)
+    sq.square()
+    cu.cube()
+    assert sk.Decrypt(sq) == mul(mb, mb) and sk.Decrypt(cu) == mul(mul(mb, mb), mb)
+    # a 4-part ciphertext survives the wire (the s^3 handle) and still decrypts
+    from helib_amd import wire
+    from oracle.backend import OPoly
+    blob = wire.write_ctxt(wire.from_ctxt(t))
+    desc, off = wire.read_ctxt(blob)
+    assert off == len(blob) and [h for _, _, h in desc["parts"]] == [(0, 1, 0), (1, 1, 0), (2, 1, 0), (3, 1, 0)]
+    t2 = wire.to_ctxt(desc, hc.Ctxt, cc, be.ops, lambda idx, rows: OPoly(octx, idx, rows))
+    assert sk.Decrypt(t2) == abc
+    # no matrix for s^3 -> the reference's LogicError
+    sk.keySwitching.pop((3, 1))
+    c4 = sk.Encrypt(ma)
+    with pytest.raises(LookupError):
+        c4.multiplyBy2(sk.Encrypt(mb), sk.Encrypt(mc))
