@@ -1049,3 +1049,57 @@ class BasicAutomorphPrecon:
         if amt != k:                   # more automorphisms to do: the usual smartAutomorph (:177-181)
             res.smartAutomorph(k * pow(amt, -1, ctx.m) % ctx.m)
         return res
+
+
+# ---------------------------------------------------------------------------------------------
+# products of many ciphertexts (src/Ctxt.cpp:2803-2904)
+# ---------------------------------------------------------------------------------------------
+def _split(n):
+    """n1 = the highest power of two below n (n/2 <= n1 < n): NumBits(n - 1) = l, n1 = 2^(l-1)"""
+    return 1 << ((n - 1).bit_length() - 1)
+
+
+def incrementalProduct(v):
+    """For i = n-1 .. 0: v[i] = prod_{j <= i} v[j], depth log n and (n log n)/2 products, in place."""
+    def rec(lo, n):
+        if n <= 1:
+            return
+        n1 = _split(n)
+        rec(lo, n1)
+        rec(lo + n1, n - n1)
+        for i in range(lo + n1, lo + n):
+            v[i].multiplyBy(v[lo + n1 - 1])
+    rec(0, len(v))
+
+
+def totalProduct(v):
+    """prod_i v[i] in depth log n with n-1 products (triples through multiplyBy2); a new Ctxt."""
+    def rec(lo, n):
+        out = v[lo].clone()
+        if n == 2:
+            out.multiplyBy(v[lo + 1])
+        elif n == 3:
+            out.multiplyBy2(v[lo + 1], v[lo + 2])
+        elif n > 3:
+            n1 = _split(n)
+            out = rec(lo, n1)
+            out.multiplyBy(rec(lo + n1, n - n1))
+        return out
+    if not v:
+        raise ValueError("totalProduct of an empty vector")
+    return rec(0, len(v))
+
+
+def innerProduct(v1, v2):
+    """sum_i v1[i] * v2[i] with the low-level product and ONE relinearisation at the end"""
+    n = min(len(v1), len(v2))
+    if n <= 0:
+        raise ValueError("innerProduct of empty vectors")
+    result = v1[0].clone()
+    result.multLowLvl(v2[0])
+    for i in range(1, n):
+        tmp = v1[i].clone()
+        tmp.multLowLvl(v2[i])
+        result.addCtxt(tmp)
+    result.reLinearize()
+    return result

@@ -604,3 +604,33 @@ def test_multiplyBy2_square_cube(m, p, bits):
     c4 = sk.Encrypt(ma)
     with pytest.raises(LookupError):
         c4.multiplyBy2(sk.Encrypt(mb), sk.Encrypt(mc))
+
+
+def test_incrementalProduct_totalProduct_innerProduct():
+    """src/Ctxt.cpp:2803-2904 over five ciphertexts: prefix products in place, the total product by
+    halves and triples, and sum_i a_i*b_i with one relinearisation (3-part ciphertexts on possibly
+    different prime sets are added before the key switch)."""
+    m, p = 64, 65537
+    cc, octx, be, sk = setup(m, p, 500)
+    rng = np.random.default_rng(41)
+    msgs = [rng.integers(0, p, size=cc.phim) for _ in range(5)]
+    mul = lambda x, y: [int(v) for v in B.polymul_mod_phi(x, y, m, p)]   # noqa: E731
+    prefix = [[int(v) for v in msgs[0]]]
+    for x in msgs[1:]:
+        prefix.append(mul(prefix[-1], x))
+    v = [sk.Encrypt(x) for x in msgs]
+    hc.incrementalProduct(v)
+    assert [sk.Decrypt(c) for c in v] == prefix
+    v = [sk.Encrypt(x) for x in msgs]
+    assert sk.Decrypt(hc.totalProduct(v)) == prefix[-1]
+    assert sk.Decrypt(v[0]) == prefix[0]                      # the inputs are left alone
+    for n in (1, 2, 3, 4):
+        assert sk.Decrypt(hc.totalProduct(v[:n])) == prefix[n - 1]
+    a, b = [sk.Encrypt(x) for x in msgs[:3]], [sk.Encrypt(x) for x in msgs[2:]]
+    want = [0] * cc.phim
+    for x, y in zip(msgs[:3], msgs[2:]):
+        want = [(u + w) % p for u, w in zip(want, mul(x, y))]
+    ip = hc.innerProduct(a, b)
+    assert set(ip.parts) == {"1", "s"} and sk.Decrypt(ip) == want
+    with pytest.raises(ValueError):
+        hc.totalProduct([])
