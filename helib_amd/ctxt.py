@@ -87,6 +87,23 @@ def _powerOfS(handle):
     return handle_powers(handle)[0]
 
 
+def polyNormBnd(m):
+    """calcPolyNormBnd (src/PAlgebra.cpp:215-240) where it is closed-form: 1 for a power of two,
+    2 cot(pi/(2u))/u when the odd part of m is a power of one prime u.  (The general case is a
+    search over the cyclotomic's roots; it is not restated here.)"""
+    while m % 2 == 0:
+        m //= 2
+    if m == 1:
+        return 1.0
+    u = next(d for d in range(3, m + 1, 2) if m % d == 0)
+    r = m
+    while r % u == 0:
+        r //= u
+    if r != 1:
+        raise NotImplementedError("polyNormBnd for m with two or more odd prime factors")
+    return 2.0 / math.tan(math.pi / (2.0 * u)) / u
+
+
 def _ln(x):
     return math.log(x) if x > 0 else -math.inf
 
@@ -530,6 +547,43 @@ class Ctxt:
         self.bringToSet(target)
 
     # ---- arithmetic ----
+    # ---- size / correctness accessors (include/helib/Ctxt.h:1291-1325, src/Ctxt.cpp:116-127) ----
+    def lnTotalNoiseBound(self):
+        """ln of totalNoiseBound(): for CKKS ptxtMag*ratFactor + noiseBound, else noiseBound"""
+        if self.context.ckks:
+            return logaddexp(_ln(self.ptxtMag) + self.lnRatFactor, self.lnNoise)
+        return self.lnNoise
+
+    def capacity(self):
+        """log2 of the modulus over the TOTAL noise bound (at least 1)"""
+        return (self.logOfPrimeSet() - max(self.lnTotalNoiseBound(), 0.0)) / LN2
+
+    def bitCapacity(self):
+        return int(self.capacity())
+
+    def isCorrect(self):
+        """totalNoiseBound * polyNormBnd <= 0.48 Q: would this ciphertext decrypt without errors?"""
+        return self.lnTotalNoiseBound() + math.log(polyNormBnd(self.context.m)) <= \
+            math.log(0.48) + self.logOfPrimeSet()
+
+    def frobeniusAutomorph(self, j):
+        """Ctxt::frobeniusAutomorph (src/Ctxt.cpp:2526-2545): X -> X^(p^j) for BGV (j mod ord(p));
+        for CKKS complex conjugation when j is odd (X -> X^(m-1))."""
+        if not self.parts or j == 0:
+            return
+        ctx = self.context
+        if ctx.ckks:
+            if j & 1:
+                self.smartAutomorph(ctx.m - 1)
+            return
+        d, x = 1, ctx.p % ctx.m
+        while x != 1:
+            x = x * ctx.p % ctx.m
+            d += 1
+        j %= d
+        if j:
+            self.smartAutomorph(pow(ctx.p, j, ctx.m))
+
     def mulIntFactor(self, e):
         """Ctxt::mulIntFactor (src/Ctxt.cpp:331-340)"""
         if e == 1:
@@ -837,9 +891,7 @@ class Ctxt:
                 c = o.clone()
                 self.__dict__.update(c.__dict__)
                 return
-        cap = self.logOfPrimeSet() - max(self.lnNoise, 0.0)
-        cap1 = other1.logOfPrimeSet() - max(other1.lnNoise, 0.0)
-        cap2 = other2.logOfPrimeSet() - max(other2.lnNoise, 0.0)
+        cap, cap1, cap2 = self.capacity(), other1.capacity(), other2.capacity()
         if cap < cap1 and cap < cap2:
             tmp = other1.clone()
             tmp.multLowLvl(other2)

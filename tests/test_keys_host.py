@@ -634,3 +634,34 @@ def test_incrementalProduct_totalProduct_innerProduct():
     assert set(ip.parts) == {"1", "s"} and sk.Decrypt(ip) == want
     with pytest.raises(ValueError):
         hc.totalProduct([])
+
+
+def test_capacity_isCorrect_frobenius():
+    cc, octx, be, sk = setup(128, 257, 300)
+    rng = np.random.default_rng(51)
+    msg = rng.integers(0, 257, size=cc.phim)
+    ct = sk.Encrypt(msg)
+    c0 = ct.capacity()
+    assert ct.isCorrect() and ct.bitCapacity() == int(c0)
+    assert abs(c0 - (ct.logOfPrimeSet() - ct.lnNoise) / math.log(2)) < 1e-9
+    ct.multiplyBy(sk.Encrypt(msg))
+    assert ct.isCorrect() and ct.capacity() < c0                       # a level was spent
+    ct.lnNoise = ct.logOfPrimeSet()                                    # noise as large as the modulus
+    assert not ct.isCorrect()
+    assert hc.polyNormBnd(32768) == 1.0 and abs(hc.polyNormBnd(2 * 9) - 2 / math.tan(math.pi / 6) / 3) < 1e-12
+    with pytest.raises(NotImplementedError):
+        hc.polyNormBnd(105)
+    # Frobenius: X -> X^(p^j); ord(257) in Z_128^* is 2 (257 = 1 mod 128 -> order 1: identity)
+    cc2, octx2, be2, sk2 = setup(128, 7, 300)
+    hk.addFrbMatrices(sk2)
+    m7 = rng.integers(0, 7, size=cc2.phim)
+    c7 = sk2.Encrypt(m7)
+    c7.frobeniusAutomorph(1)
+    assert sk2.Decrypt(c7) == [int(v) for v in B.automorph_mod_phi([int(v) for v in m7], 128, 7, 7)]
+    d = hk._zmstar(sk2).ordP
+    c7.frobeniusAutomorph(d - 1)                                       # back to the start: p^d = 1
+    assert sk2.Decrypt(c7) == [int(v) for v in m7]
+    # CKKS: capacity counts the scaled plaintext as well (totalNoiseBound)
+    ck, _, _, skc = setup_ckks(128, 20, 250)
+    c = skc.CKKSencrypt(np.zeros(ck.phim, dtype=np.int64) + 5, 1.0, float(1 << 20))
+    assert c.lnTotalNoiseBound() > c.lnNoise and c.capacity() < (c.logOfPrimeSet() - c.lnNoise) / math.log(2)
