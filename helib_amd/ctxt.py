@@ -999,6 +999,54 @@ class Ctxt:
         self.lnNoise = self.lnNoise + _ln(size)
         return self
 
+    def multByConstantCKKS(self, dcrt, size, factor, roundingErr):
+        """Ctxt::multByConstantCKKS(const DoubleCRT&, size, factor, roundingErr) (src/Ctxt.cpp:1905-
+        1938): dcrt encodes a constant of magnitude <= size scaled by `factor` with encoding error
+        <= roundingErr (the reference takes absent values from EncryptedArrayCx, which is out of
+        scope here: they are arguments).  noise' = noise*factor*size + roundingErr*ratFactor*ptxtMag +
+        noise*roundingErr; ptxtMag *= size; ratFactor *= factor."""
+        if not self.parts:
+            return self
+        if size <= 0:
+            size = 1.0
+        if factor <= 0 or roundingErr < 0:
+            raise ValueError("factor and roundingErr are the encoder's: pass them")
+        n = self.lnNoise
+        self.lnNoise = logaddexp(logaddexp(n + math.log(factor) + math.log(size),
+                                           _ln(roundingErr) + self.lnRatFactor + _ln(self.ptxtMag)),
+                                 n + _ln(roundingErr))
+        self.ptxtMag *= size
+        self.lnRatFactor += math.log(factor)
+        for p in self.parts.values():
+            p *= dcrt
+        return self
+
+    def addConstantCKKS(self, dcrt, size, factor):
+        """Ctxt::addConstantCKKS(const DoubleCRT&, size, factor) (src/Ctxt.cpp:951-1045): the constant
+        (scaled by `factor`) is multiplied by round(ratFactor / factor) and added to the part of 1;
+        ptxtMag += size, noiseBound += 0.5.  The reference mod-switches up (addSomePrimes) when the
+        rounded ratio is off by more than 2^-precision; here that case is an error."""
+        if size <= 0:
+            size = 1.0
+        if factor <= 0:
+            raise ValueError("factor is the encoder's: pass it")
+        x = math.exp(self.lnRatFactor - math.log(factor))
+        ratio = int(math.floor(x + 0.5))
+        if ratio < 1 or abs(ratio / x - 1.0) * (1 << self.context.r) > 1.0:
+            raise RuntimeError("addConstantCKKS: ratFactor / factor is too far from an integer "
+                               "(the reference would call addSomePrimes here)")
+        self.ptxtMag += size
+        self.lnNoise = logaddexp(self.lnNoise, math.log(0.5))
+        if "1" not in self.parts:
+            raise RuntimeError("Ctxt::addPart: no part pointing at 1")
+        if ratio == 1:
+            self.parts["1"] += dcrt
+        else:
+            tmp = dcrt.copy()
+            tmp.mulConstant(ratio)
+            self.parts["1"] += tmp
+        return self
+
     def addConstant(self, dcrt, size=-1.0):
         """Ctxt::addConstant(const DoubleCRT&, double size) (src/Ctxt.cpp:896-935), BGV: the
         constant is scaled by f = balRem(intFactor * Q mod ptxtSpace) and added to the part of 1."""

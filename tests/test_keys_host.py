@@ -665,3 +665,34 @@ def test_capacity_isCorrect_frobenius():
     ck, _, _, skc = setup_ckks(128, 20, 250)
     c = skc.CKKSencrypt(np.zeros(ck.phim, dtype=np.int64) + 5, 1.0, float(1 << 20))
     assert c.lnTotalNoiseBound() > c.lnNoise and c.capacity() < (c.logOfPrimeSet() - c.lnNoise) / math.log(2)
+
+
+def test_ckks_constants():
+    """multByConstantCKKS / addConstantCKKS (src/Ctxt.cpp:1905-1938, 951-1045): an encrypted real
+    polynomial times a plaintext one, plus another, decoded within the reported bound."""
+    cc, octx, be, sk = setup_ckks(128, 20, 250)
+    rng = np.random.default_rng(61)
+    n = cc.phim
+    a, b, c = (rng.uniform(-1, 1, n) / n for _ in range(3))
+    f = float(1 << 20)
+    allp = list(cc.ctxtPrimes) + list(cc.specialPrimes)
+    enc = lambda v: be.fromCoeffs(allp, np.rint(v * f).astype(np.int64))     # noqa: E731
+    ra, rb, rc = (np.rint(v * f) / f for v in (a, b, c))
+    ct = sk.CKKSencrypt(np.rint(a * f).astype(np.int64), 1.0, f)
+    r0 = ct.lnRatFactor
+    ct.multByConstantCKKS(enc(b), 1.0, f, 0.5 * math.sqrt(n))
+    assert abs(ct.lnRatFactor - (r0 + math.log(f))) < 1e-12 and ct.ptxtMag == 1.0
+    dec = lambda t: np.array([float(v) for v in sk.Decrypt(t)]) / math.exp(t.lnRatFactor)   # noqa: E731
+    err = be.embeddingLargestCoeff((dec(ct) - negacyclic(ra, rb)) * math.exp(ct.lnRatFactor))
+    assert math.log(err) <= ct.lnNoise
+    assert np.max(np.abs(dec(ct) - negacyclic(a, b))) < 2.0 ** -14 / n
+    # + c: the ciphertext's factor is an integer multiple of f (ef * f * f), so the ratio is exact
+    ct.addConstantCKKS(enc(c), 1.0, f)
+    assert ct.ptxtMag == 2.0
+    got = dec(ct)
+    assert np.max(np.abs(got - (negacyclic(ra, rb) + rc))) <= math.exp(ct.lnNoise - ct.lnRatFactor)
+    assert np.max(np.abs(got - (negacyclic(a, b) + c))) < 2.0 ** -14
+    with pytest.raises(ValueError):
+        ct.multByConstantCKKS(enc(b), 1.0, 0.0, 0.5)
+    with pytest.raises(RuntimeError):
+        ct.addConstantCKKS(enc(c), 1.0, math.exp(ct.lnRatFactor) / 2.5)   # ratio 2.5: not an integer
