@@ -999,6 +999,56 @@ class Ctxt:
         self.lnNoise = self.lnNoise + _ln(size)
         return self
 
+    def multByScalar(self, c):
+        """Ctxt::multByConstant(const ZZ& / long / double / xdouble) (src/Ctxt.cpp:2033-2110).
+        BGV: c mod ptxtSpace = c1 * d with d = gcd(c, ptxtSpace); the ciphertext is multiplied by the
+        balanced d only and the unit c1 goes into intFactor (its inverse).  CKKS: no polynomial work
+        at all -- ptxtMag *= |c|, ratFactor /= |c|, a sign flips the parts."""
+        if not self.parts:
+            return self
+        if self.context.ckks:
+            c = float(c)
+            if c == 1.0:
+                return self
+            if c == 0.0:
+                self.parts = {}
+                return self
+            self.ptxtMag *= abs(c)
+            self.lnRatFactor -= math.log(abs(c))
+            if c < 0:
+                self.negate()
+            return self
+        if isinstance(c, float):
+            raise TypeError("multByConstant(double) not supported for BGV")     # LogicError in the reference
+        P = self.ptxtSpace
+        c0 = int(c) % P
+        if c0 == 1:
+            return self
+        if c0 == 0:
+            self.parts = {}
+            return self
+        d = math.gcd(c0, P)
+        self.intFactor = self.intFactor * pow(c0 // d, -1, P) % P
+        if d == 1:
+            return self
+        cc = d - P if d > P // 2 else d
+        self.lnNoise = self.lnNoise + math.log(abs(cc))
+        for p in self.parts.values():
+            p.mulConstant(cc)
+        return self
+
+    def __iadd__(self, other):       # Ctxt::operator+=
+        self.addCtxt(other)
+        return self
+
+    def __isub__(self, other):       # Ctxt::operator-=
+        self.addCtxt(other, negative=True)
+        return self
+
+    def __imul__(self, other):       # Ctxt::operator*= (ciphertext): multiplyBy
+        self.multiplyBy(other)
+        return self
+
     def multByConstantCKKS(self, dcrt, size, factor, roundingErr):
         """Ctxt::multByConstantCKKS(const DoubleCRT&, size, factor, roundingErr) (src/Ctxt.cpp:1905-
         1938): dcrt encodes a constant of magnitude <= size scaled by `factor` with encoding error

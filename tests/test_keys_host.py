@@ -696,3 +696,44 @@ def test_ckks_constants():
         ct.multByConstantCKKS(enc(b), 1.0, 0.0, 0.5)
     with pytest.raises(RuntimeError):
         ct.addConstantCKKS(enc(c), 1.0, math.exp(ct.lnRatFactor) / 2.5)   # ratio 2.5: not an integer
+
+
+def test_scalar_constants_and_operators():
+    """Ctxt::multByConstant with an integer (BGV: units go to intFactor, only gcd(c, p^r) touches the
+    polynomials) and a real (CKKS: bookkeeping only); operator sugar += -= *=."""
+    cc = hc.ChainContext(64, 3, 2, bits=250, c=3)           # ptxtSpace 9: non-units exist
+    octx = O.Ctx(64)
+    for q in cc.primes:
+        octx.add_prime(q)
+    be = OracleBackend(octx, cc)
+    sk = hk.SecKey(cc, be, 5)
+    sk.GenSecKey()
+    rng = np.random.default_rng(71)
+    msg = rng.integers(0, 9, size=cc.phim)
+    for c in (2, 3, 6, 7, -1, 10, 9 * 5 + 4):
+        ct = sk.Encrypt(msg)
+        rows = ct.parts["1"].download().copy()
+        ct.multByScalar(c)
+        assert sk.Decrypt(ct) == [int(v) * c % 9 for v in msg], c
+        if math.gcd(c % 9, 9) == 1:                         # a unit: the polynomials are untouched
+            assert np.array_equal(ct.parts["1"].download(), rows) and ct.intFactor == pow(c % 9, -1, 9)
+    z = sk.Encrypt(msg)
+    z.multByScalar(18)
+    assert z.parts == {}
+    with pytest.raises(TypeError):
+        sk.Encrypt(msg).multByScalar(2.5)
+    a, b = sk.Encrypt(msg), sk.Encrypt(msg)
+    a += b
+    a -= sk.Encrypt(msg)
+    a *= b
+    assert sk.Decrypt(a) == [int(v) for v in B.polymul_mod_phi(msg, msg, 64, 9)]
+    # CKKS
+    ck, _, bek, skc = setup_ckks(128, 20, 250)
+    v = rng.uniform(-1, 1, ck.phim) / ck.phim
+    f = float(1 << 20)
+    ct = skc.CKKSencrypt(np.rint(v * f).astype(np.int64), 1.0, f)
+    rows = ct.parts["1"].download().copy()
+    ct.multByScalar(-2.5)
+    assert ct.ptxtMag == 2.5 and not np.array_equal(ct.parts["1"].download(), rows)      # negated only
+    got = np.array([float(x) for x in skc.Decrypt(ct)]) / math.exp(ct.lnRatFactor)
+    assert np.max(np.abs(got - (-2.5) * v)) < 2.0 ** -17
