@@ -72,13 +72,26 @@ def test_no_cpu_fallback_without_device():
 
 
 def test_product_does_not_import_oracle():
-    pkg = os.path.join(ROOT, "helib_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".h", ".hip", ".cpp")):
-                txt = open(os.path.join(dirpath, f)).read()
-                assert "import oracle" not in txt and "from oracle" not in txt, f
-                assert "hx_oracle" not in txt, f
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's
+    cpu_baseline leg may touch it -- not the package, not the C/C++ headers, not the tools."""
+    for sub in ("helib_amd", "include", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".sh")):
+                    txt = open(os.path.join(dirpath, f)).read()
+                    assert "import oracle" not in txt and "from oracle" not in txt, f
+                    assert "hx_oracle" not in txt and "liboracle" not in txt, f
+    # bench.py: the oracle appears only inside the cpu_baseline functions
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef):
+            body = ast.get_source_segment(src, node)
+            uses = any(k in body for k in ("from oracle", "import oracle", "build_native_oracle()", "hx_oracle",
+                                            "cpu_baseline_fresh(", "cpu_baseline_fixed("))
+            if uses and node.name != "main":       # main() only calls the cpu_baseline functions
+                assert node.name in ("build_native_oracle", "cpu_baseline_fixed", "cpu_baseline_fresh",
+                                     "cpu_baseline_all_cores"), node.name
 
 
 def test_hostnt_matches_oracle():
