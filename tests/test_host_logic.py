@@ -133,7 +133,8 @@ def test_cpp_facade_header_compiles_and_links():
 
 
 @pytest.mark.parametrize("m,p,bits", [(32768, 65537, 950), (16384, 65537, 250), (128, 257, 150), (1705, 7, 200),
-                                      (32768, 2, 300), (65536, -1, 1400), (128, -1, 250)])
+                                      (32768, 2, 300), (65536, -1, 1400), (128, -1, 250), (65536, -1, 440),
+                                      (16384, -1, 300)])
 def test_cpp_host_chain_and_prime_set_decision_match_the_python_mirror(m, p, bits, tmp_path):
     """include/helib_amd_ctxt.hpp (C++ host side: PrimeGenerator, buildModChain, ModuliSizes,
     computeIntervalForMul) against helib_amd/ctxt.py: same primes, digits, table size and the same
