@@ -912,6 +912,31 @@ class Ctxt:
         """Ctxt::cube: multiplyBy2(*this, *this)"""
         self.multiplyBy2(self.clone(), self.clone())
 
+    def power(self, e):
+        """Ctxt::power (src/polyEval.cpp:392-414): repeated squaring for a power of two, otherwise
+        DynamicCtxtPowers (:18-29): X^e = X^(e-k) * X^k with k the largest power of two below e, every
+        power computed once -- the multiplication depth stays at ceil(log2 e)."""
+        if e < 1:
+            raise ValueError("Cannot raise a ctxt to a non positive exponent")
+        if e == 1:
+            return self
+        if e & (e - 1) == 0:
+            for _ in range(e.bit_length() - 1):
+                self.square()
+            return self
+        powers = {1: self.clone()}
+
+        def get(n):
+            if n not in powers:
+                k = 1 << ((n - 1).bit_length() - 1)      # NextPowerOfTwo(n) - 1
+                c = get(n - k).clone()
+                c.multiplyBy(get(k))
+                powers[n] = c
+            return powers[n]
+        r = get(e)
+        self.__dict__.update(r.__dict__)
+        return self
+
     def _relin_CKKS_adjust(self):
         """Ctxt::relin_CKKS_adjust (src/Ctxt.cpp:664-717): if the noise is below what the special
         primes were sized for, scale the ciphertext (and its factor) up by an integer."""

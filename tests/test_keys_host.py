@@ -737,3 +737,24 @@ def test_scalar_constants_and_operators():
     assert ct.ptxtMag == 2.5 and not np.array_equal(ct.parts["1"].download(), rows)      # negated only
     got = np.array([float(x) for x in skc.Decrypt(ct)]) / math.exp(ct.lnRatFactor)
     assert np.max(np.abs(got - (-2.5) * v)) < 2.0 ** -17
+
+
+@pytest.mark.parametrize("e", [1, 2, 3, 4, 5, 7, 8])
+def test_power(e):
+    """Ctxt::power: x^e at multiplication depth ceil(log2 e) (DynamicCtxtPowers for e not a power of two)"""
+    m, p = 64, 65537
+    cc, octx, be, sk = setup(m, p, 600)
+    rng = np.random.default_rng(81)
+    msg = rng.integers(0, p, size=cc.phim)
+    want = [int(v) for v in msg]
+    for _ in range(e - 1):
+        want = [int(v) for v in B.polymul_mod_phi(want, msg, m, p)]
+    ct = sk.Encrypt(msg)
+    c0 = ct.capacity()
+    ct.power(e)
+    assert sk.Decrypt(ct) == want and ct.isCorrect()
+    if e > 1:
+        depth = (e - 1).bit_length()
+        assert c0 - ct.capacity() < (depth + 0.5) * 62        # about one 60-bit prime per level
+    with pytest.raises(ValueError):
+        ct.power(0)
