@@ -54,7 +54,7 @@ SYMBOLS = [
     "hx_intel_FFTFwd", "hx_intel_FFTRev1", "hx_intel_EltwiseAddMod", "hx_intel_EltwiseAddModScalar",
     "hx_intel_EltwiseSubMod", "hx_intel_EltwiseSubModScalar", "hx_intel_EltwiseMultMod",
     "hx_intel_EltwiseMultModScalar",
-    "hx_time_ntt",
+    "hx_time_ntt", "hx_ctx_timer_begin", "hx_ctx_timer_end",
 ]
 
 
@@ -132,6 +132,7 @@ def lib():
             "hx_intel_EltwiseSubModScalar": [vp, vp, C.c_long, C.c_long, C.c_long],
             "hx_intel_EltwiseMultModScalar": [vp, vp, C.c_long, C.c_long, C.c_long],
             "hx_time_ntt": [vp, ip, ip, ip, vp],
+            "hx_ctx_timer_begin": [vp], "hx_ctx_timer_end": [vp, vp],
         }
         for name, args in sig.items():
             f = getattr(L, name)
@@ -199,6 +200,16 @@ class Context:
 
     def set_stream(self, stream_ptr):
         _chk(lib().hx_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def timerBegin(self):
+        """HIP event on this context's stream (hx_ctx_timer_begin)."""
+        _chk(lib().hx_ctx_timer_begin(self.h))
+
+    def timerEnd(self):
+        """Milliseconds of device time since timerBegin (waits for the closing event)."""
+        ms = C.c_float()
+        _chk(lib().hx_ctx_timer_end(self.h, C.byref(ms)))
+        return ms.value
 
     def deferNorms(self, on):
         """Deferred read-back of the measured-noise norms (hx_ctx_defer_norms)."""

@@ -188,6 +188,7 @@ struct hx_ctx {
   };
   bool defer_norms = false;
   std::vector<NormPending> norm_pending, norm_free;
+  hipEvent_t timer[2] = {nullptr, nullptr};  // hx_ctx_timer_begin / _end
 };
 
 struct hx_poly {
@@ -396,6 +397,9 @@ static void ctx_free(hx_ctx* c)
   }
   if (c->d_cprimes)
     hipFree(c->d_cprimes);
+  for (hipEvent_t e : c->timer)
+    if (e)
+      hipEventDestroy(e);
   hipFree(c->d_zms);
   hipFree(c->d_zms_index);
   hipFree(c->d_perm);
@@ -1429,6 +1433,34 @@ extern "C" int hx_time_ntt(hx_poly* p, int dir, int iters, int max_rows, float* 
   *avg_ms = ms / iters;
   hipEventDestroy(e0);
   hipEventDestroy(e1);
+  return HX_OK;
+}
+
+// HIP events on the context's own stream around whatever the caller enqueues in between (the
+// bench times a launch set such as one hx_bring_to_set_multi this way; torch.cuda.Event would see
+// torch's current stream only).
+extern "C" int hx_ctx_timer_begin(hx_ctx* c)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null context");
+  CTX_ENTER(c);
+  if (!c->timer[0]) {
+    HIPCHK(hipEventCreate(&c->timer[0]));
+    HIPCHK(hipEventCreate(&c->timer[1]));
+  }
+  HIPCHK(hipEventRecord(c->timer[0], c->stream));
+  return HX_OK;
+}
+extern "C" int hx_ctx_timer_end(hx_ctx* c, float* ms)
+{
+  if (!c || !ms)
+    return fail(HX_ERR_INVALID, "bad argument");
+  CTX_ENTER(c);
+  if (!c->timer[0])
+    return fail(HX_ERR_INVALID, "hx_ctx_timer_end without hx_ctx_timer_begin");
+  HIPCHK(hipEventRecord(c->timer[1], c->stream));
+  HIPCHK(hipEventSynchronize(c->timer[1]));
+  HIPCHK(hipEventElapsedTime(ms, c->timer[0], c->timer[1]));
   return HX_OK;
 }
 

@@ -109,17 +109,60 @@ HXD QC make_qc(uint64_t q) { return make_qc(q, ~(uint64_t)0 / q); }
 // middle products' low halves are dropped), h - 2 <= h' <= h, so r' = r + (h-h') q < 4q; all of
 // it modulo 2^64, which is exact because r' < 2^62.  -h' q is accumulated as + h' * (2^64 - q)
 // so that the low 64 bits form one multiply-add chain.
-HXD uint64_t shoup4(uint64_t y, TW t, uint64_t nq)
+//
+// Device form (shoup4_acc): x + y*w - h'q for a 64-bit addend x, everything as v_mad_u64_u32
+// chains.  On gfx950 a v_mad_u64_u32 issues in 5.05 cycles per wave64 against 9.12 for
+// v_mul_hi_u32 and 5.33 + an add for v_mul_lo_u32 (profiles/r01_imul_issue_rates.txt), and its
+// 64-bit addend is free: the two high halves come from full products, the four cross products
+// of the low 64 bits are one accumulation chain whose low word is all that is used, and the
+// butterfly's x + T rides on the chain's first addend.  The empty asm statements keep the
+// compiler from narrowing the chains back into v_mul_hi / v_mul_lo + add.  Same h', same value.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_SHOUP4_OLD)
+#define HX_KEEP64(x) asm("" : "+v"(x))
+#else
+#define HX_KEEP64(x) ((void)0)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint64_t mad_x1(uint32_t a, uint64_t c)  // c + a
+{
+  uint64_t d, cy;
+  asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(cy) : "v"(a), "v"(c));
+  return d;
+}
+#endif
+HXD uint64_t shoup4_acc(uint64_t y, TW t, uint64_t nq, uint64_t x)
 {
   const uint32_t yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
   const uint32_t pl = (uint32_t)t.wp, ph = (uint32_t)(t.wp >> 32);
   const uint32_t wl = (uint32_t)t.w, wh = (uint32_t)(t.w >> 32);
   const uint32_t nl = (uint32_t)nq, nh = (uint32_t)(nq >> 32);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_SHOUP4_OLD)
+  uint64_t A = (uint64_t)yh * pl, B = (uint64_t)yl * ph;
+  HX_KEEP64(A);
+  HX_KEEP64(B);
+  // + hi32(A) + hi32(B) as multiply-adds by 1: a 32-bit value enters a 64-bit sum without a
+  // (value, 0) register pair having to be built for it (two v_mov each otherwise)
+  uint64_t h = (uint64_t)yh * ph;
+  h = mad_x1((uint32_t)(A >> 32), h);
+  h = mad_x1((uint32_t)(B >> 32), h);
+  const uint32_t hl = (uint32_t)h, hh = (uint32_t)(h >> 32);
+  uint64_t u = (uint64_t)yl * wh;
+  u += (uint64_t)yh * wl;
+  u += (uint64_t)hl * nh;
+  u += (uint64_t)hh * nl;
+  HX_KEEP64(u);
+  uint64_t acc = (uint64_t)yl * wl + x;
+  acc += (uint64_t)hl * nl;
+  const uint32_t al = (uint32_t)acc, ah = (uint32_t)(acc >> 32);
+  uint32_t rh;
+  asm("v_add_u32 %0, %1, %2" : "=v"(rh) : "v"(ah), "v"((uint32_t)u));
+  return ((uint64_t)rh << 32) | al;
+#else
   const uint32_t a1 = mulhi32(yh, pl), b1 = mulhi32(yl, ph);
   const uint64_t h = (uint64_t)yh * ph + a1 + b1;
   const uint32_t hl = (uint32_t)h, hh = (uint32_t)(h >> 32);
   const uint32_t t0 = yl * wh + yh * wl + hl * nh + hh * nl;
-  uint64_t acc = (uint64_t)yl * wl;
+  uint64_t acc = (uint64_t)yl * wl + x;
   acc += (uint64_t)hl * nl;
   const uint32_t al = (uint32_t)acc, ah = (uint32_t)(acc >> 32);
   uint32_t rh;
@@ -130,7 +173,9 @@ HXD uint64_t shoup4(uint64_t y, TW t, uint64_t nq)
   rh = ah + t0;
 #endif
   return ((uint64_t)rh << 32) | al;
+#endif
 }
+HXD uint64_t shoup4(uint64_t y, TW t, uint64_t nq) { return shoup4_acc(y, t, nq, 0); }
 // x in [0, 2m) -> [0, m)
 HXD uint64_t csub(uint64_t x, uint64_t m)
 {
@@ -240,9 +285,20 @@ HXD void ct_bfly4(uint64_t& X, uint64_t& Y, TW t, const QC& c)
   uint64_t x = X;
   if constexpr (CORR)
     x = csub(x, c.q8);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_SHOUP4_OLD)
+  // X' rides on the multiply-add chain; Y' = x + 4q - T = (2x + 4q) - X' (one v_lshl_add_u64 and
+  // one 64-bit subtraction; the intermediate may wrap, the value x + 4q - T < 16q does not)
+  uint64_t xn = shoup4_acc(Y, t, c.nq, x);
+  HX_KEEP64(xn);  // (opaque: otherwise the subtraction below is distributed over xn's halves)
+  X = xn;
+  uint64_t x2 = (x << 1) + c.q4;
+  HX_KEEP64(x2);
+  Y = x2 - xn;
+#else
   const uint64_t v = shoup4(Y, t, c.nq);
   X = x + v;
   Y = x + c.q4 - v;
+#endif
 }
 constexpr int fwd_bound_in(int bin, int sp)  // bound of the values entering stage sp of a pass
 {
@@ -491,15 +547,85 @@ HXD unsigned bc_addr_C(unsigned tid, int i)  // i = gi*GC + e'
   return (tid + (unsigned)T * gi) + 1024u * ep;
 }
 
-// LDS read that the compiler may not fuse with a neighbour into a ds_read2: the two results of
-// a fused read land in one register pair although they are halves of two DIFFERENT 64-bit
-// coefficients, and un-pairing them costs a v_mov per word plus the registers to hold both
-// copies (the inverse kernels spilled on exactly that).
-#ifndef HX_LDS_RD_PLAIN
-HXD uint32_t lds_rd(const uint32_t* lds, unsigned a) { return *(const volatile uint32_t*)(lds + a); }
+// LDS reads of the two transposes.  Each of the 32 words a thread reads goes into its own
+// register (the low or high half of one 64-bit coefficient); a compiler-fused ds_read2 would
+// deliver halves of two DIFFERENT coefficients in one register pair and un-pairing them costs a
+// v_mov per word plus the registers to hold both copies (the inverse kernels spilled on exactly
+// that).  Round 1 prevented the fusion with a `volatile` read -- which the compiler cannot prove
+// to be an LDS access (address-space inference skips volatile), so it became a system-scope
+// flat_load_dword followed by s_waitcnt vmcnt(0), 128 fully serialised round trips per thread.
+// Now: 32 explicit ds_read_b32 (one base VGPR per 64 KiB of LDS, the per-element part in the
+// 16-bit immediate offset) in flight together, one s_waitcnt.  `Cst(e)` = word offset of element
+// e relative to element 0's word `base`, a constexpr function of e only.
+template <class Cst, int E>
+struct LdsOff {
+  static constexpr unsigned bytes = Cst::at(E) * 4u;
+  static constexpr unsigned chunk = bytes >> 16, imm = bytes & 0xffffu;
+};
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_LDS_RD_PLAIN)
+template <int OFF>
+__device__ __forceinline__ uint32_t ds_rd_b32(unsigned a)
+{
+  uint32_t x;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(x) : "v"(a), "n"(OFF) : "memory");
+  return x;
+}
+template <class Cst>
+HXD void lds_read32(const uint32_t* lds, unsigned base, uint32_t (&o)[32])
+{
+  // low 32 bits of a generic (flat) pointer into the LDS aperture = the LDS byte address
+  const unsigned a0 = (unsigned)(uintptr_t)lds + base * 4u;
+  const unsigned a1 = a0 + 0x10000u, a2 = a0 + 0x20000u;
+  static_for<0, 32>([&](auto I) {
+    constexpr int e = decltype(I)::value;
+    using O = LdsOff<Cst, e>;
+    static_assert(O::chunk <= 2, "LDS offset");
+    o[e] = ds_rd_b32<(int)O::imm>(O::chunk == 0 ? a0 : (O::chunk == 1 ? a1 : a2));
+  });
+  // the results exist only after the wait: every consumer is made to depend on it (two asm
+  // statements because one takes at most 30 operands; volatile asms keep their order)
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]),
+                 "+v"(o[7]), "+v"(o[8]), "+v"(o[9]), "+v"(o[10]), "+v"(o[11]), "+v"(o[12]),
+                 "+v"(o[13]), "+v"(o[14]), "+v"(o[15])
+               :
+               : "memory");
+  asm volatile(""
+               : "+v"(o[16]), "+v"(o[17]), "+v"(o[18]), "+v"(o[19]), "+v"(o[20]), "+v"(o[21]),
+                 "+v"(o[22]), "+v"(o[23]), "+v"(o[24]), "+v"(o[25]), "+v"(o[26]), "+v"(o[27]),
+                 "+v"(o[28]), "+v"(o[29]), "+v"(o[30]), "+v"(o[31])
+               :
+               : "memory");
+}
 #else
-HXD uint32_t lds_rd(const uint32_t* lds, unsigned a) { return lds[a]; }
+template <class Cst>
+HXD void lds_read32(const uint32_t* lds, unsigned base, uint32_t (&o)[32])
+{
+  for (int e = 0; e < 32; e++)
+    o[e] = lds[base + Cst::at(e)];
+}
 #endif
+// element-e word offsets of the four read patterns relative to element 0 (cf. the *_addr_*
+// functions above: each is base(tid) + a function of e alone)
+template <int LOGN>
+struct CstAbB {  // ab_addr_B(tid, e) - ab_addr_B(tid, 0)
+  static constexpr unsigned at(int e) { return 33u * ((unsigned)e << Geo<LOGN>::LC); }
+};
+template <int LOGN>
+struct CstBcC {  // bc_addr_C(tid, i) - bc_addr_C(tid, 0)
+  static constexpr unsigned at(int i)
+  {
+    return (unsigned)Geo<LOGN>::T * ((unsigned)i >> Geo<LOGN>::LC) + 1024u * ((unsigned)i & ((1u << Geo<LOGN>::LC) - 1u));
+  }
+};
+template <int LOGN>
+struct CstBcB {  // bc_addr_B(tid, e) - bc_addr_B(tid, 0)
+  static constexpr unsigned at(int e) { return 32u * brev_bits((unsigned)e, 5); }
+};
+template <int LOGN>
+struct CstAbA {  // ab_addr_A(tid, e) - ab_addr_A(tid, 0)
+  static constexpr unsigned at(int e) { return brev_bits((unsigned)e, 5); }
+};
 HXD uint32_t half_of(uint64_t x, int half) { return half ? (uint32_t)(x >> 32) : (uint32_t)x; }
 HXD void set_half(uint64_t& x, int half, uint32_t w)
 {
@@ -625,17 +751,17 @@ struct RowNTT {
       for (int e = 0; e < 32; e++)
         lds[ab_addr_A<LOGN>(tid, e)] = half_of(v[e], 0);
     } else if constexpr (PH == 1) {
-#pragma unroll
-      for (int e = 0; e < 32; e++)
-        nl[e] = lds_rd(lds, ab_addr_B<LOGN>(tid, e));
+      lds_read32<CstAbB<LOGN>>(lds, ab_addr_B<LOGN>(tid, 0), nl);
     } else if constexpr (PH == 2) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
         lds[ab_addr_A<LOGN>(tid, e)] = half_of(v[e], 1);
     } else if constexpr (PH == 3) {
+      uint32_t nh[32];
+      lds_read32<CstAbB<LOGN>>(lds, ab_addr_B<LOGN>(tid, 0), nh);
 #pragma unroll
       for (int e = 0; e < 32; e++)
-        v[e] = ((uint64_t)lds_rd(lds, ab_addr_B<LOGN>(tid, e)) << 32) | nl[e];
+        v[e] = ((uint64_t)nh[e] << 32) | nl[e];
       run_pass<5, false, 1, 31, FA>(v, c, [&](int, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWB, tid & 31u, ((1u << sp) - 1u + (unsigned)k) * 32u, dep);
       });
@@ -644,17 +770,17 @@ struct RowNTT {
       for (int e = 0; e < 32; e++)
         lds[bc_addr_B<LOGN>(tid, e)] = half_of(v[e], 0);
     } else if constexpr (PH == 5) {
-#pragma unroll
-      for (int i = 0; i < 32; i++)
-        nl[i] = lds_rd(lds, bc_addr_C<LOGN>(tid, i));
+      lds_read32<CstBcC<LOGN>>(lds, bc_addr_C<LOGN>(tid, 0), nl);
     } else if constexpr (PH == 6) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
         lds[bc_addr_B<LOGN>(tid, e)] = half_of(v[e], 1);
     } else if constexpr (PH == 7) {
+      uint32_t nh[32];
+      lds_read32<CstBcC<LOGN>>(lds, bc_addr_C<LOGN>(tid, 0), nh);
 #pragma unroll
       for (int i = 0; i < 32; i++)
-        v[i] = ((uint64_t)lds_rd(lds, bc_addr_C<LOGN>(tid, i)) << 32) | nl[i];
+        v[i] = ((uint64_t)nh[i] << 32) | nl[i];
       run_pass<G::LC, false, G::NGC, G::GC - 1, FB>(v, c, [&](int gi, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWC, tid, ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi), dep);
       });
@@ -697,17 +823,17 @@ struct RowNTT {
       for (int i = 0; i < 32; i++)
         lds[bc_addr_C<LOGN>(tid, i)] = half_of(v[i], 0);
     } else if constexpr (PH == 1) {
-#pragma unroll
-      for (int e = 0; e < 32; e++)
-        nl[e] = lds_rd(lds, bc_addr_B<LOGN>(tid, e));
+      lds_read32<CstBcB<LOGN>>(lds, bc_addr_B<LOGN>(tid, 0), nl);
     } else if constexpr (PH == 2) {
 #pragma unroll
       for (int i = 0; i < 32; i++)
         lds[bc_addr_C<LOGN>(tid, i)] = half_of(v[i], 1);
     } else if constexpr (PH == 3) {
+      uint32_t nh[32];
+      lds_read32<CstBcB<LOGN>>(lds, bc_addr_B<LOGN>(tid, 0), nh);
 #pragma unroll
       for (int e = 0; e < 32; e++)
-        v[e] = ((uint64_t)lds_rd(lds, bc_addr_B<LOGN>(tid, e)) << 32) | nl[e];
+        v[e] = ((uint64_t)nh[e] << 32) | nl[e];
       run_pass<5, true, 1, 31, IC_>(v, c, [&](int, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWB, tid & 31u, ((1u << sp) - 1u + (unsigned)k) * 32u, dep);
       });
@@ -716,17 +842,17 @@ struct RowNTT {
       for (int e = 0; e < 32; e++)
         lds[ab_addr_B<LOGN>(tid, e)] = half_of(v[e], 0);
     } else if constexpr (PH == 5) {
-#pragma unroll
-      for (int e = 0; e < 32; e++)
-        nl[e] = lds_rd(lds, ab_addr_A<LOGN>(tid, e));
+      lds_read32<CstAbA<LOGN>>(lds, ab_addr_A<LOGN>(tid, 0), nl);
     } else if constexpr (PH == 6) {
 #pragma unroll
       for (int e = 0; e < 32; e++)
         lds[ab_addr_B<LOGN>(tid, e)] = half_of(v[e], 1);
     } else if constexpr (PH == 7) {
+      uint32_t nh[32];
+      lds_read32<CstAbA<LOGN>>(lds, ab_addr_A<LOGN>(tid, 0), nh);
 #pragma unroll
       for (int e = 0; e < 32; e++)
-        v[e] = ((uint64_t)lds_rd(lds, ab_addr_A<LOGN>(tid, e)) << 32) | nl[e];
+        v[e] = ((uint64_t)nh[e] << 32) | nl[e];
       // stages 4..1 (30 groups), then stage 0 with N^-1 folded in:
       // slot 0 = S0*N^-1, slot 31 = N^-1
       run_pass<5, true, 1, 30, IB>(v, c, [&](int, int sp, int k, uint32_t) {

@@ -265,6 +265,10 @@ int hx_intel_EltwiseMultModScalar(long* r, const long* a, long scalar, long n, l
  * events recorded on the context's stream and returns the average kernel time
  * in milliseconds (bench.py roofline leg). */
 int hx_time_ntt(hx_poly* p, int dir, int iters, int max_rows, float* avg_ms);
+/* HIP events on the context's stream: begin records one, end records the second, waits for it
+ * and returns the elapsed milliseconds of everything enqueued on the context in between. */
+int hx_ctx_timer_begin(hx_ctx* ctx);
+int hx_ctx_timer_end(hx_ctx* ctx, float* ms);
 
 #ifdef __cplusplus
 }

@@ -65,3 +65,31 @@ def test_two_rank_gloo_timing_and_sharding(tmp_path):
     assert outs[0]["total"] == 513 and outs[1]["total"] == 513
     # both ranks report the slow rank's time
     assert abs(outs[0]["dt"] - outs[1]["dt"]) < 1e-9 and outs[0]["dt"] >= 0.09
+
+
+def test_bench_launcher_spawns_ranks_and_aggregates():
+    """`bench.py --gpus N` started as one process spawns N ranks (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set), shards a global batch with helib_amd.dist.shard and prints ONE line with
+    n_gpus = N.  --dry-launch runs exactly that path over gloo with no engine call."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch",
+                          "--global-batch", "513", "--steps", "3"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["dry_launch"] is True and line["scaling"] == "strong"
+    assert line["config"]["pairs_all_ranks"] == 513 and line["config"]["last_rank_start"] == 257
+    # weak scaling: every rank keeps --batch pairs
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch",
+                          "--batch", "64", "--steps", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["pairs_all_ranks"] == 128
+
+
+def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_world():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-launch"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)

@@ -528,6 +528,61 @@ def test_ctxt_multiplyBy_full_sequence_gpu_vs_oracle(hx, m, p, bits, monkeypatch
         assert got == T.decrypt(ctx, P.o, s, oa, rows)
 
 
+@pytest.mark.parametrize("bits,B", [(950, 4)])
+def test_fresh_multiplyBy_at_the_benchmarked_shape_batched(hx, bits, B, monkeypatch):
+    """bench.py's own step, bit-exact: BASELINE configs[2] (m=32768, p=65537, bits=950 -> L=16, K=6,
+    D=3), the FRESH multiplyBy sequence of src/Ctxt.cpp:1681-1774 over a batch of B DISTINCT
+    ciphertext pairs in one set of launches -- hx_bring_to_set_multi at nkeep=16 (the mod-down
+    apply kernel's g=2 row-group tile, csrc/ntt_kernels.hip md_tile) and hx_mul_relin batched.  The
+    oracle runs the same host logic once per batch element; EVERY part, row and batch element is
+    compared, and every element decrypts to its plaintext product."""
+    from helib_amd import ctxt as hc
+    from tests import test_ctxt_host as T
+    from oracle.backend import OKeySwitch, OPoly, OracleOps
+    m, p = 32768, 65537
+    monkeypatch.setattr(hc.Ctxt, "measure", True)
+    ctx = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    assert len(ctx.ctxtPrimes) == 16 and len(ctx.specialPrimes) == 6 and len(ctx.digits) == 3
+    P = Pair(hx, m, ctx.primes)
+    s, allp, kb, ka, rows = T.make_keys(ctx, P.o)
+    rng = np.random.default_rng(40)
+    msgs = rng.integers(0, p, size=(2, B, P.N))
+    enc = [[T.encrypt(ctx, P.o, s, msgs[j, b], 10 * j + b + 1, rows) for b in range(B)] for j in range(2)]
+    oops, oW = OracleOps(P.o), OKeySwitch(allp, kb, ka)
+    outs = []
+    for b in range(B):
+        oa = hc.Ctxt.fresh(ctx, oops, *(OPoly(P.o, ctx.ctxtPrimes, x) for x in enc[0][b]), ksw=oW)
+        ob = hc.Ctxt.fresh(ctx, oops, *(OPoly(P.o, ctx.ctxtPrimes, x) for x in enc[1][b]), ksw=oW)
+        oa.multiplyBy(ob)
+        outs.append(oa)
+    gW = hx.KeySwitch(P.g, allp, kb, ka)
+
+    def batched(j):
+        return [hx.DoubleCRT(P.g, ctx.ctxtPrimes, B, np.stack([enc[j][b][k] for b in range(B)], axis=1))
+                for k in range(2)]
+
+    ga = hc.Ctxt.fresh(ctx, hx, *batched(0), ksw=gW)
+    gb = hc.Ctxt.fresh(ctx, hx, *batched(1), ksw=gW)
+    ga.multiplyBy(gb)
+    # the batch shares one prime-set decision: the estimate is the maximum over its elements
+    assert all(ga.primeSet == o.primeSet and ga.intFactor == o.intFactor for o in outs)
+    on = [o.lnNoise for o in outs]
+    assert max(on) - 1e-6 <= ga.lnNoise <= max(on) + 0.05
+    for h in ("1", "s"):
+        gi = ga.parts[h].getIndexSet()
+        gd = ga.parts[h].download()
+        assert gd.shape[1] == B
+        for b in range(B):
+            oi, od = outs[b].parts[h].getIndexSet(), outs[b].parts[h].download()[:, 0]
+            assert sorted(gi) == sorted(oi)
+            for r, i in enumerate(gi):
+                assert np.array_equal(gd[r, b], od[oi.index(i)]), (h, i, b)
+    for b in range(B):
+        full = np.convolve(msgs[0, b].astype(np.int64), msgs[1, b].astype(np.int64))
+        want = (full[:P.N] - np.append(full[P.N:], 0)) % p
+        assert T.decrypt(ctx, P.o, s, outs[b], rows) == [int(v) for v in want]
+
+
 @pytest.mark.parametrize("ptxt", [65537, 2, 1, 4])
 @pytest.mark.parametrize("m", [16384, 32768])
 def test_scale_down_single_prime_fused_path(hx, m, ptxt):
@@ -866,6 +921,44 @@ def test_multiply_relin_at_the_reference_benchmark_chain_size(hx):
     assert np.array_equal(o0.download()[:, 0], P.o.scale_down(allp, w0, sp, 65537))
 
 
+def test_fresh_multiplyBy_at_the_reference_benchmark_chain_size(hx, monkeypatch):
+    """benchmarks/bgv_basic.cpp:247 (m=32768, p=65537, bits=6400: L=107, K=36, three digits of 36/36/35
+    primes) -- the FRESH Ctxt::multiplyBy sequence (both bringToSet mod-switches, tensorProduct,
+    dropSmallAndSpecialPrimes, reLinearize), not only hx_mul_relin at a fixed level: device vs
+    oracle under the same host logic, every row, and the product decrypts."""
+    from helib_amd import ctxt as hc
+    from tests import test_ctxt_host as T
+    from oracle.backend import OKeySwitch, OPoly, OracleOps
+    m, p = 32768, 65537
+    monkeypatch.setattr(hc.Ctxt, "measure", True)
+    ctx = hc.ChainContext(m, p, 1, bits=6400, c=3)
+    assert len(ctx.ctxtPrimes) == 107 and len(ctx.specialPrimes) == 36
+    P = Pair(hx, m, ctx.primes)
+    s, allp, kb, ka, rows = T.make_keys(ctx, P.o)
+    rng = np.random.default_rng(41)
+    ma, mb = rng.integers(0, p, size=P.N), rng.integers(0, p, size=P.N)
+    ea, eb = T.encrypt(ctx, P.o, s, ma, 1, rows), T.encrypt(ctx, P.o, s, mb, 2, rows)
+    oops, oW = OracleOps(P.o), OKeySwitch(allp, kb, ka)
+    oa = hc.Ctxt.fresh(ctx, oops, *(OPoly(P.o, ctx.ctxtPrimes, x) for x in ea), ksw=oW)
+    ob = hc.Ctxt.fresh(ctx, oops, *(OPoly(P.o, ctx.ctxtPrimes, x) for x in eb), ksw=oW)
+    oa.multiplyBy(ob)
+    gW = hx.KeySwitch(P.g, allp, kb, ka)
+    ga = hc.Ctxt.fresh(ctx, hx, *(hx.DoubleCRT(P.g, ctx.ctxtPrimes, 1, x[:, None, :]) for x in ea), ksw=gW)
+    gb = hc.Ctxt.fresh(ctx, hx, *(hx.DoubleCRT(P.g, ctx.ctxtPrimes, 1, x[:, None, :]) for x in eb), ksw=gW)
+    ga.multiplyBy(gb)
+    assert ga.primeSet == oa.primeSet and ga.intFactor == oa.intFactor
+    assert abs(ga.lnNoise - oa.lnNoise) < 1e-8
+    for h in ("1", "s"):
+        gi, oi = ga.parts[h].getIndexSet(), oa.parts[h].getIndexSet()
+        assert sorted(gi) == sorted(oi)
+        gd, od = ga.parts[h].download()[:, 0], oa.parts[h].download()[:, 0]
+        for r, i in enumerate(gi):
+            assert np.array_equal(gd[r], od[oi.index(i)]), (h, i)
+    full = np.convolve(ma.astype(np.int64), mb.astype(np.int64))
+    want = (full[:P.N] - np.append(full[P.N:], 0)) % p
+    assert T.decrypt(ctx, P.o, s, oa, rows) == [int(v) for v in want]
+
+
 # ---------------------------------------------------------------- SURVEY row N2: keys, encrypt, decrypt
 @pytest.mark.parametrize("m,p,bits", [(16384, 65537, 250), (128, 257, 150), (1705, 7, 200)])
 def test_keys_encrypt_decrypt_gpu_vs_oracle(hx, m, p, bits, monkeypatch):
@@ -934,8 +1027,9 @@ def test_keys_encrypt_decrypt_gpu_vs_oracle(hx, m, p, bits, monkeypatch):
         assert withc == [(int(x) + int(y)) % p for x, y in zip(B.polymul_mod_phi(rot, mb, m, p), mb)]
 
 
-@pytest.mark.parametrize("m,precision,bits", [(16384, 20, 300), (128, 20, 200)])
-def test_ckks_encrypt_multiply_decrypt_gpu_vs_oracle(hx, m, precision, bits, monkeypatch):
+@pytest.mark.parametrize("m,precision,bits,c", [(16384, 20, 300, 2), (128, 20, 200, 2),
+                                                (65536, 20, 1400, 3)])   # BASELINE configs[3]: L=24, K=8, D=3
+def test_ckks_encrypt_multiply_decrypt_gpu_vs_oracle(hx, m, precision, bits, c, monkeypatch):
     """The CKKS chain of the same path (BASELINE configs[3]; PubKey::CKKSencrypt src/keys.cpp:501-581,
     the CKKS branches of computeIntervalForMul / tensorProduct / relin_CKKS_adjust in src/Ctxt.cpp):
     device vs oracle backend from one seed -- identical parts, prime sets and raw decryptions, and
@@ -943,7 +1037,9 @@ def test_ckks_encrypt_multiply_decrypt_gpu_vs_oracle(hx, m, precision, bits, mon
     from helib_amd import ctxt as hc, keys as hk
     from oracle.backend import OracleBackend
     monkeypatch.setattr(hc.Ctxt, "measure", True)
-    cc = hc.ChainContext(m, -1, precision, bits=bits, c=2, ckks=True)
+    cc = hc.ChainContext(m, -1, precision, bits=bits, c=c, ckks=True)
+    if m == 65536:   # the benchmark chain of benchmarks/ckks_basic.cpp at the "~24 primes" of BASELINE
+        assert (len(cc.ctxtPrimes), len(cc.specialPrimes), len(cc.digits)) == (24, 8, 3)
     P = Pair(hx, m, cc.primes)
     gsk = hk.SecKey(cc, hk.HxBackend(P.g, cc), seed=13)
     osk = hk.SecKey(cc, OracleBackend(P.o, cc), seed=13)
@@ -968,8 +1064,10 @@ def test_ckks_encrypt_multiply_decrypt_gpu_vs_oracle(hx, m, precision, bits, mon
 
     same(ga, oa)
     for g, o in ((ga, gb), (oa, ob)):
-        g.multiplyBy(o)
-        g.multiplyBy(g.clone())           # (a*b)^2: the second product is mod-switched first
+        g.multiplyBy(o)                   # level 1: fresh x fresh (no mod-switch; tensor + key switch)
+    same(ga, oa)
+    for g in (ga, oa):
+        g.multiplyBy(g.clone())           # level 2, (a*b)^2: the several-primes mod-down first
     same(ga, oa)
     raw = gsk.Decrypt(ga)
     assert raw == osk.Decrypt(oa)

@@ -4,7 +4,7 @@
 # in-tree build with that environment variable set).  Two rounds each.  BATCH overrides --batch.
 out=gpurun_out/variants.log
 mkdir -p gpurun_out; : > $out
-for round in 1 2; do
+for round in $(seq 1 ${ROUNDS:-2}); do
   for v in "$@"; do
     lib=""; envs=""
     case "$v" in
@@ -12,7 +12,7 @@ for round in 1 2; do
       env:*) envs="${v#env:}" ;;
       *) lib=$PWD/helib_amd/lib/variants/libhelib_amd_$v.so ;;
     esac
-    env $envs HX_LIB=$lib timeout 150 python bench.py --steps 10 --warmup 3 --cpu-sample 0 --inputs uniform ${BATCH:+--batch $BATCH} 2>/dev/null | tail -1 | python -c "
+    env $envs HX_LIB=$lib timeout 150 python bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-extras --inputs uniform ${BATCH:+--batch $BATCH} 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']; r=d['roofline']
 print('$v', 'batch', c['batch_per_gpu'], 'measured', d['value'], 'bound', c['bound_noise_mult_per_s'], 'fixed', c['fixed_level_mult_per_s'], 'fwd_ms', r['avg_launch_ms'], 'inv_ms', r['inverse_avg_launch_ms'])" >> $out
