@@ -54,7 +54,7 @@ SYMBOLS = [
     "hx_intel_FFTFwd", "hx_intel_FFTRev1", "hx_intel_EltwiseAddMod", "hx_intel_EltwiseAddModScalar",
     "hx_intel_EltwiseSubMod", "hx_intel_EltwiseSubModScalar", "hx_intel_EltwiseMultMod",
     "hx_intel_EltwiseMultModScalar",
-    "hx_time_ntt", "hx_ctx_timer_begin", "hx_ctx_timer_end",
+    "hx_time_ntt", "hx_ctx_timer_begin", "hx_ctx_timer_end", "hx_randomize",
 ]
 
 
@@ -133,6 +133,7 @@ def lib():
             "hx_intel_EltwiseMultModScalar": [vp, vp, C.c_long, C.c_long, C.c_long],
             "hx_time_ntt": [vp, ip, ip, ip, vp],
             "hx_ctx_timer_begin": [vp], "hx_ctx_timer_end": [vp, vp],
+            "hx_randomize": [vp, C.c_char_p, C.c_uint64],
         }
         for name, args in sig.items():
             f = getattr(L, name)
@@ -297,6 +298,14 @@ class DoubleCRT:
         out = np.zeros((nrows, self.batch, self.context.phim), dtype=np.uint64)
         _chk(lib().hx_poly_download(self.h, _p(out)))
         return out
+
+    def randomize(self, key32, stream):
+        """DoubleCRT::randomize (src/DoubleCRT.cpp:1258-1378) on the device: uniform rows by the
+        reference's rejection sampling from the ChaCha20 stream (key32, stream) -- hx_randomize."""
+        key32 = bytes(key32)
+        assert len(key32) == 32
+        _chk(lib().hx_randomize(self.h, key32, int(stream)))
+        return self
 
     def copy(self):
         # (a digit block lists its primes once per digit: hx_poly_copy resizes the destination and

@@ -61,7 +61,7 @@ struct ModDownRow {
   TW inv;              // qd^-1 mod q_r
   TW cf;               // fused mod-up: F * qd^-1 mod q_r (multiplies c_r instead of inv)
   uint32_t out_row;
-  uint32_t mode;       // 0/1: c_r <- c_r*cf - v (cf = inv or F*inv) ; 2: new row, c_r = 0
+  uint32_t mode;       // 0/1: c_r <- c_r*cf - v (cf = inv or F*inv) ; 2: new row, c_r = 0 (cf = 0)
                        // (|S| < q_r is checked by the host before it takes the fused path)
 };
 struct ModDownApply {

@@ -19,6 +19,7 @@
 #include "bluestein.h"
 #include "rns_kernels.h"
 #include "norm_kernels.h"
+#include "prg_kernels.h"
 
 namespace hx {
 hipError_t launch_ntt_pow2(int logn, bool inverse, const uint64_t* in, uint64_t* out,
@@ -1300,6 +1301,38 @@ extern "C" int hx_poly_set_zero(hx_poly* p)
   return HX_OK;
 }
 
+// DoubleCRT::randomize (src/DoubleCRT.cpp:1258-1378) on the device: prg_kernels.h
+extern "C" int hx_randomize(hx_poly* p, const uint8_t* key32, uint64_t stream)
+{
+  if (!p || !key32)
+    return fail(HX_ERR_INVALID, "null argument");
+  hx_ctx* c = p->ctx;
+  CTX_ENTER(c);
+  if (p->nrows() == 0)
+    return HX_OK;
+  if (p->nrows() > MAX_ROWS || p->batch > 65535)
+    return fail(HX_ERR_UNSUPPORTED, "hx_randomize: more than %d rows or 65535 batch elements", MAX_ROWS);
+  hx::RandArgs A;
+  memset(&A, 0, sizeof A);
+  A.data = p->d;
+  for (int i = 0; i < 8; i++)
+    A.key[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) | ((uint32_t)key32[4 * i + 2] << 16) |
+               ((uint32_t)key32[4 * i + 3] << 24);
+  A.stream_lo = (uint32_t)stream;
+  A.stream_hi = (uint32_t)(stream >> 32);
+  A.phim = c->phim;
+  A.batch = p->batch;
+  for (int r = 0; r < p->nrows(); r++) {
+    if (p->prime_idx[r] > 65535)
+      return fail(HX_ERR_UNSUPPORTED, "hx_randomize: prime index above 65535");
+    A.rows.p[r] = (uint16_t)p->prime_idx[r];
+  }
+  hipLaunchKernelGGL(hx::randomize_kernel, dim3((unsigned)p->nrows() * (unsigned)p->batch), dim3(256), 0,
+                     c->stream, A, c->d_primes);
+  HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+
 static int find_row(const std::vector<int>& v, int prime)
 {
   for (size_t i = 0; i < v.size(); i++)
@@ -2362,7 +2395,8 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
       hr[i].cf = hr[i].inv;
       if (nadd > 0) {
         if (r >= nrows_old) {
-          hr[i].mode = 2;
+          hr[i].mode = 2;  // a row the mod-up adds: c_r = 0, i.e. cf = 0 (its slot is never initialised)
+          hr[i].cf.w = hr[i].cf.wp = 0;
         } else {
           uint64_t F = 1;
           for (int j = 0; j < nadd; j++)

@@ -662,6 +662,8 @@ HXD unsigned eval_const(int i)
 struct PtrIO {
   static constexpr int LOAD_BOUND = 1;
   static constexpr bool LAZY_STORE = false;
+  static constexpr bool PIPELINED = false;
+  struct StorePrefetch {};
   const uint64_t* in;
   uint64_t* out;
   HXD uint64_t load(unsigned tid, unsigned c) const { return in[tid + c]; }
@@ -739,10 +741,14 @@ struct RowNTT {
     constexpr int FC = pass_bound_out<G::LC, false, G::GC - 1, FB>();
     static_assert(IO::LOAD_BOUND <= 12 && FA <= 16 && FB <= 16 && FC <= 16, "lazy bounds");
     if constexpr (PH == 0) {
+      if constexpr (IO::PIPELINED) {
+        io.template load_all<LOGN>(tid, v, c);  // (software-pipelined element loads, see ModDownIO)
+      } else {
 #pragma unroll
-      for (int e = 0; e < 32; e++) {
-        v[e] = io.load(tid, coef_const<LOGN>(e));
-        HX_IO_FENCE(e);
+        for (int e = 0; e < 32; e++) {
+          v[e] = io.load(tid, coef_const<LOGN>(e));
+          HX_IO_FENCE(e);
+        }
       }
       run_pass<5, false, 1, 31, IO::LOAD_BOUND>(v, c, [&](int, int sp, int k, uint32_t) {
         return tw_uni(tw, (unsigned)((1 << sp) - 1 + k));  // uniform: scalar loads
@@ -781,6 +787,10 @@ struct RowNTT {
 #pragma unroll
       for (int i = 0; i < 32; i++)
         v[i] = ((uint64_t)nh[i] << 32) | nl[i];
+      // a fused store that reads its own operand row starts on it before the last register pass
+      typename IO::StorePrefetch pre;
+      if constexpr (IO::LAZY_STORE)
+        io.template store_prefetch<LOGN>(tid, pre);
       run_pass<G::LC, false, G::NGC, G::GC - 1, FB>(v, c, [&](int gi, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWC, tid, ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi), dep);
       });
@@ -788,9 +798,9 @@ struct RowNTT {
       // per element fragments the schedule into 32 blocks and the register file spills)
       if constexpr (IO::LAZY_STORE) {
         if (c.mu32)
-          io.template store_all<LOGN, FC, true>(tid, v, c);
+          io.template store_all<LOGN, FC, true>(tid, v, c, pre);
         else
-          io.template store_all<LOGN, FC, false>(tid, v, c);
+          io.template store_all<LOGN, FC, false>(tid, v, c, pre);
       } else if (c.mu32) {
 #pragma unroll
         for (int i = 0; i < 32; i++) {

@@ -43,9 +43,14 @@ from . import hostnt
 # samplers (host, as in the reference)
 # ---------------------------------------------------------------------------------------------
 class Sampler:
-    def __init__(self, context, backend, seed=0):
+    """seed=None (the default): every draw comes from a ChaCha20 stream keyed with 256 bits of OS
+    entropy, as the reference seeds NTL's PRG.  seed=<int>: a key derived from the seed --
+    DETERMINISTIC, for tests and benchmarks only (helib_amd.prg)."""
+
+    def __init__(self, context, backend, seed=None):
+        from .prg import ChaChaRng
         self.cc, self.be = context, backend
-        self.rng = np.random.default_rng(seed)
+        self.rng = seed if isinstance(seed, ChaChaRng) else ChaChaRng(seed)
 
     # -- unbounded draws: power-of-two m takes n = phi(m) coefficients directly; general m samples m
     #    coefficients and reduces modulo Phi_m (src/sample.cpp:240-256, 321-341, 420-440) --
@@ -138,7 +143,7 @@ class KeySwitchInfo:
 
 
 class PubKey:
-    def __init__(self, context, backend, seed=0):
+    def __init__(self, context, backend, seed=None):
         self.cc, self.be = context, backend
         self.sampler = Sampler(context, backend, seed)
         self.pubEncrKey = None            # (part "1", part "s") over the ctxt primes
@@ -285,7 +290,7 @@ class PubKey:
 
 
 class SecKey(PubKey):
-    def __init__(self, context, backend, seed=0):
+    def __init__(self, context, backend, seed=None):
         super().__init__(context, backend, seed)
         self.sKeys = []                   # secret keys as small coefficient vectors (the DoubleCRT
                                           # over any prime set is be.fromCoeffs(set, coeffs))
@@ -562,10 +567,9 @@ class HxBackend:
         return self.hx.DoubleCRT(self.gctx, idx, 1, rows[:, None, :]).FFT()
 
     def randomize(self, idx, rng):
-        idx = list(idx)
-        n = self.cc.phim
-        rows = np.stack([rng.integers(0, self.cc.primes[i], size=n, dtype=np.uint64) for i in idx])
-        return self.hx.DoubleCRT(self.gctx, idx, 1, rows[:, None, :])
+        """DoubleCRT::randomize on the device: no host fill, no upload (hx_randomize; one fresh
+        ChaCha20 stream of the sampler's key per call)."""
+        return self.hx.DoubleCRT(self.gctx, list(idx), 1, zero=False).randomize(rng.key, rng.next_stream())
 
     def toPoly(self, poly):
         idx = poly.getIndexSet()

@@ -734,7 +734,7 @@ def from_seckey(sk, gens=(), ords=()):
     return k
 
 
-def to_seckey(desc, key_cls, cc, be, make_poly, ksw_a=None, seed=0):
+def to_seckey(desc, key_cls, cc, be, make_poly, ksw_a=None, seed=None):
     """the SecKey (or PubKey) description -> key_cls (helib_amd.keys.SecKey / PubKey) over backend
     `be`; make_poly(idx, rows) builds a backend DoubleCRT.  Key-switching matrices are installed
     only when their a-columns are supplied (ksw_a[(powerOfS, powerOfX)] = [D][rows][N]) -- see

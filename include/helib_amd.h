@@ -105,6 +105,14 @@ int hx_poly_download(const hx_poly* p, uint64_t* host);       /* synchronous */
  * (dst capacity must be >= src rows). */
 int hx_poly_copy(hx_poly* dst, const hx_poly* src);
 int hx_poly_set_zero(hx_poly* p);
+/* DoubleCRT::randomize (src/DoubleCRT.cpp:1258-1378): every row of every batch element filled with
+ * uniform residues by the reference's rejection sampling (2048-byte buffers, ceil(k/8) bytes per
+ * candidate, little endian, masked to k = NumBits(q-1) bits, kept when < q) -- on the device, from
+ * a ChaCha20 (RFC 8439) key stream per row: 256-bit key `key32`, nonce = (stream low word, stream
+ * high word, prime index | batch element << 16), block counter from 0.  NTL's RandomStream (the
+ * reference's source of bytes) cannot be reproduced without NTL; the sampling rule is the
+ * reference's, the stream is this library's (known-answer tests: RFC 8439 2.3.2 + the oracle). */
+int hx_randomize(hx_poly* p, const uint8_t* key32, uint64_t stream);
 /* DoubleCRT::removePrimes: metadata only (rows are compacted on the device). */
 int hx_poly_remove_primes(hx_poly* p, const int* prime_idx, int n);
 

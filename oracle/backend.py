@@ -161,8 +161,9 @@ class OracleBackend:
         return OPoly(self.o, idx, self.o.fft(idx, coef))
 
     def randomize(self, idx, rng):
-        idx = list(idx)
-        rows = np.stack([rng.integers(0, self.o.primes[i], size=self.o.N, dtype=np.uint64) for i in idx])
+        """DoubleCRT::randomize over the same ChaCha20 stream the device kernel uses"""
+        idx, stream = list(idx), rng.next_stream()
+        rows = np.stack([O.randomize_row(self.o.N, self.o.primes[i], rng.key, stream, i)[0] for i in idx])
         return OPoly(self.o, idx, rows)
 
     def toPoly(self, poly):

@@ -1413,3 +1413,86 @@ double ho_embedding_largest_coeff(uint64_t m, const double* f, long n)
   free(sw);
   return (double)sqrtl(best);
 }
+
+/* ------------------------------------------------------------------ */
+/* DoubleCRT::randomize (src/DoubleCRT.cpp:1258-1378): every row is     */
+/* filled by rejection sampling from a byte stream taken in 2048-byte   */
+/* buffers: nb = ceil(k/8) bytes per candidate (little endian), masked  */
+/* to k = NumBits(q-1) bits, kept when < q, until phi(m) values are     */
+/* there; the rest of the last buffer is discarded.  The reference's    */
+/* stream is NTL's RandomStream (ChaCha20 keyed by NTL's own seed       */
+/* expansion, unreproducible without NTL).  Here the stream of a row is */
+/* the RFC 8439 ChaCha20 key stream under the caller's 256-bit key with */
+/* nonce (stream_lo, stream_hi, prime index | batch element << 16) and  */
+/* block counter 0.. -- one independent stream per row, which is what   */
+/* lets the device fill all rows at once.  Same acceptance rule, same   */
+/* byte order, same buffer discipline as the reference.                 */
+/* ------------------------------------------------------------------ */
+#define HO_ROTL32(x, n) (((x) << (n)) | ((x) >> (32 - (n))))
+#define HO_QR(a, b, c, d)        \
+  do {                           \
+    a += b; d ^= a; d = HO_ROTL32(d, 16); \
+    c += d; b ^= c; b = HO_ROTL32(b, 12); \
+    a += b; d ^= a; d = HO_ROTL32(d, 8);  \
+    c += d; b ^= c; b = HO_ROTL32(b, 7);  \
+  } while (0)
+
+/* RFC 8439 section 2.3: key = 8 LE words, counter, nonce = 3 LE words -> 64 bytes */
+void ho_chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], uint8_t out[64])
+{
+  uint32_t s[16], x[16];
+  s[0] = 0x61707865u; s[1] = 0x3320646eu; s[2] = 0x79622d32u; s[3] = 0x6b206574u;
+  for (int i = 0; i < 8; i++)
+    s[4 + i] = key[i];
+  s[12] = counter;
+  s[13] = nonce[0]; s[14] = nonce[1]; s[15] = nonce[2];
+  memcpy(x, s, sizeof x);
+  for (int r = 0; r < 10; r++) {
+    HO_QR(x[0], x[4], x[8], x[12]);
+    HO_QR(x[1], x[5], x[9], x[13]);
+    HO_QR(x[2], x[6], x[10], x[14]);
+    HO_QR(x[3], x[7], x[11], x[15]);
+    HO_QR(x[0], x[5], x[10], x[15]);
+    HO_QR(x[1], x[6], x[11], x[12]);
+    HO_QR(x[2], x[7], x[8], x[13]);
+    HO_QR(x[3], x[4], x[9], x[14]);
+  }
+  for (int i = 0; i < 16; i++) {
+    uint32_t v = x[i] + s[i];
+    out[4 * i] = (uint8_t)v;
+    out[4 * i + 1] = (uint8_t)(v >> 8);
+    out[4 * i + 2] = (uint8_t)(v >> 16);
+    out[4 * i + 3] = (uint8_t)(v >> 24);
+  }
+}
+
+/* one row: returns the number of 2048-byte buffers consumed */
+long ho_randomize_row(uint64_t* row, long phim, uint64_t q, const uint32_t key[8], const uint32_t nonce[3])
+{
+  enum { BUFSZ = 2048 };
+  uint8_t buf[BUFSZ];
+  int k = 0;
+  for (uint64_t t = q - 1; t; t >>= 1)
+    k++;                                   /* NTL::NumBits(pi - 1) */
+  const long nb = (k + 7) / 8;
+  const uint64_t mask = k >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << k) - 1);
+  long j = 0, nbuf = 0;
+  uint32_t ctr = 0;
+  if (phim <= 0)
+    return 0;
+  for (;;) {
+    for (int b = 0; b < BUFSZ / 64; b++)
+      ho_chacha20_block(key, ctr++, nonce, buf + 64 * b);   /* stream.get(buf, bufsz) */
+    nbuf++;
+    for (long pos = 0; pos <= BUFSZ - nb; pos += nb) {
+      uint64_t u = 0;
+      for (long c = nb - 1; c >= 0; c--)
+        u = (u << 8) | buf[pos + c];
+      u &= mask;
+      row[j] = u;
+      j += (u < q);
+      if (j >= phim)
+        return nbuf;
+    }
+  }
+}

@@ -193,6 +193,11 @@ void ho_dcrt_break_into_digits_norms(const ho_ctx* c, const int* own_idx, int no
 /* deterministic test data: splitmix64 stream, rejection-sampled into [0,q) */
 void ho_fill_uniform(uint64_t* out, long n, uint64_t q, uint64_t seed);
 
+/* DoubleCRT::randomize (src/DoubleCRT.cpp:1258-1378) over a ChaCha20 (RFC 8439) stream per row;
+ * see hx_oracle.c.  ho_randomize_row returns the number of 2048-byte buffers consumed. */
+void ho_chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], uint8_t out[64]);
+long ho_randomize_row(uint64_t* row, long phim, uint64_t q, const uint32_t key[8], const uint32_t nonce[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,9 @@ def lib():
         L.ho_dcrt_to_poly_limbs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_int, C.c_void_p]
         L.ho_fill_uniform.argtypes = [C.c_void_p, C.c_long, C.c_uint64, C.c_uint64]
+        L.ho_chacha20_block.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.ho_randomize_row.restype = C.c_long
+        L.ho_randomize_row.argtypes = [C.c_void_p, C.c_long, C.c_uint64, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -157,6 +160,26 @@ def fill_uniform(n, q, seed):
     out = np.zeros(n, dtype=np.uint64)
     lib().ho_fill_uniform(_p(out), n, q, seed)
     return out
+
+
+def chacha20_block(key, counter, nonce):
+    """RFC 8439 block function: key = 32 bytes, nonce = 12 bytes -> 64 bytes."""
+    k = np.frombuffer(bytes(key), dtype="<u4").astype(np.uint32)
+    nn = np.frombuffer(bytes(nonce), dtype="<u4").astype(np.uint32)
+    out = np.zeros(64, dtype=np.uint8)
+    lib().ho_chacha20_block(_p(k), counter, _p(nn), _p(out))
+    return out.tobytes()
+
+
+def randomize_row(n, q, key, stream, prime_index, batch_element=0):
+    """One row of DoubleCRT::randomize over the ChaCha20 stream (key, nonce = stream_lo, stream_hi,
+    prime_index | batch_element << 16).  Returns (row, buffers consumed)."""
+    k = np.frombuffer(bytes(key), dtype="<u4").astype(np.uint32)
+    nonce = np.array([stream & 0xffffffff, (stream >> 32) & 0xffffffff,
+                      (prime_index & 0xffff) | ((batch_element & 0xffff) << 16)], dtype=np.uint32)
+    out = np.zeros(n, dtype=np.uint64)
+    nbuf = lib().ho_randomize_row(_p(out), n, q, _p(k), _p(nonce))
+    return out, int(nbuf)
 
 
 class Cmod:

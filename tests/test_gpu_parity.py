@@ -959,6 +959,45 @@ def test_fresh_multiplyBy_at_the_reference_benchmark_chain_size(hx, monkeypatch)
     assert T.decrypt(ctx, P.o, s, oa, rows) == [int(v) for v in want]
 
 
+# ---------------------------------------------------------------- DoubleCRT::randomize
+@pytest.mark.parametrize("m,batch", [(16384, 3), (32768, 2), (128, 2), (1705, 1)])
+def test_randomize_on_the_device_matches_oracle(hx, m, batch):
+    """hx_randomize = DoubleCRT::randomize (src/DoubleCRT.cpp:1258-1378) on the device: the
+    reference's rejection sampling (2048-byte buffers, ceil(k/8) bytes per candidate, k-bit mask,
+    keep when < q) from one ChaCha20 stream per (row, batch element).  Against the oracle's
+    restatement on every word -- HElib-style primes just below 2^60 / 2^56 / 2^40 (a rejection is a
+    2^-30 event), and primes just ABOVE a power of two, where every second candidate is rejected
+    and the order-preserving compaction and the extra buffers are exercised."""
+    if m & (m - 1) == 0:
+        near = [O.PrimeGen(60, m).next(), O.PrimeGen(56, m).next(), O.PrimeGen(40, m).next()]
+        step = 2 * m
+        above = []
+        for lo in (1 << 59, 1 << 47, (1 << 33) + (1 << 31)):
+            q = lo - (lo % step) + step + 1
+            while not O.lib().ho_is_prime(q):
+                q += step
+            above.append(q)
+        primes = near + above
+    else:
+        g = O.PrimeGen(60, m)
+        primes = [g.next(), g.next()]
+    P = Pair(hx, m, primes)
+    idx = list(range(len(primes)))
+    key = bytes((7 * i + 3) & 0xff for i in range(32))
+    for stream in (1, (5 << 32) | 9):
+        d = hx.DoubleCRT(P.g, idx, batch, zero=False).randomize(key, stream)
+        got = d.download()
+        for r, i in enumerate(idx):
+            for b in range(batch):
+                want, nbuf = O.randomize_row(P.N, primes[i], key, stream, i, b)
+                assert np.array_equal(got[r, b], want), (primes[i], b, stream)
+                assert got[r, b].max() < primes[i]
+    # distinct streams / rows / batch elements are distinct
+    a = hx.DoubleCRT(P.g, idx, batch, zero=False).randomize(key, 1).download()
+    assert not np.array_equal(a, got)
+    assert not np.array_equal(a[0, 0], a[0, batch - 1]) or batch == 1
+
+
 # ---------------------------------------------------------------- SURVEY row N2: keys, encrypt, decrypt
 @pytest.mark.parametrize("m,p,bits", [(16384, 65537, 250), (128, 257, 150), (1705, 7, 200)])
 def test_keys_encrypt_decrypt_gpu_vs_oracle(hx, m, p, bits, monkeypatch):

@@ -183,3 +183,48 @@ def test_automorph_matches_polynomial_substitution():
     assert got.tolist() == want.tolist()
     with pytest.raises(RuntimeError):
         O.automorph(cm.fft(x), m, zms, 4)
+
+
+def test_chacha20_block_rfc8439_known_answer():
+    """RFC 8439 section 2.3.2 test vector for the block function that the randomize restatement
+    (oracle) and helib_amd.prg (host draws) are built on; the device kernel is compared with the
+    oracle word for word in the -m gpu suite."""
+    from oracle import oracle as O
+    from helib_amd import prg
+    key = bytes(range(32))
+    nonce = bytes.fromhex("000000090000004a00000000")
+    want = bytes.fromhex("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+                         "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    assert O.chacha20_block(key, 1, nonce) == want
+    assert prg.chacha20_blocks(key, nonce, 1, 1) == want
+    # consecutive counters, and the python generator against the C one
+    assert prg.chacha20_blocks(key, nonce, 1, 3)[64:128] == O.chacha20_block(key, 2, nonce)
+    assert prg.chacha20_blocks(key, nonce, 0xffffffff, 2)[64:] == O.chacha20_block(key, 0, nonce)
+
+
+def test_randomize_row_follows_the_reference_sampling_rule():
+    """ho_randomize_row against a pure-python restatement of src/DoubleCRT.cpp:1279-1376 over the
+    same byte stream: nb = ceil(k/8) little-endian bytes per candidate, k-bit mask, keep when < q,
+    2048-byte buffers whose tail is discarded."""
+    from oracle import oracle as O
+    from helib_amd import prg
+    key = bytes(range(1, 33))
+    for q, n, pidx, b in [((1 << 60) - (1 << 18) + 1, 700, 3, 0), ((1 << 59) + 12345, 600, 9, 2),
+                          ((1 << 40) - 87, 1000, 1, 1), (65537, 1500, 0, 0)]:
+        stream = 77
+        got, nbuf = O.randomize_row(n, q, key, stream, pidx, b)
+        k = (q - 1).bit_length()
+        nb, mask = (k + 7) // 8, (1 << k) - 1
+        nonce = (stream & 0xffffffff, stream >> 32, pidx | (b << 16))
+        data = prg.chacha20_blocks(key, nonce, 0, 32 * (nbuf + 1))
+        out, used = [], 0
+        while len(out) < n:
+            buf = data[2048 * used:2048 * (used + 1)]
+            used += 1
+            for pos in range(0, 2048 - nb + 1, nb):
+                u = int.from_bytes(buf[pos:pos + nb], "little") & mask
+                if u < q:
+                    out.append(u)
+                    if len(out) == n:
+                        break
+        assert used == nbuf and [int(v) for v in got] == out
