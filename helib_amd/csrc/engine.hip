@@ -25,10 +25,10 @@ namespace hx {
 hipError_t launch_ntt_pow2(int logn, bool inverse, const uint64_t* in, uint64_t* out,
                            const NttRows& rows, int nrows, int batch, const PrimeDev* primes,
                            const TW* tw_arena, hipStream_t st);
-hipError_t launch_moddown_pow2(int logn, const PolyBases& data, int drop_row, int drop_prime,
-                               const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
-                               const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena,
-                               hipStream_t st);
+hipError_t launch_moddown_pow2(int logn, const PolyBases& data, const PolyBases& out, int drop_row,
+                               int drop_prime, const NttRows& keep, int nkeep, int batch,
+                               const ModDownPrep& P, const ModDownApply& A, const PrimeDev* primes,
+                               const TW* tw_arena, hipStream_t st);
 }
 
 using hx::ExtArgs;
@@ -199,8 +199,18 @@ struct hx_poly {
   std::vector<int> prime_idx;  // one per row
   uint64_t* d;
   bool owns;
+  // Copy-on-write: hx_poly_copy between pool-backed polys shares the source's slab (all sharers
+  // have the same d / cap_rows) and bumps this count; whoever writes first takes a private copy
+  // (poly_own) -- except the fused mod-switch, which reads the shared slab and writes its result
+  // straight into a fresh one, so that `Ctxt tmp = other; tmp.bringToSet(...)`
+  // (src/Ctxt.cpp:1700-1745) never moves the operand twice.
+  struct Share {
+    int refs;
+  };
+  Share* share = nullptr;
   size_t row_words() const { return (size_t)batch * ctx->phim; }
   int nrows() const { return (int)prime_idx.size(); }
+  bool shared() const { return share && share->refs > 1; }
 };
 
 struct hx_ksk {
@@ -289,6 +299,71 @@ static int dcopy(hx_ctx* c, uint64_t* dst, const uint64_t* src, size_t words)
   hipLaunchKernelGGL(hx::copy_words_kernel, dim3((unsigned)std::max<size_t>(blocks, 1)), dim3(256), 0, c->stream,
                      dst, src, words);
   HIPCHK(hipGetLastError());
+  return HX_OK;
+}
+
+// give up p's slab (pool memory): the last holder returns it to the pool
+static void storage_release(hx_poly* p)
+{
+  if (!p->owns || !p->d)
+    return;
+  const size_t bytes = (size_t)p->cap_rows * p->row_words() * 8;
+  if (p->share) {
+    if (--p->share->refs == 0) {
+      pool_free(p->ctx, p->d, bytes);
+      delete p->share;
+    }
+    p->share = nullptr;
+  } else {
+    pool_free(p->ctx, p->d, bytes);
+  }
+  p->d = nullptr;
+}
+// make p the only holder of its slab (every entry point that writes p's rows calls this first)
+static int poly_own(hx_poly* p)
+{
+  if (!p->share)
+    return HX_OK;
+  if (p->share->refs == 1) {
+    delete p->share;
+    p->share = nullptr;
+    return HX_OK;
+  }
+  hx_ctx* c = p->ctx;
+  uint64_t* nd = nullptr;
+  const size_t bytes = (size_t)p->cap_rows * p->row_words() * 8;
+  hipError_t e = pool_alloc(c, bytes, (void**)&nd);
+  if (e != hipSuccess)
+    return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  CHK(dcopy(c, nd, p->d, (size_t)p->nrows() * p->row_words()));
+  p->share->refs--;
+  p->share = nullptr;
+  p->d = nd;
+  return HX_OK;
+}
+#define OWN(p) CHK(poly_own(p))
+// p is about to have every live row overwritten by kernels that can read the old rows from another
+// address: a shared p moves to a fresh slab WITHOUT copying; *old_rows is where the old rows are
+// (the shared slab stays with its other holders; reuse of pool memory is stream-ordered, so the
+// kernels enqueued by this entry point still see it even if those holders are destroyed next).
+static int poly_fresh(hx_poly* p, const uint64_t** old_rows)
+{
+  *old_rows = p->d;
+  if (!p->share)
+    return HX_OK;
+  if (p->share->refs == 1) {
+    delete p->share;
+    p->share = nullptr;
+    return HX_OK;
+  }
+  uint64_t* nd = nullptr;
+  const size_t bytes = (size_t)p->cap_rows * p->row_words() * 8;
+  hipError_t e = pool_alloc(p->ctx, bytes, (void**)&nd);
+  if (e != hipSuccess)
+    return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  p->share->refs--;
+  p->share = nullptr;
+  p->d = nd;
   return HX_OK;
 }
 
@@ -1210,8 +1285,7 @@ extern "C" int hx_poly_destroy(hx_poly* p)
   {
     std::lock_guard<std::recursive_mutex> lk(p->ctx->mu);
     hipSetDevice(p->ctx->device);
-    if (p->owns && p->d)
-      pool_free(p->ctx, p->d, (size_t)p->cap_rows * p->row_words() * 8);
+    storage_release(p);
   }
   ctx_release(p->ctx);
   delete p;
@@ -1237,13 +1311,23 @@ extern "C" int hx_poly_primes(const hx_poly* p, int* out)
     out[i] = p->prime_idx[i];
   return HX_OK;
 }
-extern "C" void* hx_poly_device_ptr(hx_poly* p) { return p ? p->d : nullptr; }
+extern "C" void* hx_poly_device_ptr(hx_poly* p)
+{
+  if (!p)
+    return nullptr;
+  std::lock_guard<std::recursive_mutex> lk(p->ctx->mu);
+  hipSetDevice(p->ctx->device);
+  if (poly_own(p) != HX_OK)  // the caller may write through the pointer
+    return nullptr;
+  return p->d;
+}
 
 extern "C" int hx_poly_upload(hx_poly* p, const uint64_t* host)
 {
   if (!p || !host)
     return fail(HX_ERR_INVALID, "null argument");
   CTX_ENTER(p->ctx);
+  OWN(p);
   size_t bytes = (size_t)p->nrows() * p->row_words() * 8;
   HIPCHK(hipMemcpyAsync(p->d, host, bytes, hipMemcpyHostToDevice, p->ctx->stream));
   HIPCHK(hipStreamSynchronize(p->ctx->stream));
@@ -1276,7 +1360,7 @@ static int poly_reserve(hx_poly* p, int cap, bool keep = true)
     return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
   if (keep && p->nrows() > 0)
     CHK(dcopy(c, nd, p->d, (size_t)p->nrows() * p->row_words()));
-  pool_free(c, p->d, (size_t)p->cap_rows * p->row_words() * 8);  // stream-ordered reuse
+  storage_release(p);  // stream-ordered reuse (a shared slab stays with its other holders)
   p->d = nd;
   p->cap_rows = cap;
   return HX_OK;
@@ -1287,6 +1371,24 @@ extern "C" int hx_poly_copy(hx_poly* dst, const hx_poly* src)
   if (!dst || !src || dst->ctx != src->ctx || dst->batch != src->batch)
     return fail(HX_ERR_INVALID, "Context mismatch");
   CTX_ENTER(dst->ctx);
+  if (dst == src)
+    return HX_OK;
+  if (dst->owns && src->owns) {
+    // lazy: share the source's slab (see hx_poly::Share); nothing moves until somebody writes
+    hx_poly* s = const_cast<hx_poly*>(src);
+    if (dst->d == s->d)
+      return HX_OK;  // already sharing
+    storage_release(dst);
+    if (!s->share)
+      s->share = new hx_poly::Share{1};
+    s->share->refs++;
+    dst->share = s->share;
+    dst->d = s->d;
+    dst->cap_rows = s->cap_rows;
+    dst->prime_idx = s->prime_idx;
+    return HX_OK;
+  }
+  OWN(dst);
   CHK(poly_reserve(dst, src->nrows(), /*keep=*/false));
   dst->prime_idx = src->prime_idx;
   CHK(dcopy(dst->ctx, dst->d, src->d, (size_t)src->nrows() * src->row_words()));
@@ -1297,6 +1399,7 @@ extern "C" int hx_poly_set_zero(hx_poly* p)
   if (!p)
     return fail(HX_ERR_INVALID, "null poly");
   CTX_ENTER(p->ctx);
+  OWN(p);
   HIPCHK(hipMemsetAsync(p->d, 0, (size_t)p->nrows() * p->row_words() * 8, p->ctx->stream));
   return HX_OK;
 }
@@ -1312,6 +1415,7 @@ extern "C" int hx_randomize(hx_poly* p, const uint8_t* key32, uint64_t stream)
     return HX_OK;
   if (p->nrows() > MAX_ROWS || p->batch > 65535)
     return fail(HX_ERR_UNSUPPORTED, "hx_randomize: more than %d rows or 65535 batch elements", MAX_ROWS);
+  OWN(p);
   hx::RandArgs A;
   memset(&A, 0, sizeof A);
   A.data = p->d;
@@ -1346,6 +1450,7 @@ extern "C" int hx_poly_remove_primes(hx_poly* p, const int* idx, int n)
   if (!p || (n > 0 && !idx))
     return fail(HX_ERR_INVALID, "null argument");
   CTX_ENTER(p->ctx);
+  OWN(p);
   std::vector<int> keep;
   size_t rw = p->row_words();
   int w = 0;
@@ -1428,19 +1533,31 @@ static int ntt_rows(hx_ctx* c, uint64_t* data, const std::vector<int>& plist, in
   return ntt_list(c, data, data, rows, batch, inverse);
 }
 
+// all rows of p; a shared p (copy-on-write) is transformed out of place into its own new slab
+static int ntt_poly(hx_poly* p, bool inverse)
+{
+  const uint64_t* src;
+  CHK(poly_fresh(p, &src));
+  std::vector<std::pair<int, int>> rows;
+  rows.reserve(p->nrows());
+  for (int r = 0; r < p->nrows(); r++)
+    rows.emplace_back(r, p->prime_idx[r]);
+  return ntt_list(p->ctx, src, p->d, rows, p->batch, inverse);
+}
+
 extern "C" int hx_ntt_forward(hx_poly* p)
 {
   if (!p)
     return fail(HX_ERR_INVALID, "null poly");
   CTX_ENTER(p->ctx);
-  return ntt_rows(p->ctx, p->d, p->prime_idx, p->nrows(), 0, p->nrows(), p->batch, false);
+  return ntt_poly(p, false);
 }
 extern "C" int hx_ntt_inverse(hx_poly* p)
 {
   if (!p)
     return fail(HX_ERR_INVALID, "null poly");
   CTX_ENTER(p->ctx);
-  return ntt_rows(p->ctx, p->d, p->prime_idx, p->nrows(), 0, p->nrows(), p->batch, true);
+  return ntt_poly(p, true);
 }
 
 extern "C" int hx_time_ntt(hx_poly* p, int dir, int iters, int max_rows, float* avg_ms)
@@ -1449,6 +1566,7 @@ extern "C" int hx_time_ntt(hx_poly* p, int dir, int iters, int max_rows, float* 
     return fail(HX_ERR_INVALID, "bad argument");
   hx_ctx* c = p->ctx;
   CTX_ENTER(c);
+  OWN(p);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
@@ -1537,6 +1655,7 @@ static int ew_binary(hx_poly* a, const hx_poly* b)
     map.brow[r] = (uint16_t)br;
   }
   size_t rw = a->row_words();
+  OWN(a);
   hipLaunchKernelGGL((hx::ew_binary_kernel<OP>), ew_grid(rw, rows), dim3(256), 0, a->ctx->stream,
                      a->d, b->d, map, rw, b->row_words(), (int)(b->batch != a->batch),
                      (size_t)a->ctx->phim, a->ctx->d_primes);
@@ -1568,6 +1687,7 @@ static int ew_scalar_rows(hx_poly* a, const uint64_t* c_per_row, uint64_t expone
     sc.cp[r] = OP == hx::EWS_EXP ? exponent : hxh::shoup(cv, q);
   }
   size_t rw = a->row_words();
+  OWN(a);
   hipLaunchKernelGGL((hx::ew_scalar_kernel<OP>), ew_grid(rw, rows), dim3(256), 0, a->ctx->stream,
                      a->d, map, sc, rw, a->ctx->d_primes);
   HIPCHK(hipGetLastError());
@@ -1619,7 +1739,13 @@ extern "C" int hx_automorph(hx_poly* a, uint64_t k)
   if (rows == 0)
     return HX_OK;
   size_t words = (size_t)rows * a->row_words();
-  CHK(ensure_scratch(c, 3, words));
+  // a shared poly (copy-on-write) is permuted straight from the shared slab into its own new one;
+  // otherwise through a scratch copy
+  const uint64_t* src;
+  CHK(poly_fresh(a, &src));
+  const bool direct = src != a->d;
+  if (!direct)
+    CHK(ensure_scratch(c, 3, words));
   if (!c->pow2) {
     hipLaunchKernelGGL(hx::perm_build_kernel, dim3((c->phim + 255) / 256), dim3(256), 0, c->stream,
                        c->d_perm, c->d_zms, c->d_zms_index, c->phim, c->m, k);
@@ -1630,9 +1756,10 @@ extern "C" int hx_automorph(hx_poly* a, uint64_t k)
   if (bx > 64)
     bx = 64;
   hipLaunchKernelGGL(hx::gather_kernel, dim3(bx, (unsigned)nseg), dim3(256), 0, c->stream,
-                     c->scratch[3], a->d, c->d_perm, c->phim, nseg, (int)c->pow2, c->m, k);
+                     direct ? a->d : c->scratch[3], src, c->d_perm, c->phim, nseg, (int)c->pow2, c->m, k);
   HIPCHK(hipGetLastError());
-  CHK(dcopy(c, a->d, c->scratch[3], words));
+  if (!direct)
+    CHK(dcopy(c, a->d, c->scratch[3], words));
   return HX_OK;
 }
 extern "C" int hx_complex_conj(hx_poly* a)
@@ -2164,6 +2291,7 @@ extern "C" int hx_add_primes_and_scale(hx_poly* a, const int* add_idx, int nadd)
     if (find_row(a->prime_idx, add_idx[i]) >= 0)
       return fail(HX_ERR_PRIMESET, "addPrimes can only be called on a disjoint set");
   int old = a->nrows();
+  OWN(a);
   if (old > 0)
     CHK(scale_rows_by_primes(a, add_idx, nadd));
   CHK(poly_reserve(a, old + nadd));
@@ -2187,6 +2315,7 @@ extern "C" int hx_add_primes(hx_poly* a, const int* add_idx, int nadd)
     if (find_row(a->prime_idx, add_idx[i]) >= 0)
       return fail(HX_ERR_PRIMESET, "addPrimes can only be called on a disjoint set");
   int old = a->nrows();
+  OWN(a);
   CHK(poly_reserve(a, old + nadd));
   size_t rw = a->row_words();
   if (old == 0) {  // special case for empty DCRT (src/DoubleCRT.cpp:579-585)
@@ -2294,10 +2423,13 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
       ok = a->prime_idx[r] == drop_idx[0] || ptxt / 2 + 2 < c->primes[a->prime_idx[r]].q;
     if (!ok)
       return HX_ERR_UNSUPPORTED;
-    // make room and append the new (all-zero, never read) rows
-    CHK(poly_reserve(a, a->nrows() + nadd));
+    // make room and append the new (never read) rows; a shared poly (copy-on-write) gets its output
+    // slab below instead
+    if (!a->shared())
+      CHK(poly_reserve(a, a->nrows() + nadd));
     for (int i = 0; i < nother; i++)
-      CHK(poly_reserve(others[i], a->nrows() + nadd));
+      if (!others[i]->shared())
+        CHK(poly_reserve(others[i], a->nrows() + nadd));
     for (int i = 0; i < nadd; i++)
       a->prime_idx.push_back(add_idx[i]);
   }
@@ -2334,12 +2466,50 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     // the dropped row's slot, so no compaction copy is needed.
     const int dprime = drop[0], drow = find_row(a->prime_idx, dprime), last = a->nrows() - 1;
     const uint64_t qd = c->primes[dprime].q;
-    PolyBases pb;
+    // inputs and outputs: in place, except for polys that share their slab with a copy
+    // (hx_poly_copy is lazy) -- those read the shared slab and write a fresh one, which is what
+    // makes `Ctxt tmp = other; tmp.bringToSet(s)` cost no copy at all
+    PolyBases pb, pbo;
     memset(&pb, 0, sizeof pb);
-    pb.n = 1 + nother;
-    pb.d[0] = a->d;
+    memset(&pbo, 0, sizeof pbo);
+    pb.n = pbo.n = 1 + nother;
+    hx_poly* ps[hx::MD_MAXPOLY];
+    uint64_t* fresh[hx::MD_MAXPOLY] = {nullptr};
+    ps[0] = a;
     for (int i = 0; i < nother; i++)
-      pb.d[1 + i] = others[i]->d;
+      ps[1 + i] = others[i];
+    const int ncap = a->nrows() + 2;
+    const size_t nbytes = (size_t)ncap * rw * 8;
+    for (int i = 0; i < pb.n; i++)
+      if (ps[i]->share && !ps[i]->shared())
+        CHK(poly_own(ps[i]));  // last holder of its slab: plain in-place
+    // (all output slabs are taken BEFORE any shared slab is released: two listed polys may share
+    // one slab, and a slab returned to the pool could come straight back as somebody's output)
+    auto drop_fresh = [&]() {
+      for (int i = 0; i < pb.n; i++)
+        if (fresh[i])
+          pool_free(c, fresh[i], nbytes);
+    };
+    for (int i = 0; i < pb.n; i++) {
+      pb.d[i] = pbo.d[i] = ps[i]->d;
+      if (ps[i]->shared()) {
+        hipError_t pe = pool_alloc(c, nbytes, (void**)&fresh[i]);
+        if (pe != hipSuccess) {
+          drop_fresh();
+          return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(pe));
+        }
+        pbo.d[i] = fresh[i];
+      }
+    }
+    struct FreshGuard {  // error paths below give the output slabs back
+      decltype(drop_fresh)& f;
+      bool armed = true;
+      ~FreshGuard()
+      {
+        if (armed)
+          f();
+      }
+    } fresh_guard{drop_fresh};
     CHK(ensure_scratch(c, 0, rw * pb.n));
     CHK(ensure_scratch(c, 1, rw * pb.n));
     hx::ModDownPrep P;
@@ -2422,10 +2592,17 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     A.xs = c->scratch[0];
     A.S = reinterpret_cast<const int64_t*>(c->scratch[1]);
     A.rows = reinterpret_cast<const hx::ModDownRow*>(it->second->blob);
-    hipError_t e = hx::launch_moddown_pow2(c->logn, pb, drow, dprime, kr, nk, a->batch, P, A,
+    hipError_t e = hx::launch_moddown_pow2(c->logn, pb, pbo, drow, dprime, kr, nk, a->batch, P, A,
                                            c->d_primes, c->d_tw, c->stream);
     if (e != hipSuccess)
       return fail(HX_ERR_DEVICE, "mod-down launch failed: %s", hipGetErrorString(e));
+    fresh_guard.armed = false;
+    for (int i = 0; i < pb.n; i++)
+      if (fresh[i]) {  // the shared input slab stays with its other holders (or goes back to the
+        storage_release(ps[i]);  // pool, whose reuse is ordered behind the kernels just enqueued)
+        ps[i]->d = fresh[i];
+        ps[i]->cap_rows = ncap;
+      }
     if (c->want_frac) {
       const size_t n = rw * (size_t)pb.n;
       double* fr = frac_take(c, n);
@@ -2509,7 +2686,7 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
                      a->d, map, sc, rw, c->d_primes);
   HIPCHK(hipGetLastError());
   if (a->owns) {
-    pool_free(c, a->d, (size_t)a->cap_rows * rw * 8);  // stream-ordered reuse
+    storage_release(a);  // stream-ordered reuse (a shared slab stays with its other holders)
     a->d = nd_buf;
     a->cap_rows = ncap;
   } else {  // caller-owned storage: the compact result goes back into it
@@ -2812,6 +2989,7 @@ extern "C" int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const 
   if (nall > MAX_ROWS)
     return fail(HX_ERR_UNSUPPORTED, "too many rows");
   size_t rw = a->row_words();
+  OWN(out);
   CHK(poly_reserve(out, ndig * nall, /*keep=*/out == a));
   out->prime_idx.clear();
   for (int d = 0; d < ndig; d++)
@@ -2918,6 +3096,7 @@ extern "C" int hx_tensor(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0
   for (auto* o : os) {
     if (o->ctx != c0->ctx || o->batch != c0->batch)
       return fail(HX_ERR_INVALID, "Context mismatch");
+    OWN(o);
     CHK(poly_reserve(o, c0->nrows(), /*keep=*/false));
     o->prime_idx = c0->prime_idx;
   }
@@ -3025,6 +3204,8 @@ extern "C" int hx_key_switch_digits(const hx_poly* digits, const hx_ksk* W, hx_p
     for (int r = 0; r < nall; r++)
       if (digits->prime_idx[(size_t)d * nall + r] != out0->prime_idx[r])
         return fail(HX_ERR_PRIMESET, "digit rows do not match the ciphertext's primes");
+  OWN(out0);
+  OWN(out1);
   return keyswitch_launch(c, digits->d, W, out0->prime_idx, digits->batch, out0->d, out1->d, nall,
                           nullptr, nullptr, nullptr, ndig);
 }
@@ -3110,6 +3291,8 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
     return fail(HX_ERR_INVALID, "Context mismatch");
   size_t rw = c0->row_words();
   // (an output that aliases an input keeps its rows when it has to grow)
+  OWN(out0);
+  OWN(out1);
   CHK(poly_reserve(out0, nall, out0 == c0 || out0 == c1 || out0 == d0 || out0 == d1));
   CHK(poly_reserve(out1, nall, out1 == c0 || out1 == c1 || out1 == d0 || out1 == d1));
   out0->prime_idx = W->row_idx;
@@ -3153,6 +3336,8 @@ extern "C" int hx_relinearize(const hx_poly* t0, const hx_poly* t1, const hx_pol
       return fail(HX_ERR_PRIMESET, "No key-switching matrix row for prime %d", r);
   size_t rw = t0->row_words();
   // (an output that aliases an input keeps its rows when it has to grow)
+  OWN(out0);
+  OWN(out1);
   CHK(poly_reserve(out0, nall, out0 == t0 || out0 == t1 || out0 == t2));
   CHK(poly_reserve(out1, nall, out1 == t0 || out1 == t1 || out1 == t2));
   // parts (1),(s): addPrimesAndScale(special) happens inside the key-switch kernel, which reads

@@ -137,6 +137,13 @@ HXD uint64_t shoup4_acc(uint64_t y, TW t, uint64_t nq, uint64_t x)
   const uint32_t wl = (uint32_t)t.w, wh = (uint32_t)(t.w >> 32);
   const uint32_t nl = (uint32_t)nq, nh = (uint32_t)(nq >> 32);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_SHOUP4_OLD)
+#ifndef HX_SHOUP4_MADX1
+  // the two high halves by v_mul_hi_u32 and summed by the compiler: measured 1-2.5 % faster on
+  // the row kernels than the all-multiply-add form below (a v_mad_u64_u32 issues in 2.4 ns per
+  // wave64 per SIMD, a v_mul_hi_u32 in 1.9 ns: tools/ubench/issue_bench.hip, profiles/r02_issue_rates.txt)
+  const uint32_t a1 = mulhi32(yh, pl), b1 = mulhi32(yl, ph);
+  const uint64_t h = (uint64_t)yh * ph + a1 + b1;
+#else
   uint64_t A = (uint64_t)yh * pl, B = (uint64_t)yl * ph;
   HX_KEEP64(A);
   HX_KEEP64(B);
@@ -145,6 +152,7 @@ HXD uint64_t shoup4_acc(uint64_t y, TW t, uint64_t nq, uint64_t x)
   uint64_t h = (uint64_t)yh * ph;
   h = mad_x1((uint32_t)(A >> 32), h);
   h = mad_x1((uint32_t)(B >> 32), h);
+#endif
   const uint32_t hl = (uint32_t)h, hh = (uint32_t)(h >> 32);
   uint64_t u = (uint64_t)yl * wh;
   u += (uint64_t)yh * wl;
@@ -368,11 +376,17 @@ HXD void gs_bfly4_last(uint64_t& X, uint64_t& Y, TW tNinv, TW tS0Ninv, const QC&
 #else
 #define HX_LAUNDER(ptr, dep) ((void)(dep))
 #endif
-// Depth 2 (with the per-phase work-item id and the IO fences below) is what keeps the N = 2^14
-// kernels at or near zero scratch inside the 128-VGPR budget of two workgroups per CU; depth 4
-// measured the same speed where scratch is fast and up to 1.8x slower where it is not.
+// Round 1: depth 2 (with the per-phase work-item id and the IO fences below) was what kept the
+// N = 2^14 kernels at or near zero scratch inside the 128-VGPR budget of two workgroups per CU.
+// Round 2: with the LDS reads no longer volatile the kernels sit near 100 VGPRs and the queue can be
+// deeper -- forward 4, inverse 6 (measured: forward 0.546 -> 0.510 ms per 6400 rows, inverse
+// 0.631 -> 0.593); depth 6 in the forward kernels spills in the N = 2^15 mod-down apply, depth 8
+// spills in several (profiles/r02_variants_twiddle_queue.txt).
 #ifndef HX_TW_PF
-#define HX_TW_PF 2
+#define HX_TW_PF 4
+#endif
+#ifndef HX_TW_PF_INV
+#define HX_TW_PF_INV 6
 #endif
 #ifndef HX_IO_GROUP
 #define HX_IO_GROUP 4
@@ -472,7 +486,7 @@ constexpr int pass_bound_out()
 template <int S, bool INV, int REP, int NGRUN, int BIN, class Fetch>
 HXD void run_pass(uint64_t (&v)[32], const QC& c, Fetch fetch)
 {
-  constexpr int PF = HX_TW_PF;
+  constexpr int PF = INV ? HX_TW_PF_INV : HX_TW_PF;
   constexpr int TOT = REP * NGRUN;
   TW tq[PF];
   static_for<0, (PF < TOT ? PF : TOT)>([&](auto I) {

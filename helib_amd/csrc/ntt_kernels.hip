@@ -406,7 +406,7 @@ ntt_moddown_prep_kernel(PolyBases polys, int row, int prime, int batch, ModDownP
 // ... forward transform of delta on every kept row, subtract + divide in the store
 template <int LOGN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
-ntt_moddown_apply_kernel(PolyBases polys, NttRows rows, int nkeep, int batch, ModDownApply A,
+ntt_moddown_apply_kernel(PolyBases polys, PolyBases outs, NttRows rows, int nkeep, int batch, ModDownApply A,
                          const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -439,10 +439,15 @@ ntt_moddown_apply_kernel(PolyBases polys, NttRows rows, int nkeep, int batch, Mo
   const PrimeDev* pd = primes + uniform_u16(rows.prime, ri);
   const size_t N = Geo<LOGN>::N;
   const ModDownRow R = A.rows[ri];
-  uint64_t* data = poly_base(polys, pi);
+  // c_r is read from the poly's input slab and the result written to its output slab (the same
+  // slab unless the poly was a lazy copy: engine.hip, hx_poly::Share).  A row the fused mod-up adds
+  // has no c_r (cf = 0): its never-initialised OUTPUT slot stands in, the input slab may be
+  // too small to have that row at all.
+  uint64_t* odata = poly_base(outs, pi);
+  const uint64_t* idata = R.mode == 2 ? odata : poly_base(polys, pi);
   const ModDownIO io(A, R, ((size_t)pi * batch + b) * N,
-                     data + ((size_t)uniform_u16(rows.row, ri) * batch + b) * N,
-                     data + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd->q);
+                     idata + ((size_t)(R.mode == 2 ? R.out_row : uniform_u16(rows.row, ri)) * batch + b) * N,
+                     odata + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd->q);
   ntt_body<LOGN, false>(lds, io, tw_arena + pd->tw_fwd_off, pd);
 }
 
@@ -488,7 +493,7 @@ static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& r
 }
 
 template <int LOGN>
-static hipError_t launch_moddown(const PolyBases& polys, int drop_row, int drop_prime,
+static hipError_t launch_moddown(const PolyBases& polys, const PolyBases& outs, int drop_row, int drop_prime,
                                  const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
                                  const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena,
                                  hipStream_t st)
@@ -519,19 +524,19 @@ static hipError_t launch_moddown(const PolyBases& polys, int drop_row, int drop_
   const unsigned apply_grid = 8u * md_tile((unsigned)nkeep, (unsigned)polys.n * (unsigned)batch).per_xcd;
 #endif
   hipLaunchKernelGGL((ntt_moddown_apply_kernel<LOGN>), dim3(apply_grid), dim3(Geo<LOGN>::T),
-                     lds_bytes, st, polys, keep, nkeep, batch, A, primes, tw_arena);
+                     lds_bytes, st, polys, outs, keep, nkeep, batch, A, primes, tw_arena);
   return hipGetLastError();
 }
 
-hipError_t launch_moddown_pow2(int logn, const PolyBases& data, int drop_row, int drop_prime,
-                               const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
-                               const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena,
-                               hipStream_t st)
+hipError_t launch_moddown_pow2(int logn, const PolyBases& data, const PolyBases& out, int drop_row,
+                               int drop_prime, const NttRows& keep, int nkeep, int batch,
+                               const ModDownPrep& P, const ModDownApply& A, const PrimeDev* primes,
+                               const TW* tw_arena, hipStream_t st)
 {
   switch (logn) {
-    case 13: return launch_moddown<13>(data, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
-    case 14: return launch_moddown<14>(data, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
-    case 15: return launch_moddown<15>(data, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+    case 13: return launch_moddown<13>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+    case 14: return launch_moddown<14>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+    case 15: return launch_moddown<15>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
   }
   return hipErrorInvalidValue;
 }

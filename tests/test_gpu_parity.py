@@ -959,6 +959,94 @@ def test_fresh_multiplyBy_at_the_reference_benchmark_chain_size(hx, monkeypatch)
     assert T.decrypt(ctx, P.o, s, oa, rows) == [int(v) for v in want]
 
 
+# ---------------------------------------------------------------- copy-on-write DoubleCRT copies
+def test_lazy_copies_are_copy_on_write(hx):
+    """hx_poly_copy shares the source's slab until somebody writes (engine.hip, hx_poly::Share).
+    Every mutating entry point must leave all other holders untouched, and must give the result
+    it gives on an independent object -- whichever side (copy or source) is written, with the
+    fused mod-switch / transforms / automorphism taking their out-of-place routes."""
+    P, own, sp = setup_rns(hx, m=16384, L=5, K=2)
+    allp = own + sp
+    B = 2
+    base = P.rand(allp, 77, batch=B)
+    other = P.rand(allp, 78, batch=B)
+    key = bytes(range(32))
+
+    def fresh():        # an independent object with the same rows (uploaded, shares nothing)
+        return hx.DoubleCRT(P.g, allp, B, base)
+
+    o = hx.DoubleCRT(P.g, allp, B, other)
+    ops = {
+        "iFFT": lambda d: d.iFFT(),
+        "FFT": lambda d: d.FFT(),
+        "iadd": lambda d: d.__iadd__(o),
+        "imul": lambda d: d.__imul__(o),
+        "Negate": lambda d: d.Negate(),
+        "mulConstant": lambda d: d.mulConstant(12345),
+        "addConstant": lambda d: d.addConstant(7),
+        "setConstant": lambda d: d.setConstant(3),
+        "Exp": lambda d: d.Exp(3),
+        "automorph": lambda d: d.automorph(5),
+        "removePrimes": lambda d: d.removePrimes([allp[1]]),
+        "scaleDown1": lambda d: d.scaleDownToSet([i for i in allp if i != allp[2]], 65537),   # fused path
+        "scaleDown2": lambda d: d.scaleDownToSet(own, 65537),                                # generic path
+        "randomize": lambda d: d.randomize(key, 9),
+        "upload": lambda d: d.upload(other),
+        "selfmul": lambda d: d.__imul__(d),
+    }
+
+    def rows_by_prime(d):
+        return dict(zip(d.getIndexSet(), d.download()))
+
+    def same(x, y):
+        a, b = rows_by_prime(x), rows_by_prime(y)
+        return sorted(a) == sorted(b) and all(np.array_equal(a[i], b[i]) for i in a)
+
+    for name, op in ops.items():
+        want = fresh()
+        op(want)
+        # write the copy: the source keeps its rows
+        src = fresh()
+        cp = src.copy()
+        cp2 = cp.copy()                 # a chain of copies
+        op(cp)
+        assert np.array_equal(src.download(), base), name
+        assert np.array_equal(cp2.download(), base), name
+        assert same(cp, want), name
+        # write the source: the copies keep theirs
+        op(src)
+        assert same(src, want), name
+        assert np.array_equal(cp2.download(), base), name
+        # the last holder works in place (no other holder left to disturb)
+        del src, cp
+        op(cp2)
+        assert same(cp2, want), name
+    # subset operands
+    low = hx.DoubleCRT(P.g, own, B, base[:len(own)])
+    for add_then in ("addPrimesAndScale", "addPrimes"):
+        want = hx.DoubleCRT(P.g, own, B, base[:len(own)])
+        getattr(want, add_then)(sp)
+        cp = low.copy()
+        getattr(cp, add_then)(sp)
+        assert np.array_equal(low.download(), base[:len(own)]) and same(cp, want)
+    # the fused bringToSet on several parts, two of which share ONE slab, one a lazy copy of a
+    # third object, one exclusive
+    x, y = hx.DoubleCRT(P.g, own, B, base[:len(own)]), hx.DoubleCRT(P.g, own, B, other[:len(own)])
+    parts = [x.copy(), x.copy(), y.copy(), hx.DoubleCRT(P.g, own, B, other[:len(own)])]
+    keep = [i for i in own + [sp[0]] if i != own[-1]]
+    hx.bringToSetMulti(parts, [sp[0]], keep, 65537)
+    wx, wy = hx.DoubleCRT(P.g, own, B, base[:len(own)]), hx.DoubleCRT(P.g, own, B, other[:len(own)])
+    hx.bringToSetMulti([wx, wy], [sp[0]], keep, 65537)
+    assert np.array_equal(x.download(), base[:len(own)]) and np.array_equal(y.download(), other[:len(own)])
+    assert same(parts[0], wx) and same(parts[1], wx) and same(parts[2], wy) and same(parts[3], wy)
+    # outputs that are lazy copies
+    t = [hx.DoubleCRT(P.g, own, B, P.rand(own, 80 + i, batch=B)) for i in range(4)]
+    w0, w1, w2 = hx.tensorProduct(*t)
+    spare = hx.DoubleCRT(P.g, own, B, base[:len(own)])
+    held = spare.copy()
+    assert np.array_equal(held.download(), base[:len(own)])
+
+
 # ---------------------------------------------------------------- SURVEY row a16: DoubleCRT::randomize
 @pytest.mark.parametrize("m,batch", [(16384, 3), (32768, 2), (128, 2), (1705, 1)])
 def test_randomize_on_the_device_matches_oracle(hx, m, batch):
