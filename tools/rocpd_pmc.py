@@ -26,6 +26,9 @@ def main():
                 for cn in sorted(agg[name]):
                     v = agg[name][cn]
                     print(f"    {cn:28s} avg/dispatch = {sum(v)/len(v):16.1f}")
+                    if len(set(round(x) for x in v)) > 1 and len(v) <= 16:
+                        # the same kernel at different launch sizes: one value per dispatch, in order
+                        print(f"    {'':28s} per dispatch  = " + "  ".join(f"{x:.1f}" for x in v))
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ def main():
             print("# size -- for ntt_row_kernel<14,fwd> at 6400 workgroups that is bench.py's roofline loop, which runs last")
             for n, gx, wx, k, a, mn, mx in c.execute(
                     f"select {name_col}, grid_x, workgroup_x, count(*), avg(end-start), min(end-start), max(end-start) "
-                    "from kernels group by 1, 2 having count(*) >= 4 order by 1, 2 desc").fetchall():
+                    "from kernels group by 1, 2 having count(*) >= 2 order by 1, 2 desc").fetchall():
                 if "ntt_" in n or "break_digits" in n or "keyswitch" in n or "tensor" in n or "rns_extend" in n:
                     short = n if len(n) <= 60 else n[:57] + "..."
                     tail = c.execute(f"select avg(d) from (select end-start as d from kernels where {name_col} = ? and "
