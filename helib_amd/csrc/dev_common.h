@@ -55,6 +55,9 @@ struct ModDownPrep {
   TW upS, upN;         // fused mod-up (the dropped row times F = prod(added primes)): the last
                        // inverse stage's twiddles with F folded in, F*S0*N^-1 and F*N^-1
   uint64_t qd;
+  uint64_t poly_stride;  // words between the x blocks of consecutive polys (0: batch*N, the
+                         // single-prime layout [poly][batch][N]; the several-primes path keeps
+                         // [poly][dropped prime][batch][N] and launches once per dropped prime)
 };
 struct ModDownRow {
   TW qdm;              // qd mod q_r
@@ -68,6 +71,11 @@ struct ModDownApply {
   const uint64_t* xs;
   const int64_t* S;
   const ModDownRow* rows;  // [launch rows]
+  // several dropped primes: delta * P^-1 on the kept primes was written by the basis-extension
+  // kernel as coefficient rows [poly][kept row][batch][N]; the transform loads those instead of
+  // forming x*inv - S (PLAIN instantiation of the apply kernel)
+  const uint64_t* delta;
+  uint64_t delta_poly_stride;  // words
 };
 // several DoubleCRT objects with the same prime set (the parts of one or two ciphertexts) are
 // mod-switched by one pair of launches: xs/S hold [poly][batch][N]

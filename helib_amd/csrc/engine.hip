@@ -29,6 +29,12 @@ hipError_t launch_moddown_pow2(int logn, const PolyBases& data, const PolyBases&
                                int drop_prime, const NttRows& keep, int nkeep, int batch,
                                const ModDownPrep& P, const ModDownApply& A, const PrimeDev* primes,
                                const TW* tw_arena, hipStream_t st);
+hipError_t launch_moddown_prep_pow2(int logn, const PolyBases& polys, int drop_row, int drop_prime, int batch,
+                                    const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena,
+                                    hipStream_t st);
+hipError_t launch_moddown_apply_plain_pow2(int logn, const PolyBases& polys, const PolyBases& outs,
+                                           const NttRows& keep, int nkeep, int batch, const ModDownApply& A,
+                                           const PrimeDev* primes, const TW* tw_arena, hipStream_t st);
 }
 
 using hx::ExtArgs;
@@ -1774,8 +1780,12 @@ extern "C" int hx_complex_conj(hx_poly* a)
 // ------------------------------------------------------------------
 // tgt_moduli (optional): explicit target moduli instead of context primes (tgt then only sizes the
 // plan): any t in [2, 2^60) -- a target needs no transform tables (hx_poly_rem).
+// scaled: every target residue comes out multiplied by P^-1 mod q_t (W[t][k] and P mod t are
+// stored times P^-1: the kernels themselves are unchanged) -- the several-primes mod-switch wants
+// delta / P, whose transform it subtracts from c_r / P.
 static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<int>& tgt,
-                    uint64_t ptxt, ExtPlan** out, const std::vector<uint64_t>* tgt_moduli = nullptr)
+                    uint64_t ptxt, ExtPlan** out, const std::vector<uint64_t>* tgt_moduli = nullptr,
+                    bool scaled = false)
 {
   int n = (int)src.size(), nt = (int)tgt.size();
   if (n < 1 || n > 64)
@@ -1789,6 +1799,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   for (int t : tgt)
     key.push_back((uint64_t)t);
   key.push_back(ptxt);
+  if (scaled)
+    key.push_back(0x5ca1edull << 40);
   if (tgt_moduli) {
     key.push_back(0x7e57ull << 48);
     for (uint64_t t : *tgt_moduli)
@@ -1875,6 +1887,16 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     uint64_t pinv = hxh::invmod(run, q);
     h[o_upd + 2 * (size_t)t] = pinv;
     h[o_upd + 2 * (size_t)t + 1] = hxh::shoup(pinv, q);
+    if (scaled) {
+      if (pinv == 0)
+        return fail(HX_ERR_INVALID, "dropped primes are not invertible modulo a kept prime");
+      for (int k = 0; k < n; k++) {
+        const uint64_t w = hxh::mulmod(h[o_W + 2 * ((size_t)t * n + k)], pinv, q);
+        h[o_W + 2 * ((size_t)t * n + k)] = w;
+        h[o_W + 2 * ((size_t)t * n + k) + 1] = hxh::shoup(w, q);
+      }
+      h[o_pmod + t] = 1 % q;
+    }
   }
   ExtPlan* pl = new ExtPlan();
   memset(&pl->dev, 0, sizeof pl->dev);
@@ -1917,7 +1939,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   pl->dev.upd = reinterpret_cast<const TW*>(d + o_upd);
   pl->dev.Wp = reinterpret_cast<const TW*>(d + o_Wp);
   pl->dev.tgt_lazy = reinterpret_cast<const uint32_t*>(d + o_tlazy);
-  pl->dev.garner_cs = (max_src / 2 < min_src && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;  // a_l < q_l <= max < 2*min <= 2*p_k
+  // a_l < q_l <= max < 2*min <= 2*p_k, or the sources ascend (a_l < p_l <= p_k for l < k)
+  pl->dev.garner_cs = ((max_src / 2 < min_src || std::is_sorted(p.begin(), p.end())) && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;
   pl->dev.src_rq = reinterpret_cast<const double*>(d + o_srcrq);
   pl->dev.tgt_mu63 = d + o_tmu63;
   {
@@ -2395,6 +2418,178 @@ extern "C" int hx_poly_rem(const hx_poly* a, uint64_t t, uint64_t* out_host)
 // others[0..nother): further polys with exactly a's prime rows and batch, mod-switched by the
 // same launches when the fused single-prime path applies (returns HX_ERR_UNSUPPORTED otherwise
 // when nother > 0, so that the caller can fall back to one call per poly).
+// scaleDownToSet / bringToSet dropping SEVERAL primes, for all listed polys (one prime set, one
+// batch) in one set of launches -- what every multiply after the first goes through (the special
+// primes of the previous key switch, the small primes on the way out of a product).  Round 1 did this
+// per polynomial and unfused (inverse transforms, basis extension writing delta, forward transforms,
+// then a separate (c - delta)/P pass; the mod-up as a scaling pass of its own before).  Now:
+//   1. per dropped prime, ONE launch of the mod-down prep kernel over all polys: inverse transform
+//      of that row into the x block, the mod-up factor F = prod(added primes) riding on the last
+//      stage's N^-1 twiddles (no scaled copy of the operand is ever made);
+//   2. per poly, the basis-extension kernel on a plan whose tables carry P^-1 (get_plan scaled):
+//      Garner + centring + ptxtSpace correction, out comes delta/P on every kept prime
+//      (the dropped primes are taken in ascending order, so that the lazy Garner form applies to
+//      any mix of prime sizes);
+//   3. ONE launch of the apply kernel with a plain load over all polys: forward transform of
+//      delta/P with the store  c_r <- c_r*(F/P) - NTT(.)  into a fresh, compact slab per poly --
+//      out of place by construction, so lazily copied operands (hx_poly::Share) are never copied.
+// Returns HX_ERR_UNSUPPORTED (nothing touched) when the shape is not covered; the callers then
+// take the per-polynomial path.
+static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& drop_in,
+                                  const std::vector<int>& keep, uint64_t ptxt, const int* add_idx, int nadd)
+{
+  hx_poly* a = ps[0];
+  hx_ctx* c = a->ctx;
+  const int nd = (int)drop_in.size(), nk = (int)keep.size();
+  if (!c->pow2 || c->logn < 13 || c->logn > 15 || nd < 2 || nd > 64 || nk > MAX_ROWS || np > hx::MD_MAXPOLY)
+    return HX_ERR_UNSUPPORTED;
+  for (int i = 0; i < np; i++)
+    if (!ps[i]->owns)
+      return HX_ERR_UNSUPPORTED;  // caller-owned storage wants its result in place
+  const size_t rw = a->row_words();
+  const int batch = a->batch;
+  std::vector<int> drop = drop_in;
+  std::sort(drop.begin(), drop.end(), [&](int x, int y) { return c->primes[x].q < c->primes[y].q; });
+  // kept row t: prime keep[t]; its c_r lives in row in_row[t] of the input slab (-1: a row the
+  // fused mod-up adds, c_r = 0)
+  std::vector<int> in_row(nk);
+  for (int t = 0; t < nk; t++)
+    in_row[t] = find_row(a->prime_idx, keep[t]);  // (the added primes are not among the poly's rows)
+  ExtPlan* pl;
+  CHK(get_plan(c, drop, keep, ptxt > 1 ? ptxt : 0, &pl, nullptr, /*scaled=*/true));
+  CHK(ensure_scratch(c, 0, (size_t)np * nd * rw));  // x blocks  [poly][dropped prime][batch][N]
+  CHK(ensure_scratch(c, 1, (size_t)np * nk * rw));  // delta / P [poly][kept row][batch][N]
+  // per-row constants of the apply launch, cached per (dropped set, kept rows, added primes)
+  std::vector<uint64_t> key;
+  key.push_back(0xD1D1D1D1ull);
+  for (int d : drop)
+    key.push_back((uint64_t)d);
+  key.push_back(0xFFFFull << 32);
+  for (int j = 0; j < nadd; j++)
+    key.push_back(0xA000000ull | (uint64_t)add_idx[j]);
+  NttRows kr;
+  std::vector<hx::ModDownRow> hr(nk);
+  for (int t = 0; t < nk; t++) {
+    const int pr = keep[t];
+    const uint64_t q = c->primes[pr].q;
+    kr.row[t] = (uint16_t)(in_row[t] < 0 ? 0 : in_row[t]);
+    kr.prime[t] = (uint16_t)pr;
+    uint64_t P = 1;
+    for (int d : drop)
+      P = hxh::mulmod(P, c->primes[d].q % q, q);
+    uint64_t cf = hxh::invmod(P, q);
+    if (cf == 0)
+      return fail(HX_ERR_INVALID, "dropped primes are not invertible modulo a kept prime");
+    memset(&hr[t], 0, sizeof hr[t]);
+    hr[t].out_row = (uint32_t)t;
+    if (in_row[t] < 0) {
+      hr[t].mode = 2;  // c_r = 0: cf stays 0
+    } else {
+      for (int j = 0; j < nadd; j++)
+        cf = hxh::mulmod(cf, c->primes[add_idx[j]].q % q, q);
+      hr[t].mode = nadd > 0 ? 1 : 0;
+      hr[t].cf.w = cf;
+      hr[t].cf.wp = hxh::shoup(cf, q);
+    }
+    key.push_back(((uint64_t)pr << 28) | ((uint64_t)kr.row[t] << 12) | hr[t].mode);
+  }
+  auto it = c->plans.find(key);
+  if (it == c->plans.end()) {
+    ExtPlan* rp = new ExtPlan();
+    memset(&rp->dev, 0, sizeof rp->dev);
+    HIPCHK(hipMalloc(&rp->blob, sizeof(hx::ModDownRow) * nk));
+    HIPCHK(hipMemcpy(rp->blob, hr.data(), sizeof(hx::ModDownRow) * nk, hipMemcpyHostToDevice));
+    it = c->plans.emplace(key, rp).first;
+  }
+  // output slabs first (see the single-prime path: nothing is released before everything is taken)
+  const int ncap = nk + 2;
+  const size_t nbytes = (size_t)ncap * rw * 8;
+  uint64_t* fresh[hx::MD_MAXPOLY] = {nullptr};
+  auto drop_fresh = [&]() {
+    for (int i = 0; i < np; i++)
+      if (fresh[i])
+        pool_free(c, fresh[i], nbytes);
+  };
+  PolyBases pb, pbo;
+  memset(&pb, 0, sizeof pb);
+  memset(&pbo, 0, sizeof pbo);
+  pb.n = pbo.n = np;
+  for (int i = 0; i < np; i++) {
+    hipError_t pe = pool_alloc(c, nbytes, (void**)&fresh[i]);
+    if (pe != hipSuccess) {
+      drop_fresh();
+      return fail(HX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(pe));
+    }
+    pb.d[i] = ps[i]->d;
+    pbo.d[i] = fresh[i];
+  }
+  int rc = HX_OK;
+  // 1. inverse transforms of the dropped rows (one launch per dropped prime, all polys)
+  for (int j = 0; j < nd && rc == HX_OK; j++) {
+    const int dprime = drop[j], drow = find_row(a->prime_idx, dprime);
+    const uint64_t qd = c->primes[dprime].q;
+    ModDownPrep P;
+    memset(&P, 0, sizeof P);
+    P.xs = c->scratch[0] + (size_t)j * rw;
+    P.poly_stride = (uint64_t)nd * rw;
+    P.qd = qd;
+    if (nadd > 0) {
+      uint64_t F = 1;
+      for (int i = 0; i < nadd; i++)
+        F = hxh::mulmod(F, c->primes[add_idx[i]].q % qd, qd);
+      P.has_up = 1;
+      P.upS.w = hxh::mulmod(F, c->primes[dprime].last_s, qd);
+      P.upS.wp = hxh::shoup(P.upS.w, qd);
+      P.upN.w = hxh::mulmod(F, c->primes[dprime].last_n, qd);
+      P.upN.wp = hxh::shoup(P.upN.w, qd);
+    }
+    hipError_t e = hx::launch_moddown_prep_pow2(c->logn, pb, drow, dprime, batch, P, c->d_primes, c->d_tw, c->stream);
+    if (e != hipSuccess)
+      rc = fail(HX_ERR_DEVICE, "mod-down launch failed: %s", hipGetErrorString(e));
+  }
+  // 2. delta / P on the kept primes, per poly
+  for (int i = 0; i < np && rc == HX_OK; i++) {
+    ExtArgs args;
+    clear_args(args);
+    args.src = c->scratch[0] + (size_t)i * nd * rw;
+    args.dst = c->scratch[1] + (size_t)i * nk * rw;
+    for (int k = 0; k < nd; k++)
+      args.src_row[k] = (uint16_t)k;
+    for (int t = 0; t < nk; t++)
+      args.dst_row[t] = (uint16_t)t;
+    if (c->want_frac) {
+      args.frac = frac_take(c, rw);
+      if (!args.frac)
+        rc = fail(HX_ERR_INVALID, "internal: fraction buffer too small");
+    }
+    if (rc == HX_OK)
+      rc = launch_extend(c, pl, args, rw);
+  }
+  // 3. forward transforms with the subtraction and the division in the store
+  if (rc == HX_OK) {
+    ModDownApply A;
+    memset(&A, 0, sizeof A);
+    A.rows = reinterpret_cast<const hx::ModDownRow*>(it->second->blob);
+    A.delta = c->scratch[1];
+    A.delta_poly_stride = (uint64_t)nk * rw;
+    hipError_t e = hx::launch_moddown_apply_plain_pow2(c->logn, pb, pbo, kr, nk, batch, A, c->d_primes, c->d_tw,
+                                                       c->stream);
+    if (e != hipSuccess)
+      rc = fail(HX_ERR_DEVICE, "mod-down launch failed: %s", hipGetErrorString(e));
+  }
+  if (rc != HX_OK) {
+    drop_fresh();
+    return rc;
+  }
+  for (int i = 0; i < np; i++) {
+    storage_release(ps[i]);  // (a slab shared with a lazy copy stays with its other holders)
+    ps[i]->d = fresh[i];
+    ps[i]->cap_rows = ncap;
+    ps[i]->prime_idx = keep;
+  }
+  return HX_OK;
+}
+
 static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* drop_idx, int ndrop,
                            uint64_t ptxt, const int* add_idx = nullptr, int nadd = 0)
 {
@@ -2410,6 +2605,34 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     CHK(flush_xs(c));  // the scratch slots of an earlier fused block are about to be reused
   if (ptxt < 1)
     return fail(HX_ERR_INVALID, "ptxtSpace must be at least 1");
+  if (nadd > 0 && ndrop != 1) {
+    // several dropped primes behind a mod-up: the batched path or nothing (the caller then does
+    // addPrimesAndScale and the mod-down as two steps)
+    std::vector<int> drop, keep;
+    for (int r = 0; r < a->nrows(); r++) {
+      bool d = false;
+      for (int i = 0; i < ndrop; i++)
+        d = d || drop_idx[i] == a->prime_idx[r];
+      (d ? drop : keep).push_back(a->prime_idx[r]);
+    }
+    for (int i = 0; i < nadd; i++) {
+      if (find_row(a->prime_idx, add_idx[i]) >= 0)
+        return HX_ERR_UNSUPPORTED;
+      for (int j = 0; j < ndrop; j++)
+        if (drop_idx[j] == add_idx[i])
+          return HX_ERR_UNSUPPORTED;
+      keep.push_back(add_idx[i]);
+    }
+    if (drop.size() < 2 || (int)keep.size() == nadd)
+      return HX_ERR_UNSUPPORTED;
+    hx_poly* ps[hx::MD_MAXPOLY];
+    if (1 + nother > hx::MD_MAXPOLY)
+      return HX_ERR_UNSUPPORTED;
+    ps[0] = a;
+    for (int i = 0; i < nother; i++)
+      ps[1 + i] = others[i];
+    return scale_down_multi_fused(ps, 1 + nother, drop, keep, ptxt, add_idx, nadd);
+  }
   if (nadd > 0) {
     bool ok = ndrop == 1 && c->pow2 && c->logn >= 13 && c->logn <= 15 && find_row(a->prime_idx, drop_idx[0]) >= 0 &&
               a->nrows() + nadd - 1 <= MAX_ROWS && ptxt < ((uint64_t)1 << 62);
@@ -2627,6 +2850,15 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
       others[i]->prime_idx = a->prime_idx;
     return HX_OK;
   }
+  if (nd >= 2 && 1 + nother <= hx::MD_MAXPOLY) {
+    hx_poly* ps[hx::MD_MAXPOLY];
+    ps[0] = a;
+    for (int i = 0; i < nother; i++)
+      ps[1 + i] = others[i];
+    int rc = scale_down_multi_fused(ps, 1 + nother, drop, keep, ptxt, nullptr, 0);
+    if (rc != HX_ERR_UNSUPPORTED)
+      return rc;
+  }
   if (nother > 0)
     return HX_ERR_UNSUPPORTED;
   // toPoly(delta, diff): inverse transform of the dropped rows, out of place into scratch rows
@@ -2752,7 +2984,7 @@ extern "C" int hx_bring_to_set_multi(hx_poly** polys, int npoly, const int* add_
         return fail(HX_ERR_INVALID, "the same poly listed twice");
   }
   CHK(check_rows(polys[0]->ctx, add_idx, nadd));
-  if (same && nadd > 0 && ndrop == 1) {
+  if (same && nadd > 0 && ndrop >= 1) {
     int rc = scale_down_impl(polys[0], polys + 1, npoly - 1, drop_idx, ndrop, ptxt, add_idx, nadd);
     if (rc != HX_ERR_UNSUPPORTED)
       return rc;

@@ -153,10 +153,13 @@ moddown_S_kernel(ModDownPrep P, size_t n)
 //   load  = delta * inv = x*inv - S  (mod q_r)      (qd*inv = 1: S needs no multiplication,
 //                                                    and x < 2^64 needs no reduction before Shoup)
 //   store = c_r*cf - NTT(load)   with cf = inv (plain scale-down) or F*inv (mod-up folded in)
+// PLAIN: the transform's input is a ready coefficient row (delta * P^-1 mod q_r from the
+// basis-extension kernel, several dropped primes) instead of x*inv - S
+template <bool PLAIN>
 struct ModDownIO {
   // the load is x*inv (shoup4: [0,4q)) plus a residue of -S in [0,q]; the store takes the lazy
   // transform output and normalises once, after the subtraction
-  static constexpr int LOAD_BOUND = 5;
+  static constexpr int LOAD_BOUND = PLAIN ? 1 : 5;
   static constexpr bool LAZY_STORE = true;
   // Element IO is software-pipelined in groups of IOG elements.  Round 1 loaded x, S (and, in the
   // store, c_r) inside the same scheduling region as the ~40 instructions that consume them, one
@@ -165,7 +168,7 @@ struct ModDownIO {
   // first (they land in the coefficient file itself), S runs one group ahead of the arithmetic
   // in a double buffer, and c_r is requested one group ahead starting BEFORE the last register
   // pass (StorePrefetch).
-  static constexpr bool PIPELINED = true;
+  static constexpr bool PIPELINED = !PLAIN;
   static constexpr int IOG = 4;
   struct StorePrefetch {
     uint64_t c[IOG];
@@ -173,12 +176,14 @@ struct ModDownIO {
   v4i32 rx, rS, rc, ro;
   TW inv, cf;
   uint64_t q;
-  __device__ ModDownIO(const ModDownApply& A, const ModDownRow& R, size_t boff, const uint64_t* c_row,
+  // x_row: the x block of this (poly, batch) element, or -- PLAIN -- its delta row for this prime
+  __device__ ModDownIO(const uint64_t* x_row, const int64_t* S_row, const ModDownRow& R, const uint64_t* c_row,
                        uint64_t* o_row, unsigned bytes, uint64_t q_)
-      : rx(make_rsrc(A.xs + boff, bytes)), rS(make_rsrc((const uint64_t*)(A.S + boff), bytes)),
+      : rx(make_rsrc(x_row, bytes)), rS(make_rsrc((const uint64_t*)S_row, bytes)),
         rc(make_rsrc(c_row, bytes)), ro(make_rsrc(o_row, bytes)), inv(R.inv), cf(R.cf), q(q_)
   {
   }
+  __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const { return ld(rx, tid, c); }  // (PLAIN)
   static __device__ __forceinline__ uint64_t ld(const v4i32& r, unsigned tid, unsigned c)
   {
     v2i32 a = hx_buffer_load_v2(r, (int)(tid * 8u), (int)(c * 8u), 0);
@@ -399,12 +404,13 @@ ntt_moddown_prep_kernel(PolyBases polys, int row, int prime, int batch, ModDownP
   const PrimeDev* pd = primes + prime;
   const size_t N = Geo<LOGN>::N;
   const uint64_t* in = poly_base(polys, (unsigned)pi);
-  const InvPrepIO io(in + ((size_t)row * batch + b) * N, P, ((size_t)pi * batch + b) * N,
+  const size_t pstride = P.poly_stride ? (size_t)P.poly_stride : (size_t)batch * N;
+  const InvPrepIO io(in + ((size_t)row * batch + b) * N, P, (size_t)pi * pstride + (size_t)b * N,
                      (unsigned)N * 8u);
   ntt_body<LOGN, true>(lds, io, tw_arena + pd->tw_inv_off, pd);
 }
 // ... forward transform of delta on every kept row, subtract + divide in the store
-template <int LOGN>
+template <int LOGN, bool PLAIN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
 ntt_moddown_apply_kernel(PolyBases polys, PolyBases outs, NttRows rows, int nkeep, int batch, ModDownApply A,
                          const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
@@ -445,9 +451,12 @@ ntt_moddown_apply_kernel(PolyBases polys, PolyBases outs, NttRows rows, int nkee
   // too small to have that row at all.
   uint64_t* odata = poly_base(outs, pi);
   const uint64_t* idata = R.mode == 2 ? odata : poly_base(polys, pi);
-  const ModDownIO io(A, R, ((size_t)pi * batch + b) * N,
-                     idata + ((size_t)(R.mode == 2 ? R.out_row : uniform_u16(rows.row, ri)) * batch + b) * N,
-                     odata + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd->q);
+  const size_t eoff = ((size_t)pi * batch + b) * N;
+  const uint64_t* xrow = PLAIN ? A.delta + (size_t)pi * (size_t)A.delta_poly_stride + ((size_t)ri * batch + b) * N
+                               : A.xs + eoff;
+  const ModDownIO<PLAIN> io(xrow, PLAIN ? nullptr : A.S + eoff, R,
+                            idata + ((size_t)(R.mode == 2 ? R.out_row : uniform_u16(rows.row, ri)) * batch + b) * N,
+                            odata + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd->q);
   ntt_body<LOGN, false>(lds, io, tw_arena + pd->tw_fwd_off, pd);
 }
 
@@ -493,10 +502,7 @@ static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& r
 }
 
 template <int LOGN>
-static hipError_t launch_moddown(const PolyBases& polys, const PolyBases& outs, int drop_row, int drop_prime,
-                                 const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
-                                 const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena,
-                                 hipStream_t st)
+static hipError_t moddown_attrs()
 {
   constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
   static bool attr_set = false;
@@ -504,12 +510,36 @@ static hipError_t launch_moddown(const PolyBases& polys, const PolyBases& outs, 
     hipError_t e = hipFuncSetAttribute((const void*)ntt_moddown_prep_kernel<LOGN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_kernel<LOGN>,
+      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_kernel<LOGN, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_kernel<LOGN, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
       return e;
     attr_set = true;
   }
+  return hipSuccess;
+}
+static unsigned moddown_apply_grid(unsigned npoly, unsigned nkeep, unsigned batch)
+{
+#ifdef HX_MD_OLDMAP
+  return npoly * nkeep * batch;
+#else
+  return 8u * md_tile(nkeep, npoly * batch).per_xcd;
+#endif
+}
+
+template <int LOGN>
+static hipError_t launch_moddown(const PolyBases& polys, const PolyBases& outs, int drop_row, int drop_prime,
+                                 const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
+                                 const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena,
+                                 hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+  hipError_t e = moddown_attrs<LOGN>();
+  if (e != hipSuccess)
+    return e;
   hipLaunchKernelGGL((ntt_moddown_prep_kernel<LOGN>), dim3((unsigned)polys.n * (unsigned)batch),
                      dim3(Geo<LOGN>::T), lds_bytes, st, polys, drop_row, drop_prime, batch, P, primes,
                      tw_arena);
@@ -518,13 +548,9 @@ static hipError_t launch_moddown(const PolyBases& polys, const PolyBases& outs, 
     hipLaunchKernelGGL(moddown_S_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)),
                        dim3(256), 0, st, P, n);
   }
-#ifdef HX_MD_OLDMAP
-  const unsigned apply_grid = (unsigned)polys.n * (unsigned)nkeep * (unsigned)batch;
-#else
-  const unsigned apply_grid = 8u * md_tile((unsigned)nkeep, (unsigned)polys.n * (unsigned)batch).per_xcd;
-#endif
-  hipLaunchKernelGGL((ntt_moddown_apply_kernel<LOGN>), dim3(apply_grid), dim3(Geo<LOGN>::T),
-                     lds_bytes, st, polys, outs, keep, nkeep, batch, A, primes, tw_arena);
+  hipLaunchKernelGGL((ntt_moddown_apply_kernel<LOGN, false>),
+                     dim3(moddown_apply_grid((unsigned)polys.n, (unsigned)nkeep, (unsigned)batch)),
+                     dim3(Geo<LOGN>::T), lds_bytes, st, polys, outs, keep, nkeep, batch, A, primes, tw_arena);
   return hipGetLastError();
 }
 
@@ -537,6 +563,61 @@ hipError_t launch_moddown_pow2(int logn, const PolyBases& data, const PolyBases&
     case 13: return launch_moddown<13>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
     case 14: return launch_moddown<14>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
     case 15: return launch_moddown<15>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// Several dropped primes, two launches the engine brackets around its basis-extension kernel:
+//   (1) inverse transform of ONE dropped row of every listed poly (with the mod-up factor folded
+//       into the last stage, as in the single-prime path) into the x block P.xs / P.poly_stride;
+//   (2) forward transform of delta * P^-1 (A.delta) on every kept row with the store
+//       c_r <- c_r*cf - NTT(.)  -- the apply kernel with a plain load.
+template <int LOGN>
+static hipError_t launch_prep_one(const PolyBases& polys, int drop_row, int drop_prime, int batch,
+                                  const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+  hipError_t e = moddown_attrs<LOGN>();
+  if (e != hipSuccess)
+    return e;
+  hipLaunchKernelGGL((ntt_moddown_prep_kernel<LOGN>), dim3((unsigned)polys.n * (unsigned)batch),
+                     dim3(Geo<LOGN>::T), lds_bytes, st, polys, drop_row, drop_prime, batch, P, primes,
+                     tw_arena);
+  return hipGetLastError();
+}
+template <int LOGN>
+static hipError_t launch_apply_plain(const PolyBases& polys, const PolyBases& outs, const NttRows& keep,
+                                     int nkeep, int batch, const ModDownApply& A, const PrimeDev* primes,
+                                     const TW* tw_arena, hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+  hipError_t e = moddown_attrs<LOGN>();
+  if (e != hipSuccess)
+    return e;
+  hipLaunchKernelGGL((ntt_moddown_apply_kernel<LOGN, true>),
+                     dim3(moddown_apply_grid((unsigned)polys.n, (unsigned)nkeep, (unsigned)batch)),
+                     dim3(Geo<LOGN>::T), lds_bytes, st, polys, outs, keep, nkeep, batch, A, primes, tw_arena);
+  return hipGetLastError();
+}
+hipError_t launch_moddown_prep_pow2(int logn, const PolyBases& polys, int drop_row, int drop_prime, int batch,
+                                    const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena,
+                                    hipStream_t st)
+{
+  switch (logn) {
+    case 13: return launch_prep_one<13>(polys, drop_row, drop_prime, batch, P, primes, tw_arena, st);
+    case 14: return launch_prep_one<14>(polys, drop_row, drop_prime, batch, P, primes, tw_arena, st);
+    case 15: return launch_prep_one<15>(polys, drop_row, drop_prime, batch, P, primes, tw_arena, st);
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_moddown_apply_plain_pow2(int logn, const PolyBases& polys, const PolyBases& outs,
+                                           const NttRows& keep, int nkeep, int batch, const ModDownApply& A,
+                                           const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  switch (logn) {
+    case 13: return launch_apply_plain<13>(polys, outs, keep, nkeep, batch, A, primes, tw_arena, st);
+    case 14: return launch_apply_plain<14>(polys, outs, keep, nkeep, batch, A, primes, tw_arena, st);
+    case 15: return launch_apply_plain<15>(polys, outs, keep, nkeep, batch, A, primes, tw_arena, st);
   }
   return hipErrorInvalidValue;
 }

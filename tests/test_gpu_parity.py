@@ -627,6 +627,46 @@ def test_bring_to_set_multi_matches_separate_steps(hx, ndrop):
                 assert np.array_equal(got[r, b], want[keep.index(i)])
 
 
+@pytest.mark.parametrize("m", [16384, 65536])
+@pytest.mark.parametrize("ptxt", [65537, 1])
+def test_several_primes_mod_switch_batched_over_parts_mixed_prime_sizes(hx, m, ptxt):
+    """The batched several-primes mod-switch (engine.hip scale_down_multi_fused): three parts, two of
+    them lazy copies of one object, a batch of 2, dropped primes of DIFFERENT sizes (56-bit special
+    primes next to a 60-bit ctxt prime, as every multiply after the first drops them: the dropped
+    set is Garner-ed in ascending order), with and without a mod-up by a small prime folded in.
+    Every word against the oracle's addPrimesAndScale + scaleDownToSet."""
+    g60, g56, g45 = O.PrimeGen(60, m), O.PrimeGen(56, m), O.PrimeGen(45, m)
+    primes = [g60.next() for _ in range(5)] + [g56.next() for _ in range(3)] + [g45.next()]
+    P = Pair(hx, m, primes)
+    ct, sp, small = [0, 1, 2, 3, 4], [5, 6, 7], 8
+    cur = ct + sp
+    B = 2
+    base = [P.rand(cur, 300 + i, batch=B) for i in range(2)]
+    for add in ([], [small]):
+        drop = sp + [ct[-1]]
+        keep = [i for i in cur if i not in drop] + add
+        x = hx.DoubleCRT(P.g, cur, B, base[0])
+        parts = [x.copy(), x.copy(), hx.DoubleCRT(P.g, cur, B, base[1])]
+        if add:
+            hx.bringToSetMulti(parts, add, keep, ptxt)
+        else:
+            hx.scaleDownToSetMulti(parts, keep, ptxt)
+        assert np.array_equal(x.download(), base[0])          # the shared source is untouched
+        for part, src in zip(parts, (base[0], base[0], base[1])):
+            idx = part.getIndexSet()
+            assert sorted(idx) == sorted(keep)
+            got = part.download()
+            for b in range(B):
+                rows, have = src[:, b], list(cur)
+                if add:
+                    rows = np.vstack([P.o.scale_by_primes(cur, rows, add), np.zeros((len(add), P.N), dtype=np.uint64)])
+                    have = cur + add
+                want = P.o.scale_down(have, rows, drop, ptxt)
+                wkeep = [i for i in have if i not in drop]
+                for r, i in enumerate(idx):
+                    assert np.array_equal(got[r, b], want[wkeep.index(i)]), (add, i, b)
+
+
 # ---------------------------------------------------------------- C++ host facade
 def test_cpp_facade_matches_oracle(hx, tmp_path):
     """include/helib_amd.hpp (the reference-named C++ classes over the C ABI) driven by a C++

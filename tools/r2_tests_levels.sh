@@ -1,0 +1,6 @@
+#!/bin/bash
+export TMPDIR=/tmp
+tag=${1:-r2f}; out=gpurun_out/$tag; mkdir -p $out
+timeout 900 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -15 $out/pytest_gpu.log
+timeout 200 python tools/bench_levels.py --scheme bgv --m 32768 --bits 950 --batch 128 --steps 6 > $out/bgv.json 2> $out/bgv.err; echo "bgv rc=$?"; cat $out/bgv.json; tail -3 $out/bgv.err
+timeout 200 python tools/bench_levels.py --steps 6 > $out/ckks.json 2> $out/ckks.err; echo "ckks rc=$?"; cat $out/ckks.json; tail -3 $out/ckks.err
