@@ -109,6 +109,32 @@ struct RowScalars {
 
 typedef unsigned __int128 u128;
 
+// Read-only tables (basis-extension plans, per-row constants): pointers into the CONSTANT address
+// space.  A load through a plain pointer held in a by-value kernel-argument struct is a vector
+// global_load even when its address is wave-uniform -- the kernel also stores, so the compiler
+// may not assume the table is invariant -- and a loop over targets then waits a full memory
+// round trip per iteration (round 1: rns_extend_fast_kernel<8> ran 4x below its instruction count).
+// Through address space 4 the same loads are s_load (scalar cache, issued ahead by the compiler).
+#define HX_RO __attribute__((address_space(4)))
+typedef const HX_RO uint64_t* ro_u64;
+typedef const HX_RO uint32_t* ro_u32;
+typedef const HX_RO double* ro_f64;
+typedef const HX_RO TW* ro_tw;
+template <class T>
+__host__ __device__ inline const HX_RO T* as_ro(const T* p)
+{
+  return (const HX_RO T*)(uintptr_t)p;
+}
+// (a struct cannot be copy-constructed out of another address space: word by word)
+__device__ __forceinline__ TW ld_tw(ro_tw p, size_t i)
+{
+  ro_u64 w = (ro_u64)p;
+  TW t;
+  t.w = w[2 * i];
+  t.wp = w[2 * i + 1];
+  return t;
+}
+
 __device__ __forceinline__ uint64_t add_mod(uint64_t a, uint64_t b, uint64_t q)
 {
   uint64_t s = a + b;

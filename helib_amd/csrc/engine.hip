@@ -1926,23 +1926,23 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   pl->blob = d;
   pl->dev.n = n;
   pl->dev.nt = nt;
-  pl->dev.src_q = d + o_srcq;
-  pl->dev.src_mu64 = d + o_srcmu;
-  pl->dev.ginv = reinterpret_cast<const TW*>(d + o_ginv);
-  pl->dev.half = d + o_half;
-  pl->dev.tgt_q = d + o_tq;
-  pl->dev.tgt_mu64 = d + o_tmu64;
-  pl->dev.tgt_mu = d + o_tmu;
-  pl->dev.tgt_k = reinterpret_cast<const uint32_t*>(d + o_tk);
-  pl->dev.pmod = d + o_pmod;
-  pl->dev.W = reinterpret_cast<const TW*>(d + o_W);
-  pl->dev.upd = reinterpret_cast<const TW*>(d + o_upd);
-  pl->dev.Wp = reinterpret_cast<const TW*>(d + o_Wp);
-  pl->dev.tgt_lazy = reinterpret_cast<const uint32_t*>(d + o_tlazy);
+  pl->dev.src_q = hx::as_ro(d + o_srcq);
+  pl->dev.src_mu64 = hx::as_ro(d + o_srcmu);
+  pl->dev.ginv = hx::as_ro(reinterpret_cast<const TW*>(d + o_ginv));
+  pl->dev.half = hx::as_ro(d + o_half);
+  pl->dev.tgt_q = hx::as_ro(d + o_tq);
+  pl->dev.tgt_mu64 = hx::as_ro(d + o_tmu64);
+  pl->dev.tgt_mu = hx::as_ro(d + o_tmu);
+  pl->dev.tgt_k = hx::as_ro(reinterpret_cast<const uint32_t*>(d + o_tk));
+  pl->dev.pmod = hx::as_ro(d + o_pmod);
+  pl->dev.W = hx::as_ro(reinterpret_cast<const TW*>(d + o_W));
+  pl->dev.upd = hx::as_ro(reinterpret_cast<const TW*>(d + o_upd));
+  pl->dev.Wp = hx::as_ro(reinterpret_cast<const TW*>(d + o_Wp));
+  pl->dev.tgt_lazy = hx::as_ro(reinterpret_cast<const uint32_t*>(d + o_tlazy));
   // a_l < q_l <= max < 2*min <= 2*p_k, or the sources ascend (a_l < p_l <= p_k for l < k)
   pl->dev.garner_cs = ((max_src / 2 < min_src || std::is_sorted(p.begin(), p.end())) && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;
-  pl->dev.src_rq = reinterpret_cast<const double*>(d + o_srcrq);
-  pl->dev.tgt_mu63 = d + o_tmu63;
+  pl->dev.src_rq = hx::as_ro(reinterpret_cast<const double*>(d + o_srcrq));
+  pl->dev.tgt_mu63 = hx::as_ro(d + o_tmu63);
   {
     bool ok = pl->dev.garner_cs && n <= 8 && (min_src >> 32) != 0 && !getenv("HX_NO_FAST_BREAK");
     for (int t = 0; t < nt && ok; t++)
@@ -1953,7 +1953,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
       ok16 = (tq(t) >> 32) != 0;
     pl->dev.fast16_ok = ok16 ? 1u : 0u;
   }
-  pl->dev.tgt_chunk7 = reinterpret_cast<const uint32_t*>(d + o_tchunk);
+  pl->dev.tgt_chunk7 = hx::as_ro(reinterpret_cast<const uint32_t*>(d + o_tchunk));
   c->plans[key] = pl;
   *out = pl;
   return HX_OK;

@@ -331,45 +331,45 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
 struct ExtPlanDev {
   int n;                   // source primes
   int nt;                  // target primes
-  const uint64_t* src_q;   // [n]
-  const uint64_t* src_mu64;  // [n]
-  const TW* ginv;          // [n*n]  ginv[k*n+l] = p_l^-1 mod p_k   (l<k)
-  const uint64_t* half;    // [n] mixed-radix digits of (P-1)/2
-  const uint64_t* tgt_q;   // [nt]
-  const uint64_t* tgt_mu64;  // [nt]
-  const uint64_t* tgt_mu;  // [nt]  Barrett mu (128-bit products)
-  const uint32_t* tgt_k;   // [nt]
-  const uint64_t* pmod;    // [nt]  P mod t
-  const TW* W;             // [nt*n] W[t*n+k] = (p_0..p_{k-1}) mod t
-  const TW* upd;           // [nt]  P^-1 mod t (Shoup) for the breakIntoDigits update
+  ro_u64 src_q;   // [n]
+  ro_u64 src_mu64;  // [n]
+  ro_tw ginv;          // [n*n]  ginv[k*n+l] = p_l^-1 mod p_k   (l<k)
+  ro_u64 half;    // [n] mixed-radix digits of (P-1)/2
+  ro_u64 tgt_q;   // [nt]
+  ro_u64 tgt_mu64;  // [nt]
+  ro_u64 tgt_mu;  // [nt]  Barrett mu (128-bit products)
+  ro_u32 tgt_k;   // [nt]
+  ro_u64 pmod;    // [nt]  P mod t
+  ro_tw W;             // [nt*n] W[t*n+k] = (p_0..p_{k-1}) mod t
+  ro_tw upd;           // [nt]  P^-1 mod t (Shoup) for the breakIntoDigits update
   // BGV mod-switch correction (scaleDownToSet): ptxt = 0 disables
   uint64_t ptxt, ptxt_mu64, pinv_ptxt /* P^-1 mod ptxt */, pmod_ptxt /* P mod ptxt */;
   uint64_t ptxt_mu;  uint32_t ptxt_k;
-  const TW* Wp;            // [n] (p_0..p_{k-1}) mod ptxt
+  ro_tw Wp;            // [n] (p_0..p_{k-1}) mod ptxt
   // strength reductions decided by the host from the actual primes:
   uint32_t garner_cs;        // every source residue is < 2*p_k for every later source prime p_k:
                              // "a_l mod p_k" is one conditional subtraction
-  const uint32_t* tgt_lazy;  // [nt] 1: sum_k q_k <= 8*q_t, so the target residue can be taken from
+  ro_u32 tgt_lazy;  // [nt] 1: sum_k q_k <= 8*q_t, so the target residue can be taken from
                              // the 128-bit sum of the n products with ONE Barrett reduction
-  const double* src_rq;      // [n] 1.0 / q_k (host-rounded), for the value/P fraction
-  const uint64_t* tgt_mu63;  // [nt] floor(2^(63+k) / q_t), k = bitlen(q_t)  (red128_q8)
+  ro_f64 src_rq;      // [n] 1.0 / q_k (host-rounded), for the value/P fraction
+  ro_u64 tgt_mu63;  // [nt] floor(2^(63+k) / q_t), k = bitlen(q_t)  (red128_q8)
   uint32_t fast_ok;          // break_digits_fast_kernel's preconditions hold for this plan:
                              // garner_cs, every prime > 2^32 (32-bit reciprocals), n <= 8
   uint32_t fast16_ok;        // the same with n <= 16: rns_extend_fast_kernel
-  const uint32_t* tgt_chunk7;  // [nt] 1: every source prime <= q_t, so the limb sum may be taken 7
+  ro_u32 tgt_chunk7;  // [nt] 1: every source prime <= q_t, so the limb sum may be taken 7
                                // terms at a time with the previous remainder carried (r + 7 p q < 8 q^2)
 };
 
 // sum_k a_k * W[k]  mod q for a target whose plan says the lazy 128-bit form is exact
 template <int NMAX>
-__device__ __forceinline__ uint64_t mixed_radix_residue_lazy(const uint64_t (&a)[NMAX], const TW* Wt, int n,
+__device__ __forceinline__ uint64_t mixed_radix_residue_lazy(const uint64_t (&a)[NMAX], ro_tw Wt, int n,
                                                              uint64_t q, uint64_t mu, uint32_t k)
 {
   u128 acc = 0;
 #pragma unroll
   for (int i = 0; i < NMAX; i++)
     if (i < n)
-      acc += (u128)a[i] * Wt[i].w;
+      acc += (u128)a[i] * ld_tw(Wt, i).w;
   return red128_wide(acc, q, mu, k);
 }
 
@@ -389,7 +389,7 @@ struct ExtArgs {
 // value / P in [0,1) from the mixed-radix digits (value = a_0 + a_1 q_0 + a_2 q_0 q_1 + ...):
 // (((a_0/q_0 + a_1)/q_1 + a_2)/q_2 ...)/q_(n-1), the most significant digit entering last
 template <int NMAX>
-__device__ __forceinline__ double mixed_radix_fraction(const uint64_t (&a)[NMAX], const uint64_t* q, int n)
+__device__ __forceinline__ double mixed_radix_fraction(const uint64_t (&a)[NMAX], ro_u64 q, int n)
 {
   double acc = 0;
 #pragma unroll
@@ -421,7 +421,7 @@ rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
         if (l < k) {
           uint64_t al = P.garner_cs ? (a[l] >= pk ? a[l] - pk : a[l]) : red64(a[l], pk, mk);
           uint64_t d = sub_mod(x, al, pk);
-          TW g = P.ginv[k * n + l];
+          TW g = ld_tw(P.ginv, k * n + l);
           x = mul_shoup(d, g.w, g.wp, pk);
         }
       }
@@ -448,7 +448,7 @@ rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
 #pragma unroll
     for (int k = 0; k < NMAX; k++) {
       if (k < n) {
-        TW w = P.Wp[k];
+        TW w = ld_tw(P.Wp, k);
         acc += shoup_lazy(a[k], w, p);  // each < 2p
         if ((k & 3) == 3)
           acc = red64(acc, p, P.ptxt_mu64);
@@ -477,7 +477,7 @@ rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
   // ---- residues modulo every target prime ----
   auto residue = [&](int t) -> uint64_t {
     const uint64_t q = P.tgt_q[t], mu64 = P.tgt_mu64[t];
-    const TW* Wt = P.W + (size_t)t * n;
+    ro_tw Wt = P.W + (size_t)t * n;
     uint64_t r;
     if (P.tgt_lazy[t]) {
       r = mixed_radix_residue_lazy<NMAX>(a, Wt, n, q, P.tgt_mu[t], P.tgt_k[t]);
@@ -486,7 +486,7 @@ rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
 #pragma unroll
       for (int k = 0; k < NMAX; k++) {
         if (k < n) {
-          acc += shoup_lazy(a[k], Wt[k], q);  // each < 2q < 2^61 (q < 2^60)
+          acc += shoup_lazy(a[k], ld_tw(Wt, k), q);  // each < 2q < 2^61 (q < 2^60)
           if ((k & 3) == 3)
             acc = red64(acc, q, mu64);
         }
@@ -511,7 +511,7 @@ rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
       A.dst[(size_t)A.dst_row[t] * row_words + i] = r;
     if (A.upd_row[t] != 0xffff) {
       uint64_t* u = A.upd + (size_t)A.upd_row[t] * row_words + i;
-      const TW pinv = P.upd[t];
+      const TW pinv = ld_tw(P.upd, t);
       *u = mul_shoup(sub_mod(*u, r, q), pinv.w, pinv.wp, q);
     }
   }
@@ -562,7 +562,7 @@ break_digits_kernel(BreakArgs A, size_t row_words)
         for (int l = 0; l < NMAX; l++) {
           if (l < k) {
             uint64_t al = P.garner_cs ? (a[l] >= pk ? a[l] - pk : a[l]) : red64(a[l], pk, mk);
-            TW g = P.ginv[k * n + l];
+            TW g = ld_tw(P.ginv, k * n + l);
             x = mul_shoup(sub_mod(x, al, pk), g.w, g.wp, pk);
           }
         }
@@ -584,7 +584,7 @@ break_digits_kernel(BreakArgs A, size_t row_words)
     for (int t = 0; t < P.nt; t++) {
       const int r = t < off ? t : t + n;  // row of target t in the all-rows order
       const uint64_t q = P.tgt_q[t], mu64 = P.tgt_mu64[t];
-      const TW* Wt = P.W + (size_t)t * n;
+      ro_tw Wt = P.W + (size_t)t * n;
       uint64_t v;
       if (P.tgt_lazy[t]) {
         v = mixed_radix_residue_lazy<NMAX>(a, Wt, n, q, P.tgt_mu[t], P.tgt_k[t]);
@@ -593,7 +593,7 @@ break_digits_kernel(BreakArgs A, size_t row_words)
 #pragma unroll
         for (int k = 0; k < NMAX; k++) {
           if (k < n) {
-            acc += shoup_lazy(a[k], Wt[k], q);
+            acc += shoup_lazy(a[k], ld_tw(Wt, k), q);
             if ((k & 3) == 3)
               acc = red64(acc, q, mu64);
           }
@@ -604,7 +604,7 @@ break_digits_kernel(BreakArgs A, size_t row_words)
         v = sub_mod(v, P.pmod[t], q);
       dd[(size_t)r * row_words] = v;
       if (r >= off + n && r < A.L) {
-        const TW pinv = P.upd[t];
+        const TW pinv = ld_tw(P.upd, t);
         uint64_t* u = &xs[r * BRK_THREADS + tid];
         *u = mul_shoup(sub_mod(*u, v, q), pinv.w, pinv.wp, q);
       }
@@ -668,7 +668,7 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
     const uint64_t pk = P.src_q[k], npk = 0 - pk, pk2 = pk + pk;
 #pragma unroll
     for (int l = 0; l < k; l++)
-      x = shoup4(x + pk2 - a[l], P.ginv[k * N + l], npk);  // a_l < p_l < 2 p_k (garner_cs)
+      x = shoup4(x + pk2 - a[l], ld_tw(P.ginv, k * N + l), npk);  // a_l < p_l < 2 p_k (garner_cs)
     x = csub(x, pk2);
     a[k] = csub(x, pk);
   }
@@ -697,14 +697,14 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
   for (int t = 0; t < P.nt; t++) {
     const int r = t < off ? t : t + N;  // row of target t in the all-rows order
     const uint64_t q = P.tgt_q[t];
-    const TW* Wt = P.W + (size_t)t * N;
+    ro_tw Wt = P.W + (size_t)t * N;
     const uint64_t negfix = neg ? q - P.pmod[t] : 0;
     uint64_t v;
     if (P.tgt_lazy[t]) {
       uint64_t c00 = negfix, c01 = 0, c11 = 0;
 #pragma unroll
       for (int k = 0; k < N; k++) {
-        const uint64_t w = Wt[k].w;
+        const uint64_t w = ld_tw(Wt, k).w;
         const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
         c00 += (uint64_t)a0[k] * w0;
         c01 += (uint64_t)a0[k] * w1;
@@ -723,7 +723,7 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
       uint64_t acc = negfix;
 #pragma unroll
       for (int k = 0; k < N; k++) {
-        acc += shoup4(a[k], Wt[k], nq);
+        acc += shoup4(a[k], ld_tw(Wt, k), nq);
         if ((k & 1) && wide)
           acc = csub(acc, q8);
       }
@@ -733,7 +733,7 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
     if (r >= off + N && r < L) {
       // digits[j] -= digits[i]; digits[j] /= P_i on a later digit's own row (kept lazy, < 4q)
       uint64_t* u = &xs[r * BRK_THREADS + tid];
-      *u = shoup4(*u + q - v, P.upd[t], 0 - q);
+      *u = shoup4(*u + q - v, ld_tw(P.upd, t), 0 - q);
     }
   }
 }
@@ -763,7 +763,7 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
     const uint64_t pk = P.src_q[k], npk = 0 - pk, pk2 = pk + pk;
 #pragma unroll
     for (int l = 0; l < k; l++)
-      x = shoup4(x + pk2 - a[l], P.ginv[k * N + l], npk);  // a_l < p_l < 2 p_k (garner_cs)
+      x = shoup4(x + pk2 - a[l], ld_tw(P.ginv, k * N + l), npk);  // a_l < p_l < 2 p_k (garner_cs)
     x = csub(x, pk2);
     a[k] = csub(x, pk);
   }
@@ -783,7 +783,7 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-      acc += shoup_lazy(a[k], P.Wp[k], p);  // each < 2p
+      acc += shoup_lazy(a[k], ld_tw(P.Wp, k), p);  // each < 2p
       if ((k & 3) == 3)
         acc = red64(acc, p, P.ptxt_mu64);
     }
@@ -813,7 +813,7 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
   }
   for (int t = 0; t < P.nt; t++) {
     const uint64_t q = P.tgt_q[t];
-    const TW* Wt = P.W + (size_t)t * N;
+    ro_tw Wt = P.W + (size_t)t * N;
     const uint64_t negfix = neg ? q - P.pmod[t] : 0;
     uint64_t r;
     if (P.tgt_lazy[t]) {
@@ -821,7 +821,7 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
       uint64_t c00 = 0, c01 = 0, c10 = 0, c11 = 0;
 #pragma unroll
       for (int k = 0; k < N; k++) {
-        const uint64_t w = Wt[k].w;
+        const uint64_t w = ld_tw(Wt, k).w;
         const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
         c00 += (uint64_t)a0[k] * w0;
         c01 += (uint64_t)a0[k] * w1;
@@ -837,7 +837,7 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
         uint64_t c00 = 0, c01 = 0, c11 = 0;
 #pragma unroll
         for (int k = k0; k < (k0 + 7 < N ? k0 + 7 : N); k++) {
-          const uint64_t w = Wt[k].w;
+          const uint64_t w = ld_tw(Wt, k).w;
           const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
           c00 += (uint64_t)a0[k] * w0;
           c01 += (uint64_t)a0[k] * w1;
@@ -853,7 +853,7 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
       uint64_t acc = negfix;
 #pragma unroll
       for (int k = 0; k < N; k++) {
-        acc += shoup4(a[k], Wt[k], nq);
+        acc += shoup4(a[k], ld_tw(Wt, k), nq);
         if ((k & 1) && wide)
           acc = csub(acc, q8);
       }
@@ -869,7 +869,7 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
       A.dst[(size_t)A.dst_row[t] * row_words + i] = r;
     if (A.upd_row[t] != 0xffff) {
       uint64_t* u = A.upd + (size_t)A.upd_row[t] * row_words + i;
-      const TW pinv = P.upd[t];
+      const TW pinv = ld_tw(P.upd, t);
       *u = mul_shoup(sub_mod(*u, r, q), pinv.w, pinv.wp, q);
     }
   }
