@@ -21,11 +21,11 @@ workload : (default `bgv32768`) BGV m=32768, p=65537, bits=950 -> L=16 x 60-bit 
            reference's alternative noise bounds (no norms).
            `config.fixed_level_mult_per_s` additionally reports tensorProduct+reLinearize alone
            (hx_mul_relin, no prime-set changes), the kernel-level pipeline DESIGN.md analyses.
-step     : `--mults-per-step` (16) x [copy(ctxt1); copy.multiplyBy(ctxt2)] over the batch of
+step     : `--mults-per-step` (32) x [copy(ctxt1); copy.multiplyBy(ctxt2)] over the batch of
            `--batch` (128) independent ciphertext pairs resident in HBM -- the loop body of
            benchmarks/bgv_basic.cpp:158-164, which also multiplies the same two operands every
-           iteration -- i.e. 2048 ciphertext multiplications per step, so that the driver's 20 steps
-           time about 2 s of device work.  BOTH operand copies are inside the timed region (the
+           iteration -- i.e. 4096 ciphertext multiplications per step, so that the driver's 20 steps
+           time about 2.5 s of device work.  BOTH operand copies are inside the timed region (the
            reference pauses its timer for copy(ctxt1); multiplyBy's own copy of `other`,
            src/Ctxt.cpp:1700-1745, is timed there too).  A result is dropped once the next one is
            complete (the reference's loop overwrites its ciphertext): the slab pool recycles storage.
@@ -290,11 +290,11 @@ def real_inputs(hx, hc, cc, ctx, B, seed):
             if got != [int(v) for v in want]:
                 raise SystemExit(f"bench: decrypt(multiplyBy(a, b)) != a*b at batch element {b} -- results are wrong")
         return len(todo)
-    return out[0], out[1], check
+    return out[0], out[1], check, sk, msgs
 
 
 def run_fresh(hx, hc, cc, ctx, B, steps, warmup, rng, sync, barrier, measure=True, inputs="real", seed=7,
-              prepared=None, mults_per_step=16, verify=True):
+              prepared=None, mults_per_step=32, verify=True):
     """measure=True: added noise measured as in the reference's default build (canonical-embedding
     norms of the mod-switch deltas and of the key-switch digits, evaluated on the device);
     False: the reference's alternative high-probability bounds, no norms.
@@ -307,7 +307,7 @@ def run_fresh(hx, hc, cc, ctx, B, steps, warmup, rng, sync, barrier, measure=Tru
     D = len(cc.digits)
     check = None
     if inputs == "real":
-        fa, fb, check = prepared or real_inputs(hx, hc, cc, ctx, B, seed)
+        fa, fb, check = (prepared or real_inputs(hx, hc, cc, ctx, B, seed))[:3]
     else:
         kb = np.stack([uniform_rows(rng, cc.primes, allp, 1, n)[:, 0] for _ in range(D)])
         ka = np.stack([uniform_rows(rng, cc.primes, allp, 1, n)[:, 0] for _ in range(D)])
@@ -346,8 +346,14 @@ def run_fresh(hx, hc, cc, ctx, B, steps, warmup, rng, sync, barrier, measure=Tru
     sync()
     barrier()
     total = time.perf_counter() - t0
+    # host cost of enqueueing one multiply, from an idle device (inside the loop above the HIP
+    # queue fills up and the host is throttled to the device's pace, so `host` is not it)
+    t1 = time.perf_counter()
+    run(4)
+    enq = (time.perf_counter() - t1) / 4
+    sync()
     nver = check(last) if (check and verify) else 0
-    return total, sorted(last.primeSet), host, nver
+    return total, sorted(last.primeSet), host, nver, enq
 
 
 def batch1_latency(hx, hc, fa, fb, sync, reps=12):
@@ -370,6 +376,77 @@ def batch1_latency(hx, hc, fa, fb, sync, reps=12):
             ts.append((time.perf_counter() - t0) * 1e3)
     ts.sort()
     return ts[len(ts) // 2], ts[0]
+
+
+def bgv_basic_ops(hx, hc, cc, fa, fb, sk, msgs, sync, reps=8):
+    """The other lines of the reference's benchmark list (benchmarks/bgv_basic.cpp:36-211) on the same
+    key pair and fresh ciphertexts: += / -= / negate / square / multLowLvl (no relinearisation) /
+    rotate by one generator step (EncryptedArray::rotate on a native dimension is one smartAutomorph;
+    the key-switching matrix for it is generated here, untimed) over the resident batch -- the copy of
+    the operand is made before the timer starts, as the reference pauses its timer for it -- and
+    PubKey::Encrypt / SecKey::Decrypt of one ciphertext.  Milliseconds per call and, for the batched
+    ones, operations per second; decrypt(op(a, b)) is checked for one batch element of each."""
+    from helib_amd import hostnt
+    p, n, B = cc.ptxtSpace, cc.phim, fa.parts["1"].batch
+    g = hostnt.ZmStar(cc.m, cc.p).gens[0]
+    sk.GenKeySWmatrix(1, g)
+    fa.ksw_auto[g] = sk.keySwitching[(1, g)].W      # (a ciphertext carries the matrices its key had at encryption)
+    ma, mb = msgs[0, 0].astype(object), msgs[1, 0].astype(object)
+
+    def negacyclic(x, y):
+        full = np.convolve(np.array(x, dtype=np.int64) % p, np.array(y, dtype=np.int64) % p)
+        return [int(v) % p for v in (full[:n] - np.append(full[n:], 0))]
+
+    def rot(x):   # f(X) -> f(X^g) mod X^n + 1
+        out = [0] * n
+        for i, v in enumerate(x):
+            e = i * g % (2 * n)
+            out[e % n] = (out[e % n] + (int(v) if e < n else -int(v))) % p
+        return out
+    ops = {
+        "adding_two_ciphertexts": (lambda c: c.__iadd__(fb), lambda: [int(v) % p for v in (ma + mb)]),
+        "subtracting_two_ciphertexts": (lambda c: c.__isub__(fb), lambda: [int(v) % p for v in (ma - mb)]),
+        "negating_a_ciphertext": (lambda c: c.negate(), lambda: [int(-v) % p for v in ma]),
+        "square_a_ciphertext": (lambda c: c.square(), lambda: negacyclic(ma, ma)),
+        "multiplying_two_ciphertexts_no_relin": (lambda c: c.multLowLvl(fb), lambda: negacyclic(ma, mb)),
+        "rotate_a_ciphertext_by1": (lambda c: c.smartAutomorph(g), lambda: rot(ma)),
+    }
+    out = {}
+    for name, (fn, want) in ops.items():
+        copies = [fa.clone() for _ in range(reps + 1)]
+        fn(copies[0])                      # warm (plans, slabs)
+        _ = copies[0].lnNoise
+        sync()
+        t0 = time.perf_counter()
+        for c in copies[1:]:
+            fn(c)
+        _ = copies[-1].lnNoise
+        sync()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        res = copies[-1]
+        one = res.clone()
+        one.parts = {h: hx.DoubleCRT(q.context, q.getIndexSet(), 1, q.download()[:, 0:1]) for h, q in res.parts.items()}
+        if sk.Decrypt(one) != want():
+            raise SystemExit(f"bench: decrypt({name}) is wrong")
+        out[name] = {"ms_per_call_batch": round(ms, 4), "batch": B, "per_s": round(B / (ms * 1e-3), 1)}
+        del copies, res, one
+    msg = msgs[0, 0]
+    sk.Encrypt(msg)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ct = sk.Encrypt(msg)
+    sync()
+    out["encrypting_ciphertexts"] = {"ms_per_call": round((time.perf_counter() - t0) / reps * 1e3, 4), "batch": 1}
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dec = sk.Decrypt(ct)
+    out["decrypting_ciphertexts"] = {"ms_per_call": round((time.perf_counter() - t0) / reps * 1e3, 4), "batch": 1}
+    if dec != [int(v) for v in msg]:
+        raise SystemExit("bench: decrypt(encrypt(m)) != m")
+    out["note"] = ("benchmarks/bgv_basic.cpp:36-211 at m=32768 p=65537; operand copy before the timer as there; "
+                   "batched lines run the whole resident batch per call, encrypt/decrypt one ciphertext")
+    return out
 
 
 def moddown_launch_set(hx, hc, cc, ctx, fa, fb, iters=6):
@@ -523,8 +600,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="independent ciphertext pairs per GPU per launch set")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="split this many pairs over the ranks (strong scaling; configs[3]: 512) instead of --batch per rank")
-    ap.add_argument("--mults-per-step", type=int, default=16,
-                    help="multiplyBy calls over the resident batch per step (16 x 128 = 2048 multiplications per step)")
+    ap.add_argument("--mults-per-step", type=int, default=32,
+                    help="multiplyBy calls over the resident batch per step (32 x 128 = 4096 multiplications per step)")
     ap.add_argument("--cpu-sample", type=int, default=60, help="multiplies timed on the CPU (0 = skip); 60 = about 15 s of one core")
     ap.add_argument("--ntt-iters", type=int, default=50)
     ap.add_argument("--workload", default="bgv32768", choices=["bgv32768", "bgv32768_fixed", "ckks65536"])
@@ -579,12 +656,12 @@ def main():
         l, k, d = len(cc.ctxtPrimes), len(cc.specialPrimes), len(cc.digits)
         hc.Ctxt.measure = True
         prepared = real_inputs(hx, hc, cc, ctx, B, 7 + rank) if args.inputs == "real" else None
-        dtb, _, host_b, _ = run_fresh(hx, hc, cc, ctx, B, max(1, args.steps // 4), args.warmup, rng, sync,
+        dtb, _, host_b, _, enq_b = run_fresh(hx, hc, cc, ctx, B, max(1, args.steps // 4), args.warmup, rng, sync,
                                       group.barrier, measure=False, inputs=args.inputs, prepared=prepared,
                                       mults_per_step=R, verify=False)
         dtb = group.max_over_ranks(dtb) / max(1, args.steps // 4) * args.steps
         host_b = host_b / max(1, args.steps // 4) * args.steps
-        dt, res_primes, host_s, nver = run_fresh(hx, hc, cc, ctx, B, args.steps, args.warmup, rng, sync,
+        dt, res_primes, host_s, nver, _ = run_fresh(hx, hc, cc, ctx, B, args.steps, args.warmup, rng, sync,
                                                  group.barrier, measure=True, inputs=args.inputs,
                                                  prepared=prepared, mults_per_step=R)
         dt = group.max_over_ranks(dt)
@@ -618,6 +695,8 @@ def main():
                  # norm read-backs; the bound-noise run has no waits and is the pure enqueue cost
                  "host_ms_per_step_incl_norm_waits": round(host_s / args.steps * 1e3, 4),
                  "host_enqueue_ms_per_step": round(host_b / args.steps * 1e3, 4),
+                 # one multiply enqueued on an idle device, noise bounds (no read-backs): the host's own cost
+                 "host_enqueue_ms_per_mult_from_idle": round(enq_b * 1e3, 4),
                  "result_primes": res_primes,
                  "inputs": ("key pair, relinearisation matrix and public-key encryptions of random plaintexts "
                             "from helib_amd.keys (as benchmarks/bgv_basic.cpp:144-157)" if args.inputs == "real"
@@ -628,7 +707,11 @@ def main():
             roof = ntt_roofline(hx, sub, fixed_primes, list(range(l)), list(range(l, l + k)),
                                 shape["digits"], B, rng, args.ntt_iters)
             if args.inputs == "real" and not args.no_extras:
-                fa, fb, _ = prepared
+                fa, fb, _, sk, msgs = prepared
+                try:
+                    extra["bgv_basic_ops"] = bgv_basic_ops(hx, hc, cc, fa, fb, sk, msgs, sync)
+                except Exception as e:   # (a wrong result is a SystemExit and still aborts the bench)
+                    extra["bgv_basic_ops"] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
                 med, best = batch1_latency(hx, hc, fa, fb, sync)
                 extra["batch1_latency_ms"] = round(med, 4)
                 extra["batch1_latency_ms_min"] = round(best, 4)

@@ -172,6 +172,86 @@ conv_split8_kernel(uint64_t* __restrict__ cbuf, uint64_t* __restrict__ qbuf, Ptr
   }
 }
 
+// ---- power-of-two rings beyond one row kernel (N = 2^16 .. 2^18, m up to 2^19): Cmodulus::FFT /
+// iFFT (src/CModulus.cpp:389-426, 493-553; the reference only needs k <= NTL's MaxRoot, :108-110) as
+// S = 4 / 8 sub-transforms of Q = N/S points (conv_core.h) with NATURAL order on both sides:
+//   forward   big_pre  : in[row][b][p + gQ] --first log2(S) Cooley-Tukey stages--> qbuf[((ri*S+g)*batch+b)][p]
+//             row kernels on the S sub-blocks (each natural order within its block)
+//             big_post : out[row][b][j*S + brev(g)] = qbuf[g][j]       (the bit reversal of the top index bits)
+//   inverse   big_pre  : qbuf[g][j] = in[row][b][j*S + brev(g)]; sub-inverses (scaled by 1/Q);
+//             big_post : last log2(S) Gentleman-Sande stages incl. 1/S -> out[row][b][p + gQ]
+template <int S>
+__global__ void __launch_bounds__(256)
+big_pre_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ qbuf, NttRows rows, PtrList cps, int batch,
+               uint32_t Q, int inverse)
+{
+  constexpr int LS = S == 8 ? 3 : 2;
+  const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
+  const ConvPrimeDev* C = (const ConvPrimeDev*)cps.p[ri];
+  const uint64_t q = C->q;
+  const uint64_t* src = in + ((size_t)rows.row[ri] * batch + b) * S * Q;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < Q; p += gridDim.x * blockDim.x) {
+    uint64_t e[S];
+    if (!inverse) {
+#pragma unroll
+      for (int g = 0; g < S; g++)
+        e[g] = src[p + (size_t)g * Q];
+      if constexpr (S == 8) {
+        split_fwd8(e, C->S8, q);
+      } else {
+        uint64_t o[4];
+        split_fwd4(e[0], e[1], e[2], e[3], C->S, q, o);
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+          e[g] = o[g];
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < S; g++)
+        e[g] = src[(size_t)p * S + brev_bits((unsigned)g, LS)];
+    }
+#pragma unroll
+    for (int g = 0; g < S; g++)
+      qbuf[(((size_t)ri * S + g) * batch + b) * Q + p] = e[g];
+  }
+}
+template <int S>
+__global__ void __launch_bounds__(256)
+big_post_kernel(const uint64_t* __restrict__ qbuf, uint64_t* __restrict__ out, NttRows rows, PtrList cps, int batch,
+                uint32_t Q, int inverse)
+{
+  constexpr int LS = S == 8 ? 3 : 2;
+  const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
+  const ConvPrimeDev* C = (const ConvPrimeDev*)cps.p[ri];
+  const uint64_t q = C->q;
+  uint64_t* dst = out + ((size_t)rows.row[ri] * batch + b) * S * Q;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < Q; p += gridDim.x * blockDim.x) {
+    uint64_t e[S];
+#pragma unroll
+    for (int g = 0; g < S; g++)
+      e[g] = qbuf[(((size_t)ri * S + g) * batch + b) * Q + p];
+    if (!inverse) {
+#pragma unroll
+      for (int g = 0; g < S; g++)
+        dst[(size_t)p * S + brev_bits((unsigned)g, LS)] = e[g];
+    } else {
+      if constexpr (S == 8) {
+        split_inv8(e, C->S8, q);
+      } else {
+        const uint64_t c4[4] = {e[0], e[1], e[2], e[3]};
+        uint64_t a[4];
+        split_inv4(c4, C->S, q, a);
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+          e[g] = a[g];
+      }
+#pragma unroll
+      for (int g = 0; g < S; g++)
+        dst[p + (size_t)g * Q] = e[g];
+    }
+  }
+}
+
 // ---- convolution modulo a prime WITHOUT the 2-power roots (q-1 not divisible by 2^(bk+1)):
 // the exact integer convolution is taken modulo three auxiliary NTT primes A0, A1, A2 (each
 // 2^20 | A-1, A > 2^59) and recombined -- what NTL does for a zz_p modulus that is not an FFT prime.

@@ -155,6 +155,7 @@ struct hx_ctx {
   PrimeDev* d_cprimes = nullptr;
   int ncprimes = 0, cprimes_cap = 0;
   std::vector<struct BluePrime*> blue;
+  std::vector<ConvPlan> bigplan;  // power-of-two rings with N = 2^16..2^18: per-prime split plans (pow2_big_rows)
   std::vector<int64_t> psi_low, phi_coef;  // -Psi mod X^(dq+1) and Phi_m, small integers
   std::map<std::vector<uint64_t>, ExtPlan*> plans;
   // stream-ordered device-memory pool for poly slabs: every slab is used on the context's one
@@ -1168,7 +1169,20 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
   if (root == 0)
     root = hxh::find_prim_root(q, e);
   // verify the order (reference: FindPrimRootT's independent check)
-  if (hxh::powmod(root, e, q) != 1 || hxh::powmod(root, e / 2, q) == 1)
+  // (order exactly e: root^e = 1 and root^(e/p) != 1 for every prime factor p of e)
+  bool prim = hxh::powmod(root, e, q) == 1;
+  {
+    uint64_t rest = e;
+    for (uint64_t p = 2; prim && p * p <= rest; p++)
+      if (rest % p == 0) {
+        prim = hxh::powmod(root, e / p, q) != 1;
+        while (rest % p == 0)
+          rest /= p;
+      }
+    if (prim && rest > 1)
+      prim = hxh::powmod(root, e / rest, q) != 1;
+  }
+  if (!prim)
     return fail(HX_ERR_INVALID, "root is not a primitive %llu-th root of unity mod q",
                 (unsigned long long)e);
   PrimeHost ph;
@@ -1183,9 +1197,12 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
       default:
         if (c->logn >= 1 && c->logn <= 12)
           CHK(upload_tw_small(c, ph));
-        break;  // larger rings: element-wise / RNS ops still work; NTT reports UNSUPPORTED
+        break;  // N = 2^16..2^18: split plans below; beyond that element-wise / RNS ops still work
     }
   }
+  ConvPlan big;
+  if (c->pow2 && c->logn >= 16 && c->logn <= 18)
+    CHK(conv_plan_create(c, q, c->logn, root, &big));
   PrimeDev pd;
   memset(&pd, 0, sizeof pd);
   pd.q = q;
@@ -1198,6 +1215,8 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
   int idx = (int)c->primes.size();
   HIPCHK(hipMemcpy(c->d_primes + idx, &pd, sizeof pd, hipMemcpyHostToDevice));
   c->primes.push_back(ph);
+  if (c->pow2)
+    c->bigplan.push_back(big);
   if (!c->pow2) {
     int rc = blue_prime_create(c, idx);
     if (rc != HX_OK) {
@@ -1233,8 +1252,8 @@ static int poly_new(hx_ctx* c, int batch, const int* idx, int nrows, int cap, vo
 {
   if (!c || !out || batch < 1)
     return fail(HX_ERR_INVALID, "bad argument");
+  CTX_ENTER(c);   // (before check_rows: it reads the prime list a concurrent hx_ctx_add_prime grows)
   CHK(check_rows(c, idx, nrows, allow_dup));
-  CTX_ENTER(c);
   if (cap < nrows)
     cap = nrows;
   if (cap < 1)
@@ -1515,6 +1534,51 @@ static int ntt_launch(hx_ctx* c, int logn, const PrimeDev* table, const uint64_t
 static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
                           const std::vector<std::pair<int, int>>& rows, int batch, bool inverse);
 
+// power-of-two rings with N = 2^16..2^18: split into 4 / 8 sub-transforms on the row kernels, natural
+// order in and out (kernels and layout: bluestein.h big_pre / big_post); in == out is allowed
+static int pow2_big_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
+                         const std::vector<std::pair<int, int>>& rows, int batch, bool inverse)
+{
+  const int logn = c->logn;
+  const int S = logn > 17 ? 8 : 4, lsub = logn - (S == 8 ? 3 : 2);
+  const uint32_t Q = 1u << lsub;
+  const size_t row_words = (size_t)batch << logn;
+  // rows per pass: one launch descriptor, and at most 512 MiB of sub-block scratch
+  size_t chunk = std::max<size_t>(1, std::min<size_t>(MAX_ROWS / S, ((size_t)64 << 20) / row_words));
+  CHK(ensure_scratch(c, 9, std::min(chunk, rows.size()) * row_words));
+  uint64_t* qbuf = c->scratch[9];
+  for (size_t first = 0; first < rows.size(); first += chunk) {
+    const int R = (int)std::min(chunk, rows.size() - first);
+    NttRows d;
+    hx::PtrList cps;
+    std::vector<std::pair<int, int>> sub;
+    for (int r = 0; r < R; r++) {
+      const auto& rp = rows[first + r];
+      if (rp.first > 0xffff)
+        return fail(HX_ERR_UNSUPPORTED, "row index too large for one launch descriptor");
+      d.row[r] = (uint16_t)rp.first;
+      d.prime[r] = (uint16_t)rp.second;
+      const ConvPlan& pl = c->bigplan[(size_t)rp.second];
+      cps.p[r] = pl.dev;
+      for (int g = 0; g < S; g++)
+        sub.emplace_back(r * S + g, pl.pd[g]);
+    }
+    const dim3 grid = grid2(Q, (size_t)R * batch);
+    if (S == 8)
+      hipLaunchKernelGGL(hx::big_pre_kernel<8>, grid, dim3(256), 0, c->stream, in, qbuf, d, cps, batch, Q, inverse ? 1 : 0);
+    else
+      hipLaunchKernelGGL(hx::big_pre_kernel<4>, grid, dim3(256), 0, c->stream, in, qbuf, d, cps, batch, Q, inverse ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    CHK(ntt_launch(c, lsub, c->d_cprimes, qbuf, qbuf, sub, batch, inverse));
+    if (S == 8)
+      hipLaunchKernelGGL(hx::big_post_kernel<8>, grid, dim3(256), 0, c->stream, qbuf, out, d, cps, batch, Q, inverse ? 1 : 0);
+    else
+      hipLaunchKernelGGL(hx::big_post_kernel<4>, grid, dim3(256), 0, c->stream, qbuf, out, d, cps, batch, Q, inverse ? 1 : 0);
+    HIPCHK(hipGetLastError());
+  }
+  return HX_OK;
+}
+
 // Cmodulus::FFT / iFFT on the listed (row, prime) pairs of a [rows][batch][phi(m)] buffer
 static int ntt_list(hx_ctx* c, const uint64_t* in, uint64_t* out,
                     const std::vector<std::pair<int, int>>& rows, int batch, bool inverse)
@@ -1523,8 +1587,10 @@ static int ntt_list(hx_ctx* c, const uint64_t* in, uint64_t* out,
     return HX_OK;
   if (!c->pow2)
     return bluestein_rows(c, in, out, rows, batch, inverse);
-  if (c->logn < 1 || c->logn > 15)
-    return fail(HX_ERR_UNSUPPORTED, "power-of-two NTT supports 2 <= phi(m) <= 32768");
+  if (c->logn >= 16 && c->logn <= 18)
+    return pow2_big_rows(c, in, out, rows, batch, inverse);
+  if (c->logn < 1 || c->logn > 18)
+    return fail(HX_ERR_UNSUPPORTED, "power-of-two NTT supports 2 <= phi(m) <= 262144");
   return ntt_launch(c, c->logn, c->d_primes, in, out, rows, batch, inverse);
 }
 
@@ -1829,6 +1895,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   size_t o_tlazy = take((nt + 1) / 2);
   size_t o_srcrq = take(n), o_tmu63 = take(nt);
   size_t o_tchunk = take((nt + 1) / 2);
+  const size_t pack_stride = 8 + 2 * (size_t)n;   // per-target record of the fast kernels (TgtRec in rns_kernels.h)
+  size_t o_pack = take((size_t)nt * pack_stride);
   std::vector<uint64_t> h(off, 0);
   hxh::BigU P(1);
   for (int k = 0; k < n; k++) {
@@ -1920,10 +1988,26 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     pl->dev.pinv_ptxt = pinv;
     pl->dev.pmod_ptxt = run;
   }
+  for (int t = 0; t < nt; t++) {
+    uint64_t* rec = &h[o_pack + (size_t)t * pack_stride];
+    rec[0] = h[o_tq + t];
+    rec[1] = h[o_pmod + t];
+    rec[2] = h[o_tmu63 + t];
+    rec[3] = h[o_tmu64 + t];
+    rec[4] = (uint64_t)tk[t] | ((uint64_t)tlazy[t] << 8) | ((uint64_t)tchunk[t] << 9);
+    rec[5] = h[o_upd + 2 * (size_t)t];
+    rec[6] = h[o_upd + 2 * (size_t)t + 1];
+    rec[7] = h[o_tmu + t];
+    for (int k = 0; k < n; k++) {
+      rec[8 + k] = h[o_W + 2 * ((size_t)t * n + k)];
+      rec[8 + n + k] = h[o_W + 2 * ((size_t)t * n + k) + 1];
+    }
+  }
   uint64_t* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, off * 8));
   HIPCHK(hipMemcpy(d, h.data(), off * 8, hipMemcpyHostToDevice));
   pl->blob = d;
+  pl->dev.tgt_pack = hx::as_ro(d + o_pack);
   pl->dev.n = n;
   pl->dev.nt = nt;
   pl->dev.src_q = hx::as_ro(d + o_srcq);
@@ -3169,7 +3253,8 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
       attrf = true;
     }
-    hipLaunchKernelGGL(hx::break_digits_fast_kernel, grid, block, lds, c->stream, A, rw);
+    const size_t lds_fast = (size_t)std::max(1, L - hx::break_fast_n0(A)) * hx::BRK_THREADS * 8;
+    hipLaunchKernelGGL(hx::break_digits_fast_kernel, grid, block, lds_fast, c->stream, A, rw);
   } else if (nmax <= 8) {
     static bool attr8 = false;
     if (!attr8) {

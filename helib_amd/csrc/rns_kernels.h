@@ -358,6 +358,75 @@ struct ExtPlanDev {
   uint32_t fast16_ok;        // the same with n <= 16: rns_extend_fast_kernel
   ro_u32 tgt_chunk7;  // [nt] 1: every source prime <= q_t, so the limb sum may be taken 7
                                // terms at a time with the previous remainder carried (r + 7 p q < 8 q^2)
+  ro_u64 tgt_pack;    // [nt][8 + 2n] everything the fast kernels need of one target in ONE record
+                      // (TgtRec): the loop over targets then makes one scalar-memory round trip per
+                      // target instead of one per table (q, P mod t, flags, k, mu, W row: six
+                      // dependent s_load / s_waitcnt pairs per iteration before)
+};
+
+// one target of the fast kernels, read from ExtPlanDev::tgt_pack: header and multipliers are loaded
+// unconditionally at the top of the iteration and pinned in SGPRs (the empty asm keeps the compiler
+// from sinking a load into the branch that uses it, where it would wait for it alone) -- the
+// compiler merges them into s_load_dwordx8/x16 with ONE wait per target.  The Shoup companions
+// (wp, upd) are only read on the paths that need them.
+template <int N>
+struct TgtRec {
+  static constexpr bool WIDE_HDR = N <= 8;  // whole 8-word header in one s_load_dwordx16 (SGPR budget)
+  ro_u64 r;
+  uint64_t q_, pmod_, mu63_, mu64_, fl_, updw_, updp_;
+  uint64_t w_[N];
+  __device__ __forceinline__ TgtRec(const ExtPlanDev& P, int t) : r(P.tgt_pack + (size_t)t * (8 + 2 * N))
+  {
+    q_ = r[0];
+    pmod_ = r[1];
+    mu63_ = r[2];
+    mu64_ = r[3];
+    fl_ = r[4];
+    if constexpr (WIDE_HDR) {
+      updw_ = r[5];
+      updp_ = r[6];
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      w_[k] = r[8 + k];
+    asm volatile("" : "+s"(q_), "+s"(pmod_), "+s"(mu63_), "+s"(mu64_), "+s"(fl_));
+    if constexpr (WIDE_HDR)
+      asm volatile("" : "+s"(updw_), "+s"(updp_));
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      asm volatile("" : "+s"(w_[k]));
+  }
+  __device__ __forceinline__ uint64_t q() const { return q_; }
+  __device__ __forceinline__ uint64_t pmod() const { return pmod_; }
+  __device__ __forceinline__ uint64_t mu63() const { return mu63_; }
+  __device__ __forceinline__ uint64_t mu64() const { return mu64_; }
+  __device__ __forceinline__ uint32_t k() const { return (uint32_t)fl_ & 0xffu; }
+  __device__ __forceinline__ bool lazy() const { return ((uint32_t)fl_ >> 8) & 1u; }
+  __device__ __forceinline__ bool chunk7() const { return ((uint32_t)fl_ >> 9) & 1u; }
+  __device__ __forceinline__ TW upd() const
+  {
+    TW t;
+    if constexpr (WIDE_HDR) {
+      t.w = updw_;
+      t.wp = updp_;
+    } else {
+      t.w = r[5];
+      t.wp = r[6];
+    }
+    return t;
+  }
+  __device__ __forceinline__ uint64_t mu() const { return r[7]; }
+  __device__ __forceinline__ uint64_t w(int k) const { return w_[k]; }
+  // the Shoup companions of the multipliers, all at once (the non-lazy path)
+  __device__ __forceinline__ void load_wp(uint64_t (&wp)[N]) const
+  {
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      wp[k] = r[8 + N + k];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      asm volatile("" : "+s"(wp[k]));
+  }
 };
 
 // sum_k a_k * W[k]  mod q for a target whose plan says the lazy 128-bit form is exact
@@ -538,6 +607,12 @@ struct BreakArgs {
                          // src/DoubleCRT.cpp:538-545)
 };
 
+// rows of the first digit that the fast kernel does not keep in LDS (host and device agree on this)
+__host__ __device__ inline int break_fast_n0(const BreakArgs& A)
+{
+  return (A.ndig > 1 && A.off[0] == 0) ? A.off[1] : 0;
+}
+
 template <int NMAX>
 __global__ void __launch_bounds__(BRK_THREADS)
 break_digits_kernel(BreakArgs A, size_t row_words)
@@ -656,15 +731,21 @@ __device__ __forceinline__ uint64_t norm_any(uint64_t x, uint64_t q, uint32_t mu
   return csub(r, q);
 }
 
+// xs holds rows [n0, L) only: the rows of the FIRST digit (n0 of them when it starts at row 0) are
+// consumed once, by their own pass, and are read straight from global memory (src0) -- 10 instead of
+// 16 LDS rows per thread at L = 16, digits 6/5/5, which is what bounds the resident waves.
 template <int N>
 __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* xs, unsigned tid, int off, int L,
-                                                 uint64_t* dd, size_t row_words, double* frac_out)
+                                                 uint64_t* dd, size_t row_words, double* frac_out, int n0,
+                                                 const uint64_t* src0)
 {
   uint64_t a[N];
   // ---- Garner mixed-radix digits (src/DoubleCRT.cpp:1031-1100 computes the same value by CRT) ----
+  const bool from_global = off < n0;   // (uniform; a digit is either entirely below n0 or entirely above)
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    uint64_t x = xs[(off + k) * BRK_THREADS + tid];  // [0,4 p_k): later digits' rows are updated lazily
+    // [0,4 p_k): later digits' rows are updated lazily
+    uint64_t x = from_global ? src0[(size_t)(off + k) * row_words] : xs[(off + k - n0) * BRK_THREADS + tid];
     const uint64_t pk = P.src_q[k], npk = 0 - pk, pk2 = pk + pk;
 #pragma unroll
     for (int l = 0; l < k; l++)
@@ -696,15 +777,15 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
   // ---- residues modulo every other prime ----
   for (int t = 0; t < P.nt; t++) {
     const int r = t < off ? t : t + N;  // row of target t in the all-rows order
-    const uint64_t q = P.tgt_q[t];
-    ro_tw Wt = P.W + (size_t)t * N;
-    const uint64_t negfix = neg ? q - P.pmod[t] : 0;
+    const TgtRec<N> T(P, t);
+    const uint64_t q = T.q();
+    const uint64_t negfix = neg ? q - T.pmod() : 0;
     uint64_t v;
-    if (P.tgt_lazy[t]) {
+    if (T.lazy()) {
       uint64_t c00 = negfix, c01 = 0, c11 = 0;
 #pragma unroll
       for (int k = 0; k < N; k++) {
-        const uint64_t w = ld_tw(Wt, k).w;
+        const uint64_t w = T.w(k);
         const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
         c00 += (uint64_t)a0[k] * w0;
         c01 += (uint64_t)a0[k] * w1;
@@ -713,27 +794,32 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
       }
       const u128 S = (u128)c00 + ((u128)c01 << 30) + ((u128)c11 << 60);
 #ifdef HX_RED128_WIDE
-      v = red128_wide(S, q, P.tgt_mu[t], P.tgt_k[t]);
+      v = red128_wide(S, q, T.mu(), T.k());
 #else
-      v = red128_q8(S, q, P.tgt_mu63[t], P.tgt_k[t]);
+      v = red128_q8(S, q, T.mu63(), T.k());
 #endif
     } else {
       const uint64_t nq = 0 - q, q8 = q << 3;
-      const bool wide = P.tgt_k[t] >= 58;  // 8 terms of < 4q could pass 2^64: fold every second term
+      const bool wide = T.k() >= 58;  // 8 terms of < 4q could pass 2^64: fold every second term
       uint64_t acc = negfix;
+      uint64_t wp[N];
+      T.load_wp(wp);
 #pragma unroll
       for (int k = 0; k < N; k++) {
-        acc += shoup4(a[k], ld_tw(Wt, k), nq);
+        TW tw;
+        tw.w = T.w(k);
+        tw.wp = wp[k];
+        acc += shoup4(a[k], tw, nq);
         if ((k & 1) && wide)
           acc = csub(acc, q8);
       }
-      v = norm_any(acc, q, (uint32_t)P.tgt_mu64[t]);
+      v = norm_any(acc, q, (uint32_t)T.mu64());
     }
     dd[(size_t)r * row_words] = v;
     if (r >= off + N && r < L) {
       // digits[j] -= digits[i]; digits[j] /= P_i on a later digit's own row (kept lazy, < 4q)
-      uint64_t* u = &xs[r * BRK_THREADS + tid];
-      *u = shoup4(*u + q - v, ld_tw(P.upd, t), 0 - q);
+      uint64_t* u = &xs[(r - n0) * BRK_THREADS + tid];
+      *u = shoup4(*u + q - v, T.upd(), 0 - q);
     }
   }
 }
@@ -748,7 +834,7 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
 // generic kernel's, so every output word and every fraction is the same.
 // =====================================================================
 template <int N>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 11 ? 8 : 4)))
 rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -812,16 +898,16 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
     a1[k] = (uint32_t)(a[k] >> 30);
   }
   for (int t = 0; t < P.nt; t++) {
-    const uint64_t q = P.tgt_q[t];
-    ro_tw Wt = P.W + (size_t)t * N;
-    const uint64_t negfix = neg ? q - P.pmod[t] : 0;
+    const TgtRec<N> T(P, t);
+    const uint64_t q = T.q();
+    const uint64_t negfix = neg ? q - T.pmod() : 0;
     uint64_t r;
-    if (P.tgt_lazy[t]) {
+    if (T.lazy()) {
       // N <= 16 products of < 2^60 per accumulator
       uint64_t c00 = 0, c01 = 0, c10 = 0, c11 = 0;
 #pragma unroll
       for (int k = 0; k < N; k++) {
-        const uint64_t w = ld_tw(Wt, k).w;
+        const uint64_t w = T.w(k);
         const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
         c00 += (uint64_t)a0[k] * w0;
         c01 += (uint64_t)a0[k] * w1;
@@ -829,15 +915,15 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
         c11 += (uint64_t)a1[k] * w1;
       }
       const u128 S = (u128)negfix + c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
-      r = red128_q8(S, q, P.tgt_mu63[t], P.tgt_k[t]);
-    } else if (P.tgt_chunk7[t]) {
+      r = red128_q8(S, q, T.mu63(), T.k());
+    } else if (T.chunk7()) {
       r = negfix;
 #pragma unroll
       for (int k0 = 0; k0 < N; k0 += 7) {
         uint64_t c00 = 0, c01 = 0, c11 = 0;
 #pragma unroll
         for (int k = k0; k < (k0 + 7 < N ? k0 + 7 : N); k++) {
-          const uint64_t w = ld_tw(Wt, k).w;
+          const uint64_t w = T.w(k);
           const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
           c00 += (uint64_t)a0[k] * w0;
           c01 += (uint64_t)a0[k] * w1;
@@ -845,60 +931,67 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
           c11 += (uint64_t)a1[k] * w1;
         }
         const u128 S = (u128)r + c00 + ((u128)c01 << 30) + ((u128)c11 << 60);
-        r = red128_q8(S, q, P.tgt_mu63[t], P.tgt_k[t]);
+        r = red128_q8(S, q, T.mu63(), T.k());
       }
     } else {
       const uint64_t nq = 0 - q, q8 = q << 3;
-      const bool wide = P.tgt_k[t] >= 58;  // terms of < 4q could pass 2^64: fold every second term
+      const bool wide = T.k() >= 58;  // terms of < 4q could pass 2^64: fold every second term
       uint64_t acc = negfix;
+      uint64_t wp[N];
+      T.load_wp(wp);
 #pragma unroll
       for (int k = 0; k < N; k++) {
-        acc += shoup4(a[k], ld_tw(Wt, k), nq);
+        TW tw;
+        tw.w = T.w(k);
+        tw.wp = wp[k];
+        acc += shoup4(a[k], tw, nq);
         if ((k & 1) && wide)
           acc = csub(acc, q8);
       }
-      r = norm_any(acc, q, (uint32_t)P.tgt_mu64[t]);
+      r = norm_any(acc, q, (uint32_t)T.mu64());
     }
     if (dm_nonzero) {
       // delta -= diffProd * delta_i_modP
-      uint64_t d = red64(dm_abs, q, P.tgt_mu64[t]);
-      uint64_t corr = mul_mod(P.pmod[t], d, q, P.tgt_mu[t], P.tgt_k[t]);
+      uint64_t d = red64(dm_abs, q, T.mu64());
+      uint64_t corr = mul_mod(T.pmod(), d, q, T.mu(), T.k());
       r = dm_negative ? add_mod(r, corr, q) : sub_mod(r, corr, q);
     }
     if (A.dst_row[t] != 0xffff)
       A.dst[(size_t)A.dst_row[t] * row_words + i] = r;
     if (A.upd_row[t] != 0xffff) {
       uint64_t* u = A.upd + (size_t)A.upd_row[t] * row_words + i;
-      const TW pinv = ld_tw(P.upd, t);
+      const TW pinv = T.upd();
       *u = mul_shoup(sub_mod(*u, r, q), pinv.w, pinv.wp, q);
     }
   }
 }
 
-__global__ void __launch_bounds__(BRK_THREADS)
+__global__ void __launch_bounds__(BRK_THREADS) __attribute__((amdgpu_waves_per_eu(8)))
 break_digits_fast_kernel(BreakArgs A, size_t row_words)
 {
-  extern __shared__ __attribute__((aligned(16))) uint64_t xs[];  // [L][BRK_THREADS]
+  extern __shared__ __attribute__((aligned(16))) uint64_t xs[];  // [L - n0][BRK_THREADS]
   const unsigned tid = threadIdx.x;
   const size_t i = (size_t)blockIdx.x * BRK_THREADS + tid;
   if (i >= row_words)
     return;
-  for (int r = 0; r < A.L; r++)
-    xs[r * BRK_THREADS + tid] = A.src[(size_t)r * row_words + i];
+  const int n0 = break_fast_n0(A);
+  for (int r = n0; r < A.L; r++)
+    xs[(r - n0) * BRK_THREADS + tid] = A.src[(size_t)r * row_words + i];
+  const uint64_t* src0 = A.src + i;
   for (int d = 0; d < A.ndig; d++) {
     const ExtPlanDev& P = A.plan[d];
     const int off = A.off[d];
     uint64_t* dd = A.dst + (size_t)d * A.nall * row_words + i;
     double* fo = A.frac ? A.frac + (size_t)d * row_words + i : nullptr;
     switch (P.n) {
-      case 1: break_digit_pass<1>(P, xs, tid, off, A.L, dd, row_words, fo); break;
-      case 2: break_digit_pass<2>(P, xs, tid, off, A.L, dd, row_words, fo); break;
-      case 3: break_digit_pass<3>(P, xs, tid, off, A.L, dd, row_words, fo); break;
-      case 4: break_digit_pass<4>(P, xs, tid, off, A.L, dd, row_words, fo); break;
-      case 5: break_digit_pass<5>(P, xs, tid, off, A.L, dd, row_words, fo); break;
-      case 6: break_digit_pass<6>(P, xs, tid, off, A.L, dd, row_words, fo); break;
-      case 7: break_digit_pass<7>(P, xs, tid, off, A.L, dd, row_words, fo); break;
-      default: break_digit_pass<8>(P, xs, tid, off, A.L, dd, row_words, fo); break;
+      case 1: break_digit_pass<1>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 2: break_digit_pass<2>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 3: break_digit_pass<3>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 4: break_digit_pass<4>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 5: break_digit_pass<5>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 6: break_digit_pass<6>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 7: break_digit_pass<7>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      default: break_digit_pass<8>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
     }
   }
 }

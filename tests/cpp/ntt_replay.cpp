@@ -210,3 +210,91 @@ extern "C" int split_conv8_replay(int logq, uint64_t q, uint64_t psi, const uint
   }
   return -1;
 }
+
+
+// ---------------------------------------------------------------------------------------
+// CPU replay of the power-of-two transform beyond one row kernel (N = S * 2^LOGQ, S = 4 / 8;
+// engine.hip pow2_big_rows, bluestein.h big_pre / big_post): first log2(S) Cooley-Tukey stages on
+// elements Q apart, S sub-transforms with their own tables, and the interleave that restores the
+// natural order -- out[j] = in(psi^(2j+1)) as Cmodulus::FFT defines it -- and the way back.
+// ---------------------------------------------------------------------------------------
+template <int LOGQ, int S>
+static int big_ntt(int inverse, uint64_t q, uint64_t psi, const uint64_t* in, uint64_t* out)
+{
+  using G = hx::Geo<LOGQ>;
+  constexpr int LS = S == 8 ? 3 : 2;
+  const int Q = G::N, FULL = LOGQ + LS;
+  uint64_t psi_inv = pw(psi, q - 2, q);
+  uint64_t qinv = pw((uint64_t)Q % q, q - 2, q);
+  std::vector<std::vector<hx::TW>> F(S, std::vector<hx::TW>(G::TW_TOTAL)), I(S, std::vector<hx::TW>(G::TW_TOTAL));
+  for (unsigned g = 0; g < (unsigned)S; g++)
+    hx::build_tw_tables_sub<LOGQ>(q, psi, psi_inv, qinv, mm, LS, g, F[g].data(), I[g].data());
+  auto mk = [&](uint64_t w) { hx::TW t; t.w = w; t.wp = (uint64_t)((((u128)w) << 64) / q); return t; };
+  auto prev = [&](unsigned idx) { return pw(psi, hx::brev_bits(idx, FULL), q); };
+  hx::SplitTW S4;
+  hx::SplitTW8 S8;
+  if (S == 4) {
+    uint64_t T1 = prev(1), T2 = prev(2), T3 = prev(3), quarter = pw(4, q - 2, q);
+    S4.T1 = mk(T1); S4.T2 = mk(T2); S4.T3 = mk(T3);
+    S4.iT2 = mk(pw(T2, q - 2, q)); S4.iT3 = mk(pw(T3, q - 2, q));
+    S4.iT1q = mk(mm(pw(T1, q - 2, q), quarter, q)); S4.quarter = mk(quarter);
+  } else {
+    uint64_t eighth = pw(8, q - 2, q);
+    for (unsigned idx = 1; idx < 8; idx++) {
+      S8.T[idx] = mk(prev(idx));
+      S8.iT[idx] = mk(pw(prev(idx), q - 2, q));
+    }
+    S8.T[0] = S8.iT[0] = mk(0);
+    S8.eighth = mk(eighth);
+    S8.iT1e = mk(mm(S8.iT[1].w, eighth, q));
+  }
+  std::vector<uint64_t> qa((size_t)S * Q), fa((size_t)S * Q);
+  for (int p = 0; p < Q; p++) {  // big_pre
+    uint64_t e[8];
+    if (!inverse) {
+      for (int g = 0; g < S; g++) e[g] = in[p + (size_t)g * Q];
+      if (S == 8) {
+        hx::split_fwd8(e, S8, q);
+      } else {
+        uint64_t o[4];
+        hx::split_fwd4(e[0], e[1], e[2], e[3], S4, q, o);
+        for (int g = 0; g < 4; g++) e[g] = o[g];
+      }
+    } else {
+      for (int g = 0; g < S; g++) e[g] = in[(size_t)p * S + hx::brev_bits((unsigned)g, LS)];
+    }
+    for (int g = 0; g < S; g++) qa[(size_t)g * Q + p] = e[g];
+  }
+  for (int g = 0; g < S; g++)
+    sub_transform<LOGQ>(inverse != 0, inverse ? I[g].data() : F[g].data(), q, qa.data() + (size_t)g * Q,
+                        fa.data() + (size_t)g * Q);
+  for (int p = 0; p < Q; p++) {  // big_post
+    uint64_t e[8];
+    for (int g = 0; g < S; g++) e[g] = fa[(size_t)g * Q + p];
+    if (!inverse) {
+      for (int g = 0; g < S; g++) out[(size_t)p * S + hx::brev_bits((unsigned)g, LS)] = e[g];
+    } else {
+      if (S == 8) {
+        hx::split_inv8(e, S8, q);
+      } else {
+        const uint64_t c4[4] = {e[0], e[1], e[2], e[3]};
+        uint64_t a[4];
+        hx::split_inv4(c4, S4, q, a);
+        for (int g = 0; g < 4; g++) e[g] = a[g];
+      }
+      for (int g = 0; g < S; g++) out[p + (size_t)g * Q] = e[g];
+    }
+  }
+  return 0;
+}
+
+extern "C" int big_ntt_replay(int logq, int radix, int inverse, uint64_t q, uint64_t psi, const uint64_t* in,
+                              uint64_t* out)
+{
+  if (radix == 4 && logq == 13) return big_ntt<13, 4>(inverse, q, psi, in, out);
+  if (radix == 4 && logq == 14) return big_ntt<14, 4>(inverse, q, psi, in, out);
+  if (radix == 4 && logq == 15) return big_ntt<15, 4>(inverse, q, psi, in, out);
+  if (radix == 8 && logq == 13) return big_ntt<13, 8>(inverse, q, psi, in, out);
+  if (radix == 8 && logq == 15) return big_ntt<15, 8>(inverse, q, psi, in, out);
+  return -1;
+}

@@ -190,3 +190,29 @@ def test_split_convolution_replayed_on_cpu(replay, radix, logq):
     fn.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     assert fn(logq, q, psi, a.ctypes.data, b.ctypes.data, c.ctypes.data) == 0
     assert [int(v) for v in c] == want
+
+
+@pytest.mark.parametrize("radix,logq", [(4, 14), (4, 13), (8, 13)])
+def test_big_power_of_two_transform_replayed_on_cpu(replay, radix, logq):
+    """Power-of-two rings beyond one row kernel (engine.hip pow2_big_rows: N = 2^16 .. 2^18 as 4 / 8
+    sub-transforms, natural order in and out): the kernel phase functions, the sub-transform twiddle
+    tables and the interleave replayed on the CPU against the oracle's Cmodulus::FFT / iFFT
+    (src/CModulus.cpp:389-426, 493-553).  (4, 14) is m = 131072 as the engine runs it."""
+    n = radix << logq
+    m = 2 * n
+    q = O.PrimeGen(55, m).next()
+    o = O.Ctx(m)
+    i = o.add_prime(q)
+    psi = o.roots[i]
+    rng = np.random.default_rng(radix * 100 + logq)
+    x = rng.integers(0, q, n, dtype=np.uint64)
+    x[:3] = [q - 1, 0, 1]
+    want = o.fft([i], x[None, :])[0]
+    fn = replay.big_ntt_replay
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    y = np.zeros(n, dtype=np.uint64)
+    assert fn(logq, radix, 0, q, psi, x.ctypes.data, y.ctypes.data) == 0
+    assert np.array_equal(y, want)
+    back = np.zeros(n, dtype=np.uint64)
+    assert fn(logq, radix, 1, q, psi, want.ctypes.data, back.ctypes.data) == 0
+    assert np.array_equal(back, x)
