@@ -498,6 +498,28 @@ def cpp_host_rate(B, mults):
         return f"unavailable: {str(e)[:120]}"
 
 
+def level_lines():
+    """tools/bench_levels.py as its own processes: the multiply one level further down (operands that
+    carry the special primes of a previous key switch: the several-primes mod-switch in front of the
+    tensor product) next to the fresh one, for this workload and for the CKKS chain of BASELINE
+    configs[3] (benchmarks/ckks_basic.cpp:161-180 at m=65536, bits=1400 -> L=24, K=8); real keys and
+    encryptions, decrypted / decoded results checked there."""
+    out = {}
+    tool = os.path.join(ROOT, "tools", "bench_levels.py")
+    for name, extra in (("bgv32768", ["--scheme", "bgv", "--m", "32768", "--bits", "950", "--batch", "128"]),
+                        ("ckks65536", ["--batch", "64"])):
+        try:
+            r = subprocess.run([sys.executable, tool, "--steps", "6", *extra], capture_output=True, text=True,
+                               timeout=240)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            keep = ("workload", "level1_fresh_mult_per_s", "level1_ms_per_step", "level2_mult_per_s",
+                    "level2_ms_per_step", "verified")
+            out[name] = {k: d[k] for k in keep if k in d}
+        except Exception as e:
+            out[name] = f"unavailable: {type(e).__name__}: {str(e)[:120]}"
+    return out
+
+
 def ntt_roofline(hx, ctx, primes_list, own, sp, digits, B, rng, iters):
     """Forward NTT at the launch shape it has inside the key switch: D*(L+K)-L rows x B."""
     n = ctx.phim
@@ -724,6 +746,7 @@ def main():
                 if world == 1:
                     sync()
                     extra["cpp_host_mult_per_s"] = cpp_host_rate(B, 40)
+                    extra["levels"] = level_lines()
             if args.cpu_sample > 0 and world == 1:
                 cpu = cpu_baseline_fresh(cc, max(1, args.cpu_sample // 2))
                 cpu["all_cores"] = cpu_baseline_all_cores(args.bits, max(1, args.cpu_sample // 4))

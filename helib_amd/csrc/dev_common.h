@@ -59,6 +59,15 @@ struct ModDownPrep {
                          // single-prime layout [poly][batch][N]; the several-primes path keeps
                          // [poly][dropped prime][batch][N] and launches once per dropped prime)
 };
+// several dropped primes in ONE prep launch (scale_down_multi_fused): workgroup block j of
+// polys.n * batch workgroups inverse-transforms dropped row row[j] (prime prime[j]) of every poly
+// into x block j; up[2j], up[2j+1] = that prime's F*S0*N^-1 and F*N^-1 when the mod-up is folded in
+constexpr int MD_MAXDROP = 16;
+struct PrepMulti {
+  uint16_t row[MD_MAXDROP];
+  uint16_t prime[MD_MAXDROP];
+  TW up[2 * MD_MAXDROP];
+};
 struct ModDownRow {
   TW qdm;              // qd mod q_r
   TW inv;              // qd^-1 mod q_r

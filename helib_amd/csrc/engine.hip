@@ -32,6 +32,9 @@ hipError_t launch_moddown_pow2(int logn, const PolyBases& data, const PolyBases&
 hipError_t launch_moddown_prep_pow2(int logn, const PolyBases& polys, int drop_row, int drop_prime, int batch,
                                     const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena,
                                     hipStream_t st);
+hipError_t launch_moddown_prep_multi_pow2(int logn, const PolyBases& polys, const PrepMulti& M, int ndrop, int batch,
+                                          const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena,
+                                          hipStream_t st);
 hipError_t launch_moddown_apply_plain_pow2(int logn, const PolyBases& polys, const PolyBases& outs,
                                            const NttRows& keep, int nkeep, int batch, const ModDownApply& A,
                                            const PrimeDev* primes, const TW* tw_arena, hipStream_t st);
@@ -377,6 +380,7 @@ static int poly_fresh(hx_poly* p, const uint64_t** old_rows)
 // ------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------
+static void ctx_free(hx_ctx* c);
 extern "C" int hx_ctx_create(hx_ctx** out, int device, uint64_t m)
 {
   if (!out || m < 2 || m > (1ull << 24))
@@ -388,6 +392,16 @@ extern "C" int hx_ctx_create(hx_ctx** out, int device, uint64_t m)
     return fail(HX_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
   HIPCHK(hipSetDevice(device));
   hx_ctx* c = new hx_ctx();
+  // a failing allocation below returns through HIPCHK: the half-built context and whatever it
+  // already holds on the device go with it
+  struct Guard {
+    hx_ctx* c;
+    ~Guard()
+    {
+      if (c)
+        ctx_free(c);
+    }
+  } guard{c};
   c->device = device;
   c->m = m;
   std::vector<int32_t> zidx((size_t)m, -1);
@@ -411,11 +425,11 @@ extern "C" int hx_ctx_create(hx_ctx** out, int device, uint64_t m)
   HIPCHK(hipMemcpy(c->d_zms_index, zidx.data(), (size_t)m * 4, hipMemcpyHostToDevice));
   c->primes_cap = 1024;
   HIPCHK(hipMalloc((void**)&c->d_primes, sizeof(PrimeDev) * c->primes_cap));
+  guard.c = nullptr;
   *out = c;
   return HX_OK;
 }
 
-static void ctx_free(hx_ctx* c);
 static void ctx_release(hx_ctx* c)
 {
   bool last;
@@ -2608,26 +2622,32 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
     pbo.d[i] = fresh[i];
   }
   int rc = HX_OK;
-  // 1. inverse transforms of the dropped rows (one launch per dropped prime, all polys)
-  for (int j = 0; j < nd && rc == HX_OK; j++) {
-    const int dprime = drop[j], drow = find_row(a->prime_idx, dprime);
-    const uint64_t qd = c->primes[dprime].q;
+  // 1. inverse transforms of the dropped rows: all polys and up to MD_MAXDROP dropped primes per launch
+  for (int j0 = 0; j0 < nd && rc == HX_OK; j0 += hx::MD_MAXDROP) {
+    const int nj = std::min(hx::MD_MAXDROP, nd - j0);
+    hx::PrepMulti M;
+    memset(&M, 0, sizeof M);
     ModDownPrep P;
     memset(&P, 0, sizeof P);
-    P.xs = c->scratch[0] + (size_t)j * rw;
+    P.xs = c->scratch[0] + (size_t)j0 * rw;
     P.poly_stride = (uint64_t)nd * rw;
-    P.qd = qd;
-    if (nadd > 0) {
-      uint64_t F = 1;
-      for (int i = 0; i < nadd; i++)
-        F = hxh::mulmod(F, c->primes[add_idx[i]].q % qd, qd);
-      P.has_up = 1;
-      P.upS.w = hxh::mulmod(F, c->primes[dprime].last_s, qd);
-      P.upS.wp = hxh::shoup(P.upS.w, qd);
-      P.upN.w = hxh::mulmod(F, c->primes[dprime].last_n, qd);
-      P.upN.wp = hxh::shoup(P.upN.w, qd);
+    P.has_up = nadd > 0 ? 1 : 0;
+    for (int j = 0; j < nj; j++) {
+      const int dprime = drop[j0 + j];
+      const uint64_t qd = c->primes[dprime].q;
+      M.row[j] = (uint16_t)find_row(a->prime_idx, dprime);
+      M.prime[j] = (uint16_t)dprime;
+      if (nadd > 0) {
+        uint64_t F = 1;
+        for (int i = 0; i < nadd; i++)
+          F = hxh::mulmod(F, c->primes[add_idx[i]].q % qd, qd);
+        M.up[2 * j].w = hxh::mulmod(F, c->primes[dprime].last_s, qd);
+        M.up[2 * j].wp = hxh::shoup(M.up[2 * j].w, qd);
+        M.up[2 * j + 1].w = hxh::mulmod(F, c->primes[dprime].last_n, qd);
+        M.up[2 * j + 1].wp = hxh::shoup(M.up[2 * j + 1].w, qd);
+      }
     }
-    hipError_t e = hx::launch_moddown_prep_pow2(c->logn, pb, drow, dprime, batch, P, c->d_primes, c->d_tw, c->stream);
+    hipError_t e = hx::launch_moddown_prep_multi_pow2(c->logn, pb, M, nj, batch, P, c->d_primes, c->d_tw, c->stream);
     if (e != hipSuccess)
       rc = fail(HX_ERR_DEVICE, "mod-down launch failed: %s", hipGetErrorString(e));
   }
@@ -3347,6 +3367,17 @@ extern "C" int hx_ksk_create(hx_ctx* c, int ndig, const int* row_idx, int nrows,
   CTX_ENTER(c);
   CHK(check_rows(c, row_idx, nrows));
   hx_ksk* k = new hx_ksk();
+  struct Guard {   // a failing allocation / copy below returns through HIPCHK
+    hx_ksk* k;
+    ~Guard()
+    {
+      if (k) {
+        hipFree(k->d_b);
+        hipFree(k->d_a);
+        delete k;
+      }
+    }
+  } guard{k};
   k->ctx = c;
   k->ndig = ndig;
   k->row_idx.assign(row_idx, row_idx + nrows);
@@ -3356,6 +3387,7 @@ extern "C" int hx_ksk_create(hx_ctx* c, int ndig, const int* row_idx, int nrows,
   HIPCHK(hipMemcpy(k->d_b, b, bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(k->d_a, a, bytes, hipMemcpyHostToDevice));
   c->refs++;
+  guard.k = nullptr;
   *out = k;
   return HX_OK;
 }

@@ -409,6 +409,30 @@ ntt_moddown_prep_kernel(PolyBases polys, int row, int prime, int batch, ModDownP
                      (unsigned)N * 8u);
   ntt_body<LOGN, true>(lds, io, tw_arena + pd->tw_inv_off, pd);
 }
+// the same for up to MD_MAXDROP dropped primes at once (the several-primes mod-switch): one launch of
+// ndrop * polys * batch workgroups instead of ndrop launches of polys * batch -- a single such launch
+// is one round of resident workgroups (512 at batch 128), i.e. latency- and not throughput-bound
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
+ntt_moddown_prep_multi_kernel(PolyBases polys, PrepMulti M, int batch, ModDownPrep P,
+                              const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const unsigned per = (unsigned)polys.n * (unsigned)batch;
+  const unsigned j = blockIdx.x / per, rem = blockIdx.x % per;
+  const int b = (int)(rem % (unsigned)batch), pi = (int)(rem / (unsigned)batch);
+  const PrimeDev* pd = primes + uniform_u16(M.prime, j);
+  const int row = (int)uniform_u16(M.row, j);
+  const size_t N = Geo<LOGN>::N;
+  const uint64_t* in = poly_base(polys, (unsigned)pi);
+  ModDownPrep Pj = P;
+  Pj.xs = P.xs + (size_t)j * (size_t)batch * N;
+  Pj.upS = M.up[2 * j];
+  Pj.upN = M.up[2 * j + 1];
+  const InvPrepIO io(in + ((size_t)row * batch + b) * N, Pj, (size_t)pi * (size_t)P.poly_stride + (size_t)b * N,
+                     (unsigned)N * 8u);
+  ntt_body<LOGN, true>(lds, io, tw_arena + pd->tw_inv_off, pd);
+}
 // ... forward transform of delta on every kept row, subtract + divide in the store
 template <int LOGN, bool PLAIN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
@@ -510,6 +534,9 @@ static hipError_t moddown_attrs()
     hipError_t e = hipFuncSetAttribute((const void*)ntt_moddown_prep_kernel<LOGN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)ntt_moddown_prep_multi_kernel<LOGN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)ntt_moddown_apply_kernel<LOGN, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess)
@@ -598,6 +625,31 @@ static hipError_t launch_apply_plain(const PolyBases& polys, const PolyBases& ou
                      dim3(moddown_apply_grid((unsigned)polys.n, (unsigned)nkeep, (unsigned)batch)),
                      dim3(Geo<LOGN>::T), lds_bytes, st, polys, outs, keep, nkeep, batch, A, primes, tw_arena);
   return hipGetLastError();
+}
+template <int LOGN>
+static hipError_t launch_prep_multi(const PolyBases& polys, const PrepMulti& M, int ndrop, int batch,
+                                    const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+  hipError_t e = moddown_attrs<LOGN>();
+  if (e != hipSuccess)
+    return e;
+  hipLaunchKernelGGL((ntt_moddown_prep_multi_kernel<LOGN>), dim3((unsigned)ndrop * (unsigned)polys.n * (unsigned)batch),
+                     dim3(Geo<LOGN>::T), lds_bytes, st, polys, M, batch, P, primes, tw_arena);
+  return hipGetLastError();
+}
+// P.xs = x block of the first listed prime, P.poly_stride = words between the x blocks of two polys,
+// x blocks of consecutive listed primes batch*N words apart
+hipError_t launch_moddown_prep_multi_pow2(int logn, const PolyBases& polys, const PrepMulti& M, int ndrop, int batch,
+                                          const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena,
+                                          hipStream_t st)
+{
+  switch (logn) {
+    case 13: return launch_prep_multi<13>(polys, M, ndrop, batch, P, primes, tw_arena, st);
+    case 14: return launch_prep_multi<14>(polys, M, ndrop, batch, P, primes, tw_arena, st);
+    case 15: return launch_prep_multi<15>(polys, M, ndrop, batch, P, primes, tw_arena, st);
+  }
+  return hipErrorInvalidValue;
 }
 hipError_t launch_moddown_prep_pow2(int logn, const PolyBases& polys, int drop_row, int drop_prime, int batch,
                                     const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena,

@@ -24,6 +24,7 @@ in the reference) -- only their logs are ever compared.
 """
 import math
 from functools import reduce
+from helib_amd import timing
 
 from . import hostnt
 
@@ -88,20 +89,53 @@ def _powerOfS(handle):
 
 
 def polyNormBnd(m):
-    """calcPolyNormBnd (src/PAlgebra.cpp:215-240) where it is closed-form: 1 for a power of two,
-    2 cot(pi/(2u))/u when the odd part of m is a power of one prime u.  (The general case is a
-    search over the cyclotomic's roots; it is not restated here.)"""
+    """calcPolyNormBnd (src/PAlgebra.cpp:215-434): the ring constant c_M.  1 for a power of two,
+    2 cot(pi/(2u))/u when the odd part of m is a power of one prime u; otherwise, with m replaced by
+    the radical of its odd part, the maximal absolute row sum of the inverse of the Vandermonde matrix
+    of the primitive m-th roots x_j: row i of column j is q_i(x_j) / Phi_m'(x_j) with the Horner
+    prefixes q_0 = 1, q_i = q_(i-1) x_j + a_(n-i) of Phi_m (:360-372).  |Phi_m'(x_j)| = prod_i |x_i -
+    x_j| is taken as exp of a sum of logarithms (the reference keeps a frexp-normalised running
+    product, :300-357); the sums over i for all j at once are one cyclic correlation."""
+    import numpy as np
     while m % 2 == 0:
         m //= 2
     if m == 1:
         return 1.0
-    u = next(d for d in range(3, m + 1, 2) if m % d == 0)
-    r = m
-    while r % u == 0:
-        r //= u
-    if r != 1:
-        raise NotImplementedError("polyNormBnd for m with two or more odd prime factors")
-    return 2.0 / math.tan(math.pi / (2.0 * u)) / u
+    fac, r, d = [], m, 3
+    while r > 1:
+        if r % d == 0:
+            fac.append(d)
+            while r % d == 0:
+                r //= d
+        d += 2
+    if len(fac) == 1:
+        u = fac[0]
+        return 2.0 / math.tan(math.pi / (2.0 * u)) / u
+    m = 1
+    for u in fac:
+        m *= u
+    phi_coef = np.array(hostnt.phimx(m)[:-1], dtype=np.float64)      # a_0 .. a_(n-1): without the leading 1
+    n = len(phi_coef)
+    res = np.array([i for i in range(1, m) if math.gcd(i, m) == 1])
+    assert len(res) == n
+    k = np.arange(m, dtype=np.longdouble)
+    x = (np.cos(2 * np.pi * k / m)[res] + 1j * np.sin(2 * np.pi * k / m)[res]).astype(np.complex128)
+    # ln |Phi'(x_j)| = sum over units i != j of ln(2 sin(pi |i - j| / m)): correlation of the unit
+    # indicator with the table of logarithms (dist 0 counts as 1, as dist_tab[0] = 1 does)
+    logd = np.zeros(m)
+    logd[1:] = np.log(2.0 * np.sin(np.pi * k[1:] / m).astype(np.float64))
+    ind = np.zeros(m)
+    ind[res] = 1.0
+    corr = np.fft.irfft(np.fft.rfft(logd) * np.conj(np.fft.rfft(ind)), m)   # corr[t] = sum_s ind[s] logd[s+t]
+    # sum_i logd[(res_i - res_j) mod m] = sum_s ind[s] logd[(s - res_j) mod m] = corr[-res_j]
+    inv_prod = np.exp(-corr[(-res) % m])
+    norm_col = np.empty(n)
+    q = np.ones(n, dtype=np.complex128)
+    norm_col[0] = inv_prod.sum()
+    for i in range(1, n):
+        q = q * x + phi_coef[n - i]
+        norm_col[i] = float(np.dot(np.abs(q), inv_prod))
+    return float(norm_col.max())
 
 
 def _ln(x):
@@ -157,6 +191,9 @@ class ModuliSizes:
             if best_cost is None or c <= best_cost:
                 best, best_cost = ii, c
             ii += 1
+        w = "window1" if from2 is None else "window2"         # src/primeChain.cpp:207-208, 288-289
+        timing.STATS_UPDATE(w + "-out", best == -1)
+        timing.STATS_UPDATE(w + "-nchoices", ii - idx)
         if best == -1:
             if reverse:
                 if ii < n:
@@ -423,6 +460,7 @@ class Ctxt:
         return added * self.context.noiseBoundForUniform(self.ptxtSpace / 2.0, self.context.phim)
 
     # ---- prime-set maintenance ----
+    @timing.timed
     def modUpToSet(self, s):
         diff = sorted(frozenset(s) - self.primeSet)
         if not diff:
@@ -433,6 +471,7 @@ class Ctxt:
         self.lnRatFactor += self.context.logOfProduct(diff)   # "If CKKS, the rational factor grows" (:366)
         self.primeSet = self.primeSet | frozenset(diff)
 
+    @timing.timed
     def modDownToSet(self, s):
         inter = self.primeSet & frozenset(s)
         if not inter:
@@ -443,7 +482,14 @@ class Ctxt:
         added = Ctxt._modDownParts([self], sorted(inter))[0]
         logdiff = self.context.logOfProduct(diff)
         self.lnRatFactor -= logdiff                              # ratFactor /= f (:533, :553)
-        self._defer(lambda: setattr(self, "_ln", logaddexp(self._ln - logdiff, _ln(added()))))
+        bound = math.log(self.modSwitchAddedNoiseBound()) if timing.fhe_stats else None
+
+        def update():
+            add = _ln(added())
+            if bound is not None:   # src/Ctxt.cpp:535-537: added noise over its a-priori bound
+                timing.STATS_UPDATE("mod-switch-added-noise", math.exp(add - bound))
+            self._ln = logaddexp(self._ln - logdiff, add)
+        self._defer(update)
         self.primeSet = inter
 
     @staticmethod
@@ -474,6 +520,7 @@ class Ctxt:
             k += len(keys)
         return out
 
+    @timing.timed
     def bringToSet(self, s):
         s = frozenset(s) if s else frozenset([self.context.ctxtPrimes[0]])
         if hasattr(self.ops, "bringToSetMulti"):
@@ -527,6 +574,7 @@ class Ctxt:
             c._defer(lambda c=c, ad=ad: setattr(c, "_ln", logaddexp(c._ln - logdiff, _ln(ad()))))
             c.primeSet = inter
 
+    @timing.timed
     def dropSmallAndSpecialPrimes(self):
         ctx = self.context
         small, ctp = frozenset(ctx.smallPrimes), frozenset(ctx.ctxtPrimes)
@@ -648,6 +696,7 @@ class Ctxt:
         big.lnRatFactor = small.lnRatFactor = math.log(f) + base
         big.lnNoise, small.lnNoise = _ln(fe1) + base, _ln(fe2) + base
 
+    @timing.timed
     def addCtxt(self, other, negative=False):
         """Ctxt::addCtxt (src/Ctxt.cpp:1405-1556): plaintext spaces reduced to their gcd (BGV),
         both operands mod-switched UP to the union of their prime sets, CKKS factors equalised,
@@ -736,6 +785,7 @@ class Ctxt:
         hi = min(cap1 + adn1, cap2 + adn2) - Ctxt.safety
         return hi - 4 * LN2, hi
 
+    @timing.timed
     def multLowLvl(self, other, destructive=False):
         o = other if destructive else other.clone()
         ckks = self.context.ckks
@@ -787,6 +837,7 @@ class Ctxt:
         else:
             self.lnNoise = self.lnNoise + o.lnNoise
 
+    @timing.timed
     def reLinearize(self):
         """Ctxt::reLinearize (src/Ctxt.cpp:720-786) for the shapes of this path: (1, s, s^2) after a
         multiplication, or (1, [s,] s(X^k)) after an automorphism."""
@@ -817,11 +868,16 @@ class Ctxt:
         def update():
             added = -math.inf
             for k, d in enumerate(digits):
+                bnd = math.log(ctx.noiseBoundForUniform(0.5, ctx.phim)) + ctx.logOfProduct(d)
                 if self._meas:   # norm_val = embeddingLargestCoeff(digit) (src/DoubleCRT.cpp:538-545)
                     nb = _ln(float(max(res[2][k]))) + ctx.logOfProduct(d)
+                    if timing.fhe_stats:   # (src/DoubleCRT.cpp:547-548)
+                        timing.STATS_UPDATE("break-into-digits-ratio", math.exp(nb - bnd))
                 else:            # high-probability bound (src/DoubleCRT.cpp:520-529)
-                    nb = math.log(ctx.noiseBoundForUniform(0.5, ctx.phim)) + ctx.logOfProduct(d)
+                    nb = bnd
                 added = logaddexp(added, nb + self.ksw_lnNoise)
+            if timing.fhe_stats:           # (src/Ctxt.cpp:833-835): added noise over the ciphertext's own
+                timing.STATS_UPDATE("KS-noise-ratio", math.exp(added - (self._ln + logProd)))
             self._ln = logaddexp(self._ln + logProd, added)
 
         self.parts = {"1": o0, "s": o1}
@@ -881,6 +937,7 @@ class Ctxt:
         self.parts = {"1": part0, "s": part1}
         self.primeSet = self.primeSet | frozenset(sp)
 
+    @timing.timed
     def multiplyBy2(self, other1, other2):
         """Ctxt::multiplyBy2 (src/Ctxt.cpp:1776-1828): the product of three ciphertexts with ONE
         relinearisation at the end (parts up to s^3), multiplying in the order of their capacities."""
@@ -904,6 +961,7 @@ class Ctxt:
         self.multLowLvl(second)
         self.reLinearize()
 
+    @timing.timed
     def square(self):
         """Ctxt::square: multiplyBy(*this)"""
         self.multiplyBy(self.clone())
@@ -987,6 +1045,7 @@ class Ctxt:
             raise LookupError(f"no key-switching matrices for k={k}")
         return k
 
+    @timing.timed
     def smartAutomorph(self, k):
         """Ctxt::smartAutomorph (src/Ctxt.cpp:2462-2515): re-linearise, then walk the path of
         available matrices -- automorph(amt), reLinearize, k <- k * amt^-1 -- until k = 1."""
@@ -1005,6 +1064,7 @@ class Ctxt:
             k = k * pow(amt, -1, m) % m
         return self
 
+    @timing.timed
     def multiplyBy(self, other):
         self.multLowLvl(other)
         self.reLinearize()

@@ -314,9 +314,24 @@ def ctxt_from_json(j, primes=None, phim=None):
             "primeSet": sorted(c["primeSet"]), "parts": parts}
 
 
-def write_keyswitch(k, legacy=False):
+ENGINE_ONLY_MSG = ("this key-switching matrix keeps its a-columns explicitly (helib_amd.keys): they are not on the "
+                   "reference's wire, which carries only prgSeed -- a reference HElib would load the blob, "
+                   "regenerate DIFFERENT a-columns from the seed and every reLinearize / rotation would silently "
+                   "decrypt to garbage.  Pass engine_only=True to write it anyway (loadable by this engine with "
+                   "to_seckey / to_pubkey(..., ksw_a=...) only)")
+
+
+def _check_engine_only(k, engine_only):
+    if k.get("explicit_a") and not engine_only:
+        raise ValueError(ENGINE_ONLY_MSG)
+
+
+def write_keyswitch(k, legacy=False, engine_only=False):
     """k = {fromKey: (powerOfS, powerOfX, keyID), toKeyID, ptxtSpace, b: [(idx, rows)], prgSeed:
-    int > 0, noiseBound}; legacy=True (the reference fixture's layout): no noiseBound."""
+    int > 0, noiseBound}; legacy=True (the reference fixture's layout): no noiseBound.
+    A description marked explicit_a (made by from_pubkey / from_seckey from this engine's keys) is
+    refused unless engine_only=True: see ENGINE_ONLY_MSG."""
+    _check_engine_only(k, engine_only)
     seed = int(k["prgSeed"])
     if seed <= 0:
         raise ValueError("Number of bytes to write must be non-negative")   # write_raw_ZZ's assert
@@ -357,7 +372,8 @@ def read_keyswitch(buf, off=0, legacy=False):
             "prgSeed": seed, "noiseBound": xdouble_value(m, e)}, off + 4
 
 
-def keyswitch_to_json(k):
+def keyswitch_to_json(k, engine_only=False):
+    _check_engine_only(k, engine_only)
     return _typed("KeySwitch", {"fromKey": _skh_json(k["fromKey"]), "toKeyID": int(k["toKeyID"]),
                                 "ptxtSpace": int(k["ptxtSpace"]),
                                 "b": [to_json(idx, rows) for idx, rows in k["b"]],
@@ -545,7 +561,7 @@ def context_of(cc, gens=(), ords=()):
             "e_param": 0, "ePrime_param": 0, "mvec": [], "build_cache": 0, "alsoThick": 0}
 
 
-def write_pubkey(k, legacy=False):
+def write_pubkey(k, legacy=False, engine_only=False):
     """PubKey::writeTo (src/keys.cpp:888-921).  k = {context, pubEncrKey (ctxt description),
     skBounds [double], keySwitching [key-switch descriptions], keySwitchMap [[long]], KS_strategy
     [long], recryptKeyID, recryptEkey (ctxt description)}.
@@ -561,7 +577,7 @@ def write_pubkey(k, legacy=False):
     else:
         out.append(struct.pack(f"<q{len(k['skBounds'])}d", len(k["skBounds"]), *[float(x) for x in k["skBounds"]]))
     out.append(struct.pack("<q", len(k["keySwitching"])))
-    out += [write_keyswitch(w, legacy) for w in k["keySwitching"]]
+    out += [write_keyswitch(w, legacy, engine_only) for w in k["keySwitching"]]
     out.append(struct.pack("<q", len(k["keySwitchMap"])))
     out += [_longs(v) for v in k["keySwitchMap"]]
     out += [_vec_long(k["KS_strategy"]), struct.pack("<q", int(k["recryptKeyID"])),
@@ -609,11 +625,11 @@ def read_pubkey(buf, off=0, legacy=False, context=None):
     return k, _eye(buf, off, b"]PK|", "post-public key")
 
 
-def write_seckey(k, legacy=False, sk_only=False):
+def write_seckey(k, legacy=False, sk_only=False, engine_only=False):
     """SecKey::writeTo (src/keys.cpp:1736-1753): the public key (or, sk_only, just the context),
     then vector<DoubleCRT> sKeys.  k = the PubKey description + {"sKeys": [(idx, rows)]}."""
     out = [b"|SK["] if legacy else [header("SecKey"), b"|SK["]
-    out.append(write_context(k["context"], legacy) if sk_only else write_pubkey(k, legacy))
+    out.append(write_context(k["context"], legacy) if sk_only else write_pubkey(k, legacy, engine_only))
     out.append(struct.pack("<q", len(k["sKeys"])))
     out += [write_rows(idx, rows) for idx, rows in k["sKeys"]]
     out.append(b"]SK|")
@@ -640,11 +656,11 @@ def read_seckey(buf, off=0, legacy=False, sk_only=False, context=None):
     return k, _eye(buf, off, b"]SK|", "post-secret key")
 
 
-def pubkey_to_json(k):
+def pubkey_to_json(k, engine_only=False):
     return _typed("PubKey", {
         "context": context_to_json(k["context"]), "pubEncrKey": ctxt_to_json(k["pubEncrKey"]),
         "skBounds": [float(x) for x in k["skBounds"]],
-        "keySwitching": [keyswitch_to_json(w) for w in k["keySwitching"]],
+        "keySwitching": [keyswitch_to_json(w, engine_only) for w in k["keySwitching"]],
         "keySwitchMap": [list(v) for v in k["keySwitchMap"]], "KS_strategy": list(k["KS_strategy"]),
         "recryptKeyID": int(k["recryptKeyID"]),
         "recryptEkey": ctxt_to_json(k["recryptEkey"]) if k["recryptKeyID"] >= 0 else "nullptr"})
@@ -666,8 +682,8 @@ def pubkey_from_json(j, primes=None, phim=None):
     return k
 
 
-def seckey_to_json(k, sk_only=False):
-    body = {"context": context_to_json(k["context"])} if sk_only else {"PubKey": pubkey_to_json(k)}
+def seckey_to_json(k, sk_only=False, engine_only=False):
+    body = {"context": context_to_json(k["context"])} if sk_only else {"PubKey": pubkey_to_json(k, engine_only)}
     body["sKeys"] = [to_json(idx, rows) for idx, rows in k["sKeys"]]
     return _typed("SecKey", body)
 
@@ -701,8 +717,10 @@ def key_switch_map(m, keySwitching, keyId=0):
 def from_pubkey(pk, gens=(), ords=()):
     """helib_amd.keys.PubKey/SecKey -> the PubKey description.  The a-columns of a key-switching
     matrix are regenerated by the reference from prgSeed with NTL's PRG; this engine keeps them
-    explicitly (helib_amd.keys.KeySwitchInfo.a), so matrices written here carry prgSeed = 1 and are
-    only loadable by this engine (to_pubkey(..., a_columns=...)), as DESIGN.md section 7.2 says."""
+    explicitly (helib_amd.keys.KeySwitchInfo.a), so the matrix descriptions made here carry prgSeed = 1
+    and the mark explicit_a: the writers (write_pubkey / write_seckey / *_to_json) refuse them unless
+    engine_only=True, because a reference HElib would load such a blob without complaint and
+    regenerate different a-columns (ENGINE_ONLY_MSG)."""
     import math
     cc = pk.cc
     enc = {"ptxtSpace": pk.ptxtSpace, "intFactor": 1, "ptxtMag": 1.0, "ratFactor": 1.0,
@@ -711,7 +729,7 @@ def from_pubkey(pk, gens=(), ords=()):
                      (pk.pubEncrKey[1].getIndexSet(), pk.pubEncrKey[1].download()[:, 0], (1, 1, 0))]}
     allp = list(cc.ctxtPrimes) + list(cc.specialPrimes)
     ksw = [{"fromKey": (sp, xp, 0), "toKeyID": 0, "ptxtSpace": w.ptxtSpace,
-            "b": [(allp, np.asarray(w.b[i])) for i in range(len(w.b))], "prgSeed": 1,
+            "b": [(allp, np.asarray(w.b[i])) for i in range(len(w.b))], "prgSeed": 1, "explicit_a": True,
             "noiseBound": float(w.noiseBound)} for (sp, xp), w in pk.keySwitching.items()]
     kmap = [key_switch_map(cc.m, ksw)] if getattr(pk, "keySwitchMap", None) else []
     empty = {"ptxtSpace": pk.ptxtSpace, "intFactor": 1, "ptxtMag": 1.0, "ratFactor": 1.0, "noiseBound": 0.0,

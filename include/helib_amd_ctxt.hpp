@@ -27,6 +27,7 @@
 #include <set>
 
 #include "helib_amd.hpp"
+#include "helib_amd_timing.hpp"
 
 namespace helib_amd {
 
@@ -188,6 +189,13 @@ public:
         best_cost = c;
       }
       ii++;
+    }
+    if (from2) {   // src/primeChain.cpp:288-289 / :207-208
+      HELIB_AMD_STATS_UPDATE("window2-out", best == -1);
+      HELIB_AMD_STATS_UPDATE("window2-nchoices", (double)(ii - idx));
+    } else {
+      HELIB_AMD_STATS_UPDATE("window1-out", best == -1);
+      HELIB_AMD_STATS_UPDATE("window1-nchoices", (double)(ii - idx));
     }
     if (best == -1) {
       const double LN2 = std::log(2.0);
@@ -549,6 +557,7 @@ public:
   // ---- prime-set maintenance ----
   void modUpToSet(const PrimeSet& s)
   {
+    HELIB_AMD_TIMER_START;
     PrimeSet diff = s - primeSet;
     if (diff.empty())
       return;
@@ -561,6 +570,7 @@ public:
   }
   void modDownToSet(const PrimeSet& s)
   {
+    HELIB_AMD_TIMER_START;
     PrimeSet inter = primeSet & s;
     if (inter.empty())
       throw RuntimeError("modDownToSet called with disjoint sets");
@@ -568,19 +578,23 @@ public:
     if (diff.empty())
       return;
     std::vector<Ctxt*> one{this};
+    const double addedBound = modSwitchAddedNoiseBound();
     std::vector<double> added = modDownParts(one, inter, PrimeSet());
+    HELIB_AMD_STATS_UPDATE("mod-switch-added-noise", added[0] / addedBound);   // src/Ctxt.cpp:535-537
     lnNoise = detail::logaddexp(lnNoise - context->logOfProduct(diff), detail::ln(added[0]));
     lnRatFactor -= context->logOfProduct(diff);  // ratFactor /= f (:533, :553)
     primeSet = inter;
   }
   void bringToSet(const PrimeSet& s0)
   {
+    HELIB_AMD_TIMER_START;
     PrimeSet s = s0.empty() ? PrimeSet{context->ctxtPrimes[0]} : s0;
     std::vector<Ctxt*> one{this};
     bringManyToSet(one, s);
   }
   void dropSmallAndSpecialPrimes()
   {
+    HELIB_AMD_TIMER_START;
     PrimeSet small = toSet(context->smallPrimes), ctp = toSet(context->ctxtPrimes);
     if ((primeSet & small).empty()) {
       modDownToSet(ctp);
@@ -689,6 +703,7 @@ public:
   // then the parts added handle by handle.
   void addCtxt(const Ctxt& other, bool negative = false)
   {
+    HELIB_AMD_TIMER_START;
     if (other.parts.empty())
       return;
     if (parts.empty()) {
@@ -781,6 +796,7 @@ public:
   // multLowLvl: bring both to a common set, tensor
   void multLowLvl(Ctxt other)
   {
+    HELIB_AMD_TIMER_START;
     if (parts.empty() || other.parts.empty()) {
       parts.clear();
       return;
@@ -809,16 +825,19 @@ public:
   }
   void multiplyBy(const Ctxt& other)
   {
+    HELIB_AMD_TIMER_START;
     multLowLvl(other);  // works on a copy of `other`, as the reference does (src/Ctxt.cpp:1716-1745)
     reLinearize();
   }
   void multiplyBy(Ctxt&& other)  // the operand may be consumed: no copy
   {
+    HELIB_AMD_TIMER_START;
     multLowLvl(std::move(other));
     reLinearize();
   }
   void reLinearize()
   {
+    HELIB_AMD_TIMER_START;
     SKHandle hnd;
     int n_other = 0;
     for (auto& kv : parts)
@@ -897,6 +916,7 @@ public:
   // Ctxt::automorph: F(X) -> F(X^k) on every part; handles follow
   void automorph(long k)
   {
+    HELIB_AMD_TIMER_START;
     long m = context->m;
     k = ((k % m) + m) % m;
     if (std::gcd(k, m) != 1)
@@ -916,6 +936,7 @@ public:
   // Ctxt::smartAutomorph (src/Ctxt.cpp:2462-2515): walk the path of available matrices
   void smartAutomorph(long k)
   {
+    HELIB_AMD_TIMER_START;
     long m = context->m;
     k = ((k % m) + m) % m;
     if (k == 1 || parts.empty())

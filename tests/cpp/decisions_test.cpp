@@ -15,6 +15,7 @@ using namespace helib_amd;
 int main()
 {
   ChainContext c(128, 257, 1, 100);
+  fhe_stats() = true;   // the decision statistics of src/primeChain.cpp:207-208, 288-289 are collected on the way
   std::string line;
   while (std::getline(std::cin, line)) {
     std::istringstream in(line);
@@ -60,5 +61,13 @@ int main()
       printf("\n");
     }
   }
+  // the reference's instrumentation hooks (helib_amd_timing.hpp): statistics and a named timer
+  {
+    HELIB_AMD_NTIMER_START(decisions_test_tail);
+    HELIB_AMD_NTIMER_STOP(decisions_test_tail);
+  }
+  const FHEtimer* t = getTimerByName("decisions_test_tail");
+  fprintf(stderr, "timer %s calls %ld\n", t ? t->name : "?", t ? t->getNumCalls() : -1L);
+  print_stats(std::cerr);
   return 0;
 }

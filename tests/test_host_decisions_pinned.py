@@ -66,8 +66,14 @@ def test_getSet4Size_cpp(tmp_path):
         for c in cases:
             f2 = ints(c["from2"]) if "from2" in c else "-1"
             lines.append(f"set4 {c['low_bits'] * LN2!r} {c['high_bits'] * LN2!r} {int(c['reverse'])} {ints(c['from1'])} {f2}")
-        out = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout
-        rows = out.splitlines()
+        run = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True)
+        rows = run.stdout.splitlines()
+        # the reference's hooks (include/helib_amd_timing.hpp): the window statistics were collected
+        # (src/primeChain.cpp:207-208, 288-289) and the named timer ran once
+        assert "timer decisions_test_tail calls 1" in run.stderr
+        assert "window1-nchoices ave=" in run.stderr and "window1-out ave=" in run.stderr
+        if any("from2" in c for c in cases):
+            assert "window2-nchoices ave=" in run.stderr
         assert int(rows[0]) == len(FIX["table_order"])
         for c, r in zip(cases, rows[1:]):
             assert [int(x) for x in r.split()] == c["want"], c["name"]

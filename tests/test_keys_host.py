@@ -649,8 +649,17 @@ def test_capacity_isCorrect_frobenius():
     ct.lnNoise = ct.logOfPrimeSet()                                    # noise as large as the modulus
     assert not ct.isCorrect()
     assert hc.polyNormBnd(32768) == 1.0 and abs(hc.polyNormBnd(2 * 9) - 2 / math.tan(math.pi / 6) / 3) < 1e-12
-    with pytest.raises(NotImplementedError):
-        hc.polyNormBnd(105)
+    # m with several odd prime factors (calcPolyNormBnd's general case, src/PAlgebra.cpp:240-434): the
+    # maximal absolute row sum of the inverse Vandermonde matrix of the primitive rad(m)-th roots,
+    # here against numpy's inverse of that matrix; only the radical of the odd part matters
+    for m in (15, 105, 1705):
+        res = [i for i in range(1, m) if math.gcd(i, m) == 1]
+        V = np.vander(np.exp(2j * np.pi * np.array(res) / m), len(res), increasing=True)
+        want = np.abs(np.linalg.inv(V)).sum(axis=1).max()
+        assert abs(hc.polyNormBnd(m) - want) < 1e-9 * want
+    assert hc.polyNormBnd(4 * 45) == hc.polyNormBnd(15)
+    cg, _, _, skg = setup(105, 2, 200)
+    assert skg.Encrypt(rng.integers(0, 2, size=cg.phim)).isCorrect()   # used to raise for such m
     # Frobenius: X -> X^(p^j); ord(257) in Z_128^* is 2 (257 = 1 mod 128 -> order 1: identity)
     cc2, octx2, be2, sk2 = setup(128, 7, 300)
     hk.addFrbMatrices(sk2)
@@ -758,3 +767,55 @@ def test_power(e):
         assert c0 - ct.capacity() < (depth + 0.5) * 62        # about one 60-bit prime per level
     with pytest.raises(ValueError):
         ct.power(0)
+
+
+def test_named_timers_and_fhe_stats_hooks():
+    """The reference's instrumentation hooks on this path (helib_amd/timing.py): HELIB_TIMER_START
+    timers named after the functions (include/helib/timing.h:44-131; multiplyBy, multLowLvl,
+    reLinearize, modDownToSet ... as src/Ctxt.cpp has them), getTimerByName / resetAllTimers /
+    printNamedTimer, and the statistics the reference collects under fhe_stats: window2-nchoices /
+    window2-out (src/primeChain.cpp:288-289), mod-switch-added-noise (src/Ctxt.cpp:537),
+    KS-noise-ratio (:835) and break-into-digits-ratio (src/DoubleCRT.cpp:548)."""
+    import io
+    from helib_amd import timing
+    cc, octx, be, sk = setup(128, 257, 150)
+    rng = np.random.default_rng(3)
+    ma, mb = rng.integers(0, 257, size=cc.phim), rng.integers(0, 257, size=cc.phim)
+    timing.resetAllTimers()
+    timing.reset_stats()
+    old_measure, old_stats = hc.Ctxt.measure, timing.fhe_stats
+    hc.Ctxt.measure, timing.fhe_stats = True, True
+    try:
+        a, b = sk.Encrypt(ma), sk.Encrypt(mb)
+        a.multiplyBy(b)
+        a.multiplyBy(a.clone())        # level 2: a real mod-down on the way in
+        _ = a.lnNoise
+    finally:
+        hc.Ctxt.measure, timing.fhe_stats = old_measure, old_stats
+    assert sk.Decrypt(a) == [int(v) for v in B.polymul_mod_phi(B.polymul_mod_phi(ma, mb, 128, 257),
+                                                                B.polymul_mod_phi(ma, mb, 128, 257), 128, 257)]
+    for name, calls in (("multiplyBy", 2), ("multLowLvl", 2), ("reLinearize", 2)):
+        t = timing.getTimerByName(name)
+        assert t is not None and t.getNumCalls() == calls and t.getTime() > 0
+    assert timing.getTimerByName("modDownToSet").getNumCalls() >= 1
+    assert timing.getTimerByName("no such timer") is None
+    buf = io.StringIO()
+    assert timing.printNamedTimer("multiplyBy", buf) and " / 2 = " in buf.getvalue()
+    assert not timing.printNamedTimer("no such timer", buf)
+    timing.printAllTimers(buf)
+    stats = io.StringIO()
+    timing.print_stats(stats)
+    text = stats.getvalue()
+    for name in ("window2-nchoices", "window2-out", "mod-switch-added-noise", "KS-noise-ratio",
+                 "break-into-digits-ratio"):
+        assert name + " ave=" in text, text
+    # the measured added noise stays below its a-priori bound (the reference warns otherwise)
+    assert timing._stats["mod-switch-added-noise"].max < 1.0
+    assert timing._stats["break-into-digits-ratio"].max < 1.0
+    # nothing is collected while fhe_stats is off (the default)
+    timing.reset_stats()
+    c = sk.Encrypt(ma)
+    c.multiplyBy(sk.Encrypt(mb))
+    assert not timing._stats
+    timing.resetAllTimers()
+    assert timing.getTimerByName("multiplyBy").getNumCalls() == 0

@@ -253,6 +253,27 @@ def _keys(m=128, p=257, bits=150):
     return cc, octx, be, sk
 
 
+def test_keys_with_explicit_a_columns_are_not_written_as_reference_blobs_by_default():
+    """The a-columns of a key-switching matrix are not on the reference's wire (KeySwitch::writeTo,
+    src/keySwitching.cpp:196-240, stores prgSeed and HElib re-derives them with NTL's PRG, src/Ctxt.cpp:
+    196-206); this engine's keys hold them explicitly.  A well-formed reference blob of such a key would
+    load into HElib without complaint and key-switch to garbage, so the writers refuse it unless the
+    caller says engine_only=True; sk_only blobs (no matrices) and blobs read from the wire are not
+    affected."""
+    cc, octx, be, sk = _keys()
+    d = wire.from_seckey(sk)
+    assert all(w["explicit_a"] for w in d["keySwitching"])
+    for call in (lambda: wire.write_pubkey(d), lambda: wire.write_seckey(d), lambda: wire.pubkey_to_json(d),
+                 lambda: wire.seckey_to_json(d), lambda: wire.write_keyswitch(d["keySwitching"][0]),
+                 lambda: wire.keyswitch_to_json(d["keySwitching"][0])):
+        with pytest.raises(ValueError, match="engine_only=True"):
+            call()
+    assert wire.write_seckey(d, sk_only=True)                       # no matrices inside
+    raw = wire.write_seckey(d, engine_only=True)
+    back, _ = wire.read_seckey(raw)
+    assert wire.write_seckey(back) == raw                           # what came off the wire goes back on it
+
+
 def test_context_pubkey_seckey_2_2_0_layout_round_trip():
     cc, octx, be, sk = _keys()
     d = wire.from_seckey(sk, gens=[3, 127], ords=[32, -2])
@@ -265,7 +286,7 @@ def test_context_pubkey_seckey_2_2_0_layout_round_trip():
     assert wire.context_from_json(json.dumps(wire.context_to_json(d["context"]))) == c2
     # PubKey / SecKey, binary
     for writer, reader, sid in ((wire.write_pubkey, wire.read_pubkey, 10), (wire.write_seckey, wire.read_seckey, 15)):
-        raw = writer(d)
+        raw = writer(d, engine_only=True)
         assert raw[12] == sid
         k2, off = reader(raw, context=d["context"])
         assert off == len(raw) and writer(k2) == raw
@@ -291,9 +312,9 @@ def test_context_pubkey_seckey_2_2_0_layout_round_trip():
     assert off == len(raw) and set(k3) == {"context", "sKeys"} and len(raw) < 40000
     assert np.array_equal(k3["sKeys"][0][1], d["sKeys"][0][1])
     # JSON
-    j = json.dumps(wire.seckey_to_json(d))
+    j = json.dumps(wire.seckey_to_json(d, engine_only=True))
     k4 = wire.seckey_from_json(j, primes={i: q for i, q in enumerate(cc.primes)}, phim=cc.phim)
-    assert wire.write_seckey(k4) == wire.write_seckey(d)
+    assert wire.write_seckey(k4) == wire.write_seckey(d, engine_only=True)
     jj = json.loads(j)
     assert jj["type"] == "SecKey" and jj["content"]["PubKey"]["type"] == "PubKey"
     assert jj["content"]["PubKey"]["content"]["recryptEkey"] == "nullptr"
@@ -308,7 +329,7 @@ def test_keys_through_the_wire_still_work():
     from tests import bgv_ref as B
     cc, octx, be, sk = _keys()
     p, m = cc.p, cc.m
-    raw = wire.write_seckey(wire.from_seckey(sk))
+    raw = wire.write_seckey(wire.from_seckey(sk), engine_only=True)
     desc, _ = wire.read_seckey(raw)
     a_cols = {k: w.a for k, w in sk.keySwitching.items()}
     sk2 = wire.to_seckey(desc, hk.SecKey, cc, be, lambda idx, rows: OPoly(octx, idx, rows), ksw_a=a_cols, seed=77)
@@ -375,8 +396,8 @@ def test_cpp_wire_header_2_2_0_layout_against_the_python_writer(wire_exe):
     by the C++ reader/writer; header / eye-catcher / truncation / context errors are raised."""
     cc, octx, be, sk = _keys()
     d = wire.from_seckey(sk)
-    for mode, blob in (("context", wire.write_context(d["context"])), ("pubkey", wire.write_pubkey(d)),
-                       ("seckey", wire.write_seckey(d)), ("skonly", wire.write_seckey(d, sk_only=True))):
+    for mode, blob in (("context", wire.write_context(d["context"])), ("pubkey", wire.write_pubkey(d, engine_only=True)),
+                       ("seckey", wire.write_seckey(d, engine_only=True)), ("skonly", wire.write_seckey(d, sk_only=True))):
         got = wire_exe(mode, blob)
         assert got["consumed"] and got["same_bytes"], mode
         assert got["context"]["qs"] == [int(q) for q in cc.primes] and got["context"]["gens"] == d["context"]["gens"]
@@ -411,7 +432,7 @@ def test_cpp_wire_header_2_2_0_layout_against_the_python_writer(wire_exe):
     got = wire_exe("ctxt", wire.write_ctxt(desc))
     assert got["consumed"] and got["same_bytes"] and got["ptxtSpace"] == 1
     assert got["ratFactor"] == [desc["ratFactor"][0], desc["ratFactor"][1]] and got["ratFactor"][1] >= 1
-    assert all(wire_exe("errors", wire.write_seckey(d))["errors"])
+    assert all(wire_exe("errors", wire.write_seckey(d, engine_only=True))["errors"])
 
 
 def test_cpp_and_python_wire_agree_on_random_objects(wire_exe):
