@@ -188,6 +188,8 @@ struct hx_ctx {
   size_t bn_rows_cap = 0;
   unsigned long long* d_norm2 = nullptr;
   size_t norm_cap = 0;
+  double2* d_norm_park = nullptr;      // embed_norm_quarter_split_kernel: the parked sub-transforms
+  size_t norm_park_cap = 0;
   // deferred read-back of norms (hx_ctx_defer_norms): squared norms land in pinned host slots,
   // an event marks each; hx_norms_flush converts them into the callers' arrays
   struct NormPending {
@@ -469,6 +471,7 @@ static void ctx_free(hx_ctx* c)
   hipFree(c->d_bn_chat);
   hipFree(c->d_bn_Z);
   hipFree(c->d_norm2);
+  hipFree(c->d_norm_park);
   for (auto* v : {&c->norm_pending, &c->norm_free})
     for (auto& np : *v) {
       hipEventDestroy(np.ev);
@@ -2286,6 +2289,9 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_kernel<hx::NormSrcXS>,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                16 << hx::NORM_MAX_LOGH));
+    HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_split_kernel,
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               16 << hx::NORM_MAX_LOGH));
     attr = true;
   }
   if (!c->pow2) {
@@ -2306,6 +2312,23 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
                          lds, c->stream, src, c->d_wtab, logn, c->d_norm2);
     }
     c->xs_rows = 0;
+  } else if (logn - 1 > hx::NORM_MAX_LOGH && !getenv("HX_NORM_PLAIN")) {
+    // real-input form beyond one workgroup's LDS: S = N/2/8192 sub-transforms, one workgroup per pair
+    CHK(flush_xs(c));
+    const int logh = hx::NORM_MAX_LOGH;
+    const unsigned H = 1u << logh, S = (N >> 1) >> logh;
+    const size_t park_words = (size_t)rows * (S / 2) * H;   // complex doubles
+    if (c->norm_park_cap < park_words) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->d_norm_park)
+        HIPCHK(hipFree(c->d_norm_park));
+      c->d_norm_park = nullptr;
+      c->norm_park_cap = 0;
+      HIPCHK(hipMalloc((void**)&c->d_norm_park, park_words * sizeof(double2)));
+      c->norm_park_cap = park_words;
+    }
+    hipLaunchKernelGGL(hx::embed_norm_quarter_split_kernel, dim3((unsigned)rows * (S / 2)), dim3(hx::NORM_THREADS),
+                       16 * (size_t)H, c->stream, d_f, c->d_wtab, logn, logh, c->d_norm_park, c->d_norm2);
   } else {
     CHK(flush_xs(c));
     const int logh = std::min(logn, hx::NORM_MAX_LOGH);

@@ -10,9 +10,10 @@
 // f(W^(2j+1)) = sum_i g_i V^(ij), V = W^2 -- one N-point complex DFT.  Only the maximum modulus is
 // wanted, so the output order is irrelevant: decimation-in-frequency, in place, no bit-reversal,
 // two stages per LDS pass.  N <= 2^14 uses the real-input "quarter" form (one N/2-point transform
-// in one workgroup); larger N is split by log2(S) DIF levels applied while loading into S
-// independent H-point transforms (H = N/S <= 8192 complex doubles = 128 KiB of LDS), one workgroup
-// each.  Every workgroup folds its maximum into out2[row] with an atomic max on the bit pattern
+// in one workgroup); larger N (up to 2^17) the same form split into S = N/2/8192 sub-transforms, one
+// workgroup per pair of them (embed_norm_quarter_split_kernel); embed_norm_kernel is the plain
+// N-point form, split by log2(S) DIF levels applied while loading into S independent H-point
+// transforms (H = N/S <= 8192 complex doubles = 128 KiB of LDS), one workgroup each.  Every workgroup folds its maximum into out2[row] with an atomic max on the bit pattern
 // (non-negative doubles order like unsigned integers).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -190,6 +191,71 @@ embed_norm_quarter_kernel(SRC src, const double2* __restrict__ wtab, int logn,
     const double zr = re[p], zi = im[p], cr = re[M - 1 - p], ci = -im[M - 1 - p];
     const double er = 0.5 * (zr + cr), ei = 0.5 * (zi + ci);
     // O = (Z - C)/(2i) = (-i/2)(Z - C)
+    const double dr = zr - cr, di = zi - ci;
+    const double orr = 0.5 * di, oi = -0.5 * dr;
+    const double2 w = wtab[2 * j + 1];
+    const double tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
+    const double a = (er + tr) * (er + tr) + (ei + ti) * (ei + ti);
+    const double b = (er - tr) * (er - tr) + (ei - ti) * (ei - ti);
+    const double n2 = a > b ? a : b;
+    mx = n2 > mx ? n2 : mx;
+  }
+  block_max_to(mx, sm, tid, nth, out2 + row);
+}
+
+// The quarter form for N > 2^14 (M = N/2 = S*H points, H = 8192, S = 2, 4, 8): the M-point transform
+// of z_i = (f_2i + i f_(2i+1)) V^i as S sub-transforms of H points, the first log2(S) decimation
+// levels applied while loading (sub-transform s holds Z_j for j = s + S k', at p = brev(k')).  The
+// pairing partner Z_(M-1-j) lives in sub-transform S-1-s at position H-1-p, so one workgroup takes
+// the pair (s, S-1-s) of one row: sub-transform S-1-s first, parked in global memory (park:
+// [row][s][H] complex), then sub-transform s in LDS and the pairing pass of the quarter kernel over
+// its H positions -- the positions of sub-transform S-1-s give the complex conjugates of the same
+// four values.  Half the transform work and half the reads of embed_norm_kernel at the same N.
+__global__ void __launch_bounds__(NORM_THREADS)
+embed_norm_quarter_split_kernel(const double* __restrict__ f, const double2* __restrict__ wtab, int logn, int logh,
+                                double2* __restrict__ park, unsigned long long* __restrict__ out2)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const unsigned N = 1u << logn, M = N >> 1, H = 1u << logh, S = M >> logh, half = S >> 1;
+  double* re = sm;
+  double* im = sm + H;
+  const unsigned row = blockIdx.x / half, s = blockIdx.x % half;
+  const unsigned tid = threadIdx.x, nth = blockDim.x;
+  const double2* fp = reinterpret_cast<const double2*>(f + (size_t)row * N);
+  double2* pk = park + ((size_t)row * half + s) * H;
+  const unsigned mmask = 2 * N - 1;
+  for (int pass = 0; pass < 2; pass++) {
+    const unsigned sub = pass == 0 ? S - 1 - s : s;
+    // h_i = sum_t z_(i+tH) U^((i+tH) sub),  z_n U^(n sub) = (f_2n + i f_(2n+1)) W^(2n (2 sub + 1))
+    for (unsigned i = tid; i < H; i += nth) {
+      double ar = 0, ai = 0;
+      for (unsigned t = 0; t < S; t++) {
+        const unsigned idx = i + t * H;
+        const unsigned e = (2u * idx * (2u * sub + 1u)) & mmask;
+        const double2 w = wtab[e & (N - 1)];
+        const double2 v = fp[idx];
+        const double zr = v.x * w.x - v.y * w.y, zi = v.x * w.y + v.y * w.x;
+        ar += e >= N ? -zr : zr;
+        ai += e >= N ? -zi : zi;
+      }
+      re[i] = ar;
+      im[i] = ai;
+    }
+    __syncthreads();
+    // root U^S = W^(4S) = W^(2N/H): the table stride dif_fft_lds expects
+    dif_fft_lds(re, im, logh, N, wtab, tid, nth);
+    if (pass == 0) {
+      for (unsigned p = tid; p < H; p += nth)
+        pk[p] = make_double2(re[p], im[p]);
+      __syncthreads();
+    }
+  }
+  double mx = 0;
+  for (unsigned p = tid; p < H; p += nth) {
+    const unsigned j = s + S * (__brev(p) >> (32 - logh));
+    const double2 c = pk[H - 1 - p];
+    const double zr = re[p], zi = im[p], cr = c.x, ci = -c.y;
+    const double er = 0.5 * (zr + cr), ei = 0.5 * (zi + ci);
     const double dr = zr - cr, di = zi - ci;
     const double orr = 0.5 * di, oi = -0.5 * dr;
     const double2 w = wtab[2 * j + 1];

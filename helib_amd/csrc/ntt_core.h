@@ -160,6 +160,7 @@ HXD uint64_t shoup4_acc(uint64_t y, TW t, uint64_t nq, uint64_t x)
   u += (uint64_t)hh * nl;
   HX_KEEP64(u);
   uint64_t acc = (uint64_t)yl * wl + x;
+  HX_KEEP64(acc);  // (x stays the first multiply-add's addend: re-associated, it came back as a 64-bit add of its own)
   acc += (uint64_t)hl * nl;
   const uint32_t al = (uint32_t)acc, ah = (uint32_t)(acc >> 32);
   uint32_t rh;

@@ -157,9 +157,9 @@ moddown_S_kernel(ModDownPrep P, size_t n)
 // basis-extension kernel, several dropped primes) instead of x*inv - S
 template <bool PLAIN>
 struct ModDownIO {
-  // the load is x*inv (shoup4: [0,4q)) plus a residue of -S in [0,q]; the store takes the lazy
+  // the load is x*inv (shoup4: [0,4q)) plus q - S in (0,2q); the store takes the lazy
   // transform output and normalises once, after the subtraction
-  static constexpr int LOAD_BOUND = PLAIN ? 1 : 5;
+  static constexpr int LOAD_BOUND = PLAIN ? 1 : 6;
   static constexpr bool LAZY_STORE = true;
   // Element IO is software-pipelined in groups of IOG elements.  Round 1 loaded x, S (and, in the
   // store, c_r) inside the same scheduling region as the ~40 instructions that consume them, one
@@ -211,10 +211,10 @@ struct ModDownIO {
         });
       static_for<0, IOG>([&](auto J) {
         constexpr int j = decltype(J)::value, e = g * IOG + j;
-        const int64_t S = (int64_t)sb[g & 1][j];
-        const uint64_t r = shoup4(v[e], inv, qc.nq);          // [0,4q)
-        const uint64_t mag = (uint64_t)(S < 0 ? -S : S);      // <= ptxtSpace/2 + 1 < q (host-checked)
-        v[e] = r + (S > 0 ? q - mag : mag);                   // -S mod q as a value in [0,q]
+        // x*inv in [0,4q) plus q - S in (0,2q): |S| <= ptxtSpace/2 + 1 < q (host-checked), so the
+        // two's-complement difference q - S is the right positive number whatever the sign of S,
+        // and it rides on the multiply-add chain of the product as its addend -- no sign handling
+        v[e] = shoup4_acc(v[e], inv, qc.nq, q - sb[g & 1][j]);
       });
       HX_SCHED_FENCE();
     });
@@ -272,7 +272,7 @@ struct ModDownIO {
         if constexpr (B > 8)
           x = csub(x, qc.q8);                            // [0,8q)
         // c_r*cf - x as a value in (0,12q), normalised once
-        put(tid, eval_const<LOGN>(i), norm_from<12, EST>(shoup4(cb[g & 1][j], cf, qc.nq) + qc.q8 - x, qc));
+        put(tid, eval_const<LOGN>(i), norm_from<12, EST>(shoup4_acc(cb[g & 1][j], cf, qc.nq, qc.q8 - x), qc));
       });
       HX_SCHED_FENCE();
     });
