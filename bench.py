@@ -726,6 +726,16 @@ def main():
                  "verified": (f"decrypt(last product) == m_a*m_b mod (X^N+1, p) for all {nver} batch elements"
                               if nver else None)}
         if rank == 0:
+            rec = os.path.join(ROOT, "profiles", "r02_pmc_fresh_multiply_traffic.json")
+            if os.path.exists(rec):
+                with open(rec) as f:
+                    tr = json.load(f)
+                if tr.get("batch") == B and tr.get("bits") == args.bits:
+                    gb = tr["traffic_GB_per_multiply_of_the_batch"]
+                    # HBM bytes actually moved (PMC passes, recorded): all kernels of one step
+                    extra["hbm_traffic_GB_per_step"] = round(gb * R, 1)
+                    extra["hbm_traffic_avg_TBps_over_the_step"] = round(gb * R / (dt / args.steps) / 1e3, 2)
+                    extra["hbm_traffic_source"] = "profiles/r02_pmc_fresh_multiply_traffic.json"
             roof = ntt_roofline(hx, sub, fixed_primes, list(range(l)), list(range(l, l + k)),
                                 shape["digits"], B, rng, args.ntt_iters)
             if args.inputs == "real" and not args.no_extras:

@@ -146,6 +146,10 @@ public:
     return out;
   }
 
+  // DoubleCRT::randomize (src/DoubleCRT.cpp:1258-1378) on the device: uniform residues in every row
+  // from the ChaCha20 stream (key, stream) -- see hx_randomize in helib_amd.h
+  DoubleCRT& randomize(const uint8_t key32[32], uint64_t stream) { return chk(hx_randomize(h_.get(), key32, stream)); }
+
   // Cmodulus::FFT / iFFT on every row (coefficients <-> evaluations)
   DoubleCRT& FFT() { return chk(hx_ntt_forward(h_.get())); }
   DoubleCRT& iFFT() { return chk(hx_ntt_inverse(h_.get())); }

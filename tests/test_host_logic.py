@@ -216,3 +216,19 @@ def test_big_power_of_two_transform_replayed_on_cpu(replay, radix, logq):
     back = np.zeros(n, dtype=np.uint64)
     assert fn(logq, radix, 1, q, psi, want.ctypes.data, back.ctypes.data) == 0
     assert np.array_equal(back, x)
+
+
+def test_cpp_key_material_generator_is_chacha20_keyed_from_os_entropy(tmp_path):
+    """include/helib_amd_keys.hpp draws key material from a ChaCha20 generator keyed with
+    std::random_device by default (the reference seeds NTL's PRG from OS entropy, src/keys.cpp
+    GenKeySWmatrix: RandomBits(prgSeed, 256)); an explicit seed is deterministic, for tests.  The block
+    function reproduces RFC 8439 section 2.3.2."""
+    exe = str(tmp_path / "prg_test")
+    libdir = os.path.join(ROOT, "helib_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "prg_test.cpp"), "-L" + libdir, "-lhelib_amd",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.check_output([exe], text=True).splitlines()
+    assert out[0] == ("block e4e7f110 15593bd1 1fdd0f50 c47120a3 c7f4d1c7 0368c033 9aaa2204 4e6cd4c3 "
+                      "466482d2 09aa9f07 05d7c214 a2028bd9 d19c12b5 b94e16de e883d0cb 4e3c50a2")
+    assert out[1:] == ["seeded 1 1", "entropy 1", "urbg 1"]
