@@ -88,7 +88,9 @@ class ChaChaRng:
 
     def bytes(self, n):
         while len(self._buf) < n:
-            nb = max(64, (n - len(self._buf) + 63) // 64)
+            # (the block function is vectorised over blocks: large batches amortise the numpy calls --
+            # the bytes of the stream are the same whatever the batch size)
+            nb = max(4096, (n - len(self._buf) + 63) // 64)
             self._buf += chacha20_blocks(self.key, (0, 0, 0), self._ctr, nb)
             self._ctr += nb
         out, self._buf = self._buf[:n], self._buf[n:]
@@ -114,8 +116,10 @@ class ChaChaRng:
         mask = np.uint64((1 << bits) - 1)
         out = np.empty(n, dtype=np.uint64)
         have = 0
+        width = 1 if bits <= 8 else 2 if bits <= 16 else 4 if bits <= 32 else 8   # bytes per candidate
         while have < n:
-            c = self._u64(max(16, int((n - have) * 1.3))) & mask
+            want = max(16, int((n - have) * 1.3))
+            c = np.frombuffer(self.bytes(width * want), dtype=f"<u{width}").astype(np.uint64) & mask
             c = c[c < np.uint64(span)][:n - have]
             out[have:have + len(c)] = c
             have += len(c)
