@@ -288,21 +288,67 @@ static void bitrev_permute(uint64_t* a, long n)
   }
 }
 
-static void cyclic_ntt(uint64_t* a, long n, uint64_t omega, uint64_t q)
+/* x*w mod q (canonical) with wp = floor(w 2^64 / q), any x < 2^64, q < 2^63: Shoup's form of the
+ * same product ho_mulmod computes -- r = x w - floor(x wp / 2^64) q lies in [0, 2q).  Used for the
+ * butterflies only (what NTL's MulModPrecon does in its FFT), so that the CPU baseline bench.py
+ * reports is not dominated by 128-by-64-bit divisions; every value is the same canonical residue. */
+static inline uint64_t mulmod_precon(uint64_t x, uint64_t w, uint64_t wp, uint64_t q)
 {
-  bitrev_permute(a, n);
+  uint64_t h = (uint64_t)(((u128)x * wp) >> 64);
+  uint64_t r = x * w - h * q;
+  return r >= q ? r - q : r;
+}
+
+/* The stage tables (w^j and their Shoup companions for every stage, n - 1 entries each) are built
+ * once per (q, n, omega) and kept per thread -- NTL keeps its FFT tables per prime the same way
+ * (FFTTablesType); building them by a dependent chain of ho_mulmod on every call cost more than
+ * the butterflies. */
+typedef struct {
+  uint64_t q, omega;
+  long n;
+  uint64_t* w;  /* [2*(n-1)]: stage with half-length h starts at h-1; wp after the w block */
+} ntt_tab;
+static __thread ntt_tab* g_tabs = NULL;
+static __thread long g_ntabs = 0, g_tabcap = 0;
+
+static const uint64_t* ntt_tables(long n, uint64_t omega, uint64_t q)
+{
+  for (long i = 0; i < g_ntabs; i++)
+    if (g_tabs[i].q == q && g_tabs[i].n == n && g_tabs[i].omega == omega)
+      return g_tabs[i].w;
+  if (g_ntabs == g_tabcap) {
+    g_tabcap = g_tabcap ? 2 * g_tabcap : 64;
+    g_tabs = (ntt_tab*)realloc(g_tabs, (size_t)g_tabcap * sizeof(ntt_tab));
+  }
+  uint64_t* w = (uint64_t*)malloc((size_t)2 * (size_t)n * sizeof(uint64_t));
+  uint64_t* wp = w + n;
   for (long len = 2; len <= n; len <<= 1) {
     uint64_t wlen = ho_powmod(omega, (uint64_t)(n / len), q);
     long half = len >> 1;
-    /* twiddle table for this stage */
-    uint64_t* w = (uint64_t*)malloc((size_t)half * sizeof(uint64_t));
-    w[0] = 1;
+    uint64_t* ws = w + (half - 1);
+    ws[0] = 1 % q;
     for (long j = 1; j < half; j++)
-      w[j] = ho_mulmod(w[j - 1], wlen, q);
+      ws[j] = ho_mulmod(ws[j - 1], wlen, q);
+    for (long j = 0; j < half; j++)
+      wp[half - 1 + j] = (uint64_t)((((u128)ws[j]) << 64) / q);
+  }
+  ntt_tab t = {q, omega, n, w};
+  g_tabs[g_ntabs++] = t;
+  return w;
+}
+
+static void cyclic_ntt(uint64_t* a, long n, uint64_t omega, uint64_t q)
+{
+  bitrev_permute(a, n);
+  const uint64_t* tab = ntt_tables(n, omega, q);
+  for (long len = 2; len <= n; len <<= 1) {
+    long half = len >> 1;
+    const uint64_t* w = tab + (half - 1);
+    const uint64_t* wp = tab + n + (half - 1);
     for (long i = 0; i < n; i += len) {
       for (long j = 0; j < half; j++) {
         uint64_t u = a[i + j];
-        uint64_t v = ho_mulmod(a[i + j + half], w[j], q);
+        uint64_t v = mulmod_precon(a[i + j + half], w[j], wp[j], q);
         uint64_t s = u + v;
         if (s >= q)
           s -= q;
@@ -311,7 +357,6 @@ static void cyclic_ntt(uint64_t* a, long n, uint64_t omega, uint64_t q)
         a[i + j + half] = d;
       }
     }
-    free(w);
   }
 }
 
@@ -326,6 +371,9 @@ struct ho_cmod {
   uint32_t* zms; /* Z_m^* reps, increasing */
   /* pow2: powers[i] = w0^i, ipowers[i] = w1^i  (src/CModulus.cpp:118-135) */
   uint64_t *powers, *ipowers;
+  /* pow2 only: Shoup companions of powers[i], and ipowers[i]/N with its companions (the
+   * reference's MulModPrecon tables, src/CModulus.cpp:121-135: same canonical products) */
+  uint64_t *powers_p, *ipn, *ipn_p;
   /* Bluestein (src/bluestein.cpp:76-132): powers[i]=root^{i^2}, chirp b */
   long bk, bk2;      /* conv length 2^bk */
   uint64_t *b, *ib;  /* chirp polys, length bk2 (time domain) */
@@ -398,10 +446,17 @@ ho_cmod* ho_cmod_create(uint64_t m, uint64_t q, uint64_t root)
     long phim = c->phim;
     c->powers = (uint64_t*)malloc((size_t)phim * 8);
     c->ipowers = (uint64_t*)malloc((size_t)phim * 8);
+    c->powers_p = (uint64_t*)malloc((size_t)phim * 8);
+    c->ipn = (uint64_t*)malloc((size_t)phim * 8);
+    c->ipn_p = (uint64_t*)malloc((size_t)phim * 8);
+    const uint64_t ninv = ho_invmod((uint64_t)phim % q, q);
     uint64_t w = 1, iw = 1;
     for (long i = 0; i < phim; i++) {
       c->powers[i] = w;
       c->ipowers[i] = iw;
+      c->powers_p[i] = (uint64_t)((((u128)w) << 64) / q);
+      c->ipn[i] = ho_mulmod(iw, ninv, q);
+      c->ipn_p[i] = (uint64_t)((((u128)c->ipn[i]) << 64) / q);
       w = ho_mulmod(w, c->root, q);
       iw = ho_mulmod(iw, c->rInv, q);
     }
@@ -446,6 +501,9 @@ void ho_cmod_destroy(ho_cmod* c)
   free(c->zms);
   free(c->powers);
   free(c->ipowers);
+  free(c->powers_p);
+  free(c->ipn);
+  free(c->ipn_p);
   free(c->b);
   free(c->ib);
   free(c->Rb);
@@ -530,7 +588,7 @@ void ho_cmod_fft(const ho_cmod* c, const uint64_t* x, uint64_t* y)
     /* src/CModulus.cpp:389-426 */
     uint64_t* t = (uint64_t*)malloc((size_t)phim * 8);
     for (long i = 0; i < phim; i++)
-      t[i] = ho_mulmod(x[i] % q, c->powers[i], q);
+      t[i] = mulmod_precon(x[i], c->powers[i], c->powers_p[i], q);   /* (any x < 2^64: the % q is implied) */
     cyclic_ntt(t, phim, ho_mulmod(c->root, c->root, q), q);
     memcpy(y, t, (size_t)phim * 8);
     free(t);
@@ -557,11 +615,8 @@ void ho_cmod_ifft(const ho_cmod* c, const uint64_t* y, uint64_t* x)
     memcpy(t, y, (size_t)phim * 8);
     uint64_t w1sq = ho_mulmod(c->rInv, c->rInv, q);
     cyclic_ntt(t, phim, w1sq, q);
-    uint64_t ninv = ho_invmod((uint64_t)phim % q, q);
-    for (long i = 0; i < phim; i++) {
-      uint64_t v = ho_mulmod(t[i], ninv, q);
-      x[i] = ho_mulmod(v, c->ipowers[i], q);
-    }
+    for (long i = 0; i < phim; i++)   /* (t/N) * w1^i as one product with ipn[i] = w1^i / N */
+      x[i] = mulmod_precon(t[i], c->ipn[i], c->ipn_p[i], q);
     free(t);
     return;
   }
