@@ -43,6 +43,7 @@ hipError_t launch_moddown_apply_plain_pow2(int logn, const PolyBases& polys, con
 using hx::ExtArgs;
 using hx::ExtPlanDev;
 using hx::MAX_ROWS;
+static constexpr int MAX_EXT_SRC = hx::EXT_MAXSRC;  // source primes of one exact basis extension (generic kernel)
 using hx::ModDownApply;
 using hx::ModDownPrep;
 using hx::NttRows;
@@ -1871,8 +1872,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
                     bool scaled = false)
 {
   int n = (int)src.size(), nt = (int)tgt.size();
-  if (n < 1 || n > 64)
-    return fail(HX_ERR_UNSUPPORTED, "basis extension supports 1..64 source primes (got %d)", n);
+  if (n < 1 || n > MAX_EXT_SRC)
+    return fail(HX_ERR_UNSUPPORTED, "basis extension supports 1..%d source primes (got %d)", MAX_EXT_SRC, n);
   if (nt > MAX_ROWS)
     return fail(HX_ERR_UNSUPPORTED, "too many target primes");
   std::vector<uint64_t> key;
@@ -2055,6 +2056,12 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     pl->dev.fast16_ok = ok16 ? 1u : 0u;
   }
   pl->dev.tgt_chunk7 = hx::as_ro(reinterpret_cast<const uint32_t*>(d + o_tchunk));
+  {
+    bool unit = scaled && ptxt > 1;   // (P mod t is 1 in a scaled plan)
+    for (int t = 0; t < nt && unit; t++)
+      unit = ptxt <= tq(t);
+    pl->dev.corr_unit = unit ? 1u : 0u;
+  }
   c->plans[key] = pl;
   *out = pl;
   return HX_OK;
@@ -2087,8 +2094,12 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args, size
   else if (n <= 40)
     hipLaunchKernelGGL((hx::rns_extend_kernel<40>), grid, block, 0, c->stream, pl->dev, args,
                        row_words);
-  else
+  else if (n <= 64)
     hipLaunchKernelGGL((hx::rns_extend_kernel<64>), grid, block, 0, c->stream, pl->dev, args,
+                       row_words);
+  else  // whole chains of the reference's own benchmark parameter (bits=6400: 143 primes, e.g. the
+        // toPoly of a decryption): the digits live in private memory -- slow, and rare
+    hipLaunchKernelGGL((hx::rns_extend_kernel<MAX_EXT_SRC>), grid, block, 0, c->stream, pl->dev, args,
                        row_words);
   HIPCHK(hipGetLastError());
   return HX_OK;
@@ -2467,8 +2478,8 @@ extern "C" int hx_add_primes(hx_poly* a, const int* add_idx, int nadd)
     a->prime_idx.assign(add_idx, add_idx + nadd);
     return HX_OK;
   }
-  if (old > 64)
-    return fail(HX_ERR_UNSUPPORTED, "addPrimes from more than 64 primes");
+  if (old > MAX_EXT_SRC)
+    return fail(HX_ERR_UNSUPPORTED, "addPrimes from more than %d primes", MAX_EXT_SRC);
   // toPoly: inverse transform of a copy
   CHK(ensure_scratch(c, 0, (size_t)old * rw));
   CHK(dcopy(c, c->scratch[0], a->d, (size_t)old * rw));
@@ -2514,8 +2525,8 @@ extern "C" int hx_poly_rem(const hx_poly* a, uint64_t t, uint64_t* out_host)
     memset(out_host, 0, rw * 8);
     return HX_OK;
   }
-  if (n > 64)
-    return fail(HX_ERR_UNSUPPORTED, "toPoly from more than 64 primes on the device");
+  if (n > MAX_EXT_SRC)
+    return fail(HX_ERR_UNSUPPORTED, "toPoly from more than %d primes on the device", MAX_EXT_SRC);
   CHK(ensure_scratch(c, 0, (size_t)(n + 1) * rw));
   CHK(dcopy(c, c->scratch[0], a->d, (size_t)n * rw));
   CHK(ntt_rows(c, c->scratch[0], a->prime_idx, n, 0, n, a->batch, true));
@@ -2803,8 +2814,8 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
   }
   if (keep.empty())
     return fail(HX_ERR_PRIMESET, "s and the index set must have some intersection");
-  if ((int)drop.size() > 64)
-    return fail(HX_ERR_UNSUPPORTED, "scaleDownToSet dropping more than 64 primes");
+  if ((int)drop.size() > MAX_EXT_SRC)
+    return fail(HX_ERR_UNSUPPORTED, "scaleDownToSet dropping more than %d primes", MAX_EXT_SRC);
   size_t rw = a->row_words();
   int nd = (int)drop.size(), nk = (int)keep.size();
   bool small_S = true;  // |S| <= ptxtSpace/2 + 1 is a reduced residue of every kept prime

@@ -356,6 +356,9 @@ struct ExtPlanDev {
   uint32_t fast_ok;          // break_digits_fast_kernel's preconditions hold for this plan:
                              // garner_cs, every prime > 2^32 (32-bit reciprocals), n <= 8
   uint32_t fast16_ok;        // the same with n <= 16: rns_extend_fast_kernel
+  uint32_t corr_unit;        // scaled plan (tables carry P^-1, so "P mod t" is 1) and ptxtSpace <= every
+                             // target prime: the plaintext-space correction of a target is the balanced
+                             // remainder itself -- no reduction, no 128-bit Barrett product per target
   ro_u32 tgt_chunk7;  // [nt] 1: every source prime <= q_t, so the limb sum may be taken 7
                                // terms at a time with the previous remainder carried (r + 7 p q < 8 q^2)
   ro_u64 tgt_pack;    // [nt][8 + 2n] everything the fast kernels need of one target in ONE record
@@ -442,12 +445,13 @@ __device__ __forceinline__ uint64_t mixed_radix_residue_lazy(const uint64_t (&a)
   return red128_wide(acc, q, mu, k);
 }
 
+constexpr int EXT_MAXSRC = 192;  // source primes of one extension (a whole bits=6400 chain: 143)
 struct ExtArgs {
   const uint64_t* src;       // coefficient rows, [row][batch][N]
   uint64_t* dst;             // output rows,      [row][batch][N]
   uint64_t* upd;             // rows updated in place (breakIntoDigits), may alias src
-  uint16_t src_row[64];      // row of source prime k inside src      (n <= 64)
-  uint16_t own_dst_row[64];  // where to copy the source residue in dst (0xffff: no copy)
+  uint16_t src_row[EXT_MAXSRC];      // row of source prime k inside src
+  uint16_t own_dst_row[EXT_MAXSRC];  // where to copy the source residue in dst (0xffff: no copy)
   uint16_t dst_row[MAX_ROWS];  // output row of target t inside dst
   uint16_t upd_row[MAX_ROWS];  // row inside upd to update (0xffff: none)
   int nu;                    // targets [0,nu) are the ones with an upd_row (host orders them first)
@@ -566,8 +570,9 @@ rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
       r = sub_mod(r, P.pmod[t], q);
     if (dm_nonzero) {
       // delta -= diffProd * delta_i_modP
-      uint64_t d = red64(dm_abs, q, mu64);
-      uint64_t corr = mul_mod(P.pmod[t], d, q, P.tgt_mu[t], P.tgt_k[t]);
+      uint64_t corr = dm_abs;
+      if (!P.corr_unit)
+        corr = mul_mod(P.pmod[t], red64(dm_abs, q, mu64), q, P.tgt_mu[t], P.tgt_k[t]);
       r = dm_negative ? add_mod(r, corr, q) : sub_mod(r, corr, q);
     }
     return r;
@@ -952,8 +957,9 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
     }
     if (dm_nonzero) {
       // delta -= diffProd * delta_i_modP
-      uint64_t d = red64(dm_abs, q, T.mu64());
-      uint64_t corr = mul_mod(T.pmod(), d, q, T.mu(), T.k());
+      uint64_t corr = dm_abs;
+      if (!P.corr_unit)
+        corr = mul_mod(T.pmod(), red64(dm_abs, q, T.mu64()), q, T.mu(), T.k());
       r = dm_negative ? add_mod(r, corr, q) : sub_mod(r, corr, q);
     }
     if (A.dst_row[t] != 0xffff)

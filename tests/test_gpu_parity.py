@@ -1267,7 +1267,10 @@ def test_ckks_encrypt_multiply_decrypt_gpu_vs_oracle(hx, m, precision, bits, c, 
         assert np.max(np.abs(got - want)) < 2.0 ** (-precision + 6) / n
 
 
-@pytest.mark.parametrize("m,L,t", [(16384, 5, 65537), (16384, 3, 2), (128, 4, (1 << 59) + 1), (1705, 3, 49)])
+@pytest.mark.parametrize("m,L,t", [(16384, 5, 65537), (16384, 3, 2), (128, 4, (1 << 59) + 1), (1705, 3, 49),
+                                   # whole chains of the reference's own benchmark parameter (bits=6400: 143
+                                   # primes): beyond 64 source primes the digits live in private memory
+                                   (128, 70, 257), (256, 150, 65537)])
 def test_poly_rem_is_toPoly_then_PolyRed(hx, m, L, t):
     """hx_poly_rem = DoubleCRT::toPoly (centred CRT) + PolyRed(t, abs=true), the tail of
     SecKey::Decrypt (src/keys.cpp:1383-1405), against the oracle's big-integer toPoly."""
