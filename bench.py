@@ -376,7 +376,38 @@ def batch1_latency(hx, hc, fa, fb, sync, reps=12):
         if i >= 2:
             ts.append((time.perf_counter() - t0) * 1e3)
     ts.sort()
-    return ts[len(ts) // 2], ts[0]
+    # the same multiply recorded once into a HIP graph and replayed with one launch (the reference's
+    # loop multiplies the same two ciphertexts every iteration too); noise bounds instead of measured
+    # noise: a recording cannot contain the read-backs
+    graph_ms = None
+    measure = hc.Ctxt.measure
+    try:
+        hc.Ctxt.measure = False
+        w = a1.clone()
+        w.multiplyBy(b1)                      # eagerly once with bounds (plans of this variant)
+        sync()
+        ctx = a1.parts["1"].context
+        ctx.graphBegin()
+        rec = a1.clone()
+        rec.multiplyBy(b1)
+        graph = ctx.graphEnd()
+        gs = []
+        for i in range(reps + 2):
+            sync()
+            t0 = time.perf_counter()
+            graph.launch()
+            sync()
+            if i >= 2:
+                gs.append((time.perf_counter() - t0) * 1e3)
+        gs.sort()
+        same = all(np.array_equal(rec.parts[h].download(), w.parts[h].download()) for h in w.parts)
+        graph.destroy()
+        graph_ms = (gs[len(gs) // 2], gs[0]) if same else "replayed result differs from the eager one"
+    except Exception as e:
+        graph_ms = f"unavailable: {type(e).__name__}: {str(e)[:120]}"
+    finally:
+        hc.Ctxt.measure = measure
+    return ts[len(ts) // 2], ts[0], graph_ms
 
 
 def bgv_basic_ops(hx, hc, cc, fa, fb, sk, msgs, sync, reps=8):
@@ -746,9 +777,11 @@ def main():
                     extra["bgv_basic_ops"] = bgv_basic_ops(hx, hc, cc, fa, fb, sk, msgs, sync)
                 except Exception as e:   # (a wrong result is a SystemExit and still aborts the bench)
                     extra["bgv_basic_ops"] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
-                med, best = batch1_latency(hx, hc, fa, fb, sync)
+                med, best, gms = batch1_latency(hx, hc, fa, fb, sync)
                 extra["batch1_latency_ms"] = round(med, 4)
                 extra["batch1_latency_ms_min"] = round(best, 4)
+                # one hipGraphLaunch per multiply (noise bounds): [median, min] in ms
+                extra["batch1_latency_hip_graph_ms"] = [round(v, 4) for v in gms] if isinstance(gms, tuple) else gms
                 md = moddown_launch_set(hx, hc, cc, ctx, fa, fb)
                 if md:
                     t, src = recorded_traffic("r02_pmc_moddown_apply_traffic.json", "ntt_moddown_apply_kernel<14>",

@@ -55,6 +55,7 @@ SYMBOLS = [
     "hx_intel_EltwiseSubMod", "hx_intel_EltwiseSubModScalar", "hx_intel_EltwiseMultMod",
     "hx_intel_EltwiseMultModScalar",
     "hx_time_ntt", "hx_ctx_timer_begin", "hx_ctx_timer_end", "hx_randomize",
+    "hx_ctx_graph_begin", "hx_ctx_graph_end", "hx_graph_launch", "hx_graph_destroy",
 ]
 
 
@@ -134,6 +135,8 @@ def lib():
             "hx_time_ntt": [vp, ip, ip, ip, vp],
             "hx_ctx_timer_begin": [vp], "hx_ctx_timer_end": [vp, vp],
             "hx_randomize": [vp, C.c_char_p, C.c_uint64],
+            "hx_ctx_graph_begin": [vp], "hx_ctx_graph_end": [vp, vp], "hx_graph_launch": [vp],
+            "hx_graph_destroy": [vp],
         }
         for name, args in sig.items():
             f = getattr(L, name)
@@ -212,6 +215,18 @@ class Context:
         _chk(lib().hx_ctx_timer_end(self.h, C.byref(ms)))
         return ms.value
 
+    def graphBegin(self):
+        """Start recording everything enqueued on this context into a HIP graph (hx_ctx_graph_begin):
+        the calls return as usual, nothing runs.  Run the sequence once eagerly first; no uploads,
+        downloads or measured-noise read-backs inside."""
+        _chk(lib().hx_ctx_graph_begin(self.h))
+
+    def graphEnd(self):
+        """Close the recording; returns a Graph whose launch() replays it with one launch."""
+        g = C.c_void_p()
+        _chk(lib().hx_ctx_graph_end(self.h, C.byref(g)))
+        return Graph(self, g)
+
     def deferNorms(self, on):
         """Deferred read-back of the measured-noise norms (hx_ctx_defer_norms)."""
         if bool(on) != getattr(self, "_defer", False):
@@ -238,6 +253,30 @@ class Context:
 
     def sync(self):
         _chk(lib().hx_ctx_sync(self.h))
+
+
+class Graph:
+    """A captured sequence of engine calls (hx_graph): launch() re-executes the same kernels on the
+    same buffers -- the inputs are whatever the input polys hold now, the results land in the polys
+    the recorded calls produced."""
+
+    def __init__(self, ctx, handle):
+        self.context, self.h = ctx, handle
+
+    def launch(self):
+        _chk(lib().hx_graph_launch(self.h))
+        return self
+
+    def destroy(self):
+        if self.h:
+            lib().hx_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 class DoubleCRT:

@@ -71,9 +71,11 @@ static int fail(int code, const char* fmt, ...)
 #define HIPCHK(expr)                                                                     \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \
-    if (_e != hipSuccess)                                                                \
+    if (_e != hipSuccess) {                                                              \
+      (void)hipGetLastError(); /* reported here: do not leave it for an unrelated check */ \
       return fail(HX_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
                   __FILE__, __LINE__);                                                   \
+    }                                                                                    \
   } while (0)
 #define CHK(expr)          \
   do {                     \
@@ -203,6 +205,14 @@ struct hx_ctx {
   bool defer_norms = false;
   std::vector<NormPending> norm_pending, norm_free;
   hipEvent_t timer[2] = {nullptr, nullptr};  // hx_ctx_timer_begin / _end
+  // HIP graphs (hx_ctx_graph_begin / _end): while a capture is open or a captured graph is alive,
+  // nothing a graph may point at is handed back -- slabs released by polys wait in graph_deferred,
+  // buffers that are re-grown (scratch, twiddle arena, tables) are retired instead of freed
+  bool capturing = false;
+  int graphs_alive = 0;
+  hipStream_t own_stream = nullptr;   // created by the first capture of a context that ran on the default stream
+  std::vector<std::pair<void*, size_t>> graph_deferred;
+  std::vector<void*> graph_retired;
 };
 
 struct hx_poly {
@@ -248,6 +258,14 @@ static int use(hx_ctx* c)
   std::lock_guard<std::recursive_mutex> _ctx_lock((ctx)->mu);      \
   CHK(use(ctx))
 
+// entry points that must wait for the device cannot be recorded into a graph: they fail before
+// touching HIP, so that the open capture stays valid
+#define NO_CAPTURE(ctx, what)                                                                      \
+  do {                                                                                             \
+    if ((ctx)->capturing)                                                                          \
+      return fail(HX_ERR_INVALID, what " waits for the device and cannot be captured in a graph"); \
+  } while (0)
+
 static constexpr size_t POOL_GRAIN = (size_t)2 << 20;        // slabs are multiples of 2 MiB
 static constexpr size_t POOL_LIMIT = (size_t)64 << 30;        // keep at most 64 GiB cached
 static size_t pool_round(size_t bytes) { return (bytes + POOL_GRAIN - 1) / POOL_GRAIN * POOL_GRAIN; }
@@ -272,9 +290,29 @@ static hipError_t pool_alloc(hx_ctx* c, size_t bytes, void** out)
   }
   return e;
 }
+// a device buffer that is being replaced by a larger one: freed now, or kept for the graphs that
+// may have its address baked in (released when the last of them is destroyed)
+static void retire_or_free(hx_ctx* c, void* p, bool device_wide_sync = false)
+{
+  if (!p)
+    return;
+  if (c->capturing || c->graphs_alive > 0) {
+    c->graph_retired.push_back(p);
+    return;
+  }
+  if (device_wide_sync)
+    hipDeviceSynchronize();
+  else
+    hipStreamSynchronize(c->stream);
+  hipFree(p);
+}
 static void pool_free(hx_ctx* c, void* p, size_t bytes)
 {
   size_t sz = pool_round(bytes);
+  if (c->capturing || c->graphs_alive > 0) {
+    c->graph_deferred.emplace_back(p, sz);
+    return;
+  }
   if (c->pool_bytes + sz > POOL_LIMIT) {
     hipStreamSynchronize(c->stream);
     hipFree(p);
@@ -289,8 +327,7 @@ static int ensure_scratch(hx_ctx* c, int slot, size_t words)
   if (c->scratch_words[slot] >= words)
     return HX_OK;
   if (c->scratch[slot]) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipFree(c->scratch[slot]));
+    retire_or_free(c, c->scratch[slot]);
     c->scratch[slot] = nullptr;
     c->scratch_words[slot] = 0;
   }
@@ -465,6 +502,12 @@ static void ctx_free(hx_ctx* c)
       hipFree(c->scratch[i]);
   for (auto& kv : c->pool)
     hipFree(kv.second);
+  for (auto& kv : c->graph_deferred)
+    hipFree(kv.first);
+  if (c->own_stream)
+    hipStreamDestroy(c->own_stream);
+  for (void* q : c->graph_retired)
+    hipFree(q);
   hipFree(c->d_frac);
   hipFree(c->d_wtab);
   hipFree(c->d_bn_v);
@@ -520,6 +563,8 @@ extern "C" int hx_ctx_set_stream(hx_ctx* c, void* s)
   if (!c)
     return fail(HX_ERR_INVALID, "null context");
   std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (c->capturing)
+    return fail(HX_ERR_INVALID, "hx_ctx_set_stream while a graph is being captured");
   if (c->stream != (hipStream_t)s) {
     // pooled slabs are recycled in stream order: drain the old stream before switching
     hipSetDevice(c->device);
@@ -533,6 +578,7 @@ extern "C" int hx_ctx_sync(hx_ctx* c)
   if (!c)
     return fail(HX_ERR_INVALID, "null context");
   CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_ctx_sync");
   HIPCHK(hipStreamSynchronize(c->stream));
   return HX_OK;
 }
@@ -569,7 +615,7 @@ static int tw_reserve(hx_ctx* c, size_t extra)
   if (c->d_tw) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(nd, c->d_tw, c->tw_used * sizeof(TW), hipMemcpyDeviceToDevice));
-    HIPCHK(hipFree(c->d_tw));
+    retire_or_free(c, c->d_tw, true);   // (a live graph keeps using the old arena: its content stays valid)
   }
   c->d_tw = nd;
   c->tw_cap = ncap;
@@ -694,7 +740,7 @@ static int cprime_add(hx_ctx* c, uint64_t q, uint64_t fwd_off, uint64_t inv_off,
     if (c->d_cprimes) {
       HIPCHK(hipDeviceSynchronize());
       HIPCHK(hipMemcpy(nd, c->d_cprimes, sizeof(PrimeDev) * c->ncprimes, hipMemcpyDeviceToDevice));
-      HIPCHK(hipFree(c->d_cprimes));
+      retire_or_free(c, c->d_cprimes, true);
     }
     c->d_cprimes = nd;
     c->cprimes_cap = ncap;
@@ -1174,6 +1220,8 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
   if (!c)
     return fail(HX_ERR_INVALID, "null context");
   CTX_ENTER(c);
+  if (c->capturing)
+    return fail(HX_ERR_INVALID, "hx_ctx_add_prime while a graph is being captured");
   // 16q <= 2^64 is what the lazy butterflies of the row kernels need (ntt_core.h); the reference
   // cannot make larger primes either (HELIB_SP_NBITS <= 60, src/PrimeGenerator.h:54-59)
   if (q < 3 || q >= (1ull << 60) || !hxh::is_prime(q))
@@ -1370,6 +1418,7 @@ extern "C" int hx_poly_upload(hx_poly* p, const uint64_t* host)
   if (!p || !host)
     return fail(HX_ERR_INVALID, "null argument");
   CTX_ENTER(p->ctx);
+  NO_CAPTURE(p->ctx, "hx_poly_upload");
   OWN(p);
   size_t bytes = (size_t)p->nrows() * p->row_words() * 8;
   HIPCHK(hipMemcpyAsync(p->d, host, bytes, hipMemcpyHostToDevice, p->ctx->stream));
@@ -1381,6 +1430,7 @@ extern "C" int hx_poly_download(const hx_poly* p, uint64_t* host)
   if (!p || !host)
     return fail(HX_ERR_INVALID, "null argument");
   CTX_ENTER(p->ctx);
+  NO_CAPTURE(p->ctx, "hx_poly_download");
   size_t bytes = (size_t)p->nrows() * p->row_words() * 8;
   HIPCHK(hipMemcpyAsync(host, p->d, bytes, hipMemcpyDeviceToHost, p->ctx->stream));
   HIPCHK(hipStreamSynchronize(p->ctx->stream));
@@ -1656,6 +1706,7 @@ extern "C" int hx_time_ntt(hx_poly* p, int dir, int iters, int max_rows, float* 
     return fail(HX_ERR_INVALID, "bad argument");
   hx_ctx* c = p->ctx;
   CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_time_ntt");
   OWN(p);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
@@ -1697,11 +1748,114 @@ extern "C" int hx_ctx_timer_end(hx_ctx* c, float* ms)
   if (!c || !ms)
     return fail(HX_ERR_INVALID, "bad argument");
   CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_ctx_timer_end");
   if (!c->timer[0])
     return fail(HX_ERR_INVALID, "hx_ctx_timer_end without hx_ctx_timer_begin");
   HIPCHK(hipEventRecord(c->timer[1], c->stream));
   HIPCHK(hipEventSynchronize(c->timer[1]));
   HIPCHK(hipEventElapsedTime(ms, c->timer[0], c->timer[1]));
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------
+// HIP graphs: a sequence of engine calls captured once and replayed with one launch -- for the
+// launch-bound case (one ciphertext at a time, as benchmarks/bgv_basic.cpp:158-164 runs: ~40 kernels
+// of a few microseconds each per multiply).  Everything enqueued on the context between begin and
+// end is recorded instead of run.  A replay re-executes exactly those kernels on exactly those
+// buffers: the inputs are whatever the input polys hold at replay time, the outputs land in the polys
+// the captured calls returned.  While a graph is alive the context keeps every buffer the graph may
+// point at (see hx_ctx::graph_deferred / graph_retired).  Calls that must wait for the device
+// (downloads, uploads, norm read-backs) cannot be captured: HIP fails them, and so does end().
+// ------------------------------------------------------------------
+struct hx_graph {
+  hx_ctx* ctx;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+extern "C" int hx_ctx_graph_begin(hx_ctx* c)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null context");
+  CTX_ENTER(c);
+  if (c->capturing)
+    return fail(HX_ERR_INVALID, "a graph is already being captured on this context");
+  if (!c->norm_pending.empty())
+    return fail(HX_ERR_INVALID, "deferred norms are pending: hx_norms_flush before capturing");
+  if (!c->stream) {
+    // the legacy default stream cannot be captured: from here on the context runs on a stream of
+    // its own (everything enqueued so far is complete after the device-wide wait)
+    HIPCHK(hipDeviceSynchronize());
+    if (!c->own_stream)
+      HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+  }
+  HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+  c->capturing = true;
+  return HX_OK;
+}
+extern "C" int hx_ctx_graph_end(hx_ctx* c, hx_graph** out)
+{
+  if (!c || !out)
+    return fail(HX_ERR_INVALID, "null argument");
+  CTX_ENTER(c);
+  if (!c->capturing)
+    return fail(HX_ERR_INVALID, "hx_ctx_graph_end without hx_ctx_graph_begin");
+  c->capturing = false;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(c->stream, &g);
+  if (e != hipSuccess || !g)
+    return fail(HX_ERR_DEVICE, "graph capture failed (a captured call needed the device to finish?): %s",
+                hipGetErrorString(e));
+  hipGraphExec_t x = nullptr;
+  e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    hipGraphDestroy(g);
+    return fail(HX_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  }
+  hx_graph* h = new hx_graph();
+  h->ctx = c;
+  h->graph = g;
+  h->exec = x;
+  c->graphs_alive++;
+  c->refs++;
+  *out = h;
+  return HX_OK;
+}
+extern "C" int hx_graph_launch(hx_graph* g)
+{
+  if (!g)
+    return fail(HX_ERR_INVALID, "null graph");
+  hx_ctx* c = g->ctx;
+  CTX_ENTER(c);
+  if (c->capturing)
+    return fail(HX_ERR_INVALID, "hx_graph_launch while another graph is being captured");
+  HIPCHK(hipGraphLaunch(g->exec, c->stream));
+  return HX_OK;
+}
+extern "C" int hx_graph_destroy(hx_graph* g)
+{
+  if (!g)
+    return HX_OK;
+  hx_ctx* c = g->ctx;
+  {
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    hipGraphExecDestroy(g->exec);
+    hipGraphDestroy(g->graph);
+    if (--c->graphs_alive == 0 && !c->capturing) {
+      // nothing points at them any more: slabs go back to the pool, replaced buffers are freed
+      std::vector<std::pair<void*, size_t>> d;
+      d.swap(c->graph_deferred);
+      for (auto& kv : d)
+        pool_free(c, kv.first, kv.second);
+      for (void* q : c->graph_retired)
+        hipFree(q);
+      c->graph_retired.clear();
+    }
+  }
+  ctx_release(c);
+  delete g;
   return HX_OK;
 }
 
@@ -2129,9 +2283,7 @@ static int frac_begin(hx_ctx* c, size_t doubles)
                 "device embedding norms need m a power of two or m <= 131072 (otherwise the host keeps "
                 "the reference's noiseBoundForUniform bound)");
   if (c->frac_cap < doubles) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->d_frac)
-      HIPCHK(hipFree(c->d_frac));
+    retire_or_free(c, c->d_frac);
     c->d_frac = nullptr;
     c->frac_cap = 0;
     HIPCHK(hipMalloc((void**)&c->d_frac, doubles * sizeof(double)));
@@ -2236,8 +2388,7 @@ static int embed_norms_general(hx_ctx* c, const double* d_f, int rows)
   const unsigned H = 1u << logh, S = (unsigned)(P >> logh);
   const size_t cap = std::max<size_t>(1, ((size_t)1 << 28) / (16 * P));  // <= 256 MiB of work buffer
   if (c->bn_rows_cap < std::min<size_t>(cap, (size_t)rows)) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    hipFree(c->d_bn_Z);
+    retire_or_free(c, c->d_bn_Z);
     c->d_bn_Z = nullptr;
     c->bn_rows_cap = std::min<size_t>(cap, (size_t)rows);
     HIPCHK(hipMalloc((void**)&c->d_bn_Z, c->bn_rows_cap * P * 16));
@@ -2277,9 +2428,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     HIPCHK(hipMemcpy(c->d_wtab, h.data(), sizeof(double) * 2 * (size_t)N, hipMemcpyHostToDevice));
   }
   if (c->norm_cap < (size_t)rows) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->d_norm2)
-      HIPCHK(hipFree(c->d_norm2));
+    retire_or_free(c, c->d_norm2);
     c->d_norm2 = nullptr;
     c->norm_cap = 0;
     HIPCHK(hipMalloc((void**)&c->d_norm2, sizeof(unsigned long long) * (size_t)rows));
@@ -2330,9 +2479,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     const unsigned H = 1u << logh, S = (N >> 1) >> logh;
     const size_t park_words = (size_t)rows * (S / 2) * H;   // complex doubles
     if (c->norm_park_cap < park_words) {
-      HIPCHK(hipStreamSynchronize(c->stream));
-      if (c->d_norm_park)
-        HIPCHK(hipFree(c->d_norm_park));
+      retire_or_free(c, c->d_norm_park);
       c->d_norm_park = nullptr;
       c->norm_park_cap = 0;
       HIPCHK(hipMalloc((void**)&c->d_norm_park, park_words * sizeof(double2)));
@@ -2381,6 +2528,7 @@ extern "C" int hx_norms_flush(hx_ctx* c)
   if (!c)
     return fail(HX_ERR_INVALID, "null context");
   CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_norms_flush");
   for (auto& np : c->norm_pending) {
     HIPCHK(hipEventSynchronize(np.ev));
     for (int r = 0; r < np.rows; r++) {
@@ -2409,6 +2557,7 @@ extern "C" int hx_embedding_norm(hx_ctx* c, const double* f_host, int rows, doub
   if (!c || !f_host || !norms_out || rows < 1)
     return fail(HX_ERR_INVALID, "bad argument");
   CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_embedding_norm");
   const size_t n = (size_t)rows * c->phim;
   CHK(frac_begin(c, n));
   c->want_frac = false;
@@ -2519,6 +2668,7 @@ extern "C" int hx_poly_rem(const hx_poly* a, uint64_t t, uint64_t* out_host)
     return fail(HX_ERR_INVALID, "modulus must be in [2, 2^60)");
   hx_ctx* c = a->ctx;
   CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_poly_rem");
   const int n = a->nrows();
   const size_t rw = a->row_words();
   if (n == 0) {  // the zero polynomial

@@ -278,6 +278,24 @@ int hx_time_ntt(hx_poly* p, int dir, int iters, int max_rows, float* avg_ms);
 int hx_ctx_timer_begin(hx_ctx* ctx);
 int hx_ctx_timer_end(hx_ctx* ctx, float* ms);
 
+/* ---- HIP graphs: the launch-bound case -------------------------------------------------------
+ * The reference's benchmark loop runs ONE ciphertext at a time (benchmarks/bgv_basic.cpp:158-164:
+ * copy, multiplyBy); on the device that is ~40 kernels of a few microseconds each, bound by launch
+ * latency.  hx_ctx_graph_begin starts recording everything enqueued on the context (the calls
+ * return as usual but nothing runs), hx_ctx_graph_end closes the recording into a graph, and
+ * hx_graph_launch replays it with one launch: the same kernels on the same buffers -- inputs are
+ * whatever the input polys hold at launch time, results land in the polys the recorded calls
+ * produced (keep them).  Run the sequence once eagerly first (plans, tables and kernel attributes
+ * are set up on first use).  Calls that must wait for the device -- uploads, downloads, norm
+ * read-backs (use the reference's noise bounds, not measured noise, in a captured sequence) --
+ * cannot be recorded and make hx_ctx_graph_end fail.  While a graph is alive the context keeps
+ * every buffer it may reference. */
+typedef struct hx_graph hx_graph;
+int hx_ctx_graph_begin(hx_ctx* ctx);
+int hx_ctx_graph_end(hx_ctx* ctx, hx_graph** out);
+int hx_graph_launch(hx_graph* g);
+int hx_graph_destroy(hx_graph* g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,25 @@ public:
   void sync() const { check(hx_ctx_sync(h_.get())); }
   hx_ctx* handle() const { return h_.get(); }
 
+  // HIP graphs (helib_amd.h: hx_ctx_graph_begin / _end): everything enqueued on this context between
+  // graphBegin() and graphEnd() is recorded instead of run; Graph::launch() replays it with one launch
+  // on the same buffers.  For the launch-bound case: one ciphertext at a time.
+  class Graph {
+  public:
+    explicit Graph(hx_graph* g) : g_(g, [](hx_graph* p) { hx_graph_destroy(p); }) {}
+    void launch() const { check(hx_graph_launch(g_.get())); }
+
+  private:
+    std::shared_ptr<hx_graph> g_;
+  };
+  void graphBegin() const { check(hx_ctx_graph_begin(h_.get())); }
+  Graph graphEnd() const
+  {
+    hx_graph* g = nullptr;
+    check(hx_ctx_graph_end(h_.get(), &g));
+    return Graph(g);
+  }
+
 private:
   uint64_t m_;
   long phim_ = 0;

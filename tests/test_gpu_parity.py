@@ -1634,3 +1634,101 @@ def test_cpp_host_keys_encrypt_multiply_rotate_decrypt(hx, m, p, bits, measure, 
                            "-Wl,-rpath," + libdir, "-o", exe])
     r = subprocess.run([exe, str(m), str(p), str(bits), str(measure)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "keys_test OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_captured_graph_replays_a_multiply(hx):
+    """hx_ctx_graph_begin / _end / hx_graph_launch: tensorProduct + reLinearize (hx_mul_relin) recorded
+    once and replayed with one launch.  A replay re-executes the same kernels on the same buffers, so
+    (a) nothing runs while recording, (b) new data uploaded into the SAME input polys gives the new
+    product in the SAME output polys, bit-exact against the oracle, (c) slabs released while a graph
+    is alive are not handed out again (the graph may point at them), and come back to the pool when it
+    is destroyed."""
+    m, L, K = 16384, 3, 1
+    digits = [[0, 1], [2]]
+    g60 = O.PrimeGen(60, m)
+    primes = [g60.next() for _ in range(L + K)]
+    P = Pair(hx, m, primes)
+    own, sp = list(range(L)), list(range(L, L + K))
+    allp = own + sp
+    batch = 2
+    ins = [P.rand(own, s, batch) for s in (1, 2, 3, 4)]
+    kb = np.stack([P.rand(allp, 20 + i)[:, 0] for i in range(len(digits))])
+    ka = np.stack([P.rand(allp, 30 + i)[:, 0] for i in range(len(digits))])
+    W = hx.KeySwitch(P.g, allp, kb, ka)
+    G = [hx.DoubleCRT(P.g, own, batch, x) for x in ins]
+
+    def want(data):
+        return [P.o.mul_relin(own, sp, digits, *(x[:, b] for x in data), kb, ka) for b in range(batch)]
+
+    def check(o0, o1, data):
+        g0, g1 = o0.download(), o1.download()
+        for b, (w0, w1) in enumerate(want(data)):
+            assert np.array_equal(g0[:, b], w0) and np.array_equal(g1[:, b], w1)
+
+    e0, e1 = hx.multiplyBy(*G, W, digits)              # eagerly once: plans, tables, kernel attributes
+    check(e0, e1, ins)
+    P.g.graphBegin()
+    o0, o1 = hx.multiplyBy(*G, W, digits)
+    graph = P.g.graphEnd()
+    zeros = np.zeros_like(o0.download())
+    o0.upload(zeros)                                    # (whatever the slabs held: nothing ran yet)
+    o1.upload(zeros)
+    graph.launch()
+    check(o0, o1, ins)
+    # new operands in the same polys; garbage allocated and dropped in between (would reuse a slab the
+    # graph's temporaries live in if the context handed those out)
+    new = [P.rand(own, 50 + s, batch) for s in range(4)]
+    for d, x in zip(G, new):
+        d.upload(x)
+    junk = [hx.DoubleCRT(P.g, allp, batch, P.rand(allp, 70 + i, batch)) for i in range(6)]
+    del junk
+    o0.upload(zeros)
+    graph.launch()
+    check(o0, o1, new)
+    graph.launch().launch()                             # idempotent on unchanged inputs
+    check(o0, o1, new)
+    # not capturable: a call that has to wait for the device fails (and leaves the recording open)
+    P.g.graphBegin()
+    with pytest.raises(hx.HxError) as ei:
+        o0.download()
+    assert "cannot be captured" in str(ei.value)
+    with pytest.raises(hx.HxError):
+        P.g.graphBegin()                                # one recording at a time
+    P.g.graphEnd().destroy()
+    graph.destroy()
+    f0, f1 = hx.multiplyBy(*G, W, digits)              # the context works as before
+    check(f0, f1, new)
+
+
+def test_captured_graph_of_the_fresh_multiplyBy_sequence(hx, monkeypatch):
+    """The whole fresh Ctxt::multiplyBy (copy, both bringToSet mod-switches, tensor product,
+    dropSmallAndSpecialPrimes, key switch; the reference's noise bounds -- measured noise needs
+    read-backs) recorded through the python mirror and replayed: the replayed result equals the
+    eager one word for word -- the loop body of benchmarks/bgv_basic.cpp:158-164 as one launch."""
+    from helib_amd import ctxt as hc
+    from tests import test_ctxt_host as T
+    m, p = 16384, 65537
+    monkeypatch.setattr(hc.Ctxt, "measure", False)
+    ctx = hc.ChainContext(m, p, 1, bits=250, c=3)
+    P = Pair(hx, m, ctx.primes)
+    s, allp, kb, ka, rows = T.make_keys(ctx, P.o)
+    rng = np.random.default_rng(8)
+    ma, mb = rng.integers(0, p, size=P.N), rng.integers(0, p, size=P.N)
+    ea, eb = T.encrypt(ctx, P.o, s, ma, 1, rows), T.encrypt(ctx, P.o, s, mb, 2, rows)
+    gW = hx.KeySwitch(P.g, allp, kb, ka)
+    fa = hc.Ctxt.fresh(ctx, hx, *(hx.DoubleCRT(P.g, ctx.ctxtPrimes, 1, x[:, None, :]) for x in ea), ksw=gW)
+    fb = hc.Ctxt.fresh(ctx, hx, *(hx.DoubleCRT(P.g, ctx.ctxtPrimes, 1, x[:, None, :]) for x in eb), ksw=gW)
+    eager = fa.clone()
+    eager.multiplyBy(fb)
+    want = {h: (q.getIndexSet(), q.download()) for h, q in eager.parts.items()}
+    P.g.graphBegin()
+    rec = fa.clone()
+    rec.multiplyBy(fb)
+    graph = P.g.graphEnd()
+    for _ in range(3):
+        graph.launch()
+    assert rec.primeSet == eager.primeSet and set(rec.parts) == set(want)
+    for h, (idx, data) in want.items():
+        assert rec.parts[h].getIndexSet() == idx and np.array_equal(rec.parts[h].download(), data)
+    assert T.decrypt(ctx, P.o, s, rec, rows) == T.decrypt(ctx, P.o, s, eager, rows)
+    graph.destroy()
