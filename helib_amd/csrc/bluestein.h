@@ -23,6 +23,7 @@ struct ConvPrimeDev {
   uint32_t k, logn;
   SplitTW S;           // only for split sizes (radix 4: 2^16, 2^17)
   SplitTW8 S8;         // radix 8: 2^18
+  SplitTW16 S16;       // radix 16: 2^19
 };
 // per prime constants of the Bluestein transform
 struct BluePrimeDev {
@@ -141,40 +142,50 @@ conv_split_kernel(uint64_t* __restrict__ cbuf, uint64_t* __restrict__ qbuf, PtrL
   }
 }
 
-// radix-8 split: cbuf[(ri*batch+b)][8Q]  <->  qbuf[((ri*8+g)*batch+b)][Q]
+// radix-8 / radix-16 split: cbuf[(ri*batch+b)][R Q]  <->  qbuf[((ri*R+g)*batch+b)][Q]
+template <int LS>
+__device__ __forceinline__ const SplitTWN<LS>& split_tw(const ConvPrimeDev* C)
+{
+  if constexpr (LS == 3)
+    return C->S8;
+  else
+    return C->S16;
+}
+template <int LS>
 __global__ void __launch_bounds__(256)
-conv_split8_kernel(uint64_t* __restrict__ cbuf, uint64_t* __restrict__ qbuf, PtrList cps, int batch,
+conv_splitN_kernel(uint64_t* __restrict__ cbuf, uint64_t* __restrict__ qbuf, PtrList cps, int batch,
                    uint32_t Q, int inverse)
 {
+  constexpr int R = 1 << LS;
   const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
   const ConvPrimeDev* C = (const ConvPrimeDev*)cps.p[ri];
   const uint64_t q = C->q;
-  uint64_t* c = cbuf + ((size_t)ri * batch + b) * 8 * Q;
+  uint64_t* c = cbuf + ((size_t)ri * batch + b) * R * Q;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < Q; p += gridDim.x * blockDim.x) {
-    uint64_t e[8];
+    uint64_t e[R];
     if (!inverse) {
 #pragma unroll
-      for (int g = 0; g < 8; g++)
+      for (int g = 0; g < R; g++)
         e[g] = c[p + (size_t)g * Q];
-      split_fwd8(e, C->S8, q);
+      split_fwdN<LS>(e, split_tw<LS>(C), q);
 #pragma unroll
-      for (int g = 0; g < 8; g++)
-        qbuf[(((size_t)ri * 8 + g) * batch + b) * Q + p] = e[g];
+      for (int g = 0; g < R; g++)
+        qbuf[(((size_t)ri * R + g) * batch + b) * Q + p] = e[g];
     } else {
 #pragma unroll
-      for (int g = 0; g < 8; g++)
-        e[g] = qbuf[(((size_t)ri * 8 + g) * batch + b) * Q + p];
-      split_inv8(e, C->S8, q);
+      for (int g = 0; g < R; g++)
+        e[g] = qbuf[(((size_t)ri * R + g) * batch + b) * Q + p];
+      split_invN<LS>(e, split_tw<LS>(C), q);
 #pragma unroll
-      for (int g = 0; g < 8; g++)
+      for (int g = 0; g < R; g++)
         c[p + (size_t)g * Q] = e[g];
     }
   }
 }
 
-// ---- power-of-two rings beyond one row kernel (N = 2^16 .. 2^18, m up to 2^19): Cmodulus::FFT /
+// ---- power-of-two rings beyond one row kernel (N = 2^16 .. 2^19, m up to 2^20): Cmodulus::FFT /
 // iFFT (src/CModulus.cpp:389-426, 493-553; the reference only needs k <= NTL's MaxRoot, :108-110) as
-// S = 4 / 8 sub-transforms of Q = N/S points (conv_core.h) with NATURAL order on both sides:
+// S = 4 / 8 / 16 sub-transforms of Q = N/S points (conv_core.h) with NATURAL order on both sides:
 //   forward   big_pre  : in[row][b][p + gQ] --first log2(S) Cooley-Tukey stages--> qbuf[((ri*S+g)*batch+b)][p]
 //             row kernels on the S sub-blocks (each natural order within its block)
 //             big_post : out[row][b][j*S + brev(g)] = qbuf[g][j]       (the bit reversal of the top index bits)
@@ -185,7 +196,7 @@ __global__ void __launch_bounds__(256)
 big_pre_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ qbuf, NttRows rows, PtrList cps, int batch,
                uint32_t Q, int inverse)
 {
-  constexpr int LS = S == 8 ? 3 : 2;
+  constexpr int LS = S == 16 ? 4 : (S == 8 ? 3 : 2);
   const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
   const ConvPrimeDev* C = (const ConvPrimeDev*)cps.p[ri];
   const uint64_t q = C->q;
@@ -196,8 +207,8 @@ big_pre_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ qbuf, Ntt
 #pragma unroll
       for (int g = 0; g < S; g++)
         e[g] = src[p + (size_t)g * Q];
-      if constexpr (S == 8) {
-        split_fwd8(e, C->S8, q);
+      if constexpr (S >= 8) {
+        split_fwdN<LS>(e, split_tw<LS>(C), q);
       } else {
         uint64_t o[4];
         split_fwd4(e[0], e[1], e[2], e[3], C->S, q, o);
@@ -220,7 +231,7 @@ __global__ void __launch_bounds__(256)
 big_post_kernel(const uint64_t* __restrict__ qbuf, uint64_t* __restrict__ out, NttRows rows, PtrList cps, int batch,
                 uint32_t Q, int inverse)
 {
-  constexpr int LS = S == 8 ? 3 : 2;
+  constexpr int LS = S == 16 ? 4 : (S == 8 ? 3 : 2);
   const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
   const ConvPrimeDev* C = (const ConvPrimeDev*)cps.p[ri];
   const uint64_t q = C->q;
@@ -235,8 +246,8 @@ big_post_kernel(const uint64_t* __restrict__ qbuf, uint64_t* __restrict__ out, N
       for (int g = 0; g < S; g++)
         dst[(size_t)p * S + brev_bits((unsigned)g, LS)] = e[g];
     } else {
-      if constexpr (S == 8) {
-        split_inv8(e, C->S8, q);
+      if constexpr (S >= 8) {
+        split_invN<LS>(e, split_tw<LS>(C), q);
       } else {
         const uint64_t c4[4] = {e[0], e[1], e[2], e[3]};
         uint64_t a[4];

@@ -4,7 +4,7 @@
 // convolution whenever deg(a)+deg(b) < 2^k, which is how it is used here.
 //
 // Sizes up to 2^15 run directly on the row kernels of ntt_core.h.  Sizes 2^16 / 2^17 are
-// split radix-4: the first two Cooley-Tukey stages are done by split_fwd4 on four elements
+// split radix-4 (2^18 radix-8, 2^19 radix-16: below): the first two Cooley-Tukey stages are done by split_fwd4 on four elements
 // Q = 2^(k-2) apart, then four independent Q-point sub-transforms follow, each with its own
 // twiddle table (build_tw_tables_sub, OUT = 2).  The output order of the split transform is
 // not the natural one -- irrelevant for convolutions (forward, pointwise, inverse).
@@ -52,18 +52,23 @@ HXD void split_inv4(const uint64_t (&c)[4], const SplitTW& S, uint64_t q, uint64
   a[3] = shoup_full(subm(e1, e3, q), S.iT1q, q);
 }
 
-// ---- radix-8 split (convolution size 2^18 = 8 x 2^15): the first THREE Cooley-Tukey stages on
-// eight elements Q = 2^(k-3) apart, generic form of the above.  T[idx] = psi_rev_full[idx] for
-// idx = 1..7 (stage s uses idx = 2^s + group), iT[idx] their inverses; the inverse folds 1/8 into
-// its last stage (iT1e = T[1]^-1 / 8, eighth = 1/8).
-struct SplitTW8 {
-  TW T[8], iT[8];
-  TW iT1e, eighth;
+// ---- radix-2^LS split, LS = 3 (convolution size 2^18 = 8 x 2^15) or 4 (2^19 = 16 x 2^15): the first
+// LS Cooley-Tukey stages on 2^LS elements Q = 2^(k-LS) apart, generic form of the above.
+// T[idx] = psi_rev_full[idx] for idx = 1 .. 2^LS - 1 (stage s uses idx = 2^s + group), iT[idx] their
+// inverses; the inverse folds 1/2^LS into its last stage (iT1e = T[1]^-1 / 2^LS, inv = 1/2^LS).
+template <int LS>
+struct SplitTWN {
+  TW T[1 << LS], iT[1 << LS];
+  TW iT1e, inv;
 };
-HXD void split_fwd8(uint64_t (&e)[8], const SplitTW8& S, uint64_t q)
+typedef SplitTWN<3> SplitTW8;
+typedef SplitTWN<4> SplitTW16;
+template <int LS>
+HXD void split_fwdN(uint64_t (&e)[1 << LS], const SplitTWN<LS>& S, uint64_t q)
 {
-  for (int s = 0; s < 3; s++) {
-    const int m = 1 << s, half = 4 >> s;
+  constexpr int R = 1 << LS;
+  for (int s = 0; s < LS; s++) {
+    const int m = 1 << s, half = (R / 2) >> s;
     for (int g = 0; g < m; g++)
       for (int j = 0; j < half; j++) {
         const int a = g * 2 * half + j, b = a + half;
@@ -74,10 +79,12 @@ HXD void split_fwd8(uint64_t (&e)[8], const SplitTW8& S, uint64_t q)
       }
   }
 }
-HXD void split_inv8(uint64_t (&e)[8], const SplitTW8& S, uint64_t q)
+template <int LS>
+HXD void split_invN(uint64_t (&e)[1 << LS], const SplitTWN<LS>& S, uint64_t q)
 {
-  for (int s = 2; s >= 1; s--) {
-    const int m = 1 << s, half = 4 >> s;
+  constexpr int R = 1 << LS;
+  for (int s = LS - 1; s >= 1; s--) {
+    const int m = 1 << s, half = (R / 2) >> s;
     for (int g = 0; g < m; g++)
       for (int j = 0; j < half; j++) {
         const int a = g * 2 * half + j, b = a + half;
@@ -86,11 +93,13 @@ HXD void split_inv8(uint64_t (&e)[8], const SplitTW8& S, uint64_t q)
         e[b] = shoup_full(subm(x, y, q), S.iT[m + g], q);
       }
   }
-  for (int j = 0; j < 4; j++) {
-    const uint64_t x = e[j], y = e[j + 4];
-    e[j] = shoup_full(addm(x, y, q), S.eighth, q);
-    e[j + 4] = shoup_full(subm(x, y, q), S.iT1e, q);
+  for (int j = 0; j < R / 2; j++) {
+    const uint64_t x = e[j], y = e[j + R / 2];
+    e[j] = shoup_full(addm(x, y, q), S.inv, q);
+    e[j + R / 2] = shoup_full(subm(x, y, q), S.iT1e, q);
   }
 }
+HXD void split_fwd8(uint64_t (&e)[8], const SplitTW8& S, uint64_t q) { split_fwdN<3>(e, S, q); }
+HXD void split_inv8(uint64_t (&e)[8], const SplitTW8& S, uint64_t q) { split_invN<3>(e, S, q); }
 
 }  // namespace hx

@@ -116,8 +116,8 @@ struct ExtPlan {
 
 struct ConvPlan {  // negacyclic NTT of size 2^logn for one prime
   int logn = 0;
-  int split = 0;             // 0: one row transform; 4 / 8: radix-4 / radix-8 split into sub-transforms
-  int pd[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // indices into hx_ctx::d_cprimes
+  int split = 0;             // 0: one row transform; 4 / 8 / 16: radix-4 / -8 / -16 split into sub-transforms
+  int pd[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // indices into hx_ctx::d_cprimes
   hx::ConvPrimeDev* dev = nullptr;
 };
 struct BluePrime {
@@ -788,8 +788,8 @@ static int conv_tables_sub(hx_ctx* c, uint64_t q, uint64_t psi, int OUT, unsigne
 static int conv_plan_create(hx_ctx* c, uint64_t q, int logn, uint64_t psi, ConvPlan* pl)
 {
   pl->logn = logn;
-  pl->split = logn > 17 ? 8 : (logn > 15 ? 4 : 0);
-  if (logn < 1 || logn > 18)
+  pl->split = logn > 18 ? 16 : (logn > 17 ? 8 : (logn > 15 ? 4 : 0));
+  if (logn < 1 || logn > 19)
     return fail(HX_ERR_UNSUPPORTED, "convolution size 2^%d not supported (m too large)", logn);
   hx::ConvPrimeDev h;
   memset(&h, 0, sizeof h);
@@ -812,24 +812,31 @@ static int conv_plan_create(hx_ctx* c, uint64_t q, int logn, uint64_t psi, ConvP
       case 14: CHK(conv_tables_sub<14>(c, q, psi, 0, 0, &pl->pd[0])); break;
       case 15: CHK(conv_tables_sub<15>(c, q, psi, 0, 0, &pl->pd[0])); break;
     }
-  } else if (pl->split == 8) {
-    for (unsigned g = 0; g < 8; g++)
-      CHK(conv_tables_sub<15>(c, q, psi, 3, g, &pl->pd[g]));
+  } else if (pl->split >= 8) {
+    const int LS = pl->split == 16 ? 4 : 3, R = pl->split;
+    for (unsigned g = 0; g < (unsigned)R; g++)
+      CHK(conv_tables_sub<15>(c, q, psi, LS, g, &pl->pd[g]));
     auto mk = [&](uint64_t w) {
       TW t;
       t.w = w;
       t.wp = hxh::shoup(w, q);
       return t;
     };
-    const uint64_t eighth = hxh::invmod(8 % q, q);
-    for (unsigned idx = 1; idx < 8; idx++) {
-      const uint64_t T = hxh::powmod(psi, hx::brev_bits(idx, logn), q);
-      h.S8.T[idx] = mk(T);
-      h.S8.iT[idx] = mk(hxh::invmod(T, q));
-    }
-    h.S8.T[0] = h.S8.iT[0] = mk(0);
-    h.S8.eighth = mk(eighth);
-    h.S8.iT1e = mk(hxh::mulmod(h.S8.iT[1].w, eighth, q));
+    const uint64_t rinv = hxh::invmod((uint64_t)R % q, q);
+    auto fill = [&](auto& S) {
+      for (unsigned idx = 1; idx < (unsigned)R; idx++) {
+        const uint64_t T = hxh::powmod(psi, hx::brev_bits(idx, logn), q);
+        S.T[idx] = mk(T);
+        S.iT[idx] = mk(hxh::invmod(T, q));
+      }
+      S.T[0] = S.iT[0] = mk(0);
+      S.inv = mk(rinv);
+      S.iT1e = mk(hxh::mulmod(S.iT[1].w, rinv, q));
+    };
+    if (R == 16)
+      fill(h.S16);
+    else
+      fill(h.S8);
   } else {
     for (unsigned g = 0; g < 4; g++) {
       if (logn == 16)
@@ -904,13 +911,16 @@ static int conv_core(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vector
     return ntt_launch(c, logn, c->d_cprimes, buf, buf, rows, batch, true);
   }
   const uint32_t Q = N / (uint32_t)split;
-  const int lsub = logn - (split == 8 ? 3 : 2);
+  const int lsub = logn - (split == 16 ? 4 : (split == 8 ? 3 : 2));
   for (int r = 0; r < R; r++)
     for (int g = 0; g < split; g++)
       rows.emplace_back(r * split + g, plans[r]->pd[g]);
   auto split_launch = [&](int inverse) {
-    if (split == 8)
-      hipLaunchKernelGGL(hx::conv_split8_kernel, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
+    if (split == 16)
+      hipLaunchKernelGGL(hx::conv_splitN_kernel<4>, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
+                         cps, batch, Q, inverse);
+    else if (split == 8)
+      hipLaunchKernelGGL(hx::conv_splitN_kernel<3>, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
                          cps, batch, Q, inverse);
     else
       hipLaunchKernelGGL(hx::conv_split_kernel, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
@@ -1044,7 +1054,7 @@ static int blue_prime_create(hx_ctx* c, int idx)
     c->psi_low.assign(psi.begin(), psi.begin() + c->dq + 1);
   }
   int maxk = std::max(c->bk, std::max(c->n1, c->n2));
-  if (maxk > 18)
+  if (maxk > 19)
     return fail(HX_ERR_UNSUPPORTED, "m too large for the Bluestein path (conv size 2^%d)", maxk);
   if ((int)c->blue.size() <= idx)
     c->blue.resize(idx + 1, nullptr);
@@ -1158,7 +1168,7 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
   const uint32_t NB = 1u << c->bk, N1 = 1u << c->n1, N2 = 1u << c->n2;
   // chunk so that the convolution buffers stay below ~1 GiB each
   size_t per_row = (size_t)batch * NB * 8;
-  int chunk = (int)std::max<size_t>(1, std::min<size_t>(MAX_ROWS / (c->bk > 17 ? 8 : 4), ((size_t)1 << 30) / per_row));
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>(MAX_ROWS / (c->bk > 18 ? 16 : (c->bk > 17 ? 8 : 4)), ((size_t)1 << 30) / per_row));
   for (size_t first = 0; first < rows.size(); first += chunk) {
     const int R = (int)std::min<size_t>(chunk, rows.size() - first);
     NttRows nr;
@@ -1267,7 +1277,7 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
     }
   }
   ConvPlan big;
-  if (c->pow2 && c->logn >= 16 && c->logn <= 18)
+  if (c->pow2 && c->logn >= 16 && c->logn <= 19)
     CHK(conv_plan_create(c, q, c->logn, root, &big));
   PrimeDev pd;
   memset(&pd, 0, sizeof pd);
@@ -1602,13 +1612,13 @@ static int ntt_launch(hx_ctx* c, int logn, const PrimeDev* table, const uint64_t
 static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
                           const std::vector<std::pair<int, int>>& rows, int batch, bool inverse);
 
-// power-of-two rings with N = 2^16..2^18: split into 4 / 8 sub-transforms on the row kernels, natural
+// power-of-two rings with N = 2^16..2^19: split into 4 / 8 / 16 sub-transforms on the row kernels, natural
 // order in and out (kernels and layout: bluestein.h big_pre / big_post); in == out is allowed
 static int pow2_big_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
                          const std::vector<std::pair<int, int>>& rows, int batch, bool inverse)
 {
   const int logn = c->logn;
-  const int S = logn > 17 ? 8 : 4, lsub = logn - (S == 8 ? 3 : 2);
+  const int S = logn > 18 ? 16 : (logn > 17 ? 8 : 4), lsub = logn - (S == 16 ? 4 : (S == 8 ? 3 : 2));
   const uint32_t Q = 1u << lsub;
   const size_t row_words = (size_t)batch << logn;
   // rows per pass: one launch descriptor, and at most 512 MiB of sub-block scratch
@@ -1632,13 +1642,17 @@ static int pow2_big_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
         sub.emplace_back(r * S + g, pl.pd[g]);
     }
     const dim3 grid = grid2(Q, (size_t)R * batch);
-    if (S == 8)
+    if (S == 16)
+      hipLaunchKernelGGL(hx::big_pre_kernel<16>, grid, dim3(256), 0, c->stream, in, qbuf, d, cps, batch, Q, inverse ? 1 : 0);
+    else if (S == 8)
       hipLaunchKernelGGL(hx::big_pre_kernel<8>, grid, dim3(256), 0, c->stream, in, qbuf, d, cps, batch, Q, inverse ? 1 : 0);
     else
       hipLaunchKernelGGL(hx::big_pre_kernel<4>, grid, dim3(256), 0, c->stream, in, qbuf, d, cps, batch, Q, inverse ? 1 : 0);
     HIPCHK(hipGetLastError());
     CHK(ntt_launch(c, lsub, c->d_cprimes, qbuf, qbuf, sub, batch, inverse));
-    if (S == 8)
+    if (S == 16)
+      hipLaunchKernelGGL(hx::big_post_kernel<16>, grid, dim3(256), 0, c->stream, qbuf, out, d, cps, batch, Q, inverse ? 1 : 0);
+    else if (S == 8)
       hipLaunchKernelGGL(hx::big_post_kernel<8>, grid, dim3(256), 0, c->stream, qbuf, out, d, cps, batch, Q, inverse ? 1 : 0);
     else
       hipLaunchKernelGGL(hx::big_post_kernel<4>, grid, dim3(256), 0, c->stream, qbuf, out, d, cps, batch, Q, inverse ? 1 : 0);
@@ -1655,10 +1669,10 @@ static int ntt_list(hx_ctx* c, const uint64_t* in, uint64_t* out,
     return HX_OK;
   if (!c->pow2)
     return bluestein_rows(c, in, out, rows, batch, inverse);
-  if (c->logn >= 16 && c->logn <= 18)
+  if (c->logn >= 16 && c->logn <= 19)
     return pow2_big_rows(c, in, out, rows, batch, inverse);
-  if (c->logn < 1 || c->logn > 18)
-    return fail(HX_ERR_UNSUPPORTED, "power-of-two NTT supports 2 <= phi(m) <= 262144");
+  if (c->logn < 1 || c->logn > 19)
+    return fail(HX_ERR_UNSUPPORTED, "power-of-two NTT supports 2 <= phi(m) <= 524288");
   return ntt_launch(c, c->logn, c->d_primes, in, out, rows, batch, inverse);
 }
 

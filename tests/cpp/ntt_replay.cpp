@@ -174,7 +174,7 @@ static int split_conv8(uint64_t q, uint64_t psi /* primitive 2^(LOGQ+4)-th root 
     S.T[idx] = mk(T);
     S.iT[idx] = mk(pw(T, q - 2, q));
   }
-  S.eighth = mk(eighth);
+  S.inv = mk(eighth);
   S.iT1e = mk(mm(S.iT[1].w, eighth, q));
   std::vector<uint64_t> qa(8 * Q), qb(8 * Q), fa(8 * Q), fb(8 * Q);
   for (int p = 0; p < Q; p++) {
@@ -222,7 +222,7 @@ template <int LOGQ, int S>
 static int big_ntt(int inverse, uint64_t q, uint64_t psi, const uint64_t* in, uint64_t* out)
 {
   using G = hx::Geo<LOGQ>;
-  constexpr int LS = S == 8 ? 3 : 2;
+  constexpr int LS = S == 16 ? 4 : (S == 8 ? 3 : 2);
   const int Q = G::N, FULL = LOGQ + LS;
   uint64_t psi_inv = pw(psi, q - 2, q);
   uint64_t qinv = pw((uint64_t)Q % q, q - 2, q);
@@ -232,29 +232,29 @@ static int big_ntt(int inverse, uint64_t q, uint64_t psi, const uint64_t* in, ui
   auto mk = [&](uint64_t w) { hx::TW t; t.w = w; t.wp = (uint64_t)((((u128)w) << 64) / q); return t; };
   auto prev = [&](unsigned idx) { return pw(psi, hx::brev_bits(idx, FULL), q); };
   hx::SplitTW S4;
-  hx::SplitTW8 S8;
+  hx::SplitTWN<(S >= 8 ? LS : 3)> S8;
   if (S == 4) {
     uint64_t T1 = prev(1), T2 = prev(2), T3 = prev(3), quarter = pw(4, q - 2, q);
     S4.T1 = mk(T1); S4.T2 = mk(T2); S4.T3 = mk(T3);
     S4.iT2 = mk(pw(T2, q - 2, q)); S4.iT3 = mk(pw(T3, q - 2, q));
     S4.iT1q = mk(mm(pw(T1, q - 2, q), quarter, q)); S4.quarter = mk(quarter);
   } else {
-    uint64_t eighth = pw(8, q - 2, q);
-    for (unsigned idx = 1; idx < 8; idx++) {
+    uint64_t eighth = pw((uint64_t)S % q, q - 2, q);
+    for (unsigned idx = 1; idx < (unsigned)S; idx++) {
       S8.T[idx] = mk(prev(idx));
       S8.iT[idx] = mk(pw(prev(idx), q - 2, q));
     }
     S8.T[0] = S8.iT[0] = mk(0);
-    S8.eighth = mk(eighth);
+    S8.inv = mk(eighth);
     S8.iT1e = mk(mm(S8.iT[1].w, eighth, q));
   }
   std::vector<uint64_t> qa((size_t)S * Q), fa((size_t)S * Q);
   for (int p = 0; p < Q; p++) {  // big_pre
-    uint64_t e[8];
+    uint64_t e[S >= 8 ? S : 8];
     if (!inverse) {
       for (int g = 0; g < S; g++) e[g] = in[p + (size_t)g * Q];
-      if (S == 8) {
-        hx::split_fwd8(e, S8, q);
+      if constexpr (S >= 8) {
+        hx::split_fwdN<LS>(e, S8, q);
       } else {
         uint64_t o[4];
         hx::split_fwd4(e[0], e[1], e[2], e[3], S4, q, o);
@@ -269,13 +269,13 @@ static int big_ntt(int inverse, uint64_t q, uint64_t psi, const uint64_t* in, ui
     sub_transform<LOGQ>(inverse != 0, inverse ? I[g].data() : F[g].data(), q, qa.data() + (size_t)g * Q,
                         fa.data() + (size_t)g * Q);
   for (int p = 0; p < Q; p++) {  // big_post
-    uint64_t e[8];
+    uint64_t e[S >= 8 ? S : 8];
     for (int g = 0; g < S; g++) e[g] = fa[(size_t)g * Q + p];
     if (!inverse) {
       for (int g = 0; g < S; g++) out[(size_t)p * S + hx::brev_bits((unsigned)g, LS)] = e[g];
     } else {
-      if (S == 8) {
-        hx::split_inv8(e, S8, q);
+      if constexpr (S >= 8) {
+        hx::split_invN<LS>(e, S8, q);
       } else {
         const uint64_t c4[4] = {e[0], e[1], e[2], e[3]};
         uint64_t a[4];
@@ -296,5 +296,7 @@ extern "C" int big_ntt_replay(int logq, int radix, int inverse, uint64_t q, uint
   if (radix == 4 && logq == 15) return big_ntt<15, 4>(inverse, q, psi, in, out);
   if (radix == 8 && logq == 13) return big_ntt<13, 8>(inverse, q, psi, in, out);
   if (radix == 8 && logq == 15) return big_ntt<15, 8>(inverse, q, psi, in, out);
+  if (radix == 16 && logq == 13) return big_ntt<13, 16>(inverse, q, psi, in, out);
+  if (radix == 16 && logq == 15) return big_ntt<15, 16>(inverse, q, psi, in, out);
   return -1;
 }

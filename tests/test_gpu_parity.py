@@ -71,8 +71,8 @@ def test_ntt_single_prime_like_fft_bench(hx, m):
 
 
 @pytest.mark.parametrize("m,L,batch", [(32768, 16, 3), (16384, 5, 2), (65536, 4, 2),
-                                       # N = 2^16 .. 2^18: radix-4 / radix-8 split into row-kernel sub-transforms
-                                       (131072, 3, 2), (262144, 2, 2), (524288, 2, 1)])
+                                       # N = 2^16 .. 2^19: radix-4 / -8 / -16 split into row-kernel sub-transforms
+                                       (131072, 3, 2), (262144, 2, 2), (524288, 2, 1), (1048576, 2, 1)])
 def test_ntt_doublecrt_batched(hx, m, L, batch):
     P = Pair(hx, m, primes_for(m, L))
     idx = list(range(L))
@@ -1569,11 +1569,13 @@ def test_bluestein_auxiliary_prime_path_matches_oracle(hx, m):
     assert np.array_equal(d.iFFT().download(), x)
 
 
-@pytest.mark.parametrize("m", [65539, 131071])
+@pytest.mark.parametrize("m", [65539, 131071, 262139])
 def test_bluestein_conv_2_18_radix8_split(hx, m):
     """General m with 2m-1 > 2^17: the chirp convolution has 2^18 points = eight 2^15-point
-    sub-transforms behind a radix-8 split (conv_core.h split_fwd8/inv8); m = 131071 is the largest
-    prime m with 2m-1 <= 2^18.  Forward and inverse vs the oracle, batch 2."""
+    sub-transforms behind a radix-8 split (conv_core.h split_fwdN<3>); m = 131071 is the largest
+    prime m with 2m-1 <= 2^18.  Beyond it (m = 262139, prime) the convolution
+    has 2^19 points = sixteen sub-transforms behind the radix-16 split (split_fwdN<4>).  Forward and
+    inverse vs the oracle, batch 2."""
     g = O.PrimeGen(56, m)
     P = Pair(hx, m, [g.next(), g.next()])
     idx = [0, 1]
@@ -1583,8 +1585,9 @@ def test_bluestein_conv_2_18_radix8_split(hx, m):
     for b in range(2):
         assert np.array_equal(y[:, b], P.o.fft(idx, x[:, b]))
     assert np.array_equal(d.iFFT().download(), x)
-    with pytest.raises(hx.HxError):                      # one step further: conv size 2^19
-        hx.Context(131073).add_prime(O.PrimeGen(56, 131073).next())
+    if m == 131071:
+        with pytest.raises(hx.HxError):                  # beyond the radix-16 split: conv size 2^20
+            hx.Context(262145).add_prime(O.PrimeGen(56, 262145).next())
 
 
 def test_wrapped_poly_multi_prime_scale_down_stays_in_caller_memory(hx):

@@ -192,9 +192,9 @@ def test_split_convolution_replayed_on_cpu(replay, radix, logq):
     assert [int(v) for v in c] == want
 
 
-@pytest.mark.parametrize("radix,logq", [(4, 14), (4, 13), (8, 13)])
+@pytest.mark.parametrize("radix,logq", [(4, 14), (4, 13), (8, 13), (16, 13)])
 def test_big_power_of_two_transform_replayed_on_cpu(replay, radix, logq):
-    """Power-of-two rings beyond one row kernel (engine.hip pow2_big_rows: N = 2^16 .. 2^18 as 4 / 8
+    """Power-of-two rings beyond one row kernel (engine.hip pow2_big_rows: N = 2^16 .. 2^19 as 4 / 8 / 16
     sub-transforms, natural order in and out): the kernel phase functions, the sub-transform twiddle
     tables and the interleave replayed on the CPU against the oracle's Cmodulus::FFT / iFFT
     (src/CModulus.cpp:389-426, 493-553).  (4, 14) is m = 131072 as the engine runs it."""
