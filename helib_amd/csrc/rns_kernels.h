@@ -224,13 +224,19 @@ tensor_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
 // rows that the accumulation reads anyway -- so those 16 rows are neither written, transformed
 // nor re-read.
 constexpr int KS_MAXD = 8;
+// (occupancy A/B, round 2: capped at 64 VGPRs / 8 waves per SIMD the kernel spills 60 bytes per lane
+// inside its loop and the fixed-level multiply drops from 66 k to 52 k mult/s; at 72 VGPRs / 7 waves
+// it is the same as uncapped -- 78 VGPRs, 6 waves: gpurun_out/variants.log, profiles/r02_variants_keyswitch_waves.txt)
+#ifndef HX_KS_WAVES
+#define HX_KS_WAVES
+#endif
 struct KsFix {
   int64_t owner;        // digit owning this row, -1 for special primes
   TW pinv[KS_MAXD];     // P_e^-1 mod q_row for e < owner
   TW pscale;            // product of the special primes mod q_row (addPrimesAndScale factor)
 };
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) HX_KS_WAVES
 keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ kb,
                  const uint64_t* __restrict__ ka, uint64_t* __restrict__ out0,
                  uint64_t* __restrict__ out1, RowMap2 map, int ndig, int nall, int wrows, int batch,
