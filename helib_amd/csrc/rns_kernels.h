@@ -223,6 +223,13 @@ tensor_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
 // in the evaluation domain, c = the s^2 part (own_src), d_e = the earlier digits' extension
 // rows that the accumulation reads anyway -- so those 16 rows are neither written, transformed
 // nor re-read.
+// waves per SIMD the fast RNS kernels are compiled for (A/B knobs)
+#ifndef HX_EXT_WAVES
+#define HX_EXT_WAVES 7
+#endif
+#ifndef HX_BRK_WAVES
+#define HX_BRK_WAVES 7
+#endif
 constexpr int KS_MAXD = 8;
 // (occupancy A/B, round 2: capped at 64 VGPRs / 8 waves per SIMD the kernel spills 60 bytes per lane
 // inside its loop and the fixed-level multiply drops from 66 k to 52 k mult/s; at 72 VGPRs / 7 waves
@@ -845,7 +852,7 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
 // generic kernel's, so every output word and every fraction is the same.
 // =====================================================================
 template <int N>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 11 ? 8 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 11 ? HX_EXT_WAVES : 4)))
 rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -978,7 +985,7 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
   }
 }
 
-__global__ void __launch_bounds__(BRK_THREADS) __attribute__((amdgpu_waves_per_eu(8)))
+__global__ void __launch_bounds__(BRK_THREADS) __attribute__((amdgpu_waves_per_eu(HX_BRK_WAVES)))
 break_digits_fast_kernel(BreakArgs A, size_t row_words)
 {
   extern __shared__ __attribute__((aligned(16))) uint64_t xs[];  // [L - n0][BRK_THREADS]
