@@ -296,7 +296,7 @@ static inline uint64_t mulmod_precon(uint64_t x, uint64_t w, uint64_t wp, uint64
 {
   uint64_t h = (uint64_t)(((u128)x * wp) >> 64);
   uint64_t r = x * w - h * q;
-  return r >= q ? r - q : r;
+  return r - (q & (0 - (uint64_t)(r >= q)));   /* (branch-free: the outcome is a coin flip on random data) */
 }
 
 /* The stage tables (w^j and their Shoup companions for every stage, n - 1 entries each) are built
@@ -350,9 +350,8 @@ static void cyclic_ntt(uint64_t* a, long n, uint64_t omega, uint64_t q)
         uint64_t u = a[i + j];
         uint64_t v = mulmod_precon(a[i + j + half], w[j], wp[j], q);
         uint64_t s = u + v;
-        if (s >= q)
-          s -= q;
-        uint64_t d = u >= v ? u - v : u + q - v;
+        s -= q & (0 - (uint64_t)(s >= q));
+        uint64_t d = u - v + (q & (0 - (uint64_t)(u < v)));
         a[i + j] = s;
         a[i + j + half] = d;
       }
