@@ -19,6 +19,7 @@ struct PrimeDev {
   uint64_t mu64;   // floor(2^64 / q)                     (Barrett, 64-bit values)
   uint32_t k;      // bitlen(q)
   uint32_t pad;
+  uint64_t mu63;   // floor(2^(63+k) / q)                 (red128_q8: 128-bit sums below 8 q^2)
   // power-of-two NTT tables (ntt_core.h layout) as offsets, in TW units, into the
   // context's single twiddle arena: the arena base is a kernel ARGUMENT so the
   // compiler addresses it as global memory (scalar loads for uniform entries)

@@ -752,6 +752,7 @@ static int cprime_add(hx_ctx* c, uint64_t q, uint64_t fwd_off, uint64_t inv_off,
   pd.k = (uint32_t)hxh::bitlen(q);
   pd.mu = (uint64_t)((((hxh::u128)1) << (2 * pd.k)) / q);
   pd.mu64 = (uint64_t)((((hxh::u128)1) << 64) / q);
+  pd.mu63 = (uint64_t)((((hxh::u128)1) << (63 + pd.k)) / q);
   pd.tw_fwd_off = fwd_off;
   pd.tw_inv_off = inv_off;
   HIPCHK(hipMemcpy(c->d_cprimes + c->ncprimes, &pd, sizeof pd, hipMemcpyHostToDevice));
@@ -1286,6 +1287,7 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
   pd.k = (uint32_t)hxh::bitlen(q);
   pd.mu = (uint64_t)((((hxh::u128)1) << (2 * pd.k)) / q);
   pd.mu64 = (uint64_t)((((hxh::u128)1) << 64) / q);
+  pd.mu63 = (uint64_t)((((hxh::u128)1) << (63 + pd.k)) / q);
   pd.tw_fwd_off = ph.tw_fwd_off;
   pd.tw_inv_off = ph.tw_inv_off;
   int idx = (int)c->primes.size();

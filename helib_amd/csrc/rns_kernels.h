@@ -223,6 +223,7 @@ tensor_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
 // in the evaluation domain, c = the s^2 part (own_src), d_e = the earlier digits' extension
 // rows that the accumulation reads anyway -- so those 16 rows are neither written, transformed
 // nor re-read.
+__device__ __forceinline__ uint64_t red128_q8(u128 S, uint64_t q, uint64_t mu63, uint32_t k);  // (below)
 // waves per SIMD the fast RNS kernels are compiled for (A/B knobs)
 #ifndef HX_EXT_WAVES
 #define HX_EXT_WAVES 7
@@ -320,10 +321,13 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
       }
     }
     if (lazy) {
-      acc0.x = add_mod(acc0.x, red128_wide(s0x, q, mu, k), q);
-      acc0.y = add_mod(acc0.y, red128_wide(s0y, q, mu, k), q);
-      acc1.x = add_mod(acc1.x, red128_wide(s1x, q, mu, k), q);
-      acc1.y = add_mod(acc1.y, red128_wide(s1y, q, mu, k), q);
+      // (red128_q8: approximate-quotient Barrett with 7 word multiplications -- the classical form
+      // with its runtime 128-bit shifts and four compare-subtract steps was a quarter of this kernel's
+      // instructions)
+      acc0.x = add_mod(acc0.x, red128_q8(s0x, q, pd.mu63, k), q);
+      acc0.y = add_mod(acc0.y, red128_q8(s0y, q, pd.mu63, k), q);
+      acc1.x = add_mod(acc1.x, red128_q8(s1x, q, pd.mu63, k), q);
+      acc1.y = add_mod(acc1.y, red128_q8(s1y, q, pd.mu63, k), q);
     }
     *reinterpret_cast<ulonglong2*>(out0 + (size_t)row * row_words + e) = acc0;
     *reinterpret_cast<ulonglong2*>(out1 + (size_t)row * row_words + e) = acc1;
