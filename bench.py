@@ -822,7 +822,11 @@ def main():
         cfg = {"workload": workload, "batch_per_gpu": B, "pairs_all_ranks": pairs_all,
                "parallelism": f"replica x{world}, batch-sharded, no data-path collective",
                "algorithmic_MB_per_mult": round(per_mult / 1e6, 2),
-               "hbm_roofline_mult_per_s_per_gpu": round(HBM_PEAK_GBS * 1e9 / per_mult, 0)}
+               "hbm_roofline_mult_per_s_per_gpu": round(HBM_PEAK_GBS * 1e9 / per_mult, 0),
+               "roofline_note": ("algorithmic_MB_per_mult counts the reference-equivalent unfused sequence with "
+                                 "per-multiply key rows (SURVEY 8d); value / hbm_roofline_mult_per_s_per_gpu is "
+                                 "therefore not an efficiency -- the per-kernel fractions under `roofline` and "
+                                 "hbm_traffic_GB_per_step (bytes actually moved, PMC) are")}
         cfg.update(extra)
         line = {"metric": "ctxt_x_ctxt_mults_per_sec_incl_relinearize",
                 "value": round(pairs_all * R * args.steps / dt, 1), "unit": "mult/s", "n_gpus": world,
