@@ -1788,6 +1788,21 @@ struct hx_graph {
   hipGraph_t graph;
   hipGraphExec_t exec;
 };
+// no recording open and no graph alive: nothing points at the kept buffers any more -- slabs go back
+// to the pool, replaced buffers are freed (the stream is drained first)
+static void graph_release_if_idle(hx_ctx* c)
+{
+  if (c->capturing || c->graphs_alive > 0 || (c->graph_deferred.empty() && c->graph_retired.empty()))
+    return;
+  hipStreamSynchronize(c->stream);
+  std::vector<std::pair<void*, size_t>> d;
+  d.swap(c->graph_deferred);
+  for (auto& kv : d)
+    pool_free(c, kv.first, kv.second);
+  for (void* q : c->graph_retired)
+    hipFree(q);
+  c->graph_retired.clear();
+}
 extern "C" int hx_ctx_graph_begin(hx_ctx* c)
 {
   if (!c)
@@ -1819,13 +1834,18 @@ extern "C" int hx_ctx_graph_end(hx_ctx* c, hx_graph** out)
   c->capturing = false;
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(c->stream, &g);
-  if (e != hipSuccess || !g)
+  if (e != hipSuccess || !g) {
+    (void)hipGetLastError();
+    graph_release_if_idle(c);
     return fail(HX_ERR_DEVICE, "graph capture failed (a captured call needed the device to finish?): %s",
                 hipGetErrorString(e));
+  }
   hipGraphExec_t x = nullptr;
   e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
   if (e != hipSuccess) {
+    (void)hipGetLastError();
     hipGraphDestroy(g);
+    graph_release_if_idle(c);
     return fail(HX_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
   }
   hx_graph* h = new hx_graph();
@@ -1859,16 +1879,8 @@ extern "C" int hx_graph_destroy(hx_graph* g)
     hipStreamSynchronize(c->stream);
     hipGraphExecDestroy(g->exec);
     hipGraphDestroy(g->graph);
-    if (--c->graphs_alive == 0 && !c->capturing) {
-      // nothing points at them any more: slabs go back to the pool, replaced buffers are freed
-      std::vector<std::pair<void*, size_t>> d;
-      d.swap(c->graph_deferred);
-      for (auto& kv : d)
-        pool_free(c, kv.first, kv.second);
-      for (void* q : c->graph_retired)
-        hipFree(q);
-      c->graph_retired.clear();
-    }
+    --c->graphs_alive;
+    graph_release_if_idle(c);
   }
   ctx_release(c);
   delete g;
