@@ -2471,12 +2471,16 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_kernel,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                16 << hx::NORM_MAX_LOGH));
-    HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_kernel<hx::NormSrcF64>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               16 << hx::NORM_MAX_LOGH));
-    HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_kernel<hx::NormSrcXS>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               16 << hx::NORM_MAX_LOGH));
+#define HX_NORM_ATTR(...)                                                                               \
+  HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_kernel<__VA_ARGS__>,                   \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 16 << hx::NORM_MAX_LOGH))
+    HX_NORM_ATTR(hx::NormSrcF64, 0);
+    HX_NORM_ATTR(hx::NormSrcF64, 13);
+    HX_NORM_ATTR(hx::NormSrcF64, 14);
+    HX_NORM_ATTR(hx::NormSrcXS, 0);
+    HX_NORM_ATTR(hx::NormSrcXS, 13);
+    HX_NORM_ATTR(hx::NormSrcXS, 14);
+#undef HX_NORM_ATTR
     HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_split_kernel,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                16 << hx::NORM_MAX_LOGH));
@@ -2489,16 +2493,29 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     const unsigned M = N >> 1;
     const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, M / 4));
     const size_t lds = std::max<size_t>(16 * (size_t)M, 256);
+    // (N = 2^13 / 2^14 with the full thread count: the instantiations with constant loop bounds)
+    const bool full = threads == (unsigned)hx::NORM_THREADS;
+#define HX_NORM_LAUNCH(SRCT, srcv)                                                                              \
+  do {                                                                                                          \
+    if (full && logn == 14)                                                                                     \
+      hipLaunchKernelGGL((hx::embed_norm_quarter_kernel<SRCT, 14>), dim3((unsigned)rows), dim3(threads), lds,   \
+                         c->stream, srcv, c->d_wtab, logn, c->d_norm2);                                         \
+    else if (full && logn == 13)                                                                                \
+      hipLaunchKernelGGL((hx::embed_norm_quarter_kernel<SRCT, 13>), dim3((unsigned)rows), dim3(threads), lds,   \
+                         c->stream, srcv, c->d_wtab, logn, c->d_norm2);                                         \
+    else                                                                                                        \
+      hipLaunchKernelGGL((hx::embed_norm_quarter_kernel<SRCT, 0>), dim3((unsigned)rows), dim3(threads), lds,    \
+                         c->stream, srcv, c->d_wtab, logn, c->d_norm2);                                         \
+  } while (0)
     if (c->xs_rows == rows && d_f == c->d_frac) {
       hx::NormSrcXS src{c->scratch[0], reinterpret_cast<const int64_t*>(c->scratch[1]), c->xs_inv_qd};
-      hipLaunchKernelGGL(hx::embed_norm_quarter_kernel<hx::NormSrcXS>, dim3((unsigned)rows), dim3(threads),
-                         lds, c->stream, src, c->d_wtab, logn, c->d_norm2);
+      HX_NORM_LAUNCH(hx::NormSrcXS, src);
     } else {
       CHK(flush_xs(c));
       hx::NormSrcF64 src{d_f};
-      hipLaunchKernelGGL(hx::embed_norm_quarter_kernel<hx::NormSrcF64>, dim3((unsigned)rows), dim3(threads),
-                         lds, c->stream, src, c->d_wtab, logn, c->d_norm2);
+      HX_NORM_LAUNCH(hx::NormSrcF64, src);
     }
+#undef HX_NORM_LAUNCH
     c->xs_rows = 0;
   } else if (logn - 1 > hx::NORM_MAX_LOGH && !getenv("HX_NORM_PLAIN")) {
     // real-input form beyond one workgroup's LDS: S = N/2/8192 sub-transforms, one workgroup per pair

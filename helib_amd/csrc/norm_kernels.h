@@ -39,17 +39,27 @@ __device__ __forceinline__ cplx cmul_i(cplx a) { return {-a.y, a.x}; }
 //   stage len  : x0=a0+a2, x2=(a0-a2)T, x1=a1+a3, x3=(a1-a3)T*i      (T = T_len(j), T_len(j+len/2) = i T)
 //   stage len/2: y0=x0+x1, y1=(x0-x1)T2, y2=x2+x3, y3=(x2-x3)T2     (T2 = T_(len/2)(j))
 // Output order is bit-reversed; callers only take maxima (or pair positions p and H-1-p).
-__device__ __forceinline__ void dif_fft_lds(double* re, double* im, int logh, unsigned tw_half,
-                                            const double2* __restrict__ wtab, unsigned tid, unsigned nth)
+// CLOGH / CNTH: compile-time transform size and thread count (0 = take the runtime arguments).  With
+// both known the loops over a thread's butterflies have constant trip counts and are unrolled, so that
+// the twiddle and LDS loads of all of a thread's butterflies in a pass are in flight together -- with
+// runtime bounds every iteration exposed its own global-memory round trip (the norm kernels were
+// latency-bound: 40 us per 8192-point transform, one workgroup per CU).
+template <int CLOGH = 0, int CNTH = 0>
+__device__ __forceinline__ void dif_fft_lds(double* re, double* im, int logh_rt, unsigned tw_half,
+                                            const double2* __restrict__ wtab, unsigned tid, unsigned nth_rt)
 {
   // tw_half: the table size N
+  const int logh = CLOGH ? CLOGH : logh_rt;
+  const unsigned nth = CNTH ? (unsigned)CNTH : nth_rt;
   const unsigned H = 1u << logh;
   int stages = logh;
   unsigned len = H >> 1;
+#pragma unroll
   while (stages >= 2) {
     const unsigned hl = len >> 1;        // j < len/2
     const unsigned s1 = tw_half / len;   // T_len(j)      = wtab[j * s1]
     const unsigned s2 = s1 * 2;          // T_(len/2)(j)  = wtab[j * s2]
+#pragma unroll
     for (unsigned q = tid; q < (H >> 2); q += nth) {
       const unsigned j = q & (hl - 1), blk = q / hl, k = blk * 2 * len + j;
       const cplx a0{re[k], im[k]}, a1{re[k + hl], im[k + hl]}, a2{re[k + len], im[k + len]},
@@ -69,6 +79,7 @@ __device__ __forceinline__ void dif_fft_lds(double* re, double* im, int logh, un
     stages -= 2;
   }
   if (stages == 1) {  // len == 1: twiddle 1
+#pragma unroll
     for (unsigned k2 = tid; k2 < (H >> 1); k2 += nth) {
       const unsigned k = 2 * k2;
       const double ar = re[k], ai = im[k], br = re[k + 1], bi = im[k + 1];
@@ -165,17 +176,21 @@ struct NormSrcXS {
   }
 };
 
-template <class SRC>
+// CLOGN: compile-time log2 N for the sizes that matter (13, 14; launched with NORM_THREADS threads),
+// 0 = any size from the runtime argument
+template <class SRC, int CLOGN = 0>
 __global__ void __launch_bounds__(NORM_THREADS)
-embed_norm_quarter_kernel(SRC src, const double2* __restrict__ wtab, int logn,
+embed_norm_quarter_kernel(SRC src, const double2* __restrict__ wtab, int logn_rt,
                           unsigned long long* __restrict__ out2)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int logn = CLOGN ? CLOGN : logn_rt;
   const unsigned N = 1u << logn, M = N >> 1;
   const int logm = logn - 1;
   double* re = sm;
   double* im = sm + M;
-  const unsigned row = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+  const unsigned row = blockIdx.x, tid = threadIdx.x, nth = CLOGN ? (unsigned)NORM_THREADS : blockDim.x;
+#pragma unroll
   for (unsigned i = tid; i < M; i += nth) {
     const double2 v = src.pair(row, N, i);   // (f_2i, f_(2i+1))
     const double2 w = wtab[2 * i];    // V^i = W^(2i)
@@ -184,8 +199,9 @@ embed_norm_quarter_kernel(SRC src, const double2* __restrict__ wtab, int logn,
   }
   __syncthreads();
   // root V^2 = W^4 (primitive M-th root): T_len(j) = W^(4 j M/(2 len)) = W^(j N/len)
-  dif_fft_lds(re, im, logm, N, wtab, tid, nth);
+  dif_fft_lds<(CLOGN ? CLOGN - 1 : 0), (CLOGN ? NORM_THREADS : 0)>(re, im, logm, N, wtab, tid, nth);
   double mx = 0;
+#pragma unroll
   for (unsigned p = tid; p < M; p += nth) {
     const unsigned j = __brev(p) >> (32 - logm);
     const double zr = re[p], zi = im[p], cr = re[M - 1 - p], ci = -im[M - 1 - p];
@@ -242,8 +258,8 @@ embed_norm_quarter_split_kernel(const double* __restrict__ f, const double2* __r
       im[i] = ai;
     }
     __syncthreads();
-    // root U^S = W^(4S) = W^(2N/H): the table stride dif_fft_lds expects
-    dif_fft_lds(re, im, logh, N, wtab, tid, nth);
+    // root U^S = W^(4S) = W^(2N/H): the table stride dif_fft_lds expects (H = 8192, 1024 threads: always)
+    dif_fft_lds<NORM_MAX_LOGH, NORM_THREADS>(re, im, logh, N, wtab, tid, nth);
     if (pass == 0) {
       for (unsigned p = tid; p < H; p += nth)
         pk[p] = make_double2(re[p], im[p]);
