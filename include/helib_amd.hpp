@@ -12,6 +12,7 @@
 // (hx_last_error) and are the reference's own where one exists.
 // Header-only; link with -lhelib_amd.  No NTL: coefficients cross the boundary as uint64 rows.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -126,7 +127,12 @@ public:
   }
   DoubleCRT(const DoubleCRT& other) : context_(other.context_), batch_(other.batch_)
   {
-    IndexSet s = other.getIndexSet();
+    // (a digit block lists its primes once per digit: hx_poly_copy takes over the source's row list,
+    // the destination only has to exist)
+    IndexSet s;
+    for (int i : other.getIndexSet())
+      if (std::find(s.begin(), s.end(), i) == s.end())
+        s.push_back(i);
     hx_poly* p = nullptr;
     check(hx_poly_create_uninit(context_->handle(), batch_, s.data(), (int)s.size(), &p));
     h_.reset(p);
@@ -231,7 +237,10 @@ public:
   }
   // breakIntoDigits: digit d = digits[d] (prime indices), special primes appended to every digit;
   // result: one object with digits.size()*(rows+|special|) rows, block d = digit d
-  DoubleCRT breakIntoDigits(const std::vector<IndexSet>& digits, const IndexSet& special) const
+  // norms (optional): digits.size()*batch values embeddingLargestCoeff(digit d of element b) / P_d, the
+  // pieces of the reference's return value (src/DoubleCRT.cpp:538-545), measured on the device
+  DoubleCRT breakIntoDigits(const std::vector<IndexSet>& digits, const IndexSet& special,
+                            std::vector<double>* norms = nullptr) const
   {
     std::vector<int> idx, off(1, 0);
     for (auto& d : digits) {
@@ -239,8 +248,15 @@ public:
       off.push_back((int)idx.size());
     }
     DoubleCRT out(*context_, getIndexSet(), batch_);
-    check(hx_break_into_digits(h_.get(), idx.data(), off.data(), (int)digits.size(), special.data(),
-                               (int)special.size(), out.h_.get()));
+    if (norms) {
+      norms->assign(digits.size() * (size_t)batch_, 0.0);
+      check(hx_ctx_defer_norms(context_->handle(), 0));
+      check(hx_break_into_digits_norms(h_.get(), idx.data(), off.data(), (int)digits.size(), special.data(),
+                                       (int)special.size(), out.h_.get(), norms->data()));
+    } else {
+      check(hx_break_into_digits(h_.get(), idx.data(), off.data(), (int)digits.size(), special.data(),
+                                 (int)special.size(), out.h_.get()));
+    }
     return out;
   }
 

@@ -483,12 +483,27 @@ struct SKHandle {
   {
     return (powerOfS == 0 && o.powerOfS == 0) || (powerOfS == o.powerOfS && powerOfX == o.powerOfX);
   }
+  // SKHandle::mul (include/helib/Ctxt.h:140-165): powers of s add; the automorphism amounts must agree
+  // unless one side is the constant handle
+  bool mul(const SKHandle& a, const SKHandle& b)
+  {
+    if (a.isOne())
+      *this = b;
+    else if (b.isOne())
+      *this = a;
+    else if (a.powerOfX != b.powerOfX)
+      return false;
+    else
+      *this = SKHandle{a.powerOfS + b.powerOfS, a.powerOfX};
+    return true;
+  }
 };
 
 // the key-switching matrices a ciphertext can reach (PubKey::getKeySWmatrix for this path)
 struct KeySet {
   const KeySwitch* relin = nullptr;             // s^2 -> s
   std::map<long, const KeySwitch*> automorph;   // k -> s(X^k) -> s
+  std::map<long, const KeySwitch*> pow;         // e >= 3 -> s^e -> s (GenSecKey(maxDegKswitch >= 3))
   long ptxtSpace = 0;                           // KeySwitch::ptxtSpace
   double lnNoise = 0;                           // ln KeySwitch::noiseBound
   std::vector<long> keySwitchMap;               // k -> first step on the way to X -> X^k (0: none)
@@ -508,6 +523,21 @@ struct KeySet {
         }
       }
     }
+  }
+  // PubKey::getKeySWmatrix(handle) (src/keys.cpp:218-239); nullptr when there is none
+  const KeySwitch* matrixFor(const SKHandle& h) const
+  {
+    if (h.powerOfS == 2 && h.powerOfX == 1)
+      return relin;
+    if (h.powerOfS == 1) {
+      auto it = automorph.find(h.powerOfX);
+      return it == automorph.end() ? nullptr : it->second;
+    }
+    if (h.powerOfX == 1) {
+      auto it = pow.find(h.powerOfS);
+      return it == pow.end() ? nullptr : it->second;
+    }
+    return nullptr;
   }
   bool isReachable(long k) const { return k == 1 || firstStep(k) != 0; }
   // PubKey::getNextKSWmatrix(k).fromKey.getPowerOfX()
@@ -847,15 +877,11 @@ public:
       }
     if (n_other == 0)
       return;
-    if (n_other > 1)
-      throw LogicError("one non-canonical part at a time");
-    const KeySwitch* W = nullptr;
-    if (hnd.powerOfS == 2 && hnd.powerOfX == 1)
-      W = keys->relin;
-    else if (hnd.powerOfS == 1) {
-      auto it = keys->automorph.find(hnd.powerOfX);
-      W = it == keys->automorph.end() ? nullptr : it->second;
+    if (n_other > 1) {
+      reLinearizeMany();
+      return;
     }
+    const KeySwitch* W = keys->matrixFor(hnd);
     if (!W)
       throw LogicError("no key-switching matrices for this part");
     dropSmallAndSpecialPrimes();
@@ -970,26 +996,355 @@ public:
       dropSmallAndSpecialPrimes();
   }
 
+  // ---- size / correctness accessors (include/helib/Ctxt.h:1291-1325, src/Ctxt.cpp:116-127) ----
+  // ln of totalNoiseBound(): for CKKS ptxtMag*ratFactor + noiseBound, else noiseBound
+  double lnTotalNoiseBound() const
+  {
+    return context->ckks ? detail::logaddexp(detail::ln(ptxtMag) + lnRatFactor, lnNoise) : lnNoise;
+  }
+  // log2 of the modulus over the total noise bound
+  double capacity() const { return (logOfPrimeSet() - std::max(lnTotalNoiseBound(), 0.0)) / std::log(2.0); }
+  long bitCapacity() const { return (long)capacity(); }
+  // totalNoiseBound * polyNormBnd <= 0.48 Q: would this ciphertext decrypt without errors?
+  bool isCorrect() const;
+
+  // ---- products of more than two ciphertexts ----
+  // Ctxt::multiplyBy2 (src/Ctxt.cpp:1776-1828): the product of three ciphertexts with ONE
+  // relinearisation at the end (parts up to s^3), multiplying in the order of their capacities
+  void multiplyBy2(const Ctxt& other1, const Ctxt& other2)
+  {
+    HELIB_AMD_TIMER_START;
+    if (parts.empty())
+      return;
+    if (other1.parts.empty()) {
+      *this = other1;
+      return;
+    }
+    if (other2.parts.empty()) {
+      *this = other2;
+      return;
+    }
+    const double cap = capacity(), cap1 = other1.capacity(), cap2 = other2.capacity();
+    if (cap < cap1 && cap < cap2) {
+      Ctxt tmp = other1;
+      tmp.multLowLvl(other2);
+      multLowLvl(std::move(tmp));
+      reLinearize();
+      return;
+    }
+    const bool swap = cap < cap2 || cap1 < cap2;
+    Ctxt first = swap ? other2 : other1, second = swap ? other1 : other2;   // (copies: either may be *this)
+    multLowLvl(std::move(first));
+    multLowLvl(std::move(second));
+    reLinearize();
+  }
+  void square() { multiplyBy(Ctxt(*this)); }                 // Ctxt::square
+  void cube() { multiplyBy2(Ctxt(*this), Ctxt(*this)); }     // Ctxt::cube
+  // Ctxt::power (src/polyEval.cpp:392-414): repeated squaring for a power of two, otherwise
+  // DynamicCtxtPowers (:18-29): X^e = X^(e-k) * X^k, k the largest power of two below e
+  void power(long e)
+  {
+    if (e < 1)
+      throw InvalidArgument("Cannot raise a ctxt to a non positive exponent");
+    if (e == 1)
+      return;
+    if ((e & (e - 1)) == 0) {
+      for (; e > 1; e >>= 1)
+        square();
+      return;
+    }
+    std::map<long, Ctxt> powers;
+    powers.emplace(1, *this);
+    *this = powerRec(powers, e);
+  }
+  // Ctxt::frobeniusAutomorph (src/Ctxt.cpp:2526-2545): X -> X^(p^j) for BGV (j mod ord(p)); for CKKS
+  // complex conjugation when j is odd
+  void frobeniusAutomorph(long j)
+  {
+    if (parts.empty() || j == 0)
+      return;
+    if (context->ckks) {
+      if (j & 1)
+        smartAutomorph(context->m - 1);
+      return;
+    }
+    const long m = context->m, p0 = ((context->p % m) + m) % m;
+    long d = 1, x = p0;
+    while (x != 1) {
+      x = (long)((unsigned __int128)x * (unsigned long)p0 % (unsigned long)m);
+      d++;
+    }
+    j = ((j % d) + d) % d;
+    if (j)
+      smartAutomorph((long)detail::powmod((uint64_t)p0, (uint64_t)j, (uint64_t)m));
+  }
+
+  // ---- plaintext constants ----
+  // Ctxt::multByConstant(const DoubleCRT&, double size) (src/Ctxt.cpp:1832-1856), BGV: every part
+  // times the constant (dcrt may live on more primes); size < 0: the bound for coefficients uniform
+  // in [-ptxtSpace/2, ptxtSpace/2]
+  void multByConstant(const DoubleCRT& dcrt, double size = -1.0)
+  {
+    if (parts.empty())
+      return;
+    if (size < 0.0)
+      size = context->noiseBoundForMod(ptxtSpace, context->phim);
+    for (auto& kv : parts)
+      kv.second *= dcrt;
+    lnNoise += detail::ln(size);
+  }
+  // Ctxt::multByConstant(const ZZ& / long) for BGV (src/Ctxt.cpp:2033-2110): c mod ptxtSpace = c1*d,
+  // d = gcd(c, ptxtSpace); the ciphertext is multiplied by the balanced d only, the unit c1 goes
+  // into intFactor (its inverse)
+  void multByConstant(long c)
+  {
+    if (parts.empty())
+      return;
+    if (context->ckks) {
+      multByConstantCKKS((double)c);
+      return;
+    }
+    const long P = ptxtSpace;
+    long c0 = ((c % P) + P) % P;
+    if (c0 == 1)
+      return;
+    if (c0 == 0) {
+      parts.clear();
+      return;
+    }
+    const long d = std::gcd(c0, P);
+    intFactor = (long)detail::mulmod((uint64_t)intFactor, (uint64_t)invMod(c0 / d, P), (uint64_t)P);
+    if (d == 1)
+      return;
+    const long cc = d > P / 2 ? d - P : d;
+    lnNoise += std::log((double)std::labs(cc));
+    for (auto& kv : parts)
+      kv.second *= cc;
+  }
+  // CKKS, scalar: no polynomial work at all -- ptxtMag *= |c|, ratFactor /= |c|, a sign flips the parts
+  void multByConstantCKKS(double c)
+  {
+    if (parts.empty() || c == 1.0)
+      return;
+    if (c == 0.0) {
+      parts.clear();
+      return;
+    }
+    ptxtMag *= std::fabs(c);
+    lnRatFactor -= std::log(std::fabs(c));
+    if (c < 0)
+      negate();
+  }
+  // Ctxt::multByConstantCKKS(const DoubleCRT&, size, factor, roundingErr) (src/Ctxt.cpp:1905-1938):
+  // dcrt encodes a constant of magnitude <= size scaled by `factor` with encoding error <= roundingErr
+  void multByConstantCKKS(const DoubleCRT& dcrt, double size, double factor, double roundingErr)
+  {
+    if (parts.empty())
+      return;
+    if (size <= 0)
+      size = 1.0;
+    if (factor <= 0 || roundingErr < 0)
+      throw InvalidArgument("factor and roundingErr are the encoder's: pass them");
+    const double n = lnNoise;
+    lnNoise = detail::logaddexp(detail::logaddexp(n + std::log(factor) + std::log(size),
+                                                  detail::ln(roundingErr) + lnRatFactor + detail::ln(ptxtMag)),
+                                n + detail::ln(roundingErr));
+    ptxtMag *= size;
+    lnRatFactor += std::log(factor);
+    for (auto& kv : parts)
+      kv.second *= dcrt;
+  }
+  // Ctxt::addConstant(const DoubleCRT&, double size) (src/Ctxt.cpp:896-935), BGV: the constant is
+  // scaled by f = balRem(intFactor * Q mod ptxtSpace) and added to the part of 1
+  void addConstant(const DoubleCRT& dcrt, double size = -1.0)
+  {
+    if (size < 0.0)
+      size = context->noiseBoundForMod(ptxtSpace, context->phim);
+    long f = 1;
+    if (ptxtSpace > 2) {
+      const long p = ptxtSpace;
+      f = (long)detail::mulmod(context->productOfPrimesMod(primeSet, (uint64_t)p), (uint64_t)(intFactor % p), (uint64_t)p);
+      if (f > p / 2)
+        f -= p;
+    }
+    lnNoise = detail::logaddexp(lnNoise, detail::ln(size * (double)std::labs(f)));
+    addToPartOne(dcrt, f);
+  }
+  // Ctxt::addConstantCKKS(const DoubleCRT&, size, factor) (src/Ctxt.cpp:951-1045): the constant (scaled
+  // by `factor`) is multiplied by round(ratFactor / factor) and added to the part of 1.  The reference
+  // mod-switches up (addSomePrimes) when the rounded ratio is off by more than 2^-precision; here that
+  // case is an error.
+  void addConstantCKKS(const DoubleCRT& dcrt, double size, double factor)
+  {
+    if (size <= 0)
+      size = 1.0;
+    if (factor <= 0)
+      throw InvalidArgument("factor is the encoder's: pass it");
+    const double x = std::exp(lnRatFactor - std::log(factor));
+    const double ratio = std::floor(x + 0.5);
+    if (ratio < 1 || std::fabs(ratio / x - 1.0) * std::ldexp(1.0, (int)context->r) > 1.0)
+      throw RuntimeError("addConstantCKKS: ratFactor / factor is too far from an integer "
+                         "(the reference would call addSomePrimes here)");
+    ptxtMag += size;
+    lnNoise = detail::logaddexp(lnNoise, std::log(0.5));
+    addToPartOne(dcrt, (long)ratio);
+  }
+  Ctxt& operator+=(const Ctxt& o)
+  {
+    addCtxt(o);
+    return *this;
+  }
+  Ctxt& operator-=(const Ctxt& o)
+  {
+    addCtxt(o, true);
+    return *this;
+  }
+  Ctxt& operator*=(const Ctxt& o)
+  {
+    multiplyBy(o);
+    return *this;
+  }
+
 private:
+  static long invMod(long v, long P)
+  {
+    long aa = ((v % P) + P) % P, bb = P, x0 = 1, x1 = 0;
+    while (bb) {
+      long q = aa / bb, t = aa % bb;
+      aa = bb, bb = t;
+      t = x0 - q * x1, x0 = x1, x1 = t;
+    }
+    if (aa != 1)
+      throw LogicError("not invertible modulo the plaintext space");
+    return ((x0 % P) + P) % P;
+  }
+  void addToPartOne(const DoubleCRT& dcrt, long f)
+  {
+    auto it = parts.find(SKHandle{0, 1});
+    if (it == parts.end())
+      throw RuntimeError("Ctxt::addPart: no part pointing at 1");
+    if (f == 1) {
+      it->second += dcrt;
+    } else {
+      DoubleCRT tmp = dcrt;
+      tmp *= f;
+      it->second += tmp;
+    }
+  }
+  Ctxt powerRec(std::map<long, Ctxt>& powers, long n)
+  {
+    auto it = powers.find(n);
+    if (it != powers.end())
+      return it->second;
+    long k = 1;
+    while (2 * k < n)
+      k *= 2;                                     // the largest power of two below n
+    Ctxt c = powerRec(powers, n - k);
+    c.multiplyBy(powerRec(powers, k));
+    powers.emplace(n, c);
+    return c;
+  }
+  // Ctxt::reLinearize with several non-canonical parts (after multiplyBy2: s^2 and s^3): parts 1 and s
+  // are scaled by P, every other part goes through keySwitchPart -- break into digits, key-switch with
+  // its own matrix, accumulate (src/Ctxt.cpp:720-842)
+  void reLinearizeMany()
+  {
+    std::vector<std::pair<SKHandle, const KeySwitch*>> mats;
+    for (auto& kv : parts)
+      if (!kv.first.isOne() && !kv.first.isBase()) {
+        const KeySwitch* W = keys->matrixFor(kv.first);
+        if (!W)
+          throw LogicError("no key-switching matrices for s^" + std::to_string(kv.first.powerOfS) + "(X^" +
+                           std::to_string(kv.first.powerOfX) + ")");
+        mats.emplace_back(kv.first, W);
+      }
+    dropSmallAndSpecialPrimes();
+    relin_CKKS_adjust();
+    const IndexSet& sp = context->specialPrimes;
+    const double logProd = context->logOfProduct(sp);
+    lnRatFactor += logProd;
+    std::vector<IndexSet> digits;
+    for (auto& d : context->digits) {
+      IndexSet r;
+      for (int i : d)
+        if (primeSet.count(i))
+          r.push_back(i);
+      if (!r.empty())
+        digits.push_back(r);
+    }
+    if (ptxtSpace > 1) {
+      ptxtSpace = std::gcd(ptxtSpace, keys->ptxtSpace ? keys->ptxtSpace : context->ptxtSpace);
+      intFactor %= ptxtSpace;
+    }
+    DoubleCRT part0 = std::move(parts.at(SKHandle{0, 1}));
+    part0.addPrimesAndScale(sp);
+    auto its = parts.find(SKHandle{1, 1});
+    DoubleCRT part1 = its == parts.end() ? DoubleCRT(*dev, part0.getIndexSet(), part0.batch()) : std::move(its->second);
+    if (its != parts.end())
+      part1.addPrimesAndScale(sp);
+    double added = -INFINITY;
+    for (auto& hw : mats) {
+      std::vector<double> nrm;
+      DoubleCRT dg = parts.at(hw.first).breakIntoDigits(digits, sp, measure ? &nrm : nullptr);
+      keySwitchDigits(*hw.second, dg, part0, part1);
+      for (size_t k = 0; k < digits.size(); k++) {
+        double nb;
+        if (measure) {
+          double mx = 0;
+          for (int b = 0; b < part0.batch(); b++)
+            mx = std::max(mx, nrm[k * (size_t)part0.batch() + (size_t)b]);
+          nb = detail::ln(mx);
+        } else {
+          nb = std::log(context->noiseBoundForUniform(0.5, context->phim));
+        }
+        added = detail::logaddexp(added, nb + context->logOfProduct(digits[k]) + keys->lnNoise);
+      }
+    }
+    lnNoise = detail::logaddexp(lnNoise + logProd, added);
+    parts.clear();
+    parts.emplace(SKHandle{0, 1}, std::move(part0));
+    parts.emplace(SKHandle{1, 1}, std::move(part1));
+    primeSet = primeSet | toSet(sp);
+  }
+  static bool canonicalPair(const std::map<SKHandle, DoubleCRT>& ps)
+  {
+    return ps.size() == 2 && ps.count(SKHandle{0, 1}) && ps.count(SKHandle{1, 1});
+  }
   void tensorProduct(const Ctxt& o)
   {
-    if (parts.size() != 2 || o.parts.size() != 2)
-      throw LogicError("tensorProduct: two-part operands expected");
     if (ptxtSpace > 2) {
       uint64_t q = context->productOfPrimesMod(primeSet, (uint64_t)ptxtSpace);
       intFactor = (long)detail::mulmod(detail::mulmod((uint64_t)intFactor, (uint64_t)o.intFactor, (uint64_t)ptxtSpace), q,
                                        (uint64_t)ptxtSpace);
     }
-    const DoubleCRT &c0 = parts.at(SKHandle{0, 1}), &c1 = parts.at(SKHandle{1, 1});
-    const DoubleCRT &d0 = o.parts.at(SKHandle{0, 1}), &d1 = o.parts.at(SKHandle{1, 1});
-    IndexSet idx = c0.getIndexSet();
-    DoubleCRT::Uninitialized u;
-    DoubleCRT t0(*dev, idx, c0.batch(), u), t1(*dev, idx, c0.batch(), u), t2(*dev, idx, c0.batch(), u);
-    helib_amd::tensorProduct(c0, c1, d0, d1, t0, t1, t2);
-    parts.clear();
-    parts.emplace(SKHandle{0, 1}, std::move(t0));
-    parts.emplace(SKHandle{1, 1}, std::move(t1));
-    parts.emplace(SKHandle{2, 1}, std::move(t2));
+    if (canonicalPair(parts) && canonicalPair(o.parts)) {
+      const DoubleCRT &c0 = parts.at(SKHandle{0, 1}), &c1 = parts.at(SKHandle{1, 1});
+      const DoubleCRT &d0 = o.parts.at(SKHandle{0, 1}), &d1 = o.parts.at(SKHandle{1, 1});
+      IndexSet idx = c0.getIndexSet();
+      DoubleCRT::Uninitialized u;
+      DoubleCRT t0(*dev, idx, c0.batch(), u), t1(*dev, idx, c0.batch(), u), t2(*dev, idx, c0.batch(), u);
+      helib_amd::tensorProduct(c0, c1, d0, d1, t0, t1, t2);
+      parts.clear();
+      parts.emplace(SKHandle{0, 1}, std::move(t0));
+      parts.emplace(SKHandle{1, 1}, std::move(t1));
+      parts.emplace(SKHandle{2, 1}, std::move(t2));
+    } else {  // any parts (src/Ctxt.cpp:1576-1597): all pairwise products, accumulated by handle
+      std::map<SKHandle, DoubleCRT> np;
+      for (auto& a : parts)
+        for (auto& b : o.parts) {
+          SKHandle h;
+          if (!h.mul(a.first, b.first))
+            throw LogicError("cannot multiply parts under different automorphisms");
+          DoubleCRT t = a.second;
+          t *= b.second;
+          auto it = np.find(h);
+          if (it == np.end())
+            np.emplace(h, std::move(t));
+          else
+            it->second += t;
+        }
+      parts = std::move(np);
+    }
     if (context->ckks) {  // totalNoiseBound = factor*ptxt + noiseBound on both sides (:1600-1606)
       double n1 = lnNoise, n2 = o.lnNoise;
       lnNoise = detail::logaddexp(detail::logaddexp(n1 + detail::ln(o.ptxtMag) + o.lnRatFactor,
@@ -1092,5 +1447,270 @@ inline std::pair<double, double> Ctxt::computeIntervalForMul(const Ctxt& c1, con
   double hi = std::min(cap1 + adn1, cap2 + adn2) - safety;
   return {hi - 4 * LN2, hi};
 }
+
+// calcPolyNormBnd (src/PAlgebra.cpp:215-434): the ring constant c_M.  1 for a power of two,
+// 2 cot(pi/(2u))/u when the odd part of m is a power of one prime u; otherwise, with m replaced by the
+// radical of its odd part, the maximal absolute row sum of the inverse of the Vandermonde matrix of the
+// primitive m-th roots x_j: row i of column j is q_i(x_j) / Phi_m'(x_j) with the Horner prefixes q_0 = 1,
+// q_i = q_(i-1) x_j + a_(n-i) of Phi_m (:360-372); |Phi_m'(x_j)| = prod_i |x_i - x_j| as the exponential
+// of a sum of logarithms.  O(phi(m)^2), computed once per m.
+inline double polyNormBnd(long m)
+{
+  while (m % 2 == 0)
+    m /= 2;
+  if (m == 1)
+    return 1.0;
+  std::vector<long> fac;
+  for (long r = m, d = 3; r > 1; d += 2)
+    if (r % d == 0) {
+      fac.push_back(d);
+      while (r % d == 0)
+        r /= d;
+    }
+  const double PI = std::acos(-1.0);
+  if (fac.size() == 1)
+    return 2.0 / std::tan(PI / (2.0 * fac[0])) / fac[0];
+  m = 1;
+  for (long u : fac)
+    m *= u;
+  // Phi_m = (X^m - 1) / prod_{d | m, d < m} Phi_d, by exact division over the integers
+  std::map<long, std::vector<long>> phi;
+  std::vector<long> divs;
+  for (long d = 1; d <= m; d++)
+    if (m % d == 0)
+      divs.push_back(d);
+  for (long d : divs) {
+    std::vector<long> num((size_t)d + 1, 0);
+    num[(size_t)d] = 1;
+    num[0] = -1;
+    for (long e : divs)
+      if (e < d && d % e == 0) {
+        const std::vector<long>& den = phi[e];   // monic
+        std::vector<long> quo(num.size() - den.size() + 1, 0);
+        for (size_t i = num.size(); i-- >= den.size();) {
+          long c = num[i];
+          quo[i - (den.size() - 1)] = c;
+          if (c)
+            for (size_t j = 0; j < den.size(); j++)
+              num[i - (den.size() - 1) + j] -= c * den[j];
+          if (i == 0)
+            break;
+        }
+        num = quo;
+      }
+    phi[d] = num;
+  }
+  const std::vector<long>& a = phi[m];   // a_0 .. a_n, a_n = 1
+  const size_t n = a.size() - 1;
+  std::vector<long> res;
+  for (long i = 1; i < m; i++)
+    if (std::gcd(i, m) == 1)
+      res.push_back(i);
+  std::vector<double> logd((size_t)m, 0.0), cs((size_t)m), sn((size_t)m);
+  for (long k = 0; k < m; k++) {
+    cs[(size_t)k] = std::cos(2 * PI * (double)k / (double)m);
+    sn[(size_t)k] = std::sin(2 * PI * (double)k / (double)m);
+    if (k)
+      logd[(size_t)k] = std::log(2.0 * std::sin(PI * (double)k / (double)m));
+  }
+  std::vector<double> inv_prod(n), qr(n, 1.0), qi(n, 0.0);
+  for (size_t j = 0; j < n; j++) {
+    double t = 0;
+    for (size_t i = 0; i < n; i++)
+      t += logd[(size_t)(((res[i] - res[j]) % m + m) % m)];
+    inv_prod[j] = std::exp(-t);
+  }
+  double best = 0;
+  for (size_t j = 0; j < n; j++)
+    best += inv_prod[j];            // row 0: q_0 = 1
+  for (size_t i = 1; i < n; i++) {
+    double row = 0;
+    for (size_t j = 0; j < n; j++) {
+      const double xr = cs[(size_t)res[j]], xi = sn[(size_t)res[j]];
+      const double nr = qr[j] * xr - qi[j] * xi + (double)a[n - i], ni = qr[j] * xi + qi[j] * xr;
+      qr[j] = nr;
+      qi[j] = ni;
+      row += std::hypot(nr, ni) * inv_prod[j];
+    }
+    best = std::max(best, row);
+  }
+  return best;
+}
+inline bool Ctxt::isCorrect() const
+{
+  static std::map<long, double> cache;   // (host-side constant of the ring; not thread-safe by design of the test hosts)
+  auto it = cache.find(context->m);
+  if (it == cache.end())
+    it = cache.emplace(context->m, polyNormBnd(context->m)).first;
+  return lnTotalNoiseBound() + std::log(it->second) <= std::log(0.48) + logOfPrimeSet();
+}
+
+// ---- products of many ciphertexts (src/Ctxt.cpp:2803-2904) ----
+namespace detail {
+inline size_t splitBelow(size_t n)   // the highest power of two below n (n/2 <= n1 < n)
+{
+  size_t k = 1;
+  while (2 * k < n)
+    k *= 2;
+  return k;
+}
+inline void incrementalProductRec(std::vector<Ctxt>& v, size_t lo, size_t n)
+{
+  if (n <= 1)
+    return;
+  const size_t n1 = splitBelow(n);
+  incrementalProductRec(v, lo, n1);
+  incrementalProductRec(v, lo + n1, n - n1);
+  for (size_t i = lo + n1; i < lo + n; i++)
+    v[i].multiplyBy(v[lo + n1 - 1]);
+}
+inline Ctxt totalProductRec(const std::vector<Ctxt>& v, size_t lo, size_t n)
+{
+  Ctxt out = v[lo];
+  if (n == 2)
+    out.multiplyBy(v[lo + 1]);
+  else if (n == 3)
+    out.multiplyBy2(v[lo + 1], v[lo + 2]);
+  else if (n > 3) {
+    const size_t n1 = splitBelow(n);
+    out = totalProductRec(v, lo, n1);
+    out.multiplyBy(totalProductRec(v, lo + n1, n - n1));
+  }
+  return out;
+}
+}  // namespace detail
+// for i = n-1 .. 0: v[i] = prod_{j <= i} v[j], depth log n and (n log n)/2 products, in place
+inline void incrementalProduct(std::vector<Ctxt>& v) { detail::incrementalProductRec(v, 0, v.size()); }
+// prod_i v[i] in depth log n with n-1 products (triples through multiplyBy2)
+inline Ctxt totalProduct(const std::vector<Ctxt>& v)
+{
+  if (v.empty())
+    throw InvalidArgument("totalProduct of an empty vector");
+  return detail::totalProductRec(v, 0, v.size());
+}
+// sum_i v1[i] * v2[i] with the low-level product and ONE relinearisation at the end
+inline Ctxt innerProduct(const std::vector<Ctxt>& v1, const std::vector<Ctxt>& v2)
+{
+  const size_t n = std::min(v1.size(), v2.size());
+  if (n == 0)
+    throw InvalidArgument("innerProduct of empty vectors");
+  Ctxt result = v1[0];
+  result.multLowLvl(v2[0]);
+  for (size_t i = 1; i < n; i++) {
+    Ctxt tmp = v1[i];
+    tmp.multLowLvl(v2[i]);
+    result.addCtxt(tmp);
+  }
+  result.reLinearize();
+  return result;
+}
+
+// Hoisting (src/matmul.cpp:48-184): break the `s` part of a ciphertext into digits ONCE, then every
+// automorphism rotates the digits (a permutation of evaluation rows, hx_automorph on the whole digit
+// block) and key-switches them with the matrix of that automorphism -- no inverse transform, no basis
+// extension and no forward transforms per rotation.
+class BasicAutomorphPrecon {
+public:
+  explicit BasicAutomorphPrecon(const Ctxt& ct) : ctxt_(ct)
+  {
+    Ctxt& c = ctxt_;
+    if (c.parts.size() <= 1)
+      return;
+    c.cleanUp();
+    if (c.parts.size() != 2 || !c.parts.count(SKHandle{0, 1}) || !c.parts.count(SKHandle{1, 1}))
+      throw LogicError("Ciphertext is not in canonical form");
+    const ChainContext& cc = *c.context;
+    const IndexSet& sp = cc.specialPrimes;
+    for (auto& d : cc.digits) {
+      IndexSet r;
+      for (int i : d)
+        if (c.primeSet.count(i))
+          r.push_back(i);
+      if (!r.empty())
+        digits_.push_back(r);
+    }
+    std::vector<double> nrm;
+    const DoubleCRT& ps = c.parts.at(SKHandle{1, 1});
+    polyDigits_ = std::make_unique<DoubleCRT>(ps.breakIntoDigits(digits_, sp, c.measure ? &nrm : nullptr));
+    // addedNoise = breakIntoDigits' return value * the matrices' noise bound (src/matmul.cpp:91-97);
+    // noise = ctxt.noise * P + addedNoise (:99-112)
+    double added = -INFINITY;
+    for (size_t k = 0; k < digits_.size(); k++) {
+      double nb;
+      if (c.measure) {
+        double mx = 0;
+        for (int b = 0; b < ps.batch(); b++)
+          mx = std::max(mx, nrm[k * (size_t)ps.batch() + (size_t)b]);
+        nb = detail::ln(mx);
+      } else {
+        nb = std::log(cc.noiseBoundForUniform(0.5, cc.phim));
+      }
+      added = detail::logaddexp(added, nb + cc.logOfProduct(digits_[k]));
+    }
+    added += c.keys->lnNoise;
+    lnNoise_ = detail::logaddexp(c.lnNoise + cc.logOfProduct(sp), added);
+  }
+
+  // the ciphertext rotated by X -> X^k
+  Ctxt automorph(long k) const
+  {
+    const Ctxt& c = ctxt_;
+    const ChainContext& cc = *c.context;
+    const long m = cc.m;
+    k = ((k % m) + m) % m;
+    if (k == 1 || c.parts.empty())
+      return c;
+    if (std::gcd(k, m) != 1)
+      throw InvalidArgument("k must be in Zm*");
+    const IndexSet& sp = cc.specialPrimes;
+    Ctxt res(cc, *c.dev, *c.keys);
+    res.measure = c.measure;
+    res.ptxtSpace = c.ptxtSpace;
+    res.intFactor = c.intFactor;
+    res.ptxtMag = c.ptxtMag;
+    res.lnRatFactor = c.lnRatFactor + cc.logOfProduct(sp);
+    res.primeSet = c.primeSet | toSet(sp);
+    const DoubleCRT& p0 = c.parts.at(SKHandle{0, 1});
+    if (c.parts.size() == 1) {   // only the constant part: nothing to key-switch (:145-151)
+      DoubleCRT part0 = p0;
+      part0.automorph(k);
+      part0.addPrimesAndScale(sp);
+      res.parts.emplace(SKHandle{0, 1}, std::move(part0));
+      res.lnNoise = c.lnNoise + cc.logOfProduct(sp);
+      return res;
+    }
+    const long amt = c.keys->firstStep(k);   // first key-switching matrix on the way to k (:153-162)
+    auto it = amt ? c.keys->automorph.find(amt) : c.keys->automorph.end();
+    if (it == c.keys->automorph.end())
+      throw LogicError("no key-switching matrices for k=" + std::to_string(k));
+    DoubleCRT part0 = p0;
+    part0.automorph(amt);
+    part0.addPrimesAndScale(sp);
+    DoubleCRT dg = *polyDigits_;
+    dg.automorph(amt);
+    DoubleCRT part1(*c.dev, part0.getIndexSet(), part0.batch());
+    keySwitchDigits(*it->second, dg, part0, part1);
+    res.parts.emplace(SKHandle{0, 1}, std::move(part0));
+    res.parts.emplace(SKHandle{1, 1}, std::move(part1));
+    res.lnNoise = lnNoise_;
+    if (amt != k) {   // more automorphisms to do: the usual smartAutomorph (:177-181)
+      long inv = 1, a = amt % m, e = ChainContext::eulerPhi(m) - 1;
+      while (e) {
+        if (e & 1)
+          inv = (long)((unsigned __int128)inv * (unsigned long)a % (unsigned long)m);
+        a = (long)((unsigned __int128)a * (unsigned long)a % (unsigned long)m);
+        e >>= 1;
+      }
+      res.smartAutomorph((long)((unsigned __int128)k * (unsigned long)inv % (unsigned long)m));
+    }
+    return res;
+  }
+
+private:
+  Ctxt ctxt_;
+  std::unique_ptr<DoubleCRT> polyDigits_;
+  std::vector<IndexSet> digits_;
+  double lnNoise_ = 0;
+};
 
 }  // namespace helib_amd

@@ -575,6 +575,8 @@ public:
       keys.automorph[fromXPower] = k.W.get();
       if (!keys.relin)
         keys.lnNoise = std::log(k.noiseBound);
+    } else if (fromXPower == 1) {
+      keys.pow[fromSPower] = k.W.get();
     }
   }
   void setKeySwitchMap() { keys.setKeySwitchMap(cc->m); }

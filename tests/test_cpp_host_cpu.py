@@ -1,0 +1,85 @@
+"""The C++ host side (include/helib_amd_ctxt.hpp, helib_amd_keys.hpp) on the CPU: the same C++ programs the
+`-m gpu` suite runs against libhelib_amd.so are linked here against tests/cpp/hx_mock.cpp, a stand-in for the
+C ABI over the CPU oracle (TEST INFRASTRUCTURE, built by this module into a temporary directory and linked by
+nothing else).  What is under test is the host control flow -- prime-set decisions, noise bookkeeping, handle
+algebra, key management, hoisting -- with every result decrypted and compared with plain arithmetic modulo
+(X^N + 1, p) by the programs themselves."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+
+
+@pytest.fixture(scope="module")
+def mock(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("hxmock"))
+    obj = os.path.join(d, "hx_oracle.o")
+    subprocess.check_call(["gcc", "-O3", "-fPIC", "-std=c11", "-c", os.path.join(ROOT, "oracle", "hx_oracle.c"), "-o", obj])
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Werror", "-I" + INC,
+                           "-I" + os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "cpp", "hx_mock.cpp"), obj,
+                           "-lm", "-o", os.path.join(d, "libhx_mock.so")])
+
+    def build(src, name):
+        exe = os.path.join(d, name)
+        if not os.path.exists(exe):
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + INC, src, "-L" + d, "-lhx_mock",
+                                   "-Wl,-rpath," + d, "-o", exe])
+        return exe
+    return build
+
+
+@pytest.mark.parametrize("m,p,bits,measure", [(128, 257, 150, 0), (128, 2, 300, 1), (1024, 65537, 250, 1),
+                                              (128, -1, 250, 0), (256, -1, 300, 1)])
+def test_cpp_keys_encrypt_multiply_rotate_decrypt_over_the_mock(mock, m, p, bits, measure):
+    """tests/cpp/keys_test.cpp (key generation, Encrypt, multiplyBy, addCtxt, smartAutomorph in one and two
+    steps, Decrypt; CKKS: products over two levels, sums across scaling factors) -- the program of the GPU
+    suite, here with the polynomial work done by the oracle."""
+    exe = mock(os.path.join(ROOT, "tests", "cpp", "keys_test.cpp"), "keys_test")
+    r = subprocess.run([exe, str(m), str(p), str(bits), str(measure)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "keys_test OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("m,p,bits,measure", [(128, 257, 300, 0), (128, 257, 300, 1), (128, 3, 300, 0),
+                                              (256, 65537, 400, 1), (128, -1, 400, 0), (256, -1, 500, 1)])
+def test_cpp_ctxt_operations_over_the_mock(mock, m, p, bits, measure):
+    """tests/cpp/ctxt_ops_test.cpp: multiplyBy2 / cube / power through the 4-part ciphertext and
+    keySwitchPart (src/Ctxt.cpp:1776-1828, 720-842), totalProduct / incrementalProduct / innerProduct
+    (:2803-2904), BasicAutomorphPrecon (src/matmul.cpp:48-184), frobeniusAutomorph (p = 3: order 32 modulo
+    128), multByConstant / addConstant with scalars and DoubleCRT constants, capacity / isCorrect, and the
+    CKKS forms."""
+    exe = mock(os.path.join(ROOT, "tests", "cpp", "ctxt_ops_test.cpp"), "ctxt_ops_test")
+    r = subprocess.run([exe, str(m), str(p), str(bits), str(measure)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ctxt_ops_test OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_polyNormBnd_matches_the_python_mirror(mock, tmp_path):
+    """calcPolyNormBnd (src/PAlgebra.cpp:215-434) in C++ against helib_amd.ctxt.polyNormBnd: power of two,
+    prime-power odd part (closed form) and the general case (inverse Vandermonde row sums)."""
+    from helib_amd.ctxt import polyNormBnd
+    src = tmp_path / "pnb.cpp"
+    src.write_text('#include <cstdio>\n#include <cstdlib>\n#include "helib_amd_ctxt.hpp"\n'
+                   'int main(int c, char** v) { for (int i = 1; i < c; i++) '
+                   'printf("%.15g\\n", helib_amd::polyNormBnd(atol(v[i]))); }\n')
+    exe = mock(str(src), "pnb")
+    ms = [128, 12, 45, 105, 1705, 4095]
+    out = subprocess.run([exe] + [str(m) for m in ms], capture_output=True, text=True, timeout=300).stdout.split()
+    assert len(out) == len(ms)
+    for m, got in zip(ms, out):
+        assert float(got) == pytest.approx(polyNormBnd(m), rel=1e-9), m
+
+
+def test_the_mock_is_test_infrastructure_only():
+    """nothing under helib_amd/, include/, bench.py or __graft_entry__.py refers to the mock"""
+    hits = []
+    for base, _, files in os.walk(ROOT):
+        if any(part in base for part in (os.sep + "tests", os.sep + ".git", os.sep + "gpurun_out", "__pycache__")):
+            continue
+        for f in files:
+            if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".sh")):
+                with open(os.path.join(base, f), errors="ignore") as fh:
+                    if "hx_mock" in fh.read():
+                        hits.append(os.path.join(base, f))
+    assert not hits, hits

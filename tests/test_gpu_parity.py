@@ -1639,6 +1639,34 @@ def test_cpp_host_keys_encrypt_multiply_rotate_decrypt(hx, m, p, bits, measure, 
     assert r.returncode == 0 and "keys_test OK" in r.stdout, r.stdout + r.stderr
 
 
+_CTXT_OPS_EXE = {}
+
+
+@pytest.mark.parametrize("m,p,bits,measure", [(128, 257, 300, 0), (4096, 65537, 500, 1), (2048, 3, 400, 1),
+                                              (128, -1, 400, 0), (2048, -1, 500, 1)])
+def test_cpp_host_ctxt_operations(hx, m, p, bits, measure, tmp_path_factory):
+    """include/helib_amd_ctxt.hpp beyond multiplyBy, from C++ over the C ABI (tests/cpp/ctxt_ops_test.cpp
+    checks every result against schoolbook arithmetic after decryption): multiplyBy2 / cube / power through
+    the 4-part ciphertext and keySwitchPart (hx_break_into_digits[_norms] + hx_key_switch_digits per part,
+    src/Ctxt.cpp:1776-1828, 720-842), totalProduct / incrementalProduct / innerProduct (:2803-2904),
+    BasicAutomorphPrecon (hoisting: one digit block, hx_automorph on it, one key switch per rotation,
+    src/matmul.cpp:48-184), frobeniusAutomorph, multByConstant / addConstant, capacity / isCorrect; p = -1:
+    the CKKS forms incl. complex conjugation.  The same program runs over the CPU mock of the C ABI in
+    tests/test_cpp_host_cpu.py."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if "exe" not in _CTXT_OPS_EXE:       # one build for all parameter sets
+        exe = str(tmp_path_factory.mktemp("ctxt_ops") / "ctxt_ops_test")
+        libdir = os.path.join(root, "helib_amd", "lib")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"),
+                               os.path.join(root, "tests", "cpp", "ctxt_ops_test.cpp"), "-L" + libdir, "-lhelib_amd",
+                               "-Wl,-rpath," + libdir, "-o", exe])
+        _CTXT_OPS_EXE["exe"] = exe
+    r = subprocess.run([_CTXT_OPS_EXE["exe"], str(m), str(p), str(bits), str(measure)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "ctxt_ops_test OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_captured_graph_replays_a_multiply(hx):
     """hx_ctx_graph_begin / _end / hx_graph_launch: tensorProduct + reLinearize (hx_mul_relin) recorded
     once and replayed with one launch.  A replay re-executes the same kernels on the same buffers, so
