@@ -1448,6 +1448,40 @@ inline std::pair<double, double> Ctxt::computeIntervalForMul(const Ctxt& c1, con
   return {hi - 4 * LN2, hi};
 }
 
+// Phi_m(X), coefficients a_0 .. a_phi(m) (monic): (X^m - 1) / prod_{d | m, d < m} Phi_d by exact division
+// over the integers (the reference: Cyclotomic, src/NumbTh.cpp:1034-1060)
+inline std::vector<long> cyclotomic(long m)
+{
+  std::map<long, std::vector<long>> phi;
+  std::vector<long> divs;
+  for (long d = 1; d <= m; d++)
+    if (m % d == 0)
+      divs.push_back(d);
+  for (long d : divs) {
+    std::vector<long> num((size_t)d + 1, 0);
+    num[(size_t)d] = 1;
+    num[0] = -1;
+    for (long e : divs)
+      if (e < d && d % e == 0) {
+        const std::vector<long>& den = phi[e];
+        const size_t dd = den.size() - 1;   // degree of the (monic) divisor
+        std::vector<long> quo(num.size() - dd, 0);
+        for (size_t i = num.size() - 1; i + 1 > dd; i--) {
+          const long c = num[i];
+          quo[i - dd] = c;
+          if (c)
+            for (size_t j = 0; j <= dd; j++)
+              num[i - dd + j] -= c * den[j];
+          if (i == 0)
+            break;
+        }
+        num = quo;
+      }
+    phi[d] = num;
+  }
+  return phi[m];
+}
+
 // calcPolyNormBnd (src/PAlgebra.cpp:215-434): the ring constant c_M.  1 for a power of two,
 // 2 cot(pi/(2u))/u when the odd part of m is a power of one prime u; otherwise, with m replaced by the
 // radical of its odd part, the maximal absolute row sum of the inverse of the Vandermonde matrix of the
@@ -1473,34 +1507,7 @@ inline double polyNormBnd(long m)
   m = 1;
   for (long u : fac)
     m *= u;
-  // Phi_m = (X^m - 1) / prod_{d | m, d < m} Phi_d, by exact division over the integers
-  std::map<long, std::vector<long>> phi;
-  std::vector<long> divs;
-  for (long d = 1; d <= m; d++)
-    if (m % d == 0)
-      divs.push_back(d);
-  for (long d : divs) {
-    std::vector<long> num((size_t)d + 1, 0);
-    num[(size_t)d] = 1;
-    num[0] = -1;
-    for (long e : divs)
-      if (e < d && d % e == 0) {
-        const std::vector<long>& den = phi[e];   // monic
-        std::vector<long> quo(num.size() - den.size() + 1, 0);
-        for (size_t i = num.size(); i-- >= den.size();) {
-          long c = num[i];
-          quo[i - (den.size() - 1)] = c;
-          if (c)
-            for (size_t j = 0; j < den.size(); j++)
-              num[i - (den.size() - 1) + j] -= c * den[j];
-          if (i == 0)
-            break;
-        }
-        num = quo;
-      }
-    phi[d] = num;
-  }
-  const std::vector<long>& a = phi[m];   // a_0 .. a_n, a_n = 1
+  const std::vector<long> a = cyclotomic(m);   // a_0 .. a_n, a_n = 1
   const size_t n = a.size() - 1;
   std::vector<long> res;
   for (long i = 1; i < m; i++)

@@ -14,8 +14,8 @@
 // rows (key-switching `a` columns, the public key's c1) are drawn on the device by hx_randomize from
 // streams 1, 2, ... of the same key.  The reference's stream itself is NTL's and unreproducible
 // (SURVEY section 8c): distributions, not streams, are what the algorithms fix.
-// Power-of-two m only on this host side (the general-m
-// samplers, which reduce modulo Phi_m, are in helib_amd/keys.py).  One secret key per object.
+// General m: the samplers draw m coefficients and reduce modulo Phi_m (reduceModPhimX), with the
+// reference's probabilities and bounds for that case.  One secret key per object.
 // No CPU fallback: every polynomial operation is a call into libhelib_amd.so.
 #pragma once
 #include <climits>
@@ -335,23 +335,44 @@ public:
       : cc_(&c), dev_(&d), rng_(seed ? ChaChaRng(*seed) : ChaChaRng())
   {
     if (!c.pow2)
-      throw LogicError("helib_amd_keys.hpp samples for power-of-two m only");
+      phimx_ = cyclotomic(c.m);
   }
   ChaChaRng& rng() { return rng_; }
 
-  // each coefficient 0 with probability 1/2, +-1 with probability 1/4 each
+  // unbounded draws: power-of-two m takes phi(m) coefficients directly; general m samples m coefficients
+  // and reduces modulo Phi_m (src/sample.cpp:240-256, 321-341, 420-440)
+  size_t drawLen() const { return (size_t)(cc_->pow2 ? cc_->phim : cc_->m); }
+  // reduceModPhimX (src/sample.cpp:216-226): remainder modulo the monic Phi_m(X)
+  std::vector<long> reduce(std::vector<long> a) const
+  {
+    if (cc_->pow2)
+      return a;
+    const size_t n = (size_t)cc_->phim;
+    for (size_t i = a.size(); i-- > n;) {
+      const long c = a[i];
+      if (c)
+        for (size_t j = 0; j <= n; j++)
+          a[i - n + j] -= c * phimx_[j];
+    }
+    a.resize(n);
+    return a;
+  }
+  // each coefficient 0 with probability 1 - prob, +-1 with probability prob/2 each (prob = 1/2 for
+  // power-of-two m, phi(m)/(2m) otherwise: src/sample.cpp:327-339)
   std::vector<long> sampleSmall()
   {
-    std::vector<long> v((size_t)cc_->phim);
+    const double prob = cc_->pow2 ? 0.5 : (double)cc_->phim / (2.0 * (double)cc_->m);
+    std::vector<long> v(drawLen());
     for (auto& x : v) {
-      uint64_t r = rng_();
-      x = (r & 1) ? ((r & 2) ? 1 : -1) : 0;
+      const uint64_t r = rng_();
+      const bool nz = cc_->pow2 ? (r & 1) : ((double)(r >> 11) * (1.0 / 9007199254740992.0) < prob);
+      x = nz ? ((r & 2) ? 1 : -1) : 0;
     }
-    return v;
+    return reduce(std::move(v));
   }
   std::vector<long> sampleHWt(long hwt)
   {
-    long n = cc_->phim;
+    long n = (long)drawLen();
     hwt = std::min(hwt, n);
     std::vector<long> v((size_t)n, 0);
     long placed = 0;
@@ -362,16 +383,18 @@ public:
         placed++;
       }
     }
-    return v;
+    return reduce(std::move(v));
   }
   std::vector<long> sampleGaussian(double stdev)
   {
     std::normal_distribution<double> g(0.0, stdev);
-    std::vector<long> v((size_t)cc_->phim);
+    std::vector<long> v(drawLen());
     for (auto& x : v)
       x = std::lround(g(rng_));
-    return v;
+    return reduce(std::move(v));
   }
+  // the standard deviation RLWE1 / Encrypt draw their errors with (src/keys.cpp:46-52, :422-430)
+  double errorStdev() const { return cc_->pow2 ? cc_->stdev : cc_->stdev * std::sqrt((double)cc_->m); }
   double embeddingLargestCoeff(const std::vector<long>& f) const
   {
     std::vector<double> d(f.begin(), f.end());
@@ -404,7 +427,7 @@ public:
   std::vector<long> sampleGaussianBounded(double stdev, double& bound)
   {
     double n = (double)cc_->phim;
-    bound = stdev * std::sqrt(n * std::log(n));
+    bound = stdev * std::sqrt((cc_->pow2 ? n : (double)cc_->m) * std::log(n));
     return bounded([&] { return sampleGaussian(stdev); }, bound, "sampleGaussianBounded");
   }
 
@@ -412,6 +435,7 @@ private:
   const ChainContext* cc_;
   const Context* dev_;
   ChaChaRng rng_;
+  std::vector<long> phimx_;   // general m: Phi_m(X)
 };
 
 // one key-switching matrix W[s^r(X^t) -> s] with its bookkeeping (include/helib/keySwitching.h:86-101)
@@ -495,7 +519,7 @@ public:
   double RLWE1(DoubleCRT& c0, const DoubleCRT& c1, const IndexSet& idx, long p)
   {
     double bound = 0;
-    std::vector<long> e = sampler.sampleGaussianBounded(cc->stdev, bound);
+    std::vector<long> e = sampler.sampleGaussianBounded(sampler.errorStdev(), bound);
     c0 = fromCoeffs(idx, e);
     if (p > 1) {
       c0.mulConstant(scalarRows(idx, *cc, p));
@@ -614,7 +638,7 @@ public:
     for (int i = 0; i < 2; i++) {
       parts[i] *= rr;
       double e_bound = 0;
-      DoubleCRT ee = fromCoeffs(idx, sampler.sampleGaussianBounded(cc->stdev, e_bound));
+      DoubleCRT ee = fromCoeffs(idx, sampler.sampleGaussianBounded(sampler.errorStdev(), e_bound));
       ee.mulConstant(scalarRows(idx, *cc, p));
       e_bound *= (double)p;
       if (i == 1)
@@ -652,7 +676,7 @@ public:
     for (int i = 0; i < 2; i++) {
       parts[i] *= rr;
       double e_bound = 0;
-      parts[i] += fromCoeffs(idx, sampler.sampleGaussianBounded(cc->stdev, e_bound));
+      parts[i] += fromCoeffs(idx, sampler.sampleGaussianBounded(sampler.errorStdev(), e_bound));
       if (i == 1)
         e_bound *= skBound;
       error_bound += e_bound;

@@ -1,5 +1,5 @@
 // The wider Ctxt operations of include/helib_amd_ctxt.hpp driven from C++ over the C ABI and checked against
-// plain polynomial arithmetic modulo (X^N + 1, p): multiplyBy2 / cube / power (parts up to s^3, one
+// plain polynomial arithmetic modulo (Phi_m(X), p), any m: multiplyBy2 / cube / power (parts up to s^3, one
 // relinearisation through keySwitchPart), totalProduct / incrementalProduct / innerProduct, hoisted
 // rotations (BasicAutomorphPrecon, one and two steps along the key-switch map), frobeniusAutomorph,
 // multByConstant / addConstant with scalars and DoubleCRT constants, capacity / isCorrect; and the CKKS
@@ -16,23 +16,33 @@ using namespace helib_amd;
 
 typedef std::vector<long> Poly;
 
+// arithmetic modulo (Phi_m(X), p): schoolbook product / substitution, then the remainder by the monic Phi_m
+static std::vector<long> g_phi;   // Phi_m, set by main
+static Poly reduce_phi(std::vector<long> full, long p)
+{
+  const size_t n = g_phi.size() - 1;
+  for (size_t i = full.size(); i-- > n;) {
+    const long c = full[i] % p;
+    if (c)
+      for (size_t j = 0; j <= n; j++)
+        full[i - n + j] = ((full[i - n + j] - c * (g_phi[j] % p)) % p + p) % p;
+  }
+  full.resize(n);
+  for (auto& v : full)
+    v = ((v % p) + p) % p;
+  return full;
+}
 static Poly mul(const Poly& a, const Poly& b, long p)
 {
   size_t n = a.size();
-  Poly out(n, 0);
+  std::vector<long> full(2 * n - 1, 0);
   for (size_t i = 0; i < n; i++) {
     if (a[i] == 0)
       continue;
-    for (size_t j = 0; j < n; j++) {
-      long t = (long)((unsigned __int128)a[i] * (unsigned long)b[j] % (unsigned long)p);
-      size_t k = i + j;
-      if (k < n)
-        out[k] = (out[k] + t) % p;
-      else
-        out[k - n] = (out[k - n] + p - t) % p;
-    }
+    for (size_t j = 0; j < n; j++)
+      full[i + j] = (full[i + j] + (long)((unsigned __int128)a[i] * (unsigned long)b[j] % (unsigned long)p)) % p;
   }
-  return out;
+  return reduce_phi(std::move(full), p);
 }
 static Poly add(const Poly& a, const Poly& b, long p)
 {
@@ -41,18 +51,15 @@ static Poly add(const Poly& a, const Poly& b, long p)
     out[i] = (a[i] + b[i]) % p;
   return out;
 }
-static Poly rot(const Poly& a, long k, long p)   // f(X) -> f(X^k) modulo X^N + 1
+static long g_m = 0;
+static Poly rot(const Poly& a, long k, long p)   // f(X) -> f(X^k) modulo Phi_m
 {
-  size_t n = a.size();
-  Poly out(n, 0);
-  for (size_t i = 0; i < n; i++) {
-    size_t e = (size_t)((unsigned __int128)i * (unsigned long)k % (2 * n));
-    if (e < n)
-      out[e] = (out[e] + a[i]) % p;
-    else
-      out[e - n] = (out[e - n] + p - a[i]) % p;
+  std::vector<long> full((size_t)g_m, 0);        // first modulo X^m - 1
+  for (size_t i = 0; i < a.size(); i++) {
+    size_t e = (size_t)((unsigned __int128)i * (unsigned long)k % (unsigned long)g_m);
+    full[e] = (full[e] + a[i]) % p;
   }
-  return out;
+  return reduce_phi(std::move(full), p);
 }
 static std::vector<double> mul_d(const std::vector<double>& a, const std::vector<double>& b)
 {
@@ -108,12 +115,19 @@ int main(int argc, char** argv)
     return ckks_main(m, bits, measure);
   try {
     ChainContext cc(m, p, 1, bits, 3);
+    g_m = m;
+    g_phi = cyclotomic(m);
+    REQUIRE((long)g_phi.size() == cc.phim + 1 && g_phi.back() == 1);
+    long k = 2;                            // the rotation the tests use: the least k > 1 in Zm*
+    while (std::gcd(k, m) != 1)
+      k++;
+    const long k2 = k * k % m, k3 = k2 * k % m;
     auto dev = cc.makeDeviceContext(0);
     SecKey sk(cc, *dev, 4242);
     sk.GenSecKey(3);                       // s^2 -> s and s^3 -> s
-    sk.GenKeySWmatrix(1, 3);
+    sk.GenKeySWmatrix(1, k);
     sk.setKeySwitchMap();
-    REQUIRE(sk.keys.relin && sk.keys.pow.count(3) && sk.keys.automorph.count(3));
+    REQUIRE(sk.keys.relin && sk.keys.pow.count(3) && sk.keys.automorph.count(k));
     REQUIRE(sk.keys.matrixFor(SKHandle{3, 1}) && !sk.keys.matrixFor(SKHandle{4, 1}) && !sk.keys.matrixFor(SKHandle{2, 3}));
     {
       SKHandle h;
@@ -194,13 +208,13 @@ int main(int argc, char** argv)
       Ctxt x = ct[0];
       x.multiplyBy(ct[1]);
       BasicAutomorphPrecon pre(x);
-      Ctxt r1 = pre.automorph(1), r3 = pre.automorph(3), r9 = pre.automorph(9), r27 = pre.automorph(27);
+      Ctxt r1 = pre.automorph(1), r3 = pre.automorph(k), r9 = pre.automorph(k2), r27 = pre.automorph(k3);
       REQUIRE(sk.Decrypt(r1) == ab);
-      REQUIRE(r3.parts.size() == 2 && sk.Decrypt(r3) == rot(ab, 3, p));
-      REQUIRE(sk.Decrypt(r9) == rot(ab, 9, p));       // first step hoisted, second by smartAutomorph
-      REQUIRE(sk.Decrypt(r27) == rot(ab, 27, p));
+      REQUIRE(r3.parts.size() == 2 && sk.Decrypt(r3) == rot(ab, k, p));
+      REQUIRE(sk.Decrypt(r9) == rot(ab, k2, p));      // first step hoisted, second by smartAutomorph
+      REQUIRE(sk.Decrypt(r27) == rot(ab, k3, p));
       Ctxt s3 = x;
-      s3.smartAutomorph(3);
+      s3.smartAutomorph(k);
       REQUIRE(sk.Decrypt(s3) == sk.Decrypt(r3));
       REQUIRE(std::fabs(s3.lnNoise - r3.lnNoise) < 2.0);   // same bound up to the cleanUp the precon did first
       bool threw = false;

@@ -3,7 +3,7 @@
 C ABI over the CPU oracle (TEST INFRASTRUCTURE, built by this module into a temporary directory and linked by
 nothing else).  What is under test is the host control flow -- prime-set decisions, noise bookkeeping, handle
 algebra, key management, hoisting -- with every result decrypted and compared with plain arithmetic modulo
-(X^N + 1, p) by the programs themselves."""
+(Phi_m(X), p) by the programs themselves."""
 import os
 import subprocess
 
@@ -43,13 +43,15 @@ def test_cpp_keys_encrypt_multiply_rotate_decrypt_over_the_mock(mock, m, p, bits
 
 
 @pytest.mark.parametrize("m,p,bits,measure", [(128, 257, 300, 0), (128, 257, 300, 1), (128, 3, 300, 0),
-                                              (256, 65537, 400, 1), (128, -1, 400, 0), (256, -1, 500, 1)])
+                                              (256, 65537, 400, 1), (128, -1, 400, 0), (256, -1, 500, 1),
+                                              (105, 2, 300, 0), (105, 257, 300, 1), (45, 2, 300, 1), (1705, 2, 300, 0)])
 def test_cpp_ctxt_operations_over_the_mock(mock, m, p, bits, measure):
     """tests/cpp/ctxt_ops_test.cpp: multiplyBy2 / cube / power through the 4-part ciphertext and
     keySwitchPart (src/Ctxt.cpp:1776-1828, 720-842), totalProduct / incrementalProduct / innerProduct
     (:2803-2904), BasicAutomorphPrecon (src/matmul.cpp:48-184), frobeniusAutomorph (p = 3: order 32 modulo
     128), multByConstant / addConstant with scalars and DoubleCRT constants, capacity / isCorrect, and the
-    CKKS forms."""
+    CKKS forms.  General m (105, 45 = 9*5, 1705): keys and encryptions from the samplers that reduce modulo
+    Phi_m, arithmetic checked modulo (Phi_m, p)."""
     exe = mock(os.path.join(ROOT, "tests", "cpp", "ctxt_ops_test.cpp"), "ctxt_ops_test")
     r = subprocess.run([exe, str(m), str(p), str(bits), str(measure)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ctxt_ops_test OK" in r.stdout, r.stdout + r.stderr
@@ -69,6 +71,22 @@ def test_cpp_polyNormBnd_matches_the_python_mirror(mock, tmp_path):
     assert len(out) == len(ms)
     for m, got in zip(ms, out):
         assert float(got) == pytest.approx(polyNormBnd(m), rel=1e-9), m
+
+
+def test_cpp_cyclotomic_matches_the_python_side(mock, tmp_path):
+    """Phi_m(X) by exact division in C++ (the samplers' reduceModPhimX and calcPolyNormBnd use it) against
+    helib_amd.hostnt.phimx, incl. m with repeated prime factors"""
+    from helib_amd import hostnt
+    src = tmp_path / "cyc.cpp"
+    src.write_text('#include <cstdio>\n#include <cstdlib>\n#include "helib_amd_ctxt.hpp"\n'
+                   'int main(int c, char** v) { for (int i = 1; i < c; i++) { '
+                   'for (long a : helib_amd::cyclotomic(atol(v[i]))) printf("%ld ", a); printf("\\n"); } }\n')
+    exe = mock(str(src), "cyc")
+    ms = [1, 2, 12, 45, 105, 128, 385, 1705, 4095]
+    out = subprocess.run([exe] + [str(m) for m in ms], capture_output=True, text=True, timeout=300).stdout.strip().split("\n")
+    assert len(out) == len(ms)
+    for m, line in zip(ms, out):
+        assert [int(x) for x in line.split()] == [int(c) for c in hostnt.phimx(m)], m
 
 
 def test_the_mock_is_test_infrastructure_only():

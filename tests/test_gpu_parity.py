@@ -1643,7 +1643,8 @@ _CTXT_OPS_EXE = {}
 
 
 @pytest.mark.parametrize("m,p,bits,measure", [(128, 257, 300, 0), (4096, 65537, 500, 1), (2048, 3, 400, 1),
-                                              (128, -1, 400, 0), (2048, -1, 500, 1)])
+                                              (128, -1, 400, 0), (2048, -1, 500, 1), (105, 257, 300, 0),
+                                              (1705, 2, 300, 1)])
 def test_cpp_host_ctxt_operations(hx, m, p, bits, measure, tmp_path_factory):
     """include/helib_amd_ctxt.hpp beyond multiplyBy, from C++ over the C ABI (tests/cpp/ctxt_ops_test.cpp
     checks every result against schoolbook arithmetic after decryption): multiplyBy2 / cube / power through
@@ -1651,7 +1652,8 @@ def test_cpp_host_ctxt_operations(hx, m, p, bits, measure, tmp_path_factory):
     src/Ctxt.cpp:1776-1828, 720-842), totalProduct / incrementalProduct / innerProduct (:2803-2904),
     BasicAutomorphPrecon (hoisting: one digit block, hx_automorph on it, one key switch per rotation,
     src/matmul.cpp:48-184), frobeniusAutomorph, multByConstant / addConstant, capacity / isCorrect; p = -1:
-    the CKKS forms incl. complex conjugation.  The same program runs over the CPU mock of the C ABI in
+    the CKKS forms incl. complex conjugation; m = 105 and 1705: the Bluestein rows, keys from the general-m
+    samplers (reduction modulo Phi_m).  The same program runs over the CPU mock of the C ABI in
     tests/test_cpp_host_cpu.py."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
