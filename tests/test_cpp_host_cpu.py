@@ -101,3 +101,87 @@ def test_the_mock_is_test_infrastructure_only():
                     if "hx_mock" in fh.read():
                         hits.append(os.path.join(base, f))
     assert not hits, hits
+
+
+@pytest.mark.parametrize("m,p,bits,k,measure", [(128, 257, 150, 3, 0), (128, 257, 150, 5, 1), (1024, 65537, 250, 3, 1),
+                                                (105, 2, 200, 2, 0)])
+def test_cpp_ctxt_matches_the_python_mirror_over_the_oracle(mock, m, p, bits, k, measure, tmp_path, monkeypatch):
+    """tests/cpp/ctxt_test.cpp (the program of the GPU suite's test_cpp_host_ctxt_matches_python_mirror) over the
+    mock, against helib_amd.ctxt over the oracle backend on the same keys and ciphertexts: prime sets,
+    intFactor, noise estimate and every word of every part of the product, product + product and the product
+    rotated in one and in two steps; the error paths (LogicError, InvalidArgument) counted."""
+    import struct
+
+    import numpy as np
+
+    from helib_amd import ctxt as hc
+    from oracle import oracle as O
+    from oracle.backend import OKeySwitch, OPoly, OracleOps
+    from tests import test_ctxt_host as T
+    exe = mock(os.path.join(ROOT, "tests", "cpp", "ctxt_test.cpp"), "ctxt_test")
+    monkeypatch.setattr(hc.Ctxt, "measure", bool(measure))
+    cc = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    octx = O.Ctx(m)
+    for q in cc.primes:
+        octx.add_prime(q)
+    N = octx.N
+    s, allp, kb, ka, rows = T.make_keys(cc, octx)
+    _, _, kbk, kak, _ = T.make_keys(cc, octx, auto_k=k)
+    rng = np.random.default_rng(4)
+    ma, mb = rng.integers(0, p, size=N), rng.integers(0, p, size=N)
+    ea, eb = T.encrypt(cc, octx, s, ma, 1, rows), T.encrypt(cc, octx, s, mb, 2, rows)
+    L, D = len(cc.ctxtPrimes), len(cc.digits)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<10q", m, p, bits, k, measure, len(cc.primes), D, len(allp), L, N))
+        f.write(np.array(octx.roots, dtype="<u8").tobytes())
+        for arr in (kb, ka, kbk, kak, ea[0], ea[1], eb[0], eb[1]):
+            f.write(np.ascontiguousarray(arr, dtype="<u8").tobytes())
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ops = OracleOps(octx)
+    W, Wk = OKeySwitch(allp, kb, ka), OKeySwitch(allp, kbk, kak)
+    mk = lambda e: hc.Ctxt.fresh(cc, ops, *(OPoly(octx, cc.ctxtPrimes, x) for x in e), ksw=W)  # noqa: E731
+    ga, gb = mk(ea), mk(eb)
+    ga.ksw_auto = {k: Wk}
+    ga.multiplyBy(gb)
+    prod = ga.clone()
+    gsum = ga.clone()
+    gsum.addCtxt(ga)
+    ga.smartAutomorph(k)
+    rot1 = ga.clone()
+    kmap = [0] * m                   # PubKey::setKeySwitchMap with the single edge k
+    cur = k
+    while cur != 1 and kmap[cur] == 0:
+        kmap[cur] = k
+        cur = cur * k % m
+    ga.ksw_map = kmap
+    ga.smartAutomorph(k * k % m)
+    buf = open(fout, "rb").read()
+    off = 0
+    hname = {(0, 1): "1", (1, 1): "s"}
+    for want in (prod, gsum, rot1, ga):
+        nset, intFactor, nparts = struct.unpack_from("<3q", buf, off)
+        (ln,) = struct.unpack_from("<d", buf, off + 24)
+        off += 32
+        pset = list(struct.unpack_from(f"<{nset}q", buf, off))
+        off += 8 * nset
+        assert pset == sorted(want.primeSet) and intFactor == want.intFactor and nparts == len(want.parts)
+        assert abs(ln - want.lnNoise) < 1e-8, (ln, want.lnNoise)
+        for _ in range(nparts):
+            sp, xp, nr = struct.unpack_from("<3q", buf, off)
+            idx = list(struct.unpack_from(f"<{nr}q", buf, off + 24))
+            off += 24 + 8 * nr
+            got = np.frombuffer(buf, dtype="<u8", count=nr * N, offset=off).reshape(nr, N)
+            off += 8 * nr * N
+            part = want.parts[hname[(sp, xp)]]
+            wi, wd = part.getIndexSet(), part.download()[:, 0]
+            assert sorted(idx) == sorted(wi)
+            for rr, i in enumerate(idx):
+                assert np.array_equal(got[rr], wd[wi.index(i)]), (sp, xp, i)
+    (errs,) = struct.unpack_from("<q", buf, off)
+    assert errs == 3 and off + 8 == len(buf)
+    from tests import bgv_ref as B
+    ab = [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
+    assert T.decrypt(cc, octx, s, prod, rows) == ab
+    assert T.decrypt(cc, octx, s, ga, rows) == [int(v) for v in B.automorph_mod_phi(ab, m, pow(k, 3, m), p)]
