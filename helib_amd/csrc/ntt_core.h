@@ -300,9 +300,19 @@ HXD void ct_bfly4(uint64_t& X, uint64_t& Y, TW t, const QC& c)
   uint64_t xn = shoup4_acc(Y, t, c.nq, x);
   HX_KEEP64(xn);  // (opaque: otherwise the subtraction below is distributed over xn's halves)
   X = xn;
+#ifdef HX_YNOT
+  // experiment (tools/ubench/bfly_bench.hip): the 64-bit subtraction as complement-and-add -- two v_not_b32
+  // and a v_lshl_add_u64 instead of v_sub_co / v_subb_co with their VCC wait states
+  uint64_t nx = ~xn;
+  HX_KEEP64(nx);
+  uint64_t x2 = (x << 1) + (c.q4 + 1);
+  HX_KEEP64(x2);
+  Y = x2 + nx;
+#else
   uint64_t x2 = (x << 1) + c.q4;
   HX_KEEP64(x2);
   Y = x2 - xn;
+#endif
 #else
   const uint64_t v = shoup4(Y, t, c.nq);
   X = x + v;
