@@ -771,7 +771,7 @@ def main():
                     extra["hbm_traffic_source"] = "profiles/r02_pmc_fresh_multiply_traffic.json"
             roof = ntt_roofline(hx, sub, fixed_primes, list(range(l)), list(range(l, l + k)),
                                 shape["digits"], B, rng, args.ntt_iters)
-            if args.inputs == "real" and not args.no_extras:
+            if args.inputs == "real" and not args.no_extras and world == 1:   # (N > 1: the ranks end together)
                 fa, fb, _, sk, msgs = prepared
                 try:
                     extra["bgv_basic_ops"] = bgv_basic_ops(hx, hc, cc, fa, fb, sk, msgs, sync)
@@ -788,10 +788,9 @@ def main():
                                               4 * B * (l + 1 - 1), n)
                     md["traffic"], md["traffic_source"] = t, src
                     roof["other_launch_sets"] = {"fused_bringToSet": md}
-                if world == 1:
-                    sync()
-                    extra["cpp_host_mult_per_s"] = cpp_host_rate(B, 40)
-                    extra["levels"] = level_lines()
+                sync()
+                extra["cpp_host_mult_per_s"] = cpp_host_rate(B, 40)
+                extra["levels"] = level_lines()
             if args.cpu_sample > 0 and world == 1:
                 cpu = cpu_baseline_fresh(cc, max(1, args.cpu_sample // 2))
                 cpu["all_cores"] = cpu_baseline_all_cores(args.bits, max(1, args.cpu_sample // 4))
