@@ -130,6 +130,13 @@ def test_cpp_facade_header_compiles_and_links():
         r = subprocess.run([out3, "128", "257", "150", "0"], capture_output=True, text=True)
         assert r.returncode != 0 and "no HIP device" in r.stderr
     os.remove(out3)
+    # the wider Ctxt operations and Ctxt::writeTo / read link against the product library as well
+    for name in ("ctxt_ops_test", "io_test"):
+        out4 = os.path.join(ROOT, "tests", "cpp", name + ".bin")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-L" + libdir, "-lhelib_amd",
+                               "-Wl,-rpath," + libdir, "-o", out4])
+        os.remove(out4)
 
 
 @pytest.mark.parametrize("m,p,bits", [(32768, 65537, 950), (16384, 65537, 250), (128, 257, 150), (1705, 7, 200),
