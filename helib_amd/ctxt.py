@@ -217,6 +217,29 @@ class ModuliSizes:
         return self.sizes[best][1]
 
 
+MIN_SK_HWT = 120     # include/helib/Context.h:34
+
+
+def lweEstimateSecurity(n, log2AlphaInv, hwt):
+    """src/Context.cpp:34-72: security ~ slope * n / log2(1/alpha) + const, slope and constant interpolated
+    between the fitted Hamming weights 120, 150, ..., 450 (dense keys: 3.8, -20); never negative"""
+    if hwt < 0 or 0 < hwt < MIN_SK_HWT:
+        return 0.0
+    hw = [120, 150, 180, 210, 240, 270, 300, 330, 360, 390, 420, 450]
+    sl = [2.4, 2.67, 2.83, 3.0, 3.1, 3.3, 3.3, 3.35, 3.4, 3.45, 3.5, 3.55]
+    cn = [19, 13, 10, 6, 3, 1, -3, -4, -5, -7, -10, -12]
+    if hwt == 0:
+        slope, const = 3.8, -20.0
+    else:
+        i = (hwt - 120) // 30
+        if i < len(hw) - 1:
+            a = (hwt - hw[i]) / (hw[i + 1] - hw[i])
+            slope, const = sl[i] + a * (sl[i + 1] - sl[i]), cn[i] + a * (cn[i + 1] - cn[i])
+        else:
+            slope, const = sl[-1], float(cn[-1])
+    return max(0.0, slope * n / log2AlphaInv + const)
+
+
 class ChainContext:
     """ContextBuilder<BGV>().m(m).p(p).r(r).bits(bits).c(c) -> buildModChain; with ckks=True
     ContextBuilder<CKKS>().m(m).precision(r).bits(bits).c(c): p = -1, plaintext space 1, r = the
@@ -232,6 +255,10 @@ class ChainContext:
         self.phim = phi(m)
         self.pow2 = (m & (m - 1)) == 0
         self.stdev, self.scale, self.hwt = stdev, scale, skHwt
+        if bits <= 0:      # Context::buildModChain (src/Context.cpp:1044-1046): InvalidArgument
+            raise ValueError("Cannot initialise modulus chain with nBits < 1")
+        if skHwt < 0:
+            raise ValueError("invalid skHwt parameter")
         self.primes = []
         self.smallPrimes, self.ctxtPrimes, self.specialPrimes = [], [], []
         pSize = self._ctxtPrimeSize(bits)
@@ -239,6 +266,18 @@ class ChainContext:
         self._addCtxtPrimes(bits, pSize)
         self._addSpecialPrimes(c, bitsInSpecialPrimes)
         self.modSizes = ModuliSizes(self)
+
+    # ---- size and security of the chain (include/helib/Context.h:857-889, src/Context.cpp:34-72) ----
+    def bitSizeOfQ(self):
+        """ceil(log2 of the product of the ctxt and special primes)"""
+        return int(math.ceil(self.logOfProduct(list(self.ctxtPrimes) + list(self.specialPrimes)) / LN2))
+
+    def securityLevel(self):
+        """Context::securityLevel: lweEstimateSecurity(phi(m), log2(Q / stdev'), hwt) -- the reference's
+        affine fits to the LWE estimator, by Hamming weight of the secret key (0 = dense)."""
+        s = self.stdev if self.pow2 else self.stdev * math.sqrt(self.m)
+        log2AlphaInv = (self.logOfProduct(list(self.ctxtPrimes) + list(self.specialPrimes)) - math.log(s)) / LN2
+        return lweEstimateSecurity(self.phim, log2AlphaInv, self.hwt)
 
     # ---- chain construction (src/Context.cpp:728-1035) ----
     @staticmethod

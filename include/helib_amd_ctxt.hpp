@@ -246,6 +246,10 @@ public:
                bool ckks_ = false)
       : m(m_), p(ckks_ ? -1 : p_), r(r_), hwt(skHwt), ckks(ckks_), stdev(stdev_), scale(scale_)
   {
+    if (bits <= 0)   // Context::buildModChain (src/Context.cpp:1044-1046)
+      throw InvalidArgument("Cannot initialise modulus chain with nBits < 1");
+    if (skHwt < 0)
+      throw InvalidArgument("invalid skHwt parameter");
     ptxtSpace = 1;
     for (long i = 0; i < r && !ckks; i++)
       ptxtSpace *= p;
@@ -265,6 +269,45 @@ public:
     for (size_t i = 0; i < primes.size(); i++)
       ctx->addPrime(primes[i], roots ? (*roots)[i] : 0);
     return ctx;
+  }
+
+  // ---- size and security of the chain (include/helib/Context.h:857-889, src/Context.cpp:34-72) ----
+  long bitSizeOfQ() const
+  {
+    return (long)std::ceil((logOfProduct(ctxtPrimes) + logOfProduct(specialPrimes)) / std::log(2.0));
+  }
+  // lweEstimateSecurity: the reference's affine fits to the LWE estimator, slope and constant interpolated
+  // between the fitted Hamming weights 120, 150, ..., 450 (dense keys: 3.8, -20); never negative
+  static double lweEstimateSecurity(long n, double log2AlphaInv, long hwt)
+  {
+    constexpr long MIN_SK_HWT = 120;
+    if (hwt < 0 || (hwt > 0 && hwt < MIN_SK_HWT))
+      return 0.0;
+    static const double hw[] = {120, 150, 180, 210, 240, 270, 300, 330, 360, 390, 420, 450};
+    static const double sl[] = {2.4, 2.67, 2.83, 3.0, 3.1, 3.3, 3.3, 3.35, 3.4, 3.45, 3.5, 3.55};
+    static const double cn[] = {19, 13, 10, 6, 3, 1, -3, -4, -5, -7, -10, -12};
+    const size_t nw = sizeof(hw) / sizeof(hw[0]);
+    double slope, cst;
+    if (hwt == 0) {
+      slope = 3.8, cst = -20;
+    } else {
+      const size_t i = (size_t)((hwt - 120) / 30);
+      if (i < nw - 1) {
+        const double a = ((double)hwt - hw[i]) / (hw[i + 1] - hw[i]);
+        slope = sl[i] + a * (sl[i + 1] - sl[i]);
+        cst = cn[i] + a * (cn[i + 1] - cn[i]);
+      } else {
+        slope = sl[nw - 1], cst = cn[nw - 1];
+      }
+    }
+    const double ret = slope * (double)n / log2AlphaInv + cst;
+    return ret < 0.0 ? 0.0 : ret;
+  }
+  double securityLevel() const
+  {
+    const double s = pow2 ? stdev : stdev * std::sqrt((double)m);
+    const double log2AlphaInv = (logOfProduct(ctxtPrimes) + logOfProduct(specialPrimes) - std::log(s)) / std::log(2.0);
+    return lweEstimateSecurity(phim, log2AlphaInv, hwt);
   }
 
   double logOfPrime(int i) const { return std::log((double)primes[(size_t)i]); }

@@ -39,6 +39,7 @@ int main(int argc, char** argv)
     printf("]");
   }
   printf("], \"nsizes\": %zu, \"fresh_ln\": %.17g, ", c.modSizes.count(), std::log(c.freshNoiseBound()));
+  printf("\"bitSizeOfQ\": %ld, \"securityLevel\": %.17g, ", c.bitSizeOfQ(), c.securityLevel());
   // two fresh ciphertexts (parts "1" and "s"): Ctxt::computeIntervalForMul by hand -- no device here
   PrimeSet fresh = toSet(c.ctxtPrimes);
   double lnNoise = std::log(c.freshNoiseBound());

@@ -177,3 +177,51 @@ def test_smartAutomorph_decrypts_to_the_rotated_plaintext(m, p, bits, k):
     ca.multiplyBy(cb)
     from tests import bgv_ref as B
     assert decrypt(ctx, octx, s, ca, rows) == [int(v) for v in B.polymul_mod_phi(rot, mb, m, p)]
+
+
+# ---- the reference's own Context tests (tests/TestContext.cpp) on the chain builder of this host side ----
+def test_buildModChain_throws_when_bits_is_zero():
+    """TestContextBGV.buildModChainThrowsWhenBitsIsZero (tests/TestContext.cpp:199-203, m=17 p=2 r=1)"""
+    with pytest.raises(ValueError):            # helib::InvalidArgument
+        hc.ChainContext(17, 2, 1, bits=0, c=2)
+
+
+def test_calculate_bit_size_of_Q():
+    """TestContextBGV.calculateBitSizeOfQ (:205-225): with bits = 1016, c = 2 the ctxt primes come within 4 % of
+    the bits asked for, and bitSizeOfQ is the ceiling of log2 of the product of ALL ctxt and special primes"""
+    bits = 1016
+    c = hc.ChainContext(17, 2, 1, bits=bits, c=2)
+    full = list(c.ctxtPrimes) + list(c.specialPrimes)
+    assert abs(math.ceil(c.logOfProduct(c.ctxtPrimes) / math.log(2.0)) - bits) <= 0.04 * bits
+    q = 1
+    for i in full:
+        q *= c.primes[i]
+    assert c.bitSizeOfQ() == q.bit_length()     # (exact integer arithmetic; Q is not a power of two)
+
+
+def test_context_builder_digit_clipping_and_defaults():
+    """TestContextBGV.contextBuilderClipsDigitsSizeWithSmallBits / DoesNotClipDigitsSize /
+    WithDefaultArguments (:249-306): ContextBuilder<BGV>() defaults m=3, p=2, r=1, bits=300, c=3"""
+    assert len(hc.ChainContext(3, 2, 1, bits=100, c=4).digits) < 4      # c clipped: too few ctxt primes
+    assert len(hc.ChainContext(3, 2, 1, bits=500, c=5).digits) == 5
+    d = hc.ChainContext(3, 2, 1)
+    assert len(d.digits) == 3 and len(d.ctxtPrimes) > 0 and len(d.primes) > 0
+
+
+def test_security_level_formula():
+    """Context::securityLevel = lweEstimateSecurity(phi(m), log2(Q/sigma'), hwt) (include/helib/Context.h:875-889,
+    src/Context.cpp:34-72): hand-evaluated points of the fit, its lower bound of zero, sparse-key interpolation"""
+    assert hc.lweEstimateSecurity(16384, 1000.0, 0) == pytest.approx(3.8 * 16.384 - 20)
+    assert hc.lweEstimateSecurity(16384, 1000.0, 120) == pytest.approx(2.4 * 16.384 + 19)
+    assert hc.lweEstimateSecurity(16384, 1000.0, 135) == pytest.approx((2.4 + 0.5 * 0.27) * 16.384 + 16.0)
+    assert hc.lweEstimateSecurity(16384, 1000.0, 1000) == pytest.approx(3.55 * 16.384 - 12)
+    assert hc.lweEstimateSecurity(16, 1000.0, 0) == 0.0                 # never negative
+    assert hc.lweEstimateSecurity(16384, 1000.0, 50) == 0.0             # below MIN_SK_HWT
+    c = hc.ChainContext(32768, 65537, 1, bits=950, c=3)
+    full = list(c.ctxtPrimes) + list(c.specialPrimes)
+    want = 3.8 * 16384 / ((c.logOfProduct(full) - math.log(3.2)) / math.log(2.0)) - 20
+    assert c.securityLevel() == pytest.approx(want) and 20 < want < 40
+    g = hc.ChainContext(1705, 2, 1, bits=200, c=2)                      # general m: sigma' = sigma * sqrt(m)
+    full = list(g.ctxtPrimes) + list(g.specialPrimes)
+    want = 3.8 * g.phim / ((g.logOfProduct(full) - math.log(3.2 * math.sqrt(1705))) / math.log(2.0)) - 20
+    assert g.securityLevel() == pytest.approx(max(0.0, want))

@@ -161,6 +161,7 @@ def test_cpp_host_chain_and_prime_set_decision_match_the_python_mirror(m, p, bit
     assert got["small"] == c.smallPrimes and got["ctxt"] == c.ctxtPrimes and got["special"] == c.specialPrimes
     assert got["digits"] == c.digits and got["nsizes"] == len(c.modSizes.sizes)
     assert abs(got["fresh_ln"] - math.log(c.freshNoiseBound())) < 1e-12
+    assert got["bitSizeOfQ"] == c.bitSizeOfQ() and abs(got["securityLevel"] - c.securityLevel()) < 1e-9
     a = hc.Ctxt(c, None)
     a.parts = {"1": None, "s": None}
     a.primeSet = frozenset(c.ctxtPrimes)
