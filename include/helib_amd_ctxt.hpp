@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <set>
 
@@ -1588,11 +1589,17 @@ inline double polyNormBnd(long m)
 }
 inline bool Ctxt::isCorrect() const
 {
-  static std::map<long, double> cache;   // (host-side constant of the ring; not thread-safe by design of the test hosts)
-  auto it = cache.find(context->m);
-  if (it == cache.end())
-    it = cache.emplace(context->m, polyNormBnd(context->m)).first;
-  return lnTotalNoiseBound() + std::log(it->second) <= std::log(0.48) + logOfPrimeSet();
+  static std::map<long, double> cache;   // the ring constant, computed once per m
+  static std::mutex guard;
+  double cm;
+  {
+    std::lock_guard<std::mutex> lock(guard);
+    auto it = cache.find(context->m);
+    if (it == cache.end())
+      it = cache.emplace(context->m, polyNormBnd(context->m)).first;
+    cm = it->second;
+  }
+  return lnTotalNoiseBound() + std::log(cm) <= std::log(0.48) + logOfPrimeSet();
 }
 
 // ---- products of many ciphertexts (src/Ctxt.cpp:2803-2904) ----
