@@ -1,0 +1,697 @@
+// helib_amd_json.hpp -- HElib 2.2.0's JSON serialisation of the objects of this path, for the C++ host
+// (the binary layouts are in helib_amd_wire.hpp; helib_amd/wire.py has both in python):
+//
+//   DoubleCRT::writeToJSON / readJSON    {"set": [...], "map": [[...], ...]}            src/DoubleCRT.cpp:1568-1633
+//   Ctxt / KeySwitch / Context / PubKey / SecKey inside toTypedJson                      src/io.h:161-167
+//       {"type", "HElibVersion": "2.2.0", "serializationVersion": "0.0.1", "content": {...}}
+//       src/Ctxt.cpp:2642-2712, src/keySwitching.cpp:243-290, src/Context.cpp:1180-1290, src/keys.cpp:976-1097, 1560-1640
+//   xdouble = {"mantissa", "exponent"}, ZZ = {"number": "<decimal>"}                     src/io.cpp:20-44
+//
+// The reference uses nlohmann::json; this header carries its own small value type (objects with sorted
+// keys, as nlohmann's default, compact output, integers and doubles kept apart, doubles printed to round
+// trip).  No device call: descriptions in, descriptions out (helib_amd_io.hpp bridges to live objects).
+#pragma once
+#include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "helib_amd_wire.hpp"
+
+namespace helib_amd {
+namespace wire {
+
+class Json {
+public:
+  enum Kind { Null, Bool, Int, Real, Str, Arr, Obj };
+  Kind kind = Null;
+  bool b = false;
+  int64_t i = 0;
+  double d = 0;
+  std::string s;
+  std::vector<Json> a;
+  std::map<std::string, Json> o;
+
+  Json() = default;
+  static Json boolean(bool v)
+  {
+    Json j;
+    j.kind = Bool, j.b = v;
+    return j;
+  }
+  static Json integer(int64_t v)
+  {
+    Json j;
+    j.kind = Int, j.i = v;
+    return j;
+  }
+  static Json real(double v)
+  {
+    Json j;
+    j.kind = Real, j.d = v;
+    return j;
+  }
+  static Json string(std::string v)
+  {
+    Json j;
+    j.kind = Str, j.s = std::move(v);
+    return j;
+  }
+  static Json array()
+  {
+    Json j;
+    j.kind = Arr;
+    return j;
+  }
+  static Json object()
+  {
+    Json j;
+    j.kind = Obj;
+    return j;
+  }
+  Json& operator[](const std::string& k)
+  {
+    kind = Obj;
+    return o[k];
+  }
+  const Json& at(const std::string& k) const
+  {
+    if (kind != Obj)
+      throw IOError("JSON: object expected at \"" + k + "\"");
+    auto it = o.find(k);
+    if (it == o.end())
+      throw IOError("JSON: key \"" + k + "\" not found");
+    return it->second;
+  }
+  int64_t asInt() const
+  {
+    if (kind == Int)
+      return i;
+    if (kind == Real && d == (double)(int64_t)d)
+      return (int64_t)d;
+    throw IOError("JSON: integer expected");
+  }
+  double asReal() const
+  {
+    if (kind == Real)
+      return d;
+    if (kind == Int)
+      return (double)i;
+    throw IOError("JSON: number expected");
+  }
+  bool asBool() const
+  {
+    if (kind == Bool)
+      return b;
+    if (kind == Int)
+      return i != 0;
+    throw IOError("JSON: boolean expected");
+  }
+  const std::string& asStr() const
+  {
+    if (kind != Str)
+      throw IOError("JSON: string expected");
+    return s;
+  }
+  const std::vector<Json>& asArr() const
+  {
+    if (kind != Arr)
+      throw IOError("JSON: array expected");
+    return a;
+  }
+
+  // compact text, keys in sorted order
+  void dump(std::string& out) const
+  {
+    char buf[40];
+    switch (kind) {
+      case Null: out += "null"; break;
+      case Bool: out += b ? "true" : "false"; break;
+      case Int:
+        snprintf(buf, sizeof buf, "%lld", (long long)i);
+        out += buf;
+        break;
+      case Real: {
+        int prec = 15;   // the shortest of 15..17 digits that reads back as the same double
+        for (; prec < 17; prec++) {
+          snprintf(buf, sizeof buf, "%.*g", prec, d);
+          if (strtod(buf, nullptr) == d)
+            break;
+        }
+        snprintf(buf, sizeof buf, "%.*g", prec, d);
+        out += buf;
+        if (!strpbrk(buf, ".eEn"))   // keep it a real for the reader ("n": nan / inf never occur here)
+          out += ".0";
+        break;
+      }
+      case Str:
+        out += '"';
+        for (char c : s) {
+          if (c == '"' || c == '\\') {
+            out += '\\';
+            out += c;
+          } else if ((unsigned char)c < 0x20) {
+            snprintf(buf, sizeof buf, "\\u%04x", c);
+            out += buf;
+          } else {
+            out += c;
+          }
+        }
+        out += '"';
+        break;
+      case Arr: {
+        out += '[';
+        bool first = true;
+        for (auto& v : a) {
+          if (!first)
+            out += ',';
+          first = false;
+          v.dump(out);
+        }
+        out += ']';
+        break;
+      }
+      case Obj: {
+        out += '{';
+        bool first = true;
+        for (auto& kv : o) {
+          if (!first)
+            out += ',';
+          first = false;
+          Json::string(kv.first).dump(out);
+          out += ':';
+          kv.second.dump(out);
+        }
+        out += '}';
+        break;
+      }
+    }
+  }
+  std::string dump() const
+  {
+    std::string out;
+    dump(out);
+    return out;
+  }
+
+  static Json parse(const std::string& text)
+  {
+    size_t pos = 0;
+    Json j = parseValue(text, pos, 0);
+    skip(text, pos);
+    if (pos != text.size())
+      throw IOError("JSON: trailing characters");
+    return j;
+  }
+
+private:
+  static void skip(const std::string& t, size_t& p)
+  {
+    while (p < t.size() && (t[p] == ' ' || t[p] == '\n' || t[p] == '\t' || t[p] == '\r'))
+      p++;
+  }
+  static Json parseValue(const std::string& t, size_t& p, int depth)
+  {
+    if (depth > 64)
+      throw IOError("JSON: nesting too deep");
+    skip(t, p);
+    if (p >= t.size())
+      throw IOError("JSON: unexpected end of text");
+    const char c = t[p];
+    if (c == '{') {
+      Json j = object();
+      p++;
+      skip(t, p);
+      if (p < t.size() && t[p] == '}') {
+        p++;
+        return j;
+      }
+      for (;;) {
+        skip(t, p);
+        Json k = parseString(t, p);
+        skip(t, p);
+        if (p >= t.size() || t[p] != ':')
+          throw IOError("JSON: ':' expected");
+        p++;
+        j.o[k.s] = parseValue(t, p, depth + 1);
+        skip(t, p);
+        if (p < t.size() && t[p] == ',') {
+          p++;
+          continue;
+        }
+        if (p < t.size() && t[p] == '}') {
+          p++;
+          return j;
+        }
+        throw IOError("JSON: ',' or '}' expected");
+      }
+    }
+    if (c == '[') {
+      Json j = array();
+      p++;
+      skip(t, p);
+      if (p < t.size() && t[p] == ']') {
+        p++;
+        return j;
+      }
+      for (;;) {
+        j.a.push_back(parseValue(t, p, depth + 1));
+        skip(t, p);
+        if (p < t.size() && t[p] == ',') {
+          p++;
+          continue;
+        }
+        if (p < t.size() && t[p] == ']') {
+          p++;
+          return j;
+        }
+        throw IOError("JSON: ',' or ']' expected");
+      }
+    }
+    if (c == '"')
+      return parseString(t, p);
+    if (t.compare(p, 4, "true") == 0) {
+      p += 4;
+      return boolean(true);
+    }
+    if (t.compare(p, 5, "false") == 0) {
+      p += 5;
+      return boolean(false);
+    }
+    if (t.compare(p, 4, "null") == 0) {
+      p += 4;
+      return Json();
+    }
+    // a number: integer unless it has a fraction or an exponent
+    size_t q = p;
+    bool isReal = false;
+    if (q < t.size() && (t[q] == '-' || t[q] == '+'))
+      q++;
+    while (q < t.size() && (isdigit((unsigned char)t[q]) || t[q] == '.' || t[q] == 'e' || t[q] == 'E' || t[q] == '-' ||
+                            t[q] == '+')) {
+      isReal |= t[q] == '.' || t[q] == 'e' || t[q] == 'E';
+      q++;
+    }
+    if (q == p)
+      throw IOError("JSON: value expected");
+    const std::string num = t.substr(p, q - p);
+    p = q;
+    char* end = nullptr;
+    if (!isReal) {
+      errno = 0;
+      long long v = strtoll(num.c_str(), &end, 10);
+      if (*end == 0 && errno == 0)
+        return integer((int64_t)v);
+    }
+    double v = strtod(num.c_str(), &end);
+    if (*end != 0)
+      throw IOError("JSON: malformed number");
+    return real(v);
+  }
+  static Json parseString(const std::string& t, size_t& p)
+  {
+    if (p >= t.size() || t[p] != '"')
+      throw IOError("JSON: string expected");
+    p++;
+    Json j;
+    j.kind = Str;
+    while (p < t.size() && t[p] != '"') {
+      if (t[p] == '\\') {
+        if (++p >= t.size())
+          break;
+        switch (t[p]) {
+          case 'n': j.s += '\n'; break;
+          case 't': j.s += '\t'; break;
+          case 'r': j.s += '\r'; break;
+          case 'b': j.s += '\b'; break;
+          case 'f': j.s += '\f'; break;
+          case 'u': {
+            if (p + 4 >= t.size())
+              throw IOError("JSON: bad escape");
+            unsigned v = (unsigned)strtoul(t.substr(p + 1, 4).c_str(), nullptr, 16);
+            if (v > 0x7f)
+              throw IOError("JSON: non-ASCII escapes do not occur in these objects");
+            j.s += (char)v;
+            p += 4;
+            break;
+          }
+          default: j.s += t[p];
+        }
+        p++;
+      } else {
+        j.s += t[p++];
+      }
+    }
+    if (p >= t.size())
+      throw IOError("JSON: unterminated string");
+    p++;
+    return j;
+  }
+};
+
+// ---------------------------------------------------------------- small pieces
+inline Json jsonOf(const XDouble& x)
+{
+  Json j = Json::object();
+  j["mantissa"] = Json::real(x.mantissa);
+  j["exponent"] = Json::integer(x.exponent);
+  return j;
+}
+inline XDouble xdFromJson(const Json& j) { return XDouble{j.at("mantissa").asReal(), j.at("exponent").asInt()}; }
+inline Json jsonOf(const std::vector<long>& v)
+{
+  Json j = Json::array();
+  for (long x : v)
+    j.a.push_back(Json::integer(x));
+  return j;
+}
+inline std::vector<long> longsFromJson(const Json& j)
+{
+  std::vector<long> v;
+  for (auto& x : j.asArr())
+    v.push_back((long)x.asInt());
+  return v;
+}
+inline std::vector<long> sortedLongs(std::vector<long> v)   // IndexSet::readJSON: a set
+{
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+  return v;
+}
+inline Json typed(const char* type, Json content)
+{
+  Json j = Json::object();
+  j["type"] = Json::string(type);
+  j["HElibVersion"] = Json::string("2.2.0");
+  j["serializationVersion"] = Json::string("0.0.1");
+  j["content"] = std::move(content);
+  return j;
+}
+inline const Json& untyped(const Json& j, const char* type)   // fromTypedJson's checks (src/io.h:169-196)
+{
+  if (j.at("serializationVersion").asStr() != "0.0.1")
+    throw IOError("Serialization version mismatch");
+  if (j.at("HElibVersion").asStr() != "2.2.0")
+    throw IOError("HElib version mismatch");
+  if (j.at("type").asStr() != type)
+    throw IOError("Type mismatch deserializing json object");
+  return j.at("content");
+}
+// ZZ <-> decimal: little-endian magnitude bytes (write_raw_ZZ's form, KeySwitchDesc::prgSeed)
+inline std::string decimalOf(std::vector<uint8_t> le)
+{
+  std::string out;
+  while (!le.empty() && le.back() == 0)
+    le.pop_back();
+  if (le.empty())
+    return "0";
+  while (!le.empty()) {
+    unsigned rem = 0;
+    for (size_t k = le.size(); k-- > 0;) {
+      unsigned cur = rem * 256 + le[k];
+      le[k] = (uint8_t)(cur / 10);
+      rem = cur % 10;
+    }
+    out += (char)('0' + rem);
+    while (!le.empty() && le.back() == 0)
+      le.pop_back();
+  }
+  std::reverse(out.begin(), out.end());
+  return out;
+}
+inline std::vector<uint8_t> bytesOfDecimal(const std::string& dec)
+{
+  std::vector<uint8_t> le;
+  for (char c : dec) {
+    if (c < '0' || c > '9')
+      throw IOError("JSON: a ZZ is a string of decimal digits");
+    unsigned carry = (unsigned)(c - '0');
+    for (auto& byte : le) {
+      unsigned cur = byte * 10u + carry;
+      byte = (uint8_t)cur;
+      carry = cur >> 8;
+    }
+    if (carry)
+      le.push_back((uint8_t)carry);
+  }
+  return le;
+}
+
+// ---------------------------------------------------------------- DoubleCRT
+inline Json jsonOf(const Rows& r)
+{
+  Json j = Json::object();
+  j["set"] = jsonOf(r.idx);
+  Json m = Json::array();
+  for (size_t k = 0; k < r.idx.size(); k++) {
+    Json row = Json::array();
+    row.a.reserve(r.n);
+    for (size_t c = 0; c < r.n; c++)
+      row.a.push_back(Json::integer((int64_t)r.data[k * r.n + c]));
+    m.a.push_back(std::move(row));
+  }
+  j["map"] = std::move(m);
+  return j;
+}
+inline Rows rowsFromJson(const Json& j)
+{
+  Rows r;
+  r.idx = sortedLongs(longsFromJson(j.at("set")));
+  const auto& m = j.at("map").asArr();
+  if (m.size() != r.idx.size())
+    throw IOError("one row of n words per prime index");
+  for (size_t k = 0; k < m.size(); k++) {
+    const auto& row = m[k].asArr();
+    if (k == 0)
+      r.n = row.size();
+    else if (row.size() != r.n)
+      throw IOError("rows of unequal length");
+    for (auto& v : row) {
+      const int64_t x = v.asInt();
+      if (x < 0)
+        throw IOError("this->map[i][j] invalid: must be between 0 and context.ithPrime(i)");
+      r.data.push_back((uint64_t)x);
+    }
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------- Ctxt
+inline Json handleJson(const long h[3])
+{
+  Json j = Json::object();
+  j["powerOfS"] = Json::integer(h[0]);
+  j["powerOfX"] = Json::integer(h[1]);
+  j["secretKeyID"] = Json::integer(h[2]);
+  return j;
+}
+inline void handleFromJson(const Json& j, long h[3])
+{
+  h[0] = (long)j.at("powerOfS").asInt();
+  h[1] = (long)j.at("powerOfX").asInt();
+  h[2] = (long)j.at("secretKeyID").asInt();
+}
+inline Json toJson(const CtxtDesc& c)
+{
+  Json k = Json::object();
+  k["ptxtSpace"] = Json::integer(c.ptxtSpace);
+  k["noiseBound"] = jsonOf(c.noiseBound);
+  k["primeSet"] = jsonOf(sortedLongs(c.primeSet));
+  k["intFactor"] = Json::integer(c.intFactor);
+  k["ptxtMag"] = jsonOf(c.ptxtMag);
+  k["ratFactor"] = jsonOf(c.ratFactor);
+  Json parts = Json::array();
+  for (auto& p : c.parts) {
+    Json e = Json::object();
+    e["DoubleCRT"] = jsonOf(p.rows);
+    e["skHandle"] = handleJson(p.handle);
+    parts.a.push_back(std::move(e));
+  }
+  k["parts"] = std::move(parts);
+  return typed("Ctxt", std::move(k));
+}
+inline CtxtDesc ctxtFromJson(const Json& j)
+{
+  const Json& k = untyped(j, "Ctxt");
+  CtxtDesc c;
+  c.ptxtSpace = (long)k.at("ptxtSpace").asInt();
+  c.intFactor = (long)k.at("intFactor").asInt();
+  c.noiseBound = xdFromJson(k.at("noiseBound"));
+  c.ptxtMag = xdFromJson(k.at("ptxtMag"));
+  c.ratFactor = xdFromJson(k.at("ratFactor"));
+  c.primeSet = sortedLongs(longsFromJson(k.at("primeSet")));
+  for (auto& e : k.at("parts").asArr()) {
+    Part p;
+    p.rows = rowsFromJson(e.at("DoubleCRT"));
+    if (p.rows.idx != c.primeSet)   // Ctxt::readJSON's sanity check (src/Ctxt.cpp:2697-2702)
+      throw IOError("Ciphertext part's index set does not match prime set");
+    handleFromJson(e.at("skHandle"), p.handle);
+    c.parts.push_back(std::move(p));
+  }
+  return c;
+}
+
+// ---------------------------------------------------------------- KeySwitch
+inline Json toJson(const KeySwitchDesc& w)
+{
+  Json k = Json::object();
+  k["fromKey"] = handleJson(w.fromKey);
+  k["toKeyID"] = Json::integer(w.toKeyID);
+  k["ptxtSpace"] = Json::integer(w.ptxtSpace);
+  Json b = Json::array();
+  for (auto& r : w.b)
+    b.a.push_back(jsonOf(r));
+  k["b"] = std::move(b);
+  Json seed = Json::object();
+  seed["number"] = Json::string(decimalOf(w.prgSeed));
+  k["prgSeed"] = std::move(seed);
+  k["noiseBound"] = jsonOf(w.noiseBound);
+  return typed("KeySwitch", std::move(k));
+}
+inline KeySwitchDesc keySwitchFromJson(const Json& j)
+{
+  const Json& k = untyped(j, "KeySwitch");
+  KeySwitchDesc w;
+  handleFromJson(k.at("fromKey"), w.fromKey);
+  w.toKeyID = (long)k.at("toKeyID").asInt();
+  w.ptxtSpace = (long)k.at("ptxtSpace").asInt();
+  for (auto& r : k.at("b").asArr())
+    w.b.push_back(rowsFromJson(r));
+  w.prgSeed = bytesOfDecimal(k.at("prgSeed").at("number").asStr());
+  w.noiseBound = xdFromJson(k.at("noiseBound"));
+  return w;
+}
+
+// ---------------------------------------------------------------- Context
+inline Json toJson(const ContextDesc& c)
+{
+  Json k = Json::object();
+  k["m"] = Json::integer(c.m);
+  k["p"] = Json::integer(c.p);
+  k["r"] = Json::integer(c.r);
+  k["gens"] = jsonOf(c.gens);
+  k["ords"] = jsonOf(c.ords);
+  k["stdev"] = jsonOf(c.stdev);
+  k["scale"] = Json::real(c.scale);
+  k["smallPrimes"] = jsonOf(sortedLongs(c.smallPrimes));
+  k["specialPrimes"] = jsonOf(sortedLongs(c.specialPrimes));
+  k["qs"] = jsonOf(c.qs);
+  Json dg = Json::array();
+  for (auto& d : c.digits)
+    dg.a.push_back(jsonOf(sortedLongs(d)));
+  k["digits"] = std::move(dg);
+  k["hwt_param"] = Json::integer(c.hwt_param);
+  k["e_param"] = Json::integer(c.e_param);
+  k["ePrime_param"] = Json::integer(c.ePrime_param);
+  k["mvec"] = jsonOf(c.mvec);
+  k["build_cache"] = Json::boolean(c.build_cache != 0);
+  k["alsoThick"] = Json::boolean(c.alsoThick != 0);
+  return typed("Context", std::move(k));
+}
+inline ContextDesc contextFromJson(const Json& j)
+{
+  const Json& k = untyped(j, "Context");
+  ContextDesc c;
+  c.m = (long)k.at("m").asInt();
+  c.p = (long)k.at("p").asInt();
+  c.r = (long)k.at("r").asInt();
+  c.gens = longsFromJson(k.at("gens"));
+  c.ords = longsFromJson(k.at("ords"));
+  c.stdev = xdFromJson(k.at("stdev"));
+  c.scale = k.at("scale").asReal();
+  c.smallPrimes = sortedLongs(longsFromJson(k.at("smallPrimes")));
+  c.specialPrimes = sortedLongs(longsFromJson(k.at("specialPrimes")));
+  c.qs = longsFromJson(k.at("qs"));
+  for (auto& d : k.at("digits").asArr())
+    c.digits.push_back(sortedLongs(longsFromJson(d)));
+  c.hwt_param = (long)k.at("hwt_param").asInt();
+  c.e_param = (long)k.at("e_param").asInt();
+  c.ePrime_param = (long)k.at("ePrime_param").asInt();
+  c.mvec = longsFromJson(k.at("mvec"));
+  c.build_cache = k.at("build_cache").asBool() ? 1 : 0;
+  c.alsoThick = k.at("alsoThick").asBool() ? 1 : 0;
+  return c;
+}
+
+// ---------------------------------------------------------------- PubKey / SecKey
+inline Json toJson(const PubKeyDesc& p)
+{
+  Json k = Json::object();
+  k["context"] = toJson(p.context);
+  k["pubEncrKey"] = toJson(p.pubEncrKey);
+  Json sb = Json::array();
+  for (double v : p.skBounds)
+    sb.a.push_back(Json::real(v));
+  k["skBounds"] = std::move(sb);
+  Json ks = Json::array();
+  for (auto& w : p.keySwitching)
+    ks.a.push_back(toJson(w));
+  k["keySwitching"] = std::move(ks);
+  Json km = Json::array();
+  for (auto& v : p.keySwitchMap)
+    km.a.push_back(jsonOf(v));
+  k["keySwitchMap"] = std::move(km);
+  k["KS_strategy"] = jsonOf(p.KS_strategy);
+  k["recryptKeyID"] = Json::integer(p.recryptKeyID);
+  k["recryptEkey"] = p.recryptKeyID >= 0 ? toJson(p.recryptEkey) : Json::string("nullptr");
+  return typed("PubKey", std::move(k));
+}
+inline void pubKeyFromJsonInto(const Json& j, PubKeyDesc& p)
+{
+  const Json& k = untyped(j, "PubKey");
+  p.context = contextFromJson(k.at("context"));
+  p.pubEncrKey = ctxtFromJson(k.at("pubEncrKey"));
+  for (auto& v : k.at("skBounds").asArr())
+    p.skBounds.push_back(v.asReal());
+  for (auto& w : k.at("keySwitching").asArr())
+    p.keySwitching.push_back(keySwitchFromJson(w));
+  for (auto& v : k.at("keySwitchMap").asArr())
+    p.keySwitchMap.push_back(longsFromJson(v));
+  p.KS_strategy = longsFromJson(k.at("KS_strategy"));
+  p.recryptKeyID = (long)k.at("recryptKeyID").asInt();
+  if (p.recryptKeyID >= 0) {
+    p.recryptEkey = ctxtFromJson(k.at("recryptEkey"));
+  } else {   // left as constructed by Ctxt(pubKey): empty, over the ctxt primes
+    p.recryptEkey = CtxtDesc();
+    p.recryptEkey.ptxtSpace = p.pubEncrKey.ptxtSpace;
+    p.recryptEkey.primeSet = p.pubEncrKey.primeSet;
+  }
+}
+inline PubKeyDesc pubKeyFromJson(const Json& j)
+{
+  PubKeyDesc p;
+  pubKeyFromJsonInto(j, p);
+  return p;
+}
+inline Json toJson(const SecKeyDesc& s, bool sk_only = false)
+{
+  Json k = Json::object();
+  if (sk_only)
+    k["context"] = toJson(s.context);
+  else
+    k["PubKey"] = toJson(static_cast<const PubKeyDesc&>(s));
+  Json sk = Json::array();
+  for (auto& r : s.sKeys)
+    sk.a.push_back(jsonOf(r));
+  k["sKeys"] = std::move(sk);
+  return typed("SecKey", std::move(k));
+}
+inline SecKeyDesc secKeyFromJson(const Json& j, bool sk_only = false)
+{
+  const Json& k = untyped(j, "SecKey");
+  SecKeyDesc s;
+  if (sk_only)
+    s.context = contextFromJson(k.at("context"));
+  else
+    pubKeyFromJsonInto(k.at("PubKey"), s);
+  for (auto& r : k.at("sKeys").asArr())
+    s.sKeys.push_back(rowsFromJson(r));
+  return s;
+}
+
+}  // namespace wire
+}  // namespace helib_amd

@@ -457,3 +457,82 @@ def test_cpp_and_python_wire_agree_on_random_objects(wire_exe):
         assert got["ratFactor"] == list(desc["ratFactor"]) and got["poly_round_trip"]
         back, off = wire.read_ctxt(blob)
         assert off == len(blob) and wire.write_ctxt(back) == blob
+
+
+# ---------------------------------------------------------------------------------------------
+# the JSON forms from C++ (include/helib_amd_json.hpp)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def json_exe(tmp_path_factory):
+    import subprocess
+    root = os.path.dirname(HERE)
+    d = tmp_path_factory.mktemp("json")
+    exe = str(d / "json_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "json_test.cpp"), "-o", exe])
+
+    def run(*args, data=None):
+        tmp = str(d / "in.dat")
+        if data is not None:
+            with open(tmp, "wb") as f:
+                f.write(data if isinstance(data, bytes) else data.encode())
+        argv = [exe] + [tmp if a == "@" else str(d / a) if a.startswith("out") else a for a in args]
+        r = subprocess.run(argv, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout[-400:] + r.stderr
+        return r.stdout, d
+    return run
+
+
+def test_cpp_json_forms_agree_with_the_python_side(json_exe):
+    """helib_amd_json.hpp: every object kind of the path written as JSON by helib_amd/wire.py is parsed in C++
+    into the description the binary reader produces -- the C++ binary writer gives the python writer's bytes --
+    and written back as JSON equal to the original; the other way round, binary blobs read in C++ come out as
+    the JSON python writes for them.  xdouble fields, the 256-bit prgSeed as a decimal string, the typed
+    wrapper and the "nullptr" recryption key included."""
+    cc, octx, be, sk = _keys()
+    d = wire.from_seckey(sk)
+    rng = np.random.default_rng(5)
+    ca, cb = sk.Encrypt(rng.integers(0, 257, size=cc.phim)), sk.Encrypt(rng.integers(0, 257, size=cc.phim))
+    ca.multiplyBy(cb)
+    ct = wire.from_ctxt(ca)
+    ksw = dict(d["keySwitching"][0], prgSeed=(1 << 255) + 12345678901234567890)     # a reference-style seed
+    ksw.pop("explicit_a", None)
+    cases = [("ctxt", wire.ctxt_to_json(ct), wire.write_ctxt(ct)),
+             ("keyswitch", wire.keyswitch_to_json(ksw), wire.write_keyswitch(ksw)),
+             ("context", wire.context_to_json(d["context"]), wire.write_context(d["context"])),
+             ("pubkey", wire.pubkey_to_json(d, engine_only=True), wire.write_pubkey(d, engine_only=True)),
+             ("seckey", wire.seckey_to_json(d, engine_only=True), wire.write_seckey(d, engine_only=True)),
+             ("skonly", wire.seckey_to_json(d, sk_only=True), wire.write_seckey(d, sk_only=True))]
+    for kind, j, blob in cases:
+        out, tmpd = json_exe(kind, "j2b", "@", "out.bin", data=json.dumps(j))
+        assert json.loads(out) == j, kind
+        assert open(str(tmpd / "out.bin"), "rb").read() == blob, kind
+        out, _ = json_exe(kind, "b2j", "@", data=blob)
+        assert json.loads(out) == j, kind
+    # a CKKS ciphertext: ratFactor as (mantissa, exponent)
+    from helib_amd import ctxt as hc, keys as hk
+    from oracle import oracle as O
+    from oracle.backend import OracleBackend
+    ck = hc.ChainContext(128, -1, 20, bits=250, c=2, ckks=True)
+    oc = O.Ctx(128)
+    for q in ck.primes:
+        oc.add_prime(q)
+    sk2 = hk.SecKey(ck, OracleBackend(oc, ck), 3)
+    sk2.GenSecKey()
+    f = float(1 << 20)
+    pt = np.rint(rng.uniform(-1, 1, ck.phim) / ck.phim * f).astype(np.int64)
+    c1, c2 = sk2.CKKSencrypt(pt, 1.0, f), sk2.CKKSencrypt(pt, 1.0, f)
+    c1.multiplyBy(c2)
+    ct2 = wire.from_ctxt(c1)
+    j2 = wire.ctxt_to_json(ct2)
+    out, tmpd = json_exe("ctxt", "j2b", "@", "out.bin", data=json.dumps(j2))
+    assert json.loads(out) == j2 and j2["content"]["ratFactor"]["exponent"] >= 1
+    assert open(str(tmpd / "out.bin"), "rb").read() == wire.write_ctxt(ct2)
+    # the reference's own (legacy-layout) fixture objects: read by python, handed to C++ as 2.2.0 JSON
+    pk, _ = wire.read_pubkey(WHOLE, wire.read_context(WHOLE, 0, legacy=True)[1], legacy=True)
+    for w in pk["keySwitching"]:
+        jw = wire.keyswitch_to_json(w)
+        out, _ = json_exe("keyswitch", "j2b", "@", "out.bin", data=json.dumps(jw))
+        assert json.loads(out) == jw and jw["content"]["prgSeed"]["number"] == str(w["prgSeed"])
+    out, _ = json_exe("errors")
+    assert out.strip() == "raised 22 of 22"
