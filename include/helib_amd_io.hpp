@@ -5,11 +5,13 @@
 //   wire::describe(ct)                    Ctxt -> CtxtDesc (rows downloaded, batch element b)
 //   wire::restore(desc, cc, dev, keys)    CtxtDesc -> Ctxt (rows uploaded)
 //   writeTo(ct) / readCtxtFrom(bytes, ...) the 2.2.0 blob itself
+//   writeToJSON(ct) / readCtxtFromJSON(text, ...) the typed JSON object (helib_amd_json.hpp)
 //
 // Noise and CKKS factor cross the wire as NTL xdoubles (mantissa * 2^(114 e), 2^-57 <= |mantissa| < 2^57);
 // the host keeps their natural logarithms, so the conversion never overflows a double.
 #pragma once
 #include "helib_amd_ctxt.hpp"
+#include "helib_amd_json.hpp"
 #include "helib_amd_wire.hpp"
 
 namespace helib_amd {
@@ -133,6 +135,13 @@ inline Ctxt readCtxtFrom(const void* data, size_t size, const ChainContext& cc, 
   if (used)
     *used = rd.pos;
   return wire::restore(d, cc, dev, keys);
+}
+
+// Ctxt::writeToJSON / Ctxt::readJSON (src/Ctxt.cpp:2642-2712): the typed JSON object as text
+inline std::string writeToJSON(const Ctxt& ct, int b = 0) { return wire::toJson(wire::describe(ct, b)).dump(); }
+inline Ctxt readCtxtFromJSON(const std::string& text, const ChainContext& cc, const Context& dev, const KeySet& keys)
+{
+  return wire::restore(wire::ctxtFromJson(wire::Json::parse(text)), cc, dev, keys);
 }
 
 }  // namespace helib_amd

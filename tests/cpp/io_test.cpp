@@ -1,8 +1,9 @@
 // Ctxt::writeTo / Ctxt::read from C++ (include/helib_amd_io.hpp): ciphertexts of the C++ host cross the
 // reference's binary layout and come back as working ciphertexts -- same prime set, factors and noise
 // estimate, decrypting to the same plaintext, and usable in further multiplications; malformed blobs raise
-// IOError.  Every blob is also appended to <out> as [int64 length][bytes] for the python side, which parses it
-// with helib_amd.wire (pinned on the reference's own fixture) and writes it back byte for byte.
+// IOError.  Every blob, followed by the JSON text of the same ciphertext, is also appended to <out> as
+// [int64 length][bytes] for the python side, which parses the blob with helib_amd.wire (pinned on the reference's
+// own fixture), writes it back byte for byte and compares the JSON with its own.
 //   io_test <m> <p> <bits> <out>        p = -1: CKKS
 #include <cstdio>
 #include <cstdlib>
@@ -79,6 +80,9 @@ int main(int argc, char** argv)
       ca.multiplyBy(cb);
       std::string blob = writeTo(ca);
       dump(out, blob);
+      std::string js = writeToJSON(ca);
+      dump(out, js);
+      REQUIRE(writeTo(readCtxtFromJSON(js, cc, *dev, sk.keys)) == blob);
       Ctxt rb = readCtxtFrom(blob.data(), blob.size(), cc, *dev, sk.keys);
       REQUIRE(rb.primeSet == ca.primeSet && rb.ptxtMag == ca.ptxtMag);
       REQUIRE(std::fabs(rb.lnRatFactor - ca.lnRatFactor) < 1e-9 && std::fabs(rb.lnNoise - ca.lnNoise) < 1e-9);
@@ -148,6 +152,10 @@ int main(int argc, char** argv)
       }
       REQUIRE(sk.Decrypt(r) == *wants[i]);
       REQUIRE(writeTo(r) == blob);          // and the same bytes again
+      std::string js = writeToJSON(c);      // the JSON form: same object
+      dump(out, js);
+      Ctxt rj = readCtxtFromJSON(js, cc, *dev, sk.keys);
+      REQUIRE(writeTo(rj) == blob && writeToJSON(rj) == js && sk.Decrypt(rj) == *wants[i]);
       Ctxt next = r;                        // the restored object keeps working
       next.multiplyBy(cb);
       REQUIRE(sk.Decrypt(next) == negacyclic(*wants[i], b, p));

@@ -193,7 +193,8 @@ def test_cpp_ciphertexts_cross_the_reference_wire_format(mock, m, p, bits, tmp_p
     relinearised and 3-part ciphertexts written in the reference's 2.2.0 binary layout and read back as working
     ciphertexts (same bookkeeping, same decryption, usable in a further multiplication), IOError on malformed
     input.  Every blob the C++ side wrote is parsed here with helib_amd.wire -- whose layout is pinned on the
-    reference's own binary fixture -- and written back byte for byte."""
+    reference's own binary fixture -- and written back byte for byte; the JSON text the C++ side wrote for the same
+    ciphertext (Ctxt::writeToJSON) equals the python side's."""
     import struct
 
     from helib_amd import wire
@@ -201,14 +202,16 @@ def test_cpp_ciphertexts_cross_the_reference_wire_format(mock, m, p, bits, tmp_p
     out = str(tmp_path / "blobs.bin")
     r = subprocess.run([exe, str(m), str(p), str(bits), out], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "io_test OK" in r.stdout, r.stdout + r.stderr
+    import json
     buf = open(out, "rb").read()
-    off, count = 0, 0
+    off, items = 0, []
     while off < len(buf):
         (n,) = struct.unpack_from("<q", buf, off)
-        blob = buf[off + 8:off + 8 + n]
+        items.append(buf[off + 8:off + 8 + n])
         off += 8 + n
+    assert len(items) == 2 * (1 if p == -1 else 3)
+    for blob, text in zip(items[0::2], items[1::2]):      # (binary object, JSON text of the same ciphertext)
         d, used = wire.read_ctxt(blob)
         assert used == len(blob) and wire.write_ctxt(d) == blob
         assert all(idx == d["primeSet"] for idx, _, _ in d["parts"])
-        count += 1
-    assert count == (1 if p == -1 else 3)
+        assert json.loads(text) == wire.ctxt_to_json(d)
