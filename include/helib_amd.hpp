@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -82,6 +83,42 @@ public:
   void sync() const { check(hx_ctx_sync(h_.get())); }
   hx_ctx* handle() const { return h_.get(); }
 
+  // Measured-noise norms (hx_*_norms) either land in the caller's array before the call returns, or --
+  // deferNorms(true), hx_ctx_defer_norms -- when the context is next flushed, so that the host can keep
+  // enqueueing work while the norm kernels run.  A deferred array must outlive the flush whatever becomes
+  // of the ciphertext that asked for it: normBuffer() hands out arrays this object keeps until then.
+  void deferNorms(bool on) const
+  {
+    std::lock_guard<std::mutex> lock(*norm_mu_);
+    if (on != defer_) {
+      check(hx_ctx_defer_norms(h_.get(), on ? 1 : 0));   // switching off flushes
+      defer_ = on;
+      if (!on)
+        kept_.clear();
+    }
+  }
+  bool deferringNorms() const { return defer_; }
+  std::shared_ptr<std::vector<double>> normBuffer(size_t n) const
+  {
+    auto buf = std::make_shared<std::vector<double>>(n, 0.0);
+    std::lock_guard<std::mutex> lock(*norm_mu_);
+    if (defer_) {
+      if (kept_.size() >= 256) {   // nobody is reading: complete them, keep the list short
+        check(hx_norms_flush(h_.get()));
+        kept_.clear();
+      }
+      kept_.push_back(buf);
+    }
+    return buf;
+  }
+  void flushNorms() const
+  {
+    std::lock_guard<std::mutex> lock(*norm_mu_);
+    check(hx_norms_flush(h_.get()));
+    kept_.clear();
+  }
+  size_t pendingNormBuffers() const { return kept_.size(); }
+
   // HIP graphs (helib_amd.h: hx_ctx_graph_begin / _end): everything enqueued on this context between
   // graphBegin() and graphEnd() is recorded instead of run; Graph::launch() replays it with one launch
   // on the same buffers.  For the launch-bound case: one ciphertext at a time.
@@ -106,6 +143,9 @@ private:
   long phim_ = 0;
   std::shared_ptr<hx_ctx> h_;
   std::vector<uint64_t> primes_, roots_;
+  std::shared_ptr<std::mutex> norm_mu_ = std::make_shared<std::mutex>();
+  mutable bool defer_ = false;
+  mutable std::vector<std::shared_ptr<std::vector<double>>> kept_;
 };
 
 class DoubleCRT {
@@ -239,8 +279,9 @@ public:
   // result: one object with digits.size()*(rows+|special|) rows, block d = digit d
   // norms (optional): digits.size()*batch values embeddingLargestCoeff(digit d of element b) / P_d, the
   // pieces of the reference's return value (src/DoubleCRT.cpp:538-545), measured on the device
-  DoubleCRT breakIntoDigits(const std::vector<IndexSet>& digits, const IndexSet& special,
-                            std::vector<double>* norms = nullptr) const
+  // (an array of digits.size()*batch doubles; filled on return, or -- Context::deferNorms(true) -- at the next
+  // flush: take it from Context::normBuffer then)
+  DoubleCRT breakIntoDigits(const std::vector<IndexSet>& digits, const IndexSet& special, double* norms = nullptr) const
   {
     std::vector<int> idx, off(1, 0);
     for (auto& d : digits) {
@@ -249,10 +290,8 @@ public:
     }
     DoubleCRT out(*context_, getIndexSet(), batch_);
     if (norms) {
-      norms->assign(digits.size() * (size_t)batch_, 0.0);
-      check(hx_ctx_defer_norms(context_->handle(), 0));
       check(hx_break_into_digits_norms(h_.get(), idx.data(), off.data(), (int)digits.size(), special.data(),
-                                       (int)special.size(), out.h_.get(), norms->data()));
+                                       (int)special.size(), out.h_.get(), norms));
     } else {
       check(hx_break_into_digits(h_.get(), idx.data(), off.data(), (int)digits.size(), special.data(),
                                  (int)special.size(), out.h_.get()));

@@ -22,6 +22,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <numeric>
@@ -593,10 +594,73 @@ struct KeySet {
   }
 };
 
+// ln(noiseBound) whose measured contributions may still be on the device.  With Ctxt::deferNorms an operation
+// enqueues its kernels, registers how its norms will enter the estimate and returns; the value is completed
+// (Context::flushNorms waits only for the norm kernels already enqueued) when somebody reads it -- normally the
+// next prime-set decision, by which time more work is queued behind on the GPU.  Reads, assignments and += look
+// like a double's.  The registered updates see only the value and what they captured (shared norm arrays,
+// constants), never the ciphertext, so copies and moves of a Ctxt carry them along.
+class LazyLn {
+public:
+  LazyLn(double v = -INFINITY) : v_(v) {}
+  operator double() const
+  {
+    settle();
+    return v_;
+  }
+  LazyLn& operator=(double x)   // (a value computed from this one has settled it already; an unrelated one replaces it)
+  {
+    pending_.clear();
+    v_ = x;
+    return *this;
+  }
+  LazyLn& operator+=(double x)
+  {
+    if (pending_.empty())
+      v_ += x;
+    else
+      pending_.push_back([x](double& v) { v += x; });
+    return *this;
+  }
+  // f(v) now, or -- lazy -- when the value is next read
+  void apply(const Context* dev, bool lazy, std::function<void(double&)> f)
+  {
+    if (lazy) {
+      dev_ = dev;
+      pending_.push_back(std::move(f));
+    } else {
+      settle();
+      f(v_);
+    }
+  }
+  bool pending() const { return !pending_.empty(); }
+
+private:
+  void settle() const
+  {
+    if (pending_.empty())
+      return;
+    dev_->flushNorms();
+    for (auto& f : pending_)
+      f(v_);
+    pending_.clear();
+  }
+  mutable double v_;
+  mutable std::vector<std::function<void(double&)>> pending_;
+  const Context* dev_ = nullptr;
+};
+
 class Ctxt {
 public:
   static constexpr double safety = 0.6931471805599453;  // ln 2, src/Ctxt.cpp:39
   bool measure = false;  // measured added noise (hx_*_norms) instead of the bounds; power-of-two m
+  // measured norms read back lazily (LazyLn above) instead of synchronously inside each operation
+  static bool& deferNorms()
+  {
+    static bool on = false;
+    return on;
+  }
+  bool lazy() const { return measure && deferNorms(); }
 
   const ChainContext* context;
   const Context* dev;
@@ -604,7 +668,7 @@ public:
   std::map<SKHandle, DoubleCRT> parts;
   PrimeSet primeSet;
   long ptxtSpace, intFactor = 1;
-  double lnNoise = -INFINITY;
+  LazyLn lnNoise;
   double ptxtMag = 1.0, lnRatFactor = 0.0;  // CKKS: |plaintext| bound, ln of the scaling factor
 
   Ctxt(const ChainContext& c, const Context& d, const KeySet& k) : context(&c), dev(&d), keys(&k), ptxtSpace(c.ptxtSpace) {}
@@ -652,11 +716,14 @@ public:
     if (diff.empty())
       return;
     std::vector<Ctxt*> one{this};
-    const double addedBound = modSwitchAddedNoiseBound();
-    std::vector<double> added = modDownParts(one, inter, PrimeSet());
-    HELIB_AMD_STATS_UPDATE("mod-switch-added-noise", added[0] / addedBound);   // src/Ctxt.cpp:535-537
-    lnNoise = detail::logaddexp(lnNoise - context->logOfProduct(diff), detail::ln(added[0]));
-    lnRatFactor -= context->logOfProduct(diff);  // ratFactor /= f (:533, :553)
+    const double addedBound = modSwitchAddedNoiseBound(), logdiff = context->logOfProduct(diff);
+    std::function<double()> added = modDownParts(one, inter, PrimeSet())[0];
+    lnNoise.apply(dev, lazy(), [=](double& ln) {
+      const double a = added();
+      HELIB_AMD_STATS_UPDATE("mod-switch-added-noise", a / addedBound);   // src/Ctxt.cpp:535-537
+      ln = detail::logaddexp(ln - logdiff, detail::ln(a));
+    });
+    lnRatFactor -= logdiff;  // ratFactor /= f (:533, :553)
     primeSet = inter;
   }
   void bringToSet(const PrimeSet& s0)
@@ -953,31 +1020,27 @@ public:
     DoubleCRT o0(*dev, own, t0.batch(), DoubleCRT::Uninitialized{}), o1(*dev, own, t0.batch(), DoubleCRT::Uninitialized{});
     std::vector<int> idx, off;
     flatten(digits, idx, off);
-    std::vector<double> nrm((size_t)digits.size() * (size_t)t0.batch(), 0.0);
+    const int batch = t0.batch();
+    std::shared_ptr<std::vector<double>> nrm;
     if (measure) {
-      check(hx_ctx_defer_norms(dev->handle(), 0));
+      dev->deferNorms(lazy());
+      nrm = dev->normBuffer(digits.size() * (size_t)batch);
       check(hx_relinearize_norms(t0.handle(), its == parts.end() ? nullptr : its->second.handle(), t2.handle(),
                                  W->handle(), idx.data(), off.data(), (int)digits.size(), sp.data(), (int)sp.size(),
-                                 o0.handle(), o1.handle(), nrm.data()));
+                                 o0.handle(), o1.handle(), nrm->data()));
     } else {
       check(hx_relinearize(t0.handle(), its == parts.end() ? nullptr : its->second.handle(), t2.handle(),
                            W->handle(), idx.data(), off.data(), (int)digits.size(), sp.data(), (int)sp.size(),
                            o0.handle(), o1.handle()));
     }
-    double added = -INFINITY;
-    for (size_t k = 0; k < digits.size(); k++) {
-      double nb;
-      if (measure) {
-        double mx = 0;
-        for (int b = 0; b < t0.batch(); b++)
-          mx = std::max(mx, nrm[k * (size_t)t0.batch() + (size_t)b]);
-        nb = detail::ln(mx) + context->logOfProduct(digits[k]);
-      } else {
-        nb = std::log(context->noiseBoundForUniform(0.5, context->phim)) + context->logOfProduct(digits[k]);
-      }
-      added = detail::logaddexp(added, nb + keys->lnNoise);
-    }
-    lnNoise = detail::logaddexp(lnNoise + logProd, added);
+    // noise: scaled parts + key-switch added noise (src/Ctxt.cpp:746, 827-841)
+    std::vector<double> digitLn;
+    for (auto& d : digits)
+      digitLn.push_back(context->logOfProduct(d));
+    const double uniform = std::log(context->noiseBoundForUniform(0.5, context->phim)), keyLn = keys->lnNoise;
+    lnNoise.apply(dev, lazy(), [=](double& ln) {
+      ln = detail::logaddexp(ln + logProd, keySwitchAddedNoise(nrm.get(), digitLn, batch, uniform, keyLn));
+    });
     parts.clear();
     parts.emplace(SKHandle{0, 1}, std::move(o0));
     parts.emplace(SKHandle{1, 1}, std::move(o1));
@@ -1044,7 +1107,8 @@ public:
   // ln of totalNoiseBound(): for CKKS ptxtMag*ratFactor + noiseBound, else noiseBound
   double lnTotalNoiseBound() const
   {
-    return context->ckks ? detail::logaddexp(detail::ln(ptxtMag) + lnRatFactor, lnNoise) : lnNoise;
+    const double ln = lnNoise;
+    return context->ckks ? detail::logaddexp(detail::ln(ptxtMag) + lnRatFactor, ln) : ln;
   }
   // log2 of the modulus over the total noise bound
   double capacity() const { return (logOfPrimeSet() - std::max(lnTotalNoiseBound(), 0.0)) / std::log(2.0); }
@@ -1326,25 +1390,28 @@ private:
     DoubleCRT part1 = its == parts.end() ? DoubleCRT(*dev, part0.getIndexSet(), part0.batch()) : std::move(its->second);
     if (its != parts.end())
       part1.addPrimesAndScale(sp);
-    double added = -INFINITY;
+    const int batch = part0.batch();
+    std::vector<std::shared_ptr<std::vector<double>>> norms;   // per key-switched part (measured)
     for (auto& hw : mats) {
-      std::vector<double> nrm;
-      DoubleCRT dg = parts.at(hw.first).breakIntoDigits(digits, sp, measure ? &nrm : nullptr);
-      keySwitchDigits(*hw.second, dg, part0, part1);
-      for (size_t k = 0; k < digits.size(); k++) {
-        double nb;
-        if (measure) {
-          double mx = 0;
-          for (int b = 0; b < part0.batch(); b++)
-            mx = std::max(mx, nrm[k * (size_t)part0.batch() + (size_t)b]);
-          nb = detail::ln(mx);
-        } else {
-          nb = std::log(context->noiseBoundForUniform(0.5, context->phim));
-        }
-        added = detail::logaddexp(added, nb + context->logOfProduct(digits[k]) + keys->lnNoise);
+      std::shared_ptr<std::vector<double>> nrm;
+      if (measure) {
+        dev->deferNorms(lazy());
+        nrm = dev->normBuffer(digits.size() * (size_t)batch);
       }
+      DoubleCRT dg = parts.at(hw.first).breakIntoDigits(digits, sp, nrm ? nrm->data() : nullptr);
+      keySwitchDigits(*hw.second, dg, part0, part1);
+      norms.push_back(nrm);
     }
-    lnNoise = detail::logaddexp(lnNoise + logProd, added);
+    std::vector<double> digitLn;
+    for (auto& d : digits)
+      digitLn.push_back(context->logOfProduct(d));
+    const double uniform = std::log(context->noiseBoundForUniform(0.5, context->phim)), keyLn = keys->lnNoise;
+    lnNoise.apply(dev, lazy(), [=](double& ln) {
+      double added = -INFINITY;
+      for (auto& nrm : norms)
+        added = detail::logaddexp(added, keySwitchAddedNoise(nrm.get(), digitLn, batch, uniform, keyLn));
+      ln = detail::logaddexp(ln + logProd, added);
+    });
     parts.clear();
     parts.emplace(SKHandle{0, 1}, std::move(part0));
     parts.emplace(SKHandle{1, 1}, std::move(part1));
@@ -1399,9 +1466,29 @@ private:
       lnNoise += o.lnNoise;
     }
   }
+  // sum over the digits of (norm of the digit, measured or the uniform bound) * P_digit * the matrix' noise, as ln
+  static double keySwitchAddedNoise(const std::vector<double>* nrm, const std::vector<double>& digitLn, int batch,
+                                    double uniformLn, double keyLn)
+  {
+    double added = -INFINITY;
+    for (size_t k = 0; k < digitLn.size(); k++) {
+      double nb = uniformLn;
+      if (nrm) {   // norm_val = embeddingLargestCoeff(digit) (src/DoubleCRT.cpp:538-545), largest of the batch
+        double mx = 0;
+        for (int b = 0; b < batch; b++)
+          mx = std::max(mx, (*nrm)[k * (size_t)batch + (size_t)b]);
+        nb = detail::ln(mx);
+      }
+      added = detail::logaddexp(added, nb + digitLn[k] + keyLn);
+    }
+    return added;
+  }
   // polynomial work of modDownToSet (after a mod-up by `add`) on all parts of ciphertexts that share
-  // one prime set: one fused call; returns the added noise per ciphertext
-  static std::vector<double> modDownParts(std::vector<Ctxt*>& cts, const PrimeSet& keep, const PrimeSet& add)
+  // one prime set: one fused call; returns, per ciphertext, a function giving its added noise -- measured: the
+  // sum over parts of embeddingLargestCoeff(fdelta) * h^power (src/Ctxt.cpp:495-527), to be called once the norms
+  // have been read back (LazyLn does); otherwise the bound
+  static std::vector<std::function<double()>> modDownParts(std::vector<Ctxt*>& cts, const PrimeSet& keep,
+                                                           const PrimeSet& add)
   {
     Ctxt& a = *cts[0];
     std::vector<hx_poly*> polys;
@@ -1410,39 +1497,47 @@ private:
         polys.push_back(kv.second.handle());
     PrimeSet cur = a.primeSet | add;
     IndexSet drop = toVec(cur - keep), addv = toVec(add);
-    int batch = cts[0]->parts.begin()->second.batch();
-    std::vector<double> norms(polys.size() * (size_t)batch, 0.0);
+    const int batch = cts[0]->parts.begin()->second.batch();
     uint64_t pt = (uint64_t)a.ptxtSpace;
+    std::shared_ptr<std::vector<double>> norms;
     int rc;
     if (a.measure) {
-      check(hx_ctx_defer_norms(a.dev->handle(), 0));
+      a.dev->deferNorms(a.lazy());
+      norms = a.dev->normBuffer(polys.size() * (size_t)batch);
       rc = addv.empty() ? hx_scale_down_multi_norms(polys.data(), (int)polys.size(), drop.data(), (int)drop.size(), pt,
-                                                    norms.data(), nullptr)
+                                                    norms->data(), nullptr)
                         : hx_bring_to_set_multi_norms(polys.data(), (int)polys.size(), addv.data(), (int)addv.size(),
-                                                      drop.data(), (int)drop.size(), pt, norms.data());
+                                                      drop.data(), (int)drop.size(), pt, norms->data());
     } else {
       rc = addv.empty() ? hx_scale_down_multi(polys.data(), (int)polys.size(), drop.data(), (int)drop.size(), pt)
                         : hx_bring_to_set_multi(polys.data(), (int)polys.size(), addv.data(), (int)addv.size(),
                                                 drop.data(), (int)drop.size(), pt);
     }
     check(rc);
-    std::vector<double> out;
+    std::vector<std::function<double()>> out;
     size_t k = 0;
-    double h = a.context->skBound();
+    const double h = a.context->skBound();
     for (Ctxt* c : cts) {
       if (!a.measure) {
-        out.push_back(c->modSwitchAddedNoiseBound());
+        const double bound = c->modSwitchAddedNoiseBound();
+        out.push_back([bound] { return bound; });
         continue;
       }
-      double sum = 0;
-      for (auto& kv : c->parts) {
-        double mx = 0;
-        for (int b = 0; b < batch; b++)
-          mx = std::max(mx, norms[k * (size_t)batch + (size_t)b]);
-        sum += mx * std::pow(h, (double)kv.first.powerOfS);
-        k++;
-      }
-      out.push_back(sum);
+      std::vector<double> weight;   // h^powerOfS per part, in the order the parts were listed
+      for (auto& kv : c->parts)
+        weight.push_back(std::pow(h, (double)kv.first.powerOfS));
+      const size_t k0 = k;
+      k += weight.size();
+      out.push_back([norms, weight, k0, batch] {
+        double sum = 0;
+        for (size_t i = 0; i < weight.size(); i++) {
+          double mx = 0;
+          for (int b = 0; b < batch; b++)
+            mx = std::max(mx, (*norms)[(k0 + i) * (size_t)batch + (size_t)b]);
+          sum += mx * weight[i];
+        }
+        return sum;
+      });
     }
     return out;
   }
@@ -1456,7 +1551,7 @@ private:
     PrimeSet diff = up - inter;
     if (add.empty() && diff.empty())
       return;
-    std::vector<double> added;
+    std::vector<std::function<double()>> added;
     if (diff.empty()) {  // pure mod-up
       IndexSet d = toVec(add);
       for (Ctxt* c : cts)
@@ -1471,7 +1566,9 @@ private:
       c->lnRatFactor += c->context->logOfProduct(add) - c->context->logOfProduct(diff);
       c->primeSet = up;
       if (!diff.empty()) {
-        c->lnNoise = detail::logaddexp(c->lnNoise - c->context->logOfProduct(diff), detail::ln(added[i]));
+        const double logdiff = c->context->logOfProduct(diff);
+        std::function<double()> a = added[i];
+        c->lnNoise.apply(c->dev, c->lazy(), [=](double& ln) { ln = detail::logaddexp(ln - logdiff, detail::ln(a())); });
         c->primeSet = inter;
       }
     }
@@ -1481,8 +1578,8 @@ private:
 inline std::pair<double, double> Ctxt::computeIntervalForMul(const Ctxt& c1, const Ctxt& c2)
 {
   const double LN2 = std::log(2.0);
-  double cap1 = c1.logOfPrimeSet() - std::max(c1.lnNoise, 0.0);
-  double cap2 = c2.logOfPrimeSet() - std::max(c2.lnNoise, 0.0);
+  double cap1 = c1.logOfPrimeSet() - std::max((double)c1.lnNoise, 0.0);
+  double cap2 = c2.logOfPrimeSet() - std::max((double)c2.lnNoise, 0.0);
   double adn1 = std::log(c1.modSwitchAddedNoiseBound()), adn2 = std::log(c2.modSwitchAddedNoiseBound());
   if (c1.context->ckks) {  // the opposite end: keep n*q'/q above the added noise (:1637-1651)
     double lo = std::max(cap1 + adn1, cap2 + adn2) + safety;
@@ -1686,9 +1783,11 @@ public:
       if (!r.empty())
         digits_.push_back(r);
     }
-    std::vector<double> nrm;
     const DoubleCRT& ps = c.parts.at(SKHandle{1, 1});
-    polyDigits_ = std::make_unique<DoubleCRT>(ps.breakIntoDigits(digits_, sp, c.measure ? &nrm : nullptr));
+    std::vector<double> nrm(c.measure ? digits_.size() * (size_t)ps.batch() : 0);
+    if (c.measure)
+      c.dev->deferNorms(false);   // (this estimate is needed right away: the numbers before the call returns)
+    polyDigits_ = std::make_unique<DoubleCRT>(ps.breakIntoDigits(digits_, sp, c.measure ? nrm.data() : nullptr));
     // addedNoise = breakIntoDigits' return value * the matrices' noise bound (src/matmul.cpp:91-97);
     // noise = ctxt.noise * P + addedNoise (:99-112)
     double added = -INFINITY;

@@ -109,6 +109,7 @@ int main(int argc, char** argv)
 {
   if (argc < 5)
     return 2;
+  Ctxt::deferNorms() = getenv("HX_TEST_DEFER_NORMS") != nullptr;   // measured norms read back lazily (LazyLn)
   const long m = atol(argv[1]), p = atol(argv[2]), bits = atol(argv[3]);
   const bool measure = atol(argv[4]) != 0;
   if (p == -1)

@@ -54,6 +54,7 @@ int main(int argc, char** argv)
 {
   if (argc < 3)
     return 2;
+  Ctxt::deferNorms() = getenv("HX_TEST_DEFER_NORMS") != nullptr;   // measured norms read back lazily (LazyLn)
   FILE* f = fopen(argv[1], "rb");
   if (!f)
     return 2;

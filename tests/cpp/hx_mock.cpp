@@ -20,7 +20,24 @@ struct hx_ctx {
   uint64_t m = 0;
   long phim = 0;
   std::vector<uint64_t> q, root;
+  // deferred read-back of norms, as the engine does it: with hx_ctx_defer_norms(ctx, 1) a *_norms call leaves the
+  // caller's array untouched (here: poisoned with NaN) until hx_norms_flush writes the values -- a host side that
+  // reads too early, or frees the array before the flush, shows up in the CPU tests (the latter under ASan)
+  bool defer = false;
+  std::vector<std::pair<double*, std::vector<double>>> pending;
 };
+static void deliver(hx_ctx* c, double* out, std::vector<double> vals)
+{
+  if (!out)
+    return;
+  if (!c->defer) {
+    std::copy(vals.begin(), vals.end(), out);
+    return;
+  }
+  for (size_t i = 0; i < vals.size(); i++)
+    out[i] = std::nan("");
+  c->pending.emplace_back(out, std::move(vals));
+}
 struct hx_poly {
   hx_ctx* ctx;
   int batch;
@@ -389,19 +406,20 @@ static int scale_down_one(hx_poly* a, const int* drop, int ndrop, uint64_t ptxt,
     return fail(HX_ERR_PRIMESET, "scaleDownToSet: nothing would be left");
   hx_poly t{a->ctx, a->batch, {}, {}};
   t.reshape(keep);
-  std::vector<double> fd(a->N());
+  std::vector<double> fd(a->N()), nv(norms ? (size_t)a->batch : 0);
   for (int b = 0; b < a->batch; b++) {
     std::vector<uint64_t> rows = a->elem(b), out(keep.size() * a->N());
     ho_dcrt_scale_down(a->ctx->o, a->idx.data(), a->nrows(), rows.data(), drop, ndrop, ptxt ? ptxt : 1, out.data(),
                        (norms || fdelta) ? fd.data() : nullptr);
     t.put(b, out);
     if (norms)
-      norms[b] = ho_embedding_largest_coeff(a->ctx->m, fd.data(), a->ctx->phim);
+      nv[(size_t)b] = ho_embedding_largest_coeff(a->ctx->m, fd.data(), a->ctx->phim);
     if (fdelta)
       memcpy(fdelta + (size_t)b * a->N(), fd.data(), a->N() * 8);
   }
   a->idx = t.idx;
   a->d = t.d;
+  deliver(a->ctx, norms, std::move(nv));
   return HX_OK;
 }
 int hx_scale_down(hx_poly* a, const int* drop_idx, int ndrop, uint64_t ptxt_space)
@@ -454,7 +472,7 @@ int hx_break_into_digits_norms(const hx_poly* a, const int* dig_idx, const int* 
     oidx.insert(oidx.end(), allp.begin(), allp.end());
   out->batch = a->batch;
   out->reshape(oidx);
-  std::vector<double> nrm((size_t)ndig);
+  std::vector<double> nrm((size_t)ndig), nv(norms ? (size_t)ndig * (size_t)a->batch : 0);
   for (int b = 0; b < a->batch; b++) {
     std::vector<uint64_t> rows = a->elem(b), dg(oidx.size() * a->N());
     ho_dcrt_break_into_digits_norms(a->ctx->o, a->idx.data(), a->nrows(), rows.data(), dig_idx, dig_off, ndig,
@@ -462,8 +480,9 @@ int hx_break_into_digits_norms(const hx_poly* a, const int* dig_idx, const int* 
     out->put(b, dg);
     if (norms)
       for (int d = 0; d < ndig; d++)
-        norms[(size_t)d * a->batch + (size_t)b] = nrm[(size_t)d];
+        nv[(size_t)d * a->batch + (size_t)b] = nrm[(size_t)d];
   }
+  deliver(a->ctx, norms, std::move(nv));
   return HX_OK;
 }
 int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const int* dig_off, int ndig, const int* sp_idx, int nsp,
@@ -589,13 +608,23 @@ int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const 
   return hx_relinearize(&t0, &t1, &t2, W, dig_idx, dig_off, ndig, sp.data(), (int)sp.size(), out0, out1);
 }
 
-int hx_ctx_defer_norms(hx_ctx*, int) { return HX_OK; }
-int hx_norms_flush(hx_ctx*) { return HX_OK; }
+int hx_norms_flush(hx_ctx* c)
+{
+  for (auto& pv : c->pending)
+    std::copy(pv.second.begin(), pv.second.end(), pv.first);
+  c->pending.clear();
+  return HX_OK;
+}
+int hx_ctx_defer_norms(hx_ctx* c, int on)
+{
+  c->defer = on != 0;
+  return on ? HX_OK : hx_norms_flush(c);
+}
 int hx_embedding_norm(hx_ctx* ctx, const double* f_host, int rows, double* norms_out)
 {
   for (int r = 0; r < rows; r++)
     norms_out[r] = ho_embedding_largest_coeff(ctx->m, f_host + (size_t)r * (size_t)ctx->phim, ctx->phim);
-  return HX_OK;
+  return hx_norms_flush(ctx);   // host in, host out: always complete on return (and so is everything queued before)
 }
 
 int hx_ctx_timer_begin(hx_ctx*) { return HX_OK; }

@@ -58,6 +58,7 @@ int main(int argc, char** argv)
 {
   if (argc < 5)
     return 2;
+  Ctxt::deferNorms() = getenv("HX_TEST_DEFER_NORMS") != nullptr;   // measured norms read back lazily (LazyLn)
   const long m = atol(argv[1]), p = atol(argv[2]), bits = atol(argv[3]);
   std::ofstream out(argv[4], std::ios::binary);
   try {

@@ -75,6 +75,7 @@ int main(int argc, char** argv)
 {
   if (argc < 5)
     return 2;
+  Ctxt::deferNorms() = getenv("HX_TEST_DEFER_NORMS") != nullptr;   // measured norms read back lazily (LazyLn)
   long m = atol(argv[1]), p = atol(argv[2]), bits = atol(argv[3]);
   bool measure = atol(argv[4]) != 0;
   if (p == -1)
@@ -130,7 +131,7 @@ int main(int argc, char** argv)
     REQUIRE(sk.Decrypt(ca) == rot);
     ca.smartAutomorph(9);   // two steps of 3 along the map
     REQUIRE(sk.Decrypt(ca) == automorph(rot, 9, p));
-    REQUIRE(std::isfinite(ca.lnNoise) && ca.lnNoise > 0);
+    REQUIRE(std::isfinite((double)ca.lnNoise) && ca.lnNoise > 0);
     dev->sync();
   } catch (const std::exception& ex) {
     fprintf(stderr, "exception: %s\n", ex.what());

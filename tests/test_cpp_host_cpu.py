@@ -28,23 +28,36 @@ def mock(tmp_path_factory):
             subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + INC, src, "-L" + d, "-lhx_mock",
                                    "-Wl,-rpath," + d, "-o", exe])
         return exe
+    build.dir = d
     return build
 
 
+def _env(defer):
+    """HX_TEST_DEFER_NORMS: the programs switch Ctxt::deferNorms() on -- measured norms are read back lazily
+    (LazyLn); the mock then leaves a *_norms array poisoned until hx_norms_flush, as the engine leaves it unwritten"""
+    e = dict(os.environ)
+    e.pop("HX_TEST_DEFER_NORMS", None)
+    if defer:
+        e["HX_TEST_DEFER_NORMS"] = "1"
+    return e
+
+
 @pytest.mark.parametrize("m,p,bits,measure", [(128, 257, 150, 0), (128, 2, 300, 1), (1024, 65537, 250, 1),
-                                              (128, -1, 250, 0), (256, -1, 300, 1)])
+                                              (128, -1, 250, 0), (256, -1, 300, 1), (128, 2, 300, 2), (256, -1, 300, 2)])
 def test_cpp_keys_encrypt_multiply_rotate_decrypt_over_the_mock(mock, m, p, bits, measure):
     """tests/cpp/keys_test.cpp (key generation, Encrypt, multiplyBy, addCtxt, smartAutomorph in one and two
     steps, Decrypt; CKKS: products over two levels, sums across scaling factors) -- the program of the GPU
     suite, here with the polynomial work done by the oracle."""
     exe = mock(os.path.join(ROOT, "tests", "cpp", "keys_test.cpp"), "keys_test")
-    r = subprocess.run([exe, str(m), str(p), str(bits), str(measure)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(m), str(p), str(bits), str(min(measure, 1))], capture_output=True, text=True, timeout=300,
+                       env=_env(measure == 2))          # measure = 2: measured noise with the lazy read-back
     assert r.returncode == 0 and "keys_test OK" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("m,p,bits,measure", [(128, 257, 300, 0), (128, 257, 300, 1), (128, 3, 300, 0),
                                               (256, 65537, 400, 1), (128, -1, 400, 0), (256, -1, 500, 1),
-                                              (105, 2, 300, 0), (105, 257, 300, 1), (45, 2, 300, 1), (1705, 2, 300, 0)])
+                                              (105, 2, 300, 0), (105, 257, 300, 1), (45, 2, 300, 1), (1705, 2, 300, 0),
+                                              (128, 257, 300, 2), (256, -1, 500, 2), (105, 257, 300, 2)])
 def test_cpp_ctxt_operations_over_the_mock(mock, m, p, bits, measure):
     """tests/cpp/ctxt_ops_test.cpp: multiplyBy2 / cube / power through the 4-part ciphertext and
     keySwitchPart (src/Ctxt.cpp:1776-1828, 720-842), totalProduct / incrementalProduct / innerProduct
@@ -53,7 +66,8 @@ def test_cpp_ctxt_operations_over_the_mock(mock, m, p, bits, measure):
     CKKS forms.  General m (105, 45 = 9*5, 1705): keys and encryptions from the samplers that reduce modulo
     Phi_m, arithmetic checked modulo (Phi_m, p)."""
     exe = mock(os.path.join(ROOT, "tests", "cpp", "ctxt_ops_test.cpp"), "ctxt_ops_test")
-    r = subprocess.run([exe, str(m), str(p), str(bits), str(measure)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(m), str(p), str(bits), str(min(measure, 1))], capture_output=True, text=True, timeout=300,
+                       env=_env(measure == 2))          # measure = 2: measured noise with the lazy read-back
     assert r.returncode == 0 and "ctxt_ops_test OK" in r.stdout, r.stdout + r.stderr
 
 
@@ -104,7 +118,7 @@ def test_the_mock_is_test_infrastructure_only():
 
 
 @pytest.mark.parametrize("m,p,bits,k,measure", [(128, 257, 150, 3, 0), (128, 257, 150, 5, 1), (1024, 65537, 250, 3, 1),
-                                                (105, 2, 200, 2, 0)])
+                                                (105, 2, 200, 2, 0), (128, 257, 150, 5, 2), (1024, 65537, 250, 3, 2)])
 def test_cpp_ctxt_matches_the_python_mirror_over_the_oracle(mock, m, p, bits, k, measure, tmp_path, monkeypatch):
     """tests/cpp/ctxt_test.cpp (the program of the GPU suite's test_cpp_host_ctxt_matches_python_mirror) over the
     mock, against helib_amd.ctxt over the oracle backend on the same keys and ciphertexts: prime sets,
@@ -119,6 +133,7 @@ def test_cpp_ctxt_matches_the_python_mirror_over_the_oracle(mock, m, p, bits, k,
     from oracle.backend import OKeySwitch, OPoly, OracleOps
     from tests import test_ctxt_host as T
     exe = mock(os.path.join(ROOT, "tests", "cpp", "ctxt_test.cpp"), "ctxt_test")
+    defer, measure = measure == 2, min(measure, 1)      # (2: the C++ side reads its measured norms back lazily)
     monkeypatch.setattr(hc.Ctxt, "measure", bool(measure))
     cc = hc.ChainContext(m, p, 1, bits=bits, c=3)
     octx = O.Ctx(m)
@@ -137,7 +152,7 @@ def test_cpp_ctxt_matches_the_python_mirror_over_the_oracle(mock, m, p, bits, k,
         f.write(np.array(octx.roots, dtype="<u8").tobytes())
         for arr in (kb, ka, kbk, kak, ea[0], ea[1], eb[0], eb[1]):
             f.write(np.ascontiguousarray(arr, dtype="<u8").tobytes())
-    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300, env=_env(defer))
     assert r.returncode == 0, r.stdout + r.stderr
     ops = OracleOps(octx)
     W, Wk = OKeySwitch(allp, kb, ka), OKeySwitch(allp, kbk, kak)
@@ -215,3 +230,25 @@ def test_cpp_ciphertexts_cross_the_reference_wire_format(mock, m, p, bits, tmp_p
         assert used == len(blob) and wire.write_ctxt(d) == blob
         assert all(idx == d["primeSet"] for idx, _, _ in d["parts"])
         assert json.loads(text) == wire.ctxt_to_json(d)
+
+
+def test_cpp_lazy_norm_read_back_under_the_address_sanitizer(mock, tmp_path):
+    """Ctxt::deferNorms(): a *_norms array is written by the library at the NEXT flush, whatever has become of the
+    ciphertext that asked for it (a result dropped without its noise estimate being read).  The operations test,
+    built with -fsanitize=address against a sanitized mock whose deferral leaves the arrays unwritten until
+    hx_norms_flush, must run clean: arrays outlive the flush (Context::normBuffer), estimates are completed before
+    they are used (LazyLn)."""
+    d = str(tmp_path)
+    obj = os.path.join(d, "hx_oracle.o")
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=c11", "-c", os.path.join(ROOT, "oracle", "hx_oracle.c"), "-o", obj])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fPIC", "-shared", "-I" + INC,
+                           "-I" + os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "cpp", "hx_mock.cpp"), obj,
+                           "-lm", "-o", os.path.join(d, "libhx_mock_asan.so")])
+    exe = os.path.join(d, "ctxt_ops_asan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-I" + INC,
+                           os.path.join(ROOT, "tests", "cpp", "ctxt_ops_test.cpp"), "-L" + d, "-lhx_mock_asan",
+                           "-Wl,-rpath," + d, "-o", exe])
+    for args in (("128", "257", "300", "1"), ("128", "-1", "400", "1")):
+        r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600, env=_env(True))
+        assert r.returncode == 0 and "ctxt_ops_test OK" in r.stdout and "AddressSanitizer" not in r.stderr, \
+            r.stdout + r.stderr[-2000:]

@@ -3,7 +3,7 @@
 // ciphertext pairs per step, operand copies made before the timer starts (benchmarks/bgv_basic.cpp:158-164;
 // the engine's copies are copy-on-write, so nothing moves either way).  Synthetic uniform rows.  One JSON line.
 //   g++ -O2 -std=c++17 -Iinclude tools/bench_cpp.cpp -Lhelib_amd/lib -lhelib_amd -Wl,-rpath,$PWD/helib_amd/lib -o bench_cpp
-//   ./bench_cpp [batch=128] [steps=20] [warmup=3] [measure=0|1]
+//   ./bench_cpp [batch=128] [steps=20] [warmup=3] [measure=0|1|2]     2: measured noise, norms read back lazily
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -35,7 +35,9 @@ static std::vector<uint64_t> uniform(const ChainContext& cc, const IndexSet& idx
 int main(int argc, char** argv)
 {
   int B = argc > 1 ? atoi(argv[1]) : 128, steps = argc > 2 ? atoi(argv[2]) : 20, warm = argc > 3 ? atoi(argv[3]) : 3;
-  bool measure = argc > 4 && atoi(argv[4]) != 0;
+  const int mode = argc > 4 ? atoi(argv[4]) : 0;
+  const bool measure = mode != 0;
+  Ctxt::deferNorms() = mode == 2;   // (LazyLn: a dropped result's estimate is never waited for, as in the python mirror)
   try {
     ChainContext cc(32768, 65537, 1, 950, 3);
     auto dev = cc.makeDeviceContext(0);
@@ -81,7 +83,7 @@ int main(int argc, char** argv)
     printf("{\"metric\": \"ctxt_x_ctxt_mults_per_sec_incl_relinearize\", \"host\": \"C++ (helib_amd_ctxt.hpp)\", "
            "\"value\": %.1f, \"unit\": \"mult/s\", \"batch\": %d, \"steps\": %d, \"ms_per_step\": %.4f, "
            "\"noise\": \"%s\", \"workload\": \"BGV m=32768 p=65537 bits=950 L=%zu K=%zu D=%zu fresh multiplyBy\"}\n",
-           (double)B * steps / dt, B, steps, dt / steps * 1e3, measure ? "measured (synchronous read-back)" : "bounds",
+           (double)B * steps / dt, B, steps, dt / steps * 1e3, mode == 2 ? "measured (lazy read-back)" : measure ? "measured (synchronous read-back)" : "bounds",
            cc.ctxtPrimes.size(), cc.specialPrimes.size(), D);
   } catch (const std::exception& e) {
     fprintf(stderr, "exception: %s\n", e.what());
