@@ -91,7 +91,7 @@ public:
   {
     if (kind == Int)
       return i;
-    if (kind == Real && d == (double)(int64_t)d)
+    if (kind == Real && d >= -9223372036854775808.0 && d < 9223372036854775808.0 && d == (double)(int64_t)d)
       return (int64_t)d;
     throw IOError("JSON: integer expected");
   }
@@ -426,6 +426,8 @@ inline std::string decimalOf(std::vector<uint8_t> le)
 inline std::vector<uint8_t> bytesOfDecimal(const std::string& dec)
 {
   std::vector<uint8_t> le;
+  if (dec.size() > 4096)   // (the conversion is quadratic; the seeds of this path have 78 digits)
+    throw IOError("JSON: implausibly long ZZ");
   for (char c : dec) {
     if (c < '0' || c > '9')
       throw IOError("JSON: a ZZ is a string of decimal digits");

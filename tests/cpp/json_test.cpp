@@ -71,6 +71,9 @@ int main(int argc, char** argv)
       j["content"]["parts"].a[0]["DoubleCRT"]["map"].a[0].a[0] = Json::integer(-1);
       total++, n += raises([&] { ctxtFromJson(j); });
       total++, n += raises([&] { bytesOfDecimal("12x"); });
+      total++, n += raises([&] { bytesOfDecimal(std::string(5000, '9')); });
+      total++, n += raises([&] { Json::parse("1e300").asInt(); });
+      total++, n += raises([&] { Json::parse(std::string(100, '[')); });
       total++, n += (decimalOf(bytesOfDecimal("340282366920938463463374607431768211457")) ==
                      "340282366920938463463374607431768211457");
       total++, n += (decimalOf({}) == "0" && bytesOfDecimal("0").empty());

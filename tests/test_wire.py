@@ -535,4 +535,4 @@ def test_cpp_json_forms_agree_with_the_python_side(json_exe):
         out, _ = json_exe("keyswitch", "j2b", "@", "out.bin", data=json.dumps(jw))
         assert json.loads(out) == jw and jw["content"]["prgSeed"]["number"] == str(w["prgSeed"])
     out, _ = json_exe("errors")
-    assert out.strip() == "raised 22 of 22"
+    assert out.strip() == "raised 25 of 25"
