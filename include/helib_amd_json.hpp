@@ -409,6 +409,8 @@ inline std::string decimalOf(std::vector<uint8_t> le)
     le.pop_back();
   if (le.empty())
     return "0";
+  if (le.size() > 2048)   // (quadratic conversion; a prgSeed is 32 bytes)
+    throw IOError("JSON: implausibly long ZZ");
   while (!le.empty()) {
     unsigned rem = 0;
     for (size_t k = le.size(); k-- > 0;) {
