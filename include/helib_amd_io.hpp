@@ -57,7 +57,11 @@ inline double lnOf(const XDouble& x)
 {
   return x.mantissa > 0 ? std::log(x.mantissa) + (double)x.exponent * XD_BOUND_BITS * std::log(2.0) : -INFINITY;
 }
-inline double valueOf(const XDouble& x) { return std::ldexp(x.mantissa, (int)(x.exponent * XD_BOUND_BITS)); }
+inline double valueOf(const XDouble& x)   // (exponents beyond a double's range saturate to 0 / inf)
+{
+  const int64_t e = std::max<int64_t>(-16, std::min<int64_t>(16, x.exponent));
+  return std::ldexp(x.mantissa, (int)(e * XD_BOUND_BITS));
+}
 
 // parts in the reference's order: the part of 1 first, then s, then the rest (Ctxt::addPart appends and
 // the constant part is created first) -- the order of SKHandle's operator<
