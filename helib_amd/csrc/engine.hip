@@ -2507,14 +2507,37 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       hipLaunchKernelGGL((hx::embed_norm_quarter_kernel<SRCT, 0>), dim3((unsigned)rows), dim3(threads), lds,    \
                          c->stream, srcv, c->d_wtab, logn, c->d_norm2);                                         \
   } while (0)
+    // experiment, off by default: N = 2^14 as two 4096-point sub-transforms per
+    // element -- 64 KiB of LDS and 512 threads per workgroup, two elements resident per CU
+    static const bool split14 = getenv("HX_NORM_SPLIT14") != nullptr;
+    if (split14 && logn == 14) {
+      const size_t park_words = (size_t)rows * 4096;   // complex doubles: [row][1][H]
+      if (c->norm_park_cap < park_words) {
+        retire_or_free(c, c->d_norm_park);
+        c->d_norm_park = nullptr;
+        c->norm_park_cap = 0;
+        HIPCHK(hipMalloc((void**)&c->d_norm_park, park_words * sizeof(double2)));
+        c->norm_park_cap = park_words;
+      }
+    }
+#define HX_NORM_SPLIT(SRCT, srcv)                                                                            \
+  hipLaunchKernelGGL((hx::embed_norm_quarter_splitT_kernel<SRCT, 12, 512>), dim3((unsigned)rows), dim3(512), \
+                     16 * (size_t)4096, c->stream, srcv, c->d_wtab, logn, c->d_norm_park, c->d_norm2)
     if (c->xs_rows == rows && d_f == c->d_frac) {
       hx::NormSrcXS src{c->scratch[0], reinterpret_cast<const int64_t*>(c->scratch[1]), c->xs_inv_qd};
-      HX_NORM_LAUNCH(hx::NormSrcXS, src);
+      if (split14 && logn == 14)
+        HX_NORM_SPLIT(hx::NormSrcXS, src);
+      else
+        HX_NORM_LAUNCH(hx::NormSrcXS, src);
     } else {
       CHK(flush_xs(c));
       hx::NormSrcF64 src{d_f};
-      HX_NORM_LAUNCH(hx::NormSrcF64, src);
+      if (split14 && logn == 14)
+        HX_NORM_SPLIT(hx::NormSrcF64, src);
+      else
+        HX_NORM_LAUNCH(hx::NormSrcF64, src);
     }
+#undef HX_NORM_SPLIT
 #undef HX_NORM_LAUNCH
     c->xs_rows = 0;
   } else if (logn - 1 > hx::NORM_MAX_LOGH && !getenv("HX_NORM_PLAIN")) {

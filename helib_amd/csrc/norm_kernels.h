@@ -284,6 +284,65 @@ embed_norm_quarter_split_kernel(const double* __restrict__ f, const double2* __r
   block_max_to(mx, sm, tid, nth, out2 + row);
 }
 
+// Experiment (HX_NORM_SPLIT14, off by default): the split form above for any coefficient
+// source and a compile-time sub-transform size, so that N = 2^14 can run as S = 2 sub-transforms of 4096 points --
+// 64 KiB of LDS and CNTH = 512 threads per workgroup: two elements resident per CU instead of one.
+template <class SRC, int CLOGH, int CNTH>
+__global__ void __launch_bounds__(CNTH)
+embed_norm_quarter_splitT_kernel(SRC src, const double2* __restrict__ wtab, int logn, double2* __restrict__ park,
+                                 unsigned long long* __restrict__ out2)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int logh = CLOGH;
+  const unsigned N = 1u << logn, M = N >> 1, H = 1u << logh, S = M >> logh, half = S >> 1;
+  double* re = sm;
+  double* im = sm + H;
+  const unsigned row = blockIdx.x / half, s = blockIdx.x % half;
+  const unsigned tid = threadIdx.x, nth = CNTH;
+  double2* pk = park + ((size_t)row * half + s) * H;
+  const unsigned mmask = 2 * N - 1;
+  for (int pass = 0; pass < 2; pass++) {
+    const unsigned sub = pass == 0 ? S - 1 - s : s;
+    for (unsigned i = tid; i < H; i += nth) {
+      double ar = 0, ai = 0;
+      for (unsigned t = 0; t < S; t++) {
+        const unsigned idx = i + t * H;
+        const unsigned e = (2u * idx * (2u * sub + 1u)) & mmask;
+        const double2 w = wtab[e & (N - 1)];
+        const double2 v = src.pair(row, N, idx);
+        const double zr = v.x * w.x - v.y * w.y, zi = v.x * w.y + v.y * w.x;
+        ar += e >= N ? -zr : zr;
+        ai += e >= N ? -zi : zi;
+      }
+      re[i] = ar;
+      im[i] = ai;
+    }
+    __syncthreads();
+    dif_fft_lds<CLOGH, CNTH>(re, im, logh, N, wtab, tid, nth);
+    if (pass == 0) {
+      for (unsigned p = tid; p < H; p += nth)
+        pk[p] = make_double2(re[p], im[p]);
+      __syncthreads();
+    }
+  }
+  double mx = 0;
+  for (unsigned p = tid; p < H; p += nth) {
+    const unsigned j = s + S * (__brev(p) >> (32 - logh));
+    const double2 c = pk[H - 1 - p];
+    const double zr = re[p], zi = im[p], cr = c.x, ci = -c.y;
+    const double er = 0.5 * (zr + cr), ei = 0.5 * (zi + ci);
+    const double dr = zr - cr, di = zi - ci;
+    const double orr = 0.5 * di, oi = -0.5 * dr;
+    const double2 w = wtab[2 * j + 1];
+    const double tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
+    const double a = (er + tr) * (er + tr) + (ei + ti) * (ei + ti);
+    const double b = (er - tr) * (er - tr) + (ei - ti) * (ei - ti);
+    const double n2 = a > b ? a : b;
+    mx = n2 > mx ? n2 : mx;
+  }
+  block_max_to(mx, sm, tid, nth, out2 + row);
+}
+
 // =====================================================================
 // General m: Bluestein in complex double (the reference's PGFFT does the same for a non-power-of-two
 // size, src/PGFFT.cpp).  With omega = exp(2 pi i/m) and v_k = exp(pi i k^2/m),
