@@ -56,6 +56,7 @@ SYMBOLS = [
     "hx_intel_EltwiseMultModScalar",
     "hx_time_ntt", "hx_ctx_timer_begin", "hx_ctx_timer_end", "hx_randomize",
     "hx_ctx_graph_begin", "hx_ctx_graph_end", "hx_graph_launch", "hx_graph_destroy",
+    "hx_profile_begin", "hx_profile_end", "hx_ctx_arena_stats",
 ]
 
 
@@ -137,6 +138,8 @@ def lib():
             "hx_randomize": [vp, C.c_char_p, C.c_uint64],
             "hx_ctx_graph_begin": [vp], "hx_ctx_graph_end": [vp, vp], "hx_graph_launch": [vp],
             "hx_graph_destroy": [vp],
+            "hx_profile_begin": [], "hx_profile_end": [vp, C.c_size_t, vp],
+            "hx_ctx_arena_stats": [vp, vp],
         }
         for name, args in sig.items():
             f = getattr(L, name)
@@ -214,6 +217,13 @@ class Context:
         ms = C.c_float()
         _chk(lib().hx_ctx_timer_end(self.h, C.byref(ms)))
         return ms.value
+
+    def arenaStats(self):
+        """Device memory behind this context's DoubleCRT slabs (hx_ctx_arena_stats): bytes reserved from
+        hipMalloc, bytes in use, number of hipMalloc calls so far, blocks parked for live HIP graphs."""
+        v = (C.c_uint64 * 4)()
+        _chk(lib().hx_ctx_arena_stats(self.h, v))
+        return {"reserved": int(v[0]), "in_use": int(v[1]), "sys_calls": int(v[2]), "deferred": int(v[3])}
 
     def graphBegin(self):
         """Start recording everything enqueued on this context into a HIP graph (hx_ctx_graph_begin):
@@ -624,3 +634,20 @@ def time_ntt(poly, inverse, iters, max_rows=0):
     ms = C.c_float()
     _chk(lib().hx_time_ntt(poly.h, 1 if inverse else 0, iters, max_rows, C.byref(ms)))
     return ms.value
+
+
+def profileBegin():
+    """Start timing every kernel the library launches with HIP events on its own stream (hx_profile_begin)."""
+    _chk(lib().hx_profile_begin())
+
+
+def profileEnd():
+    """Wait for the launches recorded since profileBegin and return the per-kernel summary
+    (hx_profile_end): {"launches", "dropped", "kernels": [{"kernel", "workgroups", "workgroup_size",
+    "calls", "total_us", "avg_us", "min_us", "max_us"}, ...]} ordered by total time."""
+    import json
+    need = C.c_size_t()
+    _chk(lib().hx_profile_end(None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    _chk(lib().hx_profile_end(buf, need.value, None))
+    return json.loads(buf.value.decode())

@@ -11,9 +11,12 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/helib_amd.h"
+#include "arena.h"
+#include "prof.h"
 #include "dev_common.h"
 #include "hostmath.h"
 #include "bluestein.h"
@@ -164,11 +167,12 @@ struct hx_ctx {
   std::vector<ConvPlan> bigplan;  // power-of-two rings with N = 2^16..2^18: per-prime split plans (pow2_big_rows)
   std::vector<int64_t> psi_low, phi_coef;  // -Psi mod X^(dq+1) and Phi_m, small integers
   std::map<std::vector<uint64_t>, ExtPlan*> plans;
-  // stream-ordered device-memory pool for poly slabs: every slab is used on the context's one
-  // stream only, so a freed slab can be handed out again without synchronising (hipMalloc /
-  // hipFree would serialise the device on every DoubleCRT temporary).
-  std::multimap<size_t, void*> pool;
-  size_t pool_bytes = 0;
+  // stream-ordered device-memory arena for poly slabs (arena.h): a few large hipMalloc chunks,
+  // sub-allocated; every slab is used on the context's one stream only, so a released extent can be
+  // handed out again without synchronising (hipMalloc / hipFree would serialise the device on every
+  // DoubleCRT temporary, and results that are kept alive would reach hipMalloc on every operation).
+  hxa::SlabArena arena;
+  std::unordered_set<struct hx_poly*> polys;  // every live poly of this context (graph capture un-shares them)
   // lifetime: polys and key-switch matrices keep their context alive, so the
   // handles may be destroyed in any order (hx_ctx_destroy only drops the
   // caller's reference).
@@ -206,12 +210,12 @@ struct hx_ctx {
   std::vector<NormPending> norm_pending, norm_free;
   hipEvent_t timer[2] = {nullptr, nullptr};  // hx_ctx_timer_begin / _end
   // HIP graphs (hx_ctx_graph_begin / _end): while a capture is open or a captured graph is alive,
-  // nothing a graph may point at is handed back -- slabs released by polys wait in graph_deferred,
-  // buffers that are re-grown (scratch, twiddle arena, tables) are retired instead of freed
+  // nothing a graph may point at is handed back -- slabs that were live during a capture are pinned
+  // in the arena and wait in its deferred list when their poly lets go of them; buffers that are
+  // re-grown (scratch, twiddle arena, tables) are retired instead of freed
   bool capturing = false;
   int graphs_alive = 0;
   hipStream_t own_stream = nullptr;   // created by the first capture of a context that ran on the default stream
-  std::vector<std::pair<void*, size_t>> graph_deferred;
   std::vector<void*> graph_retired;
 };
 
@@ -231,6 +235,9 @@ struct hx_poly {
     int refs;
   };
   Share* share = nullptr;
+  // the caller holds a raw device pointer into this poly's slab (hx_poly_device_ptr): copies from and
+  // to it are made eagerly from then on, so that writes through the pointer never reach a "copy"
+  bool exposed = false;
   size_t row_words() const { return (size_t)batch * ctx->phim; }
   int nrows() const { return (int)prime_idx.size(); }
   bool shared() const { return share && share->refs > 1; }
@@ -266,29 +273,23 @@ static int use(hx_ctx* c)
       return fail(HX_ERR_INVALID, what " waits for the device and cannot be captured in a graph"); \
   } while (0)
 
-static constexpr size_t POOL_GRAIN = (size_t)2 << 20;        // slabs are multiples of 2 MiB
 static constexpr size_t POOL_LIMIT = (size_t)64 << 30;        // keep at most 64 GiB cached
-static size_t pool_round(size_t bytes) { return (bytes + POOL_GRAIN - 1) / POOL_GRAIN * POOL_GRAIN; }
+static int arena_sys_alloc(size_t bytes, void** out)
+{
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess)
+    (void)hipGetLastError();
+  return (int)e;
+}
+static void arena_sys_free(void* p) { hipFree(p); }  // (hipFree waits for the device)
 static hipError_t pool_alloc(hx_ctx* c, size_t bytes, void** out)
 {
-  size_t sz = pool_round(bytes);
-  auto it = c->pool.find(sz);
-  if (it != c->pool.end()) {
-    *out = it->second;
-    c->pool.erase(it);
-    c->pool_bytes -= sz;
-    return hipSuccess;
+  if (!c->arena.sys_alloc) {
+    c->arena.sys_alloc = arena_sys_alloc;
+    c->arena.sys_free = arena_sys_free;
   }
-  hipError_t e = hipMalloc(out, sz);
-  if (e != hipSuccess && !c->pool.empty()) {  // release the cache and retry once
-    hipStreamSynchronize(c->stream);
-    for (auto& kv : c->pool)
-      hipFree(kv.second);
-    c->pool.clear();
-    c->pool_bytes = 0;
-    e = hipMalloc(out, sz);
-  }
-  return e;
+  // a block taken while a capture is open may end up inside the graph: pinned from the start
+  return (hipError_t)c->arena.alloc(bytes, c->capturing, out);
 }
 // a device buffer that is being replaced by a larger one: freed now, or kept for the graphs that
 // may have its address baked in (released when the last of them is destroyed)
@@ -308,18 +309,18 @@ static void retire_or_free(hx_ctx* c, void* p, bool device_wide_sync = false)
 }
 static void pool_free(hx_ctx* c, void* p, size_t bytes)
 {
-  size_t sz = pool_round(bytes);
-  if (c->capturing || c->graphs_alive > 0) {
-    c->graph_deferred.emplace_back(p, sz);
+  (void)bytes;
+  // only what a graph can point at waits for the graphs to go: blocks that were live while a capture
+  // was open.  Slabs of eager work next to a live graph recycle at once (no growth).
+  if ((c->capturing || c->graphs_alive > 0) && c->arena.is_pinned(p)) {
+    c->arena.defer(p);
     return;
   }
-  if (c->pool_bytes + sz > POOL_LIMIT) {
+  c->arena.release(p);
+  if (c->arena.cached() > POOL_LIMIT && !c->capturing) {
     hipStreamSynchronize(c->stream);
-    hipFree(p);
-    return;
+    c->arena.trim(POOL_LIMIT / 2);
   }
-  c->pool.emplace(sz, p);
-  c->pool_bytes += sz;
 }
 
 static int ensure_scratch(hx_ctx* c, int slot, size_t words)
@@ -346,7 +347,7 @@ static int dcopy(hx_ctx* c, uint64_t* dst, const uint64_t* src, size_t words)
     return HX_OK;
   }
   const size_t blocks = std::min<size_t>((words / 2 + 255) / 256, (size_t)256 * 16);
-  hipLaunchKernelGGL(hx::copy_words_kernel, dim3((unsigned)std::max<size_t>(blocks, 1)), dim3(256), 0, c->stream,
+  HX_LAUNCH(hx::copy_words_kernel, dim3((unsigned)std::max<size_t>(blocks, 1)), dim3(256), 0, c->stream,
                      dst, src, words);
   HIPCHK(hipGetLastError());
   return HX_OK;
@@ -500,10 +501,7 @@ static void ctx_free(hx_ctx* c)
   for (int i = 0; i < 10; i++)
     if (c->scratch[i])
       hipFree(c->scratch[i]);
-  for (auto& kv : c->pool)
-    hipFree(kv.second);
-  for (auto& kv : c->graph_deferred)
-    hipFree(kv.first);
+  c->arena.destroy();
   if (c->own_stream)
     hipStreamDestroy(c->own_stream);
   for (void* q : c->graph_retired)
@@ -580,6 +578,17 @@ extern "C" int hx_ctx_sync(hx_ctx* c)
   CTX_ENTER(c);
   NO_CAPTURE(c, "hx_ctx_sync");
   HIPCHK(hipStreamSynchronize(c->stream));
+  return HX_OK;
+}
+extern "C" int hx_ctx_arena_stats(hx_ctx* c, uint64_t out[4])
+{
+  if (!c || !out)
+    return fail(HX_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  out[0] = c->arena.reserved;
+  out[1] = c->arena.in_use;
+  out[2] = c->arena.sys_calls;
+  out[3] = c->arena.deferred.size();
   return HX_OK;
 }
 extern "C" int hx_ctx_num_primes(const hx_ctx* c, int* n)
@@ -906,7 +915,7 @@ static int conv_core(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vector
     CHK(ntt_launch(c, logn, c->d_cprimes, buf, buf, rows, batch, false));
     if (fwd_only)
       return HX_OK;
-    hipLaunchKernelGGL(hx::conv_pointwise_kernel, grid2(N, (size_t)R * batch), dim3(256), 0, c->stream,
+    HX_LAUNCH(hx::conv_pointwise_kernel, grid2(N, (size_t)R * batch), dim3(256), 0, c->stream,
                        buf, hats, cps, 1, batch, N);
     HIPCHK(hipGetLastError());
     return ntt_launch(c, logn, c->d_cprimes, buf, buf, rows, batch, true);
@@ -918,13 +927,13 @@ static int conv_core(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vector
       rows.emplace_back(r * split + g, plans[r]->pd[g]);
   auto split_launch = [&](int inverse) {
     if (split == 16)
-      hipLaunchKernelGGL(hx::conv_splitN_kernel<4>, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
+      HX_LAUNCH(hx::conv_splitN_kernel<4>, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
                          cps, batch, Q, inverse);
     else if (split == 8)
-      hipLaunchKernelGGL(hx::conv_splitN_kernel<3>, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
+      HX_LAUNCH(hx::conv_splitN_kernel<3>, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
                          cps, batch, Q, inverse);
     else
-      hipLaunchKernelGGL(hx::conv_split_kernel, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
+      HX_LAUNCH(hx::conv_split_kernel, grid2(Q, (size_t)R * batch), dim3(256), 0, c->stream, buf, qbuf,
                          cps, batch, Q, inverse);
     return hipGetLastError();
   };
@@ -932,7 +941,7 @@ static int conv_core(hx_ctx* c, uint64_t* buf, uint64_t* qbuf, const std::vector
   CHK(ntt_launch(c, lsub, c->d_cprimes, qbuf, qbuf, rows, batch, false));
   if (fwd_only)
     return HX_OK;
-  hipLaunchKernelGGL(hx::conv_pointwise_kernel, grid2(Q, (size_t)R * split * batch), dim3(256), 0, c->stream,
+  HX_LAUNCH(hx::conv_pointwise_kernel, grid2(Q, (size_t)R * split * batch), dim3(256), 0, c->stream,
                      qbuf, hats, cps, split, batch, Q);
   HIPCHK(hipGetLastError());
   CHK(ntt_launch(c, lsub, c->d_cprimes, qbuf, qbuf, rows, batch, true));
@@ -951,13 +960,13 @@ static int aux_conv_row(hx_ctx* c, uint64_t* sub, const BluePrime* bp, int batch
   const unsigned blocks = (unsigned)std::min<size_t>(4096, (n + 255) / 256);
   for (int j = 0; j < 3; j++) {
     uint64_t* t = c->scratch[8] + (size_t)j * n;
-    hipLaunchKernelGGL(hx::aux_load_kernel, dim3(blocks), dim3(256), 0, c->stream, sub, t, n, bp->crt.A[j]);
+    HX_LAUNCH(hx::aux_load_kernel, dim3(blocks), dim3(256), 0, c->stream, sub, t, n, bp->crt.A[j]);
     HIPCHK(hipGetLastError());
     std::vector<const ConvPlan*> pl(1, &bp->aconv[j][which]);
     std::vector<const uint64_t*> hv(1, bp->d_ahat[j][hat_sel]);
     CHK(conv_core(c, t, c->scratch[9], pl, hv, batch));
   }
-  hipLaunchKernelGGL(hx::crt3_kernel, dim3(blocks), dim3(256), 0, c->stream, c->scratch[8], c->scratch[8] + n,
+  HX_LAUNCH(hx::crt3_kernel, dim3(blocks), dim3(256), 0, c->stream, c->scratch[8], c->scratch[8] + n,
                      c->scratch[8] + 2 * n, sub, n, bp->crt);
   HIPCHK(hipGetLastError());
   return HX_OK;
@@ -1189,11 +1198,11 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
     uint64_t* cbuf = c->scratch[4];
     uint64_t* qbuf = c->scratch[5];
     if (!inverse) {
-      hipLaunchKernelGGL(hx::blue_pre_kernel, grid2(NB, segs), dim3(256), 0, c->stream, in, cbuf, nr, bp,
+      HX_LAUNCH(hx::blue_pre_kernel, grid2(NB, segs), dim3(256), 0, c->stream, in, cbuf, nr, bp,
                          batch, phim, NB, 0);
       HIPCHK(hipGetLastError());
       CHK(conv_apply(c, cbuf, qbuf, pr, batch, 0, 0));
-      hipLaunchKernelGGL(hx::blue_post_kernel, grid2(phim, segs), dim3(256), 0, c->stream, cbuf, out, nr,
+      HX_LAUNCH(hx::blue_post_kernel, grid2(phim, segs), dim3(256), 0, c->stream, cbuf, out, nr,
                          bp, batch, phim, m, NB, c->mpad, c->d_zms, 1);
       HIPCHK(hipGetLastError());
       continue;
@@ -1202,24 +1211,24 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
     CHK(ensure_scratch(c, 7, segs * std::max(N1, N2)));
     uint64_t* xfull = c->scratch[6];
     uint64_t* wbuf = c->scratch[7];
-    hipLaunchKernelGGL(hx::blue_scatter_kernel, grid2(NB, segs), dim3(256), 0, c->stream, in, cbuf, nr, bp,
+    HX_LAUNCH(hx::blue_scatter_kernel, grid2(NB, segs), dim3(256), 0, c->stream, in, cbuf, nr, bp,
                        batch, phim, m, NB, c->d_zms_index);
     HIPCHK(hipGetLastError());
     CHK(conv_apply(c, cbuf, qbuf, pr, batch, 0, 1));
-    hipLaunchKernelGGL(hx::blue_post_kernel, grid2(m, segs), dim3(256), 0, c->stream, cbuf, xfull, nr, bp,
+    HX_LAUNCH(hx::blue_post_kernel, grid2(m, segs), dim3(256), 0, c->stream, cbuf, xfull, nr, bp,
                        batch, phim, m, NB, c->mpad, c->d_zms, 0);
     HIPCHK(hipGetLastError());
     // rem Phi_m: Q = rev_d( top(x) * (-Psi) mod X^(d+1) ), r = x - Q*Phi_m
-    hipLaunchKernelGGL(hx::blue_rev_kernel, grid2(N1, segs), dim3(256), 0, c->stream, xfull, wbuf, batch,
+    HX_LAUNCH(hx::blue_rev_kernel, grid2(N1, segs), dim3(256), 0, c->stream, xfull, wbuf, batch,
                        c->mpad, m - 1, c->dq, N1);
     HIPCHK(hipGetLastError());
     CHK(conv_apply(c, wbuf, qbuf, pr, batch, 1, 2));
     // Q (zero padded to N2) goes to cbuf, which is free again
-    hipLaunchKernelGGL(hx::blue_rev_kernel, grid2(N2, segs), dim3(256), 0, c->stream, wbuf, cbuf, batch, N1,
+    HX_LAUNCH(hx::blue_rev_kernel, grid2(N2, segs), dim3(256), 0, c->stream, wbuf, cbuf, batch, N1,
                        c->dq, c->dq, N2);
     HIPCHK(hipGetLastError());
     CHK(conv_apply(c, cbuf, qbuf, pr, batch, 2, 3));
-    hipLaunchKernelGGL(hx::blue_final_kernel, grid2(phim, segs), dim3(256), 0, c->stream, xfull, cbuf, out,
+    HX_LAUNCH(hx::blue_final_kernel, grid2(phim, segs), dim3(256), 0, c->stream, xfull, cbuf, out,
                        nr, bp, batch, phim, c->mpad, N2);
     HIPCHK(hipGetLastError());
   }
@@ -1362,6 +1371,7 @@ static int poly_new(hx_ctx* c, int batch, const int* idx, int nrows, int cap, vo
     }
   }
   c->refs++;
+  c->polys.insert(p);
   *out = p;
   return HX_OK;
 }
@@ -1389,6 +1399,7 @@ extern "C" int hx_poly_destroy(hx_poly* p)
     std::lock_guard<std::recursive_mutex> lk(p->ctx->mu);
     hipSetDevice(p->ctx->device);
     storage_release(p);
+    p->ctx->polys.erase(p);
   }
   ctx_release(p->ctx);
   delete p;
@@ -1422,6 +1433,7 @@ extern "C" void* hx_poly_device_ptr(hx_poly* p)
   hipSetDevice(p->ctx->device);
   if (poly_own(p) != HX_OK)  // the caller may write through the pointer
     return nullptr;
+  p->exposed = true;
   return p->d;
 }
 
@@ -1478,7 +1490,13 @@ extern "C" int hx_poly_copy(hx_poly* dst, const hx_poly* src)
   CTX_ENTER(dst->ctx);
   if (dst == src)
     return HX_OK;
-  if (dst->owns && src->owns) {
+  // Lazy unless a HIP graph is involved or a raw pointer is out: a graph replays on the addresses it
+  // recorded ("inputs are whatever the input polys hold at replay time"), which only holds if an
+  // input poly never has to move off its slab to be written -- so nothing is shared while a capture
+  // is open or a graph is alive (hx_ctx_graph_begin also un-shares what was shared before).
+  hx_ctx* cc = dst->ctx;
+  const bool lazy_ok = !cc->capturing && cc->graphs_alive == 0 && !dst->exposed && !src->exposed;
+  if (dst->owns && src->owns && lazy_ok) {
     // lazy: share the source's slab (see hx_poly::Share); nothing moves until somebody writes
     hx_poly* s = const_cast<hx_poly*>(src);
     if (dst->d == s->d)
@@ -1536,7 +1554,7 @@ extern "C" int hx_randomize(hx_poly* p, const uint8_t* key32, uint64_t stream)
       return fail(HX_ERR_UNSUPPORTED, "hx_randomize: prime index above 65535");
     A.rows.p[r] = (uint16_t)p->prime_idx[r];
   }
-  hipLaunchKernelGGL(hx::randomize_kernel, dim3((unsigned)p->nrows() * (unsigned)p->batch), dim3(256), 0,
+  HX_LAUNCH(hx::randomize_kernel, dim3((unsigned)p->nrows() * (unsigned)p->batch), dim3(256), 0,
                      c->stream, A, c->d_primes);
   HIPCHK(hipGetLastError());
   return HX_OK;
@@ -1645,19 +1663,19 @@ static int pow2_big_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
     }
     const dim3 grid = grid2(Q, (size_t)R * batch);
     if (S == 16)
-      hipLaunchKernelGGL(hx::big_pre_kernel<16>, grid, dim3(256), 0, c->stream, in, qbuf, d, cps, batch, Q, inverse ? 1 : 0);
+      HX_LAUNCH(hx::big_pre_kernel<16>, grid, dim3(256), 0, c->stream, in, qbuf, d, cps, batch, Q, inverse ? 1 : 0);
     else if (S == 8)
-      hipLaunchKernelGGL(hx::big_pre_kernel<8>, grid, dim3(256), 0, c->stream, in, qbuf, d, cps, batch, Q, inverse ? 1 : 0);
+      HX_LAUNCH(hx::big_pre_kernel<8>, grid, dim3(256), 0, c->stream, in, qbuf, d, cps, batch, Q, inverse ? 1 : 0);
     else
-      hipLaunchKernelGGL(hx::big_pre_kernel<4>, grid, dim3(256), 0, c->stream, in, qbuf, d, cps, batch, Q, inverse ? 1 : 0);
+      HX_LAUNCH(hx::big_pre_kernel<4>, grid, dim3(256), 0, c->stream, in, qbuf, d, cps, batch, Q, inverse ? 1 : 0);
     HIPCHK(hipGetLastError());
     CHK(ntt_launch(c, lsub, c->d_cprimes, qbuf, qbuf, sub, batch, inverse));
     if (S == 16)
-      hipLaunchKernelGGL(hx::big_post_kernel<16>, grid, dim3(256), 0, c->stream, qbuf, out, d, cps, batch, Q, inverse ? 1 : 0);
+      HX_LAUNCH(hx::big_post_kernel<16>, grid, dim3(256), 0, c->stream, qbuf, out, d, cps, batch, Q, inverse ? 1 : 0);
     else if (S == 8)
-      hipLaunchKernelGGL(hx::big_post_kernel<8>, grid, dim3(256), 0, c->stream, qbuf, out, d, cps, batch, Q, inverse ? 1 : 0);
+      HX_LAUNCH(hx::big_post_kernel<8>, grid, dim3(256), 0, c->stream, qbuf, out, d, cps, batch, Q, inverse ? 1 : 0);
     else
-      hipLaunchKernelGGL(hx::big_post_kernel<4>, grid, dim3(256), 0, c->stream, qbuf, out, d, cps, batch, Q, inverse ? 1 : 0);
+      HX_LAUNCH(hx::big_post_kernel<4>, grid, dim3(256), 0, c->stream, qbuf, out, d, cps, batch, Q, inverse ? 1 : 0);
     HIPCHK(hipGetLastError());
   }
   return HX_OK;
@@ -1698,7 +1716,10 @@ static int ntt_poly(hx_poly* p, bool inverse)
   rows.reserve(p->nrows());
   for (int r = 0; r < p->nrows(); r++)
     rows.emplace_back(r, p->prime_idx[r]);
-  return ntt_list(p->ctx, src, p->d, rows, p->batch, inverse);
+  int rc = ntt_list(p->ctx, src, p->d, rows, p->batch, inverse);
+  if (rc != HX_OK && src != p->d)  // the poly left a shared slab for a fresh one: it keeps its old rows
+    (void)dcopy(p->ctx, p->d, src, (size_t)p->nrows() * p->row_words());
+  return rc;
 }
 
 extern "C" int hx_ntt_forward(hx_poly* p)
@@ -1773,6 +1794,30 @@ extern "C" int hx_ctx_timer_end(hx_ctx* c, float* ms)
   return HX_OK;
 }
 
+// In-situ kernel timing (prof.h): between begin and end every kernel the library launches, on any
+// context of this process, is bracketed by HIP events on its own stream.  hx_profile_end waits for
+// them and writes a JSON summary (per kernel and launch size: calls, total / avg / min / max
+// microseconds) into `json`; when `cap` is too small nothing is written and *needed tells the size.
+extern "C" int hx_profile_begin(void)
+{
+  hxp::begin();
+  return HX_OK;
+}
+extern "C" int hx_profile_end(char* json, size_t cap, size_t* needed)
+{
+  static thread_local std::string pending;
+  if (pending.empty())
+    pending = hxp::end();
+  if (needed)
+    *needed = pending.size() + 1;
+  if (!json || cap < pending.size() + 1)
+    return json ? fail(HX_ERR_INVALID, "hx_profile_end: buffer of %zu bytes, %zu needed", cap, pending.size() + 1)
+                : HX_OK;
+  memcpy(json, pending.c_str(), pending.size() + 1);
+  pending.clear();
+  return HX_OK;
+}
+
 // ------------------------------------------------------------------
 // HIP graphs: a sequence of engine calls captured once and replayed with one launch -- for the
 // launch-bound case (one ciphertext at a time, as benchmarks/bgv_basic.cpp:158-164 runs: ~40 kernels
@@ -1780,7 +1825,7 @@ extern "C" int hx_ctx_timer_end(hx_ctx* c, float* ms)
 // end is recorded instead of run.  A replay re-executes exactly those kernels on exactly those
 // buffers: the inputs are whatever the input polys hold at replay time, the outputs land in the polys
 // the captured calls returned.  While a graph is alive the context keeps every buffer the graph may
-// point at (see hx_ctx::graph_deferred / graph_retired).  Calls that must wait for the device
+// point at (pinned arena blocks / hx_ctx::graph_retired).  Calls that must wait for the device
 // (downloads, uploads, norm read-backs) cannot be captured: HIP fails them, and so does end().
 // ------------------------------------------------------------------
 struct hx_graph {
@@ -1792,13 +1837,12 @@ struct hx_graph {
 // to the pool, replaced buffers are freed (the stream is drained first)
 static void graph_release_if_idle(hx_ctx* c)
 {
-  if (c->capturing || c->graphs_alive > 0 || (c->graph_deferred.empty() && c->graph_retired.empty()))
+  if (c->capturing || c->graphs_alive > 0)
     return;
-  hipStreamSynchronize(c->stream);
-  std::vector<std::pair<void*, size_t>> d;
-  d.swap(c->graph_deferred);
-  for (auto& kv : d)
-    pool_free(c, kv.first, kv.second);
+  const bool parked = !c->arena.deferred.empty() || !c->graph_retired.empty();
+  if (parked)
+    hipStreamSynchronize(c->stream);
+  c->arena.unpin_all();
   for (void* q : c->graph_retired)
     hipFree(q);
   c->graph_retired.clear();
@@ -1820,6 +1864,14 @@ extern "C" int hx_ctx_graph_begin(hx_ctx* c)
       HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
   }
+  // every poly gets a slab of its own before the recording starts: a recorded kernel that reads an
+  // input poly must keep seeing that poly's data at replay time, which a copy-on-write move of the
+  // poly to another slab (at its next upload / set_zero / element-wise write) would break
+  for (hx_poly* p : c->polys)
+    if (p->share)
+      CHK(poly_own(p));
+  // whatever is live now may be referenced by the recording
+  c->arena.pin_all();
   HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
   c->capturing = true;
   return HX_OK;
@@ -1928,7 +1980,7 @@ static int ew_binary(hx_poly* a, const hx_poly* b)
   }
   size_t rw = a->row_words();
   OWN(a);
-  hipLaunchKernelGGL((hx::ew_binary_kernel<OP>), ew_grid(rw, rows), dim3(256), 0, a->ctx->stream,
+  HX_LAUNCH((hx::ew_binary_kernel<OP>), ew_grid(rw, rows), dim3(256), 0, a->ctx->stream,
                      a->d, b->d, map, rw, b->row_words(), (int)(b->batch != a->batch),
                      (size_t)a->ctx->phim, a->ctx->d_primes);
   HIPCHK(hipGetLastError());
@@ -1960,7 +2012,7 @@ static int ew_scalar_rows(hx_poly* a, const uint64_t* c_per_row, uint64_t expone
   }
   size_t rw = a->row_words();
   OWN(a);
-  hipLaunchKernelGGL((hx::ew_scalar_kernel<OP>), ew_grid(rw, rows), dim3(256), 0, a->ctx->stream,
+  HX_LAUNCH((hx::ew_scalar_kernel<OP>), ew_grid(rw, rows), dim3(256), 0, a->ctx->stream,
                      a->d, map, sc, rw, a->ctx->d_primes);
   HIPCHK(hipGetLastError());
   return HX_OK;
@@ -2019,7 +2071,7 @@ extern "C" int hx_automorph(hx_poly* a, uint64_t k)
   if (!direct)
     CHK(ensure_scratch(c, 3, words));
   if (!c->pow2) {
-    hipLaunchKernelGGL(hx::perm_build_kernel, dim3((c->phim + 255) / 256), dim3(256), 0, c->stream,
+    HX_LAUNCH(hx::perm_build_kernel, dim3((c->phim + 255) / 256), dim3(256), 0, c->stream,
                        c->d_perm, c->d_zms, c->d_zms_index, c->phim, c->m, k);
     HIPCHK(hipGetLastError());
   }
@@ -2027,7 +2079,7 @@ extern "C" int hx_automorph(hx_poly* a, uint64_t k)
   unsigned bx = (c->phim + 255) / 256;
   if (bx > 64)
     bx = 64;
-  hipLaunchKernelGGL(hx::gather_kernel, dim3(bx, (unsigned)nseg), dim3(256), 0, c->stream,
+  HX_LAUNCH(hx::gather_kernel, dim3(bx, (unsigned)nseg), dim3(256), 0, c->stream,
                      direct ? a->d : c->scratch[3], src, c->d_perm, c->phim, nseg, (int)c->pow2, c->m, k);
   HIPCHK(hipGetLastError());
   if (!direct)
@@ -2256,7 +2308,7 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args, size
   if (pl->dev.fast16_ok) {
 #define HX_EXT_FAST(NN)                                                                                 \
   case NN:                                                                                              \
-    hipLaunchKernelGGL((hx::rns_extend_fast_kernel<NN>), grid, block, 0, c->stream, pl->dev, args, row_words); \
+    HX_LAUNCH((hx::rns_extend_fast_kernel<NN>), grid, block, 0, c->stream, pl->dev, args, row_words); \
     break;
     switch (n) {
       HX_EXT_FAST(1) HX_EXT_FAST(2) HX_EXT_FAST(3) HX_EXT_FAST(4) HX_EXT_FAST(5) HX_EXT_FAST(6) HX_EXT_FAST(7) HX_EXT_FAST(8)
@@ -2268,20 +2320,20 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args, size
     return HX_OK;
   }
   if (n <= 8)
-    hipLaunchKernelGGL((hx::rns_extend_kernel<8>), grid, block, 0, c->stream, pl->dev, args,
+    HX_LAUNCH((hx::rns_extend_kernel<8>), grid, block, 0, c->stream, pl->dev, args,
                        row_words);
   else if (n <= 16)
-    hipLaunchKernelGGL((hx::rns_extend_kernel<16>), grid, block, 0, c->stream, pl->dev, args,
+    HX_LAUNCH((hx::rns_extend_kernel<16>), grid, block, 0, c->stream, pl->dev, args,
                        row_words);
   else if (n <= 40)
-    hipLaunchKernelGGL((hx::rns_extend_kernel<40>), grid, block, 0, c->stream, pl->dev, args,
+    HX_LAUNCH((hx::rns_extend_kernel<40>), grid, block, 0, c->stream, pl->dev, args,
                        row_words);
   else if (n <= 64)
-    hipLaunchKernelGGL((hx::rns_extend_kernel<64>), grid, block, 0, c->stream, pl->dev, args,
+    HX_LAUNCH((hx::rns_extend_kernel<64>), grid, block, 0, c->stream, pl->dev, args,
                        row_words);
   else  // whole chains of the reference's own benchmark parameter (bits=6400: 143 primes, e.g. the
         // toPoly of a decryption): the digits live in private memory -- slow, and rare
-    hipLaunchKernelGGL((hx::rns_extend_kernel<MAX_EXT_SRC>), grid, block, 0, c->stream, pl->dev, args,
+    HX_LAUNCH((hx::rns_extend_kernel<MAX_EXT_SRC>), grid, block, 0, c->stream, pl->dev, args,
                        row_words);
   HIPCHK(hipGetLastError());
   return HX_OK;
@@ -2338,7 +2390,7 @@ static int flush_xs(hx_ctx* c)
   if (c->xs_rows <= 0)
     return HX_OK;
   const size_t n = (size_t)c->xs_rows * c->phim;
-  hipLaunchKernelGGL(hx::frac_from_xs_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)),
+  HX_LAUNCH(hx::frac_from_xs_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)),
                      dim3(256), 0, c->stream, c->scratch[0],
                      reinterpret_cast<const int64_t*>(c->scratch[1]), c->xs_inv_qd,
                      c->d_frac + (size_t)c->xs_first * c->phim, n);
@@ -2398,7 +2450,7 @@ static int bnorm_setup(hx_ctx* c)
   const int logp = bk, logh = std::min(logp, hx::NORM_MAX_LOGH);
   const unsigned H = 1u << logh, S = (unsigned)(P >> logh);
   const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, H / 4));
-  hipLaunchKernelGGL(hx::bnorm_fwd_kernel, dim3(S), dim3(threads), std::max<size_t>(16 * (size_t)H, 256), c->stream,
+  HX_LAUNCH(hx::bnorm_fwd_kernel, dim3(S), dim3(threads), std::max<size_t>(16 * (size_t)H, 256), c->stream,
                      (const double*)nullptr, (const double2*)nullptr, (const double2*)d_cv, c->d_bn_w,
                      (const double2*)nullptr, c->d_bn_chat, logp, logh, c->phim, 1);
   HIPCHK(hipGetLastError());
@@ -2425,15 +2477,15 @@ static int embed_norms_general(hx_ctx* c, const double* d_f, int rows)
   const size_t lds = std::max<size_t>(16 * (size_t)H, 256);
   for (size_t r0 = 0; r0 < (size_t)rows; r0 += c->bn_rows_cap) {
     const unsigned nr = (unsigned)std::min<size_t>(c->bn_rows_cap, (size_t)rows - r0);
-    hipLaunchKernelGGL(hx::bnorm_fwd_kernel, dim3(nr * S), dim3(threads), lds, c->stream,
+    HX_LAUNCH(hx::bnorm_fwd_kernel, dim3(nr * S), dim3(threads), lds, c->stream,
                        d_f + r0 * c->phim, (const double2*)c->d_bn_v, (const double2*)nullptr, c->d_bn_w,
                        (const double2*)c->d_bn_chat, c->d_bn_Z, logp, logh, c->phim, 0);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(hx::bnorm_inv_kernel, dim3(nr * S), dim3(threads), lds, c->stream, c->d_bn_Z, c->d_bn_w,
+    HX_LAUNCH(hx::bnorm_inv_kernel, dim3(nr * S), dim3(threads), lds, c->stream, c->d_bn_Z, c->d_bn_w,
                        logp, logh);
     HIPCHK(hipGetLastError());
     const unsigned gx = std::min<unsigned>(64u, (c->phim + 255u) / 256u);
-    hipLaunchKernelGGL(hx::bnorm_max_kernel, dim3(gx, nr), dim3(256), 0, c->stream, (const double2*)c->d_bn_Z,
+    HX_LAUNCH(hx::bnorm_max_kernel, dim3(gx, nr), dim3(256), 0, c->stream, (const double2*)c->d_bn_Z,
                        c->d_bn_w, c->d_zms, c->phim, logp, logh, c->d_norm2 + r0);
     HIPCHK(hipGetLastError());
   }
@@ -2498,13 +2550,13 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
 #define HX_NORM_LAUNCH(SRCT, srcv)                                                                              \
   do {                                                                                                          \
     if (full && logn == 14)                                                                                     \
-      hipLaunchKernelGGL((hx::embed_norm_quarter_kernel<SRCT, 14>), dim3((unsigned)rows), dim3(threads), lds,   \
+      HX_LAUNCH((hx::embed_norm_quarter_kernel<SRCT, 14>), dim3((unsigned)rows), dim3(threads), lds,   \
                          c->stream, srcv, c->d_wtab, logn, c->d_norm2);                                         \
     else if (full && logn == 13)                                                                                \
-      hipLaunchKernelGGL((hx::embed_norm_quarter_kernel<SRCT, 13>), dim3((unsigned)rows), dim3(threads), lds,   \
+      HX_LAUNCH((hx::embed_norm_quarter_kernel<SRCT, 13>), dim3((unsigned)rows), dim3(threads), lds,   \
                          c->stream, srcv, c->d_wtab, logn, c->d_norm2);                                         \
     else                                                                                                        \
-      hipLaunchKernelGGL((hx::embed_norm_quarter_kernel<SRCT, 0>), dim3((unsigned)rows), dim3(threads), lds,    \
+      HX_LAUNCH((hx::embed_norm_quarter_kernel<SRCT, 0>), dim3((unsigned)rows), dim3(threads), lds,    \
                          c->stream, srcv, c->d_wtab, logn, c->d_norm2);                                         \
   } while (0)
     // experiment, off by default: N = 2^14 as two 4096-point sub-transforms per
@@ -2521,7 +2573,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       }
     }
 #define HX_NORM_SPLIT(SRCT, srcv)                                                                            \
-  hipLaunchKernelGGL((hx::embed_norm_quarter_splitT_kernel<SRCT, 12, 512>), dim3((unsigned)rows), dim3(512), \
+  HX_LAUNCH((hx::embed_norm_quarter_splitT_kernel<SRCT, 12, 512>), dim3((unsigned)rows), dim3(512), \
                      16 * (size_t)4096, c->stream, srcv, c->d_wtab, logn, c->d_norm_park, c->d_norm2)
     if (c->xs_rows == rows && d_f == c->d_frac) {
       hx::NormSrcXS src{c->scratch[0], reinterpret_cast<const int64_t*>(c->scratch[1]), c->xs_inv_qd};
@@ -2553,7 +2605,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       HIPCHK(hipMalloc((void**)&c->d_norm_park, park_words * sizeof(double2)));
       c->norm_park_cap = park_words;
     }
-    hipLaunchKernelGGL(hx::embed_norm_quarter_split_kernel, dim3((unsigned)rows * (S / 2)), dim3(hx::NORM_THREADS),
+    HX_LAUNCH(hx::embed_norm_quarter_split_kernel, dim3((unsigned)rows * (S / 2)), dim3(hx::NORM_THREADS),
                        16 * (size_t)H, c->stream, d_f, c->d_wtab, logn, logh, c->d_norm_park, c->d_norm2);
   } else {
     CHK(flush_xs(c));
@@ -2561,7 +2613,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     const unsigned H = 1u << logh, S = N >> logh;
     const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, H / 4));
     const size_t lds = std::max<size_t>(16 * (size_t)H, 256);
-    hipLaunchKernelGGL(hx::embed_norm_kernel, dim3((unsigned)rows * S), dim3(threads), lds, c->stream, d_f,
+    HX_LAUNCH(hx::embed_norm_kernel, dim3((unsigned)rows * S), dim3(threads), lds, c->stream, d_f,
                        c->d_wtab, logn, logh, c->d_norm2);
   }
   HIPCHK(hipGetLastError());
@@ -2961,6 +3013,18 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     CHK(flush_xs(c));  // the scratch slots of an earlier fused block are about to be reused
   if (ptxt < 1)
     return fail(HX_ERR_INVALID, "ptxtSpace must be at least 1");
+  // the fused bringToSet appends the mod-up's primes to the row list before its fallible steps (slab
+  // and scratch allocation, the invertibility check): an error return takes them off again, so the
+  // poly never advertises rows that were not written
+  struct PrimeRollback {
+    hx_poly* a;
+    int n = 0;
+    ~PrimeRollback()
+    {
+      if (n > 0)
+        a->prime_idx.resize(a->prime_idx.size() - (size_t)n);
+    }
+  } rollback{a};
   if (nadd > 0 && ndrop != 1) {
     // several dropped primes behind a mod-up: the batched path or nothing (the caller then does
     // addPrimesAndScale and the mod-down as two steps)
@@ -3011,6 +3075,7 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
         CHK(poly_reserve(others[i], a->nrows() + nadd));
     for (int i = 0; i < nadd; i++)
       a->prime_idx.push_back(add_idx[i]);
+    rollback.n = nadd;
   }
   const int nrows_old = a->nrows() - nadd;
   // diff = getIndexSet() / s : only primes actually present are dropped
@@ -3193,12 +3258,13 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
         c->xs_rows = pb.n * a->batch;
         c->xs_inv_qd = 1.0 / (double)qd;
       } else {
-        hipLaunchKernelGGL(hx::frac_from_xs_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)),
+        HX_LAUNCH(hx::frac_from_xs_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)),
                            dim3(256), 0, c->stream, c->scratch[0],
                            reinterpret_cast<const int64_t*>(c->scratch[1]), 1.0 / (double)qd, fr, n);
         HIPCHK(hipGetLastError());
       }
     }
+    rollback.n = 0;
     if (drow != last)
       a->prime_idx[drow] = a->prime_idx[last];
     a->prime_idx.pop_back();
@@ -3270,7 +3336,7 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     sc.c[r] = inv;
     sc.cp[r] = hxh::shoup(inv, q);
   }
-  hipLaunchKernelGGL(hx::sub_scale_from_kernel, ew_grid(rw, nk), dim3(256), 0, c->stream, nd_buf,
+  HX_LAUNCH(hx::sub_scale_from_kernel, ew_grid(rw, nk), dim3(256), 0, c->stream, nd_buf,
                      a->d, map, sc, rw, c->d_primes);
   HIPCHK(hipGetLastError());
   if (a->owns) {
@@ -3373,6 +3439,7 @@ extern "C" int hx_scale_down_multi_norms(hx_poly** polys, int npoly, const int* 
     return fail(HX_ERR_INVALID, "bad argument");
   hx_ctx* c = polys[0]->ctx;
   CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_scale_down_multi_norms (a norm read-back)");
   const size_t rw = polys[0]->row_words();
   const int batch = polys[0]->batch;
   CHK(frac_begin(c, (size_t)npoly * rw));
@@ -3390,6 +3457,7 @@ extern "C" int hx_bring_to_set_multi_norms(hx_poly** polys, int npoly, const int
     return fail(HX_ERR_INVALID, "bad argument");
   hx_ctx* c = polys[0]->ctx;
   CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_bring_to_set_multi_norms (a norm read-back)");
   const size_t rw = polys[0]->row_words();
   const int batch = polys[0]->batch;
   CHK(frac_begin(c, (size_t)npoly * rw));
@@ -3526,7 +3594,7 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
       attrf = true;
     }
     const size_t lds_fast = (size_t)std::max(1, L - hx::break_fast_n0(A)) * hx::BRK_THREADS * 8;
-    hipLaunchKernelGGL(hx::break_digits_fast_kernel, grid, block, lds_fast, c->stream, A, rw);
+    HX_LAUNCH(hx::break_digits_fast_kernel, grid, block, lds_fast, c->stream, A, rw);
   } else if (nmax <= 8) {
     static bool attr8 = false;
     if (!attr8) {
@@ -3534,7 +3602,7 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
       attr8 = true;
     }
-    hipLaunchKernelGGL((hx::break_digits_kernel<8>), grid, block, lds, c->stream, A, rw);
+    HX_LAUNCH((hx::break_digits_kernel<8>), grid, block, lds, c->stream, A, rw);
   } else {
     static bool attr16 = false;
     if (!attr16) {
@@ -3542,7 +3610,7 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
       attr16 = true;
     }
-    hipLaunchKernelGGL((hx::break_digits_kernel<16>), grid, block, lds, c->stream, A, rw);
+    HX_LAUNCH((hx::break_digits_kernel<16>), grid, block, lds, c->stream, A, rw);
   }
   HIPCHK(hipGetLastError());
   if (owner_out)
@@ -3602,6 +3670,7 @@ extern "C" int hx_break_into_digits_norms(const hx_poly* a, const int* dig_idx, 
     return fail(HX_ERR_INVALID, "bad argument");
   hx_ctx* c = a->ctx;
   CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_break_into_digits_norms (a norm read-back)");
   const size_t rw = a->row_words();
   CHK(frac_begin(c, (size_t)ndig * rw));
   int rc = hx_break_into_digits(a, dig_idx, dig_off, ndig, sp_idx, nsp, out);
@@ -3681,7 +3750,7 @@ static int tensor_launch(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0
     }
   }
   size_t rw = c0->row_words();
-  hipLaunchKernelGGL(hx::tensor_kernel, ew_grid(rw, rows), dim3(256), 0, c->stream, c0->d, c1->d,
+  HX_LAUNCH(hx::tensor_kernel, ew_grid(rw, rows), dim3(256), 0, c->stream, c0->d, c1->d,
                      d0->d, d1->d, o0, o1, o2, map, sc, scale_per_row ? 1 : 0, rw, c->d_primes);
   HIPCHK(hipGetLastError());
   return HX_OK;
@@ -3776,7 +3845,7 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
     }
     d_fix = reinterpret_cast<const hx::KsFix*>(it->second->blob);
   }
-  hipLaunchKernelGGL(hx::keyswitch_kernel, ew_grid(rw, nall), dim3(256), 0, c->stream, dig, W->d_b,
+  HX_LAUNCH(hx::keyswitch_kernel, ew_grid(rw, nall), dim3(256), 0, c->stream, dig, W->d_b,
                      W->d_a, out0, out1, map, ndig, nall, (int)W->row_idx.size(), batch, c->phim,
                      accumulate_rows, c->d_primes, own_src, d_fix, lazy, d_fix ? t0s : nullptr,
                      d_fix ? t1s : nullptr);
@@ -3961,6 +4030,7 @@ extern "C" int hx_relinearize_norms(const hx_poly* t0, const hx_poly* t1, const 
     return fail(HX_ERR_INVALID, "bad argument");
   hx_ctx* c = t0->ctx;
   CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_relinearize_norms (a norm read-back)");
   const size_t rw = t0->row_words();
   CHK(frac_begin(c, (size_t)ndig * rw));
   int rc = hx_relinearize(t0, t1, t2, W, dig_idx, dig_off, ndig, sp_idx, nsp, out0, out1);

@@ -8,6 +8,7 @@
 // See ntt_core.h for the math and the phase functions.
 #include <cstdlib>
 #include "dev_common.h"
+#include "prof.h"
 
 // Minimum waves per SIMD requested from the register allocator.  T = N/32
 // threads: N=2^13 -> 4 waves/WG, 2^14 -> 8, 2^15 -> 16 (=4 per SIMD already).
@@ -523,7 +524,7 @@ static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& r
     attr_set = true;
   }
   dim3 grid((unsigned)nrows * (unsigned)batch), block(Geo<LOGN>::T);
-  hipLaunchKernelGGL((ntt_row_kernel<LOGN, INV>), grid, block, lds_bytes, st, in, out, rows, batch,
+  HX_LAUNCH((ntt_row_kernel<LOGN, INV>), grid, block, lds_bytes, st, in, out, rows, batch,
                      primes, tw_arena);
   return hipGetLastError();
 }
@@ -570,15 +571,15 @@ static hipError_t launch_moddown(const PolyBases& polys, const PolyBases& outs, 
   hipError_t e = moddown_attrs<LOGN>();
   if (e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((ntt_moddown_prep_kernel<LOGN>), dim3((unsigned)polys.n * (unsigned)batch),
+  HX_LAUNCH((ntt_moddown_prep_kernel<LOGN>), dim3((unsigned)polys.n * (unsigned)batch),
                      dim3(Geo<LOGN>::T), lds_bytes, st, polys, drop_row, drop_prime, batch, P, primes,
                      tw_arena);
   {
     const size_t n = (size_t)polys.n * (size_t)batch * Geo<LOGN>::N;
-    hipLaunchKernelGGL(moddown_S_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)),
+    HX_LAUNCH(moddown_S_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)),
                        dim3(256), 0, st, P, n);
   }
-  hipLaunchKernelGGL((ntt_moddown_apply_kernel<LOGN, false>),
+  HX_LAUNCH((ntt_moddown_apply_kernel<LOGN, false>),
                      dim3(moddown_apply_grid((unsigned)polys.n, (unsigned)nkeep, (unsigned)batch)),
                      dim3(Geo<LOGN>::T), lds_bytes, st, polys, outs, keep, nkeep, batch, A, primes, tw_arena);
   return hipGetLastError();
@@ -610,7 +611,7 @@ static hipError_t launch_prep_one(const PolyBases& polys, int drop_row, int drop
   hipError_t e = moddown_attrs<LOGN>();
   if (e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((ntt_moddown_prep_kernel<LOGN>), dim3((unsigned)polys.n * (unsigned)batch),
+  HX_LAUNCH((ntt_moddown_prep_kernel<LOGN>), dim3((unsigned)polys.n * (unsigned)batch),
                      dim3(Geo<LOGN>::T), lds_bytes, st, polys, drop_row, drop_prime, batch, P, primes,
                      tw_arena);
   return hipGetLastError();
@@ -624,7 +625,7 @@ static hipError_t launch_apply_plain(const PolyBases& polys, const PolyBases& ou
   hipError_t e = moddown_attrs<LOGN>();
   if (e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((ntt_moddown_apply_kernel<LOGN, true>),
+  HX_LAUNCH((ntt_moddown_apply_kernel<LOGN, true>),
                      dim3(moddown_apply_grid((unsigned)polys.n, (unsigned)nkeep, (unsigned)batch)),
                      dim3(Geo<LOGN>::T), lds_bytes, st, polys, outs, keep, nkeep, batch, A, primes, tw_arena);
   return hipGetLastError();
@@ -637,7 +638,7 @@ static hipError_t launch_prep_multi(const PolyBases& polys, const PrepMulti& M, 
   hipError_t e = moddown_attrs<LOGN>();
   if (e != hipSuccess)
     return e;
-  hipLaunchKernelGGL((ntt_moddown_prep_multi_kernel<LOGN>), dim3((unsigned)ndrop * (unsigned)polys.n * (unsigned)batch),
+  HX_LAUNCH((ntt_moddown_prep_multi_kernel<LOGN>), dim3((unsigned)ndrop * (unsigned)polys.n * (unsigned)batch),
                      dim3(Geo<LOGN>::T), lds_bytes, st, polys, M, batch, P, primes, tw_arena);
   return hipGetLastError();
 }
@@ -735,10 +736,10 @@ static hipError_t launch_small(bool inverse, const uint64_t* in, uint64_t* out, 
   dim3 grid((unsigned)nrows * (unsigned)batch), block(threads);
   size_t lds = (size_t)N * 8;
   if (inverse)
-    hipLaunchKernelGGL(ntt_small_kernel<true>, grid, block, lds, st, in, out, rows, batch, logn,
+    HX_LAUNCH(ntt_small_kernel<true>, grid, block, lds, st, in, out, rows, batch, logn,
                        primes, tw_arena);
   else
-    hipLaunchKernelGGL(ntt_small_kernel<false>, grid, block, lds, st, in, out, rows, batch, logn,
+    HX_LAUNCH(ntt_small_kernel<false>, grid, block, lds, st, in, out, rows, batch, logn,
                        primes, tw_arena);
   return hipGetLastError();
 }

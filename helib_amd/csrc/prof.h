@@ -1,0 +1,215 @@
+// prof.h -- in-situ kernel timing with HIP events (host code only).
+//
+// Every kernel launch of the library goes through HX_LAUNCH.  Between hx_profile_begin() and
+// hx_profile_end() each launch is bracketed by a pair of events recorded on the stream the kernel
+// is launched on, so a kernel is timed where it actually runs -- between its real neighbours inside
+// a multiply, with their cache and clock state -- and not in a back-to-back loop of its own.
+// bench.py derives `roofline` from this (the rocprofv3 kernel trace of the same command, committed
+// under profiles/, is the cross-check); outside a profiling window a launch costs one predictable
+// branch.  Launches recorded into a HIP graph are skipped (events cannot bracket them).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cxxabi.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace hxp {
+
+struct Rec {
+  int name;
+  unsigned wgs, wg_size;
+  hipEvent_t e0, e1;
+};
+struct State {
+  std::mutex mu;
+  std::vector<std::string> names;
+  std::unordered_map<const void*, int> by_ptr;
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> spare;
+  hipStream_t last_stream = nullptr;
+  bool open = false;  // pre() recorded e0 and the launch has not been closed by post() yet
+  size_t dropped = 0;
+};
+inline bool enabled = false;
+inline State& state()
+{
+  static State s;
+  return s;
+}
+static constexpr size_t MAX_RECS = (size_t)1 << 18;
+
+inline hipEvent_t take_event(State& s)
+{
+  hipEvent_t e = nullptr;
+  if (!s.spare.empty()) {
+    e = s.spare.back();
+    s.spare.pop_back();
+  } else if (hipEventCreate(&e) != hipSuccess) {
+    (void)hipGetLastError();
+    e = nullptr;
+  }
+  return e;
+}
+
+inline void pre(const void* fn, const char* text, hipStream_t st, dim3 grid, dim3 block)
+{
+  State& s = state();
+  std::lock_guard<std::mutex> lk(s.mu);
+  s.open = false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  if (cs != hipStreamCaptureStatusNone)
+    return;
+  if (s.recs.size() >= MAX_RECS) {
+    s.dropped++;
+    return;
+  }
+  auto it = s.by_ptr.find(fn);
+  if (it == s.by_ptr.end()) {
+    // the instantiated kernel's name as rocprofv3 prints it
+    std::string nm;
+    const char* mangled = hipKernelNameRefByPtr(fn, st);
+    if (mangled) {
+      int status = 0;
+      char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+      nm = (status == 0 && dem) ? dem : mangled;
+      free(dem);
+    } else {
+      (void)hipGetLastError();
+      nm = text;
+    }
+    const size_t paren = nm.find('(');  // drop the argument list
+    if (paren != std::string::npos && paren > 0)
+      nm.resize(paren);
+    if (nm.rfind("void ", 0) == 0)
+      nm.erase(0, 5);
+    s.names.push_back(nm);
+    it = s.by_ptr.emplace(fn, (int)s.names.size() - 1).first;
+  }
+  Rec r;
+  r.name = it->second;
+  r.wgs = grid.x * grid.y * grid.z;
+  r.wg_size = block.x * block.y * block.z;
+  r.e0 = take_event(s);
+  r.e1 = take_event(s);
+  if (!r.e0 || !r.e1 || hipEventRecord(r.e0, st) != hipSuccess) {
+    (void)hipGetLastError();
+    if (r.e0)
+      s.spare.push_back(r.e0);
+    if (r.e1)
+      s.spare.push_back(r.e1);
+    s.dropped++;
+    return;
+  }
+  s.recs.push_back(r);
+  s.last_stream = st;
+  s.open = true;
+}
+inline void post(hipStream_t st)
+{
+  State& s = state();
+  std::lock_guard<std::mutex> lk(s.mu);
+  if (!s.open)
+    return;
+  s.open = false;
+  if (hipEventRecord(s.recs.back().e1, st) != hipSuccess) {
+    (void)hipGetLastError();
+    s.spare.push_back(s.recs.back().e0);
+    s.spare.push_back(s.recs.back().e1);
+    s.recs.pop_back();
+    s.dropped++;
+  }
+}
+
+inline int begin()
+{
+  State& s = state();
+  std::lock_guard<std::mutex> lk(s.mu);
+  for (Rec& r : s.recs) {
+    s.spare.push_back(r.e0);
+    s.spare.push_back(r.e1);
+  }
+  s.recs.clear();
+  s.dropped = 0;
+  enabled = true;
+  return 0;
+}
+// waits for the recorded launches; JSON: {"launches": n, "dropped": d, "kernels": [{"kernel", "workgroups",
+// "workgroup_size", "calls", "total_us", "avg_us", "min_us", "max_us"} ... by total time]}
+inline std::string end()
+{
+  State& s = state();
+  std::lock_guard<std::mutex> lk(s.mu);
+  enabled = false;
+  struct Agg {
+    size_t calls = 0;
+    double total = 0, mn = 1e30, mx = 0;
+    unsigned wg_size = 0;
+  };
+  std::map<std::pair<int, unsigned>, Agg> agg;
+  size_t bad = 0;
+  for (Rec& r : s.recs) {
+    float ms = 0;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) {
+      (void)hipGetLastError();
+      bad++;
+    } else {
+      Agg& a = agg[{r.name, r.wgs}];
+      const double us = (double)ms * 1e3;
+      a.calls++;
+      a.total += us;
+      a.mn = us < a.mn ? us : a.mn;
+      a.mx = us > a.mx ? us : a.mx;
+      a.wg_size = r.wg_size;
+    }
+    s.spare.push_back(r.e0);
+    s.spare.push_back(r.e1);
+  }
+  const size_t n = s.recs.size();
+  s.recs.clear();
+  std::vector<std::pair<double, std::pair<int, unsigned>>> order;
+  for (auto& kv : agg)
+    order.push_back({-kv.second.total, kv.first});
+  std::sort(order.begin(), order.end());
+  std::string out = "{\"launches\": " + std::to_string(n) + ", \"dropped\": " + std::to_string(s.dropped + bad) +
+                    ", \"kernels\": [";
+  bool first = true;
+  for (auto& o : order) {
+    const Agg& a = agg[o.second];
+    std::string nm;
+    for (char ch : s.names[(size_t)o.second.first])
+      if (ch != '"' && ch != '\\')
+        nm.push_back(ch);
+    char buf[256];
+    snprintf(buf, sizeof buf,
+             "\"workgroups\": %u, \"workgroup_size\": %u, \"calls\": %zu, \"total_us\": %.2f, \"avg_us\": %.3f, "
+             "\"min_us\": %.3f, \"max_us\": %.3f}",
+             o.second.second, a.wg_size, a.calls, a.total, a.total / (double)a.calls, a.mn, a.mx);
+    out += std::string(first ? "" : ", ") + "{\"kernel\": \"" + nm + "\", " + buf;
+    first = false;
+  }
+  out += "]}";
+  return out;
+}
+
+}  // namespace hxp
+
+#define HX_LAUNCH(kern, grid, block, lds, st, ...)                                 \
+  do {                                                                              \
+    const dim3 _hx_g = (grid), _hx_b = (block);                                     \
+    if (hxp::enabled)                                                               \
+      hxp::pre((const void*)(kern), #kern, (st), _hx_g, _hx_b);                     \
+    hipLaunchKernelGGL(kern, _hx_g, _hx_b, (lds), (st), __VA_ARGS__);               \
+    if (hxp::enabled)                                                               \
+      hxp::post(st);                                                                \
+  } while (0)

@@ -277,6 +277,22 @@ int hx_time_ntt(hx_poly* p, int dir, int iters, int max_rows, float* avg_ms);
  * and returns the elapsed milliseconds of everything enqueued on the context in between. */
 int hx_ctx_timer_begin(hx_ctx* ctx);
 int hx_ctx_timer_end(hx_ctx* ctx, float* ms);
+/* In-situ kernel timing (the reference's counterpart is its FHE timers printed by printAllTimers,
+ * src/timing.cpp:87; here the unit is a device kernel).  Between begin and end every kernel the
+ * library launches, on any context of the process, is bracketed by a pair of HIP events recorded on
+ * the stream it is launched on, i.e. it is timed where it runs inside the real sequence.
+ * hx_profile_end waits for the recorded launches and writes a NUL-terminated JSON summary
+ *   {"launches": n, "dropped": d, "kernels": [{"kernel": name, "workgroups": g, "workgroup_size": t,
+ *     "calls": k, "total_us": .., "avg_us": .., "min_us": .., "max_us": ..}, ... by total time]}
+ * into json[0..cap).  With json == NULL it only reports the size in *needed (the summary is kept
+ * for the next call).  Launches recorded into a HIP graph are not timed. */
+int hx_profile_begin(void);
+int hx_profile_end(char* json, size_t cap, size_t* needed);
+/* The device-memory arena behind the context's DoubleCRT slabs (HElib leaves this to malloc through
+ * NTL's vec_long, include/helib/DoubleCRT.h:87-95): out[0] = bytes reserved from hipMalloc, out[1] =
+ * bytes handed out to polys, out[2] = hipMalloc calls made so far (a warm loop adds none, whatever it
+ * keeps alive), out[3] = blocks parked because a live HIP graph may still point at them. */
+int hx_ctx_arena_stats(hx_ctx* ctx, uint64_t out[4]);
 
 /* ---- HIP graphs: the launch-bound case -------------------------------------------------------
  * The reference's benchmark loop runs ONE ciphertext at a time (benchmarks/bgv_basic.cpp:158-164:

@@ -89,35 +89,35 @@ public:
   // of the ciphertext that asked for it: normBuffer() hands out arrays this object keeps until then.
   void deferNorms(bool on) const
   {
-    std::lock_guard<std::mutex> lock(*norm_mu_);
-    if (on != defer_) {
+    std::lock_guard<std::mutex> lock(norms_->mu);
+    if (on != norms_->defer) {
       check(hx_ctx_defer_norms(h_.get(), on ? 1 : 0));   // switching off flushes
-      defer_ = on;
+      norms_->defer = on;
       if (!on)
-        kept_.clear();
+        norms_->kept.clear();
     }
   }
-  bool deferringNorms() const { return defer_; }
+  bool deferringNorms() const { return norms_->defer; }
   std::shared_ptr<std::vector<double>> normBuffer(size_t n) const
   {
     auto buf = std::make_shared<std::vector<double>>(n, 0.0);
-    std::lock_guard<std::mutex> lock(*norm_mu_);
-    if (defer_) {
-      if (kept_.size() >= 256) {   // nobody is reading: complete them, keep the list short
+    std::lock_guard<std::mutex> lock(norms_->mu);
+    if (norms_->defer) {
+      if (norms_->kept.size() >= 256) {   // nobody is reading: complete them, keep the list short
         check(hx_norms_flush(h_.get()));
-        kept_.clear();
+        norms_->kept.clear();
       }
-      kept_.push_back(buf);
+      norms_->kept.push_back(buf);
     }
     return buf;
   }
   void flushNorms() const
   {
-    std::lock_guard<std::mutex> lock(*norm_mu_);
+    std::lock_guard<std::mutex> lock(norms_->mu);
     check(hx_norms_flush(h_.get()));
-    kept_.clear();
+    norms_->kept.clear();
   }
-  size_t pendingNormBuffers() const { return kept_.size(); }
+  size_t pendingNormBuffers() const { return norms_->kept.size(); }
 
   // HIP graphs (helib_amd.h: hx_ctx_graph_begin / _end): everything enqueued on this context between
   // graphBegin() and graphEnd() is recorded instead of run; Graph::launch() replays it with one launch
@@ -143,9 +143,14 @@ private:
   long phim_ = 0;
   std::shared_ptr<hx_ctx> h_;
   std::vector<uint64_t> primes_, roots_;
-  std::shared_ptr<std::mutex> norm_mu_ = std::make_shared<std::mutex>();
-  mutable bool defer_ = false;
-  mutable std::vector<std::shared_ptr<std::vector<double>>> kept_;
+  // copies of a Context share the device context, so they share its deferral state too: the arrays a
+  // deferred read-back will write stay alive until the flush whichever copy asked for them
+  struct NormState {
+    std::mutex mu;
+    bool defer = false;
+    std::vector<std::shared_ptr<std::vector<double>>> kept;
+  };
+  std::shared_ptr<NormState> norms_ = std::make_shared<NormState>();
 };
 
 class DoubleCRT {

@@ -19,39 +19,43 @@ namespace wire {
 
 constexpr int XD_BOUND_BITS = 114;   // NTL: xdouble's exponent counts multiples of 2^114
 
-// exp(ln) in xdouble normal form
+// exp(ln) in xdouble normal form (exponent in closed form: a crafted noise estimate cannot make this spin)
 inline XDouble xdFromLn(double ln)
 {
   if (ln == -INFINITY)
     return XDouble{0.0, 0};
+  if (!std::isfinite(ln))
+    throw IOError("xdouble: logarithm is not finite");
   const double step = XD_BOUND_BITS * std::log(2.0), half = 57 * std::log(2.0);
-  int64_t e = 0;
-  while (ln >= half) {
-    ln -= step;
-    e++;
+  double ef = std::floor((ln + half) / step);   // ln - e*step in [-half, half)
+  double r = ln - ef * step;
+  if (r >= half) {   // (rounding at the boundary)
+    r -= step;
+    ef += 1;
+  } else if (r < -half) {
+    r += step;
+    ef -= 1;
   }
-  while (ln < -half) {
-    ln += step;
-    e--;
-  }
-  return XDouble{std::exp(ln), e};
+  return XDouble{std::exp(r), (int64_t)ef};
 }
 // a non-negative double in xdouble normal form (NTL xdouble::normalize)
 inline XDouble xdOf(double x)
 {
   if (x == 0.0)
     return XDouble{0.0, 0};
-  const double hb = std::ldexp(1.0, 57), sc = std::ldexp(1.0, XD_BOUND_BITS);
-  int64_t e = 0;
-  while (std::fabs(x) >= hb) {
-    x /= sc;
-    e++;
-  }
-  while (std::fabs(x) < 1.0 / hb) {
-    x *= sc;
-    e--;
-  }
-  return XDouble{x, e};
+  if (!std::isfinite(x))
+    throw IOError("xdouble: value is not finite");
+  // |x| = f * 2^k with f in [0.5, 1): the normal form wants 2^-57 <= |mantissa| < 2^57
+  int k = 0;
+  (void)std::frexp(x, &k);
+  const int64_t e = (int64_t)std::floor((double)(k + 56) / XD_BOUND_BITS);
+  return XDouble{std::ldexp(x, (int)(-e * XD_BOUND_BITS)), e};
+}
+// what a reader accepts: finite mantissa, exponent within what a double's logarithm can carry
+inline void xdCheck(const XDouble& x, const char* what)
+{
+  if (!std::isfinite(x.mantissa) || x.exponent > ((int64_t)1 << 40) || x.exponent < -((int64_t)1 << 40))
+    throw IOError(std::string(what) + ": xdouble out of range");
 }
 inline double lnOf(const XDouble& x)
 {
@@ -88,6 +92,9 @@ inline CtxtDesc describe(const Ctxt& ct, int b = 0)
 // ciphertext's prime set, primes known to the context, residues below their prime
 inline Ctxt restore(const CtxtDesc& d, const ChainContext& cc, const Context& dev, const KeySet& keys)
 {
+  xdCheck(d.ptxtMag, "ptxtMag");
+  xdCheck(d.ratFactor, "ratFactor");
+  xdCheck(d.noiseBound, "noiseBound");
   Ctxt ct(cc, dev, keys);
   ct.ptxtSpace = d.ptxtSpace;
   ct.intFactor = d.intFactor;

@@ -1733,6 +1733,61 @@ def test_captured_graph_replays_a_multiply(hx):
     check(f0, f1, new)
 
 
+def test_captured_graph_inputs_that_had_lazy_copies(hx):
+    """hx_poly_copy is copy-on-write, a graph replays on recorded addresses.  An input
+    poly that shares its slab with a clone must not move off that slab when it is written after the
+    capture (upload / set_zero / element-wise): hx_ctx_graph_begin gives every shared poly its own slab,
+    and copies made while a recording is open or a graph is alive are eager.  Also: eager work next to
+    a live graph recycles its slabs (no growth), and a raw device pointer taken from a poly keeps later
+    copies of it independent."""
+    m, L, K = 16384, 3, 1
+    digits = [[0, 1], [2]]
+    g60 = O.PrimeGen(60, m)
+    primes = [g60.next() for _ in range(L + K)]
+    P = Pair(hx, m, primes)
+    own, sp = list(range(L)), list(range(L, L + K))
+    allp = own + sp
+    ins = [P.rand(own, s, 1) for s in (1, 2, 3, 4)]
+    kb = np.stack([P.rand(allp, 20 + i)[:, 0] for i in range(len(digits))])
+    ka = np.stack([P.rand(allp, 30 + i)[:, 0] for i in range(len(digits))])
+    W = hx.KeySwitch(P.g, allp, kb, ka)
+    G = [hx.DoubleCRT(P.g, own, 1, x) for x in ins]
+    clones = [d.copy() for d in G]                       # lazy: every input now shares its slab with a clone
+    hx.multiplyBy(*G, W, digits)                         # eagerly once
+    P.g.graphBegin()
+    during = G[0].copy()                                 # recorded as a real copy
+    o0, o1 = hx.multiplyBy(*G, W, digits)
+    graph = P.g.graphEnd()
+    new = [P.rand(own, 50 + s, 1) for s in range(4)]
+    for d, x in zip(G, new):
+        d.upload(x)                                      # must write the slab the graph reads
+    graph.launch()
+    w0, w1 = P.o.mul_relin(own, sp, digits, *(x[:, 0] for x in new), kb, ka)
+    assert np.array_equal(o0.download()[:, 0], w0) and np.array_equal(o1.download()[:, 0], w1)
+    assert np.array_equal(during.download(), new[0])     # the recorded copy replays too
+    for cl, x in zip(clones, ins):
+        assert np.array_equal(cl.download(), x)          # the clones kept the old data
+    # eager work while the graph is alive: its temporaries recycle instead of piling up
+    reserved = []
+    for rep in range(12):
+        tmp = [hx.DoubleCRT(P.g, allp, 1, P.rand(allp, 90 + i, 1)) for i in range(4)]
+        e0, e1 = hx.multiplyBy(*G, W, digits)
+        del tmp, e0, e1
+        reserved.append(P.g.arenaStats()["reserved"])
+    assert reserved[-1] == reserved[3], reserved
+    graph.launch()
+    assert np.array_equal(o0.download()[:, 0], w0)
+    graph.destroy()
+    assert P.g.arenaStats()["deferred"] == 0
+    # a raw pointer makes later copies eager
+    a = hx.DoubleCRT(P.g, own, 1, ins[0])
+    ptr = a.device_ptr()
+    b = a.copy()
+    assert b.device_ptr() != ptr
+    a.upload(new[1])
+    assert np.array_equal(b.download(), ins[0])
+
+
 def test_captured_graph_of_the_fresh_multiplyBy_sequence(hx, monkeypatch):
     """The whole fresh Ctxt::multiplyBy (copy, both bringToSet mod-switches, tensor product,
     dropSmallAndSpecialPrimes, key switch; the reference's noise bounds -- measured noise needs

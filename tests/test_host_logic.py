@@ -240,3 +240,15 @@ def test_cpp_key_material_generator_is_chacha20_keyed_from_os_entropy(tmp_path):
     assert out[0] == ("block e4e7f110 15593bd1 1fdd0f50 c47120a3 c7f4d1c7 0368c033 9aaa2204 4e6cd4c3 "
                       "466482d2 09aa9f07 05d7c214 a2028bd9 d19c12b5 b94e16de e883d0cb 4e3c50a2")
     assert out[1:] == ["seeded 1 1", "entropy 1", "urbg 1"]
+
+
+def test_slab_arena_on_the_cpu(tmp_path):
+    """helib_amd/csrc/arena.h (the device-memory arena behind every DoubleCRT slab) with malloc standing in
+    for hipMalloc: no overlapping extents over 20 000 random operations, full coalescing, no system
+    allocation per step once a keep-the-results loop is warm, the HIP-graph pin / defer rules, and the
+    out-of-memory path."""
+    exe = str(tmp_path / "arena_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "arena_test.cpp"),
+                           "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "arena_test OK" in r.stdout, r.stdout + r.stderr
