@@ -3,17 +3,22 @@
 
 metric   : ciphertext x ciphertext multiplications per second, including relinearisation
            (Ctxt::multiplyBy; timed region of benchmarks/bgv_basic.cpp:144-165)
+host     : the timed loop is driven by the C++17 host -- include/helib_amd_ctxt.hpp / helib_amd_keys.hpp
+           (HElib's Ctxt / DoubleCRT / SecKey surface over the C ABI of include/helib_amd.h) compiled
+           into helib_amd/lib/libhelib_amd_host.so (helib_amd/csrc/host_session.cpp, include/helib_amd_host.h).
+           Keys, encryptions, the loop `copy = ctxt1; copy.multiplyBy(ctxt2)` and the decryption of the
+           results all run there; python starts the loop, synchronises, times and checks the plaintexts.
+           `config.python_mirror_mult_per_s` is the same sequence driven by helib_amd/ctxt.py (secondary).
 workload : (default `bgv32768`) BGV m=32768, p=65537, bits=950 -> L=16 x 60-bit ctxt primes,
            K=6 x 56-bit special primes, 6 small primes, D=3 digits (6/5/5) -- SURVEY.md Appendix B
            shape of BASELINE configs[2].  FRESH ciphertexts, the reference's own sequence:
              multLowLvl  = bringToSet x2 (mod-up by a small prime, mod-down by a ctxt prime,
                            4 parts) + tensorProduct
              reLinearize = dropSmallAndSpecialPrimes (3 parts) + addPrimesAndScale + key switch
-           with the operand copy outside the timed region (state.PauseTiming() in the reference).
            Inputs as the reference benchmark prepares them (benchmarks/bgv_basic.cpp:144-157): a key
-           pair + relinearisation matrix and public-key encryptions of random plaintexts
-           (helib_amd.keys); the last product is decrypted and checked (config.verified).
-           Host control flow = helib_amd.ctxt (restating src/Ctxt.cpp); polynomial work on the GPU.
+           pair + relinearisation matrix and public-key encryptions of random plaintexts; after the
+           timed region EVERY batch element of the last product is decrypted and compared with the
+           plaintext product (config.verified).
            Added noise is MEASURED as in the reference's default build (embeddingLargestCoeff of
            the mod-switch deltas and of the key-switch digits, src/Ctxt.cpp:466-530,
            src/DoubleCRT.cpp:530-545) -- on the device, read back when the host logic next needs
@@ -21,16 +26,19 @@ workload : (default `bgv32768`) BGV m=32768, p=65537, bits=950 -> L=16 x 60-bit 
            reference's alternative noise bounds (no norms).
            `config.fixed_level_mult_per_s` additionally reports tensorProduct+reLinearize alone
            (hx_mul_relin, no prime-set changes), the kernel-level pipeline DESIGN.md analyses.
+           `--workload ckks65536` = BASELINE configs[3]: ContextBuilder<CKKS>().m(65536).precision(20)
+           .bits(1400) (L=24, K=8, D=3), CKKSencrypt-ed pairs through Ctxt::multiplyBy
+           (benchmarks/ckks_basic.cpp:161-180), `--global-batch 512` split over the ranks; level 2
+           (product x product) reported beside it; every rank decodes and checks its slice.
 step     : `--mults-per-step` (32) x [copy(ctxt1); copy.multiplyBy(ctxt2)] over the batch of
            `--batch` (128) independent ciphertext pairs resident in HBM -- the loop body of
            benchmarks/bgv_basic.cpp:158-164, which also multiplies the same two operands every
            iteration -- i.e. 4096 ciphertext multiplications per step, so that the driver's 20 steps
-           time about 2.5 s of device work.  BOTH operand copies are inside the timed region (the
-           reference pauses its timer for copy(ctxt1); multiplyBy's own copy of `other`,
-           src/Ctxt.cpp:1700-1745, is timed there too).  A result is dropped once the next one is
-           complete (the reference's loop overwrites its ciphertext): the slab pool recycles storage.
-           After the timed region EVERY batch element of the last product is decrypted and compared
-           with the plaintext product (config.verified).
+           time about 2.5 s of device work.  Both operand copies (the reference's copy(ctxt1), untimed
+           there, and multiplyBy's own copy of `other`, src/Ctxt.cpp:1700-1745) are made inside the
+           timed region, but the engine's copies are copy-on-write and the fused mod-switch reads the
+           shared slab and writes elsewhere: no bytes move for them.  A result is dropped once the
+           next one is complete (the reference's loop overwrites its ciphertext).
 scaling  : weak (default) -- every rank multiplies its own `--batch` pairs; `--global-batch G` splits
            G pairs over the ranks instead (helib_amd.dist.shard; configs[3]: 512 pairs, 64 per GPU) =
            strong.  No data-path collective (independent ciphertexts shard across GPUs).
@@ -39,14 +47,18 @@ launch   : `bench.py --gpus N` without WORLD_SIZE in the environment spawns the 
            RCCL for the barrier and the max-over-ranks); under torch.distributed.run it checks
            --gpus against WORLD_SIZE.  `--dry-launch` exercises exactly that launch / shard /
            barrier / aggregate path with gloo on CPUs and no engine call (tests/test_dist_cpu.py).
-other    : --workload bgv32768_fixed (fixed-level only), ckks65536 (configs[3] shape, fixed level).
-
-Adds "roofline" for the dominant kernel (forward NTT at the launch shape of the key switch,
-timed with HIP events on the launch stream) and "cpu_baseline" (the CPU oracle = a port of the
-reference algorithm driven through the same sequence: `value` on one core, as the reference
-benchmarks run, `all_cores` with one process per host core, both on a bounded sample).
-other workloads: tools/bench_levels.py times the multiply one level further down (operands that
-carry special primes) for BGV and for the CKKS chain of configs[3], with decoded results checked.
+roofline : measured IN SITU: after the timed region a few more multiplies run with every kernel launch
+           bracketed by HIP events on its own stream (hx_profile_begin / _end, helib_amd/csrc/prof.h).
+           `roofline` is the time-dominant kernel at its dominant launch shape, `achieved` = its
+           algorithmic bytes per launch / its average duration inside the multiply; the whole
+           per-kernel table is `config.kernels_in_situ`; the forward row transform is reported both in
+           situ and back to back (`roofline.ntt_forward`).  `traffic` (HBM bytes from PMC counters)
+           cannot be collected inside this process: it is the RECORDED figure of the committed
+           rocprofv3 --pmc passes over the same launch shape (labelled so).
+other    : --workload bgv32768_fixed (fixed-level only, synthetic rows).
+cpu_baseline: the CPU oracle = a port of the reference algorithm driven through the same sequence:
+           `value` on one core, as the reference benchmarks run, `all_cores` with one process per host
+           core, both on a bounded sample.
 """
 import argparse
 import json
@@ -481,82 +493,138 @@ def bgv_basic_ops(hx, hc, cc, fa, fb, sk, msgs, sync, reps=8):
     return out
 
 
-def moddown_launch_set(hx, hc, cc, ctx, fa, fb, iters=6):
-    """The fused bringToSet launch set of a fresh multiply (all four operand parts in one call:
-    inverse transform of the dropped row + S + the mod-down apply kernel over nkeep rows), timed
-    with HIP events on the engine's stream.  Algorithmic bytes: per (part, batch) element the
-    dropped row in (8N), x and S out and back in once (4 x 8N), and per kept row c_r in + out (16N)."""
-    common = None
-    a, b = fa.clone(), fb.clone()
-    lo, hi = hc.Ctxt.computeIntervalForMul(a, b)
-    common = cc.modSizes.getSet4Size(lo, hi, a.primeSet, b.primeSet, cc.ckks)
-    add = sorted(set(common) - set(a.primeSet))
-    drop = sorted(set(a.primeSet) - set(common))
-    if len(drop) != 1 or not add:
-        return None
-    keep = sorted(common)
-    ms = []
-    for i in range(iters + 1):
-        a, b = fa.clone(), fb.clone()
-        parts = [a.parts["1"], a.parts["s"], b.parts["1"], b.parts["s"]]
+def run_session(sess, level, steps, warmup, R, sync, barrier, measure):
+    """The timed region, driven by the C++ host: `steps` x hxh_multiply(level, R) -- R x [copy(a);
+    copy.multiplyBy(b)] enqueued back to back by helib_amd/csrc/host_session.cpp (level 1: the two fresh
+    ciphertexts; level 2: the kept level-1 product with itself).  Returns (seconds, host seconds)."""
+    for _ in range(max(1, warmup)):
+        sess.multiply(level, R, measure)
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    host = 0.0
+    for _ in range(steps):
+        h0 = time.perf_counter()
+        sess.multiply(level, R, measure)
+        host += time.perf_counter() - h0
+    sync()
+    barrier()
+    return time.perf_counter() - t0, host
+
+
+# static instruction counts of the row-transform kernels per 512-thread workgroup (DESIGN.md 3.0; VALU
+# instructions per wave and row x 8 waves x 64 lanes) and their 64-bit modular multiplications per row
+VALU_PER_WAVE = {"ntt_row_kernel<14, false>": 5126, "ntt_row_kernel<14, true>": 4687,
+                 "ntt_moddown_apply_kernel<14, false>": 7003, "ntt_moddown_apply_kernel<14, true>": 6498}
+
+
+def kernel_table(prof, n, B, l, k, d, mults):
+    """Per-kernel view of an in-situ profile (hx_profile_end) of `mults` multiplies of the batch: time per
+    multiply, share, and -- where SURVEY 8(d) / DESIGN.md section 3 define them -- algorithmic bytes per
+    launch, achieved GB/s and the fraction of the 8 TB/s peak.  n = phi(m), l / k / d = ctxt primes /
+    special primes / digits of the ciphertext being multiplied."""
+    total = sum(kk["total_us"] for kk in prof["kernels"]) or 1.0
+    logn = n.bit_length() - 1
+    rows = []
+    for kk in prof["kernels"]:
+        name, w = kk["kernel"].replace("hx::", ""), kk["workgroups"]
+        byts, what = None, None
+        if name.startswith("ntt_row_kernel<") or name.startswith("ntt_moddown_prep"):
+            byts, what = 16 * n * w, "16N per row"
+        elif name.startswith("ntt_moddown_apply_kernel<") and name.endswith("false>"):
+            nk = l                                   # kept rows of a single-prime bringToSet at this level
+            el = max(1, w // nk)
+            # per element: c_r in + out on every kept row (the row the fused mod-up adds has no input), x and S once
+            byts, what = el * (nk * 16 * n - 8 * n + 16 * n), f"{el} elements x ({nk} kept rows x 16N - 8N (added row) + x,S 16N)"
+        elif name.startswith("ntt_moddown_apply_kernel<"):
+            byts, what = w * 24 * n, "delta/P in 8N + c_r in + out 16N per kept row"
+        elif name.startswith("tensor_kernel"):
+            byts, what = 56 * n * l * B, "(4 in + 3 out) x 8N per prime row"
+        elif name.startswith("keyswitch_kernel"):
+            ext = d * (l + k) - l
+            byts = 8 * n * (B * (ext + l + 2 * l + 2 * (l + k)) + 2 * d * (l + k))
+            what = "extension rows + s^2 rows + parts (1),(s) in, 2(L+K) rows out per element; key rows once per batch"
+        elif name.startswith("break_digits"):
+            byts, what = 8 * n * B * (l + d * (l + k) - l + d), "L rows in, D(L+K)-L extension rows + D fraction rows out"
+        elif name.startswith("moddown_S_kernel"):
+            byts, what = min(w, 8192) * 256 * 16, "x in, S out"
+        elif name.startswith("embed_norm_quarter_kernel<hx::NormSrcXS") or name.startswith("embed_norm_quarter_kernel<NormSrcXS"):
+            byts, what = w * 16 * n, "x and S in"
+        elif name.startswith("embed_norm_quarter"):
+            byts, what = w * 8 * n, "N doubles in"
+        row = {"kernel": name, "workgroups": w, "launches_per_multiply": round(kk["calls"] / mults, 3),
+               "avg_us": round(kk["avg_us"], 2), "min_us": round(kk["min_us"], 2), "max_us": round(kk["max_us"], 2),
+               "us_per_multiply": round(kk["total_us"] / mults, 2), "share": round(kk["total_us"] / total, 4)}
+        if byts:
+            ach = byts / (kk["avg_us"] * 1e-6) / 1e9
+            row.update({"algorithmic_bytes_per_launch": int(byts), "bytes_are": what, "achieved_GBps": round(ach, 1),
+                        "frac": round(ach / HBM_PEAK_GBS, 4)})
+        if name in VALU_PER_WAVE and logn == 14:
+            # SURVEY R1: the integer rate these kernels run at -- VALU lane-operations and 64-bit modular
+            # multiplications (Shoup products: N/2 log2 N butterflies, + 2N for the mod-down apply's load / store)
+            lane_ops = w * 8 * VALU_PER_WAVE[name] * 64
+            mm = w * (n // 2 * logn + (2 * n if "apply" in name else 0))
+            row["valu_lane_ops_per_s"] = float(f"{lane_ops / (kk['avg_us'] * 1e-6):.4g}")
+            row["modmul64_per_s"] = float(f"{mm / (kk['avg_us'] * 1e-6):.4g}")
+        rows.append(row)
+    return rows, total / mults
+
+
+def in_situ_profile(hx, sess, level, mults, sync):
+    """`mults` multiplies of the batch with every kernel launch bracketed by HIP events on its own stream."""
+    sess.multiply(level, 2, True)
+    sync()
+    hx.profileBegin()
+    sess.multiply(level, mults, True)
+    sync()
+    return hx.profileEnd()
+
+
+def config5_leg(hx, iters=5, batch=32):
+    """BASELINE configs[4]: Bluestein m=21845 (phi = 16384, convolution length 2^16), DoubleCRT of L=16 primes
+    from PrimeGenerator(60, 21845), forward and inverse transforms of `batch` objects (512 rows: the chip is
+    filled), timed with HIP events on the context's stream; algorithmic bytes = 16N per row."""
+    from helib_amd import hostnt
+    m, L = 21845, 16
+    g = hostnt.PrimeGen(60, m)
+    primes = [g.next() for _ in range(L)]
+    ctx = hx.Context(m)
+    for q in primes:
+        ctx.add_prime(q)
+    n = ctx.phim
+    rng = np.random.default_rng(5)
+    rows = uniform_rows(rng, primes, list(range(L)), batch, n)
+    d = hx.DoubleCRT(ctx, list(range(L)), batch, rows)
+    d.FFT()
+    d.iFFT()
+    ok = bool(np.array_equal(d.download(), rows))
+    out = {"workload": f"Bluestein m={m} phi={n} L={L} batch {batch} ({L * batch} rows), conv length 2^16",
+           "round_trip_exact": ok}
+    for name, fn in (("forward", d.FFT), ("inverse", d.iFFT)):
         ctx.timerBegin()
-        hx.bringToSetMulti(parts, add, keep, cc.ptxtSpace)
-        t = ctx.timerEnd()
-        if i:
-            ms.append(t)
-        del a, b, parts
-    n, B, nk = ctx.phim, fa.parts["1"].batch, len(keep)
-    elements = 4 * B
-    alg = elements * (8 * n + 4 * 8 * n + nk * 16 * n)
-    avg = sum(ms) / len(ms)
-    return {"launch_set": "hx_bring_to_set_multi: ntt_moddown_prep + moddown_S + ntt_moddown_apply "
-                          f"({elements} elements x {nk} kept rows)",
-            "avg_ms": round(avg, 4), "bytes": alg, "achieved": round(alg / (avg * 1e-3) / 1e9, 1),
-            "unit": "GB/s", "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-
-
-def cpp_host_rate(B, mults, mode=0):
-    """The same fresh multiply driven by the C++17 host header (include/helib_amd_ctxt.hpp):
-    tools/bench_cpp.cpp built here with g++ and run as its own process.  mode 0: noise bounds; 2: measured
-    noise with the norms read back lazily (Ctxt::deferNorms, as the python mirror does)."""
-    exe = os.path.join(ROOT, "tools", "bench_cpp.bin")
-    libdir = os.path.join(ROOT, "helib_amd", "lib")
-    try:
-        if mode == 0 or not os.path.exists(exe):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                                   os.path.join(ROOT, "tools", "bench_cpp.cpp"), "-L" + libdir, "-lhelib_amd",
-                                   "-Wl,-rpath," + libdir, "-o", exe], stderr=subprocess.DEVNULL)
-        out = subprocess.run([exe, str(B), str(mults), "3", str(mode)], capture_output=True, text=True,
-                             timeout=300 if mode == 0 else 90)
-        return json.loads(out.stdout.strip().splitlines()[-1])["value"]
-    except Exception as e:
-        return f"unavailable: {str(e)[:120]}"
-
-
-def level_lines():
-    """tools/bench_levels.py as its own processes: the multiply one level further down (operands that
-    carry the special primes of a previous key switch: the several-primes mod-switch in front of the
-    tensor product) next to the fresh one, for this workload and for the CKKS chain of BASELINE
-    configs[3] (benchmarks/ckks_basic.cpp:161-180 at m=65536, bits=1400 -> L=24, K=8); real keys and
-    encryptions, decrypted / decoded results checked there."""
-    out = {}
-    tool = os.path.join(ROOT, "tools", "bench_levels.py")
-    for name, extra in (("bgv32768", ["--scheme", "bgv", "--m", "32768", "--bits", "950", "--batch", "128"]),
-                        ("ckks65536", ["--batch", "64"])):
-        try:
-            r = subprocess.run([sys.executable, tool, "--steps", "6", *extra], capture_output=True, text=True,
-                               timeout=240)
-            d = json.loads(r.stdout.strip().splitlines()[-1])
-            keep = ("workload", "level1_fresh_mult_per_s", "level1_ms_per_step", "level2_mult_per_s",
-                    "level2_ms_per_step", "verified")
-            out[name] = {k: d[k] for k in keep if k in d}
-        except Exception as e:
-            out[name] = f"unavailable: {type(e).__name__}: {str(e)[:120]}"
+        for _ in range(iters):
+            fn()
+        ms = ctx.timerEnd() / iters
+        byts = 16.0 * n * L * batch
+        out[name] = {"ms": round(ms, 4), "ns_per_row": round(ms * 1e6 / (L * batch), 1),
+                     "achieved_GBps": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    hx.profileBegin()
+    d.FFT()
+    d.iFFT()
+    ctx.sync()
+    prof = hx.profileEnd()
+    tot = sum(kk["total_us"] for kk in prof["kernels"]) or 1.0
+    out["kernels_in_situ_fwd_plus_inv"] = [{"kernel": kk["kernel"].replace("hx::", ""), "workgroups": kk["workgroups"],
+                                            "calls": kk["calls"], "avg_us": round(kk["avg_us"], 1),
+                                            "share": round(kk["total_us"] / tot, 3)} for kk in prof["kernels"][:12]]
     return out
 
 
-def ntt_roofline(hx, ctx, primes_list, own, sp, digits, B, rng, iters):
-    """Forward NTT at the launch shape it has inside the key switch: D*(L+K)-L rows x B."""
+def ntt_back_to_back(hx, ctx, primes_list, own, sp, digits, B, rng, iters):
+    """The forward / inverse row transform alone, `iters` launches back to back at the launch shape the forward
+    transform has inside the key switch (D*(L+K)-L rows x B), HIP events on the launch stream.  This is the
+    favourable figure (warm tables, nothing else in the caches); the in-situ one is what a multiply is made of."""
     n = ctx.phim
     nrows = len(digits) * (len(own) + len(sp)) - len(own)
     digp = hx.DoubleCRT(ctx, own, B, uniform_rows(rng, primes_list, own, B, n))
@@ -566,18 +634,69 @@ def ntt_roofline(hx, ctx, primes_list, own, sp, digits, B, rng, iters):
     ms_inv = hx.time_ntt(dg, True, iters, nrows)
     ms_fwd = hx.time_ntt(dg, False, iters, nrows)
     bytes_launch = 16.0 * n * nrows * B             # 16*N bytes per row transform
-    ach = bytes_launch / (ms_fwd * 1e-3) / 1e9
-    kernel = f"ntt_row_kernel<{n.bit_length() - 1},fwd>"
-    traffic, src = recorded_traffic("r02_pmc_ntt_fwd_traffic.json", kernel, nrows * B, n)
-    if traffic is None:
-        traffic, src = recorded_traffic("r01_pmc_ntt_fwd_traffic.json", kernel, nrows * B, n)
-    return {"bound": "hbm", "kernel": kernel,
-            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_GBS, 4),
-            "traffic": traffic, "traffic_source": src,
-            "rows_per_launch": nrows * B,
-            "avg_launch_ms": round(ms_fwd, 4), "inverse_avg_launch_ms": round(ms_inv, 4),
-            "bytes_per_launch": bytes_launch}
+    return {"rows_per_launch": nrows * B, "bytes_per_launch": bytes_launch,
+            "forward_avg_launch_ms": round(ms_fwd, 4), "inverse_avg_launch_ms": round(ms_inv, 4),
+            "forward_frac": round(bytes_launch / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "inverse_frac": round(bytes_launch / (ms_inv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def make_roofline(table, n, B, l, k, d, b2b=None):
+    """`roofline` = the time-dominant kernel of the in-situ table at its dominant launch shape."""
+    with_bytes = [r for r in table if "frac" in r]
+    if not with_bytes:
+        return None
+    by_kernel = {}
+    for r in table:
+        by_kernel[r["kernel"]] = by_kernel.get(r["kernel"], 0.0) + r["us_per_multiply"]
+    dom_name = max(by_kernel, key=by_kernel.get)
+    cands = [r for r in with_bytes if r["kernel"] == dom_name] or with_bytes
+    dom = max(cands, key=lambda r: r["us_per_multiply"])
+    roof = {"bound": "hbm", "kernel": dom["kernel"], "measured": "in situ: HIP events around every launch of this kernel "
+            "inside the multiply sequence (hx_profile_begin/_end), on the stream it is launched on",
+            "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+            "frac_of_copy_ceiling": round(dom["achieved_GBps"] / HBM_COPY_GBS, 4),
+            "workgroups_per_launch": dom["workgroups"], "avg_launch_us": dom["avg_us"],
+            "bytes_per_launch": dom["algorithmic_bytes_per_launch"], "bytes_are": dom["bytes_are"],
+            "share_of_step": round(by_kernel[dom_name] / (sum(by_kernel.values()) or 1.0), 4),
+            "other_launch_shapes": [{kk: r[kk] for kk in ("workgroups", "avg_us", "achieved_GBps", "frac")}
+                                    for r in cands if r is not dom]}
+    for kk in ("valu_lane_ops_per_s", "modmul64_per_s"):
+        if kk in dom:
+            roof[kk] = dom[kk]
+    if "modmul64_per_s" in dom:
+        roof["int_ops_per_s"] = dom["modmul64_per_s"]
+        roof["int_ops_are"] = ("64-bit modular multiplications (Shoup products, 9 32-bit multiplier instructions each) per "
+                               "second over the chip; valu_lane_ops_per_s = static VALU instruction count x 64 lanes / time")
+    # recorded PMC traffic of the same kernel and launch shape (cannot be collected inside this process)
+    traffic, src = None, None
+    short = dom["kernel"].replace(", false>", ">").replace(", true>", ",plain>")
+    for rec in ("r03_pmc_moddown_apply_traffic.json", "r02_pmc_moddown_apply_traffic.json"):
+        t, sname = recorded_traffic(rec, short, dom["workgroups"], n)
+        if t is not None:
+            traffic, src = t, sname
+            break
+    roof["traffic"] = traffic
+    roof["traffic_kind"] = "recorded (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch shape)" if traffic else None
+    roof["traffic_source"] = src
+    fwd = [r for r in with_bytes if r["kernel"].startswith("ntt_row_kernel<") and r["kernel"].endswith("false>")]
+    inv = [r for r in with_bytes if r["kernel"].startswith("ntt_row_kernel<") and r["kernel"].endswith("true>")]
+    if fwd:
+        f = max(fwd, key=lambda r: r["us_per_multiply"])
+        roof["ntt_forward"] = {"kernel": f["kernel"], "workgroups_per_launch": f["workgroups"], "avg_launch_us_in_situ": f["avg_us"],
+                               "frac_in_situ": f["frac"]}
+        if b2b and b2b["rows_per_launch"] == f["workgroups"]:
+            roof["ntt_forward"].update({"avg_launch_us_back_to_back": round(b2b["forward_avg_launch_ms"] * 1e3, 2),
+                                        "frac_back_to_back": b2b["forward_frac"]})
+        for kk in ("valu_lane_ops_per_s", "modmul64_per_s"):
+            if kk in f:
+                roof["ntt_forward"][kk] = f[kk]
+    if inv:
+        f = max(inv, key=lambda r: r["us_per_multiply"])
+        roof["ntt_inverse"] = {"kernel": f["kernel"], "workgroups_per_launch": f["workgroups"], "avg_launch_us_in_situ": f["avg_us"],
+                               "frac_in_situ": f["frac"]}
+        if b2b:
+            roof["ntt_inverse"]["frac_back_to_back_at_the_forward_shape"] = b2b["inverse_frac"]
+    return roof
 
 
 def recorded_traffic(name, kernel, rows, n):
@@ -645,7 +764,7 @@ def dry_rank(args):
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
                           "scaling": "strong" if args.global_batch else "weak",
-                          "config": {"pairs_all_ranks": int(pairs), "last_rank_start": int(firsts),
+                          "config": {"workload": args.workload, "pairs_all_ranks": int(pairs), "last_rank_start": int(firsts),
                                      "batch_this_rank": count}}))
     group.close()
 
@@ -655,7 +774,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="independent ciphertext pairs per GPU per launch set")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="independent ciphertext pairs per GPU per launch set (default 128; ckks65536: 64)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="split this many pairs over the ranks (strong scaling; configs[3]: 512) instead of --batch per rank")
     ap.add_argument("--mults-per-step", type=int, default=32,
@@ -663,15 +783,18 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=60, help="multiplies timed on the CPU (0 = skip); 60 = about 15 s of one core")
     ap.add_argument("--ntt-iters", type=int, default=50)
     ap.add_argument("--workload", default="bgv32768", choices=["bgv32768", "bgv32768_fixed", "ckks65536"])
-    ap.add_argument("--inputs", default="real", choices=["real", "uniform"],
-                    help="bgv32768: real keys + encryptions (the product is decrypted and checked) or uniform rows")
-    ap.add_argument("--bits", type=int, default=950,
-                    help="bgv32768 only: ContextBuilder::bits; 950 = the L~16 shape the metric is quoted on, "
-                         "6400 = the reference's own benchmarks/bgv_basic.cpp:247 parameter (L=107, K=36)")
-    ap.add_argument("--no-extras", action="store_true", help="skip batch-1 latency, C++ host and launch-set legs")
+    ap.add_argument("--bits", type=int, default=0,
+                    help="ContextBuilder::bits; bgv32768: 950 = the L~16 shape the metric is quoted on, 6400 = the reference's "
+                         "own benchmarks/bgv_basic.cpp:247 parameter (L=107, K=36); ckks65536: 1400 (L=24, K=8)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary legs (python mirror, batch-1 latency, op list, levels of the other scheme, config 5)")
     ap.add_argument("--dry-launch", action="store_true", help="N-rank launch/aggregation path on CPUs (gloo), no engine")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if not args.batch:
+        args.batch = 64 if args.workload == "ckks65536" else 128
+    if not args.bits:
+        args.bits = 1400 if args.workload == "ckks65536" else 950
 
     if args.cpu_worker:   # one process of the all-cores CPU baseline: no torch, no GPU
         from helib_amd import ctxt as hc
@@ -692,7 +815,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     torch.cuda.set_device(local_rank)
     group = hdist.Group(backend="nccl", device=torch.device("cuda", local_rank))
-    from helib_amd import capi as hx, ctxt as hc
+    from helib_amd import capi as hx, ctxt as hc, host as hh
 
     B = hdist.shard(args.global_batch, world, rank)[1] if args.global_batch else args.batch
     if B < 1:
@@ -703,103 +826,178 @@ def main():
     sync = torch.cuda.synchronize
     stream = torch.cuda.current_stream().cuda_stream
     extra, roof, cpu = {}, None, None
+    extras = not args.no_extras and world == 1            # (N > 1: the ranks end together)
+    steps4 = max(1, args.steps // 4)
 
-    if args.workload == "bgv32768":
-        cc = hc.ChainContext(32768, 65537, 1, bits=args.bits, c=3)
-        ctx = hx.Context(cc.m, local_rank)
-        for q in cc.primes:
-            ctx.add_prime(q)  # root = FindPrimRootT(q, m): the host-supplied root convention
-        ctx.set_stream(stream)
-        n = ctx.phim
-        l, k, d = len(cc.ctxtPrimes), len(cc.specialPrimes), len(cc.digits)
-        hc.Ctxt.measure = True
-        prepared = real_inputs(hx, hc, cc, ctx, B, 7 + rank) if args.inputs == "real" else None
-        dtb, _, host_b, _, enq_b = run_fresh(hx, hc, cc, ctx, B, max(1, args.steps // 4), args.warmup, rng, sync,
-                                      group.barrier, measure=False, inputs=args.inputs, prepared=prepared,
-                                      mults_per_step=R, verify=False)
-        dtb = group.max_over_ranks(dtb) / max(1, args.steps // 4) * args.steps
-        host_b = host_b / max(1, args.steps // 4) * args.steps
-        dt, res_primes, host_s, nver, _ = run_fresh(hx, hc, cc, ctx, B, args.steps, args.warmup, rng, sync,
-                                                 group.barrier, measure=True, inputs=args.inputs,
-                                                 prepared=prepared, mults_per_step=R)
+    if args.workload in ("bgv32768", "ckks65536"):
+        ckks = args.workload == "ckks65536"
+        # ---- the C++17 host: context, keys, encryptions, the multiply loop, the decryptions ----
+        t0 = time.perf_counter()
+        sess = (hh.Session("ckks", 65536, -1, 20, args.bits, B, device=local_rank, stream=stream, seed=7 + rank) if ckks else
+                hh.Session("bgv", 32768, 65537, 1, args.bits, B, device=local_rank, stream=stream, seed=7 + rank))
+        sync()
+        t_setup = time.perf_counter() - t0
+        n, l, k, d = sess.phim, sess.L_ctxt, sess.K, sess.D
+        dtb, host_b = run_session(sess, 1, steps4, args.warmup, R, sync, group.barrier, measure=False)
+        dtb = group.max_over_ranks(dtb) / steps4 * args.steps
+        host_b = host_b / steps4 * args.steps
+        dt, host_s = run_session(sess, 1, args.steps, args.warmup, R, sync, group.barrier, measure=True)
         dt = group.max_over_ranks(dt)
-        # the kernel-level pipeline alone (ctxt primes as rows 0.., specials after)
-        shape = dict(M=cc.m, L=l, K=k, digits=[[i - cc.ctxtPrimes[0] for i in dg] for dg in cc.digits])
-        sub = hx.Context(cc.m, local_rank)
-        fixed_primes = [cc.primes[i] for i in cc.ctxtPrimes + cc.specialPrimes]
-        for q in fixed_primes:
-            sub.add_prime(q)
-        sub.set_stream(stream)
-        dtf = run_fixed(hx, sub, fixed_primes, shape, B, args.steps * R, args.warmup, rng, sync, group.barrier)
-        dtf = group.max_over_ranks(dtf)
-        workload = (f"BGV m=32768 p=65537 bits={args.bits} (L={l}x{cc.primes[cc.ctxtPrimes[0]].bit_length()}b, "
-                    f"K={k}x{cc.primes[cc.specialPrimes[0]].bit_length()}b, {len(cc.smallPrimes)} small primes, "
-                    f"D={d} {'/'.join(str(len(g)) for g in cc.digits)}): "
-                    "Ctxt::multiplyBy on FRESH ciphertexts = multLowLvl (bringToSet x2 + tensorProduct) + "
-                    "reLinearize (dropSmallAndSpecialPrimes + key switch), added noise MEASURED as in the "
-                    "reference (device canonical-embedding norms, read back lazily); "
-                    f"step = {R} x [copy(ctxt1); copy.multiplyBy(ctxt2)] over the {B}-pair batch, both operand "
-                    "copies timed; synthetic random plaintexts")
-        per_mult = algorithmic_bytes_fresh(n, l, k, d)
+        nver = sess.verify(1)                              # every batch element of the last product, on every rank
+        res_primes = sess.result_primes(1)
+        prof1 = in_situ_profile(hx, sess, 1, 4, sync) if rank == 0 else None
+        # level 2: the kept product with itself (operands that carry the special primes of a key switch)
+        dt2, _ = run_session(sess, 2, steps4, 1, R, sync, group.barrier, measure=True)
+        dt2 = group.max_over_ranks(dt2)
+        nver2 = sess.verify(2)
+        prof2 = in_situ_profile(hx, sess, 2, 2, sync) if (rank == 0 and extras) else None
+        nver_all = int(group.sum_over_ranks(nver))
+        nver2_all = int(group.sum_over_ranks(nver2))
         mults = pairs_all * R * args.steps
-        extra = {"mults_per_step": R, "multiplications_per_step_all_ranks": pairs_all * R,
+        scheme = (f"CKKS m=65536 precision=20 bits={args.bits}" if ckks else f"BGV m=32768 p=65537 bits={args.bits}")
+        workload = (f"{scheme} (L={l}x{sess.ctxt_bits}b, K={k}x{sess.special_bits}b, {sess.n_small} small primes, D={d}): "
+                    + ("Ctxt::multiplyBy on CKKSencrypt-ed ciphertexts = tensorProduct + relin_CKKS_adjust + key switch at the full "
+                       "level (a fresh CKKS ciphertext has nothing to mod-switch), benchmarks/ckks_basic.cpp:161-180; "
+                       if ckks else
+                       "Ctxt::multiplyBy on FRESH ciphertexts = multLowLvl (bringToSet x2 + tensorProduct) + reLinearize "
+                       "(dropSmallAndSpecialPrimes + key switch), benchmarks/bgv_basic.cpp:144-165; ")
+                    + "added noise MEASURED as in the reference (device canonical-embedding norms, read back lazily); the loop is "
+                      "driven by the C++17 host (libhelib_amd_host.so); "
+                    f"step = {R} x [copy(ctxt1); copy.multiplyBy(ctxt2)] over the {B}-pair batch -- both operand copies are made "
+                    "inside the timed region but are copy-on-write: no bytes move for them; synthetic random plaintexts")
+        if ckks:
+            # level 1 at the full level: the fixed-level formula; level 2 adds the several-primes mod-switches
+            per_mult = algorithmic_bytes_fixed(n, l, k, d)
+        else:
+            per_mult = algorithmic_bytes_fresh(n, l, k, d)
+        extra = {"host": "C++17: include/helib_amd_ctxt.hpp + helib_amd_keys.hpp in helib_amd/lib/libhelib_amd_host.so "
+                         "(helib_amd/csrc/host_session.cpp); python only times and checks",
+                 "mults_per_step": R, "multiplications_per_step_all_ranks": pairs_all * R,
                  "timed_region_s": round(dt, 3),
                  "bound_noise_mult_per_s": round(mults / dtb, 1),
                  "bound_noise_ms_per_step": round(dtb / args.steps * 1e3, 4),
-                 "fixed_level_mult_per_s": round(mults / dtf, 1),
-                 "fixed_level_ms_per_mult_batch": round(dtf / (args.steps * R) * 1e3, 4),
-                 "fixed_level_algorithmic_MB_per_mult": round(algorithmic_bytes_fixed(n, l, k, d) / 1e6, 2),
-                 # host time to enqueue a step: with measured noise it contains the waits for the
-                 # norm read-backs; the bound-noise run has no waits and is the pure enqueue cost
+                 # host time to enqueue a step: with measured noise it contains the waits for the norm read-backs;
+                 # the bound-noise run has no waits and is the enqueue cost (throttled by the HIP queue once it is full)
                  "host_ms_per_step_incl_norm_waits": round(host_s / args.steps * 1e3, 4),
                  "host_enqueue_ms_per_step": round(host_b / args.steps * 1e3, 4),
-                 # one multiply enqueued on an idle device, noise bounds (no read-backs): the host's own cost
-                 "host_enqueue_ms_per_mult_from_idle": round(enq_b * 1e3, 4),
+                 "setup_s_keys_and_encryptions": round(t_setup, 2),
                  "result_primes": res_primes,
-                 "inputs": ("key pair, relinearisation matrix and public-key encryptions of random plaintexts "
-                            "from helib_amd.keys (as benchmarks/bgv_basic.cpp:144-157)" if args.inputs == "real"
-                            else "uniform rows, no keys"),
-                 "verified": (f"decrypt(last product) == m_a*m_b mod (X^N+1, p) for all {nver} batch elements"
-                              if nver else None)}
+                 "inputs": ("key pair, relinearisation matrix and public-key encryptions of random plaintexts made by the C++ "
+                            "host (helib_amd_keys.hpp: SecKey::GenSecKey, Encrypt / CKKSencrypt), as benchmarks/bgv_basic.cpp:144-157"),
+                 "verified": (f"decrypt(last product) == plaintext product mod (X^N+1{'' if ckks else ', p'}) for all {nver_all} batch "
+                              f"elements of all ranks" + (" (decoded, within the error bound the ciphertext reports)" if ckks else "")),
+                 "level2": {"what": "product x product: both operands carry the special primes of the previous key switch "
+                                    "(the several-primes mod-switch in front of the tensor product)",
+                            "mult_per_s": round(pairs_all * R * steps4 / dt2, 1),
+                            "ms_per_mult_of_the_batch": round(dt2 / (steps4 * R) * 1e3, 4),
+                            "over_level1": round((dt2 / steps4) / (dt / args.steps), 3),
+                            "verified_elements": nver2_all, "result_primes": sess.result_primes(2)}}
         if rank == 0:
-            rec = os.path.join(ROOT, "profiles", "r02_pmc_fresh_multiply_traffic.json")
-            if os.path.exists(rec):
-                with open(rec) as f:
-                    tr = json.load(f)
-                if tr.get("batch") == B and tr.get("bits") == args.bits:
-                    gb = tr["traffic_GB_per_multiply_of_the_batch"]
-                    # HBM bytes actually moved (PMC passes, recorded): all kernels of one step
-                    extra["hbm_traffic_GB_per_step"] = round(gb * R, 1)
-                    extra["hbm_traffic_avg_TBps_over_the_step"] = round(gb * R / (dt / args.steps) / 1e3, 2)
-                    extra["hbm_traffic_source"] = "profiles/r02_pmc_fresh_multiply_traffic.json"
-            roof = ntt_roofline(hx, sub, fixed_primes, list(range(l)), list(range(l, l + k)),
-                                shape["digits"], B, rng, args.ntt_iters)
-            if args.inputs == "real" and not args.no_extras and world == 1:   # (N > 1: the ranks end together)
-                fa, fb, _, sk, msgs = prepared
-                try:
-                    extra["bgv_basic_ops"] = bgv_basic_ops(hx, hc, cc, fa, fb, sk, msgs, sync)
-                except Exception as e:   # (a wrong result is a SystemExit and still aborts the bench)
-                    extra["bgv_basic_ops"] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
-                med, best, gms = batch1_latency(hx, hc, fa, fb, sync)
-                extra["batch1_latency_ms"] = round(med, 4)
-                extra["batch1_latency_ms_min"] = round(best, 4)
-                # one hipGraphLaunch per multiply (noise bounds): [median, min] in ms
-                extra["batch1_latency_hip_graph_ms"] = [round(v, 4) for v in gms] if isinstance(gms, tuple) else gms
-                md = moddown_launch_set(hx, hc, cc, ctx, fa, fb)
-                if md:
-                    t, src = recorded_traffic("r02_pmc_moddown_apply_traffic.json", "ntt_moddown_apply_kernel<14>",
-                                              4 * B * (l + 1 - 1), n)
-                    md["traffic"], md["traffic_source"] = t, src
-                    roof["other_launch_sets"] = {"fused_bringToSet": md}
+            table, us_per_mult = kernel_table(prof1, n, B, l, k, d, 4)
+            extra["kernels_in_situ"] = {"what": "one multiply of the batch, every launch bracketed by HIP events on its stream "
+                                                "(4 multiplies profiled after the timed region)",
+                                        "kernel_us_per_multiply_of_the_batch": round(us_per_mult, 1),
+                                        "wall_us_per_multiply_of_the_batch": round(dt / (args.steps * R) * 1e6, 1),
+                                        "dropped_launch_records": prof1["dropped"], "kernels": table[:16]}
+            if prof2:
+                t2, us2 = kernel_table(prof2, n, B, l, k, d, 2)
+                extra["level2"]["kernels_in_situ"] = [{kk: r[kk] for kk in ("kernel", "workgroups", "launches_per_multiply", "avg_us",
+                                                                            "us_per_multiply", "share")} for r in t2[:14]]
+            b2b = None
+            if not ckks:
+                # the kernel-level pipeline alone (ctxt primes as rows 0.., specials after) + the back-to-back transform
+                cc = hc.ChainContext(32768, 65537, 1, bits=args.bits, c=3)
+                shape = dict(M=cc.m, L=l, K=k, digits=[[i - cc.ctxtPrimes[0] for i in dg] for dg in cc.digits])
+                sub = hx.Context(cc.m, local_rank)
+                fixed_primes = [cc.primes[i] for i in cc.ctxtPrimes + cc.specialPrimes]
+                for q in fixed_primes:
+                    sub.add_prime(q)
+                sub.set_stream(stream)
+                if world == 1:
+                    dtf = run_fixed(hx, sub, fixed_primes, shape, B, args.steps * R, args.warmup, rng, sync, lambda: None)
+                    extra["fixed_level_mult_per_s"] = round(B * R * args.steps / dtf, 1)
+                    extra["fixed_level_ms_per_mult_batch"] = round(dtf / (args.steps * R) * 1e3, 4)
+                    extra["fixed_level_algorithmic_MB_per_mult"] = round(algorithmic_bytes_fixed(n, l, k, d) / 1e6, 2)
+                b2b = ntt_back_to_back(hx, sub, fixed_primes, list(range(l)), list(range(l, l + k)), shape["digits"], B, rng,
+                                       args.ntt_iters)
+                rec = os.path.join(ROOT, "profiles", "r02_pmc_fresh_multiply_traffic.json")
+                if os.path.exists(rec):
+                    with open(rec) as f:
+                        tr = json.load(f)
+                    if tr.get("batch") == B and tr.get("bits") == args.bits:
+                        gb = tr["traffic_GB_per_multiply_of_the_batch"]
+                        extra["hbm_traffic_GB_per_step_recorded"] = round(gb * R, 1)
+                        extra["hbm_traffic_avg_TBps_over_the_step_recorded"] = round(gb * R / (dt / args.steps) / 1e3, 2)
+                        extra["hbm_traffic_source"] = ("recorded, not measured in this run: profiles/r02_pmc_fresh_multiply_traffic.json "
+                                                       "(rocprofv3 --pmc passes over the same sequence, round-2 kernels)")
+            roof = make_roofline(table, n, B, l, k, d, b2b)
+            if extras:
                 sync()
-                extra["cpp_host_mult_per_s"] = cpp_host_rate(B, 40)
-                extra["cpp_host_measured_noise_mult_per_s"] = cpp_host_rate(B, 40, mode=2)
-                extra["levels"] = level_lines()
-            if args.cpu_sample > 0 and world == 1:
+                ts = []
+                for i in range(14):                      # one ciphertext pair at a time, as benchmarks/bgv_basic.cpp:158-164 times it
+                    sync()
+                    t0 = time.perf_counter()
+                    sess.multiply_single(True)
+                    sync()
+                    if i >= 2:
+                        ts.append((time.perf_counter() - t0) * 1e3)
+                ts.sort()
+                extra["batch1_latency_ms"] = round(ts[len(ts) // 2], 4)
+                extra["batch1_latency_ms_min"] = round(ts[0], 4)
+                try:
+                    extra["config5_bluestein"] = config5_leg(hx)
+                except Exception as e:
+                    extra["config5_bluestein"] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
+                other = "ckks65536" if not ckks else "bgv32768"
+                try:                                        # the two levels of the other scheme, same host
+                    so = (hh.Session("ckks", 65536, -1, 20, 1400, 64, device=local_rank, stream=stream, seed=17) if not ckks else
+                          hh.Session("bgv", 32768, 65537, 1, 950, 128, device=local_rank, stream=stream, seed=17))
+                    o1, _ = run_session(so, 1, 2, 1, 8, sync, lambda: None, True)
+                    v1 = so.verify(1, elements=[0, so.batch - 1])
+                    o2, _ = run_session(so, 2, 2, 1, 8, sync, lambda: None, True)
+                    v2 = so.verify(2, elements=[0, so.batch - 1])
+                    extra["levels_" + other] = {"workload": ("CKKS m=65536 precision=20 bits=1400" if not ckks else "BGV m=32768 p=65537 bits=950")
+                                                + f": L={so.L_ctxt}, K={so.K}, D={so.D}, batch {so.batch}, noise measured, C++ host",
+                                                "level1_mult_per_s": round(so.batch * 16 / o1, 1), "level1_ms_per_mult_of_the_batch": round(o1 / 16 * 1e3, 3),
+                                                "level2_mult_per_s": round(so.batch * 16 / o2, 1), "level2_ms_per_mult_of_the_batch": round(o2 / 16 * 1e3, 3),
+                                                "level2_over_level1": round(o2 / o1, 3), "verified_elements": [v1, v2]}
+                    so.close()
+                    del so
+                except Exception as e:
+                    extra["levels_" + other] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
+                if not ckks:
+                    # the python mirror of the same host logic (helib_amd/ctxt.py + keys.py): secondary figure, the
+                    # reference's other benchmark lines, and the HIP-graph replay of one multiply
+                    try:
+                        cc = hc.ChainContext(32768, 65537, 1, bits=args.bits, c=3)
+                        pctx = hx.Context(cc.m, local_rank)
+                        for q in cc.primes:
+                            pctx.add_prime(q)
+                        pctx.set_stream(stream)
+                        prepared = real_inputs(hx, hc, cc, pctx, B, 7 + rank)
+                        dtp, _, _, nvp, enq = run_fresh(hx, hc, cc, pctx, B, steps4, 1, rng, sync, lambda: None, measure=True,
+                                                        prepared=prepared, mults_per_step=R)
+                        extra["python_mirror_mult_per_s"] = round(B * R * steps4 / dtp, 1)
+                        extra["python_mirror_host_enqueue_ms_per_mult_from_idle"] = round(enq * 1e3, 4)
+                        fa, fb, _, sk, msgs = prepared
+                        extra["bgv_basic_ops"] = bgv_basic_ops(hx, hc, cc, fa, fb, sk, msgs, sync)
+                        _, _, gms = batch1_latency(hx, hc, fa, fb, sync)
+                        extra["batch1_latency_hip_graph_ms"] = [round(v, 4) for v in gms] if isinstance(gms, tuple) else gms
+                    except SystemExit:
+                        raise
+                    except Exception as e:
+                        extra["python_mirror"] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
+            if args.cpu_sample > 0 and world == 1 and not ckks:
+                cc = hc.ChainContext(32768, 65537, 1, bits=args.bits, c=3)
                 cpu = cpu_baseline_fresh(cc, max(1, args.cpu_sample // 2))
                 cpu["all_cores"] = cpu_baseline_all_cores(args.bits, max(1, args.cpu_sample // 4))
-                cpu["fixed_level_value"] = cpu_baseline_fixed(
-                    dict(M=cc.m, L=l, K=k, digits=shape["digits"]), fixed_primes, args.cpu_sample)["value"]
+                shape = dict(M=cc.m, L=l, K=k, digits=[[i - cc.ctxtPrimes[0] for i in dg] for dg in cc.digits])
+                cpu["fixed_level_value"] = cpu_baseline_fixed(shape, [cc.primes[i] for i in cc.ctxtPrimes + cc.specialPrimes],
+                                                              args.cpu_sample)["value"]
+            elif args.cpu_sample > 0 and world == 1:
+                shape = SHAPES["ckks65536"]
+                cpu = cpu_baseline_fixed(shape, gen_primes(shape), max(2, args.cpu_sample // 6))
+        sess.close()
     else:
         shape = SHAPES[args.workload]
         primes = gen_primes(shape)
@@ -811,13 +1009,17 @@ def main():
         l, k, d = shape["L"], shape["K"], len(shape["digits"])
         dt = run_fixed(hx, ctx, primes, shape, B, args.steps * R, args.warmup, rng, sync, group.barrier)
         dt = group.max_over_ranks(dt)
-        workload = shape["name"] + f"; step = {R} multiplications of the {B}-pair batch"
+        workload = shape["name"] + f"; synthetic uniform rows; step = {R} multiplications of the {B}-pair batch"
         per_mult = algorithmic_bytes_fixed(n, l, k, d)
         extra = {"mults_per_step": R, "multiplications_per_step_all_ranks": pairs_all * R,
                  "timed_region_s": round(dt, 3)}
         if rank == 0:
-            roof = ntt_roofline(hx, ctx, primes, list(range(l)), list(range(l, l + k)), shape["digits"], B,
-                                rng, args.ntt_iters)
+            b2b = ntt_back_to_back(hx, ctx, primes, list(range(l)), list(range(l, l + k)), shape["digits"], B, rng, args.ntt_iters)
+            by = b2b["bytes_per_launch"]
+            ach = by / (b2b["forward_avg_launch_ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": f"ntt_row_kernel<{n.bit_length() - 1}, false>", "measured": "back to back (HIP events)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": None, "bytes_per_launch": by, "rows_per_launch": b2b["rows_per_launch"]}
             if args.cpu_sample > 0 and world == 1:
                 cpu = cpu_baseline_fixed(shape, primes, args.cpu_sample)
 
@@ -829,7 +1031,7 @@ def main():
                "roofline_note": ("algorithmic_MB_per_mult counts the reference-equivalent unfused sequence with "
                                  "per-multiply key rows (SURVEY 8d); value / hbm_roofline_mult_per_s_per_gpu is "
                                  "therefore not an efficiency -- the per-kernel fractions under `roofline` and "
-                                 "hbm_traffic_GB_per_step (bytes actually moved, PMC) are")}
+                                 "`config.kernels_in_situ` are")}
         cfg.update(extra)
         line = {"metric": "ctxt_x_ctxt_mults_per_sec_incl_relinearize",
                 "value": round(pairs_all * R * args.steps / dt, 1), "unit": "mult/s", "n_gpus": world,

@@ -57,7 +57,29 @@ def build(force=False, extra_flags=(), verbose=False):
             list(ex.map(run, jobs))
     if jobs or force or _stale(SO, objs):
         run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs])
+    build_host(force=force, verbose=verbose)
     return SO
+
+
+HOST_SO = os.path.join(LIBDIR, "libhelib_amd_host.so")
+
+
+def build_host(force=False, verbose=False, link_dir=None, link_lib="helib_amd", out=None):
+    """The C++17 host (include/helib_amd_ctxt.hpp, helib_amd_keys.hpp) as a shared library behind
+    include/helib_amd_host.h: plain g++, linked against libhelib_amd.so (tests link it against their CPU
+    stand-in for the C ABI instead)."""
+    inc = os.path.join(HERE, "..", "include")
+    src = os.path.join(CSRC, "host_session.cpp")
+    out = out or HOST_SO
+    deps = [src] + [os.path.join(inc, h) for h in os.listdir(inc)]
+    if not (force or _stale(out, deps)):
+        return out
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-I" + inc, src, "-L" + (link_dir or LIBDIR),
+           "-l" + link_lib, "-Wl,-rpath," + (link_dir or "$ORIGIN"), "-o", out]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
 
 
 if __name__ == "__main__":

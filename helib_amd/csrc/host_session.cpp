@@ -1,0 +1,306 @@
+// host_session.cpp -- the C++17 host (include/helib_amd_ctxt.hpp, helib_amd_keys.hpp) compiled into
+// libhelib_amd_host.so behind the C ABI of include/helib_amd_host.h: the reference's benchmark loops
+// (benchmarks/bgv_basic.cpp:144-165, benchmarks/ckks_basic.cpp:161-180) with the C++ Ctxt /
+// DoubleCRT / SecKey on the timed path.  Host code only: every polynomial operation goes through
+// libhelib_amd.so (include/helib_amd.h); there is no CPU arithmetic path here.
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/helib_amd_host.h"
+#include "../../include/helib_amd_keys.hpp"
+
+using namespace helib_amd;
+
+static thread_local std::string g_err;
+extern "C" const char* hxh_last_error(void) { return g_err.c_str(); }
+
+struct hxh_session {
+  int scheme = 0, batch = 1;
+  std::unique_ptr<ChainContext> cc;
+  std::unique_ptr<Context> dev;
+  std::unique_ptr<SecKey> sk;
+  std::vector<double> ptxt[2];                 // [b][j]
+  std::unique_ptr<Ctxt> fresh[2];              // the two batched operands
+  std::unique_ptr<Ctxt> fresh1[2];             // batch element 0 alone
+  std::unique_ptr<Ctxt> prod[3];               // kept products: [1] level 1, [2] level 2
+  // host copies of a kept product's rows (hxh_decrypt slices elements out of them)
+  struct HostParts {
+    bool valid = false;
+    std::vector<std::pair<SKHandle, std::vector<uint64_t>>> rows;
+    std::vector<IndexSet> idx;
+  } host[3];
+};
+
+template <class F>
+static int guarded(F&& f)
+{
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  } catch (...) {
+    g_err = "unknown exception";
+    return -1;
+  }
+}
+
+static uint64_t sm64(uint64_t& s)
+{
+  uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+extern "C" int hxh_session_create(hxh_session** out, int device, void* stream, int scheme, long m, long p, long r,
+                                  long bits, int batch, uint64_t seed)
+{
+  if (!out || batch < 1 || (scheme != 0 && scheme != 1)) {
+    g_err = "hxh_session_create: bad argument";
+    return -1;
+  }
+  return guarded([&] {
+    auto s = std::make_unique<hxh_session>();
+    s->scheme = scheme;
+    s->batch = batch;
+    const bool ckks = scheme == 1;
+    s->cc = std::make_unique<ChainContext>(m, ckks ? -1 : p, r, bits, 3, 3.2, 10.0, 0, 3, 0, ckks);
+    const ChainContext& cc = *s->cc;
+    s->dev = cc.makeDeviceContext(device);
+    s->dev->setStream(stream);
+    s->sk = seed ? std::make_unique<SecKey>(cc, *s->dev, seed) : std::make_unique<SecKey>(cc, *s->dev);
+    s->sk->GenSecKey(2);   // s^2 -> s: what multiplyBy relinearises with (benchmarks/bgv_basic.cpp:150-152)
+    const size_t N = (size_t)cc.phim, L = cc.ctxtPrimes.size(), B = (size_t)batch;
+    uint64_t ps = seed * 0x9e3779b97f4a7c15ull + 12345;
+    const double f = std::ldexp(1.0, (int)r);
+    std::vector<uint64_t> packed[2][2];   // [operand][part] : [row][b][N]
+    for (int j = 0; j < 2; j++) {
+      s->ptxt[j].resize(B * N);
+      for (int part = 0; part < 2; part++)
+        packed[j][part].resize(L * B * N);
+      for (size_t b = 0; b < B; b++) {
+        std::vector<long> msg(N);
+        for (size_t i = 0; i < N; i++) {
+          if (ckks) {
+            // reals in [-1, 1] / phi(m): canonical embedding at most 1 (benchmarks/ckks_basic.cpp fills slots with small reals)
+            const double v = ((double)(sm64(ps) >> 11) / 9007199254740992.0 * 2.0 - 1.0) / (double)N;
+            msg[i] = (long)std::llrint(v * f);
+            s->ptxt[j][b * N + i] = (double)msg[i] / f;
+          } else {
+            msg[i] = (long)(((unsigned __int128)sm64(ps) * (uint64_t)cc.ptxtSpace) >> 64);
+            s->ptxt[j][b * N + i] = (double)msg[i];
+          }
+        }
+        Ctxt ct = ckks ? s->sk->CKKSencrypt(msg, 1.0, f) : s->sk->Encrypt(msg);
+        if (b == 0)
+          s->fresh1[j] = std::make_unique<Ctxt>(ct);
+        const SKHandle h[2] = {SKHandle{0, 1}, SKHandle{1, 1}};
+        for (int part = 0; part < 2; part++) {
+          const DoubleCRT& d = ct.parts.at(h[part]);
+          if (d.getIndexSet() != cc.ctxtPrimes)
+            throw LogicError("a fresh ciphertext is not on the ctxt primes");
+          const std::vector<uint64_t> rows = d.getRows();   // [row][1][N]
+          for (size_t row = 0; row < L; row++)
+            memcpy(&packed[j][part][(row * B + b) * N], &rows[row * N], N * 8);
+        }
+        if (b == 0) {
+          // the batched operand carries the bookkeeping of its first element (identical for every
+          // element: it depends on the parameters only, not on the random draws -- checked below)
+          s->fresh[j] = std::make_unique<Ctxt>(cc, *s->dev, s->sk->keys);
+          Ctxt& bt = *s->fresh[j];
+          bt.primeSet = ct.primeSet;
+          bt.ptxtSpace = ct.ptxtSpace;
+          bt.intFactor = ct.intFactor;
+          bt.lnNoise = (double)ct.lnNoise;
+          bt.ptxtMag = ct.ptxtMag;
+          bt.lnRatFactor = ct.lnRatFactor;
+        } else {
+          const Ctxt& bt = *s->fresh[j];
+          if (std::fabs(bt.lnRatFactor - ct.lnRatFactor) > 1e-12 || bt.primeSet != ct.primeSet ||
+              bt.intFactor != ct.intFactor)
+            throw LogicError("batch elements disagree in their bookkeeping");
+          // (a batched ciphertext's noise estimate is the largest of its elements')
+          if ((double)ct.lnNoise > (double)bt.lnNoise)
+            s->fresh[j]->lnNoise = (double)ct.lnNoise;
+        }
+      }
+      for (int part = 0; part < 2; part++) {
+        DoubleCRT d(*s->dev, cc.ctxtPrimes, batch, DoubleCRT::Uninitialized{});
+        d.setRows(packed[j][part]);
+        s->fresh[j]->parts.emplace(SKHandle{(long)part, 1}, std::move(d));
+        packed[j][part].clear();
+        packed[j][part].shrink_to_fit();
+      }
+    }
+    s->dev->sync();
+    *out = s.release();
+  });
+}
+
+extern "C" int hxh_session_destroy(hxh_session* s)
+{
+  return guarded([&] { delete s; });
+}
+
+extern "C" int hxh_session_info(const hxh_session* s, long info[8])
+{
+  if (!s || !info) {
+    g_err = "null argument";
+    return -1;
+  }
+  auto bitsOf = [](uint64_t q) {
+    long b = 0;
+    while (q) {
+      b++;
+      q >>= 1;
+    }
+    return b;
+  };
+  const ChainContext& cc = *s->cc;
+  info[0] = cc.phim;
+  info[1] = (long)cc.ctxtPrimes.size();
+  info[2] = (long)cc.specialPrimes.size();
+  info[3] = (long)cc.digits.size();
+  info[4] = (long)cc.smallPrimes.size();
+  info[5] = bitsOf(cc.primes[(size_t)cc.ctxtPrimes[0]]);
+  info[6] = cc.specialPrimes.empty() ? 0 : bitsOf(cc.primes[(size_t)cc.specialPrimes[0]]);
+  info[7] = s->batch;
+  return 0;
+}
+
+static void run_loop(hxh_session* s, const Ctxt& a0, const Ctxt& b0, int k, int measure, std::unique_ptr<Ctxt>& keep)
+{
+  Ctxt::deferNorms() = measure != 0;
+  std::unique_ptr<Ctxt> prev;
+  for (int i = 0; i < k; i++) {
+    auto a = std::make_unique<Ctxt>(a0);   // copy(ctxt1): benchmarks/bgv_basic.cpp:160 (copy-on-write on the device)
+    a->measure = measure != 0;
+    Ctxt b = b0;                            // Ctxt::multLowLvl's own copy of `other` (src/Ctxt.cpp:1716-1745)
+    b.measure = measure != 0;
+    a->multiplyBy(std::move(b));
+    if (prev)
+      (void)(double)prev->lnNoise;          // the previous result's estimate, one multiply later
+    prev = std::move(a);                    // ... and the previous result is dropped (its slabs recycle)
+  }
+  if (prev)
+    (void)(double)prev->lnNoise;
+  keep = std::move(prev);
+}
+
+extern "C" int hxh_multiply(hxh_session* s, int level, int k, int measure)
+{
+  if (!s || k < 1 || (level != 1 && level != 2)) {
+    g_err = "hxh_multiply: bad argument";
+    return -1;
+  }
+  return guarded([&] {
+    if (level == 1) {
+      run_loop(s, *s->fresh[0], *s->fresh[1], k, measure, s->prod[1]);
+      s->host[1].valid = false;
+    } else {
+      if (!s->prod[1])
+        throw LogicError("hxh_multiply: level 2 needs a level-1 product (call level 1 first)");
+      run_loop(s, *s->prod[1], *s->prod[1], k, measure, s->prod[2]);
+      s->host[2].valid = false;
+    }
+  });
+}
+
+extern "C" int hxh_multiply_single(hxh_session* s, int measure)
+{
+  if (!s) {
+    g_err = "null session";
+    return -1;
+  }
+  return guarded([&] {
+    std::unique_ptr<Ctxt> keep;
+    run_loop(s, *s->fresh1[0], *s->fresh1[1], 1, measure, keep);
+  });
+}
+
+extern "C" int hxh_plaintext(const hxh_session* s, int which, double* out)
+{
+  if (!s || !out || which < 0 || which > 1) {
+    g_err = "hxh_plaintext: bad argument";
+    return -1;
+  }
+  memcpy(out, s->ptxt[which].data(), s->ptxt[which].size() * sizeof(double));
+  return 0;
+}
+
+extern "C" int hxh_decrypt(hxh_session* s, int level, int b, double* out, double* bound)
+{
+  if (!s || !out || level < 0 || level > 2 || b < 0 || b >= s->batch) {
+    g_err = "hxh_decrypt: bad argument";
+    return -1;
+  }
+  return guarded([&] {
+    const Ctxt* src = level == 0 ? s->fresh[0].get() : s->prod[level].get();
+    if (!src)
+      throw LogicError("hxh_decrypt: no product kept for this level");
+    hxh_session::HostParts& H = s->host[level];
+    const size_t N = (size_t)s->cc->phim, B = (size_t)s->batch;
+    if (!H.valid) {
+      H.rows.clear();
+      H.idx.clear();
+      for (auto& kv : src->parts) {
+        H.rows.emplace_back(kv.first, kv.second.getRows());
+        H.idx.push_back(kv.second.getIndexSet());
+      }
+      H.valid = true;
+    }
+    Ctxt one(*s->cc, *s->dev, s->sk->keys);
+    one.primeSet = src->primeSet;
+    one.ptxtSpace = src->ptxtSpace;
+    one.intFactor = src->intFactor;
+    one.lnNoise = (double)src->lnNoise;
+    one.ptxtMag = src->ptxtMag;
+    one.lnRatFactor = src->lnRatFactor;
+    for (size_t i = 0; i < H.rows.size(); i++) {
+      const size_t R = H.idx[i].size();
+      std::vector<uint64_t> rows(R * N);
+      for (size_t r = 0; r < R; r++)
+        memcpy(&rows[r * N], &H.rows[i].second[(r * B + (size_t)b) * N], N * 8);
+      DoubleCRT d(*s->dev, H.idx[i], 1, DoubleCRT::Uninitialized{});
+      d.setRows(rows);
+      one.parts.emplace(H.rows[i].first, std::move(d));
+    }
+    if (s->scheme == 1) {
+      const std::vector<double> v = s->sk->DecryptCKKS(one);   // raw / ratFactor
+      memcpy(out, v.data(), N * sizeof(double));
+      if (bound)
+        *bound = std::exp((double)src->lnNoise - src->lnRatFactor);
+    } else {
+      const std::vector<long> v = s->sk->Decrypt(one);
+      for (size_t i = 0; i < N; i++)
+        out[i] = (double)v[i];
+      if (bound)
+        *bound = src->capacity();
+    }
+  });
+}
+
+extern "C" int hxh_result_primes(const hxh_session* s, int level, int* out, int cap, int* n)
+{
+  if (!s || !n || level < 0 || level > 2) {
+    g_err = "hxh_result_primes: bad argument";
+    return -1;
+  }
+  const Ctxt* src = level == 0 ? s->fresh[0].get() : s->prod[level].get();
+  if (!src) {
+    g_err = "no product kept for this level";
+    return -1;
+  }
+  *n = (int)src->primeSet.size();
+  int i = 0;
+  for (int pidx : src->primeSet)
+    if (out && i < cap)
+      out[i++] = pidx;
+  return 0;
+}

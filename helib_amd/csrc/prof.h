@@ -1,14 +1,17 @@
 // prof.h -- in-situ kernel timing with HIP events (host code only).
 //
 // Every kernel launch of the library goes through HX_LAUNCH.  Between hx_profile_begin() and
-// hx_profile_end() each launch is bracketed by a pair of events recorded on the stream the kernel
-// is launched on, so a kernel is timed where it actually runs -- between its real neighbours inside
+// hx_profile_end() each launch carries a pair of events that take the dispatch's own start and stop
+// timestamps (hipExtLaunchKernelGGL: no extra barrier or cache write-back between kernels, which a
+// hipEventRecord pair would insert -- measured: it made the mod-down apply kernel look 8 % slower than
+// rocprofv3 sees it), so a kernel is timed where it actually runs -- between its real neighbours inside
 // a multiply, with their cache and clock state -- and not in a back-to-back loop of its own.
 // bench.py derives `roofline` from this (the rocprofv3 kernel trace of the same command, committed
 // under profiles/, is the cross-check); outside a profiling window a launch costs one predictable
 // branch.  Launches recorded into a HIP graph are skipped (events cannot bracket them).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cxxabi.h>
 #include <algorithm>
@@ -33,8 +36,6 @@ struct State {
   std::unordered_map<const void*, int> by_ptr;
   std::vector<Rec> recs;
   std::vector<hipEvent_t> spare;
-  hipStream_t last_stream = nullptr;
-  bool open = false;  // pre() recorded e0 and the launch has not been closed by post() yet
   size_t dropped = 0;
 };
 inline bool enabled = false;
@@ -58,21 +59,21 @@ inline hipEvent_t take_event(State& s)
   return e;
 }
 
-inline void pre(const void* fn, const char* text, hipStream_t st, dim3 grid, dim3 block)
+// registers the launch; true: launch with (e0, e1) as the dispatch's start / stop events
+inline bool pre(const void* fn, const char* text, hipStream_t st, dim3 grid, dim3 block, hipEvent_t* e0, hipEvent_t* e1)
 {
   State& s = state();
   std::lock_guard<std::mutex> lk(s.mu);
-  s.open = false;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
     (void)hipGetLastError();
-    return;
+    return false;
   }
   if (cs != hipStreamCaptureStatusNone)
-    return;
+    return false;
   if (s.recs.size() >= MAX_RECS) {
     s.dropped++;
-    return;
+    return false;
   }
   auto it = s.by_ptr.find(fn);
   if (it == s.by_ptr.end()) {
@@ -102,33 +103,18 @@ inline void pre(const void* fn, const char* text, hipStream_t st, dim3 grid, dim
   r.wg_size = block.x * block.y * block.z;
   r.e0 = take_event(s);
   r.e1 = take_event(s);
-  if (!r.e0 || !r.e1 || hipEventRecord(r.e0, st) != hipSuccess) {
-    (void)hipGetLastError();
+  if (!r.e0 || !r.e1) {
     if (r.e0)
       s.spare.push_back(r.e0);
     if (r.e1)
       s.spare.push_back(r.e1);
     s.dropped++;
-    return;
+    return false;
   }
   s.recs.push_back(r);
-  s.last_stream = st;
-  s.open = true;
-}
-inline void post(hipStream_t st)
-{
-  State& s = state();
-  std::lock_guard<std::mutex> lk(s.mu);
-  if (!s.open)
-    return;
-  s.open = false;
-  if (hipEventRecord(s.recs.back().e1, st) != hipSuccess) {
-    (void)hipGetLastError();
-    s.spare.push_back(s.recs.back().e0);
-    s.spare.push_back(s.recs.back().e1);
-    s.recs.pop_back();
-    s.dropped++;
-  }
+  *e0 = r.e0;
+  *e1 = r.e1;
+  return true;
 }
 
 inline int begin()
@@ -204,12 +190,12 @@ inline std::string end()
 
 }  // namespace hxp
 
-#define HX_LAUNCH(kern, grid, block, lds, st, ...)                                 \
-  do {                                                                              \
-    const dim3 _hx_g = (grid), _hx_b = (block);                                     \
-    if (hxp::enabled)                                                               \
-      hxp::pre((const void*)(kern), #kern, (st), _hx_g, _hx_b);                     \
-    hipLaunchKernelGGL(kern, _hx_g, _hx_b, (lds), (st), __VA_ARGS__);               \
-    if (hxp::enabled)                                                               \
-      hxp::post(st);                                                                \
+#define HX_LAUNCH(kern, grid, block, lds, st, ...)                                                        \
+  do {                                                                                                     \
+    const dim3 _hx_g = (grid), _hx_b = (block);                                                            \
+    hipEvent_t _hx_e0, _hx_e1;                                                                             \
+    if (hxp::enabled && hxp::pre((const void*)(kern), #kern, (st), _hx_g, _hx_b, &_hx_e0, &_hx_e1))        \
+      hipExtLaunchKernelGGL(kern, _hx_g, _hx_b, (lds), (st), _hx_e0, _hx_e1, 0, __VA_ARGS__);              \
+    else                                                                                                   \
+      hipLaunchKernelGGL(kern, _hx_g, _hx_b, (lds), (st), __VA_ARGS__);                                    \
   } while (0)

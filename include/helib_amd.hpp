@@ -5,6 +5,8 @@
 //   helib_amd::Context      Context::moduli + zMStar      (include/helib/Context.h:117, 339-366)
 //   helib_amd::DoubleCRT    DoubleCRT                     (include/helib/DoubleCRT.h:212-385)
 //   helib_amd::KeySwitch    KeySwitch (b columns + expanded a columns, keySwitching.h:86-101)
+//   helib_amd::Cmodulus     Cmodulus: FFT / iFFT of one row (include/helib/CModulus.h:56-145)
+//   helib_amd::BigInt       the ZZ coefficients of DoubleCRT::toPoly (src/DoubleCRT.cpp:925-1113)
 //   tensorProduct / keySwitchDigits / multiplyBy / reLinearize   (src/Ctxt.cpp:191-230, 720-842, 1563-1774)
 //
 // Exceptions mirror include/helib/exceptions.h: InvalidArgument for bad arguments, RuntimeError
@@ -52,6 +54,138 @@ inline void check(int rc)
 
 using IndexSet = std::vector<int>;  // prime indices, Context::moduli order
 
+// A signed big integer for the coefficients DoubleCRT::toPoly returns (the reference hands out NTL::ZZ,
+// src/DoubleCRT.cpp:925-1113; NTL and GMP are not dependencies of this host).  Sign and magnitude,
+// 64-bit limbs, little endian, no leading zero limbs; just what the CRT reconstruction and its
+// callers' checks need.  toString() is decimal; limbs()/negative() feed mpz_import where GMP is at hand.
+class BigInt {
+public:
+  BigInt() = default;
+  explicit BigInt(uint64_t v)
+  {
+    if (v)
+      mag_.push_back(v);
+  }
+  bool isZero() const { return mag_.empty(); }
+  bool negative() const { return neg_; }
+  const std::vector<uint64_t>& limbs() const { return mag_; }
+  // this = this * m + a   (non-negative values)
+  void mulAdd(uint64_t m, uint64_t a)
+  {
+    unsigned __int128 carry = a;
+    for (auto& w : mag_) {
+      unsigned __int128 t = (unsigned __int128)w * m + carry;
+      w = (uint64_t)t;
+      carry = t >> 64;
+    }
+    if (carry)
+      mag_.push_back((uint64_t)carry);
+  }
+  // magnitude comparison: -1, 0, 1
+  static int cmpMag(const BigInt& a, const BigInt& b)
+  {
+    if (a.mag_.size() != b.mag_.size())
+      return a.mag_.size() < b.mag_.size() ? -1 : 1;
+    for (size_t i = a.mag_.size(); i-- > 0;)
+      if (a.mag_[i] != b.mag_[i])
+        return a.mag_[i] < b.mag_[i] ? -1 : 1;
+    return 0;
+  }
+  // |big| - |small| for |big| >= |small|
+  static BigInt subMag(const BigInt& big, const BigInt& small)
+  {
+    BigInt r;
+    r.mag_ = big.mag_;
+    uint64_t borrow = 0;
+    for (size_t i = 0; i < r.mag_.size(); i++) {
+      const uint64_t s = i < small.mag_.size() ? small.mag_[i] : 0;
+      const uint64_t a = r.mag_[i];
+      const uint64_t d = a - s - borrow;
+      borrow = (a < s || (a == s && borrow)) ? 1 : 0;
+      r.mag_[i] = d;
+    }
+    while (!r.mag_.empty() && r.mag_.back() == 0)
+      r.mag_.pop_back();
+    return r;
+  }
+  BigInt negated() const
+  {
+    BigInt r = *this;
+    r.neg_ = !mag_.empty() && !neg_;
+    return r;
+  }
+  // (this + 1) / 2 for a non-negative value: the reference's prod_half
+  BigInt halfUp() const
+  {
+    BigInt r = *this;
+    uint64_t carry = 1;
+    for (auto& w : r.mag_) {
+      w += carry;
+      carry = (w == 0 && carry) ? 1 : 0;
+      if (!carry)
+        break;
+    }
+    if (carry)
+      r.mag_.push_back(1);
+    uint64_t hi = 0;
+    for (size_t i = r.mag_.size(); i-- > 0;) {
+      const uint64_t w = r.mag_[i];
+      r.mag_[i] = (w >> 1) | (hi << 63);
+      hi = w & 1;
+    }
+    while (!r.mag_.empty() && r.mag_.back() == 0)
+      r.mag_.pop_back();
+    return r;
+  }
+  // the value modulo q, in [0, q)  (mathematical residue: a negative value gives q - (|v| mod q))
+  uint64_t mod(uint64_t q) const
+  {
+    unsigned __int128 r = 0;
+    for (size_t i = mag_.size(); i-- > 0;)
+      r = ((r << 64) | mag_[i]) % q;
+    uint64_t v = (uint64_t)r;
+    return (neg_ && v) ? q - v : v;
+  }
+  double toDouble() const
+  {
+    double v = 0;
+    for (size_t i = mag_.size(); i-- > 0;)
+      v = v * 18446744073709551616.0 + (double)mag_[i];
+    return neg_ ? -v : v;
+  }
+  std::string toString() const
+  {
+    if (mag_.empty())
+      return "0";
+    std::vector<uint64_t> t = mag_;
+    std::string digits;
+    while (!t.empty()) {
+      unsigned __int128 r = 0;
+      for (size_t i = t.size(); i-- > 0;) {
+        unsigned __int128 cur = (r << 64) | t[i];
+        t[i] = (uint64_t)(cur / 10000000000000000000ull);
+        r = cur % 10000000000000000000ull;
+      }
+      while (!t.empty() && t.back() == 0)
+        t.pop_back();
+      uint64_t chunk = (uint64_t)r;
+      for (int i = 0; i < 19; i++) {
+        digits.push_back((char)('0' + chunk % 10));
+        chunk /= 10;
+        if (t.empty() && chunk == 0)
+          break;
+      }
+    }
+    if (neg_)
+      digits.push_back('-');
+    return std::string(digits.rbegin(), digits.rend());
+  }
+
+private:
+  bool neg_ = false;
+  std::vector<uint64_t> mag_;
+};
+
 class Context {
 public:
   explicit Context(uint64_t m, int device = 0) : m_(m)
@@ -81,6 +215,8 @@ public:
   uint64_t ithRoot(long i) const { return roots_.at((size_t)i); }
   long numPrimes() const { return (long)primes_.size(); }
   void sync() const { check(hx_ctx_sync(h_.get())); }
+  // the HIP stream (hipStream_t) every call on this context enqueues on; nullptr = the default stream
+  void setStream(void* stream) const { check(hx_ctx_set_stream(h_.get(), stream)); }
   hx_ctx* handle() const { return h_.get(); }
 
   // Measured-noise norms (hx_*_norms) either land in the caller's array before the call returns, or --
@@ -263,6 +399,69 @@ public:
   {
     check(hx_poly_rem(h_.get(), (uint64_t)t, reinterpret_cast<uint64_t*>(out)));
   }
+  // DoubleCRT::toPoly(poly, s, positive) (src/DoubleCRT.cpp:925-1113): the integer polynomial of batch
+  // element b modulo Q = the product of this object's primes that are in s (all of them by default):
+  // inverse transform of a copy on the device, then the CRT reconstruction on the host -- coefficients
+  // in [0, Q) when positive, else centred: v - Q for v >= (Q + 1) / 2 (:1053-1056, 1097-1098).
+  // phi(m) coefficients, trailing zeros kept (the reference's ZZX is normalised; callers index by degree).
+  std::vector<BigInt> toPoly(const IndexSet* s = nullptr, bool positive = false, int b = 0) const
+  {
+    if (b < 0 || b >= batch_)
+      throw InvalidArgument("DoubleCRT::toPoly: batch element out of range");
+    DoubleCRT tmp(*this);
+    if (s) {
+      IndexSet drop;
+      for (int i : tmp.getIndexSet())
+        if (std::find(s->begin(), s->end(), i) == s->end())
+          drop.push_back(i);
+      if (!drop.empty())
+        tmp.removePrimes(drop);
+    }
+    const IndexSet idx = tmp.getIndexSet();
+    const size_t L = idx.size(), n = (size_t)context_->getPhiM(), B = (size_t)batch_;
+    std::vector<BigInt> out(n);
+    if (L == 0)
+      return out;
+    tmp.iFFT();
+    const std::vector<uint64_t> rows = tmp.getRows();
+    auto mulmod = [](uint64_t a, uint64_t c, uint64_t q) { return (uint64_t)((unsigned __int128)a * c % q); };
+    auto powmod = [&](uint64_t a, uint64_t e, uint64_t q) {
+      uint64_t r = 1;
+      for (a %= q; e; e >>= 1, a = mulmod(a, a, q))
+        if (e & 1)
+          r = mulmod(r, a, q);
+      return r;
+    };
+    std::vector<uint64_t> q(L), inv(L * L, 0);
+    for (size_t k = 0; k < L; k++)
+      q[k] = (uint64_t)context_->ithPrime(idx[k]);
+    for (size_t k = 0; k < L; k++)
+      for (size_t l = 0; l < k; l++)
+        inv[k * L + l] = powmod(q[l] % q[k], q[k] - 2, q[k]);   // q_l^-1 mod q_k
+    BigInt Q(1);
+    for (size_t k = 0; k < L; k++)
+      Q.mulAdd(q[k], 0);
+    const BigInt half = Q.halfUp();
+    std::vector<uint64_t> a(L);
+    for (size_t j = 0; j < n; j++) {
+      // Garner: v = a_0 + a_1 q_0 + a_2 q_0 q_1 + ...  with 0 <= a_k < q_k
+      for (size_t k = 0; k < L; k++) {
+        uint64_t x = rows[(k * B + (size_t)b) * n + j];
+        for (size_t l = 0; l < k; l++) {
+          const uint64_t al = a[l] % q[k];
+          x = mulmod(x >= al ? x - al : x + q[k] - al, inv[k * L + l], q[k]);
+        }
+        a[k] = x;
+      }
+      BigInt v(a[L - 1]);
+      for (size_t k = L - 1; k-- > 0;)
+        v.mulAdd(q[k], a[k]);
+      if (!positive && BigInt::cmpMag(v, half) >= 0)
+        v = BigInt::subMag(Q, v).negated();
+      out[j] = std::move(v);
+    }
+    return out;
+  }
   DoubleCRT& addPrimesAndScale(const IndexSet& s)
   {
     return chk(hx_add_primes_and_scale(h_.get(), s.data(), (int)s.size()));
@@ -337,6 +536,71 @@ private:
     void operator()(hx_ksk* p) const { hx_ksk_destroy(p); }
   };
   std::unique_ptr<hx_ksk, Del> h_;
+};
+
+// Cmodulus (include/helib/CModulus.h:56-145): one modulus q with the tables for FFT / iFFT modulo q over
+// Z_m^*.  The reference's constructor takes (PAlgebra, q, root); this one takes m and builds its own
+// one-prime device context.  root: the 2m-th (m even, incl. powers of two: NTL's RootTable[0][k]) or m-th
+// (m odd) root of unity the rows are defined by; 0 = FindPrimRootT(q, e) (src/CModulus.cpp:148-164).
+// FFT / iFFT move one row over PCIe per call -- the reference's own granularity, kept for code written
+// against Cmodulus; whole DoubleCRT objects stay on the device (class DoubleCRT above).
+class Cmodulus {
+public:
+  Cmodulus(unsigned long m, long q, long root = 0, int device = 0) : ctx_(std::make_shared<Context>((uint64_t)m, device))
+  {
+    if (q <= 1)
+      throw InvalidArgument("Cmodulus: q must be a prime");
+    ctx_->addPrime((uint64_t)q, (uint64_t)(root < 0 ? 0 : root));
+    row_ = std::make_shared<DoubleCRT>(*ctx_, IndexSet{0}, 1);
+  }
+  unsigned long getM() const { return (unsigned long)ctx_->getM(); }
+  unsigned long getPhiM() const { return (unsigned long)ctx_->getPhiM(); }
+  long getQ() const { return ctx_->ithPrime(0); }
+  long getRoot() const { return (long)ctx_->ithRoot(0); }
+  const Context& getContext() const { return *ctx_; }
+  // y = FFT(x): x = coefficients (degree < phi(m); any sign, reduced modulo q here as the reference's
+  // conv(ZZX -> zz_pX) does, src/CModulus.cpp:446-484); y[j] = x(zeta^{t_j}), t_j the j-th element of Z_m^*
+  void FFT(std::vector<long>& y, const std::vector<long>& x) const
+  {
+    const size_t n = getPhiM();
+    if (x.size() > n)
+      throw InvalidArgument("Cmodulus::FFT: polynomial of degree >= phi(m)");
+    const long q = getQ();
+    std::vector<uint64_t> rows(n, 0);
+    for (size_t i = 0; i < x.size(); i++) {
+      long r = x[i] % q;
+      rows[i] = (uint64_t)(r < 0 ? r + q : r);
+    }
+    std::lock_guard<std::mutex> lock(*mu_);
+    row_->setRows(rows);
+    row_->FFT();
+    rows = row_->getRows();
+    y.assign(rows.begin(), rows.end());
+  }
+  // x = FFT^{-1}(y): phi(m) coefficients in [0, q) (src/CModulus.cpp:486-578, incl. rem Phi_m for general m)
+  void iFFT(std::vector<long>& x, const std::vector<long>& y) const
+  {
+    const size_t n = getPhiM();
+    if (y.size() != n)
+      throw InvalidArgument("Cmodulus::iFFT: y must have phi(m) entries");
+    const long q = getQ();
+    std::vector<uint64_t> rows(n);
+    for (size_t i = 0; i < n; i++) {
+      if (y[i] < 0 || y[i] >= q)
+        throw InvalidArgument("Cmodulus::iFFT: entries must be in [0, q)");
+      rows[i] = (uint64_t)y[i];
+    }
+    std::lock_guard<std::mutex> lock(*mu_);
+    row_->setRows(rows);
+    row_->iFFT();
+    rows = row_->getRows();
+    x.assign(rows.begin(), rows.end());
+  }
+
+private:
+  std::shared_ptr<Context> ctx_;
+  std::shared_ptr<DoubleCRT> row_;                         // the one-row work object (copies of a Cmodulus share it)
+  std::shared_ptr<std::mutex> mu_ = std::make_shared<std::mutex>();
 };
 
 inline void flatten(const std::vector<IndexSet>& digits, std::vector<int>& idx, std::vector<int>& off)

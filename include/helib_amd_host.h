@@ -1,0 +1,65 @@
+/* helib_amd_host.h -- C ABI of the C++17 host library (helib_amd/lib/libhelib_amd_host.so).
+ *
+ * The north star keeps the host in C++17 with HElib's Ctxt / DoubleCRT / KeySwitch surface
+ * (include/helib_amd_ctxt.hpp, helib_amd_keys.hpp over include/helib_amd.h).  This library is that
+ * host compiled once, behind a handful of C entry points, so that a driver written in any language
+ * (bench.py, a cgo / JNI / ctypes stub) runs the reference's benchmark loops with the C++ host on the
+ * timed path -- the loops of benchmarks/bgv_basic.cpp:144-165 and benchmarks/ckks_basic.cpp:161-180:
+ *
+ *     ContextBuilder<BGV>().m(m).p(p).r(r).bits(bits).c(3)          (scheme 0)
+ *     ContextBuilder<CKKS>().m(m).precision(r).bits(bits).c(3)      (scheme 1)
+ *     SecKey::GenSecKey + the relinearisation matrix (addSome1DMatrices is not needed for multiplyBy)
+ *     two public-key encryptions of random plaintexts               (x batch, packed along the batch axis)
+ *     loop:  copy = ctxt1;  copy.multiplyBy(ctxt2);                 (hxh_multiply, level 1)
+ *            copy = prod;   copy.multiplyBy(prod);                  (level 2: operands that carry the
+ *                                                                    special primes of a key switch)
+ *
+ * Every function returns 0 or a negative code with the message in hxh_last_error() (thread-local);
+ * no exception crosses the ABI.  The device work is enqueued on `stream` (a hipStream_t; NULL = the
+ * default stream): the caller brackets its timed region with its own synchronisation.
+ */
+#ifndef HELIB_AMD_HOST_H
+#define HELIB_AMD_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hxh_session hxh_session;
+
+/* Builds the context, the key pair with its relinearisation matrix, and `batch` pairs of fresh
+ * encryptions of seeded random plaintexts (BGV: uniform residues mod p^r; CKKS: reals in [-1,1]/phi(m)
+ * encoded at scale 2^r).  seed = 0: key material from OS entropy (the plaintexts stay seeded). */
+int hxh_session_create(hxh_session** out, int device, void* stream, int scheme, long m, long p, long r,
+                       long bits, int batch, uint64_t seed);
+int hxh_session_destroy(hxh_session* s);
+/* info[0..7] = phi(m), #ctxt primes, #special primes, #digits, #small primes, bits of the first ctxt prime,
+ * bits of the first special prime, batch */
+int hxh_session_info(const hxh_session* s, long info[8]);
+
+/* k x [copy(a); copy.multiplyBy(b)] enqueued back to back; level 1: a, b = the two fresh ciphertexts,
+ * level 2: a = b = the product kept by the last level-1 call.  measure = 1: added noise measured on the
+ * device as in the reference's default build, read back lazily (each result's estimate is completed
+ * one multiply later); 0: the reference's alternative bounds.  The last product is kept for
+ * hxh_decrypt / the next level.  Returns when everything is enqueued and the estimates are read. */
+int hxh_multiply(hxh_session* s, int level, int k, int measure);
+/* one multiply of batch element 0 alone (the reference's own loop shape: one ciphertext at a time) */
+int hxh_multiply_single(hxh_session* s, int measure);
+
+/* the plaintexts: out[b*phi + j], which = 0 / 1.  BGV: residues in [0, p^r); CKKS: the encoded reals
+ * rint(v * 2^r) / 2^r */
+int hxh_plaintext(const hxh_session* s, int which, double* out);
+/* decrypts batch element b of the kept product of `level` (0 = the first fresh ciphertext itself):
+ * BGV: phi(m) residues; CKKS: phi(m) decoded reals (raw / ratFactor).  bound (optional): CKKS error
+ * bound the ciphertext reports (noiseBound / ratFactor); BGV: log2 of the remaining capacity */
+int hxh_decrypt(hxh_session* s, int level, int b, double* out, double* bound);
+/* prime indices of the kept product of `level` (ascending); returns the count through *n (cap = size of out) */
+int hxh_result_primes(const hxh_session* s, int level, int* out, int cap, int* n);
+
+const char* hxh_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELIB_AMD_HOST_H */

@@ -638,4 +638,47 @@ int hx_ctx_graph_end(hx_ctx*, hx_graph**) { return fail(HX_ERR_UNSUPPORTED, "no 
 int hx_graph_launch(hx_graph*) { return fail(HX_ERR_UNSUPPORTED, "no graphs in the CPU mock"); }
 int hx_graph_destroy(hx_graph*) { return HX_OK; }
 
+// the HEXL-shim layer (src/intelExt.h:20-59) over the oracle's Cmodulus for m = 2n: the shim's own root
+// choice, FindPrimRootT(q, 2n), as the engine's hx_intel_* documents
+static int shim_ntt(long* out, const long* in, long n, long q, bool inverse)
+{
+  if (n < 2 || (n & (n - 1)) || q < 3)
+    return fail(HX_ERR_INVALID, "intel shim: n must be a power of two");
+  ho_cmod* c = ho_cmod_create(2 * (uint64_t)n, (uint64_t)q, 0);
+  if (!c)
+    return fail(HX_ERR_INVALID, "intel shim: no 2n-th root of unity modulo q");
+  std::vector<uint64_t> a((size_t)n), b((size_t)n);
+  for (long i = 0; i < n; i++)
+    a[(size_t)i] = (uint64_t)in[i];
+  if (inverse)
+    ho_cmod_ifft(c, a.data(), b.data());
+  else
+    ho_cmod_fft(c, a.data(), b.data());
+  for (long i = 0; i < n; i++)
+    out[i] = (long)b[(size_t)i];
+  ho_cmod_destroy(c);
+  return HX_OK;
+}
+int hx_intel_FFTFwd(long* out, const long* in, long n, long q) { return shim_ntt(out, in, n, q, false); }
+int hx_intel_FFTRev1(long* out, const long* in, long n, long q) { return shim_ntt(out, in, n, q, true); }
+#define SHIM_BIN(NAME, FN)                                                                   \
+  int NAME(long* r, const long* a, const long* b, long n, long q)                            \
+  {                                                                                          \
+    FN((uint64_t*)r, (const uint64_t*)a, (const uint64_t*)b, n, (uint64_t)q);                \
+    return HX_OK;                                                                            \
+  }
+#define SHIM_SC(NAME, FN)                                                                    \
+  int NAME(long* r, const long* a, long s, long n, long q)                                   \
+  {                                                                                          \
+    long t = s % q;                                                                          \
+    FN((uint64_t*)r, (const uint64_t*)a, (uint64_t)(t < 0 ? t + q : t), n, (uint64_t)q);     \
+    return HX_OK;                                                                            \
+  }
+SHIM_BIN(hx_intel_EltwiseAddMod, ho_row_add)
+SHIM_BIN(hx_intel_EltwiseSubMod, ho_row_sub)
+SHIM_BIN(hx_intel_EltwiseMultMod, ho_row_mul)
+SHIM_SC(hx_intel_EltwiseAddModScalar, ho_row_add_scalar)
+SHIM_SC(hx_intel_EltwiseSubModScalar, ho_row_sub_scalar)
+SHIM_SC(hx_intel_EltwiseMultModScalar, ho_row_mul_scalar)
+
 }  // extern "C"

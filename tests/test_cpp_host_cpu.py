@@ -252,3 +252,38 @@ def test_cpp_lazy_norm_read_back_under_the_address_sanitizer(mock, tmp_path):
         r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600, env=_env(True))
         assert r.returncode == 0 and "ctxt_ops_test OK" in r.stdout and "AddressSanitizer" not in r.stderr, \
             r.stdout + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("scheme,m,p,r,bits,batch,measure", [("bgv", 128, 257, 1, 300, 3, False), ("bgv", 256, 65537, 1, 400, 2, True),
+                                                           ("ckks", 256, -1, 20, 500, 2, True), ("ckks", 128, -1, 20, 400, 3, False)])
+def test_cpp_host_session_library_over_the_mock(mock, scheme, m, p, r, bits, batch, measure):
+    """helib_amd/csrc/host_session.cpp (the C++17 host behind include/helib_amd_host.h, the library bench.py times)
+    linked against the CPU stand-in for the C ABI: keys and batched encryptions made in C++, the benchmark loop
+    `copy = ctxt1; copy.multiplyBy(ctxt2)` at level 1 and level 2 (operands carrying special primes), every batch
+    element of both products decrypted in C++ and compared here with the plaintext product -- BGV exactly, CKKS
+    within the bound the ciphertext reports."""
+    from helib_amd import build as hb, host
+    so = hb.build_host(force=True, link_dir=mock.dir, link_lib="hx_mock", out=os.path.join(mock.dir, "libhelib_amd_host_mock.so"))
+    s = host.Session(scheme, m, p, r, bits, batch, seed=11, lib_path=so)
+    assert s.batch == batch and s.phim == m // 2 and s.D >= 1
+    assert s.verify(0) == batch                                   # decrypt(encrypt(m)) == m
+    s.multiply(1, 2, measure)
+    assert s.verify(1) == batch
+    s.multiply(2, 2, measure)
+    assert s.verify(2) == batch
+    assert set(s.result_primes(2)) < set(s.result_primes(1)) or len(s.result_primes(2)) <= len(s.result_primes(1))
+    s.multiply_single(measure)
+    with pytest.raises(host.HostError):
+        s.multiply(3, 1)
+    s.close()
+
+
+@pytest.mark.parametrize("m", [128, 1024, 105, 1705])
+def test_cpp_cmodulus_bignum_toPoly_and_namespace_intel_over_the_mock(mock, m):
+    """tests/cpp/facade2_test.cpp: Cmodulus{FFT, iFFT} against the O(N^2) definition, DoubleCRT::toPoly with
+    big-integer coefficients (every coefficient reduces to the inverse-transformed rows and lies in the centred
+    range), and `namespace intel` (include/helib_amd_intel.hpp) through call sites shaped like the reference's
+    USE_INTEL_HEXL ones -- the program of the GPU suite, here over the CPU stand-in for the C ABI."""
+    exe = mock(os.path.join(ROOT, "tests", "cpp", "facade2_test.cpp"), "facade2_test")
+    r = subprocess.run([exe, str(m)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "facade2_test OK" in r.stdout, r.stdout + r.stderr

@@ -86,6 +86,14 @@ def test_bench_launcher_spawns_ranks_and_aggregates():
     assert out.returncode == 0, out.stderr
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["pairs_all_ranks"] == 128
+    # BASELINE configs[3] as the driver's 8-GPU run would start it: the CKKS chain, 512 pairs split over the ranks
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "ckks65536",
+                          "--global-batch", "512", "--dry-launch", "--steps", "2"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["pairs_all_ranks"] == 512
+    assert line["config"]["batch_this_rank"] == 256 and line["config"]["workload"] == "ckks65536"
 
 
 def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_world():

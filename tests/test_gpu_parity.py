@@ -1820,3 +1820,44 @@ def test_captured_graph_of_the_fresh_multiplyBy_sequence(hx, monkeypatch):
         assert rec.parts[h].getIndexSet() == idx and np.array_equal(rec.parts[h].download(), data)
     assert T.decrypt(ctx, P.o, s, rec, rows) == T.decrypt(ctx, P.o, s, eager, rows)
     graph.destroy()
+
+
+_FACADE2_EXE = {}
+
+
+@pytest.mark.parametrize("m", [128, 32768, 1705, 21845])
+def test_cpp_cmodulus_bignum_toPoly_and_namespace_intel(hx, m, tmp_path_factory):
+    """The facade pieces a HElib caller of this path also uses, from C++ on the device (tests/cpp/facade2_test.cpp,
+    self-checking): Cmodulus{FFT, iFFT} (include/helib/CModulus.h:137-145) against the O(N^2) definition,
+    DoubleCRT::toPoly with big-integer coefficients (src/DoubleCRT.cpp:925-1113), and `namespace intel`
+    (include/helib_amd_intel.hpp: the eight signatures of src/intelExt.h:20-59) through call sites shaped like
+    the reference's USE_INTEL_HEXL ones.  m = 32768: the benchmark ring; 1705, 21845: Bluestein rows."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if "exe" not in _FACADE2_EXE:
+        exe = str(tmp_path_factory.mktemp("facade2") / "facade2_test")
+        libdir = os.path.join(root, "helib_amd", "lib")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(root, "include"),
+                               os.path.join(root, "tests", "cpp", "facade2_test.cpp"), "-L" + libdir, "-lhelib_amd",
+                               "-Wl,-rpath," + libdir, "-o", exe])
+        _FACADE2_EXE["exe"] = exe
+    r = subprocess.run([_FACADE2_EXE["exe"], str(m)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "facade2_test OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("scheme,m,p,r,bits,batch", [("bgv", 16384, 65537, 1, 300, 3), ("ckks", 16384, -1, 20, 500, 2)])
+def test_cpp_host_session_library_on_the_device(hx, scheme, m, p, r, bits, batch):
+    """helib_amd/lib/libhelib_amd_host.so (the C++17 host bench.py times, include/helib_amd_host.h) on the device:
+    keys and batched encryptions in C++, the benchmark loop at level 1 and level 2 with measured noise read back
+    lazily, every batch element of both products decrypted in C++ and compared with the plaintext product."""
+    from helib_amd import host
+    s = host.Session(scheme, m, p, r, bits, batch, seed=5)
+    assert s.verify(0) == batch
+    s.multiply(1, 3, True)
+    assert s.verify(1) == batch
+    s.multiply(2, 2, True)
+    assert s.verify(2) == batch
+    s.multiply(1, 2, False)                       # noise bounds instead of measured noise
+    assert s.verify(1) == batch
+    s.multiply_single(True)
+    s.close()
