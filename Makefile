@@ -13,7 +13,7 @@ lib: $(LIB)/libhelib_amd.so
 $(LIB)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(LIB)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(LIB)/libhelib_amd.so: $(LIB)/ntt_kernels.o $(LIB)/engine.o
+$(LIB)/libhelib_amd.so: $(LIB)/ntt_kernels.o $(LIB)/conv_kernels.o $(LIB)/engine.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^
 oracle:
 	$(MAKE) -s -C oracle

@@ -571,9 +571,11 @@ def kernel_table(prof, n, B, l, k, d, mults):
     return rows, total / mults
 
 
-def in_situ_profile(hx, sess, level, mults, sync):
-    """`mults` multiplies of the batch with every kernel launch bracketed by HIP events on its own stream."""
-    sess.multiply(level, 2, True)
+def in_situ_profile(hx, sess, level, mults, sync, warm=24):
+    """`mults` multiplies of the batch with every kernel launch carrying the dispatch's own start / stop events.
+    A stretch of un-profiled multiplies runs right before (the decryption check in front of this leaves the
+    device nearly idle for seconds and its clocks low; 24 multiplies of the batch are ~0.1 s of full load)."""
+    sess.multiply(level, warm, True)
     sync()
     hx.profileBegin()
     sess.multiply(level, mults, True)
@@ -845,12 +847,12 @@ def main():
         dt = group.max_over_ranks(dt)
         nver = sess.verify(1)                              # every batch element of the last product, on every rank
         res_primes = sess.result_primes(1)
-        prof1 = in_situ_profile(hx, sess, 1, 4, sync) if rank == 0 else None
+        prof1 = in_situ_profile(hx, sess, 1, 8, sync) if rank == 0 else None
         # level 2: the kept product with itself (operands that carry the special primes of a key switch)
         dt2, _ = run_session(sess, 2, steps4, 1, R, sync, group.barrier, measure=True)
         dt2 = group.max_over_ranks(dt2)
         nver2 = sess.verify(2)
-        prof2 = in_situ_profile(hx, sess, 2, 2, sync) if (rank == 0 and extras) else None
+        prof2 = in_situ_profile(hx, sess, 2, 4, sync, warm=8) if (rank == 0 and extras) else None
         nver_all = int(group.sum_over_ranks(nver))
         nver2_all = int(group.sum_over_ranks(nver2))
         mults = pairs_all * R * args.steps
@@ -893,14 +895,14 @@ def main():
                             "over_level1": round((dt2 / steps4) / (dt / args.steps), 3),
                             "verified_elements": nver2_all, "result_primes": sess.result_primes(2)}}
         if rank == 0:
-            table, us_per_mult = kernel_table(prof1, n, B, l, k, d, 4)
+            table, us_per_mult = kernel_table(prof1, n, B, l, k, d, 8)
             extra["kernels_in_situ"] = {"what": "one multiply of the batch, every launch bracketed by HIP events on its stream "
-                                                "(4 multiplies profiled after the timed region)",
+                                                "(8 multiplies profiled after the timed region, behind 24 un-profiled ones)",
                                         "kernel_us_per_multiply_of_the_batch": round(us_per_mult, 1),
                                         "wall_us_per_multiply_of_the_batch": round(dt / (args.steps * R) * 1e6, 1),
                                         "dropped_launch_records": prof1["dropped"], "kernels": table[:16]}
             if prof2:
-                t2, us2 = kernel_table(prof2, n, B, l, k, d, 2)
+                t2, us2 = kernel_table(prof2, n, B, l, k, d, 4)
                 extra["level2"]["kernels_in_situ"] = [{kk: r[kk] for kk in ("kernel", "workgroups", "launches_per_multiply", "avg_us",
                                                                             "us_per_multiply", "share")} for r in t2[:14]]
             b2b = None

@@ -13,9 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libhelib_amd.so")
-SOURCES = ["ntt_kernels.hip", "engine.hip"]
+SOURCES = ["ntt_kernels.hip", "conv_kernels.hip", "engine.hip"]
 HEADERS = ["ntt_core.h", "dev_common.h", "rns_kernels.h", "hostmath.h", "conv_core.h", "bluestein.h", "norm_kernels.h",
-           "prg_kernels.h", "arena.h",
+           "prg_kernels.h", "arena.h", "prof.h", "conv_dev.h", "ntt_kernel_util.h",
            os.path.join("..", "..", "include", "helib_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-Wno-pass-failed"]

@@ -12,29 +12,9 @@
 // is rev(top(x) * (-Psi)) and the remainder x - Q*Phi_m, two more exact convolutions.
 // Included by engine.hip only.
 #pragma once
-#include "conv_core.h"
-#include "dev_common.h"
+#include "conv_dev.h"
 
 namespace hx {
-
-// per (prime, conv size) constants
-struct ConvPrimeDev {
-  uint64_t q, mu, mu64;
-  uint32_t k, logn;
-  SplitTW S;           // only for split sizes (radix 4: 2^16, 2^17)
-  SplitTW8 S8;         // radix 8: 2^18
-  SplitTW16 S16;       // radix 16: 2^19
-};
-// per prime constants of the Bluestein transform
-struct BluePrimeDev {
-  uint64_t q;
-  const TW* powers;    // [m] root^(i^2)      (src/bluestein.cpp:94-98)
-  const TW* ipowers;   // [m] rInv^(i^2)
-  TW minv;             // m^-1 mod q          (src/CModulus.cpp:574-577)
-};
-struct PtrList {
-  const void* p[MAX_ROWS];
-};
 
 // cbuf[(ri*batch+b)][Nc] <- x_i * powers[i] (i < phim), 0 elsewhere.  in: poly rows [row][b][phim]
 __global__ void __launch_bounds__(256)
@@ -94,6 +74,41 @@ blue_post_kernel(const uint64_t* __restrict__ cbuf, uint64_t* __restrict__ out, 
     // odd m : coefficients 0..2(m-1), folded mod x^m - 1  (src/bluestein.cpp:166-187)
     // even m: coefficients m-1 .. 2(m-1)                   (src/bluestein.cpp:189-199)
     uint64_t v = odd ? addm(h[i], h[i + m], q) : h[m - 1 + i];
+    dst[j] = shoup_full(v, pw[i], q);
+  }
+}
+
+// The same for a radix-4 split result still in its four sub-blocks (the fused convolution kernel's
+// output, qbuf[((ri*4+g)*batch+b)][Q]): value i of the 4Q-point result is rebuilt on the fly from the
+// sub-block outputs at position i mod Q (split_inv4_one), so the inverse split pass, the window / fold
+// and the second twist are one kernel.
+__global__ void __launch_bounds__(256)
+blue_post4_kernel(const uint64_t* __restrict__ qbuf, uint64_t* __restrict__ out, NttRows rows, PtrList bp, PtrList cps,
+                  int batch, uint32_t phim, uint32_t m, uint32_t logq, uint32_t mpad,
+                  const uint32_t* __restrict__ zms, int gather)
+{
+  const unsigned ri = blockIdx.y / (unsigned)batch, b = blockIdx.y % (unsigned)batch;
+  const BluePrimeDev* P = (const BluePrimeDev*)bp.p[ri];
+  const ConvPrimeDev* C = (const ConvPrimeDev*)cps.p[ri];
+  const uint64_t q = P->q;
+  const SplitTW S = C->S;
+  const TW* pw = gather ? P->powers : P->ipowers;
+  const uint32_t Q = 1u << logq;
+  const uint64_t* sub[4];
+  for (int g = 0; g < 4; g++)
+    sub[g] = qbuf + (((size_t)ri * 4 + g) * batch + b) * Q;
+  uint64_t* dst = gather ? out + ((size_t)rows.row[ri] * batch + b) * phim
+                         : out + ((size_t)ri * batch + b) * mpad;
+  const uint32_t n = gather ? phim : m;
+  const bool odd = (m & 1u) != 0;
+  auto value = [&](uint32_t i) {
+    const uint32_t p = i & (Q - 1u);
+    const uint64_t c[4] = {sub[0][p], sub[1][p], sub[2][p], sub[3][p]};
+    return split_inv4_one(c, S, q, i >> logq);
+  };
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const uint32_t i = gather ? zms[j] : j;
+    const uint64_t v = odd ? addm(value(i), value(i + m), q) : value(m - 1 + i);
     dst[j] = shoup_full(v, pw[i], q);
   }
 }

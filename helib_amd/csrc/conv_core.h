@@ -102,4 +102,17 @@ HXD void split_invN(uint64_t (&e)[1 << LS], const SplitTWN<LS>& S, uint64_t q)
 HXD void split_fwd8(uint64_t (&e)[8], const SplitTW8& S, uint64_t q) { split_fwdN<3>(e, S, q); }
 HXD void split_inv8(uint64_t (&e)[8], const SplitTW8& S, uint64_t q) { split_invN<3>(e, S, q); }
 
+
+// value i of the reconstructed 4Q-point result from the four sub-block outputs c[g] at position i mod Q
+// (one output of split_inv4)
+HXD uint64_t split_inv4_one(const uint64_t (&c)[4], const SplitTW& S, uint64_t q, unsigned quarter)
+{
+  if ((quarter & 1u) == 0) {
+    const uint64_t e0 = addm(c[0], c[1], q), e2 = addm(c[2], c[3], q);
+    return quarter == 0 ? shoup_full(addm(e0, e2, q), S.quarter, q) : shoup_full(subm(e0, e2, q), S.iT1q, q);
+  }
+  const uint64_t e1 = shoup_full(subm(c[0], c[1], q), S.iT2, q), e3 = shoup_full(subm(c[2], c[3], q), S.iT3, q);
+  return quarter == 1 ? shoup_full(addm(e1, e3, q), S.quarter, q) : shoup_full(subm(e1, e3, q), S.iT1q, q);
+}
+
 }  // namespace hx

@@ -41,6 +41,8 @@ hipError_t launch_moddown_prep_multi_pow2(int logn, const PolyBases& polys, cons
 hipError_t launch_moddown_apply_plain_pow2(int logn, const PolyBases& polys, const PolyBases& outs,
                                            const NttRows& keep, int nkeep, int batch, const ModDownApply& A,
                                            const PrimeDev* primes, const TW* tw_arena, hipStream_t st);
+hipError_t launch_conv_rows(int logn, const ConvRowArgs& A, const ConvRows& R, int nunits, const PrimeDev* cprimes,
+                            const TW* tw_arena, hipStream_t st);
 }
 
 using hx::ExtArgs;
@@ -135,6 +137,7 @@ struct BluePrime {
   TW* d_powers = nullptr;
   TW* d_ipowers = nullptr;
   uint64_t* d_hat[4] = {nullptr, nullptr, nullptr, nullptr};  // Rb, iRb, NTT(-Psi), NTT(Phi)
+  TW* d_hatw[4] = {nullptr, nullptr, nullptr, nullptr};       // the same as Shoup pairs (fused convolution kernel)
   ConvPlan conv[3];                                           // sizes bk, n1, n2
 };
 
@@ -208,6 +211,15 @@ struct hx_ctx {
   };
   bool defer_norms = false;
   std::vector<NormPending> norm_pending, norm_free;
+  // The norm kernels run on a stream of their own, next to whatever the context enqueues after them
+  // (they have no consumer on the device: only the host reads the result).  One LDS-bound workgroup per
+  // CU with almost no VALU work co-resides with the HBM-bound tensor / key-switch kernels.  Ordering:
+  // the side stream waits for an event recorded behind the producers of its input; the main stream
+  // waits for the side stream (norm_join) before anything rewrites what an in-flight norm kernel reads:
+  // scratch[0] / [1] (the mod-down's x, S) or d_frac.
+  hipStream_t norm_stream = nullptr;
+  hipEvent_t norm_in_ev = nullptr, norm_out_ev = nullptr;
+  bool norm_reads_xs = false, norm_reads_frac = false;
   hipEvent_t timer[2] = {nullptr, nullptr};  // hx_ctx_timer_begin / _end
   // HIP graphs (hx_ctx_graph_begin / _end): while a capture is open or a captured graph is alive,
   // nothing a graph may point at is handed back -- slabs that were live during a capture are pinned
@@ -297,6 +309,8 @@ static void retire_or_free(hx_ctx* c, void* p, bool device_wide_sync = false)
 {
   if (!p)
     return;
+  if (c->norm_stream)
+    hipStreamSynchronize(c->norm_stream);  // (the buffer may be one the norm kernels use)
   if (c->capturing || c->graphs_alive > 0) {
     c->graph_retired.push_back(p);
     return;
@@ -323,8 +337,20 @@ static void pool_free(hx_ctx* c, void* p, size_t bytes)
   }
 }
 
+// the main stream waits for the norm kernels still reading the (x, S) scratch slots / d_frac
+static int norm_join(hx_ctx* c, bool xs, bool frac)
+{
+  if ((xs && c->norm_reads_xs) || (frac && c->norm_reads_frac)) {
+    HIPCHK(hipStreamWaitEvent(c->stream, c->norm_out_ev, 0));
+    c->norm_reads_xs = c->norm_reads_frac = false;   // (one event: everything on the side stream so far)
+  }
+  return HX_OK;
+}
+
 static int ensure_scratch(hx_ctx* c, int slot, size_t words)
 {
+  if (slot <= 1)  // about to be rewritten by the caller
+    CHK(norm_join(c, true, false));
   if (c->scratch_words[slot] >= words)
     return HX_OK;
   if (c->scratch[slot]) {
@@ -502,6 +528,11 @@ static void ctx_free(hx_ctx* c)
     if (c->scratch[i])
       hipFree(c->scratch[i]);
   c->arena.destroy();
+  if (c->norm_stream) {
+    hipStreamDestroy(c->norm_stream);
+    hipEventDestroy(c->norm_in_ev);
+    hipEventDestroy(c->norm_out_ev);
+  }
   if (c->own_stream)
     hipStreamDestroy(c->own_stream);
   for (void* q : c->graph_retired)
@@ -525,8 +556,10 @@ static void ctx_free(hx_ctx* c)
     hipFree(b->dev);
     hipFree(b->d_powers);
     hipFree(b->d_ipowers);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++) {
       hipFree(b->d_hat[i]);
+      hipFree(b->d_hatw[i]);
+    }
     for (int i = 0; i < 3; i++)
       hipFree(b->conv[i].dev);
     for (int j = 0; j < 3; j++) {
@@ -567,6 +600,8 @@ extern "C" int hx_ctx_set_stream(hx_ctx* c, void* s)
     // pooled slabs are recycled in stream order: drain the old stream before switching
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    if (c->norm_stream)
+      hipStreamSynchronize(c->norm_stream);
   }
   c->stream = (hipStream_t)s;
   return HX_OK;
@@ -578,6 +613,8 @@ extern "C" int hx_ctx_sync(hx_ctx* c)
   CTX_ENTER(c);
   NO_CAPTURE(c, "hx_ctx_sync");
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->norm_stream)
+    HIPCHK(hipStreamSynchronize(c->norm_stream));
   return HX_OK;
 }
 extern "C" int hx_ctx_arena_stats(hx_ctx* c, uint64_t out[4])
@@ -1045,6 +1082,19 @@ static int make_hat(hx_ctx* c, int prime, int which, int slot, const std::vector
   HIPCHK(hipMemcpyAsync(bp->d_hat[slot], bp->conv[which].split ? c->scratch[5] : c->scratch[4], N * 8,
                         hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  {
+    // the same transform as Shoup pairs {w, floor(w 2^64 / q)}: what the fused convolution kernel multiplies by
+    std::vector<uint64_t> w(N);
+    HIPCHK(hipMemcpy(w.data(), bp->d_hat[slot], N * 8, hipMemcpyDeviceToHost));
+    std::vector<TW> t(N);
+    const uint64_t q = c->primes[prime].q;
+    for (size_t i = 0; i < N; i++) {
+      t[i].w = w[i];
+      t[i].wp = hxh::shoup(w[i], q);
+    }
+    HIPCHK(hipMalloc((void**)&bp->d_hatw[slot], N * sizeof(TW)));
+    HIPCHK(hipMemcpy(bp->d_hatw[slot], t.data(), N * sizeof(TW), hipMemcpyHostToDevice));
+  }
   return HX_OK;
 }
 
@@ -1179,6 +1229,113 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
   // chunk so that the convolution buffers stay below ~1 GiB each
   size_t per_row = (size_t)batch * NB * 8;
   int chunk = (int)std::max<size_t>(1, std::min<size_t>(MAX_ROWS / (c->bk > 18 ? 16 : (c->bk > 17 ? 8 : 4)), ((size_t)1 << 30) / per_row));
+  // fused path (conv_dev.h): every convolution is ONE launch of the convolution row kernel + one
+  // element-wise pass; needs primes that convolve modulo themselves and sizes the row kernels take
+  // (2^13..2^15, the chirp convolution optionally as a radix-4 split)
+  static const bool old_path = getenv("HX_BLUE_OLD") != nullptr;
+  auto sub_ok = [](const ConvPlan& pl) {
+    const int l = pl.split == 4 ? pl.logn - 2 : pl.logn;
+    return (pl.split == 0 || pl.split == 4) && l >= 13 && l <= 15;
+  };
+  bool fused = !old_path;
+  for (auto& rp : rows) {
+    if (rp.second >= (int)c->blue.size() || !c->blue[rp.second])
+      return fail(HX_ERR_INVALID, "prime %d has no Bluestein tables", rp.second);
+    const BluePrime* b0 = c->blue[rp.second];
+    fused = fused && !b0->aux && sub_ok(b0->conv[0]) &&
+            (!inverse || (b0->conv[1].split == 0 && sub_ok(b0->conv[1]) && b0->conv[2].split == 0 && sub_ok(b0->conv[2])));
+  }
+  if (fused)
+    chunk = std::min(chunk, hx::CONV_MAXROWS);
+  for (size_t first = 0; fused && first < rows.size(); first += chunk) {
+    const int R = (int)std::min<size_t>(chunk, rows.size() - first);
+    const size_t segs = (size_t)R * batch;
+    const BluePrime* b0 = c->blue[rows[first].second];
+    const int split = b0->conv[0].split ? 4 : 1, lsub = b0->conv[0].logn - (split == 4 ? 2 : 0);
+    NttRows nr;
+    hx::PtrList bp, cps;
+    hx::ConvRows CR;
+    memset(&CR, 0, sizeof CR);
+    for (int r = 0; r < R; r++) {
+      const BluePrime* b = c->blue[rows[first + r].second];
+      nr.row[r] = (uint16_t)rows[first + r].first;
+      nr.prime[r] = (uint16_t)rows[first + r].second;
+      bp.p[r] = b->dev;
+      cps.p[r] = b->conv[0].dev;
+      CR.bp[r] = b->dev;
+      CR.row[r] = (uint16_t)rows[first + r].first;
+    }
+    auto set_conv = [&](int which, int slot, int sp) {
+      for (int r = 0; r < R; r++) {
+        const BluePrime* b = c->blue[rows[first + r].second];
+        CR.hat[r] = b->d_hatw[slot];
+        CR.cp[r] = b->conv[which].dev;
+        for (int g = 0; g < sp; g++)
+          CR.pd[r * sp + g] = (uint16_t)b->conv[which].pd[g];
+      }
+    };
+    CHK(ensure_scratch(c, 5, segs * NB));
+    uint64_t* qbuf = c->scratch[5];
+    hx::ConvRowArgs A;
+    memset(&A, 0, sizeof A);
+    A.batch = (uint32_t)batch;
+    A.phim = phim;
+    A.m = m;
+    A.in = in;
+    A.out = qbuf;
+    A.split = (uint32_t)split;
+    A.dst_mode = hx::CONV_DST_SUB;
+    A.zidx = c->d_zms_index;
+    A.src_mode = inverse ? hx::CONV_SRC_SCATTER : hx::CONV_SRC_BLUE_PRE;
+    set_conv(0, inverse ? 1 : 0, split);
+    hipError_t e = hx::launch_conv_rows(lsub, A, CR, R * split, c->d_cprimes, c->d_tw, c->stream);
+    if (e != hipSuccess)
+      return fail(HX_ERR_DEVICE, "convolution launch failed: %s", hipGetErrorString(e));
+    uint64_t* xfull = nullptr;
+    if (inverse) {
+      CHK(ensure_scratch(c, 6, segs * c->mpad));
+      CHK(ensure_scratch(c, 7, segs * N1));
+      xfull = c->scratch[6];
+    }
+    // window / fold + second twist (+ the inverse split when the result is in four sub-blocks)
+    uint64_t* pdst = inverse ? xfull : out;
+    const uint32_t pn = inverse ? m : phim;
+    if (split == 4)
+      HX_LAUNCH(hx::blue_post4_kernel, grid2(pn, segs), dim3(256), 0, c->stream, qbuf, pdst, nr, bp, cps, batch, phim, m,
+                (uint32_t)lsub, c->mpad, c->d_zms, inverse ? 0 : 1);
+    else
+      HX_LAUNCH(hx::blue_post_kernel, grid2(pn, segs), dim3(256), 0, c->stream, qbuf, pdst, nr, bp, batch, phim, m, NB,
+                c->mpad, c->d_zms, inverse ? 0 : 1);
+    HIPCHK(hipGetLastError());
+    if (!inverse)
+      continue;
+    // rem Phi_m: Q = rev_d( top(x) * (-Psi) mod X^(d+1) ), r = x - Q*Phi_m, then * m^-1
+    uint64_t* wbuf = c->scratch[7];
+    A.split = 1;
+    A.src_mode = hx::CONV_SRC_REV;
+    A.in = xfull;
+    A.in_stride = c->mpad;
+    A.base = m - 1;
+    A.d = c->dq;
+    A.out = wbuf;
+    set_conv(1, 2, 1);
+    e = hx::launch_conv_rows(c->n1, A, CR, R, c->d_cprimes, c->d_tw, c->stream);
+    if (e != hipSuccess)
+      return fail(HX_ERR_DEVICE, "convolution launch failed: %s", hipGetErrorString(e));
+    A.in = wbuf;
+    A.in_stride = N1;
+    A.base = c->dq;
+    A.aux = xfull;
+    A.aux_stride = c->mpad;
+    A.dst_mode = hx::CONV_DST_FINAL;
+    A.out = out;
+    set_conv(2, 3, 1);
+    e = hx::launch_conv_rows(c->n2, A, CR, R, c->d_cprimes, c->d_tw, c->stream);
+    if (e != hipSuccess)
+      return fail(HX_ERR_DEVICE, "convolution launch failed: %s", hipGetErrorString(e));
+  }
+  if (fused)
+    return HX_OK;
   for (size_t first = 0; first < rows.size(); first += chunk) {
     const int R = (int)std::min<size_t>(chunk, rows.size() - first);
     NttRows nr;
@@ -2363,12 +2520,14 @@ static int frac_begin(hx_ctx* c, size_t doubles)
                 "device embedding norms need m a power of two or m <= 131072 (otherwise the host keeps "
                 "the reference's noiseBoundForUniform bound)");
   if (c->frac_cap < doubles) {
+    CHK(norm_join(c, false, true));
     retire_or_free(c, c->d_frac);
     c->d_frac = nullptr;
     c->frac_cap = 0;
     HIPCHK(hipMalloc((void**)&c->d_frac, doubles * sizeof(double)));
     c->frac_cap = doubles;
   }
+  CHK(norm_join(c, false, true));  // d_frac is about to be rewritten
   c->frac_pos = 0;
   c->want_frac = true;
   c->xs_rows = 0;
@@ -2460,7 +2619,7 @@ static int bnorm_setup(hx_ctx* c)
 }
 
 // squared norms of `rows` polynomials into c->d_norm2 (general m)
-static int embed_norms_general(hx_ctx* c, const double* d_f, int rows)
+static int embed_norms_general(hx_ctx* c, const double* d_f, int rows, hipStream_t ns)
 {
   CHK(bnorm_setup(c));
   const int logp = bn_logp(c), logh = std::min(logp, hx::NORM_MAX_LOGH);
@@ -2477,15 +2636,15 @@ static int embed_norms_general(hx_ctx* c, const double* d_f, int rows)
   const size_t lds = std::max<size_t>(16 * (size_t)H, 256);
   for (size_t r0 = 0; r0 < (size_t)rows; r0 += c->bn_rows_cap) {
     const unsigned nr = (unsigned)std::min<size_t>(c->bn_rows_cap, (size_t)rows - r0);
-    HX_LAUNCH(hx::bnorm_fwd_kernel, dim3(nr * S), dim3(threads), lds, c->stream,
+    HX_LAUNCH(hx::bnorm_fwd_kernel, dim3(nr * S), dim3(threads), lds, ns,
                        d_f + r0 * c->phim, (const double2*)c->d_bn_v, (const double2*)nullptr, c->d_bn_w,
                        (const double2*)c->d_bn_chat, c->d_bn_Z, logp, logh, c->phim, 0);
     HIPCHK(hipGetLastError());
-    HX_LAUNCH(hx::bnorm_inv_kernel, dim3(nr * S), dim3(threads), lds, c->stream, c->d_bn_Z, c->d_bn_w,
+    HX_LAUNCH(hx::bnorm_inv_kernel, dim3(nr * S), dim3(threads), lds, ns, c->d_bn_Z, c->d_bn_w,
                        logp, logh);
     HIPCHK(hipGetLastError());
     const unsigned gx = std::min<unsigned>(64u, (c->phim + 255u) / 256u);
-    HX_LAUNCH(hx::bnorm_max_kernel, dim3(gx, nr), dim3(256), 0, c->stream, (const double2*)c->d_bn_Z,
+    HX_LAUNCH(hx::bnorm_max_kernel, dim3(gx, nr), dim3(256), 0, ns, (const double2*)c->d_bn_Z,
                        c->d_bn_w, c->d_zms, c->phim, logp, logh, c->d_norm2 + r0);
     HIPCHK(hipGetLastError());
   }
@@ -2514,11 +2673,29 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     HIPCHK(hipMalloc((void**)&c->d_norm2, sizeof(unsigned long long) * (size_t)rows));
     c->norm_cap = (size_t)rows;
   }
-  HIPCHK(hipMemsetAsync(c->d_norm2, 0, sizeof(unsigned long long) * (size_t)rows, c->stream));
+  // which source the kernel will read: the mod-down's (x, S) in place, or doubles at d_f (then a pending
+  // (x, S) block is written out as doubles first -- on the main stream, before the hand-over below)
+  const bool quarter_form = c->pow2 && logn >= 2 && logn - 1 <= hx::NORM_MAX_LOGH;
+  const bool use_xs = quarter_form && c->xs_rows == rows && d_f == c->d_frac;
+  if (!use_xs)
+    CHK(flush_xs(c));
+  hipStream_t ns = c->stream;
+  static const bool side_stream_off = getenv("HX_NORM_SYNC") != nullptr;
+  if (!side_stream_off && !c->capturing) {
+    if (!c->norm_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&c->norm_stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&c->norm_in_ev, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&c->norm_out_ev, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(c->norm_in_ev, c->stream));             // behind the producers of the input
+    HIPCHK(hipStreamWaitEvent(c->norm_stream, c->norm_in_ev, 0));
+    ns = c->norm_stream;
+  }
+  HIPCHK(hipMemsetAsync(c->d_norm2, 0, sizeof(unsigned long long) * (size_t)rows, ns));
   static bool attr = false;
   if (!c->pow2) {
     CHK(flush_xs(c));
-    CHK(embed_norms_general(c, d_f, rows));
+    CHK(embed_norms_general(c, d_f, rows, ns));
   } else if (!attr) {
     HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_kernel,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2551,13 +2728,13 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   do {                                                                                                          \
     if (full && logn == 14)                                                                                     \
       HX_LAUNCH((hx::embed_norm_quarter_kernel<SRCT, 14>), dim3((unsigned)rows), dim3(threads), lds,   \
-                         c->stream, srcv, c->d_wtab, logn, c->d_norm2);                                         \
+                         ns, srcv, c->d_wtab, logn, c->d_norm2);                                         \
     else if (full && logn == 13)                                                                                \
       HX_LAUNCH((hx::embed_norm_quarter_kernel<SRCT, 13>), dim3((unsigned)rows), dim3(threads), lds,   \
-                         c->stream, srcv, c->d_wtab, logn, c->d_norm2);                                         \
+                         ns, srcv, c->d_wtab, logn, c->d_norm2);                                         \
     else                                                                                                        \
       HX_LAUNCH((hx::embed_norm_quarter_kernel<SRCT, 0>), dim3((unsigned)rows), dim3(threads), lds,    \
-                         c->stream, srcv, c->d_wtab, logn, c->d_norm2);                                         \
+                         ns, srcv, c->d_wtab, logn, c->d_norm2);                                         \
   } while (0)
     // experiment, off by default: N = 2^14 as two 4096-point sub-transforms per
     // element -- 64 KiB of LDS and 512 threads per workgroup, two elements resident per CU
@@ -2574,7 +2751,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     }
 #define HX_NORM_SPLIT(SRCT, srcv)                                                                            \
   HX_LAUNCH((hx::embed_norm_quarter_splitT_kernel<SRCT, 12, 512>), dim3((unsigned)rows), dim3(512), \
-                     16 * (size_t)4096, c->stream, srcv, c->d_wtab, logn, c->d_norm_park, c->d_norm2)
+                     16 * (size_t)4096, ns, srcv, c->d_wtab, logn, c->d_norm_park, c->d_norm2)
     if (c->xs_rows == rows && d_f == c->d_frac) {
       hx::NormSrcXS src{c->scratch[0], reinterpret_cast<const int64_t*>(c->scratch[1]), c->xs_inv_qd};
       if (split14 && logn == 14)
@@ -2606,14 +2783,14 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       c->norm_park_cap = park_words;
     }
     HX_LAUNCH(hx::embed_norm_quarter_split_kernel, dim3((unsigned)rows * (S / 2)), dim3(hx::NORM_THREADS),
-                       16 * (size_t)H, c->stream, d_f, c->d_wtab, logn, logh, c->d_norm_park, c->d_norm2);
+                       16 * (size_t)H, ns, d_f, c->d_wtab, logn, logh, c->d_norm_park, c->d_norm2);
   } else {
     CHK(flush_xs(c));
     const int logh = std::min(logn, hx::NORM_MAX_LOGH);
     const unsigned H = 1u << logh, S = N >> logh;
     const unsigned threads = std::min<unsigned>(hx::NORM_THREADS, std::max<unsigned>(64u, H / 4));
     const size_t lds = std::max<size_t>(16 * (size_t)H, 256);
-    HX_LAUNCH(hx::embed_norm_kernel, dim3((unsigned)rows * S), dim3(threads), lds, c->stream, d_f,
+    HX_LAUNCH(hx::embed_norm_kernel, dim3((unsigned)rows * S), dim3(threads), lds, ns, d_f,
                        c->d_wtab, logn, logh, c->d_norm2);
   }
   HIPCHK(hipGetLastError());
@@ -2635,9 +2812,13 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   np.rows = rows;
   np.out = out_host;
   HIPCHK(hipMemcpyAsync(np.pinned, c->d_norm2, sizeof(unsigned long long) * (size_t)rows,
-                        hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipEventRecord(np.ev, c->stream));
+                        hipMemcpyDeviceToHost, ns));
+  HIPCHK(hipEventRecord(np.ev, ns));
   c->norm_pending.push_back(np);
+  if (ns != c->stream) {
+    HIPCHK(hipEventRecord(c->norm_out_ev, ns));
+    (use_xs ? c->norm_reads_xs : c->norm_reads_frac) = true;
+  }
   if (c->defer_norms)
     return HX_OK;
   return hx_norms_flush(c);
@@ -3895,13 +4076,15 @@ static int relin_core(hx_ctx* c, const uint64_t* t2e, const std::vector<int>& ow
   // scratch: [2] = s^2 part in the coefficient domain; [1] = digits (ndig*nall rows; a digit's
   // own rows are never materialised)
   CHK(ensure_scratch(c, 2, (size_t)L * rw));
-  CHK(ensure_scratch(c, 1, (size_t)ndig * nall * rw));
   {
     std::vector<std::pair<int, int>> rows;
     for (int r = 0; r < L; r++)
       rows.emplace_back(r, own[r]);
     CHK(ntt_list(c, t2e, c->scratch[2], rows, batch, true));  // toPoly side, out of place
   }
+  // (after the inverse transform is enqueued: taking slot 1 makes the stream wait for a norm kernel that
+  // still reads the preceding mod-switch's S there -- it runs next to the inverse transform meanwhile)
+  CHK(ensure_scratch(c, 1, (size_t)ndig * nall * rw));
   std::vector<int> owner;
   {
     int rc = break_digits_fused(c, c->scratch[2], own, dig_idx, dig_off, ndig, all, c->scratch[1],

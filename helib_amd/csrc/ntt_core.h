@@ -29,6 +29,7 @@
 #if defined(HX_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #endif
 
 #if defined(__HIPCC__)
@@ -683,6 +684,14 @@ HXD unsigned eval_const(int i)
   return brev_bits(ep, LC) * 1024u + (unsigned)T * gi;
 }
 
+// An IO functor may state SKIP_LOAD = true: the inverse transform then starts from what the register
+// file already holds (the convolution kernel: forward transform, pointwise product, inverse transform
+// without leaving the registers).
+template <class IO, class = void>
+struct io_skip_load : std::false_type {};
+template <class IO>
+struct io_skip_load<IO, std::void_t<decltype(IO::SKIP_LOAD)>> : std::integral_constant<bool, IO::SKIP_LOAD> {};
+
 // Plain-pointer row accessor (CPU replay; also valid on the device).
 struct PtrIO {
   static constexpr int LOAD_BOUND = 1;
@@ -848,9 +857,11 @@ struct RowNTT {
                       const IO& io, const TWS& tw, const QC& c)
   {
     if constexpr (PH == 0) {
+      if constexpr (!io_skip_load<IO>::value) {
 #pragma unroll
-      for (int i = 0; i < 32; i++)
-        v[i] = io.load(tid, eval_const<LOGN>(i));
+        for (int i = 0; i < 32; i++)
+          v[i] = io.load(tid, eval_const<LOGN>(i));
+      }
       run_pass<G::LC, true, G::NGC, G::GC - 1, 1>(v, c, [&](int gi, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWC, tid, ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi), dep);
       });

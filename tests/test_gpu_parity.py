@@ -473,6 +473,50 @@ def test_bluestein_m21845_config5(hx):
     assert np.array_equal(da.iFFT().download(), np.roll(a, 1, axis=2))
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_bluestein_m21845_config5_at_L16(hx, fused, monkeypatch):
+    """BASELINE configs[4] at its own shape: m = 21845, L = 16 primes of PrimeGenerator(60, 21845), a batch of 2
+    DoubleCRT objects -- forward and inverse transforms of all 32 rows against the restatement of
+    src/bluestein.cpp / src/CModulus.cpp:431-443, 555-577, every word.  fused: the convolution row kernel
+    (conv_kernels.hip: chirp pre-twist or scatter on load, pointwise product in registers, the window / fold /
+    second twist with the inverse split in one pass; rem Phi_m as two more fused launches); not fused
+    (HX_BLUE_OLD): the round-2 chain of separate passes, kept as the fallback for exotic primes and sizes.
+    Both must give the same words."""
+    import subprocess, sys, json
+    if not fused:
+        # the switch is read once per process: run the comparison in a child with HX_BLUE_OLD set
+        code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+                "from tests.test_gpu_parity import Pair, primes_for\n"
+                "from helib_amd import capi as hx\n"
+                "P = Pair(hx, 21845, primes_for(21845, 16, 60)); idx = list(range(16))\n"
+                "x = P.rand(idx, 9, batch=2); d = hx.DoubleCRT(P.g, idx, 2, x)\n"
+                "got = d.FFT().download()\n"
+                "ok = all(np.array_equal(got[:, b], P.o.fft(idx, x[:, b])) for b in range(2))\n"
+                "ok = ok and np.array_equal(d.iFFT().download(), x)\n"
+                "print('OK' if ok else 'MISMATCH')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, HX_BLUE_OLD="1"))
+        assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+        return
+    m, L = 21845, 16
+    P = Pair(hx, m, primes_for(m, L, 60))
+    idx = list(range(L))
+    x = P.rand(idx, 9, batch=2)
+    d = hx.DoubleCRT(P.g, idx, 2, x)
+    got = d.FFT().download()
+    for b in range(2):
+        assert np.array_equal(got[:, b], P.o.fft(idx, x[:, b]))
+    assert np.array_equal(d.iFFT().download(), x)
+    y = P.rand(idx, 10, batch=2)
+    d1 = hx.DoubleCRT(P.g, idx, 2, y)
+    back = d1.iFFT().download()
+    for b in range(2):
+        assert np.array_equal(back[:, b], P.o.ifft(idx, y[:, b]))
+    # a lazily copied (shared) poly is transformed out of place into its own slab
+    c = d1.copy()
+    assert np.array_equal(c.FFT().download(), y) and np.array_equal(d1.download(), back)
+
+
 def test_general_m_multiply_relin_and_automorph(hx):
     m = 1705                                    # 5*11*31, phi = 1200
     L, K = 4, 2
@@ -501,7 +545,7 @@ def test_general_m_multiply_relin_and_automorph(hx):
 
 
 # ---------------------------------------------------------------- full Ctxt::multiplyBy sequence
-@pytest.mark.parametrize("m,p,bits", [(16384, 65537, 250), (1705, 7, 200)])
+@pytest.mark.parametrize("m,p,bits", [(16384, 65537, 250), (1705, 7, 200), (21845, 2, 950)])
 def test_ctxt_multiplyBy_full_sequence_gpu_vs_oracle(hx, m, p, bits, monkeypatch):
     """The reference's own order of operations for fresh ciphertexts (src/Ctxt.cpp:1681-1774):
     bringToSet (mod-up by a small prime, mod-down by a ctxt prime) -> tensorProduct ->

@@ -21,7 +21,7 @@ def main():
     m = int(os.environ.get("HX_M", "21845"))
     L = int(os.environ.get("HX_L", "16"))
     B = int(os.environ.get("HX_BATCH", "32"))
-    iters = int(os.environ.get("HX_ITERS", "3"))
+    iters = int(os.environ.get("HX_ITERS", "5"))
     rng = np.random.default_rng(7)
     g = hostnt.PrimeGen(60, m)
     primes = [g.next() for _ in range(L)]
@@ -37,16 +37,22 @@ def main():
     d.iFFT()
     ctx.sync()
     assert np.array_equal(d.download(), o), "iFFT(FFT(x)) != x"
-    t0 = time.perf_counter()
+    # (a stretch of load right before each timed loop: the download + comparison above leave the device idle
+    # long enough for its clocks to drop, and the first launches after that are not representative)
+    for _ in range(6):
+        d.FFT()
+        d.iFFT()
+    ctx.timerBegin()
     for _ in range(iters):
         d.FFT()
-    ctx.sync()
-    tf = (time.perf_counter() - t0) / iters
-    t0 = time.perf_counter()
+    tf = ctx.timerEnd() / iters * 1e-3
+    for _ in range(3):
+        d.iFFT()
+        d.FFT()
+    ctx.timerBegin()
     for _ in range(iters):
         d.iFFT()
-    ctx.sync()
-    ti = (time.perf_counter() - t0) / iters
+    ti = ctx.timerEnd() / iters * 1e-3
     byts = 16 * n * L * B
     print(json.dumps({"config": f"Bluestein m={m} phi={n} L={L} batch={B}", "rows": L * B,
                       "fwd_ms": round(tf * 1e3, 4), "inv_ms": round(ti * 1e3, 4),
