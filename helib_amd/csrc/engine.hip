@@ -2680,8 +2680,10 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   if (!use_xs)
     CHK(flush_xs(c));
   hipStream_t ns = c->stream;
-  static const bool side_stream_off = getenv("HX_NORM_SYNC") != nullptr;
-  if (!side_stream_off && !c->capturing) {
+  // (measured, profiles/r03_norm_side_stream_ab.txt: no gain -- the one-workgroup-per-CU norm kernel does not get
+  // onto the CUs next to a kernel that fills them -- so the side stream is opt-in: HX_NORM_ASYNC=1)
+  static const bool side_stream = getenv("HX_NORM_ASYNC") != nullptr;
+  if (side_stream && !c->capturing) {
     if (!c->norm_stream) {
       HIPCHK(hipStreamCreateWithFlags(&c->norm_stream, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&c->norm_in_ev, hipEventDisableTiming));
@@ -2752,16 +2754,35 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
 #define HX_NORM_SPLIT(SRCT, srcv)                                                                            \
   HX_LAUNCH((hx::embed_norm_quarter_splitT_kernel<SRCT, 12, 512>), dim3((unsigned)rows), dim3(512), \
                      16 * (size_t)4096, ns, srcv, c->d_wtab, logn, c->d_norm_park, c->d_norm2)
+    // N = 2^14: the register-tiled kernel (norm_r16.h); HX_NORM_OLD keeps the LDS-pass kernel (A/B)
+    static const bool r16 = getenv("HX_NORM_OLD") == nullptr && getenv("HX_NORM_SPLIT14") == nullptr;
+    constexpr size_t r16_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
+    if (r16 && logn == 14) {
+      static bool attr16 = false;
+      if (!attr16) {
+        HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_r16_kernel<hx::NormSrcXS>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds));
+        HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_r16_kernel<hx::NormSrcF64>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds));
+        attr16 = true;
+      }
+    }
     if (c->xs_rows == rows && d_f == c->d_frac) {
       hx::NormSrcXS src{c->scratch[0], reinterpret_cast<const int64_t*>(c->scratch[1]), c->xs_inv_qd};
-      if (split14 && logn == 14)
+      if (r16 && logn == 14)
+        HX_LAUNCH((hx::embed_norm_r16_kernel<hx::NormSrcXS>), dim3((unsigned)rows), dim3(hx::R16_THREADS), r16_lds, ns, src,
+                  c->d_wtab, c->d_norm2);
+      else if (split14 && logn == 14)
         HX_NORM_SPLIT(hx::NormSrcXS, src);
       else
         HX_NORM_LAUNCH(hx::NormSrcXS, src);
     } else {
       CHK(flush_xs(c));
       hx::NormSrcF64 src{d_f};
-      if (split14 && logn == 14)
+      if (r16 && logn == 14)
+        HX_LAUNCH((hx::embed_norm_r16_kernel<hx::NormSrcF64>), dim3((unsigned)rows), dim3(hx::R16_THREADS), r16_lds, ns, src,
+                  c->d_wtab, c->d_norm2);
+      else if (split14 && logn == 14)
         HX_NORM_SPLIT(hx::NormSrcF64, src);
       else
         HX_NORM_LAUNCH(hx::NormSrcF64, src);
@@ -2782,6 +2803,18 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       HIPCHK(hipMalloc((void**)&c->d_norm_park, park_words * sizeof(double2)));
       c->norm_park_cap = park_words;
     }
+    static const bool r16s = getenv("HX_NORM_OLD") == nullptr;
+    if (r16s && logn == 15) {   // the register-tiled form (norm_r16.h), one workgroup per polynomial
+      constexpr size_t r16_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
+      static bool attr16s = false;
+      if (!attr16s) {
+        HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_r16_split_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds));
+        attr16s = true;
+      }
+      HX_LAUNCH(hx::embed_norm_r16_split_kernel, dim3((unsigned)rows), dim3(hx::R16_THREADS), r16_lds, ns, d_f, c->d_wtab,
+                c->d_norm_park, c->d_norm2);
+    } else
     HX_LAUNCH(hx::embed_norm_quarter_split_kernel, dim3((unsigned)rows * (S / 2)), dim3(hx::NORM_THREADS),
                        16 * (size_t)H, ns, d_f, c->d_wtab, logn, logh, c->d_norm_park, c->d_norm2);
   } else {

@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "norm_r16.h"
+
 namespace hx {
 
 constexpr int NORM_MAX_LOGH = 13;  // 2^13 complex doubles = 128 KiB LDS
@@ -217,6 +219,144 @@ embed_norm_quarter_kernel(SRC src, const double2* __restrict__ wtab, int logn_rt
     mx = n2 > mx ? n2 : mx;
   }
   block_max_to(mx, sm, tid, nth, out2 + row);
+}
+
+// N = 2^14 (the benchmark ring), register-tiled: norm_r16.h.  512 threads x 16 points, three radix-16 register
+// passes, the last stage inside the pairing pass; five barriers instead of nine, four stages per LDS round trip
+// instead of two, 16 independent butterflies per thread in flight instead of 2.
+template <class SRC>
+__global__ void __launch_bounds__(R16_THREADS)
+embed_norm_r16_kernel(SRC src, const double2* __restrict__ wtab, unsigned long long* __restrict__ out2)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* re = sm;
+  double* im = sm + R16_LDS_DOUBLES;
+  const unsigned row = blockIdx.x, t = threadIdx.x;
+  const tw16* wt = reinterpret_cast<const tw16*>(wtab);
+  cplx16 v[16];
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++) {
+    const unsigned i = r16_pos_A(t, k);
+    const double2 p = src.pair(row, R16_N, i);   // (f_2i, f_(2i+1))
+    // V^i = W^(2i) = W^(2t) W^(1024 k): one table entry per thread, the 16 constants at uniform addresses
+    const tw16 w = k == 0 ? wt[2 * t] : r16_cmul(wt[2 * t], wt[1024u * k]);
+    v[k].x = p.x * w.x - p.y * w.y;
+    v[k].y = p.x * w.y + p.y * w.x;
+  }
+  r16_pass<9>(v, t, wt);
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++) {
+    re[r16_pad(r16_pos_A(t, k))] = v[k].x;
+    im[r16_pad(r16_pos_A(t, k))] = v[k].y;
+  }
+  __syncthreads();
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++) {
+    v[k].x = re[r16_pad(r16_pos_B(t, k))];
+    v[k].y = im[r16_pad(r16_pos_B(t, k))];
+  }
+  r16_pass<5>(v, t & 31u, wt);
+  __syncthreads();
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++) {
+    re[r16_pad(r16_pos_B(t, k))] = v[k].x;
+    im[r16_pad(r16_pos_B(t, k))] = v[k].y;
+  }
+  __syncthreads();
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++) {
+    v[k].x = re[r16_pad(r16_pos_C(t, k))];
+    v[k].y = im[r16_pad(r16_pos_C(t, k))];
+  }
+  r16_pass<1>(v, t & 1u, wt);
+  __syncthreads();
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++) {
+    re[r16_pad(r16_pos_C(t, k))] = v[k].x;
+    im[r16_pad(r16_pos_C(t, k))] = v[k].y;
+  }
+  __syncthreads();
+  double mx = 0;
+  const tw16 wpair = wt[32u * r16_brev9(t)];
+#pragma unroll
+  for (unsigned i = 0; i < 16; i++) {
+    const double n2 = r16_pair(re, im, t, i, wpair, wt);
+    mx = n2 > mx ? n2 : mx;
+  }
+  block_max_to(mx, sm, t, R16_THREADS, out2 + row);
+}
+
+// N = 2^15 (the CKKS ring of BASELINE configs[3]) on the same register passes: the 16384-point transform of the
+// quarter form as S = 2 sub-transforms of 8192 points (embed_norm_quarter_split_kernel below describes the split);
+// one workgroup per polynomial: sub-transform 1 first, parked in global memory straight from the registers, then
+// sub-transform 0 in LDS and the pairing across the two.
+__global__ void __launch_bounds__(R16_THREADS)
+embed_norm_r16_split_kernel(const double* __restrict__ f, const double2* __restrict__ wtab, double2* __restrict__ park,
+                            unsigned long long* __restrict__ out2)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* re = sm;
+  double* im = sm + R16_LDS_DOUBLES;
+  const unsigned row = blockIdx.x, t = threadIdx.x;
+  const tw16* wt = reinterpret_cast<const tw16*>(wtab);
+  const double* fr = f + (size_t)row * (1u << 15);
+  cplx16* pk = reinterpret_cast<cplx16*>(park) + (size_t)row * 8192u;
+  cplx16 v[16];
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    const unsigned sub = pass == 0 ? 1u : 0u;
+#pragma unroll
+    for (unsigned k = 0; k < 16; k++)
+      v[k] = r16_split_input(fr, wt, r16_pos_A(t, k), sub);
+    r16_pass<9, 15>(v, t, wt);
+    __syncthreads();   // (second round: the pairing-free LDS of round one is being rewritten)
+#pragma unroll
+    for (unsigned k = 0; k < 16; k++) {
+      re[r16_pad(r16_pos_A(t, k))] = v[k].x;
+      im[r16_pad(r16_pos_A(t, k))] = v[k].y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned k = 0; k < 16; k++) {
+      v[k].x = re[r16_pad(r16_pos_B(t, k))];
+      v[k].y = im[r16_pad(r16_pos_B(t, k))];
+    }
+    r16_pass<5, 15>(v, t & 31u, wt);
+    __syncthreads();
+#pragma unroll
+    for (unsigned k = 0; k < 16; k++) {
+      re[r16_pad(r16_pos_B(t, k))] = v[k].x;
+      im[r16_pad(r16_pos_B(t, k))] = v[k].y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned k = 0; k < 16; k++) {
+      v[k].x = re[r16_pad(r16_pos_C(t, k))];
+      v[k].y = im[r16_pad(r16_pos_C(t, k))];
+    }
+    r16_pass<1, 15>(v, t & 1u, wt);
+    if (pass == 0) {
+#pragma unroll
+      for (unsigned k = 0; k < 16; k++)
+        pk[r16_pos_C(t, k)] = v[k];
+    } else {
+      __syncthreads();
+#pragma unroll
+      for (unsigned k = 0; k < 16; k++) {
+        re[r16_pad(r16_pos_C(t, k))] = v[k].x;
+        im[r16_pad(r16_pos_C(t, k))] = v[k].y;
+      }
+    }
+  }
+  __syncthreads();   // LDS of sub-transform 0 complete; the parked values of this workgroup visible to it
+  double mx = 0;
+  const tw16 wpair = wt[64u * r16_brev9(t)];
+#pragma unroll
+  for (unsigned i = 0; i < 16; i++) {
+    const double n2 = r16_split_pair(re, im, pk, t, i, wpair, wt);
+    mx = n2 > mx ? n2 : mx;
+  }
+  block_max_to(mx, sm, t, R16_THREADS, out2 + row);
 }
 
 // The quarter form for N > 2^14 (M = N/2 = S*H points, H = 8192, S = 2, 4, 8): the M-point transform

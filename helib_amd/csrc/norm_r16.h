@@ -1,0 +1,159 @@
+// norm_r16.h -- register-tiled form of the canonical-embedding norm for N = 2^14 (the benchmark ring):
+// the 8192-point complex transform of the "quarter" trick (norm_kernels.h, src/norms.cpp:200-262) as
+// THREE radix-16 register passes of 512 threads x 16 points plus one stage folded into the pairing
+// pass, five barriers in all.  The round-1/2 kernel (embed_norm_quarter_kernel) makes seven radix-4
+// passes through LDS with 1024 threads x 2 butterflies each, nine barriers, every pass exposing an LDS
+// round trip per two stages: 40 us per element on a CU against 7.5 us of LDS bandwidth.
+//
+// Decimation in frequency, output in bit-reversed order (only maxima are taken).  Stage with half-length
+// len: (a, b) = (x[k], x[k+len]) -> x[k] = a + b, x[k+len] = (a - b) T_len(j), j = k mod len,
+// T_len(j) = W^(j N / len) = wtab[j N/len]  (N = 16384, W = exp(2 pi i / 2N) ... as dif_fft_lds).
+//   pass A  len = 4096, 2048, 1024, 512   positions  t + 512 k            (t < 512,  k < 16)
+//   pass B  len =  256,  128,   64,  32   positions  512 b + j + 32 k     (b = t>>5, j = t&31)
+//   pass C  len =   16,    8,    4,   2   positions   32 b + j +  2 k     (b = t>>1, j = t&1)
+//   stage len = 1 inside the pairing pass: Z[p] = x[p] + x[p+1] (p even), x[p-1] - x[p] (p odd)
+// LDS index i is stored at i + (i >> 5): pass C's stride-32 block starts then fall on different banks.
+// The phase functions are plain C++ (HXD) so that tests/cpp/norm_replay.cpp runs them thread by thread
+// on the CPU against the definition.
+#pragma once
+#include <stdint.h>
+
+#ifndef HXD
+#if defined(__HIPCC__)
+#define HXD __host__ __device__ __forceinline__
+#else
+#define HXD inline
+#endif
+#endif
+
+namespace hx {
+
+struct cplx16 {
+  double x, y;
+};
+struct tw16 {   // layout-compatible with double2
+  double x, y;
+};
+constexpr unsigned R16_LOGN = 14, R16_N = 1u << R16_LOGN, R16_M = R16_N >> 1, R16_THREADS = 512;
+constexpr unsigned R16_LDS_DOUBLES = R16_M + (R16_M >> 5);   // one of the two arrays (re / im), padded
+HXD unsigned r16_pad(unsigned i) { return i + (i >> 5); }
+
+HXD tw16 r16_cmul(tw16 a, tw16 b) { return tw16{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// four DIF stages on 16 points S apart (S = 2^LOGS): v[k] <-> position base + j0 + S k, j0 < S.
+// LOGTAB: log2 of the twiddle table's size (T_len(j) = wtab[j 2^LOGTAB / len]): 14 for N = 2^14; 15 when the
+// 8192-point transform is one of the two sub-transforms of N = 2^15 (embed_norm_r16_split_kernel).
+// Twiddles: the stage with len = S h multiplies position j0 + S k' (k' < h) by
+//   T = W^((j0 + S k') 2^LOGTAB / (S h)) = B_h * exp(pi i k' / h),   B_h = W^(j0 2^LOGTAB / (S h)),
+// so ONE table entry per pass and thread is loaded (B_8; B_4 = B_8^2, B_2 = B_4^2, B_1 = B_2^2) and the
+// rest are its products with the 16th roots of unity exp(pi i k / 8), read from the table at wave-uniform
+// addresses (wtab[k 2^LOGTAB / 8]) -- the first version loaded all 15 twiddles of a pass per thread from the
+// strided table and was latency-bound on them (slower than the LDS-pass kernel it was to replace).
+template <int LOGS, int LOGTAB = 14>
+HXD void r16_pass(cplx16 (&v)[16], unsigned j0, const tw16* wtab)
+{
+  constexpr unsigned S = 1u << LOGS;
+  tw16 B = wtab[j0 * ((1u << LOGTAB) / (S * 8u))];
+#pragma unroll
+  for (unsigned h = 8; h >= 1; h >>= 1) {
+#pragma unroll
+    for (unsigned k = 0; k < 16; k++) {
+      if (k & h)
+        continue;
+      const unsigned kp = k & (h - 1);
+      // exp(pi i kp / h) = W^(kp 2^LOGTAB / h)
+      const tw16 T = kp == 0 ? B : r16_cmul(B, wtab[kp * ((1u << LOGTAB) / h)]);
+      const cplx16 a = v[k], b = v[k + h];
+      const double dx = a.x - b.x, dy = a.y - b.y;
+      v[k].x = a.x + b.x;
+      v[k].y = a.y + b.y;
+      v[k + h].x = dx * T.x - dy * T.y;
+      v[k + h].y = dx * T.y + dy * T.x;
+    }
+    B = r16_cmul(B, B);
+  }
+}
+// where thread t keeps its 16 points of each pass: position of v[k]
+HXD unsigned r16_pos_A(unsigned t, unsigned k) { return t + 512u * k; }
+HXD unsigned r16_pos_B(unsigned t, unsigned k) { return 512u * (t >> 5) + (t & 31u) + 32u * k; }
+HXD unsigned r16_pos_C(unsigned t, unsigned k) { return 32u * (t >> 1) + (t & 1u) + 2u * k; }
+
+HXD unsigned r16_brev13(unsigned p)
+{
+  unsigned r = 0;
+  for (int i = 0; i < 13; i++)
+    r |= ((p >> i) & 1u) << (12 - i);
+  return r;
+}
+// value at output position p after the last stage (len = 1, twiddle 1), from the padded LDS arrays / from a
+// plain complex array (the parked sub-transform of the N = 2^15 form)
+HXD cplx16 r16_last_lds(const double* re, const double* im, unsigned p)
+{
+  const unsigned pe = p & ~1u;
+  const double ar = re[r16_pad(pe)], ai = im[r16_pad(pe)], br = re[r16_pad(pe + 1)], bi = im[r16_pad(pe + 1)];
+  return (p & 1u) ? cplx16{ar - br, ai - bi} : cplx16{ar + br, ai + bi};
+}
+HXD cplx16 r16_last_mem(const cplx16* x, unsigned p)
+{
+  const unsigned pe = p & ~1u;
+  const cplx16 a = x[pe], b = x[pe + 1];
+  return (p & 1u) ? cplx16{a.x - b.x, a.y - b.y} : cplx16{a.x + b.x, a.y + b.y};
+}
+// max of |f|^2 at the two evaluation points that Z_j = z and Z_(M-1-j) = partner give, w = W^(2j+1)
+// (embed_norm_quarter_kernel's formula)
+HXD double r16_pair_norm2(cplx16 z, cplx16 partner, tw16 w)
+{
+  const double cr = partner.x, ci = -partner.y;
+  const double er = 0.5 * (z.x + cr), ei = 0.5 * (z.y + ci);
+  const double dr = z.x - cr, di = z.y - ci;
+  const double orr = 0.5 * di, oi = -0.5 * dr;
+  const double tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
+  const double a = (er + tr) * (er + tr) + (ei + ti) * (ei + ti);
+  const double b = (er - tr) * (er - tr) + (ei - ti) * (ei - ti);
+  return a > b ? a : b;
+}
+HXD unsigned r16_brev9(unsigned t)
+{
+  unsigned r = 0;
+  for (int i = 0; i < 9; i++)
+    r |= ((t >> i) & 1u) << (8 - i);
+  return r;
+}
+HXD unsigned r16_brev4(unsigned i) { return ((i & 1u) << 3) | ((i & 2u) << 1) | ((i & 4u) >> 1) | ((i & 8u) >> 3); }
+// N = 2^14: the pairing pass for output position p = t + 512 i (t < 512, i < 16): j = brev13(p) =
+// 16 brev9(t) + brev4(i), so W^(2j+1) = W^(32 brev9(t)) * W^(2 brev4(i) + 1): wt = the first factor (one
+// load per thread), the second is read at a wave-uniform address
+HXD double r16_pair(const double* re, const double* im, unsigned t, unsigned i, tw16 wt, const tw16* wtab)
+{
+  const unsigned p = t + 512u * i;
+  const tw16 w = r16_cmul(wt, wtab[2u * r16_brev4(i) + 1u]);
+  return r16_pair_norm2(r16_last_lds(re, im, p), r16_last_lds(re, im, R16_M - 1u - p), w);
+}
+// N = 2^15 as S = 2 sub-transforms of H = 8192 points (norm_kernels.h, embed_norm_quarter_split_kernel):
+// input point i of sub-transform `sub`: h_i = sum_{t<2} z_(i+tH) U^((i+tH) sub),
+//   z_n U^(n sub) = (f_2n + i f_(2n+1)) W^(2n (2 sub + 1)),  W = exp(2 pi i / 2N),  wtab[k] = W^k for k < N
+HXD cplx16 r16_split_input(const double* f, const tw16* wtab, unsigned i, unsigned sub)
+{
+  constexpr unsigned N = 1u << 15, H = 8192u, mmask = 2u * N - 1u;
+  cplx16 acc{0.0, 0.0};
+  for (unsigned t = 0; t < 2; t++) {
+    const unsigned idx = i + t * H;
+    const unsigned e = (2u * idx * (2u * sub + 1u)) & mmask;
+    const tw16 w = wtab[e & (N - 1u)];
+    const double vx = f[2 * idx], vy = f[2 * idx + 1];
+    const double zr = vx * w.x - vy * w.y, zi = vx * w.y + vy * w.x;
+    acc.x += e >= N ? -zr : zr;
+    acc.y += e >= N ? -zi : zi;
+  }
+  return acc;
+}
+// pairing of sub-transform 0 (in LDS) with the parked sub-transform 1: Z_j, j = 2 brev13(p), and Z_(M-1-j) at H-1-p
+// (p = t + 512 i: W^(4 brev13(p) + 1) = W^(64 brev9(t)) * W^(4 brev4(i) + 1); wt = the first factor)
+HXD double r16_split_pair(const double* re, const double* im, const cplx16* park, unsigned t, unsigned i, tw16 wt,
+                          const tw16* wtab)
+{
+  const unsigned p = t + 512u * i;
+  const tw16 w = r16_cmul(wt, wtab[4u * r16_brev4(i) + 1u]);
+  return r16_pair_norm2(r16_last_lds(re, im, p), r16_last_mem(park, 8191u - p), w);
+}
+
+}  // namespace hx

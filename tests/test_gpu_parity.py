@@ -1311,6 +1311,62 @@ def test_ckks_encrypt_multiply_decrypt_gpu_vs_oracle(hx, m, precision, bits, c, 
         assert np.max(np.abs(got - want)) < 2.0 ** (-precision + 6) / n
 
 
+def test_ckks_m65536_chain_batched_bit_exact(hx, monkeypatch):
+    """BASELINE configs[3] as bench.py --workload ckks65536 runs it: m = 65536, bits = 1400 (L = 24, K = 8, D = 3),
+    a BATCH of two distinct CKKSencrypt-ed pairs packed along the batch axis, multiplied at level 1 (fresh x fresh)
+    and level 2 (product x product: the several-primes mod-switch at N = 32768, batched) in one set of launches;
+    the oracle backend runs the same host logic once per pair.  Every part, row and batch element must agree
+    word for word (the prime-set decisions are the batch's: its noise estimate is the largest element's)."""
+    from helib_amd import ctxt as hc, keys as hk
+    from oracle.backend import OracleBackend
+    monkeypatch.setattr(hc.Ctxt, "measure", True)
+    m, precision, B = 65536, 20, 2
+    cc = hc.ChainContext(m, -1, precision, bits=1400, c=3, ckks=True)
+    P = Pair(hx, m, cc.primes)
+    gsk = hk.SecKey(cc, hk.HxBackend(P.g, cc), seed=21)
+    osk = hk.SecKey(cc, OracleBackend(P.o, cc), seed=21)
+    for sk in (gsk, osk):
+        sk.GenSecKey(maxDegKswitch=2)
+    n, L = cc.phim, len(cc.ctxtPrimes)
+    rng = np.random.default_rng(9)
+    f = float(1 << precision)
+    vals = rng.uniform(-1, 1, size=(2, B, n)) / n
+    genc = [[gsk.CKKSencrypt(np.rint(vals[j, b] * f).astype(np.int64), 1.0, f) for b in range(B)] for j in range(2)]
+    oenc = [[osk.CKKSencrypt(np.rint(vals[j, b] * f).astype(np.int64), 1.0, f) for b in range(B)] for j in range(2)]
+    ops = []
+    for j in range(2):
+        c = genc[j][0].clone()
+        c.lnNoise = max(x.lnNoise for x in genc[j])
+        c.parts = {h: hx.DoubleCRT(P.g, list(cc.ctxtPrimes), B,
+                                   np.stack([genc[j][b].parts[h].download()[:, 0] for b in range(B)], axis=1))
+                   for h in ("1", "s")}
+        ops.append(c)
+    ga, gb = ops
+
+    def same(gc, ocs):
+        for b, oc in enumerate(ocs):
+            assert gc.primeSet == oc.primeSet and set(gc.parts) == set(oc.parts)
+            for h in gc.parts:
+                gi, oi = gc.parts[h].getIndexSet(), oc.parts[h].getIndexSet()
+                gd, od = gc.parts[h].download()[:, b], oc.parts[h].download()[:, 0]
+                for r, i in enumerate(gi):
+                    assert np.array_equal(gd[r], od[oi.index(i)]), (b, h, i)
+
+    ga.multiplyBy(gb)
+    for b in range(B):
+        oenc[0][b].multiplyBy(oenc[1][b])
+    same(ga, oenc[0])
+    # the batch takes its prime-set decision from its largest noise estimate: give each oracle element that estimate
+    worst = max(o.lnNoise for o in oenc[0])
+    assert abs(ga.lnNoise - worst) < 1e-7
+    for o in oenc[0]:
+        o.lnNoise = worst
+    ga.multiplyBy(ga.clone())
+    for o in oenc[0]:
+        o.multiplyBy(o.clone())
+    same(ga, oenc[0])
+
+
 @pytest.mark.parametrize("m,L,t", [(16384, 5, 65537), (16384, 3, 2), (128, 4, (1 << 59) + 1), (1705, 3, 49),
                                    # whole chains of the reference's own benchmark parameter (bits=6400: 143
                                    # primes): beyond 64 source primes the digits live in private memory

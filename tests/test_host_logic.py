@@ -252,3 +252,15 @@ def test_slab_arena_on_the_cpu(tmp_path):
                            "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "arena_test OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_register_tiled_norm_kernel_replayed_on_cpu(tmp_path):
+    """helib_amd/csrc/norm_r16.h (the N = 2^14 canonical-embedding norm as three radix-16 register passes + the
+    last stage inside the pairing pass): its phase functions run thread by thread on the CPU, with the kernel's
+    index maps, twiddle strides and padded LDS layout, against the long-double definition max_j |f(W^(2j+1))|
+    over ALL evaluation points, for a sparse and a dense polynomial (1e-9 relative)."""
+    exe = str(tmp_path / "norm_replay")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unknown-pragmas",
+                           os.path.join(ROOT, "tests", "cpp", "norm_replay.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "norm_replay OK" in r.stdout, r.stdout + r.stderr

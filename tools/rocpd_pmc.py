@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Per-kernel PMC totals from rocprofv3 (ROCm 7.x sqlite) --pmc runs.
-usage: python tools/rocpd_pmc.py gpurun_out/pmc1 [gpurun_out/pmc2 ...]"""
+"""Per-kernel, per-launch-size PMC totals from rocprofv3 (ROCm 7.x sqlite) --pmc runs.
+usage: python tools/rocpd_pmc.py gpurun_out/pmc1 [gpurun_out/pmc2 ...] [--min-us 20]
+One line per (kernel, workgroups per launch, counter): dispatches, average duration, average counter value
+per dispatch (summed over the counter's instances).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+counts a 128-byte request as 64 bytes (MI355X_MICROARCH.md): the `bytes` column doubles it."""
 import glob
 import os
 import sqlite3
@@ -9,26 +12,35 @@ from collections import defaultdict
 
 
 def main():
-    for path in sys.argv[1:]:
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    min_us = 20.0
+    if "--min-us" in sys.argv:
+        min_us = float(sys.argv[sys.argv.index("--min-us") + 1])
+    for path in args:
         for db in sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True)):
             c = sqlite3.connect(db)
-            rows = c.execute("select name, counter_name, dispatch_id, sum(counter_value), max(duration) "
-                             "from pmc_events group by name, counter_name, dispatch_id").fetchall()
-            agg = defaultdict(lambda: defaultdict(list))
-            dur = defaultdict(dict)
-            for name, cn, did, val, d in rows:
-                agg[name][cn].append(val)
-                dur[name][did] = d
+            rows = c.execute(
+                "select p.name, k.grid_x * k.grid_y * k.grid_z / (k.workgroup_x * k.workgroup_y * k.workgroup_z), "
+                "p.counter_name, p.dispatch_id, sum(p.counter_value), max(p.duration) "
+                "from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id "
+                "group by p.name, p.counter_name, p.dispatch_id").fetchall()
+            agg = defaultdict(list)
+            for name, wgs, cn, did, val, d in rows:
+                agg[(name, wgs, cn)].append((val, d))
             print(f"# {db}")
-            for name in sorted(agg, key=lambda n: -sum(dur[n].values())):
-                nd = len(dur[name])
-                print(f"{name[:100]}\n    dispatches={nd} avg_us={sum(dur[name].values())/nd/1e3:.1f}")
-                for cn in sorted(agg[name]):
-                    v = agg[name][cn]
-                    print(f"    {cn:28s} avg/dispatch = {sum(v)/len(v):16.1f}")
-                    if len(set(round(x) for x in v)) > 1 and len(v) <= 16:
-                        # the same kernel at different launch sizes: one value per dispatch, in order
-                        print(f"    {'':28s} per dispatch  = " + "  ".join(f"{x:.1f}" for x in v))
+            print(f"{'kernel':64s} {'workgroups':>10s} {'counter':>14s} {'dispatches':>10s} {'avg_us':>9s} {'avg/dispatch':>16s} {'bytes':>16s}")
+            for (name, wgs, cn), v in sorted(agg.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
+                avg_us = sum(x[1] for x in v) / len(v) / 1e3
+                if avg_us < min_us:
+                    continue
+                avg = sum(x[0] for x in v) / len(v)
+                byts = ""
+                if cn == "FETCH_SIZE":
+                    byts = f"{avg * 1024 * 2:.0f}"
+                elif cn == "WRITE_SIZE":
+                    byts = f"{avg * 1024:.0f}"
+                short = name if len(name) <= 64 else name[:61] + "..."
+                print(f"{short:64s} {wgs:10d} {cn:>14s} {len(v):10d} {avg_us:9.1f} {avg:16.1f} {byts:>16s}")
 
 
 if __name__ == "__main__":
