@@ -56,7 +56,7 @@ SYMBOLS = [
     "hx_intel_EltwiseMultModScalar",
     "hx_time_ntt", "hx_ctx_timer_begin", "hx_ctx_timer_end", "hx_randomize",
     "hx_ctx_graph_begin", "hx_ctx_graph_end", "hx_graph_launch", "hx_graph_destroy",
-    "hx_profile_begin", "hx_profile_end", "hx_ctx_arena_stats",
+    "hx_profile_begin", "hx_profile_end", "hx_ctx_arena_stats", "hx_ctx_reserve",
 ]
 
 
@@ -139,7 +139,7 @@ def lib():
             "hx_ctx_graph_begin": [vp], "hx_ctx_graph_end": [vp, vp], "hx_graph_launch": [vp],
             "hx_graph_destroy": [vp],
             "hx_profile_begin": [], "hx_profile_end": [vp, C.c_size_t, vp],
-            "hx_ctx_arena_stats": [vp, vp],
+            "hx_ctx_arena_stats": [vp, vp], "hx_ctx_reserve": [vp, C.c_uint64],
         }
         for name, args in sig.items():
             f = getattr(L, name)
@@ -217,6 +217,10 @@ class Context:
         ms = C.c_float()
         _chk(lib().hx_ctx_timer_end(self.h, C.byref(ms)))
         return ms.value
+
+    def reserve(self, nbytes):
+        """Reserve device memory for this context's slabs up front (hx_ctx_reserve)."""
+        _chk(lib().hx_ctx_reserve(self.h, int(nbytes)))
 
     def arenaStats(self):
         """Device memory behind this context's DoubleCRT slabs (hx_ctx_arena_stats): bytes reserved from

@@ -133,6 +133,14 @@ struct SlabArena {
     for (void* p : d)
       release(p);
   }
+  // make sure at least `bytes` are reserved from the system allocator (one chunk for the difference), so that
+  // a loop whose footprint is known up front never reaches the system allocator while it is being timed
+  int reserve(size_t bytes)
+  {
+    if (reserved >= bytes)
+      return 0;
+    return grow_exact(round_up(bytes - reserved));
+  }
   size_t cached() const { return reserved - in_use; }
   // give wholly free chunks back to the system until at most `keep` bytes stay cached (the caller has
   // drained the stream: the system allocator is not stream-ordered); returns the bytes released
@@ -182,6 +190,34 @@ struct SlabArena {
         return;
       }
   }
+  int grow_exact(size_t want)
+  {
+    void* p = nullptr;
+    sys_calls++;
+    int rc = sys_alloc(want, &p);
+    if (rc != 0)
+      return rc;
+    add_chunk(p, want);
+    return 0;
+  }
+  void add_chunk(void* p, size_t want)
+  {
+    int ci = -1;
+    for (size_t i = 0; i < chunks.size(); i++)
+      if (!chunks[i].base) {
+        ci = (int)i;
+        break;
+      }
+    if (ci < 0) {
+      chunks.emplace_back();
+      ci = (int)chunks.size() - 1;
+    }
+    chunks[(size_t)ci].base = (char*)p;
+    chunks[(size_t)ci].size = want;
+    chunks[(size_t)ci].used = 0;
+    reserved += want;
+    put_free(ci, 0, want);
+  }
   int grow(size_t len)
   {
     // geometric: the next chunk is as large as everything reserved so far (at least first_chunk, at
@@ -205,21 +241,7 @@ struct SlabArena {
     }
     if (rc != 0)
       return rc;
-    int ci = -1;
-    for (size_t i = 0; i < chunks.size(); i++)
-      if (!chunks[i].base) {
-        ci = (int)i;
-        break;
-      }
-    if (ci < 0) {
-      chunks.emplace_back();
-      ci = (int)chunks.size() - 1;
-    }
-    chunks[(size_t)ci].base = (char*)p;
-    chunks[(size_t)ci].size = want;
-    chunks[(size_t)ci].used = 0;
-    reserved += want;
-    put_free(ci, 0, want);
+    add_chunk(p, want);
     return 0;
   }
 };

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -288,7 +289,12 @@ static int use(hx_ctx* c)
 static constexpr size_t POOL_LIMIT = (size_t)64 << 30;        // keep at most 64 GiB cached
 static int arena_sys_alloc(size_t bytes, void** out)
 {
+  static const bool trace = getenv("HX_ARENA_TRACE") != nullptr;   // one line per hipMalloc the arena makes
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(out, bytes);
+  if (trace)
+    fprintf(stderr, "[helib_amd arena] hipMalloc(%zu MiB) took %.2f ms\n", bytes >> 20,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   if (e != hipSuccess)
     (void)hipGetLastError();
   return (int)e;
@@ -615,6 +621,20 @@ extern "C" int hx_ctx_sync(hx_ctx* c)
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->norm_stream)
     HIPCHK(hipStreamSynchronize(c->norm_stream));
+  return HX_OK;
+}
+extern "C" int hx_ctx_reserve(hx_ctx* c, uint64_t bytes)
+{
+  if (!c)
+    return fail(HX_ERR_INVALID, "null context");
+  CTX_ENTER(c);
+  if (!c->arena.sys_alloc) {
+    c->arena.sys_alloc = arena_sys_alloc;
+    c->arena.sys_free = arena_sys_free;
+  }
+  const int rc = c->arena.reserve((size_t)bytes);
+  if (rc != 0)
+    return fail(HX_ERR_NOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString((hipError_t)rc));
   return HX_OK;
 }
 extern "C" int hx_ctx_arena_stats(hx_ctx* c, uint64_t out[4])
@@ -2803,8 +2823,11 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       HIPCHK(hipMalloc((void**)&c->d_norm_park, park_words * sizeof(double2)));
       c->norm_park_cap = park_words;
     }
-    static const bool r16s = getenv("HX_NORM_OLD") == nullptr;
-    if (r16s && logn == 15) {   // the register-tiled form (norm_r16.h), one workgroup per polynomial
+    // the register-tiled form (norm_r16.h) at N = 2^15: measured SLOWER than the kernel below (140 vs 82 us per 192
+    // polynomials, profiles/r03_norm_kernels_ab.txt: both sub-transforms run one after the other in one workgroup,
+    // where the kernel below overlaps 16 waves) -- opt-in for experiments only
+    static const bool r16s = getenv("HX_NORM_R16_SPLIT") != nullptr;
+    if (r16s && logn == 15) {
       constexpr size_t r16_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
       static bool attr16s = false;
       if (!attr16s) {

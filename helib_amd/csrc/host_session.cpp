@@ -74,6 +74,13 @@ extern "C" int hxh_session_create(hxh_session** out, int device, void* stream, i
     const ChainContext& cc = *s->cc;
     s->dev = cc.makeDeviceContext(device);
     s->dev->setStream(stream);
+    {
+      // the loop's working set, reserved before anything is timed: about 48 slabs of the largest DoubleCRT of the
+      // chain (operands, their mod-switched copies, tensor and key-switch outputs, the kept products of two levels)
+      const uint64_t slab = (uint64_t)(cc.ctxtPrimes.size() + cc.specialPrimes.size() + 2) * (uint64_t)batch *
+                            (uint64_t)cc.phim * 8u;
+      s->dev->reserve(std::min<uint64_t>(48 * slab, (uint64_t)64 << 30));
+    }
     s->sk = seed ? std::make_unique<SecKey>(cc, *s->dev, seed) : std::make_unique<SecKey>(cc, *s->dev);
     s->sk->GenSecKey(2);   // s^2 -> s: what multiplyBy relinearises with (benchmarks/bgv_basic.cpp:150-152)
     const size_t N = (size_t)cc.phim, L = cc.ctxtPrimes.size(), B = (size_t)batch;

@@ -293,6 +293,11 @@ int hx_profile_end(char* json, size_t cap, size_t* needed);
  * bytes handed out to polys, out[2] = hipMalloc calls made so far (a warm loop adds none, whatever it
  * keeps alive), out[3] = blocks parked because a live HIP graph may still point at them. */
 int hx_ctx_arena_stats(hx_ctx* ctx, uint64_t out[4]);
+/* Reserves at least `bytes` of device memory for the context's slabs now (one hipMalloc for what is missing), so
+ * that a loop whose footprint is known -- a benchmark's batch, a pipeline's working set -- never reaches hipMalloc
+ * while it runs: a multi-GiB hipMalloc takes tens of milliseconds and stalls the stream.  Sized for 288 GB parts:
+ * reserve generously. */
+int hx_ctx_reserve(hx_ctx* ctx, uint64_t bytes);
 
 /* ---- HIP graphs: the launch-bound case -------------------------------------------------------
  * The reference's benchmark loop runs ONE ciphertext at a time (benchmarks/bgv_basic.cpp:158-164:

@@ -217,6 +217,8 @@ public:
   void sync() const { check(hx_ctx_sync(h_.get())); }
   // the HIP stream (hipStream_t) every call on this context enqueues on; nullptr = the default stream
   void setStream(void* stream) const { check(hx_ctx_set_stream(h_.get(), stream)); }
+  // device memory for the slabs of this context's DoubleCRT objects, reserved up front (hx_ctx_reserve)
+  void reserve(uint64_t bytes) const { check(hx_ctx_reserve(h_.get(), bytes)); }
   hx_ctx* handle() const { return h_.get(); }
 
   // Measured-noise norms (hx_*_norms) either land in the caller's array before the call returns, or --

@@ -122,6 +122,7 @@ int hx_ctx_phim(const hx_ctx* c, uint64_t* phim)
   return HX_OK;
 }
 int hx_ctx_set_stream(hx_ctx*, void*) { return HX_OK; }
+int hx_ctx_reserve(hx_ctx*, uint64_t) { return HX_OK; }
 int hx_ctx_sync(hx_ctx*) { return HX_OK; }
 int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_out)
 {
