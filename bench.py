@@ -539,6 +539,15 @@ def kernel_table(prof, n, B, l, k, d, mults):
             byts, what = el * (nk * 16 * n - 8 * n + 16 * n), f"{el} elements x ({nk} kept rows x 16N - 8N (added row) + x,S 16N)"
         elif name.startswith("ntt_moddown_apply_kernel<"):
             byts, what = w * 24 * n, "delta/P in 8N + c_r in + out 16N per kept row"
+        elif name.startswith("ntt_moddown_apply_tensor_kernel<"):
+            nk = l                                   # tensorProduct folded into the product's single-prime mod-switch
+            el = max(1, w // (3 * nk))               # batch elements (three product parts each)
+            # compulsory traffic per batch element: the four operand parts' nk-1 real rows in once (the kernel reads
+            # a row once per product part that uses it: 8 row reads for 4 rows), the three parts' nk rows out, x and S
+            byts = el * 8 * n * (4 * (nk - 1) + 3 * nk + 6)
+            what = f"{el} elements x 8N x (4 operand parts x {nk - 1} rows in + 3 parts x {nk} rows out + x,S of 3 parts)"
+        elif name.startswith("ntt_moddown_prep_tensor_kernel<"):
+            byts, what = (w // 3) * 8 * n * (4 + 3), "4 operand rows in, x of 3 parts out per batch element"
         elif name.startswith("tensor_kernel"):
             byts, what = 56 * n * l * B, "(4 in + 3 out) x 8N per prime row"
         elif name.startswith("keyswitch_kernel"):

@@ -57,6 +57,7 @@ SYMBOLS = [
     "hx_time_ntt", "hx_ctx_timer_begin", "hx_ctx_timer_end", "hx_randomize",
     "hx_ctx_graph_begin", "hx_ctx_graph_end", "hx_graph_launch", "hx_graph_destroy",
     "hx_profile_begin", "hx_profile_end", "hx_ctx_arena_stats", "hx_ctx_reserve",
+    "hx_tensor_bring_to_set", "hx_tensor_bring_to_set_norms",
 ]
 
 
@@ -140,6 +141,8 @@ def lib():
             "hx_graph_destroy": [vp],
             "hx_profile_begin": [], "hx_profile_end": [vp, C.c_size_t, vp],
             "hx_ctx_arena_stats": [vp, vp], "hx_ctx_reserve": [vp, C.c_uint64],
+            "hx_tensor_bring_to_set": [vp] * 8 + [ip, vp, ip, u64],
+            "hx_tensor_bring_to_set_norms": [vp] * 8 + [ip, vp, ip, u64, vp],
         }
         for name, args in sig.items():
             f = getattr(L, name)
@@ -655,3 +658,25 @@ def profileEnd():
     buf = C.create_string_buffer(need.value)
     _chk(lib().hx_profile_end(buf, need.value, None))
     return json.loads(buf.value.decode())
+
+
+def tensorBringToSet(c0, c1, d0, d1, add_set, keep_set, ptxtSpace, norms=False, defer=False):
+    """Ctxt::tensorProduct followed by Ctxt::bringToSet of the three product parts (hx_tensor_bring_to_set): the
+    parts (1), (s), (s^2) on `keep_set` (= the operands' primes + add_set - what is dropped).  norms: also the
+    embeddingLargestCoeff of the mod-switch deltas, [3][batch] (deferred read-back as in bringToSetMulti)."""
+    ctx = c0.context
+    cur = c0.getIndexSet()
+    add = [i for i in add_set if i not in cur]
+    drop = [i for i in cur + add if i not in set(keep_set)]
+    outs = [DoubleCRT(ctx, cur, c0.batch, zero=False) for _ in range(3)]
+    a, d = _i32(add), _i32(drop)
+    if not norms:
+        _chk(lib().hx_tensor_bring_to_set(c0.h, c1.h, d0.h, d1.h, outs[0].h, outs[1].h, outs[2].h, _p(a), len(add),
+                                          _p(d), len(drop), int(ptxtSpace)))
+        return outs
+    nrm = np.zeros((3, c0.batch), dtype=np.float64)
+    ctx.deferNorms(defer)
+    ctx.keepUntilFlush(nrm)
+    _chk(lib().hx_tensor_bring_to_set_norms(c0.h, c1.h, d0.h, d1.h, outs[0].h, outs[1].h, outs[2].h, _p(a), len(add),
+                                            _p(d), len(drop), int(ptxtSpace), _p(nrm)))
+    return outs, nrm

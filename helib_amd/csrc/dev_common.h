@@ -87,6 +87,16 @@ struct ModDownApply {
   const uint64_t* delta;
   uint64_t delta_poly_stride;  // words
 };
+// Ctxt::tensorProduct folded into the mod-switch that follows it (Ctxt::multiplyBy on fresh ciphertexts:
+// multLowLvl's tensorProduct, then reLinearize's dropSmallAndSpecialPrimes, src/Ctxt.cpp:1563-1608, 720-760):
+// the three product parts are never materialised on the old prime set -- the mod-down kernels form
+// part(1) = a0 b0, part(s) = a0 b1 + a1 b0, part(s^2) = a1 b1 from the operand rows where they consume them.
+struct TensorSrc {
+  const uint64_t* a0;
+  const uint64_t* a1;
+  const uint64_t* b0;
+  const uint64_t* b1;
+};
 // several DoubleCRT objects with the same prime set (the parts of one or two ciphertexts) are
 // mod-switched by one pair of launches: xs/S hold [poly][batch][N]
 constexpr int MD_MAXPOLY = 8;

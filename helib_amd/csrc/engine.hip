@@ -42,6 +42,9 @@ hipError_t launch_moddown_prep_multi_pow2(int logn, const PolyBases& polys, cons
 hipError_t launch_moddown_apply_plain_pow2(int logn, const PolyBases& polys, const PolyBases& outs,
                                            const NttRows& keep, int nkeep, int batch, const ModDownApply& A,
                                            const PrimeDev* primes, const TW* tw_arena, hipStream_t st);
+hipError_t launch_moddown_tensor_pow2(int logn, const TensorSrc& T, const PolyBases& outs, int drop_row, int drop_prime,
+                                      const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
+                                      const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena, hipStream_t st);
 hipError_t launch_conv_rows(int logn, const ConvRowArgs& A, const ConvRows& R, int nunits, const PrimeDev* cprimes,
                             const TW* tw_arena, hipStream_t st);
 }
@@ -3236,8 +3239,11 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
 }
 
 static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* drop_idx, int ndrop,
-                           uint64_t ptxt, const int* add_idx = nullptr, int nadd = 0)
+                           uint64_t ptxt, const int* add_idx = nullptr, int nadd = 0,
+                           const hx::TensorSrc* tsrc = nullptr)
 {
+  // tsrc (tensorProduct folded in): a / others are the three product parts, storage reserved, prime list =
+  // the operands', contents not yet computed -- only the fused single-prime path can take them
   // add_idx (fused bringToSet): the polys are first mod-switched UP by these primes
   // (addPrimesAndScale); only the fused single-prime path folds that in, otherwise the caller
   // gets HX_ERR_UNSUPPORTED and does the two steps separately.
@@ -3341,6 +3347,8 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
   bool small_S = true;  // |S| <= ptxtSpace/2 + 1 is a reduced residue of every kept prime
   for (int pr : keep)
     small_S = small_S && ptxt / 2 + 2 < c->primes[pr].q;
+  if (tsrc && !(nd == 1 && nk <= MAX_ROWS && small_S))
+    return HX_ERR_UNSUPPORTED;   // (checked before anything was changed: nadd > 0 passed its own test above)
   if (nd == 1 && c->pow2 && c->logn >= 13 && c->logn <= 15 && nk <= MAX_ROWS && ptxt < ((uint64_t)1 << 62) && small_S) {
     // fused path: [inverse NTT of the dropped row + delta preparation] then [forward NTT of
     // delta on every kept row, with  c <- (c - delta) / qd  in its store].  The last row takes
@@ -3473,8 +3481,10 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     A.xs = c->scratch[0];
     A.S = reinterpret_cast<const int64_t*>(c->scratch[1]);
     A.rows = reinterpret_cast<const hx::ModDownRow*>(it->second->blob);
-    hipError_t e = hx::launch_moddown_pow2(c->logn, pb, pbo, drow, dprime, kr, nk, a->batch, P, A,
-                                           c->d_primes, c->d_tw, c->stream);
+    hipError_t e = tsrc ? hx::launch_moddown_tensor_pow2(c->logn, *tsrc, pbo, drow, dprime, kr, nk, a->batch, P, A,
+                                                         c->d_primes, c->d_tw, c->stream)
+                        : hx::launch_moddown_pow2(c->logn, pb, pbo, drow, dprime, kr, nk, a->batch, P, A,
+                                                  c->d_primes, c->d_tw, c->stream);
     if (e != hipSuccess)
       return fail(HX_ERR_DEVICE, "mod-down launch failed: %s", hipGetErrorString(e));
     fresh_guard.armed = false;
@@ -3700,6 +3710,74 @@ extern "C" int hx_bring_to_set_multi_norms(hx_poly** polys, int npoly, const int
   CHK(frac_begin(c, (size_t)npoly * rw));
   int rc = hx_bring_to_set_multi(polys, npoly, add_idx, nadd, drop_idx, ndrop, ptxt);
   return finish_norms(c, rc, (size_t)npoly * rw, npoly * batch, norms, nullptr);
+}
+
+static int tensor_launch(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1, uint64_t* o0,
+                         uint64_t* o1, uint64_t* o2, const uint64_t* scale_per_row);
+// Ctxt::tensorProduct of two canonical ciphertexts (src/Ctxt.cpp:1563-1608) immediately followed by
+// Ctxt::bringToSet of the product (reLinearize's dropSmallAndSpecialPrimes, :720-760): o0, o1, o2 = the three
+// product parts (1), (s), (s^2) mod-switched up by add_idx and down by drop_idx.  With one dropped prime the
+// product parts are never materialised on the operands' prime set (TensorSrc); any other shape runs the two
+// steps one after the other -- same result either way.
+static int tensor_bring_to_set(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1,
+                               hx_poly* o0, hx_poly* o1, hx_poly* o2, const int* add_idx, int nadd,
+                               const int* drop_idx, int ndrop, uint64_t ptxt)
+{
+  hx_ctx* c = c0->ctx;
+  hx_poly* os[3] = {o0, o1, o2};
+  const hx_poly* in[4] = {c0, c1, d0, d1};
+  for (auto* p : in)
+    if (p->ctx != c || p->batch != c0->batch || p->prime_idx != c0->prime_idx)
+      return fail(HX_ERR_PRIMESET, "tensorProduct: parts must be defined relative to the same set of primes");
+  for (int i = 0; i < 3; i++) {
+    if (os[i]->ctx != c || os[i]->batch != c0->batch)
+      return fail(HX_ERR_INVALID, "Context mismatch");
+    for (auto* p : in)
+      if (p == os[i])
+        return fail(HX_ERR_INVALID, "hx_tensor_bring_to_set: an output aliases an operand");
+    for (int j = 0; j < i; j++)
+      if (os[j] == os[i])
+        return fail(HX_ERR_INVALID, "the same poly listed twice");
+  }
+  CHK(check_rows(c, add_idx, nadd));
+  for (auto* o : os) {
+    OWN(o);
+    CHK(poly_reserve(o, c0->nrows() + nadd, /*keep=*/false));
+    o->prime_idx = c0->prime_idx;
+  }
+  if (c0->nrows() <= MAX_ROWS && ndrop == 1) {
+    hx::TensorSrc T{c0->d, c1->d, d0->d, d1->d};
+    int rc = scale_down_impl(o0, os + 1, 2, drop_idx, ndrop, ptxt, add_idx, nadd, &T);
+    if (rc != HX_ERR_UNSUPPORTED)
+      return rc;
+    for (auto* o : os)
+      o->prime_idx = c0->prime_idx;   // (untouched by an unsupported attempt; restated for clarity)
+  }
+  CHK(tensor_launch(c0, c1, d0, d1, o0->d, o1->d, o2->d, nullptr));
+  return hx_bring_to_set_multi(os, 3, add_idx, nadd, drop_idx, ndrop, ptxt);
+}
+extern "C" int hx_tensor_bring_to_set(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1,
+                                      hx_poly* o0, hx_poly* o1, hx_poly* o2, const int* add_idx, int nadd,
+                                      const int* drop_idx, int ndrop, uint64_t ptxt)
+{
+  if (!c0 || !c1 || !d0 || !d1 || !o0 || !o1 || !o2 || (nadd > 0 && !add_idx) || (ndrop > 0 && !drop_idx))
+    return fail(HX_ERR_INVALID, "null argument");
+  CTX_ENTER(c0->ctx);
+  return tensor_bring_to_set(c0, c1, d0, d1, o0, o1, o2, add_idx, nadd, drop_idx, ndrop, ptxt);
+}
+extern "C" int hx_tensor_bring_to_set_norms(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1,
+                                            hx_poly* o0, hx_poly* o1, hx_poly* o2, const int* add_idx, int nadd,
+                                            const int* drop_idx, int ndrop, uint64_t ptxt, double* norms)
+{
+  if (!c0 || !c1 || !d0 || !d1 || !o0 || !o1 || !o2 || !norms || (nadd > 0 && !add_idx) || (ndrop > 0 && !drop_idx))
+    return fail(HX_ERR_INVALID, "null argument");
+  hx_ctx* c = c0->ctx;
+  CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_tensor_bring_to_set_norms (a norm read-back)");
+  const size_t rw = c0->row_words();
+  CHK(frac_begin(c, 3 * rw));
+  int rc = tensor_bring_to_set(c0, c1, d0, d1, o0, o1, o2, add_idx, nadd, drop_idx, ndrop, ptxt);
+  return finish_norms(c, rc, 3 * rw, 3 * c0->batch, norms, nullptr);
 }
 
 // ------------------------------------------------------------------

@@ -439,6 +439,224 @@ ntt_moddown_apply_kernel(PolyBases polys, PolyBases outs, NttRows rows, int nkee
   ntt_body<LOGN, false>(lds, io, tw_arena + pd->tw_fwd_off, pd);
 }
 
+// ---- tensorProduct folded into the single-prime mod-switch (dev_common.h: TensorSrc) ----
+// S mod q for S < 8 q^2: the approximate-quotient Barrett of rns_kernels.h (red128_q8: 7 word multiplications, the
+// quotient estimate at most 5 short), restated here for this translation unit
+__device__ __forceinline__ uint64_t tensor_red128(u128 S, uint64_t q, uint64_t mu63, uint32_t k)
+{
+  const uint64_t xt = (uint64_t)(S >> (k - 1));
+  const uint32_t xl = (uint32_t)xt, xh = (uint32_t)(xt >> 32);
+  const uint32_t ml = (uint32_t)mu63, mh = (uint32_t)(mu63 >> 32);
+  const uint64_t qh = (uint64_t)xh * mh + __umulhi(xh, ml) + __umulhi(xl, mh);
+  uint64_t r = (uint64_t)S - qh * q;
+  r = csub(r, q << 2);
+  r = csub(r, q << 1);
+  return csub(r, q);
+}
+// product part `part` (0: a0 b0, 1: a0 b1 + a1 b0, 2: a1 b1) of one coefficient, canonical; part 1 takes the
+// two 128-bit products in ONE reduction (x < 2 q^2).  mu = PrimeDev::mu63.
+__device__ __forceinline__ uint64_t tensor_value(unsigned part, uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1,
+                                                 uint64_t q, uint64_t mu, uint32_t k)
+{
+  if (part == 1)
+    return tensor_red128((u128)a0 * b1 + (u128)a1 * b0, q, mu, k);
+  return tensor_red128((u128)a0 * b0, q, mu, k);   // (the caller hands part 2 its operands in the a0 / b0 slots)
+}
+// inverse transform of the dropped row of a product part: the row is formed from the operands' rows on load
+struct InvPrepTensorIO {
+  static constexpr int LOAD_BOUND = 1;
+  static constexpr bool LAZY_STORE = false;
+  static constexpr bool PIPELINED = false;
+  struct StorePrefetch {};
+  v4i32 ra, rb, rc, rd, rx;   // ra/rb: the operand pair of parts 0 and 2 (or a0, b1 of part 1); rc/rd: a1, b0 (part 1)
+  TW upS, upN;
+  uint32_t has_up, part, k;
+  uint64_t q, mu;
+  __device__ InvPrepTensorIO(const TensorSrc& T, unsigned part_, size_t roff, const ModDownPrep& p, size_t xoff,
+                             unsigned bytes, const PrimeDev* pd)
+      : ra(make_rsrc((part_ == 2 ? T.a1 : T.a0) + roff, bytes)),
+        rb(make_rsrc((part_ == 0 ? T.b0 : T.b1) + roff, bytes)),
+        rc(make_rsrc(T.a1 + roff, bytes)), rd(make_rsrc(T.b0 + roff, bytes)),
+        rx(make_rsrc(p.xs + xoff, bytes)), upS(p.upS), upN(p.upN), has_up(p.has_up), part(part_), k(pd->k), q(pd->q),
+        mu(pd->mu63)
+  {
+  }
+  static __device__ __forceinline__ uint64_t ld(const v4i32& r, unsigned tid, unsigned c)
+  {
+    v2i32 a = hx_buffer_load_v2(r, (int)(tid * 8u), (int)(c * 8u), 0);
+    return ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
+  }
+  __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
+  {
+    const uint64_t x = ld(ra, tid, c), y = ld(rb, tid, c);
+    if (part == 1)
+      return tensor_value(1, x, ld(rc, tid, c), ld(rd, tid, c), y, q, mu, k);   // a0 b1 + a1 b0
+    return tensor_value(0, x, 0, y, 0, q, mu, k);
+  }
+  __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t x) const
+  {
+    v2i32 d;
+    d.x = (int)(uint32_t)x;
+    d.y = (int)(uint32_t)(x >> 32);
+    hx_buffer_store_v2(d, rx, (int)(tid * 8u), (int)(c * 8u), 0);
+  }
+  __device__ __forceinline__ TW last_tw(TW def, int which) const { return has_up ? (which ? upN : upS) : def; }
+};
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
+ntt_moddown_prep_tensor_kernel(TensorSrc T, int row, int prime, int batch, ModDownPrep P,
+                               const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int b = (int)(blockIdx.x % (unsigned)batch), pi = (int)(blockIdx.x / (unsigned)batch);   // pi = product part
+  const PrimeDev* pd = primes + prime;
+  const size_t N = Geo<LOGN>::N;
+  const InvPrepTensorIO io(T, (unsigned)pi, ((size_t)row * batch + b) * N, P, ((size_t)pi * batch + b) * N,
+                           (unsigned)N * 8u, pd);
+  ntt_body<LOGN, true>(lds, io, tw_arena + pd->tw_inv_off, pd);
+}
+
+// forward transform of a kept row whose c_r is a product part formed from the operands' rows in the store
+struct ModDownTensorIO {
+  static constexpr int LOAD_BOUND = 6;
+  static constexpr bool LAZY_STORE = true;
+  static constexpr bool PIPELINED = true;
+  static constexpr int IOG = 4;
+  struct StorePrefetch {};
+  v4i32 rx, rS, ra, rb, rc, rd, ro;
+  TW inv, cf;
+  uint64_t q, mu;
+  uint32_t part, k;
+  // operand rows: [row][batch][N] slabs of the four operands at `roff`; a row the fused mod-up adds has no operand
+  // row (cf = 0): its own output row stands in for all four, whatever it holds is multiplied away
+  __device__ ModDownTensorIO(const uint64_t* x_row, const int64_t* S_row, const ModDownRow& R, const TensorSrc& T,
+                             unsigned part_, size_t roff, bool has_row, uint64_t* o_row, unsigned bytes, const PrimeDev* pd)
+      : rx(make_rsrc(x_row, bytes)), rS(make_rsrc((const uint64_t*)S_row, bytes)),
+        ra(make_rsrc(has_row ? (part_ == 2 ? T.a1 : T.a0) + roff : o_row, bytes)),
+        rb(make_rsrc(has_row ? (part_ == 0 ? T.b0 : T.b1) + roff : o_row, bytes)),
+        rc(make_rsrc(has_row ? T.a1 + roff : o_row, bytes)), rd(make_rsrc(has_row ? T.b0 + roff : o_row, bytes)),
+        ro(make_rsrc(o_row, bytes)), inv(R.inv), cf(R.cf), q(pd->q), mu(pd->mu63), part(part_), k(pd->k)
+  {
+  }
+  static __device__ __forceinline__ uint64_t ld(const v4i32& r, unsigned tid, unsigned c)
+  {
+    v2i32 a = hx_buffer_load_v2(r, (int)(tid * 8u), (int)(c * 8u), 0);
+    return ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
+  }
+  __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const { return ld(rx, tid, c); }
+  // the load of ModDownIO<false>: x*inv - S with S one group ahead
+  template <int LOGN>
+  __device__ __forceinline__ void load_all(unsigned tid, uint64_t (&v)[32], const QC& qc) const
+  {
+    static_for<0, 32>([&](auto E) {
+      constexpr int e = decltype(E)::value;
+      v[e] = ld(rx, tid, coef_const<LOGN>(e));
+    });
+    uint64_t sb[2][IOG];
+    static_for<0, IOG>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      sb[0][j] = ld(rS, tid, coef_const<LOGN>(j));
+    });
+    HX_SCHED_FENCE();
+    static_for<0, 32 / IOG>([&](auto GI) {
+      constexpr int g = decltype(GI)::value;
+      if constexpr (g + 1 < 32 / IOG)
+        static_for<0, IOG>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          sb[(g + 1) & 1][j] = ld(rS, tid, coef_const<LOGN>((g + 1) * IOG + j));
+        });
+      static_for<0, IOG>([&](auto J) {
+        constexpr int j = decltype(J)::value, e = g * IOG + j;
+        v[e] = shoup4_acc(v[e], inv, qc.nq, q - sb[g & 1][j]);
+      });
+      HX_SCHED_FENCE();
+    });
+  }
+  template <int LOGN>
+  __device__ __forceinline__ void store_prefetch(unsigned, StorePrefetch&) const {}
+  template <int LOGN, int B, bool EST>
+  __device__ __forceinline__ void store_all(unsigned tid, uint64_t (&v)[32], const QC& qc, StorePrefetch&) const
+  {
+    constexpr int G = 2;   // operand words of two coefficients in flight (up to 8 loads) ahead of their arithmetic
+    auto one = [&](auto I, uint64_t x0, uint64_t y0, uint64_t x1, uint64_t y1) {
+      constexpr int i = decltype(I)::value;
+      const uint64_t c = part == 1 ? tensor_value(1, x0, x1, y1, y0, q, mu, k) : tensor_value(0, x0, 0, y0, 0, q, mu, k);
+      uint64_t x = v[i];
+      if constexpr (B > 8)
+        x = csub(x, qc.q8);
+      put(tid, eval_const<LOGN>(i), norm_from<12, EST>(shoup4_acc(c, cf, qc.nq, qc.q8 - x), qc));
+    };
+    if (part == 1) {   // (wave-uniform: one of the two loops runs)
+      static_for<0, 32 / G>([&](auto GI) {
+        constexpr int g = decltype(GI)::value;
+        uint64_t a0[G], b1[G], a1[G], b0[G];
+        static_for<0, G>([&](auto J) {
+          constexpr int j = decltype(J)::value, i = g * G + j;
+          a0[j] = ld(ra, tid, eval_const<LOGN>(i));
+          b1[j] = ld(rb, tid, eval_const<LOGN>(i));
+          a1[j] = ld(rc, tid, eval_const<LOGN>(i));
+          b0[j] = ld(rd, tid, eval_const<LOGN>(i));
+        });
+        static_for<0, G>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          one(std::integral_constant<int, g * G + j>{}, a0[j], b1[j], a1[j], b0[j]);
+        });
+        HX_SCHED_FENCE();
+      });
+    } else {
+      static_for<0, 32 / G>([&](auto GI) {
+        constexpr int g = decltype(GI)::value;
+        uint64_t x0[G], y0[G];
+        static_for<0, G>([&](auto J) {
+          constexpr int j = decltype(J)::value, i = g * G + j;
+          x0[j] = ld(ra, tid, eval_const<LOGN>(i));
+          y0[j] = ld(rb, tid, eval_const<LOGN>(i));
+        });
+        static_for<0, G>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          one(std::integral_constant<int, g * G + j>{}, x0[j], y0[j], 0, 0);
+        });
+        HX_SCHED_FENCE();
+      });
+    }
+  }
+  __device__ __forceinline__ void put(unsigned tid, unsigned c, uint64_t o) const
+  {
+    v2i32 d;
+    d.x = (int)(uint32_t)o;
+    d.y = (int)(uint32_t)(o >> 32);
+    hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), 0);
+  }
+  __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
+};
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
+ntt_moddown_apply_tensor_kernel(TensorSrc T, PolyBases outs, NttRows rows, int nkeep, int batch, ModDownApply A,
+                                const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const MdTile Tl = md_tile((unsigned)nkeep, 3u * (unsigned)batch);
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const unsigned grp = xcd % Tl.g, partx = xcd / Tl.g;
+  const unsigned r0 = grp * Tl.rg, pb0 = partx * Tl.chunk;
+  const unsigned nr = r0 < (unsigned)nkeep ? min(Tl.rg, (unsigned)nkeep - r0) : 0u;
+  const unsigned npb = 3u * (unsigned)batch;
+  const unsigned nloc = pb0 < npb ? min(Tl.chunk, npb - pb0) : 0u;
+  if (slot >= nr * nloc)
+    return;
+  const unsigned ri = r0 + slot % nr, pb = pb0 + slot / nr;
+  const int b = (int)(pb % (unsigned)batch);
+  const unsigned pi = pb / (unsigned)batch;   // product part 0, 1, 2
+  const PrimeDev* pd = primes + uniform_u16(rows.prime, ri);
+  const size_t N = Geo<LOGN>::N;
+  const ModDownRow R = A.rows[ri];
+  uint64_t* odata = poly_base(outs, pi);
+  const size_t eoff = ((size_t)pi * batch + b) * N;
+  const ModDownTensorIO io(A.xs + eoff, A.S + eoff, R, T, pi, ((size_t)uniform_u16(rows.row, ri) * batch + b) * N,
+                           R.mode != 2, odata + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd);
+  ntt_body<LOGN, false>(lds, io, tw_arena + pd->tw_fwd_off, pd);
+}
+
 template <int LOGN, bool INV>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
 ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
@@ -547,6 +765,47 @@ hipError_t launch_moddown_pow2(int logn, const PolyBases& data, const PolyBases&
     case 13: return launch_moddown<13>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
     case 14: return launch_moddown<14>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
     case 15: return launch_moddown<15>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// tensorProduct + single-prime mod-switch of the three product parts (TensorSrc): prep from the operands' dropped
+// rows, S, apply forming c_r from the operands' kept rows
+template <int LOGN>
+static hipError_t launch_moddown_tensor(const TensorSrc& T, const PolyBases& outs, int drop_row, int drop_prime,
+                                        const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
+                                        const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)ntt_moddown_prep_tensor_kernel<LOGN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_tensor_kernel<LOGN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess)
+      return e;
+    attr_set = true;
+  }
+  HX_LAUNCH((ntt_moddown_prep_tensor_kernel<LOGN>), dim3(3u * (unsigned)batch), dim3(Geo<LOGN>::T), lds_bytes, st, T,
+            drop_row, drop_prime, batch, P, primes, tw_arena);
+  {
+    const size_t n = (size_t)3 * (size_t)batch * Geo<LOGN>::N;
+    HX_LAUNCH(moddown_S_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), dim3(256), 0, st, P, n);
+  }
+  HX_LAUNCH((ntt_moddown_apply_tensor_kernel<LOGN>), dim3(moddown_apply_grid(3u, (unsigned)nkeep, (unsigned)batch)),
+            dim3(Geo<LOGN>::T), lds_bytes, st, T, outs, keep, nkeep, batch, A, primes, tw_arena);
+  return hipGetLastError();
+}
+hipError_t launch_moddown_tensor_pow2(int logn, const TensorSrc& T, const PolyBases& outs, int drop_row, int drop_prime,
+                                      const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
+                                      const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  switch (logn) {
+    case 13: return launch_moddown_tensor<13>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+    case 14: return launch_moddown_tensor<14>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+    case 15: return launch_moddown_tensor<15>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
   }
   return hipErrorInvalidValue;
 }

@@ -173,6 +173,7 @@ gather_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ in,
 // the parts that point at 1 and s (reLinearize, src/Ctxt.cpp:764-767).
 // 56 B/element instead of the reference's 5 separate passes (120 B/element).
 // =====================================================================
+__device__ __forceinline__ uint64_t red128_q8(u128 S, uint64_t q, uint64_t mu63, uint32_t k);  // (defined below)
 __global__ void __launch_bounds__(256)
 tensor_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
               const uint64_t* __restrict__ d0, const uint64_t* __restrict__ d1,
@@ -182,7 +183,7 @@ tensor_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
 {
   const int row = blockIdx.y;
   const PrimeDev pd = primes[map.p[row]];
-  const uint64_t q = pd.q, mu = pd.mu;
+  const uint64_t q = pd.q;
   const uint32_t k = pd.k;
   const uint64_t c = sc.c[row], cp = sc.cp[row];
   const size_t off = (size_t)row * row_words;
@@ -195,12 +196,15 @@ tensor_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
     ulonglong2 b0 = *reinterpret_cast<const ulonglong2*>(d0 + e);
     ulonglong2 b1 = *reinterpret_cast<const ulonglong2*>(d1 + e);
     ulonglong2 r0, r1, r2;
-    r0.x = mul_mod(a0.x, b0.x, q, mu, k);
-    r0.y = mul_mod(a0.y, b0.y, q, mu, k);
-    r1.x = add_mod(mul_mod(a0.x, b1.x, q, mu, k), mul_mod(a1.x, b0.x, q, mu, k), q);
-    r1.y = add_mod(mul_mod(a0.y, b1.y, q, mu, k), mul_mod(a1.y, b0.y, q, mu, k), q);
-    r2.x = mul_mod(a1.x, b1.x, q, mu, k);
-    r2.y = mul_mod(a1.y, b1.y, q, mu, k);
+    // (red128_q8: the approximate-quotient Barrett, 7 word multiplications; the (s) part takes its two 128-bit
+    // products in one reduction -- three reductions per coefficient instead of four classical ones)
+    const uint64_t m63 = pd.mu63;
+    r0.x = red128_q8((u128)a0.x * b0.x, q, m63, k);
+    r0.y = red128_q8((u128)a0.y * b0.y, q, m63, k);
+    r1.x = red128_q8((u128)a0.x * b1.x + (u128)a1.x * b0.x, q, m63, k);
+    r1.y = red128_q8((u128)a0.y * b1.y + (u128)a1.y * b0.y, q, m63, k);
+    r2.x = red128_q8((u128)a1.x * b1.x, q, m63, k);
+    r2.y = red128_q8((u128)a1.y * b1.y, q, m63, k);
     if (scale) {
       r0.x = mul_shoup(r0.x, c, cp, q);
       r0.y = mul_shoup(r0.y, c, cp, q);

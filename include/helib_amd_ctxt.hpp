@@ -22,6 +22,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -670,6 +671,24 @@ public:
   long ptxtSpace, intFactor = 1;
   LazyLn lnNoise;
   double ptxtMag = 1.0, lnRatFactor = 0.0;  // CKKS: |plaintext| bound, ln of the scaling factor
+  // multiplyBy only: the tensor product's bookkeeping is done, its data not yet -- the four operand parts wait
+  // here and `parts` holds storage for the three product parts.  The mod-switch that follows in reLinearize
+  // (dropSmallAndSpecialPrimes) consumes them through hx_tensor_bring_to_set: the products are formed inside the
+  // mod-down kernels; anything else that needs the data first calls materializeTensor().  Never visible outside
+  // multiplyBy.
+  struct PendingTensor {
+    DoubleCRT c0, c1, d0, d1;
+  };
+  std::shared_ptr<PendingTensor> pendingTensor;
+  void materializeTensor()
+  {
+    if (!pendingTensor)
+      return;
+    std::shared_ptr<PendingTensor> t = std::move(pendingTensor);
+    pendingTensor.reset();
+    helib_amd::tensorProduct(t->c0, t->c1, t->d0, t->d1, parts.at(SKHandle{0, 1}), parts.at(SKHandle{1, 1}),
+                             parts.at(SKHandle{2, 1}));
+  }
 
   Ctxt(const ChainContext& c, const Context& d, const KeySet& k) : context(&c), dev(&d), keys(&k), ptxtSpace(c.ptxtSpace) {}
   // a fresh 2-part ciphertext over the ctxt primes (noise bound of PubKey::Encrypt)
@@ -699,6 +718,7 @@ public:
     PrimeSet diff = s - primeSet;
     if (diff.empty())
       return;
+    materializeTensor();
     IndexSet d = toVec(diff);
     for (auto& kv : parts)
       kv.second.addPrimesAndScale(d);
@@ -768,6 +788,7 @@ public:
     double log_phim = std::max(std::log((double)context->phim), 1.0);
     double lnGamma = std::log(8.0 * (double)(long)context->scale * std::sqrt(context->phim * log_phim * h / 12.0));
     if (lnGamma > lnNoise) {
+      materializeTensor();
       long xf = (long)std::ceil(std::exp(lnGamma - lnNoise));
       for (auto& kv : parts)
         kv.second *= xf;
@@ -780,6 +801,7 @@ public:
   {
     if (e == 1)
       return;
+    materializeTensor();
     intFactor = (long)detail::mulmod((uint64_t)intFactor, (uint64_t)e, (uint64_t)ptxtSpace);
     long bal = e > ptxtSpace / 2 ? e - ptxtSpace : e;
     for (auto& kv : parts)
@@ -935,7 +957,7 @@ public:
   // Ctxt::computeIntervalForMul (src/Ctxt.cpp:1610-1656): [lo, hi] = ln of the target modulus size
   static std::pair<double, double> computeIntervalForMul(const Ctxt& c1, const Ctxt& c2);
   // multLowLvl: bring both to a common set, tensor
-  void multLowLvl(Ctxt other)
+  void multLowLvl(Ctxt other, bool lazyTensor = false)
   {
     HELIB_AMD_TIMER_START;
     if (parts.empty() || other.parts.empty()) {
@@ -962,19 +984,21 @@ public:
       bringToSet(s);
       other.bringToSet(s);
     }
-    tensorProduct(other);
+    tensorProduct(other, lazyTensor);
   }
   void multiplyBy(const Ctxt& other)
   {
     HELIB_AMD_TIMER_START;
-    multLowLvl(other);  // works on a copy of `other`, as the reference does (src/Ctxt.cpp:1716-1745)
+    multLowLvl(other, true);  // works on a copy of `other`, as the reference does (src/Ctxt.cpp:1716-1745)
     reLinearize();
+    materializeTensor();
   }
   void multiplyBy(Ctxt&& other)  // the operand may be consumed: no copy
   {
     HELIB_AMD_TIMER_START;
-    multLowLvl(std::move(other));
+    multLowLvl(std::move(other), true);
     reLinearize();
+    materializeTensor();
   }
   void reLinearize()
   {
@@ -989,6 +1013,7 @@ public:
     if (n_other == 0)
       return;
     if (n_other > 1) {
+      materializeTensor();
       reLinearizeMany();
       return;
     }
@@ -997,6 +1022,7 @@ public:
       throw LogicError("no key-switching matrices for this part");
     dropSmallAndSpecialPrimes();
     relin_CKKS_adjust();
+    materializeTensor();   // (no mod-switch consumed the pending tensor product: form it now)
     const IndexSet& sp = context->specialPrimes;
     double logProd = context->logOfProduct(sp);
     lnRatFactor += logProd;  // the CKKS factor after the mod-up by the special primes (:757)
@@ -1368,6 +1394,7 @@ private:
       }
     dropSmallAndSpecialPrimes();
     relin_CKKS_adjust();
+    materializeTensor();   // (no mod-switch consumed the pending tensor product: form it now)
     const IndexSet& sp = context->specialPrimes;
     const double logProd = context->logOfProduct(sp);
     lnRatFactor += logProd;
@@ -1421,7 +1448,7 @@ private:
   {
     return ps.size() == 2 && ps.count(SKHandle{0, 1}) && ps.count(SKHandle{1, 1});
   }
-  void tensorProduct(const Ctxt& o)
+  void tensorProduct(const Ctxt& o, bool lazy = false)
   {
     if (ptxtSpace > 2) {
       uint64_t q = context->productOfPrimesMod(primeSet, (uint64_t)ptxtSpace);
@@ -1434,7 +1461,11 @@ private:
       IndexSet idx = c0.getIndexSet();
       DoubleCRT::Uninitialized u;
       DoubleCRT t0(*dev, idx, c0.batch(), u), t1(*dev, idx, c0.batch(), u), t2(*dev, idx, c0.batch(), u);
-      helib_amd::tensorProduct(c0, c1, d0, d1, t0, t1, t2);
+      static const bool lazy_off = std::getenv("HX_NO_LAZY_TENSOR") != nullptr;   // (A/B switch)
+      if (lazy && !lazy_off)   // copies of the operand parts are copy-on-write handles: nothing moves
+        pendingTensor = std::make_shared<PendingTensor>(PendingTensor{c0, c1, d0, d1});
+      else
+        helib_amd::tensorProduct(c0, c1, d0, d1, t0, t1, t2);
       parts.clear();
       parts.emplace(SKHandle{0, 1}, std::move(t0));
       parts.emplace(SKHandle{1, 1}, std::move(t1));
@@ -1501,7 +1532,28 @@ private:
     uint64_t pt = (uint64_t)a.ptxtSpace;
     std::shared_ptr<std::vector<double>> norms;
     int rc;
-    if (a.measure) {
+    std::shared_ptr<PendingTensor> pend;
+    if (cts.size() == 1 && a.pendingTensor) {   // the tensor product is formed inside this mod-switch
+      pend = std::move(a.pendingTensor);
+      a.pendingTensor.reset();
+    } else {
+      for (Ctxt* c : cts)
+        c->materializeTensor();
+    }
+    if (pend) {
+      hx_poly* o0 = a.parts.at(SKHandle{0, 1}).handle();
+      hx_poly* o1 = a.parts.at(SKHandle{1, 1}).handle();
+      hx_poly* o2 = a.parts.at(SKHandle{2, 1}).handle();
+      if (a.measure) {
+        a.dev->deferNorms(a.lazy());
+        norms = a.dev->normBuffer(3 * (size_t)batch);
+        rc = hx_tensor_bring_to_set_norms(pend->c0.handle(), pend->c1.handle(), pend->d0.handle(), pend->d1.handle(), o0, o1,
+                                          o2, addv.data(), (int)addv.size(), drop.data(), (int)drop.size(), pt, norms->data());
+      } else {
+        rc = hx_tensor_bring_to_set(pend->c0.handle(), pend->c1.handle(), pend->d0.handle(), pend->d1.handle(), o0, o1, o2,
+                                    addv.data(), (int)addv.size(), drop.data(), (int)drop.size(), pt);
+      }
+    } else if (a.measure) {
       a.dev->deferNorms(a.lazy());
       norms = a.dev->normBuffer(polys.size() * (size_t)batch);
       rc = addv.empty() ? hx_scale_down_multi_norms(polys.data(), (int)polys.size(), drop.data(), (int)drop.size(), pt,
@@ -1554,6 +1606,8 @@ private:
     std::vector<std::function<double()>> added;
     if (diff.empty()) {  // pure mod-up
       IndexSet d = toVec(add);
+      for (Ctxt* c : cts)
+        c->materializeTensor();
       for (Ctxt* c : cts)
         for (auto& kv : c->parts)
           kv.second.addPrimesAndScale(d);

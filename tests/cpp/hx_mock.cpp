@@ -546,6 +546,22 @@ int hx_tensor(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_
   }
   return HX_OK;
 }
+int hx_tensor_bring_to_set_norms(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1, hx_poly* o0,
+                                 hx_poly* o1, hx_poly* o2, const int* add_idx, int nadd, const int* drop_idx, int ndrop,
+                                 uint64_t ptxt_space, double* norms)
+{
+  int rc = hx_tensor(c0, c1, d0, d1, o0, o1, o2);
+  if (rc)
+    return rc;
+  hx_poly* os[3] = {o0, o1, o2};
+  return hx_bring_to_set_multi_norms(os, 3, add_idx, nadd, drop_idx, ndrop, ptxt_space, norms);
+}
+int hx_tensor_bring_to_set(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1, hx_poly* o0,
+                           hx_poly* o1, hx_poly* o2, const int* add_idx, int nadd, const int* drop_idx, int ndrop,
+                           uint64_t ptxt_space)
+{
+  return hx_tensor_bring_to_set_norms(c0, c1, d0, d1, o0, o1, o2, add_idx, nadd, drop_idx, ndrop, ptxt_space, nullptr);
+}
 int hx_key_switch_digits(const hx_poly* digits, const hx_ksk* W, hx_poly* out0, hx_poly* out1)
 {
   const std::vector<int>& allp = out0->idx;

@@ -691,6 +691,47 @@ def test_bring_to_set_multi_matches_separate_steps(hx, ndrop):
                 assert np.array_equal(got[r, b], want[keep.index(i)])
 
 
+@pytest.mark.parametrize("m,ptxt", [(16384, 65537), (32768, 65537), (16384, 2), (65536, 1)])
+@pytest.mark.parametrize("shape", ["add1_drop1", "drop1", "drop_last", "add1_drop2"])
+def test_tensor_folded_into_the_mod_switch(hx, m, ptxt, shape):
+    """hx_tensor_bring_to_set (Ctxt::tensorProduct followed by Ctxt::bringToSet of the product, what Ctxt::multiplyBy
+    does between multLowLvl and the key switch): the product parts formed inside the single-prime mod-down kernels
+    from the operands' rows must equal hx_tensor + hx_bring_to_set_multi word for word -- and those equal the
+    oracle's tensor product, addPrimesAndScale and scaleDownToSet.  Shapes: mod-up by one prime + one dropped prime
+    (the fresh multiply's), a pure single-prime mod-down (dropped row in the middle and last), and two dropped
+    primes (the two-step fallback).  A batch of 3, operands that are lazy copies of each other, measured norms."""
+    P, own, sp = setup_rns(hx, m=m, L=5, K=2)
+    B = 3
+    add = [sp[0]] if shape.startswith("add1") else []
+    drop = {"add1_drop1": [own[2]], "drop1": [own[1]], "drop_last": [own[-1]], "add1_drop2": [own[1], own[3]]}[shape]
+    keep = [i for i in own + add if i not in drop]
+    ops = [P.rand(own, 700 + i, batch=B) for i in range(3)]
+    c0 = hx.DoubleCRT(P.g, own, B, ops[0])
+    c1 = hx.DoubleCRT(P.g, own, B, ops[1])
+    d0 = c0.copy()                                           # lazily shared with c0
+    d1 = hx.DoubleCRT(P.g, own, B, ops[2])
+    fused, nf = hx.tensorBringToSet(c0, c1, d0, d1, add, keep, ptxt, norms=True)
+    for d, x in zip((c0, c1, d0, d1), (ops[0], ops[1], ops[0], ops[2])):
+        assert np.array_equal(d.download(), x)               # operands untouched
+    t = list(hx.tensorProduct(c0, c1, d0, d1))
+    ns = hx.bringToSetMulti(t, add, keep, ptxt, norms=True)
+    for part in range(3):
+        assert sorted(fused[part].getIndexSet()) == sorted(keep) == sorted(t[part].getIndexSet())
+        gi, ti = fused[part].getIndexSet(), t[part].getIndexSet()
+        gd, td = fused[part].download(), t[part].download()
+        for r, i in enumerate(gi):
+            assert np.array_equal(gd[r], td[ti.index(i)]), (part, i)
+    assert np.allclose(nf, ns, rtol=1e-12, atol=0)
+    # and against the oracle, element 0 of the batch
+    w = P.o.tensor(own, ops[0][:, 0], ops[1][:, 0], ops[0][:, 0], ops[2][:, 0])
+    for part in range(3):
+        up = np.vstack([P.o.scale_by_primes(own, w[part], add)] + [np.zeros((1, P.N), dtype=np.uint64)] * len(add)) if add else w[part]
+        want = P.o.scale_down(own + add, up, drop, ptxt)
+        gi, gd = fused[part].getIndexSet(), fused[part].download()
+        for r, i in enumerate(gi):
+            assert np.array_equal(gd[r, 0], want[keep.index(i)]), (part, i)
+
+
 @pytest.mark.parametrize("m", [16384, 65536])
 @pytest.mark.parametrize("ptxt", [65537, 1])
 def test_several_primes_mod_switch_batched_over_parts_mixed_prime_sizes(hx, m, ptxt):
