@@ -57,7 +57,7 @@ SYMBOLS = [
     "hx_time_ntt", "hx_ctx_timer_begin", "hx_ctx_timer_end", "hx_randomize",
     "hx_ctx_graph_begin", "hx_ctx_graph_end", "hx_graph_launch", "hx_graph_destroy",
     "hx_profile_begin", "hx_profile_end", "hx_ctx_arena_stats", "hx_ctx_reserve",
-    "hx_tensor_bring_to_set", "hx_tensor_bring_to_set_norms",
+    "hx_tensor_bring_to_set", "hx_tensor_bring_to_set_norms", "hx_mul_relin_norms",
 ]
 
 
@@ -141,6 +141,7 @@ def lib():
             "hx_graph_destroy": [vp],
             "hx_profile_begin": [], "hx_profile_end": [vp, C.c_size_t, vp],
             "hx_ctx_arena_stats": [vp, vp], "hx_ctx_reserve": [vp, C.c_uint64],
+            "hx_mul_relin_norms": [vp, vp, vp, vp, vp, vp, vp, ip, vp, vp, vp],
             "hx_tensor_bring_to_set": [vp] * 8 + [ip, vp, ip, u64],
             "hx_tensor_bring_to_set_norms": [vp] * 8 + [ip, vp, ip, u64, vp],
         }

@@ -45,6 +45,8 @@ hipError_t launch_moddown_apply_plain_pow2(int logn, const PolyBases& polys, con
 hipError_t launch_moddown_tensor_pow2(int logn, const TensorSrc& T, const PolyBases& outs, int drop_row, int drop_prime,
                                       const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
                                       const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena, hipStream_t st);
+hipError_t launch_ntt_inv_mul_pow2(int logn, const uint64_t* a, const uint64_t* b, uint64_t* out, const NttRows& rows,
+                                   int nrows, int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st);
 hipError_t launch_conv_rows(int logn, const ConvRowArgs& A, const ConvRows& R, int nunits, const PrimeDev* cprimes,
                             const TW* tw_arena, hipStream_t st);
 }
@@ -4096,7 +4098,8 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
                             int accumulate_rows, const uint64_t* own_src = nullptr,
                             const std::vector<int>* owner = nullptr,
                             const std::vector<std::vector<int>>* digit_primes = nullptr,
-                            int ndig = -1, const uint64_t* t0s = nullptr, const uint64_t* t1s = nullptr)
+                            int ndig = -1, const uint64_t* t0s = nullptr, const uint64_t* t1s = nullptr,
+                            const hx::TensorSrc* ts = nullptr)
 {
   int nall = (int)all.size();
   if (ndig < 0)
@@ -4117,7 +4120,7 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
     if (hxh::bitlen(c->primes[r].q) > 60)
       lazy = 0;
   const hx::KsFix* d_fix = nullptr;
-  if (own_src) {
+  if (own_src || ts) {
     // cached table: owner digit of every row and P_e^-1 mod q_row for the earlier digits
     std::vector<uint64_t> key;
     key.push_back(0xF1F1F1F1ull);
@@ -4163,7 +4166,7 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
   HX_LAUNCH(hx::keyswitch_kernel, ew_grid(rw, nall), dim3(256), 0, c->stream, dig, W->d_b,
                      W->d_a, out0, out1, map, ndig, nall, (int)W->row_idx.size(), batch, c->phim,
                      accumulate_rows, c->d_primes, own_src, d_fix, lazy, d_fix ? t0s : nullptr,
-                     d_fix ? t1s : nullptr);
+                     d_fix ? t1s : nullptr, ts ? *ts : hx::TensorSrc{nullptr, nullptr, nullptr, nullptr});
   HIPCHK(hipGetLastError());
   return HX_OK;
 }
@@ -4203,14 +4206,27 @@ extern "C" int hx_key_switch_digits(const hx_poly* digits, const hx_ksk* W, hx_p
 static int relin_core(hx_ctx* c, const uint64_t* t2e, const std::vector<int>& own,
                       const std::vector<int>& all, const hx_ksk* W, const int* dig_idx,
                       const int* dig_off, int ndig, int batch, uint64_t* out0, uint64_t* out1,
-                      const uint64_t* t0s = nullptr, const uint64_t* t1s = nullptr)
+                      const uint64_t* t0s = nullptr, const uint64_t* t1s = nullptr, const hx::TensorSrc* ts = nullptr)
 {
+  // ts (hx_mul_relin): the tensor product is folded in -- t2e is null; the s^2 part's coefficient rows come from
+  // the inverse transform of a1 * b1 formed on load, and the key-switch kernel forms the parts (1), (s) and the
+  // s^2 evaluation rows it needs from the four operand parts (own[r] is row r of each of them)
   const int L = (int)own.size(), nall = (int)all.size();
   const size_t rw = (size_t)batch * c->phim;
   // scratch: [2] = s^2 part in the coefficient domain; [1] = digits (ndig*nall rows; a digit's
   // own rows are never materialised)
   CHK(ensure_scratch(c, 2, (size_t)L * rw));
-  {
+  if (ts) {
+    NttRows nr;
+    for (int r = 0; r < L; r++) {
+      nr.row[r] = (uint16_t)r;
+      nr.prime[r] = (uint16_t)own[r];
+    }
+    hipError_t e = hx::launch_ntt_inv_mul_pow2(c->logn, ts->a1, ts->b1, c->scratch[2], nr, L, batch, c->d_primes,
+                                               c->d_tw, c->stream);
+    if (e != hipSuccess)
+      return fail(HX_ERR_DEVICE, "NTT launch failed: %s", hipGetErrorString(e));
+  } else {
     std::vector<std::pair<int, int>> rows;
     for (int r = 0; r < L; r++)
       rows.emplace_back(r, own[r]);
@@ -4242,7 +4258,7 @@ static int relin_core(hx_ctx* c, const uint64_t* t2e, const std::vector<int>& ow
   for (int d = 0; d < ndig; d++)
     dprimes[d].assign(dig_idx + dig_off[d], dig_idx + dig_off[d + 1]);
   return keyswitch_launch(c, c->scratch[1], W, all, batch, out0, out1, L, t2e, &owner, &dprimes, ndig,
-                          t0s, t1s);
+                          t0s, t1s, ts);
 }
 
 static std::vector<uint64_t> special_factor(hx_ctx* c, const std::vector<int>& own, const int* sp,
@@ -4284,12 +4300,44 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
   CHK(poly_reserve(out1, nall, out1 == c0 || out1 == c1 || out1 == d0 || out1 == d1));
   out0->prime_idx = W->row_idx;
   out1->prime_idx = W->row_idx;
+  // the tensor product folded into the inverse transform's load and the key-switch kernel (no tensor_kernel pass,
+  // the three product parts are never written): power-of-two rings the row kernels take, outputs that are not
+  // operands (the key-switch kernel reads operand rows of the coefficient it writes)
+  static const bool fuse_off = getenv("HX_NO_MULRELIN_FUSE") != nullptr;
+  const hx_poly* ins[4] = {c0, c1, d0, d1};
+  bool alias = false;
+  for (auto* p : ins)
+    alias = alias || p == out0 || p == out1 || p->d == out0->d || p->d == out1->d;
+  for (auto* p : ins)
+    if (p->ctx != c || p->batch != c0->batch || p->prime_idx != c0->prime_idx)
+      return fail(HX_ERR_PRIMESET, "tensorProduct: parts must be defined relative to the same set of primes");
+  if (!fuse_off && !alias && c->pow2 && c->logn >= 13 && c->logn <= 15 && L <= MAX_ROWS) {
+    hx::TensorSrc T{c0->d, c1->d, d0->d, d1->d};
+    return relin_core(c, nullptr, c0->prime_idx, W->row_idx, W, dig_idx, dig_off, ndig, c0->batch, out0->d, out1->d,
+                      nullptr, nullptr, &T);
+  }
   CHK(ensure_scratch(c, 0, (size_t)L * rw));  // s^2 part, evaluation domain
   // tensorProduct + (parts 1,s) addPrimesAndScale(special)
   std::vector<uint64_t> f = special_factor(c, c0->prime_idx, W->row_idx.data() + L, K);
   CHK(tensor_launch(c0, c1, d0, d1, out0->d, out1->d, c->scratch[0], f.data()));
   return relin_core(c, c->scratch[0], c0->prime_idx, W->row_idx, W, dig_idx, dig_off, ndig,
                     c0->batch, out0->d, out1->d);
+}
+
+// hx_mul_relin with the digit norms Ctxt::keySwitchPart feeds into the noise estimate (as hx_relinearize_norms)
+extern "C" int hx_mul_relin_norms(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1,
+                                  const hx_ksk* W, const int* dig_idx, const int* dig_off, int ndig, hx_poly* out0,
+                                  hx_poly* out1, double* norms)
+{
+  if (!c0 || !norms || ndig < 1)
+    return fail(HX_ERR_INVALID, "bad argument");
+  hx_ctx* c = c0->ctx;
+  CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_mul_relin_norms (a norm read-back)");
+  const size_t rw = c0->row_words();
+  CHK(frac_begin(c, (size_t)ndig * rw));
+  int rc = hx_mul_relin(c0, c1, d0, d1, W, dig_idx, dig_off, ndig, out0, out1);
+  return finish_norms(c, rc, (size_t)ndig * rw, ndig * c0->batch, norms, nullptr);
 }
 
 // Ctxt::reLinearize for a 3-part ciphertext (1, s, s^2) (src/Ctxt.cpp:720-786): parts 1 and s get

@@ -679,6 +679,82 @@ ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
   ntt_body<LOGN, INV>(lds, io, tw, pd);
 }
 
+// inverse transform of a(X) * b(X) given in evaluation form: the s^2 part of a tensor product (a1 b1) goes
+// straight from the operands' rows to its coefficient rows (hx_mul_relin: toPoly side of breakIntoDigits)
+struct MulLoadIO {
+  static constexpr int LOAD_BOUND = 1;
+  static constexpr bool LAZY_STORE = false;
+  static constexpr bool PIPELINED = false;
+  struct StorePrefetch {};
+  v4i32 ra, rb, ro;
+  uint64_t q, mu63;
+  uint32_t k;
+  __device__ MulLoadIO(const uint64_t* a_row, const uint64_t* b_row, uint64_t* o_row, unsigned bytes, const PrimeDev* pd)
+      : ra(make_rsrc(a_row, bytes)), rb(make_rsrc(b_row, bytes)), ro(make_rsrc(o_row, bytes)), q(pd->q), mu63(pd->mu63),
+        k(pd->k)
+  {
+  }
+  __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
+  {
+    const v2i32 x = hx_buffer_load_v2(ra, (int)(tid * 8u), (int)(c * 8u), 0);
+    const v2i32 y = hx_buffer_load_v2(rb, (int)(tid * 8u), (int)(c * 8u), 0);
+    const uint64_t a = ((uint64_t)(uint32_t)x.y << 32) | (uint32_t)x.x, b = ((uint64_t)(uint32_t)y.y << 32) | (uint32_t)y.x;
+    return tensor_red128((u128)a * b, q, mu63, k);
+  }
+  __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t v) const
+  {
+    v2i32 d;
+    d.x = (int)(uint32_t)v;
+    d.y = (int)(uint32_t)(v >> 32);
+    hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), 0);
+  }
+  __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
+};
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
+ntt_inv_mul_kernel(const uint64_t* a, const uint64_t* b, uint64_t* out, NttRows rows, int batch,
+                   const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned ri = wid / (unsigned)batch;
+  const int bb = (int)(wid % (unsigned)batch);
+  const int row = (int)uniform_u16(rows.row, ri);
+  const PrimeDev* pd = primes + uniform_u16(rows.prime, ri);
+  const size_t N = Geo<LOGN>::N;
+  const size_t roff = ((size_t)row * batch + bb) * N, ooff = ((size_t)ri * batch + bb) * N;   // output rows are compact
+  const MulLoadIO io(a + roff, b + roff, out + ooff, (unsigned)N * 8u, pd);
+  ntt_body<LOGN, true>(lds, io, tw_arena + pd->tw_inv_off, pd);
+}
+template <int LOGN>
+static hipError_t launch_inv_mul(const uint64_t* a, const uint64_t* b, uint64_t* out, const NttRows& rows, int nrows,
+                                 int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)ntt_inv_mul_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess)
+      return e;
+    attr_set = true;
+  }
+  HX_LAUNCH((ntt_inv_mul_kernel<LOGN>), dim3((unsigned)nrows * (unsigned)batch), dim3(Geo<LOGN>::T), lds_bytes, st, a, b,
+            out, rows, batch, primes, tw_arena);
+  return hipGetLastError();
+}
+// out[i] (compact rows i < nrows) = inverse transform of a[rows.row[i]] * b[rows.row[i]]
+hipError_t launch_ntt_inv_mul_pow2(int logn, const uint64_t* a, const uint64_t* b, uint64_t* out, const NttRows& rows,
+                                   int nrows, int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  switch (logn) {
+    case 13: return launch_inv_mul<13>(a, b, out, rows, nrows, batch, primes, tw_arena, st);
+    case 14: return launch_inv_mul<14>(a, b, out, rows, nrows, batch, primes, tw_arena, st);
+    case 15: return launch_inv_mul<15>(a, b, out, rows, nrows, batch, primes, tw_arena, st);
+  }
+  return hipErrorInvalidValue;
+}
+
 template <int LOGN, bool INV>
 static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows,
                              int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)

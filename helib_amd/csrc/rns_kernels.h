@@ -255,8 +255,11 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
                  uint32_t n, int accumulate_rows /* rows < this accumulate, others overwrite */,
                  const PrimeDev* __restrict__ primes, const uint64_t* __restrict__ own_src,
                  const KsFix* __restrict__ fix, int lazy, const uint64_t* __restrict__ t0s,
-                 const uint64_t* __restrict__ t1s)
+                 const uint64_t* __restrict__ t1s, TensorSrc ts)
 {
+  // ts.a0 != null (hx_mul_relin): the tensor product is folded in -- for the rows < accumulate_rows the parts
+  // (1), (s) and the s^2 part's evaluation rows are formed here from the four operand parts' rows:
+  // t0 = a0 b0, t1 = a0 b1 + a1 b0, t2 = a1 b1; no tensor_kernel pass, no product rows in memory.
   const int row = blockIdx.y;
   const PrimeDev pd = primes[map.p[row]];
   const uint64_t q = pd.q, mu = pd.mu;
@@ -268,7 +271,22 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
     const size_t e = 2 * i;            // within the row: b*n + j
     const size_t j = e % n;            // coefficient index (pairs never straddle: n even)
     ulonglong2 acc0, acc1;
-    if (row < accumulate_rows && t0s) {
+    ulonglong2 own = make_ulonglong2(0, 0);
+    if (row < accumulate_rows && ts.a0) {
+      const size_t o = (size_t)row * row_words + e;
+      const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(ts.a0 + o);
+      const ulonglong2 a1 = *reinterpret_cast<const ulonglong2*>(ts.a1 + o);
+      const ulonglong2 b0 = *reinterpret_cast<const ulonglong2*>(ts.b0 + o);
+      const ulonglong2 b1 = *reinterpret_cast<const ulonglong2*>(ts.b1 + o);
+      const TW ps = fix[row].pscale;
+      const uint64_t m63 = pd.mu63;
+      acc0.x = mul_shoup(red128_q8((u128)a0.x * b0.x, q, m63, k), ps.w, ps.wp, q);
+      acc0.y = mul_shoup(red128_q8((u128)a0.y * b0.y, q, m63, k), ps.w, ps.wp, q);
+      acc1.x = mul_shoup(red128_q8((u128)a0.x * b1.x + (u128)a1.x * b0.x, q, m63, k), ps.w, ps.wp, q);
+      acc1.y = mul_shoup(red128_q8((u128)a0.y * b1.y + (u128)a1.y * b0.y, q, m63, k), ps.w, ps.wp, q);
+      own.x = red128_q8((u128)a1.x * b1.x, q, m63, k);
+      own.y = red128_q8((u128)a1.y * b1.y, q, m63, k);
+    } else if (row < accumulate_rows && t0s) {
       // parts (1),(s) enter scaled by the special primes (Ctxt::keySwitchPart's
       // addPrimesAndScale, src/Ctxt.cpp:816-820), read straight from the unscaled parts
       const TW ps = fix[row].pscale;
@@ -290,8 +308,7 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
       acc1 = make_ulonglong2(0, 0);
     }
     const int owner = fix ? (int)fix[row].owner : -1;
-    ulonglong2 own = make_ulonglong2(0, 0);
-    if (owner >= 0)
+    if (owner >= 0 && !ts.a0)
       own = *reinterpret_cast<const ulonglong2*>(own_src + (size_t)row * row_words + e);
     // lazy inner product: 128-bit sums of the D products, ONE Barrett reduction per output word
     // (q < 2^60 and D <= 8 => the sums stay below 2^123)

@@ -220,6 +220,11 @@ int hx_key_switch_digits(const hx_poly* digits, const hx_ksk* W, hx_poly* out0, 
 int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1,
                  const hx_ksk* W, const int* dig_idx, const int* dig_off, int ndig,
                  hx_poly* out0, hx_poly* out1);
+/* ... with the digit norms of hx_relinearize_norms: norms[d * batch + b] (what keySwitchPart multiplies by the
+ * matrix' noise bound, src/Ctxt.cpp:828-841) */
+int hx_mul_relin_norms(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1,
+                       const hx_ksk* W, const int* dig_idx, const int* dig_off, int ndig,
+                       hx_poly* out0, hx_poly* out1, double* norms);
 
 /* Ctxt::reLinearize of a 3-part ciphertext (1, s, s^2) (src/Ctxt.cpp:720-786, keySwitchPart
  * :805-842): parts (1),(s) get addPrimesAndScale(special), part s^2 is broken into digits and

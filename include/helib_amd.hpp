@@ -530,14 +530,31 @@ public:
     hx_ksk* k = nullptr;
     check(hx_ksk_create(c.handle(), ndig, rows.data(), (int)rows.size(), b.data(), a.data(), &k));
     h_.reset(k);
+    rows_ = rows;
   }
   hx_ksk* handle() const { return h_.get(); }
+  const IndexSet& rows() const { return rows_; }
+  // the matrix' rows are exactly `first` followed by `then`, in this order (what hx_mul_relin expects of the
+  // ciphertext's primes and the special primes)
+  bool coversInOrder(const IndexSet& first, const IndexSet& then) const
+  {
+    if (rows_.size() != first.size() + then.size())
+      return false;
+    for (size_t i = 0; i < first.size(); i++)
+      if (rows_[i] != first[i])
+        return false;
+    for (size_t i = 0; i < then.size(); i++)
+      if (rows_[first.size() + i] != then[i])
+        return false;
+    return true;
+  }
 
 private:
   struct Del {
     void operator()(hx_ksk* p) const { hx_ksk_destroy(p); }
   };
   std::unique_ptr<hx_ksk, Del> h_;
+  IndexSet rows_;
 };
 
 // Cmodulus (include/helib/CModulus.h:56-145): one modulus q with the tables for FFT / iFFT modulo q over

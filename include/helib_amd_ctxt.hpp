@@ -1022,8 +1022,18 @@ public:
       throw LogicError("no key-switching matrices for this part");
     dropSmallAndSpecialPrimes();
     relin_CKKS_adjust();
-    materializeTensor();   // (no mod-switch consumed the pending tensor product: form it now)
     const IndexSet& sp = context->specialPrimes;
+    // No mod-switch consumed the pending tensor product (a fresh CKKS product, a product at a level that needs
+    // none): at the full level the key switch takes the operands themselves -- hx_mul_relin forms the product
+    // parts inside the inverse transform's load and the key-switch kernel; otherwise the product is formed now.
+    std::shared_ptr<PendingTensor> pend;
+    if (pendingTensor && pendingTensor->c0.getIndexSet() == context->ctxtPrimes && toSet(context->ctxtPrimes) == primeSet &&
+        W->coversInOrder(context->ctxtPrimes, sp)) {
+      pend = std::move(pendingTensor);
+      pendingTensor.reset();
+    } else {
+      materializeTensor();
+    }
     double logProd = context->logOfProduct(sp);
     lnRatFactor += logProd;  // the CKKS factor after the mod-up by the special primes (:757)
     std::vector<IndexSet> digits;
@@ -1048,7 +1058,17 @@ public:
     flatten(digits, idx, off);
     const int batch = t0.batch();
     std::shared_ptr<std::vector<double>> nrm;
-    if (measure) {
+    if (pend) {
+      if (measure) {
+        dev->deferNorms(lazy());
+        nrm = dev->normBuffer(digits.size() * (size_t)batch);
+        check(hx_mul_relin_norms(pend->c0.handle(), pend->c1.handle(), pend->d0.handle(), pend->d1.handle(), W->handle(),
+                                 idx.data(), off.data(), (int)digits.size(), o0.handle(), o1.handle(), nrm->data()));
+      } else {
+        check(hx_mul_relin(pend->c0.handle(), pend->c1.handle(), pend->d0.handle(), pend->d1.handle(), W->handle(),
+                           idx.data(), off.data(), (int)digits.size(), o0.handle(), o1.handle()));
+      }
+    } else if (measure) {
       dev->deferNorms(lazy());
       nrm = dev->normBuffer(digits.size() * (size_t)batch);
       check(hx_relinearize_norms(t0.handle(), its == parts.end() ? nullptr : its->second.handle(), t2.handle(),
@@ -1394,7 +1414,7 @@ private:
       }
     dropSmallAndSpecialPrimes();
     relin_CKKS_adjust();
-    materializeTensor();   // (no mod-switch consumed the pending tensor product: form it now)
+    materializeTensor();
     const IndexSet& sp = context->specialPrimes;
     const double logProd = context->logOfProduct(sp);
     lnRatFactor += logProd;

@@ -624,6 +624,19 @@ int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const 
       sp.push_back(i);
   return hx_relinearize(&t0, &t1, &t2, W, dig_idx, dig_off, ndig, sp.data(), (int)sp.size(), out0, out1);
 }
+int hx_mul_relin_norms(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1, const hx_ksk* W,
+                       const int* dig_idx, const int* dig_off, int ndig, hx_poly* out0, hx_poly* out1, double* norms)
+{
+  hx_poly t0{c0->ctx, c0->batch, {}, {}}, t1 = t0, t2 = t0;
+  int rc = hx_tensor(c0, c1, d0, d1, &t0, &t1, &t2);
+  if (rc)
+    return rc;
+  std::vector<int> sp;
+  for (int i : W->rows)
+    if (find(c0->idx, i) < 0)
+      sp.push_back(i);
+  return hx_relinearize_norms(&t0, &t1, &t2, W, dig_idx, dig_off, ndig, sp.data(), (int)sp.size(), out0, out1, norms);
+}
 
 int hx_norms_flush(hx_ctx* c)
 {
