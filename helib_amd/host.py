@@ -17,7 +17,7 @@ class HostError(RuntimeError):
 
 
 def lib(path=None):
-    path = path or _SO
+    path = path or os.environ.get("HX_HOST_LIB") or _SO   # (HX_HOST_LIB + HX_LIB: a variant build, tools/build_variant.sh)
     if path not in _libs:
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: build it with `python -m helib_amd.build`")

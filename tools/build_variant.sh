@@ -1,0 +1,19 @@
+#!/bin/bash
+# tools/build_variant.sh NAME [-DFLAG ...]: the engine and the C++ host built with extra compiler flags into
+# helib_amd/lib/variants/NAME/ (libhelib_amd.so + libhelib_amd_host.so side by side, rpath $ORIGIN).  Run a
+# benchmark against it with   HX_LIB=$PWD/helib_amd/lib/variants/NAME/libhelib_amd.so
+#                             HX_HOST_LIB=$PWD/helib_amd/lib/variants/NAME/libhelib_amd_host.so python bench.py ...
+set -e
+name=$1; shift
+d=helib_amd/lib/variants/$name
+mkdir -p $d
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed"
+pids=""
+for s in ntt_kernels conv_kernels engine; do
+  /opt/rocm/bin/hipcc $F "$@" -c helib_amd/csrc/$s.hip -o $d/$s.o & pids="$pids $!"
+done
+for p in $pids; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $d/libhelib_amd.so $d/ntt_kernels.o $d/conv_kernels.o $d/engine.o
+g++ -std=c++17 -O2 -fPIC -shared -Iinclude helib_amd/csrc/host_session.cpp -L$d -lhelib_amd -Wl,-rpath,'$ORIGIN' -o $d/libhelib_amd_host.so
+rm -f $d/*.o
+ls -la $d

@@ -1,0 +1,98 @@
+#!/bin/bash
+# Round 3's GPU calls as stages of one script (each gpurun call of the round ran a subset):
+#   gpurun --timeout 2400 -- 'bash tools/r3_gpu_calls.sh OUT stage [stage ...]'
+# OUT = directory name under gpurun_out/.  Stages:
+#   tests            the GPU parity suite (pytest -m gpu), through the C ABI
+#   tests:EXPR       the same with -k EXPR
+#   smoke            __graft_entry__.smoke()
+#   bench            the driver's command, full line  -> bench_full.json
+#   bench_ckks       config 4 (--workload ckks65536)   -> bench_ckks.json
+#   bench_fixed      the fixed-level multiply          -> bench_fixed.json
+#   trace            rocprofv3 --kernel-trace over the driver's command -> bench_kernel_trace.txt + bench_traced.json
+#   pmc              three separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU) -> pmc_summary.txt
+#   bluestein        tools/prof_bluestein.py fused and old chain + kernel trace of the fused one
+#   levels           tools/prof_levels.py for both schemes
+#   ab:A,B,...       same-box A/B of the fresh multiply, two rounds; A = default | env:VAR=1 | a variant
+#                    directory under helib_amd/lib/variants (tools/build_variant.sh); WORKLOAD=ckks65536 for config 4
+#   ubench           tools/ubench/bfly_* binaries
+export TMPDIR=/tmp
+name=$1; shift
+out=gpurun_out/$name
+mkdir -p $out
+R=${GRAFT_REPO_ROOT:-$PWD}
+QUICK="--no-extras --cpu-sample 0"
+
+line() {  # one-line digest of a bench JSON
+  python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+except Exception as e:
+    print(sys.argv[2], 'no line:', e); sys.exit(0)
+c, r = d['config'], d['roofline']
+l2 = c.get('level2') or {}
+ks = [(k['kernel'][:34], k['workgroups'], k['avg_us']) for k in (c.get('kernels_in_situ') or {}).get('kernels', [])[:6]]
+print(sys.argv[2], 'value', d['value'], 'bound', c.get('bound_noise_mult_per_s'), 'level2', l2.get('mult_per_s'), l2.get('over_level1'),
+      'roofline', r.get('kernel'), r.get('avg_launch_us'), r.get('frac'), ks)
+PY
+}
+
+for st in "$@"; do
+  case "$st" in
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $out/pytest_gpu.log ;;
+    tests:*)
+      timeout 1200 python -m pytest tests -m gpu -q -x -k "${st#tests:}" > $out/pytest_k.log 2>&1; echo "pytest -k rc=$?"; tail -4 $out/pytest_k.log ;;
+    smoke)
+      timeout 300 python __graft_entry__.py --smoke > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $out/smoke.log ;;
+    bench)
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_full.json 2> $out/bench_full.err; echo "bench rc=$?"
+      line $out/bench_full.json bgv; tail -3 $out/bench_full.err ;;
+    bench_ckks)
+      timeout 600 python bench.py --workload ckks65536 --steps 8 --warmup 3 > $out/bench_ckks.json 2> $out/bench_ckks.err; echo "bench ckks rc=$?"
+      line $out/bench_ckks.json ckks; tail -3 $out/bench_ckks.err ;;
+    bench_fixed)
+      timeout 400 python bench.py --workload bgv32768_fixed --steps 8 --warmup 3 --cpu-sample 0 > $out/bench_fixed.json 2> $out/bench_fixed.err
+      python -c "import json;print('fixed level', json.load(open('$out/bench_fixed.json'))['value'])" ;;
+    trace)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/$out/kt -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 $QUICK \
+         > $R/$out/bench_traced.json 2> $R/$out/bench_traced.err); echo "trace rc=$?"
+      python tools/rocpd_summary.py $out/kt --by-grid > $out/bench_kernel_trace.txt 2>&1
+      line $out/bench_traced.json traced
+      grep -E "wgs" $out/bench_kernel_trace.txt | head -16 ;;
+    pmc)
+      for ctr in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
+        (cd /tmp && timeout 400 rocprofv3 --pmc $ctr -d $R/$out/pmc_$ctr -- python3 $R/bench.py --gpus 1 --steps 2 --warmup 1 \
+           --mults-per-step 4 $QUICK > /dev/null 2> $R/$out/pmc_$ctr.err); echo "pmc $ctr rc=$?"
+      done
+      python tools/rocpd_pmc.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ_INSTS_VALU > $out/pmc_summary.txt 2>&1
+      head -40 $out/pmc_summary.txt ;;
+    bluestein)
+      timeout 200 python tools/prof_bluestein.py > $out/blue_fused.json 2> $out/blue_fused.err; cat $out/blue_fused.json
+      HX_BLUE_OLD=1 timeout 200 python tools/prof_bluestein.py > $out/blue_old.json 2> $out/blue_old.err; cat $out/blue_old.json
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $R/$out/blue_kt -- python3 $R/tools/prof_bluestein.py > /dev/null 2> $R/$out/blue_kt.err)
+      python tools/rocpd_summary.py $out/blue_kt > $out/blue_kernel_trace.txt 2>&1; head -14 $out/blue_kernel_trace.txt ;;
+    levels)
+      timeout 300 python tools/prof_levels.py --scheme bgv > $out/levels_bgv.json 2> $out/levels_bgv.err; cut -c1-1500 $out/levels_bgv.json
+      timeout 300 python tools/prof_levels.py --scheme ckks > $out/levels_ckks.json 2> $out/levels_ckks.err; cut -c1-1500 $out/levels_ckks.json ;;
+    ab:*)
+      IFS=, read -ra VS <<< "${st#ab:}"
+      for round in 1 2; do
+        for v in "${VS[@]}"; do
+          envs=""
+          case "$v" in
+            default) ;;
+            env:*) envs="${v#env:}" ;;
+            *) envs="HX_LIB=$R/helib_amd/lib/variants/$v/libhelib_amd.so HX_HOST_LIB=$R/helib_amd/lib/variants/$v/libhelib_amd_host.so" ;;
+          esac
+          f=$out/ab_${v//[^A-Za-z0-9_]/_}_$round.json
+          env $envs timeout 300 python bench.py --steps 8 --warmup 3 $QUICK ${WORKLOAD:+--workload $WORKLOAD} > $f 2> ${f%.json}.err
+          line $f "$v#$round"
+        done
+      done ;;
+    ubench)
+      for b in tools/ubench/bfly_*; do [ -x $b ] && { echo "== $b"; timeout 60 $b; }; done > $out/ubench.txt 2>&1; cat $out/ubench.txt ;;
+    *) echo "unknown stage $st" ;;
+  esac
+done
+find $out -name "*.db" -size +20M -delete
