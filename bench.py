@@ -539,6 +539,13 @@ def kernel_table(prof, n, B, l, k, d, mults):
             byts, what = el * (nk * 16 * n - 8 * n + 16 * n), f"{el} elements x ({nk} kept rows x 16N - 8N (added row) + x,S 16N)"
         elif name.startswith("ntt_moddown_apply_kernel<"):
             byts, what = w * 24 * n, "delta/P in 8N + c_r in + out 16N per kept row"
+        elif name.startswith("ntt_moddown_apply_tensor_kernel<") and name.endswith("true>"):
+            # tensorProduct folded into the product's SEVERAL-primes mod-switch (every multiply after the first):
+            # nk kept rows per part, of which the k special primes are added by the fused mod-up (no operand rows)
+            nk = max(1, w // (3 * B))
+            nin = nk - k if nk > k else nk
+            byts = B * 8 * n * (3 * nk + 4 * nin + 3 * nk)
+            what = f"{B} elements x 8N x (3 parts x {nk} delta rows in + 4 operand parts x {nin} rows in + 3 parts x {nk} rows out)"
         elif name.startswith("ntt_moddown_apply_tensor_kernel<"):
             nk = l                                   # tensorProduct folded into the product's single-prime mod-switch
             el = max(1, w // (3 * nk))               # batch elements (three product parts each)
@@ -546,6 +553,8 @@ def kernel_table(prof, n, B, l, k, d, mults):
             # a row once per product part that uses it: 8 row reads for 4 rows), the three parts' nk rows out, x and S
             byts = el * 8 * n * (4 * (nk - 1) + 3 * nk + 6)
             what = f"{el} elements x 8N x (4 operand parts x {nk - 1} rows in + 3 parts x {nk} rows out + x,S of 3 parts)"
+        elif name.startswith("ntt_moddown_prep_multi_tensor_kernel<"):
+            byts, what = (w // 3) * 8 * n * (4 + 3), "4 operand rows in, x of 3 parts out per batch element and dropped prime"
         elif name.startswith("ntt_moddown_prep_tensor_kernel<"):
             byts, what = (w // 3) * 8 * n * (4 + 3), "4 operand rows in, x of 3 parts out per batch element"
         elif name.startswith("tensor_kernel"):
@@ -681,7 +690,7 @@ def make_roofline(table, n, B, l, k, d, b2b=None):
     # recorded PMC traffic of the same kernel and launch shape (cannot be collected inside this process)
     traffic, src = None, None
     short = dom["kernel"].replace(", false>", ">").replace(", true>", ",plain>")
-    for rec in ("r03_pmc_moddown_apply_traffic.json", "r02_pmc_moddown_apply_traffic.json"):
+    for rec in ("r03_pmc_roofline_kernel_traffic.json", "r03_pmc_moddown_apply_traffic.json", "r02_pmc_moddown_apply_traffic.json"):
         t, sname = recorded_traffic(rec, short, dom["workgroups"], n)
         if t is not None:
             traffic, src = t, sname
@@ -718,9 +727,10 @@ def recorded_traffic(name, kernel, rows, n):
     rec = os.path.join(ROOT, "profiles", name)
     if os.path.exists(rec):
         with open(rec) as f:
-            r = json.load(f)
-        if r.get("kernel") == kernel and r.get("rows_per_launch") == rows and r.get("N") == n:
-            return r["traffic_bytes_per_launch"], "profiles/" + name
+            recs = json.load(f)
+        for r in recs if isinstance(recs, list) else [recs]:
+            if r.get("kernel") == kernel and r.get("rows_per_launch") == rows and r.get("N") == n:
+                return r["traffic_bytes_per_launch"], "profiles/" + name
     return None, None
 
 

@@ -42,6 +42,12 @@ hipError_t launch_moddown_prep_multi_pow2(int logn, const PolyBases& polys, cons
 hipError_t launch_moddown_apply_plain_pow2(int logn, const PolyBases& polys, const PolyBases& outs,
                                            const NttRows& keep, int nkeep, int batch, const ModDownApply& A,
                                            const PrimeDev* primes, const TW* tw_arena, hipStream_t st);
+hipError_t launch_moddown_prep_multi_tensor_pow2(int logn, const TensorSrc& T, const PrepMulti& M, int ndrop, int batch,
+                                                 const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena,
+                                                 hipStream_t st);
+hipError_t launch_moddown_apply_plain_tensor_pow2(int logn, const TensorSrc& T, const PolyBases& outs, const NttRows& keep,
+                                                  int nkeep, int batch, const ModDownApply& A, const PrimeDev* primes,
+                                                  const TW* tw_arena, hipStream_t st);
 hipError_t launch_moddown_tensor_pow2(int logn, const TensorSrc& T, const PolyBases& outs, int drop_row, int drop_prime,
                                       const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
                                       const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena, hipStream_t st);
@@ -3079,8 +3085,12 @@ extern "C" int hx_poly_rem(const hx_poly* a, uint64_t t, uint64_t* out_host)
 //      out of place by construction, so lazily copied operands (hx_poly::Share) are never copied.
 // Returns HX_ERR_UNSUPPORTED (nothing touched) when the shape is not covered; the callers then
 // take the per-polynomial path.
+// tsrc (tensorProduct folded in): the polys are the three product parts with reserved storage and the operands'
+// prime list; their rows are formed from the operands' rows inside the transforms and the results go into the
+// parts' own slabs.
 static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& drop_in,
-                                  const std::vector<int>& keep, uint64_t ptxt, const int* add_idx, int nadd)
+                                  const std::vector<int>& keep, uint64_t ptxt, const int* add_idx, int nadd,
+                                  const hx::TensorSrc* tsrc = nullptr)
 {
   hx_poly* a = ps[0];
   hx_ctx* c = a->ctx;
@@ -3090,6 +3100,8 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
   for (int i = 0; i < np; i++)
     if (!ps[i]->owns)
       return HX_ERR_UNSUPPORTED;  // caller-owned storage wants its result in place
+  if (tsrc && (np != 3 || getenv("HX_NO_TENSOR_MULTI")))
+    return HX_ERR_UNSUPPORTED;
   const size_t rw = a->row_words();
   const int batch = a->batch;
   std::vector<int> drop = drop_in;
@@ -3159,6 +3171,12 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
   memset(&pbo, 0, sizeof pbo);
   pb.n = pbo.n = np;
   for (int i = 0; i < np; i++) {
+    if (tsrc) {  // nothing of the part exists yet: its own slab takes the result
+      if (ps[i]->cap_rows < nk)
+        return HX_ERR_UNSUPPORTED;
+      pb.d[i] = pbo.d[i] = ps[i]->d;
+      continue;
+    }
     hipError_t pe = pool_alloc(c, nbytes, (void**)&fresh[i]);
     if (pe != hipSuccess) {
       drop_fresh();
@@ -3193,7 +3211,9 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
         M.up[2 * j + 1].wp = hxh::shoup(M.up[2 * j + 1].w, qd);
       }
     }
-    hipError_t e = hx::launch_moddown_prep_multi_pow2(c->logn, pb, M, nj, batch, P, c->d_primes, c->d_tw, c->stream);
+    hipError_t e = tsrc ? hx::launch_moddown_prep_multi_tensor_pow2(c->logn, *tsrc, M, nj, batch, P, c->d_primes, c->d_tw,
+                                                                    c->stream)
+                        : hx::launch_moddown_prep_multi_pow2(c->logn, pb, M, nj, batch, P, c->d_primes, c->d_tw, c->stream);
     if (e != hipSuccess)
       rc = fail(HX_ERR_DEVICE, "mod-down launch failed: %s", hipGetErrorString(e));
   }
@@ -3222,8 +3242,10 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
     A.rows = reinterpret_cast<const hx::ModDownRow*>(it->second->blob);
     A.delta = c->scratch[1];
     A.delta_poly_stride = (uint64_t)nk * rw;
-    hipError_t e = hx::launch_moddown_apply_plain_pow2(c->logn, pb, pbo, kr, nk, batch, A, c->d_primes, c->d_tw,
-                                                       c->stream);
+    hipError_t e = tsrc ? hx::launch_moddown_apply_plain_tensor_pow2(c->logn, *tsrc, pbo, kr, nk, batch, A, c->d_primes,
+                                                                     c->d_tw, c->stream)
+                        : hx::launch_moddown_apply_plain_pow2(c->logn, pb, pbo, kr, nk, batch, A, c->d_primes, c->d_tw,
+                                                              c->stream);
     if (e != hipSuccess)
       rc = fail(HX_ERR_DEVICE, "mod-down launch failed: %s", hipGetErrorString(e));
   }
@@ -3232,9 +3254,11 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
     return rc;
   }
   for (int i = 0; i < np; i++) {
-    storage_release(ps[i]);  // (a slab shared with a lazy copy stays with its other holders)
-    ps[i]->d = fresh[i];
-    ps[i]->cap_rows = ncap;
+    if (!tsrc) {
+      storage_release(ps[i]);  // (a slab shared with a lazy copy stays with its other holders)
+      ps[i]->d = fresh[i];
+      ps[i]->cap_rows = ncap;
+    }
     ps[i]->prime_idx = keep;
   }
   return HX_OK;
@@ -3296,7 +3320,7 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     ps[0] = a;
     for (int i = 0; i < nother; i++)
       ps[1 + i] = others[i];
-    return scale_down_multi_fused(ps, 1 + nother, drop, keep, ptxt, add_idx, nadd);
+    return scale_down_multi_fused(ps, 1 + nother, drop, keep, ptxt, add_idx, nadd, tsrc);
   }
   if (nadd > 0) {
     bool ok = ndrop == 1 && c->pow2 && c->logn >= 13 && c->logn <= 15 && find_row(a->prime_idx, drop_idx[0]) >= 0 &&
@@ -3349,6 +3373,15 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
   bool small_S = true;  // |S| <= ptxtSpace/2 + 1 is a reduced residue of every kept prime
   for (int pr : keep)
     small_S = small_S && ptxt / 2 + 2 < c->primes[pr].q;
+  if (tsrc && nd >= 2) {   // (nadd == 0 here: the mod-up case went to the batched path above)
+    hx_poly* ps[hx::MD_MAXPOLY];
+    if (1 + nother > hx::MD_MAXPOLY)
+      return HX_ERR_UNSUPPORTED;
+    ps[0] = a;
+    for (int i = 0; i < nother; i++)
+      ps[1 + i] = others[i];
+    return scale_down_multi_fused(ps, 1 + nother, drop, keep, ptxt, nullptr, 0, tsrc);
+  }
   if (tsrc && !(nd == 1 && nk <= MAX_ROWS && small_S))
     return HX_ERR_UNSUPPORTED;   // (checked before anything was changed: nadd > 0 passed its own test above)
   if (nd == 1 && c->pow2 && c->logn >= 13 && c->logn <= 15 && nk <= MAX_ROWS && ptxt < ((uint64_t)1 << 62) && small_S) {
@@ -3747,7 +3780,7 @@ static int tensor_bring_to_set(const hx_poly* c0, const hx_poly* c1, const hx_po
     CHK(poly_reserve(o, c0->nrows() + nadd, /*keep=*/false));
     o->prime_idx = c0->prime_idx;
   }
-  if (c0->nrows() <= MAX_ROWS && ndrop == 1) {
+  if (c0->nrows() <= MAX_ROWS && ndrop >= 1) {
     hx::TensorSrc T{c0->d, c1->d, d0->d, d1->d};
     int rc = scale_down_impl(o0, os + 1, 2, drop_idx, ndrop, ptxt, add_idx, nadd, &T);
     if (rc != HX_ERR_UNSUPPORTED)

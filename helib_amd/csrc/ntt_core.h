@@ -138,24 +138,7 @@ HXD uint64_t shoup4_acc(uint64_t y, TW t, uint64_t nq, uint64_t x)
   const uint32_t wl = (uint32_t)t.w, wh = (uint32_t)(t.w >> 32);
   const uint32_t nl = (uint32_t)nq, nh = (uint32_t)(nq >> 32);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_SHOUP4_OLD)
-#if defined(HX_SHOUP4_CARRY)
-  // experiment: a1 + b1 as a 32-bit sum and its carry -- the (low, high) words of the high product's 64-bit
-  // addend without the two zero-extending moves
-  const uint32_t a1 = mulhi32(yh, pl), b1 = mulhi32(yl, ph);
-  uint32_t s32, c32;
-  asm("v_add_co_u32 %0, vcc, %2, %3\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc"
-      : "=&v"(s32), "=v"(c32)
-      : "v"(a1), "v"(b1)
-      : "vcc");
-  const uint64_t h = (uint64_t)yh * ph + (((uint64_t)c32 << 32) | s32);
-#elif defined(HX_SHOUP4_CARRYC)
-  const uint32_t a1 = mulhi32(yh, pl), b1 = mulhi32(yl, ph);
-  uint32_t s32;
-  const uint32_t c32 = __builtin_add_overflow(a1, b1, &s32) ? 1u : 0u;
-  uint64_t add = ((uint64_t)c32 << 32) | s32;
-  HX_KEEP64(add);
-  const uint64_t h = (uint64_t)yh * ph + add;
-#elif !defined(HX_SHOUP4_MADX1)
+#ifndef HX_SHOUP4_MADX1
   // the two high halves by v_mul_hi_u32 and summed by the compiler: measured 1-2.5 % faster on
   // the row kernels than the all-multiply-add form below (a v_mad_u64_u32 issues in 2.4 ns per
   // wave64 per SIMD, a v_mul_hi_u32 in 1.9 ns: tools/ubench/issue_bench.hip, profiles/r02_issue_rates.txt)

@@ -516,11 +516,35 @@ ntt_moddown_prep_tensor_kernel(TensorSrc T, int row, int prime, int batch, ModDo
   ntt_body<LOGN, true>(lds, io, tw_arena + pd->tw_inv_off, pd);
 }
 
+// the same for up to MD_MAXDROP dropped primes at once (ntt_moddown_prep_multi_kernel with the product parts as input)
+template <int LOGN>
+__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
+ntt_moddown_prep_multi_tensor_kernel(TensorSrc T, PrepMulti M, int batch, ModDownPrep P,
+                                     const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const unsigned per = 3u * (unsigned)batch;
+  const unsigned j = blockIdx.x / per, rem = blockIdx.x % per;
+  const int b = (int)(rem % (unsigned)batch), pi = (int)(rem / (unsigned)batch);   // pi = product part
+  const PrimeDev* pd = primes + uniform_u16(M.prime, j);
+  const int row = (int)uniform_u16(M.row, j);
+  const size_t N = Geo<LOGN>::N;
+  ModDownPrep Pj = P;
+  Pj.xs = P.xs + (size_t)j * (size_t)batch * N;
+  Pj.upS = M.up[2 * j];
+  Pj.upN = M.up[2 * j + 1];
+  const InvPrepTensorIO io(T, (unsigned)pi, ((size_t)row * batch + b) * N, Pj,
+                           (size_t)pi * (size_t)P.poly_stride + (size_t)b * N, (unsigned)N * 8u, pd);
+  ntt_body<LOGN, true>(lds, io, tw_arena + pd->tw_inv_off, pd);
+}
+
 // forward transform of a kept row whose c_r is a product part formed from the operands' rows in the store
+// PLAIN (several dropped primes): the transform's input is the ready delta * P^-1 row of the basis extension
+template <bool PLAIN>
 struct ModDownTensorIO {
-  static constexpr int LOAD_BOUND = 6;
+  static constexpr int LOAD_BOUND = PLAIN ? 1 : 6;
   static constexpr bool LAZY_STORE = true;
-  static constexpr bool PIPELINED = true;
+  static constexpr bool PIPELINED = !PLAIN;
   static constexpr int IOG = 4;
   struct StorePrefetch {};
   v4i32 rx, rS, ra, rb, rc, rd, ro;
@@ -629,7 +653,7 @@ struct ModDownTensorIO {
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
 };
-template <int LOGN>
+template <int LOGN, bool PLAIN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
 ntt_moddown_apply_tensor_kernel(TensorSrc T, PolyBases outs, NttRows rows, int nkeep, int batch, ModDownApply A,
                                 const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
@@ -652,8 +676,11 @@ ntt_moddown_apply_tensor_kernel(TensorSrc T, PolyBases outs, NttRows rows, int n
   const ModDownRow R = A.rows[ri];
   uint64_t* odata = poly_base(outs, pi);
   const size_t eoff = ((size_t)pi * batch + b) * N;
-  const ModDownTensorIO io(A.xs + eoff, A.S + eoff, R, T, pi, ((size_t)uniform_u16(rows.row, ri) * batch + b) * N,
-                           R.mode != 2, odata + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd);
+  const uint64_t* xrow = PLAIN ? A.delta + (size_t)pi * (size_t)A.delta_poly_stride + ((size_t)ri * batch + b) * N
+                               : A.xs + eoff;
+  const ModDownTensorIO<PLAIN> io(xrow, PLAIN ? nullptr : A.S + eoff, R, T, pi,
+                                  ((size_t)uniform_u16(rows.row, ri) * batch + b) * N, R.mode != 2,
+                                  odata + ((size_t)R.out_row * batch + b) * N, (unsigned)N * 8u, pd);
   ntt_body<LOGN, false>(lds, io, tw_arena + pd->tw_fwd_off, pd);
 }
 
@@ -848,9 +875,7 @@ hipError_t launch_moddown_pow2(int logn, const PolyBases& data, const PolyBases&
 // tensorProduct + single-prime mod-switch of the three product parts (TensorSrc): prep from the operands' dropped
 // rows, S, apply forming c_r from the operands' kept rows
 template <int LOGN>
-static hipError_t launch_moddown_tensor(const TensorSrc& T, const PolyBases& outs, int drop_row, int drop_prime,
-                                        const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
-                                        const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+static hipError_t moddown_tensor_attrs()
 {
   constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
   static bool attr_set = false;
@@ -858,19 +883,36 @@ static hipError_t launch_moddown_tensor(const TensorSrc& T, const PolyBases& out
     hipError_t e = hipFuncSetAttribute((const void*)ntt_moddown_prep_tensor_kernel<LOGN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_tensor_kernel<LOGN>,
+      e = hipFuncSetAttribute((const void*)ntt_moddown_prep_multi_tensor_kernel<LOGN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_tensor_kernel<LOGN, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_tensor_kernel<LOGN, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
       return e;
     attr_set = true;
   }
+  return hipSuccess;
+}
+template <int LOGN>
+static hipError_t launch_moddown_tensor(const TensorSrc& T, const PolyBases& outs, int drop_row, int drop_prime,
+                                        const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
+                                        const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+  hipError_t ea = moddown_tensor_attrs<LOGN>();
+  if (ea != hipSuccess)
+    return ea;
   HX_LAUNCH((ntt_moddown_prep_tensor_kernel<LOGN>), dim3(3u * (unsigned)batch), dim3(Geo<LOGN>::T), lds_bytes, st, T,
             drop_row, drop_prime, batch, P, primes, tw_arena);
   {
     const size_t n = (size_t)3 * (size_t)batch * Geo<LOGN>::N;
     HX_LAUNCH(moddown_S_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), dim3(256), 0, st, P, n);
   }
-  HX_LAUNCH((ntt_moddown_apply_tensor_kernel<LOGN>), dim3(moddown_apply_grid(3u, (unsigned)nkeep, (unsigned)batch)),
+  HX_LAUNCH((ntt_moddown_apply_tensor_kernel<LOGN, false>), dim3(moddown_apply_grid(3u, (unsigned)nkeep, (unsigned)batch)),
             dim3(Geo<LOGN>::T), lds_bytes, st, T, outs, keep, nkeep, batch, A, primes, tw_arena);
   return hipGetLastError();
 }
@@ -882,6 +924,56 @@ hipError_t launch_moddown_tensor_pow2(int logn, const TensorSrc& T, const PolyBa
     case 13: return launch_moddown_tensor<13>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
     case 14: return launch_moddown_tensor<14>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
     case 15: return launch_moddown_tensor<15>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// tensorProduct + several-primes mod-switch: the two launches below (prep_multi / apply_plain) with the product parts
+// formed from the operands' rows (three parts, outs = their slabs)
+template <int LOGN>
+static hipError_t launch_prep_multi_tensor(const TensorSrc& T, const PrepMulti& M, int ndrop, int batch, const ModDownPrep& P,
+                                           const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+  hipError_t e = moddown_tensor_attrs<LOGN>();
+  if (e != hipSuccess)
+    return e;
+  HX_LAUNCH((ntt_moddown_prep_multi_tensor_kernel<LOGN>), dim3((unsigned)ndrop * 3u * (unsigned)batch), dim3(Geo<LOGN>::T),
+            lds_bytes, st, T, M, batch, P, primes, tw_arena);
+  return hipGetLastError();
+}
+template <int LOGN>
+static hipError_t launch_apply_plain_tensor(const TensorSrc& T, const PolyBases& outs, const NttRows& keep, int nkeep,
+                                            int batch, const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena,
+                                            hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+  hipError_t e = moddown_tensor_attrs<LOGN>();
+  if (e != hipSuccess)
+    return e;
+  HX_LAUNCH((ntt_moddown_apply_tensor_kernel<LOGN, true>), dim3(moddown_apply_grid(3u, (unsigned)nkeep, (unsigned)batch)),
+            dim3(Geo<LOGN>::T), lds_bytes, st, T, outs, keep, nkeep, batch, A, primes, tw_arena);
+  return hipGetLastError();
+}
+hipError_t launch_moddown_prep_multi_tensor_pow2(int logn, const TensorSrc& T, const PrepMulti& M, int ndrop, int batch,
+                                                 const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena,
+                                                 hipStream_t st)
+{
+  switch (logn) {
+    case 13: return launch_prep_multi_tensor<13>(T, M, ndrop, batch, P, primes, tw_arena, st);
+    case 14: return launch_prep_multi_tensor<14>(T, M, ndrop, batch, P, primes, tw_arena, st);
+    case 15: return launch_prep_multi_tensor<15>(T, M, ndrop, batch, P, primes, tw_arena, st);
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_moddown_apply_plain_tensor_pow2(int logn, const TensorSrc& T, const PolyBases& outs, const NttRows& keep,
+                                                  int nkeep, int batch, const ModDownApply& A, const PrimeDev* primes,
+                                                  const TW* tw_arena, hipStream_t st)
+{
+  switch (logn) {
+    case 13: return launch_apply_plain_tensor<13>(T, outs, keep, nkeep, batch, A, primes, tw_arena, st);
+    case 14: return launch_apply_plain_tensor<14>(T, outs, keep, nkeep, batch, A, primes, tw_arena, st);
+    case 15: return launch_apply_plain_tensor<15>(T, outs, keep, nkeep, batch, A, primes, tw_arena, st);
   }
   return hipErrorInvalidValue;
 }

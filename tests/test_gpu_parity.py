@@ -692,18 +692,21 @@ def test_bring_to_set_multi_matches_separate_steps(hx, ndrop):
 
 
 @pytest.mark.parametrize("m,ptxt", [(16384, 65537), (32768, 65537), (16384, 2), (65536, 1)])
-@pytest.mark.parametrize("shape", ["add1_drop1", "drop1", "drop_last", "add1_drop2"])
+@pytest.mark.parametrize("shape", ["add1_drop1", "drop1", "drop_last", "add1_drop2", "drop2", "drop3"])
 def test_tensor_folded_into_the_mod_switch(hx, m, ptxt, shape):
     """hx_tensor_bring_to_set (Ctxt::tensorProduct followed by Ctxt::bringToSet of the product, what Ctxt::multiplyBy
     does between multLowLvl and the key switch): the product parts formed inside the single-prime mod-down kernels
     from the operands' rows must equal hx_tensor + hx_bring_to_set_multi word for word -- and those equal the
     oracle's tensor product, addPrimesAndScale and scaleDownToSet.  Shapes: mod-up by one prime + one dropped prime
-    (the fresh multiply's), a pure single-prime mod-down (dropped row in the middle and last), and two dropped
-    primes (the two-step fallback).  A batch of 3, operands that are lazy copies of each other, measured norms."""
+    (the fresh multiply's), a pure single-prime mod-down (dropped row in the middle and last), and two / three dropped
+    primes with and without a mod-up (the several-primes kernels with the product parts formed on load and in the
+    store: every multiply after the first).  A batch of 3, operands that are lazy copies of each other, measured
+    norms."""
     P, own, sp = setup_rns(hx, m=m, L=5, K=2)
     B = 3
     add = [sp[0]] if shape.startswith("add1") else []
-    drop = {"add1_drop1": [own[2]], "drop1": [own[1]], "drop_last": [own[-1]], "add1_drop2": [own[1], own[3]]}[shape]
+    drop = {"add1_drop1": [own[2]], "drop1": [own[1]], "drop_last": [own[-1]], "add1_drop2": [own[1], own[3]],
+            "drop2": [own[0], own[4]], "drop3": [own[1], own[2], own[4]]}[shape]
     keep = [i for i in own + add if i not in drop]
     ops = [P.rand(own, 700 + i, batch=B) for i in range(3)]
     c0 = hx.DoubleCRT(P.g, own, B, ops[0])

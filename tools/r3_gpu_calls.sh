@@ -15,6 +15,7 @@
 #   ab:A,B,...       same-box A/B of the fresh multiply, two rounds; A = default | env:VAR=1 | a variant
 #                    directory under helib_amd/lib/variants (tools/build_variant.sh); WORKLOAD=ckks65536 for config 4
 #   ubench           tools/ubench/bfly_* binaries
+#   clocks           rocm-smi engine clock / power samples while the fresh multiply runs -> clocks.txt
 export TMPDIR=/tmp
 name=$1; shift
 out=gpurun_out/$name
@@ -90,6 +91,12 @@ for st in "$@"; do
           line $f "$v#$round"
         done
       done ;;
+    clocks)
+      (for i in $(seq 1 40); do rocm-smi -d 0 --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|Power" | tr '\n' ' '; echo; sleep 0.5; done) > $out/clocks.txt &
+      smi=$!
+      timeout 300 python bench.py --steps 12 --warmup 3 $QUICK > $out/bench_clocks.json 2> $out/bench_clocks.err
+      wait $smi
+      line $out/bench_clocks.json clocks; sed -n '1p;10p;20p;30p;40p' $out/clocks.txt ;;
     ubench)
       for b in tools/ubench/bfly_*; do [ -x $b ] && { echo "== $b"; timeout 60 $b; }; done > $out/ubench.txt 2>&1; cat $out/ubench.txt ;;
     *) echo "unknown stage $st" ;;
