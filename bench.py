@@ -493,6 +493,130 @@ def bgv_basic_ops(hx, hc, cc, fa, fb, sk, msgs, sync, reps=8):
     return out
 
 
+def ckks_basic_ops(hx, hc, device, stream, sync, bits, B=16, reps=6, m=65536, backend=None):
+    """The reference's CKKS benchmark list (benchmarks/ckks_basic.cpp:38-236: add / subtract / negate / square /
+    rotate by one / multiply without and with relinearisation / encrypt / decrypt / multiply-and-add) at the
+    BASELINE configs[3] shape, ContextBuilder<CKKS>().m(65536).precision(20).bits(1400): a key pair, B pairs of
+    CKKSencrypt-ed ciphertexts packed along the batch axis (python mirror of the host, helib_amd/ctxt.py + keys.py:
+    this leg is about the device operations, the timed multiply of the headline runs in the C++ host), the operand
+    copy made before the timer as the reference pauses its timer for it.  Every result is decrypted and decoded
+    for one batch element and compared with the plaintext operation within the error bound the ciphertext reports."""
+    import math
+    from helib_amd import hostnt, keys as hk
+    cc = hc.ChainContext(m, -1, 20, bits=bits, c=3, ckks=True)
+    if backend is None:
+        ctx = hx.Context(cc.m, device)
+        for q in cc.primes:
+            ctx.add_prime(q)
+        ctx.set_stream(stream)
+        be = hk.HxBackend(ctx, cc)
+
+        def make(idx, rows_):
+            return hx.DoubleCRT(ctx, idx, rows_.shape[1], rows_)
+    else:
+        be, make = backend(cc)        # (tests: the same list over the CPU checker at a small m)
+    sk = hk.SecKey(cc, be, 23)
+    sk.GenSecKey(maxDegKswitch=2)
+    g = hostnt.ZmStar(cc.m, cc.p).gens[0]
+    sk.GenKeySWmatrix(1, g)
+    n, L = cc.phim, len(cc.ctxtPrimes)
+    f = float(1 << 20)
+    rng = np.random.default_rng(29)
+    vals = rng.uniform(-1, 1, size=(2, B, n)) / n
+    enc = np.rint(vals * f) / f                                   # what is actually encrypted
+    rows = np.empty((2, 2, L, B, n), dtype=np.uint64)
+    first = None
+    for j in range(2):
+        for b in range(B):
+            ct = sk.CKKSencrypt(np.rint(vals[j, b] * f).astype(np.int64), 1.0, f)
+            first = first or ct
+            rows[j, 0, :, b] = np.asarray(ct.parts["1"].download()).reshape(L, -1, n)[:, 0]
+            rows[j, 1, :, b] = np.asarray(ct.parts["s"].download()).reshape(L, -1, n)[:, 0]
+    ops_in = []
+    for j in range(2):
+        c = first.clone()
+        c.parts = {"1": make(list(cc.ctxtPrimes), rows[j, 0]), "s": make(list(cc.ctxtPrimes), rows[j, 1])}
+        ops_in.append(c)
+    fa, fb = ops_in
+    fa.ksw_auto[g] = sk.keySwitching[(1, g)].W
+
+    def decode(ct, b=0):
+        one = ct.clone()
+        one.parts = {h: make(q.getIndexSet(), np.asarray(q.download()).reshape(len(q.getIndexSet()), -1, n)[:, b:b + 1])
+                     for h, q in ct.parts.items()}
+        return np.array([float(v) for v in sk.Decrypt(one)]) / math.exp(ct.lnRatFactor)
+
+    def nega(x, y):
+        full = np.convolve(x, y)
+        return full[:n] - np.append(full[n:], 0.0)
+
+    def rot(x):                                                   # f(X) -> f(X^g) mod X^n + 1
+        out = np.zeros(n)
+        e = (np.arange(n) * g) % (2 * n)
+        np.add.at(out, e % n, np.where(e < n, x, -x))
+        return out
+
+    def mul_add(c):
+        c.multiplyBy(fb)
+        c += fb          # (the reference adds into ctxt1; the same device work: operator+= equalises level and scale first)
+    a0, b0 = enc[0, 0], enc[1, 0]
+    ops = {
+        "adding_two_ciphertexts": (lambda c: c.__iadd__(fb), lambda: a0 + b0),
+        "subtracting_two_ciphertexts": (lambda c: c.__isub__(fb), lambda: a0 - b0),
+        "negating_a_ciphertext": (lambda c: c.negate(), lambda: -a0),
+        "square_a_ciphertext": (lambda c: c.square(), lambda: nega(a0, a0)),
+        "rotate_a_ciphertext_by1": (lambda c: c.smartAutomorph(g), lambda: rot(a0)),
+        "multiplying_two_ciphertexts_no_relin": (lambda c: c.multLowLvl(fb), lambda: nega(a0, b0)),
+        "multiplying_two_ciphertexts": (lambda c: c.multiplyBy(fb), lambda: nega(a0, b0)),
+        "multiply_and_add_two_ciphertexts": (mul_add, lambda: nega(a0, b0) + b0),
+    }
+    out = {}
+    for name, (fn, want) in ops.items():
+        try:
+            copies = [fa.clone() for _ in range(reps + 1)]
+            fn(copies[0])                                         # warm (plans, slabs)
+            _ = copies[0].lnNoise
+            sync()
+            t0 = time.perf_counter()
+            for c in copies[1:]:
+                fn(c)
+            _ = copies[-1].lnNoise
+            sync()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            res, w = copies[-1], want()
+            err = float(np.max(np.abs(decode(res) - w)))
+            tol = math.exp(res.lnNoise - res.lnRatFactor)
+        except SystemExit:
+            raise
+        except Exception as e:
+            out[name] = f"unavailable: {type(e).__name__}: {str(e)[:120]}"
+            continue
+        if not (err <= tol and err <= 1e-3 * max(float(np.max(np.abs(w))), 1e-30)):
+            raise SystemExit(f"bench: decode(decrypt({name})) is off by {err:g} (reported bound {tol:g})")
+        out[name] = {"ms_per_call_batch": round(ms, 4), "batch": B, "per_s": round(B / (ms * 1e-3), 1),
+                     "decode_max_abs_err": float(f"{err:.3g}"), "reported_error_bound": float(f"{tol:.3g}")}
+        del copies, res
+    msg = np.rint(vals[0, 0] * f).astype(np.int64)
+    sk.CKKSencrypt(msg, 1.0, f)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ct = sk.CKKSencrypt(msg, 1.0, f)
+    sync()
+    out["encrypting_ciphertexts"] = {"ms_per_call": round((time.perf_counter() - t0) / reps * 1e3, 4), "batch": 1}
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dec = sk.Decrypt(ct)
+    out["decrypting_ciphertexts"] = {"ms_per_call": round((time.perf_counter() - t0) / reps * 1e3, 4), "batch": 1}
+    got = np.array([float(v) for v in dec]) / math.exp(ct.lnRatFactor)
+    if float(np.max(np.abs(got - enc[0, 0]))) > math.exp(ct.lnNoise - ct.lnRatFactor):
+        raise SystemExit("bench: decode(decrypt(CKKSencrypt(v))) is off")
+    out["note"] = (f"benchmarks/ckks_basic.cpp:38-236 at m={m} precision=20 bits={bits} (L={L}, K={len(cc.specialPrimes)}); "
+                   "operand copy before the timer as there; batched lines run the whole batch per call, encrypt / decrypt one "
+                   "ciphertext; python mirror of the host")
+    return out
+
+
 def run_session(sess, level, steps, warmup, R, sync, barrier, measure):
     """The timed region, driven by the C++ host: `steps` x hxh_multiply(level, R) -- R x [copy(a);
     copy.multiplyBy(b)] enqueued back to back by helib_amd/csrc/host_session.cpp (level 1: the two fresh
@@ -986,6 +1110,13 @@ def main():
                     del so
                 except Exception as e:
                     extra["levels_" + other] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
+                if ckks:
+                    try:
+                        extra["ckks_basic_ops"] = ckks_basic_ops(hx, hc, local_rank, stream, sync, args.bits)
+                    except SystemExit:
+                        raise
+                    except Exception as e:
+                        extra["ckks_basic_ops"] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
                 if not ckks:
                     # the python mirror of the same host logic (helib_amd/ctxt.py + keys.py): secondary figure, the
                     # reference's other benchmark lines, and the HIP-graph replay of one multiply

@@ -264,3 +264,27 @@ def test_register_tiled_norm_kernel_replayed_on_cpu(tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "norm_replay.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "norm_replay OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_ckks_basic_op_list_over_the_cpu_checker():
+    """bench.py's ckks_basic_ops leg (the reference's benchmarks/ckks_basic.cpp list: add / subtract / negate /
+    square / rotate / multiply without and with relinearisation / multiply-and-add / encrypt / decrypt) run at
+    m = 1024 with the CPU checker standing in for the device polynomials: every operation decodes to the plaintext
+    operation within the error bound its ciphertext reports (the leg aborts the benchmark otherwise)."""
+    import bench
+    from helib_amd import ctxt as hc
+    from oracle.backend import OracleBackend, OPoly
+
+    def backend(cc):
+        o = O.Ctx(cc.m)
+        for q in cc.primes:
+            o.add_prime(q)
+        return OracleBackend(o, cc), (lambda idx, rows: OPoly(o, idx, rows[:, 0]))
+    out = bench.ckks_basic_ops(None, hc, 0, 0, lambda: None, 300, B=1, reps=1, m=1024, backend=backend)
+    names = ["adding_two_ciphertexts", "subtracting_two_ciphertexts", "negating_a_ciphertext", "square_a_ciphertext",
+             "rotate_a_ciphertext_by1", "multiplying_two_ciphertexts_no_relin", "multiplying_two_ciphertexts",
+             "multiply_and_add_two_ciphertexts", "encrypting_ciphertexts", "decrypting_ciphertexts"]
+    for nme in names:
+        assert isinstance(out[nme], dict), (nme, out[nme])
+    for nme in names[:8]:
+        assert out[nme]["decode_max_abs_err"] <= out[nme]["reported_error_bound"]
