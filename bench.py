@@ -509,6 +509,7 @@ def ckks_basic_ops(hx, hc, device, stream, sync, bits, B=16, reps=6, m=65536, ba
         for q in cc.primes:
             ctx.add_prime(q)
         ctx.set_stream(stream)
+        ctx.reserve(12 << 30)         # the copies and results of the timed loops: no hipMalloc inside them
         be = hk.HxBackend(ctx, cc)
 
         def make(idx, rows_):

@@ -669,8 +669,15 @@ ntt_moddown_apply_tensor_kernel(TensorSrc T, PolyBases outs, NttRows rows, int n
   if (slot >= nr * nloc)
     return;
   const unsigned ri = r0 + slot % nr, pb = pb0 + slot / nr;
+#ifdef HX_TENSOR_PARTS_APART
   const int b = (int)(pb % (unsigned)batch);
   const unsigned pi = pb / (unsigned)batch;   // product part 0, 1, 2
+#else
+  // the three product parts of one batch element are neighbours in the XCD's dispatch order: an operand row is read
+  // by two of them (a0: parts 0, 1; a1: 1, 2; ...), 3 * nr slots apart at most, i.e. while it is still in that XCD's L2
+  const int b = (int)(pb / 3u);
+  const unsigned pi = pb % 3u;                // product part 0, 1, 2
+#endif
   const PrimeDev* pd = primes + uniform_u16(rows.prime, ri);
   const size_t N = Geo<LOGN>::N;
   const ModDownRow R = A.rows[ri];
