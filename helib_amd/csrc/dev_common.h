@@ -91,6 +91,33 @@ struct ModDownApply {
 // multLowLvl's tensorProduct, then reLinearize's dropSmallAndSpecialPrimes, src/Ctxt.cpp:1563-1608, 720-760):
 // the three product parts are never materialised on the old prime set -- the mod-down kernels form
 // part(1) = a0 b0, part(s) = a0 b1 + a1 b0, part(s^2) = a1 b1 from the operand rows where they consume them.
+// Streaming rows (read once / written once) are moved with the non-temporal hint so that the data an XCD's L2
+// actually re-uses (key-switching matrix rows shared by the batch, twiddle tables, x / S of the mod-down) stays in it;
+// -DHX_NO_NT restores the default policy (A/B).
+#if defined(__HIPCC__)
+typedef unsigned long long hx_v2u64 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ulonglong2 ld_stream2(const uint64_t* p)
+{
+#ifdef HX_NO_NT
+  return *reinterpret_cast<const ulonglong2*>(p);
+#else
+  const hx_v2u64 v = __builtin_nontemporal_load(reinterpret_cast<const hx_v2u64*>(p));
+  return make_ulonglong2(v.x, v.y);
+#endif
+}
+__device__ __forceinline__ void st_stream2(uint64_t* p, ulonglong2 v)
+{
+#ifdef HX_NO_NT
+  *reinterpret_cast<ulonglong2*>(p) = v;
+#else
+  hx_v2u64 w;
+  w.x = v.x;
+  w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<hx_v2u64*>(p));
+#endif
+}
+#endif
+
 struct TensorSrc {
   const uint64_t* a0;
   const uint64_t* a1;

@@ -25,6 +25,17 @@ __device__ v2i32 hx_buffer_load_v2(v4i32 rsrc, int voffset, int soffset,
 __device__ void hx_buffer_store_v2(v2i32 data, v4i32 rsrc, int voffset, int soffset,
                                    int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
 
+// Cache policy of rows that are read once or written once (the polynomial rows themselves): non-temporal, so that
+// what IS shared inside an XCD's L2 -- twiddle tables, the x / S words every kept row of an element re-reads, the
+// operand rows the three product parts share -- is not pushed out by them.  (aux bit 1 = nt on gfx940+.)
+#ifdef HX_NO_NT
+#define HX_NT 0
+#define HX_NT_ASM ""
+#else
+#define HX_NT 2
+#define HX_NT_ASM " nt"
+#endif
+
 __device__ v4i32 hx_buffer_load_v4(v4i32 rsrc, int voffset, int soffset,
                                    int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 
@@ -71,7 +82,7 @@ struct BufIO {
   }
   __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
   {
-    v2i32 r = hx_buffer_load_v2(rin, (int)(tid * 8u), (int)(c * 8u), 0);
+    v2i32 r = hx_buffer_load_v2(rin, (int)(tid * 8u), (int)(c * 8u), HX_NT);
     return ((uint64_t)(uint32_t)r.y << 32) | (uint32_t)r.x;
   }
   __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t v) const
@@ -79,7 +90,7 @@ struct BufIO {
     v2i32 d;
     d.x = (int)(uint32_t)v;
     d.y = (int)(uint32_t)(v >> 32);
-    hx_buffer_store_v2(d, rout, (int)(tid * 8u), (int)(c * 8u), 0);
+    hx_buffer_store_v2(d, rout, (int)(tid * 8u), (int)(c * 8u), HX_NT);
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
 };
@@ -103,7 +114,7 @@ struct InvPrepIO {
   }
   __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
   {
-    v2i32 r = hx_buffer_load_v2(rin, (int)(tid * 8u), (int)(c * 8u), 0);
+    v2i32 r = hx_buffer_load_v2(rin, (int)(tid * 8u), (int)(c * 8u), HX_NT);
     return ((uint64_t)(uint32_t)r.y << 32) | (uint32_t)r.x;
   }
   __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t x) const
@@ -178,7 +189,11 @@ struct ModDownIO {
         rc(make_rsrc(c_row, bytes)), ro(make_rsrc(o_row, bytes)), inv(R.inv), cf(R.cf), q(q_)
   {
   }
-  __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const { return ld(rx, tid, c); }  // (PLAIN)
+  __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const   // (PLAIN: the delta row, read once)
+  {
+    v2i32 a = hx_buffer_load_v2(rx, (int)(tid * 8u), (int)(c * 8u), HX_NT);
+    return ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
+  }
   static __device__ __forceinline__ uint64_t ld(const v4i32& r, unsigned tid, unsigned c)
   {
     v2i32 a = hx_buffer_load_v2(r, (int)(tid * 8u), (int)(c * 8u), 0);
@@ -222,7 +237,7 @@ struct ModDownIO {
   static __device__ __forceinline__ uint64_t ld_pinned(const v4i32& r, unsigned tid, unsigned c)
   {
     uint64_t x;
-    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen"
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" HX_NT_ASM
                  : "=v"(x)
                  : "v"((int)(tid * 8u)), "s"(r), "s"((int)(c * 8u))
                  : "memory");
@@ -277,7 +292,7 @@ struct ModDownIO {
     v2i32 d;
     d.x = (int)(uint32_t)o;
     d.y = (int)(uint32_t)(o >> 32);
-    hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), 0);
+    hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), HX_NT);
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
 };
@@ -567,7 +582,11 @@ struct ModDownTensorIO {
     v2i32 a = hx_buffer_load_v2(r, (int)(tid * 8u), (int)(c * 8u), 0);
     return ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
   }
-  __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const { return ld(rx, tid, c); }
+  __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const   // (PLAIN: the delta row, read once)
+  {
+    v2i32 a = hx_buffer_load_v2(rx, (int)(tid * 8u), (int)(c * 8u), HX_NT);
+    return ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
+  }
   // the load of ModDownIO<false>: x*inv - S with S one group ahead
   template <int LOGN>
   __device__ __forceinline__ void load_all(unsigned tid, uint64_t (&v)[32], const QC& qc) const
@@ -649,7 +668,7 @@ struct ModDownTensorIO {
     v2i32 d;
     d.x = (int)(uint32_t)o;
     d.y = (int)(uint32_t)(o >> 32);
-    hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), 0);
+    hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), HX_NT);
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
 };
@@ -730,8 +749,8 @@ struct MulLoadIO {
   }
   __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
   {
-    const v2i32 x = hx_buffer_load_v2(ra, (int)(tid * 8u), (int)(c * 8u), 0);
-    const v2i32 y = hx_buffer_load_v2(rb, (int)(tid * 8u), (int)(c * 8u), 0);
+    const v2i32 x = hx_buffer_load_v2(ra, (int)(tid * 8u), (int)(c * 8u), HX_NT);
+    const v2i32 y = hx_buffer_load_v2(rb, (int)(tid * 8u), (int)(c * 8u), HX_NT);
     const uint64_t a = ((uint64_t)(uint32_t)x.y << 32) | (uint32_t)x.x, b = ((uint64_t)(uint32_t)y.y << 32) | (uint32_t)y.x;
     return tensor_red128((u128)a * b, q, mu63, k);
   }
@@ -740,7 +759,7 @@ struct MulLoadIO {
     v2i32 d;
     d.x = (int)(uint32_t)v;
     d.y = (int)(uint32_t)(v >> 32);
-    hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), 0);
+    hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), HX_NT);
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
 };

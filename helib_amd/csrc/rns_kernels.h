@@ -274,10 +274,10 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
     ulonglong2 own = make_ulonglong2(0, 0);
     if (row < accumulate_rows && ts.a0) {
       const size_t o = (size_t)row * row_words + e;
-      const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(ts.a0 + o);
-      const ulonglong2 a1 = *reinterpret_cast<const ulonglong2*>(ts.a1 + o);
-      const ulonglong2 b0 = *reinterpret_cast<const ulonglong2*>(ts.b0 + o);
-      const ulonglong2 b1 = *reinterpret_cast<const ulonglong2*>(ts.b1 + o);
+      const ulonglong2 a0 = ld_stream2(ts.a0 + o);
+      const ulonglong2 a1 = ld_stream2(ts.a1 + o);
+      const ulonglong2 b0 = ld_stream2(ts.b0 + o);
+      const ulonglong2 b1 = ld_stream2(ts.b1 + o);
       const TW ps = fix[row].pscale;
       const uint64_t m63 = pd.mu63;
       acc0.x = mul_shoup(red128_q8((u128)a0.x * b0.x, q, m63, k), ps.w, ps.wp, q);
@@ -290,26 +290,26 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
       // parts (1),(s) enter scaled by the special primes (Ctxt::keySwitchPart's
       // addPrimesAndScale, src/Ctxt.cpp:816-820), read straight from the unscaled parts
       const TW ps = fix[row].pscale;
-      acc0 = *reinterpret_cast<const ulonglong2*>(t0s + (size_t)row * row_words + e);
+      acc0 = ld_stream2(t0s + (size_t)row * row_words + e);
       acc0.x = mul_shoup(acc0.x, ps.w, ps.wp, q);
       acc0.y = mul_shoup(acc0.y, ps.w, ps.wp, q);
       if (t1s) {  // no part pointing at s (a 2-part ciphertext after an automorphism): zero
-        acc1 = *reinterpret_cast<const ulonglong2*>(t1s + (size_t)row * row_words + e);
+        acc1 = ld_stream2(t1s + (size_t)row * row_words + e);
         acc1.x = mul_shoup(acc1.x, ps.w, ps.wp, q);
         acc1.y = mul_shoup(acc1.y, ps.w, ps.wp, q);
       } else {
         acc1 = make_ulonglong2(0, 0);
       }
     } else if (row < accumulate_rows) {
-      acc0 = *reinterpret_cast<const ulonglong2*>(out0 + (size_t)row * row_words + e);
-      acc1 = *reinterpret_cast<const ulonglong2*>(out1 + (size_t)row * row_words + e);
+      acc0 = ld_stream2(out0 + (size_t)row * row_words + e);
+      acc1 = ld_stream2(out1 + (size_t)row * row_words + e);
     } else {
       acc0 = make_ulonglong2(0, 0);
       acc1 = make_ulonglong2(0, 0);
     }
     const int owner = fix ? (int)fix[row].owner : -1;
     if (owner >= 0 && !ts.a0)
-      own = *reinterpret_cast<const ulonglong2*>(own_src + (size_t)row * row_words + e);
+      own = ld_stream2(own_src + (size_t)row * row_words + e);
     // lazy inner product: 128-bit sums of the D products, ONE Barrett reduction per output word
     // (q < 2^60 and D <= 8 => the sums stay below 2^123)
     u128 s0x = 0, s0y = 0, s1x = 0, s1y = 0;
@@ -319,7 +319,7 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
       if (d == owner) {
         x = own;
       } else {
-        x = *reinterpret_cast<const ulonglong2*>(dig + dr * row_words + e);
+        x = ld_stream2(dig + dr * row_words + e);
         if (d < owner) {
           const TW pi = fix[row].pinv[d];
           own.x = mul_shoup(sub_mod(own.x, x.x, q), pi.w, pi.wp, q);
@@ -350,8 +350,8 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
       acc1.x = add_mod(acc1.x, red128_q8(s1x, q, pd.mu63, k), q);
       acc1.y = add_mod(acc1.y, red128_q8(s1y, q, pd.mu63, k), q);
     }
-    *reinterpret_cast<ulonglong2*>(out0 + (size_t)row * row_words + e) = acc0;
-    *reinterpret_cast<ulonglong2*>(out1 + (size_t)row * row_words + e) = acc1;
+    st_stream2(out0 + (size_t)row * row_words + e, acc0);
+    st_stream2(out1 + (size_t)row * row_words + e, acc1);
   }
 }
 
