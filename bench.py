@@ -574,16 +574,45 @@ def ckks_basic_ops(hx, hc, device, stream, sync, bits, B=16, reps=6, m=65536, ba
     out = {}
     for name, (fn, want) in ops.items():
         try:
+            # warm-up: three calls, enqueued as deep as the timed loop will be -- plans and slabs, and the HIP runtime's
+            # own command / signal pools, whose growth is a one-time event of tens of milliseconds in this process
+            # (it maps tens of GB already) and would otherwise land in one of the few timed calls
+            for wc in [fa.clone() for _ in range(3)]:
+                fn(wc)
+            _ = wc.lnNoise
+            del wc
             copies = [fa.clone() for _ in range(reps + 1)]
-            fn(copies[0])                                         # warm (plans, slabs)
-            _ = copies[0].lnNoise
             sync()
+            prof = None
+            if os.environ.get("HX_BENCH_PYPROFILE") == name:      # debugging aid: where the host time of one line goes
+                import cProfile
+                prof = cProfile.Profile()
+                prof.enable()
+            gprof = backend is None and os.environ.get("HX_BENCH_GPUPROFILE") == name
+            if gprof:
+                hx.profileBegin()
             t0 = time.perf_counter()
+            each = []
             for c in copies[1:]:
+                e0 = time.perf_counter()
                 fn(c)
+                each.append(round((time.perf_counter() - e0) * 1e3, 3))
+            e0 = time.perf_counter()
             _ = copies[-1].lnNoise
+            each.append(round((time.perf_counter() - e0) * 1e3, 3))
+            th = time.perf_counter()
+            if gprof:
+                sync()
+                for kk in hx.profileEnd()["kernels"][:12]:
+                    print("  [gpu profile]", name, kk["kernel"][:50], kk["workgroups"], kk["calls"], round(kk["avg_us"], 1),
+                          round(kk["max_us"], 1), file=sys.stderr)
+            if prof:
+                import pstats
+                prof.disable()
+                pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(25)
             sync()
             ms = (time.perf_counter() - t0) / reps * 1e3
+            host_ms = (th - t0) / reps * 1e3
             res, w = copies[-1], want()
             err = float(np.max(np.abs(decode(res) - w)))
             tol = math.exp(res.lnNoise - res.lnRatFactor)
@@ -594,7 +623,9 @@ def ckks_basic_ops(hx, hc, device, stream, sync, bits, B=16, reps=6, m=65536, ba
             continue
         if not (err <= tol and err <= 1e-3 * max(float(np.max(np.abs(w))), 1e-30)):
             raise SystemExit(f"bench: decode(decrypt({name})) is off by {err:g} (reported bound {tol:g})")
-        out[name] = {"ms_per_call_batch": round(ms, 4), "batch": B, "per_s": round(B / (ms * 1e-3), 1),
+        out[name] = {"ms_per_call_batch": round(ms, 4), "host_ms_per_call": round(host_ms, 4), "host_ms_each_call_then_norm_wait": each,
+                     "batch": B,
+                     "per_s": round(B / (ms * 1e-3), 1),
                      "decode_max_abs_err": float(f"{err:.3g}"), "reported_error_bound": float(f"{tol:.3g}")}
         del copies, res
     msg = np.rint(vals[0, 0] * f).astype(np.int64)

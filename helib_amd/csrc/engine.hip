@@ -220,7 +220,10 @@ struct hx_ctx {
     size_t cap;
     int rows;
     double* out;
+    bool slab;   // pinned points into one of norm_slabs (freed with it)
   };
+  // pinned read-back buffers come 64 at a time (one hipHostMalloc per 64 read-backs kept pending, not one each)
+  std::vector<void*> norm_slabs;
   bool defer_norms = false;
   std::vector<NormPending> norm_pending, norm_free;
   // The norm kernels run on a stream of their own, next to whatever the context enqueues after them
@@ -565,8 +568,11 @@ static void ctx_free(hx_ctx* c)
   for (auto* v : {&c->norm_pending, &c->norm_free})
     for (auto& np : *v) {
       hipEventDestroy(np.ev);
-      hipHostFree(np.pinned);
+      if (!np.slab)
+        hipHostFree(np.pinned);
     }
+  for (void* q : c->norm_slabs)
+    hipHostFree(q);
   for (BluePrime* b : c->blue) {
     if (!b)
       continue;
@@ -2862,7 +2868,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   }
   HIPCHK(hipGetLastError());
   // read-back through a pinned slot and an event
-  hx_ctx::NormPending np;
+  hx_ctx::NormPending np{};
   bool have = false;
   for (size_t i = 0; i < c->norm_free.size(); i++)
     if (c->norm_free[i].cap >= (size_t)rows) {
@@ -2871,8 +2877,26 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       have = true;
       break;
     }
+  if (!have && rows <= 1024) {
+    constexpr size_t PER = 64, CAP = 1024;
+    unsigned long long* slab = nullptr;
+    HIPCHK(hipHostMalloc((void**)&slab, PER * CAP * sizeof(unsigned long long), hipHostMallocDefault));
+    c->norm_slabs.push_back(slab);
+    for (size_t i = 0; i < PER; i++) {
+      hx_ctx::NormPending f{};
+      f.pinned = slab + i * CAP;
+      f.cap = CAP;
+      f.slab = true;
+      HIPCHK(hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
+      c->norm_free.push_back(f);
+    }
+    np = c->norm_free.back();
+    c->norm_free.pop_back();
+    have = true;
+  }
   if (!have) {
-    np.cap = std::max<size_t>((size_t)rows, 1024);
+    np.cap = (size_t)rows;
+    np.slab = false;
     HIPCHK(hipHostMalloc((void**)&np.pinned, np.cap * sizeof(unsigned long long), hipHostMallocDefault));
     HIPCHK(hipEventCreateWithFlags(&np.ev, hipEventDisableTiming));
   }

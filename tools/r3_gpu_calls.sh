@@ -92,8 +92,8 @@ for st in "$@"; do
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $R/$out/blue_kt -- python3 $R/tools/prof_bluestein.py > /dev/null 2> $R/$out/blue_kt.err)
       python tools/rocpd_summary.py $out/blue_kt > $out/blue_kernel_trace.txt 2>&1; head -14 $out/blue_kernel_trace.txt ;;
     levels)
-      timeout 300 python tools/prof_levels.py --scheme bgv > $out/levels_bgv.json 2> $out/levels_bgv.err; cut -c1-1500 $out/levels_bgv.json
-      timeout 300 python tools/prof_levels.py --scheme ckks > $out/levels_ckks.json 2> $out/levels_ckks.err; cut -c1-1500 $out/levels_ckks.json ;;
+      timeout 300 python tools/prof_levels.py bgv > $out/levels_bgv.json 2> $out/levels_bgv.err; cut -c1-1500 $out/levels_bgv.json
+      timeout 300 python tools/prof_levels.py ckks > $out/levels_ckks.json 2> $out/levels_ckks.err; cut -c1-1500 $out/levels_ckks.json ;;
     ab:*)
       IFS=, read -ra VS <<< "${st#ab:}"
       for round in 1 2; do
