@@ -1097,7 +1097,7 @@ def main():
                     extra["fixed_level_algorithmic_MB_per_mult"] = round(algorithmic_bytes_fixed(n, l, k, d) / 1e6, 2)
                 b2b = ntt_back_to_back(hx, sub, fixed_primes, list(range(l)), list(range(l, l + k)), shape["digits"], B, rng,
                                        args.ntt_iters)
-                rec = os.path.join(ROOT, "profiles", "r02_pmc_fresh_multiply_traffic.json")
+                rec = os.path.join(ROOT, "profiles", "r03_pmc_fresh_multiply_traffic.json")
                 if os.path.exists(rec):
                     with open(rec) as f:
                         tr = json.load(f)
@@ -1105,8 +1105,8 @@ def main():
                         gb = tr["traffic_GB_per_multiply_of_the_batch"]
                         extra["hbm_traffic_GB_per_step_recorded"] = round(gb * R, 1)
                         extra["hbm_traffic_avg_TBps_over_the_step_recorded"] = round(gb * R / (dt / args.steps) / 1e3, 2)
-                        extra["hbm_traffic_source"] = ("recorded, not measured in this run: profiles/r02_pmc_fresh_multiply_traffic.json "
-                                                       "(rocprofv3 --pmc passes over the same sequence, round-2 kernels)")
+                        extra["hbm_traffic_source"] = ("recorded, not measured in this run: profiles/r03_pmc_fresh_multiply_traffic.json "
+                                                       "(rocprofv3 --pmc passes over the same command, round-3 final kernels)")
             roof = make_roofline(table, n, B, l, k, d, b2b)
             if extras:
                 sync()
