@@ -687,18 +687,8 @@ ntt_moddown_apply_tensor_kernel(TensorSrc T, PolyBases outs, NttRows rows, int n
   const unsigned nloc = pb0 < npb ? min(Tl.chunk, npb - pb0) : 0u;
   if (slot >= nr * nloc)
     return;
-#ifdef HX_TENSOR_PARTS_FASTEST
-  // experiment: part index fastest, then the row, then the element -- the two readers of an operand row are adjacent slots
-  const unsigned pi = slot % 3u, s3 = slot / 3u;
-  const unsigned ri = r0 + s3 % nr;
-  const int b = (int)(pb0 / 3u + s3 / nr);
-  if (b >= batch)
-    return;
-#else
   const unsigned ri = r0 + slot % nr, pb = pb0 + slot / nr;
-#endif
-#if defined(HX_TENSOR_PARTS_FASTEST)
-#elif defined(HX_TENSOR_PARTS_APART)
+#ifdef HX_TENSOR_PARTS_APART
   const int b = (int)(pb % (unsigned)batch);
   const unsigned pi = pb / (unsigned)batch;   // product part 0, 1, 2
 #else
