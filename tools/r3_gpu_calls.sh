@@ -10,6 +10,7 @@
 #   bench_fixed      the fixed-level multiply          -> bench_fixed.json
 #   trace            rocprofv3 --kernel-trace over the driver's command -> bench_kernel_trace.txt + bench_traced.json
 #   pmc              three separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU) -> pmc_summary.txt
+#   pmc_sq           two more --pmc passes: SQ VALU activity + GRBM_GUI_ACTIVE (clock), LDS bank conflicts -> pmc_sq_summary.txt
 #   bluestein        tools/prof_bluestein.py fused and old chain + kernel trace of the fused one
 #   levels           tools/prof_levels.py for both schemes
 #   ab:A,B,...       same-box A/B of the fresh multiply, two rounds; A = default | env:VAR=1 | a variant
@@ -86,6 +87,16 @@ for st in "$@"; do
       done
       python tools/rocpd_pmc.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ_INSTS_VALU > $out/pmc_summary.txt 2>&1
       head -40 $out/pmc_summary.txt ;;
+    pmc_sq)
+      # two more passes: VALU activity and the clock the kernels actually ran at; LDS conflicts (norm kernels)
+      i=0
+      for ctrs in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS"; do
+        i=$((i+1))
+        (cd /tmp && timeout 400 rocprofv3 --pmc $ctrs -d $R/$out/pmc_sq$i -- python3 $R/bench.py --gpus 1 --steps 2 --warmup 1 \
+           --mults-per-step 4 $QUICK > /dev/null 2> $R/$out/pmc_sq$i.err); echo "pmc_sq pass $i rc=$?"
+      done
+      python tools/rocpd_pmc.py $out/pmc_sq1 $out/pmc_sq2 > $out/pmc_sq_summary.txt 2>&1
+      grep -E "ntt_row_kernel<14, false>.* 6400 |apply_kernel<14, false>|embed_norm" $out/pmc_sq_summary.txt | cut -c1-200 | head -40 ;;
     bluestein)
       timeout 200 python tools/prof_bluestein.py > $out/blue_fused.json 2> $out/blue_fused.err; cat $out/blue_fused.json
       HX_BLUE_OLD=1 timeout 200 python tools/prof_bluestein.py > $out/blue_old.json 2> $out/blue_old.err; cat $out/blue_old.json
