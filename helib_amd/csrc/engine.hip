@@ -170,6 +170,8 @@ struct hx_ctx {
   TW* d_tw = nullptr;  // twiddle arena shared by all primes
   size_t tw_cap = 0, tw_used = 0;
   uint64_t* scratch[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint32_t* d_redo = nullptr;   // redo list of the HPS-form RNS kernels: [0] = count, [1..] = coefficient indices
+  size_t redo_cap = 0;          // (in 32-bit words)
   size_t scratch_words[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t aux_q[3] = {0, 0, 0};  // auxiliary NTT primes of the aux Bluestein path (lazily chosen)
   // general m (Bluestein): conv sizes 2^bk (chirp), 2^n1 / 2^n2 (rem Phi_m), pseudo "primes"
@@ -557,6 +559,7 @@ static void ctx_free(hx_ctx* c)
     hipStreamDestroy(c->own_stream);
   for (void* q : c->graph_retired)
     hipFree(q);
+  hipFree(c->d_redo);
   hipFree(c->d_frac);
   hipFree(c->d_wtab);
   hipFree(c->d_bn_v);
@@ -2343,6 +2346,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   size_t o_tchunk = take((nt + 1) / 2);
   const size_t pack_stride = 8 + 2 * (size_t)n;   // per-target record of the fast kernels (TgtRec in rns_kernels.h)
   size_t o_pack = take((size_t)nt * pack_stride);
+  size_t o_pack2 = take((size_t)nt * pack_stride);   // the same for the HPS front end (rns_kernels.h)
+  size_t o_hinv = take((size_t)2 * n), o_Wp2 = take((size_t)2 * n);
   std::vector<uint64_t> h(off, 0);
   hxh::BigU P(1);
   for (int k = 0; k < n; k++) {
@@ -2449,11 +2454,55 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
       rec[8 + n + k] = h[o_W + 2 * ((size_t)t * n + k) + 1];
     }
   }
+  // HPS front end: y_k = a_k (P/p_k)^-1 mod p_k, multipliers (P/p_k) mod t (scaled plans: / P, i.e.
+  // p_k^-1 mod t), the same header; "lazy" needs room for up to n + 1 extra multiples of t in the sum
+  bool hps_ok = n >= 2 && n <= 16 && (ptxt <= 1 || ptxt < ((uint64_t)1 << 58)) && !getenv("HX_NO_HPS");
+  if (hps_ok) {
+    auto prod_except = [&](int k, uint64_t m) {   // (P / p_k) mod m
+      uint64_t r = 1 % m;
+      for (int l = 0; l < n; l++)
+        if (l != k)
+          r = hxh::mulmod(r, p[l] % m, m);
+      return r;
+    };
+    for (int k = 0; k < n && hps_ok; k++) {
+      const uint64_t inv = hxh::invmod(prod_except(k, p[k]), p[k]);
+      hps_ok = inv != 0;
+      h[o_hinv + 2 * (size_t)k] = inv;
+      h[o_hinv + 2 * (size_t)k + 1] = hxh::shoup(inv, p[k]);
+      if (ptxt > 1) {
+        const uint64_t w = prod_except(k, ptxt);
+        h[o_Wp2 + 2 * (size_t)k] = w;
+        h[o_Wp2 + 2 * (size_t)k + 1] = hxh::shoup(w, ptxt);
+      }
+    }
+    for (int t = 0; t < nt && hps_ok; t++) {
+      const uint64_t q = tq(t);
+      const uint64_t* rec = &h[o_pack + (size_t)t * pack_stride];
+      uint64_t* rec2 = &h[o_pack2 + (size_t)t * pack_stride];
+      for (int j = 0; j < 8; j++)
+        rec2[j] = rec[j];
+      const uint32_t lazy2 = (hxh::bitlen(q) <= 60 && sum_src + 32 <= (hxh::u128)8 * q && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;
+      rec2[4] = (uint64_t)tk[t] | ((uint64_t)lazy2 << 8) | ((uint64_t)tchunk[t] << 9);
+      const uint64_t pinv_t = h[o_upd + 2 * (size_t)t];   // P^-1 mod t
+      for (int k = 0; k < n; k++) {
+        uint64_t w = prod_except(k, q);
+        if (scaled)
+          w = hxh::mulmod(w, pinv_t, q);
+        rec2[8 + k] = w;
+        rec2[8 + n + k] = hxh::shoup(w, q);
+      }
+    }
+  }
   uint64_t* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, off * 8));
   HIPCHK(hipMemcpy(d, h.data(), off * 8, hipMemcpyHostToDevice));
   pl->blob = d;
   pl->dev.tgt_pack = hx::as_ro(d + o_pack);
+  pl->dev.tgt_pack_hps = hx::as_ro(d + o_pack2);
+  pl->dev.hps_inv = hx::as_ro(reinterpret_cast<const TW*>(d + o_hinv));
+  pl->dev.Wp_hps = hx::as_ro(reinterpret_cast<const TW*>(d + o_Wp2));
+  pl->dev.hps_eps = getenv("HX_HPS_EPS") ? atof(getenv("HX_HPS_EPS")) : 1.0 / (double)(1u << 30);
   pl->dev.n = n;
   pl->dev.nt = nt;
   pl->dev.src_q = hx::as_ro(d + o_srcq);
@@ -2482,6 +2531,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     for (int t = 0; t < nt && ok16; t++)
       ok16 = (tq(t) >> 32) != 0;
     pl->dev.fast16_ok = ok16 ? 1u : 0u;
+    pl->dev.hps_ok = (hps_ok && ok16) ? 1u : 0u;   // (the front end lives in the fast kernels only)
   }
   pl->dev.tgt_chunk7 = hx::as_ro(reinterpret_cast<const uint32_t*>(d + o_tchunk));
   {
@@ -2495,14 +2545,53 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   return HX_OK;
 }
 
-static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args, size_t row_words)
+// The redo list of the HPS-form RNS kernels (rns_kernels.h: ExtRep): room for every coefficient of the launch, count
+// zeroed on the stream in front of the launch that fills it.
+static int redo_prepare(hx_ctx* c, size_t row_words, uint32_t** out)
+{
+  const size_t need = row_words + 1;
+  if (c->redo_cap < need) {
+    uint32_t* nd = nullptr;
+    HIPCHK(hipMalloc((void**)&nd, need * sizeof(uint32_t)));
+    retire_or_free(c, c->d_redo);
+    c->d_redo = nd;
+    c->redo_cap = need;
+  }
+  HIPCHK(hipMemsetAsync(c->d_redo, 0, sizeof(uint32_t), c->stream));
+  *out = c->d_redo;
+  return HX_OK;
+}
+// The HPS form pays from nine source primes on: measured same-box (gpurun_out r3c29), the digit kernel with 5-8 primes
+// per digit is 3-5 % SLOWER with it (366 vs 350 us at BGV L=16, 828 vs 808 us at CKKS L=24: eight u64 -> double
+// conversions cost what the 10-28 dependent Garner products cost), the basis extension of 11 dropped primes is faster
+// (Garner there is 55 products and spills 62 dwords; CKKS level 2 +3 %).  HX_HPS_MIN_N overrides (tests force 2).
+static int hps_min_n()
+{
+  const char* e = getenv("HX_HPS_MIN_N");
+  return e ? atoi(e) : 9;
+}
+static const dim3 REDO_GRID(64);   // the Garner pass over the listed coefficients (grid-stride; the list is almost always empty)
+
+static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args_in, size_t row_words)
 {
   dim3 grid((unsigned)((row_words + 255) / 256)), block(256);
   int n = pl->dev.n;
+  ExtArgs args = args_in;
+  args.redo = nullptr;
   if (pl->dev.fast16_ok) {
-#define HX_EXT_FAST(NN)                                                                                 \
-  case NN:                                                                                              \
-    HX_LAUNCH((hx::rns_extend_fast_kernel<NN>), grid, block, 0, c->stream, pl->dev, args, row_words); \
+    // HPS form + Garner over its redo list when the plan has the tables and no row is updated in place (an in-place
+    // update cannot be redone); otherwise Garner over everything
+    const bool hps = pl->dev.hps_ok && n >= hps_min_n() && args.upd == nullptr && row_words < ((size_t)1 << 32);
+    if (hps)
+      CHK(redo_prepare(c, row_words, &args.redo));
+#define HX_EXT_FAST(NN)                                                                                            \
+  case NN:                                                                                                         \
+    if (hps) {                                                                                                     \
+      HX_LAUNCH((hx::rns_extend_fast_kernel<NN, true>), grid, block, 0, c->stream, pl->dev, args, row_words);      \
+      HX_LAUNCH((hx::rns_extend_fast_kernel<NN, false>), REDO_GRID, block, 0, c->stream, pl->dev, args, row_words); \
+    } else {                                                                                                       \
+      HX_LAUNCH((hx::rns_extend_fast_kernel<NN, false>), grid, block, 0, c->stream, pl->dev, args, row_words);     \
+    }                                                                                                              \
     break;
     switch (n) {
       HX_EXT_FAST(1) HX_EXT_FAST(2) HX_EXT_FAST(3) HX_EXT_FAST(4) HX_EXT_FAST(5) HX_EXT_FAST(6) HX_EXT_FAST(7) HX_EXT_FAST(8)
@@ -2541,6 +2630,7 @@ static void clear_args(ExtArgs& a)
   a.upd = nullptr;
   a.nu = 0;
   a.frac = nullptr;
+  a.redo = nullptr;
 }
 
 // ------------------------------------------------------------------
@@ -3979,15 +4069,27 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
   bool fast = true;
   for (int d = 0; d < ndig; d++)
     fast = fast && A.plan[d].fast_ok;
+  A.redo = nullptr;
   if (fast) {
     static bool attrf = false;
     if (!attrf) {
-      HIPCHK(hipFuncSetAttribute((const void*)hx::break_digits_fast_kernel,
+      HIPCHK(hipFuncSetAttribute((const void*)hx::break_digits_fast_kernel<true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
+      HIPCHK(hipFuncSetAttribute((const void*)hx::break_digits_fast_kernel<false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
       attrf = true;
     }
     const size_t lds_fast = (size_t)std::max(1, L - hx::break_fast_n0(A)) * hx::BRK_THREADS * 8;
-    HX_LAUNCH(hx::break_digits_fast_kernel, grid, block, lds_fast, c->stream, A, rw);
+    bool hps = rw < ((size_t)1 << 32);
+    for (int d = 0; d < ndig; d++)
+      hps = hps && A.plan[d].hps_ok && (int)A.plan[d].n >= hps_min_n();
+    if (hps) {   // HPS form, then Garner over the coefficients it could not vouch for (rns_kernels.h: ExtRep)
+      CHK(redo_prepare(c, rw, &A.redo));
+      HX_LAUNCH(hx::break_digits_fast_kernel<true>, grid, block, lds_fast, c->stream, A, rw);
+      HX_LAUNCH(hx::break_digits_fast_kernel<false>, REDO_GRID, block, lds_fast, c->stream, A, rw);
+    } else {
+      HX_LAUNCH(hx::break_digits_fast_kernel<false>, grid, block, lds_fast, c->stream, A, rw);
+    }
   } else if (nmax <= 8) {
     static bool attr8 = false;
     if (!attr8) {

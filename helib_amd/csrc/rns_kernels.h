@@ -399,6 +399,16 @@ struct ExtPlanDev {
                              // remainder itself -- no reduction, no 128-bit Barrett product per target
   ro_u32 tgt_chunk7;  // [nt] 1: every source prime <= q_t, so the limb sum may be taken 7
                                // terms at a time with the previous remainder carried (r + 7 p q < 8 q^2)
+  // HPS front end of the fast kernels (hps_ok): instead of Garner's n(n-1)/2 dependent products,
+  //   y_k = a_k (P/p_k)^-1 mod p_k,  value = sum_k y_k (P/p_k) - v P,  v = floor(sum_k y_k / p_k),
+  // the quotient v taken from a double-precision sum that is trusted only when its fractional part
+  // is at least hps_eps away from 0, 1/2 and 1 (centring compares with 1/2); a wavefront with an
+  // untrusted lane takes the Garner path, so the result is exact either way.
+  ro_tw hps_inv;       // [n] (P/p_k)^-1 mod p_k
+  ro_u64 tgt_pack_hps; // [nt][8 + 2n] as tgt_pack with the multipliers (P/p_k) mod t (scaled: / P)
+  ro_tw Wp_hps;        // [n] (P/p_k) mod ptxt
+  double hps_eps;
+  uint32_t hps_ok;
   ro_u64 tgt_pack;    // [nt][8 + 2n] everything the fast kernels need of one target in ONE record
                       // (TgtRec): the loop over targets then makes one scalar-memory round trip per
                       // target instead of one per table (q, P mod t, flags, k, mu, W row: six
@@ -416,7 +426,7 @@ struct TgtRec {
   ro_u64 r;
   uint64_t q_, pmod_, mu63_, mu64_, fl_, updw_, updp_;
   uint64_t w_[N];
-  __device__ __forceinline__ TgtRec(const ExtPlanDev& P, int t) : r(P.tgt_pack + (size_t)t * (8 + 2 * N))
+  __device__ __forceinline__ TgtRec(ro_u64 pack, int t) : r(pack + (size_t)t * (8 + 2 * N))
   {
     q_ = r[0];
     pmod_ = r[1];
@@ -495,6 +505,7 @@ struct ExtArgs {
   int nu;                    // targets [0,nu) are the ones with an upd_row (host orders them first)
   double* frac;              // optional [batch][N]: (centred, corrected) value / P as a double
                              // (the fdelta of src/Ctxt.cpp:466-478 for scaleDownToSet)
+  uint32_t* redo;            // fast kernels: [0] = count, [1..] = coefficient indices (see ExtRep below); or null
 };
 
 // value / P in [0,1) from the mixed-radix digits (value = a_0 + a_1 q_0 + a_2 q_0 q_1 + ...):
@@ -648,6 +659,7 @@ struct BreakArgs {
   ExtPlanDev plan[KS_MAXD];  // plan d: sources = digit d's primes, targets = all other rows, ascending
   double* frac;          // optional [ndig][batch][N]: centred digit / P_d (for its canonical norm,
                          // src/DoubleCRT.cpp:538-545)
+  uint32_t* redo;        // as ExtArgs::redo
 };
 
 // rows of the first digit that the fast kernel does not keep in LDS (host and device agree on this)
@@ -774,43 +786,106 @@ __device__ __forceinline__ uint64_t norm_any(uint64_t x, uint64_t q, uint32_t mu
   return csub(r, q);
 }
 
-// xs holds rows [n0, L) only: the rows of the FIRST digit (n0 of them when it starts at row 0) are
-// consumed once, by their own pass, and are read straight from global memory (src0) -- 10 instead of
-// 16 LDS rows per thread at L = 16, digits 6/5/5, which is what bounds the resident waves.
+// ---- front ends of the fast kernels: the representation the target sums run over ----
+// rep[k]: mixed-radix digits (Garner) or the y_k of the HPS form; cnt: how many times P is subtracted
+// in the target sums (Garner: 1 if centred negative; HPS: v + that); fr: value / P - [negative]
 template <int N>
-__device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* xs, unsigned tid, int off, int L,
-                                                 uint64_t* dd, size_t row_words, double* frac_out, int n0,
-                                                 const uint64_t* src0)
+struct ExtRep {
+  uint64_t rep[N];
+  uint32_t cnt;
+  bool neg;
+  double fr;
+};
+// Garner mixed-radix digits (src/DoubleCRT.cpp:1031-1100 computes the same value by CRT); x may be lazy
+// (< 4 p_k).  a_l < p_l < 2 p_k (garner_cs).
+template <int N, class Load>
+__device__ __forceinline__ void garner_front(const ExtPlanDev& P, Load load, ExtRep<N>& R, bool want_frac)
 {
-  uint64_t a[N];
-  // ---- Garner mixed-radix digits (src/DoubleCRT.cpp:1031-1100 computes the same value by CRT) ----
-  const bool from_global = off < n0;   // (uniform; a digit is either entirely below n0 or entirely above)
+  uint64_t (&a)[N] = R.rep;
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    // [0,4 p_k): later digits' rows are updated lazily
-    uint64_t x = from_global ? src0[(size_t)(off + k) * row_words] : xs[(off + k - n0) * BRK_THREADS + tid];
+    uint64_t v = load(k);
     const uint64_t pk = P.src_q[k], npk = 0 - pk, pk2 = pk + pk;
 #pragma unroll
     for (int l = 0; l < k; l++)
-      x = shoup4(x + pk2 - a[l], ld_tw(P.ginv, k * N + l), npk);  // a_l < p_l < 2 p_k (garner_cs)
-    x = csub(x, pk2);
-    a[k] = csub(x, pk);
+      v = shoup4(v + pk2 - a[l], ld_tw(P.ginv, k * N + l), npk);
+    v = csub(v, pk2);
+    a[k] = csub(v, pk);
   }
-  // ---- centring: v > (P-1)/2, top digit first ----
+  // centring: value > (P-1)/2, top digit first
   int cmp = 0;
 #pragma unroll
   for (int k = N - 1; k >= 0; k--) {
     const uint64_t h = P.half[k];
     cmp = cmp != 0 ? cmp : (a[k] > h ? 1 : (a[k] < h ? -1 : 0));
   }
-  const bool neg = cmp > 0;
-  if (frac_out) {
+  R.neg = cmp > 0;
+  R.cnt = R.neg ? 1u : 0u;
+  R.fr = 0;
+  if (want_frac) {
     double f = 0;
 #pragma unroll
     for (int k = 0; k < N; k++)
       f = ((double)a[k] + f) * P.src_rq[k];
-    *frac_out = f - (neg ? 1.0 : 0.0);
+    R.fr = f - (R.neg ? 1.0 : 0.0);
   }
+}
+// HPS form; returns false when this lane's quotient or sign cannot be trusted to the double sum
+template <int N, class Load>
+__device__ __forceinline__ bool hps_front(const ExtPlanDev& P, Load load, ExtRep<N>& R)
+{
+  double z = 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const uint64_t pk = P.src_q[k];
+    uint64_t y = shoup4(load(k), ld_tw(P.hps_inv, k), 0 - pk);  // any 64-bit x -> [0, 4 p_k)
+    y = csub(y, pk + pk);
+    y = csub(y, pk);
+    R.rep[k] = y;
+    z += (double)y * P.src_rq[k];
+  }
+  const double fl = floor(z), f = z - fl, eps = P.hps_eps;
+  R.neg = f > 0.5;
+  R.cnt = (uint32_t)fl + (R.neg ? 1u : 0u);
+  R.fr = f - (R.neg ? 1.0 : 0.0);
+  return !(f < eps || f > 1.0 - eps || fabs(f - 0.5) < eps);
+}
+// The fast kernels exist in two forms (template parameter HPS).  HPS = true: the HPS front end alone -- a lane that
+// cannot trust its double-precision quotient appends its coefficient index to the redo list (ExtArgs / BreakArgs
+// ::redo: [0] = count, [1..] = indices) and carries on with whatever it has; nothing it writes is read by another
+// lane.  HPS = false: Garner; given a redo list it visits the listed coefficients only and overwrites what the first
+// form wrote for them (every output is a pure function of the unmodified source rows), given none it is the whole
+// kernel as before.  With both front ends in ONE kernel the allocator needed 90-96 VGPRs (round 2,
+// profiles/r02_hps_front_end_ab.log); apart they fit the 7-waves-per-SIMD budget the kernels are tuned for.
+__device__ __forceinline__ void redo_append(uint32_t* redo, size_t i)
+{
+  const uint32_t slot = atomicAdd(&redo[0], 1u);
+  redo[1 + slot] = (uint32_t)i;
+}
+
+// xs holds rows [n0, L) only: the rows of the FIRST digit (n0 of them when it starts at row 0) are
+// consumed once, by their own pass, and are read straight from global memory (src0) -- 10 instead of
+// 16 LDS rows per thread at L = 16, digits 6/5/5, which is what bounds the resident waves.
+template <int N, bool HPS>
+__device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* xs, unsigned tid, int off, int L,
+                                                 uint64_t* dd, size_t row_words, double* frac_out, int n0,
+                                                 const uint64_t* src0)
+{
+  const bool from_global = off < n0;   // (uniform; a digit is either entirely below n0 or entirely above)
+  auto load = [&](int k) -> uint64_t {   // [0,4 p_k): later digits' rows are updated lazily
+    return from_global ? src0[(size_t)(off + k) * row_words] : xs[(off + k - n0) * BRK_THREADS + tid];
+  };
+  ExtRep<N> R;
+  bool trusted = true;
+  if constexpr (HPS)
+    trusted = hps_front<N>(P, load, R);
+  else
+    garner_front<N>(P, load, R, frac_out != nullptr);
+  const uint64_t (&a)[N] = R.rep;
+  const uint32_t cnt = R.cnt;
+  ro_u64 pack = HPS ? P.tgt_pack_hps : P.tgt_pack;
+  if (frac_out)
+    *frac_out = R.fr;
   uint32_t a0[N], a1[N];
 #pragma unroll
   for (int k = 0; k < N; k++) {
@@ -820,12 +895,12 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
   // ---- residues modulo every other prime ----
   for (int t = 0; t < P.nt; t++) {
     const int r = t < off ? t : t + N;  // row of target t in the all-rows order
-    const TgtRec<N> T(P, t);
+    const TgtRec<N> T(pack, t);
     const uint64_t q = T.q();
-    const uint64_t negfix = neg ? q - T.pmod() : 0;
+    const uint64_t negP = q - T.pmod();   // -P mod t: enters cnt times (centring, and the HPS quotient)
     uint64_t v;
     if (T.lazy()) {
-      uint64_t c00 = negfix, c01 = 0, c11 = 0;
+      uint64_t c00 = 0, c01 = 0, c11 = 0;
 #pragma unroll
       for (int k = 0; k < N; k++) {
         const uint64_t w = T.w(k);
@@ -835,7 +910,7 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
         c01 += (uint64_t)a1[k] * w0;
         c11 += (uint64_t)a1[k] * w1;
       }
-      const u128 S = (u128)c00 + ((u128)c01 << 30) + ((u128)c11 << 60);
+      const u128 S = (u128)cnt * negP + c00 + ((u128)c01 << 30) + ((u128)c11 << 60);
 #ifdef HX_RED128_WIDE
       v = red128_wide(S, q, T.mu(), T.k());
 #else
@@ -844,7 +919,7 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
     } else {
       const uint64_t nq = 0 - q, q8 = q << 3;
       const bool wide = T.k() >= 58;  // 8 terms of < 4q could pass 2^64: fold every second term
-      uint64_t acc = negfix;
+      uint64_t acc = cnt == 1 ? negP : 0;
       uint64_t wp[N];
       T.load_wp(wp);
 #pragma unroll
@@ -857,6 +932,8 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
           acc = csub(acc, q8);
       }
       v = norm_any(acc, q, (uint32_t)T.mu64());
+      if (cnt > 1)   // (HPS quotient: a small multiple of -P, reduced on its own)
+        v = add_mod(v, mul_mod((uint64_t)cnt, negP, q, T.mu(), T.k()), q);
     }
     dd[(size_t)r * row_words] = v;
     if (r >= off + N && r < L) {
@@ -865,6 +942,7 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
       *u = shoup4(*u + q - v, T.upd(), 0 - q);
     }
   }
+  return trusted;
 }
 
 // =====================================================================
@@ -876,33 +954,46 @@ __device__ __forceinline__ void break_digit_pass(const ExtPlanDev& P, uint64_t* 
 // products normalised once.  The plaintext-space correction, the fraction and the stores are the
 // generic kernel's, so every output word and every fraction is the same.
 // =====================================================================
-template <int N>
+template <int N, bool HPS>
+__device__ __forceinline__ void rns_extend_fast_one(const ExtPlanDev& P, const ExtArgs& A, size_t row_words, size_t i);
+
+template <int N, bool HPS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N <= 11 ? HX_EXT_WAVES : 4)))
 rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
 {
+  if constexpr (!HPS) {
+    if (A.redo) {   // the listed coefficients only (grid-stride over the list)
+      const uint32_t n = A.redo[0];
+      for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x)
+        rns_extend_fast_one<N, false>(P, A, row_words, A.redo[1 + j]);
+      return;
+    }
+  }
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= row_words)
     return;
-  uint64_t a[N];
+  rns_extend_fast_one<N, HPS>(P, A, row_words, i);
+}
+template <int N, bool HPS>
+__device__ __forceinline__ void rns_extend_fast_one(const ExtPlanDev& P, const ExtArgs& A, size_t row_words, size_t i)
+{
 #pragma unroll
-  for (int k = 0; k < N; k++) {
-    uint64_t x = A.src[(size_t)A.src_row[k] * row_words + i];
+  for (int k = 0; k < N; k++)
     if (A.own_dst_row[k] != 0xffff)
-      A.dst[(size_t)A.own_dst_row[k] * row_words + i] = x;
-    const uint64_t pk = P.src_q[k], npk = 0 - pk, pk2 = pk + pk;
-#pragma unroll
-    for (int l = 0; l < k; l++)
-      x = shoup4(x + pk2 - a[l], ld_tw(P.ginv, k * N + l), npk);  // a_l < p_l < 2 p_k (garner_cs)
-    x = csub(x, pk2);
-    a[k] = csub(x, pk);
+      A.dst[(size_t)A.own_dst_row[k] * row_words + i] = A.src[(size_t)A.src_row[k] * row_words + i];
+  auto load = [&](int k) -> uint64_t { return A.src[(size_t)A.src_row[k] * row_words + i]; };
+  ExtRep<N> R;
+  if constexpr (HPS) {
+    if (!hps_front<N>(P, load, R))
+      redo_append(A.redo, i);
+  } else {
+    garner_front<N>(P, load, R, A.frac != nullptr);
   }
-  int cmp = 0;
-#pragma unroll
-  for (int k = N - 1; k >= 0; k--) {
-    const uint64_t h = P.half[k];
-    cmp = cmp != 0 ? cmp : (a[k] > h ? 1 : (a[k] < h ? -1 : 0));
-  }
-  const bool neg = cmp > 0;
+  const uint64_t (&a)[N] = R.rep;
+  const bool neg = R.neg;
+  const uint32_t cnt = R.cnt;
+  ro_u64 pack = HPS ? P.tgt_pack_hps : P.tgt_pack;
+  ro_tw Wp = HPS ? P.Wp_hps : P.Wp;
 
   // ---- BGV: make delta divisible by ptxtSpace (src/DoubleCRT.cpp:1485-1508) ----
   bool dm_nonzero = false, dm_negative = false;
@@ -912,13 +1003,15 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-      acc += shoup_lazy(a[k], ld_tw(P.Wp, k), p);  // each < 2p
+      acc += shoup_lazy(a[k], ld_tw(Wp, k), p);  // each < 2p
       if ((k & 3) == 3)
         acc = red64(acc, p, P.ptxt_mu64);
     }
     uint64_t r = red64(acc, p, P.ptxt_mu64);
-    if (neg)
+    if (cnt == 1)
       r = sub_mod(r, P.pmod_ptxt, p);
+    else if (cnt > 1)   // (HPS: cnt * (P mod ptxt) < 2^63, hps_ok asks for ptxt < 2^58)
+      r = sub_mod(r, red64((uint64_t)cnt * P.pmod_ptxt, p, P.ptxt_mu64), p);
     if (r != 0) {
       uint64_t dm = mul_mod(r, P.pinv_ptxt, p, P.ptxt_mu, P.ptxt_k);
       const uint64_t p_over_2 = p >> 1;
@@ -929,7 +1022,7 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
     }
   }
   if (A.frac) {
-    double fr = mixed_radix_fraction<N>(a, P.src_q, N) - (neg ? 1.0 : 0.0);
+    double fr = R.fr;
     if (dm_nonzero)
       fr += dm_negative ? (double)dm_abs : -(double)dm_abs;
     A.frac[i] = fr;
@@ -941,9 +1034,9 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
     a1[k] = (uint32_t)(a[k] >> 30);
   }
   for (int t = 0; t < P.nt; t++) {
-    const TgtRec<N> T(P, t);
+    const TgtRec<N> T(pack, t);
     const uint64_t q = T.q();
-    const uint64_t negfix = neg ? q - T.pmod() : 0;
+    const uint64_t negP = q - T.pmod();   // -P mod t: enters cnt times (centring, and the HPS quotient)
     uint64_t r;
     if (T.lazy()) {
       // N <= 16 products of < 2^60 per accumulator
@@ -957,10 +1050,10 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
         c10 += (uint64_t)a1[k] * w0;
         c11 += (uint64_t)a1[k] * w1;
       }
-      const u128 S = (u128)negfix + c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
+      const u128 S = (u128)cnt * negP + c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
       r = red128_q8(S, q, T.mu63(), T.k());
     } else if (T.chunk7()) {
-      r = negfix;
+      u128 carry = (u128)cnt * negP;   // (first chunk; afterwards the previous remainder)
 #pragma unroll
       for (int k0 = 0; k0 < N; k0 += 7) {
         uint64_t c00 = 0, c01 = 0, c11 = 0;
@@ -973,13 +1066,14 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
           c01 += (uint64_t)a1[k] * w0;
           c11 += (uint64_t)a1[k] * w1;
         }
-        const u128 S = (u128)r + c00 + ((u128)c01 << 30) + ((u128)c11 << 60);
+        const u128 S = carry + c00 + ((u128)c01 << 30) + ((u128)c11 << 60);
         r = red128_q8(S, q, T.mu63(), T.k());
+        carry = r;
       }
     } else {
       const uint64_t nq = 0 - q, q8 = q << 3;
       const bool wide = T.k() >= 58;  // terms of < 4q could pass 2^64: fold every second term
-      uint64_t acc = negfix;
+      uint64_t acc = cnt == 1 ? negP : 0;
       uint64_t wp[N];
       T.load_wp(wp);
 #pragma unroll
@@ -992,6 +1086,8 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
           acc = csub(acc, q8);
       }
       r = norm_any(acc, q, (uint32_t)T.mu64());
+      if (cnt > 1)
+        r = add_mod(r, mul_mod((uint64_t)cnt, negP, q, T.mu(), T.k()), q);
     }
     if (dm_nonzero) {
       // delta -= diffProd * delta_i_modP
@@ -1010,34 +1106,53 @@ rns_extend_fast_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
   }
 }
 
-__global__ void __launch_bounds__(BRK_THREADS) __attribute__((amdgpu_waves_per_eu(HX_BRK_WAVES)))
-break_digits_fast_kernel(BreakArgs A, size_t row_words)
+template <bool HPS>
+__device__ __forceinline__ void break_digits_fast_one(const BreakArgs& A, size_t row_words, uint64_t* xs, unsigned tid, size_t i)
 {
-  extern __shared__ __attribute__((aligned(16))) uint64_t xs[];  // [L - n0][BRK_THREADS]
-  const unsigned tid = threadIdx.x;
-  const size_t i = (size_t)blockIdx.x * BRK_THREADS + tid;
-  if (i >= row_words)
-    return;
   const int n0 = break_fast_n0(A);
   for (int r = n0; r < A.L; r++)
     xs[(r - n0) * BRK_THREADS + tid] = A.src[(size_t)r * row_words + i];
   const uint64_t* src0 = A.src + i;
+  bool trusted = true;
   for (int d = 0; d < A.ndig; d++) {
     const ExtPlanDev& P = A.plan[d];
     const int off = A.off[d];
     uint64_t* dd = A.dst + (size_t)d * A.nall * row_words + i;
     double* fo = A.frac ? A.frac + (size_t)d * row_words + i : nullptr;
+    bool ok;
     switch (P.n) {
-      case 1: break_digit_pass<1>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 2: break_digit_pass<2>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 3: break_digit_pass<3>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 4: break_digit_pass<4>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 5: break_digit_pass<5>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 6: break_digit_pass<6>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 7: break_digit_pass<7>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      default: break_digit_pass<8>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 1: ok = break_digit_pass<1, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 2: ok = break_digit_pass<2, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 3: ok = break_digit_pass<3, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 4: ok = break_digit_pass<4, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 5: ok = break_digit_pass<5, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 6: ok = break_digit_pass<6, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 7: ok = break_digit_pass<7, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      default: ok = break_digit_pass<8, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+    }
+    trusted = trusted && ok;
+  }
+  if (HPS && !trusted)   // (one entry per coefficient: a wrong digit also spoils the later digits' rows of this lane)
+    redo_append(A.redo, i);
+}
+template <bool HPS>
+__global__ void __launch_bounds__(BRK_THREADS) __attribute__((amdgpu_waves_per_eu(HX_BRK_WAVES)))
+break_digits_fast_kernel(BreakArgs A, size_t row_words)
+{
+  extern __shared__ __attribute__((aligned(16))) uint64_t xs[];  // [L - n0][BRK_THREADS]: one private column per thread
+  const unsigned tid = threadIdx.x;
+  if constexpr (!HPS) {
+    if (A.redo) {   // the listed coefficients only
+      const uint32_t n = A.redo[0];
+      for (size_t j = (size_t)blockIdx.x * BRK_THREADS + tid; j < n; j += (size_t)gridDim.x * BRK_THREADS)
+        break_digits_fast_one<false>(A, row_words, xs, tid, A.redo[1 + j]);
+      return;
     }
   }
+  const size_t i = (size_t)blockIdx.x * BRK_THREADS + tid;
+  if (i >= row_words)
+    return;
+  break_digits_fast_one<HPS>(A, row_words, xs, tid, i);
 }
 
 // (x - y) * c per row: the tail of scaleDownToSet (*this -= delta; *this /= diffProd)

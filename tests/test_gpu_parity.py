@@ -2005,3 +2005,25 @@ def test_cpp_host_session_library_on_the_device(hx, scheme, m, p, r, bits, batch
     assert s.verify(1) == batch
     s.multiply_single(True)
     s.close()
+
+
+@pytest.mark.parametrize("eps", ["default", "0.05", "1.0"])
+def test_hps_form_of_the_rns_kernels_and_its_redo_list(hx, monkeypatch, eps):
+    """The fast basis-extension / digit kernels in their HPS form (rns_kernels.h: ExtRep, engine.hip: hps_min_n) --
+    y_k = a_k (P/p_k)^-1, quotient from a double-precision sum, coefficients whose sum is too close to a boundary
+    appended to a redo list that a Garner launch then recomputes.  HX_HPS_MIN_N = 2 sends every plan through it
+    (default: nine source primes and more); eps = 2^-30 (default: the list is almost always empty), 0.05 (about
+    a third of the coefficients redone next to trusted ones) and 1.0 (every coefficient redone).  Same checks as
+    the plain tests: every output word against the oracle, fdelta and norms within their tolerances."""
+    monkeypatch.setenv("HX_HPS_MIN_N", "2")
+    if eps != "default":
+        monkeypatch.setenv("HX_HPS_EPS", eps)
+    test_scale_down_to_set(hx, 65537)
+    test_scale_down_to_set(hx, 1)
+    test_break_into_digits(hx, [[0, 1], [2, 3], [4]])
+    test_break_into_digits(hx, [[0, 1, 2, 3, 4]])
+    test_scale_down_norms_and_fdelta(hx, 2, 65537)
+    test_scale_down_norms_and_fdelta(hx, 2, 1)
+    test_break_into_digits_and_relinearize_norms(hx, [[0, 1], [2, 3], [4]])
+    test_several_primes_mod_switch_batched_over_parts_mixed_prime_sizes(hx, 16384, 65537)
+    test_tensor_folded_into_the_mod_switch(hx, 16384, 65537, "drop3")
