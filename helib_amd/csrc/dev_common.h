@@ -105,6 +105,22 @@ __device__ __forceinline__ ulonglong2 ld_stream2(const uint64_t* p)
   return make_ulonglong2(v.x, v.y);
 #endif
 }
+__device__ __forceinline__ uint64_t ld_stream1(const uint64_t* p)
+{
+#if defined(HX_NO_NT) || defined(HX_RNS_NO_NT)
+  return *p;
+#else
+  return __builtin_nontemporal_load(p);
+#endif
+}
+__device__ __forceinline__ void st_stream1(uint64_t* p, uint64_t v)
+{
+#if defined(HX_NO_NT) || defined(HX_RNS_NO_NT)
+  *p = v;
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
 __device__ __forceinline__ void st_stream2(uint64_t* p, ulonglong2 v)
 {
 #ifdef HX_NO_NT

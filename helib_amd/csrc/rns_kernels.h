@@ -873,7 +873,7 @@ __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* 
 {
   const bool from_global = off < n0;   // (uniform; a digit is either entirely below n0 or entirely above)
   auto load = [&](int k) -> uint64_t {   // [0,4 p_k): later digits' rows are updated lazily
-    return from_global ? src0[(size_t)(off + k) * row_words] : xs[(off + k - n0) * BRK_THREADS + tid];
+    return from_global ? ld_stream1(src0 + (size_t)(off + k) * row_words) : xs[(off + k - n0) * BRK_THREADS + tid];
   };
   ExtRep<N> R;
   bool trusted = true;
@@ -935,7 +935,7 @@ __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* 
       if (cnt > 1)   // (HPS quotient: a small multiple of -P, reduced on its own)
         v = add_mod(v, mul_mod((uint64_t)cnt, negP, q, T.mu(), T.k()), q);
     }
-    dd[(size_t)r * row_words] = v;
+    st_stream1(dd + (size_t)r * row_words, v);
     if (r >= off + N && r < L) {
       // digits[j] -= digits[i]; digits[j] /= P_i on a later digit's own row (kept lazy, < 4q)
       uint64_t* u = &xs[(r - n0) * BRK_THREADS + tid];
@@ -980,8 +980,8 @@ __device__ __forceinline__ void rns_extend_fast_one(const ExtPlanDev& P, const E
 #pragma unroll
   for (int k = 0; k < N; k++)
     if (A.own_dst_row[k] != 0xffff)
-      A.dst[(size_t)A.own_dst_row[k] * row_words + i] = A.src[(size_t)A.src_row[k] * row_words + i];
-  auto load = [&](int k) -> uint64_t { return A.src[(size_t)A.src_row[k] * row_words + i]; };
+      st_stream1(A.dst + (size_t)A.own_dst_row[k] * row_words + i, ld_stream1(A.src + (size_t)A.src_row[k] * row_words + i));
+  auto load = [&](int k) -> uint64_t { return ld_stream1(A.src + (size_t)A.src_row[k] * row_words + i); };
   ExtRep<N> R;
   if constexpr (HPS) {
     if (!hps_front<N>(P, load, R))
@@ -1097,7 +1097,7 @@ __device__ __forceinline__ void rns_extend_fast_one(const ExtPlanDev& P, const E
       r = dm_negative ? add_mod(r, corr, q) : sub_mod(r, corr, q);
     }
     if (A.dst_row[t] != 0xffff)
-      A.dst[(size_t)A.dst_row[t] * row_words + i] = r;
+      st_stream1(A.dst + (size_t)A.dst_row[t] * row_words + i, r);
     if (A.upd_row[t] != 0xffff) {
       uint64_t* u = A.upd + (size_t)A.upd_row[t] * row_words + i;
       const TW pinv = T.upd();
@@ -1111,7 +1111,7 @@ __device__ __forceinline__ void break_digits_fast_one(const BreakArgs& A, size_t
 {
   const int n0 = break_fast_n0(A);
   for (int r = n0; r < A.L; r++)
-    xs[(r - n0) * BRK_THREADS + tid] = A.src[(size_t)r * row_words + i];
+    xs[(r - n0) * BRK_THREADS + tid] = ld_stream1(A.src + (size_t)r * row_words + i);
   const uint64_t* src0 = A.src + i;
   bool trusted = true;
   for (int d = 0; d < A.ndig; d++) {
