@@ -571,6 +571,16 @@ def ckks_basic_ops(hx, hc, device, stream, sync, bits, B=16, reps=6, m=65536, ba
         "multiplying_two_ciphertexts": (lambda c: c.multiplyBy(fb), lambda: nega(a0, b0)),
         "multiply_and_add_two_ciphertexts": (mul_add, lambda: nega(a0, b0) + b0),
     }
+    # burn-in: the HIP runtime grows its own command / signal pools the first time a process keeps this much work in
+    # flight, a one-time event of tens of milliseconds in a process that already maps tens of GB -- it landed in whichever
+    # op happened to be the fourth or fifth heavy call (profiles/r03_bench_line_ckks65536_*: square or rotate at 10 ms)
+    for wc in [fa.clone() for _ in range(12)]:
+        wc.multiplyBy(fb)
+    for wc in [fa.clone() for _ in range(6)]:
+        wc.smartAutomorph(g)
+    _ = wc.lnNoise
+    del wc
+    sync()
     out = {}
     for name, (fn, want) in ops.items():
         try:
