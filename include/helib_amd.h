@@ -177,9 +177,10 @@ int hx_bring_to_set_multi(hx_poly** polys, int npoly, const int* add_idx, int na
  * switch (reLinearize -> dropSmallAndSpecialPrimes, src/Ctxt.cpp:720-760).  c0, c1 / d0, d1: the parts (1), (s) of
  * the two operands on one prime set; o0, o1, o2 receive the product parts (1), (s), (s^2) on that set with add_idx
  * added and drop_idx dropped (their previous contents and prime sets are irrelevant; they must not alias an operand).
- * With one dropped prime on a power-of-two ring the product is formed inside the mod-down kernels from the operands'
- * rows and never written on the old prime set; otherwise hx_tensor and hx_bring_to_set_multi run one after the
- * other.  Results are identical to that sequence word for word.  _norms: as hx_bring_to_set_multi_norms, three
+ * On a power-of-two ring (N = 2^13..2^15) the product is formed inside the mod-down kernels from the operands' rows
+ * and never written on the old prime set -- one dropped prime (a fresh multiply) and several (every later multiply)
+ * alike; any other shape runs hx_tensor and hx_bring_to_set_multi one after the other.  Results are identical to
+ * that sequence word for word.  _norms: as hx_bring_to_set_multi_norms, three
  * polys. */
 int hx_tensor_bring_to_set(const hx_poly* c0, const hx_poly* c1, const hx_poly* d0, const hx_poly* d1,
                            hx_poly* o0, hx_poly* o1, hx_poly* o2, const int* add_idx, int nadd,
