@@ -47,8 +47,14 @@ launch   : `bench.py --gpus N` without WORLD_SIZE in the environment spawns the 
            RCCL for the barrier and the max-over-ranks); under torch.distributed.run it checks
            --gpus against WORLD_SIZE.  `--dry-launch` exercises exactly that launch / shard /
            barrier / aggregate path with gloo on CPUs and no engine call (tests/test_dist_cpu.py).
+other legs (rank 0, skipped by --no-extras): the reference's other benchmark lines over the resident batch --
+           `config.bgv_basic_ops` (benchmarks/bgv_basic.cpp:36-211) in the default line, `config.ckks_basic_ops`
+           (benchmarks/ckks_basic.cpp:38-236) in the `--workload ckks65536` line, every result decrypted /
+           decoded and checked --, the two levels of the other scheme, BASELINE configs[4] (Bluestein m=21845),
+           one ciphertext pair at a time eagerly and as one hipGraphLaunch.
 roofline : measured IN SITU: after the timed region a few more multiplies run with every kernel launch
-           bracketed by HIP events on its own stream (hx_profile_begin / _end, helib_amd/csrc/prof.h).
+           carrying the dispatch's own start / stop events on its stream (hx_profile_begin / _end,
+           helib_amd/csrc/prof.h).
            `roofline` is the time-dominant kernel at its dominant launch shape, `achieved` = its
            algorithmic bytes per launch / its average duration inside the multiply; the whole
            per-kernel table is `config.kernels_in_situ`; the forward row transform is reported both in
