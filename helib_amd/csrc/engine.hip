@@ -2992,8 +2992,17 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   }
   np.rows = rows;
   np.out = out_host;
-  HIPCHK(hipMemcpyAsync(np.pinned, c->d_norm2, sizeof(unsigned long long) * (size_t)rows,
-                        hipMemcpyDeviceToHost, ns));
+  // the few words go to the pinned slot by a kernel writing host memory (hipHostMalloc memory is device-visible),
+  // not by a device-to-host copy command: HX_NORM_MEMCPY=1 restores the copy (A/B)
+  static const bool by_copy = getenv("HX_NORM_MEMCPY") != nullptr;
+  if (by_copy) {
+    HIPCHK(hipMemcpyAsync(np.pinned, c->d_norm2, sizeof(unsigned long long) * (size_t)rows,
+                          hipMemcpyDeviceToHost, ns));
+  } else {
+    HX_LAUNCH(hx::copy_words_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ns,
+              reinterpret_cast<uint64_t*>(np.pinned), reinterpret_cast<const uint64_t*>(c->d_norm2), (size_t)rows);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipEventRecord(np.ev, ns));
   c->norm_pending.push_back(np);
   if (ns != c->stream) {
