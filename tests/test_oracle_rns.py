@@ -191,3 +191,40 @@ def test_bgv_multiply_relin_decrypts(m, p):
     r1 = P.ctx.scale_down(P.all, o1, P.special, p)
     got2, _ = B.decrypt(P, s, r0, r1, P.own)
     assert got2 == [int(v) for v in B.polymul_mod_phi(ma, mb, m, p)]
+
+
+@pytest.mark.parametrize("n", [2, 5, 8, 11])
+def test_hps_quotient_rule_is_exact_whenever_it_is_trusted(n):
+    """The arithmetic behind the HPS form of the fast RNS kernels (helib_amd/csrc/rns_kernels.h: hps_front), restated
+    in numpy / python integers: y_k = x_k (P/p_k)^-1 mod p_k, z = sum_k double(y_k) * double(1/p_k), v = floor(z),
+    centred when frac(z) > 1/2.  Claim the kernels rely on: whenever frac(z) is at least eps = 2^-30 away from 0, 1/2
+    and 1, v and the centring decision are the exact ones -- sum_k y_k (P/p_k) - v P is the value in [0, P) and
+    value > (P-1)/2 iff frac(z) > 1/2; everything else goes to the redo list.  Random values and the adversarial
+    ones (0, 1, P-1, the two neighbours of P/2, values a hair away from a multiple of P in the y-sum)."""
+    g = O.PrimeGen(60, 32768)
+    p = [g.next() for _ in range(n)]
+    P = reduce(lambda a, b: a * b, p)
+    Pk = [P // q for q in p]
+    inv = [pow(Pk[k] % p[k], -1, p[k]) for k in range(n)]
+    rq = [1.0 / q for q in p]
+    eps = 2.0 ** -30
+    rng = np.random.default_rng(n)
+    vals = [int.from_bytes(rng.bytes(8 * n + 8), "little") % P for _ in range(3000)]
+    nrandom = len(vals)
+    vals += [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, (P - 1) // 2 - 1, (P + 1) // 2 + 1]
+    vals += [Pk[k] * j % P for k in range(n) for j in (1, 2, p[k] - 1)]        # single non-zero y_k
+    vals += [(P // 3 + d) % P for d in (-1, 0, 1)] + [(P // 2 + d * (P >> 70)) % P for d in range(-3, 4)]
+    untrusted = 0
+    for v in vals:
+        y = [(v % p[k]) * inv[k] % p[k] for k in range(n)]
+        z = 0.0
+        for k in range(n):
+            z += float(y[k]) * rq[k]
+        fl = np.floor(z)
+        f = z - fl
+        if f < eps or f > 1.0 - eps or abs(f - 0.5) < eps:
+            untrusted += 1
+            continue
+        assert sum(y[k] * Pk[k] for k in range(n)) - int(fl) * P == v
+        assert (f > 0.5) == (v > (P - 1) // 2)
+    assert untrusted <= len(vals) - nrandom      # (only adversarial values land on the redo list)
