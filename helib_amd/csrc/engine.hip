@@ -3499,6 +3499,8 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
     (d ? drop : keep).push_back(a->prime_idx[r]);
   }
   if (drop.empty()) {  // nothing to do; a requested norm is that of delta = 0
+    if (tsrc)
+      return HX_ERR_UNSUPPORTED;   // (none of the listed primes is there: the caller forms the product on its own)
     if (c->want_frac) {
       double* fr = frac_take(c, a->row_words() * (size_t)(1 + nother));
       if (fr)

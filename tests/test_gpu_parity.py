@@ -2027,3 +2027,20 @@ def test_hps_form_of_the_rns_kernels_and_its_redo_list(hx, monkeypatch, eps):
     test_break_into_digits_and_relinearize_norms(hx, [[0, 1], [2, 3], [4]])
     test_several_primes_mod_switch_batched_over_parts_mixed_prime_sizes(hx, 16384, 65537)
     test_tensor_folded_into_the_mod_switch(hx, 16384, 65537, "drop3")
+
+
+def test_tensor_bring_to_set_when_none_of_the_listed_primes_is_there(hx):
+    """hx_tensor_bring_to_set with a drop list that does not meet the operands' prime set (nothing to mod-switch):
+    the product parts must still be formed -- the plain tensor product on the operands' primes."""
+    P, own, sp = setup_rns(hx, m=16384, L=4, K=2)
+    B = 2
+    ops = [P.rand(own, 900 + i, batch=B) for i in range(4)]
+    c0, c1, d0, d1 = (hx.DoubleCRT(P.g, own, B, x) for x in ops)
+    outs = [hx.DoubleCRT(P.g, own, B, zero=False) for _ in range(3)]
+    drop = hx._i32([sp[0], sp[1]])
+    hx._chk(hx.lib().hx_tensor_bring_to_set(c0.h, c1.h, d0.h, d1.h, outs[0].h, outs[1].h, outs[2].h, None, 0,
+                                            hx._p(drop), 2, 65537))
+    want = list(hx.tensorProduct(c0, c1, d0, d1))
+    for o, w in zip(outs, want):
+        assert o.getIndexSet() == w.getIndexSet() == own
+        assert np.array_equal(o.download(), w.download())
