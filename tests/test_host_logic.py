@@ -288,3 +288,39 @@ def test_bench_ckks_basic_op_list_over_the_cpu_checker():
         assert isinstance(out[nme], dict), (nme, out[nme])
     for nme in names[:8]:
         assert out[nme]["decode_max_abs_err"] <= out[nme]["reported_error_bound"]
+
+
+def test_approximate_barrett_of_the_fused_kernels_restated():
+    """red128_q8 / tensor_red128 (helib_amd/csrc/rns_kernels.h, ntt_kernels.hip): S mod q for S < 8 q^2 with ONE
+    approximate high product -- xt = S >> (k-1) (k = bitlen q), qh = xh*mh + hi32(xh*ml) + hi32(xl*mh) with
+    mu63 = floor(2^(63+k)/q) split into 32-bit halves, r = S - qh*q mod 2^64, then conditional subtractions of
+    4q, 2q, q.  Restated with python integers: the estimate is at most 5 short of floor(S/q) and never above it, so
+    r < 8q and three conditional subtractions finish the job -- for 31..60-bit primes, random and extreme S
+    (0, q-1, q, 8q^2-1, products of (q-1)s as the tensor product and the key switch form them)."""
+    import random
+    rnd = random.Random(5)
+
+    def red(S, q):
+        k = q.bit_length()
+        mu63 = (1 << (63 + k)) // q
+        assert mu63 < (1 << 64)
+        xt = S >> (k - 1)
+        assert xt < (1 << 64)
+        xl, xh = xt & 0xffffffff, xt >> 32
+        ml, mh = mu63 & 0xffffffff, mu63 >> 32
+        qh = (xh * mh + ((xh * ml) >> 32) + ((xl * mh) >> 32)) & ((1 << 64) - 1)
+        true_q = S // q
+        assert true_q - 5 <= qh <= true_q, (S, q, true_q - qh)
+        r = (S - qh * q) & ((1 << 64) - 1)
+        assert r == S - qh * q and r < 8 * q
+        for m in (4 * q, 2 * q, q):
+            if r >= m:
+                r -= m
+        return r
+    for bits, m in ((60, 32768), (59, 65536), (56, 32768), (49, 16384), (36, 16384), (31, 4096)):
+        g = O.PrimeGen(bits, m)
+        for _ in range(3):
+            q = g.next()
+            edge = [0, 1, q - 1, q, q + 1, 8 * q * q - 1, (q - 1) * (q - 1), 2 * (q - 1) * (q - 1), 7 * (q - 1) * (q - 1) + q - 1]
+            for S in edge + [rnd.randrange(8 * q * q) for _ in range(4000)]:
+                assert red(S, q) == S % q
