@@ -502,6 +502,7 @@ class KeySwitch:
         self.ndig = b.shape[0]
         self.h = C.c_void_p()
         self.context = context
+        self.row_idx = [int(i) for i in row_idx]
         _chk(lib().hx_ksk_create(context.h, self.ndig, _p(idx), len(idx), _p(b), _p(a),
                                  C.byref(self.h)))
 
@@ -681,3 +682,23 @@ def tensorBringToSet(c0, c1, d0, d1, add_set, keep_set, ptxtSpace, norms=False, 
     _chk(lib().hx_tensor_bring_to_set_norms(c0.h, c1.h, d0.h, d1.h, outs[0].h, outs[1].h, outs[2].h, _p(a), len(add),
                                             _p(d), len(drop), int(ptxtSpace), _p(nrm)))
     return outs, nrm
+
+
+def mulRelin(c0, c1, d0, d1, W, digits, norms=False, defer=False):
+    """Ctxt::tensorProduct + Ctxt::reLinearize at the full level of the matrix W with the product parts formed inside
+    the key-switch kernels (hx_mul_relin[_norms]); the operands' primes must be W's leading rows.  norms=True also
+    returns the [ndigits, batch] array of reLinearize (embeddingLargestCoeff(digit) / P_digit)."""
+    ctx = c0.context
+    dig_idx = _i32([p for d in digits for p in d])
+    dig_off = _i32(np.concatenate([[0], np.cumsum([len(d) for d in digits])]))
+    out0 = DoubleCRT(ctx, c0.getIndexSet(), c0.batch, zero=False)
+    out1 = DoubleCRT(ctx, c0.getIndexSet(), c0.batch, zero=False)
+    if not norms:
+        _chk(lib().hx_mul_relin(c0.h, c1.h, d0.h, d1.h, W.h, _p(dig_idx), _p(dig_off), len(digits), out0.h, out1.h))
+        return out0, out1
+    nrm = np.zeros((len(digits), c0.batch), dtype=np.float64)
+    ctx.deferNorms(defer)
+    ctx.keepUntilFlush(nrm)
+    _chk(lib().hx_mul_relin_norms(c0.h, c1.h, d0.h, d1.h, W.h, _p(dig_idx), _p(dig_off), len(digits), out0.h, out1.h,
+                                  _p(nrm)))
+    return out0, out1, nrm

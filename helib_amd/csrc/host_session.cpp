@@ -85,7 +85,13 @@ extern "C" int hxh_session_create(hxh_session** out, int device, void* stream, i
     s->sk->GenSecKey(2);   // s^2 -> s: what multiplyBy relinearises with (benchmarks/bgv_basic.cpp:150-152)
     const size_t N = (size_t)cc.phim, L = cc.ctxtPrimes.size(), B = (size_t)batch;
     uint64_t ps = seed * 0x9e3779b97f4a7c15ull + 12345;
-    const double f = std::ldexp(1.0, (int)r);
+    // CKKS: the factor PubKey::Encrypt(Ptxt<CKKS>) encodes with, EncryptedArrayCx::encodeScalingFactor() / size with
+    // size = 1 (2^11 at m = 65536, precision(1); 2^30 at precision(20))
+    const double f = ckks ? (double)cc.encodeScalingFactor() : 1.0;
+    // ... and real coefficients uniform in +-1 / (8 sqrt(phi(m)/3)): the canonical embedding of such a polynomial
+    // stays below 1 (eight standard deviations of a slot value), the size the encryption declares; slot encoding
+    // itself (EncryptedArrayCx::encode) is not on this path
+    const double amp = 1.0 / (8.0 * std::sqrt((double)cc.phim / 3.0));
     std::vector<uint64_t> packed[2][2];   // [operand][part] : [row][b][N]
     for (int j = 0; j < 2; j++) {
       s->ptxt[j].resize(B * N);
@@ -95,8 +101,7 @@ extern "C" int hxh_session_create(hxh_session** out, int device, void* stream, i
         std::vector<long> msg(N);
         for (size_t i = 0; i < N; i++) {
           if (ckks) {
-            // reals in [-1, 1] / phi(m): canonical embedding at most 1 (benchmarks/ckks_basic.cpp fills slots with small reals)
-            const double v = ((double)(sm64(ps) >> 11) / 9007199254740992.0 * 2.0 - 1.0) / (double)N;
+            const double v = ((double)(sm64(ps) >> 11) / 9007199254740992.0 * 2.0 - 1.0) * amp;
             msg[i] = (long)std::llrint(v * f);
             s->ptxt[j][b * N + i] = (double)msg[i] / f;
           } else {

@@ -395,6 +395,22 @@ class ChainContext:
     def noiseBoundForUniform(self, magBound, degBound):
         return self.scale * math.sqrt(degBound / 3.0) * magBound
 
+    def encodeRoundingError(self):
+        """EncryptedArrayCx::encodeRoundingError (include/helib/EncryptedArray.h:1287-1297)"""
+        return self.noiseBoundForUniform(0.5, self.phim)
+
+    def encodeScalingFactor(self, precision=-1, roundErr=-1.0):
+        """EncryptedArrayCx::encodeScalingFactor (include/helib/EncryptedArray.h:1299-1312): the factor CKKS
+        plaintexts are scaled by before rounding -- ceil(precision * roundErr) rounded up to a power of two, with
+        precision defaulting to 2^r of ContextBuilder<CKKS>::precision(r).  (m = 65536: 2^11 at precision(1),
+        2^30 at precision(20).)"""
+        if precision <= 0:
+            precision = 1 << self.r
+        if roundErr < 0:
+            roundErr = self.encodeRoundingError()
+        f = int(math.ceil(precision * roundErr))
+        return 1 << max(f - 1, 0).bit_length()       # NTL::NextPowerOfTwo
+
     def noiseBoundForMod(self, modulus, degBound):
         var = modulus * modulus / 12.0 + (1.0 / 6.0 if modulus % 2 == 0 else 0.0)
         return self.scale * math.sqrt(degBound * var)
@@ -424,6 +440,7 @@ class Ctxt:
     """BGV ciphertext: parts keyed by secret-key handle ("1", "s", "s2")."""
     safety = LN2  # src/Ctxt.cpp:39
     measure = True  # measured added noise (the reference's default) when the backend supports it
+    lazyTensor = True  # multiplyBy leaves the tensor product to the mod-switch / key-switch kernels (tests A/B this)
 
     def __init__(self, context, ops, ksw=None, ksw_ptxtSpace=None, ksw_noise=None):
         self.context, self.ops = context, ops
@@ -434,6 +451,11 @@ class Ctxt:
         self.ksw_pow = {}      # r -> key-switching matrix from s^r to s, r >= 3 (r = 2 is self.ksw)
         self.ksw_map = None    # PubKey::keySwitchMap: k -> first step n on the way to X -> X^k (0: none)
         self.parts = {}
+        # multiplyBy only (as the C++ host's Ctxt::pendingTensor): the tensor product's bookkeeping is done, its
+        # data not yet -- the four operand parts wait here while `parts` holds the three product handles with no
+        # storage; the mod-switch or the key switch that follows forms the product inside its own kernels
+        # (ops.tensorBringToSet / ops.mulRelin), anything else calls _materializeTensor() first
+        self._pendT = None
         self.primeSet = frozenset()
         self.ptxtSpace = context.ptxtSpace
         self.intFactor = 1
@@ -452,6 +474,7 @@ class Ctxt:
         return c
 
     def clone(self):
+        self._materializeTensor()
         c = Ctxt(self.context, self.ops, self.ksw, self.ksw_ptxtSpace, self.ksw_lnNoise)
         c.parts = {h: p.copy() for h, p in self.parts.items()}
         c.primeSet, c.ptxtSpace = self.primeSet, self.ptxtSpace
@@ -471,7 +494,8 @@ class Ctxt:
     def lnNoise(self):
         if self._pending:
             if hasattr(self.ops, "normsFlush") and self.parts:
-                self.ops.normsFlush(next(iter(self.parts.values())))
+                some = self._pendT[0] if self._pendT is not None else next(iter(self.parts.values()))
+                self.ops.normsFlush(some)
             todo, self._pending = self._pending, []
             for fn in todo:
                 fn()
@@ -489,6 +513,14 @@ class Ctxt:
         else:
             fn()
 
+    def _materializeTensor(self):
+        """the pending tensor product's data, now (Ctxt::tensorProduct's DoubleCRT work, src/Ctxt.cpp:1576-1597)"""
+        if self._pendT is None:
+            return
+        t, self._pendT = self._pendT, None
+        t0, t1, t2 = self.ops.tensorProduct(*t)
+        self.parts = {"1": t0, "s": t1, "s2": t2}
+
     # ---- bookkeeping ----
     def logOfPrimeSet(self):
         return self.context.logOfProduct(self.primeSet)
@@ -504,6 +536,7 @@ class Ctxt:
         diff = sorted(frozenset(s) - self.primeSet)
         if not diff:
             return
+        self._materializeTensor()
         for p in self.parts.values():
             p.addPrimesAndScale(diff)
         self.lnNoise += self.context.logOfProduct(diff)
@@ -540,10 +573,24 @@ class Ctxt:
         norms have been read back (Ctxt.lnNoise does) -- else the bound."""
         a = cts[0]
         ops, meas, ptxt = a.ops, a._meas, a.ptxtSpace
-        parts = [p for c in cts for p in c.parts.values()]
         kw = {"norms": True, "defer": True} if meas else {}
-        if add:
+        pend = None
+        if len(cts) == 1 and a._pendT is not None:   # the tensor product is formed inside this mod-switch
+            pend, a._pendT = a._pendT, None
+        else:
+            for c in cts:
+                c._materializeTensor()
+        parts = [p for c in cts for p in c.parts.values()]
+        if pend is not None:
+            res = ops.tensorBringToSet(*pend, list(add), keep, ptxt, **kw)
+            outs, norms = res if meas else (res, None)
+            a.parts = {"1": outs[0], "s": outs[1], "s2": outs[2]}
+        elif add and hasattr(ops, "bringToSetMulti"):
             norms = ops.bringToSetMulti(parts, add, keep, ptxt, **kw)
+        elif add:
+            for p in parts:
+                p.addPrimesAndScale(list(add))
+            norms = [p.scaleDownToSet(keep, ptxt, **({"norms": True} if meas else {})) for p in parts]
         elif hasattr(ops, "scaleDownToSetMulti"):
             norms = ops.scaleDownToSetMulti(parts, keep, ptxt, **kw)
         else:
@@ -562,7 +609,7 @@ class Ctxt:
     @timing.timed
     def bringToSet(self, s):
         s = frozenset(s) if s else frozenset([self.context.ctxtPrimes[0]])
-        if hasattr(self.ops, "bringToSetMulti"):
+        if hasattr(self.ops, "bringToSetMulti") or self._pendT is not None:
             Ctxt._bringManyToSet([self], s)
             return
         self.modUpToSet(s)
@@ -580,9 +627,12 @@ class Ctxt:
         if not inter:
             raise RuntimeError(f"modDownToSet called from {sorted(up)} to {sorted(s)}")
         diff = up - inter
-        added = Ctxt._modDownParts(cts, sorted(inter), add=add or ())
         if not add and not diff:
             return
+        if not diff:        # a pure mod-up: no mod-switch kernel to form a pending product in
+            for c in cts:
+                c._materializeTensor()
+        added = Ctxt._modDownParts(cts, sorted(inter), add=add or ())
         for c, ad in zip(cts, added):
             c.lnNoise += c.context.logOfProduct(add)
             c.lnRatFactor += c.context.logOfProduct(add) - c.context.logOfProduct(diff)
@@ -825,7 +875,7 @@ class Ctxt:
         return hi - 4 * LN2, hi
 
     @timing.timed
-    def multLowLvl(self, other, destructive=False):
+    def multLowLvl(self, other, destructive=False, lazyTensor=False):
         o = other if destructive else other.clone()
         ckks = self.context.ckks
         if ckks:
@@ -846,15 +896,21 @@ class Ctxt:
         else:
             self.bringToSet(common)
             o.bringToSet(common)
-        self._tensorProduct(o)
+        self._tensorProduct(o, lazyTensor)
 
-    def _tensorProduct(self, o):
+    def _tensorProduct(self, o, lazy=False):
         if self.ptxtSpace > 2:
             q = self.context.productOfPrimes(self.primeSet) % self.ptxtSpace
             self.intFactor = self.intFactor * o.intFactor % self.ptxtSpace * q % self.ptxtSpace
         if set(self.parts) == {"1", "s"} and set(o.parts) == {"1", "s"}:
-            t0, t1, t2 = self.ops.tensorProduct(self.parts["1"], self.parts["s"], o.parts["1"], o.parts["s"])
-            self.parts = {"1": t0, "s": t1, "s2": t2}
+            four = (self.parts["1"], self.parts["s"], o.parts["1"], o.parts["s"])
+            if lazy and Ctxt.lazyTensor and hasattr(self.ops, "tensorBringToSet"):
+                # the product's data is left to the kernels that consume it (include/helib_amd_ctxt.hpp, pendingTensor)
+                self._pendT = four
+                self.parts = {"1": None, "s": None, "s2": None}
+            else:
+                t0, t1, t2 = self.ops.tensorProduct(*four)
+                self.parts = {"1": t0, "s": t1, "s2": t2}
         else:   # any parts (src/Ctxt.cpp:1576-1597): all pairwise products, accumulated by handle
             new = {}
             for h1, p1 in self.parts.items():
@@ -884,6 +940,7 @@ class Ctxt:
         if not other:
             return
         if len(other) > 1:
+            self._materializeTensor()
             return self._reLinearizeMany(other)
         hnd = other[0]
         W = self._matrixFor(hnd)
@@ -891,6 +948,17 @@ class Ctxt:
         self.dropSmallAndSpecialPrimes()
         self._relin_CKKS_adjust()
         sp = list(ctx.specialPrimes)
+        # No mod-switch consumed a pending tensor product (a fresh CKKS product, a product at a level that needs
+        # none): at the full level the key switch takes the operands themselves (ops.mulRelin = hx_mul_relin);
+        # otherwise the product is formed now.
+        pend = None
+        if self._pendT is not None:
+            cp = list(ctx.ctxtPrimes)
+            if (hasattr(self.ops, "mulRelin") and self._pendT[0].getIndexSet() == cp and frozenset(cp) == self.primeSet
+                    and list(getattr(W, "row_idx", ())) == cp + sp):
+                pend, self._pendT = self._pendT, None
+            else:
+                self._materializeTensor()
         logProd = ctx.logOfProduct(sp)
         self.lnRatFactor += logProd                              # CKKS factor after mod-up (:757)
         # digits of the context restricted to the current prime set (src/DoubleCRT.cpp:485-493)
@@ -899,8 +967,11 @@ class Ctxt:
         if self.ptxtSpace > 1:   # g == 1 for CKKS
             self.ptxtSpace = math.gcd(self.ptxtSpace, self.ksw_ptxtSpace)
             self.intFactor %= self.ptxtSpace
-        res = self.ops.reLinearize(self.parts["1"], self.parts.get("s"), self.parts[hnd], W,
-                                   digits, sp, **({"norms": True, "defer": True} if self._meas else {}))
+        kw = {"norms": True, "defer": True} if self._meas else {}
+        if pend is not None:
+            res = self.ops.mulRelin(*pend, W, digits, **kw)
+        else:
+            res = self.ops.reLinearize(self.parts["1"], self.parts.get("s"), self.parts[hnd], W, digits, sp, **kw)
         o0, o1 = res[0], res[1]
 
         # noise: scaled parts + key-switch added noise (src/Ctxt.cpp:746, 827-841)
@@ -1044,6 +1115,7 @@ class Ctxt:
         log_phim = max(math.log(ctx.phim), 1.0)
         gamma = 8.0 * int(ctx.scale) * math.sqrt(ctx.phim * log_phim * h / 12.0)
         if math.log(gamma) > self.lnNoise:
+            self._materializeTensor()
             xf = int(math.ceil(math.exp(math.log(gamma) - self.lnNoise)))
             for p in self.parts.values():
                 p.mulConstant(xf)
@@ -1105,8 +1177,9 @@ class Ctxt:
 
     @timing.timed
     def multiplyBy(self, other):
-        self.multLowLvl(other)
+        self.multLowLvl(other, lazyTensor=True)
         self.reLinearize()
+        self._materializeTensor()
         return self
 
     # ---- plaintext constants ----

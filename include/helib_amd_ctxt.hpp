@@ -334,6 +334,21 @@ public:
   {
     return scale * std::sqrt(degBound / 3.0) * magBound;
   }
+  // EncryptedArrayCx::encodeRoundingError / encodeScalingFactor (include/helib/EncryptedArray.h:1287-1312): the
+  // factor CKKS plaintexts are scaled by before rounding -- ceil(precision * roundErr) rounded up to a power of
+  // two, precision defaulting to 2^r of ContextBuilder<CKKS>::precision(r)
+  double encodeRoundingError() const { return noiseBoundForUniform(0.5, phim); }
+  long encodeScalingFactor(long precision = -1, double roundErr = -1.0) const
+  {
+    if (precision <= 0)
+      precision = 1L << r;
+    if (roundErr < 0)
+      roundErr = encodeRoundingError();
+    long f = (long)std::ceil((double)precision * roundErr), k = 0;
+    while ((1L << k) < f)   // NTL::NextPowerOfTwo
+      k++;
+    return 1L << k;
+  }
   double noiseBoundForMod(long modulus, long degBound) const
   {
     double var = (double)modulus * modulus / 12.0 + (modulus % 2 == 0 ? 1.0 / 6.0 : 0.0);

@@ -102,6 +102,26 @@ class OracleOps:
         t = self.o.tensor(c0.idx, c0.rows, c1.rows, d0.rows, d1.rows)
         return [OPoly(self.o, c0.idx, x) for x in t]
 
+    def tensorBringToSet(self, c0, c1, d0, d1, add_set, keep_set, ptxtSpace, norms=False, defer=False):
+        """The reference's own sequence for what the device fuses: Ctxt::tensorProduct (src/Ctxt.cpp:1563-1608), then
+        per product part addPrimesAndScale(add) and scaleDownToSet(keep) (Ctxt::bringToSet, :346-562)."""
+        outs = self.tensorProduct(c0, c1, d0, d1)
+        add = [i for i in add_set if i not in c0.idx]
+        nrm = []
+        for t in outs:
+            if add:
+                t.addPrimesAndScale(add)
+            r = t.scaleDownToSet(keep_set, ptxtSpace, norms=norms)
+            if norms:
+                nrm.append(r)
+        return (outs, np.array(nrm).reshape(3, 1)) if norms else outs
+
+    def mulRelin(self, c0, c1, d0, d1, W, digits, norms=False, defer=False):
+        """Ctxt::tensorProduct followed by Ctxt::reLinearize at the full level (src/Ctxt.cpp:1563-1608, :720-786)"""
+        t = self.tensorProduct(c0, c1, d0, d1)
+        sp = W.row_idx[len(c0.idx):]
+        return self.reLinearize(t[0], t[1], t[2], W, digits, sp, norms=norms)
+
     @staticmethod
     def supportsNorms(m):
         return True

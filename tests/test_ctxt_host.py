@@ -143,6 +143,63 @@ def test_multiplyBy_full_sequence_decrypts(m, p, bits):
     assert decrypt(ctx, octx, s, ca, rows) == want
 
 
+@pytest.mark.parametrize("m,p,bits", [(128, 257, 150), (64, 65537, 250)])
+def test_multiplyBy_leaves_the_tensor_product_to_its_consumer(m, p, bits, monkeypatch):
+    """Ctxt.multiplyBy parks the tensor product (as the C++ host's pendingTensor) and hands the operand parts to
+    ops.tensorBringToSet (a mod-switch follows) or ops.mulRelin (none does): the calls are seen, tensorProduct is
+    not, and the result -- parts, prime set, intFactor, noise estimate -- equals the eager sequence's word for word,
+    at level 1 and at level 2 (operands that carry the special primes)."""
+    ctx = hc.ChainContext(m, p, 1, bits=bits, c=3)
+    octx = O.Ctx(m)
+    for q in ctx.primes:
+        octx.add_prime(q)
+    s, allp, kb, ka, rows = make_keys(ctx, octx)
+    W = OKeySwitch(allp, kb, ka)
+    rng = np.random.default_rng(19)
+    ma, mb = rng.integers(0, p, size=octx.N), rng.integers(0, p, size=octx.N)
+    ea, eb = encrypt(ctx, octx, s, ma, 1, rows), encrypt(ctx, octx, s, mb, 2, rows)
+
+    class Spy(OracleOps):
+        def __init__(self, o):
+            super().__init__(o)
+            self.calls = []
+
+        def tensorProduct(self, *a):
+            self.calls.append("tensorProduct")
+            return super().tensorProduct(*a)
+
+        def tensorBringToSet(self, *a, **k):
+            self.calls.append("tensorBringToSet")
+            return OracleOps.tensorBringToSet(OracleOps(self.o), *a, **k)
+
+        def mulRelin(self, *a, **k):
+            self.calls.append("mulRelin")
+            return OracleOps.mulRelin(OracleOps(self.o), *a, **k)
+
+    def run(lazy):
+        monkeypatch.setattr(hc.Ctxt, "lazyTensor", lazy)
+        ops = Spy(octx)
+        ca = hc.Ctxt.fresh(ctx, ops, *(OPoly(octx, ctx.ctxtPrimes, x) for x in ea), ksw=W)
+        cb = hc.Ctxt.fresh(ctx, ops, *(OPoly(octx, ctx.ctxtPrimes, x) for x in eb), ksw=W)
+        ca.multiplyBy(cb)
+        l1 = ca.clone()
+        ca.multiplyBy(l1)
+        return ops.calls, l1, ca
+
+    calls_lazy, a1, a2 = run(True)
+    calls_eager, b1, b2 = run(False)
+    assert "tensorProduct" not in calls_lazy and len(calls_lazy) == 2 and set(calls_lazy) <= {"tensorBringToSet", "mulRelin"}
+    assert calls_eager == ["tensorProduct", "tensorProduct"]
+    for x, y in ((a1, b1), (a2, b2)):
+        assert x._pendT is None and x.primeSet == y.primeSet and x.intFactor == y.intFactor
+        assert abs(x.lnNoise - y.lnNoise) < 1e-12
+        for h in ("1", "s"):
+            assert x.parts[h].getIndexSet() == y.parts[h].getIndexSet()
+            assert np.array_equal(x.parts[h].rows, y.parts[h].rows)
+    want = B.polymul_mod_phi(ma, mb, m, p)
+    assert decrypt(ctx, octx, s, a1, rows) == [int(v) for v in want]
+
+
 def plain_automorph(msg, m, k, p):
     """F(X) -> F(X^k) mod (Phi_m, p) on coefficient vectors, through the evaluation rows of a
     prime the oracle knows (any prime works: the map is the same permutation of evaluations)."""

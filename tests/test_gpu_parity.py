@@ -592,19 +592,58 @@ def test_ctxt_multiplyBy_full_sequence_gpu_vs_oracle(hx, m, p, bits, monkeypatch
         assert got == T.decrypt(ctx, P.o, s, oa, rows)
 
 
+class FusedCallSpy:
+    """Wraps the backend module's fused entry points for one test: records every hx.tensorBringToSet / hx.mulRelin
+    call of the host logic with its shape (operand primes, added, dropped, kept, batch) and fails the test if the
+    unfused hx.tensorProduct runs -- i.e. it pins WHICH device path a ciphertext-level parity test went through."""
+
+    def __init__(self, hx, monkeypatch, allow_tensor=False):
+        self.calls = []
+        tb, mr, tp = hx.tensorBringToSet, hx.mulRelin, hx.tensorProduct
+
+        def tensorBringToSet(c0, c1, d0, d1, add, keep, ptxt, **kw):
+            own = c0.getIndexSet()
+            a = [i for i in add if i not in own]
+            self.calls.append(("tensorBringToSet", dict(own=own, add=a, drop=[i for i in own + a if i not in set(keep)],
+                                                        nkeep=len(set(keep)), batch=c0.batch)))
+            return tb(c0, c1, d0, d1, add, keep, ptxt, **kw)
+
+        def mulRelin(c0, c1, d0, d1, W, digits, **kw):
+            self.calls.append(("mulRelin", dict(own=c0.getIndexSet(), batch=c0.batch)))
+            return mr(c0, c1, d0, d1, W, digits, **kw)
+
+        def tensorProduct(*a):
+            assert allow_tensor, "the unfused tensor product ran: the host did not take the fused path"
+            return tp(*a)
+
+        monkeypatch.setattr(hx, "tensorBringToSet", tensorBringToSet)
+        monkeypatch.setattr(hx, "mulRelin", mulRelin)
+        monkeypatch.setattr(hx, "tensorProduct", tensorProduct)
+
+    def names(self):
+        return [c[0] for c in self.calls]
+
+
 @pytest.mark.parametrize("bits,B", [(950, 4)])
 def test_fresh_multiplyBy_at_the_benchmarked_shape_batched(hx, bits, B, monkeypatch):
-    """bench.py's own step, bit-exact: BASELINE configs[2] (m=32768, p=65537, bits=950 -> L=16, K=6,
-    D=3), the FRESH multiplyBy sequence of src/Ctxt.cpp:1681-1774 over a batch of B DISTINCT
-    ciphertext pairs in one set of launches -- hx_bring_to_set_multi at nkeep=16 (the mod-down
-    apply kernel's g=2 row-group tile, csrc/ntt_kernels.hip md_tile) and hx_mul_relin batched.  The
-    oracle runs the same host logic once per batch element; EVERY part, row and batch element is
-    compared, and every element decrypts to its plaintext product."""
+    """bench.py's own step through the kernels bench.py times, bit-exact: BASELINE configs[2] (m=32768, p=65537,
+    bits=950 -> L=16, K=6, D=3), the FRESH multiplyBy sequence of src/Ctxt.cpp:1681-1774 over a batch of B DISTINCT
+    ciphertext pairs in one set of launches, driven by helib_amd.ctxt -- which, like the C++ host of the timed loop,
+    leaves the tensor product to its consumer: hx_bring_to_set_multi of the four operand parts (add 1 small prime,
+    drop 1 ctxt prime), then hx_tensor_bring_to_set_norms (ntt_moddown_prep_tensor_kernel +
+    ntt_moddown_apply_tensor_kernel<14,false> at nkeep = 16, the md_tile g=2 launch of the bench), then
+    hx_relinearize.  Then LEVEL 2, the product times itself (operands that carry the special primes):
+    the several-primes mod-switch of the operands and hx_tensor_bring_to_set_norms in its several-primes form
+    (ntt_moddown_prep_multi_tensor_kernel + ntt_moddown_apply_tensor_kernel<14,true>).  The call spy pins that
+    these entry points -- and never hx_tensor -- ran, with the shapes named above.  The oracle runs the same host
+    logic once per batch element over the reference's unfused sequence (oracle/backend.py); EVERY part, row and
+    batch element is compared at both levels, and every element decrypts to its plaintext product."""
     from helib_amd import ctxt as hc
     from tests import test_ctxt_host as T
     from oracle.backend import OKeySwitch, OPoly, OracleOps
     m, p = 32768, 65537
     monkeypatch.setattr(hc.Ctxt, "measure", True)
+    spy = FusedCallSpy(hx, monkeypatch)
     ctx = hc.ChainContext(m, p, 1, bits=bits, c=3)
     assert len(ctx.ctxtPrimes) == 16 and len(ctx.specialPrimes) == 6 and len(ctx.digits) == 3
     P = Pair(hx, m, ctx.primes)
@@ -625,26 +664,97 @@ def test_fresh_multiplyBy_at_the_benchmarked_shape_batched(hx, bits, B, monkeypa
         return [hx.DoubleCRT(P.g, ctx.ctxtPrimes, B, np.stack([enc[j][b][k] for b in range(B)], axis=1))
                 for k in range(2)]
 
+    def same(gc, ocs):
+        for h in ("1", "s"):
+            gi = gc.parts[h].getIndexSet()
+            gd = gc.parts[h].download()
+            assert gd.shape[1] == B
+            for b in range(B):
+                oi, od = ocs[b].parts[h].getIndexSet(), ocs[b].parts[h].download()[:, 0]
+                assert sorted(gi) == sorted(oi)
+                for r, i in enumerate(gi):
+                    assert np.array_equal(gd[r, b], od[oi.index(i)]), (h, i, b)
+
     ga = hc.Ctxt.fresh(ctx, hx, *batched(0), ksw=gW)
     gb = hc.Ctxt.fresh(ctx, hx, *batched(1), ksw=gW)
     ga.multiplyBy(gb)
+    # the device path taken: the product formed inside the single-prime mod-switch at nkeep = 16
+    assert spy.names() == ["tensorBringToSet"]
+    shape = spy.calls[0][1]
+    assert (len(shape["own"]), len(shape["add"]), len(shape["drop"]), shape["nkeep"], shape["batch"]) == (16, 1, 1, 16, B)
     # the batch shares one prime-set decision: the estimate is the maximum over its elements
     assert all(ga.primeSet == o.primeSet and ga.intFactor == o.intFactor for o in outs)
     on = [o.lnNoise for o in outs]
     assert max(on) - 1e-6 <= ga.lnNoise <= max(on) + 0.05
-    for h in ("1", "s"):
-        gi = ga.parts[h].getIndexSet()
-        gd = ga.parts[h].download()
-        assert gd.shape[1] == B
-        for b in range(B):
-            oi, od = outs[b].parts[h].getIndexSet(), outs[b].parts[h].download()[:, 0]
-            assert sorted(gi) == sorted(oi)
-            for r, i in enumerate(gi):
-                assert np.array_equal(gd[r, b], od[oi.index(i)]), (h, i, b)
+    same(ga, outs)
     for b in range(B):
         full = np.convolve(msgs[0, b].astype(np.int64), msgs[1, b].astype(np.int64))
         want = (full[:P.N] - np.append(full[P.N:], 0)) % p
         assert T.decrypt(ctx, P.o, s, outs[b], rows) == [int(v) for v in want]
+    # level 2: (a*b)^2, every element with the batch's estimate (its prime-set decisions are the batch's)
+    worst = ga.lnNoise
+    for o in outs:
+        o.lnNoise = worst
+    ga.multiplyBy(ga.clone())
+    for o in outs:
+        o.multiplyBy(o.clone())
+    assert spy.names() == ["tensorBringToSet", "tensorBringToSet"]
+    shape = spy.calls[1][1]
+    assert len(shape["drop"]) >= 2 and shape["nkeep"] == 16 and shape["batch"] == B, shape   # the several-primes form
+    assert all(ga.primeSet == o.primeSet and ga.intFactor == o.intFactor for o in outs)
+    same(ga, outs)
+
+
+BENCH_SHAPES = {
+    # the tensorBringToSet calls of the benchmark loops, as helib_amd.ctxt / the C++ host issue them (pinned by the
+    # call spies of test_fresh_multiplyBy_at_the_benchmarked_shape_batched and the CKKS chain tests):
+    # name: (scheme, m, p or precision, bits, own rows, add, drop, batch); c = ctxt primes, s = small primes by position
+    "bgv950_level1": ("bgv", 32768, 65537, 950, "c[:15] + [s[4]]", "[c[15]]", "[s[4]]", 4),
+    "bgv950_level2": ("bgv", 32768, 65537, 950, "c[:14] + s[0:2]", "c[14:16]", "s[0:2]", 4),
+    "ckks1400_level2": ("ckks", 65536, 20, 1400, "c[:21] + [s[0], s[2], s[3]]", "c[21:23]", "[s[0], s[2], s[3]]", 2),
+    "ckks1400_precision1_level2": ("ckks", 65536, 1, 1400, "c[:22] + s[2:4]", "c[22:24]", "s[2:4]", 2),
+    "ckks440_level2": ("ckks", 65536, 1, 440, "c[:6] + s[2:4]", "c[6:8]", "s[2:4]", 2),
+}
+
+
+@pytest.mark.parametrize("name", list(BENCH_SHAPES))
+def test_tensor_folded_into_the_mod_switch_at_the_benchmarked_shapes(hx, name):
+    """hx_tensor_bring_to_set_norms at the launch shapes of the timed loops (bench.py; benchmarks/bgv_basic.cpp:144-165,
+    benchmarks/ckks_basic.cpp:161-180 on the chains of bits = 950 / 1400 / 440): the real chain's primes (60-bit
+    ctxt primes next to 40..57-bit small primes), operand rows in the order the host leaves them, nkeep = 16 (BGV:
+    the md_tile g=2 tile of ntt_moddown_apply_tensor_kernel<14,*>) / 23 and 8 (CKKS, <15,true>), every word of every
+    batch element of the three product parts against (a) hx_tensor + hx_bring_to_set_multi on the device and (b) the
+    oracle's tensor product, addPrimesAndScale and scaleDownToSet; the measured norms against each other."""
+    from helib_amd import ctxt as hc
+    scheme, m, pr, bits, own_e, add_e, drop_e, B = BENCH_SHAPES[name]
+    ctx = hc.ChainContext(m, 65537, 1, bits=bits, c=3) if scheme == "bgv" else \
+        hc.ChainContext(m, -1, pr, bits=bits, c=3, ckks=True)
+    env = {"c": list(ctx.ctxtPrimes), "s": list(ctx.smallPrimes)}
+    own, add, drop = (list(eval(e, env)) for e in (own_e, add_e, drop_e))
+    ptxt = 65537 if scheme == "bgv" else 1
+    keep = [i for i in own + add if i not in drop]
+    P = Pair(hx, m, ctx.primes)
+    ops = [P.rand(own, 900 + i, batch=B) for i in range(4)]
+    c0, c1, d0, d1 = (hx.DoubleCRT(P.g, own, B, x) for x in ops)
+    fused, nf = hx.tensorBringToSet(c0, c1, d0, d1, add, keep, ptxt, norms=True)
+    t = list(hx.tensorProduct(c0, c1, d0, d1))
+    ns = hx.bringToSetMulti(t, add, keep, ptxt, norms=True)
+    assert np.allclose(nf, ns, rtol=1e-12, atol=0)
+    for part in range(3):
+        gi, ti = fused[part].getIndexSet(), t[part].getIndexSet()
+        assert sorted(gi) == sorted(keep) == sorted(ti)
+        gd, td = fused[part].download(), t[part].download()
+        for r, i in enumerate(gi):
+            assert np.array_equal(gd[r], td[ti.index(i)]), (part, i)
+    fd = [f.download() for f in fused]
+    for b in range(B):
+        w = P.o.tensor(own, ops[0][:, b], ops[1][:, b], ops[2][:, b], ops[3][:, b])
+        for part in range(3):
+            up = np.vstack([P.o.scale_by_primes(own, w[part], add)] + [np.zeros((1, P.N), dtype=np.uint64)] * len(add))
+            want = P.o.scale_down(own + add, up, drop, ptxt)
+            gi = fused[part].getIndexSet()
+            for r, i in enumerate(gi):
+                assert np.array_equal(fd[part][r, b], want[keep.index(i)]), (part, i, b)
 
 
 @pytest.mark.parametrize("ptxt", [65537, 2, 1, 4])
@@ -1355,17 +1465,26 @@ def test_ckks_encrypt_multiply_decrypt_gpu_vs_oracle(hx, m, precision, bits, c, 
         assert np.max(np.abs(got - want)) < 2.0 ** (-precision + 6) / n
 
 
-def test_ckks_m65536_chain_batched_bit_exact(hx, monkeypatch):
-    """BASELINE configs[3] as bench.py --workload ckks65536 runs it: m = 65536, bits = 1400 (L = 24, K = 8, D = 3),
-    a BATCH of two distinct CKKSencrypt-ed pairs packed along the batch axis, multiplied at level 1 (fresh x fresh)
-    and level 2 (product x product: the several-primes mod-switch at N = 32768, batched) in one set of launches;
-    the oracle backend runs the same host logic once per pair.  Every part, row and batch element must agree
-    word for word (the prime-set decisions are the batch's: its noise estimate is the largest element's)."""
+@pytest.mark.parametrize("precision,bits,shape", [(20, 1400, (24, 8, 3)), (1, 1400, (24, 8, 3)), (1, 440, (8, 3, 3))])
+def test_ckks_m65536_chain_batched_bit_exact(hx, monkeypatch, precision, bits, shape):
+    """BASELINE configs[3] as bench.py --workload ckks65536 runs it: m = 65536, bits = 1400 (L = 24, K = 8, D = 3) --
+    and the reference's own benchmark parameters, ContextBuilder<CKKS>().m(65536).precision(1).bits(440).scale(10)
+    (benchmarks/ckks_basic.cpp:263, benchmarks/ckks_common.h:45-50: L = 8 primes of 56 bits, K = 3 of 55) --
+    a BATCH of two distinct CKKSencrypt-ed pairs packed along the batch axis, multiplied at level 1 (fresh x fresh:
+    hx_mul_relin_norms, the product formed inside ntt_inv_mul_kernel<15> and the key-switch kernel) and level 2
+    (product x product: the several-primes mod-switch of the operands at N = 32768, then hx_tensor_bring_to_set_norms
+    = ntt_moddown_prep_multi_tensor_kernel + ntt_moddown_apply_tensor_kernel<15,true>) in one set of launches -- the
+    call spy pins these entry points; the oracle backend runs the same host logic once per pair over the
+    reference's unfused sequence.  Every part, row and batch element must agree word for word (the prime-set
+    decisions are the batch's: its noise estimate is the largest element's), and the level-2 result decodes to the
+    real product of the encoded values within the bound the ciphertext reports."""
     from helib_amd import ctxt as hc, keys as hk
     from oracle.backend import OracleBackend
     monkeypatch.setattr(hc.Ctxt, "measure", True)
-    m, precision, B = 65536, 20, 2
-    cc = hc.ChainContext(m, -1, precision, bits=1400, c=3, ckks=True)
+    spy = FusedCallSpy(hx, monkeypatch)
+    m, B = 65536, 2
+    cc = hc.ChainContext(m, -1, precision, bits=bits, c=3, ckks=True)
+    assert (len(cc.ctxtPrimes), len(cc.specialPrimes), len(cc.digits)) == shape
     P = Pair(hx, m, cc.primes)
     gsk = hk.SecKey(cc, hk.HxBackend(P.g, cc), seed=21)
     osk = hk.SecKey(cc, OracleBackend(P.o, cc), seed=21)
@@ -1373,8 +1492,12 @@ def test_ckks_m65536_chain_batched_bit_exact(hx, monkeypatch):
         sk.GenSecKey(maxDegKswitch=2)
     n, L = cc.phim, len(cc.ctxtPrimes)
     rng = np.random.default_rng(9)
-    f = float(1 << precision)
-    vals = rng.uniform(-1, 1, size=(2, B, n)) / n
+    # the factor PubKey::Encrypt(Ptxt<CKKS>) encodes with (EncryptedArrayCx::encodeScalingFactor: 2^11 at
+    # precision(1), 2^30 at precision(20)) and real coefficients whose canonical embedding stays below the declared
+    # size 1 -- the plaintexts of helib_amd/csrc/host_session.cpp
+    f = float(cc.encodeScalingFactor())
+    assert f == {1: 2.0 ** 11, 20: 2.0 ** 30}[precision]
+    vals = rng.uniform(-1, 1, size=(2, B, n)) / (8.0 * math.sqrt(n / 3.0))
     genc = [[gsk.CKKSencrypt(np.rint(vals[j, b] * f).astype(np.int64), 1.0, f) for b in range(B)] for j in range(2)]
     oenc = [[osk.CKKSencrypt(np.rint(vals[j, b] * f).astype(np.int64), 1.0, f) for b in range(B)] for j in range(2)]
     ops = []
@@ -1409,6 +1532,19 @@ def test_ckks_m65536_chain_batched_bit_exact(hx, monkeypatch):
     for o in oenc[0]:
         o.multiplyBy(o.clone())
     same(ga, oenc[0])
+    assert spy.names() == ["mulRelin", "tensorBringToSet"], spy.names()
+    assert len(spy.calls[0][1]["own"]) == shape[0] and spy.calls[0][1]["batch"] == B
+    assert len(spy.calls[1][1]["drop"]) >= 2 and spy.calls[1][1]["batch"] == B
+    # decode (raw / ratFactor) against the real product of the encoded values, within the reported bound
+    for b in range(B):
+        raw = osk.Decrypt(oenc[0][b])
+        got = np.array([float(v) for v in raw]) / math.exp(oenc[0][b].lnRatFactor)
+        x, y = (np.rint(vals[j, b] * f) / f for j in range(2))
+        xy = np.convolve(x, y)
+        xy = xy[:n] - np.append(xy[n:], 0.0)
+        w = np.convolve(xy, xy)
+        want = w[:n] - np.append(w[n:], 0.0)
+        assert np.max(np.abs(got - want)) <= math.exp(oenc[0][b].lnNoise - oenc[0][b].lnRatFactor)
 
 
 @pytest.mark.parametrize("m,L,t", [(16384, 5, 65537), (16384, 3, 2), (128, 4, (1 << 59) + 1), (1705, 3, 49),
