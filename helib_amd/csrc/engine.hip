@@ -2348,6 +2348,11 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   size_t o_pack = take((size_t)nt * pack_stride);
   size_t o_pack2 = take((size_t)nt * pack_stride);   // the same for the HPS front end (rns_kernels.h)
   size_t o_hinv = take((size_t)2 * n), o_Wp2 = take((size_t)2 * n);
+  // rns_extend_wide_kernel (17..40 source primes): per-target record of 8 + n words, padded so that the last
+  // record's group-of-four multiplier reads stay inside the blob
+  const bool wide_cand = n > 16 && n <= 40 && !getenv("HX_NO_WIDE_EXTEND");
+  const size_t wide_stride = 8 + (size_t)n;
+  size_t o_wide = wide_cand ? take((size_t)nt * wide_stride + 4) : 0;
   std::vector<uint64_t> h(off, 0);
   hxh::BigU P(1);
   for (int k = 0; k < n; k++) {
@@ -2456,7 +2461,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   }
   // HPS front end: y_k = a_k (P/p_k)^-1 mod p_k, multipliers (P/p_k) mod t (scaled plans: / P, i.e.
   // p_k^-1 mod t), the same header; "lazy" needs room for up to n + 1 extra multiples of t in the sum
-  bool hps_ok = n >= 2 && n <= 16 && (ptxt <= 1 || ptxt < ((uint64_t)1 << 58)) && !getenv("HX_NO_HPS");
+  bool hps_ok = n >= 2 && (n <= 16 || wide_cand) && (ptxt <= 1 || ptxt < ((uint64_t)1 << (wide_cand ? 56 : 58))) &&
+                (!getenv("HX_NO_HPS") || wide_cand);
   if (hps_ok) {
     auto prod_except = [&](int k, uint64_t m) {   // (P / p_k) mod m
       uint64_t r = 1 % m;
@@ -2476,7 +2482,29 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
         h[o_Wp2 + 2 * (size_t)k + 1] = hxh::shoup(w, ptxt);
       }
     }
-    for (int t = 0; t < nt && hps_ok; t++) {
+    for (int t = 0; t < nt && hps_ok && wide_cand; t++) {
+      // WideRec: q, P mod t (scaled: 1), 2^64 mod t with its Shoup companion, floor(2^64/t), P^-1 mod t with its
+      // companion, the companion of P mod t; then the multipliers (P/p_k) mod t (scaled: / P) as 30-bit limbs
+      const uint64_t q = tq(t);
+      uint64_t* rec = &h[o_wide + (size_t)t * wide_stride];
+      const uint64_t r64 = (uint64_t)((((hxh::u128)1) << 64) % q);
+      rec[0] = q;
+      rec[1] = h[o_pmod + t];
+      rec[2] = r64;
+      rec[3] = hxh::shoup(r64, q);
+      rec[4] = h[o_tmu64 + t];
+      rec[5] = h[o_upd + 2 * (size_t)t];
+      rec[6] = h[o_upd + 2 * (size_t)t + 1];
+      rec[7] = hxh::shoup(h[o_pmod + t], q);
+      const uint64_t pinv_t = h[o_upd + 2 * (size_t)t];   // P^-1 mod t
+      for (int k = 0; k < n; k++) {
+        uint64_t w = prod_except(k, q);
+        if (scaled)
+          w = hxh::mulmod(w, pinv_t, q);
+        rec[8 + k] = (w & 0x3fffffffull) | ((w >> 30) << 32);
+      }
+    }
+    for (int t = 0; t < nt && hps_ok && !wide_cand; t++) {
       const uint64_t q = tq(t);
       const uint64_t* rec = &h[o_pack + (size_t)t * pack_stride];
       uint64_t* rec2 = &h[o_pack2 + (size_t)t * pack_stride];
@@ -2532,6 +2560,11 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
       ok16 = (tq(t) >> 32) != 0;
     pl->dev.fast16_ok = ok16 ? 1u : 0u;
     pl->dev.hps_ok = (hps_ok && ok16) ? 1u : 0u;   // (the front end lives in the fast kernels only)
+    bool okw = wide_cand && hps_ok && (min_src >> 32) != 0 && hxh::bitlen(max_src) <= 60;
+    for (int t = 0; t < nt && okw; t++)
+      okw = (tq(t) >> 32) != 0 && hxh::bitlen(tq(t)) <= 60;
+    pl->dev.wide_ok = okw ? 1u : 0u;
+    pl->dev.wide_pack = hx::as_ro(d + o_wide);
   }
   pl->dev.tgt_chunk7 = hx::as_ro(reinterpret_cast<const uint32_t*>(d + o_tchunk));
   {
@@ -2599,6 +2632,20 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args_in, s
       HX_EXT_FAST(16)
     }
 #undef HX_EXT_FAST
+    HIPCHK(hipGetLastError());
+    return HX_OK;
+  }
+  if (pl->dev.wide_ok && row_words < ((size_t)1 << 32)) {
+    // 17..40 source primes (the reference's own benchmark chain): HPS form, then Garner over the coefficients it
+    // could not vouch for (they were left untouched, so in-place updates are redone correctly too)
+    CHK(redo_prepare(c, row_words, &args.redo));
+    if (n <= 24)
+      HX_LAUNCH((hx::rns_extend_wide_kernel<24>), grid, block, 0, c->stream, pl->dev, args, row_words);
+    else if (n <= 32)
+      HX_LAUNCH((hx::rns_extend_wide_kernel<32>), grid, block, 0, c->stream, pl->dev, args, row_words);
+    else
+      HX_LAUNCH((hx::rns_extend_wide_kernel<40>), grid, block, 0, c->stream, pl->dev, args, row_words);
+    HX_LAUNCH((hx::rns_extend_kernel<40>), REDO_GRID, block, 0, c->stream, pl->dev, args, row_words);
     HIPCHK(hipGetLastError());
     return HX_OK;
   }

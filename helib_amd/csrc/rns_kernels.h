@@ -409,6 +409,8 @@ struct ExtPlanDev {
   ro_tw Wp_hps;        // [n] (P/p_k) mod ptxt
   double hps_eps;
   uint32_t hps_ok;
+  ro_u64 wide_pack;   // [nt][8 + n] rns_extend_wide_kernel's record of one target (WideRec), HPS multipliers
+  uint32_t wide_ok;   // 16 < n <= 40 sources, every prime in (2^32, 2^60), the HPS tables exist
   ro_u64 tgt_pack;    // [nt][8 + 2n] everything the fast kernels need of one target in ONE record
                       // (TgtRec): the loop over targets then makes one scalar-memory round trip per
                       // target instead of one per table (q, P mod t, flags, k, mu, W row: six
@@ -522,12 +524,28 @@ __device__ __forceinline__ double mixed_radix_fraction(const uint64_t (&a)[NMAX]
 }
 
 template <int NMAX>
+__device__ __forceinline__ void rns_extend_one(const ExtPlanDev& P, const ExtArgs& A, size_t row_words, size_t i);
+
+// A.redo given: the listed coefficients only (grid-stride over the list) -- the Garner pass behind the HPS-form
+// rns_extend_wide_kernel, whose untrusted lanes write nothing but their index
+template <int NMAX>
 __global__ void __launch_bounds__(256)
 rns_extend_kernel(ExtPlanDev P, ExtArgs A, size_t row_words /* batch*N */)
 {
+  if (A.redo) {
+    const uint32_t n = A.redo[0];
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x)
+      rns_extend_one<NMAX>(P, A, row_words, A.redo[1 + j]);
+    return;
+  }
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= row_words)
     return;
+  rns_extend_one<NMAX>(P, A, row_words, i);
+}
+template <int NMAX>
+__device__ __forceinline__ void rns_extend_one(const ExtPlanDev& P, const ExtArgs& A, size_t row_words, size_t i)
+{
   const int n = P.n;
   uint64_t a[NMAX];
   // ---- load + Garner ----
@@ -1102,6 +1120,153 @@ __device__ __forceinline__ void rns_extend_fast_one(const ExtPlanDev& P, const E
       uint64_t* u = A.upd + (size_t)A.upd_row[t] * row_words + i;
       const TW pinv = T.upd();
       *u = mul_shoup(sub_mod(*u, r, q), pinv.w, pinv.wp, q);
+    }
+  }
+}
+
+// =====================================================================
+// rns_extend_kernel for MANY source primes (16 < n <= NMAX <= 40: the 36-prime digits and the 36 dropped special
+// primes of the reference's own benchmark chain, bits = 6400 -- benchmarks/bgv_basic.cpp:247), same contract.
+// Garner there is n(n-1)/2 = 630 dependent modular products per coefficient and a non-lazy target costs nine
+// word multiplications per term; this form is O(n) in front and four per term:
+//   * HPS front end only: y_k = x_k (P/p_k)^-1 mod p_k, quotient and sign from the double-precision sum of
+//     y_k / p_k.  A lane that cannot trust them (fraction within hps_eps of 0, 1/2 or 1) appends its coefficient
+//     to the redo list and writes NOTHING -- rns_extend_kernel<NMAX> (Garner) then does the listed coefficients
+//     from the untouched source rows, in-place updates included.
+//   * residues modulo a target: sum_k y_k W_k over 30-bit limbs -- the y limbs stay in registers for all targets,
+//     the W limbs come pre-split from the host (one 64-bit scalar word per term: w0 | w1 << 32) -- four
+//     v_mad_u64_u32 per term into four 64-bit accumulators, flushed into a 128-bit sum every 16 terms (16 products
+//     of < 2^60 fit), then ONE reduction of the whole sum, which is below 2^127 whatever the primes' sizes:
+//     S = H 2^64 + Lo  ->  shoup4(H, 2^64 mod t) + norm(Lo) in [0,5t), three conditional subtractions.
+// n is a run-time value (uniform guards inside a loop unrolled to NMAX), so one instantiation serves every digit
+// size of a chain.
+// =====================================================================
+// (static_for of ntt_core.h: an unrolled loop by construction -- a `#pragma unroll` over 40 iterations of a large
+// body is only partly honoured, and the limb arrays then live in LDS / scratch)
+template <int K, int N>
+__device__ __forceinline__ void pin_limbs(uint32_t (&a)[N], uint32_t (&b)[N])
+{
+  if constexpr (K < N) {
+    asm volatile("" : "+v"(a[K]), "+v"(b[K]));
+    pin_limbs<K + 1, N>(a, b);
+  }
+}
+
+template <int NMAX>   // NMAX a multiple of 4
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
+rns_extend_wide_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= row_words)
+    return;
+  const int n = P.n;
+  uint32_t a0[NMAX], a1[NMAX];
+  double z = 0;
+  const uint64_t p = P.ptxt;
+  uint64_t pacc = 0;
+  static_for<0, NMAX>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    uint32_t lo = 0, hi = 0;
+    if (k < n) {
+      const uint64_t x = ld_stream1(A.src + (size_t)A.src_row[k] * row_words + i);
+      if (A.own_dst_row[k] != 0xffff)
+        st_stream1(A.dst + (size_t)A.own_dst_row[k] * row_words + i, x);
+      const uint64_t pk = P.src_q[k];
+      uint64_t y = shoup4(x, ld_tw(P.hps_inv, k), 0 - pk);  // any 64-bit x -> [0, 4 p_k)
+      y = csub(y, pk + pk);
+      y = csub(y, pk);
+      lo = (uint32_t)y & 0x3fffffffu;
+      hi = (uint32_t)(y >> 30);
+      z += (double)y * P.src_rq[k];
+      if (p > 1) {
+        pacc += shoup_lazy(y, ld_tw(P.Wp_hps, k), p);  // each < 2p
+        if ((k & 3) == 3)
+          pacc = red64(pacc, p, P.ptxt_mu64);
+      }
+    }
+    // (pinned as 32-bit values: the compiler otherwise keeps each limb zero-extended in a register PAIR for the
+    // 64-bit multiply-adds below -- 160 VGPRs of limbs at n = 40)
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    a0[k] = lo;
+    a1[k] = hi;
+  });
+  const double fl = floor(z), f = z - fl, eps = P.hps_eps;
+  if (f < eps || f > 1.0 - eps || fabs(f - 0.5) < eps) {
+    redo_append(A.redo, i);
+    return;
+  }
+  const bool neg = f > 0.5;
+  const uint32_t cnt = (uint32_t)fl + (neg ? 1u : 0u);
+
+  // ---- BGV: make delta divisible by ptxtSpace (src/DoubleCRT.cpp:1485-1508) ----
+  bool dm_nonzero = false, dm_negative = false;
+  uint64_t dm_abs = 0;
+  if (p > 1) {
+    uint64_t r = red64(pacc, p, P.ptxt_mu64);
+    r = sub_mod(r, red64((uint64_t)cnt * P.pmod_ptxt, p, P.ptxt_mu64), p);   // (cnt (P mod ptxt) < 2^63: ptxt < 2^56)
+    if (r != 0) {
+      uint64_t dm = mul_mod(r, P.pinv_ptxt, p, P.ptxt_mu, P.ptxt_k);
+      const uint64_t p_over_2 = p >> 1;
+      bool sub_p = dm > p_over_2 || (((p & 1) == 0) && dm == p_over_2 && neg);
+      dm_nonzero = true;
+      dm_negative = sub_p;
+      dm_abs = sub_p ? p - dm : dm;
+    }
+  }
+  if (A.frac) {
+    double fr = f - (neg ? 1.0 : 0.0);
+    if (dm_nonzero)
+      fr += dm_negative ? (double)dm_abs : -(double)dm_abs;
+    A.frac[i] = fr;
+  }
+  const size_t stride = 8 + (size_t)n;
+  for (int t = 0; t < P.nt; t++) {
+    ro_u64 rec = P.wide_pack + (size_t)t * stride;
+    const uint64_t q = rec[0], pmod = rec[1];
+    TW R64;
+    R64.w = rec[2];
+    R64.wp = rec[3];
+    const uint32_t mu32 = (uint32_t)rec[4];
+    u128 S = (u128)cnt * (q - pmod);   // -P mod t, cnt times: the HPS quotient and the centring
+    // (re-pinned every iteration: a zero-extension hoisted out of this loop would double the limbs' registers)
+    pin_limbs<0, NMAX>(a0, a1);
+    static_for<0, (NMAX + 15) / 16>([&](auto cc) {
+      constexpr int k0 = decltype(cc)::value * 16;
+      if (k0 < n) {
+        uint64_t c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+        static_for<0, (k0 + 16 < NMAX ? 16 : NMAX - k0) / 4>([&](auto gc) {
+          constexpr int k4 = k0 + decltype(gc)::value * 4;
+          if (k4 < n) {   // (groups of four: the limbs of k >= n are zero, the record is padded)
+            static_for<k4, k4 + 4>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              const uint64_t w = rec[8 + k];
+              const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+              c00 += (uint64_t)a0[k] * w0;
+              c01 += (uint64_t)a0[k] * w1;
+              c10 += (uint64_t)a1[k] * w0;
+              c11 += (uint64_t)a1[k] * w1;
+            });
+          }
+        });
+        S += (u128)c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
+      }
+    });
+    uint64_t r = shoup4((uint64_t)(S >> 64), R64, 0 - q) + norm_any((uint64_t)S, q, mu32);   // [0, 5q)
+    r = csub(r, q << 2);
+    r = csub(r, q << 1);
+    r = csub(r, q);
+    if (dm_nonzero) {
+      // delta -= diffProd * delta_i_modP
+      uint64_t corr = dm_abs;
+      if (!P.corr_unit)
+        corr = mul_shoup(red64(dm_abs, q, rec[4]), pmod, rec[7], q);
+      r = dm_negative ? add_mod(r, corr, q) : sub_mod(r, corr, q);
+    }
+    if (A.dst_row[t] != 0xffff)
+      st_stream1(A.dst + (size_t)A.dst_row[t] * row_words + i, r);
+    if (A.upd_row[t] != 0xffff) {
+      uint64_t* u = A.upd + (size_t)A.upd_row[t] * row_words + i;
+      *u = mul_shoup(sub_mod(*u, r, q), rec[5], rec[6], q);
     }
   }
 }

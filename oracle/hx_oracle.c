@@ -1266,7 +1266,7 @@ void ho_dcrt_scale_down(const ho_ctx* c, const int* own_idx, int nown,
       }
     }
     if (fdelta)
-      fdelta[h] = (double)((long double)bn_to_double_signed(v, nl, tmp) / prod_ld);
+      fdelta[h] = (double)(bn_to_ldouble_signed(v, nl, tmp) / prod_ld);   /* (xdouble in the reference: delta itself exceeds the range of a double from 18 dropped primes on) */
     for (int r = 0; r < nkeep; r++)
       dcoef[(size_t)r * N + h] = bn_smod_word(v, nl, c->mod[keep[r]]->q, tmp);
   }

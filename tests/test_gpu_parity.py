@@ -1189,6 +1189,7 @@ def test_fresh_multiplyBy_at_the_reference_benchmark_chain_size(hx, monkeypatch)
     from oracle.backend import OKeySwitch, OPoly, OracleOps
     m, p = 32768, 65537
     monkeypatch.setattr(hc.Ctxt, "measure", True)
+    spy = FusedCallSpy(hx, monkeypatch)
     ctx = hc.ChainContext(m, p, 1, bits=6400, c=3)
     assert len(ctx.ctxtPrimes) == 107 and len(ctx.specialPrimes) == 36
     P = Pair(hx, m, ctx.primes)
@@ -1215,6 +1216,20 @@ def test_fresh_multiplyBy_at_the_reference_benchmark_chain_size(hx, monkeypatch)
     full = np.convolve(ma.astype(np.int64), mb.astype(np.int64))
     want = (full[:P.N] - np.append(full[P.N:], 0)) % p
     assert T.decrypt(ctx, P.o, s, oa, rows) == [int(v) for v in want]
+    assert spy.names() == ["tensorBringToSet"]
+    # level 2: both operands carry the 36 special primes -- the several-primes mod-switch drops them through
+    # rns_extend_wide_kernel<40> on a plan that carries P^-1 and the ptxtSpace correction
+    ga.multiplyBy(ga.clone())
+    oa.multiplyBy(oa.clone())
+    assert ga.primeSet == oa.primeSet and ga.intFactor == oa.intFactor
+    assert abs(ga.lnNoise - oa.lnNoise) < 1e-8
+    for h in ("1", "s"):
+        gi, oi = ga.parts[h].getIndexSet(), oa.parts[h].getIndexSet()
+        assert sorted(gi) == sorted(oi)
+        gd, od = ga.parts[h].download()[:, 0], oa.parts[h].download()[:, 0]
+        for r, i in enumerate(gi):
+            assert np.array_equal(gd[r], od[oi.index(i)]), (h, i)
+    assert spy.names() == ["tensorBringToSet", "tensorBringToSet"]
 
 
 # ---------------------------------------------------------------- copy-on-write DoubleCRT copies
@@ -2163,6 +2178,63 @@ def test_hps_form_of_the_rns_kernels_and_its_redo_list(hx, monkeypatch, eps):
     test_break_into_digits_and_relinearize_norms(hx, [[0, 1], [2, 3], [4]])
     test_several_primes_mod_switch_batched_over_parts_mixed_prime_sizes(hx, 16384, 65537)
     test_tensor_folded_into_the_mod_switch(hx, 16384, 65537, "drop3")
+
+
+@pytest.mark.parametrize("eps", ["default", "0.05", "1.0"])
+@pytest.mark.parametrize("n", [17, 24, 25, 33, 36, 40])
+def test_wide_rns_kernel_17_to_40_source_primes(hx, monkeypatch, n, eps):
+    """rns_extend_wide_kernel<24/32/40> (rns_kernels.h; engine.hip launch_extend): the exact basis extension from
+    17..40 source primes -- the 36-prime digits and the 36 dropped special primes of the reference's own benchmark
+    chain (benchmarks/bgv_basic.cpp:247, bits = 6400) -- in its HPS form with the Garner redo pass behind it
+    (eps = 2^-30: list almost always empty; 0.05: a third of the coefficients redone next to trusted ones; 1.0:
+    all of them).  On a small ring (m = 256) so that the oracle's O(n^2) Garner stays cheap: addPrimes (toPoly +
+    FFT on the new primes, src/DoubleCRT.cpp:565-599), scaleDownToSet for ptxtSpace 65537 / 2 / 1 with fdelta and
+    norms (:1464-1516, src/Ctxt.cpp:466-507), and breakIntoDigits with an n-prime digit whose fix-up updates the
+    later digit's rows in place (:479-561) -- 60-bit sources onto 60-, 56- and 45-bit targets, every word."""
+    if eps != "default":
+        monkeypatch.setenv("HX_HPS_EPS", eps)
+    m, B = 256, 3
+    g60, g56, g45 = O.PrimeGen(60, m), O.PrimeGen(56, m), O.PrimeGen(45, m)
+    primes = [g60.next() for _ in range(n + 6)] + [g56.next() for _ in range(3)] + [g45.next() for _ in range(2)]
+    P = Pair(hx, m, primes)
+    src = list(range(n))
+    rest = list(range(n, n + 11))
+    allp = src + rest
+    # addPrimes: n sources -> 11 new primes
+    a = P.rand(src, 31, batch=B)
+    d = hx.DoubleCRT(P.g, src, B, a)
+    d.addPrimes(rest)
+    got = d.download()
+    assert d.getIndexSet() == allp
+    for b in range(B):
+        assert np.array_equal(got[:n, b], a[:, b])
+        assert np.array_equal(got[n:, b], P.o.add_primes(src, a[:, b], rest))
+    # scaleDownToSet: drop the n primes, keep the 11 (the plan that carries P^-1 and the ptxtSpace correction)
+    x = P.rand(allp, 32, batch=B)
+    for ptxt in (65537, 2, 1):
+        d = hx.DoubleCRT(P.g, allp, B, x)
+        nrm, fd = hx.scaleDownToSetMulti([d], rest, ptxt, norms=True, fdelta=True)
+        got = d.download()
+        assert sorted(d.getIndexSet()) == rest
+        gi = d.getIndexSet()
+        for b in range(B):
+            want, wfd = P.o.scale_down(allp, x[:, b], src, ptxt, want_fdelta=True)
+            for r, i in enumerate(gi):
+                assert np.array_equal(got[r, b], want[rest.index(i)]), (ptxt, i, b)
+            assert np.allclose(fd[0, b], wfd, rtol=0, atol=1e-9 * max(1.0, float(ptxt)))
+            assert np.isclose(nrm[0, b], O.embedding_largest_coeff(m, wfd), rtol=1e-9)
+    # breakIntoDigits: digits of n and 4 primes (in both orders), special primes = the rest
+    own = src + rest[:4]
+    sp = rest[4:]
+    y = P.rand(own, 33, batch=B)
+    for digits in ([src, rest[:4]], [rest[:4], src]):
+        dg, nr = hx.DoubleCRT(P.g, own, B, y).breakIntoDigits(digits, sp, norms=True)
+        got = dg.download()
+        nall = len(own) + len(sp)
+        for b in range(B):
+            want, wn = P.o.break_into_digits(own, y[:, b], digits, own + sp, want_norms=True)
+            assert np.array_equal(got[:, b].reshape(len(digits), nall, P.N), want)
+            assert np.allclose(nr[:, b], wn, rtol=1e-9)
 
 
 def test_tensor_bring_to_set_when_none_of_the_listed_primes_is_there(hx):

@@ -146,6 +146,44 @@ def test_scale_down_matches_python(m, ptxt):
         assert (n * D + d - c) % Qk == 0
 
 
+@pytest.mark.parametrize("ndrop,ptxt", [(18, 65537), (24, 2), (38, 65537), (38, 1)])
+def test_scale_down_fdelta_with_many_dropped_primes(ndrop, ptxt):
+    """fdelta = delta / diffProd (src/Ctxt.cpp:466-478 forms it in xdouble) when delta itself is far outside the
+    range of a double: 18..38 dropped primes of 60 bits (the reference's own benchmark chain drops its 36 special
+    primes at once).  Against exact python-integer arithmetic; the kept rows against (c - delta) / D."""
+    from fractions import Fraction
+    ctx = make_ctx(32, ndrop + 3, bits=60)
+    own = list(range(ndrop + 3))
+    drop = own[1:ndrop + 1]
+    keep = [i for i in own if i not in drop]
+    rows = rand_rows(ctx, own, 17)
+    got, fd = ctx.scale_down(own, rows, drop, ptxt, want_fdelta=True)
+    assert np.isfinite(fd).all()
+    D = reduce(lambda a, b: a * b, [ctx.primes[i] for i in drop])
+    delta = ctx.to_poly(drop, rows[[own.index(i) for i in drop]])
+    if ptxt > 1:
+        Dinv = pow(D % ptxt, -1, ptxt)
+        fixed = []
+        for v in delta:
+            dm = v % ptxt
+            if dm != 0:
+                dm = dm * Dinv % ptxt
+                if dm > ptxt // 2 or (ptxt % 2 == 0 and dm == ptxt // 2 and v < 0):
+                    dm -= ptxt
+                v -= D * dm
+            fixed.append(v)
+        delta = fixed
+    want = np.array([float(Fraction(int(v), D)) for v in delta])
+    assert np.allclose(fd, want, rtol=1e-12, atol=1e-12)
+    full = ctx.to_poly(own, rows)
+    want_rows = []
+    for k in keep:
+        q = ctx.primes[k]
+        Dk = pow(D % q, -1, q)
+        want_rows.append([((c - d) % q) * Dk % q for c, d in zip(full, delta)])
+    assert got.tolist() == ctx.fft(keep, np.array(want_rows, dtype=np.uint64)).tolist()
+
+
 def test_mul_relin_composes():
     m = 32
     ctx = make_ctx(m, 7)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 3's GPU calls as stages of one script (each gpurun call of the round ran a subset):
-#   gpurun --timeout 2400 -- 'bash tools/r3_gpu_calls.sh OUT stage [stage ...]'
+# The rounds' GPU calls as stages of one script (each gpurun call runs a subset):
+#   gpurun --timeout 2400 -- 'bash tools/gpu_calls.sh OUT stage [stage ...]'
 # OUT = directory name under gpurun_out/.  Stages:
 #   tests            the GPU parity suite (pytest -m gpu), through the C ABI
 #   tests:EXPR       the same with -k EXPR
@@ -71,6 +71,11 @@ for st in "$@"; do
     bench_ckks)
       timeout 600 python bench.py --workload ckks65536 --steps 8 --warmup 3 > $out/bench_ckks.json 2> $out/bench_ckks.err; echo "bench ckks rc=$?"
       line $out/bench_ckks.json ckks; tail -3 $out/bench_ckks.err ;;
+    bench6400)
+      # the reference's own BGV parameter (benchmarks/bgv_basic.cpp:247): bits=6400 -> L=107, K=36, D=3
+      timeout 900 python bench.py --bits 6400 --batch 16 --steps 4 --warmup 1 --mults-per-step 4 --no-extras --cpu-sample 0 \
+         > $out/bench_6400.json 2> $out/bench_6400.err; echo "bench6400 rc=$?"
+      line $out/bench_6400.json bits6400; tail -3 $out/bench_6400.err ;;
     bench_fixed)
       timeout 400 python bench.py --workload bgv32768_fixed --steps 8 --warmup 3 --cpu-sample 0 > $out/bench_fixed.json 2> $out/bench_fixed.err
       python -c "import json;print('fixed level', json.load(open('$out/bench_fixed.json'))['value'])" ;;
