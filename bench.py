@@ -26,8 +26,9 @@ workload : (default `bgv32768`) BGV m=32768, p=65537, bits=950 -> L=16 x 60-bit 
            reference's alternative noise bounds (no norms).
            `config.fixed_level_mult_per_s` additionally reports tensorProduct+reLinearize alone
            (hx_mul_relin, no prime-set changes), the kernel-level pipeline DESIGN.md analyses.
-           `--workload ckks65536` = BASELINE configs[3]: ContextBuilder<CKKS>().m(65536).precision(20)
-           .bits(1400) (L=24, K=8, D=3), CKKSencrypt-ed pairs through Ctxt::multiplyBy
+           `--workload ckks65536` = BASELINE configs[3]: ContextBuilder<CKKS>().m(65536).precision(1).bits(1400)
+           .scale(10) (L=24, K=8, D=3; precision and scale as benchmarks/ckks_common.h:45-50; `--bits 440` = the
+           reference's own big_params, benchmarks/ckks_basic.cpp:263), CKKSencrypt-ed pairs through Ctxt::multiplyBy
            (benchmarks/ckks_basic.cpp:161-180), `--global-batch 512` split over the ranks; level 2
            (product x product) reported beside it; every rank decodes and checks its slice.
 step     : `--mults-per-step` (32) x [copy(ctxt1); copy.multiplyBy(ctxt2)] over the batch of
@@ -499,17 +500,17 @@ def bgv_basic_ops(hx, hc, cc, fa, fb, sk, msgs, sync, reps=8):
     return out
 
 
-def ckks_basic_ops(hx, hc, device, stream, sync, bits, B=16, reps=6, m=65536, backend=None):
+def ckks_basic_ops(hx, hc, device, stream, sync, bits, B=16, reps=6, m=65536, backend=None, precision=1):
     """The reference's CKKS benchmark list (benchmarks/ckks_basic.cpp:38-236: add / subtract / negate / square /
     rotate by one / multiply without and with relinearisation / encrypt / decrypt / multiply-and-add) at the
-    BASELINE configs[3] shape, ContextBuilder<CKKS>().m(65536).precision(20).bits(1400): a key pair, B pairs of
+    BASELINE configs[3] shape, ContextBuilder<CKKS>().m(65536).precision(1).bits(1400).scale(10): a key pair, B pairs of
     CKKSencrypt-ed ciphertexts packed along the batch axis (python mirror of the host, helib_amd/ctxt.py + keys.py:
     this leg is about the device operations, the timed multiply of the headline runs in the C++ host), the operand
     copy made before the timer as the reference pauses its timer for it.  Every result is decrypted and decoded
     for one batch element and compared with the plaintext operation within the error bound the ciphertext reports."""
     import math
     from helib_amd import hostnt, keys as hk
-    cc = hc.ChainContext(m, -1, 20, bits=bits, c=3, ckks=True)
+    cc = hc.ChainContext(m, -1, precision, bits=bits, c=3, ckks=True)
     if backend is None:
         ctx = hx.Context(cc.m, device)
         for q in cc.primes:
@@ -527,9 +528,11 @@ def ckks_basic_ops(hx, hc, device, stream, sync, bits, B=16, reps=6, m=65536, ba
     g = hostnt.ZmStar(cc.m, cc.p).gens[0]
     sk.GenKeySWmatrix(1, g)
     n, L = cc.phim, len(cc.ctxtPrimes)
-    f = float(1 << 20)
+    # the factor PubKey::Encrypt(Ptxt<CKKS>) encodes with and plaintexts whose canonical embedding stays below the
+    # declared size 1 (as helib_amd/csrc/host_session.cpp)
+    f = float(cc.encodeScalingFactor())
     rng = np.random.default_rng(29)
-    vals = rng.uniform(-1, 1, size=(2, B, n)) / n
+    vals = rng.uniform(-1, 1, size=(2, B, n)) / (8.0 * math.sqrt(n / 3.0))
     enc = np.rint(vals * f) / f                                   # what is actually encrypted
     rows = np.empty((2, 2, L, B, n), dtype=np.uint64)
     first = None
@@ -637,7 +640,9 @@ def ckks_basic_ops(hx, hc, device, stream, sync, bits, B=16, reps=6, m=65536, ba
         except Exception as e:
             out[name] = f"unavailable: {type(e).__name__}: {str(e)[:120]}"
             continue
-        if not (err <= tol and err <= 1e-3 * max(float(np.max(np.abs(w))), 1e-30)):
+        # (precision(r) promises 2^-r: at precision(1) the reported bound is all there is to check; from ten bits on
+        # the result must also be right to 1e-3 of its size)
+        if not (err <= tol and (precision < 10 or err <= 1e-3 * max(float(np.max(np.abs(w))), 1e-30))):
             raise SystemExit(f"bench: decode(decrypt({name})) is off by {err:g} (reported bound {tol:g})")
         out[name] = {"ms_per_call_batch": round(ms, 4), "host_ms_per_call": round(host_ms, 4), "host_ms_each_call_then_norm_wait": each,
                      "batch": B,
@@ -659,7 +664,7 @@ def ckks_basic_ops(hx, hc, device, stream, sync, bits, B=16, reps=6, m=65536, ba
     got = np.array([float(v) for v in dec]) / math.exp(ct.lnRatFactor)
     if float(np.max(np.abs(got - enc[0, 0]))) > math.exp(ct.lnNoise - ct.lnRatFactor):
         raise SystemExit("bench: decode(decrypt(CKKSencrypt(v))) is off")
-    out["note"] = (f"benchmarks/ckks_basic.cpp:38-236 at m={m} precision=20 bits={bits} (L={L}, K={len(cc.specialPrimes)}); "
+    out["note"] = (f"benchmarks/ckks_basic.cpp:38-236 at m={m} precision={precision} bits={bits} (L={L}, K={len(cc.specialPrimes)}); "
                    "operand copy before the timer as there; batched lines run the whole batch per call, encrypt / decrypt one "
                    "ciphertext; python mirror of the host")
     return out
@@ -669,7 +674,7 @@ def run_session(sess, level, steps, warmup, R, sync, barrier, measure):
     """The timed region, driven by the C++ host: `steps` x hxh_multiply(level, R) -- R x [copy(a);
     copy.multiplyBy(b)] enqueued back to back by helib_amd/csrc/host_session.cpp (level 1: the two fresh
     ciphertexts; level 2: the kept level-1 product with itself).  Returns (seconds, host seconds)."""
-    for _ in range(max(1, warmup)):
+    for _ in range(warmup):
         sess.multiply(level, R, measure)
     sync()
     barrier()
@@ -683,6 +688,36 @@ def run_session(sess, level, steps, warmup, R, sync, barrier, measure):
     sync()
     barrier()
     return time.perf_counter() - t0, host
+
+
+def levels_leg(hh, sparams, batch, R, device, stream, sync, warm_steps=2, steps=5, elements=None, seed=17):
+    """A second workload through the same C++ host: level 1 (fresh x fresh) and level 2 (product x product) of
+    `sparams` = (scheme, m, p, r, bits), `steps` x R multiplies of a `batch`-pair batch each after `warm_steps` full
+    steps (plans, arena chunks and clocks settle there; the session reserved its working set at creation), noise
+    measured.  hipMalloc calls made inside the two timed windows are reported (must be 0: an allocation in a timed
+    window once doubled a figure of this leg)."""
+    t0 = time.perf_counter()
+    so = hh.Session(*sparams, batch, device=device, stream=stream, seed=seed)
+    sync()
+    setup = time.perf_counter() - t0
+    out = {"workload": f"{sparams[0].upper()} m={sparams[1]} " + (f"precision={sparams[3]}" if sparams[0] == "ckks" else f"p={sparams[2]}")
+           + f" bits={sparams[4]}: L={so.L_ctxt}x{so.ctxt_bits}b, K={so.K}x{so.special_bits}b, D={so.D}, batch {so.batch}, "
+           f"{steps} x {R} multiplies timed per level after {warm_steps} x {R}, noise measured, C++ host",
+           "setup_s": round(setup, 2)}
+    mallocs = 0
+    for level in (1, 2):
+        run_session(so, level, warm_steps, 1, R, sync, lambda: None, True)
+        m0 = so.arena_stats()["hipMalloc_calls"]
+        dt, _ = run_session(so, level, steps, 0, R, sync, lambda: None, True)
+        mallocs += so.arena_stats()["hipMalloc_calls"] - m0
+        nv = so.verify(level, elements=elements if elements is not None else [0, so.batch - 1])
+        out[f"level{level}_mult_per_s"] = round(so.batch * R * steps / dt, 1)
+        out[f"level{level}_ms_per_mult_of_the_batch"] = round(dt / (steps * R) * 1e3, 4)
+        out[f"level{level}_verified_elements"] = nv
+        out[f"level{level}_result_primes"] = len(so.result_primes(level))
+    out["level2_over_level1"] = round(out["level2_ms_per_mult_of_the_batch"] / out["level1_ms_per_mult_of_the_batch"], 3)
+    out["hipMalloc_calls_in_timed_windows"] = mallocs
+    return out, so
 
 
 # static instruction counts of the row-transform kernels per 512-thread workgroup (DESIGN.md 3.0; VALU
@@ -810,6 +845,63 @@ def config5_leg(hx, iters=5, batch=32):
     out["kernels_in_situ_fwd_plus_inv"] = [{"kernel": kk["kernel"].replace("hx::", ""), "workgroups": kk["workgroups"],
                                             "calls": kk["calls"], "avg_us": round(kk["avg_us"], 1),
                                             "share": round(kk["total_us"] / tot, 3)} for kk in prof["kernels"][:12]]
+    return out
+
+
+def config1_2_leg(hx):
+    """BASELINE configs[0] and [1].  Config 1 = benchmarks/fft_bench.cpp:24-73: Cmodulus forward / inverse transform
+    at m=16384 (N=8192) modulo one 49-bit prime -- one row at a time as fft_bench times it (latency, input and
+    output resident on the device) and 4096 rows per launch (GB/s by 16N per row).  Config 2 = DoubleCRT += and *=
+    at m=32768, L=16 primes of 60 bits (src/DoubleCRT.cpp:216-337), batch 64 and batch 1, GB/s by 24N per row.
+    HIP events on the context's stream."""
+    from helib_amd import hostnt
+    rng = np.random.default_rng(7)
+    out = {}
+
+    def timed(ctx, fn, iters):
+        fn()
+        ctx.timerBegin()
+        for _ in range(iters):
+            fn()
+        return ctx.timerEnd() / iters * 1e-3      # seconds per call
+    m = 16384
+    q = hostnt.PrimeGen(49, m).next()
+    ctx = hx.Context(m)
+    ctx.add_prime(q)
+    n = ctx.phim
+    c1 = {"workload": f"fft_bench: m={m} N={n}, one {q.bit_length()}-bit prime (benchmarks/fft_bench.cpp:24-73)"}
+    for B, tag in ((1, "one_row"), (4096, "4096_rows")):
+        d = hx.DoubleCRT(ctx, [0], B, rng.integers(0, q, size=(1, B, n), dtype=np.uint64))
+        tf, ti = timed(ctx, d.FFT, 30), timed(ctx, d.iFFT, 30)
+        c1[f"forward_us_{tag}"] = round(tf * 1e6, 2)
+        c1[f"inverse_us_{tag}"] = round(ti * 1e6, 2)
+        if B > 1:
+            c1["forward_GBps"] = round(16 * n * B / tf / 1e9, 1)
+            c1["inverse_GBps"] = round(16 * n * B / ti / 1e9, 1)
+            c1["forward_frac"] = round(16 * n * B / tf / 1e9 / HBM_PEAK_GBS, 4)
+            c1["inverse_frac"] = round(16 * n * B / ti / 1e9 / HBM_PEAK_GBS, 4)
+        del d
+    out["config1_fft_bench"] = c1
+    del ctx
+    m, L = 32768, 16
+    g = hostnt.PrimeGen(60, m)
+    primes = [g.next() for _ in range(L)]
+    ctx = hx.Context(m)
+    for p in primes:
+        ctx.add_prime(p)
+    n = ctx.phim
+    idx = list(range(L))
+    c2 = {"workload": f"DoubleCRT += / *= at m={m} N={n}, L={L} x 60-bit primes (src/DoubleCRT.cpp:216-337), 24N bytes per row"}
+    for B in (64, 1):
+        a = hx.DoubleCRT(ctx, idx, B, uniform_rows(rng, primes, idx, B, n))
+        b = hx.DoubleCRT(ctx, idx, B, uniform_rows(rng, primes, idx, B, n))
+        ta, tm = timed(ctx, lambda: a.__iadd__(b), 60), timed(ctx, lambda: a.__imul__(b), 60)
+        byts = 24.0 * n * L * B
+        c2[f"batch{B}"] = {"add_us": round(ta * 1e6, 2), "mul_us": round(tm * 1e6, 2), "add_GBps": round(byts / ta / 1e9, 1),
+                           "mul_GBps": round(byts / tm / 1e9, 1), "add_frac": round(byts / ta / 1e9 / HBM_PEAK_GBS, 4),
+                           "mul_frac": round(byts / tm / 1e9 / HBM_PEAK_GBS, 4)}
+        del a, b
+    out["config2_doublecrt_add_mul"] = c2
     return out
 
 
@@ -943,6 +1035,11 @@ def dry_rank(args):
         start, count = hdist.shard(args.global_batch, world, rank)
     else:
         start, count = rank * args.batch, args.batch
+    # the key material of the one key pair: rank 0's words reach every rank (same call as the engine run)
+    import numpy as np
+    words = np.arange(1, 4097, dtype=np.uint64) * np.uint64(0x9e3779b97f4a7c15) if rank == 0 else None
+    words, key_bytes = group.broadcast_words(words, src=0)
+    key_sum = int(np.bitwise_xor.reduce(words))
     group.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -951,6 +1048,8 @@ def dry_rank(args):
     dt = group.max_over_ranks(time.perf_counter() - t0)
     pairs = group.sum_over_ranks(count)
     firsts = group.sum_over_ranks(start if rank == world - 1 else 0)
+    want = int(np.bitwise_xor.reduce(np.arange(1, 4097, dtype=np.uint64) * np.uint64(0x9e3779b97f4a7c15)))
+    ok_all = int(group.sum_over_ranks(1 if key_sum == want else 0))
     if rank == 0:
         print(json.dumps({"metric": "ctxt_x_ctxt_mults_per_sec_incl_relinearize", "dry_launch": True,
                           "value": round(pairs * args.mults_per_step * args.steps / dt, 1), "unit": "mult/s",
@@ -958,7 +1057,9 @@ def dry_rank(args):
                           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
                           "scaling": "strong" if args.global_batch else "weak",
                           "config": {"workload": args.workload, "pairs_all_ranks": int(pairs), "last_rank_start": int(firsts),
-                                     "batch_this_rank": count}}))
+                                     "batch_this_rank": count, "process_group_world_size": group.world_size_seen(),
+                                     "key_material_bytes_broadcast": key_bytes,
+                                     "key_material_same_on_all_ranks": bool(ok_all == world)}}))
     group.close()
 
 
@@ -979,6 +1080,12 @@ def main():
     ap.add_argument("--bits", type=int, default=0,
                     help="ContextBuilder::bits; bgv32768: 950 = the L~16 shape the metric is quoted on, 6400 = the reference's "
                          "own benchmarks/bgv_basic.cpp:247 parameter (L=107, K=36); ckks65536: 1400 (L=24, K=8)")
+    ap.add_argument("--precision", type=int, default=1,
+                    help="ckks65536: ContextBuilder<CKKS>::precision (1 = the reference's benchmarks/ckks_common.h:45-50)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="N ranks on GPU 0 (a 1-GPU box): the N-rank path -- one key pair broadcast from rank 0, per-rank "
+                         "arenas, barriers -- runs functionally with the real engine; the process group is gloo, because "
+                         "RCCL refuses two ranks on one device.  Not a scaling measurement.")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary legs (python mirror, batch-1 latency, op list, levels of the other scheme, config 5)")
     ap.add_argument("--dry-launch", action="store_true", help="N-rank launch/aggregation path on CPUs (gloo), no engine")
@@ -1006,8 +1113,11 @@ def main():
     world, rank, local_rank = hdist.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    group = hdist.Group(backend="nccl", device=torch.device("cuda", local_rank))
+    group = (hdist.Group(backend="gloo") if args.one_device else
+             hdist.Group(backend="nccl", device=torch.device("cuda", local_rank)))
     from helib_amd import capi as hx, ctxt as hc, host as hh
 
     B = hdist.shard(args.global_batch, world, rank)[1] if args.global_batch else args.batch
@@ -1026,8 +1136,19 @@ def main():
         ckks = args.workload == "ckks65536"
         # ---- the C++17 host: context, keys, encryptions, the multiply loop, the decryptions ----
         t0 = time.perf_counter()
-        sess = (hh.Session("ckks", 65536, -1, 20, args.bits, B, device=local_rank, stream=stream, seed=7 + rank) if ckks else
-                hh.Session("bgv", 32768, 65537, 1, args.bits, B, device=local_rank, stream=stream, seed=7 + rank))
+        sparams = ("ckks", 65536, -1, args.precision, args.bits) if ckks else ("bgv", 32768, 65537, 1, args.bits)
+        # ONE key pair for the whole job: rank 0 generates it, its material -- secret key, public
+        # encryption key, the relinearisation matrix with its a columns -- is broadcast once (RCCL between device
+        # buffers), every other rank builds its session on it and encrypts its own slice of the pairs
+        key_bytes = 0
+        if rank == 0:
+            sess = hh.Session(*sparams, B, device=local_rank, stream=stream, seed=7)
+            keys = sess.export_keys() if world > 1 else None
+        if world > 1:
+            keys, key_bytes = group.broadcast_words(keys if rank == 0 else None, src=0)
+            if rank != 0:
+                sess = hh.Session(*sparams, B, device=local_rank, stream=stream, seed=7 + rank, keys=keys)
+            del keys
         sync()
         t_setup = time.perf_counter() - t0
         n, l, k, d = sess.phim, sess.L_ctxt, sess.K, sess.D
@@ -1040,14 +1161,17 @@ def main():
         res_primes = sess.result_primes(1)
         prof1 = in_situ_profile(hx, sess, 1, 8, sync) if rank == 0 else None
         # level 2: the kept product with itself (operands that carry the special primes of a key switch)
-        dt2, _ = run_session(sess, 2, steps4, 1, R, sync, group.barrier, measure=True)
+        run_session(sess, 2, 1, 1, R, sync, group.barrier, measure=True)            # two full warm steps
+        malloc0 = sess.arena_stats()["hipMalloc_calls"]
+        dt2, _ = run_session(sess, 2, steps4, 0, R, sync, group.barrier, measure=True)
+        malloc2 = sess.arena_stats()["hipMalloc_calls"] - malloc0
         dt2 = group.max_over_ranks(dt2)
         nver2 = sess.verify(2)
         prof2 = in_situ_profile(hx, sess, 2, 4, sync, warm=8) if (rank == 0 and extras) else None
         nver_all = int(group.sum_over_ranks(nver))
         nver2_all = int(group.sum_over_ranks(nver2))
         mults = pairs_all * R * args.steps
-        scheme = (f"CKKS m=65536 precision=20 bits={args.bits}" if ckks else f"BGV m=32768 p=65537 bits={args.bits}")
+        scheme = (f"CKKS m=65536 precision={args.precision} bits={args.bits}" if ckks else f"BGV m=32768 p=65537 bits={args.bits}")
         workload = (f"{scheme} (L={l}x{sess.ctxt_bits}b, K={k}x{sess.special_bits}b, {sess.n_small} small primes, D={d}): "
                     + ("Ctxt::multiplyBy on CKKSencrypt-ed ciphertexts = tensorProduct + relin_CKKS_adjust + key switch at the full "
                        "level (a fresh CKKS ciphertext has nothing to mod-switch), benchmarks/ckks_basic.cpp:161-180; "
@@ -1074,6 +1198,10 @@ def main():
                  "host_ms_per_step_incl_norm_waits": round(host_s / args.steps * 1e3, 4),
                  "host_enqueue_ms_per_step": round(host_b / args.steps * 1e3, 4),
                  "setup_s_keys_and_encryptions": round(t_setup, 2),
+                 "one_key_pair": (f"rank 0's key pair for all {world} ranks: {key_bytes} bytes of key material broadcast once "
+                                  f"({'gloo, --one-device' if args.one_device else 'RCCL'}), every rank encrypts its own slice under it"
+                                  if world > 1 else "single rank"),
+                 "process_group_world_size": group.world_size_seen(), "key_material_bytes_broadcast": key_bytes,
                  "result_primes": res_primes,
                  "inputs": ("key pair, relinearisation matrix and public-key encryptions of random plaintexts made by the C++ "
                             "host (helib_amd_keys.hpp: SecKey::GenSecKey, Encrypt / CKKSencrypt), as benchmarks/bgv_basic.cpp:144-157"),
@@ -1084,7 +1212,10 @@ def main():
                             "mult_per_s": round(pairs_all * R * steps4 / dt2, 1),
                             "ms_per_mult_of_the_batch": round(dt2 / (steps4 * R) * 1e3, 4),
                             "over_level1": round((dt2 / steps4) / (dt / args.steps), 3),
+                            "hipMalloc_calls_in_timed_window": malloc2,
                             "verified_elements": nver2_all, "result_primes": sess.result_primes(2)}}
+        extra["level2_mult_per_s"] = extra["level2"]["mult_per_s"]
+        extra["level2_over_level1"] = extra["level2"]["over_level1"]
         if rank == 0:
             table, us_per_mult = kernel_table(prof1, n, B, l, k, d, 8)
             extra["kernels_in_situ"] = {"what": "one multiply of the batch, every launch bracketed by HIP events on its stream "
@@ -1092,6 +1223,15 @@ def main():
                                         "kernel_us_per_multiply_of_the_batch": round(us_per_mult, 1),
                                         "wall_us_per_multiply_of_the_batch": round(dt / (args.steps * R) * 1e6, 1),
                                         "dropped_launch_records": prof1["dropped"], "kernels": table[:16]}
+            # the fused sequence's own compulsory bytes: what the kernels that ran are entitled to move (their
+            # algorithmic bytes per launch x launches per multiply), per ciphertext multiplication
+            fused = sum(r["algorithmic_bytes_per_launch"] * r["launches_per_multiply"] for r in table
+                        if "algorithmic_bytes_per_launch" in r) / B
+            share = sum(r["share"] for r in table if "algorithmic_bytes_per_launch" in r)
+            extra["fused_algorithmic_MB_per_mult"] = round(fused / 1e6, 2)
+            extra["fused_hbm_roofline_mult_per_s_per_gpu"] = round(HBM_PEAK_GBS * 1e9 / fused, 0)
+            extra["value_over_fused_roofline"] = round((pairs_all / world * R * args.steps / dt) / (HBM_PEAK_GBS * 1e9 / fused), 4)
+            extra["fused_bytes_cover_share_of_kernel_time"] = round(share, 3)
             if prof2:
                 t2, us2 = kernel_table(prof2, n, B, l, k, d, 4)
                 extra["level2"]["kernels_in_situ"] = [{kk: r[kk] for kk in ("kernel", "workgroups", "launches_per_multiply", "avg_us",
@@ -1138,29 +1278,43 @@ def main():
                 extra["batch1_latency_ms"] = round(ts[len(ts) // 2], 4)
                 extra["batch1_latency_ms_min"] = round(ts[0], 4)
                 try:
+                    c12 = config1_2_leg(hx)
+                    extra.update(c12)
+                    c1, c2 = c12["config1_fft_bench"], c12["config2_doublecrt_add_mul"]["batch64"]
+                    extra.update({"config1_fft_forward_us_one_row": c1["forward_us_one_row"], "config1_fft_forward_GBps": c1["forward_GBps"],
+                                  "config1_fft_inverse_GBps": c1["inverse_GBps"], "config2_add_GBps": c2["add_GBps"],
+                                  "config2_mul_GBps": c2["mul_GBps"]})
+                except Exception as e:
+                    extra["config1_fft_bench"] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
+                try:
                     extra["config5_bluestein"] = config5_leg(hx)
+                    extra["config5_bluestein_forward_ns_per_row"] = extra["config5_bluestein"]["forward"]["ns_per_row"]
+                    extra["config5_bluestein_inverse_ns_per_row"] = extra["config5_bluestein"]["inverse"]["ns_per_row"]
                 except Exception as e:
                     extra["config5_bluestein"] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
-                other = "ckks65536" if not ckks else "bgv32768"
-                try:                                        # the two levels of the other scheme, same host
-                    so = (hh.Session("ckks", 65536, -1, 20, 1400, 64, device=local_rank, stream=stream, seed=17) if not ckks else
-                          hh.Session("bgv", 32768, 65537, 1, 950, 128, device=local_rank, stream=stream, seed=17))
-                    o1, _ = run_session(so, 1, 2, 1, 8, sync, lambda: None, True)
-                    v1 = so.verify(1, elements=[0, so.batch - 1])
-                    o2, _ = run_session(so, 2, 2, 1, 8, sync, lambda: None, True)
-                    v2 = so.verify(2, elements=[0, so.batch - 1])
-                    extra["levels_" + other] = {"workload": ("CKKS m=65536 precision=20 bits=1400" if not ckks else "BGV m=32768 p=65537 bits=950")
-                                                + f": L={so.L_ctxt}, K={so.K}, D={so.D}, batch {so.batch}, noise measured, C++ host",
-                                                "level1_mult_per_s": round(so.batch * 16 / o1, 1), "level1_ms_per_mult_of_the_batch": round(o1 / 16 * 1e3, 3),
-                                                "level2_mult_per_s": round(so.batch * 16 / o2, 1), "level2_ms_per_mult_of_the_batch": round(o2 / 16 * 1e3, 3),
-                                                "level2_over_level1": round(o2 / o1, 3), "verified_elements": [v1, v2]}
-                    so.close()
-                    del so
-                except Exception as e:
-                    extra["levels_" + other] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
+                # the other workloads through the same C++ host, two levels each: the other scheme at its BASELINE shape,
+                # and the reference's OWN benchmark parameters (benchmarks/bgv_basic.cpp:247 bits=6400,
+                # benchmarks/ckks_basic.cpp:263 precision=1 bits=440)
+                legs = {"bgv32768_bits950": (("bgv", 32768, 65537, 1, 950), 128, 8),
+                        "ckks65536_bits1400": (("ckks", 65536, -1, args.precision, 1400), 64, 8),
+                        "ckks65536_bits440_reference_params": (("ckks", 65536, -1, 1, 440), 64, 8),
+                        "bgv32768_bits6400_reference_params": (("bgv", 32768, 65537, 1, 6400), 16, 4)}
+                mine = "ckks65536_bits%d" % args.bits if ckks else "bgv32768_bits%d" % args.bits
+                for name, (sp, bb, rr) in legs.items():
+                    if name.startswith(mine):
+                        continue
+                    try:
+                        leg, so = levels_leg(hh, sp, bb, rr, local_rank, stream, sync)
+                        so.close()
+                        del so
+                        extra["levels_" + name] = leg
+                        for kk in ("level1_mult_per_s", "level2_mult_per_s", "level2_over_level1", "hipMalloc_calls_in_timed_windows"):
+                            extra[f"{name}_{kk}"] = leg[kk]          # (flat copies: nested objects do not survive every reader)
+                    except Exception as e:
+                        extra["levels_" + name] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
                 if ckks:
                     try:
-                        extra["ckks_basic_ops"] = ckks_basic_ops(hx, hc, local_rank, stream, sync, args.bits)
+                        extra["ckks_basic_ops"] = ckks_basic_ops(hx, hc, local_rank, stream, sync, args.bits, precision=args.precision)
                     except SystemExit:
                         raise
                     except Exception as e:
@@ -1225,13 +1379,16 @@ def main():
 
     if rank == 0:
         cfg = {"workload": workload, "batch_per_gpu": B, "pairs_all_ranks": pairs_all,
-               "parallelism": f"replica x{world}, batch-sharded, no data-path collective",
+               "parallelism": (f"replica x{world}, batch-sharded under one key pair (broadcast once), no data-path collective"
+                               + (" -- all ranks on ONE device (--one-device): functional run, not a scaling point" if args.one_device else "")),
                "algorithmic_MB_per_mult": round(per_mult / 1e6, 2),
                "hbm_roofline_mult_per_s_per_gpu": round(HBM_PEAK_GBS * 1e9 / per_mult, 0),
                "roofline_note": ("algorithmic_MB_per_mult counts the reference-equivalent unfused sequence with "
                                  "per-multiply key rows (SURVEY 8d); value / hbm_roofline_mult_per_s_per_gpu is "
-                                 "therefore not an efficiency -- the per-kernel fractions under `roofline` and "
-                                 "`config.kernels_in_situ` are")}
+                                 "therefore not an efficiency.  fused_algorithmic_MB_per_mult is the compulsory traffic of "
+                                 "the kernels that actually ran (sum of their algorithmic bytes) and value_over_fused_roofline "
+                                 "the whole-operation fraction of the 8 TB/s roofline; the per-kernel fractions are under "
+                                 "`roofline` and `config.kernels_in_situ`")}
         cfg.update(extra)
         line = {"metric": "ctxt_x_ctxt_mults_per_sec_incl_relinearize",
                 "value": round(pairs_all * R * args.steps / dt, 1), "unit": "mult/s", "n_gpus": world,

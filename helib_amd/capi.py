@@ -46,7 +46,7 @@ SYMBOLS = [
     "hx_automorph", "hx_complex_conj",
     "hx_add_primes_and_scale", "hx_add_primes", "hx_poly_rem", "hx_scale_down", "hx_scale_down_multi",
     "hx_bring_to_set_multi", "hx_break_into_digits",
-    "hx_ksk_create", "hx_ksk_destroy", "hx_tensor", "hx_key_switch_digits", "hx_mul_relin",
+    "hx_ksk_create", "hx_ksk_destroy", "hx_ksk_shape", "hx_ksk_download", "hx_tensor", "hx_key_switch_digits", "hx_mul_relin",
     "hx_relinearize",
     "hx_ctx_defer_norms", "hx_norms_flush",
     "hx_embedding_norm", "hx_scale_down_multi_norms", "hx_bring_to_set_multi_norms",
@@ -117,6 +117,7 @@ def lib():
             "hx_bring_to_set_multi": [vp, ip, vp, ip, vp, ip, u64],
             "hx_break_into_digits": [vp, vp, vp, ip, vp, ip, vp],
             "hx_ksk_create": [vp, ip, vp, ip, vp, vp, vp], "hx_ksk_destroy": [vp],
+            "hx_ksk_shape": [vp, vp, vp, vp], "hx_ksk_download": [vp, vp, vp],
             "hx_tensor": [vp] * 7, "hx_key_switch_digits": [vp] * 4,
             "hx_mul_relin": [vp, vp, vp, vp, vp, vp, vp, ip, vp, vp],
             "hx_relinearize": [vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, vp],
@@ -505,6 +506,13 @@ class KeySwitch:
         self.row_idx = [int(i) for i in row_idx]
         _chk(lib().hx_ksk_create(context.h, self.ndig, _p(idx), len(idx), _p(b), _p(a),
                                  C.byref(self.h)))
+
+    def download(self):
+        """(b, a) back on the host, [ndig][nrows][phim] (hx_ksk_download)"""
+        shape = (self.ndig, len(self.row_idx), self.context.phim)
+        b, a = np.empty(shape, dtype=np.uint64), np.empty(shape, dtype=np.uint64)
+        _chk(lib().hx_ksk_download(self.h, _p(b), _p(a)))
+        return b, a
 
     def __del__(self):
         try:

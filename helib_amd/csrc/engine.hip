@@ -4265,6 +4265,30 @@ extern "C" int hx_ksk_create(hx_ctx* c, int ndig, const int* row_idx, int nrows,
   *out = k;
   return HX_OK;
 }
+extern "C" int hx_ksk_shape(const hx_ksk* k, int* ndig, int* nrows, int* row_idx_out)
+{
+  if (!k || !ndig || !nrows)
+    return fail(HX_ERR_INVALID, "null argument");
+  *ndig = k->ndig;
+  *nrows = (int)k->row_idx.size();
+  if (row_idx_out)
+    for (size_t r = 0; r < k->row_idx.size(); r++)
+      row_idx_out[r] = k->row_idx[r];
+  return HX_OK;
+}
+extern "C" int hx_ksk_download(const hx_ksk* k, uint64_t* b, uint64_t* a)
+{
+  if (!k || !b || !a)
+    return fail(HX_ERR_INVALID, "null argument");
+  hx_ctx* c = k->ctx;
+  CTX_ENTER(c);
+  NO_CAPTURE(c, "hx_ksk_download (a synchronous copy)");
+  const size_t bytes = (size_t)k->ndig * k->row_idx.size() * c->phim * 8;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(b, k->d_b, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(a, k->d_a, bytes, hipMemcpyDeviceToHost));
+  return HX_OK;
+}
 extern "C" int hx_ksk_destroy(hx_ksk* k)
 {
   if (!k)

@@ -33,6 +33,7 @@ struct hxh_session {
     std::vector<std::pair<SKHandle, std::vector<uint64_t>>> rows;
     std::vector<IndexSet> idx;
   } host[3];
+  std::vector<uint64_t> key_blob;              // hxh_export_keys: kept between the size query and the copy
 };
 
 template <class F>
@@ -58,8 +59,10 @@ static uint64_t sm64(uint64_t& s)
   return z ^ (z >> 31);
 }
 
-extern "C" int hxh_session_create(hxh_session** out, int device, void* stream, int scheme, long m, long p, long r,
-                                  long bits, int batch, uint64_t seed)
+// keys == nullptr: the session makes its own key pair (seed; 0 = OS entropy).  Otherwise the key pair is the
+// exported one (SecKey::importKeys) and `seed` drives this session's encryption randomness and plaintexts only.
+static int session_create(hxh_session** out, int device, void* stream, int scheme, long m, long p, long r, long bits,
+                          int batch, uint64_t seed, const uint64_t* keys, size_t key_words)
 {
   if (!out || batch < 1 || (scheme != 0 && scheme != 1)) {
     g_err = "hxh_session_create: bad argument";
@@ -79,10 +82,20 @@ extern "C" int hxh_session_create(hxh_session** out, int device, void* stream, i
       // chain (operands, their mod-switched copies, tensor and key-switch outputs, the kept products of two levels)
       const uint64_t slab = (uint64_t)(cc.ctxtPrimes.size() + cc.specialPrimes.size() + 2) * (uint64_t)batch *
                             (uint64_t)cc.phim * 8u;
-      s->dev->reserve(std::min<uint64_t>(48 * slab, (uint64_t)64 << 30));
+      // (not fatal: on a device with less free memory the loop still fits by growing on demand)
+      for (uint64_t want = std::min<uint64_t>(48 * slab, (uint64_t)64 << 30); want >= slab; want /= 2) {
+        try {
+          s->dev->reserve(want);
+          break;
+        } catch (const std::exception&) {
+        }
+      }
     }
     s->sk = seed ? std::make_unique<SecKey>(cc, *s->dev, seed) : std::make_unique<SecKey>(cc, *s->dev);
-    s->sk->GenSecKey(2);   // s^2 -> s: what multiplyBy relinearises with (benchmarks/bgv_basic.cpp:150-152)
+    if (keys)
+      s->sk->importKeys(keys, key_words);
+    else
+      s->sk->GenSecKey(2);   // s^2 -> s: what multiplyBy relinearises with (benchmarks/bgv_basic.cpp:150-152)
     const size_t N = (size_t)cc.phim, L = cc.ctxtPrimes.size(), B = (size_t)batch;
     uint64_t ps = seed * 0x9e3779b97f4a7c15ull + 12345;
     // CKKS: the factor PubKey::Encrypt(Ptxt<CKKS>) encodes with, EncryptedArrayCx::encodeScalingFactor() / size with
@@ -153,6 +166,148 @@ extern "C" int hxh_session_create(hxh_session** out, int device, void* stream, i
     s->dev->sync();
     *out = s.release();
   });
+}
+
+extern "C" int hxh_session_create(hxh_session** out, int device, void* stream, int scheme, long m, long p, long r,
+                                  long bits, int batch, uint64_t seed)
+{
+  return session_create(out, device, stream, scheme, m, p, r, bits, batch, seed, nullptr, 0);
+}
+
+extern "C" int hxh_session_create_with_keys(hxh_session** out, int device, void* stream, int scheme, long m, long p,
+                                            long r, long bits, int batch, uint64_t enc_seed, const uint64_t* keys,
+                                            size_t key_words)
+{
+  if (!keys || key_words == 0) {
+    g_err = "hxh_session_create_with_keys: no key material";
+    return -1;
+  }
+  return session_create(out, device, stream, scheme, m, p, r, bits, batch, enc_seed, keys, key_words);
+}
+
+extern "C" int hxh_export_keys(hxh_session* s, uint64_t* out, size_t cap_words, size_t* need_words)
+{
+  if (!s) {
+    g_err = "null session";
+    return -1;
+  }
+  return guarded([&] {
+    if (s->key_blob.empty())
+      s->key_blob = s->sk->exportKeys();
+    if (need_words)
+      *need_words = s->key_blob.size();
+    if (out) {
+      if (cap_words < s->key_blob.size())
+        throw InvalidArgument("hxh_export_keys: buffer too small");
+      memcpy(out, s->key_blob.data(), s->key_blob.size() * 8);
+      s->key_blob.clear();
+      s->key_blob.shrink_to_fit();
+    }
+  });
+}
+
+static const Ctxt* session_ctxt(const hxh_session* s, int level, int which)
+{
+  if (level == 0)
+    return (which == 0 || which == 1) ? s->fresh[which].get() : nullptr;
+  return (level == 1 || level == 2) ? s->prod[level].get() : nullptr;
+}
+
+extern "C" int hxh_chain_primes(const hxh_session* s, uint64_t* out, int cap, int* n)
+{
+  if (!s || !n) {
+    g_err = "null argument";
+    return -1;
+  }
+  *n = (int)s->cc->primes.size();
+  for (int i = 0; out && i < cap && i < *n; i++)
+    out[i] = s->cc->primes[(size_t)i];
+  return 0;
+}
+
+extern "C" int hxh_ctxt_info(hxh_session* s, int level, int which, double info[8])
+{
+  if (!s || !info) {
+    g_err = "null argument";
+    return -1;
+  }
+  return guarded([&] {
+    const Ctxt* c = session_ctxt(s, level, which);
+    if (!c)
+      throw LogicError("hxh_ctxt_info: no such ciphertext");
+    info[0] = (double)c->lnNoise;
+    info[1] = c->lnRatFactor;
+    info[2] = c->ptxtMag;
+    info[3] = (double)c->intFactor;
+    info[4] = (double)c->ptxtSpace;
+    info[5] = (double)c->parts.size();
+    info[6] = s->sk->keys.lnNoise;
+    info[7] = (double)(s->sk->keys.ptxtSpace ? s->sk->keys.ptxtSpace : s->cc->ptxtSpace);
+  });
+}
+
+extern "C" int hxh_ctxt_rows(hxh_session* s, int level, int which, int part, uint64_t* out, int* idx_out, int cap_rows,
+                             int* nrows)
+{
+  if (!s || !nrows || part < 0) {
+    g_err = "hxh_ctxt_rows: bad argument";
+    return -1;
+  }
+  return guarded([&] {
+    const Ctxt* c = session_ctxt(s, level, which);
+    if (!c)
+      throw LogicError("hxh_ctxt_rows: no such ciphertext");
+    auto it = c->parts.find(SKHandle{(long)part, 1});
+    if (it == c->parts.end())
+      throw LogicError("hxh_ctxt_rows: no such part");
+    const IndexSet idx = it->second.getIndexSet();
+    *nrows = (int)idx.size();
+    if (idx_out)
+      for (int r = 0; r < *nrows && r < cap_rows; r++)
+        idx_out[r] = idx[(size_t)r];
+    if (out) {
+      if (cap_rows < *nrows)
+        throw InvalidArgument("hxh_ctxt_rows: buffer too small");
+      const std::vector<uint64_t> rows = it->second.getRows();   // [row][batch][phi(m)]
+      memcpy(out, rows.data(), rows.size() * 8);
+    }
+  });
+}
+
+extern "C" int hxh_relin_matrix(hxh_session* s, uint64_t* b, uint64_t* a, int* idx_out, int cap_rows, int* ndig,
+                                int* nrows)
+{
+  if (!s || !ndig || !nrows) {
+    g_err = "null argument";
+    return -1;
+  }
+  return guarded([&] {
+    const KeySwitch* W = s->sk->keys.relin;
+    if (!W)
+      throw LogicError("hxh_relin_matrix: the session has no relinearisation matrix");
+    *ndig = W->ndig();
+    *nrows = (int)W->rows().size();
+    if (idx_out)
+      for (int r = 0; r < *nrows && r < cap_rows; r++)
+        idx_out[r] = W->rows()[(size_t)r];
+    if (b && a) {
+      if (cap_rows < *nrows)
+        throw InvalidArgument("hxh_relin_matrix: buffer too small");
+      std::vector<uint64_t> hb, ha;
+      W->download(hb, ha, (size_t)s->cc->phim);
+      memcpy(b, hb.data(), hb.size() * 8);
+      memcpy(a, ha.data(), ha.size() * 8);
+    }
+  });
+}
+
+extern "C" int hxh_arena_stats(hxh_session* s, uint64_t out[4])
+{
+  if (!s || !out) {
+    g_err = "null argument";
+    return -1;
+  }
+  return guarded([&] { s->dev->arenaStats(out); });
 }
 
 extern "C" int hxh_session_destroy(hxh_session* s)

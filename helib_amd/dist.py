@@ -1,8 +1,10 @@
 """Multi-GPU harness for the one axis this path shards on: independent ciphertexts.
 
 One process per GPU; each rank owns a contiguous slice of the ciphertext batch and a replica
-of the (small) key-switch matrix.  There is no data-path collective: torch.distributed
-(backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests) is used only for the
+of the (small) key-switch matrix: rank 0 makes the key pair, broadcast_words() replicates its
+material once (RCCL broadcast between device buffers), every rank encrypts and multiplies its
+own slice under it.  There is no data-path collective during the multiplies: torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests) otherwise carries only the
 barrier around the timed region and the max-over-ranks of the elapsed time."""
 import os
 
@@ -56,6 +58,33 @@ class Group:
         t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
+
+    def broadcast_words(self, words, src=0):
+        """A numpy uint64 array from rank `src` to every rank -- the key material of the one key pair all ranks
+        multiply under (the KeySwitch matrix replicated once).  The length first, then the payload as ONE
+        tensor on the group's device: with backend "nccl" that is an RCCL broadcast over xGMI between device
+        buffers; gloo (CPU tests) moves host memory.  Returns (array, payload bytes); `words` is ignored on the
+        other ranks."""
+        import numpy as np
+        if self.dist is None:
+            return np.ascontiguousarray(words, dtype=np.uint64), 0
+        import torch
+        dev = self.device if self.device is not None else "cpu"
+        n = torch.tensor([int(len(words)) if self.rank == src else 0], dtype=torch.int64, device=dev)
+        self.dist.broadcast(n, src=src)
+        count = int(n.item())
+        if self.rank == src:
+            host = np.ascontiguousarray(words, dtype=np.uint64).view(np.int64)
+            t = torch.from_numpy(host).to(dev)
+        else:
+            t = torch.empty(count, dtype=torch.int64, device=dev)
+        self.dist.broadcast(t, src=src)
+        out = t.cpu().numpy().view(np.uint64)
+        return (np.ascontiguousarray(words, dtype=np.uint64) if self.rank == src else out), count * 8
+
+    def world_size_seen(self):
+        """the size of the process group as torch.distributed reports it (1 without a group)"""
+        return int(self.dist.get_world_size()) if self.dist is not None else 1
 
     def close(self):
         if self.dist is not None:

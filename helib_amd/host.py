@@ -33,6 +33,11 @@ def lib(path=None):
             "hxh_multiply": [vp, ip, ip, ip], "hxh_multiply_single": [vp, ip],
             "hxh_plaintext": [vp, ip, vp], "hxh_decrypt": [vp, ip, ip, vp, vp],
             "hxh_result_primes": [vp, ip, vp, ip, vp],
+            "hxh_export_keys": [vp, vp, C.c_size_t, vp],
+            "hxh_session_create_with_keys": [vp, ip, vp, ip, lg, lg, lg, lg, ip, C.c_uint64, vp, C.c_size_t],
+            "hxh_chain_primes": [vp, vp, ip, vp], "hxh_ctxt_info": [vp, ip, ip, vp],
+            "hxh_ctxt_rows": [vp, ip, ip, ip, vp, vp, ip, vp],
+            "hxh_relin_matrix": [vp, vp, vp, vp, ip, vp, vp], "hxh_arena_stats": [vp, vp],
         }
         for name, args in sig.items():
             f = getattr(L, name)
@@ -43,7 +48,9 @@ def lib(path=None):
 
 
 SYMBOLS = ["hxh_session_create", "hxh_session_destroy", "hxh_session_info", "hxh_multiply", "hxh_multiply_single",
-           "hxh_plaintext", "hxh_decrypt", "hxh_result_primes", "hxh_last_error"]
+           "hxh_plaintext", "hxh_decrypt", "hxh_result_primes", "hxh_last_error", "hxh_export_keys",
+           "hxh_session_create_with_keys", "hxh_chain_primes", "hxh_ctxt_info", "hxh_ctxt_rows", "hxh_relin_matrix",
+           "hxh_arena_stats"]
 
 
 class Session:
@@ -51,12 +58,20 @@ class Session:
     or "ckks" (ContextBuilder<CKKS>().m(m).precision(r).bits(bits)), a key pair with its relinearisation
     matrix and `batch` pairs of fresh encryptions of seeded random plaintexts."""
 
-    def __init__(self, scheme, m, p, r, bits, batch, device=0, stream=0, seed=7, lib_path=None):
+    def __init__(self, scheme, m, p, r, bits, batch, device=0, stream=0, seed=7, lib_path=None, keys=None):
+        """keys: key material exported by another session of the same parameters (export_keys(): a numpy uint64
+        array, e.g. as received from rank 0) -- the session then holds THAT key pair and `seed` drives only its own
+        encryptions and plaintexts; None: the session generates its own key pair from `seed` (0 = OS entropy)."""
         self.L = lib(lib_path)
         self.scheme = scheme
         self.h = C.c_void_p()
-        self._chk(self.L.hxh_session_create(C.byref(self.h), device, C.c_void_p(stream), 1 if scheme == "ckks" else 0,
-                                            m, p, r, bits, batch, seed))
+        sc = 1 if scheme == "ckks" else 0
+        if keys is None:
+            self._chk(self.L.hxh_session_create(C.byref(self.h), device, C.c_void_p(stream), sc, m, p, r, bits, batch, seed))
+        else:
+            keys = np.ascontiguousarray(keys, dtype=np.uint64)
+            self._chk(self.L.hxh_session_create_with_keys(C.byref(self.h), device, C.c_void_p(stream), sc, m, p, r, bits,
+                                                          batch, seed, keys.ctypes.data_as(C.c_void_p), keys.size))
         info = (C.c_long * 8)()
         self._chk(self.L.hxh_session_info(self.h, info))
         (self.phim, self.L_ctxt, self.K, self.D, self.n_small, self.ctxt_bits, self.special_bits, self.batch) = \
@@ -101,6 +116,54 @@ class Session:
         n = C.c_int()
         self._chk(self.L.hxh_result_primes(self.h, level, out, 512, C.byref(n)))
         return [int(out[i]) for i in range(min(n.value, 512))]
+
+    # ---- one key pair, many GPUs; and what a checker needs of a session ----
+    def export_keys(self):
+        """the key pair with its relinearisation matrix as uint64 words (hxh_export_keys)"""
+        need = C.c_size_t()
+        self._chk(self.L.hxh_export_keys(self.h, None, 0, C.byref(need)))
+        out = np.empty(need.value, dtype=np.uint64)
+        self._chk(self.L.hxh_export_keys(self.h, out.ctypes.data_as(C.c_void_p), out.size, None))
+        return out
+
+    def chain_primes(self):
+        n = C.c_int()
+        self._chk(self.L.hxh_chain_primes(self.h, None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.uint64)
+        self._chk(self.L.hxh_chain_primes(self.h, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return [int(q) for q in out]
+
+    def ctxt_info(self, level, which=0):
+        """dict of the bookkeeping of fresh operand `which` (level 0) or the kept product of level 1 / 2"""
+        info = (C.c_double * 8)()
+        self._chk(self.L.hxh_ctxt_info(self.h, level, which, info))
+        keys = ("lnNoise", "lnRatFactor", "ptxtMag", "intFactor", "ptxtSpace", "nparts", "key_lnNoise", "key_ptxtSpace")
+        return dict(zip(keys, (float(v) for v in info)))
+
+    def ctxt_rows(self, level, which, part):
+        """(prime indices by row, rows [nrows, batch, phi(m)]) of part 0 / 1 of a ciphertext the session holds"""
+        n = C.c_int()
+        self._chk(self.L.hxh_ctxt_rows(self.h, level, which, part, None, None, 0, C.byref(n)))
+        idx = (C.c_int * n.value)()
+        out = np.empty((n.value, self.batch, self.phim), dtype=np.uint64)
+        self._chk(self.L.hxh_ctxt_rows(self.h, level, which, part, out.ctypes.data_as(C.c_void_p), idx, n.value, C.byref(n)))
+        return [int(i) for i in idx], out
+
+    def relin_matrix(self):
+        """(row primes, b, a) of the relinearisation matrix, b / a = [ndig, nrows, phi(m)]"""
+        nd, nr = C.c_int(), C.c_int()
+        self._chk(self.L.hxh_relin_matrix(self.h, None, None, None, 0, C.byref(nd), C.byref(nr)))
+        idx = (C.c_int * nr.value)()
+        b = np.empty((nd.value, nr.value, self.phim), dtype=np.uint64)
+        a = np.empty_like(b)
+        self._chk(self.L.hxh_relin_matrix(self.h, b.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), idx, nr.value,
+                                          C.byref(nd), C.byref(nr)))
+        return [int(i) for i in idx], b, a
+
+    def arena_stats(self):
+        out = (C.c_uint64 * 4)()
+        self._chk(self.L.hxh_arena_stats(self.h, out))
+        return {"reserved_bytes": int(out[0]), "in_use_bytes": int(out[1]), "hipMalloc_calls": int(out[2]), "parked_blocks": int(out[3])}
 
     # ---- the checks bench.py and the tests apply to a kept product ----
     @staticmethod
@@ -151,15 +214,17 @@ class Session:
 
     def verify(self, level, elements=None):
         """decrypt(product) == plaintext product for the listed batch elements (all by default); returns the
-        number checked, raises HostError on a mismatch.  CKKS: within the bound the ciphertext reports and
-        1e-3 of the largest coefficient."""
+        number checked, raises HostError on a mismatch.  CKKS: within the bound the ciphertext reports (and, from
+        precision(10) on, 1e-3 of the largest coefficient)."""
         todo = range(self.batch) if elements is None else elements
         for b in todo:
             got, bound = self.decrypt(level, b)
             want = self.expected(level, b)
             if self.scheme == "ckks":
+                # precision(r) promises 2^-r: at the reference's benchmark setting precision(1) the reported bound is
+                # all there is to check; from 10 bits on the product must also be right to 1e-3 of its size
                 err = float(np.max(np.abs(got - want)))
-                if not (err <= bound and err < 1e-3 * float(np.max(np.abs(want)))):
+                if not (err <= bound and (self.r < 10 or err < 1e-3 * float(np.max(np.abs(want))))):
                     raise HostError(f"CKKS level {level} element {b}: decode error {err} (bound {bound})")
             elif not np.array_equal(got.astype(np.int64).astype(object), np.asarray(want).astype(object)):
                 raise HostError(f"decrypt(multiplyBy(a, b)) != a*b at level {level}, batch element {b}")

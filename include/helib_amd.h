@@ -204,6 +204,11 @@ int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const int* dig_of
 int hx_ksk_create(hx_ctx* ctx, int ndig, const int* row_idx, int nrows, const uint64_t* b,
                   const uint64_t* a, hx_ksk** out);
 int hx_ksk_destroy(hx_ksk* k);
+/* the matrix back on the host, for a checker or for another process that is to hold the same key (one key pair
+ * replicated over the GPUs of a node): shape first (row_idx_out may be NULL), then b, a =
+ * [ndig][nrows][phim] as hx_ksk_create took them (KeySwitch::b / the expanded a column, include/helib/keySwitching.h:86-101) */
+int hx_ksk_shape(const hx_ksk* k, int* ndig, int* nrows, int* row_idx_out /* nrows */);
+int hx_ksk_download(const hx_ksk* k, uint64_t* b, uint64_t* a);   /* synchronous */
 
 /* Ctxt::tensorProduct for two 2-part ciphertexts (src/Ctxt.cpp:1576-1597):
  * o0 = c0*d0, o1 = c0*d1 + c1*d0, o2 = c1*d1. */

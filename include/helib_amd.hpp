@@ -219,6 +219,8 @@ public:
   void setStream(void* stream) const { check(hx_ctx_set_stream(h_.get(), stream)); }
   // device memory for the slabs of this context's DoubleCRT objects, reserved up front (hx_ctx_reserve)
   void reserve(uint64_t bytes) const { check(hx_ctx_reserve(h_.get(), bytes)); }
+  // reserved bytes, bytes in use, hipMalloc calls so far, blocks parked for a live graph (hx_ctx_arena_stats)
+  void arenaStats(uint64_t out[4]) const { check(hx_ctx_arena_stats(h_.get(), out)); }
   hx_ctx* handle() const { return h_.get(); }
 
   // Measured-noise norms (hx_*_norms) either land in the caller's array before the call returns, or --
@@ -534,6 +536,20 @@ public:
   }
   hx_ksk* handle() const { return h_.get(); }
   const IndexSet& rows() const { return rows_; }
+  int ndig() const
+  {
+    int d = 0, n = 0;
+    check(hx_ksk_shape(h_.get(), &d, &n, nullptr));
+    return d;
+  }
+  // the matrix back on the host, [ndig][rows][phi(m)] each (what the constructor took)
+  void download(std::vector<uint64_t>& b, std::vector<uint64_t>& a, size_t phim) const
+  {
+    const size_t words = (size_t)ndig() * rows_.size() * phim;
+    b.resize(words);
+    a.resize(words);
+    check(hx_ksk_download(h_.get(), b.data(), a.data()));
+  }
   // the matrix' rows are exactly `first` followed by `then`, in this order (what hx_mul_relin expects of the
   // ciphertext's primes and the special primes)
   bool coversInOrder(const IndexSet& first, const IndexSet& then) const

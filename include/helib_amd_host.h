@@ -57,6 +57,27 @@ int hxh_decrypt(hxh_session* s, int level, int b, double* out, double* bound);
 /* prime indices of the kept product of `level` (ascending); returns the count through *n (cap = size of out) */
 int hxh_result_primes(const hxh_session* s, int level, int* out, int cap, int* n);
 
+/* ---- one key pair, many GPUs: rank 0's key material replicated, every rank encrypts and multiplies
+ * its own shard under it.  hxh_export_keys: the key pair with its relinearisation matrix as 64-bit words (size
+ * query with out = NULL); hxh_session_create_with_keys: a session of the same parameters whose key pair is that
+ * material -- enc_seed drives this session's encryption randomness and plaintexts only. ---- */
+int hxh_export_keys(hxh_session* s, uint64_t* out, size_t cap_words, size_t* need_words);
+int hxh_session_create_with_keys(hxh_session** out, int device, void* stream, int scheme, long m, long p, long r,
+                                 long bits, int batch, uint64_t enc_seed, const uint64_t* keys, size_t key_words);
+
+/* ---- what a checker needs of a session: the chain, the ciphertexts' rows and bookkeeping, the matrix ---- */
+/* the chain's primes in Context::moduli order (small, ctxt, special) */
+int hxh_chain_primes(const hxh_session* s, uint64_t* out, int cap, int* n);
+/* a ciphertext the session holds: level 0 = fresh operand `which` (0 / 1), level 1 / 2 = the kept product;
+ * info = lnNoise, lnRatFactor, ptxtMag, intFactor, ptxtSpace, #parts, the key's ln noiseBound and ptxtSpace */
+int hxh_ctxt_info(hxh_session* s, int level, int which, double info[8]);
+/* part 0 / 1 (handles 1, s) of it: out = [row][batch][phi(m)] words (NULL: shape only), idx_out = the rows' primes */
+int hxh_ctxt_rows(hxh_session* s, int level, int which, int part, uint64_t* out, int* idx_out, int cap_rows, int* nrows);
+/* the relinearisation matrix: b, a = [ndig][nrows][phi(m)] (NULL: shape only), idx_out = the rows' primes */
+int hxh_relin_matrix(hxh_session* s, uint64_t* b, uint64_t* a, int* idx_out, int cap_rows, int* ndig, int* nrows);
+/* hx_ctx_arena_stats of the session's device context: reserved bytes, bytes in use, hipMalloc calls, chunks */
+int hxh_arena_stats(hxh_session* s, uint64_t out[4]);
+
 const char* hxh_last_error(void);
 
 #ifdef __cplusplus

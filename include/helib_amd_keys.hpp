@@ -590,20 +590,128 @@ public:
     ks.W = std::make_unique<KeySwitch>(*dev, (int)D, idx, hb, ha);
     ks.ptxtSpace = ptxtSpace;
     ks.noiseBound = noise;
+    registerMatrix(std::move(ks));
+  }
+  // a finished matrix joins the key: the vector in generation order, and what a Ctxt consults (KeySet)
+  void registerMatrix(KeySwitchMatrix&& ks)
+  {
     keySwitching.push_back(std::move(ks));
     const KeySwitchMatrix& k = keySwitching.back();
-    if (fromSPower == 2 && fromXPower == 1) {
+    if (k.fromSPower == 2 && k.fromXPower == 1) {
       keys.relin = k.W.get();
       keys.lnNoise = std::log(k.noiseBound);
-    } else if (fromSPower == 1) {
-      keys.automorph[fromXPower] = k.W.get();
+    } else if (k.fromSPower == 1) {
+      keys.automorph[k.fromXPower] = k.W.get();
       if (!keys.relin)
         keys.lnNoise = std::log(k.noiseBound);
-    } else if (fromXPower == 1) {
-      keys.pow[fromSPower] = k.W.get();
+    } else if (k.fromXPower == 1) {
+      keys.pow[k.fromSPower] = k.W.get();
     }
   }
   void setKeySwitchMap() { keys.setKeySwitchMap(cc->m); }
+
+  // ---- one key pair, several processes (the keys are made once and replicated to every GPU of the
+  // node; in the reference a PubKey / SecKey travels through writeTo / readFrom, src/keys.cpp:904-1097 and
+  // :1547-1600 -- helib_amd_wire.hpp has that format; this is the engine's own flat form, with the key-switching
+  // matrices' a columns expanded as the device holds them) ----
+  // words: magic, m, phi(m), #ctxt primes, #matrices, ptxtSpace, skBound, pubEncrKeyNoise (doubles as bits), the
+  // secret polynomial (phi(m) longs), pubEncrKey parts 0 and 1 ([L][phi(m)]), then per matrix: fromSPower,
+  // fromXPower, ptxtSpace, noiseBound, ndig, nrows, the row primes, b and a ([ndig][nrows][phi(m)])
+  static constexpr uint64_t KEYS_MAGIC = 0x68786b6579733031ull;   // "hxkeys01"
+  std::vector<uint64_t> exportKeys() const
+  {
+    if (sKey.empty() || !pubEncrKey0)
+      throw LogicError("exportKeys: no key has been generated");
+    const size_t n = (size_t)cc->phim, L = cc->ctxtPrimes.size();
+    auto bits = [](double v) {
+      uint64_t u;
+      memcpy(&u, &v, 8);
+      return u;
+    };
+    std::vector<uint64_t> w{KEYS_MAGIC, (uint64_t)cc->m, (uint64_t)n, (uint64_t)L, (uint64_t)keySwitching.size(),
+                            (uint64_t)ptxtSpace, bits(skBound), bits(pubEncrKeyNoise)};
+    for (size_t j = 0; j < n; j++)
+      w.push_back((uint64_t)(j < sKey.size() ? sKey[j] : 0));
+    for (const DoubleCRT* pk : {pubEncrKey0.get(), pubEncrKey1.get()}) {
+      if (pk->getIndexSet() != cc->ctxtPrimes)
+        throw LogicError("exportKeys: the public encryption key is not on the ctxt primes");
+      const std::vector<uint64_t> rows = pk->getRows();
+      w.insert(w.end(), rows.begin(), rows.end());
+    }
+    for (auto& k : keySwitching) {
+      const IndexSet& rows = k.W->rows();
+      const int D = k.W->ndig();
+      for (uint64_t v : {(uint64_t)k.fromSPower, (uint64_t)k.fromXPower, (uint64_t)k.ptxtSpace, bits(k.noiseBound),
+                         (uint64_t)D, (uint64_t)rows.size()})
+        w.push_back(v);
+      for (int r : rows)
+        w.push_back((uint64_t)r);
+      std::vector<uint64_t> b, a;
+      k.W->download(b, a, n);
+      w.insert(w.end(), b.begin(), b.end());
+      w.insert(w.end(), a.begin(), a.end());
+    }
+    return w;
+  }
+  void importKeys(const uint64_t* w, size_t nwords)
+  {
+    if (!sKey.empty())
+      throw LogicError("this host side holds one secret key per SecKey object");
+    const size_t n = (size_t)cc->phim, L = cc->ctxtPrimes.size();
+    size_t pos = 0;
+    auto take = [&](size_t k) {
+      if (pos + k > nwords)
+        throw InvalidArgument("importKeys: truncated key material");
+      const uint64_t* p = w + pos;
+      pos += k;
+      return p;
+    };
+    auto dbl = [](uint64_t u) {
+      double v;
+      memcpy(&v, &u, 8);
+      return v;
+    };
+    const uint64_t* h = take(8);
+    if (h[0] != KEYS_MAGIC || h[1] != (uint64_t)cc->m || h[2] != n || h[3] != L)
+      throw InvalidArgument("importKeys: key material of another context");
+    const size_t nks = (size_t)h[4];
+    ptxtSpace = (long)h[5];
+    skBound = dbl(h[6]);
+    pubEncrKeyNoise = dbl(h[7]);
+    const uint64_t* sk = take(n);
+    sKey.resize(n);
+    for (size_t j = 0; j < n; j++)
+      sKey[j] = (long)sk[j];
+    for (auto* slot : {&pubEncrKey0, &pubEncrKey1}) {
+      const uint64_t* rows = take(L * n);
+      *slot = std::make_unique<DoubleCRT>(*dev, cc->ctxtPrimes, 1, DoubleCRT::Uninitialized{});
+      (*slot)->setRows(std::vector<uint64_t>(rows, rows + L * n));
+    }
+    keys.ptxtSpace = ptxtSpace;
+    for (size_t i = 0; i < nks; i++) {
+      const uint64_t* kh = take(6);
+      KeySwitchMatrix ks;
+      ks.fromSPower = (long)kh[0];
+      ks.fromXPower = (long)kh[1];
+      ks.ptxtSpace = (long)kh[2];
+      ks.noiseBound = dbl(kh[3]);
+      const size_t D = (size_t)kh[4], nr = (size_t)kh[5];
+      if (D < 1 || D > 64 || nr < 1 || nr > cc->primes.size())
+        throw InvalidArgument("importKeys: bad matrix shape");
+      const uint64_t* ri = take(nr);
+      IndexSet rows;
+      for (size_t r = 0; r < nr; r++) {
+        if (ri[r] >= cc->primes.size())
+          throw InvalidArgument("importKeys: a matrix row is not a prime of the chain");
+        rows.push_back((int)ri[r]);
+      }
+      const uint64_t* b = take(D * nr * n);
+      const uint64_t* a = take(D * nr * n);
+      ks.W = std::make_unique<KeySwitch>(*dev, (int)D, rows, std::vector<uint64_t>(b, b + D * nr * n),
+                                         std::vector<uint64_t>(a, a + D * nr * n));
+      registerMatrix(std::move(ks));
+    }
+  }
 
   // balanced_MulMod(ptxt, Q mod p, p) (src/NumbTh.cpp:876-891)
   std::vector<long> ptxtFixed(const std::vector<long>& ptxt, const IndexSet& primeSet, long p)

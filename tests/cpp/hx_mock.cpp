@@ -123,6 +123,11 @@ int hx_ctx_phim(const hx_ctx* c, uint64_t* phim)
 }
 int hx_ctx_set_stream(hx_ctx*, void*) { return HX_OK; }
 int hx_ctx_reserve(hx_ctx*, uint64_t) { return HX_OK; }
+int hx_ctx_arena_stats(hx_ctx*, uint64_t out[4])
+{
+  out[0] = out[1] = out[2] = out[3] = 0;
+  return HX_OK;
+}
 int hx_ctx_sync(hx_ctx*) { return HX_OK; }
 int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_out)
 {
@@ -500,6 +505,21 @@ int hx_ksk_create(hx_ctx* ctx, int ndig, const int* row_idx, int nrows, const ui
   k->b.assign(b, b + n);
   k->a.assign(a, a + n);
   *out = k;
+  return HX_OK;
+}
+int hx_ksk_shape(const hx_ksk* k, int* ndig, int* nrows, int* row_idx_out)
+{
+  *ndig = k->ndig;
+  *nrows = (int)k->rows.size();
+  if (row_idx_out)
+    for (size_t r = 0; r < k->rows.size(); r++)
+      row_idx_out[r] = k->rows[r];
+  return HX_OK;
+}
+int hx_ksk_download(const hx_ksk* k, uint64_t* b, uint64_t* a)
+{
+  memcpy(b, k->b.data(), k->b.size() * 8);
+  memcpy(a, k->a.data(), k->a.size() * 8);
   return HX_OK;
 }
 int hx_ksk_destroy(hx_ksk* k)

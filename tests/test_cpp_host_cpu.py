@@ -7,6 +7,7 @@ algebra, key management, hoisting -- with every result decrypted and compared wi
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -276,6 +277,36 @@ def test_cpp_host_session_library_over_the_mock(mock, scheme, m, p, r, bits, bat
     with pytest.raises(host.HostError):
         s.multiply(3, 1)
     s.close()
+
+
+@pytest.mark.parametrize("scheme,m,p,r,bits,batch,measure", [("bgv", 256, 65537, 1, 400, 2, True), ("ckks", 256, -1, 1, 500, 2, True),
+                                                           ("bgv", 128, 257, 1, 300, 2, False)])
+def test_cpp_session_products_equal_the_oracle_replay_and_one_key_pair_serves_two_sessions(mock, scheme, m, p, r, bits, batch, measure):
+    """(a) tests/session_replay.py: the session's own operands, relinearisation matrix and bookkeeping downloaded
+    (hxh_ctxt_rows / hxh_relin_matrix / hxh_ctxt_info), the python mirror driven over the oracle backend per batch
+    element, every word of the kept products of level 1 and level 2 compared -- the C++ host's fused calls
+    (hx_tensor_bring_to_set / hx_mul_relin through the mock) against the reference's unfused sequence.
+    (b) hxh_export_keys / hxh_session_create_with_keys (one key pair replicated): a second session built
+    from the first one's key material, with its own encryptions, holds the same matrix, and its products decrypt
+    under the imported secret key."""
+    from helib_amd import build as hb, host
+    from tests.session_replay import replay_and_compare
+    so = hb.build_host(force=True, link_dir=mock.dir, link_lib="hx_mock", out=os.path.join(mock.dir, "libhelib_amd_host_mock.so"))
+    s = host.Session(scheme, m, p, r, bits, batch, seed=21, lib_path=so)
+    keys = s.export_keys()
+    assert replay_and_compare(s, scheme, m, p, r, bits, measure) > 0
+    t = host.Session(scheme, m, p, r, bits, batch, seed=22, lib_path=so, keys=keys)
+    si, sb, sa = s.relin_matrix()
+    ti, tb, ta = t.relin_matrix()
+    assert si == ti and np.array_equal(sb, tb) and np.array_equal(sa, ta)
+    assert not np.array_equal(s.ctxt_rows(0, 0, 0)[1], t.ctxt_rows(0, 0, 0)[1])     # its own encryptions
+    assert t.verify(0) == batch
+    t.multiply(1, 1, measure)
+    assert t.verify(1) == batch
+    with pytest.raises(host.HostError):
+        host.Session(scheme, m, p, r, bits + 200, batch, seed=23, lib_path=so, keys=keys)   # another chain
+    s.close()
+    t.close()
 
 
 @pytest.mark.parametrize("m", [128, 1024, 105, 1705])

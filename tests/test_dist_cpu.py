@@ -80,6 +80,9 @@ def test_bench_launcher_spawns_ranks_and_aggregates():
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["dry_launch"] is True and line["scaling"] == "strong"
     assert line["config"]["pairs_all_ranks"] == 513 and line["config"]["last_rank_start"] == 257
+    # one key pair: rank 0's key material reaches every rank through Group.broadcast_words
+    assert line["config"]["process_group_world_size"] == 2 and line["config"]["key_material_bytes_broadcast"] == 4096 * 8
+    assert line["config"]["key_material_same_on_all_ranks"] is True
     # weak scaling: every rank keeps --batch pairs
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch",
                           "--batch", "64", "--steps", "2"], env=env, capture_output=True, text=True, timeout=300)

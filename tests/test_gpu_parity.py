@@ -2158,6 +2158,36 @@ def test_cpp_host_session_library_on_the_device(hx, scheme, m, p, r, bits, batch
     s.close()
 
 
+@pytest.mark.parametrize("scheme,m,p,r,bits,batch,shape", [
+    ("bgv", 32768, 65537, 1, 950, 4, (16, 6, 3)),          # bench.py's default line (BASELINE configs[2])
+    ("ckks", 65536, -1, 1, 1400, 2, (24, 8, 3)),           # bench.py --workload ckks65536 (BASELINE configs[3])
+    ("ckks", 65536, -1, 1, 440, 2, (8, 3, 3)),             # the reference's own benchmarks/ckks_basic.cpp:263 parameters
+    ("bgv", 16384, 65537, 1, 300, 3, None)])
+def test_cpp_session_products_equal_the_oracle_replay(hx, scheme, m, p, r, bits, batch, shape):
+    """The TIMED path of bench.py against the oracle, word for word: libhelib_amd_host.so's session (C++ Ctxt /
+    SecKey; multiplyBy leaving the tensor product to hx_tensor_bring_to_set_norms / hx_mul_relin_norms, i.e.
+    ntt_moddown_prep_tensor_kernel, ntt_moddown_apply_tensor_kernel<14|15, false|true>, ntt_inv_mul_kernel and the
+    key-switch kernel with a TensorSrc) at the benchmark parameters.  tests/session_replay.py downloads the session's
+    own operands, relinearisation matrix and bookkeeping, drives the python mirror over the oracle backend (the
+    reference's unfused sequence, src/Ctxt.cpp:1563-1608, :346-562, :720-786) per batch element, and compares every
+    word of the kept products of level 1 and level 2.  Then a second session built from the first one's exported key
+    material (one key pair replicated) multiplies its own encryptions and decrypts under that key."""
+    from helib_amd import host
+    from tests.session_replay import replay_and_compare
+    s = host.Session(scheme, m, p, r, bits, batch, seed=31)
+    if shape:
+        assert (s.L_ctxt, s.K, s.D) == shape
+    keys = s.export_keys()
+    words = replay_and_compare(s, scheme, m, p, r, bits, measure=True)
+    assert words == 2 * 2 * batch * s.phim * (len(s.result_primes(1)) + len(s.result_primes(2)))
+    assert s.verify(2) == batch
+    t = host.Session(scheme, m, p, r, bits, batch, seed=32, keys=keys)
+    t.multiply(1, 1, True)
+    assert t.verify(1) == batch
+    s.close()
+    t.close()
+
+
 @pytest.mark.parametrize("eps", ["default", "0.05", "1.0"])
 def test_hps_form_of_the_rns_kernels_and_its_redo_list(hx, monkeypatch, eps):
     """The fast basis-extension / digit kernels in their HPS form (rns_kernels.h: ExtRep, engine.hip: hps_min_n) --

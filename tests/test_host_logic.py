@@ -280,7 +280,12 @@ def test_bench_ckks_basic_op_list_over_the_cpu_checker():
         for q in cc.primes:
             o.add_prime(q)
         return OracleBackend(o, cc), (lambda idx, rows: OPoly(o, idx, rows[:, 0]))
-    out = bench.ckks_basic_ops(None, hc, 0, 0, lambda: None, 300, B=1, reps=1, m=1024, backend=backend)
+    for precision in (1, 20):      # the reference's benchmark setting, and one where the relative check applies too
+        out = bench.ckks_basic_ops(None, hc, 0, 0, lambda: None, 300, B=1, reps=1, m=1024, backend=backend, precision=precision)
+        _check_ckks_list(out)
+
+
+def _check_ckks_list(out):
     names = ["adding_two_ciphertexts", "subtracting_two_ciphertexts", "negating_a_ciphertext", "square_a_ciphertext",
              "rotate_a_ciphertext_by1", "multiplying_two_ciphertexts_no_relin", "multiplying_two_ciphertexts",
              "multiply_and_add_two_ciphertexts", "encrypting_ciphertexts", "decrypting_ciphertexts"]
