@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libhelib_amd.so")
 SOURCES = ["ntt_kernels.hip", "conv_kernels.hip", "engine.hip"]
 HEADERS = ["ntt_core.h", "dev_common.h", "rns_kernels.h", "hostmath.h", "conv_core.h", "bluestein.h", "norm_kernels.h",
-           "prg_kernels.h", "arena.h", "prof.h", "conv_dev.h", "ntt_kernel_util.h", "norm_r16.h",
+           "prg_kernels.h", "arena.h", "prof.h", "switches.h", "conv_dev.h", "ntt_kernel_util.h", "norm_r16.h",
            os.path.join("..", "..", "include", "helib_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-Wno-pass-failed"]

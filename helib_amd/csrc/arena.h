@@ -235,10 +235,8 @@ struct SlabArena {
       sys_calls++;
       rc = sys_alloc(want, &p);
     }
-    if (rc != 0 && trim(0) > 0) {  // (engine.hip drains the stream before it lets the arena get here)
-      sys_calls++;
-      rc = sys_alloc(want, &p);
-    }
+    // (no trim here: giving empty chunks back means the system free, a device-wide wait that must not happen inside
+    // a stream capture -- the owner decides: engine.hip's pool_alloc drains its stream, trims and retries)
     if (rc != 0)
       return rc;
     add_chunk(p, want);

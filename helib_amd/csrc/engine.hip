@@ -18,6 +18,7 @@
 #include "../../include/helib_amd.h"
 #include "arena.h"
 #include "prof.h"
+#include "switches.h"
 #include "dev_common.h"
 #include "hostmath.h"
 #include "bluestein.h"
@@ -305,7 +306,7 @@ static int use(hx_ctx* c)
 static constexpr size_t POOL_LIMIT = (size_t)64 << 30;        // keep at most 64 GiB cached
 static int arena_sys_alloc(size_t bytes, void** out)
 {
-  static const bool trace = getenv("HX_ARENA_TRACE") != nullptr;   // one line per hipMalloc the arena makes
+  const bool trace = hxs::current().arena_trace;   // (HX_ARENA_TRACE) one line per hipMalloc the arena makes
   const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(out, bytes);
   if (trace)
@@ -323,7 +324,16 @@ static hipError_t pool_alloc(hx_ctx* c, size_t bytes, void** out)
     c->arena.sys_free = arena_sys_free;
   }
   // a block taken while a capture is open may end up inside the graph: pinned from the start
-  return (hipError_t)c->arena.alloc(bytes, c->capturing, out);
+  int rc = c->arena.alloc(bytes, c->capturing, out);
+  if (rc != 0 && !c->capturing) {
+    // out of device memory: give the arena's empty chunks back and try once more -- explicitly after the stream has
+    // drained (extents of those chunks may have been released behind work still in flight), never inside a capture
+    (void)hipGetLastError();
+    hipStreamSynchronize(c->stream);
+    if (c->arena.trim(0) > 0)
+      rc = c->arena.alloc(bytes, false, out);
+  }
+  return (hipError_t)rc;
 }
 // a device buffer that is being replaced by a larger one: freed now, or kept for the graphs that
 // may have its address baked in (released when the last of them is destroyed)
@@ -480,6 +490,7 @@ extern "C" int hx_ctx_create(hx_ctx** out, int device, uint64_t m)
   if (device < 0 || device >= ndev)
     return fail(HX_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
   HIPCHK(hipSetDevice(device));
+  hxs::refresh();   // the environment switches (switches.h), snapshotted here and nowhere else
   hx_ctx* c = new hx_ctx();
   // a failing allocation below returns through HIPCHK: the half-built context and whatever it
   // already holds on the device go with it
@@ -1272,7 +1283,7 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
   // fused path (conv_dev.h): every convolution is ONE launch of the convolution row kernel + one
   // element-wise pass; needs primes that convolve modulo themselves and sizes the row kernels take
   // (2^13..2^15, the chirp convolution optionally as a radix-4 split)
-  static const bool old_path = getenv("HX_BLUE_OLD") != nullptr;
+  const bool old_path = hxs::current().blue_old;
   auto sub_ok = [](const ConvPlan& pl) {
     const int l = pl.split == 4 ? pl.logn - 2 : pl.logn;
     return (pl.split == 0 || pl.split == 4) && l >= 13 && l <= 15;
@@ -2002,16 +2013,15 @@ extern "C" int hx_profile_begin(void)
 }
 extern "C" int hx_profile_end(char* json, size_t cap, size_t* needed)
 {
-  static thread_local std::string pending;
-  if (pending.empty())
-    pending = hxp::end();
+  // a size query or a too-small buffer leaves the summary in place (hxp::State, under its mutex: any thread may
+  // fetch it; hx_profile_begin drops an unfetched one); recording stops at the first call either way
+  const std::string sum = hxp::end(/*fetch=*/false);
   if (needed)
-    *needed = pending.size() + 1;
-  if (!json || cap < pending.size() + 1)
-    return json ? fail(HX_ERR_INVALID, "hx_profile_end: buffer of %zu bytes, %zu needed", cap, pending.size() + 1)
-                : HX_OK;
-  memcpy(json, pending.c_str(), pending.size() + 1);
-  pending.clear();
+    *needed = sum.size() + 1;
+  if (!json || cap < sum.size() + 1)
+    return json ? fail(HX_ERR_INVALID, "hx_profile_end: buffer of %zu bytes, %zu needed", cap, sum.size() + 1) : HX_OK;
+  memcpy(json, sum.c_str(), sum.size() + 1);
+  (void)hxp::end(/*fetch=*/true);
   return HX_OK;
 }
 
@@ -2350,7 +2360,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   size_t o_hinv = take((size_t)2 * n), o_Wp2 = take((size_t)2 * n);
   // rns_extend_wide_kernel (17..40 source primes): per-target record of 8 + n words, padded so that the last
   // record's group-of-four multiplier reads stay inside the blob
-  const bool wide_cand = n > 16 && n <= 40 && !getenv("HX_NO_WIDE_EXTEND");
+  const bool wide_cand = n > 16 && n <= 40 && !hxs::current().no_wide_extend;
   const size_t wide_stride = 8 + (size_t)n;
   size_t o_wide = wide_cand ? take((size_t)nt * wide_stride + 4) : 0;
   std::vector<uint64_t> h(off, 0);
@@ -2392,9 +2402,9 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     uint64_t q = tq(t);
     // lazy 128-bit accumulation is exact when sum_k a_k*W_k < (sum_k q_k)*q_t <= 8*q_t^2
     // (red128_wide's domain; q_t <= 60 bits)
-    tlazy[t] = (hxh::bitlen(q) <= 60 && sum_src <= (hxh::u128)8 * q && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;
+    tlazy[t] = (hxh::bitlen(q) <= 60 && sum_src <= (hxh::u128)8 * q && !hxs::current().no_lazy_rns) ? 1u : 0u;
     // seven terms + the carried remainder: r + 7 max_src q < 8 q^2 needs max_src <= q
-    tchunk[t] = (hxh::bitlen(q) <= 60 && max_src <= q && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;
+    tchunk[t] = (hxh::bitlen(q) <= 60 && max_src <= q && !hxs::current().no_lazy_rns) ? 1u : 0u;
     h[o_tq + t] = q;
     h[o_tmu64 + t] = (uint64_t)((((hxh::u128)1) << 64) / q);
     int kb = hxh::bitlen(q);
@@ -2462,7 +2472,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   // HPS front end: y_k = a_k (P/p_k)^-1 mod p_k, multipliers (P/p_k) mod t (scaled plans: / P, i.e.
   // p_k^-1 mod t), the same header; "lazy" needs room for up to n + 1 extra multiples of t in the sum
   bool hps_ok = n >= 2 && (n <= 16 || wide_cand) && (ptxt <= 1 || ptxt < ((uint64_t)1 << (wide_cand ? 56 : 58))) &&
-                (!getenv("HX_NO_HPS") || wide_cand);
+                (!hxs::current().no_hps || wide_cand);
   if (hps_ok) {
     auto prod_except = [&](int k, uint64_t m) {   // (P / p_k) mod m
       uint64_t r = 1 % m;
@@ -2510,7 +2520,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
       uint64_t* rec2 = &h[o_pack2 + (size_t)t * pack_stride];
       for (int j = 0; j < 8; j++)
         rec2[j] = rec[j];
-      const uint32_t lazy2 = (hxh::bitlen(q) <= 60 && sum_src + 32 <= (hxh::u128)8 * q && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;
+      const uint32_t lazy2 = (hxh::bitlen(q) <= 60 && sum_src + 32 <= (hxh::u128)8 * q && !hxs::current().no_lazy_rns) ? 1u : 0u;
       rec2[4] = (uint64_t)tk[t] | ((uint64_t)lazy2 << 8) | ((uint64_t)tchunk[t] << 9);
       const uint64_t pinv_t = h[o_upd + 2 * (size_t)t];   // P^-1 mod t
       for (int k = 0; k < n; k++) {
@@ -2530,7 +2540,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   pl->dev.tgt_pack_hps = hx::as_ro(d + o_pack2);
   pl->dev.hps_inv = hx::as_ro(reinterpret_cast<const TW*>(d + o_hinv));
   pl->dev.Wp_hps = hx::as_ro(reinterpret_cast<const TW*>(d + o_Wp2));
-  pl->dev.hps_eps = getenv("HX_HPS_EPS") ? atof(getenv("HX_HPS_EPS")) : 1.0 / (double)(1u << 30);
+  pl->dev.hps_eps = hxs::current().hps_eps;
   pl->dev.n = n;
   pl->dev.nt = nt;
   pl->dev.src_q = hx::as_ro(d + o_srcq);
@@ -2547,15 +2557,15 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   pl->dev.Wp = hx::as_ro(reinterpret_cast<const TW*>(d + o_Wp));
   pl->dev.tgt_lazy = hx::as_ro(reinterpret_cast<const uint32_t*>(d + o_tlazy));
   // a_l < q_l <= max < 2*min <= 2*p_k, or the sources ascend (a_l < p_l <= p_k for l < k)
-  pl->dev.garner_cs = ((max_src / 2 < min_src || std::is_sorted(p.begin(), p.end())) && !getenv("HX_NO_LAZY_RNS")) ? 1u : 0u;
+  pl->dev.garner_cs = ((max_src / 2 < min_src || std::is_sorted(p.begin(), p.end())) && !hxs::current().no_lazy_rns) ? 1u : 0u;
   pl->dev.src_rq = hx::as_ro(reinterpret_cast<const double*>(d + o_srcrq));
   pl->dev.tgt_mu63 = hx::as_ro(d + o_tmu63);
   {
-    bool ok = pl->dev.garner_cs && n <= 8 && (min_src >> 32) != 0 && !getenv("HX_NO_FAST_BREAK");
+    bool ok = pl->dev.garner_cs && n <= 8 && (min_src >> 32) != 0 && !hxs::current().no_fast_break;
     for (int t = 0; t < nt && ok; t++)
       ok = (tq(t) >> 32) != 0;
     pl->dev.fast_ok = ok ? 1u : 0u;
-    bool ok16 = pl->dev.garner_cs && n <= 16 && (min_src >> 32) != 0 && !getenv("HX_NO_FAST_EXTEND");
+    bool ok16 = pl->dev.garner_cs && n <= 16 && (min_src >> 32) != 0 && !hxs::current().no_fast_extend;
     for (int t = 0; t < nt && ok16; t++)
       ok16 = (tq(t) >> 32) != 0;
     pl->dev.fast16_ok = ok16 ? 1u : 0u;
@@ -2600,8 +2610,7 @@ static int redo_prepare(hx_ctx* c, size_t row_words, uint32_t** out)
 // (Garner there is 55 products and spills 62 dwords; CKKS level 2 +3 %).  HX_HPS_MIN_N overrides (tests force 2).
 static int hps_min_n()
 {
-  const char* e = getenv("HX_HPS_MIN_N");
-  return e ? atoi(e) : 9;
+  return hxs::current().hps_min_n;
 }
 static const dim3 REDO_GRID(64);   // the Garner pass over the listed coefficients (grid-stride; the list is almost always empty)
 
@@ -2856,7 +2865,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   hipStream_t ns = c->stream;
   // (measured, profiles/r03_norm_side_stream_ab.txt: no gain -- the one-workgroup-per-CU norm kernel does not get
   // onto the CUs next to a kernel that fills them -- so the side stream is opt-in: HX_NORM_ASYNC=1)
-  static const bool side_stream = getenv("HX_NORM_ASYNC") != nullptr;
+  const bool side_stream = hxs::current().norm_async;
   if (side_stream && !c->capturing) {
     if (!c->norm_stream) {
       HIPCHK(hipStreamCreateWithFlags(&c->norm_stream, hipStreamNonBlocking));
@@ -2914,7 +2923,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   } while (0)
     // experiment, off by default: N = 2^14 as two 4096-point sub-transforms per
     // element -- 64 KiB of LDS and 512 threads per workgroup, two elements resident per CU
-    static const bool split14 = getenv("HX_NORM_SPLIT14") != nullptr;
+    const bool split14 = hxs::current().norm_split14;
     if (split14 && logn == 14) {
       const size_t park_words = (size_t)rows * 4096;   // complex doubles: [row][1][H]
       if (c->norm_park_cap < park_words) {
@@ -2929,7 +2938,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   HX_LAUNCH((hx::embed_norm_quarter_splitT_kernel<SRCT, 12, 512>), dim3((unsigned)rows), dim3(512), \
                      16 * (size_t)4096, ns, srcv, c->d_wtab, logn, c->d_norm_park, c->d_norm2)
     // N = 2^14: the register-tiled kernel (norm_r16.h); HX_NORM_OLD keeps the LDS-pass kernel (A/B)
-    static const bool r16 = getenv("HX_NORM_OLD") == nullptr && getenv("HX_NORM_SPLIT14") == nullptr;
+    const bool r16 = !hxs::current().norm_old && !hxs::current().norm_split14;
     constexpr size_t r16_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
     if (r16 && logn == 14) {
       static bool attr16 = false;
@@ -2964,7 +2973,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
 #undef HX_NORM_SPLIT
 #undef HX_NORM_LAUNCH
     c->xs_rows = 0;
-  } else if (logn - 1 > hx::NORM_MAX_LOGH && !getenv("HX_NORM_PLAIN")) {
+  } else if (logn - 1 > hx::NORM_MAX_LOGH && !hxs::current().norm_plain) {
     // real-input form beyond one workgroup's LDS: S = N/2/8192 sub-transforms, one workgroup per pair
     CHK(flush_xs(c));
     const int logh = hx::NORM_MAX_LOGH;
@@ -2980,7 +2989,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     // the register-tiled form (norm_r16.h) at N = 2^15: measured SLOWER than the kernel below (140 vs 82 us per 192
     // polynomials, profiles/r03_norm_kernels_ab.txt: both sub-transforms run one after the other in one workgroup,
     // where the kernel below overlaps 16 waves) -- opt-in for experiments only
-    static const bool r16s = getenv("HX_NORM_R16_SPLIT") != nullptr;
+    const bool r16s = hxs::current().norm_r16_split;
     if (r16s && logn == 15) {
       constexpr size_t r16_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
       static bool attr16s = false;
@@ -3041,7 +3050,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   np.out = out_host;
   // the few words go to the pinned slot by a kernel writing host memory (hipHostMalloc memory is device-visible),
   // not by a device-to-host copy command: HX_NORM_MEMCPY=1 restores the copy (A/B)
-  static const bool by_copy = getenv("HX_NORM_MEMCPY") != nullptr;
+  const bool by_copy = hxs::current().norm_memcpy;
   if (by_copy) {
     HIPCHK(hipMemcpyAsync(np.pinned, c->d_norm2, sizeof(unsigned long long) * (size_t)rows,
                           hipMemcpyDeviceToHost, ns));
@@ -3289,7 +3298,7 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
   for (int i = 0; i < np; i++)
     if (!ps[i]->owns)
       return HX_ERR_UNSUPPORTED;  // caller-owned storage wants its result in place
-  if (tsrc && (np != 3 || getenv("HX_NO_TENSOR_MULTI")))
+  if (tsrc && (np != 3 || hxs::current().no_tensor_multi))
     return HX_ERR_UNSUPPORTED;
   const size_t rw = a->row_words();
   const int batch = a->batch;
@@ -4552,6 +4561,12 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
       return fail(HX_ERR_PRIMESET, "key-switching matrix rows must start with the ctxt primes");
   if (out0->batch != c0->batch || out1->batch != c0->batch || out0->ctx != c || out1->ctx != c)
     return fail(HX_ERR_INVALID, "Context mismatch");
+  {   // every operand check comes before the outputs are touched: a failing call leaves them as they were
+    const hx_poly* ops4[4] = {c0, c1, d0, d1};
+    for (auto* p : ops4)
+      if (p->ctx != c || p->batch != c0->batch || p->prime_idx != c0->prime_idx)
+        return fail(HX_ERR_PRIMESET, "tensorProduct: parts must be defined relative to the same set of primes");
+  }
   size_t rw = c0->row_words();
   // (an output that aliases an input keeps its rows when it has to grow)
   OWN(out0);
@@ -4563,14 +4578,11 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
   // the tensor product folded into the inverse transform's load and the key-switch kernel (no tensor_kernel pass,
   // the three product parts are never written): power-of-two rings the row kernels take, outputs that are not
   // operands (the key-switch kernel reads operand rows of the coefficient it writes)
-  static const bool fuse_off = getenv("HX_NO_MULRELIN_FUSE") != nullptr;
+  const bool fuse_off = hxs::current().no_mulrelin_fuse;
   const hx_poly* ins[4] = {c0, c1, d0, d1};
   bool alias = false;
   for (auto* p : ins)
     alias = alias || p == out0 || p == out1 || p->d == out0->d || p->d == out1->d;
-  for (auto* p : ins)
-    if (p->ctx != c || p->batch != c0->batch || p->prime_idx != c0->prime_idx)
-      return fail(HX_ERR_PRIMESET, "tensorProduct: parts must be defined relative to the same set of primes");
   if (!fuse_off && !alias && c->pow2 && c->logn >= 13 && c->logn <= 15 && L <= MAX_ROWS) {
     hx::TensorSrc T{c0->d, c1->d, d0->d, d1->d};
     return relin_core(c, nullptr, c0->prime_idx, W->row_idx, W, dig_idx, dig_off, ndig, c0->batch, out0->d, out1->d,

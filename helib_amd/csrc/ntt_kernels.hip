@@ -812,9 +812,7 @@ template <int LOGN, bool INV>
 static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows,
                              int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
 {
-  // (HX_NTT_LDS_PAD: occupancy experiment -- extra dynamic LDS so that fewer workgroups fit a CU)
-  static const size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4 +
-                                  (getenv("HX_NTT_LDS_PAD") ? (size_t)atol(getenv("HX_NTT_LDS_PAD")) : 0);
+  static const size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)ntt_row_kernel<LOGN, INV>,

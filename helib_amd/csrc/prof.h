@@ -15,6 +15,7 @@
 
 #include <cxxabi.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -26,7 +27,7 @@
 namespace hxp {
 
 struct Rec {
-  int name;
+  int name, device;
   unsigned wgs, wg_size;
   hipEvent_t e0, e1;
 };
@@ -35,10 +36,13 @@ struct State {
   std::vector<std::string> names;
   std::unordered_map<const void*, int> by_ptr;
   std::vector<Rec> recs;
-  std::vector<hipEvent_t> spare;
+  std::map<int, std::vector<hipEvent_t>> spare;   // by device: an event is reused on the device it was created on
   size_t dropped = 0;
+  std::string summary;                            // of the window that ended last, until it has been fetched
+  bool have_summary = false;
 };
-inline bool enabled = false;
+// read by every launch from any thread, written under State::mu by begin() / end()
+inline std::atomic<bool> enabled{false};
 inline State& state()
 {
   static State s;
@@ -46,12 +50,13 @@ inline State& state()
 }
 static constexpr size_t MAX_RECS = (size_t)1 << 18;
 
-inline hipEvent_t take_event(State& s)
+inline hipEvent_t take_event(State& s, int device)
 {
   hipEvent_t e = nullptr;
-  if (!s.spare.empty()) {
-    e = s.spare.back();
-    s.spare.pop_back();
+  std::vector<hipEvent_t>& pool = s.spare[device];
+  if (!pool.empty()) {
+    e = pool.back();
+    pool.pop_back();
   } else if (hipEventCreate(&e) != hipSuccess) {
     (void)hipGetLastError();
     e = nullptr;
@@ -99,15 +104,18 @@ inline bool pre(const void* fn, const char* text, hipStream_t st, dim3 grid, dim
   }
   Rec r;
   r.name = it->second;
+  r.device = 0;
+  if (hipGetDevice(&r.device) != hipSuccess)
+    (void)hipGetLastError();
   r.wgs = grid.x * grid.y * grid.z;
   r.wg_size = block.x * block.y * block.z;
-  r.e0 = take_event(s);
-  r.e1 = take_event(s);
+  r.e0 = take_event(s, r.device);
+  r.e1 = take_event(s, r.device);
   if (!r.e0 || !r.e1) {
     if (r.e0)
-      s.spare.push_back(r.e0);
+      s.spare[r.device].push_back(r.e0);
     if (r.e1)
-      s.spare.push_back(r.e1);
+      s.spare[r.device].push_back(r.e1);
     s.dropped++;
     return false;
   }
@@ -122,21 +130,33 @@ inline int begin()
   State& s = state();
   std::lock_guard<std::mutex> lk(s.mu);
   for (Rec& r : s.recs) {
-    s.spare.push_back(r.e0);
-    s.spare.push_back(r.e1);
+    s.spare[r.device].push_back(r.e0);
+    s.spare[r.device].push_back(r.e1);
   }
   s.recs.clear();
   s.dropped = 0;
-  enabled = true;
+  s.summary.clear();
+  s.have_summary = false;
+  enabled.store(true, std::memory_order_relaxed);
   return 0;
 }
 // waits for the recorded launches; JSON: {"launches": n, "dropped": d, "kernels": [{"kernel", "workgroups",
 // "workgroup_size", "calls", "total_us", "avg_us", "min_us", "max_us"} ... by total time]}
-inline std::string end()
+// The window closes at the FIRST call (recording stops there whatever becomes of the summary); the summary is kept
+// -- under the mutex, for whichever thread asks -- until fetch = true hands it out or the next begin() drops it.
+inline std::string end(bool fetch)
 {
   State& s = state();
   std::lock_guard<std::mutex> lk(s.mu);
-  enabled = false;
+  enabled.store(false, std::memory_order_relaxed);
+  if (s.have_summary) {
+    std::string out = s.summary;
+    if (fetch) {
+      s.summary.clear();
+      s.have_summary = false;
+    }
+    return out;
+  }
   struct Agg {
     size_t calls = 0;
     double total = 0, mn = 1e30, mx = 0;
@@ -158,8 +178,8 @@ inline std::string end()
       a.mx = us > a.mx ? us : a.mx;
       a.wg_size = r.wg_size;
     }
-    s.spare.push_back(r.e0);
-    s.spare.push_back(r.e1);
+    s.spare[r.device].push_back(r.e0);
+    s.spare[r.device].push_back(r.e1);
   }
   const size_t n = s.recs.size();
   s.recs.clear();
@@ -185,6 +205,10 @@ inline std::string end()
     first = false;
   }
   out += "]}";
+  if (!fetch) {
+    s.summary = out;
+    s.have_summary = true;
+  }
   return out;
 }
 
@@ -194,7 +218,7 @@ inline std::string end()
   do {                                                                                                     \
     const dim3 _hx_g = (grid), _hx_b = (block);                                                            \
     hipEvent_t _hx_e0, _hx_e1;                                                                             \
-    if (hxp::enabled && hxp::pre((const void*)(kern), #kern, (st), _hx_g, _hx_b, &_hx_e0, &_hx_e1))        \
+    if (hxp::enabled.load(std::memory_order_relaxed) && hxp::pre((const void*)(kern), #kern, (st), _hx_g, _hx_b, &_hx_e0, &_hx_e1))        \
       hipExtLaunchKernelGGL(kern, _hx_g, _hx_b, (lds), (st), _hx_e0, _hx_e1, 0, __VA_ARGS__);              \
     else                                                                                                   \
       hipLaunchKernelGGL(kern, _hx_g, _hx_b, (lds), (st), __VA_ARGS__);                                    \

@@ -1,0 +1,70 @@
+// switches.h -- every environment switch of the library, in ONE place (host code only).
+//
+// None of them is needed in production.  They select the older or more generic form of a path so that tests can
+// reach it and same-box A/B measurements can compare it (tools/gpu_calls.sh ab:...); every one leaves results
+// bit-identical.  They are listed for users in include/helib_amd.h and read ONCE PER CONTEXT: hx_ctx_create()
+// snapshots the environment (hxs::refresh), every later decision of the library reads the snapshot -- so a test
+// process can change a switch between two contexts, and nothing consults the environment on a hot path.
+// (The C++ host has one switch of its own, HX_NO_LAZY_TENSOR in include/helib_amd_ctxt.hpp, read once per process.)
+#pragma once
+#include <cstdlib>
+
+namespace hxs {
+
+struct Switches {
+  // exact RNS kernels (rns_kernels.h)
+  bool no_hps = false;           // HX_NO_HPS=1          fast kernels (<= 16 sources): Garner instead of the HPS front end
+  double hps_eps = 1.0 / (double)(1u << 30);   // HX_HPS_EPS=x   distance from 0, 1/2, 1 below which an HPS quotient is redone
+  int hps_min_n = 9;             // HX_HPS_MIN_N=n       fast kernels: HPS form from n source primes on
+  bool no_lazy_rns = false;      // HX_NO_LAZY_RNS=1     no 128-bit lazy sums / one-subtraction Garner steps
+  bool no_fast_break = false;    // HX_NO_FAST_BREAK=1   generic break_digits_kernel instead of the fast one
+  bool no_fast_extend = false;   // HX_NO_FAST_EXTEND=1  generic rns_extend_kernel instead of rns_extend_fast_kernel
+  bool no_wide_extend = false;   // HX_NO_WIDE_EXTEND=1  generic rns_extend_kernel<40> instead of rns_extend_wide_kernel (17..40 sources)
+  // fused ciphertext-level paths
+  bool no_tensor_multi = false;  // HX_NO_TENSOR_MULTI=1 tensor product + several-primes mod-switch as two steps
+  bool no_mulrelin_fuse = false; // HX_NO_MULRELIN_FUSE=1 hx_mul_relin with a tensor pass
+  // general m
+  bool blue_old = false;         // HX_BLUE_OLD=1        Bluestein as the round-2 chain of passes instead of ntt_conv_kernel
+  // canonical-embedding norm kernels
+  bool norm_async = false;       // HX_NORM_ASYNC=1      norm kernels on a side stream
+  bool norm_split14 = false;     // HX_NORM_SPLIT14=1    N = 2^14: the split kernel instead of the radix-16 one
+  bool norm_old = false;         // HX_NORM_OLD=1        N = 2^14: the LDS-pass kernel instead of the radix-16 one
+  bool norm_plain = false;       // HX_NORM_PLAIN=1      no split into sub-transforms above 2^14 points
+  bool norm_r16_split = false;   // HX_NORM_R16_SPLIT=1  N = 2^15: radix-16 kernel per half
+  bool norm_memcpy = false;      // HX_NORM_MEMCPY=1     norm read-back by hipMemcpy instead of mapped host memory
+  // diagnostics
+  bool arena_trace = false;      // HX_ARENA_TRACE=1     one line on stderr per hipMalloc the slab arena makes
+};
+
+inline Switches& current()
+{
+  static Switches s;
+  return s;
+}
+inline void refresh()
+{
+  Switches s;
+  auto on = [](const char* name) { return std::getenv(name) != nullptr; };
+  s.no_hps = on("HX_NO_HPS");
+  if (const char* e = std::getenv("HX_HPS_EPS"))
+    s.hps_eps = std::atof(e);
+  if (const char* e = std::getenv("HX_HPS_MIN_N"))
+    s.hps_min_n = std::atoi(e);
+  s.no_lazy_rns = on("HX_NO_LAZY_RNS");
+  s.no_fast_break = on("HX_NO_FAST_BREAK");
+  s.no_fast_extend = on("HX_NO_FAST_EXTEND");
+  s.no_wide_extend = on("HX_NO_WIDE_EXTEND");
+  s.no_tensor_multi = on("HX_NO_TENSOR_MULTI");
+  s.no_mulrelin_fuse = on("HX_NO_MULRELIN_FUSE");
+  s.blue_old = on("HX_BLUE_OLD");
+  s.norm_async = on("HX_NORM_ASYNC");
+  s.norm_split14 = on("HX_NORM_SPLIT14");
+  s.norm_old = on("HX_NORM_OLD");
+  s.norm_plain = on("HX_NORM_PLAIN");
+  s.norm_r16_split = on("HX_NORM_R16_SPLIT");
+  s.norm_memcpy = on("HX_NORM_MEMCPY");
+  s.arena_trace = on("HX_ARENA_TRACE");
+  current() = s;
+}
+
+}  // namespace hxs

@@ -196,6 +196,22 @@ int hx_tensor_bring_to_set_norms(const hx_poly* c0, const hx_poly* c1, const hx_
 int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const int* dig_off, int ndig,
                          const int* sp_idx, int nsp, hx_poly* digits_out);
 
+/* ---------------- environment switches ----------------
+ * None is needed in production: each selects the older or the generic form of a path, for tests that must reach it
+ * and for same-box A/B measurements; results are bit-identical either way.  The library snapshots them when a
+ * context is created (hx_ctx_create; helib_amd/csrc/switches.h is the one place that reads the environment).
+ *   HX_NO_HPS, HX_HPS_EPS=x, HX_HPS_MIN_N=n   exact-RNS kernels: Garner instead of the HPS front end; the trust
+ *                                            margin of an HPS quotient (default 2^-30); HPS from n sources on (9)
+ *   HX_NO_LAZY_RNS                            no 128-bit lazy sums / single-subtraction Garner steps
+ *   HX_NO_FAST_BREAK, HX_NO_FAST_EXTEND, HX_NO_WIDE_EXTEND   generic breakIntoDigits / basis-extension kernels
+ *   HX_NO_TENSOR_MULTI, HX_NO_MULRELIN_FUSE   tensor product as a pass of its own in front of the several-primes
+ *                                            mod-switch / inside hx_mul_relin
+ *   HX_BLUE_OLD                               general m: the chain of passes instead of one convolution kernel
+ *   HX_NORM_ASYNC, HX_NORM_SPLIT14, HX_NORM_OLD, HX_NORM_PLAIN, HX_NORM_R16_SPLIT, HX_NORM_MEMCPY
+ *                                            variants of the canonical-embedding norm kernels and their read-back
+ *   HX_ARENA_TRACE                            one line on stderr per hipMalloc of the slab arena
+ * (include/helib_amd_ctxt.hpp, the C++ host: HX_NO_LAZY_TENSOR -- multiplyBy forms the tensor product eagerly.) */
+
 /* ---------------- ciphertext-level fused loops ---------------- */
 /* KeySwitch matrix W (include/helib/keySwitching.h:86-101) with the a-column
  * expanded once by the host (HElib regenerates it from W.prgSeed on every key

@@ -1600,6 +1600,8 @@ private:
                         : hx_bring_to_set_multi(polys.data(), (int)polys.size(), addv.data(), (int)addv.size(),
                                                 drop.data(), (int)drop.size(), pt);
     }
+    if (rc != HX_OK && pend)
+      a.pendingTensor = pend;   // the product was not formed: `parts` still holds no data, the operands wait again
     check(rc);
     std::vector<std::function<double()>> out;
     size_t k = 0;

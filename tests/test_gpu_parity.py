@@ -2179,7 +2179,7 @@ def test_cpp_session_products_equal_the_oracle_replay(hx, scheme, m, p, r, bits,
         assert (s.L_ctxt, s.K, s.D) == shape
     keys = s.export_keys()
     words = replay_and_compare(s, scheme, m, p, r, bits, measure=True)
-    assert words == 2 * 2 * batch * s.phim * (len(s.result_primes(1)) + len(s.result_primes(2)))
+    assert words == 2 * batch * s.phim * (len(s.result_primes(1)) + len(s.result_primes(2)))   # both parts, both levels
     assert s.verify(2) == batch
     t = host.Session(scheme, m, p, r, bits, batch, seed=32, keys=keys)
     t.multiply(1, 1, True)

@@ -71,6 +71,19 @@ for st in "$@"; do
     bench_ckks)
       timeout 600 python bench.py --workload ckks65536 --steps 8 --warmup 3 > $out/bench_ckks.json 2> $out/bench_ckks.err; echo "bench ckks rc=$?"
       line $out/bench_ckks.json ckks; tail -3 $out/bench_ckks.err ;;
+    ranks2)
+      # the N-rank path with the real engine on this 1-GPU box: two ranks on GPU 0, one key pair broadcast from rank 0
+      timeout 600 python bench.py --gpus 2 --one-device --batch 16 --steps 3 --warmup 1 --mults-per-step 8 --no-extras --cpu-sample 0 \
+         > $out/bench_ranks2.json 2> $out/bench_ranks2.err; echo "ranks2 rc=$?"
+      python - $out/bench_ranks2.json <<'PY'
+import json, sys
+try:
+    d = json.loads([ln for ln in open(sys.argv[1]) if ln.startswith('{')][-1]); c = d['config']
+    print('ranks2: value', d['value'], 'n_gpus', d['n_gpus'], 'world', c.get('process_group_world_size'), 'key bytes', c.get('key_material_bytes_broadcast'), c.get('verified'))
+except Exception as e:
+    print('ranks2: no line', e)
+PY
+      tail -3 $out/bench_ranks2.err ;;
     bench6400)
       # the reference's own BGV parameter (benchmarks/bgv_basic.cpp:247): bits=6400 -> L=107, K=36, D=3
       timeout 900 python bench.py --bits 6400 --batch 16 --steps 4 --warmup 1 --mults-per-step 4 --no-extras --cpu-sample 0 \
