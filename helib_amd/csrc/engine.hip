@@ -2354,7 +2354,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   size_t o_tlazy = take((nt + 1) / 2);
   size_t o_srcrq = take(n), o_tmu63 = take(nt);
   size_t o_tchunk = take((nt + 1) / 2);
-  const size_t pack_stride = 8 + 2 * (size_t)n;   // per-target record of the fast kernels (TgtRec in rns_kernels.h)
+  const size_t pack_stride = 10 + 2 * (size_t)n;  // per-target record of the fast kernels (TgtRec in rns_kernels.h)
   size_t o_pack = take((size_t)nt * pack_stride);
   size_t o_pack2 = take((size_t)nt * pack_stride);   // the same for the HPS front end (rns_kernels.h)
   size_t o_hinv = take((size_t)2 * n), o_Wp2 = take((size_t)2 * n);
@@ -2468,6 +2468,9 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
       rec[8 + k] = h[o_W + 2 * ((size_t)t * n + k)];
       rec[8 + n + k] = h[o_W + 2 * ((size_t)t * n + k) + 1];
     }
+    const uint64_t r64 = (uint64_t)((((hxh::u128)1) << 64) % rec[0]);   // red128_any's constant
+    rec[8 + 2 * n] = r64;
+    rec[8 + 2 * n + 1] = hxh::shoup(r64, rec[0]);
   }
   // HPS front end: y_k = a_k (P/p_k)^-1 mod p_k, multipliers (P/p_k) mod t (scaled plans: / P, i.e.
   // p_k^-1 mod t), the same header; "lazy" needs room for up to n + 1 extra multiples of t in the sum
@@ -2520,6 +2523,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
       uint64_t* rec2 = &h[o_pack2 + (size_t)t * pack_stride];
       for (int j = 0; j < 8; j++)
         rec2[j] = rec[j];
+      rec2[8 + 2 * n] = rec[8 + 2 * n];
+      rec2[8 + 2 * n + 1] = rec[8 + 2 * n + 1];
       const uint32_t lazy2 = (hxh::bitlen(q) <= 60 && sum_src + 32 <= (hxh::u128)8 * q && !hxs::current().no_lazy_rns) ? 1u : 0u;
       rec2[4] = (uint64_t)tk[t] | ((uint64_t)lazy2 << 8) | ((uint64_t)tchunk[t] << 9);
       const uint64_t pinv_t = h[o_upd + 2 * (size_t)t];   // P^-1 mod t
@@ -2563,11 +2568,11 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   {
     bool ok = pl->dev.garner_cs && n <= 8 && (min_src >> 32) != 0 && !hxs::current().no_fast_break;
     for (int t = 0; t < nt && ok; t++)
-      ok = (tq(t) >> 32) != 0;
+      ok = (tq(t) >> 32) != 0 && hxh::bitlen(tq(t)) <= 60;
     pl->dev.fast_ok = ok ? 1u : 0u;
     bool ok16 = pl->dev.garner_cs && n <= 16 && (min_src >> 32) != 0 && !hxs::current().no_fast_extend;
     for (int t = 0; t < nt && ok16; t++)
-      ok16 = (tq(t) >> 32) != 0;
+      ok16 = (tq(t) >> 32) != 0 && hxh::bitlen(tq(t)) <= 60;
     pl->dev.fast16_ok = ok16 ? 1u : 0u;
     pl->dev.hps_ok = (hps_ok && ok16) ? 1u : 0u;   // (the front end lives in the fast kernels only)
     bool okw = wide_cand && hps_ok && (min_src >> 32) != 0 && hxh::bitlen(max_src) <= 60;

@@ -615,53 +615,90 @@ struct ModDownTensorIO {
       HX_SCHED_FENCE();
     });
   }
+  // Operand words are requested one group (eight words: two coefficients of part 1, four of parts 0 / 2) AHEAD of
+  // the arithmetic that consumes them, in a double buffer, with loads the compiler can neither sink nor delay
+  // (ModDownIO::ld_pinned) and explicit vmcnt waits -- round 3 loaded a group and then waited for it, sixteen
+  // exposed round trips per workgroup, which is what kept this kernel 19 % above its instruction floor
+  // (profiles/r04_valu_floor_by_class.json).
+  static __device__ __forceinline__ uint64_t ld_pinned(const v4i32& r, unsigned tid, unsigned c)
+  {
+    uint64_t x;
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(x) : "v"((int)(tid * 8u)), "s"(r), "s"((int)(c * 8u)) : "memory");
+    return x;
+  }
+  template <int N>
+  static __device__ __forceinline__ void pinned_wait(uint64_t (&x)[8])
+  {
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+                 : "n"(N)
+                 : "memory");
+  }
+  // the eight words of group g: part 1: (a0, b1, a1, b0) of coefficients 2g, 2g+1; else (x, y) of 4g .. 4g+3
+  template <int LOGN, bool P1, int g>
+  __device__ __forceinline__ void request(unsigned tid, uint64_t (&w)[8]) const
+  {
+    if constexpr (P1) {
+      static_for<0, 2>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int i = 2 * g + j;
+        const unsigned c = eval_const<LOGN>(i);
+        w[4 * j + 0] = ld_pinned(ra, tid, c);
+        w[4 * j + 1] = ld_pinned(rb, tid, c);
+        w[4 * j + 2] = ld_pinned(rc, tid, c);
+        w[4 * j + 3] = ld_pinned(rd, tid, c);
+      });
+    } else {
+      static_for<0, 4>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int i = 4 * g + j;
+        const unsigned c = eval_const<LOGN>(i);
+        w[2 * j + 0] = ld_pinned(ra, tid, c);
+        w[2 * j + 1] = ld_pinned(rb, tid, c);
+      });
+    }
+  }
   template <int LOGN>
   __device__ __forceinline__ void store_prefetch(unsigned, StorePrefetch&) const {}
-  template <int LOGN, int B, bool EST>
-  __device__ __forceinline__ void store_all(unsigned tid, uint64_t (&v)[32], const QC& qc, StorePrefetch&) const
+  template <int LOGN, int B, bool EST, bool P1>
+  __device__ __forceinline__ void store_part(unsigned tid, uint64_t (&v)[32], const QC& qc) const
   {
-    constexpr int G = 2;   // operand words of two coefficients in flight (up to 8 loads) ahead of their arithmetic
+    constexpr int CPG = P1 ? 2 : 4, NG = 32 / CPG;   // coefficients per group, groups
     auto one = [&](auto I, uint64_t x0, uint64_t y0, uint64_t x1, uint64_t y1) {
       constexpr int i = decltype(I)::value;
-      const uint64_t c = part == 1 ? tensor_value(1, x0, x1, y1, y0, q, mu, k) : tensor_value(0, x0, 0, y0, 0, q, mu, k);
+      const uint64_t c = P1 ? tensor_value(1, x0, x1, y1, y0, q, mu, k) : tensor_value(0, x0, 0, y0, 0, q, mu, k);
       uint64_t x = v[i];
       if constexpr (B > 8)
         x = csub(x, qc.q8);
       put(tid, eval_const<LOGN>(i), norm_from<12, EST>(shoup4_acc(c, cf, qc.nq, qc.q8 - x), qc));
     };
-    if (part == 1) {   // (wave-uniform: one of the two loops runs)
-      static_for<0, 32 / G>([&](auto GI) {
-        constexpr int g = decltype(GI)::value;
-        uint64_t a0[G], b1[G], a1[G], b0[G];
-        static_for<0, G>([&](auto J) {
-          constexpr int j = decltype(J)::value, i = g * G + j;
-          a0[j] = ld(ra, tid, eval_const<LOGN>(i));
-          b1[j] = ld(rb, tid, eval_const<LOGN>(i));
-          a1[j] = ld(rc, tid, eval_const<LOGN>(i));
-          b0[j] = ld(rd, tid, eval_const<LOGN>(i));
-        });
-        static_for<0, G>([&](auto J) {
-          constexpr int j = decltype(J)::value;
-          one(std::integral_constant<int, g * G + j>{}, a0[j], b1[j], a1[j], b0[j]);
-        });
-        HX_SCHED_FENCE();
+    uint64_t wb[2][8];
+    request<LOGN, P1, 0>(tid, wb[0]);
+    static_for<0, NG>([&](auto GI) {
+      constexpr int g = decltype(GI)::value;
+      constexpr bool more = g + 1 < NG;
+      if constexpr (more)
+        request<LOGN, P1, g + 1>(tid, wb[(g + 1) & 1]);
+      // in flight behind group g's words: the CPG stores of group g-1 and the eight loads of group g+1
+      pinned_wait<(g > 0 ? CPG : 0) + (more ? 8 : 0)>(wb[g & 1]);
+      static_for<0, CPG>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (P1)
+          one(std::integral_constant<int, g * CPG + j>{}, wb[g & 1][4 * j], wb[g & 1][4 * j + 1], wb[g & 1][4 * j + 2],
+              wb[g & 1][4 * j + 3]);
+        else
+          one(std::integral_constant<int, g * CPG + j>{}, wb[g & 1][2 * j], wb[g & 1][2 * j + 1], 0, 0);
       });
-    } else {
-      static_for<0, 32 / G>([&](auto GI) {
-        constexpr int g = decltype(GI)::value;
-        uint64_t x0[G], y0[G];
-        static_for<0, G>([&](auto J) {
-          constexpr int j = decltype(J)::value, i = g * G + j;
-          x0[j] = ld(ra, tid, eval_const<LOGN>(i));
-          y0[j] = ld(rb, tid, eval_const<LOGN>(i));
-        });
-        static_for<0, G>([&](auto J) {
-          constexpr int j = decltype(J)::value;
-          one(std::integral_constant<int, g * G + j>{}, x0[j], y0[j], 0, 0);
-        });
-        HX_SCHED_FENCE();
-      });
-    }
+      HX_SCHED_FENCE();
+    });
+  }
+  template <int LOGN, int B, bool EST>
+  __device__ __forceinline__ void store_all(unsigned tid, uint64_t (&v)[32], const QC& qc, StorePrefetch&) const
+  {
+    if (part == 1)   // (wave-uniform: one of the two loops runs)
+      store_part<LOGN, B, EST, true>(tid, v, qc);
+    else
+      store_part<LOGN, B, EST, false>(tid, v, qc);
   }
   __device__ __forceinline__ void put(unsigned tid, unsigned c, uint64_t o) const
   {

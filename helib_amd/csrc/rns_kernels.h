@@ -405,19 +405,20 @@ struct ExtPlanDev {
   // is at least hps_eps away from 0, 1/2 and 1 (centring compares with 1/2); a wavefront with an
   // untrusted lane takes the Garner path, so the result is exact either way.
   ro_tw hps_inv;       // [n] (P/p_k)^-1 mod p_k
-  ro_u64 tgt_pack_hps; // [nt][8 + 2n] as tgt_pack with the multipliers (P/p_k) mod t (scaled: / P)
+  ro_u64 tgt_pack_hps; // [nt][10 + 2n] as tgt_pack with the multipliers (P/p_k) mod t (scaled: / P)
   ro_tw Wp_hps;        // [n] (P/p_k) mod ptxt
   double hps_eps;
   uint32_t hps_ok;
   ro_u64 wide_pack;   // [nt][8 + n] rns_extend_wide_kernel's record of one target (WideRec), HPS multipliers
   uint32_t wide_ok;   // 16 < n <= 40 sources, every prime in (2^32, 2^60), the HPS tables exist
-  ro_u64 tgt_pack;    // [nt][8 + 2n] everything the fast kernels need of one target in ONE record
+  ro_u64 tgt_pack;    // [nt][10 + 2n] everything the fast kernels need of one target in ONE record
                       // (TgtRec): the loop over targets then makes one scalar-memory round trip per
                       // target instead of one per table (q, P mod t, flags, k, mu, W row: six
                       // dependent s_load / s_waitcnt pairs per iteration before)
 };
 
-// one target of the fast kernels, read from ExtPlanDev::tgt_pack: header and multipliers are loaded
+// one target of the fast kernels, read from ExtPlanDev::tgt_pack (record of 10 + 2N words: header, the N multipliers,
+// their Shoup companions, 2^64 mod t with its companion): header and multipliers are loaded
 // unconditionally at the top of the iteration and pinned in SGPRs (the empty asm keeps the compiler
 // from sinking a load into the branch that uses it, where it would wait for it alone) -- the
 // compiler merges them into s_load_dwordx8/x16 with ONE wait per target.  The Shoup companions
@@ -428,7 +429,8 @@ struct TgtRec {
   ro_u64 r;
   uint64_t q_, pmod_, mu63_, mu64_, fl_, updw_, updp_;
   uint64_t w_[N];
-  __device__ __forceinline__ TgtRec(ro_u64 pack, int t) : r(pack + (size_t)t * (8 + 2 * N))
+  static constexpr int STRIDE = 10 + 2 * N;   // header, N multipliers, their N Shoup companions, 2^64 mod t and its companion
+  __device__ __forceinline__ TgtRec(ro_u64 pack, int t) : r(pack + (size_t)t * STRIDE)
   {
     q_ = r[0];
     pmod_ = r[1];
@@ -469,6 +471,14 @@ struct TgtRec {
     return t;
   }
   __device__ __forceinline__ uint64_t mu() const { return r[7]; }
+  // 2^64 mod q with its Shoup companion, for red128_any (the slots behind the multipliers)
+  __device__ __forceinline__ TW r64() const
+  {
+    TW t;
+    t.w = r[8 + 2 * N];
+    t.wp = r[8 + 2 * N + 1];
+    return t;
+  }
   __device__ __forceinline__ uint64_t w(int k) const { return w_[k]; }
   // the Shoup companions of the multipliers, all at once (the non-lazy path)
   __device__ __forceinline__ void load_wp(uint64_t (&wp)[N]) const
@@ -792,6 +802,19 @@ __device__ __forceinline__ uint64_t red128_q8(u128 S, uint64_t q, uint64_t mu63,
   return csub(r, q);
 }
 
+__device__ __forceinline__ uint64_t norm_any(uint64_t x, uint64_t q, uint32_t mu32);
+// S mod q for ANY S < 2^127 and any prime q in (2^32, 2^60): S = H 2^64 + Lo; H (2^64 mod q) as an approximate Shoup
+// product in [0,4q) (shoup4 takes any 64-bit H), Lo normalised with the 32-bit reciprocal, the sum in [0,5q) finished
+// by three conditional subtractions.  Ten word multiplications -- against seven for red128_q8, whose domain
+// (S < 8 q^2) a sum of more than eight same-size terms, or terms from larger primes, leaves.
+__device__ __forceinline__ uint64_t red128_any(u128 S, uint64_t q, TW r64, uint32_t mu32)
+{
+  uint64_t r = shoup4((uint64_t)(S >> 64), r64, 0 - q) + norm_any((uint64_t)S, q, mu32);
+  r = csub(r, q << 2);
+  r = csub(r, q << 1);
+  return csub(r, q);
+}
+
 __device__ __forceinline__ uint64_t norm_any(uint64_t x, uint64_t q, uint32_t mu32)
 {
   // any 64-bit x -> [0,q), q > 2^32: e = floor(x mu32 / 2^64) is floor(x/q) or one less
@@ -935,23 +958,20 @@ __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* 
       v = red128_q8(S, q, T.mu63(), T.k());
 #endif
     } else {
-      const uint64_t nq = 0 - q, q8 = q << 3;
-      const bool wide = T.k() >= 58;  // 8 terms of < 4q could pass 2^64: fold every second term
-      uint64_t acc = cnt == 1 ? negP : 0;
-      uint64_t wp[N];
-      T.load_wp(wp);
+      // a target the terms outgrow (a 56-bit special prime under 60-bit digit primes): the same limb sums,
+      // reduced by red128_any -- round 3 summed a Shoup product per term here (nine multiplications each)
+      uint64_t c00 = 0, c01 = 0, c10 = 0, c11 = 0;
 #pragma unroll
       for (int k = 0; k < N; k++) {
-        TW tw;
-        tw.w = T.w(k);
-        tw.wp = wp[k];
-        acc += shoup4(a[k], tw, nq);
-        if ((k & 1) && wide)
-          acc = csub(acc, q8);
+        const uint64_t w = T.w(k);
+        const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
+        c00 += (uint64_t)a0[k] * w0;
+        c01 += (uint64_t)a0[k] * w1;
+        c10 += (uint64_t)a1[k] * w0;
+        c11 += (uint64_t)a1[k] * w1;
       }
-      v = norm_any(acc, q, (uint32_t)T.mu64());
-      if (cnt > 1)   // (HPS quotient: a small multiple of -P, reduced on its own)
-        v = add_mod(v, mul_mod((uint64_t)cnt, negP, q, T.mu(), T.k()), q);
+      const u128 S = (u128)cnt * negP + c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
+      v = red128_any(S, q, T.r64(), (uint32_t)T.mu64());
     }
     st_stream1(dd + (size_t)r * row_words, v);
     if (r >= off + N && r < L) {
@@ -1070,42 +1090,22 @@ __device__ __forceinline__ void rns_extend_fast_one(const ExtPlanDev& P, const E
       }
       const u128 S = (u128)cnt * negP + c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
       r = red128_q8(S, q, T.mu63(), T.k());
-    } else if (T.chunk7()) {
-      u128 carry = (u128)cnt * negP;   // (first chunk; afterwards the previous remainder)
-#pragma unroll
-      for (int k0 = 0; k0 < N; k0 += 7) {
-        uint64_t c00 = 0, c01 = 0, c11 = 0;
-#pragma unroll
-        for (int k = k0; k < (k0 + 7 < N ? k0 + 7 : N); k++) {
-          const uint64_t w = T.w(k);
-          const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
-          c00 += (uint64_t)a0[k] * w0;
-          c01 += (uint64_t)a0[k] * w1;
-          c01 += (uint64_t)a1[k] * w0;
-          c11 += (uint64_t)a1[k] * w1;
-        }
-        const u128 S = carry + c00 + ((u128)c01 << 30) + ((u128)c11 << 60);
-        r = red128_q8(S, q, T.mu63(), T.k());
-        carry = r;
-      }
     } else {
-      const uint64_t nq = 0 - q, q8 = q << 3;
-      const bool wide = T.k() >= 58;  // terms of < 4q could pass 2^64: fold every second term
-      uint64_t acc = cnt == 1 ? negP : 0;
-      uint64_t wp[N];
-      T.load_wp(wp);
+      // the terms outgrow red128_q8's domain (more than eight same-size sources, or sources larger than the
+      // target): the same limb sums, reduced by red128_any.  (Round 2 carried a remainder through chunks of seven
+      // terms, or summed a Shoup product per term: 150-190 VALU instructions per target where this takes ~100.)
+      uint64_t c00 = 0, c01 = 0, c10 = 0, c11 = 0;
 #pragma unroll
       for (int k = 0; k < N; k++) {
-        TW tw;
-        tw.w = T.w(k);
-        tw.wp = wp[k];
-        acc += shoup4(a[k], tw, nq);
-        if ((k & 1) && wide)
-          acc = csub(acc, q8);
+        const uint64_t w = T.w(k);
+        const uint32_t w0 = (uint32_t)w & 0x3fffffffu, w1 = (uint32_t)(w >> 30);
+        c00 += (uint64_t)a0[k] * w0;
+        c01 += (uint64_t)a0[k] * w1;
+        c10 += (uint64_t)a1[k] * w0;
+        c11 += (uint64_t)a1[k] * w1;
       }
-      r = norm_any(acc, q, (uint32_t)T.mu64());
-      if (cnt > 1)
-        r = add_mod(r, mul_mod((uint64_t)cnt, negP, q, T.mu(), T.k()), q);
+      const u128 S = (u128)cnt * negP + c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
+      r = red128_any(S, q, T.r64(), (uint32_t)T.mu64());
     }
     if (dm_nonzero) {
       // delta -= diffProd * delta_i_modP
