@@ -2361,8 +2361,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   // rns_extend_wide_kernel (17..40 source primes): per-target record of 8 + n words, padded so that the last
   // record's group-of-four multiplier reads stay inside the blob
   const bool wide_cand = n > 16 && n <= 40 && !hxs::current().no_wide_extend;
-  const size_t wide_stride = 8 + (size_t)n;
-  size_t o_wide = wide_cand ? take((size_t)nt * wide_stride + 4) : 0;
+  const size_t wide_stride = (size_t)hx::wide_stride(n);
+  size_t o_wide = wide_cand ? take((size_t)nt * wide_stride) : 0;
   std::vector<uint64_t> h(off, 0);
   hxh::BigU P(1);
   for (int k = 0; k < n; k++) {
@@ -2653,12 +2653,30 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args_in, s
     // 17..40 source primes (the reference's own benchmark chain): HPS form, then Garner over the coefficients it
     // could not vouch for (they were left untouched, so in-place updates are redone correctly too)
     CHK(redo_prepare(c, row_words, &args.redo));
-    if (n <= 24)
-      HX_LAUNCH((hx::rns_extend_wide_kernel<24>), grid, block, 0, c->stream, pl->dev, args, row_words);
+    const dim3 wgrid((unsigned)((row_words + hx::WIDE_THREADS - 1) / hx::WIDE_THREADS)), wblock(hx::WIDE_THREADS);
+    const size_t lds = (size_t)pl->dev.nt * (size_t)hx::wide_stride(n) * 8;   // the plan's multipliers, once per workgroup
+    static bool wide_attr = false;
+    if (!wide_attr) {
+      for (const void* f : {(const void*)hx::rns_extend_wide_kernel<20>, (const void*)hx::rns_extend_wide_kernel<24>,
+                            (const void*)hx::rns_extend_wide_kernel<28>, (const void*)hx::rns_extend_wide_kernel<32>,
+                            (const void*)hx::rns_extend_wide_kernel<36>, (const void*)hx::rns_extend_wide_kernel<40>})
+        HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      wide_attr = true;
+    }
+    if (lds > 160 * 1024)
+      return fail(HX_ERR_UNSUPPORTED, "internal: basis-extension table of %zu bytes does not fit the LDS", lds);
+    if (n <= 20)
+      HX_LAUNCH((hx::rns_extend_wide_kernel<20>), wgrid, wblock, lds, c->stream, pl->dev, args, row_words);
+    else if (n <= 24)
+      HX_LAUNCH((hx::rns_extend_wide_kernel<24>), wgrid, wblock, lds, c->stream, pl->dev, args, row_words);
+    else if (n <= 28)
+      HX_LAUNCH((hx::rns_extend_wide_kernel<28>), wgrid, wblock, lds, c->stream, pl->dev, args, row_words);
     else if (n <= 32)
-      HX_LAUNCH((hx::rns_extend_wide_kernel<32>), grid, block, 0, c->stream, pl->dev, args, row_words);
+      HX_LAUNCH((hx::rns_extend_wide_kernel<32>), wgrid, wblock, lds, c->stream, pl->dev, args, row_words);
+    else if (n <= 36)
+      HX_LAUNCH((hx::rns_extend_wide_kernel<36>), wgrid, wblock, lds, c->stream, pl->dev, args, row_words);
     else
-      HX_LAUNCH((hx::rns_extend_wide_kernel<40>), grid, block, 0, c->stream, pl->dev, args, row_words);
+      HX_LAUNCH((hx::rns_extend_wide_kernel<40>), wgrid, wblock, lds, c->stream, pl->dev, args, row_words);
     HX_LAUNCH((hx::rns_extend_kernel<40>), REDO_GRID, block, 0, c->stream, pl->dev, args, row_words);
     HIPCHK(hipGetLastError());
     return HX_OK;

@@ -409,7 +409,7 @@ struct ExtPlanDev {
   ro_tw Wp_hps;        // [n] (P/p_k) mod ptxt
   double hps_eps;
   uint32_t hps_ok;
-  ro_u64 wide_pack;   // [nt][8 + n] rns_extend_wide_kernel's record of one target (WideRec), HPS multipliers
+  ro_u64 wide_pack;   // [nt][wide_stride(n)] rns_extend_wide_kernel's record of one target: 8 header words, HPS multipliers as limb pairs
   uint32_t wide_ok;   // 16 < n <= 40 sources, every prime in (2^32, 2^60), the HPS tables exist
   ro_u64 tgt_pack;    // [nt][10 + 2n] everything the fast kernels need of one target in ONE record
                       // (TgtRec): the loop over targets then makes one scalar-memory round trip per
@@ -1152,14 +1152,31 @@ __device__ __forceinline__ void pin_limbs(uint32_t (&a)[N], uint32_t (&b)[N])
   }
 }
 
+constexpr int WIDE_THREADS = 1024;   // one workgroup per CU at <= 128 VGPRs: ONE copy of the plan's multipliers in its LDS
+// words of one target's record: 8 header words + the multipliers padded to a multiple of four (host and device agree)
+__host__ __device__ inline int wide_stride(int n) { return 8 + ((n + 3) & ~3); }
+
 template <int NMAX>   // NMAX a multiple of 4
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
+__global__ void __launch_bounds__(WIDE_THREADS)
 rns_extend_wide_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
 {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // The multipliers of ALL targets (nt x n words of 2 x 30-bit limbs; 107 x 36 x 8 B = 30 KB for a digit of the
+  // bits = 6400 chain) are staged in LDS once per workgroup of 1024 coefficients and read from there as broadcast
+  // ds_read_b128 -- two terms per read, in-order returns the compiler can wait on one by one.  (First form of this
+  // kernel: one s_load_dwordx8 per four terms with a full wait behind each -- nine exposed scalar round trips per
+  // target at four waves per SIMD: 341 us per digit where the multiply-adds alone need ~150.)
+  extern __shared__ __attribute__((aligned(16))) uint64_t wide_lds[];
+  const int n = P.n;
+  const int stride = wide_stride(n);
+  {
+    const int words = P.nt * stride;
+    for (int j = (int)threadIdx.x; j < words; j += WIDE_THREADS)
+      wide_lds[j] = P.wide_pack[j];
+  }
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * WIDE_THREADS + threadIdx.x;
   if (i >= row_words)
     return;
-  const int n = P.n;
   uint32_t a0[NMAX], a1[NMAX];
   double z = 0;
   const uint64_t p = P.ptxt;
@@ -1219,42 +1236,39 @@ rns_extend_wide_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
       fr += dm_negative ? (double)dm_abs : -(double)dm_abs;
     A.frac[i] = fr;
   }
-  const size_t stride = 8 + (size_t)n;
   for (int t = 0; t < P.nt; t++) {
-    ro_u64 rec = P.wide_pack + (size_t)t * stride;
+    // header from the global copy through the scalar unit (uniform), multipliers from LDS
+    ro_u64 rec = P.wide_pack + (size_t)t * (size_t)stride;
     const uint64_t q = rec[0], pmod = rec[1];
     TW R64;
     R64.w = rec[2];
     R64.wp = rec[3];
     const uint32_t mu32 = (uint32_t)rec[4];
+    const ulonglong2* wl = reinterpret_cast<const ulonglong2*>(wide_lds + (size_t)t * (size_t)stride + 8);
     u128 S = (u128)cnt * (q - pmod);   // -P mod t, cnt times: the HPS quotient and the centring
     // (re-pinned every iteration: a zero-extension hoisted out of this loop would double the limbs' registers)
     pin_limbs<0, NMAX>(a0, a1);
+    // straight-line over all NMAX terms (NMAX - n <= 3 of them idle: their limbs are zero and the record is padded
+    // with zeros) -- no branch between the LDS reads and the multiply-adds, so the reads run ahead of their use
     static_for<0, (NMAX + 15) / 16>([&](auto cc) {
       constexpr int k0 = decltype(cc)::value * 16;
-      if (k0 < n) {
-        uint64_t c00 = 0, c01 = 0, c10 = 0, c11 = 0;
-        static_for<0, (k0 + 16 < NMAX ? 16 : NMAX - k0) / 4>([&](auto gc) {
-          constexpr int k4 = k0 + decltype(gc)::value * 4;
-          if (k4 < n) {   // (groups of four: the limbs of k >= n are zero, the record is padded)
-            static_for<k4, k4 + 4>([&](auto kc) {
-              constexpr int k = decltype(kc)::value;
-              const uint64_t w = rec[8 + k];
-              const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
-              c00 += (uint64_t)a0[k] * w0;
-              c01 += (uint64_t)a0[k] * w1;
-              c10 += (uint64_t)a1[k] * w0;
-              c11 += (uint64_t)a1[k] * w1;
-            });
-          }
+      uint64_t c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+      static_for<0, (k0 + 16 < NMAX ? 16 : NMAX - k0) / 2>([&](auto gc) {
+        constexpr int k2 = k0 + decltype(gc)::value * 2;
+        const ulonglong2 w = wl[k2 / 2];
+        const uint64_t w2[2] = {w.x, w.y};
+        static_for<0, 2>([&](auto jc) {
+          constexpr int j = decltype(jc)::value, k = k2 + j;
+          const uint32_t w0 = (uint32_t)w2[j], w1 = (uint32_t)(w2[j] >> 32);
+          c00 += (uint64_t)a0[k] * w0;
+          c01 += (uint64_t)a0[k] * w1;
+          c10 += (uint64_t)a1[k] * w0;
+          c11 += (uint64_t)a1[k] * w1;
         });
-        S += (u128)c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
-      }
+      });
+      S += (u128)c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
     });
-    uint64_t r = shoup4((uint64_t)(S >> 64), R64, 0 - q) + norm_any((uint64_t)S, q, mu32);   // [0, 5q)
-    r = csub(r, q << 2);
-    r = csub(r, q << 1);
-    r = csub(r, q);
+    uint64_t r = red128_any(S, q, R64, mu32);
     if (dm_nonzero) {
       // delta -= diffProd * delta_i_modP
       uint64_t corr = dm_abs;
