@@ -2944,7 +2944,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       HX_LAUNCH((hx::embed_norm_quarter_kernel<SRCT, 0>), dim3((unsigned)rows), dim3(threads), lds,    \
                          ns, srcv, c->d_wtab, logn, c->d_norm2);                                         \
   } while (0)
-    // experiment, off by default (DESIGN.md section 7, item 2c): N = 2^14 as two 4096-point sub-transforms per
+    // experiment, off by default (DESIGN.md section 8, item 2c): N = 2^14 as two 4096-point sub-transforms per
     // element -- 64 KiB of LDS and 512 threads per workgroup, two elements resident per CU
     const bool split14 = hxs::current().norm_split14;
     if (split14 && logn == 14) {

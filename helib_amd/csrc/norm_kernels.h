@@ -424,7 +424,7 @@ embed_norm_quarter_split_kernel(const double* __restrict__ f, const double2* __r
   block_max_to(mx, sm, tid, nth, out2 + row);
 }
 
-// Experiment (HX_NORM_SPLIT14, off by default; DESIGN.md section 7 item 2c): the split form above for any coefficient
+// Experiment (HX_NORM_SPLIT14, off by default; DESIGN.md section 8 item 2c): the split form above for any coefficient
 // source and a compile-time sub-transform size, so that N = 2^14 can run as S = 2 sub-transforms of 4096 points --
 // 64 KiB of LDS and CNTH = 512 threads per workgroup: two elements resident per CU instead of one.
 template <class SRC, int CLOGH, int CNTH>

@@ -228,7 +228,7 @@ tensor_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
 // rows that the accumulation reads anyway -- so those 16 rows are neither written, transformed
 // nor re-read.
 __device__ __forceinline__ uint64_t red128_q8(u128 S, uint64_t q, uint64_t mu63, uint32_t k);  // (below)
-// waves per SIMD the fast RNS kernels are compiled for (A/B knobs; see DESIGN.md 3.5)
+// waves per SIMD the fast RNS kernels are compiled for (A/B knobs; see DESIGN.md 3.7)
 #ifndef HX_EXT_WAVES
 #define HX_EXT_WAVES 7
 #endif

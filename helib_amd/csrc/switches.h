@@ -12,7 +12,7 @@
 namespace hxs {
 
 struct Switches {
-  // exact RNS kernels (rns_kernels.h; DESIGN.md 3.5)
+  // exact RNS kernels (rns_kernels.h; DESIGN.md 3.7)
   bool no_hps = false;           // HX_NO_HPS=1          fast kernels (<= 16 sources): Garner instead of the HPS front end
   double hps_eps = 1.0 / (double)(1u << 30);   // HX_HPS_EPS=x   distance from 0, 1/2, 1 below which an HPS quotient is redone
   int hps_min_n = 9;             // HX_HPS_MIN_N=n       fast kernels: HPS form from n source primes on
@@ -25,7 +25,7 @@ struct Switches {
   bool no_mulrelin_fuse = false; // HX_NO_MULRELIN_FUSE=1 hx_mul_relin with a tensor pass
   // general m
   bool blue_old = false;         // HX_BLUE_OLD=1        Bluestein as the round-2 chain of passes instead of ntt_conv_kernel
-  // canonical-embedding norm kernels (DESIGN.md 3.2)
+  // canonical-embedding norm kernels (DESIGN.md 3.9)
   bool norm_async = false;       // HX_NORM_ASYNC=1      norm kernels on a side stream
   bool norm_split14 = false;     // HX_NORM_SPLIT14=1    N = 2^14: the split kernel instead of the radix-16 one
   bool norm_old = false;         // HX_NORM_OLD=1        N = 2^14: the LDS-pass kernel instead of the radix-16 one

@@ -76,7 +76,7 @@ class Session:
         self._chk(self.L.hxh_session_info(self.h, info))
         (self.phim, self.L_ctxt, self.K, self.D, self.n_small, self.ctxt_bits, self.special_bits, self.batch) = \
             (int(v) for v in info)
-        self.p, self.r = p, r
+        self.p, self.r, self.m = p, r, m
 
     def _chk(self, rc):
         if rc != 0:
@@ -209,8 +209,28 @@ class Session:
         ai, ci = a.astype(np.int64), c.astype(np.int64)
         if level == 0:
             return ai
-        w = self._negacyclic_mod(ai, ci, P)
-        return w if level == 1 else self._negacyclic_mod(w, w, P)
+        mul = self._negacyclic_mod if (self.m & (self.m - 1)) == 0 else self._mul_mod_phi_prime_m
+        w = mul(ai, ci, P)
+        return w if level == 1 else mul(w, w, P)
+
+    def _mul_mod_phi_prime_m(self, x, y, P):
+        """x * y mod (Phi_m, P) for a PRIME m (Phi_m = 1 + X + ... + X^(m-1); the reference's general-m benchmark
+        ring, m = 32003): fold modulo X^m - 1, then subtract the coefficient of X^(m-1) from every other one."""
+        m = self.m
+        if any(m % d == 0 for d in range(2, int(m ** 0.5) + 1)) or self.phim != m - 1:
+            raise NotImplementedError("Session.expected: m a power of two or a prime")
+        from scipy.signal import fftconvolve
+        x, y = np.asarray(x, dtype=np.int64), np.asarray(y, dtype=np.int64)
+        if P < (1 << 10):
+            full = np.rint(fftconvolve(x.astype(np.float64), y.astype(np.float64))).astype(np.int64)   # exact: sums < 2^35
+        else:
+            full = np.convolve(x.astype(object), y.astype(object))
+        c = np.zeros(m, dtype=full.dtype)
+        c[:min(len(full), m)] += full[:m]
+        if len(full) > m:
+            c[:len(full) - m] += full[m:]
+        out = (c[:m - 1] - c[m - 1])
+        return np.array([int(v) % P for v in out], dtype=np.int64)
 
     def verify(self, level, elements=None):
         """decrypt(product) == plaintext product for the listed batch elements (all by default); returns the
