@@ -954,11 +954,27 @@ def make_roofline(table, n, B, l, k, d, b2b=None):
     # recorded PMC traffic of the same kernel and launch shape (cannot be collected inside this process)
     traffic, src = None, None
     short = dom["kernel"].replace(", false>", ">").replace(", true>", ",plain>")
-    for rec in ("r03_pmc_roofline_kernel_traffic.json", "r03_pmc_moddown_apply_traffic.json", "r02_pmc_moddown_apply_traffic.json"):
+    for rec in ("r04_pmc_roofline_kernel_traffic.json", "r03_pmc_roofline_kernel_traffic.json", "r03_pmc_moddown_apply_traffic.json"):
         t, sname = recorded_traffic(rec, short, dom["workgroups"], n)
         if t is not None:
             traffic, src = t, sname
             break
+    # the instruction-class-weighted issue floor of this kernel (recorded: tools/valu_floor.py over the kernel's ISA with
+    # the per-class issue costs of tools/ubench/issue_bench, profiles/r04_valu_floor_by_class.json), scaled to this launch
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_valu_floor_by_class.json")) as f:
+            fl = json.load(f)["kernels"]
+        m = dom["kernel"].replace(" ", "")
+        tag = m[:m.index("<")] + "ILi" + m[m.index("<") + 1:m.index(",")] + "ELb" + ("1" if m.endswith("true>") else "0")
+        for e in fl:
+            if tag in e["kernel"] and "floor_us_of_the_in_situ_launch_w8_dynamic_count" in e:
+                fus = e["floor_us_of_the_in_situ_launch_w8_dynamic_count"] * dom["workgroups"] / e["in_situ_launch"]["workgroups"]
+                roof["issue_floor"] = {"floor_us_per_launch": round(fus, 1), "measured_over_floor": round(dom["avg_us"] / fus, 3),
+                                       "valu_per_wave_dynamic": e["dynamic_valu_per_wave_SQ_INSTS_VALU"],
+                                       "kind": "recorded per-class issue costs (idle-chip micro-benchmark) x this kernel's instruction "
+                                               "histogram scaled to its SQ_INSTS_VALU; profiles/r04_valu_floor_by_class.json"}
+    except Exception:
+        pass
     roof["traffic"] = traffic
     roof["traffic_kind"] = "recorded (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch shape)" if traffic else None
     roof["traffic_source"] = src
