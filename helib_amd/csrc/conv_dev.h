@@ -57,6 +57,8 @@ struct ConvRowArgs {
   uint32_t src_mode, dst_mode, split, batch;
   uint32_t phim, m, in_stride, aux_stride;   // strides: words between (row, batch) segments of in / aux (non-poly layouts)
   uint32_t d, base;
+  uint32_t alias;   // CONV_DST_FINAL: the product was taken modulo X^Q + 1 with Q < m -- coefficient i also carries
+                    // -(Q Phi_m)_(i + Q) = -x_(i + Q), which the store adds back (engine.hip, hx_ctx::n3)
 };
 
 }  // namespace hx

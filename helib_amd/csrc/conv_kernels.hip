@@ -47,7 +47,7 @@ struct ConvIO {
   const SplitTW* S;         // split constants of this row
   const int32_t* zidx;
   uint32_t g;
-  uint32_t split, Q, phim, m, d, base;
+  uint32_t split, Q, phim, m, d, base, alias;
   __device__ __forceinline__ uint64_t element(unsigned i, const TW* pw, uint64_t q) const
   {
     if constexpr (SRC == CONV_SRC_BLUE_PRE) {
@@ -107,8 +107,13 @@ struct ConvIO {
     } else {
       const uint64_t q = uniform_u64(P->q);
       const TW minv = uniform_tw(P->minv);
-      if (p < phim)
-        dst[p] = shoup_full(subm(aux[p], x, q), minv, q);
+      if (p < phim) {
+        // r = x - Q Phi_m; with the product modulo X^Q + 1 (alias) its coefficient p is (Q Phi)_p - x_(p + Q)
+        uint64_t a = aux[p];
+        if (alias && p + Q < m)
+          a = subm(a, aux[p + Q], q);
+        dst[p] = shoup_full(subm(a, x, q), minv, q);
+      }
     }
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
@@ -141,6 +146,7 @@ ntt_conv_kernel(ConvRowArgs A, ConvRows R, const PrimeDev* __restrict__ cprimes,
   io.m = A.m;
   io.d = A.d;
   io.base = A.base;
+  io.alias = A.alias;
   const QC q = make_qc(pd->q, pd->mu64);
   const TW* twf = tw_arena + pd->tw_fwd_off;
   const TW* twi = tw_arena + pd->tw_inv_off;

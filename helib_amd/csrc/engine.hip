@@ -149,9 +149,9 @@ struct BluePrime {
   hx::BluePrimeDev* dev = nullptr;
   TW* d_powers = nullptr;
   TW* d_ipowers = nullptr;
-  uint64_t* d_hat[4] = {nullptr, nullptr, nullptr, nullptr};  // Rb, iRb, NTT(-Psi), NTT(Phi)
-  TW* d_hatw[4] = {nullptr, nullptr, nullptr, nullptr};       // the same as Shoup pairs (fused convolution kernel)
-  ConvPlan conv[3];                                           // sizes bk, n1, n2
+  uint64_t* d_hat[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // Rb, iRb, NTT(-Psi), NTT(Phi), NTT(Phi mod X^(2^n3) + 1)
+  TW* d_hatw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // the same as Shoup pairs (fused convolution kernel)
+  ConvPlan conv[4];                                           // sizes bk, n1, n2, n3 (n3: the aliased form of the last one)
 };
 
 struct hx_ctx {
@@ -177,7 +177,7 @@ struct hx_ctx {
   uint64_t aux_q[3] = {0, 0, 0};  // auxiliary NTT primes of the aux Bluestein path (lazily chosen)
   // general m (Bluestein): conv sizes 2^bk (chirp), 2^n1 / 2^n2 (rem Phi_m), pseudo "primes"
   // (twiddle tables of the conv sizes) and per-prime tables
-  int bk = 0, n1 = 0, n2 = 0;
+  int bk = 0, n1 = 0, n2 = 0, n3 = 0;   // n3 < n2: rem Phi_m's product Q Phi_m taken modulo X^(2^n3) + 1 (bluestein_rows)
   uint32_t dq = 0, mpad = 0;  // dq = m-1-phi(m) = deg of the quotient by Phi_m
   PrimeDev* d_cprimes = nullptr;
   int ncprimes = 0, cprimes_cap = 0;
@@ -593,11 +593,11 @@ static void ctx_free(hx_ctx* c)
     hipFree(b->dev);
     hipFree(b->d_powers);
     hipFree(b->d_ipowers);
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 5; i++) {
       hipFree(b->d_hat[i]);
       hipFree(b->d_hatw[i]);
     }
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 4; i++)
       hipFree(b->conv[i].dev);
     for (int j = 0; j < 3; j++) {
       for (int i = 0; i < 4; i++)
@@ -1159,6 +1159,14 @@ static int blue_prime_create(hx_ctx* c, int idx)
     c->dq = (uint32_t)(m - 1 - c->phim);
     c->n1 = std::max(1, next_pow2_exp(2 * (uint64_t)c->dq + 1));
     c->n2 = std::max(1, next_pow2_exp(m));
+    // Q Phi_m has degree m - 1 but only its low phi(m) coefficients are unknown: the ones above are x's own (the
+    // remainder has degree < phi(m)).  Modulo X^N3 + 1 with phi(m) <= N3 and m - 1 < 2 N3 coefficient i of the
+    // negacyclic product is (Q Phi)_i - (Q Phi)_(i + N3) = (Q Phi)_i - x_(i + N3): half the transform size.
+    {
+      const int n3 = std::max(1, next_pow2_exp(c->phim));
+      // (Q itself, degree <= dq, must fit the transform unwrapped: dq < N3, which with phi(m) <= N3 gives m - 1 < 2 N3)
+      c->n3 = (n3 < c->n2 && (uint64_t)c->dq < ((uint64_t)1 << n3)) ? n3 : c->n2;
+    }
     c->mpad = (uint32_t)((m + 1) & ~(uint64_t)1);
     c->phi_coef = cyclo_product(m, c->phim + 1, true);
     std::vector<int64_t> psi = cyclo_product(m, c->dq + 2, false);
@@ -1179,6 +1187,8 @@ static int blue_prime_create(hx_ctx* c, int idx)
       uint64_t psi = hxh::powmod(gen, (uint64_t)1 << (maxk - sizes[w]), q);
       CHK(conv_plan_create(c, q, sizes[w], psi, &bp->conv[w]));
     }
+    if (c->n3 < c->n2)
+      CHK(conv_plan_create(c, q, c->n3, hxh::powmod(gen, (uint64_t)1 << (maxk - c->n3), q), &bp->conv[3]));
   } else {
     // no 2^(maxk+1)-th root of unity modulo q (e.g. the primes of the reference's legacy fixture):
     // exact convolutions through three auxiliary NTT primes
@@ -1268,6 +1278,15 @@ static int blue_prime_create(hx_ctx* c, int idx)
   }
   CHK(make_hat(c, idx, 1, 2, npsi));
   CHK(make_hat(c, idx, 2, 3, phi));
+  if (!bp->aux && c->n3 < c->n2) {   // Phi_m modulo X^N3 + 1: the coefficients from N3 on wrap with a minus sign
+    const size_t N3 = (size_t)1 << c->n3;
+    std::vector<uint64_t> folded(N3, 0);
+    for (size_t i = 0; i < phi.size(); i++) {
+      uint64_t& f = folded[i % N3];
+      f = ((i / N3) & 1) ? (f >= phi[i] ? f - phi[i] : f + q - phi[i]) : (f + phi[i] >= q ? f + phi[i] - q : f + phi[i]);
+    }
+    CHK(make_hat(c, idx, 3, 4, folded));
+  }
   return HX_OK;
 }
 
@@ -1380,8 +1399,11 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
     A.aux_stride = c->mpad;
     A.dst_mode = hx::CONV_DST_FINAL;
     A.out = out;
-    set_conv(2, 3, 1);
-    e = hx::launch_conv_rows(c->n2, A, CR, R, c->d_cprimes, c->d_tw, c->stream);
+    // Q Phi_m at half the size where the aliased coefficients are x's own (n3 < n2, blue_prime_create)
+    const bool small = c->n3 < c->n2 && b0->conv[3].dev && b0->conv[3].split == 0 && sub_ok(b0->conv[3]);
+    A.alias = small ? 1u : 0u;
+    set_conv(small ? 3 : 2, small ? 4 : 3, 1);
+    e = hx::launch_conv_rows(small ? c->n3 : c->n2, A, CR, R, c->d_cprimes, c->d_tw, c->stream);
     if (e != hipSuccess)
       return fail(HX_ERR_DEVICE, "convolution launch failed: %s", hipGetErrorString(e));
   }
