@@ -32,8 +32,11 @@ class Group:
             os.environ.setdefault("MASTER_PORT", "29500")
             kw = {}
             if backend == "nccl" and device is not None:
-                kw["device_id"] = device
-            dist.init_process_group(backend or "gloo", rank=self.rank, world_size=self.world, **kw)
+                kw["device_id"] = device    # binds the communicator to this rank's GPU up front (eager init)
+            try:
+                dist.init_process_group(backend or "gloo", rank=self.rank, world_size=self.world, **kw)
+            except TypeError:               # a torch without the device_id keyword: lazy init on first collective
+                dist.init_process_group(backend or "gloo", rank=self.rank, world_size=self.world)
             self.dist = dist
         self.device = device
 
