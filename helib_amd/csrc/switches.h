@@ -36,6 +36,8 @@ struct Switches {
   bool arena_trace = false;      // HX_ARENA_TRACE=1     one line on stderr per hipMalloc the slab arena makes
 };
 
+// (a plain struct of flags, replaced whole by refresh(): contexts are created before the threads that use them
+// start work, and a context created later in a running process sees the same environment)
 inline Switches& current()
 {
   static Switches s;
