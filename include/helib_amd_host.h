@@ -7,7 +7,7 @@
  * timed path -- the loops of benchmarks/bgv_basic.cpp:144-165 and benchmarks/ckks_basic.cpp:161-180:
  *
  *     ContextBuilder<BGV>().m(m).p(p).r(r).bits(bits).c(3)          (scheme 0)
- *     ContextBuilder<CKKS>().m(m).precision(r).bits(bits).c(3)      (scheme 1)
+ *     ContextBuilder<CKKS>().m(m).precision(r).bits(bits).scale(10).c(3)   (scheme 1; benchmarks/ckks_common.h:45-50)
  *     SecKey::GenSecKey + the relinearisation matrix (addSome1DMatrices is not needed for multiplyBy)
  *     two public-key encryptions of random plaintexts               (x batch, packed along the batch axis)
  *     loop:  copy = ctxt1;  copy.multiplyBy(ctxt2);                 (hxh_multiply, level 1)
@@ -29,8 +29,10 @@ extern "C" {
 typedef struct hxh_session hxh_session;
 
 /* Builds the context, the key pair with its relinearisation matrix, and `batch` pairs of fresh
- * encryptions of seeded random plaintexts (BGV: uniform residues mod p^r; CKKS: reals in [-1,1]/phi(m)
- * encoded at scale 2^r).  seed = 0: key material from OS entropy (the plaintexts stay seeded). */
+ * encryptions of seeded random plaintexts (BGV: uniform residues mod p^r; CKKS: real coefficients uniform in
+ * +-1 / (8 sqrt(phi(m)/3)) -- canonical embedding below the declared size 1 -- encoded at the factor
+ * PubKey::Encrypt(Ptxt<CKKS>) uses, EncryptedArrayCx::encodeScalingFactor(): 2^11 at m = 65536, precision(1)).
+ * seed = 0: key material from OS entropy (the plaintexts stay seeded). */
 int hxh_session_create(hxh_session** out, int device, void* stream, int scheme, long m, long p, long r,
                        long bits, int batch, uint64_t seed);
 int hxh_session_destroy(hxh_session* s);
@@ -48,7 +50,7 @@ int hxh_multiply(hxh_session* s, int level, int k, int measure);
 int hxh_multiply_single(hxh_session* s, int measure);
 
 /* the plaintexts: out[b*phi + j], which = 0 / 1.  BGV: residues in [0, p^r); CKKS: the encoded reals
- * rint(v * 2^r) / 2^r */
+ * rint(v * f) / f, f = encodeScalingFactor() */
 int hxh_plaintext(const hxh_session* s, int which, double* out);
 /* decrypts batch element b of the kept product of `level` (0 = the first fresh ciphertext itself):
  * BGV: phi(m) residues; CKKS: phi(m) decoded reals (raw / ratFactor).  bound (optional): CKKS error

@@ -89,6 +89,16 @@ PY
       timeout 900 python bench.py --bits 6400 --batch 16 --steps 4 --warmup 1 --mults-per-step 4 --no-extras --cpu-sample 0 \
          > $out/bench_6400.json 2> $out/bench_6400.err; echo "bench6400 rc=$?"
       line $out/bench_6400.json bits6400; tail -3 $out/bench_6400.err ;;
+    trace_ckks)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/$out/kt_ckks -- python3 $R/bench.py --workload ckks65536 --steps 8 --warmup 3 $QUICK \
+         > $R/$out/bench_ckks_traced.json 2> $R/$out/bench_ckks_traced.err); echo "trace_ckks rc=$?"
+      python tools/rocpd_summary.py $out/kt_ckks --by-grid > $out/bench_ckks_kernel_trace.txt 2>&1
+      grep -E "wgs" $out/bench_ckks_kernel_trace.txt | head -14 ;;
+    trace6400)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/$out/kt_6400 -- python3 $R/bench.py --bits 6400 --batch 16 --steps 4 --warmup 1 --mults-per-step 4 $QUICK \
+         > $R/$out/bench_6400_traced.json 2> $R/$out/bench_6400_traced.err); echo "trace6400 rc=$?"
+      python tools/rocpd_summary.py $out/kt_6400 --by-grid > $out/bench_6400_kernel_trace.txt 2>&1
+      grep -E "wgs" $out/bench_6400_kernel_trace.txt | head -14 ;;
     bench_fixed)
       timeout 400 python bench.py --workload bgv32768_fixed --steps 8 --warmup 3 --cpu-sample 0 > $out/bench_fixed.json 2> $out/bench_fixed.err
       python -c "import json;print('fixed level', json.load(open('$out/bench_fixed.json'))['value'])" ;;
