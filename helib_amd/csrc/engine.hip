@@ -30,6 +30,8 @@ namespace hx {
 hipError_t launch_ntt_pow2(int logn, bool inverse, const uint64_t* in, uint64_t* out,
                            const NttRows& rows, int nrows, int batch, const PrimeDev* primes,
                            const TW* tw_arena, hipStream_t st);
+hipError_t launch_ntt_pow2_lazy_in(int logn, const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows, int batch,
+                                   const PrimeDev* primes, const TW* tw_arena, hipStream_t st);
 hipError_t launch_moddown_pow2(int logn, const PolyBases& data, const PolyBases& out, int drop_row,
                                int drop_prime, const NttRows& keep, int nkeep, int batch,
                                const ModDownPrep& P, const ModDownApply& A, const PrimeDev* primes,
@@ -758,7 +760,7 @@ static int upload_tw_small(hx_ctx* c, PrimeHost& ph)
 // general m: Bluestein tables and convolution plans
 // ------------------------------------------------------------------
 static int ntt_launch(hx_ctx* c, int logn, const PrimeDev* table, const uint64_t* in, uint64_t* out,
-                      const std::vector<std::pair<int, int>>& rows, int batch, bool inverse);
+                      const std::vector<std::pair<int, int>>& rows, int batch, bool inverse, bool lazy_in = false);
 static int ensure_scratch(hx_ctx* c, int slot, size_t words);
 
 static int next_pow2_exp(uint64_t n)  // NTL::NextPowerOfTwo: least k with 2^k >= n
@@ -1836,8 +1838,10 @@ static int make_map(const std::vector<int>& primes, int first, int count, RowMap
 }
 
 // raw launch: listed (row, table-entry) pairs of a [rows][batch][2^logn] buffer, in -> out
+// lazy_in (forward, N = 2^13..2^15 only): the rows hold words in [0,8q), e.g. the unreduced output of
+// break_digits_fast_kernel<., true>
 static int ntt_launch(hx_ctx* c, int logn, const PrimeDev* table, const uint64_t* in, uint64_t* out,
-                      const std::vector<std::pair<int, int>>& rows, int batch, bool inverse)
+                      const std::vector<std::pair<int, int>>& rows, int batch, bool inverse, bool lazy_in)
 {
   if (rows.empty())
     return HX_OK;
@@ -1852,7 +1856,9 @@ static int ntt_launch(hx_ctx* c, int logn, const PrimeDev* table, const uint64_t
       d.row[i] = (uint16_t)rows[first + i].first;
       d.prime[i] = (uint16_t)rows[first + i].second;
     }
-    hipError_t e = hx::launch_ntt_pow2(logn, inverse, in, out, d, n, batch, table, c->d_tw, c->stream);
+    hipError_t e = (lazy_in && !inverse && logn >= 13 && logn <= 15)
+                       ? hx::launch_ntt_pow2_lazy_in(logn, in, out, d, n, batch, table, c->d_tw, c->stream)
+                       : hx::launch_ntt_pow2(logn, inverse, in, out, d, n, batch, table, c->d_tw, c->stream);
     if (e != hipSuccess)
       return fail(HX_ERR_DEVICE, "NTT launch failed: %s", hipGetErrorString(e));
   }
@@ -1912,8 +1918,12 @@ static int pow2_big_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
 }
 
 // Cmodulus::FFT / iFFT on the listed (row, prime) pairs of a [rows][batch][phi(m)] buffer
+// a ring whose forward row transform takes lazy input (ntt_launch lazy_in): the exact-RNS kernels in front of it may
+// leave their output words unreduced
+static bool ntt_lazy_input_ok(const hx_ctx* c) { return c->pow2 && c->logn >= 13 && c->logn <= 15; }
+
 static int ntt_list(hx_ctx* c, const uint64_t* in, uint64_t* out,
-                    const std::vector<std::pair<int, int>>& rows, int batch, bool inverse)
+                    const std::vector<std::pair<int, int>>& rows, int batch, bool inverse, bool lazy_in = false)
 {
   if (rows.empty())
     return HX_OK;
@@ -1923,7 +1933,7 @@ static int ntt_list(hx_ctx* c, const uint64_t* in, uint64_t* out,
     return pow2_big_rows(c, in, out, rows, batch, inverse);
   if (c->logn < 1 || c->logn > 19)
     return fail(HX_ERR_UNSUPPORTED, "power-of-two NTT supports 2 <= phi(m) <= 524288");
-  return ntt_launch(c, c->logn, c->d_primes, in, out, rows, batch, inverse);
+  return ntt_launch(c, c->logn, c->d_primes, in, out, rows, batch, inverse, lazy_in && ntt_lazy_input_ok(c));
 }
 
 // in place: rows [row0,row0+nrows); row r uses prime plist[r % period]
@@ -4133,10 +4143,11 @@ static int break_digits_coef(hx_ctx* c, uint64_t* coef, const std::vector<int>& 
 // Fused variant for hx_mul_relin: digits are contiguous row runs of `own` (checked), own rows
 // are not materialised.  Returns HX_ERR_UNSUPPORTED when the shape does not fit (caller falls
 // back to break_digits_coef).
+// lazy_out: the extension words may be left in [0,6q) (fast kernels only; the caller's forward transform takes lazy input)
 static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector<int>& own,
                               const int* dig_idx, const int* dig_off, int ndig,
                               const std::vector<int>& all, uint64_t* dig, size_t rw,
-                              std::vector<int>* owner_out)
+                              std::vector<int>* owner_out, bool lazy_out = false)
 {
   const int L = (int)own.size(), nall = (int)all.size();
   if (ndig > hx::KS_MAXD || L > 64 || dig_off[ndig] != L)
@@ -4185,10 +4196,9 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
   if (fast) {
     static bool attrf = false;
     if (!attrf) {
-      HIPCHK(hipFuncSetAttribute((const void*)hx::break_digits_fast_kernel<true>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
-      HIPCHK(hipFuncSetAttribute((const void*)hx::break_digits_fast_kernel<false>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
+      for (const void* f : {(const void*)hx::break_digits_fast_kernel<true, false>, (const void*)hx::break_digits_fast_kernel<false, false>,
+                            (const void*)hx::break_digits_fast_kernel<true, true>, (const void*)hx::break_digits_fast_kernel<false, true>})
+        HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
       attrf = true;
     }
     const size_t lds_fast = (size_t)std::max(1, L - hx::break_fast_n0(A)) * hx::BRK_THREADS * 8;
@@ -4197,10 +4207,17 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
       hps = hps && A.plan[d].hps_ok && (int)A.plan[d].n >= hps_min_n();
     if (hps) {   // HPS form, then Garner over the coefficients it could not vouch for (rns_kernels.h: ExtRep)
       CHK(redo_prepare(c, rw, &A.redo));
-      HX_LAUNCH(hx::break_digits_fast_kernel<true>, grid, block, lds_fast, c->stream, A, rw);
-      HX_LAUNCH(hx::break_digits_fast_kernel<false>, REDO_GRID, block, lds_fast, c->stream, A, rw);
+      if (lazy_out) {
+        HX_LAUNCH((hx::break_digits_fast_kernel<true, true>), grid, block, lds_fast, c->stream, A, rw);
+        HX_LAUNCH((hx::break_digits_fast_kernel<false, true>), REDO_GRID, block, lds_fast, c->stream, A, rw);
+      } else {
+        HX_LAUNCH((hx::break_digits_fast_kernel<true, false>), grid, block, lds_fast, c->stream, A, rw);
+        HX_LAUNCH((hx::break_digits_fast_kernel<false, false>), REDO_GRID, block, lds_fast, c->stream, A, rw);
+      }
+    } else if (lazy_out) {
+      HX_LAUNCH((hx::break_digits_fast_kernel<false, true>), grid, block, lds_fast, c->stream, A, rw);
     } else {
-      HX_LAUNCH(hx::break_digits_fast_kernel<false>, grid, block, lds_fast, c->stream, A, rw);
+      HX_LAUNCH((hx::break_digits_fast_kernel<false, false>), grid, block, lds_fast, c->stream, A, rw);
     }
   } else if (nmax <= 8) {
     static bool attr8 = false;
@@ -4551,8 +4568,10 @@ static int relin_core(hx_ctx* c, const uint64_t* t2e, const std::vector<int>& ow
   CHK(ensure_scratch(c, 1, (size_t)ndig * nall * rw));
   std::vector<int> owner;
   {
+    // the extension words go straight into the forward transform below: where that takes lazy input they are left
+    // unreduced (three conditional subtractions less per word)
     int rc = break_digits_fused(c, c->scratch[2], own, dig_idx, dig_off, ndig, all, c->scratch[1],
-                                rw, &owner);
+                                rw, &owner, ntt_lazy_input_ok(c));
     if (rc == HX_ERR_UNSUPPORTED)
       rc = break_digits_coef(c, c->scratch[2], own, dig_idx, dig_off, ndig, all, c->scratch[1], rw,
                              /*copy_own=*/false, &owner);
@@ -4566,7 +4585,7 @@ static int relin_core(hx_ctx* c, const uint64_t* t2e, const std::vector<int>& ow
       for (int r = 0; r < nall; r++)
         if (owner[r] != d)
           rows.emplace_back(d * nall + r, all[r]);
-    CHK(ntt_list(c, c->scratch[1], c->scratch[1], rows, batch, false));
+    CHK(ntt_list(c, c->scratch[1], c->scratch[1], rows, batch, false, /*lazy_in=*/true));
   }
   std::vector<std::vector<int>> dprimes(ndig);
   for (int d = 0; d < ndig; d++)

@@ -70,13 +70,17 @@ __device__ __forceinline__ TW tw_vec(const BufTw& t, unsigned base, unsigned lan
   return w;
 }
 
-struct BufIO {
-  static constexpr int LOAD_BOUND = 1;
+// LB: bound (in units of q) of the words the row holds on entry -- 1: canonical residues; 8: the lazy output of
+// the exact-RNS kernels (break_digits_fast_kernel<., true>: values in [0,6q) they did not finish reducing, because
+// the forward transform that reads them takes any bound up to 12 and tracks it at compile time)
+template <int LB>
+struct BufIOT {
+  static constexpr int LOAD_BOUND = LB;
   static constexpr bool LAZY_STORE = false;
   static constexpr bool PIPELINED = false;
   struct StorePrefetch {};
   v4i32 rin, rout;
-  __device__ BufIO(const uint64_t* in_row, uint64_t* out_row, unsigned bytes)
+  __device__ BufIOT(const uint64_t* in_row, uint64_t* out_row, unsigned bytes)
       : rin(make_rsrc(in_row, bytes)), rout(make_rsrc(out_row, bytes))
   {
   }
@@ -747,7 +751,7 @@ ntt_moddown_apply_tensor_kernel(TensorSrc T, PolyBases outs, NttRows rows, int n
   ntt_body<LOGN, false>(lds, io, tw_arena + pd->tw_fwd_off, pd);
 }
 
-template <int LOGN, bool INV>
+template <int LOGN, bool INV, int LB = 1>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
 ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
                const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
@@ -764,7 +768,7 @@ ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
 #ifdef HX_NTT_PTRIO
   const PtrIO io{in + roff, out + roff};
 #else
-  const BufIO io(in + roff, out + roff, (unsigned)Geo<LOGN>::N * 8u);
+  const BufIOT<LB> io(in + roff, out + roff, (unsigned)Geo<LOGN>::N * 8u);
 #endif
   ntt_body<LOGN, INV>(lds, io, tw, pd);
 }
@@ -845,21 +849,21 @@ hipError_t launch_ntt_inv_mul_pow2(int logn, const uint64_t* a, const uint64_t* 
   return hipErrorInvalidValue;
 }
 
-template <int LOGN, bool INV>
+template <int LOGN, bool INV, int LB = 1>
 static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows,
                              int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
 {
   static const size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ntt_row_kernel<LOGN, INV>,
+    hipError_t e = hipFuncSetAttribute((const void*)ntt_row_kernel<LOGN, INV, LB>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
       return e;
     attr_set = true;
   }
   dim3 grid((unsigned)nrows * (unsigned)batch), block(Geo<LOGN>::T);
-  HX_LAUNCH((ntt_row_kernel<LOGN, INV>), grid, block, lds_bytes, st, in, out, rows, batch,
+  HX_LAUNCH((ntt_row_kernel<LOGN, INV, LB>), grid, block, lds_bytes, st, in, out, rows, batch,
                      primes, tw_arena);
   return hipGetLastError();
 }
@@ -1183,6 +1187,18 @@ static hipError_t launch_small(bool inverse, const uint64_t* in, uint64_t* out, 
     HX_LAUNCH(ntt_small_kernel<false>, grid, block, lds, st, in, out, rows, batch, logn,
                        primes, tw_arena);
   return hipGetLastError();
+}
+
+// forward transform of rows whose words are lazy, in [0,8q) (N = 2^13..2^15 only: ntt_lazy_input_ok)
+hipError_t launch_ntt_pow2_lazy_in(int logn, const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows, int batch,
+                                   const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  switch (logn) {
+    case 13: return launch_one<13, false, 8>(in, out, rows, nrows, batch, primes, tw_arena, st);
+    case 14: return launch_one<14, false, 8>(in, out, rows, nrows, batch, primes, tw_arena, st);
+    case 15: return launch_one<15, false, 8>(in, out, rows, nrows, batch, primes, tw_arena, st);
+  }
+  return hipErrorInvalidValue;
 }
 
 // entry point used by engine.hip: transform `nrows` (<= MAX_ROWS) listed rows, in -> out

@@ -803,6 +803,20 @@ __device__ __forceinline__ uint64_t red128_q8(u128 S, uint64_t q, uint64_t mu63,
 }
 
 __device__ __forceinline__ uint64_t norm_any(uint64_t x, uint64_t q, uint32_t mu32);
+// the same two reductions stopped before their conditional subtractions: a value congruent to S in [0,6q) resp.
+// [0,5q) -- for words whose only reader is a forward row transform that takes lazy input (ntt_row_kernel<., false, 8>)
+__device__ __forceinline__ uint64_t red128_q8_lazy(u128 S, uint64_t q, uint64_t mu63, uint32_t k)
+{
+  const uint64_t xt = (uint64_t)(S >> (k - 1));
+  const uint32_t xl = (uint32_t)xt, xh = (uint32_t)(xt >> 32);
+  const uint32_t ml = (uint32_t)mu63, mh = (uint32_t)(mu63 >> 32);
+  const uint64_t qh = (uint64_t)xh * mh + __umulhi(xh, ml) + __umulhi(xl, mh);
+  return (uint64_t)S - qh * q;
+}
+__device__ __forceinline__ uint64_t red128_any_lazy(u128 S, uint64_t q, TW r64, uint32_t mu32)
+{
+  return shoup4((uint64_t)(S >> 64), r64, 0 - q) + norm_any((uint64_t)S, q, mu32);
+}
 // S mod q for ANY S < 2^127 and any prime q in (2^32, 2^60): S = H 2^64 + Lo; H (2^64 mod q) as an approximate Shoup
 // product in [0,4q) (shoup4 takes any 64-bit H), Lo normalised with the 32-bit reciprocal, the sum in [0,5q) finished
 // by three conditional subtractions.  Ten word multiplications -- against seven for red128_q8, whose domain
@@ -907,7 +921,9 @@ __device__ __forceinline__ void redo_append(uint32_t* redo, size_t i)
 // xs holds rows [n0, L) only: the rows of the FIRST digit (n0 of them when it starts at row 0) are
 // consumed once, by their own pass, and are read straight from global memory (src0) -- 10 instead of
 // 16 LDS rows per thread at L = 16, digits 6/5/5, which is what bounds the resident waves.
-template <int N, bool HPS>
+// LAZY: the extension words are left in [0,6q) (congruent, not reduced): three conditional subtractions less per
+// word; hx_mul_relin / hx_relinearize, whose forward transform of these rows takes lazy input
+template <int N, bool HPS, bool LAZY>
 __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* xs, unsigned tid, int off, int L,
                                                  uint64_t* dd, size_t row_words, double* frac_out, int n0,
                                                  const uint64_t* src0)
@@ -952,11 +968,7 @@ __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* 
         c11 += (uint64_t)a1[k] * w1;
       }
       const u128 S = (u128)cnt * negP + c00 + ((u128)c01 << 30) + ((u128)c11 << 60);
-#ifdef HX_RED128_WIDE
-      v = red128_wide(S, q, T.mu(), T.k());
-#else
-      v = red128_q8(S, q, T.mu63(), T.k());
-#endif
+      v = LAZY ? red128_q8_lazy(S, q, T.mu63(), T.k()) : red128_q8(S, q, T.mu63(), T.k());
     } else {
       // a target the terms outgrow (a 56-bit special prime under 60-bit digit primes): the same limb sums,
       // reduced by red128_any -- round 3 summed a Shoup product per term here (nine multiplications each)
@@ -971,13 +983,14 @@ __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* 
         c11 += (uint64_t)a1[k] * w1;
       }
       const u128 S = (u128)cnt * negP + c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
-      v = red128_any(S, q, T.r64(), (uint32_t)T.mu64());
+      v = LAZY ? red128_any_lazy(S, q, T.r64(), (uint32_t)T.mu64()) : red128_any(S, q, T.r64(), (uint32_t)T.mu64());
     }
     st_stream1(dd + (size_t)r * row_words, v);
     if (r >= off + N && r < L) {
-      // digits[j] -= digits[i]; digits[j] /= P_i on a later digit's own row (kept lazy, < 4q)
+      // digits[j] -= digits[i]; digits[j] /= P_i on a later digit's own row (kept lazy, < 4q; v < 6q when LAZY:
+      // the offset that keeps the difference positive is 8q then, 12q < 2^64 in all)
       uint64_t* u = &xs[(r - n0) * BRK_THREADS + tid];
-      *u = shoup4(*u + q - v, T.upd(), 0 - q);
+      *u = shoup4(*u + (LAZY ? q << 3 : q) - v, T.upd(), 0 - q);
     }
   }
   return trusted;
@@ -1285,7 +1298,7 @@ rns_extend_wide_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
   }
 }
 
-template <bool HPS>
+template <bool HPS, bool LAZY>
 __device__ __forceinline__ void break_digits_fast_one(const BreakArgs& A, size_t row_words, uint64_t* xs, unsigned tid, size_t i)
 {
   const int n0 = break_fast_n0(A);
@@ -1300,21 +1313,21 @@ __device__ __forceinline__ void break_digits_fast_one(const BreakArgs& A, size_t
     double* fo = A.frac ? A.frac + (size_t)d * row_words + i : nullptr;
     bool ok;
     switch (P.n) {
-      case 1: ok = break_digit_pass<1, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 2: ok = break_digit_pass<2, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 3: ok = break_digit_pass<3, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 4: ok = break_digit_pass<4, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 5: ok = break_digit_pass<5, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 6: ok = break_digit_pass<6, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      case 7: ok = break_digit_pass<7, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
-      default: ok = break_digit_pass<8, HPS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 1: ok = break_digit_pass<1, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 2: ok = break_digit_pass<2, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 3: ok = break_digit_pass<3, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 4: ok = break_digit_pass<4, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 5: ok = break_digit_pass<5, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 6: ok = break_digit_pass<6, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 7: ok = break_digit_pass<7, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      default: ok = break_digit_pass<8, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
     }
     trusted = trusted && ok;
   }
   if (HPS && !trusted)   // (one entry per coefficient: a wrong digit also spoils the later digits' rows of this lane)
     redo_append(A.redo, i);
 }
-template <bool HPS>
+template <bool HPS, bool LAZY = false>
 __global__ void __launch_bounds__(BRK_THREADS) __attribute__((amdgpu_waves_per_eu(HX_BRK_WAVES)))
 break_digits_fast_kernel(BreakArgs A, size_t row_words)
 {
@@ -1324,14 +1337,14 @@ break_digits_fast_kernel(BreakArgs A, size_t row_words)
     if (A.redo) {   // the listed coefficients only
       const uint32_t n = A.redo[0];
       for (size_t j = (size_t)blockIdx.x * BRK_THREADS + tid; j < n; j += (size_t)gridDim.x * BRK_THREADS)
-        break_digits_fast_one<false>(A, row_words, xs, tid, A.redo[1 + j]);
+        break_digits_fast_one<false, LAZY>(A, row_words, xs, tid, A.redo[1 + j]);
       return;
     }
   }
   const size_t i = (size_t)blockIdx.x * BRK_THREADS + tid;
   if (i >= row_words)
     return;
-  break_digits_fast_one<HPS>(A, row_words, xs, tid, i);
+  break_digits_fast_one<HPS, LAZY>(A, row_words, xs, tid, i);
 }
 
 // (x - y) * c per row: the tail of scaleDownToSet (*this -= delta; *this /= diffProd)
