@@ -2994,7 +2994,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
                      16 * (size_t)4096, ns, srcv, c->d_wtab, logn, c->d_norm_park, c->d_norm2)
     // N = 2^14: the register-tiled kernel (norm_r16.h); HX_NORM_OLD keeps the LDS-pass kernel (A/B)
     const bool r16 = !hxs::current().norm_old && !hxs::current().norm_split14;
-    constexpr size_t r16_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
+    constexpr size_t r16_lds = (size_t)hx::R16_LDS_DOUBLES * sizeof(double);   // one array: two workgroups per CU
     if (r16 && logn == 14) {
       static bool attr16 = false;
       if (!attr16) {

@@ -222,15 +222,47 @@ embed_norm_quarter_kernel(SRC src, const double2* __restrict__ wtab, int logn_rt
 }
 
 // N = 2^14 (the benchmark ring), register-tiled: norm_r16.h.  512 threads x 16 points, three radix-16 register
-// passes, the last stage inside the pairing pass; five barriers instead of nine, four stages per LDS round trip
-// instead of two, 16 independent butterflies per thread in flight instead of 2.
+// passes, four stages per LDS round trip, 16 independent butterflies per thread in flight.
+//
+// Round 4: ONE padded array (66 KiB) instead of one per component, so that TWO workgroups share a CU.  The round-3
+// form (132 KiB) ran one workgroup per CU: all 256 of a launch load their rows at the same time (262 KB each: the
+// launch's 67-134 MB in one burst, ~10 us), then all compute with the memory system idle (~12 us), then the next
+// round of rows does the same -- 384 rows cost as much as 512.  With two co-resident workgroups one computes while
+// the other loads, and every row of a launch of <= 512 rows is resident at once.  The price is barriers (the real
+// parts cross the array, then the imaginary parts); the last stage moved from the pairing pass into a lane
+// exchange (DPP quad_perm), and the pairing forms each pair once instead of twice.
+__device__ __forceinline__ double lane_xor1(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// FROM -> TO: positions of the 16 values before / after (r16_pos_A / _B / _C)
+template <unsigned (*FROM)(unsigned, unsigned), unsigned (*TO)(unsigned, unsigned)>
+__device__ __forceinline__ void r16_transpose(cplx16 (&v)[16], double* sm, unsigned t)
+{
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++)
+    sm[r16_pad(FROM(t, k))] = v[k].x;
+  __syncthreads();
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++)
+    v[k].x = sm[r16_pad(TO(t, k))];
+  __syncthreads();
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++)
+    sm[r16_pad(FROM(t, k))] = v[k].y;
+  __syncthreads();
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++)
+    v[k].y = sm[r16_pad(TO(t, k))];
+}
 template <class SRC>
 __global__ void __launch_bounds__(R16_THREADS)
 embed_norm_r16_kernel(SRC src, const double2* __restrict__ wtab, unsigned long long* __restrict__ out2)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* re = sm;
-  double* im = sm + R16_LDS_DOUBLES;
   const unsigned row = blockIdx.x, t = threadIdx.x;
   const tw16* wt = reinterpret_cast<const tw16*>(wtab);
   cplx16 v[16];
@@ -244,43 +276,29 @@ embed_norm_r16_kernel(SRC src, const double2* __restrict__ wtab, unsigned long l
     v[k].y = p.x * w.y + p.y * w.x;
   }
   r16_pass<9>(v, t, wt);
-#pragma unroll
-  for (unsigned k = 0; k < 16; k++) {
-    re[r16_pad(r16_pos_A(t, k))] = v[k].x;
-    im[r16_pad(r16_pos_A(t, k))] = v[k].y;
-  }
-  __syncthreads();
-#pragma unroll
-  for (unsigned k = 0; k < 16; k++) {
-    v[k].x = re[r16_pad(r16_pos_B(t, k))];
-    v[k].y = im[r16_pad(r16_pos_B(t, k))];
-  }
+  r16_transpose<r16_pos_A, r16_pos_B>(v, sm, t);
   r16_pass<5>(v, t & 31u, wt);
   __syncthreads();
-#pragma unroll
-  for (unsigned k = 0; k < 16; k++) {
-    re[r16_pad(r16_pos_B(t, k))] = v[k].x;
-    im[r16_pad(r16_pos_B(t, k))] = v[k].y;
-  }
-  __syncthreads();
-#pragma unroll
-  for (unsigned k = 0; k < 16; k++) {
-    v[k].x = re[r16_pad(r16_pos_C(t, k))];
-    v[k].y = im[r16_pad(r16_pos_C(t, k))];
-  }
+  r16_transpose<r16_pos_B, r16_pos_C>(v, sm, t);
   r16_pass<1>(v, t & 1u, wt);
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++)
+    v[k] = r16_last_lane(v[k], cplx16{lane_xor1(v[k].x), lane_xor1(v[k].y)}, t);
   __syncthreads();
 #pragma unroll
-  for (unsigned k = 0; k < 16; k++) {
-    re[r16_pad(r16_pos_C(t, k))] = v[k].x;
-    im[r16_pad(r16_pos_C(t, k))] = v[k].y;
+  for (unsigned kk = 0; kk < 8; kk++) {
+    sm[r16_xchg_idx(t, kk)] = v[8 + kk].x;
+    sm[R16_XCHG_IM + r16_xchg_idx(t, kk)] = v[8 + kk].y;
   }
   __syncthreads();
   double mx = 0;
-  const tw16 wpair = wt[32u * r16_brev9(t)];
+  const tw16 wth = wt[r16_pair_tw_thread(t)];
 #pragma unroll
-  for (unsigned i = 0; i < 16; i++) {
-    const double n2 = r16_pair(re, im, t, i, wpair, wt);
+  for (unsigned k = 0; k < 8; k++) {
+    const unsigned o = r16_xchg_idx(R16_THREADS - 1u - t, 7u - k);
+    const cplx16 partner{sm[o], sm[R16_XCHG_IM + o]};
+    const tw16 w = k == 0 ? wth : r16_cmul(wth, wt[r16_pair_tw_k(k)]);
+    const double n2 = r16_pair_norm2(v[k], partner, w);
     mx = n2 > mx ? n2 : mx;
   }
   block_max_to(mx, sm, t, R16_THREADS, out2 + row);

@@ -128,6 +128,31 @@ HXD double r16_pair(const double* re, const double* im, unsigned t, unsigned i, 
   const tw16 w = r16_cmul(wt, wtab[2u * r16_brev4(i) + 1u]);
   return r16_pair_norm2(r16_last_lds(re, im, p), r16_last_lds(re, im, R16_M - 1u - p), w);
 }
+// ---- the same transform through ONE padded array of R16_LDS_DOUBLES doubles (66 KiB: two workgroups per CU) ----
+// The two transposes move the real parts through the array, then the imaginary parts.  After pass C thread t holds
+// positions p = 32 (t>>1) + (t&1) + 2k: the partner p ^ 1 of the last stage (len = 1) is the same k of lane t ^ 1,
+// so that stage is a lane exchange and the finished Z stay in registers:
+HXD cplx16 r16_last_lane(cplx16 own, cplx16 other, unsigned t)   // other: the value lane t ^ 1 holds at the same k
+{
+  return (t & 1u) ? cplx16{other.x - own.x, other.y - own.y} : cplx16{own.x + other.x, own.y + other.y};
+}
+// Pairing: Z at p meets Z at M - 1 - p = pos_C(511 - t, 15 - k); (p, M-1-p) and (M-1-p, p) give the same two
+// evaluation points, so thread t pairs its k < 8 with what thread 511 - t holds at 15 - k >= 8 -- every unordered
+// pair once (the two-array kernel formed each twice).  The upper halves cross through the array at
+// [kk][t], kk = k - 8 (real parts; imaginary parts R16_XCHG_IM further on).
+constexpr unsigned R16_XCHG_IM = 4096;
+HXD unsigned r16_xchg_idx(unsigned t, unsigned kk) { return kk * 512u + t; }
+HXD unsigned r16_brev8(unsigned x)
+{
+  unsigned r = 0;
+  for (int i = 0; i < 8; i++)
+    r |= ((x >> i) & 1u) << (7 - i);
+  return r;
+}
+// j = brev13(p) = 4096 (t&1) + 256 brev4(k) + brev8(t>>1):  W^(2j+1) = wtab[r16_pair_tw_thread(t)] * wtab[r16_pair_tw_k(k)]
+HXD unsigned r16_pair_tw_thread(unsigned t) { return 8192u * (t & 1u) + 2u * r16_brev8(t >> 1) + 1u; }
+HXD unsigned r16_pair_tw_k(unsigned k) { return 512u * r16_brev4(k); }
+
 // N = 2^15 as S = 2 sub-transforms of H = 8192 points (norm_kernels.h, embed_norm_quarter_split_kernel):
 // input point i of sub-transform `sub`: h_i = sum_{t<2} z_(i+tH) U^((i+tH) sub),
 //   z_n U^(n sub) = (f_2n + i f_(2n+1)) W^(2n (2 sub + 1)),  W = exp(2 pi i / 2N),  wtab[k] = W^k for k < N

@@ -3,7 +3,8 @@
 //   max_j | f(W^(2j+1)) |,  W = exp(2 pi i / 2N),  N = 16384
 // evaluated directly (long double) at every point for a sparse polynomial and at sampled points for a
 // dense one.  Checks the index maps of the three radix-16 passes, the twiddle strides, the padded LDS
-// layout and the last stage folded into the pairing pass.
+// layout (one array, real parts then imaginary parts), the last stage as a lane exchange, and the pairing that
+// forms each pair once through the exchange area.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -13,10 +14,25 @@
 
 using namespace hx;
 
+// one transpose of embed_norm_r16_kernel: the real parts cross the ONE padded array, then the imaginary parts
+// (write all, barrier, read all, barrier -- each loop over t below is one phase between two barriers)
+template <class FROM, class TO>
+static void transpose(std::vector<cplx16>& regs, std::vector<double>& sm, FROM from, TO to)
+{
+  const unsigned T = R16_THREADS;
+  for (int comp = 0; comp < 2; comp++) {
+    for (unsigned t = 0; t < T; t++)
+      for (unsigned k = 0; k < 16; k++)
+        sm[r16_pad(from(t, k))] = comp ? regs[(size_t)t * 16 + k].y : regs[(size_t)t * 16 + k].x;
+    for (unsigned t = 0; t < T; t++)
+      for (unsigned k = 0; k < 16; k++)
+        (comp ? regs[(size_t)t * 16 + k].y : regs[(size_t)t * 16 + k].x) = sm[r16_pad(to(t, k))];
+  }
+}
 static double replay(const std::vector<double>& f, const std::vector<tw16>& wtab)
 {
   const unsigned T = R16_THREADS;
-  std::vector<double> re(R16_LDS_DOUBLES), im(R16_LDS_DOUBLES);
+  std::vector<double> sm(R16_LDS_DOUBLES, 0.0);
   std::vector<cplx16> regs((size_t)T * 16);
   // load + pre-twist + pass A
   for (unsigned t = 0; t < T; t++) {
@@ -29,45 +45,49 @@ static double replay(const std::vector<double>& f, const std::vector<tw16>& wtab
       v[k].y = a * w.y + b * w.x;
     }
     r16_pass<9>(v, t, wtab.data());
-    for (unsigned k = 0; k < 16; k++) {
-      re[r16_pad(r16_pos_A(t, k))] = v[k].x;
-      im[r16_pad(r16_pos_A(t, k))] = v[k].y;
-    }
+    for (unsigned k = 0; k < 16; k++)
+      regs[(size_t)t * 16 + k] = v[k];
   }
-  // barrier; pass B: all threads read, barrier, all threads write
+  transpose(regs, sm, r16_pos_A, r16_pos_B);
   for (unsigned t = 0; t < T; t++) {
     cplx16 v[16];
     for (unsigned k = 0; k < 16; k++)
-      v[k] = {re[r16_pad(r16_pos_B(t, k))], im[r16_pad(r16_pos_B(t, k))]};
+      v[k] = regs[(size_t)t * 16 + k];
     r16_pass<5>(v, t & 31u, wtab.data());
     for (unsigned k = 0; k < 16; k++)
       regs[(size_t)t * 16 + k] = v[k];
   }
-  for (unsigned t = 0; t < T; t++)
-    for (unsigned k = 0; k < 16; k++) {
-      re[r16_pad(r16_pos_B(t, k))] = regs[(size_t)t * 16 + k].x;
-      im[r16_pad(r16_pos_B(t, k))] = regs[(size_t)t * 16 + k].y;
-    }
-  // barrier; pass C
+  transpose(regs, sm, r16_pos_B, r16_pos_C);
   for (unsigned t = 0; t < T; t++) {
     cplx16 v[16];
     for (unsigned k = 0; k < 16; k++)
-      v[k] = {re[r16_pad(r16_pos_C(t, k))], im[r16_pad(r16_pos_C(t, k))]};
+      v[k] = regs[(size_t)t * 16 + k];
     r16_pass<1>(v, t & 1u, wtab.data());
     for (unsigned k = 0; k < 16; k++)
       regs[(size_t)t * 16 + k] = v[k];
   }
+  // last stage: the lane exchange with t ^ 1 (all lanes read the partner's value of before the exchange)
+  {
+    std::vector<cplx16> z(regs.size());
+    for (unsigned t = 0; t < T; t++)
+      for (unsigned k = 0; k < 16; k++)
+        z[(size_t)t * 16 + k] = r16_last_lane(regs[(size_t)t * 16 + k], regs[(size_t)(t ^ 1u) * 16 + k], t);
+    regs.swap(z);
+  }
+  // barrier; the upper halves into the array; barrier; pairing
   for (unsigned t = 0; t < T; t++)
-    for (unsigned k = 0; k < 16; k++) {
-      re[r16_pad(r16_pos_C(t, k))] = regs[(size_t)t * 16 + k].x;
-      im[r16_pad(r16_pos_C(t, k))] = regs[(size_t)t * 16 + k].y;
+    for (unsigned kk = 0; kk < 8; kk++) {
+      sm[r16_xchg_idx(t, kk)] = regs[(size_t)t * 16 + 8 + kk].x;
+      sm[R16_XCHG_IM + r16_xchg_idx(t, kk)] = regs[(size_t)t * 16 + 8 + kk].y;
     }
-  // barrier; pairing
   double mx = 0;
   for (unsigned t = 0; t < T; t++) {
-    const tw16 wt = wtab[32u * r16_brev9(t)];
-    for (unsigned i = 0; i < 16; i++) {
-      const double n2 = r16_pair(re.data(), im.data(), t, i, wt, wtab.data());
+    const tw16 wth = wtab[r16_pair_tw_thread(t)];
+    for (unsigned k = 0; k < 8; k++) {
+      const unsigned o = r16_xchg_idx(T - 1u - t, 7u - k);
+      const cplx16 partner{sm[o], sm[R16_XCHG_IM + o]};
+      const tw16 w = k == 0 ? wth : r16_cmul(wth, wtab[r16_pair_tw_k(k)]);
+      const double n2 = r16_pair_norm2(regs[(size_t)t * 16 + k], partner, w);
       mx = n2 > mx ? n2 : mx;
     }
   }
