@@ -2742,6 +2742,7 @@ static void clear_args(ExtArgs& a)
   a.nu = 0;
   a.frac = nullptr;
   a.redo = nullptr;
+  a.lazy_out = 0;
 }
 
 // ------------------------------------------------------------------
@@ -3480,6 +3481,7 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
       args.src_row[k] = (uint16_t)k;
     for (int t = 0; t < nk; t++)
       args.dst_row[t] = (uint16_t)t;
+    args.lazy_out = 1;   // scratch[1] is read by step 3 only, whose row loads are declared with LOAD_BOUND 8
     if (c->want_frac) {
       args.frac = frac_take(c, rw);
       if (!args.frac)

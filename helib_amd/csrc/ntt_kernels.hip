@@ -169,7 +169,7 @@ template <bool PLAIN>
 struct ModDownIO {
   // the load is x*inv (shoup4: [0,4q)) plus q - S in (0,2q); the store takes the lazy
   // transform output and normalises once, after the subtraction
-  static constexpr int LOAD_BOUND = PLAIN ? 1 : 6;
+  static constexpr int LOAD_BOUND = PLAIN ? 8 : 6;   // (PLAIN: ExtArgs::lazy_out words, [0,8q))
   static constexpr bool LAZY_STORE = true;
   // Element IO is software-pipelined in groups of IOG elements.  Round 1 loaded x, S (and, in the
   // store, c_r) inside the same scheduling region as the ~40 instructions that consume them, one
@@ -561,7 +561,7 @@ ntt_moddown_prep_multi_tensor_kernel(TensorSrc T, PrepMulti M, int batch, ModDow
 // PLAIN (several dropped primes): the transform's input is the ready delta * P^-1 row of the basis extension
 template <bool PLAIN>
 struct ModDownTensorIO {
-  static constexpr int LOAD_BOUND = PLAIN ? 1 : 6;
+  static constexpr int LOAD_BOUND = PLAIN ? 8 : 6;   // (PLAIN: ExtArgs::lazy_out words, [0,8q))
   static constexpr bool LAZY_STORE = true;
   static constexpr bool PIPELINED = !PLAIN;
   static constexpr int IOG = 4;

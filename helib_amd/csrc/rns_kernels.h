@@ -518,6 +518,9 @@ struct ExtArgs {
   double* frac;              // optional [batch][N]: (centred, corrected) value / P as a double
                              // (the fdelta of src/Ctxt.cpp:466-478 for scaleDownToSet)
   uint32_t* redo;            // fast kernels: [0] = count, [1..] = coefficient indices (see ExtRep below); or null
+  uint32_t lazy_out;         // 1: the dst words may stay unreduced in [0,8q) -- their only reader is a forward row
+                             // transform declared with LOAD_BOUND 8 (the several-primes mod-down's apply kernels);
+                             // honoured by rns_extend_fast_kernel, never together with upd rows
 };
 
 // value / P in [0,1) from the mixed-radix digits (value = a_0 + a_1 q_0 + a_2 q_0 q_1 + ...):
@@ -1102,7 +1105,7 @@ __device__ __forceinline__ void rns_extend_fast_one(const ExtPlanDev& P, const E
         c11 += (uint64_t)a1[k] * w1;
       }
       const u128 S = (u128)cnt * negP + c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
-      r = red128_q8(S, q, T.mu63(), T.k());
+      r = red128_q8_lazy(S, q, T.mu63(), T.k());
     } else {
       // the terms outgrow red128_q8's domain (more than eight same-size sources, or sources larger than the
       // target): the same limb sums, reduced by red128_any.  (Round 2 carried a remainder through chunks of seven
@@ -1118,14 +1121,26 @@ __device__ __forceinline__ void rns_extend_fast_one(const ExtPlanDev& P, const E
         c11 += (uint64_t)a1[k] * w1;
       }
       const u128 S = (u128)cnt * negP + c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
-      r = red128_any(S, q, T.r64(), (uint32_t)T.mu64());
+      r = red128_any_lazy(S, q, T.r64(), (uint32_t)T.mu64());
+    }
+    // r in [0,6q).  A.lazy_out (uniform): the reader takes any bound up to 8, so the three conditional subtractions
+    // -- 12 of the ~100 instructions of a target -- are left out and the plaintext-space correction adds without
+    // reducing ([0,7q))
+    const bool lazy_out = A.lazy_out != 0;
+    if (!lazy_out) {
+      r = csub(r, q << 2);
+      r = csub(r, q << 1);
+      r = csub(r, q);
     }
     if (dm_nonzero) {
       // delta -= diffProd * delta_i_modP
       uint64_t corr = dm_abs;
       if (!P.corr_unit)
         corr = mul_mod(T.pmod(), red64(dm_abs, q, T.mu64()), q, T.mu(), T.k());
-      r = dm_negative ? add_mod(r, corr, q) : sub_mod(r, corr, q);
+      if (lazy_out)
+        r += dm_negative ? corr : q - corr;
+      else
+        r = dm_negative ? add_mod(r, corr, q) : sub_mod(r, corr, q);
     }
     if (A.dst_row[t] != 0xffff)
       st_stream1(A.dst + (size_t)A.dst_row[t] * row_words + i, r);
