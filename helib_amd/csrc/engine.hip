@@ -3139,7 +3139,7 @@ static hipError_t wait_event(hipEvent_t ev)
       if (e != hipErrorNotReady)
         return e;
     }
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(hxs::current().wait_poll_us))
       break;
   }
   return hipEventSynchronize(ev);

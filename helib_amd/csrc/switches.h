@@ -32,6 +32,8 @@ struct Switches {
   bool norm_plain = false;       // HX_NORM_PLAIN=1      no split into sub-transforms above 2^14 points
   bool norm_r16_split = false;   // HX_NORM_R16_SPLIT=1  N = 2^15: radix-16 kernel per half
   bool norm_memcpy = false;      // HX_NORM_MEMCPY=1     norm read-back by hipMemcpy instead of mapped host memory
+  // host waits
+  int wait_poll_us = 2000;       // HX_WAIT_POLL_US=n    how long a norm read-back is polled for before the thread sleeps in hipEventSynchronize
   // diagnostics
   bool arena_trace = false;      // HX_ARENA_TRACE=1     one line on stderr per hipMalloc the slab arena makes
 };
@@ -65,6 +67,8 @@ inline void refresh()
   s.norm_plain = on("HX_NORM_PLAIN");
   s.norm_r16_split = on("HX_NORM_R16_SPLIT");
   s.norm_memcpy = on("HX_NORM_MEMCPY");
+  if (const char* e = std::getenv("HX_WAIT_POLL_US"))
+    s.wait_poll_us = std::atoi(e);
   s.arena_trace = on("HX_ARENA_TRACE");
   current() = s;
 }

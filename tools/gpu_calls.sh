@@ -14,7 +14,8 @@
 #   bluestein        tools/prof_bluestein.py fused and old chain + kernel trace of the fused one
 #   levels           tools/prof_levels.py for both schemes
 #   ab:A,B,...       same-box A/B of the fresh multiply, two rounds; A = default | env:VAR=1 | a variant
-#                    directory under helib_amd/lib/variants (tools/build_variant.sh); WORKLOAD=ckks65536 for config 4
+#                    directory under helib_amd/lib/variants (tools/build_variant.sh), or variant@VAR=1;
+#                    WORKLOAD=ckks65536 for config 4
 #   ubench           tools/ubench/bfly_* binaries
 #   clocks           rocm-smi engine clock / power samples while the fresh multiply runs -> clocks.txt
 export TMPDIR=/tmp
@@ -141,6 +142,7 @@ PY
           case "$v" in
             default) ;;
             env:*) envs="${v#env:}" ;;
+            *@*) envs="HX_LIB=$R/helib_amd/lib/variants/${v%%@*}/libhelib_amd.so HX_HOST_LIB=$R/helib_amd/lib/variants/${v%%@*}/libhelib_amd_host.so ${v#*@}" ;;
             *) envs="HX_LIB=$R/helib_amd/lib/variants/$v/libhelib_amd.so HX_HOST_LIB=$R/helib_amd/lib/variants/$v/libhelib_amd_host.so" ;;
           esac
           f=$out/ab_${v//[^A-Za-z0-9_]/_}_$round.json
