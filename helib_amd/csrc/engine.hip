@@ -4496,10 +4496,18 @@ static int keyswitch_launch(hx_ctx* c, const uint64_t* dig, const hx_ksk* W,
     }
     d_fix = reinterpret_cast<const hx::KsFix*>(it->second->blob);
   }
-  HX_LAUNCH(hx::keyswitch_kernel, ew_grid(rw, nall), dim3(256), 0, c->stream, dig, W->d_b,
-                     W->d_a, out0, out1, map, ndig, nall, (int)W->row_idx.size(), batch, c->phim,
-                     accumulate_rows, c->d_primes, own_src, d_fix, lazy, d_fix ? t0s : nullptr,
-                     d_fix ? t1s : nullptr, ts ? *ts : hx::TensorSrc{nullptr, nullptr, nullptr, nullptr});
+#define HX_KS_LAUNCH(ND)                                                                                           \
+  HX_LAUNCH(hx::keyswitch_kernel<ND>, ew_grid(rw, nall), dim3(256), 0, c->stream, dig, W->d_b, W->d_a, out0, out1,  \
+            map, ndig, nall, (int)W->row_idx.size(), batch, c->phim, accumulate_rows, c->d_primes, own_src, d_fix,  \
+            lazy, d_fix ? t0s : nullptr, d_fix ? t1s : nullptr,                                                    \
+            ts ? *ts : hx::TensorSrc{nullptr, nullptr, nullptr, nullptr})
+  switch (ndig) {
+    case 2: HX_KS_LAUNCH(2); break;
+    case 3: HX_KS_LAUNCH(3); break;
+    case 4: HX_KS_LAUNCH(4); break;
+    default: HX_KS_LAUNCH(0); break;
+  }
+#undef HX_KS_LAUNCH
   HIPCHK(hipGetLastError());
   return HX_OK;
 }

@@ -228,6 +228,7 @@ tensor_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1,
 // rows that the accumulation reads anyway -- so those 16 rows are neither written, transformed
 // nor re-read.
 __device__ __forceinline__ uint64_t red128_q8(u128 S, uint64_t q, uint64_t mu63, uint32_t k);  // (below)
+__device__ __forceinline__ uint64_t red128_q8_lazy(u128 S, uint64_t q, uint64_t mu63, uint32_t k);
 // waves per SIMD the fast RNS kernels are compiled for (A/B knobs)
 #ifndef HX_EXT_WAVES
 #define HX_EXT_WAVES 7
@@ -248,6 +249,9 @@ struct KsFix {
   TW pscale;            // product of the special primes mod q_row (addPrimesAndScale factor)
 };
 
+// ND: compile-time digit count (2..4: every digit's words and key words are requested before the first is used
+// -- the run-time loop of ND = 0 waits for each digit's loads in turn, one or two 16-byte loads in flight per lane)
+template <int ND>
 __global__ void __launch_bounds__(256) HX_KS_WAVES
 keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ kb,
                  const uint64_t* __restrict__ ka, uint64_t* __restrict__ out0,
@@ -272,6 +276,18 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
     const size_t j = e % n;            // coefficient index (pairs never straddle: n even)
     ulonglong2 acc0, acc1;
     ulonglong2 own = make_ulonglong2(0, 0);
+    const int owner = fix ? (int)fix[row].owner : -1;
+    ulonglong2 xs[ND ? ND : 1], kbs[ND ? ND : 1], kas[ND ? ND : 1];
+    if constexpr (ND > 0) {
+#pragma unroll
+      for (int d = 0; d < ND; d++) {
+        if (d != owner)
+          xs[d] = ld_stream2(dig + ((size_t)d * nall + row) * row_words + e);
+        const size_t kr = (size_t)d * wrows + map.brow[row];
+        kbs[d] = *reinterpret_cast<const ulonglong2*>(kb + kr * n + j);
+        kas[d] = *reinterpret_cast<const ulonglong2*>(ka + kr * n + j);
+      }
+    }
     if (row < accumulate_rows && ts.a0) {
       const size_t o = (size_t)row * row_words + e;
       const ulonglong2 a0 = ld_stream2(ts.a0 + o);
@@ -280,12 +296,20 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
       const ulonglong2 b1 = ld_stream2(ts.b1 + o);
       const TW ps = fix[row].pscale;
       const uint64_t m63 = pd.mu63;
-      acc0.x = mul_shoup(red128_q8((u128)a0.x * b0.x, q, m63, k), ps.w, ps.wp, q);
-      acc0.y = mul_shoup(red128_q8((u128)a0.y * b0.y, q, m63, k), ps.w, ps.wp, q);
-      acc1.x = mul_shoup(red128_q8((u128)a0.x * b1.x + (u128)a1.x * b0.x, q, m63, k), ps.w, ps.wp, q);
-      acc1.y = mul_shoup(red128_q8((u128)a0.y * b1.y + (u128)a1.y * b0.y, q, m63, k), ps.w, ps.wp, q);
-      own.x = red128_q8((u128)a1.x * b1.x, q, m63, k);
-      own.y = red128_q8((u128)a1.y * b1.y, q, m63, k);
+      // (mul_shoup takes any 64-bit operand -- its result is below q (1 + x / 2^64) before the one conditional
+      // subtraction -- so the products it scales stay in [0,6q): no conditional subtractions in between)
+      acc0.x = mul_shoup(red128_q8_lazy((u128)a0.x * b0.x, q, m63, k), ps.w, ps.wp, q);
+      acc0.y = mul_shoup(red128_q8_lazy((u128)a0.y * b0.y, q, m63, k), ps.w, ps.wp, q);
+      acc1.x = mul_shoup(red128_q8_lazy((u128)a0.x * b1.x + (u128)a1.x * b0.x, q, m63, k), ps.w, ps.wp, q);
+      acc1.y = mul_shoup(red128_q8_lazy((u128)a0.y * b1.y + (u128)a1.y * b0.y, q, m63, k), ps.w, ps.wp, q);
+      // the s^2 part of this row: with earlier digits to take off (owner > 0) its first use is own + q - x inside a
+      // mul_shoup as well; as digit 0's own row it enters the sums directly and is finished here (uniform branch)
+      own.x = red128_q8_lazy((u128)a1.x * b1.x, q, m63, k);
+      own.y = red128_q8_lazy((u128)a1.y * b1.y, q, m63, k);
+      if (owner <= 0) {
+        own.x = csub(csub(csub(own.x, q << 2), q << 1), q);
+        own.y = csub(csub(csub(own.y, q << 2), q << 1), q);
+      }
     } else if (row < accumulate_rows && t0s) {
       // parts (1),(s) enter scaled by the special primes (Ctxt::keySwitchPart's
       // addPrimesAndScale, src/Ctxt.cpp:816-820), read straight from the unscaled parts
@@ -307,28 +331,38 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
       acc0 = make_ulonglong2(0, 0);
       acc1 = make_ulonglong2(0, 0);
     }
-    const int owner = fix ? (int)fix[row].owner : -1;
     if (owner >= 0 && !ts.a0)
       own = ld_stream2(own_src + (size_t)row * row_words + e);
     // lazy inner product: 128-bit sums of the D products, ONE Barrett reduction per output word
     // (q < 2^60 and D <= 8 => the sums stay below 2^123)
     u128 s0x = 0, s0y = 0, s1x = 0, s1y = 0;
-    for (int d = 0; d < ndig; d++) {
+    const int nd = ND ? ND : ndig;
+#pragma unroll
+    for (int d = 0; d < nd; d++) {
       const size_t dr = (size_t)d * nall + row;
       ulonglong2 x;
       if (d == owner) {
         x = own;
       } else {
-        x = ld_stream2(dig + dr * row_words + e);
+        if constexpr (ND > 0)
+          x = xs[d];
+        else
+          x = ld_stream2(dig + dr * row_words + e);
         if (d < owner) {
           const TW pi = fix[row].pinv[d];
-          own.x = mul_shoup(sub_mod(own.x, x.x, q), pi.w, pi.wp, q);
-          own.y = mul_shoup(sub_mod(own.y, x.y, q), pi.w, pi.wp, q);
+          own.x = mul_shoup(own.x + q - x.x, pi.w, pi.wp, q);   // own in [0,6q), x in [0,q)
+          own.y = mul_shoup(own.y + q - x.y, pi.w, pi.wp, q);
         }
       }
       const size_t kr = (size_t)d * wrows + map.brow[row];  // row of W (may cover more primes)
-      ulonglong2 b = *reinterpret_cast<const ulonglong2*>(kb + kr * n + j);
-      ulonglong2 a = *reinterpret_cast<const ulonglong2*>(ka + kr * n + j);
+      ulonglong2 b, a;
+      if constexpr (ND > 0) {
+        b = kbs[d];
+        a = kas[d];
+      } else {
+        b = *reinterpret_cast<const ulonglong2*>(kb + kr * n + j);
+        a = *reinterpret_cast<const ulonglong2*>(ka + kr * n + j);
+      }
       if (lazy) {
         s0x += (u128)x.x * b.x;
         s0y += (u128)x.y * b.y;
@@ -345,10 +379,11 @@ keyswitch_kernel(const uint64_t* __restrict__ dig, const uint64_t* __restrict__ 
       // (red128_q8: approximate-quotient Barrett with 7 word multiplications -- the classical form
       // with its runtime 128-bit shifts and four compare-subtract steps was a quarter of this kernel's
       // instructions)
-      acc0.x = add_mod(acc0.x, red128_q8(s0x, q, pd.mu63, k), q);
-      acc0.y = add_mod(acc0.y, red128_q8(s0y, q, pd.mu63, k), q);
-      acc1.x = add_mod(acc1.x, red128_q8(s1x, q, pd.mu63, k), q);
-      acc1.y = add_mod(acc1.y, red128_q8(s1y, q, pd.mu63, k), q);
+      // (the accumulator rides in the same sum: D q^2 + q stays far inside red128_q8's domain for D <= 7)
+      acc0.x = red128_q8(s0x + acc0.x, q, pd.mu63, k);
+      acc0.y = red128_q8(s0y + acc0.y, q, pd.mu63, k);
+      acc1.x = red128_q8(s1x + acc1.x, q, pd.mu63, k);
+      acc1.y = red128_q8(s1y + acc1.y, q, pd.mu63, k);
     }
     st_stream2(out0 + (size_t)row * row_words + e, acc0);
     st_stream2(out1 + (size_t)row * row_words + e, acc1);
