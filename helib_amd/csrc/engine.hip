@@ -3035,7 +3035,8 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     const int logh = hx::NORM_MAX_LOGH;
     const unsigned H = 1u << logh, S = (N >> 1) >> logh;
     const size_t park_words = (size_t)rows * (S / 2) * H;   // complex doubles
-    if (c->norm_park_cap < park_words) {
+    const bool x2 = logn == 15 && !hxs::current().norm_r16_split && !hxs::current().norm_old;
+    if (!x2 && c->norm_park_cap < park_words) {
       retire_or_free(c, c->d_norm_park);
       c->d_norm_park = nullptr;
       c->norm_park_cap = 0;
@@ -3046,7 +3047,18 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     // polynomials, profiles/r03_norm_kernels_ab.txt: both sub-transforms run one after the other in one workgroup,
     // where the kernel below overlaps 16 waves) -- opt-in for experiments only
     const bool r16s = hxs::current().norm_r16_split;
-    if (r16s && logn == 15) {
+    if (x2) {
+      // both sub-transforms at once in one 1024-thread workgroup (norm_r16.h: r16x2), nothing parked
+      constexpr size_t x2_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
+      static bool attrx2 = false;
+      if (!attrx2) {
+        HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_r16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)x2_lds));
+        attrx2 = true;
+      }
+      HX_LAUNCH(hx::embed_norm_r16x2_kernel, dim3((unsigned)rows), dim3(2 * hx::R16_THREADS), x2_lds, ns, d_f, c->d_wtab,
+                c->d_norm2);
+    } else if (r16s && logn == 15) {
       constexpr size_t r16_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
       static bool attr16s = false;
       if (!attr16s) {

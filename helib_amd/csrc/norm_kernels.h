@@ -377,6 +377,51 @@ embed_norm_r16_split_kernel(const double* __restrict__ f, const double2* __restr
   block_max_to(mx, sm, t, R16_THREADS, out2 + row);
 }
 
+// N = 2^15, round 4: BOTH sub-transforms at once -- 1024 threads, half h = sub-transform h in its own 66 KiB array
+// (norm_r16.h: r16x2_*), last stage as a lane exchange, the pairing across the halves through the arrays; nothing
+// parked in global memory.  The round-2 kernel below (radix-4 LDS passes, sub-transform 1 parked, then sub-transform
+// 0) takes 73 us for the 192 polynomials of a CKKS multiply, one workgroup each on 192 of the 256 CUs.
+__global__ void __launch_bounds__(2 * R16_THREADS)
+embed_norm_r16x2_kernel(const double* __restrict__ f, const double2* __restrict__ wtab, unsigned long long* __restrict__ out2)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const unsigned row = blockIdx.x, h = threadIdx.x >> 9, t = threadIdx.x & 511u;
+  double* mine = sm + h * R16_LDS_DOUBLES;
+  const double* theirs = sm + (1u - h) * R16_LDS_DOUBLES;
+  const tw16* wt = reinterpret_cast<const tw16*>(wtab);
+  const double* fr = f + (size_t)row * (1u << 15);
+  cplx16 v[16];
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++)
+    v[k] = r16_split_input(fr, wt, r16_pos_A(t, k), h);
+  r16_pass<9, 15>(v, t, wt);
+  r16_transpose<r16_pos_A, r16_pos_B>(v, mine, t);
+  r16_pass<5, 15>(v, t & 31u, wt);
+  __syncthreads();
+  r16_transpose<r16_pos_B, r16_pos_C>(v, mine, t);
+  r16_pass<1, 15>(v, t & 1u, wt);
+#pragma unroll
+  for (unsigned k = 0; k < 16; k++)
+    v[k] = r16_last_lane(v[k], cplx16{lane_xor1(v[k].x), lane_xor1(v[k].y)}, t);
+  __syncthreads();
+#pragma unroll
+  for (unsigned kk = 0; kk < 8; kk++) {
+    mine[r16_xchg_idx(t, kk)] = v[8 + kk].x;
+    mine[R16_XCHG_IM + r16_xchg_idx(t, kk)] = v[8 + kk].y;
+  }
+  __syncthreads();
+  double mx = 0;
+  const tw16 wth = wt[r16x2_pair_tw_thread(h, t)];
+#pragma unroll
+  for (unsigned k = 0; k < 8; k++) {
+    const unsigned o = r16_xchg_idx(R16_THREADS - 1u - t, 7u - k);
+    const cplx16 other{theirs[o], theirs[R16_XCHG_IM + o]};
+    const double n2 = r16x2_pair(h, v[k], other, wth, wt[r16x2_pair_tw_k(k)], k);
+    mx = n2 > mx ? n2 : mx;
+  }
+  block_max_to(mx, sm, threadIdx.x, 2 * R16_THREADS, out2 + row);
+}
+
 // The quarter form for N > 2^14 (M = N/2 = S*H points, H = 8192, S = 2, 4, 8): the M-point transform
 // of z_i = (f_2i + i f_(2i+1)) V^i as S sub-transforms of H points, the first log2(S) decimation
 // levels applied while loading (sub-transform s holds Z_j for j = s + S k', at p = brev(k')).  The

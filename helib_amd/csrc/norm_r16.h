@@ -181,4 +181,24 @@ HXD double r16_split_pair(const double* re, const double* im, const cplx16* park
   return r16_pair_norm2(r16_last_lds(re, im, p), r16_last_mem(park, 8191u - p), w);
 }
 
+// N = 2^15 with both sub-transforms at once (embed_norm_r16x2_kernel): 1024 threads, half h = sub-transform h in its
+// own array; after the lane-exchange stage Z_h sits in registers at pos_C(t, k).  Z0 at p meets Z1 at 8191 - p, i.e.
+// what thread 511 - t of the OTHER half holds at 15 - k: half 0 forms the pairs of its k < 8, half 1 those of its
+// own k < 8 (the pairs of half 0's k >= 8) -- every pair once, the upper halves crossing through the arrays as in the
+// N = 2^14 kernel.  Twiddle W^(4 brev13(p) + 1) for the Z0 position p of the pair (W = exp(2 pi i / 2^16)):
+//   half 0, own p:        4 j + 1,       j = 4096 (t&1) + 256 brev4(k) + brev8(t>>1)
+//   half 1, p = 8191 - p': 32765 - 4 j'  (j' from its own t, k) = thread part * conj(W^(1024 brev4(k)))
+HXD unsigned r16x2_pair_tw_thread(unsigned h, unsigned t)
+{
+  const unsigned a = 16384u * (t & 1u) + 4u * r16_brev8(t >> 1);
+  return h ? 32765u - a : a + 1u;
+}
+HXD unsigned r16x2_pair_tw_k(unsigned k) { return 1024u * r16_brev4(k); }
+HXD double r16x2_pair(unsigned h, cplx16 own, cplx16 other, tw16 wth, tw16 wk, unsigned k)
+{
+  const tw16 u = h ? tw16{wk.x, -wk.y} : wk;
+  const tw16 w = k == 0 ? wth : r16_cmul(wth, u);
+  return h ? r16_pair_norm2(other, own, w) : r16_pair_norm2(own, other, w);
+}
+
 }  // namespace hx

@@ -28,7 +28,7 @@ struct Switches {
   // canonical-embedding norm kernels
   bool norm_async = false;       // HX_NORM_ASYNC=1      norm kernels on a side stream
   bool norm_split14 = false;     // HX_NORM_SPLIT14=1    N = 2^14: the split kernel instead of the radix-16 one
-  bool norm_old = false;         // HX_NORM_OLD=1        N = 2^14: the LDS-pass kernel instead of the radix-16 one
+  bool norm_old = false;         // HX_NORM_OLD=1        N = 2^14 / 2^15: the LDS-pass kernels instead of the radix-16 ones
   bool norm_plain = false;       // HX_NORM_PLAIN=1      no split into sub-transforms above 2^14 points
   bool norm_r16_split = false;   // HX_NORM_R16_SPLIT=1  N = 2^15: radix-16 kernel per half
   bool norm_memcpy = false;      // HX_NORM_MEMCPY=1     norm read-back by hipMemcpy instead of mapped host memory

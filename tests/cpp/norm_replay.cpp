@@ -155,6 +155,64 @@ static double replay_split(const std::vector<double>& f, const std::vector<tw16>
   return std::sqrt(mx);
 }
 
+// N = 2^15, both sub-transforms at once (embed_norm_r16x2_kernel): half h of the 1024 threads = sub-transform h
+static double replay_x2(const std::vector<double>& f, const std::vector<tw16>& wtab)
+{
+  const unsigned T = R16_THREADS;
+  std::vector<double> sm[2] = {std::vector<double>(R16_LDS_DOUBLES, 0.0), std::vector<double>(R16_LDS_DOUBLES, 0.0)};
+  std::vector<cplx16> regs[2] = {std::vector<cplx16>((size_t)T * 16), std::vector<cplx16>((size_t)T * 16)};
+  for (unsigned h = 0; h < 2; h++) {
+    for (unsigned t = 0; t < T; t++) {
+      cplx16 v[16];
+      for (unsigned k = 0; k < 16; k++)
+        v[k] = r16_split_input(f.data(), wtab.data(), r16_pos_A(t, k), h);
+      r16_pass<9, 15>(v, t, wtab.data());
+      for (unsigned k = 0; k < 16; k++)
+        regs[h][(size_t)t * 16 + k] = v[k];
+    }
+    transpose(regs[h], sm[h], r16_pos_A, r16_pos_B);
+    for (unsigned t = 0; t < T; t++) {
+      cplx16 v[16];
+      for (unsigned k = 0; k < 16; k++)
+        v[k] = regs[h][(size_t)t * 16 + k];
+      r16_pass<5, 15>(v, t & 31u, wtab.data());
+      for (unsigned k = 0; k < 16; k++)
+        regs[h][(size_t)t * 16 + k] = v[k];
+    }
+    transpose(regs[h], sm[h], r16_pos_B, r16_pos_C);
+    for (unsigned t = 0; t < T; t++) {
+      cplx16 v[16];
+      for (unsigned k = 0; k < 16; k++)
+        v[k] = regs[h][(size_t)t * 16 + k];
+      r16_pass<1, 15>(v, t & 1u, wtab.data());
+      for (unsigned k = 0; k < 16; k++)
+        regs[h][(size_t)t * 16 + k] = v[k];
+    }
+    std::vector<cplx16> z(regs[h].size());
+    for (unsigned t = 0; t < T; t++)
+      for (unsigned k = 0; k < 16; k++)
+        z[(size_t)t * 16 + k] = r16_last_lane(regs[h][(size_t)t * 16 + k], regs[h][(size_t)(t ^ 1u) * 16 + k], t);
+    regs[h].swap(z);
+    for (unsigned t = 0; t < T; t++)
+      for (unsigned kk = 0; kk < 8; kk++) {
+        sm[h][r16_xchg_idx(t, kk)] = regs[h][(size_t)t * 16 + 8 + kk].x;
+        sm[h][R16_XCHG_IM + r16_xchg_idx(t, kk)] = regs[h][(size_t)t * 16 + 8 + kk].y;
+      }
+  }
+  double mx = 0;
+  for (unsigned h = 0; h < 2; h++)
+    for (unsigned t = 0; t < T; t++) {
+      const tw16 wth = wtab[r16x2_pair_tw_thread(h, t)];
+      for (unsigned k = 0; k < 8; k++) {
+        const unsigned o = r16_xchg_idx(T - 1u - t, 7u - k);
+        const cplx16 other{sm[1 - h][o], sm[1 - h][R16_XCHG_IM + o]};
+        const double n2 = r16x2_pair(h, regs[h][(size_t)t * 16 + k], other, wth, wtab[r16x2_pair_tw_k(k)], k);
+        mx = n2 > mx ? n2 : mx;
+      }
+    }
+  return std::sqrt(mx);
+}
+
 static std::vector<long double> g_cos, g_sin;   // W^e, e < 2N
 static long double direct_at(const std::vector<double>& f, unsigned j)
 {
@@ -264,12 +322,22 @@ int main()
       printf("norm_replay FAILED (N = 2^15, sparse): got %.17g want %.17g\n", got, want);
       return 1;
     }
+    got = replay_x2(f, w2);
+    if (!(std::fabs(got - want) <= 1e-9 * want)) {
+      printf("norm_replay FAILED (N = 2^15 x2, sparse): got %.17g want %.17g\n", got, want);
+      return 1;
+    }
     for (auto& v : f)
       v = rnd();
     want = scan(f);
     got = replay_split(f, w2);
     if (!(std::fabs(got - want) <= 1e-9 * want)) {
       printf("norm_replay FAILED (N = 2^15, dense): got %.17g want %.17g\n", got, want);
+      return 1;
+    }
+    got = replay_x2(f, w2);
+    if (!(std::fabs(got - want) <= 1e-9 * want)) {
+      printf("norm_replay FAILED (N = 2^15 x2, dense): got %.17g want %.17g\n", got, want);
       return 1;
     }
   }
