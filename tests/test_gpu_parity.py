@@ -262,6 +262,11 @@ def test_tensor_and_keyswitch(hx):
     (32768, 16, 6, [list(range(0, 6)), list(range(6, 11)), list(range(11, 16))], 1),
     # a ring beyond one row kernel (m = 131072: transforms through pow2_big_rows)
     (131072, 4, 2, [[0, 1], [2, 3]], 2),
+    # every digit count the key-switch kernel is instantiated for (keyswitch_kernel<ND>: 2, 3, 4 with the loads
+    # hoisted, 0 = the run-time loop for anything else)
+    (16384, 3, 2, [[0, 1, 2]], 2),
+    (16384, 6, 2, [[0, 1], [2, 3], [4], [5]], 2),
+    (16384, 6, 2, [[0, 1], [2], [3], [4], [5]], 3),
 ])
 def test_multiply_relin_matches_oracle(hx, m, L, K, digits, batch):
     g = O.PrimeGen(60, m)
