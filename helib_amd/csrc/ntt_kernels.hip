@@ -136,26 +136,38 @@ struct InvPrepIO {
 
 // delta = x - qd*S:  S = [x > (qd-1)/2]  (centring, src/DoubleCRT.cpp:1098-1099)
 //                      + balanced((delta0 mod p) * qd^-1 mod p)  (ptxtSpace correction, :1485-1508)
-__global__ void __launch_bounds__(256)
-moddown_S_kernel(ModDownPrep P, size_t n)
+__device__ __forceinline__ int64_t moddown_S_of(const ModDownPrep& P, uint64_t x)
 {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const uint64_t x = P.xs[i];
-    const bool neg = x > P.half;
-    int64_t S = neg ? 1 : 0;
-    if (P.ptxt > 1) {
-      const uint64_t p = P.ptxt;
-      uint64_t r = red64(x, p, P.ptxt_mu64);
-      if (neg)
-        r = sub_mod(r, P.qd_mod_p, p);  // delta mod p, non-negative
-      if (r != 0) {
-        uint64_t dm = mul_mod(r, P.qdinv_mod_p, p, P.ptxt_mu, P.ptxt_k);
-        const uint64_t p2 = p >> 1;
-        const bool sub_p = dm > p2 || (((p & 1) == 0) && dm == p2 && neg);
-        S += sub_p ? (int64_t)dm - (int64_t)p : (int64_t)dm;
-      }
+  const bool neg = x > P.half;
+  int64_t S = neg ? 1 : 0;
+  if (P.ptxt > 1) {
+    const uint64_t p = P.ptxt;
+    uint64_t r = red64(x, p, P.ptxt_mu64);
+    if (neg)
+      r = sub_mod(r, P.qd_mod_p, p);  // delta mod p, non-negative
+    if (r != 0) {
+      // (uniform: a plaintext space below 2^32 -- the product fits a word and red64 replaces the 128-bit Barrett)
+      const uint64_t dm = (p >> 32) == 0 ? red64(r * P.qdinv_mod_p, p, P.ptxt_mu64)
+                                         : mul_mod(r, P.qdinv_mod_p, p, P.ptxt_mu, P.ptxt_k);
+      const uint64_t p2 = p >> 1;
+      const bool sub_p = dm > p2 || (((p & 1) == 0) && dm == p2 && neg);
+      S += sub_p ? (int64_t)dm - (int64_t)p : (int64_t)dm;
     }
-    P.S[i] = S;
+  }
+  return S;
+}
+// n2 = pairs of words (a block of whole rows: even, 16-byte aligned)
+__global__ void __launch_bounds__(256)
+moddown_S_kernel(ModDownPrep P, size_t n2)
+{
+  const ulonglong2* xs = reinterpret_cast<const ulonglong2*>(P.xs);
+  longlong2* S = reinterpret_cast<longlong2*>(P.S);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+    const ulonglong2 x = xs[i];
+    longlong2 s;
+    s.x = moddown_S_of(P, x.x);
+    s.y = moddown_S_of(P, x.y);
+    S[i] = s;
   }
 }
 
@@ -915,8 +927,8 @@ static hipError_t launch_moddown(const PolyBases& polys, const PolyBases& outs, 
                      tw_arena);
   {
     const size_t n = (size_t)polys.n * (size_t)batch * Geo<LOGN>::N;
-    HX_LAUNCH(moddown_S_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)),
-                       dim3(256), 0, st, P, n);
+    HX_LAUNCH(moddown_S_kernel, dim3((unsigned)((n / 2 + 255) / 256 > 8192 ? 8192 : (n / 2 + 255) / 256)),
+                       dim3(256), 0, st, P, n / 2);
   }
   HX_LAUNCH((ntt_moddown_apply_kernel<LOGN, false>),
                      dim3(moddown_apply_grid((unsigned)polys.n, (unsigned)nkeep, (unsigned)batch)),
@@ -975,7 +987,8 @@ static hipError_t launch_moddown_tensor(const TensorSrc& T, const PolyBases& out
             drop_row, drop_prime, batch, P, primes, tw_arena);
   {
     const size_t n = (size_t)3 * (size_t)batch * Geo<LOGN>::N;
-    HX_LAUNCH(moddown_S_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), dim3(256), 0, st, P, n);
+    HX_LAUNCH(moddown_S_kernel, dim3((unsigned)((n / 2 + 255) / 256 > 8192 ? 8192 : (n / 2 + 255) / 256)), dim3(256), 0, st, P,
+              n / 2);
   }
   HX_LAUNCH((ntt_moddown_apply_tensor_kernel<LOGN, false>), dim3(moddown_apply_grid(3u, (unsigned)nkeep, (unsigned)batch)),
             dim3(Geo<LOGN>::T), lds_bytes, st, T, outs, keep, nkeep, batch, A, primes, tw_arena);

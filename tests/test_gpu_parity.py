@@ -762,7 +762,7 @@ def test_tensor_folded_into_the_mod_switch_at_the_benchmarked_shapes(hx, name):
                 assert np.array_equal(fd[part][r, b], want[keep.index(i)]), (part, i, b)
 
 
-@pytest.mark.parametrize("ptxt", [65537, 2, 1, 4])
+@pytest.mark.parametrize("ptxt", [65537, 2, 1, 4, 4294967311, 1 << 40])   # (the last two: beyond a 32-bit word)
 @pytest.mark.parametrize("m", [16384, 32768])
 def test_scale_down_single_prime_fused_path(hx, m, ptxt):
     """One dropped prime takes the fused path (delta prepared inside the inverse transform of

@@ -97,7 +97,7 @@ def test_break_into_digits_matches_python(m, digits):
         assert got[di].tolist() == ctx.fft(all_idx, coef).tolist()
 
 
-@pytest.mark.parametrize("m,ptxt", [(32, 257), (32, 2), (15, 7), (32, 1), (16, 4)])
+@pytest.mark.parametrize("m,ptxt", [(32, 257), (32, 2), (15, 7), (32, 1), (16, 4), (32, 4294967311), (32, 1 << 40)])
 def test_scale_down_matches_python(m, ptxt):
     ctx = make_ctx(m, 6)
     own = [0, 1, 2, 3, 4, 5]
