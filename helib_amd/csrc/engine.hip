@@ -2932,7 +2932,61 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     HIPCHK(hipStreamWaitEvent(c->norm_stream, c->norm_in_ev, 0));
     ns = c->norm_stream;
   }
-  HIPCHK(hipMemsetAsync(c->d_norm2, 0, sizeof(unsigned long long) * (size_t)rows, ns));
+  // read-back through a pinned slot and an event
+  hx_ctx::NormPending np{};
+  bool have = false;
+  for (size_t i = 0; i < c->norm_free.size(); i++)
+    if (c->norm_free[i].cap >= (size_t)rows) {
+      np = c->norm_free[i];
+      c->norm_free.erase(c->norm_free.begin() + (long)i);
+      have = true;
+      break;
+    }
+  if (!have && rows <= 1024) {
+    constexpr size_t PER = 64, CAP = 1024;
+    unsigned long long* slab = nullptr;
+    HIPCHK(hipHostMalloc((void**)&slab, PER * CAP * sizeof(unsigned long long), hipHostMallocDefault));
+    c->norm_slabs.push_back(slab);
+    for (size_t i = 0; i < PER; i++) {
+      hx_ctx::NormPending f{};
+      f.pinned = slab + i * CAP;
+      f.cap = CAP;
+      f.slab = true;
+      HIPCHK(hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
+      c->norm_free.push_back(f);
+    }
+    np = c->norm_free.back();
+    c->norm_free.pop_back();
+    have = true;
+  }
+  if (!have) {
+    np.cap = (size_t)rows;
+    np.slab = false;
+    HIPCHK(hipHostMalloc((void**)&np.pinned, np.cap * sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&np.ev, hipEventDisableTiming));
+  }
+  // (the slot goes back to the free list if anything below fails before it is queued)
+  struct SlotGuard {
+    hx_ctx* c;
+    hx_ctx::NormPending* np;
+    bool armed = true;
+    ~SlotGuard()
+    {
+      if (armed)
+        c->norm_free.push_back(*np);
+    }
+  } slot_guard{c, &np};
+  // One workgroup per polynomial and a plain store of its maximum (the radix-16 kernels): the kernel writes the pinned,
+  // device-visible slot itself -- no zero-fill of d_norm2 in front of it (an atomicMax target) and no copy kernel behind
+  // it, two ~4 us launches with their gaps per norm call, three calls per multiply.
+  const bool by_copy = hxs::current().norm_memcpy;
+  const bool r16_path = c->pow2 && !hxs::current().norm_old && !hxs::current().norm_split14 && logn == 14;
+  const bool x2_path = c->pow2 && logn == 15 && !hxs::current().norm_r16_split && !hxs::current().norm_old &&
+                       !hxs::current().norm_plain;
+  const bool direct = !by_copy && (r16_path || x2_path);
+  unsigned long long* const out2 = direct ? np.pinned : c->d_norm2;
+  if (!direct)
+    HIPCHK(hipMemsetAsync(c->d_norm2, 0, sizeof(unsigned long long) * (size_t)rows, ns));
   static bool attr = false;
   if (!c->pow2) {
     CHK(flush_xs(c));
@@ -3010,7 +3064,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       hx::NormSrcXS src{c->scratch[0], reinterpret_cast<const int64_t*>(c->scratch[1]), c->xs_inv_qd};
       if (r16 && logn == 14)
         HX_LAUNCH((hx::embed_norm_r16_kernel<hx::NormSrcXS>), dim3((unsigned)rows), dim3(hx::R16_THREADS), r16_lds, ns, src,
-                  c->d_wtab, c->d_norm2);
+                  c->d_wtab, out2, direct);
       else if (split14 && logn == 14)
         HX_NORM_SPLIT(hx::NormSrcXS, src);
       else
@@ -3020,7 +3074,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       hx::NormSrcF64 src{d_f};
       if (r16 && logn == 14)
         HX_LAUNCH((hx::embed_norm_r16_kernel<hx::NormSrcF64>), dim3((unsigned)rows), dim3(hx::R16_THREADS), r16_lds, ns, src,
-                  c->d_wtab, c->d_norm2);
+                  c->d_wtab, out2, direct);
       else if (split14 && logn == 14)
         HX_NORM_SPLIT(hx::NormSrcF64, src);
       else
@@ -3057,7 +3111,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
         attrx2 = true;
       }
       HX_LAUNCH(hx::embed_norm_r16x2_kernel, dim3((unsigned)rows), dim3(2 * hx::R16_THREADS), x2_lds, ns, d_f, c->d_wtab,
-                c->d_norm2);
+                out2, direct);
     } else if (r16s && logn == 15) {
       constexpr size_t r16_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
       static bool attr16s = false;
@@ -3081,45 +3135,13 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
                        c->d_wtab, logn, logh, c->d_norm2);
   }
   HIPCHK(hipGetLastError());
-  // read-back through a pinned slot and an event
-  hx_ctx::NormPending np{};
-  bool have = false;
-  for (size_t i = 0; i < c->norm_free.size(); i++)
-    if (c->norm_free[i].cap >= (size_t)rows) {
-      np = c->norm_free[i];
-      c->norm_free.erase(c->norm_free.begin() + (long)i);
-      have = true;
-      break;
-    }
-  if (!have && rows <= 1024) {
-    constexpr size_t PER = 64, CAP = 1024;
-    unsigned long long* slab = nullptr;
-    HIPCHK(hipHostMalloc((void**)&slab, PER * CAP * sizeof(unsigned long long), hipHostMallocDefault));
-    c->norm_slabs.push_back(slab);
-    for (size_t i = 0; i < PER; i++) {
-      hx_ctx::NormPending f{};
-      f.pinned = slab + i * CAP;
-      f.cap = CAP;
-      f.slab = true;
-      HIPCHK(hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
-      c->norm_free.push_back(f);
-    }
-    np = c->norm_free.back();
-    c->norm_free.pop_back();
-    have = true;
-  }
-  if (!have) {
-    np.cap = (size_t)rows;
-    np.slab = false;
-    HIPCHK(hipHostMalloc((void**)&np.pinned, np.cap * sizeof(unsigned long long), hipHostMallocDefault));
-    HIPCHK(hipEventCreateWithFlags(&np.ev, hipEventDisableTiming));
-  }
   np.rows = rows;
   np.out = out_host;
   // the few words go to the pinned slot by a kernel writing host memory (hipHostMalloc memory is device-visible),
   // not by a device-to-host copy command: HX_NORM_MEMCPY=1 restores the copy (A/B)
-  const bool by_copy = hxs::current().norm_memcpy;
-  if (by_copy) {
+  if (direct) {
+    // (written by the norm kernel itself)
+  } else if (by_copy) {
     HIPCHK(hipMemcpyAsync(np.pinned, c->d_norm2, sizeof(unsigned long long) * (size_t)rows,
                           hipMemcpyDeviceToHost, ns));
   } else {
@@ -3129,6 +3151,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   }
   HIPCHK(hipEventRecord(np.ev, ns));
   c->norm_pending.push_back(np);
+  slot_guard.armed = false;
   if (ns != c->stream) {
     HIPCHK(hipEventRecord(c->norm_out_ev, ns));
     (use_xs ? c->norm_reads_xs : c->norm_reads_frac) = true;

@@ -93,7 +93,7 @@ __device__ __forceinline__ void dif_fft_lds(double* re, double* im, int logh_rt,
 }
 
 __device__ __forceinline__ void block_max_to(double mx, double* sm, unsigned tid, unsigned nth,
-                                             unsigned long long* dst)
+                                             unsigned long long* dst, bool direct = false)
 {
   for (int off = 32; off > 0; off >>= 1) {
     const double o = __shfl_down(mx, off, 64);
@@ -107,7 +107,12 @@ __device__ __forceinline__ void block_max_to(double mx, double* sm, unsigned tid
     const unsigned nw = (nth + 63) >> 6;
     for (unsigned w = 1; w < nw; w++)
       mx = sm[w] > mx ? sm[w] : mx;
-    atomicMax(dst, (unsigned long long)__double_as_longlong(mx));
+    // direct: this workgroup is the only writer of *dst (one workgroup per polynomial) -- a plain store, which may go
+    // to device-visible host memory; otherwise several workgroups meet in a zeroed word
+    if (direct)
+      *dst = (unsigned long long)__double_as_longlong(mx);
+    else
+      atomicMax(dst, (unsigned long long)__double_as_longlong(mx));
   }
 }
 
@@ -260,7 +265,7 @@ __device__ __forceinline__ void r16_transpose(cplx16 (&v)[16], double* sm, unsig
 }
 template <class SRC>
 __global__ void __launch_bounds__(R16_THREADS)
-embed_norm_r16_kernel(SRC src, const double2* __restrict__ wtab, unsigned long long* __restrict__ out2)
+embed_norm_r16_kernel(SRC src, const double2* __restrict__ wtab, unsigned long long* __restrict__ out2, bool direct)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const unsigned row = blockIdx.x, t = threadIdx.x;
@@ -301,7 +306,7 @@ embed_norm_r16_kernel(SRC src, const double2* __restrict__ wtab, unsigned long l
     const double n2 = r16_pair_norm2(v[k], partner, w);
     mx = n2 > mx ? n2 : mx;
   }
-  block_max_to(mx, sm, t, R16_THREADS, out2 + row);
+  block_max_to(mx, sm, t, R16_THREADS, out2 + row, direct);
 }
 
 // N = 2^15 (the CKKS ring of BASELINE configs[3]) on the same register passes: the 16384-point transform of the
@@ -382,7 +387,8 @@ embed_norm_r16_split_kernel(const double* __restrict__ f, const double2* __restr
 // parked in global memory.  The round-2 kernel below (radix-4 LDS passes, sub-transform 1 parked, then sub-transform
 // 0) takes 73 us for the 192 polynomials of a CKKS multiply, one workgroup each on 192 of the 256 CUs.
 __global__ void __launch_bounds__(2 * R16_THREADS)
-embed_norm_r16x2_kernel(const double* __restrict__ f, const double2* __restrict__ wtab, unsigned long long* __restrict__ out2)
+embed_norm_r16x2_kernel(const double* __restrict__ f, const double2* __restrict__ wtab, unsigned long long* __restrict__ out2,
+                        bool direct)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const unsigned row = blockIdx.x, h = threadIdx.x >> 9, t = threadIdx.x & 511u;
@@ -419,7 +425,7 @@ embed_norm_r16x2_kernel(const double* __restrict__ f, const double2* __restrict_
     const double n2 = r16x2_pair(h, v[k], other, wth, wt[r16x2_pair_tw_k(k)], k);
     mx = n2 > mx ? n2 : mx;
   }
-  block_max_to(mx, sm, threadIdx.x, 2 * R16_THREADS, out2 + row);
+  block_max_to(mx, sm, threadIdx.x, 2 * R16_THREADS, out2 + row, direct);
 }
 
 // The quarter form for N > 2^14 (M = N/2 = S*H points, H = 8192, S = 2, 4, 8): the M-point transform
