@@ -2980,9 +2980,8 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   // device-visible slot itself -- no zero-fill of d_norm2 in front of it (an atomicMax target) and no copy kernel behind
   // it, two ~4 us launches with their gaps per norm call, three calls per multiply.
   const bool by_copy = hxs::current().norm_memcpy;
-  const bool r16_path = c->pow2 && !hxs::current().norm_old && !hxs::current().norm_split14 && logn == 14;
-  const bool x2_path = c->pow2 && logn == 15 && !hxs::current().norm_r16_split && !hxs::current().norm_old &&
-                       !hxs::current().norm_plain;
+  const bool r16_path = c->pow2 && !hxs::current().norm_old && logn == 14;
+  const bool x2_path = c->pow2 && logn == 15 && !hxs::current().norm_old && !hxs::current().norm_plain;
   const bool direct = !by_copy && (r16_path || x2_path);
   unsigned long long* const out2 = direct ? np.pinned : c->d_norm2;
   if (!direct)
@@ -3031,24 +3030,8 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       HX_LAUNCH((hx::embed_norm_quarter_kernel<SRCT, 0>), dim3((unsigned)rows), dim3(threads), lds,    \
                          ns, srcv, c->d_wtab, logn, c->d_norm2);                                         \
   } while (0)
-    // experiment, off by default: N = 2^14 as two 4096-point sub-transforms per
-    // element -- 64 KiB of LDS and 512 threads per workgroup, two elements resident per CU
-    const bool split14 = hxs::current().norm_split14;
-    if (split14 && logn == 14) {
-      const size_t park_words = (size_t)rows * 4096;   // complex doubles: [row][1][H]
-      if (c->norm_park_cap < park_words) {
-        retire_or_free(c, c->d_norm_park);
-        c->d_norm_park = nullptr;
-        c->norm_park_cap = 0;
-        HIPCHK(hipMalloc((void**)&c->d_norm_park, park_words * sizeof(double2)));
-        c->norm_park_cap = park_words;
-      }
-    }
-#define HX_NORM_SPLIT(SRCT, srcv)                                                                            \
-  HX_LAUNCH((hx::embed_norm_quarter_splitT_kernel<SRCT, 12, 512>), dim3((unsigned)rows), dim3(512), \
-                     16 * (size_t)4096, ns, srcv, c->d_wtab, logn, c->d_norm_park, c->d_norm2)
     // N = 2^14: the register-tiled kernel (norm_r16.h); HX_NORM_OLD keeps the LDS-pass kernel (A/B)
-    const bool r16 = !hxs::current().norm_old && !hxs::current().norm_split14;
+    const bool r16 = !hxs::current().norm_old;
     constexpr size_t r16_lds = (size_t)hx::R16_LDS_DOUBLES * sizeof(double);   // one array: two workgroups per CU
     if (r16 && logn == 14) {
       static bool attr16 = false;
@@ -3065,8 +3048,6 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       if (r16 && logn == 14)
         HX_LAUNCH((hx::embed_norm_r16_kernel<hx::NormSrcXS>), dim3((unsigned)rows), dim3(hx::R16_THREADS), r16_lds, ns, src,
                   c->d_wtab, out2, direct);
-      else if (split14 && logn == 14)
-        HX_NORM_SPLIT(hx::NormSrcXS, src);
       else
         HX_NORM_LAUNCH(hx::NormSrcXS, src);
     } else {
@@ -3075,12 +3056,9 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       if (r16 && logn == 14)
         HX_LAUNCH((hx::embed_norm_r16_kernel<hx::NormSrcF64>), dim3((unsigned)rows), dim3(hx::R16_THREADS), r16_lds, ns, src,
                   c->d_wtab, out2, direct);
-      else if (split14 && logn == 14)
-        HX_NORM_SPLIT(hx::NormSrcF64, src);
       else
         HX_NORM_LAUNCH(hx::NormSrcF64, src);
     }
-#undef HX_NORM_SPLIT
 #undef HX_NORM_LAUNCH
     c->xs_rows = 0;
   } else if (logn - 1 > hx::NORM_MAX_LOGH && !hxs::current().norm_plain) {
@@ -3089,7 +3067,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     const int logh = hx::NORM_MAX_LOGH;
     const unsigned H = 1u << logh, S = (N >> 1) >> logh;
     const size_t park_words = (size_t)rows * (S / 2) * H;   // complex doubles
-    const bool x2 = logn == 15 && !hxs::current().norm_r16_split && !hxs::current().norm_old;
+    const bool x2 = logn == 15 && !hxs::current().norm_old;
     if (!x2 && c->norm_park_cap < park_words) {
       retire_or_free(c, c->d_norm_park);
       c->d_norm_park = nullptr;
@@ -3097,10 +3075,6 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       HIPCHK(hipMalloc((void**)&c->d_norm_park, park_words * sizeof(double2)));
       c->norm_park_cap = park_words;
     }
-    // the register-tiled form (norm_r16.h) at N = 2^15: measured SLOWER than the kernel below (140 vs 82 us per 192
-    // polynomials, profiles/r03_norm_kernels_ab.txt: both sub-transforms run one after the other in one workgroup,
-    // where the kernel below overlaps 16 waves) -- opt-in for experiments only
-    const bool r16s = hxs::current().norm_r16_split;
     if (x2) {
       // both sub-transforms at once in one 1024-thread workgroup (norm_r16.h: r16x2), nothing parked
       constexpr size_t x2_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
@@ -3112,16 +3086,6 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
       }
       HX_LAUNCH(hx::embed_norm_r16x2_kernel, dim3((unsigned)rows), dim3(2 * hx::R16_THREADS), x2_lds, ns, d_f, c->d_wtab,
                 out2, direct);
-    } else if (r16s && logn == 15) {
-      constexpr size_t r16_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
-      static bool attr16s = false;
-      if (!attr16s) {
-        HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_r16_split_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds));
-        attr16s = true;
-      }
-      HX_LAUNCH(hx::embed_norm_r16_split_kernel, dim3((unsigned)rows), dim3(hx::R16_THREADS), r16_lds, ns, d_f, c->d_wtab,
-                c->d_norm_park, c->d_norm2);
     } else
     HX_LAUNCH(hx::embed_norm_quarter_split_kernel, dim3((unsigned)rows * (S / 2)), dim3(hx::NORM_THREADS),
                        16 * (size_t)H, ns, d_f, c->d_wtab, logn, logh, c->d_norm_park, c->d_norm2);

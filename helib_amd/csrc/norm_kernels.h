@@ -309,79 +309,6 @@ embed_norm_r16_kernel(SRC src, const double2* __restrict__ wtab, unsigned long l
   block_max_to(mx, sm, t, R16_THREADS, out2 + row, direct);
 }
 
-// N = 2^15 (the CKKS ring of BASELINE configs[3]) on the same register passes: the 16384-point transform of the
-// quarter form as S = 2 sub-transforms of 8192 points (embed_norm_quarter_split_kernel below describes the split);
-// one workgroup per polynomial: sub-transform 1 first, parked in global memory straight from the registers, then
-// sub-transform 0 in LDS and the pairing across the two.
-__global__ void __launch_bounds__(R16_THREADS)
-embed_norm_r16_split_kernel(const double* __restrict__ f, const double2* __restrict__ wtab, double2* __restrict__ park,
-                            unsigned long long* __restrict__ out2)
-{
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* re = sm;
-  double* im = sm + R16_LDS_DOUBLES;
-  const unsigned row = blockIdx.x, t = threadIdx.x;
-  const tw16* wt = reinterpret_cast<const tw16*>(wtab);
-  const double* fr = f + (size_t)row * (1u << 15);
-  cplx16* pk = reinterpret_cast<cplx16*>(park) + (size_t)row * 8192u;
-  cplx16 v[16];
-#pragma unroll 1
-  for (int pass = 0; pass < 2; pass++) {
-    const unsigned sub = pass == 0 ? 1u : 0u;
-#pragma unroll
-    for (unsigned k = 0; k < 16; k++)
-      v[k] = r16_split_input(fr, wt, r16_pos_A(t, k), sub);
-    r16_pass<9, 15>(v, t, wt);
-    __syncthreads();   // (second round: the pairing-free LDS of round one is being rewritten)
-#pragma unroll
-    for (unsigned k = 0; k < 16; k++) {
-      re[r16_pad(r16_pos_A(t, k))] = v[k].x;
-      im[r16_pad(r16_pos_A(t, k))] = v[k].y;
-    }
-    __syncthreads();
-#pragma unroll
-    for (unsigned k = 0; k < 16; k++) {
-      v[k].x = re[r16_pad(r16_pos_B(t, k))];
-      v[k].y = im[r16_pad(r16_pos_B(t, k))];
-    }
-    r16_pass<5, 15>(v, t & 31u, wt);
-    __syncthreads();
-#pragma unroll
-    for (unsigned k = 0; k < 16; k++) {
-      re[r16_pad(r16_pos_B(t, k))] = v[k].x;
-      im[r16_pad(r16_pos_B(t, k))] = v[k].y;
-    }
-    __syncthreads();
-#pragma unroll
-    for (unsigned k = 0; k < 16; k++) {
-      v[k].x = re[r16_pad(r16_pos_C(t, k))];
-      v[k].y = im[r16_pad(r16_pos_C(t, k))];
-    }
-    r16_pass<1, 15>(v, t & 1u, wt);
-    if (pass == 0) {
-#pragma unroll
-      for (unsigned k = 0; k < 16; k++)
-        pk[r16_pos_C(t, k)] = v[k];
-    } else {
-      __syncthreads();
-#pragma unroll
-      for (unsigned k = 0; k < 16; k++) {
-        re[r16_pad(r16_pos_C(t, k))] = v[k].x;
-        im[r16_pad(r16_pos_C(t, k))] = v[k].y;
-      }
-    }
-  }
-  __syncthreads();   // LDS of sub-transform 0 complete; the parked values of this workgroup visible to it
-  double mx = 0;
-  const tw16 wpair = wt[64u * r16_brev9(t)];
-#pragma unroll
-  for (unsigned i = 0; i < 16; i++) {
-    const double n2 = r16_split_pair(re, im, pk, t, i, wpair, wt);
-    mx = n2 > mx ? n2 : mx;
-  }
-  block_max_to(mx, sm, t, R16_THREADS, out2 + row);
-}
-
 // N = 2^15, round 4: BOTH sub-transforms at once -- 1024 threads, half h = sub-transform h in its own 66 KiB array
 // (norm_r16.h: r16x2_*), last stage as a lane exchange, the pairing across the halves through the arrays; nothing
 // parked in global memory.  The round-2 kernel below (radix-4 LDS passes, sub-transform 1 parked, then sub-transform
@@ -469,65 +396,6 @@ embed_norm_quarter_split_kernel(const double* __restrict__ f, const double2* __r
     __syncthreads();
     // root U^S = W^(4S) = W^(2N/H): the table stride dif_fft_lds expects (H = 8192, 1024 threads: always)
     dif_fft_lds<NORM_MAX_LOGH, NORM_THREADS>(re, im, logh, N, wtab, tid, nth);
-    if (pass == 0) {
-      for (unsigned p = tid; p < H; p += nth)
-        pk[p] = make_double2(re[p], im[p]);
-      __syncthreads();
-    }
-  }
-  double mx = 0;
-  for (unsigned p = tid; p < H; p += nth) {
-    const unsigned j = s + S * (__brev(p) >> (32 - logh));
-    const double2 c = pk[H - 1 - p];
-    const double zr = re[p], zi = im[p], cr = c.x, ci = -c.y;
-    const double er = 0.5 * (zr + cr), ei = 0.5 * (zi + ci);
-    const double dr = zr - cr, di = zi - ci;
-    const double orr = 0.5 * di, oi = -0.5 * dr;
-    const double2 w = wtab[2 * j + 1];
-    const double tr = orr * w.x - oi * w.y, ti = orr * w.y + oi * w.x;
-    const double a = (er + tr) * (er + tr) + (ei + ti) * (ei + ti);
-    const double b = (er - tr) * (er - tr) + (ei - ti) * (ei - ti);
-    const double n2 = a > b ? a : b;
-    mx = n2 > mx ? n2 : mx;
-  }
-  block_max_to(mx, sm, tid, nth, out2 + row);
-}
-
-// Experiment (HX_NORM_SPLIT14, off by default): the split form above for any coefficient
-// source and a compile-time sub-transform size, so that N = 2^14 can run as S = 2 sub-transforms of 4096 points --
-// 64 KiB of LDS and CNTH = 512 threads per workgroup: two elements resident per CU instead of one.
-template <class SRC, int CLOGH, int CNTH>
-__global__ void __launch_bounds__(CNTH)
-embed_norm_quarter_splitT_kernel(SRC src, const double2* __restrict__ wtab, int logn, double2* __restrict__ park,
-                                 unsigned long long* __restrict__ out2)
-{
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  constexpr int logh = CLOGH;
-  const unsigned N = 1u << logn, M = N >> 1, H = 1u << logh, S = M >> logh, half = S >> 1;
-  double* re = sm;
-  double* im = sm + H;
-  const unsigned row = blockIdx.x / half, s = blockIdx.x % half;
-  const unsigned tid = threadIdx.x, nth = CNTH;
-  double2* pk = park + ((size_t)row * half + s) * H;
-  const unsigned mmask = 2 * N - 1;
-  for (int pass = 0; pass < 2; pass++) {
-    const unsigned sub = pass == 0 ? S - 1 - s : s;
-    for (unsigned i = tid; i < H; i += nth) {
-      double ar = 0, ai = 0;
-      for (unsigned t = 0; t < S; t++) {
-        const unsigned idx = i + t * H;
-        const unsigned e = (2u * idx * (2u * sub + 1u)) & mmask;
-        const double2 w = wtab[e & (N - 1)];
-        const double2 v = src.pair(row, N, idx);
-        const double zr = v.x * w.x - v.y * w.y, zi = v.x * w.y + v.y * w.x;
-        ar += e >= N ? -zr : zr;
-        ai += e >= N ? -zi : zi;
-      }
-      re[i] = ar;
-      im[i] = ai;
-    }
-    __syncthreads();
-    dif_fft_lds<CLOGH, CNTH>(re, im, logh, N, wtab, tid, nth);
     if (pass == 0) {
       for (unsigned p = tid; p < H; p += nth)
         pk[p] = make_double2(re[p], im[p]);

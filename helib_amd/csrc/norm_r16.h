@@ -1,9 +1,9 @@
-// norm_r16.h -- register-tiled form of the canonical-embedding norm for N = 2^14 (the benchmark ring):
+// norm_r16.h -- register-tiled form of the canonical-embedding norm for N = 2^14 (the benchmark ring) and 2^15:
 // the 8192-point complex transform of the "quarter" trick (norm_kernels.h, src/norms.cpp:200-262) as
-// THREE radix-16 register passes of 512 threads x 16 points plus one stage folded into the pairing
-// pass, five barriers in all.  The round-1/2 kernel (embed_norm_quarter_kernel) makes seven radix-4
+// THREE radix-16 register passes of 512 threads x 16 points, the last stage as a lane exchange, and a pairing
+// pass that forms every pair once.  The round-1/2 kernel (embed_norm_quarter_kernel) makes seven radix-4
 // passes through LDS with 1024 threads x 2 butterflies each, nine barriers, every pass exposing an LDS
-// round trip per two stages: 40 us per element on a CU against 7.5 us of LDS bandwidth (DESIGN.md).
+// round trip per two stages: 40 us per element on a CU against 7.5 us of LDS bandwidth (DESIGN.md 3.9).
 //
 // Decimation in frequency, output in bit-reversed order (only maxima are taken).  Stage with half-length
 // len: (a, b) = (x[k], x[k+len]) -> x[k] = a + b, x[k+len] = (a - b) T_len(j), j = k mod len,
@@ -11,8 +11,9 @@
 //   pass A  len = 4096, 2048, 1024, 512   positions  t + 512 k            (t < 512,  k < 16)
 //   pass B  len =  256,  128,   64,  32   positions  512 b + j + 32 k     (b = t>>5, j = t&31)
 //   pass C  len =   16,    8,    4,   2   positions   32 b + j +  2 k     (b = t>>1, j = t&1)
-//   stage len = 1 inside the pairing pass: Z[p] = x[p] + x[p+1] (p even), x[p-1] - x[p] (p odd)
-// LDS index i is stored at i + (i >> 5): pass C's stride-32 block starts then fall on different banks.
+//   stage len = 1 between lanes t and t ^ 1: Z[p] = x[p] + x[p+1] (p even), x[p-1] - x[p] (p odd)
+// Between the passes the real parts cross ONE padded array (index i stored at i + (i >> 5): pass C's stride-32
+// block starts then fall on different banks), then the imaginary parts: 66 KiB, two workgroups per CU.
 // The phase functions are plain C++ (HXD) so that tests/cpp/norm_replay.cpp runs them thread by thread
 // on the CPU against the definition.
 #pragma once
@@ -77,27 +78,6 @@ HXD unsigned r16_pos_A(unsigned t, unsigned k) { return t + 512u * k; }
 HXD unsigned r16_pos_B(unsigned t, unsigned k) { return 512u * (t >> 5) + (t & 31u) + 32u * k; }
 HXD unsigned r16_pos_C(unsigned t, unsigned k) { return 32u * (t >> 1) + (t & 1u) + 2u * k; }
 
-HXD unsigned r16_brev13(unsigned p)
-{
-  unsigned r = 0;
-  for (int i = 0; i < 13; i++)
-    r |= ((p >> i) & 1u) << (12 - i);
-  return r;
-}
-// value at output position p after the last stage (len = 1, twiddle 1), from the padded LDS arrays / from a
-// plain complex array (the parked sub-transform of the N = 2^15 form)
-HXD cplx16 r16_last_lds(const double* re, const double* im, unsigned p)
-{
-  const unsigned pe = p & ~1u;
-  const double ar = re[r16_pad(pe)], ai = im[r16_pad(pe)], br = re[r16_pad(pe + 1)], bi = im[r16_pad(pe + 1)];
-  return (p & 1u) ? cplx16{ar - br, ai - bi} : cplx16{ar + br, ai + bi};
-}
-HXD cplx16 r16_last_mem(const cplx16* x, unsigned p)
-{
-  const unsigned pe = p & ~1u;
-  const cplx16 a = x[pe], b = x[pe + 1];
-  return (p & 1u) ? cplx16{a.x - b.x, a.y - b.y} : cplx16{a.x + b.x, a.y + b.y};
-}
 // max of |f|^2 at the two evaluation points that Z_j = z and Z_(M-1-j) = partner give, w = W^(2j+1)
 // (embed_norm_quarter_kernel's formula)
 HXD double r16_pair_norm2(cplx16 z, cplx16 partner, tw16 w)
@@ -111,25 +91,9 @@ HXD double r16_pair_norm2(cplx16 z, cplx16 partner, tw16 w)
   const double b = (er - tr) * (er - tr) + (ei - ti) * (ei - ti);
   return a > b ? a : b;
 }
-HXD unsigned r16_brev9(unsigned t)
-{
-  unsigned r = 0;
-  for (int i = 0; i < 9; i++)
-    r |= ((t >> i) & 1u) << (8 - i);
-  return r;
-}
 HXD unsigned r16_brev4(unsigned i) { return ((i & 1u) << 3) | ((i & 2u) << 1) | ((i & 4u) >> 1) | ((i & 8u) >> 3); }
-// N = 2^14: the pairing pass for output position p = t + 512 i (t < 512, i < 16): j = brev13(p) =
-// 16 brev9(t) + brev4(i), so W^(2j+1) = W^(32 brev9(t)) * W^(2 brev4(i) + 1): wt = the first factor (one
-// load per thread), the second is read at a wave-uniform address
-HXD double r16_pair(const double* re, const double* im, unsigned t, unsigned i, tw16 wt, const tw16* wtab)
-{
-  const unsigned p = t + 512u * i;
-  const tw16 w = r16_cmul(wt, wtab[2u * r16_brev4(i) + 1u]);
-  return r16_pair_norm2(r16_last_lds(re, im, p), r16_last_lds(re, im, R16_M - 1u - p), w);
-}
-// ---- the same transform through ONE padded array of R16_LDS_DOUBLES doubles (66 KiB: two workgroups per CU) ----
-// The two transposes move the real parts through the array, then the imaginary parts.  After pass C thread t holds
+// ---- the last stage and the pairing ----
+// After pass C thread t holds
 // positions p = 32 (t>>1) + (t&1) + 2k: the partner p ^ 1 of the last stage (len = 1) is the same k of lane t ^ 1,
 // so that stage is a lane exchange and the finished Z stay in registers:
 HXD cplx16 r16_last_lane(cplx16 own, cplx16 other, unsigned t)   // other: the value lane t ^ 1 holds at the same k
@@ -171,16 +135,6 @@ HXD cplx16 r16_split_input(const double* f, const tw16* wtab, unsigned i, unsign
   }
   return acc;
 }
-// pairing of sub-transform 0 (in LDS) with the parked sub-transform 1: Z_j, j = 2 brev13(p), and Z_(M-1-j) at H-1-p
-// (p = t + 512 i: W^(4 brev13(p) + 1) = W^(64 brev9(t)) * W^(4 brev4(i) + 1); wt = the first factor)
-HXD double r16_split_pair(const double* re, const double* im, const cplx16* park, unsigned t, unsigned i, tw16 wt,
-                          const tw16* wtab)
-{
-  const unsigned p = t + 512u * i;
-  const tw16 w = r16_cmul(wt, wtab[4u * r16_brev4(i) + 1u]);
-  return r16_pair_norm2(r16_last_lds(re, im, p), r16_last_mem(park, 8191u - p), w);
-}
-
 // N = 2^15 with both sub-transforms at once (embed_norm_r16x2_kernel): 1024 threads, half h = sub-transform h in its
 // own array; after the lane-exchange stage Z_h sits in registers at pos_C(t, k).  Z0 at p meets Z1 at 8191 - p, i.e.
 // what thread 511 - t of the OTHER half holds at 15 - k: half 0 forms the pairs of its k < 8, half 1 those of its

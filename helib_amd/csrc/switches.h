@@ -27,10 +27,8 @@ struct Switches {
   bool blue_old = false;         // HX_BLUE_OLD=1        Bluestein as the round-2 chain of passes instead of ntt_conv_kernel
   // canonical-embedding norm kernels
   bool norm_async = false;       // HX_NORM_ASYNC=1      norm kernels on a side stream
-  bool norm_split14 = false;     // HX_NORM_SPLIT14=1    N = 2^14: the split kernel instead of the radix-16 one
   bool norm_old = false;         // HX_NORM_OLD=1        N = 2^14 / 2^15: the LDS-pass kernels instead of the radix-16 ones
   bool norm_plain = false;       // HX_NORM_PLAIN=1      no split into sub-transforms above 2^14 points
-  bool norm_r16_split = false;   // HX_NORM_R16_SPLIT=1  N = 2^15: radix-16 kernel per half
   bool norm_memcpy = false;      // HX_NORM_MEMCPY=1     norm read-back by hipMemcpy instead of mapped host memory
   // host waits
   int wait_poll_us = 2000;       // HX_WAIT_POLL_US=n    how long a norm read-back is polled for before the thread sleeps in hipEventSynchronize
@@ -62,10 +60,8 @@ inline void refresh()
   s.no_mulrelin_fuse = on("HX_NO_MULRELIN_FUSE");
   s.blue_old = on("HX_BLUE_OLD");
   s.norm_async = on("HX_NORM_ASYNC");
-  s.norm_split14 = on("HX_NORM_SPLIT14");
   s.norm_old = on("HX_NORM_OLD");
   s.norm_plain = on("HX_NORM_PLAIN");
-  s.norm_r16_split = on("HX_NORM_R16_SPLIT");
   s.norm_memcpy = on("HX_NORM_MEMCPY");
   if (const char* e = std::getenv("HX_WAIT_POLL_US"))
     s.wait_poll_us = std::atoi(e);

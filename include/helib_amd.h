@@ -207,7 +207,7 @@ int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const int* dig_of
  *   HX_NO_TENSOR_MULTI, HX_NO_MULRELIN_FUSE   tensor product as a pass of its own in front of the several-primes
  *                                            mod-switch / inside hx_mul_relin
  *   HX_BLUE_OLD                               general m: the chain of passes instead of one convolution kernel
- *   HX_NORM_ASYNC, HX_NORM_SPLIT14, HX_NORM_OLD, HX_NORM_PLAIN, HX_NORM_R16_SPLIT, HX_NORM_MEMCPY
+ *   HX_NORM_ASYNC, HX_NORM_OLD, HX_NORM_PLAIN, HX_NORM_MEMCPY
  *                                            variants of the canonical-embedding norm kernels and their read-back
  *   HX_WAIT_POLL_US=n                         how long a norm read-back is polled for before the thread sleeps (2000)
  *   HX_ARENA_TRACE                            one line on stderr per hipMalloc of the slab arena

@@ -94,67 +94,6 @@ static double replay(const std::vector<double>& f, const std::vector<tw16>& wtab
   return std::sqrt(mx);
 }
 
-// N = 2^15 as two 8192-point sub-transforms (embed_norm_r16_split_kernel): sub-transform 1 first, parked before
-// its last stage; then sub-transform 0 and the pairing across the two
-static double replay_split(const std::vector<double>& f, const std::vector<tw16>& wtab)
-{
-  const unsigned T = R16_THREADS;
-  std::vector<double> re(R16_LDS_DOUBLES), im(R16_LDS_DOUBLES);
-  std::vector<cplx16> regs((size_t)T * 16), park(8192);
-  for (int pass = 0; pass < 2; pass++) {
-    const unsigned sub = pass == 0 ? 1u : 0u;
-    for (unsigned t = 0; t < T; t++) {
-      cplx16 v[16];
-      for (unsigned k = 0; k < 16; k++)
-        v[k] = r16_split_input(f.data(), wtab.data(), r16_pos_A(t, k), sub);
-      r16_pass<9, 15>(v, t, wtab.data());
-      for (unsigned k = 0; k < 16; k++) {
-        re[r16_pad(r16_pos_A(t, k))] = v[k].x;
-        im[r16_pad(r16_pos_A(t, k))] = v[k].y;
-      }
-    }
-    for (unsigned t = 0; t < T; t++) {
-      cplx16 v[16];
-      for (unsigned k = 0; k < 16; k++)
-        v[k] = {re[r16_pad(r16_pos_B(t, k))], im[r16_pad(r16_pos_B(t, k))]};
-      r16_pass<5, 15>(v, t & 31u, wtab.data());
-      for (unsigned k = 0; k < 16; k++)
-        regs[(size_t)t * 16 + k] = v[k];
-    }
-    for (unsigned t = 0; t < T; t++)
-      for (unsigned k = 0; k < 16; k++) {
-        re[r16_pad(r16_pos_B(t, k))] = regs[(size_t)t * 16 + k].x;
-        im[r16_pad(r16_pos_B(t, k))] = regs[(size_t)t * 16 + k].y;
-      }
-    for (unsigned t = 0; t < T; t++) {
-      cplx16 v[16];
-      for (unsigned k = 0; k < 16; k++)
-        v[k] = {re[r16_pad(r16_pos_C(t, k))], im[r16_pad(r16_pos_C(t, k))]};
-      r16_pass<1, 15>(v, t & 1u, wtab.data());
-      for (unsigned k = 0; k < 16; k++)
-        regs[(size_t)t * 16 + k] = v[k];
-    }
-    for (unsigned t = 0; t < T; t++)
-      for (unsigned k = 0; k < 16; k++) {
-        if (pass == 0)
-          park[r16_pos_C(t, k)] = regs[(size_t)t * 16 + k];          // straight from the registers
-        else {
-          re[r16_pad(r16_pos_C(t, k))] = regs[(size_t)t * 16 + k].x;
-          im[r16_pad(r16_pos_C(t, k))] = regs[(size_t)t * 16 + k].y;
-        }
-      }
-  }
-  double mx = 0;
-  for (unsigned t = 0; t < T; t++) {
-    const tw16 wt = wtab[64u * r16_brev9(t)];
-    for (unsigned i = 0; i < 16; i++) {
-      const double n2 = r16_split_pair(re.data(), im.data(), park.data(), t, i, wt, wtab.data());
-      mx = n2 > mx ? n2 : mx;
-    }
-  }
-  return std::sqrt(mx);
-}
-
 // N = 2^15, both sub-transforms at once (embed_norm_r16x2_kernel): half h of the 1024 threads = sub-transform h
 static double replay_x2(const std::vector<double>& f, const std::vector<tw16>& wtab)
 {
@@ -317,12 +256,7 @@ int main()
     std::vector<double> f(N2, 0.0);
     for (int t = 0; t < 60; t++)
       f[(size_t)((s = s * 6364136223846793005ull + 1442695040888963407ull) >> 40) % N2] = rnd() * 1000.0;
-    double want = scan(f), got = replay_split(f, w2);
-    if (!(std::fabs(got - want) <= 1e-9 * want)) {
-      printf("norm_replay FAILED (N = 2^15, sparse): got %.17g want %.17g\n", got, want);
-      return 1;
-    }
-    got = replay_x2(f, w2);
+    double want = scan(f), got = replay_x2(f, w2);
     if (!(std::fabs(got - want) <= 1e-9 * want)) {
       printf("norm_replay FAILED (N = 2^15 x2, sparse): got %.17g want %.17g\n", got, want);
       return 1;
@@ -330,11 +264,6 @@ int main()
     for (auto& v : f)
       v = rnd();
     want = scan(f);
-    got = replay_split(f, w2);
-    if (!(std::fabs(got - want) <= 1e-9 * want)) {
-      printf("norm_replay FAILED (N = 2^15, dense): got %.17g want %.17g\n", got, want);
-      return 1;
-    }
     got = replay_x2(f, w2);
     if (!(std::fabs(got - want) <= 1e-9 * want)) {
       printf("norm_replay FAILED (N = 2^15 x2, dense): got %.17g want %.17g\n", got, want);
