@@ -329,3 +329,82 @@ def test_approximate_barrett_of_the_fused_kernels_restated():
             edge = [0, 1, q - 1, q, q + 1, 8 * q * q - 1, (q - 1) * (q - 1), 2 * (q - 1) * (q - 1), 7 * (q - 1) * (q - 1) + q - 1]
             for S in edge + [rnd.randrange(8 * q * q) for _ in range(4000)]:
                 assert red(S, q) == S % q
+
+
+def test_unreduced_words_of_the_rns_kernels_restated():
+    """The round-4 "lazy" hand-overs between kernels (helib_amd/csrc/rns_kernels.h), restated with python integers --
+    every value the device code leaves unreduced stays inside the 64-bit word and inside the bound its reader is
+    declared with, and is congruent to what the reduced form would have been:
+      * red128_q8_lazy: S - qh q in [0,6q) for S < 8 q^2 (break_digits_fast_kernel<., true>, the tensor fold of
+        keyswitch_kernel, ExtArgs::lazy_out);
+      * red128_any_lazy: shoup4(H, 2^64 mod q) + norm_any(Lo) in [0,5q) for any S < 2^127;
+      * mul_shoup with an unreduced operand (any 64-bit x): x c - floor(x c' / 2^64) q in [0,2q), so ONE conditional
+        subtraction gives x c mod q -- the key switch scales [0,6q) products with it and rebuilds its own digit from
+        own + q - x (own in [0,6q), x in [0,q));
+      * the plaintext-space correction on a lazy word: r + corr and r + q - corr stay below 7q (LOAD_BOUND 8);
+      * the in-place fix-up of the later digits' rows: u + 8q - v for u in [0,q), v in [0,6q) is positive and below
+        2^64, and shoup4 of it lands in [0,4q)."""
+    import random
+    rnd = random.Random(11)
+    M64 = (1 << 64) - 1
+
+    def red_q8_lazy(S, q):
+        k = q.bit_length()
+        mu63 = (1 << (63 + k)) // q
+        xt = S >> (k - 1)
+        xl, xh = xt & 0xffffffff, xt >> 32
+        ml, mh = mu63 & 0xffffffff, mu63 >> 32
+        qh = (xh * mh + ((xh * ml) >> 32) + ((xl * mh) >> 32)) & M64
+        return (S - qh * q) & M64
+
+    def shoup4(y, w, q):                       # ntt_core.h: approximate high product, result in [0,4q)
+        wp = (w << 64) // q
+        yl, yh = y & 0xffffffff, y >> 32
+        pl, ph = wp & 0xffffffff, wp >> 32
+        h = yh * ph + ((yh * pl) >> 32) + ((yl * ph) >> 32)
+        return (y * w - h * q) & M64
+
+    def norm_any(x, q):                        # any 64-bit x -> [0,q), q > 2^32
+        mu32 = (1 << 64) // q
+        assert mu32 < (1 << 32)
+        e = (x * mu32) >> 64
+        r = x - e * q
+        assert 0 <= r < 2 * q
+        return r - q if r >= q else r
+
+    def mul_shoup_raw(x, c, q):
+        cp = (c << 64) // q
+        return x * c - ((x * cp) >> 64) * q
+
+    for bits, m in ((60, 32768), (59, 65536), (56, 32768), (45, 16384), (36, 16384)):
+        g = O.PrimeGen(bits, m)
+        for _ in range(3):
+            q = g.next()
+            r64 = (1 << 64) % q
+            for _ in range(1500):
+                S = rnd.choice([rnd.randrange(8 * q * q), 8 * q * q - 1, 7 * (q - 1) ** 2 + q - 1, 0, q])
+                r = red_q8_lazy(S, q)
+                assert r < 6 * q and r % q == S % q
+                # the same word scaled by a Shoup constant without reducing it first
+                c = rnd.randrange(1, q)
+                for x in (r, 6 * q - 1, M64, rnd.randrange(1 << 64)):
+                    t = mul_shoup_raw(x, c, q)
+                    assert 0 <= t < 2 * q and t % q == x * c % q
+                # own + q - x inside mul_shoup; the plaintext-space correction on a lazy word
+                xx, corr = rnd.randrange(q), rnd.randrange(q)
+                assert 0 < r + q - xx < 7 * q <= M64
+                assert (r + corr) < 7 * q and (r + q - corr) < 7 * q + 1
+                assert (r + q - corr) % q == (S - corr) % q
+                # later digits' rows: u + 8q - v, then shoup4 with P^-1
+                u = rnd.randrange(q)
+                y = u + (q << 3) - r
+                assert 0 < y <= M64
+                t4 = shoup4(y, c, q)
+                assert t4 < 4 * q and t4 % q == (u - S) * c % q
+            for _ in range(1500):
+                S = rnd.choice([rnd.randrange(1 << 127), (1 << 127) - 1, rnd.randrange(1 << 70), 0])
+                H, Lo = S >> 64, S & M64
+                h4 = shoup4(H, r64, q)
+                assert h4 < 4 * q
+                r = h4 + norm_any(Lo, q)
+                assert r < 5 * q and r % q == S % q
