@@ -1161,7 +1161,7 @@ __device__ __forceinline__ void rns_extend_fast_one(const ExtPlanDev& P, const E
     // r in [0,6q).  A.lazy_out (uniform): the reader takes any bound up to 8, so the three conditional subtractions
     // -- 12 of the ~100 instructions of a target -- are left out and the plaintext-space correction adds without
     // reducing ([0,7q))
-    const bool lazy_out = A.lazy_out != 0;
+    const bool lazy_out = A.lazy_out != 0 && A.nu == 0;   // (an in-place update below needs the canonical word)
     if (!lazy_out) {
       r = csub(r, q << 2);
       r = csub(r, q << 1);
