@@ -408,3 +408,45 @@ def test_unreduced_words_of_the_rns_kernels_restated():
                 assert h4 < 4 * q
                 r = h4 + norm_any(Lo, q)
                 assert r < 5 * q and r % q == S % q
+
+
+def test_one_word_form_of_the_mod_down_correction_restated():
+    """moddown_S_of (helib_amd/csrc/ntt_kernels.hip) for a plaintext space below 2^32: S = [x > (qd-1)/2] +
+    balanced((delta mod p) qd^-1 mod p) with red64 (one high product and one conditional subtraction) on x, and on the
+    ONE-WORD product r * (qd^-1 mod p) < 2^64 instead of the 128-bit Barrett -- restated with python integers against
+    the definition (src/DoubleCRT.cpp:1098-1099, :1485-1508) for odd, even and prime-power p, x over the whole range of
+    a 60-bit dropped prime."""
+    import random
+    rnd = random.Random(3)
+    M64 = (1 << 64) - 1
+
+    def red64(x, q):
+        mu64 = (1 << 64) // q
+        r = x - ((x * mu64) >> 64) * q
+        assert 0 <= r < 2 * q
+        return r - q if r >= q else r
+    g = O.PrimeGen(60, 32768)
+    for p in (2, 4, 257, 65537, 1 << 16, 3 ** 20, (1 << 32) - 5, 1 << 31):
+        qd = g.next()
+        half, qd_mod_p, qdinv = (qd - 1) // 2, qd % p, pow(qd % p, -1, p) if p > 1 and (qd % p) and __import__("math").gcd(qd % p, p) == 1 else None
+        if qdinv is None:
+            continue
+        for x in [0, 1, half, half + 1, qd - 1] + [rnd.randrange(qd) for _ in range(3000)]:
+            neg = x > half
+            S = 1 if neg else 0
+            r = red64(x, p)
+            assert r == x % p
+            if neg:
+                r = (r - qd_mod_p) % p
+            prod = r * qdinv
+            assert prod <= M64
+            dm = red64(prod, p)
+            assert dm == prod % p
+            sub_p = dm > p // 2 or (p % 2 == 0 and dm == p // 2 and neg)
+            S += dm - p if sub_p else dm
+            # the definition: delta = x - [neg] qd, then the multiple of qd that makes it divisible by p, balanced
+            delta = x - qd if neg else x
+            dmod = delta % p * qdinv % p
+            if dmod > p // 2 or (p % 2 == 0 and dmod == p // 2 and delta < 0):
+                dmod -= p
+            assert S == (1 if neg else 0) + dmod and (x - qd * S) % p == 0
