@@ -4,6 +4,8 @@
 # OUT = directory name under gpurun_out/.  Stages:
 #   tests            the GPU parity suite (pytest -m gpu), through the C ABI
 #   tests:EXPR       the same with -k EXPR
+#   tests_fast       the suite without its oracle-heavy cases (the bits = 6400 and m = 32003 chains, whose CPU side takes
+#                    minutes: a -k expression that happens to include them cost 8 GPU-minutes once); ~1.5 min
 #   smoke            __graft_entry__.smoke()
 #   bench            the driver's command, full line  -> bench_full.json
 #   bench_ckks       config 4 (--workload ckks65536)   -> bench_ckks.json
@@ -62,6 +64,8 @@ for st in "$@"; do
   case "$st" in
     tests)
       timeout 1500 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $out/pytest_gpu.log ;;
+    tests_fast)
+      timeout 900 python -m pytest tests -m gpu -q -x -k "not reference_benchmark_chain_size and not 32003 and not 5800 and not 6400" > $out/pytest_fast.log 2>&1; echo "pytest fast rc=$?"; tail -3 $out/pytest_fast.log ;;
     tests:*)
       timeout 1200 python -m pytest tests -m gpu -q -x -k "${st#tests:}" > $out/pytest_k.log 2>&1; echo "pytest -k rc=$?"; tail -4 $out/pytest_k.log ;;
     smoke)
