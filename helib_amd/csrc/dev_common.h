@@ -18,7 +18,7 @@ struct PrimeDev {
   uint64_t mu;     // floor(2^(2k) / q), k = bitlen(q)   (Barrett, 128-bit products)
   uint64_t mu64;   // floor(2^64 / q)                     (Barrett, 64-bit values)
   uint32_t k;      // bitlen(q)
-  uint32_t pad;
+  uint32_t proth;  // 1: q = 1 (mod 2^32) and the row tables below hold 8-byte Proth-form entries (ntt_core.h, ArProth)
   uint64_t mu63;   // floor(2^(63+k) / q)                 (red128_q8: 128-bit sums below 8 q^2)
   // power-of-two NTT tables (ntt_core.h layout) as offsets, in TW units, into the
   // context's single twiddle arena: the arena base is a kernel ARGUMENT so the
@@ -55,6 +55,8 @@ struct ModDownPrep {
   uint32_t ptxt_k, has_up;
   TW upS, upN;         // fused mod-up (the dropped row times F = prod(added primes)): the last
                        // inverse stage's twiddles with F folded in, F*S0*N^-1 and F*N^-1
+                       // (.wp = the companion word of the dropped prime's arithmetic: Shoup's quotient, or the
+                       // Proth form w 2^64 mod qd when PrimeDev::proth -- tw_companion() in engine.hip)
   uint64_t qd;
   uint64_t poly_stride;  // words between the x blocks of consecutive polys (0: batch*N, the
                          // single-prime layout [poly][batch][N]; the several-primes path keeps

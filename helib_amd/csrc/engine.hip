@@ -127,7 +127,14 @@ struct PrimeHost {
   uint64_t q, root, rinv;
   uint64_t last_s = 0, last_n = 0;  // inverse table slots 0 / 31: S0*N^-1 and N^-1
   uint64_t tw_fwd_off = 0, tw_inv_off = 0;  // into hx_ctx::d_tw (TW units)
+  bool proth = false;  // row tables in Proth form (8-byte entries w 2^64 mod q): PrimeDev::proth
 };
+// the second word of a twiddle constant that a row kernel substitutes for a table entry (ModDownPrep::upS / upN):
+// Shoup's quotient, or -- for a prime whose rows run the Proth-form butterflies -- w 2^64 mod q
+static inline uint64_t tw_companion(const PrimeHost& ph, uint64_t w)
+{
+  return ph.proth ? hx::tw_mont_form(w, ph.q) : hxh::shoup(w, ph.q);
+}
 
 struct ExtPlan {
   ExtPlanDev dev;
@@ -731,10 +738,22 @@ static int upload_tw(hx_ctx* c, PrimeHost& ph)
   CHK(tw_reserve(c, 2 * (size_t)G::TW_TOTAL));
   ph.tw_fwd_off = c->tw_used;
   ph.tw_inv_off = c->tw_used + G::TW_TOTAL;
-  HIPCHK(hipMemcpy(c->d_tw + ph.tw_fwd_off, f.data(), sizeof(TW) * G::TW_TOTAL,
-                   hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->d_tw + ph.tw_inv_off, i.data(), sizeof(TW) * G::TW_TOTAL,
-                   hipMemcpyHostToDevice));
+  // q = 1 (mod 2^32) -- every prime PrimeGenerator makes for these rings down to ~45 bits: the rows run the
+  // Proth-form butterflies (ntt_core.h, ArProth) on 8-byte entries w 2^64 mod q at the same table positions
+  // (each table keeps its slot of TW_TOTAL 16-byte units and fills half of it; offsets stay in TW units)
+  ph.proth = hx::is_proth32(ph.q) && !hxs::current().no_proth;
+  if (ph.proth) {
+    std::vector<hx::TWM> fm(G::TW_TOTAL), im(G::TW_TOTAL);
+    hx::tw_tables_to_mont(f.data(), G::TW_TOTAL, ph.q, fm.data());
+    hx::tw_tables_to_mont(i.data(), G::TW_TOTAL, ph.q, im.data());
+    HIPCHK(hipMemcpy(c->d_tw + ph.tw_fwd_off, fm.data(), sizeof(hx::TWM) * G::TW_TOTAL, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_tw + ph.tw_inv_off, im.data(), sizeof(hx::TWM) * G::TW_TOTAL, hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(hipMemcpy(c->d_tw + ph.tw_fwd_off, f.data(), sizeof(TW) * G::TW_TOTAL,
+                     hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_tw + ph.tw_inv_off, i.data(), sizeof(TW) * G::TW_TOTAL,
+                     hipMemcpyHostToDevice));
+  }
   c->tw_used += 2 * (size_t)G::TW_TOTAL;
   ph.last_s = i[0].w;
   ph.last_n = i[31].w;
@@ -1531,6 +1550,7 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
   pd.mu63 = (uint64_t)((((hxh::u128)1) << (63 + pd.k)) / q);
   pd.tw_fwd_off = ph.tw_fwd_off;
   pd.tw_inv_off = ph.tw_inv_off;
+  pd.proth = ph.proth ? 1u : 0u;
   int idx = (int)c->primes.size();
   HIPCHK(hipMemcpy(c->d_primes + idx, &pd, sizeof pd, hipMemcpyHostToDevice));
   c->primes.push_back(ph);
@@ -3459,9 +3479,9 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
         for (int i = 0; i < nadd; i++)
           F = hxh::mulmod(F, c->primes[add_idx[i]].q % qd, qd);
         M.up[2 * j].w = hxh::mulmod(F, c->primes[dprime].last_s, qd);
-        M.up[2 * j].wp = hxh::shoup(M.up[2 * j].w, qd);
+        M.up[2 * j].wp = tw_companion(c->primes[dprime], M.up[2 * j].w);
         M.up[2 * j + 1].w = hxh::mulmod(F, c->primes[dprime].last_n, qd);
-        M.up[2 * j + 1].wp = hxh::shoup(M.up[2 * j + 1].w, qd);
+        M.up[2 * j + 1].wp = tw_companion(c->primes[dprime], M.up[2 * j + 1].w);
       }
     }
     hipError_t e = tsrc ? hx::launch_moddown_prep_multi_tensor_pow2(c->logn, *tsrc, M, nj, batch, P, c->d_primes, c->d_tw,
@@ -3715,9 +3735,9 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
         F = hxh::mulmod(F, c->primes[add_idx[i]].q % qd, qd);
       P.has_up = 1;
       P.upS.w = hxh::mulmod(F, c->primes[dprime].last_s, qd);
-      P.upS.wp = hxh::shoup(P.upS.w, qd);
+      P.upS.wp = tw_companion(c->primes[dprime], P.upS.w);
       P.upN.w = hxh::mulmod(F, c->primes[dprime].last_n, qd);
-      P.upN.wp = hxh::shoup(P.upN.w, qd);
+      P.upN.wp = tw_companion(c->primes[dprime], P.upN.w);
     }
     // per-row constants (cached per (dropped prime, kept rows and their output slots))
     std::vector<uint64_t> key;
@@ -4751,6 +4771,16 @@ extern "C" int hx_relinearize_norms(const hx_poly* t0, const hx_poly* t1, const 
 // HEXL-shim compatibility layer (src/intelExt.h:20-59): host pointers,
 // synchronous, one context per (n, q) cached under a mutex like the HEXL NTT
 // cache (src/intelExt.cpp:46-73).
+//
+// Order and root are HEXL's, because the reference's call sites rely on them:
+// intel::FFTFwd = hexl::NTT(n, q).ComputeForward (src/intelExt.cpp:76-84)
+// delivers out[i] = f(psi^(2*brev(i)+1)) -- BIT-REVERSED evaluation order --
+// and Cmodulus::FFT_aux applies BitReverseCopy to it afterwards
+// (src/CModulus.cpp:385, :421-426); Cmodulus::iFFT bit-reverses the row before
+// intel::FFTRev1 (:510-514), which therefore consumes the same order.  psi is
+// the root the NTT object picks for itself: MinimalPrimitiveRoot(2n, q).
+// The engine's rows are in natural order (j <-> psi^(2j+1)), so the shim
+// permutes on the host -- the call is a PCIe round trip anyway.
 // ------------------------------------------------------------------
 namespace {
 struct ShimEntry {
@@ -4771,7 +4801,9 @@ int shim_get(long n, long q, ShimEntry** out)
     ShimEntry e;
     CHK(hx_ctx_create(&e.ctx, 0, (uint64_t)(2 * n)));
     int idx;
-    CHK(hx_ctx_add_prime(e.ctx, (uint64_t)q, 0, &idx));
+    // (0 when 2n does not divide q-1: hx_ctx_add_prime then reports it)
+    const uint64_t root = hxh::hexl_minimal_primitive_root((uint64_t)q, (uint64_t)(2 * n));
+    CHK(hx_ctx_add_prime(e.ctx, (uint64_t)q, root, &idx));
     CHK(hx_poly_create(e.ctx, 1, &idx, 1, &e.a));
     CHK(hx_poly_create(e.ctx, 1, &idx, 1, &e.b));
     it = g_shim.emplace(key, e).first;
@@ -4802,13 +4834,41 @@ int shim_binary(long* r, const long* a, const long* b, long n, long q, F op)
 }
 }  // namespace
 
+// dst[brev(i)] = src[i] over log2(n) bits (an involution: the same call maps either order to the other)
+static void shim_bit_reverse_copy(uint64_t* dst, const uint64_t* src, long n)
+{
+  int bits = 0;
+  while ((1L << bits) < n)
+    bits++;
+  for (long i = 0; i < n; i++)
+    dst[hx::brev_bits((unsigned)i, bits)] = src[i];
+}
 extern "C" int hx_intel_FFTFwd(long* out, const long* in, long n, long q)
 {
-  return shim_unary(out, in, n, q, [](ShimEntry* e) { return hx_ntt_forward(e->a); });
+  if (!out || !in)
+    return fail(HX_ERR_INVALID, "null pointer");
+  std::lock_guard<std::mutex> lk(g_shim_mu);
+  ShimEntry* e;
+  CHK(shim_get(n, q, &e));
+  CHK(hx_poly_upload(e->a, (const uint64_t*)in));
+  CHK(hx_ntt_forward(e->a));
+  std::vector<uint64_t> nat((size_t)n);
+  CHK(hx_poly_download(e->a, nat.data()));
+  shim_bit_reverse_copy((uint64_t*)out, nat.data(), n);  // natural -> HEXL's bit-reversed output order
+  return HX_OK;
 }
 extern "C" int hx_intel_FFTRev1(long* out, const long* in, long n, long q)
 {
-  return shim_unary(out, in, n, q, [](ShimEntry* e) { return hx_ntt_inverse(e->a); });
+  if (!out || !in)
+    return fail(HX_ERR_INVALID, "null pointer");
+  std::lock_guard<std::mutex> lk(g_shim_mu);
+  ShimEntry* e;
+  CHK(shim_get(n, q, &e));
+  std::vector<uint64_t> nat((size_t)n);
+  shim_bit_reverse_copy(nat.data(), (const uint64_t*)in, n);  // HEXL's bit-reversed input order -> natural
+  CHK(hx_poly_upload(e->a, nat.data()));
+  CHK(hx_ntt_inverse(e->a));
+  return hx_poly_download(e->a, (uint64_t*)out);
 }
 extern "C" int hx_intel_EltwiseAddMod(long* r, const long* a, const long* b, long n, long q)
 {

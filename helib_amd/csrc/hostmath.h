@@ -140,6 +140,25 @@ inline uint64_t find_prim_root(uint64_t q, uint64_t e)
   return root;
 }
 
+// The root Intel HEXL's NTT(degree, q) object picks for itself (HEXL 1.2.1, hexl/number-theory:
+// MinimalPrimitiveRoot(2*degree, q)): the SMALLEST primitive e-th root of unity mod q, e a power of
+// two.  HEXL starts from a random primitive root and walks its odd powers keeping the minimum; the
+// minimum does not depend on the start, so any primitive e-th root serves as one.
+inline uint64_t hexl_minimal_primitive_root(uint64_t q, uint64_t e)
+{
+  uint64_t g = find_prim_root(q, e);
+  if (g == 0)
+    return 0;
+  const uint64_t g2 = mulmod(g, g, q);
+  uint64_t cur = g, best = g;
+  for (uint64_t i = 0; i < e / 2; i++) {  // the e/2 odd powers = every primitive e-th root
+    if (cur < best)
+      best = cur;
+    cur = mulmod(cur, g2, q);
+  }
+  return best;
+}
+
 // ---- minimal unsigned big integer (little-endian 64-bit limbs) ----
 struct BigU {
   std::vector<uint64_t> d;

@@ -89,6 +89,10 @@ struct QC {
   uint64_t nq;  // 2^64 - q
   uint64_t q4, q8;
   uint32_t mu32;  // floor(2^64 / q) when that fits 32 bits (q > 2^32), else 0
+  // Proth-form rows only (q = qh 2^32 + 1, see ArProth below; dead code elsewhere)
+  uint32_t qh;    // q >> 32
+  uint64_t c1;    // (1 + qh)(2^32 + 1): the two carry constants of the word-wise reduction
+  uint64_t q2;    // 2q
 };
 // mu64 = floor(2^64 / q) (PrimeDev::mu64 on the device)
 HXD QC make_qc(uint64_t q, uint64_t mu64)
@@ -99,8 +103,14 @@ HXD QC make_qc(uint64_t q, uint64_t mu64)
   c.q4 = q << 2;
   c.q8 = q << 3;
   c.mu32 = (mu64 >> 32) ? 0u : (uint32_t)mu64;
+  c.qh = (uint32_t)(q >> 32);
+  c.c1 = ((uint64_t)(c.qh + 1u) << 32) + (c.qh + 1u);
+  c.q2 = q << 1;
   return c;
 }
+// q = t 2^s + 1 with s >= 32 (every prime src/PrimeGenerator.h:66-118 makes for the rings and sizes of
+// the benchmark chains: cand = ((t*m) << k) + 1): the rows the Proth-form butterflies below serve
+HXD bool is_proth32(uint64_t q) { return (uint32_t)q == 1u && (q >> 32) != 0 && (q >> 60) == 0; }
 // floor(2^64/q) = floor((2^64-1)/q) for odd q > 1
 HXD QC make_qc(uint64_t q) { return make_qc(q, ~(uint64_t)0 / q); }
 
@@ -186,6 +196,57 @@ HXD uint64_t shoup4_acc(uint64_t y, TW t, uint64_t nq, uint64_t x)
 #endif
 }
 HXD uint64_t shoup4(uint64_t y, TW t, uint64_t nq) { return shoup4_acc(y, t, nq, 0); }
+
+// ---- Proth-form Montgomery product (round 5) -----------------------------------------------------
+// Every prime of a HElib chain is q = t 2^s + 1 (src/PrimeGenerator.h:66-118), and for the rings and
+// prime sizes of the benchmark chains s >= 32: the low word of q is 1.  Then q^-1 = 1 (mod 2^32) and a
+// word-wise Montgomery reduction needs NO multiplication for its quotient digit: with W = w 2^64 mod q
+// and T = y W, taking n = ~lo32(T) (so that n + 1 = -T mod 2^32, and the low word of T + (n+1) q is
+// 2^32 exactly: the carry out of it is the CONSTANT 1, no data-dependent borrow)
+//      (T + (n+1) q) / 2^32  =  (T >> 32) + 1 + (n+1) qh,        qh = q >> 32,
+// twice.  Six 32x32 multiply-adds in all (four for T, one n*qh per word) against the seven + two
+// v_mul_hi_u32 of shoup4_acc, no quotient estimate, and an 8-byte table entry instead of 16.
+//   a = yl wl                                   n0 = ~lo32(a)
+//   G = yl wh + n0 qh + hi32(a) + yh wl + c1    n1 = ~lo32(G)       c1 = (1+qh)(2^32+1): both carry constants
+//   D = yh wh + n1 qh + hi32(G) + x
+// D = x + R with R = (y W + M q) / 2^64, M = (n0+1) + (n1+1) 2^32 <= 2^64 + 2^32:  R = y w (mod q) and
+//   0 < R < q (1 + y W / (q 2^64) + 2^-32) <= q (1 + By/16 + 2^-32)   for y < By q, q < 2^60, W < q.
+// No 64-bit sum may wrap: G < 2^64 needs yh wl < 2^64 - 3 2^60 - 2^34, i.e. y < 13 2^60 - 2^34 -- the
+// multiplied operand must stay below 12.9375 q (207/16; bounds of the Proth butterflies are tracked in
+// sixteenths of q), and D needs x + R < 2^64.  The two 32-bit high words enter their 64-bit sums as
+// multiply-adds by 1 (mad_x1): no (value, 0) register pair to build.  Exact for every y below the limit,
+// checked against 128-bit arithmetic in tests/test_host_logic.py and replayed in tests/cpp/ntt_replay.cpp.
+typedef uint64_t TWM;  // W = w 2^64 mod q
+HXD uint64_t mont_acc(uint64_t y, TWM W, const QC& c, uint64_t x)
+{
+  const uint32_t yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
+  const uint32_t wl = (uint32_t)W, wh = (uint32_t)(W >> 32);
+  uint64_t a = (uint64_t)yl * wl;
+  HX_KEEP64(a);
+  const uint32_t n0 = ~(uint32_t)a;
+  uint64_t G = (uint64_t)yl * wh + c.c1;
+  G += (uint64_t)n0 * c.qh;
+  HX_KEEP64(G);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_MONT_PLAINADD)
+  G = mad_x1((uint32_t)(a >> 32), G);
+#else
+  G += (uint32_t)(a >> 32);
+#endif
+  G += (uint64_t)yh * wl;
+  HX_KEEP64(G);
+  const uint32_t n1 = ~(uint32_t)G;
+  uint64_t D = (uint64_t)yh * wh + x;
+  HX_KEEP64(D);
+  D += (uint64_t)n1 * c.qh;
+  HX_KEEP64(D);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_MONT_PLAINADD)
+  D = mad_x1((uint32_t)(G >> 32), D);
+#else
+  D += (uint32_t)(G >> 32);
+#endif
+  return D;
+}
+HXD uint64_t mont_mul(uint64_t y, TWM W, const QC& c) { return mont_acc(y, W, c, 0); }
 // x in [0, 2m) -> [0, m)
 HXD uint64_t csub(uint64_t x, uint64_t m)
 {
@@ -371,6 +432,130 @@ HXD void gs_bfly4_last(uint64_t& X, uint64_t& Y, TW tNinv, TW tS0Ninv, const QC&
   Y = shoup4(x + c.q8 - y, tS0Ninv, c.nq);
 }
 
+// ---- Proth-form butterflies (mont_acc above).  Bounds in SIXTEENTHS of q. ----
+// forward:  X' = x + R,  Y' = x + 2q - R = (2x + 2q) - X'  (0 < R < 2q; the offset must be a multiple of q).
+// Both outputs are below (Bx + 2) q; the multiplied operand must be below 207/16 q and x + 2q below 16q, so
+// BOTH arms are taken below 8q first (one conditional subtraction each) in the stages where the running bound
+// has passed 207: three of the fourteen stages at N = 2^14 for canonical input -- the same number of
+// conditional subtractions as the Shoup butterfly (six stages, one arm).
+constexpr int P16_YMAX = 207;  // multiplied operand < 12.9375 q  (mont_acc: no 64-bit sum wraps)
+constexpr int p16_corr(int b) { return b > P16_YMAX ? 128 : b; }
+constexpr int p16_k(int) { return 32; }
+constexpr int p16_fwd_in(int bin16, int sp)  // bound of the values entering stage sp of a pass
+{
+  int b = bin16;
+  for (int s = 0; s < sp; s++)
+    b = p16_corr(b) + p16_k(b);
+  return b;
+}
+#if defined(HX_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+#define HX_BOUND16(x, B16, q)                                                            \
+  do {                                                                                   \
+    if ((unsigned __int128)(x) * 16 >= (unsigned __int128)(B16) * (q)) {                 \
+      std::fprintf(stderr, "bound violated at %s:%d (B16=%d)\n", __FILE__, __LINE__, (int)(B16)); \
+      std::abort();                                                                      \
+    }                                                                                    \
+  } while (0)
+#else
+#define HX_BOUND16(x, B16, q) ((void)0)
+#endif
+template <int B16>  // common bound of x and y on entry
+HXD void ct_bfly_p(uint64_t& X, uint64_t& Y, TWM W, const QC& c)
+{
+  static_assert(B16 >= 1 && B16 <= 256, "bound");
+  uint64_t x = X, y = Y;
+  HX_BOUND16(x, B16, c.q);
+  HX_BOUND16(y, B16, c.q);
+  if constexpr (B16 > P16_YMAX) {
+    x = csub(x, c.q8);
+    y = csub(y, c.q8);
+  }
+  static_assert(p16_corr(B16) + p16_k(B16) <= 256, "x + K must stay below 16q");
+  uint64_t xn = mont_acc(y, W, c, x);
+  HX_KEEP64(xn);
+  X = xn;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (2x + 2q as ONE v_lshl_add_u64: written out, because the compiler knows q2 = q << 1 and prefers (x + q) << 1)
+  uint64_t x2;
+  asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(x2) : "v"(x), "s"(c.q2));
+#else
+  uint64_t x2 = (x << 1) + c.q2;
+#endif
+  Y = x2 - xn;
+}
+// inverse:  X' = x + y,  Y' = (x + 4q - y) W  in (0, 2q).  Every value entering a butterfly is below 4q, so
+// the multiplied operand is below 8q (R < 1.5q + ...: bound 2); the sum is taken back below 4q when its
+// operands' common bound has passed 2 -- the same places as the Shoup butterfly's, at half its bounds.
+constexpr int inv_bound_after_p(int bin, int ex, int e)
+{
+  if (ex < 0)
+    return bin;
+  if ((e >> ex) & 1)
+    return 2;
+  const int b = 2 * inv_bound_after_p(bin, ex - 1, e);
+  return b > 4 ? 4 : b;
+}
+template <int BPREV>
+HXD void gs_bfly_p(uint64_t& X, uint64_t& Y, TWM W, const QC& c)
+{
+  static_assert(BPREV >= 1 && BPREV <= 4, "bound");
+  const uint64_t x = X, y = Y;
+  HX_BOUND(x, BPREV, c.q);
+  HX_BOUND(y, BPREV, c.q);
+  uint64_t s = x + y;
+  if constexpr (2 * BPREV > 4)
+    s = csub(s, c.q4);
+  X = s;
+  Y = mont_mul(x + c.q4 - y, W, c);
+}
+template <int BPREV>
+HXD void gs_bfly_p_last(uint64_t& X, uint64_t& Y, TWM wNinv, TWM wS0Ninv, const QC& c)
+{
+  static_assert(BPREV >= 1 && BPREV <= 4, "bound");
+  const uint64_t x = X, y = Y;
+  HX_BOUND(x, BPREV, c.q);
+  HX_BOUND(y, BPREV, c.q);
+  X = mont_mul(x + y, wNinv, c);
+  Y = mont_mul(x + c.q4 - y, wS0Ninv, c);
+}
+
+// ---- the two arithmetics of the row kernels as policies of run_pass / RowNTT ----
+// U = bound units per q (1: whole q; 16: sixteenths).  fwd_out/inv_after: the compile-time schedules.
+struct ArShoup {
+  using Tw = TW;
+  static constexpr int U = 1;
+  static constexpr int FWD_LOAD_MAX = 12;   // largest IO::LOAD_BOUND (units of q) a forward pass accepts
+  static constexpr int INV_OUT = 4;         // bound (units of q) of what the inverse transform hands its store
+  static constexpr int fwd_in(int bin, int sp) { return fwd_bound_in(bin, sp); }
+  static constexpr int inv_after(int bin, int ex, int e) { return inv_bound_after(bin, ex, e); }
+  static constexpr int inv_cap() { return 8; }
+  template <int BIN, int SP>
+  static HXD void ct(uint64_t& X, uint64_t& Y, Tw t, const QC& c)
+  {
+    HX_BOUND(X, fwd_bound_in(BIN, SP), c.q);
+    ct_bfly4<fwd_corr(BIN, SP)>(X, Y, t, c);
+  }
+  template <int BPREV>
+  static HXD void gs(uint64_t& X, uint64_t& Y, Tw t, const QC& c) { gs_bfly4<BPREV>(X, Y, t, c); }
+  template <int BPREV>
+  static HXD void gs_last(uint64_t& X, uint64_t& Y, Tw tN, Tw tS, const QC& c) { gs_bfly4_last<BPREV>(X, Y, tN, tS, c); }
+};
+struct ArProth {
+  using Tw = TWM;
+  static constexpr int U = 16;
+  static constexpr int FWD_LOAD_MAX = 12;
+  static constexpr int INV_OUT = 2;
+  static constexpr int fwd_in(int bin16, int sp) { return p16_fwd_in(bin16, sp); }
+  static constexpr int inv_after(int bin, int ex, int e) { return inv_bound_after_p(bin, ex, e); }
+  static constexpr int inv_cap() { return 4; }
+  template <int BIN, int SP>
+  static HXD void ct(uint64_t& X, uint64_t& Y, Tw t, const QC& c) { ct_bfly_p<p16_fwd_in(BIN, SP)>(X, Y, t, c); }
+  template <int BPREV>
+  static HXD void gs(uint64_t& X, uint64_t& Y, Tw t, const QC& c) { gs_bfly_p<BPREV>(X, Y, t, c); }
+  template <int BPREV>
+  static HXD void gs_last(uint64_t& X, uint64_t& Y, Tw tN, Tw tS, const QC& c) { gs_bfly_p_last<BPREV>(X, Y, tN, tS, c); }
+};
+
 // ---------------------------------------------------------------------
 // register passes.  v[32] is the thread's coefficient file.
 //
@@ -434,6 +619,13 @@ HXD TW tw_vec(const TW* tw, unsigned base, unsigned lane, unsigned off, uint32_t
   HX_LAUNDER(off, dep);
   return tw[base + lane + off];
 }
+// the Proth-form tables: same positions, 8-byte entries W = w 2^64 mod q
+HXD TWM tw_uni(const TWM* tw, unsigned i) { return tw[i]; }
+HXD TWM tw_vec(const TWM* tw, unsigned base, unsigned lane, unsigned off, uint32_t dep)
+{
+  HX_LAUNDER(off, dep);
+  return tw[base + lane + off];
+}
 
 template <int S, bool INV>
 HXD constexpr int grp_sp(int i)
@@ -474,12 +666,12 @@ HXD void static_for(F&& f)
 // pass A runs 2^S-2 groups here and finishes stage 0 with gs_bfly4_last.
 // BIN: bound (units of q) of every value entering the pass; pass_bound_out gives the bound
 // of every value leaving it (forward: exact schedule above; inverse: 8, or less for short runs).
-template <int S, bool INV, int NGRUN, int BIN>
+template <class AR, int S, bool INV, int NGRUN, int BIN>
 constexpr int pass_bound_out()
 {
   if constexpr (!INV) {
     static_assert(NGRUN == (1 << S) - 1, "forward passes run all stages");
-    return fwd_bound_in(BIN, S);
+    return AR::fwd_in(BIN, S);
   } else {
     // executed stages: ex = 0 .. nst-1 (whole stages only)
     int nst = 0, g = NGRUN;
@@ -489,18 +681,18 @@ constexpr int pass_bound_out()
     }
     int b = 0;
     for (int e = 0; e < (1 << S); e++) {
-      const int be = inv_bound_after(BIN, nst - 1, e);
+      const int be = AR::inv_after(BIN, nst - 1, e);
       b = be > b ? be : b;
     }
     return b;
   }
 }
-template <int S, bool INV, int REP, int NGRUN, int BIN, class Fetch>
+template <class AR, int S, bool INV, int REP, int NGRUN, int BIN, class Fetch>
 HXD void run_pass(uint64_t (&v)[32], const QC& c, Fetch fetch)
 {
   constexpr int PF = INV ? HX_TW_PF_INV : HX_TW_PF;
   constexpr int TOT = REP * NGRUN;
-  TW tq[PF];
+  typename AR::Tw tq[PF];
   static_for<0, (PF < TOT ? PF : TOT)>([&](auto I) {
     constexpr int i = decltype(I)::value;
     constexpr int rep = i / NGRUN, sp = grp_sp<S, INV>(i % NGRUN), k = grp_k<S, INV>(i % NGRUN);
@@ -512,16 +704,15 @@ HXD void run_pass(uint64_t (&v)[32], const QC& c, Fetch fetch)
     constexpr int sp = grp_sp<S, INV>(ii), k = grp_k<S, INV>(ii);
     constexpr int half = (1 << (S - 1)) >> sp;
     constexpr int base = rep * (1 << S) + k * 2 * half;
-    const TW t = tq[i % PF];
+    const typename AR::Tw t = tq[i % PF];
     static_for<0, half>([&](auto J) {
       constexpr int j = decltype(J)::value;
       if constexpr (INV) {
         constexpr int ex = S - 1 - sp;  // executed-stage index, pair distance 2^ex
-        constexpr int bprev = inv_bound_after(BIN, ex - 1, k * 2 * half + j);
-        gs_bfly4<bprev>(v[base + j], v[base + j + half], t, c);
+        constexpr int bprev = AR::inv_after(BIN, ex - 1, k * 2 * half + j);
+        AR::template gs<bprev>(v[base + j], v[base + j + half], t, c);
       } else {
-        HX_BOUND(v[base + j], fwd_bound_in(BIN, sp), c.q);
-        ct_bfly4<fwd_corr(BIN, sp)>(v[base + j], v[base + j + half], t, c);
+        AR::template ct<BIN, sp>(v[base + j], v[base + j + half], t, c);
       }
     });
     if constexpr (i + PF < TOT) {
@@ -539,6 +730,12 @@ HXD void run_pass(uint64_t (&v)[32], const QC& c, Fetch fetch)
         HX_SCHED_FENCE();
     }
   });
+}
+// (the pre-round-5 spelling: the Shoup arithmetic)
+template <int S, bool INV, int REP, int NGRUN, int BIN, class Fetch>
+HXD void run_pass(uint64_t (&v)[32], const QC& c, Fetch fetch)
+{
+  run_pass<ArShoup, S, INV, REP, NGRUN, BIN>(v, c, fetch);
 }
 
 // ---------------------------------------------------------------------
@@ -703,6 +900,7 @@ struct PtrIO {
   HXD uint64_t load(unsigned tid, unsigned c) const { return in[tid + c]; }
   HXD void store(unsigned tid, unsigned c, uint64_t v) const { out[tid + c] = v; }
   HXD TW last_tw(TW def, int) const { return def; }
+  HXD TWM last_tw(TWM def, int) const { return def; }
 };
 
 HXD uint64_t norm4(uint64_t x, uint64_t q, uint64_t q2)  // [0,4q) -> [0,q)
@@ -753,15 +951,15 @@ HXD uint64_t norm_from(uint64_t x, const QC& c)
 // for its own tid; the CPU replay in tests/ runs every tid through phase k
 // before moving to phase k+1.  v = 32 coefficients, nl = 32 staged low words.
 // ---------------------------------------------------------------------
-template <int LOGN>
+template <int LOGN, class AR = ArShoup>
 struct RowNTT {
   using G = Geo<LOGN>;
   static constexpr int NPHASE = 8;
 
   // bounds (units of q) of the register file between the inverse passes (inputs canonical)
-  static constexpr int IC_ = pass_bound_out<G::LC, true, G::GC - 1, 1>();  // after inverse pass C
-  static constexpr int IB = pass_bound_out<5, true, 31, IC_>();
-  static_assert(IC_ <= 8 && IB <= 8, "lazy bounds");
+  static constexpr int IC_ = pass_bound_out<AR, G::LC, true, G::GC - 1, 1>();  // after inverse pass C
+  static constexpr int IB = pass_bound_out<AR, 5, true, 31, IC_>();
+  static_assert(IC_ <= AR::inv_cap() && IB <= AR::inv_cap(), "lazy bounds");
 
   // -------- forward: coefficients (natural) -> evaluations (natural) -----
   template <int PH, class IO, class TWS>
@@ -770,10 +968,13 @@ struct RowNTT {
   {
     // bounds between the forward passes; the IO functor states the bound of what it loads
     // (IO::LOAD_BOUND, 1 = canonical) and whether its store takes the lazy value (IO::LAZY_STORE)
-    constexpr int FA = pass_bound_out<5, false, 31, IO::LOAD_BOUND>();
-    constexpr int FB = pass_bound_out<5, false, 31, FA>();
-    constexpr int FC = pass_bound_out<G::LC, false, G::GC - 1, FB>();
-    static_assert(IO::LOAD_BOUND <= 12 && FA <= 16 && FB <= 16 && FC <= 16, "lazy bounds");
+    // (in the policy's units, AR::U per q; the IO functors state and take bounds in whole q)
+    constexpr int L0 = IO::LOAD_BOUND * AR::U;
+    constexpr int FA = pass_bound_out<AR, 5, false, 31, L0>();
+    constexpr int FB = pass_bound_out<AR, 5, false, 31, FA>();
+    constexpr int FCU = pass_bound_out<AR, G::LC, false, G::GC - 1, FB>();
+    constexpr int FC = (FCU + AR::U - 1) / AR::U;
+    static_assert(IO::LOAD_BOUND <= AR::FWD_LOAD_MAX && FA <= 16 * AR::U && FB <= 16 * AR::U && FCU <= 16 * AR::U, "lazy bounds");
     if constexpr (PH == 0) {
       if constexpr (IO::PIPELINED) {
         io.template load_all<LOGN>(tid, v, c);  // (software-pipelined element loads, see ModDownIO)
@@ -784,7 +985,7 @@ struct RowNTT {
           HX_IO_FENCE(e);
         }
       }
-      run_pass<5, false, 1, 31, IO::LOAD_BOUND>(v, c, [&](int, int sp, int k, uint32_t) {
+      run_pass<AR, 5, false, 1, 31, L0>(v, c, [&](int, int sp, int k, uint32_t) {
         return tw_uni(tw, (unsigned)((1 << sp) - 1 + k));  // uniform: scalar loads
       });
 #pragma unroll
@@ -802,7 +1003,7 @@ struct RowNTT {
 #pragma unroll
       for (int e = 0; e < 32; e++)
         v[e] = ((uint64_t)nh[e] << 32) | nl[e];
-      run_pass<5, false, 1, 31, FA>(v, c, [&](int, int sp, int k, uint32_t dep) {
+      run_pass<AR, 5, false, 1, 31, FA>(v, c, [&](int, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWB, tid & 31u, ((1u << sp) - 1u + (unsigned)k) * 32u, dep);
       });
     } else if constexpr (PH == 4) {
@@ -825,7 +1026,7 @@ struct RowNTT {
       typename IO::StorePrefetch pre;
       if constexpr (IO::LAZY_STORE)
         io.template store_prefetch<LOGN>(tid, pre);
-      run_pass<G::LC, false, G::NGC, G::GC - 1, FB>(v, c, [&](int gi, int sp, int k, uint32_t dep) {
+      run_pass<AR, G::LC, false, G::NGC, G::GC - 1, FB>(v, c, [&](int gi, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWC, tid, ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi), dep);
       });
       // (uniform branches are taken once here / inside store_all, never per element: a branch
@@ -862,7 +1063,7 @@ struct RowNTT {
         for (int i = 0; i < 32; i++)
           v[i] = io.load(tid, eval_const<LOGN>(i));
       }
-      run_pass<G::LC, true, G::NGC, G::GC - 1, 1>(v, c, [&](int gi, int sp, int k, uint32_t dep) {
+      run_pass<AR, G::LC, true, G::NGC, G::GC - 1, 1>(v, c, [&](int gi, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWC, tid, ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi), dep);
       });
 #pragma unroll
@@ -880,7 +1081,7 @@ struct RowNTT {
 #pragma unroll
       for (int e = 0; e < 32; e++)
         v[e] = ((uint64_t)nh[e] << 32) | nl[e];
-      run_pass<5, true, 1, 31, IC_>(v, c, [&](int, int sp, int k, uint32_t dep) {
+      run_pass<AR, 5, true, 1, 31, IC_>(v, c, [&](int, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWB, tid & 31u, ((1u << sp) - 1u + (unsigned)k) * 32u, dep);
       });
     } else if constexpr (PH == 4) {
@@ -901,22 +1102,22 @@ struct RowNTT {
         v[e] = ((uint64_t)nh[e] << 32) | nl[e];
       // stages 4..1 (30 groups), then stage 0 with N^-1 folded in:
       // slot 0 = S0*N^-1, slot 31 = N^-1
-      run_pass<5, true, 1, 30, IB>(v, c, [&](int, int sp, int k, uint32_t) {
+      run_pass<AR, 5, true, 1, 30, IB>(v, c, [&](int, int sp, int k, uint32_t) {
         return tw_uni(tw, (unsigned)((1 << sp) - 1 + k));
       });
       {
         // (the IO functor may substitute its own pair: a constant factor folded into N^-1)
-        const TW tS = io.last_tw(tw_uni(tw, 0), 0), tN = io.last_tw(tw_uni(tw, 31), 1);
+        const typename AR::Tw tS = io.last_tw(tw_uni(tw, 0), 0), tN = io.last_tw(tw_uni(tw, 31), 1);
         static_for<0, 16>([&](auto J) {
           constexpr int j = decltype(J)::value;
-          gs_bfly4_last<inv_bound_after(IB, 3, j)>(v[j], v[j + 16], tN, tS, c);
+          AR::template gs_last<AR::inv_after(IB, 3, j)>(v[j], v[j + 16], tN, tS, c);
           if constexpr (HX_BF_FENCE > 0 && j % 2 == 1)
             HX_SCHED_FENCE();
         });
       }
 #pragma unroll
       for (int e = 0; e < 32; e++) {
-        io.store(tid, coef_const<LOGN>(e), norm_from<4>(v[e], c));
+        io.store(tid, coef_const<LOGN>(e), norm_from<AR::INV_OUT>(v[e], c));
         HX_IO_FENCE(e);
       }
     }
@@ -994,6 +1195,13 @@ inline void build_tw_tables(uint64_t q, uint64_t psi, uint64_t psi_inv, uint64_t
                             MulMod mulmod, TW* fwd, TW* inv)
 {
   build_tw_tables_sub<LOGN>(q, psi, psi_inv, n_inv, mulmod, 0, 0u, fwd, inv);
+}
+// The same table in Proth form: entry i = w_i 2^64 mod q (8 bytes), positions unchanged.
+inline TWM tw_mont_form(uint64_t w, uint64_t q) { return (uint64_t)((((unsigned __int128)w) << 64) % q); }
+inline void tw_tables_to_mont(const TW* t, int n, uint64_t q, TWM* out)
+{
+  for (int i = 0; i < n; i++)
+    out[i] = tw_mont_form(t[i].w, q);
 }
 
 // ---------------------------------------------------------------------

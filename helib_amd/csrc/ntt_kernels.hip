@@ -97,6 +97,7 @@ struct BufIOT {
     hx_buffer_store_v2(d, rout, (int)(tid * 8u), (int)(c * 8u), HX_NT);
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
+  __device__ __forceinline__ TWM last_tw(TWM def, int) const { return def; }
 };
 
 // inverse transform of the dropped row: stores x = F * iNTT(row) in [0,qd)  (F = 1 without the
@@ -131,6 +132,10 @@ struct InvPrepIO {
   __device__ __forceinline__ TW last_tw(TW def, int which) const
   {
     return has_up ? (which ? upN : upS) : def;
+  }
+  __device__ __forceinline__ TWM last_tw(TWM def, int which) const   // (a Proth-form dropped prime: .wp holds w 2^64 mod qd)
+  {
+    return has_up ? (which ? upN.wp : upS.wp) : def;
   }
 };
 
@@ -311,6 +316,7 @@ struct ModDownIO {
     hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), HX_NT);
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
+  __device__ __forceinline__ TWM last_tw(TWM def, int) const { return def; }
 };
 
 // Tile shape of the mod-down apply kernel (see there): g row groups of rg rows, 8/g XCDs per group
@@ -331,16 +337,10 @@ __host__ __device__ inline MdTile md_tile(unsigned nkeep, unsigned npb)
   return t;
 }
 
-template <int LOGN, bool INV, class IO>
-__device__ __forceinline__ void ntt_body(uint32_t* lds, const IO& io, const TW* tw_ptr, const PrimeDev* pd)
+template <int LOGN, bool INV, class AR, class IO>
+__device__ __forceinline__ void ntt_body_ar(uint32_t* lds, const IO& io, const typename AR::Tw* tw, const QC& q)
 {
-  const QC q = make_qc(pd->q, pd->mu64);  // (the phase functions' last argument)
-  using R = RowNTT<LOGN>;
-#ifdef HX_TW_BUF  // experiment: measured register allocation gets worse with it (scratch 3-5x)
-  const BufTw tw(tw_ptr);
-#else
-  const TW* tw = tw_ptr;
-#endif
+  using R = RowNTT<LOGN, AR>;
   uint64_t v[32];
   uint32_t nl[32];
   const unsigned w = wave_index();
@@ -377,6 +377,22 @@ __device__ __forceinline__ void ntt_body(uint32_t* lds, const IO& io, const TW* 
     __syncthreads();
     R::template inv<7>(fresh_tid(w), v, nl, lds, io, tw, q);
   }
+}
+// One row, in the arithmetic of its prime: rows of Proth-form primes (q = 1 mod 2^32: every prime of the
+// benchmark chains, PrimeDev::proth) run the word-wise Montgomery butterflies on 8-byte table entries, any other
+// prime the Shoup butterflies on {w, w'} pairs.  The branch is uniform over the workgroup (one row, one prime)
+// and taken once; a launch may mix the two kinds of row.
+template <int LOGN, bool INV, class IO>
+__device__ __forceinline__ void ntt_body(uint32_t* lds, const IO& io, const TW* tw_ptr, const PrimeDev* pd)
+{
+  const QC q = make_qc(pd->q, pd->mu64);  // (the phase functions' last argument)
+#ifndef HX_NO_PROTH
+  if (pd->proth) {
+    ntt_body_ar<LOGN, INV, ArProth>(lds, io, reinterpret_cast<const TWM*>(tw_ptr), q);
+    return;
+  }
+#endif
+  ntt_body_ar<LOGN, INV, ArShoup>(lds, io, tw_ptr, q);
 }
 
 // scaleDownToSet, one dropped prime: inverse transform of its row with the delta preparation
@@ -532,6 +548,7 @@ struct InvPrepTensorIO {
     hx_buffer_store_v2(d, rx, (int)(tid * 8u), (int)(c * 8u), 0);
   }
   __device__ __forceinline__ TW last_tw(TW def, int which) const { return has_up ? (which ? upN : upS) : def; }
+  __device__ __forceinline__ TWM last_tw(TWM def, int which) const { return has_up ? (which ? upN.wp : upS.wp) : def; }
 };
 template <int LOGN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
@@ -724,6 +741,7 @@ struct ModDownTensorIO {
     hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), HX_NT);
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
+  __device__ __forceinline__ TWM last_tw(TWM def, int) const { return def; }
 };
 template <int LOGN, bool PLAIN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
@@ -815,6 +833,7 @@ struct MulLoadIO {
     hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), HX_NT);
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
+  __device__ __forceinline__ TWM last_tw(TWM def, int) const { return def; }
 };
 template <int LOGN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))

@@ -23,6 +23,8 @@ struct Switches {
   // fused ciphertext-level paths
   bool no_tensor_multi = false;  // HX_NO_TENSOR_MULTI=1 tensor product + several-primes mod-switch as two steps
   bool no_mulrelin_fuse = false; // HX_NO_MULRELIN_FUSE=1 hx_mul_relin with a tensor pass
+  // row transforms (ntt_core.h)
+  bool no_proth = false;         // HX_NO_PROTH=1        Shoup butterflies on every row (Proth-form primes included)
   // general m
   bool blue_old = false;         // HX_BLUE_OLD=1        Bluestein as the round-2 chain of passes instead of ntt_conv_kernel
   // canonical-embedding norm kernels
@@ -58,6 +60,7 @@ inline void refresh()
   s.no_wide_extend = on("HX_NO_WIDE_EXTEND");
   s.no_tensor_multi = on("HX_NO_TENSOR_MULTI");
   s.no_mulrelin_fuse = on("HX_NO_MULRELIN_FUSE");
+  s.no_proth = on("HX_NO_PROTH");
   s.blue_old = on("HX_BLUE_OLD");
   s.norm_async = on("HX_NORM_ASYNC");
   s.norm_old = on("HX_NORM_OLD");

@@ -206,6 +206,8 @@ int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const int* dig_of
  *   HX_NO_FAST_BREAK, HX_NO_FAST_EXTEND, HX_NO_WIDE_EXTEND   generic breakIntoDigits / basis-extension kernels
  *   HX_NO_TENSOR_MULTI, HX_NO_MULRELIN_FUSE   tensor product as a pass of its own in front of the several-primes
  *                                            mod-switch / inside hx_mul_relin
+ *   HX_NO_PROTH                               row transforms: Shoup butterflies on every row (by default rows of primes
+ *                                            q = 1 mod 2^32 -- every chain prime of the benchmarks -- run the Proth-form ones)
  *   HX_BLUE_OLD                               general m: the chain of passes instead of one convolution kernel
  *   HX_NORM_ASYNC, HX_NORM_OLD, HX_NORM_PLAIN, HX_NORM_MEMCPY
  *                                            variants of the canonical-embedding norm kernels and their read-back
@@ -298,10 +300,19 @@ int hx_relinearize_norms(const hx_poly* t0, const hx_poly* t1, const hx_poly* t2
 
 /* ---------------- HEXL-shim compatibility layer ---------------- */
 /* Same signatures and semantics as namespace intel (src/intelExt.h:20-59):
- * host pointers, synchronous, in-place allowed, negacyclic NTT whose root is
- * the shim's own choice (as with HEXL): here
- * FindPrimRootT(q, 2n).  One PCIe round trip per call -- provided for link
- * compatibility of a USE_INTEL_HEXL-style build, not for speed. */
+ * host pointers, synchronous, in-place allowed.  FFTFwd / FFTRev1 are what
+ * hexl::NTT(n, q).ComputeForward / ComputeInverse are (src/intelExt.cpp:76-98):
+ *   - the root is the NTT object's own, MinimalPrimitiveRoot(2n, q), the smallest
+ *     primitive 2n-th root of unity (no root crosses this seam);
+ *   - FFTFwd returns BIT-REVERSED evaluation order, out[i] = f(psi^(2*brev(i)+1)),
+ *     and FFTRev1 reads that order.  The reference's call sites depend on it:
+ *     Cmodulus::FFT_aux runs BitReverseCopy after intel::FFTFwd
+ *     (src/CModulus.cpp:385, :421-426) and Cmodulus::iFFT before intel::FFTRev1
+ *     (:510-514), which makes the stored row the natural one, y[j] = f(psi^(2j+1)),
+ *     that DoubleCRT::automorph (src/DoubleCRT.cpp:1160-1202) and the wire format
+ *     index.  (hx_ntt_forward / hx_ntt_inverse work on natural rows directly.)
+ * One PCIe round trip per call -- provided for link compatibility of a
+ * USE_INTEL_HEXL-style build, not for speed. */
 int hx_intel_FFTFwd(long* out, const long* in, long n, long q);
 int hx_intel_FFTRev1(long* out, const long* in, long n, long q);
 int hx_intel_EltwiseAddMod(long* r, const long* a, const long* b, long n, long q);

@@ -5,11 +5,15 @@
 // src/DoubleCRT.cpp:144-195, 329): with this header on the include path in place of src/intelExt.h --
 // and libhelib_amd.so on the link line in place of HEXL -- those call sites compile and link
 // unchanged.  Semantics are the shim's: host pointers, synchronous, void-returning (an engine error
-// becomes a std::runtime_error, where HEXL would abort), in place allowed, and -- as with HEXL, see
-// SURVEY.md fact 7 -- FFTFwd(n, q) carries no root: the 2n-th root is the shim's own choice
-// (FindPrimRootT(q, 2n)), so rows differ from an NTL build's.  One PCIe round trip per call: this is
-// the link-compatibility layer, not the fast path (that is include/helib_amd.hpp, whole DoubleCRT
-// objects resident on the device).
+// becomes a std::runtime_error, where HEXL would abort), in place allowed, and FFTFwd / FFTRev1 are HEXL's
+// transforms in HEXL's order under HEXL's root: FFTFwd(n, q) carries no root, the NTT
+// object picks MinimalPrimitiveRoot(2n, q); its output is in BIT-REVERSED evaluation order,
+// out[i] = f(psi^(2*brev(i)+1)), and FFTRev1 consumes that order -- which is why the reference runs
+// BitReverseCopy after the forward call (src/CModulus.cpp:421-426) and before the inverse one (:510).
+// With those two copies in place, as they are in the reference, rows are the natural ones that
+// DoubleCRT::automorph and the wire format index; they differ from an NTL build's rows by the root
+// only.  One PCIe round trip per call: this is the link-compatibility layer, not the fast path (that is
+// include/helib_amd.hpp, whole DoubleCRT objects resident on the device).
 #ifndef HELIB_AMD_INTEL_HPP
 #define HELIB_AMD_INTEL_HPP
 #include <stdexcept>

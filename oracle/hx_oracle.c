@@ -185,6 +185,95 @@ uint64_t ho_find_prim_root(uint64_t q, uint64_t e)
   return root;
 }
 
+/* ---- Intel HEXL (absent third-party dependency, >= 1.2.1): restated from its published
+ * reference implementation; see hx_oracle.h.  Plain loops, canonical residues throughout. */
+uint64_t ho_hexl_minimal_primitive_root(uint64_t q, uint64_t e)
+{
+  /* MinimalPrimitiveRoot(degree = e, modulus): start from any primitive e-th root, walk its odd
+   * powers (root * (root^2)^i, i < e/2 -- HEXL loops to `degree`, revisiting each once), keep the
+   * minimum */
+  uint64_t root = ho_find_prim_root(q, e);
+  if (!root)
+    return 0;
+  uint64_t sq = ho_mulmod(root, root, q), cur = root, best = root;
+  for (uint64_t i = 0; i < e; i++) {
+    if (cur < best)
+      best = cur;
+    cur = ho_mulmod(cur, sq, q);
+  }
+  return best;
+}
+static unsigned hexl_brev(unsigned x, int bits)
+{
+  unsigned r = 0;
+  for (int i = 0; i < bits; i++)
+    r |= ((x >> i) & 1u) << (bits - 1 - i);
+  return r;
+}
+/* RootOfUnityPowers: table[brev(i)] = psi^i (NTT::ComputeRootOfUnityPowers) */
+static uint64_t* hexl_root_powers(long n, uint64_t q, uint64_t psi)
+{
+  int bits = 0;
+  while ((1L << bits) < n)
+    bits++;
+  uint64_t* t = (uint64_t*)malloc((size_t)n * sizeof(uint64_t));
+  uint64_t cur = 1;
+  for (long i = 0; i < n; i++) {
+    t[hexl_brev((unsigned)i, bits)] = cur;
+    cur = ho_mulmod(cur, psi, q);
+  }
+  return t;
+}
+void ho_hexl_forward(uint64_t* out, const uint64_t* in, long n, uint64_t q)
+{
+  const uint64_t psi = ho_hexl_minimal_primitive_root(q, (uint64_t)(2 * n));
+  uint64_t* W = hexl_root_powers(n, q, psi);
+  if (out != in)
+    memcpy(out, in, (size_t)n * sizeof(uint64_t));
+  long t = n >> 1;
+  for (long m = 1; m < n; m <<= 1) {
+    long j1 = 0;
+    for (long i = 0; i < m; i++) {
+      const uint64_t w = W[m + i];
+      for (long j = j1; j < j1 + t; j++) {
+        const uint64_t x = out[j], wy = ho_mulmod(out[j + t], w, q);
+        out[j] = (x + wy) % q;
+        out[j + t] = (x + q - wy) % q;
+      }
+      j1 += 2 * t;
+    }
+    t >>= 1;
+  }
+  free(W);
+}
+void ho_hexl_inverse(uint64_t* out, const uint64_t* in, long n, uint64_t q)
+{
+  const uint64_t psi = ho_hexl_minimal_primitive_root(q, (uint64_t)(2 * n));
+  /* InvRootOfUnityPowers, consumed by the Gentleman-Sande network stage by stage: here indexed
+   * as the forward table of psi^-1 (same values the network needs at (m + i)) */
+  uint64_t* W = hexl_root_powers(n, q, ho_invmod(psi, q));
+  if (out != in)
+    memcpy(out, in, (size_t)n * sizeof(uint64_t));
+  long t = 1;
+  for (long m = n >> 1; m >= 1; m >>= 1) {
+    long j1 = 0;
+    for (long i = 0; i < m; i++) {
+      const uint64_t w = W[m + i];
+      for (long j = j1; j < j1 + t; j++) {
+        const uint64_t x = out[j], y = out[j + t];
+        out[j] = (x + y) % q;
+        out[j + t] = ho_mulmod((x + q - y) % q, w, q);
+      }
+      j1 += 2 * t;
+    }
+    t <<= 1;
+  }
+  const uint64_t ninv = ho_invmod((uint64_t)n % q, q);
+  for (long j = 0; j < n; j++)
+    out[j] = ho_mulmod(out[j], ninv, q);
+  free(W);
+}
+
 /* ------------------------------------------------------------------ */
 /* Z_m^* and Phi_m                                                       */
 /* ------------------------------------------------------------------ */

@@ -48,6 +48,20 @@ long ho_primegen_next(ho_primegen* g); /* 0 when it runs out of primes */
 /* ---- FindPrimRootT  (src/NumbTh.cpp:436-493) ---- */
 uint64_t ho_find_prim_root(uint64_t q, uint64_t e);
 
+/* ---- Intel HEXL's negacyclic NTT, as the intel:: seam calls it (src/intelExt.cpp:76-98) ----
+ * HEXL is a third-party dependency absent from /root/reference (HElib asks for >= 1.2.1,
+ * CMakeLists.txt:214); this restates its PUBLISHED reference algorithm (hexl/ntt/ntt-internal:
+ * ReferenceForwardTransformToBitReverse / ReferenceInverseTransformFromBitReverse, the radix-2
+ * Cooley-Tukey / Gentleman-Sande networks over RootOfUnityPowers in bit-reversed order) and its root
+ * rule (hexl/number-theory: MinimalPrimitiveRoot(2n, q) = the smallest primitive 2n-th root).  Parity is
+ * anchored on the reference's own call sites: forward output is consumed by BitReverseCopy
+ * (src/CModulus.cpp:385, :421-426), inverse input is produced by it (:510-514).
+ *   forward:  out[i] = sum_k in[k] * psi^(k * (2*brev(i)+1))      (bit-reversed evaluation order)
+ *   inverse:  its inverse, reading that order, returning natural coefficients (1/n included) */
+uint64_t ho_hexl_minimal_primitive_root(uint64_t q, uint64_t e);
+void ho_hexl_forward(uint64_t* out, const uint64_t* in, long n, uint64_t q);
+void ho_hexl_inverse(uint64_t* out, const uint64_t* in, long n, uint64_t q);
+
 /* ---- Z_m^* in increasing order (src/PAlgebra.cpp:532-538), returns phi(m) */
 long ho_zmstar(uint64_t m, uint32_t* rep_out, long cap);
 /* Phi_m(X) integer coefficients, out has phi(m)+1 entries */

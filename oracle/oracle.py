@@ -43,6 +43,10 @@ def lib():
         L.ho_is_prime.argtypes = [C.c_uint64]
         L.ho_find_prim_root.restype = C.c_uint64
         L.ho_find_prim_root.argtypes = [C.c_uint64, C.c_uint64]
+        L.ho_hexl_minimal_primitive_root.restype = C.c_uint64
+        L.ho_hexl_minimal_primitive_root.argtypes = [C.c_uint64, C.c_uint64]
+        for f in (L.ho_hexl_forward, L.ho_hexl_inverse):
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_uint64]
         L.ho_zmstar.restype = C.c_long
         L.ho_zmstar.argtypes = [C.c_uint64, C.c_void_p, C.c_long]
         L.ho_phimx.argtypes = [C.c_uint64, C.c_void_p]
@@ -180,6 +184,38 @@ def randomize_row(n, q, key, stream, prime_index, batch_element=0):
     out = np.zeros(n, dtype=np.uint64)
     nbuf = lib().ho_randomize_row(_p(out), n, q, _p(k), _p(nonce))
     return out, int(nbuf)
+
+
+def hexl_minimal_primitive_root(q, e):
+    """hexl::MinimalPrimitiveRoot(e, q): the root hexl::NTT(n, q) uses is this at e = 2n."""
+    return int(lib().ho_hexl_minimal_primitive_root(q, e))
+
+
+def hexl_forward(x, q):
+    """intel::FFTFwd = hexl::NTT(n, q).ComputeForward (src/intelExt.cpp:76-84): bit-reversed output."""
+    x = _u64(x)
+    y = np.zeros_like(x)
+    lib().ho_hexl_forward(_p(y), _p(x), len(x), q)
+    return y
+
+
+def hexl_inverse(y, q):
+    """intel::FFTRev1 = hexl::NTT(n, q).ComputeInverse (src/intelExt.cpp:87-98): bit-reversed input."""
+    y = _u64(y)
+    x = np.zeros_like(y)
+    lib().ho_hexl_inverse(_p(x), _p(y), len(y), q)
+    return x
+
+
+def bit_reverse_copy(a):
+    """BitReverseCopy (src/CModulus.cpp:284-353): B[rev(i)] = A[i]."""
+    a = np.asarray(a)
+    n = len(a)
+    bits = n.bit_length() - 1
+    rev = np.array([int(format(i, "0%db" % bits)[::-1], 2) if bits else 0 for i in range(n)])
+    out = np.empty_like(a)
+    out[rev] = a
+    return out
 
 
 class Cmod:

@@ -7,7 +7,9 @@
 //     coefficients are reduced; the DoubleCRT transform of the same polynomial gives the same row
 //   * toPoly: every BigInt coefficient reduces to the inverse-transformed row modulo each prime and lies in
 //     the centred range (CRT uniqueness then makes it THE value); positive form = centred form mod Q
-//   * intel::: FFTRev1(FFTFwd(x)) = x, element-wise results against plain arithmetic, both overloads
+//   * intel::: FFTRev1(FFTFwd(x)) = x; FFTFwd + BitReverseCopy = the natural row under HEXL's root, BitReverseCopy +
+//     FFTRev1 inverts it, automorph on such rows = rows of a(X^k) (the reference's call sites, src/CModulus.cpp:
+//     375-426, 493-553); element-wise results against plain arithmetic, both overloads
 //   usage: facade2_test m   (m a power of two or general)
 #include <cstdio>
 #include <cstdlib>
@@ -181,6 +183,70 @@ int main(int argc, char** argv)
       intel::FFTFwd(r1.data(), a.data(), nn, q);
       intel::FFTRev1(r2.data(), r1.data(), nn, q);
       REQUIRE(r2 == a);
+      // The call sites, not just the round trip.  Cmodulus::FFT_aux's HEXL branch (src/CModulus.cpp:375-385)
+      // is followed by BitReverseCopy (:421-426); Cmodulus::iFFT bit-reverses BEFORE intel::FFTRev1
+      // (:510-514): HEXL's forward transform delivers, and its inverse consumes, bit-reversed order.
+      // So FFTFwd + BitReverseCopy must be the NATURAL row y[j] = f(psi^(2j+1)) that DoubleCRT::automorph
+      // (src/DoubleCRT.cpp:1160-1202) indexes, under HEXL's root (the smallest primitive 2n-th root).
+      int bits = 0;
+      while ((1L << bits) < nn)
+        bits++;
+      auto brc = [&](const std::vector<long>& A) {   // B[rev(i)] = A[i]  (src/CModulus.cpp:284-299)
+        std::vector<long> Bv(A.size());
+        for (size_t i = 0; i < A.size(); i++) {
+          size_t r = 0;
+          for (int t = 0; t < bits; t++)
+            r |= ((i >> t) & 1u) << (bits - 1 - t);
+          Bv[r] = A[i];
+        }
+        return Bv;
+      };
+      uint64_t psi = root, cur = root;  // walk every primitive 2n-th root = the odd powers of any one
+      const uint64_t rsq = mulmod(root, root, (uint64_t)q);
+      for (long i = 0; i < nn; i++, cur = mulmod(cur, rsq, (uint64_t)q))
+        psi = cur < psi ? cur : psi;
+      const std::vector<long> nat = brc(r1);
+      Cmodulus hm((unsigned long)m, q, (long)psi);
+      std::vector<long> ynat;
+      hm.FFT(ynat, a);
+      REQUIRE(ynat == nat);                           // shim forward + BitReverseCopy = the engine's natural row
+      for (size_t c = 0; c < 8; c++) {                // ... which is f(psi^(2j+1)) by definition
+        const size_t j = (size_t)(next() % n);
+        const uint64_t pt = powmod(psi, 2 * j + 1, (uint64_t)q);
+        uint64_t acc = 0;
+        for (size_t i = n; i-- > 0;)
+          acc = (mulmod(acc, pt, (uint64_t)q) + (uint64_t)a[i]) % (uint64_t)q;
+        REQUIRE((uint64_t)nat[j] == acc);
+      }
+      std::vector<long> rev_in = brc(nat), back2(n);  // iFFT's order: BitReverseCopy, then FFTRev1
+      intel::FFTRev1(back2.data(), rev_in.data(), nn, q);
+      REQUIRE(back2 == a);
+      // automorph on rows that came through the shim path: X -> X^k on the coefficients (negacyclic), rows of
+      // both through FFTFwd + BitReverseCopy, against DoubleCRT::automorph of the first
+      {
+        const long k = 5 % (2 * nn) == 1 ? 3 : 5;
+        std::vector<long> ak(n, 0), rk(n);
+        for (long i = 0; i < nn; i++) {
+          const long e = (i * k) % (2 * nn);
+          if (e < nn)
+            ak[(size_t)e] = a[(size_t)i];
+          else
+            ak[(size_t)(e - nn)] = a[(size_t)i] ? q - a[(size_t)i] : 0;
+        }
+        intel::FFTFwd(rk.data(), ak.data(), nn, q);
+        const std::vector<long> natk = brc(rk);
+        Context hc((uint64_t)m);
+        IndexSet one{(int)hc.addPrime((uint64_t)q, psi)};
+        DoubleCRT dr(hc, one, 1);
+        std::vector<uint64_t> rowsv(n);
+        for (size_t j = 0; j < n; j++)
+          rowsv[j] = (uint64_t)nat[j];
+        dr.setRows(rowsv);
+        dr.automorph(k);
+        const std::vector<uint64_t> got = dr.getRows();
+        for (size_t j = 0; j < n; j++)
+          REQUIRE(got[j] == (uint64_t)natk[j]);
+      }
       AddFun add;
       SubFun sub2;
       MulFun mul;

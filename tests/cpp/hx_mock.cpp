@@ -688,25 +688,24 @@ int hx_ctx_graph_end(hx_ctx*, hx_graph**) { return fail(HX_ERR_UNSUPPORTED, "no 
 int hx_graph_launch(hx_graph*) { return fail(HX_ERR_UNSUPPORTED, "no graphs in the CPU mock"); }
 int hx_graph_destroy(hx_graph*) { return HX_OK; }
 
-// the HEXL-shim layer (src/intelExt.h:20-59) over the oracle's Cmodulus for m = 2n: the shim's own root
-// choice, FindPrimRootT(q, 2n), as the engine's hx_intel_* documents
+// the HEXL-shim layer (src/intelExt.h:20-59) over the oracle's restatement of HEXL's reference transform:
+// bit-reversed evaluation order and MinimalPrimitiveRoot(2n, q), what the reference's call sites assume
+// (src/CModulus.cpp:385 + :421-426, :510-514) and what the engine's hx_intel_* documents
 static int shim_ntt(long* out, const long* in, long n, long q, bool inverse)
 {
   if (n < 2 || (n & (n - 1)) || q < 3)
     return fail(HX_ERR_INVALID, "intel shim: n must be a power of two");
-  ho_cmod* c = ho_cmod_create(2 * (uint64_t)n, (uint64_t)q, 0);
-  if (!c)
+  if (!ho_hexl_minimal_primitive_root((uint64_t)q, 2 * (uint64_t)n))
     return fail(HX_ERR_INVALID, "intel shim: no 2n-th root of unity modulo q");
   std::vector<uint64_t> a((size_t)n), b((size_t)n);
   for (long i = 0; i < n; i++)
     a[(size_t)i] = (uint64_t)in[i];
   if (inverse)
-    ho_cmod_ifft(c, a.data(), b.data());
+    ho_hexl_inverse(b.data(), a.data(), n, (uint64_t)q);
   else
-    ho_cmod_fft(c, a.data(), b.data());
+    ho_hexl_forward(b.data(), a.data(), n, (uint64_t)q);
   for (long i = 0; i < n; i++)
     out[i] = (long)b[(size_t)i];
-  ho_cmod_destroy(c);
   return HX_OK;
 }
 int hx_intel_FFTFwd(long* out, const long* in, long n, long q) { return shim_ntt(out, in, n, q, false); }

@@ -22,17 +22,22 @@ static uint64_t pw(uint64_t a, uint64_t e, uint64_t q)
   return r;
 }
 
-template <int LOGN, int PH>
+// lazy-input forward rows (BufIOT<8> on the device): the bound the exact-RNS kernels hand over
+template <int LB>
+struct PtrIOLB : hx::PtrIO {
+  static constexpr int LOAD_BOUND = LB;
+};
+template <int LOGN, int PH, class AR, class IO>
 static void run_phase(bool inverse, std::vector<uint64_t>& V, std::vector<uint32_t>& NL,
                       std::vector<uint32_t>& lds, const uint64_t* in, uint64_t* out,
-                      const hx::TW* tw, uint64_t q)
+                      const typename AR::Tw* tw, uint64_t q)
 {
-  using R = hx::RowNTT<LOGN>;
+  using R = hx::RowNTT<LOGN, AR>;
   constexpr int T = hx::Geo<LOGN>::T;
   for (unsigned tid = 0; tid < (unsigned)T; tid++) {
     uint64_t(&v)[32] = *reinterpret_cast<uint64_t(*)[32]>(&V[tid * 32]);
     uint32_t(&nl)[32] = *reinterpret_cast<uint32_t(*)[32]>(&NL[tid * 32]);
-    hx::PtrIO io{in, out};
+    IO io{{in, out}};
     if (inverse)
       R::template inv<PH>(tid, v, nl, lds.data(), io, tw, hx::make_qc(q));
     else
@@ -40,7 +45,19 @@ static void run_phase(bool inverse, std::vector<uint64_t>& V, std::vector<uint32
   }
 }
 
-template <int LOGN>
+template <class AR>
+static std::vector<typename AR::Tw> table_of(const std::vector<hx::TW>& t, uint64_t q);
+template <>
+std::vector<hx::TW> table_of<hx::ArShoup>(const std::vector<hx::TW>& t, uint64_t) { return t; }
+template <>
+std::vector<hx::TWM> table_of<hx::ArProth>(const std::vector<hx::TW>& t, uint64_t q)
+{
+  std::vector<hx::TWM> o(t.size());
+  hx::tw_tables_to_mont(t.data(), (int)t.size(), q, o.data());
+  return o;
+}
+
+template <int LOGN, class AR, class IO = PtrIOLB<1>>
 static int replay(int inverse, uint64_t q, uint64_t psi, const uint64_t* in, uint64_t* out)
 {
   using G = hx::Geo<LOGN>;
@@ -48,19 +65,20 @@ static int replay(int inverse, uint64_t q, uint64_t psi, const uint64_t* in, uin
   uint64_t psi_inv = pw(psi, q - 2, q);
   uint64_t n_inv = pw((uint64_t)G::N % q, q - 2, q);
   hx::build_tw_tables<LOGN>(q, psi, psi_inv, n_inv, mm, f.data(), i.data());
+  const std::vector<typename AR::Tw> tab = table_of<AR>(inverse ? i : f, q);
   std::vector<uint64_t> V((size_t)G::T * 32);
   std::vector<uint32_t> NL((size_t)G::T * 32);
   std::vector<uint32_t> lds(G::LDS_WORDS, 0xdeadbeef);
   std::vector<uint64_t> inc(in, in + G::N);  // allow in == out
-  const hx::TW* tw = inverse ? i.data() : f.data();
-  run_phase<LOGN, 0>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGN, 1>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGN, 2>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGN, 3>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGN, 4>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGN, 5>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGN, 6>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGN, 7>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  const typename AR::Tw* tw = tab.data();
+  run_phase<LOGN, 0, AR, IO>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGN, 1, AR, IO>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGN, 2, AR, IO>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGN, 3, AR, IO>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGN, 4, AR, IO>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGN, 5, AR, IO>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGN, 6, AR, IO>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGN, 7, AR, IO>(inverse, V, NL, lds, inc.data(), out, tw, q);
   return 0;
 }
 
@@ -68,11 +86,39 @@ extern "C" int ntt_replay(int logn, int inverse, uint64_t q, uint64_t psi, const
                           uint64_t* out)
 {
   switch (logn) {
-    case 13: return replay<13>(inverse, q, psi, in, out);
-    case 14: return replay<14>(inverse, q, psi, in, out);
-    case 15: return replay<15>(inverse, q, psi, in, out);
+    case 13: return replay<13, hx::ArShoup>(inverse, q, psi, in, out);
+    case 14: return replay<14, hx::ArShoup>(inverse, q, psi, in, out);
+    case 15: return replay<15, hx::ArShoup>(inverse, q, psi, in, out);
   }
   return -1;
+}
+// the Proth-form arithmetic (q = 1 mod 2^32): -2 when q is not of that form.  lazy8 != 0: forward transform of
+// words in [0,8q) (the load bound of the rows the exact-RNS kernels leave unreduced)
+extern "C" int ntt_replay_proth(int logn, int inverse, int lazy8, uint64_t q, uint64_t psi, const uint64_t* in,
+                                uint64_t* out)
+{
+  if (!hx::is_proth32(q))
+    return -2;
+  if (lazy8 && !inverse)
+    switch (logn) {
+      case 13: return replay<13, hx::ArProth, PtrIOLB<8>>(0, q, psi, in, out);
+      case 14: return replay<14, hx::ArProth, PtrIOLB<8>>(0, q, psi, in, out);
+      case 15: return replay<15, hx::ArProth, PtrIOLB<8>>(0, q, psi, in, out);
+    }
+  switch (logn) {
+    case 13: return replay<13, hx::ArProth>(inverse, q, psi, in, out);
+    case 14: return replay<14, hx::ArProth>(inverse, q, psi, in, out);
+    case 15: return replay<15, hx::ArProth>(inverse, q, psi, in, out);
+  }
+  return -1;
+}
+// x + R of mont_acc for n (y, W, x) triples: the word-wise arithmetic the device runs, for the python-integer
+// restatement in tests/test_host_logic.py
+extern "C" void mont_acc_replay(uint64_t q, long n, const uint64_t* y, const uint64_t* W, const uint64_t* x, uint64_t* out)
+{
+  const hx::QC c = hx::make_qc(q);
+  for (long i = 0; i < n; i++)
+    out[i] = hx::mont_acc(y[i], W[i], c, x[i]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -90,14 +136,14 @@ static void sub_transform(bool inverse, const hx::TW* tw, uint64_t q, const uint
   std::vector<uint32_t> NL((size_t)G::T * 32);
   std::vector<uint32_t> lds(G::LDS_WORDS, 0);
   std::vector<uint64_t> inc(in, in + G::N);
-  run_phase<LOGQ, 0>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGQ, 1>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGQ, 2>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGQ, 3>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGQ, 4>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGQ, 5>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGQ, 6>(inverse, V, NL, lds, inc.data(), out, tw, q);
-  run_phase<LOGQ, 7>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 0, hx::ArShoup, PtrIOLB<1>>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 1, hx::ArShoup, PtrIOLB<1>>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 2, hx::ArShoup, PtrIOLB<1>>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 3, hx::ArShoup, PtrIOLB<1>>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 4, hx::ArShoup, PtrIOLB<1>>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 5, hx::ArShoup, PtrIOLB<1>>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 6, hx::ArShoup, PtrIOLB<1>>(inverse, V, NL, lds, inc.data(), out, tw, q);
+  run_phase<LOGQ, 7, hx::ArShoup, PtrIOLB<1>>(inverse, V, NL, lds, inc.data(), out, tw, q);
 }
 
 template <int LOGQ>

@@ -99,6 +99,62 @@ def test_ntt_edge_values(hx):
     assert not d.FFT().download().any()
 
 
+# ---------------------------------------------------------------- round 5: Proth-form rows
+@pytest.mark.parametrize("m", [16384, 32768, 65536])
+def test_proth_and_shoup_rows_in_one_launch_and_across_contexts(hx, m, monkeypatch):
+    """Rows of primes q = 1 (mod 2^32) run the Proth-form butterflies (word-wise Montgomery products on 8-byte table
+    entries, helib_amd/csrc/ntt_core.h: ArProth), rows of any other prime the Shoup butterflies; the choice is per
+    ROW.  One DoubleCRT over a 60-bit, a 31-bit (q < 2^32: never of the form), a 56-bit and a 45-bit prime is
+    transformed by one launch that mixes both kinds, forward, inverse, and through the fused single-prime
+    mod-switch (whose dropped row's last inverse stage carries the folded mod-up factor in the prime's own
+    arithmetic) -- every word against the oracle; then the same on a context created under HX_NO_PROTH=1
+    (all rows Shoup): identical words."""
+    qs = [O.PrimeGen(60, m).next(), O.PrimeGen(31, m).next(), O.PrimeGen(56, m).next(), O.PrimeGen(45, m).next(),
+          primes_for(m, 2, 60)[1]]
+    assert [q & 0xffffffff == 1 for q in qs] == [True, False, True, True, True]
+    outs = []
+    for no_proth in (False, True):
+        if no_proth:
+            monkeypatch.setenv("HX_NO_PROTH", "1")
+        else:
+            monkeypatch.delenv("HX_NO_PROTH", raising=False)
+        P = Pair(hx, m, qs)
+        idx = list(range(len(qs)))
+        x = P.rand(idx, 77, batch=3)
+        x[0, 0, :] = qs[0] - 1
+        x[2, 1, ::3] = 0
+        d = hx.DoubleCRT(P.g, idx, 3, x)
+        got = d.FFT().download()
+        for b in range(3):
+            assert np.array_equal(got[:, b], P.o.fft(idx, x[:, b]))
+        assert np.array_equal(d.iFFT().download(), x)
+        res = [got]
+        # fused mod-switch: add one prime's worth of scale (mod-up folded into the dropped row's last stage), drop one
+        for drop, keep_extra in ((0, True), (1, True), (2, False)):
+            ev = hx.DoubleCRT(P.g, idx[:4], 3, got[:4].copy())
+            keep = [i for i in idx[:4] if i != drop]
+            if keep_extra:
+                hx.bringToSetMulti([ev], [4], keep + [4], 65537)
+                up = np.stack([np.vstack([P.o.scale_by_primes(idx[:4], got[:4, b], [4]),
+                                          np.zeros((1, P.N), dtype=np.uint64)]) for b in range(3)], axis=1)
+                src_idx, want_keep = idx[:4] + [4], keep + [4]
+            else:
+                ev.scaleDownToSet(keep, 65537)
+                up, src_idx, want_keep = got[:4], idx[:4], keep
+            gi = ev.getIndexSet()
+            assert sorted(gi) == sorted(want_keep)
+            g2 = ev.download()
+            for b in range(3):
+                want = P.o.scale_down(src_idx, up[:, b], [drop], 65537)
+                for r, i in enumerate(gi):
+                    assert np.array_equal(g2[r, b], want[want_keep.index(i)]), (no_proth, drop, i)
+            res.append((gi, g2))
+        outs.append(res)
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for (ia, ga), (ib, gb) in zip(outs[0][1:], outs[1][1:]):
+        assert ia == ib and np.array_equal(ga, gb)
+
+
 # ---------------------------------------------------------------- config 2: add / mul
 def test_doublecrt_add_mul_m32768_L16(hx):
     m, L = 32768, 16
@@ -386,7 +442,11 @@ def test_CModulusFFT_like_TestHEXL(hx, phim, m):
 
 
 def test_intel_shim_like_TestHEXL_hexlInUse(hx):
-    # tests/TestHEXL.cpp:139-156: intel::FFTFwd then FFTRev1 on N=64, q=769 is the identity
+    # tests/TestHEXL.cpp:139-156: intel::FFTFwd then FFTRev1 on N=64, q=769 is the identity -- and, beyond the
+    # round trip, the ORDER the reference's call sites need: HEXL's ComputeForward delivers bit-reversed
+    # evaluations (Cmodulus::FFT_aux applies BitReverseCopy afterwards, src/CModulus.cpp:385, :421-426) and
+    # ComputeInverse consumes them (iFFT bit-reverses first, :510-514), under the NTT object's own root
+    # MinimalPrimitiveRoot(2n, q).  Checker: the oracle's restatement of HEXL's published reference transform.
     import ctypes as C
     L = hx.lib()
     N, q = 64, 769
@@ -394,10 +454,19 @@ def test_intel_shim_like_TestHEXL_hexlInUse(hx):
     out = np.zeros(N, dtype=np.int64)
     assert L.hx_intel_FFTFwd(out.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), N, q) == 0
     assert not np.array_equal(out, a)
-    cm = O.Cmod(2 * N, q)                       # same root rule: FindPrimRootT(q, 2n)
-    assert np.array_equal(out.astype(np.uint64), cm.fft(a.astype(np.uint64)))
+    assert np.array_equal(out.astype(np.uint64), O.hexl_forward(a.astype(np.uint64), q))
+    psi = O.hexl_minimal_primitive_root(q, 2 * N)
+    cm = O.Cmod(2 * N, q, psi)
+    # FFT_aux's shape: shim forward, then BitReverseCopy = the natural row y[j] = f(psi^(2j+1))
+    nat = O.bit_reverse_copy(out.astype(np.uint64))
+    assert np.array_equal(nat, cm.fft(a.astype(np.uint64)))
     back = np.zeros(N, dtype=np.int64)
     assert L.hx_intel_FFTRev1(back.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), N, q) == 0
+    assert np.array_equal(back, a)
+    # iFFT's shape: BitReverseCopy of the natural row, then shim inverse
+    rev = np.ascontiguousarray(O.bit_reverse_copy(nat)).astype(np.int64)
+    back[:] = 0
+    assert L.hx_intel_FFTRev1(back.ctypes.data_as(C.c_void_p), rev.ctypes.data_as(C.c_void_p), N, q) == 0
     assert np.array_equal(back, a)
     b = (np.arange(N, dtype=np.int64) * 13 + 5) % q
     r = np.zeros(N, dtype=np.int64)
@@ -414,6 +483,50 @@ def test_intel_shim_like_TestHEXL_hexlInUse(hx):
     assert np.array_equal(r, (a + 768) % q)
     assert L.hx_intel_EltwiseSubModScalar(p(r), p(a), 768, N, q) == 0
     assert np.array_equal(r, (a - 768) % q)
+
+
+@pytest.mark.parametrize("n,bits", [(64, 0), (16384, 60), (16384, 56), (32768, 60)])
+def test_intel_shim_at_the_reference_call_sites(hx, n, bits):
+    """The HEXL seam as src/CModulus.cpp:375-426 (FFT_aux) and :493-553 (iFFT) use it, on chain primes at the
+    benchmark ring sizes: (1) intel::FFTFwd equals the oracle's restatement of hexl::NTT::ComputeForward, every
+    word; (2) shim forward + BitReverseCopy equals hx_ntt_forward's natural row on a context that registers the
+    prime with the shim's root; (3) BitReverseCopy + intel::FFTRev1 recovers x; (4) DoubleCRT::automorph
+    (src/DoubleCRT.cpp:1160-1202, index j <-> 2j+1) applied to rows that came through the shim path gives the
+    shim-path rows of a(X^k) -- what breaks if the seam hands back natural order."""
+    import ctypes as C
+    L = hx.lib()
+    m = 2 * n
+    q = 769 if bits == 0 else primes_for(m, 1, bits)[0]
+    rng = np.random.default_rng(n + bits)
+    a = rng.integers(0, q, n, dtype=np.uint64)
+    a[:3] = [q - 1, 0, 1]
+    p = lambda v: v.ctypes.data_as(C.c_void_p)
+
+    def shim_fwd(x):
+        o = np.zeros(n, dtype=np.int64)
+        assert L.hx_intel_FFTFwd(p(o), p(np.ascontiguousarray(x).astype(np.int64)), n, q) == 0
+        return o.astype(np.uint64)
+
+    out = shim_fwd(a)
+    assert np.array_equal(out, O.hexl_forward(a, q))                       # (1)
+    psi = O.hexl_minimal_primitive_root(q, m)
+    g = hx.Context(m, 0)
+    g.add_prime(q, psi)
+    d = hx.DoubleCRT(g, [0], 1, a.reshape(1, 1, n))
+    nat = d.FFT().download().reshape(n)
+    assert np.array_equal(O.bit_reverse_copy(out), nat)                    # (2)
+    back = np.zeros(n, dtype=np.int64)
+    rev = np.ascontiguousarray(O.bit_reverse_copy(nat)).astype(np.int64)
+    assert L.hx_intel_FFTRev1(p(back), p(rev), n, q) == 0
+    assert np.array_equal(back.astype(np.uint64), a)                       # (3)
+    for k in (3, 5, m - 1, 2 * 7 + 1):
+        ak = np.zeros(n, dtype=np.uint64)                                  # a(X^k) mod X^n + 1
+        e = (np.arange(n, dtype=np.int64) * k) % m
+        ak[e % n] = np.where(e < n, a, (q - a) % q)
+        want = O.bit_reverse_copy(shim_fwd(ak))
+        dk = hx.DoubleCRT(g, [0], 1, O.bit_reverse_copy(out).reshape(1, 1, n).copy())   # rows via the shim path
+        dk.automorph(k)
+        assert np.array_equal(dk.download().reshape(n), want), k            # (4)
 
 
 # ---------------------------------------------------------------- general m (Bluestein)

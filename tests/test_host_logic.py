@@ -27,6 +27,8 @@ def replay():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-DHX_CHECK_BOUNDS", "-shared", "-fPIC", "-o", so, src])
     L = C.CDLL(so)
     L.ntt_replay.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.ntt_replay_proth.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.mont_acc_replay.argtypes = [C.c_uint64, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -48,6 +50,108 @@ def test_ntt_kernel_phases_replayed_on_cpu(replay, logn, bits):
         back = np.zeros(N, dtype=np.uint64)
         assert replay.ntt_replay(logn, 1, q, cm.root, y.ctypes.data, back.ctypes.data) == 0
         assert np.array_equal(back, x)
+
+
+# ---------------------------------------------------------------- round 5: the Proth-form butterflies
+def _proth_parts(q):
+    """q = t 2^s + 1, t odd (src/PrimeGenerator.h:66-118 makes every chain prime in this form)."""
+    s = ((q - 1) & -(q - 1)).bit_length() - 1
+    return (q - 1) >> s, s
+
+
+def _chain_primes():
+    """The primes of the benchmark chains the row kernels see: ctxt, special and small primes of the m = 32768 and
+    m = 65536 rings (helib_amd.ctxt.ChainContext restates Context::buildModChain)."""
+    from helib_amd import ctxt as CT
+    out = {}
+    for m, bits, ckks in ((32768, 950, False), (65536, 1400, True), (65536, 440, True), (32768, 6400, False)):
+        cc = CT.ChainContext(m, -1 if ckks else 65537, 1, bits=bits, c=3, ckks=ckks)
+        out[(m, bits)] = [int(q) for q in cc.primes]
+    return out
+
+
+def test_proth_form_of_the_chain_primes():
+    """every prime PrimeGenerator makes is t 2^s + 1; the Proth-form rows need s >= 32 (the
+    low word of q is 1).  That holds for every prime of the bits = 950 / 1400 / 6400 chains; rows of any other
+    prime (the two 38-bit small primes of the CKKS bits = 440 chain, s = 29; user primes; the m = 12 fixture) keep the Shoup
+    butterflies -- the choice is per row (PrimeDev::proth), not per context."""
+    for m, bits in ((32768, 60), (32768, 56), (65536, 60), (65536, 55), (32768, 50), (65536, 45)):
+        g = O.PrimeGen(bits, m)
+        for _ in range(8):
+            q = g.next()
+            t, s = _proth_parts(q)
+            assert s >= 32 and q & 0xffffffff == 1 and q >> 32 == t << (s - 32)
+    chains = _chain_primes()
+    for key, qs in chains.items():
+        bad = [q for q in qs if _proth_parts(q)[1] < 32]
+        assert (len(bad) == 2 and all(q.bit_length() <= 40 for q in bad)) if key == (65536, 440) else not bad, (key, bad)
+        assert all(q < 2 ** 60 for q in qs)
+
+
+@pytest.mark.parametrize("bits,m", [(60, 32768), (56, 32768), (57, 32768), (40, 32768), (60, 65536), (55, 65536), (45, 65536)])
+def test_proth_montgomery_product_restated_in_python_integers(replay, bits, m):
+    """mont_acc (helib_amd/csrc/ntt_core.h) against python integers: for q = qh 2^32 + 1, W = w 2^64 mod q and any
+    y below 207/16 q, the word-wise reduction with the complemented quotient digits n0, n1 returns x + R with
+    R 2^64 = y W + M q, M = (n0+1) + (n1+1) 2^32 -- so R = y w (mod q) -- and 0 < R < q (1 + y/2^64 + 2^-32) < 2q;
+    none of the 64-bit accumulators wraps.  Both the identity (in python) and the device's word arithmetic
+    (mont_acc_replay, the same source compiled for the host) are checked, incl. the extreme operands."""
+    q = O.PrimeGen(bits, m).next()
+    assert q & 0xffffffff == 1
+    qh = q >> 32
+    c1 = (1 + qh) * (2 ** 32 + 1)
+    lim = 207 * q // 16
+    rng = np.random.default_rng(bits * m)
+    n = 4000
+    ys = [0, 1, q - 1, q, lim - 1, 2 ** 32 - 1, 2 ** 32, (lim - 1) | 0xffffffff if ((lim - 1) | 0xffffffff) < lim else lim - 1]
+    ys += [int(v) % lim for v in rng.integers(0, 2 ** 63, n - len(ys), dtype=np.uint64) * 2]
+    Ws = [0, 1, q - 1, 0xffffffff, q - 2 ** 32] + [int(v) for v in rng.integers(0, q, n - 5, dtype=np.uint64)]
+    xs = [0, 2 ** 64 - 2 * q - 1] + [int(v) for v in rng.integers(0, 14 * q - 1, n - 2, dtype=np.uint64)]
+    got = np.zeros(n, dtype=np.uint64)
+    ya, Wa, xa = (np.array(v, dtype=np.uint64) for v in (ys, Ws, xs))
+    replay.mont_acc_replay(q, n, ya.ctypes.data, Wa.ctypes.data, xa.ctypes.data, got.ctypes.data)
+    Rinv = pow(2 ** 64, -1, q)
+    M32 = 2 ** 32 - 1
+    for y, W, x, g in zip(ys, Ws, xs, got):
+        yl, yh, wl, wh = y & M32, y >> 32, W & M32, W >> 32
+        a = yl * wl
+        n0 = ~a & M32
+        G = yl * wh + c1 + n0 * qh + (a >> 32) + yh * wl
+        assert G < 2 ** 64                                   # (the operand limit is what keeps this sum in a word)
+        n1 = ~G & M32
+        D = yh * wh + n1 * qh + (G >> 32)
+        Mq = (n0 + 1) + (n1 + 1) * 2 ** 32
+        assert D * 2 ** 64 == y * W + Mq * q                 # the reduction is exact: nothing was dropped
+        assert D % q == y * W * Rinv % q and 0 < D < 2 * q
+        assert D * 2 ** 64 < q * (2 ** 64 + y + 2 ** 32) + 2 ** 64   # R < q (1 + y W / (q 2^64) + 2^-32), W < q
+        assert x + D < 2 ** 64 and int(g) == x + D           # the device's words
+
+
+@pytest.mark.parametrize("logn", [13, 14, 15])
+@pytest.mark.parametrize("bits", [60, 56, 45])
+def test_proth_row_transform_replayed_on_cpu(replay, logn, bits):
+    """The row kernels' phases with the Proth-form butterflies (RowNTT<LOGN, ArProth>), thread by thread, every
+    compile-time bound (sixteenths of q forward, whole q inverse) asserted at run time (HX_CHECK_BOUNDS): canonical,
+    all-(q-1) and zero rows, and rows of lazy words in [0,8q) (the load bound of the exact-RNS kernels' output)."""
+    N = 1 << logn
+    m = 2 * N
+    q = O.PrimeGen(bits, m).next()
+    cm = O.Cmod(m, q)
+    rng = np.random.default_rng(logn * bits)
+    for x in (O.fill_uniform(N, q, 5), np.full(N, q - 1, dtype=np.uint64), np.zeros(N, dtype=np.uint64)):
+        y = cm.fft(x)
+        out = np.zeros(N, dtype=np.uint64)
+        assert replay.ntt_replay_proth(logn, 0, 0, q, cm.root, x.ctypes.data, out.ctypes.data) == 0
+        assert np.array_equal(out, y)
+        back = np.zeros(N, dtype=np.uint64)
+        assert replay.ntt_replay_proth(logn, 1, 0, q, cm.root, y.ctypes.data, back.ctypes.data) == 0
+        assert np.array_equal(back, x)
+        lazy = x + np.uint64(q) * rng.integers(0, 8, N, dtype=np.uint64)
+        lazy[0] = x[0] + np.uint64(7 * q)
+        assert replay.ntt_replay_proth(logn, 0, 1, q, cm.root, lazy.ctypes.data, out.ctypes.data) == 0
+        assert np.array_equal(out, y)
+    # a prime that is not of the form is refused by the Proth replay (the engine gives such rows the Shoup kernels)
+    q31 = O.PrimeGen(31, m).next()
+    assert replay.ntt_replay_proth(logn, 0, 0, q31, O.Cmod(m, q31).root, out.ctypes.data, out.ctypes.data) == -2
 
 
 def test_c_abi_exports_every_declared_symbol():

@@ -228,3 +228,44 @@ def test_randomize_row_follows_the_reference_sampling_rule():
                     if len(out) == n:
                         break
         assert used == nbuf and [int(v) for v in got] == out
+
+
+# ---------------------------------------------------------------- the HEXL seam (absent third-party dependency)
+def test_hexl_minimal_primitive_root_known_answers():
+    """hexl::MinimalPrimitiveRoot (HEXL >= 1.2.1, the root hexl::NTT(n, q) picks at degree 2n): the published
+    known answers of HEXL's own number-theory tests (shared with SEAL's try_minimal_primitive_root), and the
+    definition -- the smallest element of order exactly e -- by exhaustive search on small moduli."""
+    assert O.hexl_minimal_primitive_root(11, 2) == 10
+    assert O.hexl_minimal_primitive_root(29, 2) == 28
+    assert O.hexl_minimal_primitive_root(29, 4) == 12
+    assert O.hexl_minimal_primitive_root(1234565441, 2) == 1234565440
+    assert O.hexl_minimal_primitive_root(1234565441, 8) == 249725733
+    for q, e in [(769, 128), (769, 256), (12289, 4096), (257, 256), (97, 32)]:
+        want = next(x for x in range(2, q) if pow(x, e, q) == 1 and pow(x, e // 2, q) != 1)
+        assert O.hexl_minimal_primitive_root(q, e) == want
+
+
+@pytest.mark.parametrize("n,q", [(2, 5), (4, 17), (64, 769), (128, 769), (2048, 12289)])
+def test_hexl_reference_transform_is_the_bit_reversed_negacyclic_evaluation(n, q):
+    """intel::FFTFwd = hexl::NTT(n, q).ComputeForward (src/intelExt.cpp:76-84): out[i] = f(psi^(2 brev(i) + 1))
+    with psi = MinimalPrimitiveRoot(2n, q); FFTRev1 inverts it from that order.  This is why Cmodulus::FFT_aux
+    bit-reverses AFTER the call (src/CModulus.cpp:385, :421-426) and iFFT BEFORE it (:510-514): with
+    BitReverseCopy the row is the natural one the rest of HElib (automorph, the wire format) indexes, and it equals
+    the NTL branch's row for the same root."""
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, q, n, dtype=np.uint64)
+    psi = O.hexl_minimal_primitive_root(q, 2 * n)
+    y = O.hexl_forward(x, q)
+    bits = n.bit_length() - 1
+    brev = lambda i: int(format(i, "0%db" % bits)[::-1], 2) if bits else 0
+    for i in (range(n) if n <= 128 else rng.integers(0, n, 40)):
+        pt = pow(psi, 2 * brev(int(i)) + 1, q)
+        acc = 0
+        for c in x[::-1]:
+            acc = (acc * pt + int(c)) % q
+        assert int(y[int(i)]) == acc
+    assert np.array_equal(O.hexl_inverse(y, q), x)
+    # the NTL branch of the same function, same root: natural order (TestHEXL's round trip holds either way)
+    cm = O.Cmod(2 * n, q, psi)
+    assert np.array_equal(O.bit_reverse_copy(y), cm.fft(x))
+    assert np.array_equal(O.hexl_inverse(O.bit_reverse_copy(cm.fft(x)), q), x)

@@ -14,8 +14,8 @@
 using namespace hx;
 constexpr int ITER = 64;
 
-template <bool INV>
-__global__ void __launch_bounds__(512, 4) k(uint64_t* out, uint64_t* cyc, const TW* tw, uint64_t q)
+template <bool INV, class AR>
+__global__ void __launch_bounds__(512, 4) k(uint64_t* out, uint64_t* cyc, const typename AR::Tw* tw, uint64_t q)
 {
   uint64_t v[32];
   const QC c = make_qc(q);
@@ -25,9 +25,9 @@ __global__ void __launch_bounds__(512, 4) k(uint64_t* out, uint64_t* cyc, const 
 #pragma unroll 1
   for (int it = 0; it < ITER; it++) {
     if constexpr (!INV)
-      run_pass<5, false, 1, 31, 1>(v, c, [&](int, int sp, int kk, uint32_t) { return tw[(1 << sp) - 1 + kk]; });
+      run_pass<AR, 5, false, 1, 31, AR::U>(v, c, [&](int, int sp, int kk, uint32_t) { return tw[(1 << sp) - 1 + kk]; });
     else
-      run_pass<5, true, 1, 31, 1>(v, c, [&](int, int sp, int kk, uint32_t) { return tw[(1 << sp) - 1 + kk]; });
+      run_pass<AR, 5, true, 1, 31, 1>(v, c, [&](int, int sp, int kk, uint32_t) { return tw[(1 << sp) - 1 + kk]; });
   }
   const uint64_t t1 = __builtin_readcyclecounter();
   uint64_t s = 0;
@@ -36,19 +36,19 @@ __global__ void __launch_bounds__(512, 4) k(uint64_t* out, uint64_t* cyc, const 
   if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
 
-template <bool INV>
-int run(const char* name, uint64_t* d, uint64_t* dc, const TW* tw, uint64_t q)
+template <bool INV, class AR>
+int run(const char* name, uint64_t* d, uint64_t* dc, const typename AR::Tw* tw, uint64_t q)
 {
   printf("%-28s", name);
   for (int wgs : {1, 2}) {  // workgroups per CU: 512 threads = 2 waves per SIMD each
     int blocks = 256 * wgs;
-    hipLaunchKernelGGL(k<INV>, dim3(blocks), dim3(512), 0, 0, d, dc, tw, q);
+    hipLaunchKernelGGL((k<INV, AR>), dim3(blocks), dim3(512), 0, 0, d, dc, tw, q);
     CHECK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k<INV>, dim3(blocks), dim3(512), 0, 0, d, dc, tw, q);
+    hipLaunchKernelGGL((k<INV, AR>), dim3(blocks), dim3(512), 0, 0, d, dc, tw, q);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms;
@@ -60,8 +60,10 @@ int run(const char* name, uint64_t* d, uint64_t* dc, const TW* tw, uint64_t q)
     avg /= (double)h.size();
     const double bf = (double)ITER * 80;  // butterflies per thread: 5 stages x 16
     const int wps = 2 * wgs;
-    printf("  %d waves/SIMD: %6.1f cycles/butterfly/SIMD (wave sees %6.1f), %.3f ms, clock %.2f GHz", wps,
-           avg / bf / wps, avg / bf, ms, avg / (ms * 1e6));
+    // ns per wave-butterfly per SIMD: blocks x 8 waves over 1024 SIMDs
+    const double ns = ms * 1e6 / (bf * (double)blocks * 8.0 / 1024.0);
+    printf("  %d waves/SIMD: %6.1f cycles/butterfly/SIMD (wave sees %6.1f), %.3f ms = %5.2f ns/butterfly/SIMD, clock %.2f GHz", wps,
+           avg / bf / wps, avg / bf, ms, ns, avg / (ms * 1e6));
   }
   printf("\n");
   return 0;
@@ -69,24 +71,31 @@ int run(const char* name, uint64_t* d, uint64_t* dc, const TW* tw, uint64_t q)
 
 int main()
 {
-  const uint64_t q = 1152921504606584833ull;  // 2^60 - 2^18 + 1 (size is all that matters here)
+  const uint64_t q = 1152921504606584833ull - 0;  // placeholder, replaced below
+  (void)q;
+  // a 60-bit chain prime of m = 32768 (PrimeGenerator(60, 32768)): q = 0xed0000000000001 = 237 * 2^52 + 1
+  const uint64_t qp = 0xed0000000000001ull;
   std::vector<TW> t(32);
+  std::vector<TWM> tm(32);
   for (int i = 0; i < 32; i++) {
-    t[i].w = (q / 3) + (uint64_t)i * 0x9E3779B97F4A7ull % (q / 2);
-    t[i].wp = (uint64_t)((((unsigned __int128)t[i].w) << 64) / q);
+    t[i].w = (qp / 3) + (uint64_t)i * 0x9E3779B97F4A7ull % (qp / 2);
+    t[i].wp = (uint64_t)((((unsigned __int128)t[i].w) << 64) / qp);
+    tm[i] = tw_mont_form(t[i].w, qp);
   }
   uint64_t *d, *dc;
   TW* dt;
+  TWM* dtm;
   CHECK(hipMalloc(&d, (size_t)512 * 512 * 8));
   CHECK(hipMalloc(&dc, (size_t)512 * 8 * 8));
   CHECK(hipMalloc(&dt, 32 * sizeof(TW)));
+  CHECK(hipMalloc(&dtm, 32 * sizeof(TWM)));
   CHECK(hipMemcpy(dt, t.data(), 32 * sizeof(TW), hipMemcpyHostToDevice));
-#ifdef HX_SHOUP4_OLD
-  printf("butterflies: round-1 form (v_mul_hi / v_mul_lo + adds)\n");
-#else
-  printf("butterflies: multiply-add chains\n");
-#endif
-  run<false>("forward (Cooley-Tukey)", d, dc, dt, q);
-  run<true>("inverse (Gentleman-Sande)", d, dc, dt, q);
+  CHECK(hipMemcpy(dtm, tm.data(), 32 * sizeof(TWM), hipMemcpyHostToDevice));
+  for (int rep = 0; rep < 2; rep++) {
+    run<false, ArShoup>("forward Shoup (shoup4_acc)", d, dc, dt, qp);
+    run<false, ArProth>("forward Proth (mont_acc)", d, dc, dtm, qp);
+    run<true, ArShoup>("inverse Shoup", d, dc, dt, qp);
+    run<true, ArProth>("inverse Proth", d, dc, dtm, qp);
+  }
   return 0;
 }
