@@ -9,11 +9,16 @@ CSRC = helib_amd/csrc
 LIB = helib_amd/lib
 HDRS = $(wildcard $(CSRC)/*.h) include/helib_amd.h
 
+OBJS = $(LIB)/ntt_kernels_13.o $(LIB)/ntt_kernels_14.o $(LIB)/ntt_kernels_15.o $(LIB)/ntt_dispatch.o $(LIB)/conv_kernels.o $(LIB)/engine.o
 lib: $(LIB)/libhelib_amd.so
 $(LIB)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(LIB)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(LIB)/libhelib_amd.so: $(LIB)/ntt_kernels.o $(LIB)/conv_kernels.o $(LIB)/engine.o
+# the row kernels: one translation unit per ring size (make -j builds them in parallel)
+$(LIB)/ntt_kernels_%.o: $(CSRC)/ntt_kernels.hip $(HDRS)
+	@mkdir -p $(LIB)
+	$(HIPCC) $(HIPFLAGS) -DHX_NTT_ONLY=$* -c $< -o $@
+$(LIB)/libhelib_amd.so: $(OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^
 oracle:
 	$(MAKE) -s -C oracle

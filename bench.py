@@ -71,6 +71,7 @@ import argparse
 import json
 import os
 import subprocess
+import tempfile
 import sys
 import time
 
@@ -1027,18 +1028,34 @@ def launch_ranks(n, argv):
     """`bench.py --gpus N` started as ONE process: spawn the N ranks (one process per GPU), pass
     rank 0's JSON line through, fail if any rank fails."""
     port = free_port()
-    procs = []
+    procs, logs = [], []
+    logdir = os.environ.get("HX_RANK_LOG_DIR") or tempfile.mkdtemp(prefix="helib_amd_ranks_")
+    os.makedirs(logdir, exist_ok=True)
     for r in range(n):
         env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # ranks > 0 keep what they print (and their stderr) in a per-rank file: a rank that dies says why
+        log = open(os.path.join(logdir, f"rank{r}.log"), "w") if r else None
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+                                      stdout=subprocess.PIPE if r == 0 else log, stderr=None if r == 0 else subprocess.STDOUT,
+                                      text=True))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for log in logs:
+        if log:
+            log.close()
     sys.stdout.write(out)
     sys.stdout.flush()
     if any(rcs):
-        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+        for r, rc in enumerate(rcs):
+            if r and rc:
+                try:
+                    with open(os.path.join(logdir, f"rank{r}.log")) as f:
+                        sys.stderr.write(f"---- rank {r} (exit code {rc}), last lines of {f.name}:\n" + "".join(f.readlines()[-15:]))
+                except OSError:
+                    pass
+        raise SystemExit(f"bench.py: rank exit codes {rcs} (per-rank logs in {logdir})")
 
 
 def dry_rank(args):
@@ -1104,6 +1121,7 @@ def main():
                          "RCCL refuses two ranks on one device.  Not a scaling measurement.")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary legs (python mirror, batch-1 latency, op list, levels of the other scheme, config 5)")
+    ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: skip the RCCL self-check (config.rccl_selfcheck)")
     ap.add_argument("--dry-launch", action="store_true", help="N-rank launch/aggregation path on CPUs (gloo), no engine")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -1122,6 +1140,13 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
     if args.dry_launch:
         return dry_rank(args)
+
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner on fd 1 when a communicator comes
+    # up, the HIP runtime and torch now and then a warning -- everything written to fd 1 from here on goes to stderr,
+    # the line itself to the saved descriptor
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     from helib_amd import dist as hdist
@@ -1171,7 +1196,11 @@ def main():
         dtb, host_b = run_session(sess, 1, steps4, args.warmup, R, sync, group.barrier, measure=False)
         dtb = group.max_over_ranks(dtb) / steps4 * args.steps
         host_b = host_b / steps4 * args.steps
-        dt, host_s = run_session(sess, 1, args.steps, args.warmup, R, sync, group.barrier, measure=True)
+        from helib_amd import sensors
+        with sensors.Sampler(local_rank) as smp:           # engine clock / package power WHILE the timed loop runs
+            dt, host_s = run_session(sess, 1, args.steps, args.warmup, R, sync, group.barrier, measure=True)
+        rate_rank = B * R * args.steps / dt                # this rank's own rate over its own clock
+        rate_min, rate_max = group.min_over_ranks(rate_rank), group.max_over_ranks(rate_rank)
         dt = group.max_over_ranks(dt)
         nver = sess.verify(1)                              # every batch element of the last product, on every rank
         res_primes = sess.result_primes(1)
@@ -1217,7 +1246,13 @@ def main():
                  "one_key_pair": (f"rank 0's key pair for all {world} ranks: {key_bytes} bytes of key material broadcast once "
                                   f"({'gloo, --one-device' if args.one_device else 'RCCL'}), every rank encrypts its own slice under it"
                                   if world > 1 else "single rank"),
-                 "process_group_world_size": group.world_size_seen(), "key_material_bytes_broadcast": key_bytes,
+                 **smp.summary(),
+                 "process_group_world_size": group.world_size_seen(), "world_size_seen": group.world_size_seen(),
+                 "key_material_bytes_broadcast": key_bytes,
+                 "per_rank_mult_per_s_min": round(rate_min, 1), "per_rank_mult_per_s_max": round(rate_max, 1),
+                 "extras": ("all secondary legs, roofline traffic, cpu_baseline and the RCCL self-check: this is the N = 1 line"
+                            if extras else ("skipped at N > 1: the ranks end together, the line carries the headline, the "
+                                            "in-situ kernel table and the roofline only" if world > 1 else "skipped (--no-extras)")),
                  "result_primes": res_primes,
                  "inputs": ("key pair, relinearisation matrix and public-key encryptions of random plaintexts made by the C++ "
                             "host (helib_amd_keys.hpp: SecKey::GenSecKey, Encrypt / CKKSencrypt), as benchmarks/bgv_basic.cpp:144-157"),
@@ -1230,6 +1265,9 @@ def main():
                             "over_level1": round((dt2 / steps4) / (dt / args.steps), 3),
                             "hipMalloc_calls_in_timed_window": malloc2,
                             "verified_elements": nver2_all, "result_primes": sess.result_primes(2)}}
+        if world == 1 and not args.no_rccl_check:
+            # RCCL once before the 8-GPU node does it for us: the N-rank run's own calls in a world of one (<= 2 s)
+            extra["rccl_selfcheck"] = hdist.rccl_selfcheck(sess.export_keys(), torch.device("cuda", local_rank))
         extra["level2_mult_per_s"] = extra["level2"]["mult_per_s"]
         extra["level2_over_level1"] = extra["level2"]["over_level1"]
         if rank == 0:
@@ -1412,7 +1450,8 @@ def main():
                 "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
                 "vs_baseline": None, "dtype": "u64",
                 "data": "synthetic", "config": cfg, "roofline": roof, "cpu_baseline": cpu}
-        print(json.dumps(line))
+        line_out.write(json.dumps(line) + "\n")
+        line_out.flush()
     group.close()
 
 

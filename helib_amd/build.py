@@ -13,7 +13,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libhelib_amd.so")
-SOURCES = ["ntt_kernels.hip", "conv_kernels.hip", "engine.hip"]
+# (source, extra flags, object): ntt_kernels.hip is compiled once per ring size, in parallel (see the top of that file)
+UNITS = [("ntt_kernels.hip", ["-DHX_NTT_ONLY=13"], "ntt_kernels_13.o"), ("ntt_kernels.hip", ["-DHX_NTT_ONLY=14"], "ntt_kernels_14.o"),
+         ("ntt_kernels.hip", ["-DHX_NTT_ONLY=15"], "ntt_kernels_15.o"), ("ntt_dispatch.hip", [], "ntt_dispatch.o"),
+         ("conv_kernels.hip", [], "conv_kernels.o"), ("engine.hip", [], "engine.o")]
+SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["ntt_core.h", "dev_common.h", "rns_kernels.h", "hostmath.h", "conv_core.h", "bluestein.h", "norm_kernels.h",
            "prg_kernels.h", "arena.h", "prof.h", "switches.h", "conv_dev.h", "ntt_kernel_util.h", "norm_r16.h",
            os.path.join("..", "..", "include", "helib_amd.h")]
@@ -40,12 +44,12 @@ def build(force=False, extra_flags=(), verbose=False):
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     cc = hipcc()
     objs, jobs = [], []
-    for s in SOURCES:
+    for s, unit_flags, o in UNITS:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        obj = os.path.join(LIBDIR, o)
         objs.append(obj)
         if force or _stale(obj, deps + [src]):
-            jobs.append([cc, *FLAGS, *extra_flags, "-c", src, "-o", obj])
+            jobs.append([cc, *FLAGS, *unit_flags, *extra_flags, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -164,6 +164,7 @@ struct BluePrime {
 };
 
 struct hx_ctx {
+  hxs::Switches sw;  // the environment switches as they were when the context was created (switches.h)
   int device = 0;
   hipStream_t stream = nullptr;
   uint64_t m = 0;
@@ -313,9 +314,10 @@ static int use(hx_ctx* c)
   } while (0)
 
 static constexpr size_t POOL_LIMIT = (size_t)64 << 30;        // keep at most 64 GiB cached
-static int arena_sys_alloc(size_t bytes, void** out)
+template <bool TRACE>   // (HX_ARENA_TRACE) one line per hipMalloc the arena makes
+static int arena_sys_alloc_t(size_t bytes, void** out)
 {
-  const bool trace = hxs::current().arena_trace;   // (HX_ARENA_TRACE) one line per hipMalloc the arena makes
+  const bool trace = TRACE;
   const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(out, bytes);
   if (trace)
@@ -329,7 +331,7 @@ static void arena_sys_free(void* p) { hipFree(p); }  // (hipFree waits for the d
 static hipError_t pool_alloc(hx_ctx* c, size_t bytes, void** out)
 {
   if (!c->arena.sys_alloc) {
-    c->arena.sys_alloc = arena_sys_alloc;
+    c->arena.sys_alloc = c->sw.arena_trace ? arena_sys_alloc_t<true> : arena_sys_alloc_t<false>;
     c->arena.sys_free = arena_sys_free;
   }
   // a block taken while a capture is open may end up inside the graph: pinned from the start
@@ -499,8 +501,8 @@ extern "C" int hx_ctx_create(hx_ctx** out, int device, uint64_t m)
   if (device < 0 || device >= ndev)
     return fail(HX_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
   HIPCHK(hipSetDevice(device));
-  hxs::refresh();   // the environment switches (switches.h), snapshotted here and nowhere else
   hx_ctx* c = new hx_ctx();
+  c->sw = hxs::read();   // the environment switches (switches.h), snapshotted here and nowhere else
   // a failing allocation below returns through HIPCHK: the half-built context and whatever it
   // already holds on the device go with it
   struct Guard {
@@ -669,7 +671,7 @@ extern "C" int hx_ctx_reserve(hx_ctx* c, uint64_t bytes)
     return fail(HX_ERR_INVALID, "null context");
   CTX_ENTER(c);
   if (!c->arena.sys_alloc) {
-    c->arena.sys_alloc = arena_sys_alloc;
+    c->arena.sys_alloc = c->sw.arena_trace ? arena_sys_alloc_t<true> : arena_sys_alloc_t<false>;
     c->arena.sys_free = arena_sys_free;
   }
   const int rc = c->arena.reserve((size_t)bytes);
@@ -741,7 +743,7 @@ static int upload_tw(hx_ctx* c, PrimeHost& ph)
   // q = 1 (mod 2^32) -- every prime PrimeGenerator makes for these rings down to ~45 bits: the rows run the
   // Proth-form butterflies (ntt_core.h, ArProth) on 8-byte entries w 2^64 mod q at the same table positions
   // (each table keeps its slot of TW_TOTAL 16-byte units and fills half of it; offsets stay in TW units)
-  ph.proth = hx::is_proth32(ph.q) && !hxs::current().no_proth;
+  ph.proth = hx::is_proth32(ph.q) && !c->sw.no_proth;
   if (ph.proth) {
     std::vector<hx::TWM> fm(G::TW_TOTAL), im(G::TW_TOTAL);
     hx::tw_tables_to_mont(f.data(), G::TW_TOTAL, ph.q, fm.data());
@@ -1323,7 +1325,7 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
   // fused path (conv_dev.h): every convolution is ONE launch of the convolution row kernel + one
   // element-wise pass; needs primes that convolve modulo themselves and sizes the row kernels take
   // (2^13..2^15, the chirp convolution optionally as a radix-4 split)
-  const bool old_path = hxs::current().blue_old;
+  const bool old_path = c->sw.blue_old;
   auto sub_ok = [](const ConvPlan& pl) {
     const int l = pl.split == 4 ? pl.logn - 2 : pl.logn;
     return (pl.split == 0 || pl.split == 4) && l >= 13 && l <= 15;
@@ -2412,7 +2414,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   size_t o_hinv = take((size_t)2 * n), o_Wp2 = take((size_t)2 * n);
   // rns_extend_wide_kernel (17..40 source primes): per-target record of 8 + n words, padded so that the last
   // record's group-of-four multiplier reads stay inside the blob
-  const bool wide_cand = n > 16 && n <= 40 && !hxs::current().no_wide_extend;
+  const bool wide_cand = n > 16 && n <= 40 && !c->sw.no_wide_extend;
   const size_t wide_stride = (size_t)hx::wide_stride(n);
   size_t o_wide = wide_cand ? take((size_t)nt * wide_stride) : 0;
   std::vector<uint64_t> h(off, 0);
@@ -2454,9 +2456,9 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     uint64_t q = tq(t);
     // lazy 128-bit accumulation is exact when sum_k a_k*W_k < (sum_k q_k)*q_t <= 8*q_t^2
     // (red128_wide's domain; q_t <= 60 bits)
-    tlazy[t] = (hxh::bitlen(q) <= 60 && sum_src <= (hxh::u128)8 * q && !hxs::current().no_lazy_rns) ? 1u : 0u;
+    tlazy[t] = (hxh::bitlen(q) <= 60 && sum_src <= (hxh::u128)8 * q && !c->sw.no_lazy_rns) ? 1u : 0u;
     // seven terms + the carried remainder: r + 7 max_src q < 8 q^2 needs max_src <= q
-    tchunk[t] = (hxh::bitlen(q) <= 60 && max_src <= q && !hxs::current().no_lazy_rns) ? 1u : 0u;
+    tchunk[t] = (hxh::bitlen(q) <= 60 && max_src <= q && !c->sw.no_lazy_rns) ? 1u : 0u;
     h[o_tq + t] = q;
     h[o_tmu64 + t] = (uint64_t)((((hxh::u128)1) << 64) / q);
     int kb = hxh::bitlen(q);
@@ -2527,7 +2529,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   // HPS front end: y_k = a_k (P/p_k)^-1 mod p_k, multipliers (P/p_k) mod t (scaled plans: / P, i.e.
   // p_k^-1 mod t), the same header; "lazy" needs room for up to n + 1 extra multiples of t in the sum
   bool hps_ok = n >= 2 && (n <= 16 || wide_cand) && (ptxt <= 1 || ptxt < ((uint64_t)1 << (wide_cand ? 56 : 58))) &&
-                (!hxs::current().no_hps || wide_cand);
+                (!c->sw.no_hps || wide_cand);
   if (hps_ok) {
     auto prod_except = [&](int k, uint64_t m) {   // (P / p_k) mod m
       uint64_t r = 1 % m;
@@ -2577,7 +2579,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
         rec2[j] = rec[j];
       rec2[8 + 2 * n] = rec[8 + 2 * n];
       rec2[8 + 2 * n + 1] = rec[8 + 2 * n + 1];
-      const uint32_t lazy2 = (hxh::bitlen(q) <= 60 && sum_src + 32 <= (hxh::u128)8 * q && !hxs::current().no_lazy_rns) ? 1u : 0u;
+      const uint32_t lazy2 = (hxh::bitlen(q) <= 60 && sum_src + 32 <= (hxh::u128)8 * q && !c->sw.no_lazy_rns) ? 1u : 0u;
       rec2[4] = (uint64_t)tk[t] | ((uint64_t)lazy2 << 8) | ((uint64_t)tchunk[t] << 9);
       const uint64_t pinv_t = h[o_upd + 2 * (size_t)t];   // P^-1 mod t
       for (int k = 0; k < n; k++) {
@@ -2597,7 +2599,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   pl->dev.tgt_pack_hps = hx::as_ro(d + o_pack2);
   pl->dev.hps_inv = hx::as_ro(reinterpret_cast<const TW*>(d + o_hinv));
   pl->dev.Wp_hps = hx::as_ro(reinterpret_cast<const TW*>(d + o_Wp2));
-  pl->dev.hps_eps = hxs::current().hps_eps;
+  pl->dev.hps_eps = c->sw.hps_eps;
   pl->dev.n = n;
   pl->dev.nt = nt;
   pl->dev.src_q = hx::as_ro(d + o_srcq);
@@ -2614,15 +2616,15 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   pl->dev.Wp = hx::as_ro(reinterpret_cast<const TW*>(d + o_Wp));
   pl->dev.tgt_lazy = hx::as_ro(reinterpret_cast<const uint32_t*>(d + o_tlazy));
   // a_l < q_l <= max < 2*min <= 2*p_k, or the sources ascend (a_l < p_l <= p_k for l < k)
-  pl->dev.garner_cs = ((max_src / 2 < min_src || std::is_sorted(p.begin(), p.end())) && !hxs::current().no_lazy_rns) ? 1u : 0u;
+  pl->dev.garner_cs = ((max_src / 2 < min_src || std::is_sorted(p.begin(), p.end())) && !c->sw.no_lazy_rns) ? 1u : 0u;
   pl->dev.src_rq = hx::as_ro(reinterpret_cast<const double*>(d + o_srcrq));
   pl->dev.tgt_mu63 = hx::as_ro(d + o_tmu63);
   {
-    bool ok = pl->dev.garner_cs && n <= 8 && (min_src >> 32) != 0 && !hxs::current().no_fast_break;
+    bool ok = pl->dev.garner_cs && n <= 8 && (min_src >> 32) != 0 && !c->sw.no_fast_break;
     for (int t = 0; t < nt && ok; t++)
       ok = (tq(t) >> 32) != 0 && hxh::bitlen(tq(t)) <= 60;
     pl->dev.fast_ok = ok ? 1u : 0u;
-    bool ok16 = pl->dev.garner_cs && n <= 16 && (min_src >> 32) != 0 && !hxs::current().no_fast_extend;
+    bool ok16 = pl->dev.garner_cs && n <= 16 && (min_src >> 32) != 0 && !c->sw.no_fast_extend;
     for (int t = 0; t < nt && ok16; t++)
       ok16 = (tq(t) >> 32) != 0 && hxh::bitlen(tq(t)) <= 60;
     pl->dev.fast16_ok = ok16 ? 1u : 0u;
@@ -2665,9 +2667,9 @@ static int redo_prepare(hx_ctx* c, size_t row_words, uint32_t** out)
 // per digit is 3-5 % SLOWER with it (366 vs 350 us at BGV L=16, 828 vs 808 us at CKKS L=24: eight u64 -> double
 // conversions cost what the 10-28 dependent Garner products cost), the basis extension of 11 dropped primes is faster
 // (Garner there is 55 products and spills 62 dwords; CKKS level 2 +3 %).  HX_HPS_MIN_N overrides (tests force 2).
-static int hps_min_n()
+static int hps_min_n(const hx_ctx* c)
 {
-  return hxs::current().hps_min_n;
+  return c->sw.hps_min_n;
 }
 static const dim3 REDO_GRID(64);   // the Garner pass over the listed coefficients (grid-stride; the list is almost always empty)
 
@@ -2680,7 +2682,7 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args_in, s
   if (pl->dev.fast16_ok) {
     // HPS form + Garner over its redo list when the plan has the tables and no row is updated in place (an in-place
     // update cannot be redone); otherwise Garner over everything
-    const bool hps = pl->dev.hps_ok && n >= hps_min_n() && args.upd == nullptr && row_words < ((size_t)1 << 32);
+    const bool hps = pl->dev.hps_ok && n >= hps_min_n(c) && args.upd == nullptr && row_words < ((size_t)1 << 32);
     if (hps)
       CHK(redo_prepare(c, row_words, &args.redo));
 #define HX_EXT_FAST(NN)                                                                                            \
@@ -2701,22 +2703,27 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args_in, s
     HIPCHK(hipGetLastError());
     return HX_OK;
   }
-  if (pl->dev.wide_ok && row_words < ((size_t)1 << 32)) {
+  // (a plan whose multiplier table does not fit the LDS goes to the generic kernel below, which handles any plan)
+  const size_t wide_lds = (size_t)pl->dev.nt * (size_t)hx::wide_stride(n) * 8;   // the plan's multipliers, once per workgroup
+  if (pl->dev.wide_ok && row_words < ((size_t)1 << 32) && wide_lds <= 160 * 1024) {
     // 17..40 source primes (the reference's own benchmark chain): HPS form, then Garner over the coefficients it
     // could not vouch for (they were left untouched, so in-place updates are redone correctly too)
     CHK(redo_prepare(c, row_words, &args.redo));
     const dim3 wgrid((unsigned)((row_words + hx::WIDE_THREADS - 1) / hx::WIDE_THREADS)), wblock(hx::WIDE_THREADS);
-    const size_t lds = (size_t)pl->dev.nt * (size_t)hx::wide_stride(n) * 8;   // the plan's multipliers, once per workgroup
-    static bool wide_attr = false;
-    if (!wide_attr) {
-      for (const void* f : {(const void*)hx::rns_extend_wide_kernel<20>, (const void*)hx::rns_extend_wide_kernel<24>,
-                            (const void*)hx::rns_extend_wide_kernel<28>, (const void*)hx::rns_extend_wide_kernel<32>,
-                            (const void*)hx::rns_extend_wide_kernel<36>, (const void*)hx::rns_extend_wide_kernel<40>})
-        HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      wide_attr = true;
+    const size_t lds = wide_lds;
+    // (function attributes are per device: one flag per device a context of this process has used)
+    static std::mutex wide_mu;
+    static std::unordered_set<int> wide_attr;
+    {
+      std::lock_guard<std::mutex> lk(wide_mu);
+      if (!wide_attr.count(c->device)) {
+        for (const void* f : {(const void*)hx::rns_extend_wide_kernel<20>, (const void*)hx::rns_extend_wide_kernel<24>,
+                              (const void*)hx::rns_extend_wide_kernel<28>, (const void*)hx::rns_extend_wide_kernel<32>,
+                              (const void*)hx::rns_extend_wide_kernel<36>, (const void*)hx::rns_extend_wide_kernel<40>})
+          HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        wide_attr.insert(c->device);
+      }
     }
-    if (lds > 160 * 1024)
-      return fail(HX_ERR_UNSUPPORTED, "internal: basis-extension table of %zu bytes does not fit the LDS", lds);
     if (n <= 20)
       HX_LAUNCH((hx::rns_extend_wide_kernel<20>), wgrid, wblock, lds, c->stream, pl->dev, args, row_words);
     else if (n <= 24)
@@ -2941,7 +2948,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   hipStream_t ns = c->stream;
   // (measured, profiles/r03_norm_side_stream_ab.txt: no gain -- the one-workgroup-per-CU norm kernel does not get
   // onto the CUs next to a kernel that fills them -- so the side stream is opt-in: HX_NORM_ASYNC=1)
-  const bool side_stream = hxs::current().norm_async;
+  const bool side_stream = c->sw.norm_async;
   if (side_stream && !c->capturing) {
     if (!c->norm_stream) {
       HIPCHK(hipStreamCreateWithFlags(&c->norm_stream, hipStreamNonBlocking));
@@ -2999,9 +3006,9 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   // One workgroup per polynomial and a plain store of its maximum (the radix-16 kernels): the kernel writes the pinned,
   // device-visible slot itself -- no zero-fill of d_norm2 in front of it (an atomicMax target) and no copy kernel behind
   // it, two ~4 us launches with their gaps per norm call, three calls per multiply.
-  const bool by_copy = hxs::current().norm_memcpy;
-  const bool r16_path = c->pow2 && !hxs::current().norm_old && logn == 14;
-  const bool x2_path = c->pow2 && logn == 15 && !hxs::current().norm_old && !hxs::current().norm_plain;
+  const bool by_copy = c->sw.norm_memcpy;
+  const bool r16_path = c->pow2 && !c->sw.norm_old && logn == 14;
+  const bool x2_path = c->pow2 && logn == 15 && !c->sw.norm_old && !c->sw.norm_plain;
   const bool direct = !by_copy && (r16_path || x2_path);
   unsigned long long* const out2 = direct ? np.pinned : c->d_norm2;
   if (!direct)
@@ -3051,7 +3058,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
                          ns, srcv, c->d_wtab, logn, c->d_norm2);                                         \
   } while (0)
     // N = 2^14: the register-tiled kernel (norm_r16.h); HX_NORM_OLD keeps the LDS-pass kernel (A/B)
-    const bool r16 = !hxs::current().norm_old;
+    const bool r16 = !c->sw.norm_old;
     constexpr size_t r16_lds = (size_t)hx::R16_LDS_DOUBLES * sizeof(double);   // one array: two workgroups per CU
     if (r16 && logn == 14) {
       static bool attr16 = false;
@@ -3081,13 +3088,13 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     }
 #undef HX_NORM_LAUNCH
     c->xs_rows = 0;
-  } else if (logn - 1 > hx::NORM_MAX_LOGH && !hxs::current().norm_plain) {
+  } else if (logn - 1 > hx::NORM_MAX_LOGH && !c->sw.norm_plain) {
     // real-input form beyond one workgroup's LDS: S = N/2/8192 sub-transforms, one workgroup per pair
     CHK(flush_xs(c));
     const int logh = hx::NORM_MAX_LOGH;
     const unsigned H = 1u << logh, S = (N >> 1) >> logh;
     const size_t park_words = (size_t)rows * (S / 2) * H;   // complex doubles
-    const bool x2 = logn == 15 && !hxs::current().norm_old;
+    const bool x2 = logn == 15 && !c->sw.norm_old;
     if (!x2 && c->norm_park_cap < park_words) {
       retire_or_free(c, c->d_norm_park);
       c->d_norm_park = nullptr;
@@ -3149,7 +3156,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
 // multiply waits for the previous multiply's norms while the current one runs; a sleeping wait wakes up on the host's
 // timer granularity, and on part of this pool the CKKS loop then ran at exactly 3.000 ms per multiply with 2.90 ms of
 // kernels in it (profiles/r03_bench_line_ckks65536_final.json: wall_us_per_multiply_of_the_batch).
-static hipError_t wait_event(hipEvent_t ev)
+static hipError_t wait_event(const hx_ctx* c, hipEvent_t ev)
 {
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
@@ -3158,7 +3165,7 @@ static hipError_t wait_event(hipEvent_t ev)
       if (e != hipErrorNotReady)
         return e;
     }
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(hxs::current().wait_poll_us))
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(c->sw.wait_poll_us))
       break;
   }
   return hipEventSynchronize(ev);
@@ -3171,7 +3178,7 @@ extern "C" int hx_norms_flush(hx_ctx* c)
   CTX_ENTER(c);
   NO_CAPTURE(c, "hx_norms_flush");
   for (auto& np : c->norm_pending) {
-    HIPCHK(wait_event(np.ev));
+    HIPCHK(wait_event(c, np.ev));
     for (int r = 0; r < np.rows; r++) {
       double v;
       memcpy(&v, &np.pinned[r], 8);
@@ -3373,7 +3380,7 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
   for (int i = 0; i < np; i++)
     if (!ps[i]->owns)
       return HX_ERR_UNSUPPORTED;  // caller-owned storage wants its result in place
-  if (tsrc && (np != 3 || hxs::current().no_tensor_multi))
+  if (tsrc && (np != 3 || c->sw.no_tensor_multi))
     return HX_ERR_UNSUPPORTED;
   const size_t rw = a->row_words();
   const int batch = a->batch;
@@ -4225,7 +4232,7 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
     const size_t lds_fast = (size_t)std::max(1, L - hx::break_fast_n0(A)) * hx::BRK_THREADS * 8;
     bool hps = rw < ((size_t)1 << 32);
     for (int d = 0; d < ndig; d++)
-      hps = hps && A.plan[d].hps_ok && (int)A.plan[d].n >= hps_min_n();
+      hps = hps && A.plan[d].hps_ok && (int)A.plan[d].n >= hps_min_n(c);
     if (hps) {   // HPS form, then Garner over the coefficients it could not vouch for (rns_kernels.h: ExtRep)
       CHK(redo_prepare(c, rw, &A.redo));
       if (lazy_out) {
@@ -4671,7 +4678,7 @@ extern "C" int hx_mul_relin(const hx_poly* c0, const hx_poly* c1, const hx_poly*
   // the tensor product folded into the inverse transform's load and the key-switch kernel (no tensor_kernel pass,
   // the three product parts are never written): power-of-two rings the row kernels take, outputs that are not
   // operands (the key-switch kernel reads operand rows of the coefficient it writes)
-  const bool fuse_off = hxs::current().no_mulrelin_fuse;
+  const bool fuse_off = c->sw.no_mulrelin_fuse;
   const hx_poly* ins[4] = {c0, c1, d0, d1};
   bool alias = false;
   for (auto* p : ins)

@@ -12,6 +12,35 @@
 
 #include "ntt_kernel_util.h"
 
+// One translation unit per ring size.  The row kernels are straight-line code of ~7000 instructions each, in
+// 3 ring sizes x 2 arithmetics x a dozen IO functors: compiled as one unit this file takes nine minutes.  Built
+// with -DHX_NTT_ONLY=13|14|15 a unit instantiates the kernels of that ring size only and exports its entry points
+// with the suffix _L13 / _L14 / _L15; ntt_dispatch.hip picks by logn (helib_amd/build.py compiles the three in
+// parallel).  Without the macro the file is the whole thing under the plain names, as before.
+#ifdef HX_NTT_ONLY
+#define HX_SFX2(n, s) n##_L##s
+#define HX_SFX1(n, s) HX_SFX2(n, s)
+#define HX_ENTRY(n) HX_SFX1(n, HX_NTT_ONLY)
+#else
+#define HX_ENTRY(n) n
+#endif
+#if !defined(HX_NTT_ONLY) || HX_NTT_ONLY == 13
+#define HX_SZ_13(...) case 13: return __VA_ARGS__;
+#else
+#define HX_SZ_13(...)
+#endif
+#if !defined(HX_NTT_ONLY) || HX_NTT_ONLY == 14
+#define HX_SZ_14(...) case 14: return __VA_ARGS__;
+#else
+#define HX_SZ_14(...)
+#endif
+#if !defined(HX_NTT_ONLY) || HX_NTT_ONLY == 15
+#define HX_SZ_15(...) case 15: return __VA_ARGS__;
+#else
+#define HX_SZ_15(...)
+#endif
+#define HX_SZ(N, ...) HX_SZ_##N(__VA_ARGS__)
+
 namespace hx {
 
 // Row accessor through a buffer resource: the row base lives in 4 SGPRs, the
@@ -162,6 +191,9 @@ __device__ __forceinline__ int64_t moddown_S_of(const ModDownPrep& P, uint64_t x
   return S;
 }
 // n2 = pairs of words (a block of whole rows: even, 16-byte aligned)
+// (a template only so that the per-ring-size translation units may each hold a copy: kernels of templates are
+// merged by the linker, a plain __global__ function defined three times is a duplicate symbol)
+template <int UNUSED = 0>
 __global__ void __launch_bounds__(256)
 moddown_S_kernel(ModDownPrep P, size_t n2)
 {
@@ -869,13 +901,13 @@ static hipError_t launch_inv_mul(const uint64_t* a, const uint64_t* b, uint64_t*
   return hipGetLastError();
 }
 // out[i] (compact rows i < nrows) = inverse transform of a[rows.row[i]] * b[rows.row[i]]
-hipError_t launch_ntt_inv_mul_pow2(int logn, const uint64_t* a, const uint64_t* b, uint64_t* out, const NttRows& rows,
+hipError_t HX_ENTRY(launch_ntt_inv_mul_pow2)(int logn, const uint64_t* a, const uint64_t* b, uint64_t* out, const NttRows& rows,
                                    int nrows, int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
 {
   switch (logn) {
-    case 13: return launch_inv_mul<13>(a, b, out, rows, nrows, batch, primes, tw_arena, st);
-    case 14: return launch_inv_mul<14>(a, b, out, rows, nrows, batch, primes, tw_arena, st);
-    case 15: return launch_inv_mul<15>(a, b, out, rows, nrows, batch, primes, tw_arena, st);
+    HX_SZ(13, launch_inv_mul<13>(a, b, out, rows, nrows, batch, primes, tw_arena, st))
+    HX_SZ(14, launch_inv_mul<14>(a, b, out, rows, nrows, batch, primes, tw_arena, st))
+    HX_SZ(15, launch_inv_mul<15>(a, b, out, rows, nrows, batch, primes, tw_arena, st))
   }
   return hipErrorInvalidValue;
 }
@@ -946,7 +978,7 @@ static hipError_t launch_moddown(const PolyBases& polys, const PolyBases& outs, 
                      tw_arena);
   {
     const size_t n = (size_t)polys.n * (size_t)batch * Geo<LOGN>::N;
-    HX_LAUNCH(moddown_S_kernel, dim3((unsigned)((n / 2 + 255) / 256 > 8192 ? 8192 : (n / 2 + 255) / 256)),
+    HX_LAUNCH((moddown_S_kernel<0>), dim3((unsigned)((n / 2 + 255) / 256 > 8192 ? 8192 : (n / 2 + 255) / 256)),
                        dim3(256), 0, st, P, n / 2);
   }
   HX_LAUNCH((ntt_moddown_apply_kernel<LOGN, false>),
@@ -955,15 +987,15 @@ static hipError_t launch_moddown(const PolyBases& polys, const PolyBases& outs, 
   return hipGetLastError();
 }
 
-hipError_t launch_moddown_pow2(int logn, const PolyBases& data, const PolyBases& out, int drop_row,
+hipError_t HX_ENTRY(launch_moddown_pow2)(int logn, const PolyBases& data, const PolyBases& out, int drop_row,
                                int drop_prime, const NttRows& keep, int nkeep, int batch,
                                const ModDownPrep& P, const ModDownApply& A, const PrimeDev* primes,
                                const TW* tw_arena, hipStream_t st)
 {
   switch (logn) {
-    case 13: return launch_moddown<13>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
-    case 14: return launch_moddown<14>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
-    case 15: return launch_moddown<15>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+    HX_SZ(13, launch_moddown<13>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st))
+    HX_SZ(14, launch_moddown<14>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st))
+    HX_SZ(15, launch_moddown<15>(data, out, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st))
   }
   return hipErrorInvalidValue;
 }
@@ -1006,21 +1038,21 @@ static hipError_t launch_moddown_tensor(const TensorSrc& T, const PolyBases& out
             drop_row, drop_prime, batch, P, primes, tw_arena);
   {
     const size_t n = (size_t)3 * (size_t)batch * Geo<LOGN>::N;
-    HX_LAUNCH(moddown_S_kernel, dim3((unsigned)((n / 2 + 255) / 256 > 8192 ? 8192 : (n / 2 + 255) / 256)), dim3(256), 0, st, P,
+    HX_LAUNCH((moddown_S_kernel<0>), dim3((unsigned)((n / 2 + 255) / 256 > 8192 ? 8192 : (n / 2 + 255) / 256)), dim3(256), 0, st, P,
               n / 2);
   }
   HX_LAUNCH((ntt_moddown_apply_tensor_kernel<LOGN, false>), dim3(moddown_apply_grid(3u, (unsigned)nkeep, (unsigned)batch)),
             dim3(Geo<LOGN>::T), lds_bytes, st, T, outs, keep, nkeep, batch, A, primes, tw_arena);
   return hipGetLastError();
 }
-hipError_t launch_moddown_tensor_pow2(int logn, const TensorSrc& T, const PolyBases& outs, int drop_row, int drop_prime,
+hipError_t HX_ENTRY(launch_moddown_tensor_pow2)(int logn, const TensorSrc& T, const PolyBases& outs, int drop_row, int drop_prime,
                                       const NttRows& keep, int nkeep, int batch, const ModDownPrep& P,
                                       const ModDownApply& A, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
 {
   switch (logn) {
-    case 13: return launch_moddown_tensor<13>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
-    case 14: return launch_moddown_tensor<14>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
-    case 15: return launch_moddown_tensor<15>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st);
+    HX_SZ(13, launch_moddown_tensor<13>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st))
+    HX_SZ(14, launch_moddown_tensor<14>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st))
+    HX_SZ(15, launch_moddown_tensor<15>(T, outs, drop_row, drop_prime, keep, nkeep, batch, P, A, primes, tw_arena, st))
   }
   return hipErrorInvalidValue;
 }
@@ -1052,25 +1084,25 @@ static hipError_t launch_apply_plain_tensor(const TensorSrc& T, const PolyBases&
             dim3(Geo<LOGN>::T), lds_bytes, st, T, outs, keep, nkeep, batch, A, primes, tw_arena);
   return hipGetLastError();
 }
-hipError_t launch_moddown_prep_multi_tensor_pow2(int logn, const TensorSrc& T, const PrepMulti& M, int ndrop, int batch,
+hipError_t HX_ENTRY(launch_moddown_prep_multi_tensor_pow2)(int logn, const TensorSrc& T, const PrepMulti& M, int ndrop, int batch,
                                                  const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena,
                                                  hipStream_t st)
 {
   switch (logn) {
-    case 13: return launch_prep_multi_tensor<13>(T, M, ndrop, batch, P, primes, tw_arena, st);
-    case 14: return launch_prep_multi_tensor<14>(T, M, ndrop, batch, P, primes, tw_arena, st);
-    case 15: return launch_prep_multi_tensor<15>(T, M, ndrop, batch, P, primes, tw_arena, st);
+    HX_SZ(13, launch_prep_multi_tensor<13>(T, M, ndrop, batch, P, primes, tw_arena, st))
+    HX_SZ(14, launch_prep_multi_tensor<14>(T, M, ndrop, batch, P, primes, tw_arena, st))
+    HX_SZ(15, launch_prep_multi_tensor<15>(T, M, ndrop, batch, P, primes, tw_arena, st))
   }
   return hipErrorInvalidValue;
 }
-hipError_t launch_moddown_apply_plain_tensor_pow2(int logn, const TensorSrc& T, const PolyBases& outs, const NttRows& keep,
+hipError_t HX_ENTRY(launch_moddown_apply_plain_tensor_pow2)(int logn, const TensorSrc& T, const PolyBases& outs, const NttRows& keep,
                                                   int nkeep, int batch, const ModDownApply& A, const PrimeDev* primes,
                                                   const TW* tw_arena, hipStream_t st)
 {
   switch (logn) {
-    case 13: return launch_apply_plain_tensor<13>(T, outs, keep, nkeep, batch, A, primes, tw_arena, st);
-    case 14: return launch_apply_plain_tensor<14>(T, outs, keep, nkeep, batch, A, primes, tw_arena, st);
-    case 15: return launch_apply_plain_tensor<15>(T, outs, keep, nkeep, batch, A, primes, tw_arena, st);
+    HX_SZ(13, launch_apply_plain_tensor<13>(T, outs, keep, nkeep, batch, A, primes, tw_arena, st))
+    HX_SZ(14, launch_apply_plain_tensor<14>(T, outs, keep, nkeep, batch, A, primes, tw_arena, st))
+    HX_SZ(15, launch_apply_plain_tensor<15>(T, outs, keep, nkeep, batch, A, primes, tw_arena, st))
   }
   return hipErrorInvalidValue;
 }
@@ -1121,36 +1153,36 @@ static hipError_t launch_prep_multi(const PolyBases& polys, const PrepMulti& M, 
 }
 // P.xs = x block of the first listed prime, P.poly_stride = words between the x blocks of two polys,
 // x blocks of consecutive listed primes batch*N words apart
-hipError_t launch_moddown_prep_multi_pow2(int logn, const PolyBases& polys, const PrepMulti& M, int ndrop, int batch,
+hipError_t HX_ENTRY(launch_moddown_prep_multi_pow2)(int logn, const PolyBases& polys, const PrepMulti& M, int ndrop, int batch,
                                           const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena,
                                           hipStream_t st)
 {
   switch (logn) {
-    case 13: return launch_prep_multi<13>(polys, M, ndrop, batch, P, primes, tw_arena, st);
-    case 14: return launch_prep_multi<14>(polys, M, ndrop, batch, P, primes, tw_arena, st);
-    case 15: return launch_prep_multi<15>(polys, M, ndrop, batch, P, primes, tw_arena, st);
+    HX_SZ(13, launch_prep_multi<13>(polys, M, ndrop, batch, P, primes, tw_arena, st))
+    HX_SZ(14, launch_prep_multi<14>(polys, M, ndrop, batch, P, primes, tw_arena, st))
+    HX_SZ(15, launch_prep_multi<15>(polys, M, ndrop, batch, P, primes, tw_arena, st))
   }
   return hipErrorInvalidValue;
 }
-hipError_t launch_moddown_prep_pow2(int logn, const PolyBases& polys, int drop_row, int drop_prime, int batch,
+hipError_t HX_ENTRY(launch_moddown_prep_pow2)(int logn, const PolyBases& polys, int drop_row, int drop_prime, int batch,
                                     const ModDownPrep& P, const PrimeDev* primes, const TW* tw_arena,
                                     hipStream_t st)
 {
   switch (logn) {
-    case 13: return launch_prep_one<13>(polys, drop_row, drop_prime, batch, P, primes, tw_arena, st);
-    case 14: return launch_prep_one<14>(polys, drop_row, drop_prime, batch, P, primes, tw_arena, st);
-    case 15: return launch_prep_one<15>(polys, drop_row, drop_prime, batch, P, primes, tw_arena, st);
+    HX_SZ(13, launch_prep_one<13>(polys, drop_row, drop_prime, batch, P, primes, tw_arena, st))
+    HX_SZ(14, launch_prep_one<14>(polys, drop_row, drop_prime, batch, P, primes, tw_arena, st))
+    HX_SZ(15, launch_prep_one<15>(polys, drop_row, drop_prime, batch, P, primes, tw_arena, st))
   }
   return hipErrorInvalidValue;
 }
-hipError_t launch_moddown_apply_plain_pow2(int logn, const PolyBases& polys, const PolyBases& outs,
+hipError_t HX_ENTRY(launch_moddown_apply_plain_pow2)(int logn, const PolyBases& polys, const PolyBases& outs,
                                            const NttRows& keep, int nkeep, int batch, const ModDownApply& A,
                                            const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
 {
   switch (logn) {
-    case 13: return launch_apply_plain<13>(polys, outs, keep, nkeep, batch, A, primes, tw_arena, st);
-    case 14: return launch_apply_plain<14>(polys, outs, keep, nkeep, batch, A, primes, tw_arena, st);
-    case 15: return launch_apply_plain<15>(polys, outs, keep, nkeep, batch, A, primes, tw_arena, st);
+    HX_SZ(13, launch_apply_plain<13>(polys, outs, keep, nkeep, batch, A, primes, tw_arena, st))
+    HX_SZ(14, launch_apply_plain<14>(polys, outs, keep, nkeep, batch, A, primes, tw_arena, st))
+    HX_SZ(15, launch_apply_plain<15>(polys, outs, keep, nkeep, batch, A, primes, tw_arena, st))
   }
   return hipErrorInvalidValue;
 }
@@ -1222,35 +1254,32 @@ static hipError_t launch_small(bool inverse, const uint64_t* in, uint64_t* out, 
 }
 
 // forward transform of rows whose words are lazy, in [0,8q) (N = 2^13..2^15 only: ntt_lazy_input_ok)
-hipError_t launch_ntt_pow2_lazy_in(int logn, const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows, int batch,
+hipError_t HX_ENTRY(launch_ntt_pow2_lazy_in)(int logn, const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows, int batch,
                                    const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
 {
   switch (logn) {
-    case 13: return launch_one<13, false, 8>(in, out, rows, nrows, batch, primes, tw_arena, st);
-    case 14: return launch_one<14, false, 8>(in, out, rows, nrows, batch, primes, tw_arena, st);
-    case 15: return launch_one<15, false, 8>(in, out, rows, nrows, batch, primes, tw_arena, st);
+    HX_SZ(13, launch_one<13, false, 8>(in, out, rows, nrows, batch, primes, tw_arena, st))
+    HX_SZ(14, launch_one<14, false, 8>(in, out, rows, nrows, batch, primes, tw_arena, st))
+    HX_SZ(15, launch_one<15, false, 8>(in, out, rows, nrows, batch, primes, tw_arena, st))
   }
   return hipErrorInvalidValue;
 }
 
 // entry point used by engine.hip: transform `nrows` (<= MAX_ROWS) listed rows, in -> out
 // (in == out allowed: a workgroup reads its whole row before it writes it).
-hipError_t launch_ntt_pow2(int logn, bool inverse, const uint64_t* in, uint64_t* out,
+hipError_t HX_ENTRY(launch_ntt_pow2)(int logn, bool inverse, const uint64_t* in, uint64_t* out,
                            const NttRows& rows, int nrows, int batch, const PrimeDev* primes,
                            const TW* tw_arena, hipStream_t st)
 {
   if (logn >= 1 && logn <= 12)
     return launch_small(inverse, in, out, rows, nrows, batch, logn, primes, tw_arena, st);
   switch (logn) {
-    case 13:
-      return inverse ? launch_one<13, true>(in, out, rows, nrows, batch, primes, tw_arena, st)
-                     : launch_one<13, false>(in, out, rows, nrows, batch, primes, tw_arena, st);
-    case 14:
-      return inverse ? launch_one<14, true>(in, out, rows, nrows, batch, primes, tw_arena, st)
-                     : launch_one<14, false>(in, out, rows, nrows, batch, primes, tw_arena, st);
-    case 15:
-      return inverse ? launch_one<15, true>(in, out, rows, nrows, batch, primes, tw_arena, st)
-                     : launch_one<15, false>(in, out, rows, nrows, batch, primes, tw_arena, st);
+    HX_SZ(13, inverse ? launch_one<13, true>(in, out, rows, nrows, batch, primes, tw_arena, st)
+                      : launch_one<13, false>(in, out, rows, nrows, batch, primes, tw_arena, st))
+    HX_SZ(14, inverse ? launch_one<14, true>(in, out, rows, nrows, batch, primes, tw_arena, st)
+                      : launch_one<14, false>(in, out, rows, nrows, batch, primes, tw_arena, st))
+    HX_SZ(15, inverse ? launch_one<15, true>(in, out, rows, nrows, batch, primes, tw_arena, st)
+                      : launch_one<15, false>(in, out, rows, nrows, batch, primes, tw_arena, st))
   }
   return hipErrorInvalidValue;
 }

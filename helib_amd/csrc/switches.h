@@ -3,8 +3,10 @@
 // None of them is needed in production.  They select the older or more generic form of a path so that tests can
 // reach it and same-box A/B measurements can compare it (tools/gpu_calls.sh ab:...); every one leaves results
 // bit-identical.  They are listed for users in include/helib_amd.h and read ONCE PER CONTEXT: hx_ctx_create()
-// snapshots the environment (hxs::refresh), every later decision of the library reads the snapshot -- so a test
-// process can change a switch between two contexts, and nothing consults the environment on a hot path.
+// snapshots the environment INTO THE CONTEXT (hx_ctx::sw = hxs::read()), every later decision of the library reads
+// that context's copy -- so a test process can change a switch between two contexts without touching the first (no
+// process-global state: round 4 kept one struct that every hx_ctx_create rewrote under the running threads of earlier
+// contexts), and nothing consults the environment on a hot path.
 // (The C++ host has one switch of its own, HX_NO_LAZY_TENSOR in include/helib_amd_ctxt.hpp, read once per process.)
 #pragma once
 #include <cstdlib>
@@ -38,14 +40,9 @@ struct Switches {
   bool arena_trace = false;      // HX_ARENA_TRACE=1     one line on stderr per hipMalloc the slab arena makes
 };
 
-// (a plain struct of flags, replaced whole by refresh(): contexts are created before the threads that use them
-// start work, and a context created later in a running process sees the same environment)
-inline Switches& current()
-{
-  static Switches s;
-  return s;
-}
-inline void refresh()
+// The environment as it is now, by value: hx_ctx_create() stores it in the context (hx_ctx::sw) and every later decision
+// made for that context reads its own copy -- a context created later, under a changed environment, does not touch it.
+inline Switches read()
 {
   Switches s;
   auto on = [](const char* name) { return std::getenv(name) != nullptr; };
@@ -69,7 +66,7 @@ inline void refresh()
   if (const char* e = std::getenv("HX_WAIT_POLL_US"))
     s.wait_poll_us = std::atoi(e);
   s.arena_trace = on("HX_ARENA_TRACE");
-  current() = s;
+  return s;
 }
 
 }  // namespace hxs

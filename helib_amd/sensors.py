@@ -1,0 +1,123 @@
+"""Engine clock and package power of one GPU while a loop runs (measurement hygiene, not part of the data path).
+
+The fresh-multiply loop runs at the package power cap (1330-1400 W, 2.0-2.2 GHz: profiles/r04_power_and_clocks_under_load.txt)
+and the pool's boxes differ by 15 % on one binary; a benchmark line that carries the clock and the power it was measured at
+lets a reader tell a slow box from a regression.  `Sampler` reads the amdgpu hwmon files of the device (freq1_input = sclk in
+Hz, power1_average / power1_input in microwatts) from a background thread -- a few file reads per sample, no process spawned
+inside the timed region -- and falls back to `rocm-smi --json` when the files are not there."""
+import glob
+import json
+import os
+import subprocess
+import threading
+import time
+
+
+def _hwmon_dirs():
+    out = []
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+        if "-" in os.path.basename(card):
+            continue
+        hw = sorted(glob.glob(os.path.join(card, "device", "hwmon", "hwmon*")))
+        if hw and os.path.exists(os.path.join(card, "device", "vendor")):
+            try:
+                if open(os.path.join(card, "device", "vendor")).read().strip() == "0x1002":
+                    out.append(hw[0])
+            except OSError:
+                pass
+    return out
+
+
+def _read_int(path):
+    try:
+        with open(path) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return None
+
+
+def sample_sysfs(device=0):
+    dirs = _hwmon_dirs()
+    if device >= len(dirs):
+        return None
+    d = dirs[device]
+    hz = _read_int(os.path.join(d, "freq1_input"))
+    uw = _read_int(os.path.join(d, "power1_average"))
+    if uw is None:
+        uw = _read_int(os.path.join(d, "power1_input"))
+    if hz is None and uw is None:
+        return None
+    return {"sclk_mhz": None if hz is None else round(hz / 1e6), "power_w": None if uw is None else round(uw / 1e6, 1)}
+
+
+def sample_rocm_smi(device=0):
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--showpower", "--json"], capture_output=True,
+                           text=True, timeout=10)
+        d = json.loads(r.stdout)
+        card = d.get(f"card{device}") or next(iter(d.values()))
+        sclk = next((v for k, v in card.items() if k.lower().startswith("sclk")), None)
+        power = next((v for k, v in card.items() if "power" in k.lower() and "w" in k.lower()), None)
+        mhz = None
+        if sclk:
+            import re
+            m = re.search(r"(\d+)\s*mhz", str(sclk), re.I)
+            mhz = int(m.group(1)) if m else None
+        return {"sclk_mhz": mhz, "power_w": None if power is None else float(power)}
+    except Exception:
+        return None
+
+
+class Sampler:
+    """with Sampler(device) as s: <timed loop>; s.summary() -> {"clock_mhz_under_load": [...], "power_w": [...], ...}"""
+
+    def __init__(self, device=0, period_s=0.25, max_samples=64):
+        self.device, self.period, self.max = device, period_s, max_samples
+        self.samples, self.source = [], None
+        self._stop = threading.Event()
+        self._thread = None
+
+    def _one(self):
+        s = sample_sysfs(self.device)
+        if s is not None:
+            self.source = self.source or "amdgpu hwmon (freq1_input, power1_average)"
+            return s
+        s = sample_rocm_smi(self.device)
+        if s is not None:
+            self.source = self.source or "rocm-smi --showclocks --showpower --json"
+        return s
+
+    def _run(self):
+        while not self._stop.is_set() and len(self.samples) < self.max:
+            s = self._one()
+            if s is None:
+                return
+            s["t"] = time.perf_counter()
+            self.samples.append(s)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=15)
+        return False
+
+    def summary(self):
+        # the first sample is taken as the loop starts (the queue is still filling): the figures are over the rest
+        body = self.samples[1:] if len(self.samples) > 3 else self.samples
+        clk = [s["sclk_mhz"] for s in body if s.get("sclk_mhz")]
+        pw = [s["power_w"] for s in body if s.get("power_w")]
+        if not clk and not pw:
+            return {"clock_mhz_under_load": None, "power_w": None, "sensor_source": "unavailable on this box"}
+
+        def three(v):   # first, middle, last of the window
+            return [v[0], v[len(v) // 2], v[-1]] if v else None
+        return {"clock_mhz_under_load": three(clk), "power_w": three(pw),
+                "clock_mhz_min_max": [min(clk), max(clk)] if clk else None,
+                "power_w_min_max": [min(pw), max(pw)] if pw else None,
+                "sensor_samples": len(body), "sensor_source": self.source}

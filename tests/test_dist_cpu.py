@@ -1,5 +1,6 @@
 """world_size-2 gloo test of the N>1 harness (batch sharding, barrier, max-over-ranks timing)
 that bench.py uses on the GPUs with RCCL.  Runs on CPU."""
+import json
 import os
 import socket
 import subprocess
@@ -104,3 +105,33 @@ def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_world():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-launch"],
                          env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+def test_rccl_selfcheck_reports_instead_of_raising_and_restores_the_environment():
+    """helib_amd.dist.rccl_selfcheck (the N = 1 benchmark line's `config.rccl_selfcheck`): on a box without a GPU the
+    nccl backend cannot come up -- the function must say so in its result, leave no process group behind and put
+    MASTER_ADDR / MASTER_PORT / WORLD_SIZE back as they were."""
+    import numpy as np
+    from helib_amd import dist as hdist
+    import torch.distributed as td
+    before = {k: os.environ.get(k) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = hdist.rccl_selfcheck(np.arange(1024, dtype=np.uint64), None)
+    assert isinstance(out, dict) and "ok" in out and "torch" in out
+    import torch
+    if not torch.cuda.is_available():
+        assert out["ok"] is False and out.get("error")
+    assert not td.is_initialized()
+    assert {k: os.environ.get(k) for k in before} == before
+
+
+def test_launcher_keeps_a_log_per_rank(tmp_path):
+    """bench.py --gpus 2 --dry-launch: rank 1's output goes to rank1.log in HX_RANK_LOG_DIR instead of /dev/null, and the
+    N > 1 line says what it leaves out."""
+    env = dict(os.environ, HX_RANK_LOG_DIR=str(tmp_path))
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "2",
+                        "--batch", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["process_group_world_size"] == 2
+    assert (tmp_path / "rank1.log").exists()

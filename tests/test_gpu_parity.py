@@ -14,6 +14,16 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def hx():
+    # Import order matters for the tests that use torch (a caller-owned device buffer): PyTorch registers its GPU code
+    # objects with the HIP runtime lazily only while that runtime has not been initialised.  Imported AFTER this
+    # library has touched the device, every one of its fat binaries is unpacked on the spot -- on a fresh box, with a
+    # cold comgr cache (~/.cache/comgr, 1.4 GB), that took more than five minutes inside one test (round 5, measured:
+    # tools/torch_import_pytest_matrix.sh).  So: torch first, where there is a torch.  (bench.py and smoke() import
+    # it first anyway; helib_amd itself never imports torch.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     from helib_amd import capi
     if capi.device_count() <= 0:    # a plain `pytest tests` on a CPU box: the device tests are skipped, not errors
         pytest.skip("no HIP device: the GPU parity tests run on an MI355X (pytest -m gpu)")

@@ -63,11 +63,12 @@ fi
 for st in "$@"; do
   case "$st" in
     tests)
-      timeout 1500 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $out/pytest_gpu.log ;;
+      timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $out/pytest_gpu.log ;;
     tests_fast)
-      timeout 900 python -m pytest tests -m gpu -q -x -k "not reference_benchmark_chain_size and not 32003 and not 5800 and not 6400" > $out/pytest_fast.log 2>&1; echo "pytest fast rc=$?"; tail -3 $out/pytest_fast.log ;;
+      # (--timeout: a test that hangs costs its own limit, with the stack of every thread in the log, not the whole call's)
+      timeout 900 python -m pytest tests -m gpu -q -x --timeout 150 -k "not reference_benchmark_chain_size and not 32003 and not 5800 and not 6400" > $out/pytest_fast.log 2>&1; echo "pytest fast rc=$?"; tail -3 $out/pytest_fast.log ;;
     tests:*)
-      timeout 1200 python -m pytest tests -m gpu -q -x -k "${st#tests:}" > $out/pytest_k.log 2>&1; echo "pytest -k rc=$?"; tail -4 $out/pytest_k.log ;;
+      timeout 1200 python -m pytest tests -m gpu -q -x --timeout 300 -k "${st#tests:}" > $out/pytest_k.log 2>&1; echo "pytest -k rc=$?"; tail -4 $out/pytest_k.log ;;
     smoke)
       timeout 300 python __graft_entry__.py --smoke > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $out/smoke.log ;;
     bench)
