@@ -554,3 +554,22 @@ def test_one_word_form_of_the_mod_down_correction_restated():
             if dmod > p // 2 or (p % 2 == 0 and dmod == p // 2 and delta < 0):
                 dmod -= p
             assert S == (1 if neg else 0) + dmod and (x - qd * S) % p == 0
+
+
+def test_ckks_verification_is_signal_relative_at_low_precision():
+    """at precision(1) the bound a CKKS product reports (O(1)) exceeds its coefficients (~1e-4), so
+    "within the bound" accepts an all-zero or a foreign product.  helib_amd.host.ckks_correlation is the second
+    criterion of Session.verify / bench.py for r < 10: the decoded product must correlate with the expected one beyond
+    8 standard deviations of what an unrelated vector shows (1/sqrt(N))."""
+    from helib_amd.host import ckks_correlation
+    rng = np.random.default_rng(3)
+    n = 32768
+    want = rng.normal(0, 1e-4, n)
+    thr = 8.0 / np.sqrt(n)
+    for snr in (4.0, 1.0, 0.25):                                   # rms signal / rms noise
+        got = want + rng.normal(0, 1e-4 / snr, n)
+        c = ckks_correlation(got, want)
+        assert abs(c - 1 / np.sqrt(1 + 1 / snr ** 2)) < 0.02 and c > thr
+    assert ckks_correlation(np.zeros(n), want) == 0.0 < thr                       # an all-zero product
+    assert abs(ckks_correlation(rng.normal(0, 1e-4, n), want)) < thr              # a product of other operands
+    assert abs(ckks_correlation(rng.normal(0, 3e-4, n), want)) < thr              # noise alone
