@@ -78,7 +78,7 @@ struct ConvIO {
   template <int LOGN>
   __device__ __forceinline__ void store_prefetch(unsigned, StorePrefetch&) const {}
   // the forward transform's "store": v[i] <- v[i] * hat[i], canonical (the inverse transform's input)
-  template <int LOGN, int B, bool EST>
+  template <int LOGN, class AR, int B, bool EST>
   __device__ __forceinline__ void store_all(unsigned tid, uint64_t (&v)[32], const QC& qc, StorePrefetch&) const
   {
     // groups of two pairs (8 registers) ahead of their arithmetic: all 32 pairs at once would need 128

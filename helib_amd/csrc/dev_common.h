@@ -75,6 +75,10 @@ struct ModDownRow {
   TW qdm;              // qd mod q_r
   TW inv;              // qd^-1 mod q_r
   TW cf;               // fused mod-up: F * qd^-1 mod q_r (multiplies c_r instead of inv)
+                       // (inv.wp, cf.wp: the companion word of the KEPT row's arithmetic -- Shoup's quotient, or the
+                       // Proth form w 2^64 mod q_r when PrimeDev::proth)
+  uint64_t cf_r2;      // Proth rows: cf 2^128 mod q_r -- multiplies a data x data product that was reduced by
+                       // mont_redc128 (and so carries 2^-64) in the tensor form of the apply kernel; else 0
   uint32_t out_row;
   uint32_t mode;       // 0/1: c_r <- c_r*cf - v (cf = inv or F*inv) ; 2: new row, c_r = 0 (cf = 0)
                        // (|S| < q_r is checked by the host before it takes the fused path)

@@ -135,6 +135,11 @@ static inline uint64_t tw_companion(const PrimeHost& ph, uint64_t w)
 {
   return ph.proth ? hx::tw_mont_form(w, ph.q) : hxh::shoup(w, ph.q);
 }
+// w 2^128 mod q for a Proth-form prime (the constant that multiplies a value reduced by mont_redc128), else 0
+static inline uint64_t tw_r2(const PrimeHost& ph, uint64_t w)
+{
+  return ph.proth ? hx::tw_mont_form(hx::tw_mont_form(w, ph.q), ph.q) : 0;
+}
 
 struct ExtPlan {
   ExtPlanDev dev;
@@ -3425,7 +3430,8 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
         cf = hxh::mulmod(cf, c->primes[add_idx[j]].q % q, q);
       hr[t].mode = nadd > 0 ? 1 : 0;
       hr[t].cf.w = cf;
-      hr[t].cf.wp = hxh::shoup(cf, q);
+      hr[t].cf.wp = tw_companion(c->primes[pr], cf);
+      hr[t].cf_r2 = tw_r2(c->primes[pr], cf);
     }
     key.push_back(((uint64_t)pr << 28) | ((uint64_t)kr.row[t] << 12) | hr[t].mode);
   }
@@ -3766,14 +3772,16 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
       hr[i].qdm.w = qdm;
       hr[i].qdm.wp = hxh::shoup(qdm, q);
       hr[i].inv.w = inv;
-      hr[i].inv.wp = hxh::shoup(inv, q);
+      hr[i].inv.wp = tw_companion(c->primes[pr], inv);
       hr[i].out_row = (uint32_t)((r == last && drow != last) ? drow : r);
       hr[i].mode = 0;
       hr[i].cf = hr[i].inv;
+      hr[i].cf_r2 = tw_r2(c->primes[pr], inv);
       if (nadd > 0) {
         if (r >= nrows_old) {
           hr[i].mode = 2;  // a row the mod-up adds: c_r = 0, i.e. cf = 0 (its slot is never initialised)
           hr[i].cf.w = hr[i].cf.wp = 0;
+          hr[i].cf_r2 = 0;
         } else {
           uint64_t F = 1;
           for (int j = 0; j < nadd; j++)
@@ -3781,7 +3789,8 @@ static int scale_down_impl(hx_poly* a, hx_poly** others, int nother, const int* 
           uint64_t cf = hxh::mulmod(F, inv, q);
           hr[i].mode = 1;
           hr[i].cf.w = cf;
-          hr[i].cf.wp = hxh::shoup(cf, q);
+          hr[i].cf.wp = tw_companion(c->primes[pr], cf);
+          hr[i].cf_r2 = tw_r2(c->primes[pr], cf);
         }
       }
       key.push_back(((uint64_t)pr << 28) | ((uint64_t)hr[i].out_row << 12) | hr[i].mode);

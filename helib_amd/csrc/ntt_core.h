@@ -247,6 +247,30 @@ HXD uint64_t mont_acc(uint64_t y, TWM W, const QC& c, uint64_t x)
   return D;
 }
 HXD uint64_t mont_mul(uint64_t y, TWM W, const QC& c) { return mont_acc(y, W, c, 0); }
+// The reduction alone, for a 128-bit value T = lo + hi 2^64 that is already there (a product of two data words, or a
+// sum of two): (T + M q) / 2^64 = T 2^-64 (mod q), in (0, T / 2^64 + q (1 + 2^-32)); needs hi < 2^62.  Two
+// multiply-adds against the seven multiplications and up to three conditional subtractions of a Barrett reduction
+// of the same value; the stray 2^-64 is folded into the constant the value is multiplied by next.
+HXD uint64_t mont_redc128(uint64_t lo, uint64_t hi, const QC& c)
+{
+  const uint32_t n0 = ~(uint32_t)lo;
+  uint64_t G = (uint64_t)n0 * c.qh + c.c1;
+  HX_KEEP64(G);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_MONT_PLAINADD)
+  G = mad_x1((uint32_t)(lo >> 32), G);
+#else
+  G += (uint32_t)(lo >> 32);
+#endif
+  const uint32_t n1 = ~(uint32_t)G;
+  uint64_t D = (uint64_t)n1 * c.qh + hi;
+  HX_KEEP64(D);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HX_MONT_PLAINADD)
+  D = mad_x1((uint32_t)(G >> 32), D);
+#else
+  D += (uint32_t)(G >> 32);
+#endif
+  return D;
+}
 // x in [0, 2m) -> [0, m)
 HXD uint64_t csub(uint64_t x, uint64_t m)
 {
@@ -523,6 +547,7 @@ HXD void gs_bfly_p_last(uint64_t& X, uint64_t& Y, TWM wNinv, TWM wS0Ninv, const 
 // U = bound units per q (1: whole q; 16: sixteenths).  fwd_out/inv_after: the compile-time schedules.
 struct ArShoup {
   using Tw = TW;
+  static constexpr bool PROTH = false;
   static constexpr int U = 1;
   static constexpr int FWD_LOAD_MAX = 12;   // largest IO::LOAD_BOUND (units of q) a forward pass accepts
   static constexpr int INV_OUT = 4;         // bound (units of q) of what the inverse transform hands its store
@@ -542,6 +567,7 @@ struct ArShoup {
 };
 struct ArProth {
   using Tw = TWM;
+  static constexpr bool PROTH = true;
   static constexpr int U = 16;
   static constexpr int FWD_LOAD_MAX = 12;
   static constexpr int INV_OUT = 2;
@@ -889,6 +915,15 @@ struct io_skip_load : std::false_type {};
 template <class IO>
 struct io_skip_load<IO, std::void_t<decltype(IO::SKIP_LOAD)>> : std::integral_constant<bool, IO::SKIP_LOAD> {};
 
+// The bound (units of q) of what an IO functor's load hands the forward transform: IO::LOAD_BOUND, or -- when the
+// functor's own arithmetic depends on the row's arithmetic (the mod-down apply loads: a Shoup product is below 4q, a
+// Proth-form one below 2q) -- IO::load_bound<AR>().
+template <class IO, class AR, class = void>
+struct io_load_bound : std::integral_constant<int, IO::LOAD_BOUND> {};
+template <class IO, class AR>
+struct io_load_bound<IO, AR, std::void_t<decltype(IO::template load_bound<AR>())>>
+    : std::integral_constant<int, IO::template load_bound<AR>()> {};
+
 // Plain-pointer row accessor (CPU replay; also valid on the device).
 struct PtrIO {
   static constexpr int LOAD_BOUND = 1;
@@ -969,15 +1004,16 @@ struct RowNTT {
     // bounds between the forward passes; the IO functor states the bound of what it loads
     // (IO::LOAD_BOUND, 1 = canonical) and whether its store takes the lazy value (IO::LAZY_STORE)
     // (in the policy's units, AR::U per q; the IO functors state and take bounds in whole q)
-    constexpr int L0 = IO::LOAD_BOUND * AR::U;
+    constexpr int LB = io_load_bound<IO, AR>::value;
+    constexpr int L0 = LB * AR::U;
     constexpr int FA = pass_bound_out<AR, 5, false, 31, L0>();
     constexpr int FB = pass_bound_out<AR, 5, false, 31, FA>();
     constexpr int FCU = pass_bound_out<AR, G::LC, false, G::GC - 1, FB>();
     constexpr int FC = (FCU + AR::U - 1) / AR::U;
-    static_assert(IO::LOAD_BOUND <= AR::FWD_LOAD_MAX && FA <= 16 * AR::U && FB <= 16 * AR::U && FCU <= 16 * AR::U, "lazy bounds");
+    static_assert(LB <= AR::FWD_LOAD_MAX && FA <= 16 * AR::U && FB <= 16 * AR::U && FCU <= 16 * AR::U, "lazy bounds");
     if constexpr (PH == 0) {
       if constexpr (IO::PIPELINED) {
-        io.template load_all<LOGN>(tid, v, c);  // (software-pipelined element loads, see ModDownIO)
+        io.template load_all<LOGN, AR>(tid, v, c);  // (software-pipelined element loads, see ModDownIO)
       } else {
 #pragma unroll
         for (int e = 0; e < 32; e++) {
@@ -1033,9 +1069,9 @@ struct RowNTT {
       // per element fragments the schedule into 32 blocks and the register file spills)
       if constexpr (IO::LAZY_STORE) {
         if (c.mu32)
-          io.template store_all<LOGN, FC, true>(tid, v, c, pre);
+          io.template store_all<LOGN, AR, FC, true>(tid, v, c, pre);
         else
-          io.template store_all<LOGN, FC, false>(tid, v, c, pre);
+          io.template store_all<LOGN, AR, FC, false>(tid, v, c, pre);
       } else if (c.mu32) {
 #pragma unroll
         for (int i = 0; i < 32; i++) {

@@ -219,6 +219,9 @@ struct ModDownIO {
   // the load is x*inv (shoup4: [0,4q)) plus q - S in (0,2q); the store takes the lazy
   // transform output and normalises once, after the subtraction
   static constexpr int LOAD_BOUND = PLAIN ? 8 : 6;   // (PLAIN: ExtArgs::lazy_out words, [0,8q))
+  // Proth-form rows: x*inv is a Montgomery product below 2q (mont_acc), plus q - S in (0,2q)
+  template <class AR>
+  static constexpr int load_bound() { return PLAIN ? 8 : (AR::PROTH ? 4 : 6); }
   static constexpr bool LAZY_STORE = true;
   // Element IO is software-pipelined in groups of IOG elements.  Round 1 loaded x, S (and, in the
   // store, c_r) inside the same scheduling region as the ~40 instructions that consume them, one
@@ -252,7 +255,7 @@ struct ModDownIO {
     v2i32 a = hx_buffer_load_v2(r, (int)(tid * 8u), (int)(c * 8u), 0);
     return ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
   }
-  template <int LOGN>
+  template <int LOGN, class AR>
   __device__ __forceinline__ void load_all(unsigned tid, uint64_t (&v)[32], const QC& qc) const
   {
     static_for<0, 32>([&](auto E) {
@@ -274,10 +277,13 @@ struct ModDownIO {
         });
       static_for<0, IOG>([&](auto J) {
         constexpr int j = decltype(J)::value, e = g * IOG + j;
-        // x*inv in [0,4q) plus q - S in (0,2q): |S| <= ptxtSpace/2 + 1 < q (host-checked), so the
-        // two's-complement difference q - S is the right positive number whatever the sign of S,
+        // x*inv in [0,4q) (Proth-form rows: (0,2q)) plus q - S in (0,2q): |S| <= ptxtSpace/2 + 1 < q (host-checked),
+        // so the two's-complement difference q - S is the right positive number whatever the sign of S,
         // and it rides on the multiply-add chain of the product as its addend -- no sign handling
-        v[e] = shoup4_acc(v[e], inv, qc.nq, q - sb[g & 1][j]);
+        if constexpr (AR::PROTH)
+          v[e] = mont_acc(v[e], inv.wp, qc, q - sb[g & 1][j]);   // (x < qd < 2^60: below the operand limit)
+        else
+          v[e] = shoup4_acc(v[e], inv, qc.nq, q - sb[g & 1][j]);
       });
       HX_SCHED_FENCE();
     });
@@ -311,9 +317,13 @@ struct ModDownIO {
     });
   }
   // the whole store loop of the forward transform (v[i] in [0, B q), evaluation order)
-  template <int LOGN, int B, bool EST>
+  template <int LOGN, class AR, int B, bool EST>
   __device__ __forceinline__ void store_all(unsigned tid, uint64_t (&v)[32], const QC& qc, StorePrefetch& pre) const
   {
+    // Proth-form rows: c_r*cf as a Montgomery product in (0,2q) riding on B q - x > 0 -- no conditional
+    // subtraction of x first (the Shoup form takes x below 8q so that 8q - x is positive), one normalisation
+    static_assert(!AR::PROTH || B <= 14, "B q - x + 2q must stay below 16q");
+    const uint64_t Bq = (uint64_t)B * qc.q;
     // (rows added by a fused mod-up have no c_r: the host gives them cf = 0, so whatever their
     // never-initialised slot holds is multiplied away and the output is -NTT(.); no branch here --
     // a branch would let the compiler sink the prefetched loads below the last register pass)
@@ -332,10 +342,14 @@ struct ModDownIO {
       static_for<0, IOG>([&](auto J) {
         constexpr int j = decltype(J)::value, i = g * IOG + j;
         uint64_t x = v[i];
-        if constexpr (B > 8)
-          x = csub(x, qc.q8);                            // [0,8q)
-        // c_r*cf - x as a value in (0,12q), normalised once
-        put(tid, eval_const<LOGN>(i), norm_from<12, EST>(shoup4_acc(cb[g & 1][j], cf, qc.nq, qc.q8 - x), qc));
+        if constexpr (AR::PROTH) {
+          put(tid, eval_const<LOGN>(i), norm_from<B + 2, EST>(mont_acc(cb[g & 1][j], cf.wp, qc, Bq - x), qc));
+        } else {
+          if constexpr (B > 8)
+            x = csub(x, qc.q8);                            // [0,8q)
+          // c_r*cf - x as a value in (0,12q), normalised once
+          put(tid, eval_const<LOGN>(i), norm_from<12, EST>(shoup4_acc(cb[g & 1][j], cf, qc.nq, qc.q8 - x), qc));
+        }
       });
       HX_SCHED_FENCE();
     });
@@ -623,12 +637,15 @@ ntt_moddown_prep_multi_tensor_kernel(TensorSrc T, PrepMulti M, int batch, ModDow
 template <bool PLAIN>
 struct ModDownTensorIO {
   static constexpr int LOAD_BOUND = PLAIN ? 8 : 6;   // (PLAIN: ExtArgs::lazy_out words, [0,8q))
+  template <class AR>
+  static constexpr int load_bound() { return PLAIN ? 8 : (AR::PROTH ? 4 : 6); }
   static constexpr bool LAZY_STORE = true;
   static constexpr bool PIPELINED = !PLAIN;
   static constexpr int IOG = 4;
   struct StorePrefetch {};
   v4i32 rx, rS, ra, rb, rc, rd, ro;
   TW inv, cf;
+  uint64_t cf_r2;   // Proth rows: cf 2^128 mod q (ModDownRow::cf_r2)
   uint64_t q, mu;
   uint32_t part, k;
   // operand rows: [row][batch][N] slabs of the four operands at `roff`; a row the fused mod-up adds has no operand
@@ -639,7 +656,7 @@ struct ModDownTensorIO {
         ra(make_rsrc(has_row ? (part_ == 2 ? T.a1 : T.a0) + roff : o_row, bytes)),
         rb(make_rsrc(has_row ? (part_ == 0 ? T.b0 : T.b1) + roff : o_row, bytes)),
         rc(make_rsrc(has_row ? T.a1 + roff : o_row, bytes)), rd(make_rsrc(has_row ? T.b0 + roff : o_row, bytes)),
-        ro(make_rsrc(o_row, bytes)), inv(R.inv), cf(R.cf), q(pd->q), mu(pd->mu63), part(part_), k(pd->k)
+        ro(make_rsrc(o_row, bytes)), inv(R.inv), cf(R.cf), cf_r2(R.cf_r2), q(pd->q), mu(pd->mu63), part(part_), k(pd->k)
   {
   }
   static __device__ __forceinline__ uint64_t ld(const v4i32& r, unsigned tid, unsigned c)
@@ -653,7 +670,7 @@ struct ModDownTensorIO {
     return ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x;
   }
   // the load of ModDownIO<false>: x*inv - S with S one group ahead
-  template <int LOGN>
+  template <int LOGN, class AR>
   __device__ __forceinline__ void load_all(unsigned tid, uint64_t (&v)[32], const QC& qc) const
   {
     static_for<0, 32>([&](auto E) {
@@ -675,7 +692,10 @@ struct ModDownTensorIO {
         });
       static_for<0, IOG>([&](auto J) {
         constexpr int j = decltype(J)::value, e = g * IOG + j;
-        v[e] = shoup4_acc(v[e], inv, qc.nq, q - sb[g & 1][j]);
+        if constexpr (AR::PROTH)
+          v[e] = mont_acc(v[e], inv.wp, qc, q - sb[g & 1][j]);
+        else
+          v[e] = shoup4_acc(v[e], inv, qc.nq, q - sb[g & 1][j]);
       });
       HX_SCHED_FENCE();
     });
@@ -725,17 +745,29 @@ struct ModDownTensorIO {
   }
   template <int LOGN>
   __device__ __forceinline__ void store_prefetch(unsigned, StorePrefetch&) const {}
-  template <int LOGN, int B, bool EST, bool P1>
+  template <int LOGN, class AR, int B, bool EST, bool P1>
   __device__ __forceinline__ void store_part(unsigned tid, uint64_t (&v)[32], const QC& qc) const
   {
     constexpr int CPG = P1 ? 2 : 4, NG = 32 / CPG;   // coefficients per group, groups
+    static_assert(!AR::PROTH || B <= 14, "B q - x + 2q must stay below 16q");
+    const uint64_t Bq = (uint64_t)B * qc.q;
     auto one = [&](auto I, uint64_t x0, uint64_t y0, uint64_t x1, uint64_t y1) {
       constexpr int i = decltype(I)::value;
-      const uint64_t c = P1 ? tensor_value(1, x0, x1, y1, y0, q, mu, k) : tensor_value(0, x0, 0, y0, 0, q, mu, k);
       uint64_t x = v[i];
-      if constexpr (B > 8)
-        x = csub(x, qc.q8);
-      put(tid, eval_const<LOGN>(i), norm_from<12, EST>(shoup4_acc(c, cf, qc.nq, qc.q8 - x), qc));
+      if constexpr (AR::PROTH) {
+        // the 128-bit product (part 1: the sum of two, below 2 q^2) goes through the Proth-form reduction alone --
+        // two multiply-adds instead of the Barrett's seven multiplications and three conditional subtractions --
+        // and carries 2^-64; the constant it is multiplied by next is cf 2^128 (ModDownRow::cf_r2), so that the
+        // Montgomery product gives (a b) cf exactly; B q - x > 0 rides on it, one normalisation at the end
+        const u128 S = P1 ? (u128)x0 * y0 + (u128)x1 * y1 : (u128)x0 * y0;   // (x0, y0, x1, y1) = (a0, b1, a1, b0)
+        const uint64_t c2 = mont_redc128((uint64_t)S, (uint64_t)(S >> 64), qc);   // (0, 2q)
+        put(tid, eval_const<LOGN>(i), norm_from<B + 2, EST>(mont_acc(c2, cf_r2, qc, Bq - x), qc));
+      } else {
+        const uint64_t c = P1 ? tensor_value(1, x0, x1, y1, y0, q, mu, k) : tensor_value(0, x0, 0, y0, 0, q, mu, k);
+        if constexpr (B > 8)
+          x = csub(x, qc.q8);
+        put(tid, eval_const<LOGN>(i), norm_from<12, EST>(shoup4_acc(c, cf, qc.nq, qc.q8 - x), qc));
+      }
     };
     uint64_t wb[2][8];
     request<LOGN, P1, 0>(tid, wb[0]);
@@ -757,13 +789,13 @@ struct ModDownTensorIO {
       HX_SCHED_FENCE();
     });
   }
-  template <int LOGN, int B, bool EST>
+  template <int LOGN, class AR, int B, bool EST>
   __device__ __forceinline__ void store_all(unsigned tid, uint64_t (&v)[32], const QC& qc, StorePrefetch&) const
   {
     if (part == 1)   // (wave-uniform: one of the two loops runs)
-      store_part<LOGN, B, EST, true>(tid, v, qc);
+      store_part<LOGN, AR, B, EST, true>(tid, v, qc);
     else
-      store_part<LOGN, B, EST, false>(tid, v, qc);
+      store_part<LOGN, AR, B, EST, false>(tid, v, qc);
   }
   __device__ __forceinline__ void put(unsigned tid, unsigned c, uint64_t o) const
   {
