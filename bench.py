@@ -1338,6 +1338,15 @@ def main():
                     if i >= 2:
                         ts.append((time.perf_counter() - t0) * 1e3)
                 ts.sort()
+                if not ckks:
+                    try:     # batched Encrypt / Decrypt in the C++ host (the reference times one ciphertext per call)
+                        extra["batched_encrypt_decrypt"] = sess.encrypt_decrypt_batch(min(B, 64), 3)
+                        if not extra["batched_encrypt_decrypt"]["all_elements_round_trip"]:
+                            raise SystemExit("bench: DecryptBatch(EncryptBatch(m)) != m")
+                    except SystemExit:
+                        raise
+                    except Exception as e:
+                        extra["batched_encrypt_decrypt"] = f"unavailable: {type(e).__name__}: {str(e)[:160]}"
                 extra["batch1_latency_ms"] = round(ts[len(ts) // 2], 4)
                 extra["batch1_latency_ms_min"] = round(ts[0], 4)
                 try:

@@ -4,6 +4,7 @@
 // DoubleCRT / SecKey on the timed path.  Host code only: every polynomial operation goes through
 // libhelib_amd.so (include/helib_amd.h); there is no CPU arithmetic path here.
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <random>
@@ -308,6 +309,44 @@ extern "C" int hxh_arena_stats(hxh_session* s, uint64_t out[4])
     return -1;
   }
   return guarded([&] { s->dev->arenaStats(out); });
+}
+
+// Batched encryption / decryption timed inside the C++ host (benchmarks/bgv_basic.cpp:186-211 time ONE
+// PubKey::Encrypt / SecKey::Decrypt per iteration): SecKey::EncryptBatch / DecryptBatch over `batch` random plaintexts,
+// `reps` times each, wall clock with the device drained.  out = {ms per ciphertext encrypted, ms per ciphertext
+// decrypted, batch, 1.0 when every element decrypted to its plaintext}.  BGV only.
+extern "C" int hxh_encrypt_decrypt_batch(hxh_session* s, int batch, int reps, double out[4])
+{
+  if (!s || !out || batch < 1 || reps < 1) {
+    g_err = "bad argument";
+    return -1;
+  }
+  return guarded([&] {
+    const ChainContext& cc = *s->cc;
+    if (cc.ckks)
+      throw LogicError("hxh_encrypt_decrypt_batch: BGV sessions only");
+    const size_t n = (size_t)cc.phim;
+    std::vector<long> msgs((size_t)batch * n);
+    uint64_t ps = 0x243f6a8885a308d3ull;
+    for (auto& v : msgs)
+      v = (long)(((unsigned __int128)sm64(ps) * (uint64_t)cc.ptxtSpace) >> 64);
+    Ctxt warm = s->sk->EncryptBatch(msgs, batch);   // (plans, arena slabs)
+    s->dev->sync();
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; r++) {
+      Ctxt ct = s->sk->EncryptBatch(msgs, batch);
+      s->dev->sync();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    std::vector<long> dec;
+    for (int r = 0; r < reps; r++)
+      dec = s->sk->DecryptBatch(warm);
+    auto t2 = std::chrono::steady_clock::now();
+    out[0] = std::chrono::duration<double, std::milli>(t1 - t0).count() / ((double)reps * batch);
+    out[1] = std::chrono::duration<double, std::milli>(t2 - t1).count() / ((double)reps * batch);
+    out[2] = (double)batch;
+    out[3] = dec == msgs ? 1.0 : 0.0;
+  });
 }
 
 extern "C" int hxh_session_destroy(hxh_session* s)

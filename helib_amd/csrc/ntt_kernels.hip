@@ -354,12 +354,15 @@ struct ModDownIO {
       HX_SCHED_FENCE();
     });
   }
+  // (the store is written out as well: the s_waitcnt vmcnt(N) of pinned_wait counts the memory operations issued
+  // after the load it waits for -- the pinned loads of the next group AND these stores -- so each of them must be
+  // exactly one instruction, at the place it is written; a compiler-emitted store could be merged, split or moved)
   __device__ __forceinline__ void put(unsigned tid, unsigned c, uint64_t o) const
   {
-    v2i32 d;
-    d.x = (int)(uint32_t)o;
-    d.y = (int)(uint32_t)(o >> 32);
-    hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), HX_NT);
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" HX_NT_ASM
+                 :
+                 : "v"(o), "v"((int)(tid * 8u)), "s"(ro), "s"((int)(c * 8u))
+                 : "memory");
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
   __device__ __forceinline__ TWM last_tw(TWM def, int) const { return def; }
@@ -797,12 +800,15 @@ struct ModDownTensorIO {
     else
       store_part<LOGN, AR, B, EST, false>(tid, v, qc);
   }
+  // (the store is written out as well: the s_waitcnt vmcnt(N) of pinned_wait counts the memory operations issued
+  // after the load it waits for -- the pinned loads of the next group AND these stores -- so each of them must be
+  // exactly one instruction, at the place it is written; a compiler-emitted store could be merged, split or moved)
   __device__ __forceinline__ void put(unsigned tid, unsigned c, uint64_t o) const
   {
-    v2i32 d;
-    d.x = (int)(uint32_t)o;
-    d.y = (int)(uint32_t)(o >> 32);
-    hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), HX_NT);
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" HX_NT_ASM
+                 :
+                 : "v"(o), "v"((int)(tid * 8u)), "s"(ro), "s"((int)(c * 8u))
+                 : "memory");
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
   __device__ __forceinline__ TWM last_tw(TWM def, int) const { return def; }

@@ -38,6 +38,7 @@ def lib(path=None):
             "hxh_chain_primes": [vp, vp, ip, vp], "hxh_ctxt_info": [vp, ip, ip, vp],
             "hxh_ctxt_rows": [vp, ip, ip, ip, vp, vp, ip, vp],
             "hxh_relin_matrix": [vp, vp, vp, vp, ip, vp, vp], "hxh_arena_stats": [vp, vp],
+            "hxh_encrypt_decrypt_batch": [vp, ip, ip, vp],
         }
         for name, args in sig.items():
             f = getattr(L, name)
@@ -50,7 +51,7 @@ def lib(path=None):
 SYMBOLS = ["hxh_session_create", "hxh_session_destroy", "hxh_session_info", "hxh_multiply", "hxh_multiply_single",
            "hxh_plaintext", "hxh_decrypt", "hxh_result_primes", "hxh_last_error", "hxh_export_keys",
            "hxh_session_create_with_keys", "hxh_chain_primes", "hxh_ctxt_info", "hxh_ctxt_rows", "hxh_relin_matrix",
-           "hxh_arena_stats"]
+           "hxh_arena_stats", "hxh_encrypt_decrypt_batch"]
 
 
 def ckks_correlation(got, want):
@@ -171,6 +172,13 @@ class Session:
         out = (C.c_uint64 * 4)()
         self._chk(self.L.hxh_arena_stats(self.h, out))
         return {"reserved_bytes": int(out[0]), "in_use_bytes": int(out[1]), "hipMalloc_calls": int(out[2]), "parked_blocks": int(out[3])}
+
+    def encrypt_decrypt_batch(self, batch, reps=3):
+        """SecKey::EncryptBatch / DecryptBatch timed in the C++ host: ms per ciphertext, and whether all round-tripped"""
+        out = (C.c_double * 4)()
+        self._chk(self.L.hxh_encrypt_decrypt_batch(self.h, batch, reps, out))
+        return {"encrypt_ms_per_ciphertext": round(out[0], 4), "decrypt_ms_per_ciphertext": round(out[1], 4),
+                "batch": int(out[2]), "all_elements_round_trip": bool(out[3] == 1.0)}
 
     # ---- the checks bench.py and the tests apply to a kept product ----
     @staticmethod

@@ -79,6 +79,11 @@ int hxh_ctxt_rows(hxh_session* s, int level, int which, int part, uint64_t* out,
 int hxh_relin_matrix(hxh_session* s, uint64_t* b, uint64_t* a, int* idx_out, int cap_rows, int* ndig, int* nrows);
 /* hx_ctx_arena_stats of the session's device context: reserved bytes, bytes in use, hipMalloc calls, chunks */
 int hxh_arena_stats(hxh_session* s, uint64_t out[4]);
+/* SecKey::EncryptBatch / DecryptBatch (include/helib_amd_keys.hpp) over `batch` random plaintexts, `reps` times each,
+ * timed in the C++ host with the device drained: out = {ms per ciphertext encrypted, ms per ciphertext decrypted, batch,
+ * 1.0 when every element decrypted to its plaintext}.  BGV sessions.  (benchmarks/bgv_basic.cpp:186-211 time one
+ * ciphertext per call; this is the batched counterpart the engine's batch axis allows.) */
+int hxh_encrypt_decrypt_batch(hxh_session* s, int batch, int reps, double out[4]);
 
 const char* hxh_last_error(void);
 

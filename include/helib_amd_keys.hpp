@@ -482,6 +482,29 @@ public:
     d.FFT();
     return d;
   }
+  // The same for a batch: `coeffs` = B polynomials of phi(m) coefficients each, |coefficient| below every prime
+  // (samples, plaintext residues) -- one upload and ONE batched transform for all B (rows laid out [row][b][j]).
+  DoubleCRT fromCoeffsBatch(const IndexSet& idx, const std::vector<long>& coeffs, int B) const
+  {
+    const size_t n = (size_t)cc->phim;
+    if (coeffs.size() != (size_t)B * n)
+      throw InvalidArgument("fromCoeffsBatch: B * phi(m) coefficients expected");
+    std::vector<uint64_t> rows(idx.size() * (size_t)B * n);
+    for (size_t r = 0; r < idx.size(); r++) {
+      const long q = cc->primes[(size_t)idx[r]];
+      uint64_t* dst = &rows[r * (size_t)B * n];
+      for (size_t i = 0; i < (size_t)B * n; i++) {
+        long v = coeffs[i];
+        if (v >= q || v <= -q)
+          v %= q;
+        dst[i] = (uint64_t)(v < 0 ? v + q : v);
+      }
+    }
+    DoubleCRT d(*dev, idx, B, DoubleCRT::Uninitialized{});
+    d.setRows(rows);
+    d.FFT();
+    return d;
+  }
   // DoubleCRT::randomize: uniform residues (the evaluation rows of a uniform polynomial are uniform)
   // on the device (hx_randomize: the reference's rejection sampling over a ChaCha20 stream of the
   // sampler's key); `host` receives the rows when the caller needs them (key-switching `a` columns)
@@ -675,6 +698,26 @@ public:
     if (h[0] != KEYS_MAGIC || h[1] != (uint64_t)cc->m || h[2] != n || h[3] != L)
       throw InvalidArgument("importKeys: key material of another context");
     const size_t nks = (size_t)h[4];
+    {
+      // the whole blob is walked and checked BEFORE anything of this object changes: a truncated blob or a bad
+      // matrix header must not leave a half-initialised key behind (sKey set, so no retry; matrices missing)
+      size_t q = 8 + n + 2 * L * n;
+      for (size_t i = 0; i < nks; i++) {
+        if (q + 6 > nwords)
+          throw InvalidArgument("importKeys: truncated key material");
+        const size_t D = (size_t)w[q + 4], nr = (size_t)w[q + 5];
+        if (D < 1 || D > 64 || nr < 1 || nr > cc->primes.size())
+          throw InvalidArgument("importKeys: bad matrix shape");
+        if (q + 6 + nr > nwords)
+          throw InvalidArgument("importKeys: truncated key material");
+        for (size_t r = 0; r < nr; r++)
+          if (w[q + 6 + r] >= cc->primes.size())
+            throw InvalidArgument("importKeys: a matrix row is not a prime of the chain");
+        q += 6 + nr + 2 * D * nr * n;
+      }
+      if (q != nwords)
+        throw InvalidArgument(q > nwords ? "importKeys: truncated key material" : "importKeys: trailing words after the last matrix");
+    }
     ptxtSpace = (long)h[5];
     skBound = dbl(h[6]);
     pubEncrKeyNoise = dbl(h[7]);
@@ -762,6 +805,63 @@ public:
     return ct;
   }
 
+  // B encryptions as ONE batched ciphertext (the engine's batch axis: B independent DoubleCRT objects per part).
+  // Element b is exactly what the b-th of B consecutive Encrypt() calls returns -- the samples are drawn in that
+  // order from the same sampler (r, e0, e1 per element) -- but the ring work is three batched transforms, three
+  // batched products / sums and one upload per polynomial instead of B of each (benchmarks/bgv_basic.cpp:186-197
+  // times one PubKey::Encrypt per iteration; this is its batched counterpart).  The noise estimate of the batch is
+  // the largest of its elements' (one bookkeeping record per batched ciphertext).
+  Ctxt EncryptBatch(const std::vector<long>& ptxts, int B)
+  {
+    if (!pubEncrKey0)
+      throw LogicError("no public encryption key");
+    if (cc->ckks)
+      throw LogicError("EncryptBatch on a CKKS context");
+    const long p = ptxtSpace;
+    const IndexSet& idx = cc->ctxtPrimes;
+    const size_t n = (size_t)cc->phim;
+    if (B < 1 || ptxts.size() != (size_t)B * n)
+      throw InvalidArgument("EncryptBatch: B * phi(m) plaintext coefficients expected");
+    std::vector<long> r((size_t)B * n), e[2], pt((size_t)B * n);
+    e[0].resize((size_t)B * n);
+    e[1].resize((size_t)B * n);
+    double noise = 0;
+    for (int b = 0; b < B; b++) {
+      double r_bound = 0, nb = 0;
+      const std::vector<long> rb = sampler.sampleSmallBounded(r_bound);
+      std::copy(rb.begin(), rb.end(), r.begin() + (size_t)b * n);
+      nb = r_bound * pubEncrKeyNoise;
+      for (int i = 0; i < 2; i++) {
+        double e_bound = 0;
+        const std::vector<long> eb = sampler.sampleGaussianBounded(sampler.errorStdev(), e_bound);
+        std::copy(eb.begin(), eb.end(), e[i].begin() + (size_t)b * n);
+        e_bound *= (double)p;
+        if (i == 1)
+          e_bound *= skBound;
+        nb += e_bound;
+      }
+      const std::vector<long> one(ptxts.begin() + (size_t)b * n, ptxts.begin() + (size_t)(b + 1) * n);
+      const std::vector<long> fx = ptxtFixed(one, idx, p);
+      std::copy(fx.begin(), fx.end(), pt.begin() + (size_t)b * n);
+      nb += cc->noiseBoundForMod(p, cc->phim);
+      noise = std::max(noise, nb);
+    }
+    DoubleCRT rr = fromCoeffsBatch(idx, r, B);
+    DoubleCRT parts[2] = {rr, rr};
+    const DoubleCRT* pk[2] = {pubEncrKey0.get(), pubEncrKey1.get()};
+    for (int i = 0; i < 2; i++) {
+      parts[i] *= *pk[i];                       // (the key is one polynomial: broadcast over the batch)
+      DoubleCRT ee = fromCoeffsBatch(idx, e[i], B);
+      ee.mulConstant(scalarRows(idx, *cc, p));
+      parts[i] += ee;
+    }
+    parts[0] += fromCoeffsBatch(idx, pt, B);
+    Ctxt ct = Ctxt::fresh(*cc, *dev, keys, std::move(parts[0]), std::move(parts[1]));
+    ct.ptxtSpace = p;
+    ct.lnNoise = std::log(noise);
+    return ct;
+  }
+
   // PubKey::CKKSencrypt (src/keys.cpp:501-581): ptxt is an integer polynomial already scaled by
   // `scaling`; ctxt = r*pk + (e0, e1) + (ef*ptxt, 0) with ef = ceil(error_bound * 2^precision /
   // (scaling * ptxtSize)); ratFactor = scaling * ef, ptxtMag = ptxtSize rounded up to a power of two
@@ -823,12 +923,13 @@ public:
       if (h.isOne()) {
         term = std::make_unique<DoubleCRT>(kv.second);
       } else {
-        term = std::make_unique<DoubleCRT>(fromCoeffs(idx, sKey));
+        DoubleCRT key = fromCoeffs(idx, sKey);
         if (h.powerOfX > 1)
-          term->automorph(h.powerOfX);
+          key.automorph(h.powerOfX);
         if (h.powerOfS > 1)
-          term->Exp(h.powerOfS);
-        *term *= kv.second;
+          key.Exp(h.powerOfS);
+        term = std::make_unique<DoubleCRT>(kv.second);   // (the part may be a batch: the key is broadcast over it)
+        *term *= key;
       }
       if (!acc)
         acc = std::move(term);
@@ -917,6 +1018,42 @@ public:
         if (a != 1)
           throw LogicError("intFactor * Q is not invertible modulo the plaintext space");
         uint64_t inv = (uint64_t)((x0 % p + p) % p);
+        for (auto& v : out)
+          v = (long)mulmod((uint64_t)v, inv, (uint64_t)p);
+      }
+    }
+    return out;
+  }
+  // the same for a batched ciphertext: batch * phi(m) coefficients, element after element (one inner product, one
+  // inverse transform and one read-back for the whole batch -- Decrypt() above already works batch-wide, it sizes
+  // its result for one element only)
+  std::vector<long> DecryptBatch(const Ctxt& ct) const
+  {
+    if (cc->ckks)
+      throw LogicError("CKKS ciphertexts decrypt with DecryptCKKS");
+    std::unique_ptr<DoubleCRT> acc = innerProduct(ct);
+    const long p = ct.ptxtSpace;
+    const size_t total = (size_t)acc->batch() * (size_t)cc->phim;
+    std::vector<unsigned long> raw(total);
+    acc->toPolyMod((unsigned long)p, raw.data());
+    std::vector<long> out(raw.begin(), raw.end());
+    if (p > 2) {
+      uint64_t factor = (uint64_t)(ct.intFactor % p);
+      for (int i : ct.primeSet)
+        factor = mulmod(factor, (uint64_t)cc->primes[(size_t)i] % (uint64_t)p, (uint64_t)p);
+      if (factor != 1) {
+        long a = (long)factor, bb = p, x0 = 1, x1 = 0;   // inverse modulo p by the extended Euclidean algorithm
+        while (bb) {
+          const long qq = a / bb, t = a % bb;
+          a = bb;
+          bb = t;
+          const long t2 = x0 - qq * x1;
+          x0 = x1;
+          x1 = t2;
+        }
+        if (a != 1)
+          throw LogicError("intFactor * Q is not invertible modulo the plaintext space");
+        const uint64_t inv = (uint64_t)((x0 % p + p) % p);
         for (auto& v : out)
           v = (long)mulmod((uint64_t)v, inv, (uint64_t)p);
       }

@@ -261,23 +261,27 @@ int hx_ntt_inverse(hx_poly* p) { return transform(p, false); }
 
 static int binary(hx_poly* a, const hx_poly* b, int op)
 {
-  if (a->ctx != b->ctx || a->batch != b->batch)
+  if (a->ctx != b->ctx)
     return fail(HX_ERR_INVALID, "Context mismatch");
+  if (b->batch != a->batch && b->batch != 1)      // (as the engine: a batch-1 operand is broadcast over the batch)
+    return fail(HX_ERR_INVALID, "batch mismatch");
   for (int r = 0; r < a->nrows(); r++)
     if (find(b->idx, a->idx[(size_t)r]) < 0)
       return fail(HX_ERR_PRIMESET, "DoubleCRT::Op: the prime set of the operand does not cover this object's");
+  const long n1 = (long)a->rw() / a->batch;       // one element of a row
   for (int r = 0; r < a->nrows(); r++) {
     const int rb = find(b->idx, a->idx[(size_t)r]);
     const uint64_t q = a->ctx->q[(size_t)a->idx[(size_t)r]];
-    uint64_t* x = a->row(r, 0);
-    const uint64_t* y = b->row(rb, 0);
-    const long n = (long)a->rw();
-    if (op == 0)
-      ho_row_add(x, x, y, n, q);
-    else if (op == 1)
-      ho_row_sub(x, x, y, n, q);
-    else
-      ho_row_mul(x, x, y, n, q);
+    for (int e = 0; e < a->batch; e++) {
+      uint64_t* x = a->row(r, 0) + (size_t)e * (size_t)n1;
+      const uint64_t* y = b->row(rb, 0) + (b->batch == 1 ? 0 : (size_t)e * (size_t)n1);
+      if (op == 0)
+        ho_row_add(x, x, y, n1, q);
+      else if (op == 1)
+        ho_row_sub(x, x, y, n1, q);
+      else
+        ho_row_mul(x, x, y, n1, q);
+    }
   }
   return HX_OK;
 }

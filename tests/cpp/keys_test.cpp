@@ -132,6 +132,54 @@ int main(int argc, char** argv)
     ca.smartAutomorph(9);   // two steps of 3 along the map
     REQUIRE(sk.Decrypt(ca) == automorph(rot, 9, p));
     REQUIRE(std::isfinite((double)ca.lnNoise) && ca.lnNoise > 0);
+
+    // ---- batched encryption / decryption: element b of EncryptBatch(B) is the b-th of B consecutive Encrypt() calls
+    // (same key, same sampler state: two SecKey objects built from one seed), DecryptBatch returns every element,
+    // and a batched product decrypts to the B plaintext products
+    {
+      const int B = 3;
+      const size_t n = (size_t)cc.phim;
+      SecKey s1(cc, *dev, 4242), s2(cc, *dev, 4242);
+      s1.GenSecKey(2);
+      s2.GenSecKey(2);
+      std::vector<long> msgs((size_t)B * n), other((size_t)B * n);
+      for (auto& v : msgs)
+        v = (long)(rng() % (uint64_t)p);
+      for (auto& v : other)
+        v = (long)(rng() % (uint64_t)p);
+      Ctxt batch = s2.EncryptBatch(msgs, B);
+      REQUIRE(batch.parts.size() == 2 && batch.parts.begin()->second.batch() == B);
+      double worst = -1e300;
+      for (int b = 0; b < B; b++) {
+        Ctxt one = s1.Encrypt(std::vector<long>(msgs.begin() + (size_t)b * n, msgs.begin() + (size_t)(b + 1) * n));
+        worst = std::max(worst, (double)one.lnNoise);
+        for (auto& kv : one.parts) {
+          const std::vector<uint64_t> r1 = kv.second.getRows(), rB = batch.parts.at(kv.first).getRows();   // [row][B][n]
+          const size_t rows = r1.size() / n;
+          for (size_t r = 0; r < rows; r++)
+            for (size_t j = 0; j < n; j++)
+              REQUIRE(rB[(r * (size_t)B + (size_t)b) * n + j] == r1[r * n + j]);
+        }
+      }
+      REQUIRE(std::fabs((double)batch.lnNoise - worst) < 1e-9);   // the batch's estimate = its largest element's
+      REQUIRE(s2.DecryptBatch(batch) == msgs);
+      Ctxt ob = s2.EncryptBatch(other, B);
+      batch.measure = ob.measure = measure;
+      batch.multiplyBy(ob);
+      const std::vector<long> got = s2.DecryptBatch(batch);
+      for (int b = 0; b < B; b++) {
+        const std::vector<long> want = negacyclic(std::vector<long>(msgs.begin() + (size_t)b * n, msgs.begin() + (size_t)(b + 1) * n),
+                                                  std::vector<long>(other.begin() + (size_t)b * n, other.begin() + (size_t)(b + 1) * n), p);
+        REQUIRE(std::equal(want.begin(), want.end(), got.begin() + (size_t)b * n));
+      }
+      bool threw = false;
+      try {
+        s2.EncryptBatch(std::vector<long>(n + 1), 1);
+      } catch (const InvalidArgument&) {
+        threw = true;
+      }
+      REQUIRE(threw);
+    }
     dev->sync();
   } catch (const std::exception& ex) {
     fprintf(stderr, "exception: %s\n", ex.what());

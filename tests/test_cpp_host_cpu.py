@@ -305,6 +305,16 @@ def test_cpp_session_products_equal_the_oracle_replay_and_one_key_pair_serves_tw
     assert t.verify(1) == batch
     with pytest.raises(host.HostError):
         host.Session(scheme, m, p, r, bits + 200, batch, seed=23, lib_path=so, keys=keys)   # another chain
+    for bad in (keys[:-5], np.concatenate([keys, keys[:3]]), keys[:40]):   # truncated / trailing words: refused as a whole
+        with pytest.raises(host.HostError):
+            host.Session(scheme, m, p, r, bits, batch, seed=24, lib_path=so, keys=bad)
+    # batched encryption / decryption through the session (SecKey::EncryptBatch / DecryptBatch): BGV only
+    if scheme == "bgv":
+        ed = s.encrypt_decrypt_batch(3, reps=1)
+        assert ed["batch"] == 3 and ed["all_elements_round_trip"] and ed["encrypt_ms_per_ciphertext"] > 0
+    else:
+        with pytest.raises(host.HostError):
+            s.encrypt_decrypt_batch(3, reps=1)
     s.close()
     t.close()
 

@@ -13,4 +13,3 @@ run lib_loaded "from helib_amd import capi; capi.lib(); $T"
 run device_count "from helib_amd import capi; print(capi.device_count()); $T"
 run context "from helib_amd import capi as hx; c=hx.Context(16384,0); $T"
 [ -f helib_amd/lib/variants/unsplit/libhelib_amd.so ] && HX_LIB=$PWD/helib_amd/lib/variants/unsplit/libhelib_amd.so run unsplit_device_count "from helib_amd import capi; print(capi.device_count()); $T"
-run device_count_then_oracle "from helib_amd import capi; print(capi.device_count()); from oracle import oracle as O; O.lib(); $T"

@@ -21,14 +21,6 @@ import time
 def test_torch_only():
     t0 = time.time(); import torch; print("torch imported in", round(time.time() - t0, 1))
 PY
-cat > test_d.py <<'PY'
-import time
-from oracle import oracle as O
-def test_devcount_then_torch_with_oracle_imported():
-    from helib_amd import capi
-    print(capi.device_count())
-    t0 = time.time(); import torch; print("torch imported in", round(time.time() - t0, 1))
-PY
 run() { local t0=$SECONDS; timeout $LIMIT "$@" > $OLDPWD/$out/$NAME.log 2>&1; echo "$NAME rc=$? $((SECONDS-t0)) s: $(grep -h "torch imported" $OLDPWD/$out/$NAME.log | head -1)"; }
 ORDER=${3:-1}
 if [ "$ORDER" = 2 ]; then
