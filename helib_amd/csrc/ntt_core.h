@@ -611,6 +611,14 @@ struct ArProth {
 #ifndef HX_TW_PF_INV
 #define HX_TW_PF_INV 6
 #endif
+// the Proth-form rows' queue: an entry is 8 bytes (two VGPRs) instead of 16, so the same registers hold a queue twice
+// as deep (variants: tools/build_variant.sh NAME -DHX_TW_PF_P=8 -DHX_TW_PF_INV_P=8)
+#ifndef HX_TW_PF_P
+#define HX_TW_PF_P HX_TW_PF
+#endif
+#ifndef HX_TW_PF_INV_P
+#define HX_TW_PF_INV_P HX_TW_PF_INV
+#endif
 #ifndef HX_IO_GROUP
 #define HX_IO_GROUP 4
 #endif
@@ -716,7 +724,7 @@ constexpr int pass_bound_out()
 template <class AR, int S, bool INV, int REP, int NGRUN, int BIN, class Fetch>
 HXD void run_pass(uint64_t (&v)[32], const QC& c, Fetch fetch)
 {
-  constexpr int PF = INV ? HX_TW_PF_INV : HX_TW_PF;
+  constexpr int PF = AR::PROTH ? (INV ? HX_TW_PF_INV_P : HX_TW_PF_P) : (INV ? HX_TW_PF_INV : HX_TW_PF);
   constexpr int TOT = REP * NGRUN;
   typename AR::Tw tq[PF];
   static_for<0, (PF < TOT ? PF : TOT)>([&](auto I) {

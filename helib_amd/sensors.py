@@ -14,6 +14,8 @@ import time
 
 
 def _hwmon_dirs():
+    """[(pci address 'dddd:bb:dd.f', hwmon directory)] of every amdgpu device the kernel shows -- on a partitioned
+    node that is all eight GPUs, whichever of them this process may use"""
     out = []
     for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
         if "-" in os.path.basename(card):
@@ -22,10 +24,20 @@ def _hwmon_dirs():
         if hw and os.path.exists(os.path.join(card, "device", "vendor")):
             try:
                 if open(os.path.join(card, "device", "vendor")).read().strip() == "0x1002":
-                    out.append(hw[0])
+                    out.append((os.path.basename(os.path.realpath(os.path.join(card, "device"))).lower(), hw[0]))
             except OSError:
                 pass
     return out
+
+
+def pci_address(device=0):
+    """PCI address of HIP device `device` as sysfs spells it, through torch when it is there (None otherwise)"""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device)
+        return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        return None
 
 
 def _read_int(path):
@@ -36,11 +48,7 @@ def _read_int(path):
         return None
 
 
-def sample_sysfs(device=0):
-    dirs = _hwmon_dirs()
-    if device >= len(dirs):
-        return None
-    d = dirs[device]
+def _read_dir(d):
     hz = _read_int(os.path.join(d, "freq1_input"))
     uw = _read_int(os.path.join(d, "power1_average"))
     if uw is None:
@@ -48,6 +56,27 @@ def sample_sysfs(device=0):
     if hz is None and uw is None:
         return None
     return {"sclk_mhz": None if hz is None else round(hz / 1e6), "power_w": None if uw is None else round(uw / 1e6, 1)}
+
+
+def sample_sysfs(device=0, address=None):
+    """the device's own sensors when its PCI address is known; otherwise the amdgpu device drawing the most power
+    (on a node whose other GPUs idle that is the one under this process's load -- the source string says which rule)"""
+    dirs = _hwmon_dirs()
+    if not dirs:
+        return None
+    if address:
+        for a, d in dirs:
+            if a == address.lower():
+                s = _read_dir(d)
+                if s:
+                    s["picked"] = "pci " + a
+                return s
+    best = None
+    for a, d in dirs:
+        s = _read_dir(d)
+        if s and (best is None or (s["power_w"] or 0) > (best["power_w"] or 0)):
+            best = dict(s, picked="highest power of %d amdgpu devices (%s)" % (len(dirs), a))
+    return best
 
 
 def sample_rocm_smi(device=0):
@@ -74,13 +103,14 @@ class Sampler:
     def __init__(self, device=0, period_s=0.25, max_samples=64):
         self.device, self.period, self.max = device, period_s, max_samples
         self.samples, self.source = [], None
+        self.address = pci_address(device)
         self._stop = threading.Event()
         self._thread = None
 
     def _one(self):
-        s = sample_sysfs(self.device)
+        s = sample_sysfs(self.device, self.address)
         if s is not None:
-            self.source = self.source or "amdgpu hwmon (freq1_input, power1_average)"
+            self.source = "amdgpu hwmon (freq1_input, power1_average), " + s.pop("picked", "")
             return s
         s = sample_rocm_smi(self.device)
         if s is not None:
