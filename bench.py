@@ -730,8 +730,9 @@ def levels_leg(hh, sparams, batch, R, device, stream, sync, warm_steps=2, steps=
 
 # static instruction counts of the row-transform kernels per 512-thread workgroup (VALU
 # instructions per wave and row x 8 waves x 64 lanes) and their 64-bit modular multiplications per row
-VALU_PER_WAVE = {"ntt_row_kernel<14, false>": 5126, "ntt_row_kernel<14, true>": 4687,
-                 "ntt_moddown_apply_kernel<14, false>": 7003, "ntt_moddown_apply_kernel<14, true>": 6498}
+# (round 5, the Proth-form path: DYNAMIC counts per wave from the SQ_INSTS_VALU pass, profiles/r05_valu_floor_by_class.json)
+VALU_PER_WAVE = {"ntt_row_kernel<14, false, 8>": 4031, "ntt_moddown_apply_kernel<14, false>": 4836,
+                 "ntt_moddown_apply_tensor_kernel<14, false>": 5455}
 
 
 def kernel_table(prof, n, B, l, k, d, mults):
@@ -957,20 +958,22 @@ def make_roofline(table, n, B, l, k, d, b2b=None):
             roof[kk] = dom[kk]
     if "modmul64_per_s" in dom:
         roof["int_ops_per_s"] = dom["modmul64_per_s"]
-        roof["int_ops_are"] = ("64-bit modular multiplications (Shoup products, 9 32-bit multiplier instructions each) per "
+        roof["int_ops_are"] = ("64-bit modular multiplications (Proth-form Montgomery products: 6 multiply-adds + 2 carries each; "
+                               "Shoup products of 9 multiplier instructions on rows of other primes) per "
                                "second over the chip; valu_lane_ops_per_s = static VALU instruction count x 64 lanes / time")
     # recorded PMC traffic of the same kernel and launch shape (cannot be collected inside this process)
     traffic, src = None, None
     short = dom["kernel"].replace(", false>", ">").replace(", true>", ",plain>")
-    for rec in ("r04_pmc_roofline_kernel_traffic.json", "r03_pmc_roofline_kernel_traffic.json", "r03_pmc_moddown_apply_traffic.json"):
+    for rec in ("r05_pmc_roofline_kernel_traffic.json", "r04_pmc_roofline_kernel_traffic.json", "r03_pmc_roofline_kernel_traffic.json"):
         t, sname = recorded_traffic(rec, short, dom["workgroups"], n)
         if t is not None:
             traffic, src = t, sname
             break
     # the instruction-class-weighted issue floor of this kernel (recorded: tools/valu_floor.py over the kernel's ISA with
-    # the per-class issue costs of tools/ubench/issue_bench, profiles/r04_valu_floor_by_class.json), scaled to this launch
+    # the per-class issue costs of tools/ubench/issue_bench, profiles/r05_valu_floor_by_class.json: the Proth-form path of the
+    # round-5 kernels), scaled to this launch
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_valu_floor_by_class.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r05_valu_floor_by_class.json")) as f:
             fl = json.load(f)["kernels"]
         m = dom["kernel"].replace(" ", "")
         tag = m[:m.index("<")] + "ILi" + m[m.index("<") + 1:m.index(",")] + "ELb" + ("1" if m.endswith("true>") else "0")
@@ -980,7 +983,7 @@ def make_roofline(table, n, B, l, k, d, b2b=None):
                 roof["issue_floor"] = {"floor_us_per_launch": round(fus, 1), "measured_over_floor": round(dom["avg_us"] / fus, 3),
                                        "valu_per_wave_dynamic": e["dynamic_valu_per_wave_SQ_INSTS_VALU"],
                                        "kind": "recorded per-class issue costs (idle-chip micro-benchmark) x this kernel's instruction "
-                                               "histogram scaled to its SQ_INSTS_VALU; profiles/r04_valu_floor_by_class.json"}
+                                               "histogram scaled to its SQ_INSTS_VALU; profiles/r05_valu_floor_by_class.json"}
     except Exception:
         pass
     roof["traffic"] = traffic
@@ -1316,7 +1319,7 @@ def main():
                     extra["fixed_level_algorithmic_MB_per_mult"] = round(algorithmic_bytes_fixed(n, l, k, d) / 1e6, 2)
                 b2b = ntt_back_to_back(hx, sub, fixed_primes, list(range(l)), list(range(l, l + k)), shape["digits"], B, rng,
                                        args.ntt_iters)
-                rec = os.path.join(ROOT, "profiles", "r03_pmc_fresh_multiply_traffic.json")
+                rec = os.path.join(ROOT, "profiles", "r05_pmc_fresh_multiply_traffic.json")
                 if os.path.exists(rec):
                     with open(rec) as f:
                         tr = json.load(f)
@@ -1324,8 +1327,9 @@ def main():
                         gb = tr["traffic_GB_per_multiply_of_the_batch"]
                         extra["hbm_traffic_GB_per_step_recorded"] = round(gb * R, 1)
                         extra["hbm_traffic_avg_TBps_over_the_step_recorded"] = round(gb * R / (dt / args.steps) / 1e3, 2)
-                        extra["hbm_traffic_source"] = ("recorded, not measured in this run: profiles/r03_pmc_fresh_multiply_traffic.json "
-                                                       "(rocprofv3 --pmc passes over the same command, round-3 final kernels)")
+                        extra["hbm_traffic_source"] = ("recorded, not measured in this run: profiles/r05_pmc_fresh_multiply_traffic.json "
+                                                       "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same command, THIS round's "
+                                                       "kernels; counted at the L2, so Infinity-Cache hits are included)")
             roof = make_roofline(table, n, B, l, k, d, b2b)
             if extras:
                 sync()

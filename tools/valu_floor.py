@@ -71,10 +71,27 @@ def main():
         if "csub: sub, subb, 2 x cndmask (per group)" in t:
             t["csub_select"] = max(0.0, (t["csub: sub, subb, 2 x cndmask (per group)"] - t["v_sub_co + s_nop 1 + v_subb_co (per pair)"]) / 2)
     starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and re.search(regex, l)]
+    dyn = {}      # --dynamic NAME_SUBSTRING:WORKGROUPS:SQ_INSTS_VALU_PER_DISPATCH:IN_SITU_US  (repeatable)
+    for i, a in enumerate(sys.argv):
+        if a == "--dynamic":
+            k, w, v, us = sys.argv[i + 1].rsplit(":", 3)
+            dyn[k] = (int(w), float(v), float(us))
     for st in starts:
         name = lines[st].split(":")[0]
-        end = next(i for i in range(st, len(lines)) if "s_endpgm" in lines[i])
-        ops = [l.split()[0] for l in lines[st + 1:end] if l.startswith("\t") and l.strip() and not l.strip().startswith((".", ";"))]
+        # Round 5: a row kernel holds BOTH arithmetics behind one workgroup-uniform branch (ntt_body: PrimeDev::proth),
+        # each path ending in its own s_endpgm.  The histogram is taken over the path the benchmark's rows run: the
+        # segment with the complemented quotient digits (v_not_b32) of the Proth-form butterflies, when there is one.
+        stop = next((i for i in range(st + 1, len(lines)) if lines[i].startswith(".Lfunc_end")), len(lines))
+        ends = [i for i in range(st, stop) if "s_endpgm" in lines[i]]
+        segs, a0 = [], st + 1
+        for e in ends:
+            segs.append((a0, e))
+            a0 = e + 1
+        def seg_ops(a, b):
+            return [l.split()[0] for l in lines[a:b] if l.startswith("\t") and l.strip() and not l.strip().startswith((".", ";"))]
+        nots = [sum(1 for o in seg_ops(a, b) if o.startswith("v_not_b32")) for a, b in segs]
+        pick = max(range(len(segs)), key=lambda i: nots[i]) if segs and max(nots) > 100 else 0
+        ops = seg_ops(*segs[pick]) if segs else []
         hist = Counter(ops)
         valu = {k: v for k, v in hist.items() if k.startswith("v_")}
         by_class, unknown = Counter(), Counter()
@@ -97,6 +114,16 @@ def main():
             out[f"floor_ns_per_wave_{c}"] = round(ns, 1)
             out[f"floor_ns_per_row_per_cu_{c}"] = round(ns * wpr / 4.0, 1)
             out[f"floor_us_per_1000_rows_chip_{c}"] = round(ns * wpr / 4.0 * 1000 / 256 / 1e3, 3)
+        out["path"] = ("proth (segment %d of %d, %d v_not_b32)" % (pick + 1, len(segs), nots[pick])) if segs and max(nots) > 100 else "only"
+        for k, (wg, v, us) in dyn.items():
+            if k in name:
+                per_wave = v / (wg * wpr)
+                scale = per_wave / max(1, out["valu"])
+                fl = out["floor_ns_per_wave_w8"] * scale * wpr / 4.0 * wg / 256 / 1e3
+                out.update({"in_situ_launch": {"workgroups": wg, "avg_us": us},
+                            "dynamic_valu_per_wave_SQ_INSTS_VALU": round(per_wave, 1), "dynamic_over_static": round(scale, 4),
+                            "floor_us_of_the_in_situ_launch_w8_dynamic_count": round(fl, 1),
+                            "measured_over_floor_dynamic_count_w8": round(us / fl, 3)})
         print(json.dumps(out))
 
 
