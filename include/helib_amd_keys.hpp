@@ -641,9 +641,14 @@ public:
   // secret polynomial (phi(m) longs), pubEncrKey parts 0 and 1 ([L][phi(m)]), then per matrix: fromSPower,
   // fromXPower, ptxtSpace, noiseBound, ndig, nrows, the row primes, b and a ([ndig][nrows][phi(m)])
   static constexpr uint64_t KEYS_MAGIC = 0x68786b6579733031ull;   // "hxkeys01"
-  std::vector<uint64_t> exportKeys() const
+  // withSecret = false: the same blob with the secret polynomial blanked (every word NO_SECRET) -- what a process that
+  // only encrypts and multiplies needs (the public encryption key and the key-switching matrices); importKeys leaves
+  // such an object without a secret key, its Decrypt throws.  (bench.py's ranks verify their own products and take the
+  // full blob; a deployment would not send the secret key anywhere.)
+  static constexpr uint64_t NO_SECRET = 0x8000000000000000ull;
+  std::vector<uint64_t> exportKeys(bool withSecret = true) const
   {
-    if (sKey.empty() || !pubEncrKey0)
+    if ((sKey.empty() && withSecret) || !pubEncrKey0)
       throw LogicError("exportKeys: no key has been generated");
     const size_t n = (size_t)cc->phim, L = cc->ctxtPrimes.size();
     auto bits = [](double v) {
@@ -654,7 +659,7 @@ public:
     std::vector<uint64_t> w{KEYS_MAGIC, (uint64_t)cc->m, (uint64_t)n, (uint64_t)L, (uint64_t)keySwitching.size(),
                             (uint64_t)ptxtSpace, bits(skBound), bits(pubEncrKeyNoise)};
     for (size_t j = 0; j < n; j++)
-      w.push_back((uint64_t)(j < sKey.size() ? sKey[j] : 0));
+      w.push_back(withSecret ? (uint64_t)(j < sKey.size() ? sKey[j] : 0) : NO_SECRET);
     for (const DoubleCRT* pk : {pubEncrKey0.get(), pubEncrKey1.get()}) {
       if (pk->getIndexSet() != cc->ctxtPrimes)
         throw LogicError("exportKeys: the public encryption key is not on the ctxt primes");
@@ -678,7 +683,7 @@ public:
   }
   void importKeys(const uint64_t* w, size_t nwords)
   {
-    if (!sKey.empty())
+    if (!sKey.empty() || pubEncrKey0)
       throw LogicError("this host side holds one secret key per SecKey object");
     const size_t n = (size_t)cc->phim, L = cc->ctxtPrimes.size();
     size_t pos = 0;
@@ -722,9 +727,11 @@ public:
     skBound = dbl(h[6]);
     pubEncrKeyNoise = dbl(h[7]);
     const uint64_t* sk = take(n);
-    sKey.resize(n);
-    for (size_t j = 0; j < n; j++)
-      sKey[j] = (long)sk[j];
+    if (sk[0] != NO_SECRET) {          // (a blob exported without the secret key leaves this object public-only)
+      sKey.resize(n);
+      for (size_t j = 0; j < n; j++)
+        sKey[j] = (long)sk[j];
+    }
     for (auto* slot : {&pubEncrKey0, &pubEncrKey1}) {
       const uint64_t* rows = take(L * n);
       *slot = std::make_unique<DoubleCRT>(*dev, cc->ctxtPrimes, 1, DoubleCRT::Uninitialized{});
@@ -915,6 +922,8 @@ public:
   // sum_parts part * s^r(X^t): what both decryptions start from (src/keys.cpp:1360-1381)
   std::unique_ptr<DoubleCRT> innerProduct(const Ctxt& ct) const
   {
+    if (sKey.empty())
+      throw LogicError("this key object holds no secret key (public material only): it cannot decrypt");
     std::unique_ptr<DoubleCRT> acc;
     for (auto& kv : ct.parts) {
       const SKHandle& h = kv.first;

@@ -179,6 +179,25 @@ int main(int argc, char** argv)
         threw = true;
       }
       REQUIRE(threw);
+      // key material WITHOUT the secret key: the holder encrypts and multiplies, cannot decrypt; the owner of the
+      // full key decrypts what it made
+      const std::vector<uint64_t> pub = s2.exportKeys(false), full = s2.exportKeys();
+      REQUIRE(pub.size() == full.size() && pub != full);
+      SecKey only(cc, *dev, 99);
+      only.importKeys(pub.data(), pub.size());
+      REQUIRE(only.sKey.empty() && only.keys.relin);
+      const std::vector<long> m0(msgs.begin(), msgs.begin() + n), m1(other.begin(), other.begin() + n);
+      Ctxt x = only.Encrypt(m0), y = only.Encrypt(m1);
+      x.measure = y.measure = measure;
+      x.multiplyBy(y);
+      threw = false;
+      try {
+        only.Decrypt(x);
+      } catch (const LogicError&) {
+        threw = true;
+      }
+      REQUIRE(threw);
+      REQUIRE(s2.Decrypt(x) == negacyclic(m0, m1, p));
     }
     dev->sync();
   } catch (const std::exception& ex) {
