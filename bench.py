@@ -989,8 +989,8 @@ def make_roofline(table, n, B, l, k, d, b2b=None):
     roof["traffic"] = traffic
     roof["traffic_kind"] = "recorded (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch shape)" if traffic else None
     roof["traffic_source"] = src
-    fwd = [r for r in with_bytes if r["kernel"].startswith("ntt_row_kernel<") and r["kernel"].endswith("false>")]
-    inv = [r for r in with_bytes if r["kernel"].startswith("ntt_row_kernel<") and r["kernel"].endswith("true>")]
+    fwd = [r for r in with_bytes if r["kernel"].startswith("ntt_row_kernel<") and ", false" in r["kernel"]]
+    inv = [r for r in with_bytes if r["kernel"].startswith("ntt_row_kernel<") and ", true" in r["kernel"]]
     if fwd:
         f = max(fwd, key=lambda r: r["us_per_multiply"])
         roof["ntt_forward"] = {"kernel": f["kernel"], "workgroups_per_launch": f["workgroups"], "avg_launch_us_in_situ": f["avg_us"],
