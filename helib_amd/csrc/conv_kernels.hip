@@ -38,6 +38,15 @@ struct ConvIO {
   static constexpr bool LAZY_STORE = true;   // the forward side "stores" into the register file: pointwise product
   static constexpr bool PIPELINED = false;
   static constexpr bool SKIP_LOAD = true;    // ... and the inverse side starts from it
+  // Proth-form rows: the pointwise product is ONE Montgomery product by the plain table word -- below 2q, carrying
+  // 2^-64, which the inverse transform's last stage gives back (last_tw below)
+  template <class AR>
+  static constexpr int inv_load_bound() { return AR::PROTH ? 2 : 1; }
+  // (Tried in round 5 and reverted, as round 4's lazy Shoup load was: the element source's own products -- pre-twist by
+  // powers[i], split factor -- as lazy Montgomery products, a0 +- T a1 below 4q with no conditional subtraction.  Bit-exact,
+  // and 5 x slower: 2.7 ms instead of 0.45 per 512 rows; the three products per element with their uniform table
+  // pointers inside the 32-element load loop push the first register pass into scratch.  The load stays canonical.)
+  uint64_t r2;              // 2^128 mod q (PrimeDev::r2)
   struct StorePrefetch {};
   const uint64_t* src;      // segment of the source
   uint64_t* dst;            // segment of the destination
@@ -93,8 +102,15 @@ struct ConvIO {
       });
       static_for<0, IOG>([&](auto J) {
         constexpr int j = decltype(J)::value, i = g * IOG + j;
-        // (shoup4 takes any 64-bit value: the lazy [0, Bq) output of the last pass as it is)
-        v[i] = norm_from<4>(shoup4(v[i], hb[j], qc.nq), qc);
+        if constexpr (AR::PROTH) {
+          uint64_t x = v[i];
+          if constexpr (B > 12)
+            x = csub(x, qc.q8);          // (the multiplied operand must stay below 12.9 q)
+          v[i] = mont_mul(x, hb[j].w, qc);   // x hat 2^-64 in (0, 2q): not normalised, the inverse takes bound 2
+        } else {
+          // (shoup4 takes any 64-bit value: the lazy [0, Bq) output of the last pass as it is)
+          v[i] = norm_from<4>(shoup4(v[i], hb[j], qc.nq), qc);
+        }
       });
       HX_SCHED_FENCE();
     });
@@ -117,40 +133,20 @@ struct ConvIO {
     }
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
+  // the last inverse stage's constants with one more 2^64: def = w 2^64 mod q, times 2^128 as a Montgomery product
+  // = w 2^128 -- the Proth form of (w 2^64), which undoes the pointwise product's 2^-64
+  __device__ __forceinline__ TWM last_tw(TWM def, int) const
+  {
+    const QC qc = make_qc(uniform_u64(P->q), 0);   // (q, qh, c1 are all this needs: no reciprocal)
+    return csub(mont_mul(def, r2, qc), qc.q);
+  }
 };
 
-template <int LOGN, uint32_t SRC, uint32_t DST>
-__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
-ntt_conv_kernel(ConvRowArgs A, ConvRows R, const PrimeDev* __restrict__ cprimes, const TW* __restrict__ tw_arena)
+template <int LOGN, class AR, class IO>
+__device__ __forceinline__ void conv_body(uint32_t* lds, const IO& io, const typename AR::Tw* twf, const typename AR::Tw* twi,
+                                          const QC& q)
 {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned b = wid % A.batch, u = wid / A.batch, ri = u / A.split, g = u % A.split;
-  const PrimeDev* pd = cprimes + uniform_u16(R.pd, u);
-  const BluePrimeDev* P = R.bp[ri];
-  constexpr unsigned Q = Geo<LOGN>::N;
-  ConvIO<SRC, DST> io;
-  const size_t seg = (size_t)ri * A.batch + b;
-  const size_t polyseg = ((size_t)uniform_u16(R.row, ri) * A.batch + b) * A.phim;
-  io.src = SRC == CONV_SRC_REV ? A.in + seg * A.in_stride : A.in + polyseg;
-  io.dst = DST == CONV_DST_SUB ? A.out + ((size_t)u * A.batch + b) * Q : A.out + polyseg;
-  io.aux = DST == CONV_DST_FINAL ? A.aux + seg * A.aux_stride : nullptr;
-  io.hat = R.hat[ri] + (size_t)g * Q;
-  io.P = P;
-  io.S = &R.cp[ri]->S;
-  io.zidx = A.zidx;
-  io.g = g;
-  io.split = A.split;
-  io.Q = Q;
-  io.phim = A.phim;
-  io.m = A.m;
-  io.d = A.d;
-  io.base = A.base;
-  io.alias = A.alias;
-  const QC q = make_qc(pd->q, pd->mu64);
-  const TW* twf = tw_arena + pd->tw_fwd_off;
-  const TW* twi = tw_arena + pd->tw_inv_off;
-  using RN = RowNTT<LOGN>;
+  using RN = RowNTT<LOGN, AR>;
   uint64_t v[32];
   uint32_t nl[32];
   const unsigned w = wave_index();
@@ -185,6 +181,49 @@ ntt_conv_kernel(ConvRowArgs A, ConvRows R, const PrimeDev* __restrict__ cprimes,
   RN::template inv<6>(fresh_tid(w), v, nl, lds, io, twi, q);
   __syncthreads();
   RN::template inv<7>(fresh_tid(w), v, nl, lds, io, twi, q);
+}
+
+template <int LOGN, uint32_t SRC, uint32_t DST>
+__global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
+ntt_conv_kernel(ConvRowArgs A, ConvRows R, const PrimeDev* __restrict__ cprimes, const TW* __restrict__ tw_arena)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = wid % A.batch, u = wid / A.batch, ri = u / A.split, g = u % A.split;
+  const PrimeDev* pd = cprimes + uniform_u16(R.pd, u);
+  const BluePrimeDev* P = R.bp[ri];
+  constexpr unsigned Q = Geo<LOGN>::N;
+  ConvIO<SRC, DST> io;
+  const size_t seg = (size_t)ri * A.batch + b;
+  const size_t polyseg = ((size_t)uniform_u16(R.row, ri) * A.batch + b) * A.phim;
+  io.src = SRC == CONV_SRC_REV ? A.in + seg * A.in_stride : A.in + polyseg;
+  io.dst = DST == CONV_DST_SUB ? A.out + ((size_t)u * A.batch + b) * Q : A.out + polyseg;
+  io.aux = DST == CONV_DST_FINAL ? A.aux + seg * A.aux_stride : nullptr;
+  io.hat = R.hat[ri] + (size_t)g * Q;
+  io.P = P;
+  io.S = &R.cp[ri]->S;
+  io.zidx = A.zidx;
+  io.g = g;
+  io.split = A.split;
+  io.Q = Q;
+  io.phim = A.phim;
+  io.m = A.m;
+  io.d = A.d;
+  io.base = A.base;
+  io.alias = A.alias;
+  io.r2 = pd->r2;
+  const QC q = make_qc(pd->q, pd->mu64);
+  const TW* twf = tw_arena + pd->tw_fwd_off;
+  const TW* twi = tw_arena + pd->tw_inv_off;
+  // (one workgroup = one prime: the branch is uniform; the sub-transform tables of a Proth-form prime hold 8-byte
+  // entries, engine.hip conv_tables_sub)
+#ifndef HX_NO_PROTH
+  if (pd->proth) {
+    conv_body<LOGN, ArProth>(lds, io, reinterpret_cast<const TWM*>(twf), reinterpret_cast<const TWM*>(twi), q);
+    return;
+  }
+#endif
+  conv_body<LOGN, ArShoup>(lds, io, twf, twi, q);
 }
 
 template <int LOGN, uint32_t SRC, uint32_t DST>

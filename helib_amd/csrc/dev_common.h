@@ -26,6 +26,7 @@ struct PrimeDev {
   // instead of through a flat pointer fetched from memory.
   uint64_t tw_fwd_off;
   uint64_t tw_inv_off;
+  uint64_t r2;     // 2^128 mod q: a Proth-form constant times this (mont_mul) carries one more 2^64 (conv_kernels.hip)
 };
 
 // launch descriptor passed BY VALUE (kernel-arg segment): row r of the

@@ -856,7 +856,7 @@ static std::vector<int64_t> cyclo_product(uint64_t m, size_t len, bool want_phi)
   return a;
 }
 
-static int cprime_add(hx_ctx* c, uint64_t q, uint64_t fwd_off, uint64_t inv_off, int* idx)
+static int cprime_add(hx_ctx* c, uint64_t q, uint64_t fwd_off, uint64_t inv_off, int* idx, bool proth = false)
 {
   if (c->ncprimes == c->cprimes_cap) {
     int ncap = c->cprimes_cap ? c->cprimes_cap * 2 : 256;
@@ -880,6 +880,8 @@ static int cprime_add(hx_ctx* c, uint64_t q, uint64_t fwd_off, uint64_t inv_off,
   pd.mu63 = (uint64_t)((((hxh::u128)1) << (63 + pd.k)) / q);
   pd.tw_fwd_off = fwd_off;
   pd.tw_inv_off = inv_off;
+  pd.proth = proth ? 1u : 0u;
+  pd.r2 = hx::tw_mont_form(hx::tw_mont_form(1 % q, q), q);
   HIPCHK(hipMemcpy(c->d_cprimes + c->ncprimes, &pd, sizeof pd, hipMemcpyHostToDevice));
   *idx = c->ncprimes++;
   return HX_OK;
@@ -906,8 +908,20 @@ static int conv_tables_sub(hx_ctx* c, uint64_t q, uint64_t psi, int OUT, unsigne
   hx::build_tw_tables_sub<LOGQ>(q, psi, hxh::invmod(psi, q), ninv, hxh::mulmod, OUT, g, f.data(),
                                 i.data());
   uint64_t fo, io;
-  CHK(tw_upload(c, f, i, &fo, &io));
-  return cprime_add(c, q, fo, io, pd_idx);
+  // a Proth-form prime (q = 1 mod 2^32: every PrimeGenerator prime of these rings; the m = 21845 primes are
+  // c 2^36 + 1): the sub-transform's rows run the Proth-form butterflies on 8-byte entries, as the primes' own row
+  // tables do (upload_tw) -- in the convolution kernel, the split power-of-two rings and the round-2 chain alike
+  // (all of them go through RowNTT with the arithmetic chosen by PrimeDev::proth)
+  const bool proth = hx::is_proth32(q) && !c->sw.no_proth;
+  if (proth) {
+    std::vector<TW> fm((G::TW_TOTAL + 1) / 2), im((G::TW_TOTAL + 1) / 2);   // the same bytes as TW_TOTAL 8-byte entries
+    hx::tw_tables_to_mont(f.data(), G::TW_TOTAL, q, reinterpret_cast<hx::TWM*>(fm.data()));
+    hx::tw_tables_to_mont(i.data(), G::TW_TOTAL, q, reinterpret_cast<hx::TWM*>(im.data()));
+    CHK(tw_upload(c, fm, im, &fo, &io));
+  } else {
+    CHK(tw_upload(c, f, i, &fo, &io));
+  }
+  return cprime_add(c, q, fo, io, pd_idx, proth);
 }
 
 // psi: primitive 2^(logn+1)-th root of unity mod q
@@ -1558,6 +1572,7 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
   pd.tw_fwd_off = ph.tw_fwd_off;
   pd.tw_inv_off = ph.tw_inv_off;
   pd.proth = ph.proth ? 1u : 0u;
+  pd.r2 = hx::tw_mont_form(hx::tw_mont_form(1 % q, q), q);
   int idx = (int)c->primes.size();
   HIPCHK(hipMemcpy(c->d_primes + idx, &pd, sizeof pd, hipMemcpyHostToDevice));
   c->primes.push_back(ph);

@@ -26,6 +26,7 @@
 // kernel keeps the classical Harvey butterflies ([0,4q) forward / [0,2q) inverse).
 #pragma once
 #include <stdint.h>
+#include <utility>
 #if defined(HX_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
 #include <cstdio>
 #include <cstdlib>
@@ -932,6 +933,14 @@ template <class IO, class AR>
 struct io_load_bound<IO, AR, std::void_t<decltype(IO::template load_bound<AR>())>>
     : std::integral_constant<int, IO::template load_bound<AR>()> {};
 
+// ... and of what the inverse transform starts from (1: canonical; the convolution kernel's Proth-form pointwise
+// product hands over values below 2q: IO::inv_load_bound<AR>())
+template <class IO, class AR, class = void>
+struct io_inv_load_bound : std::integral_constant<int, 1> {};
+template <class IO, class AR>
+struct io_inv_load_bound<IO, AR, std::void_t<decltype(IO::template inv_load_bound<AR>())>>
+    : std::integral_constant<int, IO::template inv_load_bound<AR>()> {};
+
 // Plain-pointer row accessor (CPU replay; also valid on the device).
 struct PtrIO {
   static constexpr int LOAD_BOUND = 1;
@@ -999,10 +1008,6 @@ struct RowNTT {
   using G = Geo<LOGN>;
   static constexpr int NPHASE = 8;
 
-  // bounds (units of q) of the register file between the inverse passes (inputs canonical)
-  static constexpr int IC_ = pass_bound_out<AR, G::LC, true, G::GC - 1, 1>();  // after inverse pass C
-  static constexpr int IB = pass_bound_out<AR, 5, true, 31, IC_>();
-  static_assert(IC_ <= AR::inv_cap() && IB <= AR::inv_cap(), "lazy bounds");
 
   // -------- forward: coefficients (natural) -> evaluations (natural) -----
   template <int PH, class IO, class TWS>
@@ -1101,13 +1106,18 @@ struct RowNTT {
   static HXD void inv(unsigned tid, uint64_t (&v)[32], uint32_t (&nl)[32], uint32_t* lds,
                       const IO& io, const TWS& tw, const QC& c)
   {
+    // bounds (units of q) of the register file between the inverse passes (inputs canonical unless the IO says otherwise)
+    constexpr int I0 = io_inv_load_bound<IO, AR>::value;
+    constexpr int IC_ = pass_bound_out<AR, G::LC, true, G::GC - 1, I0>();  // after inverse pass C
+    constexpr int IB = pass_bound_out<AR, 5, true, 31, IC_>();
+    static_assert(I0 <= AR::inv_cap() && IC_ <= AR::inv_cap() && IB <= AR::inv_cap(), "lazy bounds");
     if constexpr (PH == 0) {
       if constexpr (!io_skip_load<IO>::value) {
 #pragma unroll
         for (int i = 0; i < 32; i++)
           v[i] = io.load(tid, eval_const<LOGN>(i));
       }
-      run_pass<AR, G::LC, true, G::NGC, G::GC - 1, 1>(v, c, [&](int gi, int sp, int k, uint32_t dep) {
+      run_pass<AR, G::LC, true, G::NGC, G::GC - 1, I0>(v, c, [&](int gi, int sp, int k, uint32_t dep) {
         return tw_vec(tw, G::TWC, tid, ((1u << sp) - 1u + (unsigned)k) * 1024u + (unsigned)(G::T * gi), dep);
       });
 #pragma unroll
