@@ -78,6 +78,11 @@ struct ConvIO {
     const uint64_t a0 = element(p, pw, q);
     if (SRC == CONV_SRC_REV || split == 1)   // (the reversal sources are never split)
       return a0;
+    // the source's support ends at phim (forward) or m (inverse): where a1 = 0 all four sub-blocks take a0 as it is.
+    // Config 5 (m = 21845, phim = Q = 16384): the whole forward pass, and two thirds of the inverse one, skip the
+    // second element and its product (the reference truncates the same way, src/bluestein.cpp:167, 189)
+    if (p + Q >= (SRC == CONV_SRC_SCATTER ? m : phim))
+      return a0;
     // radix-4 split of an input whose upper half is zero (every source here has support below 2Q):
     // b[g] = a0 +- T * a1 with T = T2 (g = 0, 1) or T3 (g = 2, 3)   (split_fwd4 with a2 = a3 = 0)
     const TW comb = uniform_tw(g < 2 ? S->T2 : S->T3);

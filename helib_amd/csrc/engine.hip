@@ -2432,6 +2432,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   size_t o_pack = take((size_t)nt * pack_stride);
   size_t o_pack2 = take((size_t)nt * pack_stride);   // the same for the HPS front end (rns_kernels.h)
   size_t o_hinv = take((size_t)2 * n), o_Wp2 = take((size_t)2 * n);
+  size_t o_ginvm = take((size_t)n * n);   // Garner constants times 2^64 (Proth-form sources, ExtPlanDev::ginv_m)
   // rns_extend_wide_kernel (17..40 source primes): per-target record of 8 + n words, padded so that the last
   // record's group-of-four multiplier reads stay inside the blob
   const bool wide_cand = n > 16 && n <= 40 && !c->sw.no_wide_extend;
@@ -2452,6 +2453,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
         return fail(HX_ERR_INVALID, "source primes are not pairwise coprime");
       h[o_ginv + 2 * ((size_t)k * n + l)] = inv;
       h[o_ginv + 2 * ((size_t)k * n + l) + 1] = hxh::shoup(inv, p[k]);
+      h[o_ginvm + (size_t)k * n + l] = (uint64_t)(((hxh::u128)inv << 64) % p[k]);
     }
     P.mul_word(p[k]);
   }
@@ -2528,6 +2530,19 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     pl->dev.pinv_ptxt = pinv;
     pl->dev.pmod_ptxt = run;
   }
+  // Proth-form targets (TgtRec::mont, rns_kernels.h): the record's multipliers, -P mod t (in mu63's slot) and P^-1 mod t
+  // (in the slot of 2^64 mod t) times 2^64 -- the fast kernels reduce such a target's limb sum by mont_redc128
+  const bool rns_proth = !c->sw.no_proth && !c->sw.no_proth_rns && n <= 16;
+  auto tgt_mont = [&](int t) { return rns_proth && hx::is_proth32(tq(t)); };
+  auto rec_to_mont = [&](uint64_t* rec) {
+    const uint64_t q = rec[0];
+    auto m64 = [&](uint64_t x) { return (uint64_t)(((hxh::u128)(x % q) << 64) % q); };
+    rec[2] = m64(q - rec[1] % q);
+    rec[4] |= (uint64_t)1 << 10;
+    for (int k = 0; k < n; k++)
+      rec[8 + k] = m64(rec[8 + k]);
+    rec[8 + 2 * n] = m64(rec[5]);
+  };
   for (int t = 0; t < nt; t++) {
     uint64_t* rec = &h[o_pack + (size_t)t * pack_stride];
     rec[0] = h[o_tq + t];
@@ -2545,6 +2560,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     const uint64_t r64 = (uint64_t)((((hxh::u128)1) << 64) % rec[0]);   // red128_any's constant
     rec[8 + 2 * n] = r64;
     rec[8 + 2 * n + 1] = hxh::shoup(r64, rec[0]);
+    if (tgt_mont(t))
+      rec_to_mont(rec);
   }
   // HPS front end: y_k = a_k (P/p_k)^-1 mod p_k, multipliers (P/p_k) mod t (scaled plans: / P, i.e.
   // p_k^-1 mod t), the same header; "lazy" needs room for up to n + 1 extra multiples of t in the sum
@@ -2596,18 +2613,20 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
       const uint64_t* rec = &h[o_pack + (size_t)t * pack_stride];
       uint64_t* rec2 = &h[o_pack2 + (size_t)t * pack_stride];
       for (int j = 0; j < 8; j++)
-        rec2[j] = rec[j];
+        rec2[j] = rec[j];   // (a Proth-form target: rec[2] is -P 2^64 already)
       rec2[8 + 2 * n] = rec[8 + 2 * n];
       rec2[8 + 2 * n + 1] = rec[8 + 2 * n + 1];
       const uint32_t lazy2 = (hxh::bitlen(q) <= 60 && sum_src + 32 <= (hxh::u128)8 * q && !c->sw.no_lazy_rns) ? 1u : 0u;
-      rec2[4] = (uint64_t)tk[t] | ((uint64_t)lazy2 << 8) | ((uint64_t)tchunk[t] << 9);
+      rec2[4] = (uint64_t)tk[t] | ((uint64_t)lazy2 << 8) | ((uint64_t)tchunk[t] << 9) | (rec[4] & ((uint64_t)1 << 10));
       const uint64_t pinv_t = h[o_upd + 2 * (size_t)t];   // P^-1 mod t
       for (int k = 0; k < n; k++) {
         uint64_t w = prod_except(k, q);
         if (scaled)
           w = hxh::mulmod(w, pinv_t, q);
-        rec2[8 + k] = w;
         rec2[8 + n + k] = hxh::shoup(w, q);
+        if (tgt_mont(t))
+          w = (uint64_t)(((hxh::u128)w << 64) % q);
+        rec2[8 + k] = w;
       }
     }
   }
@@ -2616,6 +2635,13 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   HIPCHK(hipMemcpy(d, h.data(), off * 8, hipMemcpyHostToDevice));
   pl->blob = d;
   pl->dev.tgt_pack = hx::as_ro(d + o_pack);
+  pl->dev.ginv_m = hx::as_ro(d + o_ginvm);
+  {
+    bool sm = rns_proth;
+    for (int k = 0; k < n && sm; k++)
+      sm = hx::is_proth32(p[k]);
+    pl->dev.src_mont = sm ? 1u : 0u;
+  }
   pl->dev.tgt_pack_hps = hx::as_ro(d + o_pack2);
   pl->dev.hps_inv = hx::as_ro(reinterpret_cast<const TW*>(d + o_hinv));
   pl->dev.Wp_hps = hx::as_ro(reinterpret_cast<const TW*>(d + o_Wp2));

@@ -446,6 +446,12 @@ struct ExtPlanDev {
   uint32_t hps_ok;
   ro_u64 wide_pack;   // [nt][wide_stride(n)] rns_extend_wide_kernel's record of one target: 8 header words, HPS multipliers as limb pairs
   uint32_t wide_ok;   // 16 < n <= 40 sources, every prime in (2^32, 2^60), the HPS tables exist
+  // Proth-form primes (q = qh 2^32 + 1, ntt_core.h is_proth32; round 5): the fast kernels' products as Montgomery
+  // products -- a target whose record carries TgtRec::mont() holds its multipliers, -P mod t and P^-1 mod t times 2^64,
+  // and its limb sum is reduced by mont_redc128 (two multiply-adds for the Barrett's seven multiplications, or the ten
+  // of red128_any); src_mont: every SOURCE prime has the form too and the Garner steps run on ginv_m
+  ro_u64 ginv_m;      // [n*n] ginv_m[k*n+l] = p_l^-1 2^64 mod p_k   (l<k)
+  uint32_t src_mont;
   ro_u64 tgt_pack;    // [nt][10 + 2n] everything the fast kernels need of one target in ONE record
                       // (TgtRec): the loop over targets then makes one scalar-memory round trip per
                       // target instead of one per table (q, P mod t, flags, k, mu, W row: six
@@ -493,6 +499,11 @@ struct TgtRec {
   __device__ __forceinline__ uint32_t k() const { return (uint32_t)fl_ & 0xffu; }
   __device__ __forceinline__ bool lazy() const { return ((uint32_t)fl_ >> 8) & 1u; }
   __device__ __forceinline__ bool chunk7() const { return ((uint32_t)fl_ >> 9) & 1u; }
+  // Proth-form target (ExtPlanDev::ginv_m): the multipliers w(k) are W 2^64 mod q, and the slots its reductions do not
+  // need hold (q - P mod q) 2^64 mod q (for mu63) and P^-1 2^64 mod q (for 2^64 mod q)
+  __device__ __forceinline__ bool mont() const { return ((uint32_t)fl_ >> 10) & 1u; }
+  __device__ __forceinline__ uint64_t negp_m() const { return mu63_; }
+  __device__ __forceinline__ uint64_t upd_m() const { return r[8 + 2 * N]; }
   __device__ __forceinline__ TW upd() const
   {
     TW t;
@@ -895,15 +906,31 @@ template <int N, class Load>
 __device__ __forceinline__ void garner_front(const ExtPlanDev& P, Load load, ExtRep<N>& R, bool want_frac)
 {
   uint64_t (&a)[N] = R.rep;
+  if (P.src_mont) {
+    // Proth-form sources: y = v + 2 p_k - a_l in (0, 6 p_k) (v < 4 p_k on load, below 2 p_k after a step), the
+    // Montgomery product by p_l^-1 2^64 in (0, p_k (1 + 6/16 + 2^-32)) -- six multiply-adds for shoup4's nine
 #pragma unroll
-  for (int k = 0; k < N; k++) {
-    uint64_t v = load(k);
-    const uint64_t pk = P.src_q[k], npk = 0 - pk, pk2 = pk + pk;
+    for (int k = 0; k < N; k++) {
+      uint64_t v = load(k);
+      const uint64_t pk = P.src_q[k], pk2 = pk + pk;
+      const QC qc = make_qc(pk, 0);
 #pragma unroll
-    for (int l = 0; l < k; l++)
-      v = shoup4(v + pk2 - a[l], ld_tw(P.ginv, k * N + l), npk);
-    v = csub(v, pk2);
-    a[k] = csub(v, pk);
+      for (int l = 0; l < k; l++)
+        v = mont_mul(v + pk2 - a[l], P.ginv_m[k * N + l], qc);
+      v = csub(v, pk2);
+      a[k] = csub(v, pk);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      uint64_t v = load(k);
+      const uint64_t pk = P.src_q[k], npk = 0 - pk, pk2 = pk + pk;
+#pragma unroll
+      for (int l = 0; l < k; l++)
+        v = shoup4(v + pk2 - a[l], ld_tw(P.ginv, k * N + l), npk);
+      v = csub(v, pk2);
+      a[k] = csub(v, pk);
+    }
   }
   // centring: value > (P-1)/2, top digit first
   int cmp = 0;
@@ -992,9 +1019,13 @@ __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* 
     const int r = t < off ? t : t + N;  // row of target t in the all-rows order
     const TgtRec<N> T(pack, t);
     const uint64_t q = T.q();
-    const uint64_t negP = q - T.pmod();   // -P mod t: enters cnt times (centring, and the HPS quotient)
+    const bool mont = T.mont();
+    const uint64_t negP = mont ? T.negp_m() : q - T.pmod();   // -P mod t: enters cnt times (centring, and the HPS quotient)
+    const QC qc = make_qc(q, 0);   // (scalar; the Proth-form branches read qh and c1 only)
     uint64_t v;
-    if (T.lazy()) {
+    if (mont || T.lazy()) {
+      // (every limb product is below 2^60 whatever the target's size: the three-accumulator form holds the 2N <= 16
+      // middle products of any target)
       uint64_t c00 = 0, c01 = 0, c11 = 0;
 #pragma unroll
       for (int k = 0; k < N; k++) {
@@ -1006,7 +1037,17 @@ __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* 
         c11 += (uint64_t)a1[k] * w1;
       }
       const u128 S = (u128)cnt * negP + c00 + ((u128)c01 << 30) + ((u128)c11 << 60);
-      v = LAZY ? red128_q8_lazy(S, q, T.mu63(), T.k()) : red128_q8(S, q, T.mu63(), T.k());
+      if (mont) {
+        // S < (sum_k p_k + cnt) q < 2^124: S 2^-64 = sum_k a_k W_k - cnt P (the 2^64 is in the record's words), in
+        // (0, q (N/16 + 1 + 2^-32)) -- below 2q for N <= 8, inside the [0,6q) the LAZY readers are declared with
+        v = mont_redc128((uint64_t)S, (uint64_t)(S >> 64), qc);
+        if (!LAZY) {
+          v = csub(v, qc.q2);
+          v = csub(v, q);
+        }
+      } else {
+        v = LAZY ? red128_q8_lazy(S, q, T.mu63(), T.k()) : red128_q8(S, q, T.mu63(), T.k());
+      }
     } else {
       // a target the terms outgrow (a 56-bit special prime under 60-bit digit primes): the same limb sums,
       // reduced by red128_any -- round 3 summed a Shoup product per term here (nine multiplications each)
@@ -1028,7 +1069,10 @@ __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* 
       // digits[j] -= digits[i]; digits[j] /= P_i on a later digit's own row (kept lazy, < 4q; v < 6q when LAZY:
       // the offset that keeps the difference positive is 8q then, 12q < 2^64 in all)
       uint64_t* u = &xs[(r - n0) * BRK_THREADS + tid];
-      *u = shoup4(*u + (LAZY ? q << 3 : q) - v, T.upd(), 0 - q);
+      if (mont)   // u < 4q, v < 2q: u + 2q - v in (0, 6q), the product by P^-1 2^64 below q (1 + 6/16 + 2^-32) < 2q
+        *u = mont_mul(*u + qc.q2 - v, T.upd_m(), qc);
+      else
+        *u = shoup4(*u + (LAZY ? q << 3 : q) - v, T.upd(), 0 - q);
     }
   }
   return trusted;
@@ -1125,9 +1169,10 @@ __device__ __forceinline__ void rns_extend_fast_one(const ExtPlanDev& P, const E
   for (int t = 0; t < P.nt; t++) {
     const TgtRec<N> T(pack, t);
     const uint64_t q = T.q();
-    const uint64_t negP = q - T.pmod();   // -P mod t: enters cnt times (centring, and the HPS quotient)
+    const bool mont = T.mont();
+    const uint64_t negP = mont ? T.negp_m() : q - T.pmod();   // -P mod t: enters cnt times (centring, and the HPS quotient)
     uint64_t r;
-    if (T.lazy()) {
+    if (mont || T.lazy()) {
       // N <= 16 products of < 2^60 per accumulator
       uint64_t c00 = 0, c01 = 0, c10 = 0, c11 = 0;
 #pragma unroll
@@ -1140,7 +1185,10 @@ __device__ __forceinline__ void rns_extend_fast_one(const ExtPlanDev& P, const E
         c11 += (uint64_t)a1[k] * w1;
       }
       const u128 S = (u128)cnt * negP + c00 + (((u128)c01 + c10) << 30) + ((u128)c11 << 60);
-      r = red128_q8_lazy(S, q, T.mu63(), T.k());
+      if (mont)   // Proth-form target (TgtRec::mont): S < (16 2^60 + cnt) q, r in (0, q (N/16 + 1 + 2^-32)) -- below 3q
+        r = mont_redc128((uint64_t)S, (uint64_t)(S >> 64), make_qc(q, 0));
+      else
+        r = red128_q8_lazy(S, q, T.mu63(), T.k());
     } else {
       // the terms outgrow red128_q8's domain (more than eight same-size sources, or sources larger than the
       // target): the same limb sums, reduced by red128_any.  (Round 2 carried a remainder through chunks of seven

@@ -21,6 +21,7 @@ struct Switches {
   bool no_lazy_rns = false;      // HX_NO_LAZY_RNS=1     no 128-bit lazy sums / one-subtraction Garner steps
   bool no_fast_break = false;    // HX_NO_FAST_BREAK=1   generic break_digits_kernel instead of the fast one
   bool no_fast_extend = false;   // HX_NO_FAST_EXTEND=1  generic rns_extend_kernel instead of rns_extend_fast_kernel
+  bool no_proth_rns = false;     // HX_NO_PROTH_RNS=1    fast kernels: Barrett / Shoup products on Proth-form primes too (HX_NO_PROTH implies it)
   bool no_wide_extend = false;   // HX_NO_WIDE_EXTEND=1  generic rns_extend_kernel<40> instead of rns_extend_wide_kernel (17..40 sources)
   // fused ciphertext-level paths
   bool no_tensor_multi = false;  // HX_NO_TENSOR_MULTI=1 tensor product + several-primes mod-switch as two steps
@@ -54,6 +55,7 @@ inline Switches read()
   s.no_lazy_rns = on("HX_NO_LAZY_RNS");
   s.no_fast_break = on("HX_NO_FAST_BREAK");
   s.no_fast_extend = on("HX_NO_FAST_EXTEND");
+  s.no_proth_rns = on("HX_NO_PROTH_RNS");
   s.no_wide_extend = on("HX_NO_WIDE_EXTEND");
   s.no_tensor_multi = on("HX_NO_TENSOR_MULTI");
   s.no_mulrelin_fuse = on("HX_NO_MULRELIN_FUSE");

@@ -2346,6 +2346,60 @@ def test_hps_form_of_the_rns_kernels_and_its_redo_list(hx, monkeypatch, eps):
     test_tensor_folded_into_the_mod_switch(hx, 16384, 65537, "drop3")
 
 
+@pytest.mark.parametrize("no_proth_rns", [False, True])
+def test_proth_form_of_the_fast_rns_kernels(hx, monkeypatch, no_proth_rns):
+    """The fast digit / basis-extension kernels on Proth-form primes (rns_kernels.h: ExtPlanDev::src_mont,
+    TgtRec::mont; engine.hip: rec_to_mont): Garner steps, the targets' limb sums and the later rows' fix-ups as
+    Montgomery products / mont_redc128 -- the choice is per source set and per TARGET.  First the plain cases
+    (every prime of the form), then a chain that mixes a 38-bit prime that is NOT of the form (q != 1 mod 2^32) in:
+    as a source next to 60-bit ones (that digit keeps the Shoup Garner steps, its targets are of both kinds) and as
+    a target of all-Proth digits (red128_any next to mont_redc128 in one launch); also in the HPS form
+    (HX_HPS_MIN_N = 2) and through addPrimes / scaleDownToSet.  Every word against the oracle, and the same under
+    HX_NO_PROTH_RNS = 1 (the Barrett / Shoup forms everywhere)."""
+    if no_proth_rns:
+        monkeypatch.setenv("HX_NO_PROTH_RNS", "1")
+    else:
+        monkeypatch.delenv("HX_NO_PROTH_RNS", raising=False)
+    test_break_into_digits(hx, [[0, 1], [2, 3], [4]])
+    test_break_into_digits(hx, [[0, 1, 2, 3, 4]])
+    test_scale_down_to_set(hx, 65537)
+    test_break_into_digits_and_relinearize_norms(hx, [[0, 1], [2, 3], [4]])
+    m = 16384
+    q38 = O.PrimeGen(38, m).next()
+    assert q38 & 0xffffffff != 1 and q38 >> 32
+    g60, g56 = O.PrimeGen(60, m), O.PrimeGen(56, m)
+    primes = [q38] + [g60.next() for _ in range(5)] + [g56.next() for _ in range(2)]
+    for hps in (False, True):
+        if hps:
+            monkeypatch.setenv("HX_HPS_MIN_N", "2")
+        P = Pair(hx, m, primes)
+        own, sp = list(range(6)), [6, 7]
+        a = P.rand(own, 9, batch=2)
+        a[1, 0, :] = primes[1] - 1
+        a[0, 1, ::2] = 0
+        for digits in ([[0, 1], [2, 3], [4, 5]], [[0], [1, 2, 3], [4, 5]], [[0, 1, 2, 3, 4, 5]]):
+            dg = hx.DoubleCRT(P.g, own, 2, a).breakIntoDigits(digits, sp)
+            got = dg.download()
+            for b in range(2):
+                want = P.o.break_into_digits(own, a[:, b], digits, own + sp)
+                assert np.array_equal(got[:, b].reshape(len(digits), 8, P.N), want), (hps, digits, b)
+        d2 = hx.DoubleCRT(P.g, [1, 2, 3], 2, a[1:4])
+        d2.addPrimes([0, 4, 6])
+        got = d2.download()
+        assert d2.getIndexSet() == [1, 2, 3, 0, 4, 6]
+        for b in range(2):
+            ext = P.o.add_primes([1, 2, 3], a[1:4, b], [0, 4, 6])
+            assert np.array_equal(got[3:, b], ext) and np.array_equal(got[:3, b], a[1:4, b])
+        for drop in ([4, 5], [0, 5], [1, 2, 3]):
+            ev = hx.DoubleCRT(P.g, own, 2, a)
+            keep = [i for i in own if i not in drop]
+            ev.scaleDownToSet(keep, 65537)
+            g2 = ev.download()
+            for b in range(2):
+                want = P.o.scale_down(own, a[:, b], drop, 65537)
+                assert np.array_equal(g2[:, b], want), (hps, drop, b)
+
+
 @pytest.mark.parametrize("eps", ["default", "0.05", "1.0"])
 @pytest.mark.parametrize("n", [17, 24, 25, 33, 36, 40])
 def test_wide_rns_kernel_17_to_40_source_primes(hx, monkeypatch, n, eps):

@@ -154,6 +154,133 @@ def test_proth_row_transform_replayed_on_cpu(replay, logn, bits):
     assert replay.ntt_replay_proth(logn, 0, 0, q31, O.Cmod(m, q31).root, out.ctypes.data, out.ctypes.data) == -2
 
 
+def test_proth_form_of_the_digit_kernel_restated():
+    """break_digit_pass / rns_extend_fast_one on Proth-form primes (helib_amd/csrc/rns_kernels.h: ExtPlanDev::src_mont,
+    TgtRec::mont; engine.hip: rec_to_mont), restated word for word with python integers on the digits of the bits = 950
+    chain (6 / 5 / 5 ctxt primes, 60 bits; 6 special primes, 56 bits) and checked against the definition
+    (src/DoubleCRT.cpp:479-561: digit = centred CRT of its own rows, extended to every other row; later digits'
+    rows -= digit, /= P):
+      * Garner steps as Montgomery products by p_l^-1 2^64: operand v + 2 p_k - a_l in (0, 6 p_k), result below 2 p_k;
+      * a target's limb sum (30-bit limbs, three accumulators, none wraps) + cnt (-P 2^64), reduced by mont_redc128:
+        the stray 2^-64 cancels the 2^64 of the record's words, the result is below 2q and congruent to the digit;
+      * the later rows' fix-up u + 2q - v (u < 4q) times P^-1 2^64: below 2q, so the next digit's loads stay lazy
+        words below 4 p_k."""
+    import random
+    rnd = random.Random(17)
+    M32, M64 = 2 ** 32 - 1, 2 ** 64 - 1
+    qs = _chain_primes()[(32768, 950)]
+    ctxt = sorted(q for q in qs if q.bit_length() == 60)[:16]
+    special = [q for q in qs if q.bit_length() == 56][:6]
+    assert len(ctxt) == 16 and len(special) == 6
+    rows = ctxt + special                    # all rows, ctxt first (the digit kernel's order is ascending row index)
+    L = 16
+    offs = [0, 6, 11, 16]
+
+    def mont_acc(y, W, q, x=0):              # ntt_core.h mont_acc, word for word
+        qh = q >> 32
+        c1 = (1 + qh) * (2 ** 32 + 1)
+        assert q & M32 == 1 and y < 207 * q // 16
+        yl, yh, wl, wh = y & M32, y >> 32, W & M32, W >> 32
+        a = yl * wl
+        n0 = ~a & M32
+        G = yl * wh + c1 + n0 * qh + (a >> 32) + yh * wl
+        assert G <= M64
+        n1 = ~G & M32
+        D = yh * wh + x + n1 * qh + (G >> 32)
+        assert D <= M64
+        return D
+
+    def mont_redc128(lo, hi, q):             # ntt_core.h mont_redc128, word for word
+        qh = q >> 32
+        c1 = (1 + qh) * (2 ** 32 + 1)
+        assert hi < 2 ** 62
+        n0 = ~lo & M32
+        G = n0 * qh + c1 + (lo >> 32)
+        assert G <= M64
+        n1 = ~G & M32
+        D = n1 * qh + hi + (G >> 32)
+        assert D <= M64
+        return D
+
+    def m64(x, q):
+        return (x << 64) % q
+
+    for trial in range(60):
+        x = [rnd.randrange(q) for q in ctxt]                     # the operand's coefficient, canonical rows
+        if trial == 0:
+            x = [q - 1 for q in ctxt]
+        if trial == 1:
+            x = [0] * 16
+        xs = list(x)                                             # the LDS column: later rows updated in place
+        want_rows = list(x)
+        for d in range(3):
+            off, N = offs[d], offs[d + 1] - offs[d]
+            p = ctxt[off:off + N]
+            P = 1
+            for v in p:
+                P *= v
+            # ---- Garner front (garner_front, src_mont) on lazy words
+            a = []
+            for k in range(N):
+                v = xs[off + k]
+                assert v < 4 * p[k]
+                for l in range(k):
+                    ginv_m = m64(pow(p[l], -1, p[k]), p[k])
+                    y = v + 2 * p[k] - a[l]
+                    assert 0 < y < 6 * p[k]
+                    v = mont_acc(y, ginv_m, p[k])
+                    assert 0 < v < 2 * p[k]
+                if v >= 2 * p[k]:
+                    v -= 2 * p[k]
+                if v >= p[k]:
+                    v -= p[k]
+                a.append(v)
+            val, run = 0, 1
+            for k in range(N):
+                val += a[k] * run
+                run *= p[k]
+            assert 0 <= val < P and all(val % p[k] == want_rows[off + k] % p[k] for k in range(N))
+            neg = val > (P - 1) // 2
+            cnt = 1 if neg else 0
+            digit = val - P if neg else val
+            a0 = [v & 0x3fffffff for v in a]
+            a1 = [v >> 30 for v in a]
+            assert all(v < 2 ** 30 for v in a1)
+            # ---- every other row
+            for r, q in enumerate(rows):
+                if off <= r < off + N:
+                    continue
+                negP_m = m64(q - P % q, q)
+                c00 = c01 = c11 = 0
+                run = 1
+                for k in range(N):
+                    W = m64(run % q, q)                          # the record's multiplier: (p_0..p_{k-1}) 2^64 mod q
+                    run *= p[k]
+                    w0, w1 = W & 0x3fffffff, W >> 30
+                    assert w1 < 2 ** 30
+                    c00 += a0[k] * w0
+                    c01 += a0[k] * w1 + a1[k] * w0
+                    c11 += a1[k] * w1
+                assert max(c00, c01, c11) <= M64
+                S = cnt * negP_m + c00 + (c01 << 30) + (c11 << 60)
+                v = mont_redc128(S & M64, S >> 64, q)
+                assert 0 < v < 2 * q and v % q == digit % q
+                if off + N <= r < L:
+                    u = xs[r]
+                    assert u < 4 * q
+                    y = u + 2 * q - v
+                    assert 0 < y < 6 * q
+                    xs[r] = mont_acc(y, m64(pow(P, -1, q), q), q)
+                    assert 0 < xs[r] < 2 * q
+                    want_rows[r] = (want_rows[r] - digit) * pow(P, -1, q) % q
+                    assert xs[r] % q == want_rows[r]
+    # a target with sixteen 60-bit sources (rns_extend_fast_one, four accumulators): S 2^-64 + q (1 + 2^-32) < 3q
+    q = special[0]
+    S = 16 * (2 ** 60 - 1) * (q - 1) + 17 * (q - 1)
+    v = mont_redc128(S & M64, S >> 64, q)
+    assert v < 3 * q and v % q == S * pow(2 ** 64, -1, q) % q
+
+
 def test_c_abi_exports_every_declared_symbol():
     from helib_amd import capi
     hdr = open(os.path.join(ROOT, "include", "helib_amd.h")).read()
