@@ -208,6 +208,9 @@ int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const int* dig_of
  *                                            mod-switch / inside hx_mul_relin
  *   HX_NO_PROTH                               row transforms: Shoup butterflies on every row (by default rows of primes
  *                                            q = 1 mod 2^32 -- every chain prime of the benchmarks -- run the Proth-form ones)
+ *   HX_NO_PROTH_RNS                           exact-RNS kernels: Barrett / Shoup products on Proth-form primes too (by default
+ *                                            their Garner steps, target sums and fix-ups are Montgomery products; HX_NO_PROTH
+ *                                            implies it)
  *   HX_BLUE_OLD                               general m: the chain of passes instead of one convolution kernel
  *   HX_NORM_ASYNC, HX_NORM_OLD, HX_NORM_PLAIN, HX_NORM_MEMCPY
  *                                            variants of the canonical-embedding norm kernels and their read-back
