@@ -1963,6 +1963,10 @@ static int pow2_big_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
 // a ring whose forward row transform takes lazy input (ntt_launch lazy_in): the exact-RNS kernels in front of it may
 // leave their output words unreduced
 static bool ntt_lazy_input_ok(const hx_ctx* c) { return c->pow2 && c->logn >= 13 && c->logn <= 15; }
+// the digit kernel may leave its extension words unreduced for that transform: rows of Proth-form primes are then read
+// at bound 2 (ntt_kernels.hip BufIOT), which is what the digit kernel's Proth-form target sums deliver -- with those
+// switched off (HX_NO_PROTH_RNS) while the rows keep the Proth-form butterflies, the words are reduced instead
+static bool digits_lazy_ok(const hx_ctx* c) { return ntt_lazy_input_ok(c) && (!c->sw.no_proth_rns || c->sw.no_proth); }
 
 static int ntt_list(hx_ctx* c, const uint64_t* in, uint64_t* out,
                     const std::vector<std::pair<int, int>>& rows, int batch, bool inverse, bool lazy_in = false)
@@ -3554,7 +3558,9 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
       args.src_row[k] = (uint16_t)k;
     for (int t = 0; t < nk; t++)
       args.dst_row[t] = (uint16_t)t;
-    args.lazy_out = 1;   // scratch[1] is read by step 3 only, whose row loads are declared with LOAD_BOUND 8
+    // scratch[1] is read by step 3 only, whose row loads are declared with LOAD_BOUND 8 -- 4 on rows of Proth-form
+    // primes, which is what the fast kernel's Proth-form target sums deliver (as digits_lazy_ok)
+    args.lazy_out = (c->sw.no_proth_rns && !c->sw.no_proth) ? 0 : 1;
     if (c->want_frac) {
       args.frac = frac_take(c, rw);
       if (!args.frac)
@@ -4657,7 +4663,7 @@ static int relin_core(hx_ctx* c, const uint64_t* t2e, const std::vector<int>& ow
     // the extension words go straight into the forward transform below: where that takes lazy input they are left
     // unreduced (three conditional subtractions less per word)
     int rc = break_digits_fused(c, c->scratch[2], own, dig_idx, dig_off, ndig, all, c->scratch[1],
-                                rw, &owner, ntt_lazy_input_ok(c));
+                                rw, &owner, digits_lazy_ok(c));
     if (rc == HX_ERR_UNSUPPORTED)
       rc = break_digits_coef(c, c->scratch[2], own, dig_idx, dig_off, ndig, all, c->scratch[1], rw,
                              /*copy_own=*/false, &owner);

@@ -102,9 +102,17 @@ __device__ __forceinline__ TW tw_vec(const BufTw& t, unsigned base, unsigned lan
 // LB: bound (in units of q) of the words the row holds on entry -- 1: canonical residues; 8: the lazy output of
 // the exact-RNS kernels (break_digits_fast_kernel<., true>: values in [0,6q) they did not finish reducing, because
 // the forward transform that reads them takes any bound up to 12 and tracks it at compile time)
+// Rows of Proth-form primes under LB = 8: their only producer is the digit kernel's Proth-form target sum
+// (rns_kernels.h TgtRec::mont: mont_redc128, below q (n/16 + 1 + 2^-32) < 2q for digits of up to eight primes) -- the
+// engine leaves digit words unreduced only when that form is on (engine.hip digits_lazy_ok) -- so the Proth-form passes
+// start from bound 2 and take one conditional-subtraction stage less (three instead of four at N = 2^14 / 2^15).
 template <int LB>
 struct BufIOT {
   static constexpr int LOAD_BOUND = LB;
+#ifndef HX_DIGITS_LB8
+  template <class AR>
+  static constexpr int load_bound() { return (LB == 8 && AR::PROTH) ? 2 : LB; }
+#endif
   static constexpr bool LAZY_STORE = false;
   static constexpr bool PIPELINED = false;
   struct StorePrefetch {};
@@ -220,8 +228,14 @@ struct ModDownIO {
   // transform output and normalises once, after the subtraction
   static constexpr int LOAD_BOUND = PLAIN ? 8 : 6;   // (PLAIN: ExtArgs::lazy_out words, [0,8q))
   // Proth-form rows: x*inv is a Montgomery product below 2q (mont_acc), plus q - S in (0,2q)
+  // PLAIN on a Proth-form row: the extension word is a mont_redc128 result below 3q plus the plaintext-space correction
+  // (rns_extend_fast_one, TgtRec::mont) -- below 4q; the engine asks for unreduced words only when that form is on
   template <class AR>
+#ifndef HX_DIGITS_LB8
+  static constexpr int load_bound() { return AR::PROTH ? 4 : (PLAIN ? 8 : 6); }
+#else
   static constexpr int load_bound() { return PLAIN ? 8 : (AR::PROTH ? 4 : 6); }
+#endif
   static constexpr bool LAZY_STORE = true;
   // Element IO is software-pipelined in groups of IOG elements.  Round 1 loaded x, S (and, in the
   // store, c_r) inside the same scheduling region as the ~40 instructions that consume them, one
@@ -641,7 +655,11 @@ template <bool PLAIN>
 struct ModDownTensorIO {
   static constexpr int LOAD_BOUND = PLAIN ? 8 : 6;   // (PLAIN: ExtArgs::lazy_out words, [0,8q))
   template <class AR>
+#ifndef HX_DIGITS_LB8
+  static constexpr int load_bound() { return AR::PROTH ? 4 : (PLAIN ? 8 : 6); }   // (PLAIN Proth rows: as ModDownIO)
+#else
   static constexpr int load_bound() { return PLAIN ? 8 : (AR::PROTH ? 4 : 6); }
+#endif
   static constexpr bool LAZY_STORE = true;
   static constexpr bool PIPELINED = !PLAIN;
   static constexpr int IOG = 4;
@@ -875,17 +893,24 @@ ntt_row_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
 
 // inverse transform of a(X) * b(X) given in evaluation form: the s^2 part of a tensor product (a1 b1) goes
 // straight from the operands' rows to its coefficient rows (hx_mul_relin: toPoly side of breakIntoDigits)
+// PROTH (rows of Proth-form primes, ntt_core.h ArProth): the 128-bit product goes through mont_redc128 alone -- two
+// multiply-adds and two carries for the Barrett's seven multiplications and three conditional subtractions -- into
+// (0, q (1/16 + 1 + 2^-32)): the inverse transform takes it as it is (bound 2, like the convolution kernel's pointwise
+// product), and the 2^-64 it carries is given back by the last stage's constants (N^-1 twiddles x 2^128 by PrimeDev::r2)
+template <bool PROTH>
 struct MulLoadIO {
   static constexpr int LOAD_BOUND = 1;
   static constexpr bool LAZY_STORE = false;
   static constexpr bool PIPELINED = false;
+  template <class AR>
+  static constexpr int inv_load_bound() { return PROTH ? 2 : 1; }
   struct StorePrefetch {};
   v4i32 ra, rb, ro;
-  uint64_t q, mu63;
+  uint64_t q, mu63, r2;
   uint32_t k;
   __device__ MulLoadIO(const uint64_t* a_row, const uint64_t* b_row, uint64_t* o_row, unsigned bytes, const PrimeDev* pd)
       : ra(make_rsrc(a_row, bytes)), rb(make_rsrc(b_row, bytes)), ro(make_rsrc(o_row, bytes)), q(pd->q), mu63(pd->mu63),
-        k(pd->k)
+        r2(pd->r2), k(pd->k)
   {
   }
   __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
@@ -893,7 +918,11 @@ struct MulLoadIO {
     const v2i32 x = hx_buffer_load_v2(ra, (int)(tid * 8u), (int)(c * 8u), HX_NT);
     const v2i32 y = hx_buffer_load_v2(rb, (int)(tid * 8u), (int)(c * 8u), HX_NT);
     const uint64_t a = ((uint64_t)(uint32_t)x.y << 32) | (uint32_t)x.x, b = ((uint64_t)(uint32_t)y.y << 32) | (uint32_t)y.x;
-    return tensor_red128((u128)a * b, q, mu63, k);
+    const u128 p = (u128)a * b;
+    if constexpr (PROTH)
+      return mont_redc128((uint64_t)p, (uint64_t)(p >> 64), make_qc(q, 0));
+    else
+      return tensor_red128(p, q, mu63, k);
   }
   __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t v) const
   {
@@ -903,7 +932,15 @@ struct MulLoadIO {
     hx_buffer_store_v2(d, ro, (int)(tid * 8u), (int)(c * 8u), HX_NT);
   }
   __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
-  __device__ __forceinline__ TWM last_tw(TWM def, int) const { return def; }
+  __device__ __forceinline__ TWM last_tw(TWM def, int) const
+  {
+    if constexpr (PROTH) {
+      const QC qc = make_qc(q, 0);   // (q, qh, c1 are all this needs)
+      return csub(mont_mul(def, r2, qc), q);
+    } else {
+      return def;
+    }
+  }
 };
 template <int LOGN>
 __global__ void __launch_bounds__(Geo<LOGN>::T, HX_NTT_MINWAVES(LOGN))
@@ -918,8 +955,21 @@ ntt_inv_mul_kernel(const uint64_t* a, const uint64_t* b, uint64_t* out, NttRows 
   const PrimeDev* pd = primes + uniform_u16(rows.prime, ri);
   const size_t N = Geo<LOGN>::N;
   const size_t roff = ((size_t)row * batch + bb) * N, ooff = ((size_t)ri * batch + bb) * N;   // output rows are compact
-  const MulLoadIO io(a + roff, b + roff, out + ooff, (unsigned)N * 8u, pd);
-  ntt_body<LOGN, true>(lds, io, tw_arena + pd->tw_inv_off, pd);
+  const QC qc = make_qc(pd->q, pd->mu64);
+  const TW* tw = tw_arena + pd->tw_inv_off;
+#ifndef HX_NO_PROTH
+  if (pd->proth) {   // (uniform: one workgroup, one prime)
+#ifndef HX_INVMUL_BARRETT
+    const MulLoadIO<true> io(a + roff, b + roff, out + ooff, (unsigned)N * 8u, pd);
+#else
+    const MulLoadIO<false> io(a + roff, b + roff, out + ooff, (unsigned)N * 8u, pd);   // (the A/B control: Barrett on load)
+#endif
+    ntt_body_ar<LOGN, true, ArProth>(lds, io, reinterpret_cast<const TWM*>(tw), qc);
+    return;
+  }
+#endif
+  const MulLoadIO<false> io(a + roff, b + roff, out + ooff, (unsigned)N * 8u, pd);
+  ntt_body_ar<LOGN, true, ArShoup>(lds, io, tw, qc);
 }
 template <int LOGN>
 static hipError_t launch_inv_mul(const uint64_t* a, const uint64_t* b, uint64_t* out, const NttRows& rows, int nrows,

@@ -27,6 +27,12 @@ template <int LB>
 struct PtrIOLB : hx::PtrIO {
   static constexpr int LOAD_BOUND = LB;
 };
+// the digit rows as the device reads them (BufIOT<8>): declared bound 8, rows of Proth-form primes at bound 2
+struct PtrIOLB8P2 : hx::PtrIO {
+  static constexpr int LOAD_BOUND = 8;
+  template <class AR>
+  static constexpr int load_bound() { return AR::PROTH ? 2 : 8; }
+};
 template <int LOGN, int PH, class AR, class IO>
 static void run_phase(bool inverse, std::vector<uint64_t>& V, std::vector<uint32_t>& NL,
                       std::vector<uint32_t>& lds, const uint64_t* in, uint64_t* out,
@@ -99,6 +105,12 @@ extern "C" int ntt_replay_proth(int logn, int inverse, int lazy8, uint64_t q, ui
 {
   if (!hx::is_proth32(q))
     return -2;
+  if (lazy8 == 2 && !inverse)   // words in [0,2q): the digit kernel's Proth-form target sums
+    switch (logn) {
+      case 13: return replay<13, hx::ArProth, PtrIOLB8P2>(0, q, psi, in, out);
+      case 14: return replay<14, hx::ArProth, PtrIOLB8P2>(0, q, psi, in, out);
+      case 15: return replay<15, hx::ArProth, PtrIOLB8P2>(0, q, psi, in, out);
+    }
   if (lazy8 && !inverse)
     switch (logn) {
       case 13: return replay<13, hx::ArProth, PtrIOLB<8>>(0, q, psi, in, out);
@@ -109,6 +121,82 @@ extern "C" int ntt_replay_proth(int logn, int inverse, int lazy8, uint64_t q, ui
     case 13: return replay<13, hx::ArProth>(inverse, q, psi, in, out);
     case 14: return replay<14, hx::ArProth>(inverse, q, psi, in, out);
     case 15: return replay<15, hx::ArProth>(inverse, q, psi, in, out);
+  }
+  return -1;
+}
+// The inverse transform of a pointwise product formed on load (MulLoadIO<true>, ntt_kernels.hip: the s^2 part of a tensor
+// product in hx_mul_relin): the 128-bit product reduced by mont_redc128 alone, handed to the Proth-form inverse passes at
+// bound 2, its 2^-64 given back by the last stage's constants times 2^128.  Same arithmetic as the device functor, with
+// plain pointers for its buffer loads; every lazy bound asserted (HX_CHECK_BOUNDS).
+struct MulPtrIO {
+  static constexpr int LOAD_BOUND = 1;
+  static constexpr bool LAZY_STORE = false;
+  static constexpr bool PIPELINED = false;
+  template <class AR>
+  static constexpr int inv_load_bound() { return 2; }
+  struct StorePrefetch {};
+  const uint64_t* a;
+  const uint64_t* b;
+  uint64_t* out;
+  uint64_t q, r2;
+  uint64_t load(unsigned tid, unsigned c) const
+  {
+    const u128 p = (u128)a[tid + c] * b[tid + c];
+    return hx::mont_redc128((uint64_t)p, (uint64_t)(p >> 64), hx::make_qc(q, 0));
+  }
+  void store(unsigned tid, unsigned c, uint64_t v) const { out[tid + c] = v; }
+  hx::TW last_tw(hx::TW def, int) const { return def; }
+  hx::TWM last_tw(hx::TWM def, int) const
+  {
+    const hx::QC qc = hx::make_qc(q, 0);
+    return hx::csub(hx::mont_mul(def, r2, qc), q);
+  }
+};
+template <int LOGN, int PH>
+static void run_mul_phase(std::vector<uint64_t>& V, std::vector<uint32_t>& NL, std::vector<uint32_t>& lds, const MulPtrIO& io,
+                          const hx::TWM* tw, uint64_t q)
+{
+  using R = hx::RowNTT<LOGN, hx::ArProth>;
+  constexpr int T = hx::Geo<LOGN>::T;
+  for (unsigned tid = 0; tid < (unsigned)T; tid++) {
+    uint64_t(&v)[32] = *reinterpret_cast<uint64_t(*)[32]>(&V[tid * 32]);
+    uint32_t(&nl)[32] = *reinterpret_cast<uint32_t(*)[32]>(&NL[tid * 32]);
+    R::template inv<PH>(tid, v, nl, lds.data(), io, tw, hx::make_qc(q));
+  }
+}
+template <int LOGN>
+static int replay_mul(uint64_t q, uint64_t psi, const uint64_t* a, const uint64_t* b, uint64_t* out)
+{
+  using G = hx::Geo<LOGN>;
+  std::vector<hx::TW> f(G::TW_TOTAL), i(G::TW_TOTAL);
+  uint64_t psi_inv = pw(psi, q - 2, q);
+  uint64_t n_inv = pw((uint64_t)G::N % q, q - 2, q);
+  hx::build_tw_tables<LOGN>(q, psi, psi_inv, n_inv, mm, f.data(), i.data());
+  const std::vector<hx::TWM> tab = table_of<hx::ArProth>(i, q);
+  std::vector<uint64_t> V((size_t)G::T * 32);
+  std::vector<uint32_t> NL((size_t)G::T * 32);
+  std::vector<uint32_t> lds(G::LDS_WORDS, 0xdeadbeef);
+  std::vector<uint64_t> ac(a, a + G::N), bc(b, b + G::N);
+  const uint64_t r1 = (uint64_t)((((u128)1) << 64) % q);
+  const MulPtrIO io{ac.data(), bc.data(), out, q, mm(r1, r1, q)};
+  run_mul_phase<LOGN, 0>(V, NL, lds, io, tab.data(), q);
+  run_mul_phase<LOGN, 1>(V, NL, lds, io, tab.data(), q);
+  run_mul_phase<LOGN, 2>(V, NL, lds, io, tab.data(), q);
+  run_mul_phase<LOGN, 3>(V, NL, lds, io, tab.data(), q);
+  run_mul_phase<LOGN, 4>(V, NL, lds, io, tab.data(), q);
+  run_mul_phase<LOGN, 5>(V, NL, lds, io, tab.data(), q);
+  run_mul_phase<LOGN, 6>(V, NL, lds, io, tab.data(), q);
+  run_mul_phase<LOGN, 7>(V, NL, lds, io, tab.data(), q);
+  return 0;
+}
+extern "C" int ntt_replay_proth_mul(int logn, uint64_t q, uint64_t psi, const uint64_t* a, const uint64_t* b, uint64_t* out)
+{
+  if (!hx::is_proth32(q))
+    return -2;
+  switch (logn) {
+    case 13: return replay_mul<13>(q, psi, a, b, out);
+    case 14: return replay_mul<14>(q, psi, a, b, out);
+    case 15: return replay_mul<15>(q, psi, a, b, out);
   }
   return -1;
 }

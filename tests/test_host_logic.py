@@ -29,6 +29,7 @@ def replay():
     L.ntt_replay.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     L.ntt_replay_proth.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     L.mont_acc_replay.argtypes = [C.c_uint64, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ntt_replay_proth_mul.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -148,6 +149,11 @@ def test_proth_row_transform_replayed_on_cpu(replay, logn, bits):
         lazy = x + np.uint64(q) * rng.integers(0, 8, N, dtype=np.uint64)
         lazy[0] = x[0] + np.uint64(7 * q)
         assert replay.ntt_replay_proth(logn, 0, 1, q, cm.root, lazy.ctypes.data, out.ctypes.data) == 0
+        assert np.array_equal(out, y)
+        # the digit rows as the device reads them (BufIOT<8>::load_bound<ArProth>() = 2): words in [0,2q)
+        lazy2 = x + np.uint64(q) * rng.integers(0, 2, N, dtype=np.uint64)
+        lazy2[0] = x[0] + np.uint64(q)
+        assert replay.ntt_replay_proth(logn, 0, 2, q, cm.root, lazy2.ctypes.data, out.ctypes.data) == 0
         assert np.array_equal(out, y)
     # a prime that is not of the form is refused by the Proth replay (the engine gives such rows the Shoup kernels)
     q31 = O.PrimeGen(31, m).next()
@@ -279,6 +285,30 @@ def test_proth_form_of_the_digit_kernel_restated():
     S = 16 * (2 ** 60 - 1) * (q - 1) + 17 * (q - 1)
     v = mont_redc128(S & M64, S >> 64, q)
     assert v < 3 * q and v % q == S * pow(2 ** 64, -1, q) % q
+
+
+@pytest.mark.parametrize("logn", [13, 14, 15])
+@pytest.mark.parametrize("bits", [60, 56, 45])
+def test_proth_product_on_load_replayed_on_cpu(replay, logn, bits):
+    """ntt_inv_mul_kernel on a Proth-form row (MulLoadIO<true>, helib_amd/csrc/ntt_kernels.hip): the inverse transform
+    of a pointwise product whose 128-bit words are reduced by mont_redc128 alone on load -- values in (0, 2q) carrying
+    2^-64, taken by the inverse passes at bound 2, the factor given back by the last stage's constants times 2^128.
+    The same arithmetic replayed thread by thread with every lazy bound asserted: random rows, all-(q-1) rows (the
+    largest products) and rows with zeros, against the oracle's iFFT of the canonical product."""
+    N = 1 << logn
+    m = 2 * N
+    q = O.PrimeGen(bits, m).next()
+    cm = O.Cmod(m, q)
+    rng = np.random.default_rng(logn + bits)
+    cases = [(O.fill_uniform(N, q, 3), O.fill_uniform(N, q, 4)),
+             (np.full(N, q - 1, dtype=np.uint64), np.full(N, q - 1, dtype=np.uint64)),
+             (O.fill_uniform(N, q, 6) * rng.integers(0, 2, N, dtype=np.uint64), O.fill_uniform(N, q, 7))]
+    for a, b in cases:
+        prod = np.array([int(x) * int(y) % q for x, y in zip(a, b)], dtype=np.uint64)
+        want = cm.ifft(prod)
+        out = np.zeros(N, dtype=np.uint64)
+        assert replay.ntt_replay_proth_mul(logn, q, cm.root, a.ctypes.data, b.ctypes.data, out.ctypes.data) == 0
+        assert np.array_equal(out, want)
 
 
 def test_c_abi_exports_every_declared_symbol():
