@@ -731,7 +731,7 @@ def levels_leg(hh, sparams, batch, R, device, stream, sync, warm_steps=2, steps=
 # static instruction counts of the row-transform kernels per 512-thread workgroup (VALU
 # instructions per wave and row x 8 waves x 64 lanes) and their 64-bit modular multiplications per row
 # (round 5, the Proth-form path: DYNAMIC counts per wave from the SQ_INSTS_VALU pass, profiles/r05_valu_floor_by_class.json)
-VALU_PER_WAVE = {"ntt_row_kernel<14, false, 8>": 4031, "ntt_moddown_apply_kernel<14, false>": 4836,
+VALU_PER_WAVE = {"ntt_row_kernel<14, false, 8>": 3903, "ntt_moddown_apply_kernel<14, false>": 4836,
                  "ntt_moddown_apply_tensor_kernel<14, false>": 5455}
 
 
