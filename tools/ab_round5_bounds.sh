@@ -1,3 +1,9 @@
+#!/bin/bash
+# One GPU call of round 5 (kept as the record of how profiles/r05_ab_digit_row_bounds_and_product_on_load.json was
+# measured): the fast GPU suite, then same-box runs of the default library against two control builds --
+#   tools/build_variant.sh lb8 -DHX_DIGITS_LB8                (digit / extension rows read at bound 8 on every row)
+#   tools/build_variant.sh invmulbarrett -DHX_INVMUL_BARRETT  (Barrett product on load in ntt_inv_mul_kernel)
+# usage: gpurun -- 'bash tools/ab_round5_bounds.sh'   (writes gpurun_out/r5h/)
 bash tools/gpu_calls.sh r5h tests_fast
 R=$PWD; out=gpurun_out/r5h
 run() { # name workload variant
