@@ -22,6 +22,7 @@
 #include "dev_common.h"
 #include "hostmath.h"
 #include "bluestein.h"
+#include "pfa_dev.h"
 #include "rns_kernels.h"
 #include "norm_kernels.h"
 #include "prg_kernels.h"
@@ -166,6 +167,7 @@ struct BluePrime {
   uint64_t* d_hat[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // Rb, iRb, NTT(-Psi), NTT(Phi), NTT(Phi mod X^(2^n3) + 1)
   TW* d_hatw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // the same as Shoup pairs (fused convolution kernel)
   ConvPlan conv[4];                                           // sizes bk, n1, n2, n3 (n3: the aliased form of the last one)
+  uint64_t* d_pfa = nullptr;   // m = 21845 on a Proth-form prime: the Good-Thomas x Rader tables (pfa_core.h), else null
 };
 
 struct hx_ctx {
@@ -197,6 +199,7 @@ struct hx_ctx {
   PrimeDev* d_cprimes = nullptr;
   int ncprimes = 0, cprimes_cap = 0;
   std::vector<struct BluePrime*> blue;
+  uint16_t* d_pfa_idx = nullptr;   // m = 21845: pos2 [16384], dlog3 [257 (+1 pad)], gpow3 [256]  (pfa::host::build_index_tables)
   std::vector<ConvPlan> bigplan;  // power-of-two rings with N = 2^16..2^18: per-prime split plans (pow2_big_rows)
   std::vector<int64_t> psi_low, phi_coef;  // -Psi mod X^(dq+1) and Phi_m, small integers
   std::map<std::vector<uint64_t>, ExtPlan*> plans;
@@ -609,6 +612,7 @@ static void ctx_free(hx_ctx* c)
     hipFree(b->dev);
     hipFree(b->d_powers);
     hipFree(b->d_ipowers);
+    hipFree(b->d_pfa);
     for (int i = 0; i < 5; i++) {
       hipFree(b->d_hat[i]);
       hipFree(b->d_hatw[i]);
@@ -628,6 +632,7 @@ static void ctx_free(hx_ctx* c)
   for (hipEvent_t e : c->timer)
     if (e)
       hipEventDestroy(e);
+  hipFree(c->d_pfa_idx);
   hipFree(c->d_zms);
   hipFree(c->d_zms_index);
   hipFree(c->d_perm);
@@ -1329,6 +1334,20 @@ static int blue_prime_create(hx_ctx* c, int idx)
     }
     CHK(make_hat(c, idx, 3, 4, folded));
   }
+  // m = 5 * 17 * 257 on a Proth-form prime: the transform itself runs as Good-Thomas x Rader (pfa_core.h), ONE launch
+  // per direction; the tables above stay for rem Phi_m (and for HX_NO_PFA / any other prime)
+  if (!bp->aux && !c->sw.no_pfa && !c->sw.no_proth && hx::pfa::host::supported(m, q)) {
+    if (!c->d_pfa_idx) {
+      std::vector<uint16_t> ix(16384 + 258 + 256, 0);
+      hx::pfa::host::build_index_tables(ix.data(), ix.data() + 16384, ix.data() + 16384 + 258);
+      HIPCHK(hipMalloc((void**)&c->d_pfa_idx, ix.size() * sizeof(uint16_t)));
+      HIPCHK(hipMemcpy(c->d_pfa_idx, ix.data(), ix.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    std::vector<uint64_t> tab(hx::pfa::TAB_WORDS);
+    hx::pfa::host::build_prime_table(q, ph.root, tab.data());
+    HIPCHK(hipMalloc((void**)&bp->d_pfa, tab.size() * 8));
+    HIPCHK(hipMemcpy(bp->d_pfa, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+  }
   return HX_OK;
 }
 
@@ -1359,6 +1378,10 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
   }
   if (fused)
     chunk = std::min(chunk, hx::CONV_MAXROWS);
+  // every row on a prime that has the Good-Thomas x Rader tables (m = 21845, blue_prime_create)
+  bool pfa = fused;
+  for (auto& rp : rows)
+    pfa = pfa && c->blue[rp.second]->d_pfa != nullptr;
   for (size_t first = 0; fused && first < rows.size(); first += chunk) {
     const int R = (int)std::min<size_t>(chunk, rows.size() - first);
     const size_t segs = (size_t)R * batch;
@@ -1386,29 +1409,46 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
           CR.pd[r * sp + g] = (uint16_t)b->conv[which].pd[g];
       }
     };
-    CHK(ensure_scratch(c, 5, segs * NB));
-    uint64_t* qbuf = c->scratch[5];
     hx::ConvRowArgs A;
     memset(&A, 0, sizeof A);
     A.batch = (uint32_t)batch;
     A.phim = phim;
     A.m = m;
-    A.in = in;
-    A.out = qbuf;
-    A.split = (uint32_t)split;
-    A.dst_mode = hx::CONV_DST_SUB;
     A.zidx = c->d_zms_index;
-    A.src_mode = inverse ? hx::CONV_SRC_SCATTER : hx::CONV_SRC_BLUE_PRE;
-    set_conv(0, inverse ? 1 : 0, split);
-    hipError_t e = hx::launch_conv_rows(lsub, A, CR, R * split, c->d_cprimes, c->d_tw, c->stream);
-    if (e != hipSuccess)
-      return fail(HX_ERR_DEVICE, "convolution launch failed: %s", hipGetErrorString(e));
+    hipError_t e = hipSuccess;
     uint64_t* xfull = nullptr;
     if (inverse) {
       CHK(ensure_scratch(c, 6, segs * c->mpad));
       CHK(ensure_scratch(c, 7, segs * N1));
       xfull = c->scratch[6];
     }
+    if (pfa) {
+      // Good-Thomas x Rader (pfa_core.h): the whole forward transform, or the inverse one up to X (all m words)
+      hx::PfaRows PR;
+      memset(&PR, 0, sizeof PR);
+      for (int r = 0; r < R; r++) {
+        PR.tab[r] = c->blue[rows[first + r].second]->d_pfa;
+        PR.row[r] = (uint16_t)rows[first + r].first;
+        PR.prime[r] = (uint16_t)rows[first + r].second;
+      }
+      e = hx::launch_pfa_rows(inverse, in, inverse ? xfull : out, PR, R, c->d_primes, c->d_pfa_idx, c->d_pfa_idx + 16384,
+                              c->d_pfa_idx + 16384 + 258, batch, c->mpad, c->stream);
+      if (e != hipSuccess)
+        return fail(HX_ERR_DEVICE, "Good-Thomas x Rader launch failed: %s", hipGetErrorString(e));
+      if (!inverse)
+        continue;
+    } else {
+    CHK(ensure_scratch(c, 5, segs * NB));
+    uint64_t* qbuf = c->scratch[5];
+    A.in = in;
+    A.out = qbuf;
+    A.split = (uint32_t)split;
+    A.dst_mode = hx::CONV_DST_SUB;
+    A.src_mode = inverse ? hx::CONV_SRC_SCATTER : hx::CONV_SRC_BLUE_PRE;
+    set_conv(0, inverse ? 1 : 0, split);
+    e = hx::launch_conv_rows(lsub, A, CR, R * split, c->d_cprimes, c->d_tw, c->stream);
+    if (e != hipSuccess)
+      return fail(HX_ERR_DEVICE, "convolution launch failed: %s", hipGetErrorString(e));
     // window / fold + second twist (+ the inverse split when the result is in four sub-blocks)
     uint64_t* pdst = inverse ? xfull : out;
     const uint32_t pn = inverse ? m : phim;
@@ -1421,6 +1461,7 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
     HIPCHK(hipGetLastError());
     if (!inverse)
       continue;
+    }
     // rem Phi_m: Q = rev_d( top(x) * (-Psi) mod X^(d+1) ), r = x - Q*Phi_m, then * m^-1
     uint64_t* wbuf = c->scratch[7];
     A.split = 1;

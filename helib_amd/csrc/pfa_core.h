@@ -39,7 +39,9 @@ constexpr int NT = 1024;
 constexpr int ROW = 272;                 // = 16 mod 32: two rows' accesses in one half-wave fall into disjoint banks
 constexpr int T_WORDS = 4 * P2 * P3;     // 17476
 constexpr int Z0_OFF = T_WORDS;          // (R needs 64 * 272 = 17408 <= 17476)
-constexpr int LDS_WORDS = Z0_OFF + 64;   // 17540 words = 140320 B
+constexpr int LDS_WORDS = Z0_OFF + 64;   // 17540 words = 140320 B  (forward)
+constexpr int OUT_LDS = 20480;           // inverse: all 160 KiB stage the output row (21845 words: the last 1365 go straight to memory)
+constexpr int INV_LDS_WORDS = OUT_LDS;
 constexpr int NUNITS = P2 * P3;          // 4369 five-point units (i2, i3)
 constexpr int UROUNDS = (NUNITS + NT - 1) / NT;   // 5
 
@@ -510,9 +512,11 @@ HXD void fwd(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
 //   phase 5  R <- results at their natural i3 = g^a3 (and i3 = 0)
 //   phase 6  thread (i3, j1): Rader-17 transposed over b2 from R; threads < 68: the i3 = 0 column, direct
 //   phase 7  T <- them
-//   phase 8  five-point units (i2, i3): Rader-5 transposed from T; X[i1 M1 + i2 M2 + i3 M3 mod m] -> global
+//   phase 8  five-point units (i2, i3): their four inputs from T into registers
+//   phase 9  Rader-5 transposed; X[i1 M1 + i2 M2 + i3 M3 mod m] -> LDS (the first 20480 words) or memory
+//   phase 10 the row <- LDS
 // ======================================================================================================
-constexpr int INV_PHASES = 9;
+constexpr int INV_PHASES = 11;
 constexpr int I_OUTER_IN = 1;
 template <int PH>
 HXD void inv(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
@@ -594,6 +598,21 @@ HXD void inv(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
     if (tid < 68u)
       lds[tid * (unsigned)P3] = s.aux;   // (j0 17 + i2) 257 + 0
   } else if constexpr (PH == 8) {
+    // (the units' inputs leave T for the registers first: T's LDS becomes the staging area of the output)
+    static_for<0, UROUNDS>([&](auto Rr) {
+      constexpr unsigned r = decltype(Rr)::value;
+      const unsigned u = tid + r * NT;
+      if (u < (unsigned)NUNITS) {
+        static_for<0, 4>([&](auto B) {
+          constexpr int b = decltype(B)::value;
+          s.e[r * 4 + b] = lds[(unsigned)(gipow1(b) - 1) * (unsigned)NUNITS + u];   // u'_b = T[j1 = g^-b]
+        });
+      }
+    });
+  } else if constexpr (PH == 9) {
+    // X[i], i = i1 M1 + i2 M2 + i3 M3 mod m, is scattered over the whole row: through the LDS (all 160 KiB of it hold
+    // the first OUT_LDS = 20480 of the m = 21845 words; the 1365 beyond go to memory as they are), so that the row
+    // leaves in 16-byte coalesced stores -- 8-byte stores 680 bytes apart made this kernel twice as slow as the forward one
     static_for<0, UROUNDS>([&](auto Rr) {
       constexpr unsigned r = decltype(Rr)::value;
       const unsigned u = tid + r * NT;
@@ -601,18 +620,31 @@ HXD void inv(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
         uint64_t e[4];
         static_for<0, 4>([&](auto B) {
           constexpr int b = decltype(B)::value;
-          e[b] = lds[(unsigned)(gipow1(b) - 1) * (unsigned)NUNITS + u];   // u'_b = T[j1 = g^-b]
+          e[b] = s.e[r * 4 + b];
         });
         using U = UConv<2, 2>;
         uint64_t dc;
         U::run(e, tab + TW4, tab + I_V1, q, &dc);
         const unsigned base = unit_base(u);
-        A.dst[base] = reduce<U::DCB, 1>(dc, q);
+        auto put = [&](unsigned i, uint64_t v) {
+          if (i < (unsigned)OUT_LDS)
+            lds[i] = v;
+          else
+            A.dst[i] = v;
+        };
+        put(base, reduce<U::DCB, 1>(dc, q));
         static_for<0, 4>([&](auto Aa) {
           constexpr int a = decltype(Aa)::value;
-          A.dst[wrap_m(base + (unsigned)gpow1(a) * (unsigned)M1)] = reduce<U::out_b(a), 1>(e[a], q);
+          put(wrap_m(base + (unsigned)gpow1(a) * (unsigned)M1), reduce<U::out_b(a), 1>(e[a], q));
         });
       }
+    });
+  } else if constexpr (PH == 10) {
+    static_for<0, OUT_LDS / (2 * NT)>([&](auto K) {
+      constexpr unsigned k = decltype(K)::value;
+      const unsigned i = 2u * (k * NT + tid);
+      A.dst[i] = lds[i];
+      A.dst[i + 1] = lds[i + 1];
     });
   }
 }
@@ -620,7 +652,6 @@ HXD void inv(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
 // ---------------------------------------------------------------------------------------------------
 // host side: tables (plain C++, 128-bit arithmetic; engine.hip and the CPU replay call the same code)
 // ---------------------------------------------------------------------------------------------------
-#if !defined(__HIP_DEVICE_COMPILE__)
 namespace host {
 typedef unsigned __int128 u128;
 inline uint64_t mulm(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((u128)a * b) % q); }
@@ -736,7 +767,6 @@ inline void build_index_tables(uint16_t* pos2 /*16384*/, uint16_t* dlog3 /*257*/
   }
 }
 }  // namespace host
-#endif
 
 }  // namespace pfa
 }  // namespace hx

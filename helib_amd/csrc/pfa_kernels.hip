@@ -1,0 +1,73 @@
+// pfa_kernels.hip -- the Good-Thomas x Rader row kernels for m = 21845 = 5 * 17 * 257 on gfx950 (pfa_core.h has the
+// method, the phase functions and the table builders): Cmodulus::FFT / iFFT of the general-m branch
+// (src/CModulus.cpp:431-443, 555-577) as ONE launch per direction instead of the Bluestein chirp convolution
+// (src/bluestein.cpp:134-201).  One 1024-thread workgroup per (row, batch element); 140 KB of LDS, so one workgroup
+// per CU at four waves per SIMD.  Callers: engine.hip (bluestein_rows).
+#include "dev_common.h"
+#include "pfa_dev.h"
+#include "ntt_kernel_util.h"
+#include "prof.h"
+
+namespace hx {
+
+template <bool INV, int PH, int NPH>
+__device__ __forceinline__ void pfa_phases(unsigned tid, pfa::St& s, uint64_t* lds, const pfa::Args& A, const QC& q)
+{
+  if constexpr (PH < NPH) {
+    if constexpr (INV)
+      pfa::inv<PH>(tid, s, lds, A, q);
+    else
+      pfa::fwd<PH>(tid, s, lds, A, q);
+    if constexpr (PH + 1 < NPH)
+      __syncthreads();
+    pfa_phases<INV, PH + 1, NPH>(tid, s, lds, A, q);
+  }
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(pfa::NT)
+pfa_row_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, PfaRows R, const PrimeDev* __restrict__ primes,
+               const uint16_t* __restrict__ pos2, const uint16_t* __restrict__ dlog3, const uint16_t* __restrict__ gpow3,
+               unsigned batch, unsigned out_stride)
+{
+  extern __shared__ __attribute__((aligned(16))) uint64_t pfa_lds[];
+  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = wid % batch, ri = wid / batch;
+  const PrimeDev* pd = primes + uniform_u16(R.prime, ri);
+  pfa::Args A;
+  A.tab = R.tab[ri];
+  A.pos2 = pos2;
+  A.dlog3 = dlog3;
+  A.gpow3 = gpow3;
+  const size_t polyseg = ((size_t)uniform_u16(R.row, ri) * batch + b) * (size_t)pfa::PHI;
+  A.src = in + polyseg;
+  A.dst = INV ? out + ((size_t)ri * batch + b) * (size_t)out_stride : out + polyseg;
+  const QC q = make_qc(pd->q, pd->mu64);
+  pfa::St s;
+  pfa_phases<INV, 0, INV ? pfa::INV_PHASES : pfa::FWD_PHASES>(threadIdx.x, s, pfa_lds, A, q);
+}
+
+template <bool INV>
+static hipError_t launch_pfa(const uint64_t* in, uint64_t* out, const PfaRows& R, int nrows, const PrimeDev* primes,
+                             const uint16_t* pos2, const uint16_t* dlog3, const uint16_t* gpow3, int batch,
+                             unsigned out_stride, hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)(INV ? pfa::INV_LDS_WORDS : pfa::LDS_WORDS) * 8;
+  hipError_t e = hipFuncSetAttribute((const void*)pfa_row_kernel<INV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+  if (e != hipSuccess)
+    return e;
+  HX_LAUNCH((pfa_row_kernel<INV>), dim3((unsigned)nrows * (unsigned)batch), dim3(pfa::NT), lds_bytes, st, in, out, R, primes,
+            pos2, dlog3, gpow3, (unsigned)batch, out_stride);
+  return hipGetLastError();
+}
+// forward: out = poly rows; inverse: out = X[(ri * batch + b)][out_stride], m words each
+hipError_t launch_pfa_rows(bool inverse, const uint64_t* in, uint64_t* out, const PfaRows& R, int nrows,
+                           const PrimeDev* primes, const uint16_t* pos2, const uint16_t* dlog3, const uint16_t* gpow3,
+                           int batch, unsigned out_stride, hipStream_t st)
+{
+  return inverse ? launch_pfa<true>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st)
+                 : launch_pfa<false>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
+}
+
+}  // namespace hx

@@ -30,6 +30,7 @@ struct Switches {
   bool no_proth = false;         // HX_NO_PROTH=1        Shoup butterflies on every row (Proth-form primes included)
   // general m
   bool blue_old = false;         // HX_BLUE_OLD=1        Bluestein as the round-2 chain of passes instead of ntt_conv_kernel
+  bool no_pfa = false;           // HX_NO_PFA=1          m = 21845: Bluestein instead of the Good-Thomas x Rader kernels (pfa_core.h)
   // canonical-embedding norm kernels
   bool norm_async = false;       // HX_NORM_ASYNC=1      norm kernels on a side stream
   bool norm_old = false;         // HX_NORM_OLD=1        N = 2^14 / 2^15: the LDS-pass kernels instead of the radix-16 ones
@@ -61,6 +62,7 @@ inline Switches read()
   s.no_mulrelin_fuse = on("HX_NO_MULRELIN_FUSE");
   s.no_proth = on("HX_NO_PROTH");
   s.blue_old = on("HX_BLUE_OLD");
+  s.no_pfa = on("HX_NO_PFA") || s.blue_old;
   s.norm_async = on("HX_NORM_ASYNC");
   s.norm_old = on("HX_NORM_OLD");
   s.norm_plain = on("HX_NORM_PLAIN");

@@ -61,7 +61,7 @@ int pfa_replay_inverse(uint64_t q, uint64_t root, const uint64_t* in, uint64_t* 
     return -1;
   Tables T(q, root);
   std::vector<St> st(NT);
-  std::vector<uint64_t> lds(LDS_WORDS, 0xdeadbeefdeadbeefull);
+  std::vector<uint64_t> lds(INV_LDS_WORDS, 0xdeadbeefdeadbeefull);
   std::vector<uint64_t> src(in, in + PHI);
   Args A{T.tab.data(), T.pos2.data(), T.dlog3.data(), T.gpow3.data(), src.data(), out};
   run_all<true, 0, INV_PHASES>(st, lds, A, hx::make_qc(q));

@@ -601,41 +601,41 @@ def test_bluestein_m21845_config5(hx):
     assert np.array_equal(da.iFFT().download(), np.roll(a, 1, axis=2))
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_bluestein_m21845_config5_at_L16(hx, fused, monkeypatch):
+@pytest.mark.parametrize("path", ["pfa", "fused", "old"])
+def test_bluestein_m21845_config5_at_L16(hx, path, monkeypatch):
     """BASELINE configs[4] at its own shape: m = 21845, L = 16 primes of PrimeGenerator(60, 21845), a batch of 2
     DoubleCRT objects -- forward and inverse transforms of all 32 rows against the restatement of
-    src/bluestein.cpp / src/CModulus.cpp:431-443, 555-577, every word.  fused: the convolution row kernel
-    (conv_kernels.hip: chirp pre-twist or scatter on load, pointwise product in registers, the window / fold /
-    second twist with the inverse split in one pass; rem Phi_m as two more fused launches); not fused
-    (HX_BLUE_OLD): the round-2 chain of separate passes, kept as the fallback for exotic primes and sizes.
-    Both must give the same words."""
-    import subprocess, sys, json
-    if not fused:
-        # the switch is read once per process: run the comparison in a child with HX_BLUE_OLD set
-        code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
-                "from tests.test_gpu_parity import Pair, primes_for\n"
-                "from helib_amd import capi as hx\n"
-                "P = Pair(hx, 21845, primes_for(21845, 16, 60)); idx = list(range(16))\n"
-                "x = P.rand(idx, 9, batch=2); d = hx.DoubleCRT(P.g, idx, 2, x)\n"
-                "got = d.FFT().download()\n"
-                "ok = all(np.array_equal(got[:, b], P.o.fft(idx, x[:, b])) for b in range(2))\n"
-                "ok = ok and np.array_equal(d.iFFT().download(), x)\n"
-                "print('OK' if ok else 'MISMATCH')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, HX_BLUE_OLD="1"))
-        assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
-        return
+    src/bluestein.cpp / src/CModulus.cpp:431-443, 555-577, every word.
+      pfa   (round 6, the default): Good-Thomas x Rader, 21845 = 5 * 17 * 257 (pfa_kernels.hip): ONE launch per
+            direction, the 4- / 16- / 256-point cyclic convolutions of Rader's form of DFT_5 (x) DFT_17 (x) DFT_257;
+            the inverse keeps rem Phi_m as two fused convolution launches;
+      fused (HX_NO_PFA): Bluestein on the convolution row kernel (conv_kernels.hip);
+      old   (HX_BLUE_OLD): the round-2 chain of separate passes, the fallback for exotic primes and sizes.
+    All three must give the oracle's words; the kernel summary pins which one ran (the switches are read per
+    context: switches.h)."""
+    if path == "fused":
+        monkeypatch.setenv("HX_NO_PFA", "1")
+    elif path == "old":
+        monkeypatch.setenv("HX_BLUE_OLD", "1")
     m, L = 21845, 16
     P = Pair(hx, m, primes_for(m, L, 60))
     idx = list(range(L))
     x = P.rand(idx, 9, batch=2)
     d = hx.DoubleCRT(P.g, idx, 2, x)
+    hx.profileBegin()
     got = d.FFT().download()
+    names = " ".join(k["kernel"] for k in hx.profileEnd()["kernels"])
+    assert ("pfa_row_kernel" in names) == (path == "pfa"), names
+    assert ("ntt_conv_kernel" in names) == (path == "fused"), names
     for b in range(2):
         assert np.array_equal(got[:, b], P.o.fft(idx, x[:, b]))
+    hx.profileBegin()
     assert np.array_equal(d.iFFT().download(), x)
+    names = " ".join(k["kernel"] for k in hx.profileEnd()["kernels"])
+    assert ("pfa_row_kernel" in names) == (path == "pfa"), names
     y = P.rand(idx, 10, batch=2)
+    # extreme words: all q - 1, all zero, a single one
+    y[:, 0, :3] = np.array([[q - 1, 0, 1] for q in P.primes[:L]], dtype=np.uint64)
     d1 = hx.DoubleCRT(P.g, idx, 2, y)
     back = d1.iFFT().download()
     for b in range(2):
@@ -643,6 +643,13 @@ def test_bluestein_m21845_config5_at_L16(hx, fused, monkeypatch):
     # a lazily copied (shared) poly is transformed out of place into its own slab
     c = d1.copy()
     assert np.array_equal(c.FFT().download(), y) and np.array_equal(d1.download(), back)
+    # the rows of all-(q-1) and of zeros (every lazy bound of the kernels at its extreme)
+    e = np.stack([np.stack([np.full(P.N, q - 1, dtype=np.uint64), np.zeros(P.N, dtype=np.uint64)]) for q in P.primes[:L]])
+    de = hx.DoubleCRT(P.g, idx, 2, e)
+    ge = de.FFT().download()
+    for b in range(2):
+        assert np.array_equal(ge[:, b], P.o.fft(idx, e[:, b]))
+    assert np.array_equal(de.iFFT().download(), e)
 
 
 def test_general_m_multiply_relin_and_automorph(hx):

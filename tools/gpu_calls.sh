@@ -13,7 +13,7 @@
 #   trace            rocprofv3 --kernel-trace over the driver's command -> bench_kernel_trace.txt + bench_traced.json
 #   pmc              three separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU) -> pmc_summary.txt
 #   pmc_sq           two more --pmc passes: SQ VALU activity + GRBM_GUI_ACTIVE (clock), LDS bank conflicts -> pmc_sq_summary.txt
-#   bluestein        tools/prof_bluestein.py fused and old chain + kernel trace of the fused one
+#   bluestein        tools/prof_bluestein.py Good-Thomas x Rader (default), fused Bluestein (HX_NO_PFA) and old chain + kernel trace of the default
 #   levels           tools/prof_levels.py for both schemes
 #   ab:A,B,...       same-box A/B of the fresh multiply, two rounds; A = default | env:VAR=1 | a variant
 #                    directory under helib_amd/lib/variants (tools/build_variant.sh), or variant@VAR=1;
@@ -132,7 +132,8 @@ PY
       python tools/rocpd_pmc.py $out/pmc_sq1 $out/pmc_sq2 > $out/pmc_sq_summary.txt 2>&1
       grep -E "ntt_row_kernel<14, false>.* 6400 |apply_kernel<14, false>|embed_norm" $out/pmc_sq_summary.txt | cut -c1-200 | head -40 ;;
     bluestein)
-      timeout 200 python tools/prof_bluestein.py > $out/blue_fused.json 2> $out/blue_fused.err; cat $out/blue_fused.json
+      timeout 200 python tools/prof_bluestein.py > $out/blue_pfa.json 2> $out/blue_pfa.err; cat $out/blue_pfa.json
+      HX_NO_PFA=1 timeout 200 python tools/prof_bluestein.py > $out/blue_fused.json 2> $out/blue_fused.err; cat $out/blue_fused.json
       HX_BLUE_OLD=1 timeout 200 python tools/prof_bluestein.py > $out/blue_old.json 2> $out/blue_old.err; cat $out/blue_old.json
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $R/$out/blue_kt -- python3 $R/tools/prof_bluestein.py > /dev/null 2> $R/$out/blue_kt.err)
       python tools/rocpd_summary.py $out/blue_kt > $out/blue_kernel_trace.txt 2>&1; head -14 $out/blue_kernel_trace.txt ;;
