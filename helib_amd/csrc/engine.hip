@@ -1417,7 +1417,7 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
     A.zidx = c->d_zms_index;
     hipError_t e = hipSuccess;
     uint64_t* xfull = nullptr;
-    if (inverse) {
+    if (inverse && !(pfa && !c->sw.pfa_no_rem)) {
       CHK(ensure_scratch(c, 6, segs * c->mpad));
       CHK(ensure_scratch(c, 7, segs * N1));
       xfull = c->scratch[6];
@@ -1431,11 +1431,14 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
         PR.row[r] = (uint16_t)rows[first + r].first;
         PR.prime[r] = (uint16_t)rows[first + r].second;
       }
-      e = hx::launch_pfa_rows(inverse, in, inverse ? xfull : out, PR, R, c->d_primes, c->d_pfa_idx, c->d_pfa_idx + 16384,
+      // (the inverse with rem Phi_m and 1/m behind it in the same launch -- binomial passes, no multiplication --
+      // unless HX_PFA_NO_REM keeps them on the convolution kernels below)
+      const int mode = !inverse ? 0 : (c->sw.pfa_no_rem ? 1 : 2);
+      e = hx::launch_pfa_rows(mode, in, mode == 1 ? xfull : out, PR, R, c->d_primes, c->d_pfa_idx, c->d_pfa_idx + 16384,
                               c->d_pfa_idx + 16384 + 258, batch, c->mpad, c->stream);
       if (e != hipSuccess)
         return fail(HX_ERR_DEVICE, "Good-Thomas x Rader launch failed: %s", hipGetErrorString(e));
-      if (!inverse)
+      if (mode != 1)
         continue;
     } else {
     CHK(ensure_scratch(c, 5, segs * NB));

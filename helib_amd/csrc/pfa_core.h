@@ -72,7 +72,8 @@ enum : int {
   I_V2 = 812,
   I_V3 = 828,
   I_W2 = 1084,         // [17][16] omega_2^(-i2 g^-b2) at [i2][b2]      (i2 = 0: ones)
-  TAB_WORDS = 1084 + 17 * 16
+  I_MINV = 1084 + 17 * 16,   // m^-1                                    (src/CModulus.cpp:574-577)
+  TAB_WORDS = I_MINV + 4
 };
 
 struct Args {
@@ -86,6 +87,8 @@ struct Args {
 struct St {
   uint64_t e[20];
   uint64_t aux;
+  uint64_t o[25];   // inverse, fused rem Phi_m: the thread's 25 words of X (five 5-point units), kept to the end
+  uint64_t v[6];    // ... and the values a thread carries from the read half of a multiply pass to its write half
 };
 
 constexpr int cpow2(int b) { return b <= 1 ? 1 : (b <= 2 ? 2 : (b <= 4 ? 4 : 8)); }
@@ -649,6 +652,265 @@ HXD void inv(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
   }
 }
 
+// ======================================================================================================
+// rem Phi_m WITHOUT a multiplication, fused behind the inverse transform (phases 9 .. of inv_rem below).
+//
+// The reference divides by Phi_m with two FFT multiplications (src/NumbTh.cpp:1741-1804 behind src/CModulus.cpp:571);
+// on this engine those were two 2^14-point convolution launches, 238 us per 512 rows against 104 for the whole
+// Good-Thomas x Rader transform in front of them.  But  Phi_m = prod_{d | m} (x^d - 1)^mu(m/d), for m = 5 * 17 * 257:
+//     Phi_m (x) =  (x^m - 1) (x^5 - 1) (x^17 - 1) (x^257 - 1)  /  [ (x - 1) (x^85 - 1) (x^1285 - 1) (x^4369 - 1) ]
+// -- a product and quotient of BINOMIALS.  Multiplying a power series by (1 - x^d) is w_i -= w_(i-d); dividing by it is
+// the running sum w_i += w_(i-d) along the d chains of stride d.  With n = phi(m), dq = m - 1 - n, t = 1/x:
+//   Xr(t) = sum_k X_(m-1-k) t^k   (the top dq + 1 words of X, reversed)
+//   Qr    = Xr / Phi_m(t) = Xr * prod_{A} (1 - t^d) / prod_{B} (1 - t^d)   mod t^(dq+1),  A = {1, 85, 1285, 4369}, B = {5, 17, 257}
+//           (Phi_m is palindromic and 1 / (t^m - 1) = -1 mod t^m),   Q_k = Qr_(dq-k)
+//   W     = Q Phi_m mod x^n = Q * prod_{B} (1 - x^d) / prod_{A} (1 - x^d)  mod x^n
+//   r_i   = (X_i - W_i) / m,  i < n
+// -- about 0.15 M modular additions per row in place of four 2^14-point transforms, all in the workgroup's LDS, the
+// same launch.  tests/pfa_ref.py: rem_by_binomials restates it in python integers; the replay checks it word for word.
+//
+// A running sum of stride D over LEN words by 1024 threads: D chains; a chain is cut into segments of SEG elements,
+// one (chain, segment) task per thread: (A) segment total -> AUX1; (B) totals of groups of 32 segments -> AUX2 (only
+// when a chain has more than 40 segments); (C) carry-in = the groups and segments before mine, running sums written.  Chains no longer than 22 elements are summed by one thread each in a single phase.
+// Everything canonical modulo q.
+// ======================================================================================================
+constexpr int RN = PHI, RDQ = M - 1 - PHI, RL1 = RDQ + 1;   // 16384, 5460, 5461
+constexpr int AUX1 = PHI, AUX2 = PHI + NT;                   // segment totals [1024], group totals [<= 64]
+constexpr int REM_LDS_WORDS = AUX2 + 64;                     // 17472
+HXD uint64_t addm(uint64_t a, uint64_t b, const QC& c) { return csub(a + b, c.q); }
+HXD uint64_t subm(uint64_t a, uint64_t b, const QC& c) { return csub(a + c.q - b, c.q); }
+
+// w <- w (1 - x^DA)(1 - x^DB) (DB = 0: one binomial), logical input w_k = lds[REV ? LEN_IN - 1 - k : k], k < LEN_IN;
+// output words k < LEN_OUT (<= 6 per thread), then zeros up to ZERO_TO
+template <int DA, int DB, int LEN_IN, int LEN_OUT, int ZERO_TO, bool REV>
+struct MulPass {
+  static constexpr int PER = (LEN_OUT + NT - 1) / NT;
+  static_assert(PER <= 6, "registers");
+  static HXD uint64_t at(const uint64_t* w, int k) { return (k >= 0 && k < LEN_IN) ? w[REV ? LEN_IN - 1 - k : k] : 0; }
+  static HXD void read(unsigned tid, St& s, const uint64_t* w, const QC& q)
+  {
+    static_for<0, PER>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      const int k = (int)tid + NT * j;
+      if (k < LEN_OUT) {
+        uint64_t v = subm(at(w, k), at(w, k - DA), q);
+        if constexpr (DB != 0)
+          v = subm(addm(v, at(w, k - DA - DB), q), at(w, k - DB), q);
+        s.v[j] = v;
+      }
+    });
+  }
+  static HXD void write(unsigned tid, const St& s, uint64_t* w)
+  {
+    static_for<0, PER>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      const int k = (int)tid + NT * j;
+      if (k < LEN_OUT)
+        w[k] = s.v[j];
+    });
+    if constexpr (ZERO_TO > LEN_OUT) {
+      static_for<0, (ZERO_TO - LEN_OUT + NT - 1) / NT>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const int k = LEN_OUT + (int)tid + NT * j;
+        if (k < ZERO_TO)
+          w[k] = 0;
+      });
+    }
+  }
+};
+template <int D, int LEN, int SEG>
+struct ScanPass {
+  static constexpr int L = (LEN + D - 1) / D;            // longest chain
+  static constexpr int NSEG = (L + SEG - 1) / SEG;
+  static constexpr int NTASK = D * NSEG;
+  static constexpr bool SINGLE = NSEG == 1;
+  static constexpr bool GROUPS = NSEG > 40;
+  static constexpr int NGRP = (NSEG + 31) / 32;
+  static_assert(SINGLE || NTASK <= NT, "one task per thread");
+  static_assert(SEG <= 17 || SINGLE, "registers");
+  static_assert(!GROUPS || NGRP * D <= 64, "AUX2");
+  // chains of at most SEG elements: one thread sums a whole chain, in place
+  static HXD void single(unsigned tid, uint64_t* w, const QC& q)
+  {
+    static_for<0, (D + NT - 1) / NT>([&](auto Rr) {
+      constexpr int r = decltype(Rr)::value;
+      const int c = (int)tid + NT * r;
+      if (c < D) {
+        uint64_t run = 0;
+        static_for<0, L>([&](auto Ll) {
+          constexpr int l = decltype(Ll)::value;
+          const int i = c + D * l;
+          if (i < LEN) {
+            run = addm(run, w[i], q);
+            w[i] = run;
+          }
+        });
+      }
+    });
+  }
+  // task = seg * D + chain (neighbouring lanes: neighbouring chains)
+  static HXD void a(unsigned tid, St&, uint64_t* w, const QC& q)
+  {
+    if ((int)tid < NTASK) {
+      const int seg = (int)tid / D, c = (int)tid - seg * D;
+      uint64_t run = 0;
+      static_for<0, SEG>([&](auto Ll) {
+        constexpr int l = decltype(Ll)::value;
+        const int i = c + D * (seg * SEG + l);
+        if (i < LEN)
+          run = addm(run, w[i], q);
+      });
+      w[AUX1 + tid] = run;
+    }
+  }
+  static HXD void b(unsigned tid, uint64_t* w, const QC& q)
+  {
+    if ((int)tid < NGRP * D) {
+      const int g = (int)tid / D, c = (int)tid - g * D;
+      uint64_t sum = 0;
+      for (int sg = 32 * g; sg < 32 * g + 32 && sg < NSEG; sg++)
+        sum = addm(sum, w[AUX1 + sg * D + c], q);
+      w[AUX2 + tid] = sum;
+    }
+  }
+  static HXD void c(unsigned tid, const St&, uint64_t* w, const QC& q)
+  {
+    if ((int)tid < NTASK) {
+      const int seg = (int)tid / D, ch = (int)tid - seg * D;
+      uint64_t carry = 0;
+      int first = 0;
+      if constexpr (GROUPS) {
+        for (int g = 0; g < seg / 32; g++)
+          carry = addm(carry, w[AUX2 + g * D + ch], q);
+        first = 32 * (seg / 32);
+      }
+      for (int sg = first; sg < seg; sg++)
+        carry = addm(carry, w[AUX1 + sg * D + ch], q);
+      // (the segment is read again rather than carried over in registers: 17 LDS reads against 34 registers that,
+      // next to the 50 of the thread's X words, spilled)
+      static_for<0, SEG>([&](auto Ll) {
+        constexpr int l = decltype(Ll)::value;
+        const int i = ch + D * (seg * SEG + l);
+        if (i < LEN) {
+          carry = addm(carry, w[i], q);
+          w[i] = carry;
+        }
+      });
+    }
+  }
+};
+// the passes of the two steps
+using RM1a = MulPass<1, 85, RL1, RL1, 0, false>;
+using RM1b = MulPass<1285, 4369, RL1, RL1, 0, false>;
+using RD1a = ScanPass<5, RL1, 7>;
+using RD1b = ScanPass<17, RL1, 11>;
+using RD1c = ScanPass<257, RL1, 22>;
+using RM2a = MulPass<5, 17, RL1, RL1 + 22, RN, true>;           // reads Q_k = Qr_(dq - k); zero beyond
+using RM2b = MulPass<257, 0, RL1 + 22, RL1 + 22 + 257, 0, false>;
+using RD2a = ScanPass<1, RN, 17>;
+using RD2b = ScanPass<85, RN, 17>;
+using RD2c = ScanPass<1285, RN, 13>;
+using RD2d = ScanPass<4369, RN, 4>;
+static_assert(RD1c::SINGLE && RD2c::SINGLE && RD2d::SINGLE && RD1a::GROUPS && !RD1b::GROUPS && RD2a::GROUPS && !RD2b::GROUPS, "pass shapes");
+
+// the inverse transform with rem Phi_m and 1/m behind it: phases 0..8 are inv<0..8>; dst = the poly row
+constexpr int INV_REM_PHASES = 33;
+template <int PH>
+HXD void inv_rem(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
+{
+  const TWM* tab = A.tab;
+  if constexpr (PH <= 8) {
+    inv<PH>(tid, s, lds, A, q);
+  } else if constexpr (PH == 9) {
+    // the five-point units: 25 words of X per thread stay in registers; the top dq + 1 go to the LDS reversed (Xr)
+    static_for<0, UROUNDS>([&](auto Rr) {
+      constexpr unsigned r = decltype(Rr)::value;
+      const unsigned u = tid + r * NT;
+      if (u < (unsigned)NUNITS) {
+        uint64_t e[4];
+        static_for<0, 4>([&](auto B) {
+          constexpr int b = decltype(B)::value;
+          e[b] = s.e[r * 4 + b];
+        });
+        using U = UConv<2, 2>;
+        uint64_t dc;
+        U::run(e, tab + TW4, tab + I_V1, q, &dc);
+        const unsigned base = unit_base(u);
+        s.o[r * 5] = reduce<U::DCB, 1>(dc, q);
+        if (base >= (unsigned)RN)
+          lds[(unsigned)(M - 1) - base] = s.o[r * 5];
+        static_for<0, 4>([&](auto Aa) {
+          constexpr int a = decltype(Aa)::value;
+          const unsigned i = wrap_m(base + (unsigned)gpow1(a) * (unsigned)M1);
+          s.o[r * 5 + 1 + a] = reduce<U::out_b(a), 1>(e[a], q);
+          if (i >= (unsigned)RN)
+            lds[(unsigned)(M - 1) - i] = s.o[r * 5 + 1 + a];
+        });
+      }
+    });
+  } else if constexpr (PH == 10) {
+    RM1a::read(tid, s, lds, q);
+  } else if constexpr (PH == 11) {
+    RM1a::write(tid, s, lds);
+  } else if constexpr (PH == 12) {
+    RM1b::read(tid, s, lds, q);
+  } else if constexpr (PH == 13) {
+    RM1b::write(tid, s, lds);
+  } else if constexpr (PH == 14) {
+    RD1a::a(tid, s, lds, q);
+  } else if constexpr (PH == 15) {
+    RD1a::b(tid, lds, q);
+  } else if constexpr (PH == 16) {
+    RD1a::c(tid, s, lds, q);
+  } else if constexpr (PH == 17) {
+    RD1b::a(tid, s, lds, q);
+  } else if constexpr (PH == 18) {
+    RD1b::c(tid, s, lds, q);
+  } else if constexpr (PH == 19) {
+    RD1c::single(tid, lds, q);
+  } else if constexpr (PH == 20) {
+    RM2a::read(tid, s, lds, q);
+  } else if constexpr (PH == 21) {
+    RM2a::write(tid, s, lds);
+  } else if constexpr (PH == 22) {
+    RM2b::read(tid, s, lds, q);
+  } else if constexpr (PH == 23) {
+    RM2b::write(tid, s, lds);
+  } else if constexpr (PH == 24) {
+    RD2a::a(tid, s, lds, q);
+  } else if constexpr (PH == 25) {
+    RD2a::b(tid, lds, q);
+  } else if constexpr (PH == 26) {
+    RD2a::c(tid, s, lds, q);
+  } else if constexpr (PH == 27) {
+    RD2b::a(tid, s, lds, q);
+  } else if constexpr (PH == 28) {
+    RD2b::c(tid, s, lds, q);
+  } else if constexpr (PH == 29) {
+    RD2c::single(tid, lds, q);
+  } else if constexpr (PH == 30) {
+    RD2d::single(tid, lds, q);
+  } else if constexpr (PH == 31) {
+    // r_i = (X_i - W_i) / m in place, by the thread that holds X_i
+    const TWM minv = tab[I_MINV];
+    static_for<0, UROUNDS>([&](auto Rr) {
+      constexpr unsigned r = decltype(Rr)::value;
+      const unsigned u = tid + r * NT;
+      if (u < (unsigned)NUNITS) {
+        const unsigned base = unit_base(u);
+        static_for<0, 5>([&](auto I) {
+          constexpr int i5 = decltype(I)::value;
+          const unsigned i = i5 == 0 ? base : wrap_m(base + (unsigned)gpow1(i5 == 0 ? 0 : i5 - 1) * (unsigned)M1);
+          if (i < (unsigned)RN)
+            lds[i] = csub(mont_mul(s.o[r * 5 + i5] + q.q - lds[i], minv, q), q.q);
+        });
+      }
+    });
+  } else if constexpr (PH == 32) {
+    fwd<9>(tid, s, lds, A, q);   // the row <- LDS
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side: tables (plain C++, 128-bit arithmetic; engine.hip and the CPU replay call the same code)
 // ---------------------------------------------------------------------------------------------------
@@ -738,6 +1000,8 @@ inline void build_prime_table(uint64_t q, uint64_t root, uint64_t* tab)
     for (int i2 = 0; i2 <= 16; i2++)
       tab[I_W2 + i2 * 16 + b2] = mont(powm(o2inv, (uint64_t)(i2 * j2), q), q);
   }
+  for (int i = 0; i < 4; i++)
+    tab[I_MINV + i] = mont(powm((uint64_t)M % q, q - 2, q), q);
 }
 // the index tables of the context (depend on m only)
 inline void build_index_tables(uint16_t* pos2 /*16384*/, uint16_t* dlog3 /*257*/, uint16_t* gpow3 /*256*/)

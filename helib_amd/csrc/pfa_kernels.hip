@@ -10,21 +10,31 @@
 
 namespace hx {
 
-template <bool INV, int PH, int NPH>
+// MODE 0: forward.  1: inverse up to X (m words per row; rem Phi_m by the convolution kernels).  2: inverse with
+// rem Phi_m and 1/m fused behind it (binomial passes in the LDS), the default.
+constexpr int pfa_nphases(int mode) { return mode == 0 ? pfa::FWD_PHASES : (mode == 1 ? pfa::INV_PHASES : pfa::INV_REM_PHASES); }
+constexpr int pfa_lds_words(int mode)
+{
+  return mode == 0 ? pfa::LDS_WORDS
+                   : (mode == 1 ? pfa::INV_LDS_WORDS : (pfa::LDS_WORDS > pfa::REM_LDS_WORDS ? pfa::LDS_WORDS : pfa::REM_LDS_WORDS));
+}
+template <int MODE, int PH>
 __device__ __forceinline__ void pfa_phases(unsigned tid, pfa::St& s, uint64_t* lds, const pfa::Args& A, const QC& q)
 {
-  if constexpr (PH < NPH) {
-    if constexpr (INV)
+  if constexpr (PH < pfa_nphases(MODE)) {
+    if constexpr (MODE == 2)
+      pfa::inv_rem<PH>(tid, s, lds, A, q);
+    else if constexpr (MODE == 1)
       pfa::inv<PH>(tid, s, lds, A, q);
     else
       pfa::fwd<PH>(tid, s, lds, A, q);
-    if constexpr (PH + 1 < NPH)
+    if constexpr (PH + 1 < pfa_nphases(MODE))
       __syncthreads();
-    pfa_phases<INV, PH + 1, NPH>(tid, s, lds, A, q);
+    pfa_phases<MODE, PH + 1>(tid, s, lds, A, q);
   }
 }
 
-template <bool INV>
+template <int MODE>
 __global__ void __launch_bounds__(pfa::NT)
 pfa_row_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, PfaRows R, const PrimeDev* __restrict__ primes,
                const uint16_t* __restrict__ pos2, const uint16_t* __restrict__ dlog3, const uint16_t* __restrict__ gpow3,
@@ -41,33 +51,37 @@ pfa_row_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, PfaR
   A.gpow3 = gpow3;
   const size_t polyseg = ((size_t)uniform_u16(R.row, ri) * batch + b) * (size_t)pfa::PHI;
   A.src = in + polyseg;
-  A.dst = INV ? out + ((size_t)ri * batch + b) * (size_t)out_stride : out + polyseg;
+  A.dst = MODE == 1 ? out + ((size_t)ri * batch + b) * (size_t)out_stride : out + polyseg;
   const QC q = make_qc(pd->q, pd->mu64);
   pfa::St s;
-  pfa_phases<INV, 0, INV ? pfa::INV_PHASES : pfa::FWD_PHASES>(threadIdx.x, s, pfa_lds, A, q);
+  pfa_phases<MODE, 0>(threadIdx.x, s, pfa_lds, A, q);
 }
 
-template <bool INV>
+template <int MODE>
 static hipError_t launch_pfa(const uint64_t* in, uint64_t* out, const PfaRows& R, int nrows, const PrimeDev* primes,
                              const uint16_t* pos2, const uint16_t* dlog3, const uint16_t* gpow3, int batch,
                              unsigned out_stride, hipStream_t st)
 {
-  constexpr size_t lds_bytes = (size_t)(INV ? pfa::INV_LDS_WORDS : pfa::LDS_WORDS) * 8;
-  hipError_t e = hipFuncSetAttribute((const void*)pfa_row_kernel<INV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  constexpr size_t lds_bytes = (size_t)pfa_lds_words(MODE) * 8;
+  hipError_t e = hipFuncSetAttribute((const void*)pfa_row_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess)
     return e;
-  HX_LAUNCH((pfa_row_kernel<INV>), dim3((unsigned)nrows * (unsigned)batch), dim3(pfa::NT), lds_bytes, st, in, out, R, primes,
+  HX_LAUNCH((pfa_row_kernel<MODE>), dim3((unsigned)nrows * (unsigned)batch), dim3(pfa::NT), lds_bytes, st, in, out, R, primes,
             pos2, dlog3, gpow3, (unsigned)batch, out_stride);
   return hipGetLastError();
 }
-// forward: out = poly rows; inverse: out = X[(ri * batch + b)][out_stride], m words each
-hipError_t launch_pfa_rows(bool inverse, const uint64_t* in, uint64_t* out, const PfaRows& R, int nrows,
+// mode 0 / 2: out = poly rows; mode 1: out = X[(ri * batch + b)][out_stride], m words each
+hipError_t launch_pfa_rows(int mode, const uint64_t* in, uint64_t* out, const PfaRows& R, int nrows,
                            const PrimeDev* primes, const uint16_t* pos2, const uint16_t* dlog3, const uint16_t* gpow3,
                            int batch, unsigned out_stride, hipStream_t st)
 {
-  return inverse ? launch_pfa<true>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st)
-                 : launch_pfa<false>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
+  switch (mode) {
+    case 0: return launch_pfa<0>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
+    case 1: return launch_pfa<1>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
+    case 2: return launch_pfa<2>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
+  }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace hx

@@ -212,6 +212,8 @@ int hx_break_into_digits(const hx_poly* a, const int* dig_idx, const int* dig_of
  *                                            their Garner steps, target sums and fix-ups are Montgomery products; HX_NO_PROTH
  *                                            implies it)
  *   HX_BLUE_OLD                               general m: the chain of passes instead of one convolution kernel
+ *   HX_NO_PFA                                 m = 21845: Bluestein instead of the Good-Thomas x Rader kernels
+ *   HX_PFA_NO_REM                             ... their inverse without the fused rem Phi_m (two convolution launches instead)
  *   HX_NORM_ASYNC, HX_NORM_OLD, HX_NORM_PLAIN, HX_NORM_MEMCPY
  *                                            variants of the canonical-embedding norm kernels and their read-back
  *   HX_WAIT_POLL_US=n                         how long a norm read-back is polled for before the thread sleeps (2000)

@@ -30,6 +30,15 @@ static void phase(std::vector<St>& st, std::vector<uint64_t>& lds, const Args& A
       fwd<PH>(tid, st[tid], lds.data(), A, q);
   }
 }
+template <int PH>
+static void run_rem(std::vector<St>& st, std::vector<uint64_t>& lds, const Args& A, const hx::QC& q)
+{
+  if constexpr (PH < INV_REM_PHASES) {
+    for (unsigned tid = 0; tid < (unsigned)NT; tid++)
+      inv_rem<PH>(tid, st[tid], lds.data(), A, q);
+    run_rem<PH + 1>(st, lds, A, q);
+  }
+}
 template <bool INV, int PH, int NPH>
 static void run_all(std::vector<St>& st, std::vector<uint64_t>& lds, const Args& A, const hx::QC& q)
 {
@@ -65,6 +74,19 @@ int pfa_replay_inverse(uint64_t q, uint64_t root, const uint64_t* in, uint64_t* 
   std::vector<uint64_t> src(in, in + PHI);
   Args A{T.tab.data(), T.pos2.data(), T.dlog3.data(), T.gpow3.data(), src.data(), out};
   run_all<true, 0, INV_PHASES>(st, lds, A, hx::make_qc(q));
+  return 0;
+}
+// in: 16384 evaluations -> out: 16384 coefficients (the whole Cmodulus::iFFT: transform, rem Phi_m, 1/m)
+int pfa_replay_inverse_rem(uint64_t q, uint64_t root, const uint64_t* in, uint64_t* out)
+{
+  if (!host::supported(M, q))
+    return -1;
+  Tables T(q, root);
+  std::vector<St> st(NT);
+  std::vector<uint64_t> lds(LDS_WORDS > REM_LDS_WORDS ? LDS_WORDS : REM_LDS_WORDS, 0xdeadbeefdeadbeefull);
+  std::vector<uint64_t> src(in, in + PHI);
+  Args A{T.tab.data(), T.pos2.data(), T.dlog3.data(), T.gpow3.data(), src.data(), out};
+  run_rem<0>(st, lds, A, hx::make_qc(q));
   return 0;
 }
 int pfa_table_words() { return TAB_WORDS; }

@@ -231,3 +231,42 @@ def rem_phi_times_minv(X, phi, m, q):
                 X[i - n + t] = (X[i - n + t] - c * phi[t]) % q
     minv = pow(m, q - 2, q)
     return [v * minv % q for v in X[:n]]
+
+
+def phi_binomials(m):
+    """Phi_m = prod_{d | m} (x^d - 1)^mu(m/d) for squarefree m: (numerator ds, denominator ds)"""
+    from itertools import combinations
+    ps = prime_factors(m)
+    num, den = [], []
+    for k in range(len(ps) + 1):
+        for sub in combinations(ps, k):
+            d = 1
+            for p in sub:
+                d *= p
+            (num if (len(ps) - k) % 2 == 0 else den).append(d)
+    return sorted(num), sorted(den)
+
+
+def rem_by_binomials(X, m, q):
+    """(X mod Phi_m) * m^-1 with no multiplication but the last one: the fused tail of the inverse kernel
+    (helib_amd/csrc/pfa_core.h, inv_rem).  Multiplying by (1 - x^d) is w_i -= w_(i-d); dividing by it is the running
+    sum w_i += w_(i-d).  With t = 1/x:  Qr = Xr / Phi_m(t) mod t^(dq+1)  (Phi_m palindromic, 1 / (t^m - 1) = -1 mod t^m),
+    W = Q Phi_m mod x^n,  r = X_low - W."""
+    num, den = phi_binomials(m)
+    num = [d for d in num if d != m]
+    n = sum(1 for j in range(m) if all(j % p for p in prime_factors(m)))
+    dq = m - 1 - n
+    w = [X[m - 1 - k] % q for k in range(dq + 1)]
+    for d in den:
+        w = [(w[k] - (w[k - d] if k >= d else 0)) % q for k in range(dq + 1)]
+    for d in num:
+        for k in range(d, dq + 1):
+            w[k] = (w[k] + w[k - d]) % q
+    W = [w[dq - k] if k <= dq else 0 for k in range(n)]
+    for d in num:
+        W = [(W[i] - (W[i - d] if i >= d else 0)) % q for i in range(n)]
+    for d in den:
+        for i in range(d, n):
+            W[i] = (W[i] + W[i - d]) % q
+    minv = pow(m, q - 2, q)
+    return [(X[i] - W[i]) * minv % q for i in range(n)]

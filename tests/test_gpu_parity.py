@@ -601,20 +601,24 @@ def test_bluestein_m21845_config5(hx):
     assert np.array_equal(da.iFFT().download(), np.roll(a, 1, axis=2))
 
 
-@pytest.mark.parametrize("path", ["pfa", "fused", "old"])
+@pytest.mark.parametrize("path", ["pfa", "pfa_conv_rem", "fused", "old"])
 def test_bluestein_m21845_config5_at_L16(hx, path, monkeypatch):
     """BASELINE configs[4] at its own shape: m = 21845, L = 16 primes of PrimeGenerator(60, 21845), a batch of 2
     DoubleCRT objects -- forward and inverse transforms of all 32 rows against the restatement of
     src/bluestein.cpp / src/CModulus.cpp:431-443, 555-577, every word.
       pfa   (round 6, the default): Good-Thomas x Rader, 21845 = 5 * 17 * 257 (pfa_kernels.hip): ONE launch per
             direction, the 4- / 16- / 256-point cyclic convolutions of Rader's form of DFT_5 (x) DFT_17 (x) DFT_257;
-            the inverse keeps rem Phi_m as two fused convolution launches;
+            the inverse has rem Phi_m behind it in the same launch as binomial passes (Phi_m is a quotient of products
+            of x^d - 1: no multiplication at all);
+      pfa_conv_rem (HX_PFA_NO_REM): the same transform, rem Phi_m as two fused convolution launches;
       fused (HX_NO_PFA): Bluestein on the convolution row kernel (conv_kernels.hip);
       old   (HX_BLUE_OLD): the round-2 chain of separate passes, the fallback for exotic primes and sizes.
     All three must give the oracle's words; the kernel summary pins which one ran (the switches are read per
     context: switches.h)."""
     if path == "fused":
         monkeypatch.setenv("HX_NO_PFA", "1")
+    elif path == "pfa_conv_rem":
+        monkeypatch.setenv("HX_PFA_NO_REM", "1")
     elif path == "old":
         monkeypatch.setenv("HX_BLUE_OLD", "1")
     m, L = 21845, 16
@@ -625,14 +629,16 @@ def test_bluestein_m21845_config5_at_L16(hx, path, monkeypatch):
     hx.profileBegin()
     got = d.FFT().download()
     names = " ".join(k["kernel"] for k in hx.profileEnd()["kernels"])
-    assert ("pfa_row_kernel" in names) == (path == "pfa"), names
+    assert ("pfa_row_kernel<0>" in names) == path.startswith("pfa"), names
     assert ("ntt_conv_kernel" in names) == (path == "fused"), names
     for b in range(2):
         assert np.array_equal(got[:, b], P.o.fft(idx, x[:, b]))
     hx.profileBegin()
     assert np.array_equal(d.iFFT().download(), x)
     names = " ".join(k["kernel"] for k in hx.profileEnd()["kernels"])
-    assert ("pfa_row_kernel" in names) == (path == "pfa"), names
+    assert ("pfa_row_kernel<2>" in names) == (path == "pfa"), names
+    assert ("pfa_row_kernel<1>" in names) == (path == "pfa_conv_rem"), names
+    assert ("ntt_conv_kernel" in names) == (path in ("pfa_conv_rem", "fused")), names
     y = P.rand(idx, 10, batch=2)
     # extreme words: all q - 1, all zero, a single one
     y[:, 0, :3] = np.array([[q - 1, 0, 1] for q in P.primes[:L]], dtype=np.uint64)

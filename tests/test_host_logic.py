@@ -730,3 +730,99 @@ def test_ckks_verification_is_signal_relative_at_low_precision():
     assert ckks_correlation(np.zeros(n), want) == 0.0 < thr                       # an all-zero product
     assert abs(ckks_correlation(rng.normal(0, 1e-4, n), want)) < thr              # a product of other operands
     assert abs(ckks_correlation(rng.normal(0, 3e-4, n), want)) < thr              # noise alone
+
+
+# ---------------------------------------------------------------- round 6: config 5 without Bluestein
+@pytest.fixture(scope="module")
+def pfa_replay():
+    src = os.path.join(ROOT, "tests", "cpp", "pfa_replay.cpp")
+    so = os.path.join(ROOT, "tests", "cpp", "libpfa_replay.so")
+    hdrs = [os.path.join(ROOT, "helib_amd", "csrc", h) for h in ("pfa_core.h", "ntt_core.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-DHX_CHECK_BOUNDS", "-shared", "-fPIC", "-o", so, src])
+    L = C.CDLL(so)
+    for f in (L.pfa_replay_forward, L.pfa_replay_inverse, L.pfa_replay_inverse_rem):
+        f.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.pfa_supported.argtypes = [C.c_uint64, C.c_uint64]
+    return L
+
+
+@pytest.mark.parametrize("m", [85, 255, 1285, 4369])
+def test_good_thomas_rader_restated_in_python_integers(m):
+    """Cmodulus::FFT / iFFT (src/CModulus.cpp:431-443, 555-577) of an m that is a product of distinct Fermat primes as
+    Good-Thomas x Rader (tests/pfa_ref.py): DFT_p1 (x) ... (x) DFT_pr with each DFT_p at its non-zero outputs ONE cyclic
+    convolution of length p - 1 (a power of two), and rem Phi_m as binomial passes -- against the oracle's Bluestein
+    restatement, every word, forward and inverse, including the extreme rows."""
+    import pfa_ref as R
+    assert R.is_fermat_product(m) and not R.is_fermat_product(32003) and not R.is_fermat_product(2 * 85)
+    g = O.PrimeGen(60, m)
+    for n in range(2):
+        q = g.next()
+        cm = O.Cmod(m, q)
+        P = R.Pfa(m, q, cm.root)
+        assert P.phim == cm.phim
+        for x in (O.fill_uniform(cm.phim, q, 3 + n), np.full(cm.phim, q - 1, dtype=np.uint64)):
+            y = cm.fft(x)
+            assert P.forward([int(v) for v in x]) == [int(v) for v in y]
+            X = P.inverse_full([int(v) for v in y])
+            # X is the length-m inverse transform of y scattered onto Z_m^*: it vanishes at the non-units ...
+            zeta = cm.root * cm.root % q
+            j = next(j for j in range(1, m) if j not in P.rank)
+            acc = 0
+            for c in reversed(X):
+                acc = (acc * pow(zeta, j, q) + c) % q
+            assert acc == 0
+            # ... and both forms of rem Phi_m give the coefficients back (long division; binomial passes)
+            phi = [int(v) % q for v in O.phimx(m)]
+            assert R.rem_phi_times_minv(X, phi, m, q) == [int(v) for v in x]
+            assert R.rem_by_binomials(X, m, q) == [int(v) for v in x]
+
+
+def test_good_thomas_rader_restatement_at_config5():
+    """the same at BASELINE config 5's own m = 21845 = 5 * 17 * 257 (one prime, python integers: ~2 s)"""
+    import pfa_ref as R
+    m = 21845
+    q = O.PrimeGen(60, m).next()
+    cm = O.Cmod(m, q)
+    P = R.Pfa(m, q, cm.root)
+    x = O.fill_uniform(cm.phim, q, 11)
+    y = cm.fft(x)
+    assert P.forward([int(v) for v in x]) == [int(v) for v in y]
+    assert R.rem_by_binomials(P.inverse_full([int(v) for v in y]), m, q) == [int(v) for v in x]
+    assert R.phi_binomials(m) == ([5, 17, 257, 21845], [1, 85, 1285, 4369])
+
+
+def test_good_thomas_rader_kernel_phases_replayed_on_cpu(pfa_replay):
+    """The phase functions of pfa_row_kernel<0 / 1 / 2> (helib_amd/csrc/pfa_core.h: forward; inverse up to X; inverse
+    with rem Phi_m and 1/m fused), run thread by thread with a vector for the LDS and every compile-time bound asserted
+    (HX_CHECK_BOUNDS aborts the process on a violation), on the tables the engine uploads (pfa::host::build_*): equal to
+    the oracle on chain primes of PrimeGenerator(60, 21845) -- random, all-(q-1), zero and single-one rows."""
+    import pfa_ref as R
+    m = 21845
+    g = O.PrimeGen(60, m)
+    for n in range(3):
+        q = g.next()
+        assert pfa_replay.pfa_supported(m, q) == 1
+        cm = O.Cmod(m, q)
+        one = np.zeros(cm.phim, dtype=np.uint64)
+        one[(977 * (n + 1)) % cm.phim] = 1
+        for x in (O.fill_uniform(cm.phim, q, 7 + n), np.full(cm.phim, q - 1, dtype=np.uint64),
+                  np.zeros(cm.phim, dtype=np.uint64), one):
+            y = cm.fft(x)
+            out = np.zeros(cm.phim, dtype=np.uint64)
+            assert pfa_replay.pfa_replay_forward(q, cm.root, x.ctypes.data, out.ctypes.data) == 0
+            assert np.array_equal(out, y)
+            back = np.zeros(cm.phim, dtype=np.uint64)
+            assert pfa_replay.pfa_replay_inverse_rem(q, cm.root, y.ctypes.data, back.ctypes.data) == 0
+            assert np.array_equal(back, x)
+            # evaluations that are not the image of a small polynomial: x itself as the evaluation row
+            assert pfa_replay.pfa_replay_inverse_rem(q, cm.root, x.ctypes.data, back.ctypes.data) == 0
+            assert np.array_equal(back, cm.ifft(x))
+        # the unfused inverse: X (all m words) as the python restatement has it
+        y = cm.fft(O.fill_uniform(cm.phim, q, 31 + n))
+        X = np.zeros(m, dtype=np.uint64)
+        assert pfa_replay.pfa_replay_inverse(q, cm.root, y.ctypes.data, X.ctypes.data) == 0
+        if n == 0:
+            assert [int(v) for v in X] == R.Pfa(m, q, cm.root).inverse_full([int(v) for v in y])
+    # a prime that is not of the form the kernels take (q != 1 mod 2^32) is refused: Bluestein serves it
+    assert pfa_replay.pfa_supported(m, 21845 * 2 * 17 + 1) == 0

@@ -133,6 +133,7 @@ PY
       grep -E "ntt_row_kernel<14, false>.* 6400 |apply_kernel<14, false>|embed_norm" $out/pmc_sq_summary.txt | cut -c1-200 | head -40 ;;
     bluestein)
       timeout 200 python tools/prof_bluestein.py > $out/blue_pfa.json 2> $out/blue_pfa.err; cat $out/blue_pfa.json
+      HX_PFA_NO_REM=1 timeout 200 python tools/prof_bluestein.py > $out/blue_pfa_conv_rem.json 2> $out/blue_pfa_conv_rem.err; cat $out/blue_pfa_conv_rem.json
       HX_NO_PFA=1 timeout 200 python tools/prof_bluestein.py > $out/blue_fused.json 2> $out/blue_fused.err; cat $out/blue_fused.json
       HX_BLUE_OLD=1 timeout 200 python tools/prof_bluestein.py > $out/blue_old.json 2> $out/blue_old.err; cat $out/blue_old.json
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $R/$out/blue_kt -- python3 $R/tools/prof_bluestein.py > /dev/null 2> $R/$out/blue_kt.err)
