@@ -818,9 +818,12 @@ def in_situ_profile(hx, sess, level, mults, sync, warm=24):
 
 
 def config5_leg(hx, iters=5, batch=32):
-    """BASELINE configs[4]: Bluestein m=21845 (phi = 16384, convolution length 2^16), DoubleCRT of L=16 primes
-    from PrimeGenerator(60, 21845), forward and inverse transforms of `batch` objects (512 rows: the chip is
-    filled), timed with HIP events on the context's stream; algorithmic bytes = 16N per row."""
+    """BASELINE configs[4]: the general-m transform at m=21845 (phi = 16384; the reference: Bluestein with a 2^16-point
+    convolution), DoubleCRT of L=16 primes from PrimeGenerator(60, 21845), forward and inverse transforms of `batch`
+    objects (512 rows: the chip is filled), timed with HIP events on the context's stream; algorithmic bytes = 16N per
+    row.  Round 6: the engine runs it as Good-Thomas x Rader (21845 = 5 * 17 * 257, pfa_kernels.hip), one
+    launch per direction, rem Phi_m fused into the inverse; `method` says which kernels actually ran (HX_NO_PFA=1:
+    Bluestein on the convolution kernels, as rounds 3-5)."""
     from helib_amd import hostnt
     m, L = 21845, 16
     g = hostnt.PrimeGen(60, m)
@@ -835,7 +838,7 @@ def config5_leg(hx, iters=5, batch=32):
     d.FFT()
     d.iFFT()
     ok = bool(np.array_equal(d.download(), rows))
-    out = {"workload": f"Bluestein m={m} phi={n} L={L} batch {batch} ({L * batch} rows), conv length 2^16",
+    out = {"workload": f"Cmodulus::FFT / iFFT at m={m} phi={n} L={L} batch {batch} ({L * batch} rows); the reference: Bluestein, conv length 2^16",
            "round_trip_exact": ok}
     for name, fn in (("forward", d.FFT), ("inverse", d.iFFT)):
         ctx.timerBegin()
@@ -851,6 +854,10 @@ def config5_leg(hx, iters=5, batch=32):
     ctx.sync()
     prof = hx.profileEnd()
     tot = sum(kk["total_us"] for kk in prof["kernels"]) or 1.0
+    names = " ".join(kk["kernel"] for kk in prof["kernels"])
+    out["method"] = ("Good-Thomas x Rader (5 x 17 x 257), rem Phi_m as binomial passes in the same launch" if "pfa_row_kernel<2>" in names
+                     else "Good-Thomas x Rader, rem Phi_m on the convolution kernels" if "pfa_row_kernel" in names
+                     else "Bluestein (chirp convolution)")
     out["kernels_in_situ_fwd_plus_inv"] = [{"kernel": kk["kernel"].replace("hx::", ""), "workgroups": kk["workgroups"],
                                             "calls": kk["calls"], "avg_us": round(kk["avg_us"], 1),
                                             "share": round(kk["total_us"] / tot, 3)} for kk in prof["kernels"][:12]]

@@ -2,6 +2,7 @@
 // (ntt_kernels.hip, conv_kernels.hip).
 #pragma once
 #include "dev_common.h"
+#include "work_map.h"
 
 // Minimum waves per SIMD requested from the register allocator.  T = N/32
 // threads: N=2^13 -> 4 waves/WG, 2^14 -> 8, 2^15 -> 16 (=4 per SIMD already).
@@ -14,17 +15,13 @@
 
 namespace hx {
 
-// XCD-aware work mapping: hardware places workgroup id on XCD (id % 8) (observed, used for speed
-// only).  Remap so that each XCD works on a contiguous chunk of the (row, batch) space, i.e. on a
-// few primes only: their twiddle tables (2*N*16 B each) then stay resident in that XCD's 4 MiB
-// L2 instead of all primes' tables cycling through every L2.  Bijective for any grid size.
+// XCD-aware work mapping (work_map.h: a pure function, checked for bijectivity on the host by tests/cpp/work_map_test.cpp)
 __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned nwg)
 {
 #ifdef HX_NO_XCD_REMAP
   return id;
 #else
-  const unsigned xcd = id & 7u, slot = id >> 3, qd = nwg >> 3, r = nwg & 7u;
-  return (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + slot;
+  return xcd_remap_id(id, nwg);
 #endif
 }
 

@@ -382,23 +382,7 @@ struct ModDownIO {
   __device__ __forceinline__ TWM last_tw(TWM def, int) const { return def; }
 };
 
-// Tile shape of the mod-down apply kernel (see there): g row groups of rg rows, 8/g XCDs per group
-// each taking `chunk` (poly, batch) elements; per_xcd = workgroups launched per XCD.
-struct MdTile {
-  unsigned g, rg, chunk, per_xcd;
-};
-__host__ __device__ inline MdTile md_tile(unsigned nkeep, unsigned npb)
-{
-  MdTile t;
-  t.g = 1;
-  while (t.g < 8 && (nkeep + t.g - 1) / t.g > 8)
-    t.g *= 2;
-  t.rg = (nkeep + t.g - 1) / t.g;
-  const unsigned xpg = 8 / t.g;
-  t.chunk = (npb + xpg - 1) / xpg;
-  t.per_xcd = t.rg * t.chunk;
-  return t;
-}
+// (tile shape and work map of the mod-down apply kernels: work_map.h -- md_tile, md_work)
 
 template <int LOGN, bool INV, class AR, class IO>
 __device__ __forceinline__ void ntt_body_ar(uint32_t* lds, const IO& io, const typename AR::Tw* tw, const QC& q)
@@ -512,22 +496,11 @@ ntt_moddown_apply_kernel(PolyBases polys, PolyBases outs, NttRows rows, int nkee
   const unsigned rp = wid / (unsigned)batch;
   const unsigned pi = rp % (unsigned)polys.n, ri = rp / (unsigned)polys.n;
 #else
-  // 2-D XCD-aware tiling.  Every kept row of one (poly, batch) element re-reads the same
-  // x and S streams, and every element of one row re-reads the same twiddle table.  XCD k (the
-  // hardware places workgroup id on XCD id % 8) owns a tile of `rg` rows x a chunk of the
-  // elements: its twiddle footprint is rg tables (<= 8 x 16N bytes, L2 resident), and the rg
-  // workgroups that share x/S are consecutive in its dispatch order, so they load them while
-  // the lines are still in that XCD's L2 -- x/S cross the fabric nkeep/rg times instead of nkeep.
-  const MdTile T = md_tile((unsigned)nkeep, (unsigned)polys.n * (unsigned)batch);
-  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const unsigned grp = xcd % T.g, part = xcd / T.g;
-  const unsigned r0 = grp * T.rg, pb0 = part * T.chunk;
-  const unsigned nr = r0 < (unsigned)nkeep ? min(T.rg, (unsigned)nkeep - r0) : 0u;
-  const unsigned npb = (unsigned)polys.n * (unsigned)batch;
-  const unsigned nloc = pb0 < npb ? min(T.chunk, npb - pb0) : 0u;
-  if (slot >= nr * nloc)
+  // 2-D XCD-aware tiling (work_map.h: md_work)
+  const MdWork Wk = md_work(blockIdx.x, (unsigned)nkeep, (unsigned)polys.n * (unsigned)batch);
+  if (!Wk.active)
     return;  // padding workgroup of an uneven tile (whole workgroup, before any barrier)
-  const unsigned ri = r0 + slot % nr, pb = pb0 + slot / nr;
+  const unsigned ri = Wk.ri, pb = Wk.pb;
   const int b = (int)(pb % (unsigned)batch);
   const unsigned pi = pb / (unsigned)batch;
 #endif
@@ -837,16 +810,10 @@ ntt_moddown_apply_tensor_kernel(TensorSrc T, PolyBases outs, NttRows rows, int n
                                 const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const MdTile Tl = md_tile((unsigned)nkeep, 3u * (unsigned)batch);
-  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const unsigned grp = xcd % Tl.g, partx = xcd / Tl.g;
-  const unsigned r0 = grp * Tl.rg, pb0 = partx * Tl.chunk;
-  const unsigned nr = r0 < (unsigned)nkeep ? min(Tl.rg, (unsigned)nkeep - r0) : 0u;
-  const unsigned npb = 3u * (unsigned)batch;
-  const unsigned nloc = pb0 < npb ? min(Tl.chunk, npb - pb0) : 0u;
-  if (slot >= nr * nloc)
+  const MdWork Wk = md_work(blockIdx.x, (unsigned)nkeep, 3u * (unsigned)batch);
+  if (!Wk.active)
     return;
-  const unsigned ri = r0 + slot % nr, pb = pb0 + slot / nr;
+  const unsigned ri = Wk.ri, pb = Wk.pb;
 #ifdef HX_TENSOR_PARTS_APART
   const int b = (int)(pb % (unsigned)batch);
   const unsigned pi = pb / (unsigned)batch;   // product part 0, 1, 2

@@ -541,6 +541,10 @@ public:
   // RLWE1 (src/keys.cpp:39-72): c0 = p*e - c1*s on the primes of c1; returns the noise bound
   double RLWE1(DoubleCRT& c0, const DoubleCRT& c1, const IndexSet& idx, long p)
   {
+    // (fromCoeffs zero-pads a short vector: without this an object that holds public material only would build
+    // "encryptions under s = 0" -- wrong key-switching matrices, no error)
+    if (sKey.empty())
+      throw LogicError("RLWE1: this key object holds no secret key (public material only)");
     double bound = 0;
     std::vector<long> e = sampler.sampleGaussianBounded(sampler.errorStdev(), bound);
     c0 = fromCoeffs(idx, e);
@@ -557,7 +561,9 @@ public:
   // SecKey::GenSecKey + ImportSecKey (src/keys.cpp:1099-1157)
   void GenSecKey(long maxDegKswitch = 3)
   {
-    if (!sKey.empty())
+    // (also after importKeys of a public-only blob: a fresh secret key under the imported matrices would leave
+    // matrices that belong to another key)
+    if (!sKey.empty() || pubEncrKey0)
       throw LogicError("this host side holds one secret key per SecKey object");
     sKey = cc->hwt > 0 ? sampler.sampleHWtBounded(cc->hwt, skBound) : sampler.sampleSmallBounded(skBound);
     ptxtSpace = cc->ptxtSpace;
@@ -585,6 +591,8 @@ public:
     if (fromSPower <= 0 || fromXPower <= 0 || (fromSPower == 1 && fromXPower == 1) ||
         haveKeySWmatrix(fromSPower, fromXPower))
       return;
+    if (sKey.empty())
+      throw LogicError("GenKeySWmatrix: this key object holds no secret key (public material only)");
     IndexSet idx = cc->ctxtPrimes;
     idx.insert(idx.end(), cc->specialPrimes.begin(), cc->specialPrimes.end());
     DoubleCRT fromKey = fromCoeffs(idx, sKey);
@@ -637,10 +645,12 @@ public:
   // node; in the reference a PubKey / SecKey travels through writeTo / readFrom, src/keys.cpp:904-1097 and
   // :1547-1600 -- helib_amd_wire.hpp has that format; this is the engine's own flat form, with the key-switching
   // matrices' a columns expanded as the device holds them) ----
-  // words: magic, m, phi(m), #ctxt primes, #matrices, ptxtSpace, skBound, pubEncrKeyNoise (doubles as bits), the
-  // secret polynomial (phi(m) longs), pubEncrKey parts 0 and 1 ([L][phi(m)]), then per matrix: fromSPower,
+  // words: magic, m, phi(m), #ctxt primes, #matrices, ptxtSpace, skBound, pubEncrKeyNoise (doubles as bits), has-secret
+  // (1 / 0), the secret polynomial (phi(m) longs; every word NO_SECRET when has-secret = 0), pubEncrKey parts 0 and 1
+  // ([L][phi(m)]), then per matrix: fromSPower,
   // fromXPower, ptxtSpace, noiseBound, ndig, nrows, the row primes, b and a ([ndig][nrows][phi(m)])
-  static constexpr uint64_t KEYS_MAGIC = 0x68786b6579733031ull;   // "hxkeys01"
+  static constexpr uint64_t KEYS_MAGIC = 0x68786b6579733032ull;   // "hxkeys02" (01 had no has-secret word)
+  static constexpr size_t KEYS_HEADER = 9;
   // withSecret = false: the same blob with the secret polynomial blanked (every word NO_SECRET) -- what a process that
   // only encrypts and multiplies needs (the public encryption key and the key-switching matrices); importKeys leaves
   // such an object without a secret key, its Decrypt throws.  (bench.py's ranks verify their own products and take the
@@ -657,7 +667,7 @@ public:
       return u;
     };
     std::vector<uint64_t> w{KEYS_MAGIC, (uint64_t)cc->m, (uint64_t)n, (uint64_t)L, (uint64_t)keySwitching.size(),
-                            (uint64_t)ptxtSpace, bits(skBound), bits(pubEncrKeyNoise)};
+                            (uint64_t)ptxtSpace, bits(skBound), bits(pubEncrKeyNoise), (uint64_t)(withSecret ? 1 : 0)};
     for (size_t j = 0; j < n; j++)
       w.push_back(withSecret ? (uint64_t)(j < sKey.size() ? sKey[j] : 0) : NO_SECRET);
     for (const DoubleCRT* pk : {pubEncrKey0.get(), pubEncrKey1.get()}) {
@@ -699,14 +709,22 @@ public:
       memcpy(&v, &u, 8);
       return v;
     };
-    const uint64_t* h = take(8);
+    const uint64_t* h = take(KEYS_HEADER);
     if (h[0] != KEYS_MAGIC || h[1] != (uint64_t)cc->m || h[2] != n || h[3] != L)
       throw InvalidArgument("importKeys: key material of another context");
+    if (h[8] > 1)
+      throw InvalidArgument("importKeys: bad has-secret word");
     const size_t nks = (size_t)h[4];
     {
       // the whole blob is walked and checked BEFORE anything of this object changes: a truncated blob or a bad
       // matrix header must not leave a half-initialised key behind (sKey set, so no retry; matrices missing)
-      size_t q = 8 + n + 2 * L * n;
+      size_t q = KEYS_HEADER + n + 2 * L * n;
+      if (q > nwords)
+        throw InvalidArgument("importKeys: truncated key material");
+      // the secret polynomial agrees with the header's has-secret word in EVERY coefficient (not just the first)
+      for (size_t j = 0; j < n; j++)
+        if ((w[KEYS_HEADER + j] == NO_SECRET) != (h[8] == 0))
+          throw InvalidArgument("importKeys: the secret polynomial does not match the has-secret word");
       for (size_t i = 0; i < nks; i++) {
         if (q + 6 > nwords)
           throw InvalidArgument("importKeys: truncated key material");
@@ -727,7 +745,7 @@ public:
     skBound = dbl(h[6]);
     pubEncrKeyNoise = dbl(h[7]);
     const uint64_t* sk = take(n);
-    if (sk[0] != NO_SECRET) {          // (a blob exported without the secret key leaves this object public-only)
+    if (h[8] == 1) {                   // (a blob exported without the secret key leaves this object public-only)
       sKey.resize(n);
       for (size_t j = 0; j < n; j++)
         sKey[j] = (long)sk[j];

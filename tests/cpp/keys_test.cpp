@@ -198,6 +198,45 @@ int main(int argc, char** argv)
       }
       REQUIRE(threw);
       REQUIRE(s2.Decrypt(x) == negacyclic(m0, m1, p));
+      // ... and it cannot make keys either: a key-switching matrix "under s = 0" or a fresh secret key
+      // next to the imported matrices would give wrong ciphertexts with no error
+      for (int what = 0; what < 3; what++) {
+        threw = false;
+        try {
+          if (what == 0)
+            only.GenKeySWmatrix(1, 3);       // (what add1DMatrices and its siblings call per family member)
+          else if (what == 1)
+            only.GenSecKey(2);
+          else
+            only.GenKeySWmatrix(3, 1);
+        } catch (const LogicError&) {
+          threw = true;
+        }
+        REQUIRE(threw);
+      }
+      REQUIRE(only.sKey.empty() && !only.haveKeySWmatrix(1, 3));
+      // the has-secret word of the header and the polynomial must agree in every coefficient
+      std::vector<uint64_t> bad = pub;
+      bad[SecKey::KEYS_HEADER + 5] = 1;      // one coefficient present in a "public" blob
+      SecKey other2(cc, *dev, 98);
+      threw = false;
+      try {
+        other2.importKeys(bad.data(), bad.size());
+      } catch (const InvalidArgument&) {
+        threw = true;
+      }
+      REQUIRE(threw && !other2.pubEncrKey0);
+      bad = full;
+      bad[8] = 0;                            // "no secret" over a blob that carries one
+      threw = false;
+      try {
+        other2.importKeys(bad.data(), bad.size());
+      } catch (const InvalidArgument&) {
+        threw = true;
+      }
+      REQUIRE(threw && !other2.pubEncrKey0);
+      other2.importKeys(full.data(), full.size());
+      REQUIRE(!other2.sKey.empty() && other2.Decrypt(x) == negacyclic(m0, m1, p));
     }
     dev->sync();
   } catch (const std::exception& ex) {

@@ -10,9 +10,12 @@ from oracle import oracle as O
 from oracle.backend import OKeySwitch, OPoly, OracleOps
 
 
-def replay_and_compare(s, scheme, m, p, r, bits, measure=True, levels=(1, 2)):
+def replay_and_compare(s, scheme, m, p, r, bits, measure=True, levels=(1, 2), elements=None):
     """s: a helib_amd.host.Session that has not multiplied yet.  Runs one multiply per level in the session and on
-    the oracle; returns the number of words compared."""
+    the oracle; returns the number of words compared.  elements: the batch elements replayed on the oracle (default
+    all) -- a stratified sample at the batch sizes bench.py times (128 / 64), where the work-to-workgroup maps of the
+    kernels (md_tile, xcd_remap: functions of the launch size) differ from the small batches' and the oracle's
+    ~9 multiplies per second allow a handful of elements."""
     ckks = scheme == "ckks"
     cc = hc.ChainContext(m, -1 if ckks else p, r, bits=bits, c=3, ckks=ckks)
     assert s.chain_primes() == [int(q) for q in cc.primes], "the C++ chain differs from the python mirror's"
@@ -28,13 +31,15 @@ def replay_and_compare(s, scheme, m, p, r, bits, measure=True, levels=(1, 2)):
     compared = 0
     try:
         B = s.batch
+        elems = list(range(B)) if elements is None else [int(b) for b in elements]
+        assert all(0 <= b < B for b in elems) and len(set(elems)) == len(elems)
         operands = []
         for which in (0, 1):
             info = s.ctxt_info(0, which)
             parts = [s.ctxt_rows(0, which, part) for part in (0, 1)]
             assert all(idx == list(cc.ctxtPrimes) for idx, _ in parts)
             cts = []
-            for b in range(B):
+            for b in elems:
                 c = hc.Ctxt(cc, ops, oW, ksw_ptxtSpace=int(info["key_ptxtSpace"]), ksw_noise=info["key_lnNoise"])
                 c.parts = {"1": OPoly(octx, parts[0][0], parts[0][1][:, b]), "s": OPoly(octx, parts[1][0], parts[1][1][:, b])}
                 c.primeSet = frozenset(cc.ctxtPrimes)
@@ -48,25 +53,26 @@ def replay_and_compare(s, scheme, m, p, r, bits, measure=True, levels=(1, 2)):
             s.multiply(level, 1, measure)
             if level == 1:
                 cur = operands[0]
-                for b in range(B):
-                    cur[b].multiplyBy(operands[1][b])
+                for e in range(len(elems)):
+                    cur[e].multiplyBy(operands[1][e])
             else:
-                for b in range(B):
-                    cur[b].multiplyBy(cur[b].clone())
+                for e in range(len(elems)):
+                    cur[e].multiplyBy(cur[e].clone())
             info = s.ctxt_info(level)
             assert int(info["nparts"]) == 2
             # the batch shares one prime-set decision: its estimate takes the largest norm of the batch per part and
             # digit, so it is the largest of its elements' estimates or slightly above
+            # (a sample of the batch need not contain the element with the largest norm: a wider margin above)
             worst = max(c.lnNoise for c in cur)
-            assert worst - 1e-6 <= info["lnNoise"] <= worst + 0.05, (level, worst, info["lnNoise"])
+            assert worst - 1e-6 <= info["lnNoise"] <= worst + (0.05 if elements is None else 0.25), (level, worst, info["lnNoise"])
             for c in cur:
                 assert sorted(c.primeSet) == s.result_primes(level)
                 assert c.intFactor == int(info["intFactor"]) and abs(c.lnRatFactor - info["lnRatFactor"]) < 1e-9
                 c.lnNoise = info["lnNoise"]
             for part, h in enumerate(("1", "s")):
                 idx, rows = s.ctxt_rows(level, 0, part)
-                for b in range(B):
-                    oi, od = cur[b].parts[h].getIndexSet(), cur[b].parts[h].rows
+                for e, b in enumerate(elems):
+                    oi, od = cur[e].parts[h].getIndexSet(), cur[e].parts[h].rows
                     assert sorted(idx) == sorted(oi)
                     for rr, i in enumerate(idx):
                         assert np.array_equal(rows[rr, b], od[oi.index(i)]), (level, h, i, b)

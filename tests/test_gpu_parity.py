@@ -2337,6 +2337,29 @@ def test_cpp_session_products_equal_the_oracle_replay(hx, scheme, m, p, r, bits,
     t.close()
 
 
+@pytest.mark.parametrize("scheme,m,p,r,bits,batch,elements,shape", [
+    ("bgv", 32768, 65537, 1, 950, 128, (0, 1, 63, 64, 127), (16, 6, 3)),   # bench.py's default line: batch 128
+    ("ckks", 65536, -1, 1, 1400, 64, (0, 31, 32, 63), (24, 8, 3))])        # bench.py --workload ckks65536: batch 64
+def test_cpp_session_products_at_the_timed_launch_shapes(hx, scheme, m, p, r, bits, batch, elements, shape):
+    """Word-for-word parity AT THE LAUNCH SHAPES THE BENCHMARK LINE TIMES.  The work-to-workgroup
+    maps of the hot kernels are functions of the launch size -- md_tile(nkeep, npoly * batch) picks the row group, the
+    chunk and the per-XCD split (ntt_kernels.hip), xcd_remap(blockIdx.x, gridDim.x) the XCD slot (ntt_kernel_util.h) --
+    so the 8192- / 6144- / 6400- / 16384-workgroup launches of the line are different index arithmetic from the
+    256-workgroup launches of the batch-4 / batch-2 cases above; decryption (Session.verify) would catch a dropped row,
+    not a wrong word that still decrypts.  Here the session runs at bench.py's own batch (128 for BGV bits = 950, 64
+    for CKKS bits = 1400), and a stratified sample of its elements -- first, second, the two around the middle, last --
+    is replayed on the oracle through the python mirror (src/Ctxt.cpp:1681-1774): every word of both parts of the
+    kept products of level 1 AND level 2.  Every element is also decrypted and compared with the plaintext product."""
+    from helib_amd import host
+    from tests.session_replay import replay_and_compare
+    s = host.Session(scheme, m, p, r, bits, batch, seed=41)
+    assert (s.L_ctxt, s.K, s.D) == shape
+    words = replay_and_compare(s, scheme, m, p, r, bits, measure=True, levels=(1, 2), elements=elements)
+    assert words == 2 * len(elements) * s.phim * sum(len(s.result_primes(lv)) for lv in (1, 2))
+    assert s.verify(2) == batch
+    s.close()
+
+
 @pytest.mark.parametrize("eps", ["default", "0.05", "1.0"])
 def test_hps_form_of_the_rns_kernels_and_its_redo_list(hx, monkeypatch, eps):
     """The fast basis-extension / digit kernels in their HPS form (rns_kernels.h: ExtRep, engine.hip: hps_min_n) --

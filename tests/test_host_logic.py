@@ -826,3 +826,38 @@ def test_good_thomas_rader_kernel_phases_replayed_on_cpu(pfa_replay):
             assert [int(v) for v in X] == R.Pfa(m, q, cm.root).inverse_full([int(v) for v in y])
     # a prime that is not of the form the kernels take (q != 1 mod 2^32) is refused: Bluestein serves it
     assert pfa_replay.pfa_supported(m, 21845 * 2 * 17 + 1) == 0
+
+
+# ---------------------------------------------------------------- round 6: the work maps at the timed launch shapes
+def test_work_maps_are_bijections_at_every_launch_shape():
+    """md_tile / md_work (the 2-D XCD tiling of ntt_moddown_apply_kernel and ntt_moddown_apply_tensor_kernel) and
+    xcd_remap (every other row kernel) are functions of the LAUNCH SIZE: the batch-128 / batch-64 launches bench.py
+    times run different index arithmetic from the batch-4 / batch-2 launches most parity tests pin.  Compiled for the
+    host (helib_amd/csrc/work_map.h has no HIP types): every (row, element) of a launch is handed to exactly one
+    workgroup, for the shapes of the benchmark legs -- bits = 950 at batch 128 (16 / 22 rows x 256 / 384 elements),
+    CKKS 1400 at batch 64 (24 / 21 / 14 rows x 128 / 192), bits = 6400 at batch 16, CKKS 440 -- and for a sweep around
+    them; the 1-D remap is one-to-one and keeps each XCD on one contiguous range for every grid size up to 4096 and
+    for the line's own 8192 / 6144 / 6400 / 2048 / 16384 / 7168 / 5376 / 4608 (src/Ctxt.cpp:1681-1774 is what these
+    launches compute)."""
+    src = os.path.join(ROOT, "tests", "cpp", "work_map_test.cpp")
+    so = os.path.join(ROOT, "tests", "cpp", "libwork_map_test.so")
+    hdr = os.path.join(ROOT, "helib_amd", "csrc", "work_map.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    L = C.CDLL(so)
+    L.check_md_work.restype = C.c_long
+    L.check_md_work.argtypes = [C.c_uint, C.c_uint, C.c_void_p]
+    for nwg in list(range(1, 4097)) + [8192, 6144, 6400, 2048, 16384, 7168, 5376, 4608, 12288, 24576, 65536 + 3]:
+        assert L.check_xcd_remap(nwg) == 0, nwg
+        assert L.check_xcd_remap_contiguous(nwg) == 0, nwg
+    pad = C.c_uint(0)
+    named = [(16, 384), (16, 256), (22, 256), (15, 384), (15, 256), (24, 192), (24, 128), (21, 192), (21, 128), (14, 192),
+             (14, 128), (32, 128), (107, 48), (143, 32), (72, 48), (8, 192), (8, 128), (11, 128), (5, 192)]
+    sweep = [(nk, npb) for nk in range(1, 65) for npb in (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512)]
+    for nk, npb in named + sweep:
+        grid = L.check_md_work(nk, npb, C.byref(pad))
+        assert grid > 0, (nk, npb, grid)
+        assert grid - pad.value == nk * npb
+        assert pad.value < 8 * (nk + npb) + 64, (nk, npb, grid, pad.value)   # uneven tiles idle a fringe, not a share
+    # the dominant launch of the headline: 16 kept rows x 3 parts x 128 elements = 6144 workgroups, none idle
+    assert L.check_md_work(16, 384, C.byref(pad)) == 6144 and pad.value == 0
