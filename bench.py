@@ -1057,16 +1057,44 @@ def launch_ranks(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else log, stderr=None if r == 0 else subprocess.STDOUT,
                                       text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # watchdog: every rank is polled; the first one that exits with an error ends the others (a rank that dies during
+    # setup would otherwise leave the rest inside a collective until RCCL's own timeout: ten minutes of an 8-GPU lease)
+    # and its log is what the launcher prints.  Rank 0's stdout is drained on a thread so that it never blocks on a full pipe.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    first_bad = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad and first_bad is None:
+            first_bad = bad[0]
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.terminate()
+            deadline = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        if all(rc is not None for rc in [p.poll() for p in procs]):
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out = "".join(c for c in chunks if c)
     for log in logs:
         if log:
             log.close()
     sys.stdout.write(out)
     sys.stdout.flush()
     if any(rcs):
+        if first_bad is not None:
+            sys.stderr.write(f"bench.py: rank {first_bad} failed first (exit code {rcs[first_bad]}); the other ranks were stopped\n")
         for r, rc in enumerate(rcs):
-            if r and rc:
+            if r and rc and (first_bad in (None, 0) or r == first_bad):
                 try:
                     with open(os.path.join(logdir, f"rank{r}.log")) as f:
                         sys.stderr.write(f"---- rank {r} (exit code {rc}), last lines of {f.name}:\n" + "".join(f.readlines()[-15:]))
@@ -1079,6 +1107,10 @@ def dry_rank(args):
     """--dry-launch: the launch / shard / barrier / max-over-ranks / aggregate path of the N-rank
     bench over gloo on CPUs, with a sleep where the engine would run (no compute, no oracle)."""
     from helib_amd import dist as hdist
+    if os.environ.get("HX_TEST_FAIL_RANK") == os.environ.get("RANK"):
+        # (test hook of the launcher's watchdog: this rank dies during setup, before its first collective)
+        print("rank dies during setup (HX_TEST_FAIL_RANK)", file=sys.stderr)
+        raise SystemExit(3)
     group = hdist.Group(backend="gloo")
     world, rank = group.world, group.rank
     if args.global_batch:
@@ -1132,6 +1164,10 @@ def main():
                          "own benchmarks/bgv_basic.cpp:247 parameter (L=107, K=36); ckks65536: 1400 (L=24, K=8)")
     ap.add_argument("--precision", type=int, default=1,
                     help="ckks65536: ContextBuilder<CKKS>::precision (1 = the reference's benchmarks/ckks_common.h:45-50)")
+    ap.add_argument("--scatter", action="store_true",
+                    help="the batch split as a service: rank 0 encrypts ALL pairs and keeps the secret key, the slices travel "
+                         "as wire-format ciphertexts (RCCL send / recv), every rank multiplies under PUBLIC key material, "
+                         "the products are gathered and rank 0 alone decrypts and verifies them")
     ap.add_argument("--one-device", action="store_true",
                     help="N ranks on GPU 0 (a 1-GPU box): the N-rank path -- one key pair broadcast from rank 0, per-rank "
                          "arenas, barriers -- runs functionally with the real engine; the process group is gloo, because "
@@ -1199,16 +1235,56 @@ def main():
         # encryption key, the relinearisation matrix with its a columns -- is broadcast once (RCCL between device
         # buffers), every other rank builds its session on it and encrypts its own slice of the pairs
         key_bytes = 0
-        if rank == 0:
-            sess = hh.Session(*sparams, B, device=local_rank, stream=stream, seed=7)
-            keys = sess.export_keys() if world > 1 else None
-        if world > 1:
-            keys, key_bytes = group.broadcast_words(keys if rank == 0 else None, src=0)
-            if rank != 0:
-                sess = hh.Session(*sparams, B, device=local_rank, stream=stream, seed=7 + rank, keys=keys)
-            del keys
+        src, split = None, None
+        if args.scatter:
+            # the batch split itself (north_star): rank 0 holds every pair and the secret key; what
+            # leaves it is PUBLIC key material (broadcast) and each rank's slice of the ciphertexts in the reference's
+            # binary format (Ctxt::writeTo), one device tensor per rank and operand
+            parts = [hdist.shard(pairs_all, world, r_) for r_ in range(world)]
+            assert parts[rank][1] == B
+            if rank == 0:
+                src = hh.Session(*sparams, pairs_all, device=local_rank, stream=stream, seed=7, source=True)
+            keys, key_bytes = group.broadcast_words(src.export_public_keys() if rank == 0 else None, src=0)
+            group.barrier()
+            ts = time.perf_counter()
+            blobs, moved = [], 0
+            for which in (0, 1):
+                blob, mv = group.scatter_blobs(None, src=0, produce=(lambda r_, w_=which: src.export_ctxts(0, w_, *parts[r_]))
+                                               if rank == 0 else None)
+                blobs.append(blob)
+                moved += mv
+            sync()
+            group.barrier()
+            split = {"scatter_ms": round((time.perf_counter() - ts) * 1e3, 1), "scatter_bytes_this_rank": int(moved),
+                     "operand_bytes_this_rank": int(blobs[0].size + blobs[1].size)}
+            sess = hh.Session(*sparams, B, device=local_rank, stream=stream, keys=keys, operands=tuple(blobs))
+            del blobs, keys
+        else:
+            if rank == 0:
+                sess = hh.Session(*sparams, B, device=local_rank, stream=stream, seed=7)
+                keys = sess.export_keys() if world > 1 else None
+            if world > 1:
+                keys, key_bytes = group.broadcast_words(keys if rank == 0 else None, src=0)
+                if rank != 0:
+                    sess = hh.Session(*sparams, B, device=local_rank, stream=stream, seed=7 + rank, keys=keys)
+                del keys
         sync()
         t_setup = time.perf_counter() - t0
+
+        def verify_level(level):
+            """every batch element of the kept product of `level`: each rank its own (it holds the secret key), or --
+            --scatter -- the products gathered as wire ciphertexts and rank 0 alone decrypting all of them"""
+            if not args.scatter:
+                return sess.verify(level), None
+            tg = time.perf_counter()
+            done = [0]
+
+            def take(r_, blob):
+                done[0] += src.verify_blob(blob, level, *parts[r_])
+            prod = sess.export_ctxts(level, 0)
+            _, mv = group.gather_blobs(prod, dst=0, consume=take if rank == 0 else None)
+            return done[0], {"gather_and_verify_ms": round((time.perf_counter() - tg) * 1e3, 1), "product_bytes_this_rank": int(prod.size),
+                             "gather_bytes_this_rank": int(mv)}
         n, l, k, d = sess.phim, sess.L_ctxt, sess.K, sess.D
         dtb, host_b = run_session(sess, 1, steps4, args.warmup, R, sync, group.barrier, measure=False)
         dtb = group.max_over_ranks(dtb) / steps4 * args.steps
@@ -1219,7 +1295,7 @@ def main():
         rate_rank = B * R * args.steps / dt                # this rank's own rate over its own clock
         rate_min, rate_max = group.min_over_ranks(rate_rank), group.max_over_ranks(rate_rank)
         dt = group.max_over_ranks(dt)
-        nver = sess.verify(1)                              # every batch element of the last product, on every rank
+        nver, gather1 = verify_level(1)                    # every batch element of the last product
         res_primes = sess.result_primes(1)
         prof1 = in_situ_profile(hx, sess, 1, 8, sync) if rank == 0 else None
         # level 2: the kept product with itself (operands that carry the special primes of a key switch)
@@ -1228,7 +1304,7 @@ def main():
         dt2, _ = run_session(sess, 2, steps4, 0, R, sync, group.barrier, measure=True)
         malloc2 = sess.arena_stats()["hipMalloc_calls"] - malloc0
         dt2 = group.max_over_ranks(dt2)
-        nver2 = sess.verify(2)
+        nver2, gather2 = verify_level(2)
         prof2 = in_situ_profile(hx, sess, 2, 4, sync, warm=8) if (rank == 0 and extras) else None
         nver_all = int(group.sum_over_ranks(nver))
         nver2_all = int(group.sum_over_ranks(nver2))
@@ -1266,6 +1342,13 @@ def main():
                  **smp.summary(),
                  "process_group_world_size": group.world_size_seen(), "world_size_seen": group.world_size_seen(),
                  "key_material_bytes_broadcast": key_bytes,
+                 "batch_split": ({"what": "rank 0 encrypts all pairs and keeps the secret key; public key material broadcast; each rank's "
+                                          "slice scattered as wire-format ciphertexts (Ctxt::writeTo, one device tensor per rank and "
+                                          f"operand, {'gloo' if args.one_device else 'RCCL send/recv'}); products gathered the same way; "
+                                          "rank 0 alone decrypts and verifies every product of every rank",
+                                  **split, "level1": gather1, "level2": gather2, "verified_on_rank0": True,
+                                  "ranks_hold_secret_key": "rank 0 only"} if args.scatter else
+                                 "not used: every rank encrypts its own slice (bench.py --scatter moves the ciphertexts instead)"),
                  "per_rank_mult_per_s_min": round(rate_min, 1), "per_rank_mult_per_s_max": round(rate_max, 1),
                  "extras": ("all secondary legs, roofline traffic, cpu_baseline and the RCCL self-check: this is the N = 1 line"
                             if extras else ("skipped at N > 1: the ranks end together, the line carries the headline, the "
@@ -1276,7 +1359,9 @@ def main():
                  "verified": (f"decrypt(last product) == plaintext product mod (X^N+1{'' if ckks else ', p'}) for all {nver_all} batch "
                               f"elements of all ranks" + (" (decoded: within the error bound the ciphertext reports AND correlated with "
                                                           "the expected product beyond 8 sigma of an unrelated one; smallest correlation "
-                                                          f"{getattr(sess, 'min_ckks_correlation', float('nan')):.4f})" if ckks else "")),
+                                                          f"{getattr(src or sess, 'min_ckks_correlation', float('nan')):.4f})" if ckks else "")
+                              + (" -- gathered as wire-format ciphertexts and decrypted by rank 0 alone (the only holder of the secret key)"
+                                 if args.scatter else "")),
                  "level2": {"what": "product x product: both operands carry the special primes of the previous key switch "
                                     "(the several-primes mod-switch in front of the tensor product)",
                             "mult_per_s": round(pairs_all * R * steps4 / dt2, 1),
@@ -1286,7 +1371,9 @@ def main():
                             "verified_elements": nver2_all, "result_primes": sess.result_primes(2)}}
         if world == 1 and not args.no_rccl_check:
             # RCCL once before the 8-GPU node does it for us: the N-rank run's own calls in a world of one (<= 2 s)
-            extra["rccl_selfcheck"] = hdist.rccl_selfcheck(sess.export_keys(), torch.device("cuda", local_rank))
+            # (with one real wire-format ciphertext through the scatter / gather code and through an RCCL broadcast)
+            extra["rccl_selfcheck"] = hdist.rccl_selfcheck(sess.export_public_keys(), torch.device("cuda", local_rank),
+                                                           ctxt_blob=sess.export_ctxts(0, 0, 0, 1))
         extra["level2_mult_per_s"] = extra["level2"]["mult_per_s"]
         extra["level2_over_level1"] = extra["level2"]["over_level1"]
         if rank == 0:

@@ -2,10 +2,16 @@
 
 One process per GPU; each rank owns a contiguous slice of the ciphertext batch and a replica
 of the (small) key-switch matrix: rank 0 makes the key pair, broadcast_words() replicates its
-material once (RCCL broadcast between device buffers), every rank encrypts and multiplies its
-own slice under it.  There is no data-path collective during the multiplies: torch.distributed
-(backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests) otherwise carries only the
-barrier around the timed region and the max-over-ranks of the elapsed time."""
+material once (RCCL broadcast between device buffers), every rank multiplies its own slice under it.
+Two ways the slices get there:
+  * every rank encrypts its own (bench.py's default N-rank line: nothing but the keys crosses a GPU boundary);
+  * the batch split itself (north_star: "RCCL over xGMI only for the batch split"):
+    scatter_blobs() hands each rank its slice of the ciphertext pairs as wire-format bytes in ONE device tensor
+    (Ctxt::writeTo, src/Ctxt.cpp:2584-2611), gather_blobs() brings the products back to rank 0, which alone
+    holds the secret key and decrypts -- the ranks in between hold public material only (bench.py --scatter).
+There is no data-path collective during the multiplies: torch.distributed (backend "nccl" = RCCL over xGMI on
+the GPUs, "gloo" in the CPU tests) otherwise carries only the barrier around the timed region and the
+max-over-ranks of the elapsed time."""
 import os
 
 
@@ -85,6 +91,92 @@ class Group:
         out = t.cpu().numpy().view(np.uint64)
         return (np.ascontiguousarray(words, dtype=np.uint64) if self.rank == src else out), count * 8
 
+    # ---- the batch split: byte blobs (wire-format ciphertexts) from / to one rank, one device tensor per rank ----
+    def _dev(self):
+        return self.device if self.device is not None else "cpu"
+
+    def _lengths(self, mine, src_is_list, root):
+        """every rank learns the blob lengths: the root's list (scatter) or everybody's own (gather)"""
+        import torch
+        t = torch.zeros(self.world, dtype=torch.int64, device=self._dev())
+        if src_is_list:
+            if self.rank == root:
+                t = torch.tensor([int(x) for x in mine], dtype=torch.int64, device=self._dev())
+            self.dist.broadcast(t, src=root)
+        else:
+            t[self.rank] = int(mine)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [int(v) for v in t.cpu().tolist()]
+
+    def scatter_blobs(self, blobs, src=0, produce=None):
+        """Rank `src` hands every rank its blob (numpy uint8): `blobs` = a list of `world` arrays on `src` (ignored
+        elsewhere), or produce(r) -> array called on `src` rank by rank so that only one slice is in host memory at
+        a time.  Lengths first, then ONE tensor per destination by send / recv on the group's device -- RCCL
+        point-to-point over xGMI with backend "nccl", host memory with gloo.  Returns (this rank's blob, bytes that
+        crossed a rank boundary as seen by this rank)."""
+        import numpy as np
+        get = (lambda r: np.ascontiguousarray(blobs[r], dtype=np.uint8)) if produce is None else \
+              (lambda r: np.ascontiguousarray(produce(r), dtype=np.uint8))
+        if self.dist is None:
+            return get(0), 0
+        import torch
+        moved = 0
+        if self.rank == src:
+            mine = None
+            sizes = []
+            # (lengths are only known slice by slice when they are produced on demand: one small message each)
+            for r in range(self.world):
+                b = get(r)
+                if r == src:
+                    mine = b
+                    continue
+                n = torch.tensor([b.size], dtype=torch.int64, device=self._dev())
+                self.dist.send(n, dst=r)
+                t = torch.from_numpy(b).to(self._dev())
+                self.dist.send(t, dst=r)
+                moved += int(b.size)
+                sizes.append(b.size)
+                del t, b
+            return mine, moved
+        n = torch.zeros(1, dtype=torch.int64, device=self._dev())
+        self.dist.recv(n, src=src)
+        t = torch.empty(int(n.item()), dtype=torch.uint8, device=self._dev())
+        self.dist.recv(t, src=src)
+        return t.cpu().numpy(), int(n.item())
+
+    def gather_blobs(self, blob, dst=0, consume=None):
+        """The reverse: every rank's blob to rank `dst`.  Returns (list of `world` arrays on `dst` -- or, with
+        consume(r, array) given, None after each blob has been handed to it as it arrives --, bytes moved); (None,
+        bytes sent) on the other ranks."""
+        import numpy as np
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        if self.dist is None:
+            if consume is not None:
+                consume(0, blob)
+                return None, 0
+            return [blob], 0
+        import torch
+        sizes = self._lengths(blob.size, False, dst)
+        if self.rank != dst:
+            t = torch.from_numpy(blob).to(self._dev())
+            self.dist.send(t, dst=dst)
+            return None, int(blob.size)
+        out, moved = [], 0
+        for r in range(self.world):
+            if r == dst:
+                got = blob
+            else:
+                t = torch.empty(sizes[r], dtype=torch.uint8, device=self._dev())
+                self.dist.recv(t, src=r)
+                got = t.cpu().numpy()
+                moved += sizes[r]
+                del t
+            if consume is not None:
+                consume(r, got)
+            else:
+                out.append(got)
+        return (None if consume is not None else out), moved
+
     def min_over_ranks(self, value):
         if self.dist is None:
             return float(value)
@@ -104,7 +196,7 @@ class Group:
             self.dist = None
 
 
-def rccl_selfcheck(words, device, port=None):
+def rccl_selfcheck(words, device, port=None, ctxt_blob=None):
     """RCCL exercised from a single-rank run: a process group of world size 1 on backend "nccl" bound to `device`,
     then exactly the calls an N-rank run makes -- Group.broadcast_words of the session's real key export between
     device buffers, the all_reduce MAX / SUM of the timing line, a barrier -- and the group torn down again.  On a
@@ -147,12 +239,28 @@ def rccl_selfcheck(words, device, port=None):
         torch.cuda.synchronize()
         out["broadcast_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
         out["bytes"] = int(nbytes)
+        if ctxt_blob is not None:
+            # one scatter / gather of a REAL wire-format ciphertext through the same code an N-rank --scatter run uses.
+            # (In a world of one the root keeps its own slice, so nothing crosses a link: what runs is the length
+            # exchange -- an all_reduce on a device tensor -- and the blob's trip through device memory, below.)
+            t0 = time.perf_counter()
+            blob = np.ascontiguousarray(ctxt_blob, dtype=np.uint8)
+            mine, _ = g.scatter_blobs([blob], src=0)
+            back, _ = g.gather_blobs(mine, dst=0)
+            sizes = g._lengths(blob.size, False, 0)
+            onto = torch.from_numpy(blob).to(device)
+            dist.broadcast(onto, src=0)                  # the blob itself through RCCL once, between device buffers
+            torch.cuda.synchronize()
+            out["ctxt_blob_bytes"] = int(blob.size)
+            out["ctxt_blob_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+            out["ctxt_blob_ok"] = bool(np.array_equal(back[0], blob) and sizes == [blob.size]
+                                       and np.array_equal(onto.cpu().numpy(), blob))
         mx = g.max_over_ranks(1.25)
         sm = g.sum_over_ranks(3.0)
         g.barrier()
         out["world_size_seen"] = g.world_size_seen()
         out["ok"] = bool(nbytes == words.nbytes and np.array_equal(got, words) and mx == 1.25 and sm == 3.0
-                         and out["world_size_seen"] == 1)
+                         and out["world_size_seen"] == 1 and out.get("ctxt_blob_ok", True))
     except Exception as e:       # (a missing RCCL, a refused communicator: reported, not fatal)
         out["ok"] = False
         out["error"] = f"{type(e).__name__}: {str(e)[:300]}"

@@ -39,6 +39,11 @@ def lib(path=None):
             "hxh_ctxt_rows": [vp, ip, ip, ip, vp, vp, ip, vp],
             "hxh_relin_matrix": [vp, vp, vp, vp, ip, vp, vp], "hxh_arena_stats": [vp, vp],
             "hxh_encrypt_decrypt_batch": [vp, ip, ip, vp],
+            "hxh_session_create_source": [vp, ip, vp, ip, lg, lg, lg, lg, ip, C.c_uint64],
+            "hxh_export_public_keys": [vp, vp, C.c_size_t, vp],
+            "hxh_export_ctxts": [vp, ip, ip, ip, ip, vp, C.c_size_t, vp],
+            "hxh_session_create_from_ctxts": [vp, ip, vp, ip, lg, lg, lg, lg, ip, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t],
+            "hxh_decrypt_wire": [vp, vp, C.c_size_t, vp, vp, vp],
         }
         for name, args in sig.items():
             f = getattr(L, name)
@@ -51,7 +56,8 @@ def lib(path=None):
 SYMBOLS = ["hxh_session_create", "hxh_session_destroy", "hxh_session_info", "hxh_multiply", "hxh_multiply_single",
            "hxh_plaintext", "hxh_decrypt", "hxh_result_primes", "hxh_last_error", "hxh_export_keys",
            "hxh_session_create_with_keys", "hxh_chain_primes", "hxh_ctxt_info", "hxh_ctxt_rows", "hxh_relin_matrix",
-           "hxh_arena_stats", "hxh_encrypt_decrypt_batch"]
+           "hxh_arena_stats", "hxh_encrypt_decrypt_batch", "hxh_session_create_source", "hxh_export_public_keys",
+           "hxh_export_ctxts", "hxh_session_create_from_ctxts", "hxh_decrypt_wire"]
 
 
 def ckks_correlation(got, want):
@@ -66,15 +72,29 @@ class Session:
     or "ckks" (ContextBuilder<CKKS>().m(m).precision(r).bits(bits)), a key pair with its relinearisation
     matrix and `batch` pairs of fresh encryptions of seeded random plaintexts."""
 
-    def __init__(self, scheme, m, p, r, bits, batch, device=0, stream=0, seed=7, lib_path=None, keys=None):
+    def __init__(self, scheme, m, p, r, bits, batch, device=0, stream=0, seed=7, lib_path=None, keys=None, source=False,
+                 operands=None):
         """keys: key material exported by another session of the same parameters (export_keys(): a numpy uint64
         array, e.g. as received from rank 0) -- the session then holds THAT key pair and `seed` drives only its own
-        encryptions and plaintexts; None: the session generates its own key pair from `seed` (0 = OS entropy)."""
+        encryptions and plaintexts; None: the session generates its own key pair from `seed` (0 = OS entropy).
+        source=True: a session that only HOLDS its `batch` pairs (the rank that scatters them; no arena reservation
+        for a multiply loop).  operands=(a, b): two blobs of `batch` wire ciphertexts each (export_ctxts of another
+        session) -- a WORKER: with keys = public material it multiplies what it was handed and cannot decrypt."""
         self.L = lib(lib_path)
         self.scheme = scheme
         self.h = C.c_void_p()
         sc = 1 if scheme == "ckks" else 0
-        if keys is None:
+        if operands is not None:
+            if keys is None:
+                raise HostError("a worker session needs key material (export_public_keys of the source)")
+            keys = np.ascontiguousarray(keys, dtype=np.uint64)
+            a, b = (np.ascontiguousarray(x, dtype=np.uint8) for x in operands)
+            self._chk(self.L.hxh_session_create_from_ctxts(C.byref(self.h), device, C.c_void_p(stream), sc, m, p, r, bits, batch,
+                                                           keys.ctypes.data_as(C.c_void_p), keys.size,
+                                                           a.ctypes.data_as(C.c_void_p), a.size, b.ctypes.data_as(C.c_void_p), b.size))
+        elif source:
+            self._chk(self.L.hxh_session_create_source(C.byref(self.h), device, C.c_void_p(stream), sc, m, p, r, bits, batch, seed))
+        elif keys is None:
             self._chk(self.L.hxh_session_create(C.byref(self.h), device, C.c_void_p(stream), sc, m, p, r, bits, batch, seed))
         else:
             keys = np.ascontiguousarray(keys, dtype=np.uint64)
@@ -133,6 +153,47 @@ class Session:
         out = np.empty(need.value, dtype=np.uint64)
         self._chk(self.L.hxh_export_keys(self.h, out.ctypes.data_as(C.c_void_p), out.size, None))
         return out
+
+    def export_public_keys(self):
+        """the same without the secret polynomial (SecKey::exportKeys(false)): what a worker needs"""
+        need = C.c_size_t()
+        self._chk(self.L.hxh_export_public_keys(self.h, None, 0, C.byref(need)))
+        out = np.empty(need.value, dtype=np.uint64)
+        self._chk(self.L.hxh_export_public_keys(self.h, out.ctypes.data_as(C.c_void_p), out.size, None))
+        return out
+
+    def export_ctxts(self, level, which=0, first=0, count=None):
+        """batch elements [first, first + count) of fresh operand `which` (level 0) or of the kept product of level
+        1 / 2, each in the reference's binary ciphertext format (Ctxt::writeTo, src/Ctxt.cpp:2584-2611), concatenated:
+        a numpy uint8 array"""
+        count = self.batch - first if count is None else count
+        need = C.c_size_t()
+        self._chk(self.L.hxh_export_ctxts(self.h, level, which, first, count, None, 0, C.byref(need)))
+        out = np.empty(need.value, dtype=np.uint8)
+        self._chk(self.L.hxh_export_ctxts(self.h, level, which, first, count, out.ctypes.data_as(C.c_void_p), out.size, None))
+        return out
+
+    def decrypt_wire(self, blob, offset=0):
+        """ONE wire ciphertext at blob[offset:] under this session's secret key -> (values, bound, bytes consumed)"""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        out = np.empty(self.phim, dtype=np.float64)
+        bound, used = C.c_double(), C.c_size_t()
+        self._chk(self.L.hxh_decrypt_wire(self.h, C.c_void_p(blob.ctypes.data + offset), blob.size - offset,
+                                          out.ctypes.data_as(C.c_void_p), C.byref(bound), C.byref(used)))
+        return out, bound.value, int(used.value)
+
+    def verify_blob(self, blob, level, first, count):
+        """decrypt(each of the `count` products of a blob) == the plaintext product of THIS session's elements
+        first .. first + count - 1 (the session that encrypted the operands and holds the secret key: rank 0 of a
+        scatter / gather).  Returns the number checked; raises HostError on a mismatch or on trailing bytes."""
+        off = 0
+        for b in range(first, first + count):
+            got, bound, used = self.decrypt_wire(blob, off)
+            off += used
+            self._check_one(level, b, got, bound)
+        if off != len(blob):
+            raise HostError(f"verify_blob: {len(blob) - off} trailing bytes after {count} ciphertexts")
+        return count
 
     def chain_primes(self):
         n = C.c_int()
@@ -254,25 +315,28 @@ class Session:
         todo = range(self.batch) if elements is None else elements
         for b in todo:
             got, bound = self.decrypt(level, b)
-            want = self.expected(level, b)
-            if self.scheme == "ckks":
-                # precision(r) promises 2^-r.  From 10 bits on the product must be right to 1e-3 of its size.  At the
-                # reference's benchmark setting precision(1) the reported bound (O(1)) exceeds the product's own
-                # coefficients (~1e-4): "within the bound" alone would accept an all-zero or a foreign product.  The
-                # signal is still there, in all N coefficients at once: the normalised correlation of the decoded
-                # product with the expected one is 1/sqrt(1 + noise^2/signal^2), while a product of other operands (or
-                # zeros) correlates like N(0, 1/N) -- it must clear 8 standard deviations of that.
-                err = float(np.max(np.abs(got - want)))
-                ok = err <= bound
-                if ok and self.r >= 10:
-                    ok = err < 1e-3 * float(np.max(np.abs(want)))
-                elif ok:
-                    corr = ckks_correlation(got, want)
-                    self.min_ckks_correlation = min(getattr(self, "min_ckks_correlation", 1.0), corr)
-                    ok = corr >= 8.0 / np.sqrt(len(want))
-                if not ok:
-                    raise HostError(f"CKKS level {level} element {b}: decode error {err} (bound {bound})"
-                                    + (f", correlation with the expected product {ckks_correlation(got, want):.4f}" if self.r < 10 else ""))
-            elif not np.array_equal(got.astype(np.int64).astype(object), np.asarray(want).astype(object)):
-                raise HostError(f"decrypt(multiplyBy(a, b)) != a*b at level {level}, batch element {b}")
+            self._check_one(level, b, got, bound)
         return len(todo)
+
+    def _check_one(self, level, b, got, bound):
+        want = self.expected(level, b)
+        if self.scheme == "ckks":
+            # precision(r) promises 2^-r.  From 10 bits on the product must be right to 1e-3 of its size.  At the
+            # reference's benchmark setting precision(1) the reported bound (O(1)) exceeds the product's own
+            # coefficients (~1e-4): "within the bound" alone would accept an all-zero or a foreign product.  The
+            # signal is still there, in all N coefficients at once: the normalised correlation of the decoded
+            # product with the expected one is 1/sqrt(1 + noise^2/signal^2), while a product of other operands (or
+            # zeros) correlates like N(0, 1/N) -- it must clear 8 standard deviations of that.
+            err = float(np.max(np.abs(got - want)))
+            ok = err <= bound
+            if ok and self.r >= 10:
+                ok = err < 1e-3 * float(np.max(np.abs(want)))
+            elif ok:
+                corr = ckks_correlation(got, want)
+                self.min_ckks_correlation = min(getattr(self, "min_ckks_correlation", 1.0), corr)
+                ok = corr >= 8.0 / np.sqrt(len(want))
+            if not ok:
+                raise HostError(f"CKKS level {level} element {b}: decode error {err} (bound {bound})"
+                                + (f", correlation with the expected product {ckks_correlation(got, want):.4f}" if self.r < 10 else ""))
+        elif not np.array_equal(got.astype(np.int64).astype(object), np.asarray(want).astype(object)):
+            raise HostError(f"decrypt(multiplyBy(a, b)) != a*b at level {level}, batch element {b}")

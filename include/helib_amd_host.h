@@ -67,6 +67,29 @@ int hxh_export_keys(hxh_session* s, uint64_t* out, size_t cap_words, size_t* nee
 int hxh_session_create_with_keys(hxh_session** out, int device, void* stream, int scheme, long m, long p, long r,
                                  long bits, int batch, uint64_t enc_seed, const uint64_t* keys, size_t key_words);
 
+/* ---- ciphertexts across processes (SURVEY 2.3 row C1 "batch scatter/gather", 8e): the service shape of BASELINE
+ * configs[3] -- the ciphertext pairs arrive at one place, the products leave from one place, the GPUs in between hold
+ * PUBLIC key material only.  A ciphertext crosses a process boundary in the reference's own binary format
+ * (Ctxt::writeTo / Ctxt::read, src/Ctxt.cpp:2584-2641; include/helib_amd_wire.hpp).
+ *   hxh_session_create_source   a session that only HOLDS `batch` pairs (keys, plaintexts, encryptions; no arena
+ *                               reservation for a multiply loop): rank 0 of a scatter
+ *   hxh_export_public_keys      the key material without the secret polynomial (SecKey::exportKeys(false))
+ *   hxh_export_ctxts            batch elements [first, first + count) of operand `which` (level 0) or of the kept product
+ *                               (level 1 / 2), one Ctxt::writeTo blob after the other (size query with out = NULL)
+ *   hxh_session_create_from_ctxts  a worker: public keys + two blobs of `batch` ciphertexts as its operands; it
+ *                               multiplies, it cannot decrypt (hxh_decrypt / hxh_plaintext fail on it)
+ *   hxh_decrypt_wire            ONE ciphertext of a blob under this session's secret key (BGV residues / CKKS decoded
+ *                               reals as hxh_decrypt); *used = bytes consumed ---- */
+int hxh_session_create_source(hxh_session** out, int device, void* stream, int scheme, long m, long p, long r, long bits,
+                              int batch, uint64_t seed);
+int hxh_export_public_keys(hxh_session* s, uint64_t* out, size_t cap_words, size_t* need_words);
+int hxh_export_ctxts(hxh_session* s, int level, int which, int first, int count, uint8_t* out, size_t cap_bytes,
+                     size_t* need_bytes);
+int hxh_session_create_from_ctxts(hxh_session** out, int device, void* stream, int scheme, long m, long p, long r, long bits,
+                                  int batch, const uint64_t* keys, size_t key_words, const uint8_t* a, size_t a_bytes,
+                                  const uint8_t* b, size_t b_bytes);
+int hxh_decrypt_wire(hxh_session* s, const uint8_t* blob, size_t bytes, double* out, double* bound, size_t* used);
+
 /* ---- what a checker needs of a session: the chain, the ciphertexts' rows and bookkeeping, the matrix ---- */
 /* the chain's primes in Context::moduli order (small, ctxt, special) */
 int hxh_chain_primes(const hxh_session* s, uint64_t* out, int cap, int* n);

@@ -135,3 +135,23 @@ def test_launcher_keeps_a_log_per_rank(tmp_path):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["process_group_world_size"] == 2
     assert (tmp_path / "rank1.log").exists()
+
+
+def test_launcher_watchdog_stops_the_other_ranks_when_one_dies():
+    """A rank > 0 that dies during setup used to leave rank 0 inside its first collective until the backend's own
+    timeout (ten minutes of an 8-GPU lease with RCCL; half an hour with gloo): launch_ranks waited on rank 0 first.
+    The launcher now polls every rank, ends the others when the first one fails and prints that rank's log."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HX_TEST_FAIL_RANK"] = "1"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "2"],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode != 0
+    assert time.time() - t0 < 120
+    assert "rank 1 failed first" in out.stderr and "rank dies during setup" in out.stderr, out.stderr[-2000:]
+    # ... and rank 0 failing is reported as rank 0's failure
+    env["HX_TEST_FAIL_RANK"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "2"],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode != 0 and "rank 0 failed first" in out.stderr

@@ -13,6 +13,7 @@
 #   trace            rocprofv3 --kernel-trace over the driver's command -> bench_kernel_trace.txt + bench_traced.json
 #   pmc              three separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU) -> pmc_summary.txt
 #   pmc_sq           two more --pmc passes: SQ VALU activity + GRBM_GUI_ACTIVE (clock), LDS bank conflicts -> pmc_sq_summary.txt
+#   scatter          bench.py --scatter at N = 1, and at two ranks on one device (gloo)
 #   bluestein        tools/prof_bluestein.py Good-Thomas x Rader (default), fused Bluestein (HX_NO_PFA) and old chain + kernel trace of the default
 #   levels           tools/prof_levels.py for both schemes
 #   ab:A,B,...       same-box A/B of the fresh multiply, two rounds; A = default | env:VAR=1 | a variant
@@ -90,6 +91,23 @@ except Exception as e:
     print('ranks2: no line', e)
 PY
       tail -3 $out/bench_ranks2.err ;;
+    scatter)
+      # the batch split as a service on this 1-GPU box: (a) one rank, source + worker session on the device;
+      # (b) two ranks on GPU 0 over gloo: slices scattered, products gathered, rank 0 alone verifies
+      timeout 600 python bench.py --scatter --steps 4 --warmup 1 --mults-per-step 8 --no-extras --cpu-sample 0 \
+         > $out/bench_scatter1.json 2> $out/bench_scatter1.err; echo "scatter1 rc=$?"
+      timeout 900 python bench.py --gpus 2 --one-device --scatter --workload ckks65536 --batch 16 --steps 3 --warmup 1 --mults-per-step 8 --no-extras --cpu-sample 0 \
+         > $out/bench_scatter2.json 2> $out/bench_scatter2.err; echo "scatter2 rc=$?"
+      python - $out/bench_scatter1.json $out/bench_scatter2.json <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        d = json.loads([ln for ln in open(f) if ln.startswith('{')][-1]); c = d['config']
+        print(f.split('/')[-1], 'value', d['value'], 'n_gpus', d['n_gpus'], 'split', json.dumps(c.get('batch_split'))[:600], c.get('verified'))
+    except Exception as e:
+        print(f, 'no line', e)
+PY
+      tail -n 3 $out/bench_scatter1.err; tail -n 3 $out/bench_scatter2.err ;;
     bench6400)
       # the reference's own BGV parameter (benchmarks/bgv_basic.cpp:247): bits=6400 -> L=107, K=36, D=3
       timeout 900 python bench.py --bits 6400 --batch 16 --steps 4 --warmup 1 --mults-per-step 4 --no-extras --cpu-sample 0 \
