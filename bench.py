@@ -696,7 +696,7 @@ def run_session(sess, level, steps, warmup, R, sync, barrier, measure):
     return time.perf_counter() - t0, host
 
 
-def levels_leg(hh, sparams, batch, R, device, stream, sync, warm_steps=2, steps=5, elements=None, seed=17):
+def levels_leg(hh, sparams, batch, R, device, stream, sync, warm_steps=2, steps=5, elements=None, seed=17, hx=None):
     """A second workload through the same C++ host: level 1 (fresh x fresh) and level 2 (product x product) of
     `sparams` = (scheme, m, p, r, bits), `steps` x R multiplies of a `batch`-pair batch each after `warm_steps` full
     steps (plans, arena chunks and clocks settle there; the session reserved its working set at creation), noise
@@ -716,8 +716,22 @@ def levels_leg(hh, sparams, batch, R, device, stream, sync, warm_steps=2, steps=
         m0 = so.arena_stats()["hipMalloc_calls"]
         dt, _ = run_session(so, level, steps, 0, R, sync, lambda: None, True)
         mallocs += so.arena_stats()["hipMalloc_calls"] - m0
-        nv = so.verify(level, elements=elements if elements is not None else [0, so.batch - 1])
+        nv = so.verify(level, elements=elements)          # every batch element (16 .. 128 of them) unless told otherwise
         out[f"level{level}_mult_per_s"] = round(so.batch * R * steps / dt, 1)
+        if hx is not None:
+            # this leg's own whole-operation fraction of the 8 TB/s roofline: the compulsory bytes of the kernels that
+            # ran (kernel_table's algorithmic bytes per launch x launches per multiply) against the measured rate
+            try:
+                prof = in_situ_profile(hx, so, level, 2, sync, warm=4)
+                table, _ = kernel_table(prof, so.phim, so.batch, so.L_ctxt, so.K, so.D, 2)
+                fused = sum(r_["algorithmic_bytes_per_launch"] * r_["launches_per_multiply"] for r_ in table
+                            if "algorithmic_bytes_per_launch" in r_) / so.batch
+                share = sum(r_["share"] for r_ in table if "algorithmic_bytes_per_launch" in r_)
+                out[f"level{level}_fused_algorithmic_MB_per_mult"] = round(fused / 1e6, 2)
+                out[f"level{level}_value_over_fused_roofline"] = round(out[f"level{level}_mult_per_s"] / (HBM_PEAK_GBS * 1e9 / fused), 4)
+                out[f"level{level}_fused_bytes_cover_share_of_kernel_time"] = round(share, 3)
+            except Exception as e:       # (a leg whose kernels have no byte model: the rate stands alone)
+                out[f"level{level}_value_over_fused_roofline"] = f"unavailable: {type(e).__name__}: {str(e)[:120]}"
         out[f"level{level}_ms_per_mult_of_the_batch"] = round(dt / (steps * R) * 1e3, 4)
         out[f"level{level}_verified_elements"] = nv
         out[f"level{level}_result_primes"] = len(so.result_primes(level))
@@ -1422,8 +1436,12 @@ def main():
                         extra["hbm_traffic_GB_per_step_recorded"] = round(gb * R, 1)
                         extra["hbm_traffic_avg_TBps_over_the_step_recorded"] = round(gb * R / (dt / args.steps) / 1e3, 2)
                         extra["hbm_traffic_source"] = ("recorded, not measured in this run: profiles/r05_pmc_fresh_multiply_traffic.json "
-                                                       "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same command, THIS round's "
-                                                       "kernels; counted at the L2, so Infinity-Cache hits are included)")
+                                                       "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same command, round 5's "
+                                                       "kernels -- the multiply path is unchanged since; counted at the L2, so "
+                                                       "Infinity-Cache hits are included)")
+                        extra["traffic_whole_operation"] = {"GB_per_multiply_of_the_batch": gb, "MB_per_mult": round(gb * 1e3 / B, 2),
+                                                            "avg_TBps_over_the_step": extra["hbm_traffic_avg_TBps_over_the_step_recorded"],
+                                                            "source": "recorded (profiles/r05_pmc_fresh_multiply_traffic.json), not measured in this run"}
             roof = make_roofline(table, n, B, l, k, d, b2b)
             if extras:
                 sync()
@@ -1478,7 +1496,8 @@ def main():
                         continue
                     try:
                         small = name.startswith("bgv32003")     # (1 warm + 2 timed steps: a multiply takes milliseconds here)
-                        leg, so = levels_leg(hh, sp, bb, rr, local_rank, stream, sync, **(dict(warm_steps=1, steps=2) if small else {}))
+                        leg, so = levels_leg(hh, sp, bb, rr, local_rank, stream, sync, hx=hx,
+                                             **(dict(warm_steps=1, steps=2) if small else {}))
                         so.close()
                         del so
                         extra["levels_" + name] = leg
@@ -1556,14 +1575,24 @@ def main():
                "parallelism": (f"replica x{world}, batch-sharded under one key pair (broadcast once), no data-path collective"
                                + (" -- all ranks on ONE device (--one-device): functional run, not a scaling point" if args.one_device else "")),
                "algorithmic_MB_per_mult": round(per_mult / 1e6, 2),
-               "hbm_roofline_mult_per_s_per_gpu": round(HBM_PEAK_GBS * 1e9 / per_mult, 0),
+               # (NOT a roofline of this engine: the bytes the REFERENCE's unfused sequence would move, at 8 TB/s -- the fused
+               # kernels move fewer, so `value` may exceed it; the engine's own bound is roofline.fused_hbm_roofline_...)
+               "unfused_reference_equivalent_hbm_bound_mult_per_s_per_gpu": round(HBM_PEAK_GBS * 1e9 / per_mult, 0),
                "roofline_note": ("algorithmic_MB_per_mult counts the reference-equivalent unfused sequence with "
-                                 "per-multiply key rows (SURVEY 8d); value / hbm_roofline_mult_per_s_per_gpu is "
-                                 "therefore not an efficiency.  fused_algorithmic_MB_per_mult is the compulsory traffic of "
-                                 "the kernels that actually ran (sum of their algorithmic bytes) and value_over_fused_roofline "
-                                 "the whole-operation fraction of the 8 TB/s roofline; the per-kernel fractions are under "
-                                 "`roofline` and `config.kernels_in_situ`")}
+                                 "per-multiply key rows (SURVEY 8d): a description of the reference's traffic, not a bound on "
+                                 "this engine.  roofline.fused_algorithmic_MB_per_mult is the compulsory traffic of the kernels "
+                                 "that actually ran (sum of their algorithmic bytes), roofline.value_over_fused_roofline the "
+                                 "whole-operation fraction of the 8 TB/s roofline, roofline.whole_operation_traffic the bytes the "
+                                 "counters saw; the per-kernel fractions are under `roofline` and `config.kernels_in_situ`")}
         cfg.update(extra)
+        if isinstance(roof, dict):
+            # the whole operation next to its dominant kernel, at the top level of the line
+            for kk in ("fused_algorithmic_MB_per_mult", "fused_hbm_roofline_mult_per_s_per_gpu", "value_over_fused_roofline",
+                       "fused_bytes_cover_share_of_kernel_time"):
+                if kk in extra:
+                    roof[kk] = extra[kk]
+            if "traffic_whole_operation" in extra:
+                roof["whole_operation_traffic"] = extra["traffic_whole_operation"]
         line = {"metric": "ctxt_x_ctxt_mults_per_sec_incl_relinearize",
                 "value": round(pairs_all * R * args.steps / dt, 1), "unit": "mult/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),

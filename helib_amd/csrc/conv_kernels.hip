@@ -236,9 +236,9 @@ static hipError_t launch_conv(const ConvRowArgs& A, const ConvRows& R, int nunit
                               const TW* tw_arena, hipStream_t st)
 {
   constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
-  static bool attr_set = false;
+  bool attr_set = false;   // (hxp::dyn_lds is idempotent per device)
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ntt_conv_kernel<LOGN, SRC, DST>,
+    hipError_t e = hxp::dyn_lds((const void*)ntt_conv_kernel<LOGN, SRC, DST>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
       return e;

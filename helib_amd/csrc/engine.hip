@@ -2722,6 +2722,16 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     for (int t = 0; t < nt && ok16; t++)
       ok16 = (tq(t) >> 32) != 0 && hxh::bitlen(tq(t)) <= 60;
     pl->dev.fast16_ok = ok16 ? 1u : 0u;
+    {
+      // lazy output is read at the Proth rows' tight bounds: legal only when the kernel that wrote a Proth-form
+      // target row took its Montgomery branch (tgt_mont) -- derived here from the plan's own flags, not from the
+      // environment switches the call sites used to consult
+      bool lz = hxh::bitlen(max_src) <= 60;
+      for (int t = 0; t < nt && lz; t++)
+        if (!c->sw.no_proth && hx::is_proth32(tq(t)) && !tgt_mont(t))
+          lz = false;
+      pl->dev.lazy_tight_ok = lz ? 1u : 0u;
+    }
     pl->dev.hps_ok = (hps_ok && ok16) ? 1u : 0u;   // (the front end lives in the fast kernels only)
     bool okw = wide_cand && hps_ok && (min_src >> 32) != 0 && hxh::bitlen(max_src) <= 60;
     for (int t = 0; t < nt && okw; t++)
@@ -2814,7 +2824,7 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args_in, s
         for (const void* f : {(const void*)hx::rns_extend_wide_kernel<20>, (const void*)hx::rns_extend_wide_kernel<24>,
                               (const void*)hx::rns_extend_wide_kernel<28>, (const void*)hx::rns_extend_wide_kernel<32>,
                               (const void*)hx::rns_extend_wide_kernel<36>, (const void*)hx::rns_extend_wide_kernel<40>})
-          HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          HIPCHK(hxp::dyn_lds(f, 160 * 1024));
         wide_attr.insert(c->device);
       }
     }
@@ -2958,12 +2968,10 @@ static int bnorm_setup(hx_ctx* c)
   HIPCHK(hipMemcpy(c->d_bn_v, v.data(), sizeof(double) * 2 * m, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->d_bn_w, w.data(), sizeof(double) * P, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_cv, cv.data(), sizeof(double) * 2 * P, hipMemcpyHostToDevice));
-  static bool attr = false;
+  bool attr = false;   // (hxp::dyn_lds is idempotent per device)
   if (!attr) {
-    HIPCHK(hipFuncSetAttribute((const void*)hx::bnorm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               16 << hx::NORM_MAX_LOGH));
-    HIPCHK(hipFuncSetAttribute((const void*)hx::bnorm_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               16 << hx::NORM_MAX_LOGH));
+    HIPCHK(hxp::dyn_lds((const void*)hx::bnorm_fwd_kernel, 16 << hx::NORM_MAX_LOGH));
+    HIPCHK(hxp::dyn_lds((const void*)hx::bnorm_inv_kernel, 16 << hx::NORM_MAX_LOGH));
     attr = true;
   }
   const int logp = bk, logh = std::min(logp, hx::NORM_MAX_LOGH);
@@ -3107,16 +3115,14 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
   unsigned long long* const out2 = direct ? np.pinned : c->d_norm2;
   if (!direct)
     HIPCHK(hipMemsetAsync(c->d_norm2, 0, sizeof(unsigned long long) * (size_t)rows, ns));
-  static bool attr = false;
+  bool attr = false;   // (hxp::dyn_lds is idempotent per device)
   if (!c->pow2) {
     CHK(flush_xs(c));
     CHK(embed_norms_general(c, d_f, rows, ns));
   } else if (!attr) {
-    HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_kernel,
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               16 << hx::NORM_MAX_LOGH));
+    HIPCHK(hxp::dyn_lds((const void*)hx::embed_norm_kernel, 16 << hx::NORM_MAX_LOGH));
 #define HX_NORM_ATTR(...)                                                                               \
-  HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_kernel<__VA_ARGS__>,                   \
+  HIPCHK(hxp::dyn_lds((const void*)hx::embed_norm_quarter_kernel<__VA_ARGS__>,                   \
                              hipFuncAttributeMaxDynamicSharedMemorySize, 16 << hx::NORM_MAX_LOGH))
     HX_NORM_ATTR(hx::NormSrcF64, 0);
     HX_NORM_ATTR(hx::NormSrcF64, 13);
@@ -3125,9 +3131,7 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     HX_NORM_ATTR(hx::NormSrcXS, 13);
     HX_NORM_ATTR(hx::NormSrcXS, 14);
 #undef HX_NORM_ATTR
-    HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_quarter_split_kernel,
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               16 << hx::NORM_MAX_LOGH));
+    HIPCHK(hxp::dyn_lds((const void*)hx::embed_norm_quarter_split_kernel, 16 << hx::NORM_MAX_LOGH));
     attr = true;
   }
   if (!c->pow2) {
@@ -3155,12 +3159,10 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     const bool r16 = !c->sw.norm_old;
     constexpr size_t r16_lds = (size_t)hx::R16_LDS_DOUBLES * sizeof(double);   // one array: two workgroups per CU
     if (r16 && logn == 14) {
-      static bool attr16 = false;
+      bool attr16 = false;   // (hxp::dyn_lds is idempotent per device)
       if (!attr16) {
-        HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_r16_kernel<hx::NormSrcXS>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds));
-        HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_r16_kernel<hx::NormSrcF64>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)r16_lds));
+        HIPCHK(hxp::dyn_lds((const void*)hx::embed_norm_r16_kernel<hx::NormSrcXS>, (int)r16_lds));
+        HIPCHK(hxp::dyn_lds((const void*)hx::embed_norm_r16_kernel<hx::NormSrcF64>, (int)r16_lds));
         attr16 = true;
       }
     }
@@ -3199,10 +3201,9 @@ static int embed_norms(hx_ctx* c, const double* d_f, int rows, double* out_host)
     if (x2) {
       // both sub-transforms at once in one 1024-thread workgroup (norm_r16.h: r16x2), nothing parked
       constexpr size_t x2_lds = 2 * (size_t)hx::R16_LDS_DOUBLES * sizeof(double);
-      static bool attrx2 = false;
+      bool attrx2 = false;   // (hxp::dyn_lds is idempotent per device)
       if (!attrx2) {
-        HIPCHK(hipFuncSetAttribute((const void*)hx::embed_norm_r16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)x2_lds));
+        HIPCHK(hxp::dyn_lds((const void*)hx::embed_norm_r16x2_kernel, (int)x2_lds));
         attrx2 = true;
       }
       HX_LAUNCH(hx::embed_norm_r16x2_kernel, dim3((unsigned)rows), dim3(2 * hx::R16_THREADS), x2_lds, ns, d_f, c->d_wtab,
@@ -3604,7 +3605,7 @@ static int scale_down_multi_fused(hx_poly** ps, int np, const std::vector<int>& 
       args.dst_row[t] = (uint16_t)t;
     // scratch[1] is read by step 3 only, whose row loads are declared with LOAD_BOUND 8 -- 4 on rows of Proth-form
     // primes, which is what the fast kernel's Proth-form target sums deliver (as digits_lazy_ok)
-    args.lazy_out = (c->sw.no_proth_rns && !c->sw.no_proth) ? 0 : 1;
+    args.lazy_out = pl->dev.lazy_tight_ok ? 1 : 0;   // (per plan: every Proth-form target on its Montgomery branch)
     if (c->want_frac) {
       args.frac = frac_take(c, rw);
       if (!args.frac)
@@ -4321,45 +4322,57 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
   for (int d = 0; d < ndig; d++)
     fast = fast && A.plan[d].fast_ok;
   A.redo = nullptr;
+  for (int d = 0; d < ndig; d++)   // (lazy words only from plans whose Proth-form targets all take the Montgomery branch)
+    lazy_out = lazy_out && A.plan[d].lazy_tight_ok;
   if (fast) {
-    static bool attrf = false;
-    if (!attrf) {
+    const int lds_rows = std::max(1, L - hx::break_fast_n0(A));
+    // the private LDS column caps the resident waves at 160 KiB / (rows x 8 B x 64 lanes) per CU: from 12 rows on that
+    // is below the seven waves per SIMD the kernel's registers allow, and the form without the column -- a later
+    // digit's own rows rebuilt from the words the thread stored in its earlier passes -- runs instead (the CKKS
+    // chain: 16 rows, five waves; HX_BRK_NOLDS=0 / 1 forces either form: A/B)
+    const bool nolds = ndig <= hx::BRK_NOLDS_MAXD && (c->sw.brk_nolds >= 0 ? c->sw.brk_nolds != 0 : lds_rows >= 12);
+    if (!nolds)
       for (const void* f : {(const void*)hx::break_digits_fast_kernel<true, false>, (const void*)hx::break_digits_fast_kernel<false, false>,
                             (const void*)hx::break_digits_fast_kernel<true, true>, (const void*)hx::break_digits_fast_kernel<false, true>})
-        HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
-      attrf = true;
-    }
-    const size_t lds_fast = (size_t)std::max(1, L - hx::break_fast_n0(A)) * hx::BRK_THREADS * 8;
+        HIPCHK(hxp::dyn_lds(f, 64 * hx::BRK_THREADS * 8));
+    // (HX_BRK_LDS_PAD: unused rows on top, to measure what the kernel's occupancy is worth -- profiles/r06_ab_digit_kernel_occupancy)
+    const size_t lds_fast = nolds ? 0 : (size_t)(lds_rows + std::max(0, std::min(40, c->sw.brk_lds_pad_rows))) * hx::BRK_THREADS * 8;
     bool hps = rw < ((size_t)1 << 32);
     for (int d = 0; d < ndig; d++)
       hps = hps && A.plan[d].hps_ok && (int)A.plan[d].n >= hps_min_n(c);
+#define HX_BRK_LAUNCH(H, Z, G)                                                                                       \
+  do {                                                                                                               \
+    if (nolds)                                                                                                       \
+      HX_LAUNCH((hx::break_digits_fast_kernel<H, Z, true>), G, block, lds_fast, c->stream, A, rw);                   \
+    else                                                                                                             \
+      HX_LAUNCH((hx::break_digits_fast_kernel<H, Z, false>), G, block, lds_fast, c->stream, A, rw);                  \
+  } while (0)
     if (hps) {   // HPS form, then Garner over the coefficients it could not vouch for (rns_kernels.h: ExtRep)
       CHK(redo_prepare(c, rw, &A.redo));
       if (lazy_out) {
-        HX_LAUNCH((hx::break_digits_fast_kernel<true, true>), grid, block, lds_fast, c->stream, A, rw);
-        HX_LAUNCH((hx::break_digits_fast_kernel<false, true>), REDO_GRID, block, lds_fast, c->stream, A, rw);
+        HX_BRK_LAUNCH(true, true, grid);
+        HX_BRK_LAUNCH(false, true, REDO_GRID);
       } else {
-        HX_LAUNCH((hx::break_digits_fast_kernel<true, false>), grid, block, lds_fast, c->stream, A, rw);
-        HX_LAUNCH((hx::break_digits_fast_kernel<false, false>), REDO_GRID, block, lds_fast, c->stream, A, rw);
+        HX_BRK_LAUNCH(true, false, grid);
+        HX_BRK_LAUNCH(false, false, REDO_GRID);
       }
     } else if (lazy_out) {
-      HX_LAUNCH((hx::break_digits_fast_kernel<false, true>), grid, block, lds_fast, c->stream, A, rw);
+      HX_BRK_LAUNCH(false, true, grid);
     } else {
-      HX_LAUNCH((hx::break_digits_fast_kernel<false, false>), grid, block, lds_fast, c->stream, A, rw);
+      HX_BRK_LAUNCH(false, false, grid);
     }
+#undef HX_BRK_LAUNCH
   } else if (nmax <= 8) {
-    static bool attr8 = false;
+    bool attr8 = false;   // (hxp::dyn_lds is idempotent per device)
     if (!attr8) {
-      HIPCHK(hipFuncSetAttribute((const void*)hx::break_digits_kernel<8>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
+      HIPCHK(hxp::dyn_lds((const void*)hx::break_digits_kernel<8>, 64 * hx::BRK_THREADS * 8));
       attr8 = true;
     }
     HX_LAUNCH((hx::break_digits_kernel<8>), grid, block, lds, c->stream, A, rw);
   } else {
-    static bool attr16 = false;
+    bool attr16 = false;   // (hxp::dyn_lds is idempotent per device)
     if (!attr16) {
-      HIPCHK(hipFuncSetAttribute((const void*)hx::break_digits_kernel<16>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * hx::BRK_THREADS * 8));
+      HIPCHK(hxp::dyn_lds((const void*)hx::break_digits_kernel<16>, 64 * hx::BRK_THREADS * 8));
       attr16 = true;
     }
     HX_LAUNCH((hx::break_digits_kernel<16>), grid, block, lds, c->stream, A, rw);

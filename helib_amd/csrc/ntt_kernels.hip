@@ -943,10 +943,9 @@ static hipError_t launch_inv_mul(const uint64_t* a, const uint64_t* b, uint64_t*
                                  int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
 {
   constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
-  static bool attr_set = false;
+  bool attr_set = false;   // (hxp::dyn_lds is idempotent per device)
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ntt_inv_mul_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes);
+    hipError_t e = hxp::dyn_lds((const void*)ntt_inv_mul_kernel<LOGN>, (int)lds_bytes);
     if (e != hipSuccess)
       return e;
     attr_set = true;
@@ -972,9 +971,9 @@ static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& r
                              int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
 {
   static const size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
-  static bool attr_set = false;
+  bool attr_set = false;   // (hxp::dyn_lds is idempotent per device)
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ntt_row_kernel<LOGN, INV, LB>,
+    hipError_t e = hxp::dyn_lds((const void*)ntt_row_kernel<LOGN, INV, LB>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
       return e;
@@ -990,18 +989,16 @@ template <int LOGN>
 static hipError_t moddown_attrs()
 {
   constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
-  static bool attr_set = false;
+  bool attr_set = false;   // (hxp::dyn_lds is idempotent per device)
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ntt_moddown_prep_kernel<LOGN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hxp::dyn_lds((const void*)ntt_moddown_prep_kernel<LOGN>, (int)lds_bytes);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)ntt_moddown_prep_multi_kernel<LOGN>,
+      e = hxp::dyn_lds((const void*)ntt_moddown_prep_multi_kernel<LOGN>, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hxp::dyn_lds((const void*)ntt_moddown_apply_kernel<LOGN, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_kernel<LOGN, false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_kernel<LOGN, true>,
+      e = hxp::dyn_lds((const void*)ntt_moddown_apply_kernel<LOGN, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
       return e;
@@ -1061,18 +1058,16 @@ template <int LOGN>
 static hipError_t moddown_tensor_attrs()
 {
   constexpr size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
-  static bool attr_set = false;
+  bool attr_set = false;   // (hxp::dyn_lds is idempotent per device)
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ntt_moddown_prep_tensor_kernel<LOGN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hxp::dyn_lds((const void*)ntt_moddown_prep_tensor_kernel<LOGN>, (int)lds_bytes);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)ntt_moddown_prep_multi_tensor_kernel<LOGN>,
+      e = hxp::dyn_lds((const void*)ntt_moddown_prep_multi_tensor_kernel<LOGN>, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hxp::dyn_lds((const void*)ntt_moddown_apply_tensor_kernel<LOGN, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_tensor_kernel<LOGN, false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)ntt_moddown_apply_tensor_kernel<LOGN, true>,
+      e = hxp::dyn_lds((const void*)ntt_moddown_apply_tensor_kernel<LOGN, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess)
       return e;

@@ -63,8 +63,7 @@ static hipError_t launch_pfa(const uint64_t* in, uint64_t* out, const PfaRows& R
                              unsigned out_stride, hipStream_t st)
 {
   constexpr size_t lds_bytes = (size_t)pfa_lds_words(MODE) * 8;
-  hipError_t e = hipFuncSetAttribute((const void*)pfa_row_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds_bytes);
+  hipError_t e = hxp::dyn_lds((const void*)pfa_row_kernel<MODE>, (int)lds_bytes);
   if (e != hipSuccess)
     return e;
   HX_LAUNCH((pfa_row_kernel<MODE>), dim3((unsigned)nrows * (unsigned)batch), dim3(pfa::NT), lds_bytes, st, in, out, R, primes,

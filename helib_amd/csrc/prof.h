@@ -26,6 +26,29 @@
 
 namespace hxp {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: raise it once per (device, kernel),
+// under a lock -- a process-wide `static bool` (rounds 1-5) left a second context on another device with the default
+// 64 KiB limit (its first large-LDS launch failed) and let two contexts' threads race on the flag.
+inline hipError_t dyn_lds(const void* kern, int bytes)
+{
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> done;   // (device, kernel) -> bytes granted
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess)
+    return e;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = done.find({dev, kern});
+  if (it != done.end() && it->second >= bytes)
+    return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess)
+    done[{dev, kern}] = bytes;
+  return e;
+}
+// (the signature of hipFuncSetAttribute, for the call sites that were written against it)
+inline hipError_t dyn_lds(const void* kern, hipFuncAttribute, int bytes) { return dyn_lds(kern, bytes); }
+
 struct Rec {
   int name, device;
   unsigned wgs, wg_size;

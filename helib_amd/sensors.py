@@ -107,14 +107,18 @@ class Sampler:
         self._stop = threading.Event()
         self._thread = None
 
-    def _one(self):
+    def _one(self, allow_spawn=False):
         s = sample_sysfs(self.device, self.address)
         if s is not None:
             self.source = "amdgpu hwmon (freq1_input, power1_average), " + s.pop("picked", "")
             return s
+        # no hwmon files on this box: rocm-smi is a process and a driver query -- never from inside the timed loop
+        # (ADVICE r5); one sample as the window opens and one as it closes instead
+        if not allow_spawn:
+            return None
         s = sample_rocm_smi(self.device)
         if s is not None:
-            self.source = self.source or "rocm-smi --showclocks --showpower --json"
+            self.source = "rocm-smi --showclocks --showpower --json, ONE sample before and one after the timed region (no hwmon files here)"
         return s
 
     def _run(self):
@@ -127,6 +131,14 @@ class Sampler:
             self._stop.wait(self.period)
 
     def __enter__(self):
+        self._t0 = time.perf_counter()
+        self._spawned = sample_sysfs(self.device, self.address) is None
+        if self._spawned:                       # (before the timed loop starts)
+            s = self._one(allow_spawn=True)
+            if s is not None:
+                s["t"] = time.perf_counter()
+                self.samples.append(s)
+            return self
         self._thread = threading.Thread(target=self._run, daemon=True)
         self._thread.start()
         return self
@@ -135,6 +147,12 @@ class Sampler:
         self._stop.set()
         if self._thread is not None:
             self._thread.join(timeout=15)
+        self.window_s = time.perf_counter() - self._t0
+        if self._spawned:                       # (after it has ended)
+            s = self._one(allow_spawn=True)
+            if s is not None:
+                s["t"] = time.perf_counter()
+                self.samples.append(s)
         return False
 
     def summary(self):
@@ -147,7 +165,14 @@ class Sampler:
 
         def three(v):   # first, middle, last of the window
             return [v[0], v[len(v) // 2], v[-1]] if v else None
-        return {"clock_mhz_under_load": three(clk), "power_w": three(pw),
-                "clock_mhz_min_max": [min(clk), max(clk)] if clk else None,
-                "power_w_min_max": [min(pw), max(pw)] if pw else None,
-                "sensor_samples": len(body), "sensor_source": self.source}
+        out = {"clock_mhz_under_load": three(clk), "power_w": three(pw),
+               "clock_mhz_min_max": [min(clk), max(clk)] if clk else None,
+               "power_w_min_max": [min(pw), max(pw)] if pw else None,
+               "sensor_samples": len(body), "sensor_source": self.source,
+               "sensor_mode": "two samples around the timed region" if getattr(self, "_spawned", False) else "sampled every %.2f s inside it" % self.period}
+        # power1_average is the driver's own running average over about a second: in a window shorter than that it still
+        # shows the load BEFORE the window (a 0.3 s leg reported 379 W three times) -- not a figure of this window
+        if getattr(self, "window_s", 10.0) < 1.0 and not getattr(self, "_spawned", False):
+            out["power_w"] = out["power_w_min_max"] = None
+            out["power_note"] = "window of %.2f s: shorter than the sensor's averaging time, power not reported" % self.window_s
+        return out
