@@ -4326,11 +4326,13 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
     lazy_out = lazy_out && A.plan[d].lazy_tight_ok;
   if (fast) {
     const int lds_rows = std::max(1, L - hx::break_fast_n0(A));
-    // the private LDS column caps the resident waves at 160 KiB / (rows x 8 B x 64 lanes) per CU: from 12 rows on that
-    // is below the seven waves per SIMD the kernel's registers allow, and the form without the column -- a later
-    // digit's own rows rebuilt from the words the thread stored in its earlier passes -- runs instead (the CKKS
-    // chain: 16 rows, five waves; HX_BRK_NOLDS=0 / 1 forces either form: A/B)
-    const bool nolds = ndig <= hx::BRK_NOLDS_MAXD && (c->sw.brk_nolds >= 0 ? c->sw.brk_nolds != 0 : lds_rows >= 12);
+    // the private LDS column caps the resident waves at 160 KiB / (rows x 8 B x 64 lanes) per CU: 16 rows at the CKKS
+    // chain = five waves per SIMD where the registers allow seven, and the kernel is latency-shaped (the BGV launch
+    // forced to five waves ran 24 % slower).  The form without the column (HX_BRK_NOLDS=1: a later digit's own rows
+    // rebuilt from the words the thread stored in its earlier passes) is bit-exact and SLOWER -- 700 against 306 us at
+    // the BGV shape, 1010 against 610 at CKKS: the drained stores and the re-read words cost more than the waves give
+    // (profiles/r06_ab_digit_kernel_occupancy.json) -- so it stays a switch, off by default
+    const bool nolds = ndig <= hx::BRK_NOLDS_MAXD && c->sw.brk_nolds == 1;
     if (!nolds)
       for (const void* f : {(const void*)hx::break_digits_fast_kernel<true, false>, (const void*)hx::break_digits_fast_kernel<false, false>,
                             (const void*)hx::break_digits_fast_kernel<true, true>, (const void*)hx::break_digits_fast_kernel<false, true>})

@@ -996,7 +996,7 @@ __device__ __forceinline__ void redo_append(uint32_t* redo, size_t i)
 // NOLDS (round 6): no private LDS column at all.  A later digit's own row is rebuilt where it is consumed,
 //   u = (...((x_r - v_0) P_0^-1 - v_1) P_1^-1 ...),
 // from the source word and the extension words v_e of the earlier digits at that row -- which this same thread stored
-// in its earlier passes (an agent-scope release / acquire pair between the passes pins that order).  The fix-up
+// in its earlier passes (the stores are drained, s_waitcnt vmcnt(0), between the passes).  The fix-up
 // arithmetic moves from the target loop to the front end, word for word the same; what changes is the occupancy: the
 // column is (L - n0) x 8 bytes per thread -- 16 rows at the CKKS chain (L = 24, digits 8 / 8 / 8) = ten workgroups per CU,
 // FIVE waves per SIMD, and this kernel is latency-shaped (one scalar record per target): the BGV launch forced to five
@@ -1011,8 +1011,8 @@ struct BrkEarlier {
   ro_u64 pk0, pk1, pk2;    // target packs of digits 0, 1, 2
   int n0, n1, n2;          // their source counts
 };
-template <bool LAZY>
-__device__ __forceinline__ uint64_t break_rebuild_row(const BrkEarlier& E, int d, int r, size_t row_words);
+template <int N, bool LAZY>
+__device__ __forceinline__ void break_rebuild_rows(const BrkEarlier& E, int d, int off, size_t row_words, uint64_t (&u)[N]);
 
 template <int N, bool HPS, bool LAZY, bool NOLDS = false>
 __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* xs, unsigned tid, int off, int L,
@@ -1020,9 +1020,12 @@ __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* 
                                                  const uint64_t* src0, const BrkEarlier& E = BrkEarlier{}, int d = 0)
 {
   const bool from_global = off < n0;   // (uniform; a digit is either entirely below n0 or entirely above)
+  uint64_t own[NOLDS ? N : 1];
+  if constexpr (NOLDS)
+    break_rebuild_rows<N, LAZY>(E, d, off, row_words, own);
   auto load = [&](int k) -> uint64_t {   // [0,4 p_k): later digits' rows are updated lazily
     if constexpr (NOLDS)
-      return break_rebuild_row<LAZY>(E, d, off + k, row_words);
+      return own[k];
     else
       return from_global ? ld_stream1(src0 + (size_t)(off + k) * row_words) : xs[(off + k - n0) * BRK_THREADS + tid];
   };
@@ -1425,30 +1428,52 @@ rns_extend_wide_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
   }
 }
 
-template <bool LAZY>
-__device__ __forceinline__ uint64_t break_rebuild_row(const BrkEarlier& E, int d, int r, size_t row_words)
+// all N own rows of digit d at once: every word the fix-ups need is requested before the first is used (one word at a
+// time -- load, wait, multiply, next -- the kernel was nine times slower than with its LDS column: 1160 full waits)
+template <int N, bool LAZY>
+__device__ __forceinline__ void break_rebuild_rows(const BrkEarlier& E, int d, int off, size_t row_words, uint64_t (&u)[N])
 {
-  uint64_t u = ld_stream1(E.src_i + (size_t)r * row_words);   // canonical
+  uint64_t v0[N], v1[N], v2[N];
+#pragma unroll
+  for (int k = 0; k < N; k++)
+    u[k] = ld_stream1(E.src_i + (size_t)(off + k) * row_words);   // canonical
+  if (d > 0) {
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      v0[k] = E.dst_i[(size_t)(off + k) * row_words];              // stored by this thread in pass 0
+  }
+  if (d > 1) {
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      v1[k] = E.dst_i[E.digit_words + (size_t)(off + k) * row_words];
+  }
+  if (d > 2) {
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      v2[k] = E.dst_i[2 * E.digit_words + (size_t)(off + k) * row_words];
+  }
   for (int e = 0; e < d; e++) {
     // digit e's record of target row r (r lies beyond digit e's own rows: target index r - n_e), the update constants
     // the LDS form reads in its target loop: P_e^-1 mod q_r as a Shoup pair, or times 2^64 on a Proth-form target
     const int ne = e == 0 ? E.n0 : (e == 1 ? E.n1 : E.n2);
     ro_u64 pk = e == 0 ? E.pk0 : (e == 1 ? E.pk1 : E.pk2);
-    ro_u64 rec = pk + (size_t)(r - ne) * (size_t)(10 + 2 * ne);
-    const uint64_t q = rec[0];
-    const bool mont = ((uint32_t)rec[4] >> 10) & 1u;
-    const uint64_t v = E.dst_i[(size_t)e * E.digit_words + (size_t)r * row_words];   // stored by this thread in pass e
-    if (mont) {   // u < 4q, v < 2q: u + 2q - v in (0, 6q), the product below 2q
-      const QC qc = make_qc(q, 0);
-      u = mont_mul(u + qc.q2 - v, rec[8 + 2 * ne], qc);
-    } else {      // v < q (< 6q when LAZY): the offset keeps the difference positive; shoup4 takes any 64-bit value
-      TW t;
-      t.w = rec[5];
-      t.wp = rec[6];
-      u = shoup4(u + (LAZY ? q << 3 : q) - v, t, 0 - q);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      ro_u64 rec = pk + (size_t)(off + k - ne) * (size_t)(10 + 2 * ne);
+      const uint64_t q = rec[0];
+      const bool mont = ((uint32_t)rec[4] >> 10) & 1u;
+      const uint64_t v = e == 0 ? v0[k] : (e == 1 ? v1[k] : v2[k]);
+      if (mont) {   // u < 4q, v < 2q: u + 2q - v in (0, 6q), the product below 2q
+        const QC qc = make_qc(q, 0);
+        u[k] = mont_mul(u[k] + qc.q2 - v, rec[8 + 2 * ne], qc);
+      } else {      // v < q (< 6q when LAZY): the offset keeps the difference positive; shoup4 takes any 64-bit value
+        TW t;
+        t.w = rec[5];
+        t.wp = rec[6];
+        u[k] = shoup4(u[k] + (LAZY ? q << 3 : q) - v, t, 0 - q);
+      }
     }
   }
-  return u;
 }
 template <bool HPS, bool LAZY, bool NOLDS = false>
 __device__ __forceinline__ void break_digits_fast_one(const BreakArgs& A, size_t row_words, uint64_t* xs, unsigned tid, size_t i)
@@ -1473,10 +1498,12 @@ __device__ __forceinline__ void break_digits_fast_one(const BreakArgs& A, size_t
     bool ok;
     if constexpr (NOLDS) {
       if (d > 0) {
-        // this thread's stores of the earlier passes before its loads of them (same lane, through memory): stores
-        // drained, the CU's vector cache dropped -- twice per coefficient
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // this thread's stores of the earlier passes before its loads of them (same lane, same address, through
+        // memory): the stores are acknowledged by the L2 before the loads issue.  The lines were never loaded by this
+        // CU before (each 128-byte line of a dst row belongs to one wave), so the write-through vector cache holds no
+        // stale copy; an agent-scope release / acquire pair here also wrote the whole L2 back (buffer_wbl2), twice
+        // per wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
     switch (P.n) {
