@@ -1489,7 +1489,10 @@ def main():
                         "bgv32768_bits6400_reference_params": (("bgv", 32768, 65537, 1, 6400), 16, 4),
                         # the reference's general-m benchmark ring (benchmarks/bgv_basic.cpp:236 big_params): m = 32003 prime,
                         # p = 2, bits = 5800 -- every transform a Bluestein convolution
-                        "bgv32003_bits5800_reference_params": (("bgv", 32003, 2, 1, 5800), 8, 2)}
+                        "bgv32003_bits5800_reference_params": (("bgv", 32003, 2, 1, 5800), 8, 2),
+                        # BASELINE configs[4]'s ring end to end (tests/GTestBootstrapping.cpp:113: m = 21845 = 5 * 17 * 257, p = 2):
+                        # every transform of the multiply is the Good-Thomas x Rader kernel (round 6; Bluestein under HX_NO_PFA)
+                        "bgv21845_bits950_config5_ring": (("bgv", 21845, 2, 1, 950), 32, 4)}
                 mine = "ckks65536_bits%d" % args.bits if ckks else "bgv32768_bits%d" % args.bits
                 for name, (sp, bb, rr) in legs.items():
                     if name.startswith(mine):

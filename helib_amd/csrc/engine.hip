@@ -1357,6 +1357,20 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
 {
   const uint32_t phim = c->phim, m = (uint32_t)c->m;
   const uint32_t NB = 1u << c->bk, N1 = 1u << c->n1, N2 = 1u << c->n2;
+  {
+    // a list that mixes rows with and without the Good-Thomas x Rader tables (m = 21845: the 40-bit small primes of a
+    // chain are not of the Proth form) is served in two parts -- one such row used to send the whole launch, the 60-bit
+    // rows included, through Bluestein: 27 % of a multiply at m = 21845, bits = 950 (tools/prof_config5_ring.py)
+    std::vector<std::pair<int, int>> with, without;
+    for (auto& rp : rows) {
+      const bool has = rp.second >= 0 && rp.second < (int)c->blue.size() && c->blue[rp.second] && c->blue[rp.second]->d_pfa;
+      (has ? with : without).push_back(rp);
+    }
+    if (!with.empty() && !without.empty()) {
+      CHK(bluestein_rows(c, in, out, with, batch, inverse));
+      return bluestein_rows(c, in, out, without, batch, inverse);
+    }
+  }
   // chunk so that the convolution buffers stay below ~1 GiB each
   size_t per_row = (size_t)batch * NB * 8;
   int chunk = (int)std::max<size_t>(1, std::min<size_t>(MAX_ROWS / (c->bk > 18 ? 16 : (c->bk > 17 ? 8 : 4)), ((size_t)1 << 30) / per_row));

@@ -285,9 +285,78 @@ class Session:
         ai, ci = a.astype(np.int64), c.astype(np.int64)
         if level == 0:
             return ai
-        mul = self._negacyclic_mod if (self.m & (self.m - 1)) == 0 else self._mul_mod_phi_prime_m
+        if (self.m & (self.m - 1)) == 0:
+            mul = self._negacyclic_mod
+        elif self.phim == self.m - 1:
+            mul = self._mul_mod_phi_prime_m
+        else:
+            mul = self._mul_mod_phi_squarefree_m
         w = mul(ai, ci, P)
         return w if level == 1 else mul(w, w, P)
+
+    def _mul_mod_phi_squarefree_m(self, x, y, P):
+        """x * y mod (Phi_m, P) for an odd SQUAREFREE m (BASELINE config 5's ring, m = 21845 = 5 * 17 * 257): the product
+        folded modulo X^m - 1, then rem Phi_m by binomial passes -- Phi_m = prod_{d | m} (X^d - 1)^mu(m/d), multiplying by
+        1 - X^d is w_i -= w_(i-d), dividing the running sum of stride d (exact over the integers, here modulo P) -- the
+        same identity the inverse transform's fused tail uses on the device (helib_amd/csrc/pfa_core.h), in numpy."""
+        from itertools import combinations
+        m, n = self.m, self.phim
+        ps, r = [], m
+        f = 3
+        while f * f <= r:
+            if r % f == 0:
+                ps.append(f)
+                r //= f
+                if r % f == 0:
+                    raise NotImplementedError("Session.expected: m not squarefree")
+            f += 2
+        if r > 1:
+            ps.append(r)
+        if m % 2 == 0:
+            raise NotImplementedError("Session.expected: even general m")
+        num, den = [], []
+        for k in range(len(ps) + 1):
+            for sub in combinations(ps, k):
+                d = int(np.prod(sub)) if sub else 1
+                (num if (len(ps) - k) % 2 == 0 else den).append(d)
+        num = [d for d in num if d != m]
+        from scipy.signal import fftconvolve
+        x, y = np.asarray(x, dtype=np.int64), np.asarray(y, dtype=np.int64)
+        if P < (1 << 10):
+            full = np.rint(fftconvolve(x.astype(np.float64), y.astype(np.float64))).astype(np.int64)   # exact: sums < 2^35
+        else:
+            full = np.array([int(v) for v in np.convolve(x.astype(object), y.astype(object))], dtype=object)
+        X = np.zeros(m, dtype=np.int64)
+        X[:min(len(full), m)] += np.asarray(full[:m] % P, dtype=np.int64)
+        if len(full) > m:
+            X[:len(full) - m] += np.asarray(full[m:] % P, dtype=np.int64)
+        X %= P
+        dq = m - 1 - n
+
+        def times(w, d):          # w (1 - t^d)
+            out = w.copy()
+            out[d:] -= w[:-d]
+            return out % P
+
+        def over(w, d):           # w / (1 - t^d): running sums along the d chains
+            L = len(w)
+            pad = (-L) % d
+            v = np.concatenate([w, np.zeros(pad, dtype=np.int64)]).reshape(-1, d)
+            return (np.cumsum(v % P, axis=0) % P).reshape(-1)[:L]
+        w = X[::-1][:dq + 1].copy()
+        for d in den:
+            if d <= dq:
+                w = times(w, d)
+        for d in num:
+            if d <= dq:
+                w = over(w, d)
+        W = np.zeros(n, dtype=np.int64)
+        W[:dq + 1] = w[::-1]
+        for d in num:
+            W = times(W, d)
+        for d in den:
+            W = over(W, d)
+        return (X[:n] - W) % P
 
     def _mul_mod_phi_prime_m(self, x, y, P):
         """x * y mod (Phi_m, P) for a PRIME m (Phi_m = 1 + X + ... + X^(m-1); the reference's general-m benchmark
