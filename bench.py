@@ -869,7 +869,7 @@ def config5_leg(hx, iters=5, batch=32):
     prof = hx.profileEnd()
     tot = sum(kk["total_us"] for kk in prof["kernels"]) or 1.0
     names = " ".join(kk["kernel"] for kk in prof["kernels"])
-    out["method"] = ("Good-Thomas x Rader (5 x 17 x 257), rem Phi_m as binomial passes in the same launch" if "pfa_row_kernel<2>" in names
+    out["method"] = ("Good-Thomas x Rader (5 x 17 x 257), rem Phi_m as binomial passes in the same launch" if "pfa_row_kernel<2," in names
                      else "Good-Thomas x Rader, rem Phi_m on the convolution kernels" if "pfa_row_kernel" in names
                      else "Bluestein (chirp convolution)")
     out["kernels_in_situ_fwd_plus_inv"] = [{"kernel": kk["kernel"].replace("hx::", ""), "workgroups": kk["workgroups"],

@@ -1334,9 +1334,11 @@ static int blue_prime_create(hx_ctx* c, int idx)
     }
     CHK(make_hat(c, idx, 3, 4, folded));
   }
-  // m = 5 * 17 * 257 on a Proth-form prime: the transform itself runs as Good-Thomas x Rader (pfa_core.h), ONE launch
-  // per direction; the tables above stay for rem Phi_m (and for HX_NO_PFA / any other prime)
-  if (!bp->aux && !c->sw.no_pfa && !c->sw.no_proth && hx::pfa::host::supported(m, q)) {
+  // m = 5 * 17 * 257 on a prime with the 256-th roots of unity: the transform itself runs as Good-Thomas x Rader
+  // (pfa_core.h), ONE launch per direction -- the Proth-form Montgomery product on rows of such primes, the generic
+  // one on the others (the 40-bit small primes of a chain; every row under HX_NO_PROTH); the tables above stay for
+  // HX_NO_PFA / HX_PFA_NO_REM
+  if (!bp->aux && !c->sw.no_pfa && hx::pfa::host::supported(m, q)) {
     if (!c->d_pfa_idx) {
       std::vector<uint16_t> ix(16384 + 258 + 256, 0);
       hx::pfa::host::build_index_tables(ix.data(), ix.data() + 16384, ix.data() + 16384 + 258);
@@ -1361,14 +1363,20 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
     // a list that mixes rows with and without the Good-Thomas x Rader tables (m = 21845: the 40-bit small primes of a
     // chain are not of the Proth form) is served in two parts -- one such row used to send the whole launch, the 60-bit
     // rows included, through Bluestein: 27 % of a multiply at m = 21845, bits = 950 (tools/prof_config5_ring.py)
-    std::vector<std::pair<int, int>> with, without;
+    // (and the rows with tables by the arithmetic their prime takes -- Proth-form or generic Montgomery product: one
+    // per launch, pfa_kernels.hip)
+    std::vector<std::pair<int, int>> part[3];   // tables + Proth form, tables + other prime, no tables
     for (auto& rp : rows) {
       const bool has = rp.second >= 0 && rp.second < (int)c->blue.size() && c->blue[rp.second] && c->blue[rp.second]->d_pfa;
-      (has ? with : without).push_back(rp);
+      // (PrimeHost::proth describes the power-of-two row tables only: decided here from the prime itself)
+      part[has ? ((hx::is_proth32(c->primes[rp.second].q) && !c->sw.no_proth) ? 0 : 1) : 2].push_back(rp);
     }
-    if (!with.empty() && !without.empty()) {
-      CHK(bluestein_rows(c, in, out, with, batch, inverse));
-      return bluestein_rows(c, in, out, without, batch, inverse);
+    const int nparts = (int)!part[0].empty() + (int)!part[1].empty() + (int)!part[2].empty();
+    if (nparts > 1) {
+      for (auto& pr : part)
+        if (!pr.empty())
+          CHK(bluestein_rows(c, in, out, pr, batch, inverse));
+      return HX_OK;
     }
   }
   // chunk so that the convolution buffers stay below ~1 GiB each
@@ -1448,7 +1456,7 @@ static int bluestein_rows(hx_ctx* c, const uint64_t* in, uint64_t* out,
       // (the inverse with rem Phi_m and 1/m behind it in the same launch -- binomial passes, no multiplication --
       // unless HX_PFA_NO_REM keeps them on the convolution kernels below)
       const int mode = !inverse ? 0 : (c->sw.pfa_no_rem ? 1 : 2);
-      e = hx::launch_pfa_rows(mode, in, mode == 1 ? xfull : out, PR, R, c->d_primes, c->d_pfa_idx, c->d_pfa_idx + 16384,
+      e = hx::launch_pfa_rows(mode, hx::is_proth32(c->primes[rows[first].second].q) && !c->sw.no_proth, in, mode == 1 ? xfull : out, PR, R, c->d_primes, c->d_pfa_idx, c->d_pfa_idx + 16384,
                               c->d_pfa_idx + 16384 + 258, batch, c->mpad, c->stream);
       if (e != hipSuccess)
         return fail(HX_ERR_DEVICE, "Good-Thomas x Rader launch failed: %s", hipGetErrorString(e));

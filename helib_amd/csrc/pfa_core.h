@@ -91,6 +91,46 @@ struct St {
   uint64_t v[6];    // ... and the values a thread carries from the read half of a multiply pass to its write half
 };
 
+// ---- the modular product, by the form of the prime ----
+// QCP: a Proth-form prime (q = 1 mod 2^32: every 60-bit PrimeGenerator prime of this ring) -- the word-wise Montgomery
+// product of ntt_core.h, six multiply-adds.  QCG: any other odd prime (the 40-bit small primes of a chain are
+// t m 2^k + 1 with k < 32) -- the textbook Montgomery product with q' = -q^-1 mod 2^64: T = y W, (T + (T q' mod 2^64) q) / 2^64,
+// in (0, 2q) for ANY 64-bit y and W < q, so every bound of the schedules below holds for it as well and the tables
+// (w 2^64 mod q) are the same.  The choice is per row (workgroup-uniform), made once by the kernel.
+struct QCP : QC {};
+struct QCG : QC {
+  uint64_t qinv;   // -q^-1 mod 2^64
+};
+HXD uint64_t neg_qinv64(uint64_t q)
+{
+  uint64_t x = q;                 // q x = 1 mod 2^3 for odd q; each step doubles the correct bits
+  for (int i = 0; i < 5; i++)
+    x *= 2 - q * x;
+  return 0 - x;
+}
+HXD QCP make_qcp(uint64_t q, uint64_t mu64)
+{
+  QCP c;
+  static_cast<QC&>(c) = make_qc(q, mu64);
+  return c;
+}
+HXD QCG make_qcg(uint64_t q, uint64_t mu64)
+{
+  QCG c;
+  static_cast<QC&>(c) = make_qc(q, mu64);
+  c.qinv = neg_qinv64(q);
+  return c;
+}
+HXD uint64_t pmul(uint64_t y, TWM W, const QCP& c) { return mont_mul(y, W, c); }
+HXD uint64_t pacc(uint64_t y, TWM W, const QCP& c, uint64_t x) { return mont_acc(y, W, c, x); }
+HXD uint64_t pmul(uint64_t y, TWM W, const QCG& c)
+{
+  const unsigned __int128 T = (unsigned __int128)y * W;
+  const uint64_t mq = (uint64_t)T * c.qinv;
+  return (uint64_t)((T + (unsigned __int128)mq * c.q) >> 64);   // T + mq q < 2^65 q: no wrap
+}
+HXD uint64_t pacc(uint64_t y, TWM W, const QCG& c, uint64_t x) { return x + pmul(y, W, c); }
+
 constexpr int cpow2(int b) { return b <= 1 ? 1 : (b <= 2 ? 2 : (b <= 4 ? 4 : 8)); }
 template <int K>
 HXD uint64_t kq(const QC& c)
@@ -134,8 +174,8 @@ constexpr int dif_b(int bin, int done, int idx)
     return bx + cpow2(by) > 4 ? 4 : bx + cpow2(by);
   return 2;
 }
-template <int BX, int BY, bool MUL>
-HXD void dif_bf(uint64_t& X, uint64_t& Y, TWM W, const QC& c)
+template <int BX, int BY, bool MUL, class Q>
+HXD void dif_bf(uint64_t& X, uint64_t& Y, TWM W, const Q& c)
 {
   const uint64_t x = X, y = Y;
   HX_BOUND(x, BX, c.q);
@@ -149,7 +189,7 @@ HXD void dif_bf(uint64_t& X, uint64_t& Y, TWM W, const QC& c)
   constexpr int BD = BX + cpow2(BY);
   if constexpr (MUL) {
     static_assert(BD <= 12, "multiplied operand");
-    d = mont_mul(d, W, c);
+    d = pmul(d, W, c);
   } else if constexpr (BD > 4) {
     static_assert(BD <= 8, "difference");
     d = csub(d, c.q4);
@@ -158,8 +198,8 @@ HXD void dif_bf(uint64_t& X, uint64_t& Y, TWM W, const QC& c)
   Y = d;
 }
 // tw(IC<s>, IC<kk>) -> the twiddle of stage s, position kk within the half block
-template <int LOG, int BIN, bool TRIV, class TwF>
-HXD void dif_pass(uint64_t* e, TwF&& tw, const QC& c)
+template <int LOG, int BIN, bool TRIV, class TwF, class Q>
+HXD void dif_pass(uint64_t* e, TwF&& tw, const Q& c)
 {
   static_for<0, LOG>([&](auto S) {
     constexpr int s = decltype(S)::value, half = (1 << (LOG - 1)) >> s;
@@ -200,8 +240,8 @@ constexpr int dit_b(int bin, int done, int idx)
   }
   return (bx > 6 ? 4 : bx) + 2;
 }
-template <int BX, int BY, bool MUL>
-HXD void dit_bf(uint64_t& X, uint64_t& Y, TWM W, const QC& c)
+template <int BX, int BY, bool MUL, class Q>
+HXD void dit_bf(uint64_t& X, uint64_t& Y, TWM W, const Q& c)
 {
   uint64_t x = X, y = Y;
   HX_BOUND(x, BX, c.q);
@@ -210,7 +250,7 @@ HXD void dit_bf(uint64_t& X, uint64_t& Y, TWM W, const QC& c)
     static_assert(BX <= 8 && BY <= 12, "bounds");
     if constexpr (BX > 6)
       x = csub(x, c.q4);
-    const uint64_t xn = mont_acc(y, W, c, x);   // x + R, 0 < R < 2q
+    const uint64_t xn = pacc(y, W, c, x);   // x + R, 0 < R < 2q
     X = xn;
     Y = (x << 1) + c.q2 - xn;                   // x + 2q - R
   } else {
@@ -224,8 +264,8 @@ HXD void dit_bf(uint64_t& X, uint64_t& Y, TWM W, const QC& c)
     Y = x + kq<cpow2(Y4)>(c) - y;
   }
 }
-template <int LOG, int BIN, bool TRIV, class TwF>
-HXD void dit_pass(uint64_t* e, TwF&& tw, const QC& c)
+template <int LOG, int BIN, bool TRIV, class TwF, class Q>
+HXD void dit_pass(uint64_t* e, TwF&& tw, const Q& c)
 {
   static_for<0, LOG>([&](auto S) {
     constexpr int s = decltype(S)::value, half = 1 << s;
@@ -259,7 +299,8 @@ struct UConv {
   static constexpr int DCB = dif_b<LOG, true>(BIN, LOG, 0);
   static constexpr int out_b(int i) { return dit_b<LOG, true>(2, LOG, i); }
   // tw: [N] powers of rho_N; hat: [N]
-  static HXD void run(uint64_t* e, const TWM* tw, const TWM* hat, const QC& c, uint64_t* dc = nullptr)
+  template <class Q>
+  static HXD void run(uint64_t* e, const TWM* tw, const TWM* hat, const Q& c, uint64_t* dc = nullptr)
   {
     dif_pass<LOG, BIN, true>(e, [&](auto S, auto K) { return tw[decltype(K)::value << decltype(S)::value]; }, c);
     if (dc)
@@ -267,7 +308,7 @@ struct UConv {
     static_assert(MID <= 12, "pointwise operand");
     static_for<0, N>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      e[i] = mont_mul(e[i], hat[i], c);
+      e[i] = pmul(e[i], hat[i], c);
     });
     dit_pass<LOG, 2, true>(
         e,
@@ -283,14 +324,14 @@ struct UConv {
 HXD unsigned pad16(unsigned idx) { return idx + (idx >> 4); }
 
 // the 4 lane-dependent stages of the 256-point transform on e[k] = element t + 16 k (stages of distance 128 .. 16)
-template <int BIN>
-HXD void dif256_outer(uint64_t* e, unsigned t, const TWM* tw256, const QC& c)
+template <int BIN, class Q>
+HXD void dif256_outer(uint64_t* e, unsigned t, const TWM* tw256, const Q& c)
 {
   dif_pass<4, BIN, false>(
       e, [&](auto S, auto K) { return tw256[(t << decltype(S)::value) + (decltype(K)::value << (4 + decltype(S)::value))]; }, c);
 }
-template <int BIN>
-HXD void dit256_outer(uint64_t* e, unsigned t, const TWM* tw256, const QC& c)
+template <int BIN, class Q>
+HXD void dit256_outer(uint64_t* e, unsigned t, const TWM* tw256, const Q& c)
 {
   dit_pass<4, BIN, false>(
       e,
@@ -314,8 +355,8 @@ HXD unsigned wrap_m(unsigned i) { return i >= (unsigned)M ? i - (unsigned)M : i;
 
 // ---- the 256-point convolution of row c, shared by both directions: three phases around two in-row exchanges ----
 // phase a: e[k] = element t + 16 k (already loaded, below BIN q): outer stages, park in the row
-template <int BIN>
-HXD void conv256_a(uint64_t* e, unsigned c, unsigned t, uint64_t* lds, const TWM* tab, const QC& q)
+template <int BIN, class Q>
+HXD void conv256_a(uint64_t* e, unsigned c, unsigned t, uint64_t* lds, const TWM* tab, const Q& q)
 {
   dif256_outer<BIN>(e, t, tab + TW256, q);
   static_for<0, 16>([&](auto K) {
@@ -324,8 +365,8 @@ HXD void conv256_a(uint64_t* e, unsigned c, unsigned t, uint64_t* lds, const TWM
   });
 }
 // phase b: thread t takes elements 16 t + k: inner 16-point stages, product with the fixed spectrum, inner stages back
-template <int BIN>   // BIN = OUTER_DIF_OUT(...)
-HXD void conv256_b(uint64_t* e, unsigned c, unsigned t, uint64_t* lds, const TWM* tab, const TWM* hat, const QC& q, uint64_t* dc)
+template <int BIN, class Q>   // BIN = OUTER_DIF_OUT(...)
+HXD void conv256_b(uint64_t* e, unsigned c, unsigned t, uint64_t* lds, const TWM* tab, const TWM* hat, const Q& q, uint64_t* dc)
 {
   static_for<0, 16>([&](auto K) {
     constexpr int k = decltype(K)::value;
@@ -339,7 +380,7 @@ HXD void conv256_b(uint64_t* e, unsigned c, unsigned t, uint64_t* lds, const TWM
     *dc = e[0];
   static_for<0, 16>([&](auto I) {
     constexpr int i = decltype(I)::value;
-    e[i] = mont_mul(e[i], h[i], q);
+    e[i] = pmul(e[i], h[i], q);
   });
   dit_pass<4, 2, true>(
       e,
@@ -359,7 +400,8 @@ constexpr int CONV_B_OUT = 8;
 static_assert(dit_out<4, true>(2) <= CONV_B_OUT, "hand-over bound");
 // phase c: back to elements t + 16 k, outer stages; element k of the result is below CONV_C_OUT q
 constexpr int CONV_C_OUT = OUTER_DIT_OUT(CONV_B_OUT);
-HXD void conv256_c(uint64_t* e, unsigned c, unsigned t, const uint64_t* lds, const TWM* tab, const QC& q)
+template <class Q>
+HXD void conv256_c(uint64_t* e, unsigned c, unsigned t, const uint64_t* lds, const TWM* tab, const Q& q)
 {
   static_for<0, 16>([&](auto K) {
     constexpr int k = decltype(K)::value;
@@ -382,8 +424,8 @@ HXD void conv256_c(uint64_t* e, unsigned c, unsigned t, const uint64_t* lds, con
 // ======================================================================================================
 constexpr int FWD_PHASES = 10;
 constexpr int F_OUTER_IN = 2;
-template <int PH>
-HXD void fwd(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
+template <int PH, class Q>
+HXD void fwd(unsigned tid, St& s, uint64_t* lds, const Args& A, const Q& q)
 {
   const TWM* tab = A.tab;
   if constexpr (PH == 0) {
@@ -445,7 +487,7 @@ HXD void fwd(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
       uint64_t acc = lds[(j0 * 17u) * (unsigned)P3];
       static_for<0, 16>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        acc = mont_acc(lds[(j0 * 17u + 1u + i) * (unsigned)P3], w2[i], q, acc);   // + (0, 2q)
+        acc = pacc(lds[(j0 * 17u + 1u + i) * (unsigned)P3], w2[i], q, acc);   // + (0, 2q)
         if constexpr (i >= 3)
           acc = csub(acc, q.q8);   // 2 + 2 (i + 1) <= 8 up to i = 2; from then on 10 -> 8
       });
@@ -521,8 +563,8 @@ HXD void fwd(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
 // ======================================================================================================
 constexpr int INV_PHASES = 11;
 constexpr int I_OUTER_IN = 1;
-template <int PH>
-HXD void inv(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
+template <int PH, class Q>
+HXD void inv(unsigned tid, St& s, uint64_t* lds, const Args& A, const Q& q)
 {
   const TWM* tab = A.tab;
   if constexpr (PH == 0) {
@@ -571,7 +613,7 @@ HXD void inv(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
       uint64_t acc = 0;
       static_for<0, 16>([&](auto B) {
         constexpr int b = decltype(B)::value;
-        acc = mont_acc(lds[(j0 * 16u + b) * ROW], w2[b], q, acc);
+        acc = pacc(lds[(j0 * 16u + b) * ROW], w2[b], q, acc);
         if constexpr (b >= 3)
           acc = csub(acc, q.q8);
       });
@@ -815,8 +857,8 @@ static_assert(RD1c::SINGLE && RD2c::SINGLE && RD2d::SINGLE && RD1a::GROUPS && !R
 
 // the inverse transform with rem Phi_m and 1/m behind it: phases 0..8 are inv<0..8>; dst = the poly row
 constexpr int INV_REM_PHASES = 33;
-template <int PH>
-HXD void inv_rem(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
+template <int PH, class Q>
+HXD void inv_rem(unsigned tid, St& s, uint64_t* lds, const Args& A, const Q& q)
 {
   const TWM* tab = A.tab;
   if constexpr (PH <= 8) {
@@ -902,7 +944,7 @@ HXD void inv_rem(unsigned tid, St& s, uint64_t* lds, const Args& A, const QC& q)
           constexpr int i5 = decltype(I)::value;
           const unsigned i = i5 == 0 ? base : wrap_m(base + (unsigned)gpow1(i5 == 0 ? 0 : i5 - 1) * (unsigned)M1);
           if (i < (unsigned)RN)
-            lds[i] = csub(mont_mul(s.o[r * 5 + i5] + q.q - lds[i], minv, q), q.q);
+            lds[i] = csub(pmul(s.o[r * 5 + i5] + q.q - lds[i], minv, q), q.q);
         });
       }
     });
@@ -950,8 +992,9 @@ inline void dft(const uint64_t* v, int n, uint64_t rho, uint64_t q, uint64_t* ou
     out[k] = acc;
   }
 }
-// a usable m / q pair: q = 1 mod 2^32 (Proth form), 256 | (q - 1) / ... is implied, root of order m given
-inline bool supported(uint64_t m, uint64_t q) { return m == (uint64_t)M && is_proth32(q) && (q - 1) % 256 == 0; }
+// a usable m / q pair: the 256-th roots of unity exist modulo q (the kernels pick the Proth-form or the generic
+// Montgomery product by the prime's form: QCP / QCG above)
+inline bool supported(uint64_t m, uint64_t q) { return m == (uint64_t)M && (q & 1) && (q >> 60) == 0 && q > 256 && (q - 1) % 256 == 0; }
 
 // rho256: any element of order 256 modulo q
 inline uint64_t order256(uint64_t q)

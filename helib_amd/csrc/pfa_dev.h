@@ -13,7 +13,8 @@ struct PfaRows {                        // per launch: up to PFA_MAXROWS rows
 };
 
 // mode 0: forward; 1: inverse up to X (rem Phi_m elsewhere); 2: inverse with rem Phi_m and 1/m fused
-hipError_t launch_pfa_rows(int mode, const uint64_t* in, uint64_t* out, const PfaRows& R, int nrows,
+// proth: all rows on Proth-form primes (PrimeDev::proth), or none (one arithmetic per launch)
+hipError_t launch_pfa_rows(int mode, bool proth, const uint64_t* in, uint64_t* out, const PfaRows& R, int nrows,
                            const PrimeDev* primes, const uint16_t* pos2, const uint16_t* dlog3, const uint16_t* gpow3,
                            int batch, unsigned out_stride, hipStream_t st);
 

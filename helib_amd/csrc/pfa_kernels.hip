@@ -18,8 +18,8 @@ constexpr int pfa_lds_words(int mode)
   return mode == 0 ? pfa::LDS_WORDS
                    : (mode == 1 ? pfa::INV_LDS_WORDS : (pfa::LDS_WORDS > pfa::REM_LDS_WORDS ? pfa::LDS_WORDS : pfa::REM_LDS_WORDS));
 }
-template <int MODE, int PH>
-__device__ __forceinline__ void pfa_phases(unsigned tid, pfa::St& s, uint64_t* lds, const pfa::Args& A, const QC& q)
+template <int MODE, int PH, class Q>
+__device__ __forceinline__ void pfa_phases(unsigned tid, pfa::St& s, uint64_t* lds, const pfa::Args& A, const Q& q)
 {
   if constexpr (PH < pfa_nphases(MODE)) {
     if constexpr (MODE == 2)
@@ -34,7 +34,10 @@ __device__ __forceinline__ void pfa_phases(unsigned tid, pfa::St& s, uint64_t* l
   }
 }
 
-template <int MODE>
+// PROTH: every row of the launch is on a Proth-form prime (the word-wise Montgomery product) / on any other prime (the
+// generic one).  One arithmetic per kernel: with both behind a uniform branch in one kernel the Proth rows ran 30 %
+// slower (94 -> 130 us per 512 rows: twice the code, four more registers).
+template <int MODE, bool PROTH>
 __global__ void __launch_bounds__(pfa::NT)
 pfa_row_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, PfaRows R, const PrimeDev* __restrict__ primes,
                const uint16_t* __restrict__ pos2, const uint16_t* __restrict__ dlog3, const uint16_t* __restrict__ gpow3,
@@ -52,33 +55,42 @@ pfa_row_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, PfaR
   const size_t polyseg = ((size_t)uniform_u16(R.row, ri) * batch + b) * (size_t)pfa::PHI;
   A.src = in + polyseg;
   A.dst = MODE == 1 ? out + ((size_t)ri * batch + b) * (size_t)out_stride : out + polyseg;
-  const QC q = make_qc(pd->q, pd->mu64);
   pfa::St s;
-  pfa_phases<MODE, 0>(threadIdx.x, s, pfa_lds, A, q);
+  if constexpr (PROTH) {
+    const pfa::QCP q = pfa::make_qcp(pd->q, pd->mu64);
+    pfa_phases<MODE, 0>(threadIdx.x, s, pfa_lds, A, q);
+  } else {
+    const pfa::QCG q = pfa::make_qcg(pd->q, pd->mu64);
+    pfa_phases<MODE, 0>(threadIdx.x, s, pfa_lds, A, q);
+  }
 }
 
-template <int MODE>
+template <int MODE, bool PROTH>
 static hipError_t launch_pfa(const uint64_t* in, uint64_t* out, const PfaRows& R, int nrows, const PrimeDev* primes,
                              const uint16_t* pos2, const uint16_t* dlog3, const uint16_t* gpow3, int batch,
                              unsigned out_stride, hipStream_t st)
 {
   constexpr size_t lds_bytes = (size_t)pfa_lds_words(MODE) * 8;
-  hipError_t e = hxp::dyn_lds((const void*)pfa_row_kernel<MODE>, (int)lds_bytes);
+  hipError_t e = hxp::dyn_lds((const void*)pfa_row_kernel<MODE, PROTH>, (int)lds_bytes);
   if (e != hipSuccess)
     return e;
-  HX_LAUNCH((pfa_row_kernel<MODE>), dim3((unsigned)nrows * (unsigned)batch), dim3(pfa::NT), lds_bytes, st, in, out, R, primes,
+  HX_LAUNCH((pfa_row_kernel<MODE, PROTH>), dim3((unsigned)nrows * (unsigned)batch), dim3(pfa::NT), lds_bytes, st, in, out, R, primes,
             pos2, dlog3, gpow3, (unsigned)batch, out_stride);
   return hipGetLastError();
 }
 // mode 0 / 2: out = poly rows; mode 1: out = X[(ri * batch + b)][out_stride], m words each
-hipError_t launch_pfa_rows(int mode, const uint64_t* in, uint64_t* out, const PfaRows& R, int nrows,
+// proth: the rows of R are all on Proth-form primes (PrimeDev::proth) / all on other primes
+hipError_t launch_pfa_rows(int mode, bool proth, const uint64_t* in, uint64_t* out, const PfaRows& R, int nrows,
                            const PrimeDev* primes, const uint16_t* pos2, const uint16_t* dlog3, const uint16_t* gpow3,
                            int batch, unsigned out_stride, hipStream_t st)
 {
-  switch (mode) {
-    case 0: return launch_pfa<0>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
-    case 1: return launch_pfa<1>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
-    case 2: return launch_pfa<2>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
+  switch (mode * 2 + (proth ? 1 : 0)) {
+    case 0: return launch_pfa<0, false>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
+    case 1: return launch_pfa<0, true>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
+    case 2: return launch_pfa<1, false>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
+    case 3: return launch_pfa<1, true>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
+    case 4: return launch_pfa<2, false>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
+    case 5: return launch_pfa<2, true>(in, out, R, nrows, primes, pos2, dlog3, gpow3, batch, out_stride, st);
   }
   return hipErrorInvalidValue;
 }

@@ -20,8 +20,8 @@ struct Tables {
   }
 };
 
-template <int PH, bool INV>
-static void phase(std::vector<St>& st, std::vector<uint64_t>& lds, const Args& A, const hx::QC& q)
+template <int PH, bool INV, class Q>
+static void phase(std::vector<St>& st, std::vector<uint64_t>& lds, const Args& A, const Q& q)
 {
   for (unsigned tid = 0; tid < (unsigned)NT; tid++) {
     if constexpr (INV)
@@ -30,8 +30,8 @@ static void phase(std::vector<St>& st, std::vector<uint64_t>& lds, const Args& A
       fwd<PH>(tid, st[tid], lds.data(), A, q);
   }
 }
-template <int PH>
-static void run_rem(std::vector<St>& st, std::vector<uint64_t>& lds, const Args& A, const hx::QC& q)
+template <int PH, class Q>
+static void run_rem(std::vector<St>& st, std::vector<uint64_t>& lds, const Args& A, const Q& q)
 {
   if constexpr (PH < INV_REM_PHASES) {
     for (unsigned tid = 0; tid < (unsigned)NT; tid++)
@@ -39,8 +39,8 @@ static void run_rem(std::vector<St>& st, std::vector<uint64_t>& lds, const Args&
     run_rem<PH + 1>(st, lds, A, q);
   }
 }
-template <bool INV, int PH, int NPH>
-static void run_all(std::vector<St>& st, std::vector<uint64_t>& lds, const Args& A, const hx::QC& q)
+template <bool INV, int PH, int NPH, class Q>
+static void run_all(std::vector<St>& st, std::vector<uint64_t>& lds, const Args& A, const Q& q)
 {
   if constexpr (PH < NPH) {
     phase<PH, INV>(st, lds, A, q);
@@ -48,7 +48,10 @@ static void run_all(std::vector<St>& st, std::vector<uint64_t>& lds, const Args&
   }
 }
 
+// force the generic Montgomery product (QCG) on Proth-form primes too: both arithmetics on the same rows
+static int g_generic = 0;
 extern "C" {
+void pfa_force_generic(int on) { g_generic = on; }
 int pfa_supported(uint64_t m, uint64_t q) { return host::supported(m, q) ? 1 : 0; }
 // in: 16384 coefficients (canonical) -> out: 16384 evaluations in Z_m^* order
 int pfa_replay_forward(uint64_t q, uint64_t root, const uint64_t* in, uint64_t* out)
@@ -60,7 +63,10 @@ int pfa_replay_forward(uint64_t q, uint64_t root, const uint64_t* in, uint64_t* 
   std::vector<uint64_t> lds(LDS_WORDS, 0xdeadbeefdeadbeefull);
   std::vector<uint64_t> src(in, in + PHI);
   Args A{T.tab.data(), T.pos2.data(), T.dlog3.data(), T.gpow3.data(), src.data(), out};
-  run_all<false, 0, FWD_PHASES>(st, lds, A, hx::make_qc(q));
+  if (g_generic || !hx::is_proth32(q))
+    run_all<false, 0, FWD_PHASES>(st, lds, A, make_qcg(q, ~(uint64_t)0 / q));
+  else
+    run_all<false, 0, FWD_PHASES>(st, lds, A, make_qcp(q, ~(uint64_t)0 / q));
   return 0;
 }
 // in: 16384 evaluations -> out: m words X[i] (before rem Phi_m and 1/m)
@@ -73,7 +79,10 @@ int pfa_replay_inverse(uint64_t q, uint64_t root, const uint64_t* in, uint64_t* 
   std::vector<uint64_t> lds(INV_LDS_WORDS, 0xdeadbeefdeadbeefull);
   std::vector<uint64_t> src(in, in + PHI);
   Args A{T.tab.data(), T.pos2.data(), T.dlog3.data(), T.gpow3.data(), src.data(), out};
-  run_all<true, 0, INV_PHASES>(st, lds, A, hx::make_qc(q));
+  if (g_generic || !hx::is_proth32(q))
+    run_all<true, 0, INV_PHASES>(st, lds, A, make_qcg(q, ~(uint64_t)0 / q));
+  else
+    run_all<true, 0, INV_PHASES>(st, lds, A, make_qcp(q, ~(uint64_t)0 / q));
   return 0;
 }
 // in: 16384 evaluations -> out: 16384 coefficients (the whole Cmodulus::iFFT: transform, rem Phi_m, 1/m)
@@ -86,7 +95,10 @@ int pfa_replay_inverse_rem(uint64_t q, uint64_t root, const uint64_t* in, uint64
   std::vector<uint64_t> lds(LDS_WORDS > REM_LDS_WORDS ? LDS_WORDS : REM_LDS_WORDS, 0xdeadbeefdeadbeefull);
   std::vector<uint64_t> src(in, in + PHI);
   Args A{T.tab.data(), T.pos2.data(), T.dlog3.data(), T.gpow3.data(), src.data(), out};
-  run_rem<0>(st, lds, A, hx::make_qc(q));
+  if (g_generic || !hx::is_proth32(q))
+    run_rem<0>(st, lds, A, make_qcg(q, ~(uint64_t)0 / q));
+  else
+    run_rem<0>(st, lds, A, make_qcp(q, ~(uint64_t)0 / q));
   return 0;
 }
 int pfa_table_words() { return TAB_WORDS; }

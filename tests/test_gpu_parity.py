@@ -629,15 +629,15 @@ def test_bluestein_m21845_config5_at_L16(hx, path, monkeypatch):
     hx.profileBegin()
     got = d.FFT().download()
     names = " ".join(k["kernel"] for k in hx.profileEnd()["kernels"])
-    assert ("pfa_row_kernel<0>" in names) == path.startswith("pfa"), names
+    assert ("pfa_row_kernel<0," in names) == path.startswith("pfa"), names
     assert ("ntt_conv_kernel" in names) == (path == "fused"), names
     for b in range(2):
         assert np.array_equal(got[:, b], P.o.fft(idx, x[:, b]))
     hx.profileBegin()
     assert np.array_equal(d.iFFT().download(), x)
     names = " ".join(k["kernel"] for k in hx.profileEnd()["kernels"])
-    assert ("pfa_row_kernel<2>" in names) == (path == "pfa"), names
-    assert ("pfa_row_kernel<1>" in names) == (path == "pfa_conv_rem"), names
+    assert ("pfa_row_kernel<2," in names) == (path == "pfa"), names
+    assert ("pfa_row_kernel<1," in names) == (path == "pfa_conv_rem"), names
     assert ("ntt_conv_kernel" in names) == (path in ("pfa_conv_rem", "fused")), names
     y = P.rand(idx, 10, batch=2)
     # extreme words: all q - 1, all zero, a single one
@@ -656,6 +656,34 @@ def test_bluestein_m21845_config5_at_L16(hx, path, monkeypatch):
     for b in range(2):
         assert np.array_equal(ge[:, b], P.o.fft(idx, e[:, b]))
     assert np.array_equal(de.iFFT().download(), e)
+
+
+@pytest.mark.parametrize("no_proth", [False, True])
+def test_good_thomas_rader_on_the_small_primes_of_a_chain(hx, no_proth, monkeypatch):
+    """m = 21845 on primes that are NOT of the Proth form -- the 36- / 40- / 48-bit small primes of a chain are
+    t m 2^k + 1 with k < 32 -- next to 60-bit ones in ONE row list: every row runs the Good-Thomas x Rader kernel
+    (the generic Montgomery product of pfa_core.h QCG on the small primes; no Bluestein launch at all), forward,
+    inverse and the extreme rows, against the oracle.  Under HX_NO_PROTH every row takes the generic product."""
+    if no_proth:
+        monkeypatch.setenv("HX_NO_PROTH", "1")
+    m = 21845
+    primes = primes_for(m, 2, 60) + primes_for(m, 2, 40) + primes_for(m, 1, 48) + primes_for(m, 1, 36)
+    assert sum(1 for q in primes if (q & 0xffffffff) == 1) == 2
+    P = Pair(hx, m, primes)
+    idx = list(range(len(primes)))
+    x = P.rand(idx, 19, batch=3)
+    x[:, 2, :] = np.array([q - 1 for q in primes], dtype=np.uint64)[:, None]
+    d = hx.DoubleCRT(P.g, idx, 3, x)
+    hx.profileBegin()
+    got = d.FFT().download()
+    back = d.iFFT().download()
+    names = " ".join(k["kernel"] for k in hx.profileEnd()["kernels"])
+    assert "pfa_row_kernel<0," in names and "pfa_row_kernel<2," in names and "ntt_conv_kernel" not in names, names
+    for b in range(3):
+        assert np.array_equal(got[:, b], P.o.fft(idx, x[:, b]))
+    assert np.array_equal(back, x)
+    y = P.rand(idx, 20, batch=1)
+    assert np.array_equal(hx.DoubleCRT(P.g, idx, 1, y).iFFT().download()[:, 0], P.o.ifft(idx, y[:, 0]))
 
 
 def test_general_m_multiply_relin_and_automorph(hx):

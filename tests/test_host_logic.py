@@ -824,7 +824,20 @@ def test_good_thomas_rader_kernel_phases_replayed_on_cpu(pfa_replay):
         assert pfa_replay.pfa_replay_inverse(q, cm.root, y.ctypes.data, X.ctypes.data) == 0
         if n == 0:
             assert [int(v) for v in X] == R.Pfa(m, q, cm.root).inverse_full([int(v) for v in y])
-    # a prime that is not of the form the kernels take (q != 1 mod 2^32) is refused: Bluestein serves it
+    # primes that are not of the Proth form (the 36- / 40- / 48-bit small primes of a chain: t m 2^k + 1 with k < 32) take
+    # the generic Montgomery product (pfa_core.h QCG) under the same bound schedules; the same forced onto a 60-bit prime
+    pfa_replay.pfa_force_generic.argtypes = [C.c_int]
+    for bits, force in ((40, 0), (48, 0), (36, 0), (60, 1)):
+        pfa_replay.pfa_force_generic(force)
+        q = O.PrimeGen(bits, m).next()
+        assert pfa_replay.pfa_supported(m, q) == 1 and (bits == 60 or (q & 0xffffffff) != 1)
+        cm = O.Cmod(m, q)
+        for x in (O.fill_uniform(cm.phim, q, 3), np.full(cm.phim, q - 1, dtype=np.uint64)):
+            y, out, back = cm.fft(x), np.zeros(cm.phim, dtype=np.uint64), np.zeros(cm.phim, dtype=np.uint64)
+            assert pfa_replay.pfa_replay_forward(q, cm.root, x.ctypes.data, out.ctypes.data) == 0 and np.array_equal(out, y)
+            assert pfa_replay.pfa_replay_inverse_rem(q, cm.root, y.ctypes.data, back.ctypes.data) == 0 and np.array_equal(back, x)
+    pfa_replay.pfa_force_generic(0)
+    # a prime without the 256-th roots of unity is refused: Bluestein serves it
     assert pfa_replay.pfa_supported(m, 21845 * 2 * 17 + 1) == 0
 
 
