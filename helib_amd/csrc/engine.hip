@@ -4348,29 +4348,18 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
     lazy_out = lazy_out && A.plan[d].lazy_tight_ok;
   if (fast) {
     const int lds_rows = std::max(1, L - hx::break_fast_n0(A));
-    // the private LDS column caps the resident waves at 160 KiB / (rows x 8 B x 64 lanes) per CU: 16 rows at the CKKS
-    // chain = five waves per SIMD where the registers allow seven, and the kernel is latency-shaped (the BGV launch
-    // forced to five waves ran 24 % slower).  The form without the column (HX_BRK_NOLDS=1: a later digit's own rows
-    // rebuilt from the words the thread stored in its earlier passes) is bit-exact and SLOWER -- 700 against 306 us at
-    // the BGV shape, 1010 against 610 at CKKS: the drained stores and the re-read words cost more than the waves give
-    // (profiles/r06_ab_digit_kernel_occupancy.json) -- so it stays a switch, off by default
-    const bool nolds = ndig <= hx::BRK_NOLDS_MAXD && c->sw.brk_nolds == 1;
-    if (!nolds)
-      for (const void* f : {(const void*)hx::break_digits_fast_kernel<true, false>, (const void*)hx::break_digits_fast_kernel<false, false>,
-                            (const void*)hx::break_digits_fast_kernel<true, true>, (const void*)hx::break_digits_fast_kernel<false, true>})
-        HIPCHK(hxp::dyn_lds(f, 64 * hx::BRK_THREADS * 8));
+    // (the column caps the resident waves at 160 KiB / (rows x 8 B x 64 lanes) per CU: 16 rows at the CKKS chain = five
+    // waves per SIMD where the registers allow seven -- worth 24 % by the HX_BRK_LDS_PAD probe; the two ways tried to
+    // move the column out of the LDS did not pay: profiles/r06_ab_digit_kernel_occupancy.json)
+    for (const void* f : {(const void*)hx::break_digits_fast_kernel<true, false>, (const void*)hx::break_digits_fast_kernel<false, false>,
+                          (const void*)hx::break_digits_fast_kernel<true, true>, (const void*)hx::break_digits_fast_kernel<false, true>})
+      HIPCHK(hxp::dyn_lds(f, 64 * hx::BRK_THREADS * 8));
     // (HX_BRK_LDS_PAD: unused rows on top, to measure what the kernel's occupancy is worth -- profiles/r06_ab_digit_kernel_occupancy)
-    const size_t lds_fast = nolds ? 0 : (size_t)(lds_rows + std::max(0, std::min(40, c->sw.brk_lds_pad_rows))) * hx::BRK_THREADS * 8;
+    const size_t lds_fast = (size_t)(lds_rows + std::max(0, std::min(40, c->sw.brk_lds_pad_rows))) * hx::BRK_THREADS * 8;
     bool hps = rw < ((size_t)1 << 32);
     for (int d = 0; d < ndig; d++)
       hps = hps && A.plan[d].hps_ok && (int)A.plan[d].n >= hps_min_n(c);
-#define HX_BRK_LAUNCH(H, Z, G)                                                                                       \
-  do {                                                                                                               \
-    if (nolds)                                                                                                       \
-      HX_LAUNCH((hx::break_digits_fast_kernel<H, Z, true>), G, block, lds_fast, c->stream, A, rw);                   \
-    else                                                                                                             \
-      HX_LAUNCH((hx::break_digits_fast_kernel<H, Z, false>), G, block, lds_fast, c->stream, A, rw);                  \
-  } while (0)
+#define HX_BRK_LAUNCH(H, Z, G) HX_LAUNCH((hx::break_digits_fast_kernel<H, Z>), G, block, lds_fast, c->stream, A, rw)
     if (hps) {   // HPS form, then Garner over the coefficients it could not vouch for (rns_kernels.h: ExtRep)
       CHK(redo_prepare(c, rw, &A.redo));
       if (lazy_out) {

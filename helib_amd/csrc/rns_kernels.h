@@ -993,41 +993,17 @@ __device__ __forceinline__ void redo_append(uint32_t* redo, size_t i)
 // 16 LDS rows per thread at L = 16, digits 6/5/5, which is what bounds the resident waves.
 // LAZY: the extension words are left in [0,6q) (congruent, not reduced): three conditional subtractions less per
 // word; hx_mul_relin / hx_relinearize, whose forward transform of these rows takes lazy input
-// NOLDS (round 6): no private LDS column at all.  A later digit's own row is rebuilt where it is consumed,
-//   u = (...((x_r - v_0) P_0^-1 - v_1) P_1^-1 ...),
-// from the source word and the extension words v_e of the earlier digits at that row -- which this same thread stored
-// in its earlier passes (the stores are drained, s_waitcnt vmcnt(0), between the passes).  The fix-up
-// arithmetic moves from the target loop to the front end, word for word the same; what changes is the occupancy: the
-// column is (L - n0) x 8 bytes per thread -- 16 rows at the CKKS chain (L = 24, digits 8 / 8 / 8) = ten workgroups per CU,
-// FIVE waves per SIMD, and this kernel is latency-shaped (one scalar record per target): the BGV launch forced to five
-// waves ran 24 % slower than at its seven (profiles/r06_ab_digit_kernel_occupancy.json).
-// (the earlier digits' records travel as scalars, three at most: indexing the by-value kernel argument with a
-// run-time digit number from a function that took its address moved the whole struct to scratch)
-constexpr int BRK_NOLDS_MAXD = 4;
-struct BrkEarlier {
-  const uint64_t* src_i;   // A.src + i
-  const uint64_t* dst_i;   // A.dst + i
-  size_t digit_words;      // nall * row_words
-  ro_u64 pk0, pk1, pk2;    // target packs of digits 0, 1, 2
-  int n0, n1, n2;          // their source counts
-};
-template <int N, bool LAZY>
-__device__ __forceinline__ void break_rebuild_rows(const BrkEarlier& E, int d, int off, size_t row_words, uint64_t (&u)[N]);
-
-template <int N, bool HPS, bool LAZY, bool NOLDS = false>
+// (Round 6 tried the column elsewhere to win back the waves its 16 rows cost at the CKKS chain -- five per SIMD instead
+// of seven, worth 24 % on the BGV launch: rebuilt from the thread's own stored extension words, 1.6 - 2.3 x slower;
+// kept in global memory, + 21 % at the BGV shape and - 2 % at CKKS.  Neither stayed: profiles/r06_ab_digit_kernel_occupancy.json.)
+template <int N, bool HPS, bool LAZY>
 __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* xs, unsigned tid, int off, int L,
                                                  uint64_t* dd, size_t row_words, double* frac_out, int n0,
-                                                 const uint64_t* src0, const BrkEarlier& E = BrkEarlier{}, int d = 0)
+                                                 const uint64_t* src0)
 {
   const bool from_global = off < n0;   // (uniform; a digit is either entirely below n0 or entirely above)
-  uint64_t own[NOLDS ? N : 1];
-  if constexpr (NOLDS)
-    break_rebuild_rows<N, LAZY>(E, d, off, row_words, own);
   auto load = [&](int k) -> uint64_t {   // [0,4 p_k): later digits' rows are updated lazily
-    if constexpr (NOLDS)
-      return own[k];
-    else
-      return from_global ? ld_stream1(src0 + (size_t)(off + k) * row_words) : xs[(off + k - n0) * BRK_THREADS + tid];
+    return from_global ? ld_stream1(src0 + (size_t)(off + k) * row_words) : xs[(off + k - n0) * BRK_THREADS + tid];
   };
   ExtRep<N> R;
   bool trusted = true;
@@ -1097,7 +1073,7 @@ __device__ __forceinline__ bool break_digit_pass(const ExtPlanDev& P, uint64_t* 
       v = LAZY ? red128_any_lazy(S, q, T.r64(), (uint32_t)T.mu64()) : red128_any(S, q, T.r64(), (uint32_t)T.mu64());
     }
     st_stream1(dd + (size_t)r * row_words, v);
-    if (!NOLDS && r >= off + N && r < L) {
+    if (r >= off + N && r < L) {
       // digits[j] -= digits[i]; digits[j] /= P_i on a later digit's own row (kept lazy, < 4q; v < 6q when LAZY:
       // the offset that keeps the difference positive is 8q then, 12q < 2^64 in all)
       uint64_t* u = &xs[(r - n0) * BRK_THREADS + tid];
@@ -1428,130 +1404,53 @@ rns_extend_wide_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
   }
 }
 
-// all N own rows of digit d at once: every word the fix-ups need is requested before the first is used (one word at a
-// time -- load, wait, multiply, next -- the kernel was nine times slower than with its LDS column: 1160 full waits)
-template <int N, bool LAZY>
-__device__ __forceinline__ void break_rebuild_rows(const BrkEarlier& E, int d, int off, size_t row_words, uint64_t (&u)[N])
-{
-  uint64_t v0[N], v1[N], v2[N];
-#pragma unroll
-  for (int k = 0; k < N; k++)
-    u[k] = ld_stream1(E.src_i + (size_t)(off + k) * row_words);   // canonical
-  if (d > 0) {
-#pragma unroll
-    for (int k = 0; k < N; k++)
-      v0[k] = E.dst_i[(size_t)(off + k) * row_words];              // stored by this thread in pass 0
-  }
-  if (d > 1) {
-#pragma unroll
-    for (int k = 0; k < N; k++)
-      v1[k] = E.dst_i[E.digit_words + (size_t)(off + k) * row_words];
-  }
-  if (d > 2) {
-#pragma unroll
-    for (int k = 0; k < N; k++)
-      v2[k] = E.dst_i[2 * E.digit_words + (size_t)(off + k) * row_words];
-  }
-  for (int e = 0; e < d; e++) {
-    // digit e's record of target row r (r lies beyond digit e's own rows: target index r - n_e), the update constants
-    // the LDS form reads in its target loop: P_e^-1 mod q_r as a Shoup pair, or times 2^64 on a Proth-form target
-    const int ne = e == 0 ? E.n0 : (e == 1 ? E.n1 : E.n2);
-    ro_u64 pk = e == 0 ? E.pk0 : (e == 1 ? E.pk1 : E.pk2);
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-      ro_u64 rec = pk + (size_t)(off + k - ne) * (size_t)(10 + 2 * ne);
-      const uint64_t q = rec[0];
-      const bool mont = ((uint32_t)rec[4] >> 10) & 1u;
-      const uint64_t v = e == 0 ? v0[k] : (e == 1 ? v1[k] : v2[k]);
-      if (mont) {   // u < 4q, v < 2q: u + 2q - v in (0, 6q), the product below 2q
-        const QC qc = make_qc(q, 0);
-        u[k] = mont_mul(u[k] + qc.q2 - v, rec[8 + 2 * ne], qc);
-      } else {      // v < q (< 6q when LAZY): the offset keeps the difference positive; shoup4 takes any 64-bit value
-        TW t;
-        t.w = rec[5];
-        t.wp = rec[6];
-        u[k] = shoup4(u[k] + (LAZY ? q << 3 : q) - v, t, 0 - q);
-      }
-    }
-  }
-}
-template <bool HPS, bool LAZY, bool NOLDS = false>
+template <bool HPS, bool LAZY>
 __device__ __forceinline__ void break_digits_fast_one(const BreakArgs& A, size_t row_words, uint64_t* xs, unsigned tid, size_t i)
 {
   const int n0 = break_fast_n0(A);
-  if constexpr (!NOLDS)
-    for (int r = n0; r < A.L; r++)
-      xs[(r - n0) * BRK_THREADS + tid] = ld_stream1(A.src + (size_t)r * row_words + i);
+  for (int r = n0; r < A.L; r++)
+    xs[(r - n0) * BRK_THREADS + tid] = ld_stream1(A.src + (size_t)r * row_words + i);
   const uint64_t* src0 = A.src + i;
   bool trusted = true;
-  BrkEarlier E{};
-  if constexpr (NOLDS) {
-    E.src_i = A.src + i;
-    E.dst_i = A.dst + i;
-    E.digit_words = (size_t)A.nall * row_words;
-  }
   for (int d = 0; d < A.ndig; d++) {
     const ExtPlanDev& P = A.plan[d];
     const int off = A.off[d];
     uint64_t* dd = A.dst + (size_t)d * A.nall * row_words + i;
     double* fo = A.frac ? A.frac + (size_t)d * row_words + i : nullptr;
     bool ok;
-    if constexpr (NOLDS) {
-      if (d > 0) {
-        // this thread's stores of the earlier passes before its loads of them (same lane, same address, through
-        // memory): the stores are acknowledged by the L2 before the loads issue.  The lines were never loaded by this
-        // CU before (each 128-byte line of a dst row belongs to one wave), so the write-through vector cache holds no
-        // stale copy; an agent-scope release / acquire pair here also wrote the whole L2 back (buffer_wbl2), twice
-        // per wave
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
     switch (P.n) {
-      case 1: ok = break_digit_pass<1, HPS, LAZY, NOLDS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0, E, d); break;
-      case 2: ok = break_digit_pass<2, HPS, LAZY, NOLDS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0, E, d); break;
-      case 3: ok = break_digit_pass<3, HPS, LAZY, NOLDS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0, E, d); break;
-      case 4: ok = break_digit_pass<4, HPS, LAZY, NOLDS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0, E, d); break;
-      case 5: ok = break_digit_pass<5, HPS, LAZY, NOLDS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0, E, d); break;
-      case 6: ok = break_digit_pass<6, HPS, LAZY, NOLDS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0, E, d); break;
-      case 7: ok = break_digit_pass<7, HPS, LAZY, NOLDS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0, E, d); break;
-      default: ok = break_digit_pass<8, HPS, LAZY, NOLDS>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0, E, d); break;
+      case 1: ok = break_digit_pass<1, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 2: ok = break_digit_pass<2, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 3: ok = break_digit_pass<3, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 4: ok = break_digit_pass<4, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 5: ok = break_digit_pass<5, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 6: ok = break_digit_pass<6, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      case 7: ok = break_digit_pass<7, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
+      default: ok = break_digit_pass<8, HPS, LAZY>(P, xs, tid, off, A.L, dd, row_words, fo, n0, src0); break;
     }
     trusted = trusted && ok;
-    if constexpr (NOLDS) {   // this digit's record for the passes that follow (uniform selects, no indexing)
-      ro_u64 pk = HPS ? P.tgt_pack_hps : P.tgt_pack;
-      if (d == 0) {
-        E.pk0 = pk;
-        E.n0 = P.n;
-      } else if (d == 1) {
-        E.pk1 = pk;
-        E.n1 = P.n;
-      } else {
-        E.pk2 = pk;
-        E.n2 = P.n;
-      }
-    }
   }
   if (HPS && !trusted)   // (one entry per coefficient: a wrong digit also spoils the later digits' rows of this lane)
     redo_append(A.redo, i);
 }
-template <bool HPS, bool LAZY = false, bool NOLDS = false>
+template <bool HPS, bool LAZY = false>
 __global__ void __launch_bounds__(BRK_THREADS) __attribute__((amdgpu_waves_per_eu(HX_BRK_WAVES)))
 break_digits_fast_kernel(BreakArgs A, size_t row_words)
 {
-  extern __shared__ __attribute__((aligned(16))) uint64_t xs[];  // [L - n0][BRK_THREADS]: one private column per thread (none: NOLDS)
+  extern __shared__ __attribute__((aligned(16))) uint64_t xs[];  // [L - n0][BRK_THREADS]: one private column per thread
   const unsigned tid = threadIdx.x;
   if constexpr (!HPS) {
     if (A.redo) {   // the listed coefficients only
       const uint32_t n = A.redo[0];
       for (size_t j = (size_t)blockIdx.x * BRK_THREADS + tid; j < n; j += (size_t)gridDim.x * BRK_THREADS)
-        break_digits_fast_one<false, LAZY, NOLDS>(A, row_words, xs, tid, A.redo[1 + j]);
+        break_digits_fast_one<false, LAZY>(A, row_words, xs, tid, A.redo[1 + j]);
       return;
     }
   }
   const size_t i = (size_t)blockIdx.x * BRK_THREADS + tid;
   if (i >= row_words)
     return;
-  break_digits_fast_one<HPS, LAZY, NOLDS>(A, row_words, xs, tid, i);
+  break_digits_fast_one<HPS, LAZY>(A, row_words, xs, tid, i);
 }
 
 // (x - y) * c per row: the tail of scaleDownToSet (*this -= delta; *this /= diffProd)

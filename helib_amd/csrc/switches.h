@@ -23,7 +23,6 @@ struct Switches {
   bool no_fast_extend = false;   // HX_NO_FAST_EXTEND=1  generic rns_extend_kernel instead of rns_extend_fast_kernel
   bool no_proth_rns = false;     // HX_NO_PROTH_RNS=1    fast kernels: Barrett / Shoup products on Proth-form primes too (HX_NO_PROTH implies it)
   bool no_wide_extend = false;   // HX_NO_WIDE_EXTEND=1  generic rns_extend_kernel<40> instead of rns_extend_wide_kernel (17..40 sources)
-  int brk_nolds = -1;            // HX_BRK_NOLDS=0|1     digit kernel: 1 = without its private LDS column (bit-exact, slower: an A/B record)
   int brk_lds_pad_rows = 0;      // HX_BRK_LDS_PAD=n     digit kernel: n more (unused) LDS rows per thread -- lowers its occupancy, an A/B probe
   // fused ciphertext-level paths
   bool no_tensor_multi = false;  // HX_NO_TENSOR_MULTI=1 tensor product + several-primes mod-switch as two steps
@@ -61,8 +60,6 @@ inline Switches read()
   s.no_fast_extend = on("HX_NO_FAST_EXTEND");
   s.no_proth_rns = on("HX_NO_PROTH_RNS");
   s.no_wide_extend = on("HX_NO_WIDE_EXTEND");
-  if (const char* e = std::getenv("HX_BRK_NOLDS"))
-    s.brk_nolds = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("HX_BRK_LDS_PAD"))
     s.brk_lds_pad_rows = std::atoi(e);
   s.no_tensor_multi = on("HX_NO_TENSOR_MULTI");
