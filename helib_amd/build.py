@@ -19,10 +19,10 @@ UNITS = [("ntt_kernels.hip", ["-DHX_NTT_ONLY=13"], "ntt_kernels_13.o"), ("ntt_ke
          ("conv_kernels.hip", [], "conv_kernels.o"), ("pfa_kernels.hip", [], "pfa_kernels.o"), ("engine.hip", [], "engine.o")]
 SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["ntt_core.h", "dev_common.h", "rns_kernels.h", "hostmath.h", "conv_core.h", "bluestein.h", "norm_kernels.h",
-           "prg_kernels.h", "arena.h", "prof.h", "switches.h", "conv_dev.h", "ntt_kernel_util.h", "norm_r16.h", "work_map.h",
+           "prg_kernels.h", "arena.h", "prof.h", "conv_dev.h", "ntt_kernel_util.h", "norm_r16.h", "work_map.h",
            os.path.join("..", "..", "include", "helib_amd.h")]
 # headers only some units include (a change there does not rebuild the row kernels: minutes)
-UNIT_HEADERS = {"pfa_kernels.hip": ["pfa_core.h", "pfa_dev.h"], "engine.hip": ["pfa_core.h", "pfa_dev.h"]}
+UNIT_HEADERS = {"pfa_kernels.hip": ["pfa_core.h", "pfa_dev.h"], "engine.hip": ["pfa_core.h", "pfa_dev.h", "switches.h"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-Wno-pass-failed"]
 

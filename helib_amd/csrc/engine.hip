@@ -4358,7 +4358,7 @@ static int break_digits_fused(hx_ctx* c, const uint64_t* coef, const std::vector
     const size_t lds_fast = (size_t)(lds_rows + std::max(0, std::min(40, c->sw.brk_lds_pad_rows))) * hx::BRK_THREADS * 8;
     bool hps = rw < ((size_t)1 << 32);
     for (int d = 0; d < ndig; d++)
-      hps = hps && A.plan[d].hps_ok && (int)A.plan[d].n >= hps_min_n(c);
+      hps = hps && A.plan[d].hps_ok && (int)A.plan[d].n >= c->sw.brk_hps_min_n;
 #define HX_BRK_LAUNCH(H, Z, G) HX_LAUNCH((hx::break_digits_fast_kernel<H, Z>), G, block, lds_fast, c->stream, A, rw)
     if (hps) {   // HPS form, then Garner over the coefficients it could not vouch for (rns_kernels.h: ExtRep)
       CHK(redo_prepare(c, rw, &A.redo));

@@ -18,6 +18,8 @@ struct Switches {
   bool no_hps = false;           // HX_NO_HPS=1          fast kernels (<= 16 sources): Garner instead of the HPS front end
   double hps_eps = 1.0 / (double)(1u << 30);   // HX_HPS_EPS=x   distance from 0, 1/2, 1 below which an HPS quotient is redone
   int hps_min_n = 9;             // HX_HPS_MIN_N=n       fast kernels: HPS form from n source primes on
+  int brk_hps_min_n = 5;         // HX_BRK_HPS_MIN_N=n   ... the digit kernel's own threshold (round 6: digits of 5 - 8 primes run faster on
+                                 //                      the HPS front end + its redo launch than on Garner; HX_HPS_MIN_N overrides both)
   bool no_lazy_rns = false;      // HX_NO_LAZY_RNS=1     no 128-bit lazy sums / one-subtraction Garner steps
   bool no_fast_break = false;    // HX_NO_FAST_BREAK=1   generic break_digits_kernel instead of the fast one
   bool no_fast_extend = false;   // HX_NO_FAST_EXTEND=1  generic rns_extend_kernel instead of rns_extend_fast_kernel
@@ -54,7 +56,9 @@ inline Switches read()
   if (const char* e = std::getenv("HX_HPS_EPS"))
     s.hps_eps = std::atof(e);
   if (const char* e = std::getenv("HX_HPS_MIN_N"))
-    s.hps_min_n = std::atoi(e);
+    s.hps_min_n = s.brk_hps_min_n = std::atoi(e);
+  if (const char* e = std::getenv("HX_BRK_HPS_MIN_N"))
+    s.brk_hps_min_n = std::atoi(e);
   s.no_lazy_rns = on("HX_NO_LAZY_RNS");
   s.no_fast_break = on("HX_NO_FAST_BREAK");
   s.no_fast_extend = on("HX_NO_FAST_EXTEND");
