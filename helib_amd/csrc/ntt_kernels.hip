@@ -970,7 +970,13 @@ template <int LOGN, bool INV, int LB = 1>
 static hipError_t launch_one(const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows,
                              int batch, const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
 {
+#ifdef HX_ROW_ONE_WG
+  // (A/B probe: more LDS than half a CU's, i.e. ONE workgroup per CU -- what a row kernel with a 256-register budget
+  // would get; profiles/r06_ab_row_kernel_one_workgroup_per_cu.json)
+  static const size_t lds_bytes = LOGN == 14 ? (size_t)90 * 1024 : (size_t)Geo<LOGN>::LDS_WORDS * 4;
+#else
   static const size_t lds_bytes = (size_t)Geo<LOGN>::LDS_WORDS * 4;
+#endif
   bool attr_set = false;   // (hxp::dyn_lds is idempotent per device)
   if (!attr_set) {
     hipError_t e = hxp::dyn_lds((const void*)ntt_row_kernel<LOGN, INV, LB>,
