@@ -14,6 +14,7 @@
 #   pmc              three separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU) -> pmc_summary.txt
 #   pmc_sq           two more --pmc passes: SQ VALU activity + GRBM_GUI_ACTIVE (clock), LDS bank conflicts -> pmc_sq_summary.txt
 #   scatter          bench.py --scatter at N = 1, and at two ranks on one device (gloo)
+#   pmc_config5      --pmc passes (traffic, VALU, LDS conflicts) over the config 5 transform driver -> pmc_config5_summary.txt
 #   bluestein        tools/prof_bluestein.py Good-Thomas x Rader (default), fused Bluestein (HX_NO_PFA) and old chain + kernel trace of the default
 #   levels           tools/prof_levels.py for both schemes
 #   ab:A,B,...       same-box A/B of the fresh multiply, two rounds; A = default | env:VAR=1 | a variant
@@ -156,6 +157,14 @@ PY
       HX_BLUE_OLD=1 timeout 200 python tools/prof_bluestein.py > $out/blue_old.json 2> $out/blue_old.err; cat $out/blue_old.json
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $R/$out/blue_kt -- python3 $R/tools/prof_bluestein.py > /dev/null 2> $R/$out/blue_kt.err)
       python tools/rocpd_summary.py $out/blue_kt > $out/blue_kernel_trace.txt 2>&1; head -14 $out/blue_kernel_trace.txt ;;
+    pmc_config5)
+      # separate --pmc passes over the config 5 transform driver (tools/prof_bluestein.py): traffic, VALU instructions, LDS
+      for ctr in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS"; do
+        tag=$(echo $ctr | cut -d" " -f1)
+        (cd /tmp && HX_ITERS=3 timeout 300 rocprofv3 --pmc $ctr -d $R/$out/pmc5_$tag -- python3 $R/tools/prof_bluestein.py > /dev/null 2> $R/$out/pmc5_$tag.err); echo "pmc5 $tag rc=$?"
+      done
+      python tools/rocpd_pmc.py $out/pmc5_FETCH_SIZE $out/pmc5_WRITE_SIZE $out/pmc5_SQ_INSTS_VALU $out/pmc5_SQ_LDS_BANK_CONFLICT > $out/pmc_config5_summary.txt 2>&1
+      grep -E "pfa_row" $out/pmc_config5_summary.txt | cut -c1-220 ;;
     levels)
       timeout 300 python tools/prof_levels.py bgv > $out/levels_bgv.json 2> $out/levels_bgv.err; cut -c1-1500 $out/levels_bgv.json
       timeout 300 python tools/prof_levels.py ckks > $out/levels_ckks.json 2> $out/levels_ckks.err; cut -c1-1500 $out/levels_ckks.json ;;
