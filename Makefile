@@ -9,7 +9,7 @@ CSRC = helib_amd/csrc
 LIB = helib_amd/lib
 HDRS = $(wildcard $(CSRC)/*.h) include/helib_amd.h
 
-OBJS = $(LIB)/ntt_kernels_13.o $(LIB)/ntt_kernels_14.o $(LIB)/ntt_kernels_15.o $(LIB)/ntt_dispatch.o $(LIB)/conv_kernels.o $(LIB)/pfa_kernels.o $(LIB)/engine.o
+OBJS = $(LIB)/ntt_kernels_13.o $(LIB)/ntt_kernels_14.o $(LIB)/ntt_kernels_15.o $(LIB)/ntt_dispatch.o $(LIB)/conv_kernels.o $(LIB)/pfa_kernels.o $(LIB)/rns_mfma_kernels.o $(LIB)/engine.o
 lib: $(LIB)/libhelib_amd.so
 $(LIB)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(LIB)

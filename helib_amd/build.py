@@ -16,13 +16,15 @@ SO = os.path.join(LIBDIR, "libhelib_amd.so")
 # (source, extra flags, object): ntt_kernels.hip is compiled once per ring size, in parallel (see the top of that file)
 UNITS = [("ntt_kernels.hip", ["-DHX_NTT_ONLY=13"], "ntt_kernels_13.o"), ("ntt_kernels.hip", ["-DHX_NTT_ONLY=14"], "ntt_kernels_14.o"),
          ("ntt_kernels.hip", ["-DHX_NTT_ONLY=15"], "ntt_kernels_15.o"), ("ntt_dispatch.hip", [], "ntt_dispatch.o"),
-         ("conv_kernels.hip", [], "conv_kernels.o"), ("pfa_kernels.hip", [], "pfa_kernels.o"), ("engine.hip", [], "engine.o")]
+         ("conv_kernels.hip", [], "conv_kernels.o"), ("pfa_kernels.hip", [], "pfa_kernels.o"), ("rns_mfma_kernels.hip", [], "rns_mfma_kernels.o"),
+         ("engine.hip", [], "engine.o")]
 SOURCES = sorted({u[0] for u in UNITS})
-HEADERS = ["ntt_core.h", "dev_common.h", "rns_kernels.h", "hostmath.h", "conv_core.h", "bluestein.h", "norm_kernels.h",
+HEADERS = ["ntt_core.h", "dev_common.h", "rns_kernels.h", "rns_types.h", "hostmath.h", "conv_core.h", "bluestein.h", "norm_kernels.h",
            "prg_kernels.h", "arena.h", "prof.h", "conv_dev.h", "ntt_kernel_util.h", "norm_r16.h", "work_map.h",
            os.path.join("..", "..", "include", "helib_amd.h")]
 # headers only some units include (a change there does not rebuild the row kernels: minutes)
-UNIT_HEADERS = {"pfa_kernels.hip": ["pfa_core.h", "pfa_dev.h"], "engine.hip": ["pfa_core.h", "pfa_dev.h", "switches.h"]}
+UNIT_HEADERS = {"pfa_kernels.hip": ["pfa_core.h", "pfa_dev.h"], "rns_mfma_kernels.hip": ["mfma_ext.h", "rns_mfma_dev.h"],
+                "engine.hip": ["pfa_core.h", "pfa_dev.h", "switches.h", "mfma_ext.h", "rns_mfma_dev.h"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-Wno-pass-failed"]
 

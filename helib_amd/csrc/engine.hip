@@ -24,6 +24,8 @@
 #include "bluestein.h"
 #include "pfa_dev.h"
 #include "rns_kernels.h"
+#include "mfma_ext.h"
+#include "rns_mfma_dev.h"
 #include "norm_kernels.h"
 #include "prg_kernels.h"
 
@@ -145,6 +147,7 @@ static inline uint64_t tw_r2(const PrimeHost& ph, uint64_t w)
 struct ExtPlan {
   ExtPlanDev dev;
   void* blob = nullptr;
+  void* blob_mfma = nullptr;   // the matrix-core form's tables (mfma_ext.h), when the plan has them
 };
 
 struct ConvPlan {  // negacyclic NTT of size 2^logn for one prime
@@ -574,6 +577,7 @@ static void ctx_free(hx_ctx* c)
     hipFree(c->d_tw);
   for (auto& kv : c->plans) {
     hipFree(kv.second->blob);
+    hipFree(kv.second->blob_mfma);
     delete kv.second;
   }
   for (int i = 0; i < 10; i++)
@@ -2509,6 +2513,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   const size_t wide_stride = (size_t)hx::wide_stride(n);
   size_t o_wide = wide_cand ? take((size_t)nt * wide_stride) : 0;
   std::vector<uint64_t> h(off, 0);
+  std::vector<uint64_t> mfma_w(wide_cand ? (size_t)nt * n : 0), mfma_negp(wide_cand ? (size_t)nt : 0);   // (mfma_ext.h)
   hxh::BigU P(1);
   for (int k = 0; k < n; k++) {
     h[o_srcq + k] = p[k];
@@ -2676,7 +2681,9 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
         if (scaled)
           w = hxh::mulmod(w, pinv_t, q);
         rec[8 + k] = (w & 0x3fffffffull) | ((w >> 30) << 32);
+        mfma_w[(size_t)t * n + k] = w;
       }
+      mfma_negp[t] = (q - rec[1] % q) % q;
     }
     for (int t = 0; t < nt && hps_ok && !wide_cand; t++) {
       const uint64_t q = tq(t);
@@ -2760,6 +2767,27 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
       okw = (tq(t) >> 32) != 0 && hxh::bitlen(tq(t)) <= 60;
     pl->dev.wide_ok = okw ? 1u : 0u;
     pl->dev.wide_pack = hx::as_ro(d + o_wide);
+    // the same extension on the matrix cores: multipliers as balanced 8-bit limbs in MFMA operand order (mfma_ext.h)
+    pl->dev.mfma_a = nullptr;
+    pl->dev.mfma_init = nullptr;
+    pl->dev.mfma_steps = 0;
+    if (okw && !c->sw.no_mfma_ext) {
+      std::vector<int8_t> ta;
+      std::vector<uint32_t> ti;
+      std::vector<uint64_t> tqs((size_t)nt);
+      for (int t = 0; t < nt; t++)
+        tqs[(size_t)t] = tq(t);
+      hx::mfx::build_tables(n, nt, tqs.data(), mfma_w.data(), mfma_negp.data(), ta, ti);
+      const size_t a_bytes = (ta.size() + 255) & ~(size_t)255;
+      uint8_t* dm = nullptr;
+      HIPCHK(hipMalloc((void**)&dm, a_bytes + ti.size() * 4));
+      HIPCHK(hipMemcpy(dm, ta.data(), ta.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(dm + a_bytes, ti.data(), ti.size() * 4, hipMemcpyHostToDevice));
+      pl->blob_mfma = dm;
+      pl->dev.mfma_a = dm;
+      pl->dev.mfma_init = reinterpret_cast<const uint32_t*>(dm + a_bytes);
+      pl->dev.mfma_steps = (uint32_t)hx::mfx::steps_for(n);
+    }
   }
   pl->dev.tgt_chunk7 = hx::as_ro(reinterpret_cast<const uint32_t*>(d + o_tchunk));
   {
@@ -2835,6 +2863,13 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args_in, s
     // 17..40 source primes (the reference's own benchmark chain): HPS form, then Garner over the coefficients it
     // could not vouch for (they were left untouched, so in-place updates are redone correctly too)
     CHK(redo_prepare(c, row_words, &args.redo));
+    if (pl->dev.mfma_steps) {
+      // the target sums as an int8 matrix product (rns_mfma_kernels.hip), the Garner pass over its redo list behind it
+      HIPCHK(hx::launch_rns_extend_mfma(pl->dev, args, row_words, c->stream));
+      HX_LAUNCH((hx::rns_extend_kernel<40>), REDO_GRID, block, 0, c->stream, pl->dev, args, row_words);
+      HIPCHK(hipGetLastError());
+      return HX_OK;
+    }
     const dim3 wgrid((unsigned)((row_words + hx::WIDE_THREADS - 1) / hx::WIDE_THREADS)), wblock(hx::WIDE_THREADS);
     const size_t lds = wide_lds;
     // (function attributes are per device: one flag per device a context of this process has used)

@@ -25,6 +25,8 @@ struct Switches {
   bool no_fast_extend = false;   // HX_NO_FAST_EXTEND=1  generic rns_extend_kernel instead of rns_extend_fast_kernel
   bool no_proth_rns = false;     // HX_NO_PROTH_RNS=1    fast kernels: Barrett / Shoup products on Proth-form primes too (HX_NO_PROTH implies it)
   bool no_wide_extend = false;   // HX_NO_WIDE_EXTEND=1  generic rns_extend_kernel<40> instead of rns_extend_wide_kernel (17..40 sources)
+  bool no_mfma_ext = false;      // HX_NO_MFMA_EXT=1     rns_extend_wide_kernel (VALU limb products) instead of the matrix-core form
+                                 //                      rns_extend_mfma_kernel (17..40 sources; HX_NO_WIDE_EXTEND implies it)
   int brk_lds_pad_rows = 0;      // HX_BRK_LDS_PAD=n     digit kernel: n more (unused) LDS rows per thread -- lowers its occupancy, an A/B probe
   // fused ciphertext-level paths
   bool no_tensor_multi = false;  // HX_NO_TENSOR_MULTI=1 tensor product + several-primes mod-switch as two steps
@@ -64,6 +66,7 @@ inline Switches read()
   s.no_fast_extend = on("HX_NO_FAST_EXTEND");
   s.no_proth_rns = on("HX_NO_PROTH_RNS");
   s.no_wide_extend = on("HX_NO_WIDE_EXTEND");
+  s.no_mfma_ext = on("HX_NO_MFMA_EXT") || s.no_wide_extend;
   if (const char* e = std::getenv("HX_BRK_LDS_PAD"))
     s.brk_lds_pad_rows = std::atoi(e);
   s.no_tensor_multi = on("HX_NO_TENSOR_MULTI");

@@ -2464,10 +2464,13 @@ def test_proth_form_of_the_fast_rns_kernels(hx, monkeypatch, no_proth_rns):
                 assert np.array_equal(g2[:, b], want), (hps, drop, b)
 
 
+@pytest.mark.parametrize("form", ["mfma", "valu"])
 @pytest.mark.parametrize("eps", ["default", "0.05", "1.0"])
 @pytest.mark.parametrize("n", [17, 24, 25, 33, 36, 40])
-def test_wide_rns_kernel_17_to_40_source_primes(hx, monkeypatch, n, eps):
-    """rns_extend_wide_kernel<24/32/40> (rns_kernels.h; engine.hip launch_extend): the exact basis extension from
+def test_wide_rns_kernel_17_to_40_source_primes(hx, monkeypatch, n, eps, form):
+    """rns_extend_mfma_kernel (rns_mfma_kernels.hip, mfma_ext.h: the target sums as an int8 matrix product on the
+    matrix cores, V_MFMA_I32_32X32X32_I8 -- the default) and rns_extend_wide_kernel<24/32/40> (rns_kernels.h: the same
+    sums as 30-bit-limb multiply-adds, HX_NO_MFMA_EXT=1 -- the control), engine.hip launch_extend: the exact basis extension from
     17..40 source primes -- the 36-prime digits and the 36 dropped special primes of the reference's own benchmark
     chain (benchmarks/bgv_basic.cpp:247, bits = 6400) -- in its HPS form with the Garner redo pass behind it
     (eps = 2^-30: list almost always empty; 0.05: a third of the coefficients redone next to trusted ones; 1.0:
@@ -2477,6 +2480,8 @@ def test_wide_rns_kernel_17_to_40_source_primes(hx, monkeypatch, n, eps):
     later digit's rows in place (:479-561) -- 60-bit sources onto 60-, 56- and 45-bit targets, every word."""
     if eps != "default":
         monkeypatch.setenv("HX_HPS_EPS", eps)
+    if form == "valu":
+        monkeypatch.setenv("HX_NO_MFMA_EXT", "1")
     m, B = 256, 3
     g60, g56, g45 = O.PrimeGen(60, m), O.PrimeGen(56, m), O.PrimeGen(45, m)
     primes = [g60.next() for _ in range(n + 6)] + [g56.next() for _ in range(3)] + [g45.next() for _ in range(2)]
@@ -2487,7 +2492,11 @@ def test_wide_rns_kernel_17_to_40_source_primes(hx, monkeypatch, n, eps):
     # addPrimes: n sources -> 11 new primes
     a = P.rand(src, 31, batch=B)
     d = hx.DoubleCRT(P.g, src, B, a)
+    hx.profileBegin()
     d.addPrimes(rest)
+    names = " ".join(k["kernel"] for k in hx.profileEnd()["kernels"])
+    assert ("rns_extend_mfma_kernel" in names) == (form == "mfma"), names
+    assert ("rns_extend_wide_kernel" in names) == (form == "valu"), names
     got = d.download()
     assert d.getIndexSet() == allp
     for b in range(B):

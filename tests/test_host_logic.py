@@ -874,3 +874,32 @@ def test_work_maps_are_bijections_at_every_launch_shape():
         assert pad.value < 8 * (nk + npb) + 64, (nk, npb, grid, pad.value)   # uneven tiles idle a fringe, not a share
     # the dominant launch of the headline: 16 kept rows x 3 parts x 128 elements = 6144 workgroups, none idle
     assert L.check_md_work(16, 384, C.byref(pad)) == 6144 and pad.value == 0
+
+
+# ---------------------------------------------------------------- round 6: the basis extension as an int8 matrix product
+def test_mfma_basis_extension_limb_split_tables_and_recombination():
+    """helib_amd/csrc/mfma_ext.h (what rns_mfma_kernels.hip computes with V_MFMA_I32_32X32X32_I8): the exact basis
+    extension from 17..40 source primes -- addPrimes / scaleDownToSet / breakIntoDigits at the reference's own
+    benchmark chain, src/DoubleCRT.cpp:565-599, benchmarks/bgv_basic.cpp:247 -- with y_k and the pre-reduced
+    multipliers W_kt 2^(8a) mod t in balanced 8-bit limbs.  Compiled for the host, the MFMA restated as a triple
+    loop over its operand layout: the host-built operand table and accumulator start values, the packing of y, the
+    register -> (target, limb) map, the 80-bit recombination and its bounds, and
+    sum_k y_k W_kt + cnt (-P) mod t for every (coefficient, target) -- random instances and the extreme ones (all
+    y = p_k - 1, cnt = n + 1, multipliers t - 1 - k), 60-bit sources onto 60- / 56- / 45- / 33-bit targets."""
+    src = os.path.join(ROOT, "tests", "cpp", "mfma_ext_test.cpp")
+    so = os.path.join(ROOT, "tests", "cpp", "libmfma_ext_test.so")
+    hdr = os.path.join(ROOT, "helib_amd", "csrc", "mfma_ext.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    L = C.CDLL(so)
+    L.mfma_ext_check.argtypes = [C.c_int] * 6 + [C.c_uint64, C.c_int, C.c_void_p]
+    mx = C.c_uint32(0)
+    for n in (17, 19, 20, 24, 25, 33, 36, 39, 40):
+        steps = (n + 1 + 3) // 4
+        for nt, tb in ((11, (60, 56, 45)), (107, (60, 60, 60)), (5, (33, 40, 59)), (143, (60, 59, 58))):
+            for worst in (0, 1, 2):
+                assert L.mfma_ext_check(n, nt, 60, *tb, 7 + n, worst, C.byref(mx)) == 0, (n, nt, tb, worst)
+                # every start-offset limb sum is a non-negative number below 2^23.5: a01 = S0 + (S1 << 8) fits 32 bits
+                assert mx.value < 2 * steps * 32 * 16384 + 256 < 2 ** 23.5
+    assert L.mfma_ext_check(16, 4, 60, 60, 60, 60, 1, 0, None) == 0      # (n + 1 = 17 slots: five steps)
+    assert L.mfma_ext_check(15, 4, 60, 60, 60, 60, 1, 0, None) == 100    # below the kernels' range
