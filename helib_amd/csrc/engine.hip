@@ -2769,23 +2769,18 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     pl->dev.wide_pack = hx::as_ro(d + o_wide);
     // the same extension on the matrix cores: multipliers as balanced 8-bit limbs in MFMA operand order (mfma_ext.h)
     pl->dev.mfma_a = nullptr;
-    pl->dev.mfma_init = nullptr;
     pl->dev.mfma_steps = 0;
     if (okw && !c->sw.no_mfma_ext) {
-      std::vector<int8_t> ta;
-      std::vector<uint32_t> ti;
+      std::vector<uint8_t> tab;
       std::vector<uint64_t> tqs((size_t)nt);
       for (int t = 0; t < nt; t++)
         tqs[(size_t)t] = tq(t);
-      hx::mfx::build_tables(n, nt, tqs.data(), mfma_w.data(), mfma_negp.data(), ta, ti);
-      const size_t a_bytes = (ta.size() + 255) & ~(size_t)255;
+      hx::mfx::build_tables(n, nt, tqs.data(), mfma_w.data(), mfma_negp.data(), &h[o_upd], tab);
       uint8_t* dm = nullptr;
-      HIPCHK(hipMalloc((void**)&dm, a_bytes + ti.size() * 4));
-      HIPCHK(hipMemcpy(dm, ta.data(), ta.size(), hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(dm + a_bytes, ti.data(), ti.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(hipMalloc((void**)&dm, tab.size()));
+      HIPCHK(hipMemcpy(dm, tab.data(), tab.size(), hipMemcpyHostToDevice));
       pl->blob_mfma = dm;
       pl->dev.mfma_a = dm;
-      pl->dev.mfma_init = reinterpret_cast<const uint32_t*>(dm + a_bytes);
       pl->dev.mfma_steps = (uint32_t)hx::mfx::steps_for(n);
     }
   }

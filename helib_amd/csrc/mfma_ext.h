@@ -63,23 +63,49 @@ HX_MFX_HD inline int row_of(int target_in_tile, int limb)
 // accumulator register `reg` (0..15) of lane half h holds row:
 HX_MFX_HD inline int cd_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
-// sizes of the two device tables
-inline size_t a_table_bytes(int nt, int steps) { return (size_t)tiles_for(nt) * (size_t)steps * 64 * 16; }
-inline size_t init_table_words(int nt) { return (size_t)tiles_for(nt) * 2 * 16; }
+// The device table: per tile, steps x 64 operand vectors (16 bytes each: lane l of step j at vector j 64 + l) followed
+// by EXTRA_VECS vectors of per-target constants -- the kernel stages a whole tile block through its LDS, so everything
+// a tile needs arrives with its operands.  Lane half h owns vectors 8 h .. 8 h + 7 of the extras, as 32-bit words:
+//   [0, 16)  the accumulator start values of its registers
+//   16, 17   floor(2^80 / t) of its targets s = 0, 1 (0 when t < 2^48: that target takes the general reduction)
+//   20 .. 23 t of s = 0 (low, high word), t of s = 1
+//   24 .. 31 P^-1 mod t with its Shoup companion (the in-place update of breakIntoDigits), s = 0 then s = 1: w, floor(w 2^64 / t)
+constexpr int EXTRA_VECS = 16;
+constexpr int EX_INIT = 0, EX_MU80 = 16, EX_Q = 20, EX_UPD = 24;
+HX_MFX_HD inline int tile_vecs(int steps) { return steps * 64 + EXTRA_VECS; }
+inline size_t table_bytes(int nt, int steps) { return (size_t)tiles_for(nt) * (size_t)tile_vecs(steps) * 16; }
+inline size_t a_byte_index(int steps, int tau, int j, int lane, int byte)
+{
+  return (((size_t)tau * tile_vecs(steps) + (size_t)j * 64 + lane) * 16) + byte;
+}
+inline size_t extra_word_index(int steps, int tau, int h, int w)   // in 32-bit words from the start of the table
+{
+  return ((size_t)tau * tile_vecs(steps) + (size_t)steps * 64 + 8 * h) * 4 + w;
+}
 
-// Host: the tables of one plan.
+// The 80-bit value V = hi 2^64 + lo (hi < 2^16) modulo t for 2^48 <= t < 2^60, congruent result in [0, 4t):
+// x = floor(V / 2^48) < 2^32, mu80 = floor(2^80 / t) < 2^32, qh = floor(x mu80 / 2^32) is floor(V / t) or up to 3 less
+// (V/t - x 2^48/t < 2^48/t <= 1; x (2^80/t - mu80) / 2^32 < 1; the floor 1), so lo - qh t (mod 2^64) is the value.
+HX_MFX_HD inline uint64_t red80_lazy(uint64_t lo, uint32_t hi, uint64_t t, uint32_t mu80)
+{
+  const uint32_t x = (hi << 16) | (uint32_t)(lo >> 48);
+  const uint32_t qh = (uint32_t)(((uint64_t)x * mu80) >> 32);
+  return lo - (uint64_t)qh * t;
+}
+
+// Host: the table of one plan.
 //   tq[t]     target primes (2^32 < t < 2^60)
 //   w[t*n+k]  the multipliers (P/p_k) mod t (a scaled plan: / P), < t
 //   negp[t]   -P mod t (a scaled plan: -1 mod t), the multiplier of the cnt slot
-//   a_out     [tiles][steps][64 lanes][16 bytes]   signed bytes
-//   init_out  [tiles][2 lane halves][16 registers] u32
-inline void build_tables(int n, int nt, const uint64_t* tq, const uint64_t* w, const uint64_t* negp,
-                         std::vector<int8_t>& a_out, std::vector<uint32_t>& init_out)
+//   upd[2t], upd[2t+1]  P^-1 mod t and its Shoup companion
+//   tab       table_bytes(nt, steps_for(n)) bytes, layout above
+inline void build_tables(int n, int nt, const uint64_t* tq, const uint64_t* w, const uint64_t* negp, const uint64_t* upd,
+                         std::vector<uint8_t>& tab)
 {
   typedef unsigned __int128 u128;
   const int steps = steps_for(n), slots = 4 * steps, tiles = tiles_for(nt);
-  a_out.assign(a_table_bytes(nt, steps), 0);
-  init_out.assign(init_table_words(nt), 0);
+  tab.assign(table_bytes(nt, steps), 0);
+  uint32_t* words = reinterpret_cast<uint32_t*>(tab.data());
   const uint32_t base = acc_base(steps);
   for (int tau = 0; tau < tiles; tau++) {
     for (int tt = 0; tt < TILE_TARGETS; tt++) {
@@ -99,10 +125,8 @@ inline void build_tables(int n, int nt, const uint64_t* tq, const uint64_t* w, c
         for (int a = 0; a < 8; a++) {
           const uint64_t wa = (uint64_t)(((u128)m << (8 * a)) % q);
           const uint64_t packed = pack_balanced(wa);
-          for (int b = 0; b < 8; b++) {
-            const int lane = row_of(tt, b) + 32 * h, byte = 8 * (k & 1) + a;
-            a_out[(((size_t)tau * steps + j) * 64 + lane) * 16 + byte] = (int8_t)limb_of(packed, b);
-          }
+          for (int b = 0; b < 8; b++)
+            tab[a_byte_index(steps, tau, j, row_of(tt, b) + 32 * h, 8 * (k & 1) + a)] = (uint8_t)(int8_t)limb_of(packed, b);
         }
       }
       // accumulator start: base + the bytes of D = -(base sum_b 2^(8b)) mod t
@@ -113,7 +137,16 @@ inline void build_tables(int n, int nt, const uint64_t* tq, const uint64_t* w, c
       for (int b = 0; b < 8; b++) {
         const uint32_t delta = b < 7 ? (uint32_t)((D >> (8 * b)) & 0xffu) : (uint32_t)(D >> 56);
         const int r = row_of(tt, b), h = (r >> 2) & 1, reg = (r & 3) + 4 * (r >> 3);
-        init_out[((size_t)tau * 2 + h) * 16 + reg] = base + delta;
+        words[extra_word_index(steps, tau, h, EX_INIT + reg)] = base + delta;
+      }
+      const int h = tt >> 1, sidx = tt & 1;
+      if (q >> 48)
+        words[extra_word_index(steps, tau, h, EX_MU80 + sidx)] = (uint32_t)((((u128)1) << 80) / q);
+      words[extra_word_index(steps, tau, h, EX_Q + 2 * sidx)] = (uint32_t)q;
+      words[extra_word_index(steps, tau, h, EX_Q + 2 * sidx + 1)] = (uint32_t)(q >> 32);
+      for (int e = 0; e < 2; e++) {
+        words[extra_word_index(steps, tau, h, EX_UPD + 4 * sidx + 2 * e)] = (uint32_t)upd[2 * (size_t)t + e];
+        words[extra_word_index(steps, tau, h, EX_UPD + 4 * sidx + 2 * e + 1)] = (uint32_t)(upd[2 * (size_t)t + e] >> 32);
       }
     }
   }

@@ -4,7 +4,7 @@
 // own benchmark parameter (src/DoubleCRT.cpp:565-599, :1464-1516, :479-561; benchmarks/bgv_basic.cpp:247, bits = 6400:
 // digits and dropped sets of 36 primes, up to 107 targets).  Method, table layout and the CPU restatement: mfma_ext.h.
 //
-// One wavefront = 64 coefficients, no workgroup-level cooperation (no LDS, no barrier):
+// One wavefront = 64 coefficients; the four wavefronts of a workgroup share only the table reads (step 3):
 //   1. front end, lane = coefficient (as the wide kernel, word for word): y_k = x_k (P/p_k)^-1 mod p_k, the quotient
 //      cnt and the sign from the double-precision sum of y_k / p_k, the plaintext-space correction, value / P;
 //      untrusted lanes go onto the redo list (the Garner pass behind this launch does them) and write nothing.
@@ -171,44 +171,95 @@ rns_extend_mfma_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
   }
 
   // ---- 3. + 4. tiles of four targets ----
+  // Nothing in this loop waits for global memory it has just asked for: a tile's block -- the A operand (steps x 1 KB)
+  // and its targets' constants (accumulator starts, t, floor(2^80 / t): mfma_ext.h) -- goes through the LDS,
+  // double-buffered: the workgroup's four wavefronts need the same block, so each fetches a quarter of the NEXT tile's
+  // (issued before this tile's MFMAs, stored behind its reductions, one barrier per tile); the output / update rows
+  // of the launch sit in the LDS from the start; the words an in-place update reads are requested before the MFMAs.
+  // (Round-6 record, n = 36 onto 107 targets, 2^18 coefficients: every wavefront loading its own operands one step
+  // ahead 303 us, a whole tile ahead in registers 252 us, through the LDS but constants and update words still loaded
+  // where they are used 250 us.)
   const int nt = P.nt, ntile = (nt + 3) >> 2, stride = wide_stride(n);
-  const mf_v4i* __restrict__ At = reinterpret_cast<const mf_v4i*>(P.mfma_a) + lane;
-  const mf_v4i* __restrict__ It = reinterpret_cast<const mf_v4i*>(P.mfma_init) + 4 * h;
   const size_t i0 = wbase + col, i1 = wbase + 32 + col;   // the two coefficients this lane finishes
+  const uint64_t* wide = (const uint64_t*)(uintptr_t)P.wide_pack;
+  const uint32_t rw32 = (uint32_t)row_words;   // (the launch is for row_words < 2^32)
+  constexpr int TV = NSTEP * 64 + mfx::EXTRA_VECS;             // 16-byte vectors of one tile block
+  constexpr int NLD = (TV + MFX_THREADS - 1) / MFX_THREADS;    // ... per thread
+#ifdef MFX_LDS_PAD_KB   // (A/B probe: more LDS per workgroup = fewer resident workgroups)
+  __shared__ mf_v4i a_lds[2 * TV + MFX_LDS_PAD_KB * 64];
+#else
+  __shared__ mf_v4i a_lds[2 * TV];
+#endif
+  __shared__ uint32_t rows_lds[MAX_ROWS + 4];   // dst_row | upd_row << 16 per target
+  const mf_v4i* __restrict__ Ag = reinterpret_cast<const mf_v4i*>(P.mfma_a);
+  mf_v4i stage[NLD];
+  // (no branch around a load: out-of-range threads re-read the block's last vector and drop it)
+  auto fetch = [&](int tau) {
+    static_for<0, NLD>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      const unsigned idx = threadIdx.x + MFX_THREADS * l;
+      stage[l] = Ag[(size_t)tau * TV + (idx < (unsigned)TV ? idx : (unsigned)TV - 1u)];
+    });
+  };
+  auto put = [&](int buf) {
+    static_for<0, NLD>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      const unsigned idx = threadIdx.x + MFX_THREADS * l;
+      if (NLD * MFX_THREADS == TV || idx < (unsigned)TV)
+        a_lds[buf * TV + idx] = stage[l];
+    });
+  };
+  const uint64_t* const safe = A.src + (size_t)A.src_row[0] * row_words;   // what a lane without an update row reads instead
+  fetch(0);
+  for (int t = (int)threadIdx.x; t < ((nt + 3) & ~3); t += MFX_THREADS)
+    rows_lds[t] = t < nt ? ((uint32_t)A.dst_row[t] | ((uint32_t)A.upd_row[t] << 16)) : 0xffffffffu;
+  put(0);
+  __syncthreads();
   for (int tau = 0; tau < ntile; tau++) {
     mf_v16i acc0, acc1;
+    fetch(tau + 1 < ntile ? tau + 1 : tau);   // (the last tile re-reads itself)
+    const mf_v4i* ac = a_lds + (tau & 1) * TV + lane;
+    const mf_v4i* ex = a_lds + (tau & 1) * TV + NSTEP * 64 + 8 * h;   // this lane half's constants
+    // rows of this lane's two targets; the words their in-place updates will read (two coefficients each), requested now
+    const uint32_t rw0 = rows_lds[4 * tau + 2 * h], rw1 = rows_lds[4 * tau + 2 * h + 1];
+    const bool up0 = (rw0 >> 16) != 0xffffu, up1 = (rw1 >> 16) != 0xffffu, ok0 = C0.flags & 1u, ok1 = C1.flags & 1u;
+    const uint64_t u00 = *((up0 && ok0) ? A.upd + ((uint64_t)(rw0 >> 16) * rw32 + i0) : safe);   // [s][cb]
+    const uint64_t u01 = *((up0 && ok1) ? A.upd + ((uint64_t)(rw0 >> 16) * rw32 + i1) : safe);
+    const uint64_t u10 = *((up1 && ok0) ? A.upd + ((uint64_t)(rw1 >> 16) * rw32 + i0) : safe);
+    const uint64_t u11 = *((up1 && ok1) ? A.upd + ((uint64_t)(rw1 >> 16) * rw32 + i1) : safe);
+    __builtin_amdgcn_sched_barrier(0);   // (the loads above are issued here, not where their values are used)
     {
       mf_v16i init;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const mf_v4i v = It[(size_t)tau * 8 + g];
+        const mf_v4i v = ex[g];
         init[4 * g] = v.x;
         init[4 * g + 1] = v.y;
         init[4 * g + 2] = v.z;
         init[4 * g + 3] = v.w;
       }
-      const mf_v4i a0 = At[((size_t)tau * NSTEP) * 64];
+      const mf_v4i a0 = ac[0];
       acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, B0[0], init, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, B1[0], init, 0, 0, 0);
     }
     static_for<1, NSTEP>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      const mf_v4i a = At[((size_t)tau * NSTEP + j) * 64];
+      const mf_v4i a = ac[j * 64];
       acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B0[j], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B1[j], acc1, 0, 0, 0);
     });
+    // the next tile's block into the other buffer now -- before this tile's stores are issued, so that the wait for the
+    // staged vectors does not wait for those stores as well (one counter for both on this target)
+    put((tau + 1) & 1);
+    const mf_v4i mu80s = ex[mfx::EX_MU80 / 4], qs = ex[mfx::EX_Q / 4], up01 = ex[mfx::EX_UPD / 4], up23 = ex[mfx::EX_UPD / 4 + 1];
     static_for<0, 2>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
-      const int t0 = 4 * tau + s, t1 = t0 + 2;          // (uniform) the targets of the lower / upper lanes
-      const int t = h ? t1 : t0;
+      const int t = 4 * tau + 2 * (int)h + s;
       if (t < nt) {
-        // header of the wide kernel's record, per lane (two distinct addresses per wavefront)
-        const uint64_t* rec = (const uint64_t*)(uintptr_t)P.wide_pack + (size_t)t * (size_t)stride;
-        const uint64_t q = rec[0], pmod = rec[1], c64 = rec[2], mu64 = rec[4];
-        const uint32_t wp32 = (uint32_t)(rec[3] >> 32), mu32 = (uint32_t)mu64;
-        const int tc0 = t0 < nt ? t0 : nt - 1, tc1 = t1 < nt ? t1 : nt - 1;
-        const uint32_t drow = h ? A.dst_row[tc1] : A.dst_row[tc0];
-        const uint32_t urow = h ? A.upd_row[tc1] : A.upd_row[tc0];
+        const uint64_t q = s ? (((uint64_t)(uint32_t)qs.w << 32) | (uint32_t)qs.z) : (((uint64_t)(uint32_t)qs.y << 32) | (uint32_t)qs.x);
+        const uint32_t mu80 = (uint32_t)(s ? mu80s.y : mu80s.x);
+        const uint32_t rws = s ? rw1 : rw0, drow = rws & 0xffffu, urow = rws >> 16;
+        const uint64_t* rec = wide + (uint32_t)t * (uint32_t)stride;   // (the wide kernel's record: the rarer constants)
         static_for<0, 2>([&](auto cbc) {
           constexpr int cb = decltype(cbc)::value;
           const MfxCoef& C = cb ? C1 : C0;
@@ -217,7 +268,14 @@ rns_extend_mfma_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
             const uint32_t S[8] = {(uint32_t)acc[8 * s], (uint32_t)acc[8 * s + 1], (uint32_t)acc[8 * s + 2], (uint32_t)acc[8 * s + 3],
                                    (uint32_t)acc[8 * s + 4], (uint32_t)acc[8 * s + 5], (uint32_t)acc[8 * s + 6], (uint32_t)acc[8 * s + 7]};
             const mfx::V80 v = mfx::recombine(S);
-            uint64_t r = mfx_shoup32(v.hi, c64, wp32, q) + mfx_norm(v.lo, q, mu32);   // [0, 3q)
+            uint64_t r;
+            if (mu80) {   // t >= 2^48 (every prime of the benchmark chains): one 32-bit quotient estimate, [0, 4t)
+              r = mfx::red80_lazy(v.lo, v.hi, q, mu80);
+            } else {      // any t > 2^32: 2^64 mod t by a 32-bit Shoup product, the low word by the 32-bit reciprocal
+              const uint64_t c64 = rec[2];
+              const uint32_t wp32 = (uint32_t)(rec[3] >> 32), mu32 = (uint32_t)rec[4];
+              r = mfx_shoup32(v.hi, c64, wp32, q) + mfx_norm(v.lo, q, mu32);   // [0, 3t)
+            }
             r = csub(r, q + q);
             r = csub(r, q);
             if (C.flags & 2u) {
@@ -225,20 +283,23 @@ rns_extend_mfma_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
               const uint64_t dm = ((uint64_t)C.dm_hi << 32) | C.dm_lo;
               uint64_t corr = dm;
               if (!P.corr_unit)
-                corr = mul_shoup(red64(dm, q, mu64), pmod, rec[7], q);
+                corr = mul_shoup(red64(dm, q, rec[4]), rec[1], rec[7], q);
               r = (C.flags & 4u) ? add_mod(r, corr, q) : sub_mod(r, corr, q);
             }
-            const size_t ic = cb ? i1 : i0;
-            if (drow != 0xffff)
-              st_stream1(A.dst + (size_t)drow * row_words + ic, r);
-            if (urow != 0xffff) {
-              uint64_t* u = A.upd + (size_t)urow * row_words + ic;
-              *u = mul_shoup(sub_mod(*u, r, q), rec[5], rec[6], q);
+            const uint64_t ic = cb ? i1 : i0;
+            if (drow != 0xffffu)
+              st_stream1(A.dst + ((uint64_t)drow * rw32 + ic), r);
+            if (urow != 0xffffu) {
+              const uint64_t uold = s ? (cb ? u11 : u10) : (cb ? u01 : u00);
+              const mf_v4i uc = s ? up23 : up01;   // P^-1 mod t, its Shoup companion
+              const uint64_t uw = ((uint64_t)(uint32_t)uc.y << 32) | (uint32_t)uc.x, uwp = ((uint64_t)(uint32_t)uc.w << 32) | (uint32_t)uc.z;
+              A.upd[(uint64_t)urow * rw32 + ic] = mul_shoup(sub_mod(uold, r, q), uw, uwp, q);
             }
           }
         });
       }
     });
+    __syncthreads();
   }
 }
 

@@ -55,8 +55,7 @@ struct ExtPlanDev {
   uint32_t wide_ok;   // 16 < n <= 40 sources, every prime in (2^32, 2^60), the HPS tables exist
   // the same extension on the matrix cores (rns_mfma_kernels.hip; layout and builder: mfma_ext.h): the multipliers as
   // balanced 8-bit limbs in V_MFMA_I32_32X32X32_I8 operand order, the accumulators' start values; mfma_steps = 0: not built
-  const void* mfma_a;        // [tiles][mfma_steps][64 lanes][16 bytes]
-  const uint32_t* mfma_init; // [tiles][2 lane halves][16 registers]
+  const void* mfma_a;        // [tiles][mfma_steps x 64 operand vectors + 16 vectors of per-target constants] (mfma_ext.h)
   uint32_t mfma_steps;       // K = 32 steps of one tile: ceil((n + 1) / 4)
   // Proth-form primes (q = qh 2^32 + 1, ntt_core.h is_proth32; round 5): the fast kernels' products as Montgomery
   // products -- a target whose record carries TgtRec::mont() holds its multipliers, -P mod t and P^-1 mod t times 2^64,

@@ -44,7 +44,7 @@ extern "C" int mfma_ext_check(int n, int nt, int sbits, int tb0, int tb1, int tb
   const int steps = steps_for(n), slots = 4 * steps, tiles = tiles_for(nt);
   if (steps < MIN_STEPS || steps > MAX_STEPS)
     return 100;
-  std::vector<uint64_t> p(n), tq(nt), w((size_t)nt * n), negp(nt);
+  std::vector<uint64_t> p(n), tq(nt), w((size_t)nt * n), negp(nt), upd(2 * (size_t)nt);
   for (int k = 0; k < n; k++)
     p[k] = (((uint64_t)1 << (sbits - 1)) | (rnd() >> (65 - sbits)) | 1);
   for (int t = 0; t < nt; t++) {
@@ -55,12 +55,15 @@ extern "C" int mfma_ext_check(int n, int nt, int sbits, int tb0, int tb1, int tb
     for (int k = 0; k < n; k++)
       w[(size_t)t * n + k] = worst == 2 ? tq[t] - 1 - (uint64_t)k : rnd() % tq[t];
     negp[t] = rnd() % tq[t];
+    upd[2 * (size_t)t] = rnd() % tq[t];
+    upd[2 * (size_t)t + 1] = rnd();
   }
-  std::vector<int8_t> A;
-  std::vector<uint32_t> init;
-  build_tables(n, nt, tq.data(), w.data(), negp.data(), A, init);
-  if (A.size() != a_table_bytes(nt, steps) || init.size() != init_table_words(nt))
+  std::vector<uint8_t> tab;
+  build_tables(n, nt, tq.data(), w.data(), negp.data(), upd.data(), tab);
+  if (tab.size() != table_bytes(nt, steps) || tab.size() != (size_t)tiles * (steps * 64 + 16) * 16)
     return 101;
+  const int8_t* A = reinterpret_cast<const int8_t*>(tab.data());
+  const uint32_t* words = reinterpret_cast<const uint32_t*>(tab.data());
   // 32 coefficients
   std::vector<uint64_t> y((size_t)32 * slots, 0);
   std::vector<uint32_t> cnt(32);
@@ -93,9 +96,9 @@ extern "C" int mfma_ext_check(int n, int nt, int sbits, int tb0, int tb1, int tb
     int32_t acc[32][32];
     for (int r = 0; r < 32; r++)
       for (int c = 0; c < 32; c++)
-        acc[r][c] = (int32_t)init[((size_t)tau * 2 + ((r >> 2) & 1)) * 16 + ((r & 3) + 4 * (r >> 3))];
+        acc[r][c] = (int32_t)words[extra_word_index(steps, tau, (r >> 2) & 1, EX_INIT + (r & 3) + 4 * (r >> 3))];
     for (int j = 0; j < steps; j++)
-      mfma_step(&A[((size_t)tau * steps + j) * 64 * 16], &B[(size_t)j * 64 * 16], acc);
+      mfma_step(&A[a_byte_index(steps, tau, j, 0, 0)], &B[(size_t)j * 64 * 16], acc);
     // lane (col, h): registers 8 s + b of its 16 = rows cd_row(8 s + b, h) = target 4 tau + 2 h + s, limb b
     for (int h = 0; h < 2; h++)
       for (int s = 0; s < 2; s++) {
@@ -128,6 +131,23 @@ extern "C" int mfma_ext_check(int n, int nt, int sbits, int tb0, int tb1, int tb
           want = (want + (u128)cnt[c] * negp[t]) % q;
           if (got != (uint64_t)want)
             return 106;
+          // the short reduction of targets >= 2^48: congruent and below 4 t
+          const uint32_t mu80 = words[extra_word_index(steps, tau, h, EX_MU80 + s)];
+          const uint64_t qtab = words[extra_word_index(steps, tau, h, EX_Q + 2 * s)] |
+                                ((uint64_t)words[extra_word_index(steps, tau, h, EX_Q + 2 * s + 1)] << 32);
+          if (qtab != q)
+            return 109;
+          for (int e = 0; e < 2; e++)
+            if ((words[extra_word_index(steps, tau, h, EX_UPD + 4 * s + 2 * e)] |
+                 ((uint64_t)words[extra_word_index(steps, tau, h, EX_UPD + 4 * s + 2 * e + 1)] << 32)) != upd[2 * (size_t)t + e])
+              return 110;
+          if ((mu80 != 0) != ((q >> 48) != 0))
+            return 107;
+          if (mu80) {
+            const uint64_t lazy = red80_lazy(v.lo, v.hi, q, mu80);
+            if (lazy >= 4 * q || lazy % q != got)
+              return 108;
+          }
         }
       }
   }
