@@ -210,23 +210,44 @@ rns_extend_mfma_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
     });
   };
   const uint64_t* const safe = A.src + (size_t)A.src_row[0] * row_words;   // what a lane without an update row reads instead
+#ifdef MFX_NO_LDS   // (A/B probe: every wavefront keeps the next tile's block in registers -- no sharing, no barrier)
+  mf_v4i an[NSTEP], exn[6];
+  auto fetchw = [&](int tau) {
+    static_for<0, NSTEP>([&](auto jc) { an[decltype(jc)::value] = Ag[(size_t)tau * TV + decltype(jc)::value * 64 + lane]; });
+    static_for<0, 6>([&](auto gc) { exn[decltype(gc)::value] = Ag[(size_t)tau * TV + NSTEP * 64 + 8 * h + decltype(gc)::value]; });
+  };
+  fetchw(0);
+#else
   fetch(0);
+#endif
   for (int t = (int)threadIdx.x; t < ((nt + 3) & ~3); t += MFX_THREADS)
     rows_lds[t] = t < nt ? ((uint32_t)A.dst_row[t] | ((uint32_t)A.upd_row[t] << 16)) : 0xffffffffu;
+#ifndef MFX_NO_LDS
   put(0);
+#endif
   __syncthreads();
   for (int tau = 0; tau < ntile; tau++) {
     mf_v16i acc0, acc1;
+#ifdef MFX_NO_LDS
+    mf_v4i acr[NSTEP], ex[6];
+    static_for<0, NSTEP>([&](auto jc) { acr[decltype(jc)::value] = an[decltype(jc)::value]; });
+    static_for<0, 6>([&](auto gc) { ex[decltype(gc)::value] = exn[decltype(gc)::value]; });
+    fetchw(tau + 1 < ntile ? tau + 1 : tau);
+#else
     fetch(tau + 1 < ntile ? tau + 1 : tau);   // (the last tile re-reads itself)
     const mf_v4i* ac = a_lds + (tau & 1) * TV + lane;
     const mf_v4i* ex = a_lds + (tau & 1) * TV + NSTEP * 64 + 8 * h;   // this lane half's constants
+#endif
     // rows of this lane's two targets; the words their in-place updates will read (two coefficients each), requested now
     const uint32_t rw0 = rows_lds[4 * tau + 2 * h], rw1 = rows_lds[4 * tau + 2 * h + 1];
-    const bool up0 = (rw0 >> 16) != 0xffffu, up1 = (rw1 >> 16) != 0xffffu, ok0 = C0.flags & 1u, ok1 = C1.flags & 1u;
-    const uint64_t u00 = *((up0 && ok0) ? A.upd + ((uint64_t)(rw0 >> 16) * rw32 + i0) : safe);   // [s][cb]
-    const uint64_t u01 = *((up0 && ok1) ? A.upd + ((uint64_t)(rw0 >> 16) * rw32 + i1) : safe);
-    const uint64_t u10 = *((up1 && ok0) ? A.upd + ((uint64_t)(rw1 >> 16) * rw32 + i0) : safe);
-    const uint64_t u11 = *((up1 && ok1) ? A.upd + ((uint64_t)(rw1 >> 16) * rw32 + i1) : safe);
+    uint64_t u00 = 0, u01 = 0, u10 = 0, u11 = 0;   // [s][cb]
+    if (4 * tau < A.nu) {   // (uniform: the targets with an update row come first, ExtArgs::nu of them)
+      const bool up0 = (rw0 >> 16) != 0xffffu, up1 = (rw1 >> 16) != 0xffffu, ok0 = C0.flags & 1u, ok1 = C1.flags & 1u;
+      u00 = *((up0 && ok0) ? A.upd + ((uint64_t)(rw0 >> 16) * rw32 + i0) : safe);
+      u01 = *((up0 && ok1) ? A.upd + ((uint64_t)(rw0 >> 16) * rw32 + i1) : safe);
+      u10 = *((up1 && ok0) ? A.upd + ((uint64_t)(rw1 >> 16) * rw32 + i0) : safe);
+      u11 = *((up1 && ok1) ? A.upd + ((uint64_t)(rw1 >> 16) * rw32 + i1) : safe);
+    }
     __builtin_amdgcn_sched_barrier(0);   // (the loads above are issued here, not where their values are used)
     {
       mf_v16i init;
@@ -238,19 +259,29 @@ rns_extend_mfma_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
         init[4 * g + 2] = v.z;
         init[4 * g + 3] = v.w;
       }
-      const mf_v4i a0 = ac[0];
-      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, B0[0], init, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, B1[0], init, 0, 0, 0);
+      mf_v4i a[NSTEP];   // (all of the tile's operand first: the MFMAs then run back to back, not one LDS round trip apart)
+#ifdef MFX_NO_LDS
+      static_for<0, NSTEP>([&](auto jc) { a[decltype(jc)::value] = acr[decltype(jc)::value]; });
+#else
+      static_for<0, NSTEP>([&](auto jc) { a[decltype(jc)::value] = ac[decltype(jc)::value * 64]; });
+#endif
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], B0[0], init, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], B1[0], init, 0, 0, 0);
+#ifdef MFX_EXP_NOMFMA    // (timing probe: one MFMA step per tile instead of all)
+      static_for<1, 1>([&](auto jc) {
+#else
+      static_for<1, NSTEP>([&](auto jc) {
+#endif
+        constexpr int j = decltype(jc)::value;
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[j], B0[j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[j], B1[j], acc1, 0, 0, 0);
+      });
     }
-    static_for<1, NSTEP>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      const mf_v4i a = ac[j * 64];
-      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B0[j], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B1[j], acc1, 0, 0, 0);
-    });
     // the next tile's block into the other buffer now -- before this tile's stores are issued, so that the wait for the
     // staged vectors does not wait for those stores as well (one counter for both on this target)
+#ifndef MFX_NO_LDS
     put((tau + 1) & 1);
+#endif
     const mf_v4i mu80s = ex[mfx::EX_MU80 / 4], qs = ex[mfx::EX_Q / 4], up01 = ex[mfx::EX_UPD / 4], up23 = ex[mfx::EX_UPD / 4 + 1];
     static_for<0, 2>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
@@ -287,7 +318,11 @@ rns_extend_mfma_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
               r = (C.flags & 4u) ? add_mod(r, corr, q) : sub_mod(r, corr, q);
             }
             const uint64_t ic = cb ? i1 : i0;
+#ifdef MFX_EXP_NOSTORE   // (timing probe: results dropped unless a value that never occurs shows up)
+            if (drow != 0xffffu && r == 0xdeadbeefdeadbeefull)
+#else
             if (drow != 0xffffu)
+#endif
               st_stream1(A.dst + ((uint64_t)drow * rw32 + ic), r);
             if (urow != 0xffffu) {
               const uint64_t uold = s ? (cb ? u11 : u10) : (cb ? u01 : u00);
@@ -299,7 +334,9 @@ rns_extend_mfma_kernel(ExtPlanDev P, ExtArgs A, size_t row_words)
         });
       }
     });
+#ifndef MFX_NO_LDS
     __syncthreads();
+#endif
   }
 }
 

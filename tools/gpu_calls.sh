@@ -15,6 +15,7 @@
 #   pmc_sq           two more --pmc passes: SQ VALU activity + GRBM_GUI_ACTIVE (clock), LDS bank conflicts -> pmc_sq_summary.txt
 #   scatter          bench.py --scatter at N = 1, and at two ranks on one device (gloo)
 #   pmc_config5      --pmc passes (traffic, VALU, LDS conflicts) over the config 5 transform driver -> pmc_config5_summary.txt
+#   pmc_mfma         --pmc passes over tools/prof_mfma_ext.py (the matrix-core basis extension, 36 -> 107 primes) -> pmc_mfma_summary.txt
 #   bluestein        tools/prof_bluestein.py Good-Thomas x Rader (default), fused Bluestein (HX_NO_PFA) and old chain + kernel trace of the default
 #   levels           tools/prof_levels.py for both schemes
 #   ab:A,B,...       same-box A/B of the fresh multiply, two rounds; A = default | env:VAR=1 | a variant
@@ -165,6 +166,13 @@ PY
       done
       python tools/rocpd_pmc.py $out/pmc5_FETCH_SIZE $out/pmc5_WRITE_SIZE $out/pmc5_SQ_INSTS_VALU $out/pmc5_SQ_LDS_BANK_CONFLICT > $out/pmc_config5_summary.txt 2>&1
       grep -E "pfa_row" $out/pmc_config5_summary.txt | cut -c1-220 ;;
+    pmc_mfma)
+      for ctr in "SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" FETCH_SIZE WRITE_SIZE; do
+        tag=$(echo $ctr | cut -d" " -f1)
+        (cd /tmp && timeout 300 rocprofv3 --pmc $ctr -d $R/$out/pmcm_$tag -- python3 $R/tools/prof_mfma_ext.py > /dev/null 2> $R/$out/pmcm_$tag.err); echo "pmc_mfma $tag rc=$?"
+      done
+      python tools/rocpd_pmc.py $out/pmcm_SQ_INSTS_VALU $out/pmcm_SQ_ACTIVE_INST_VALU $out/pmcm_SQ_VALU_MFMA_BUSY_CYCLES $out/pmcm_FETCH_SIZE $out/pmcm_WRITE_SIZE > $out/pmc_mfma_summary.txt 2>&1
+      grep -E "rns_extend_mfma|rns_extend_wide" $out/pmc_mfma_summary.txt | cut -c1-220 ;;
     levels)
       timeout 300 python tools/prof_levels.py bgv > $out/levels_bgv.json 2> $out/levels_bgv.err; cut -c1-1500 $out/levels_bgv.json
       timeout 300 python tools/prof_levels.py ckks > $out/levels_ckks.json 2> $out/levels_ckks.err; cut -c1-1500 $out/levels_ckks.json ;;
