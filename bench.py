@@ -793,6 +793,15 @@ def kernel_table(prof, n, B, l, k, d, mults):
             ext = d * (l + k) - l
             byts = 8 * n * (B * (ext + l + 2 * l + 2 * (l + k)) + 2 * d * (l + k))
             what = "extension rows + s^2 rows + parts (1),(s) in, 2(L+K) rows out per element; key rows once per batch"
+        elif name.startswith("rns_extend_mfma_kernel<") and d > 0:
+            # the basis extension of one digit on the matrix cores (bits = 6400: digits of 36 / 36 / 35 primes onto the
+            # other 107 / 108): 128 coefficients per workgroup; n from the kernel's step count (4 steps - 1 >= n + ...)
+            steps = int(name[len("rns_extend_mfma_kernel<"):].split(">")[0])
+            nsrc = next((c for c in ((l + d - 1) // d, l // d) if (c + 1 + 3) // 4 == steps), 4 * steps - 1)
+            ntg = l + k - nsrc
+            coefs = min(w * 128, B * n)
+            byts, what = coefs * 8 * (nsrc + ntg), f"{nsrc} source rows in, {ntg} target rows out (the later digits' in-place update words not counted)"
+            macs = coefs * (32 * steps) * (32 * ((ntg + 3) // 4))
         elif name.startswith("break_digits"):
             byts, what = 8 * n * B * (l + d * (l + k) - l + d), "L rows in, D(L+K)-L extension rows + D fraction rows out"
         elif name.startswith("moddown_S_kernel"):
@@ -808,6 +817,12 @@ def kernel_table(prof, n, B, l, k, d, mults):
             ach = byts / (kk["avg_us"] * 1e-6) / 1e9
             row.update({"algorithmic_bytes_per_launch": int(byts), "bytes_are": what, "achieved_GBps": round(ach, 1),
                         "frac": round(ach / HBM_PEAK_GBS, 4)})
+        if name.startswith("rns_extend_mfma_kernel<") and d > 0:
+            # the one kernel of this path with its sums on the matrix cores: int8 multiply-adds of the limb matrix
+            # product, against the dense int8 rate the micro-benchmark reaches (tools/ubench/mfma_i8_bench.hip: 3.6 POPS
+            # of the guide's >= 3.9; two operations per multiply-add)
+            row.update({"int8_macs_per_launch": int(macs), "achieved_int8_TOPS": round(2 * macs / (kk["avg_us"] * 1e-6) / 1e12, 1),
+                        "frac_of_dense_int8_peak": round(2 * macs / (kk["avg_us"] * 1e-6) / 1e12 / 3944.0, 4)})
         if name in VALU_PER_WAVE and logn == 14:
             # the integer rate these kernels run at -- VALU lane-operations and 64-bit modular
             # multiplications (Shoup products: N/2 log2 N butterflies, + 2N for the mod-down apply's load / store)
