@@ -20,7 +20,9 @@ constexpr int REPS = 8;       // tile loops per launch
 
 __device__ __forceinline__ uint64_t csub64(uint64_t x, uint64_t m) { return x >= m ? x - m : x; }
 
-// MODE 1: MFMAs only; 2: reductions only; 3: both (the kernel's tile loop without its memory traffic)
+// MODE 1: MFMAs only; 2: reductions only; 3: both (the kernel's tile loop without its memory traffic);
+// 4: as 3 with the A operand of every step read from the LDS (ds_read_b128) as the kernel does; 5: as 4 with a
+// workgroup barrier per tile; 6: MFMAs only, A from the LDS
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) tile_loop(uint64_t* out, uint64_t q, uint32_t mu80, int tiles)
 {
@@ -32,6 +34,14 @@ __global__ void __launch_bounds__(256, 2) tile_loop(uint64_t* out, uint64_t q, u
     b1[j] = v4i{(int)(lane * 0x01030507u + j), (int)(lane * 5u + j), (int)(lane ^ (j * 0x01111111u)), j + 1};
     a[j] = v4i{(int)(lane + 3 * j), (int)(lane * 3u + j), (int)(lane ^ (j * 0x10101010u)), j + 2};
   }
+  __shared__ v4i a_lds[STEPS * 64];
+  constexpr bool LDSA = MODE >= 4;
+  constexpr bool DO_MFMA = MODE != 2, DO_RED = MODE != 1 && MODE != 6;
+  if (LDSA) {
+    for (int j = (int)threadIdx.x; j < STEPS * 64; j += 256)
+      a_lds[j] = a[j / 64];
+    __syncthreads();
+  }
   uint64_t sink = 0;
   v16i init;
 #pragma unroll
@@ -40,11 +50,12 @@ __global__ void __launch_bounds__(256, 2) tile_loop(uint64_t* out, uint64_t q, u
   for (int rep = 0; rep < REPS; rep++)
     for (int tau = 0; tau < tiles; tau++) {
       v16i acc0 = init, acc1 = init;
-      if constexpr (MODE != 2) {
+      if constexpr (DO_MFMA) {
 #pragma unroll
         for (int j = 0; j < STEPS; j++) {
-          acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[j], b0[j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[j], b1[j], acc1, 0, 0, 0);
+          const v4i aj = LDSA ? a_lds[j * 64 + ((lane + tau) & 63)] : a[j];
+          acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aj, b0[j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aj, b1[j], acc1, 0, 0, 0);
         }
       } else {
 #pragma unroll
@@ -53,7 +64,7 @@ __global__ void __launch_bounds__(256, 2) tile_loop(uint64_t* out, uint64_t q, u
           acc1[r] = (acc1[r] + 3 * tau + (int)sink) & 0xffffff;
         }
       }
-      if constexpr (MODE != 1) {
+      if constexpr (DO_RED) {
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -72,6 +83,8 @@ __global__ void __launch_bounds__(256, 2) tile_loop(uint64_t* out, uint64_t q, u
         sink ^= (uint64_t)(uint32_t)acc0[lane & 15] ^ (uint32_t)acc1[(lane + 1) & 15];
       }
       init[0] = (int)(5242880u + (uint32_t)(sink & 0xff));
+      if constexpr (MODE == 5)
+        __syncthreads();
     }
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sink;
 }
@@ -111,11 +124,14 @@ static int run(const char* name, uint64_t* d, int waves_per_simd)
 int main()
 {
   uint64_t* d;
-  CHECK(hipMalloc(&d, sizeof(uint64_t) * 256 * 4 * 256));
-  for (int w = 1; w <= 3; w++) {
+  CHECK(hipMalloc(&d, sizeof(uint64_t) * 256 * 4 * 256 * 2));
+  for (int w = 1; w <= 4; w++) {
     if (run<1>("mfma only (20 per tile)", d, w)) return 1;
     if (run<2>("4 reductions only", d, w)) return 1;
     if (run<3>("mfma + 4 reductions", d, w)) return 1;
+    if (run<6>("mfma only, A from LDS", d, w)) return 1;
+    if (run<4>("mfma (A from LDS) + 4 red.", d, w)) return 1;
+    if (run<5>("... + barrier per tile", d, w)) return 1;
   }
   (void)hipFree(d);
   return 0;
