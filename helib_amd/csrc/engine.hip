@@ -2510,10 +2510,14 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   // rns_extend_wide_kernel (17..40 source primes): per-target record of 8 + n words, padded so that the last
   // record's group-of-four multiplier reads stay inside the blob
   const bool wide_cand = n > 16 && n <= 40 && !c->sw.no_wide_extend;
+  // 9 .. 16 sources (the dropped primes of a CKKS level-2 mod-switch): the fast kernels' plans, whose HPS-form launches
+  // go to the matrix-core kernel too -- it reads the wide record's header for its rarer constants
+  const bool mfma_small = n >= c->sw.mfma_min_n && n <= 16 && n >= 8 && !c->sw.no_mfma_ext && !c->sw.no_hps;
+  const bool wide_rec = wide_cand || mfma_small;
   const size_t wide_stride = (size_t)hx::wide_stride(n);
-  size_t o_wide = wide_cand ? take((size_t)nt * wide_stride) : 0;
+  size_t o_wide = wide_rec ? take((size_t)nt * wide_stride) : 0;
   std::vector<uint64_t> h(off, 0);
-  std::vector<uint64_t> mfma_w(wide_cand ? (size_t)nt * n : 0), mfma_negp(wide_cand ? (size_t)nt : 0);   // (mfma_ext.h)
+  std::vector<uint64_t> mfma_w(wide_rec ? (size_t)nt * n : 0), mfma_negp(wide_rec ? (size_t)nt : 0);   // (mfma_ext.h)
   hxh::BigU P(1);
   for (int k = 0; k < n; k++) {
     h[o_srcq + k] = p[k];
@@ -2661,7 +2665,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
         h[o_Wp2 + 2 * (size_t)k + 1] = hxh::shoup(w, ptxt);
       }
     }
-    for (int t = 0; t < nt && hps_ok && wide_cand; t++) {
+    for (int t = 0; t < nt && hps_ok && wide_rec; t++) {
       // WideRec: q, P mod t (scaled: 1), 2^64 mod t with its Shoup companion, floor(2^64/t), P^-1 mod t with its
       // companion, the companion of P mod t; then the multipliers (P/p_k) mod t (scaled: / P) as 30-bit limbs
       const uint64_t q = tq(t);
@@ -2770,7 +2774,8 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
     // the same extension on the matrix cores: multipliers as balanced 8-bit limbs in MFMA operand order (mfma_ext.h)
     pl->dev.mfma_a = nullptr;
     pl->dev.mfma_steps = 0;
-    if (okw && !c->sw.no_mfma_ext) {
+    const bool oks = mfma_small && pl->dev.hps_ok;   // (hps_ok: the fast kernels' preconditions hold and the HPS tables exist)
+    if ((okw || oks) && !c->sw.no_mfma_ext) {
       std::vector<uint8_t> tab;
       std::vector<uint64_t> tqs((size_t)nt);
       for (int t = 0; t < nt; t++)
@@ -2834,10 +2839,14 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args_in, s
     const bool hps = pl->dev.hps_ok && n >= hps_min_n(c) && args.upd == nullptr && row_words < ((size_t)1 << 32);
     if (hps)
       CHK(redo_prepare(c, row_words, &args.redo));
+    const bool mfma = hps && pl->dev.mfma_steps != 0;
+    if (mfma)   // the HPS form with its target sums on the matrix cores; the Garner form below over its redo list
+      HIPCHK(hx::launch_rns_extend_mfma(pl->dev, args, row_words, c->stream));
 #define HX_EXT_FAST(NN)                                                                                            \
   case NN:                                                                                                         \
     if (hps) {                                                                                                     \
-      HX_LAUNCH((hx::rns_extend_fast_kernel<NN, true>), grid, block, 0, c->stream, pl->dev, args, row_words);      \
+      if (!mfma)                                                                                                   \
+        HX_LAUNCH((hx::rns_extend_fast_kernel<NN, true>), grid, block, 0, c->stream, pl->dev, args, row_words);    \
       HX_LAUNCH((hx::rns_extend_fast_kernel<NN, false>), REDO_GRID, block, 0, c->stream, pl->dev, args, row_words); \
     } else {                                                                                                       \
       HX_LAUNCH((hx::rns_extend_fast_kernel<NN, false>), grid, block, 0, c->stream, pl->dev, args, row_words);     \

@@ -27,6 +27,7 @@ struct Switches {
   bool no_wide_extend = false;   // HX_NO_WIDE_EXTEND=1  generic rns_extend_kernel<40> instead of rns_extend_wide_kernel (17..40 sources)
   bool no_mfma_ext = false;      // HX_NO_MFMA_EXT=1     rns_extend_wide_kernel (VALU limb products) instead of the matrix-core form
                                  //                      rns_extend_mfma_kernel (17..40 sources; HX_NO_WIDE_EXTEND implies it)
+  int mfma_min_n = 9;            // HX_MFMA_MIN_N=n      ... from n source primes on (9 .. 16: the fast kernels' plans; 17 .. 40 always)
   int brk_lds_pad_rows = 0;      // HX_BRK_LDS_PAD=n     digit kernel: n more (unused) LDS rows per thread -- lowers its occupancy, an A/B probe
   // fused ciphertext-level paths
   bool no_tensor_multi = false;  // HX_NO_TENSOR_MULTI=1 tensor product + several-primes mod-switch as two steps
@@ -67,6 +68,8 @@ inline Switches read()
   s.no_proth_rns = on("HX_NO_PROTH_RNS");
   s.no_wide_extend = on("HX_NO_WIDE_EXTEND");
   s.no_mfma_ext = on("HX_NO_MFMA_EXT") || s.no_wide_extend;
+  if (const char* e = std::getenv("HX_MFMA_MIN_N"))
+    s.mfma_min_n = std::atoi(e);
   if (const char* e = std::getenv("HX_BRK_LDS_PAD"))
     s.brk_lds_pad_rows = std::atoi(e);
   s.no_tensor_multi = on("HX_NO_TENSOR_MULTI");

@@ -2464,24 +2464,10 @@ def test_proth_form_of_the_fast_rns_kernels(hx, monkeypatch, no_proth_rns):
                 assert np.array_equal(g2[:, b], want), (hps, drop, b)
 
 
-@pytest.mark.parametrize("form", ["mfma", "valu"])
-@pytest.mark.parametrize("eps", ["default", "0.05", "1.0"])
-@pytest.mark.parametrize("n", [17, 24, 25, 33, 36, 40])
-def test_wide_rns_kernel_17_to_40_source_primes(hx, monkeypatch, n, eps, form):
-    """rns_extend_mfma_kernel (rns_mfma_kernels.hip, mfma_ext.h: the target sums as an int8 matrix product on the
-    matrix cores, V_MFMA_I32_32X32X32_I8 -- the default) and rns_extend_wide_kernel<24/32/40> (rns_kernels.h: the same
-    sums as 30-bit-limb multiply-adds, HX_NO_MFMA_EXT=1 -- the control), engine.hip launch_extend: the exact basis extension from
-    17..40 source primes -- the 36-prime digits and the 36 dropped special primes of the reference's own benchmark
-    chain (benchmarks/bgv_basic.cpp:247, bits = 6400) -- in its HPS form with the Garner redo pass behind it
-    (eps = 2^-30: list almost always empty; 0.05: a third of the coefficients redone next to trusted ones; 1.0:
-    all of them).  On a small ring (m = 256) so that the oracle's O(n^2) Garner stays cheap: addPrimes (toPoly +
-    FFT on the new primes, src/DoubleCRT.cpp:565-599), scaleDownToSet for ptxtSpace 65537 / 2 / 1 with fdelta and
-    norms (:1464-1516, src/Ctxt.cpp:466-507), and breakIntoDigits with an n-prime digit whose fix-up updates the
-    later digit's rows in place (:479-561) -- 60-bit sources onto 60-, 56- and 45-bit targets, every word."""
-    if eps != "default":
-        monkeypatch.setenv("HX_HPS_EPS", eps)
-    if form == "valu":
-        monkeypatch.setenv("HX_NO_MFMA_EXT", "1")
+def _many_source_extension_cases(hx, n, form, valu_kernel, digits_too):
+    """addPrimes, scaleDownToSet (ptxtSpace 65537 / 2 / 1, fdelta, norms) and -- digits_too -- breakIntoDigits with an
+    n-prime digit, from n 60-bit source primes onto 60- / 56- / 45-bit ones on a small ring; every word against the
+    oracle; the extension kernel that ran is checked by name."""
     m, B = 256, 3
     g60, g56, g45 = O.PrimeGen(60, m), O.PrimeGen(56, m), O.PrimeGen(45, m)
     primes = [g60.next() for _ in range(n + 6)] + [g56.next() for _ in range(3)] + [g45.next() for _ in range(2)]
@@ -2496,7 +2482,7 @@ def test_wide_rns_kernel_17_to_40_source_primes(hx, monkeypatch, n, eps, form):
     d.addPrimes(rest)
     names = " ".join(k["kernel"] for k in hx.profileEnd()["kernels"])
     assert ("rns_extend_mfma_kernel" in names) == (form == "mfma"), names
-    assert ("rns_extend_wide_kernel" in names) == (form == "valu"), names
+    assert (valu_kernel in names) == (form == "valu"), names
     got = d.download()
     assert d.getIndexSet() == allp
     for b in range(B):
@@ -2516,6 +2502,8 @@ def test_wide_rns_kernel_17_to_40_source_primes(hx, monkeypatch, n, eps, form):
                 assert np.array_equal(got[r, b], want[rest.index(i)]), (ptxt, i, b)
             assert np.allclose(fd[0, b], wfd, rtol=0, atol=1e-9 * max(1.0, float(ptxt)))
             assert np.isclose(nrm[0, b], O.embedding_largest_coeff(m, wfd), rtol=1e-9)
+    if not digits_too:
+        return
     # breakIntoDigits: digits of n and 4 primes (in both orders), special primes = the rest
     own = src + rest[:4]
     sp = rest[4:]
@@ -2528,6 +2516,45 @@ def test_wide_rns_kernel_17_to_40_source_primes(hx, monkeypatch, n, eps, form):
             want, wn = P.o.break_into_digits(own, y[:, b], digits, own + sp, want_norms=True)
             assert np.array_equal(got[:, b].reshape(len(digits), nall, P.N), want)
             assert np.allclose(nr[:, b], wn, rtol=1e-9)
+
+
+
+
+@pytest.mark.parametrize("form", ["mfma", "valu"])
+@pytest.mark.parametrize("eps", ["default", "0.05", "1.0"])
+@pytest.mark.parametrize("n", [17, 24, 25, 33, 36, 40])
+def test_wide_rns_kernel_17_to_40_source_primes(hx, monkeypatch, n, eps, form):
+    """rns_extend_mfma_kernel (rns_mfma_kernels.hip, mfma_ext.h: the target sums as an int8 matrix product on the
+    matrix cores, V_MFMA_I32_32X32X32_I8 -- the default) and rns_extend_wide_kernel<24/32/40> (rns_kernels.h: the same
+    sums as 30-bit-limb multiply-adds, HX_NO_MFMA_EXT=1 -- the control), engine.hip launch_extend: the exact basis extension from
+    17..40 source primes -- the 36-prime digits and the 36 dropped special primes of the reference's own benchmark
+    chain (benchmarks/bgv_basic.cpp:247, bits = 6400) -- in its HPS form with the Garner redo pass behind it
+    (eps = 2^-30: list almost always empty; 0.05: a third of the coefficients redone next to trusted ones; 1.0:
+    all of them).  On a small ring (m = 256) so that the oracle's O(n^2) Garner stays cheap: addPrimes (toPoly +
+    FFT on the new primes, src/DoubleCRT.cpp:565-599), scaleDownToSet for ptxtSpace 65537 / 2 / 1 with fdelta and
+    norms (:1464-1516, src/Ctxt.cpp:466-507), and breakIntoDigits with an n-prime digit whose fix-up updates the
+    later digit's rows in place (:479-561) -- 60-bit sources onto 60-, 56- and 45-bit targets, every word."""
+    if eps != "default":
+        monkeypatch.setenv("HX_HPS_EPS", eps)
+    if form == "valu":
+        monkeypatch.setenv("HX_NO_MFMA_EXT", "1")
+    _many_source_extension_cases(hx, n, form, "rns_extend_wide_kernel", True)
+
+
+@pytest.mark.parametrize("form", ["mfma", "valu"])
+@pytest.mark.parametrize("eps", ["default", "0.05", "1.0"])
+@pytest.mark.parametrize("n", [9, 11, 12, 16])
+def test_mfma_rns_kernel_9_to_16_source_primes(hx, monkeypatch, n, eps, form):
+    """The matrix-core basis extension (rns_extend_mfma_kernel, 3 .. 5 MFMA steps) on the plans of the fast kernels:
+    9 .. 16 source primes -- the 8 + 2 / 8 + 3 dropped primes of a CKKS level-2 mod-switch (benchmarks/ckks_basic.cpp,
+    src/Ctxt.cpp:466-507 through src/DoubleCRT.cpp:1464-1516) -- in the HPS form with rns_extend_fast_kernel<n, Garner>
+    over its redo list; the control (HX_NO_MFMA_EXT=1) is rns_extend_fast_kernel<n, HPS>.  addPrimes and scaleDownToSet
+    for ptxtSpace 65537 / 2 / 1 with fdelta and norms, 60-bit sources onto 60- / 56- / 45-bit targets, every word."""
+    if eps != "default":
+        monkeypatch.setenv("HX_HPS_EPS", eps)
+    if form == "valu":
+        monkeypatch.setenv("HX_NO_MFMA_EXT", "1")
+    _many_source_extension_cases(hx, n, form, "rns_extend_fast_kernel<%d, true" % n, False)
 
 
 def test_tensor_bring_to_set_when_none_of_the_listed_primes_is_there(hx):
