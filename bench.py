@@ -1000,7 +1000,7 @@ def make_roofline(table, n, B, l, k, d, b2b=None):
     # recorded PMC traffic of the same kernel and launch shape (cannot be collected inside this process)
     traffic, src = None, None
     short = dom["kernel"].replace(", false>", ">").replace(", true>", ",plain>")
-    for rec in ("r05_pmc_roofline_kernel_traffic.json", "r04_pmc_roofline_kernel_traffic.json", "r03_pmc_roofline_kernel_traffic.json"):
+    for rec in ("r06_pmc_roofline_kernel_traffic.json", "r05_pmc_roofline_kernel_traffic.json", "r04_pmc_roofline_kernel_traffic.json", "r03_pmc_roofline_kernel_traffic.json"):
         t, sname = recorded_traffic(rec, short, dom["workgroups"], n)
         if t is not None:
             traffic, src = t, sname

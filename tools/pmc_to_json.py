@@ -19,7 +19,7 @@ N, B, L = 16384, 128, 16
 # the launches of one level-1 fresh multiply of the 128-pair batch: (name prefix, workgroups, launches per multiply)
 ONE = [("void hx::ntt_moddown_apply_kernel<14, false>", 8192, 1), ("void hx::ntt_moddown_apply_tensor_kernel<14, false>", 6144, 1),
        ("void hx::keyswitch_kernel<3>", 8206, 1), ("void hx::ntt_row_kernel<14, false, 8>", 6400, 1),
-       ("void hx::break_digits_fast_kernel<false, true>", 16384, 1), ("void hx::ntt_row_kernel<14, true, 1>", 2048, 1),
+       ("void hx::break_digits_fast_kernel<true, true>", 16384, 1), ("void hx::ntt_row_kernel<14, true, 1>", 2048, 1),
        ("void hx::ntt_moddown_prep_tensor_kernel<14>", 384, 1), ("void hx::ntt_moddown_prep_kernel<14>", 512, 1),
        ("void hx::moddown_S_kernel<0>", 8192, 2), ("void hx::embed_norm_r16_kernel<hx::NormSrcXS>", 512, 1),
        ("void hx::embed_norm_r16_kernel<hx::NormSrcXS>", 384, 1), ("void hx::embed_norm_r16_kernel<hx::NormSrcF64>", 384, 1)]
