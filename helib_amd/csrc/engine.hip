@@ -2512,7 +2512,7 @@ static int get_plan(hx_ctx* c, const std::vector<int>& src, const std::vector<in
   const bool wide_cand = n > 16 && n <= 40 && !c->sw.no_wide_extend;
   // 9 .. 16 sources (the dropped primes of a CKKS level-2 mod-switch): the fast kernels' plans, whose HPS-form launches
   // go to the matrix-core kernel too -- it reads the wide record's header for its rarer constants
-  const bool mfma_small = n >= c->sw.mfma_min_n && n <= 16 && n >= 8 && !c->sw.no_mfma_ext && !c->sw.no_hps;
+  const bool mfma_small = n >= c->sw.mfma_min_n && n <= 16 && n >= 4 && !c->sw.no_mfma_ext && !c->sw.no_hps;
   const bool wide_rec = wide_cand || mfma_small;
   const size_t wide_stride = (size_t)hx::wide_stride(n);
   size_t o_wide = wide_rec ? take((size_t)nt * wide_stride) : 0;
@@ -2836,10 +2836,11 @@ static int launch_extend(hx_ctx* c, const ExtPlan* pl, const ExtArgs& args_in, s
   if (pl->dev.fast16_ok) {
     // HPS form + Garner over its redo list when the plan has the tables and no row is updated in place (an in-place
     // update cannot be redone); otherwise Garner over everything
-    const bool hps = pl->dev.hps_ok && n >= hps_min_n(c) && args.upd == nullptr && row_words < ((size_t)1 << 32);
+    // (the plan carries the matrix-core tables from mfma_min_n sources on: below hps_min_n too)
+    const bool mfma = pl->dev.hps_ok && pl->dev.mfma_steps != 0 && args.upd == nullptr && row_words < ((size_t)1 << 32);
+    const bool hps = mfma || (pl->dev.hps_ok && n >= hps_min_n(c) && args.upd == nullptr && row_words < ((size_t)1 << 32));
     if (hps)
       CHK(redo_prepare(c, row_words, &args.redo));
-    const bool mfma = hps && pl->dev.mfma_steps != 0;
     if (mfma)   // the HPS form with its target sums on the matrix cores; the Garner form below over its redo list
       HIPCHK(hx::launch_rns_extend_mfma(pl->dev, args, row_words, c->stream));
 #define HX_EXT_FAST(NN)                                                                                            \

@@ -39,7 +39,7 @@ namespace hx {
 namespace mfx {
 
 constexpr int TILE_TARGETS = 4;      // targets per 32-row tile (8 limb rows each)
-constexpr int MIN_STEPS = 3, MAX_STEPS = 11;   // n = 8..40 sources (+ the cnt slot) in groups of four
+constexpr int MIN_STEPS = 2, MAX_STEPS = 11;   // n = 4..40 sources (+ the cnt slot) in groups of four
 
 HX_MFX_HD inline int steps_for(int n) { return (n + 1 + 3) / 4; }   // K = 32 steps; slot 4 steps - 1 carries cnt
 HX_MFX_HD inline int tiles_for(int nt) { return (nt + TILE_TARGETS - 1) / TILE_TARGETS; }

@@ -332,6 +332,7 @@ static hipError_t launch_mfx(const ExtPlanDev& P, const ExtArgs& A, size_t row_w
 hipError_t launch_rns_extend_mfma(const ExtPlanDev& P, const ExtArgs& A, size_t row_words, hipStream_t st)
 {
   switch ((int)P.mfma_steps) {
+    case 2: return launch_mfx<2>(P, A, row_words, st);
     case 3: return launch_mfx<3>(P, A, row_words, st);
     case 4: return launch_mfx<4>(P, A, row_words, st);
     case 5: return launch_mfx<5>(P, A, row_words, st);

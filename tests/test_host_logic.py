@@ -879,7 +879,7 @@ def test_work_maps_are_bijections_at_every_launch_shape():
 # ---------------------------------------------------------------- round 6: the basis extension as an int8 matrix product
 def test_mfma_basis_extension_limb_split_tables_and_recombination():
     """helib_amd/csrc/mfma_ext.h (what rns_mfma_kernels.hip computes with V_MFMA_I32_32X32X32_I8): the exact basis
-    extension from 8..40 source primes -- addPrimes / scaleDownToSet / breakIntoDigits at the reference's own
+    extension from 4..40 source primes -- addPrimes / scaleDownToSet / breakIntoDigits at the reference's own
     benchmark chain, src/DoubleCRT.cpp:565-599, benchmarks/bgv_basic.cpp:247 -- with y_k and the pre-reduced
     multipliers W_kt 2^(8a) mod t in balanced 8-bit limbs.  Compiled for the host, the MFMA restated as a triple
     loop over its operand layout: the host-built operand table and accumulator start values, the packing of y, the
@@ -894,11 +894,11 @@ def test_mfma_basis_extension_limb_split_tables_and_recombination():
     L = C.CDLL(so)
     L.mfma_ext_check.argtypes = [C.c_int] * 6 + [C.c_uint64, C.c_int, C.c_void_p]
     mx = C.c_uint32(0)
-    for n in (8, 9, 11, 12, 16, 17, 19, 20, 24, 25, 33, 36, 39, 40):
+    for n in (4, 6, 7, 8, 9, 11, 12, 16, 17, 19, 20, 24, 25, 33, 36, 39, 40):
         steps = (n + 1 + 3) // 4
         for nt, tb in ((11, (60, 56, 45)), (107, (60, 60, 60)), (5, (33, 40, 59)), (143, (60, 59, 58))):
             for worst in (0, 1, 2):
                 assert L.mfma_ext_check(n, nt, 60, *tb, 7 + n, worst, C.byref(mx)) == 0, (n, nt, tb, worst)
                 # every start-offset limb sum is a non-negative number below 2^23.5: a01 = S0 + (S1 << 8) fits 32 bits
                 assert mx.value < 2 * steps * 32 * 16384 + 256 < 2 ** 23.5
-    assert L.mfma_ext_check(7, 4, 60, 60, 60, 60, 1, 0, None) == 100     # two steps: below the kernels' range
+    assert L.mfma_ext_check(3, 4, 60, 60, 60, 60, 1, 0, None) == 100     # one step: below the kernels' range
