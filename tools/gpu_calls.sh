@@ -15,6 +15,7 @@
 #   pmc_sq           two more --pmc passes: SQ VALU activity + GRBM_GUI_ACTIVE (clock), LDS bank conflicts -> pmc_sq_summary.txt
 #   scatter          bench.py --scatter at N = 1, and at two ranks on one device (gloo)
 #   pmc_config5      --pmc passes (traffic, VALU, LDS conflicts) over the config 5 transform driver -> pmc_config5_summary.txt
+#   trace_6400       rocprofv3 --kernel-trace over bench.py --bits 6400 --batch 16 (the reference's own bgv_basic parameter) -> bits6400_kernel_trace.txt
 #   pmc_mfma         --pmc passes over tools/prof_mfma_ext.py (the matrix-core basis extension, 36 -> 107 primes) -> pmc_mfma_summary.txt
 #   bluestein        tools/prof_bluestein.py Good-Thomas x Rader (default), fused Bluestein (HX_NO_PFA) and old chain + kernel trace of the default
 #   levels           tools/prof_levels.py for both schemes
@@ -134,6 +135,12 @@ PY
       python tools/rocpd_summary.py $out/kt --by-grid > $out/bench_kernel_trace.txt 2>&1
       line $out/bench_traced.json traced
       grep -E "wgs" $out/bench_kernel_trace.txt | head -16 ;;
+    trace_6400)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/$out/kt6400 -- python3 $R/bench.py --gpus 1 --bits 6400 --batch 16 --steps 6 --warmup 2 \
+         --mults-per-step 4 $QUICK --no-rccl-check > $R/$out/bench_bits6400_traced.json 2> $R/$out/bench_bits6400_traced.err); echo "trace_6400 rc=$?"
+      python tools/rocpd_summary.py $out/kt6400 --by-grid > $out/bits6400_kernel_trace.txt 2>&1
+      line $out/bench_bits6400_traced.json traced_6400
+      grep -E "wgs" $out/bits6400_kernel_trace.txt | grep -E "rns_extend|apply|keyswitch|ntt_row" | head -16 ;;
     pmc)
       for ctr in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
         (cd /tmp && timeout 400 rocprofv3 --pmc $ctr -d $R/$out/pmc_$ctr -- python3 $R/bench.py --gpus 1 --steps 2 --warmup 1 \
