@@ -1,8 +1,12 @@
-// rns_mfma_kernels.hip -- the exact basis extension from 17..40 source primes with its target sums on the matrix cores
-// (gfx950, V_MFMA_I32_32X32X32_I8): same contract, same words as rns_extend_wide_kernel (rns_kernels.h), which stays
-// as the control (HX_NO_MFMA_EXT=1).  The reference: addPrimes / scaleDownToSet / breakIntoDigits at the chain of its
-// own benchmark parameter (src/DoubleCRT.cpp:565-599, :1464-1516, :479-561; benchmarks/bgv_basic.cpp:247, bits = 6400:
-// digits and dropped sets of 36 primes, up to 107 targets).  Method, table layout and the CPU restatement: mfma_ext.h.
+// rns_mfma_kernels.hip -- the exact basis extension from many source primes with its target sums on the matrix cores
+// (gfx950, V_MFMA_I32_32X32X32_I8): same contract, same words as the VALU kernels it stands in for -- for 17 .. 40
+// sources rns_extend_wide_kernel, for the 9 .. 16-source plans of the fast kernels rns_extend_fast_kernel<n, HPS>
+// (rns_kernels.h), which stay as the controls (HX_NO_MFMA_EXT=1; HX_MFMA_MIN_N moves the lower end, instantiations
+// exist from four sources on).  The reference: addPrimes / scaleDownToSet / breakIntoDigits
+// (src/DoubleCRT.cpp:565-599, :1464-1516, :479-561) at the chain of its own benchmark parameter
+// (benchmarks/bgv_basic.cpp:247, bits = 6400: digits and dropped sets of 36 primes, up to 107 targets) and the
+// several-primes mod-switch of the CKKS chain one level down (8 + 3 dropped primes).  Method, table layout and the
+// CPU restatement: mfma_ext.h.
 //
 // One wavefront = 32 coefficients, lanes l and l + 32 on the same one:
 //   1. front end as the wide kernel's, split by source between the two lanes: y_k = x_k (P/p_k)^-1 mod p_k for the
