@@ -27,6 +27,9 @@ struct PrimeDev {
   uint64_t tw_fwd_off;
   uint64_t tw_inv_off;
   uint64_t r2;     // 2^128 mod q: a Proth-form constant times this (mont_mul) carries one more 2^64 (conv_kernels.hip)
+  // sub-transform entries of the N = 2^15 forward half-row kernel only (ntt_kernels.hip ntt_row_half15_kernel): the
+  // first stage's twiddle psi^(N/2) as a Shoup pair and times 2^64
+  uint64_t half_t1, half_t1p, half_t1m;
 };
 
 // launch descriptor passed BY VALUE (kernel-arg segment): row r of the

@@ -35,6 +35,8 @@ hipError_t launch_ntt_pow2(int logn, bool inverse, const uint64_t* in, uint64_t*
                            const TW* tw_arena, hipStream_t st);
 hipError_t launch_ntt_pow2_lazy_in(int logn, const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows, int batch,
                                    const PrimeDev* primes, const TW* tw_arena, hipStream_t st);
+hipError_t launch_ntt_half15_fwd(bool lazy_in, const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows, int batch,
+                                 const PrimeDev* sub_primes, const TW* tw_arena, hipStream_t st);
 hipError_t launch_moddown_pow2(int logn, const PolyBases& data, const PolyBases& out, int drop_row,
                                int drop_prime, const NttRows& keep, int nkeep, int batch,
                                const ModDownPrep& P, const ModDownApply& A, const PrimeDev* primes,
@@ -131,6 +133,7 @@ struct PrimeHost {
   uint64_t last_s = 0, last_n = 0;  // inverse table slots 0 / 31: S0*N^-1 and N^-1
   uint64_t tw_fwd_off = 0, tw_inv_off = 0;  // into hx_ctx::d_tw (TW units)
   bool proth = false;  // row tables in Proth form (8-byte entries w 2^64 mod q): PrimeDev::proth
+  int half_pd = -1;    // N = 2^15: index into hx_ctx::d_cprimes of the forward half-row kernel's entry for g = 0 (g = 1 follows)
 };
 // the second word of a twiddle constant that a row kernel substitutes for a table entry (ModDownPrep::upS / upN):
 // Shoup's quotient, or -- for a prime whose rows run the Proth-form butterflies -- w 2^64 mod q
@@ -190,10 +193,10 @@ struct hx_ctx {
   int primes_cap = 0;
   TW* d_tw = nullptr;  // twiddle arena shared by all primes
   size_t tw_cap = 0, tw_used = 0;
-  uint64_t* scratch[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint64_t* scratch[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t* d_redo = nullptr;   // redo list of the HPS-form RNS kernels: [0] = count, [1..] = coefficient indices
   size_t redo_cap = 0;          // (in 32-bit words)
-  size_t scratch_words[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  size_t scratch_words[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t aux_q[3] = {0, 0, 0};  // auxiliary NTT primes of the aux Bluestein path (lazily chosen)
   // general m (Bluestein): conv sizes 2^bk (chirp), 2^n1 / 2^n2 (rem Phi_m), pseudo "primes"
   // (twiddle tables of the conv sizes) and per-prime tables
@@ -580,7 +583,7 @@ static void ctx_free(hx_ctx* c)
     hipFree(kv.second->blob_mfma);
     delete kv.second;
   }
-  for (int i = 0; i < 10; i++)
+  for (int i = 0; i < 11; i++)
     if (c->scratch[i])
       hipFree(c->scratch[i]);
   c->arena.destroy();
@@ -1621,7 +1624,24 @@ extern "C" int hx_ctx_add_prime(hx_ctx* c, uint64_t q, uint64_t root, int* idx_o
     switch (c->logn) {
       case 13: CHK(upload_tw<13>(c, ph)); break;
       case 14: CHK(upload_tw<14>(c, ph)); break;
-      case 15: CHK(upload_tw<15>(c, ph)); break;
+      case 15:
+        CHK(upload_tw<15>(c, ph));
+        if (c->sw.half15) {
+          // the forward transform as two 2^14-point workgroups per row (ntt_kernels.hip ntt_row_half15_kernel): the
+          // sub-transforms' tables (what a split power-of-two ring builds with OUT = 1) and the first stage's twiddle
+          int i0 = -1, i1 = -1;
+          CHK(conv_tables_sub<14>(c, q, root, 1, 0, &i0));
+          CHK(conv_tables_sub<14>(c, q, root, 1, 1, &i1));
+          if (i1 != i0 + 1)
+            return fail(HX_ERR_DEVICE, "internal: half-row table entries are not adjacent");
+          const uint64_t t1 = hxh::powmod(root, (uint64_t)1 << 14, q);   // psi_rev[1] = psi^(N/2)
+          const uint64_t h3[3] = {t1, hxh::shoup(t1, q), hx::tw_mont_form(t1, q)};
+          for (int g = 0; g < 2; g++)
+            HIPCHK(hipMemcpy(reinterpret_cast<char*>(c->d_cprimes + i0 + g) + offsetof(PrimeDev, half_t1), h3, sizeof h3,
+                             hipMemcpyHostToDevice));
+          ph.half_pd = i0;
+        }
+        break;
       default:
         if (c->logn >= 1 && c->logn <= 12)
           CHK(upload_tw_small(c, ph));
@@ -1959,6 +1979,11 @@ static int ntt_launch(hx_ctx* c, int logn, const PrimeDev* table, const uint64_t
     return HX_OK;
   if (logn < 1 || logn > 15)
     return fail(HX_ERR_UNSUPPORTED, "negacyclic NTT kernels support sizes 2..32768");
+  // N = 2^15 forward, out of place, on the context's own primes: two 2^14-point workgroups per row
+  bool half15 = logn == 15 && !inverse && table == c->d_primes && in != out && c->sw.half15;
+  for (size_t i = 0; i < rows.size() && half15; i++)
+    half15 = rows[i].second >= 0 && rows[i].second < (int)c->primes.size() && c->primes[(size_t)rows[i].second].half_pd >= 0 &&
+             c->primes[(size_t)rows[i].second].half_pd < 0xffff;
   for (size_t first = 0; first < rows.size(); first += MAX_ROWS) {
     int n = (int)std::min<size_t>(MAX_ROWS, rows.size() - first);
     NttRows d;
@@ -1966,7 +1991,13 @@ static int ntt_launch(hx_ctx* c, int logn, const PrimeDev* table, const uint64_t
       if (rows[first + i].first > 0xffff || rows[first + i].second > 0xffff)
         return fail(HX_ERR_UNSUPPORTED, "row index too large for one launch descriptor");
       d.row[i] = (uint16_t)rows[first + i].first;
-      d.prime[i] = (uint16_t)rows[first + i].second;
+      d.prime[i] = half15 ? (uint16_t)c->primes[(size_t)rows[first + i].second].half_pd : (uint16_t)rows[first + i].second;
+    }
+    if (half15) {
+      hipError_t e = hx::launch_ntt_half15_fwd(lazy_in, in, out, d, n, batch, c->d_cprimes, c->d_tw, c->stream);
+      if (e != hipSuccess)
+        return fail(HX_ERR_DEVICE, "NTT launch failed: %s", hipGetErrorString(e));
+      continue;
     }
     hipError_t e = (lazy_in && !inverse && logn >= 13 && logn <= 15)
                        ? hx::launch_ntt_pow2_lazy_in(logn, in, out, d, n, batch, table, c->d_tw, c->stream)
@@ -4781,18 +4812,25 @@ static int relin_core(hx_ctx* c, const uint64_t* t2e, const std::vector<int>& ow
       return rc;
   }
   // forward NTT of the extension rows only: D*(L+K) - L transforms, as in the reference
+  uint64_t* digits_eval = c->scratch[1];
   {
     std::vector<std::pair<int, int>> rows;
     for (int d = 0; d < ndig; d++)
       for (int r = 0; r < nall; r++)
         if (owner[r] != d)
           rows.emplace_back(d * nall + r, all[r]);
-    CHK(ntt_list(c, c->scratch[1], c->scratch[1], rows, batch, false, /*lazy_in=*/true));
+    // N = 2^15: out of place, so that the two-workgroups-per-row forward kernel applies (ntt_launch); the key switch
+    // reads the extension rows only, all of which are written there
+    if (c->pow2 && c->logn == 15 && c->sw.half15) {
+      CHK(ensure_scratch(c, 10, (size_t)ndig * nall * rw));
+      digits_eval = c->scratch[10];
+    }
+    CHK(ntt_list(c, c->scratch[1], digits_eval, rows, batch, false, /*lazy_in=*/true));
   }
   std::vector<std::vector<int>> dprimes(ndig);
   for (int d = 0; d < ndig; d++)
     dprimes[d].assign(dig_idx + dig_off[d], dig_idx + dig_off[d + 1]);
-  return keyswitch_launch(c, c->scratch[1], W, all, batch, out0, out1, L, t2e, &owner, &dprimes, ndig,
+  return keyswitch_launch(c, digits_eval, W, all, batch, out0, out1, L, t2e, &owner, &dprimes, ndig,
                           t0s, t1s, ts);
 }
 

@@ -1309,6 +1309,115 @@ static hipError_t launch_small(bool inverse, const uint64_t* in, uint64_t* out, 
   return hipGetLastError();
 }
 
+#if !defined(HX_NTT_ONLY) || HX_NTT_ONLY == 14
+// =====================================================================
+// The FORWARD transform of a 2^15-point row as two independent 2^14-point workgroups (Cmodulus::FFT,
+// src/CModulus.cpp:389-426, at the CKKS chain's ring m = 65536).  ntt_row_kernel<15> is one 1024-thread workgroup per
+// row and CU -- nothing covers its load and barrier phases: 5.3 ps per coefficient where the 2^14-point kernel, two
+// 512-thread workgroups per CU, takes 4.2.  The first Cooley-Tukey stage pairs x[p] with x[p + N/2] under ONE twiddle
+// T = psi^(N/2): workgroup g = 0 / 1 forms x[p] +/- T x[p + N/2] in its load and continues with the sub-transform's own
+// tables (build_tw_tables_sub, OUT = 1: what the split power-of-two rings use), and its outputs are the row's
+// evaluations 2 j + g (big_post's interleave for S = 2).  The inverse needs the cross-half stage LAST, behind both
+// sub-transforms: it stays on the one-workgroup kernel.
+// MEASURED SLOWER (round 6, config 4, same box): 818-822 us against 783-798 for the 4608 rows of a multiply of the
+// batch (1032 with non-temporal row IO: the halves fill each other's cache lines) -- each half reads the whole row and
+// stores every other word.  Off by default (HX_HALF15=1); profiles/r06_ab_half_row_forward_2p15.json.
+// =====================================================================
+template <int LB, bool PROTH>
+#ifndef HX_HALF_AUX
+#define HX_HALF_AUX 0   // (both workgroups of a row read all of it and fill each other's cache lines: not non-temporal)
+#endif
+struct HalfIO15 {
+  static constexpr unsigned Q = 1u << 14;
+  // bound of what load() hands over, in q: Proth-form rows start below 2q (canonical, or the digit kernel's Montgomery
+  // sums: BufIOT) -> x + R < 2q + q (1 + 2/16 + 2^-32), 2x + 2q - (x + R) < 4q; other rows (shoup4: R < 4q) x + R and
+  // x + 4q - R below 8q + 4q resp. q + 4q
+  static constexpr int LOAD_BOUND = PROTH ? 4 : (LB == 8 ? 12 : 5);
+  static constexpr bool LAZY_STORE = false;
+  static constexpr bool PIPELINED = false;
+  struct StorePrefetch {};
+  v4i32 rin, rout;
+  QC qc;
+  TW t1;
+  TWM t1m;
+  unsigned g;
+  __device__ HalfIO15(const uint64_t* in_row, uint64_t* out_row, const PrimeDev* pd, unsigned g_)
+      : rin(make_rsrc(in_row, 2u * Q * 8u)), rout(make_rsrc(out_row, 2u * Q * 8u)), qc(make_qc(pd->q, pd->mu64)), t1m(pd->half_t1m), g(g_)
+  {
+    t1.w = pd->half_t1;
+    t1.wp = pd->half_t1p;
+  }
+  __device__ __forceinline__ uint64_t load(unsigned tid, unsigned c) const
+  {
+    const v2i32 a = hx_buffer_load_v2(rin, (int)(tid * 8u), (int)(c * 8u), HX_HALF_AUX);
+    const v2i32 b = hx_buffer_load_v2(rin, (int)(tid * 8u), (int)((c + Q) * 8u), HX_HALF_AUX);
+    const uint64_t x = ((uint64_t)(uint32_t)a.y << 32) | (uint32_t)a.x, y = ((uint64_t)(uint32_t)b.y << 32) | (uint32_t)b.x;
+    if constexpr (PROTH) {
+      const uint64_t xn = mont_acc(y, t1m, qc, x);           // x + T y
+      return g ? (x << 1) + qc.q2 - xn : xn;                  // x - T y + 2q
+    } else {
+      const uint64_t r = shoup4(y, t1, 0 - qc.q);            // [0, 4q)
+      return g ? x + (qc.q2 << 1) - r : x + r;
+    }
+  }
+  __device__ __forceinline__ void store(unsigned tid, unsigned c, uint64_t v) const
+  {
+    v2i32 d;
+    d.x = (int)(uint32_t)v;
+    d.y = (int)(uint32_t)(v >> 32);
+    hx_buffer_store_v2(d, rout, (int)(tid * 16u), (int)(c * 16u + g * 8u), HX_HALF_AUX);
+  }
+  __device__ __forceinline__ TW last_tw(TW def, int) const { return def; }
+  __device__ __forceinline__ TWM last_tw(TWM def, int) const { return def; }
+};
+
+// rows.prime[i] = index (into `primes`: the context's sub-transform table) of row i's entry for g = 0; g = 1 follows it
+template <int LB>
+__global__ void __launch_bounds__(Geo<14>::T, HX_NTT_MINWAVES(14))
+ntt_row_half15_kernel(const uint64_t* in, uint64_t* out, NttRows rows, int batch,
+                      const PrimeDev* __restrict__ primes, const TW* __restrict__ tw_arena)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned g = wid & 1u, rb = wid >> 1;            // the two halves of a row side by side (same XCD: one L2 sees both)
+  const unsigned ri = rb / (unsigned)batch;
+  const int b = (int)(rb % (unsigned)batch);
+  const int row = (int)uniform_u16(rows.row, ri);
+  const PrimeDev* pd = primes + uniform_u16(rows.prime, ri) + g;
+  const size_t roff = ((size_t)row * batch + b) * (size_t)(2u << 14);
+  const TW* tw = tw_arena + pd->tw_fwd_off;
+  const QC q = make_qc(pd->q, pd->mu64);
+#ifndef HX_NO_PROTH
+  if (pd->proth) {
+    const HalfIO15<LB, true> io(in + roff, out + roff, pd, g);
+    ntt_body_ar<14, false, ArProth>(lds, io, reinterpret_cast<const TWM*>(tw), q);
+    return;
+  }
+#endif
+  const HalfIO15<LB, false> io(in + roff, out + roff, pd, g);
+  ntt_body_ar<14, false, ArShoup>(lds, io, tw, q);
+}
+template <int LB>
+static hipError_t launch_half15(const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows, int batch,
+                                const PrimeDev* primes, const TW* tw_arena, hipStream_t st)
+{
+  constexpr size_t lds_bytes = (size_t)Geo<14>::LDS_WORDS * 4;
+  hipError_t e = hxp::dyn_lds((const void*)ntt_row_half15_kernel<LB>, (int)lds_bytes);
+  if (e != hipSuccess)
+    return e;
+  HX_LAUNCH((ntt_row_half15_kernel<LB>), dim3(2u * (unsigned)nrows * (unsigned)batch), dim3(Geo<14>::T), lds_bytes, st, in, out,
+            rows, batch, primes, tw_arena);
+  return hipGetLastError();
+}
+// in != out (the two workgroups of a row read all of it); lazy_in: the words are in [0,8q) (Proth-form rows: below 2q)
+hipError_t launch_ntt_half15_fwd(bool lazy_in, const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows, int batch,
+                                 const PrimeDev* sub_primes, const TW* tw_arena, hipStream_t st)
+{
+  return lazy_in ? launch_half15<8>(in, out, rows, nrows, batch, sub_primes, tw_arena, st)
+                 : launch_half15<1>(in, out, rows, nrows, batch, sub_primes, tw_arena, st);
+}
+#endif
+
 // forward transform of rows whose words are lazy, in [0,8q) (N = 2^13..2^15 only: ntt_lazy_input_ok)
 hipError_t HX_ENTRY(launch_ntt_pow2_lazy_in)(int logn, const uint64_t* in, uint64_t* out, const NttRows& rows, int nrows, int batch,
                                    const PrimeDev* primes, const TW* tw_arena, hipStream_t st)

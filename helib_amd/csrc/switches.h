@@ -33,6 +33,8 @@ struct Switches {
   bool no_tensor_multi = false;  // HX_NO_TENSOR_MULTI=1 tensor product + several-primes mod-switch as two steps
   bool no_mulrelin_fuse = false; // HX_NO_MULRELIN_FUSE=1 hx_mul_relin with a tensor pass
   // row transforms (ntt_core.h)
+  bool half15 = false;           // HX_HALF15=1          N = 2^15 forward rows (out of place) as two 2^14-point workgroups per row: measured 3-4 % SLOWER
+                                 //                      than the one-workgroup kernel (profiles/r06_ab_half_row_forward_2p15.json); kept as a probe
   bool no_proth = false;         // HX_NO_PROTH=1        Shoup butterflies on every row (Proth-form primes included)
   // general m
   bool blue_old = false;         // HX_BLUE_OLD=1        Bluestein as the round-2 chain of passes instead of ntt_conv_kernel
@@ -72,6 +74,7 @@ inline Switches read()
     s.mfma_min_n = std::atoi(e);
   if (const char* e = std::getenv("HX_BRK_LDS_PAD"))
     s.brk_lds_pad_rows = std::atoi(e);
+  s.half15 = on("HX_HALF15");
   s.no_tensor_multi = on("HX_NO_TENSOR_MULTI");
   s.no_mulrelin_fuse = on("HX_NO_MULRELIN_FUSE");
   s.no_proth = on("HX_NO_PROTH");

@@ -1649,6 +1649,19 @@ def test_ckks_encrypt_multiply_decrypt_gpu_vs_oracle(hx, m, precision, bits, c, 
         assert np.max(np.abs(got - want)) < 2.0 ** (-precision + 6) / n
 
 
+def test_half_row_forward_transform_at_2p15_probe(hx, monkeypatch):
+    """HX_HALF15=1: the forward transform of the digit rows of hx_mul_relin at N = 2^15 as two 2^14-point workgroups per
+    row (ntt_kernels.hip ntt_row_half15_kernel: first Cooley-Tukey stage in the load, the sub-transform's tables,
+    interleaved outputs; Cmodulus::FFT, src/CModulus.cpp:389-426) -- measured slower than the one-workgroup kernel and off
+    by default (profiles/r06_ab_half_row_forward_2p15.json); the probe must stay bit-exact: the reference's own CKKS
+    parameters through it, and the kernel that ran checked by name."""
+    monkeypatch.setenv("HX_HALF15", "1")
+    hx.profileBegin()
+    test_ckks_m65536_chain_batched_bit_exact(hx, monkeypatch, 1, 440, (8, 3, 3))
+    names = " ".join(k["kernel"] for k in hx.profileEnd()["kernels"])
+    assert "ntt_row_half15_kernel<8>" in names, names
+
+
 @pytest.mark.parametrize("precision,bits,shape", [(20, 1400, (24, 8, 3)), (1, 1400, (24, 8, 3)), (1, 440, (8, 3, 3))])
 def test_ckks_m65536_chain_batched_bit_exact(hx, monkeypatch, precision, bits, shape):
     """BASELINE configs[3] as bench.py --workload ckks65536 runs it: m = 65536, bits = 1400 (L = 24, K = 8, D = 3) --
